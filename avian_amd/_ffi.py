@@ -1,0 +1,443 @@
+"""ctypes binding of the C ABI in ``include/avian_mi355x.h``.
+
+The same header is implemented by the HIP product (prefix ``avn_``) and by the CPU oracle
+(prefix ``avo_``, test infrastructure); :class:`Library` is parameterised by path + prefix so the
+tests drive both through identical calls.  Nothing in this module knows where the oracle lives.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+GRAPH_COLOR_COUNT = 24
+COLOR_OVERFLOW_INDEX = 23
+DYNAMIC_COLOR_COUNT = 20
+MAX_MANIFOLD_POINTS = 4
+
+RB_DYNAMIC, RB_STATIC, RB_KINEMATIC = 0, 1, 2
+BODY_SLEEPING, BODY_DISABLED, BODY_CUSTOM_VEL, BODY_CUSTOM_POS = 1, 2, 4, 8
+SB_KINEMATIC, SB_GYROSCOPIC = 1 << 6, 1 << 7
+SHAPE_CUBOID, SHAPE_BALL = 0, 1
+COLLIDER_SENSOR, COLLIDER_EVENTS, COLLIDER_FILTER_PAIRS, COLLIDER_MODIFY_CONTACTS, COLLIDER_SWEPT_CCD = 1, 2, 4, 8, 16
+MANIFOLD_GENERATES_CONSTRAINTS = 1
+PAIR_CONTACT_EVENTS, PAIR_MODIFY_CONTACTS, PAIR_GENERATE_CONSTRAINTS, PAIR_NEEDS_CUSTOM_FILTER = 1, 2, 4, 8
+
+STATUS_NAMES = {0: "AVN_OK", 1: "AVN_ERR_BAD_ARG", 2: "AVN_ERR_HIP", 3: "AVN_ERR_OOM", 4: "AVN_ERR_CAPACITY",
+                5: "AVN_ERR_NO_DEVICE", 6: "AVN_ERR_STATE"}
+
+# avn_system ids (same order as the header)
+SYSTEMS = [
+    "UPDATE_AABB", "COLLECT_COLLISION_PAIRS", "PREPARE_SOLVER_BODIES", "PREPARE_JOINTS",
+    "PREPARE_CONTACT_CONSTRAINTS", "PRE_PROCESS_VELOCITY_INCREMENTS", "INTEGRATE_VELOCITIES", "WARM_START",
+    "SOLVE_CONTACTS_BIAS", "INTEGRATE_POSITIONS", "SOLVE_CONTACTS_RELAX", "XPBD_SOLVE",
+    "XPBD_VELOCITY_PROJECTION", "JOINT_DAMPING", "CLEAR_VELOCITY_INCREMENTS", "SOLVE_RESTITUTION",
+    "WRITEBACK_SOLVER_BODIES", "STORE_CONTACT_IMPULSES", "SUBSTEP", "SOLVER",
+]
+SYS = {name: i for i, name in enumerate(SYSTEMS)}
+
+vp = C.c_void_p
+
+
+class AvnError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"{STATUS_NAMES.get(status, status)}: {message}")
+        self.status = status
+
+
+class avn_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("scalar_bits", C.c_uint32), ("device", C.c_int32), ("substeps", C.c_uint32),
+        ("dt_ns", C.c_uint64), ("gravity", C.c_double * 3), ("length_unit", C.c_double),
+        ("contact_damping_ratio", C.c_double), ("contact_frequency_factor", C.c_double),
+        ("max_overlap_solve_speed", C.c_double), ("warm_start_coefficient", C.c_double),
+        ("restitution_threshold", C.c_double), ("restitution_iterations", C.c_uint32),
+        ("match_contacts", C.c_uint32), ("default_speculative_margin", C.c_double), ("contact_tolerance", C.c_double),
+        ("solver_iterations", C.c_uint32), ("use_graph", C.c_uint32),
+    ]
+
+
+class avn_bodies(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "position", "rotation", "linear_velocity", "angular_velocity", "inv_mass", "inv_inertia_local",
+        "center_of_mass", "linear_damping", "angular_damping", "gravity_scale", "accel_linear", "accel_angular",
+        "max_linear_speed", "max_angular_speed", "rb_type", "locked_axes", "dominance", "body_flags")]
+
+
+class avn_bodies_out(C.Structure):
+    _fields_ = [(n, vp) for n in ("position", "rotation", "linear_velocity", "angular_velocity")]
+
+
+class avn_solver_bodies_out(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "linear_velocity", "angular_velocity", "delta_position", "delta_rotation", "flags", "inv_mass",
+        "inv_inertia_world", "dominance", "linear_increment", "angular_increment", "linear_damping_rhs",
+        "angular_damping_rhs")]
+
+
+class avn_manifolds(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "color_offsets", "body1", "body2", "normal", "friction", "restitution", "tangent_velocity", "point_count",
+        "manifold_flags", "anchor1", "anchor2", "penetration", "normal_speed", "warm_start_normal_impulse",
+        "warm_start_tangent_impulse")]
+
+
+class avn_impulses_out(C.Structure):
+    _fields_ = [(n, vp) for n in ("warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse")]
+
+
+class avn_constraints_out(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "point_count", "relative_dominance", "tangent1", "anchor1", "initial_separation", "normal_impulse",
+        "total_impulse", "normal_effective_mass", "tangent_impulse", "tangent_effective_inverse_mass",
+        "softness_non_dynamic")]
+
+
+class avn_distance_joints(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "body1", "body2", "local_anchor1", "local_anchor2", "limit_min", "limit_max", "compliance",
+        "damping_linear", "damping_angular", "collision_disabled")]
+
+
+class avn_joints_out(C.Structure):
+    _fields_ = [(n, vp) for n in ("world_r1", "world_r2", "center_difference", "total_lagrange", "force")]
+
+
+class avn_colliders(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "entity_index", "body", "shape", "half_extents", "memberships", "filters", "collider_flags",
+        "collision_margin", "speculative_margin")]
+
+
+class avn_pair(C.Structure):
+    _fields_ = [("collider1", C.c_uint32), ("collider2", C.c_uint32), ("body1", C.c_int32), ("body2", C.c_int32),
+                ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class avn_timers(C.Structure):
+    _fields_ = [("broad_phase_ms", C.c_double), ("prepare_ms", C.c_double), ("substeps_ms", C.c_double),
+                ("finalize_ms", C.c_double), ("step_ms", C.c_double), ("contact_constraint_count", C.c_uint32),
+                ("pair_count", C.c_uint32), ("kernel_launches", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),
+                       ("flags", "<u4"), ("reserved", "<u4")])
+
+# every symbol include/avian_mi355x.h declares (without prefix)
+ABI_SYMBOLS = [
+    "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
+    "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
+    "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
+    "aabbs_download", "run_system", "step", "synchronize", "timers", "pair_key", "constraint_graph_create",
+    "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
+]
+
+
+class Library:
+    """A loaded implementation of the ABI (``prefix`` = ``avn_`` for the product)."""
+
+    def __init__(self, path: str, prefix: str = "avn_"):
+        self.path = path
+        self.prefix = prefix
+        self.dll = C.CDLL(path)
+        missing = [s for s in ABI_SYMBOLS if not hasattr(self.dll, prefix + s)]
+        if missing:
+            raise ImportError(f"{path}: missing ABI symbols {missing}")
+        f = self.fn
+        f("world_create").argtypes = [C.POINTER(avn_config), C.POINTER(vp)]
+        f("world_destroy").argtypes = [vp]
+        f("world_destroy").restype = None
+        f("last_error").argtypes = [vp]
+        f("last_error").restype = C.c_char_p
+        for name in ("config_set", "bodies_upload", "bodies_download", "solver_bodies_download", "manifolds_upload",
+                     "impulses_download", "constraints_download", "distance_joints_upload", "joints_download",
+                     "colliders_upload", "timers"):
+            f(name).argtypes = [vp, vp]
+        f("existing_pairs_upload").argtypes = [vp, vp, C.c_size_t]
+        f("pairs_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("aabbs_download").argtypes = [vp, vp, vp, vp, C.POINTER(C.c_size_t)]
+        f("run_system").argtypes = [vp, C.c_int]
+        f("step").argtypes = [vp]
+        f("synchronize").argtypes = [vp]
+        f("pair_key").argtypes = [C.c_uint32, C.c_uint32]
+        f("pair_key").restype = C.c_uint64
+        f("constraint_graph_create").argtypes = [C.c_uint32, C.POINTER(vp)]
+        f("constraint_graph_destroy").argtypes = [vp]
+        f("constraint_graph_destroy").restype = None
+        f("constraint_graph_push").argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
+        f("constraint_graph_push").restype = C.c_int32
+        f("constraint_graph_pop").argtypes = [vp, C.c_uint64]
+        f("constraint_graph_lists").argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+
+    def fn(self, name: str):
+        return getattr(self.dll, self.prefix + name)
+
+    def pair_key(self, a: int, b: int) -> int:
+        return int(self.fn("pair_key")(a, b))
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(vp)
+
+
+def default_config(scalar_bits: int = 32, substeps: int = 6, dt: float = 1.0 / 60.0, **kw) -> avn_config:
+    """``SolverConfig::default`` / ``NarrowPhaseConfig::default`` / ``Gravity::default`` of the reference."""
+    cfg = avn_config()
+    cfg.struct_size = C.sizeof(avn_config)
+    cfg.scalar_bits = scalar_bits
+    cfg.device = 0
+    cfg.substeps = substeps
+    # Duration::from_secs_f64 rounds to the nearest nanosecond
+    cfg.dt_ns = int(round(dt * 1e9))
+    cfg.gravity[0], cfg.gravity[1], cfg.gravity[2] = 0.0, -9.81, 0.0
+    cfg.length_unit = 1.0
+    cfg.contact_damping_ratio = 10.0
+    cfg.contact_frequency_factor = 1.5
+    cfg.max_overlap_solve_speed = 4.0
+    cfg.warm_start_coefficient = 1.0
+    cfg.restitution_threshold = 1.0
+    cfg.restitution_iterations = 1
+    cfg.match_contacts = 1
+    cfg.default_speculative_margin = float(np.finfo(np.float64).max)
+    cfg.contact_tolerance = 0.005
+    cfg.solver_iterations = 1
+    cfg.use_graph = 1
+    for k, v in kw.items():
+        if k == "gravity":
+            for i in range(3):
+                cfg.gravity[i] = float(v[i])
+        else:
+            if not hasattr(cfg, k):
+                raise AttributeError(k)
+            setattr(cfg, k, v)
+    return cfg
+
+
+class World:
+    """One physics world behind the ABI.  Arrays are numpy, converted to the world's scalar type."""
+
+    def __init__(self, lib: Library, cfg: avn_config):
+        self.lib = lib
+        self.cfg = cfg
+        self.dtype = np.float32 if cfg.scalar_bits == 32 else np.float64
+        self.n_bodies = 0
+        self.n_manifolds = 0
+        self.n_joints = 0
+        self.n_colliders = 0
+        h = vp()
+        st = lib.fn("world_create")(C.byref(cfg), C.byref(h))
+        if st != 0:
+            msg = lib.fn("last_error")(None)
+            raise AvnError(st, (msg or b"").decode())
+        self.handle = h
+
+    # -- plumbing ------------------------------------------------------------------------------
+    def _check(self, st: int):
+        if st != 0:
+            msg = self.lib.fn("last_error")(self.handle)
+            raise AvnError(st, (msg or b"").decode())
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fn("world_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _s(self, a, shape=None):
+        if a is None:
+            return None
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if shape is not None:
+            a = a.reshape(shape)
+        return a
+
+    @staticmethod
+    def _i(a, dt):
+        return None if a is None else np.ascontiguousarray(a, dtype=dt)
+
+    def config_set(self, cfg: avn_config):
+        self.cfg = cfg
+        self._check(self.lib.fn("config_set")(self.handle, C.byref(cfg)))
+
+    # -- bodies ---------------------------------------------------------------------------------
+    def bodies_upload(self, position, rotation, linear_velocity, angular_velocity, inv_mass, inv_inertia_local,
+                      rb_type, center_of_mass=None, linear_damping=None, angular_damping=None, gravity_scale=None,
+                      accel_linear=None, accel_angular=None, max_linear_speed=None, max_angular_speed=None,
+                      locked_axes=None, dominance=None, body_flags=None):
+        n = len(np.asarray(inv_mass).reshape(-1))
+        keep = [self._s(position, (n, 3)), self._s(rotation, (n, 4)), self._s(linear_velocity, (n, 3)),
+                self._s(angular_velocity, (n, 3)), self._s(inv_mass, (n,)), self._s(inv_inertia_local, (n, 6)),
+                self._s(center_of_mass), self._s(linear_damping), self._s(angular_damping), self._s(gravity_scale),
+                self._s(accel_linear), self._s(accel_angular), self._s(max_linear_speed), self._s(max_angular_speed),
+                self._i(rb_type, np.uint8), self._i(locked_axes, np.uint8), self._i(dominance, np.int8),
+                self._i(body_flags, np.uint8)]
+        b = avn_bodies(n, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("bodies_upload")(self.handle, C.byref(b)))
+        self.n_bodies = n
+
+    def bodies_download(self):
+        n, dt = self.n_bodies, self.dtype
+        out = {"position": np.empty((n, 3), dt), "rotation": np.empty((n, 4), dt),
+               "linear_velocity": np.empty((n, 3), dt), "angular_velocity": np.empty((n, 3), dt)}
+        o = avn_bodies_out(*[_ptr(out[k]) for k in ("position", "rotation", "linear_velocity", "angular_velocity")])
+        self._check(self.lib.fn("bodies_download")(self.handle, C.byref(o)))
+        return out
+
+    def solver_bodies_download(self):
+        n, dt = self.n_bodies, self.dtype
+        out = {"linear_velocity": np.empty((n, 3), dt), "angular_velocity": np.empty((n, 3), dt),
+               "delta_position": np.empty((n, 3), dt), "delta_rotation": np.empty((n, 4), dt),
+               "flags": np.empty(n, np.uint32), "inv_mass": np.empty(n, dt), "inv_inertia_world": np.empty((n, 6), dt),
+               "dominance": np.empty(n, np.int16), "linear_increment": np.empty((n, 3), dt),
+               "angular_increment": np.empty((n, 3), dt), "linear_damping_rhs": np.empty(n, dt),
+               "angular_damping_rhs": np.empty(n, dt)}
+        o = avn_solver_bodies_out(*[_ptr(out[k]) for k, _ in avn_solver_bodies_out._fields_])
+        self._check(self.lib.fn("solver_bodies_download")(self.handle, C.byref(o)))
+        return out
+
+    # -- manifolds --------------------------------------------------------------------------------
+    def manifolds_upload(self, color_offsets, body1, body2, normal, friction, restitution, point_count, anchor1,
+                         anchor2, penetration, normal_speed, tangent_velocity=None, manifold_flags=None,
+                         warm_start_normal_impulse=None, warm_start_tangent_impulse=None):
+        m = len(np.asarray(body1).reshape(-1))
+        keep = [self._i(color_offsets, np.uint32), self._i(body1, np.int32), self._i(body2, np.int32),
+                self._s(normal, (m, 3)), self._s(friction, (m,)), self._s(restitution, (m,)),
+                self._s(tangent_velocity), self._i(point_count, np.uint8), self._i(manifold_flags, np.uint8),
+                self._s(anchor1, (m, 4, 3)), self._s(anchor2, (m, 4, 3)), self._s(penetration, (m, 4)),
+                self._s(normal_speed, (m, 4)), self._s(warm_start_normal_impulse), self._s(warm_start_tangent_impulse)]
+        assert keep[0].shape == (GRAPH_COLOR_COUNT + 1,)
+        s = avn_manifolds(m, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("manifolds_upload")(self.handle, C.byref(s)))
+        self.n_manifolds = m
+
+    def impulses_download(self):
+        m, dt = self.n_manifolds, self.dtype
+        out = {"warm_start_normal_impulse": np.zeros((m, 4), dt), "warm_start_tangent_impulse": np.zeros((m, 4, 2), dt),
+               "normal_impulse": np.zeros((m, 4), dt)}
+        o = avn_impulses_out(*[_ptr(out[k]) for k, _ in avn_impulses_out._fields_])
+        self._check(self.lib.fn("impulses_download")(self.handle, C.byref(o)))
+        return out
+
+    def constraints_download(self):
+        m, dt = self.n_manifolds, self.dtype
+        out = {"point_count": np.zeros(m, np.uint8), "relative_dominance": np.zeros(m, np.int16),
+               "tangent1": np.zeros((m, 3), dt), "anchor1": np.zeros((m, 4, 3), dt),
+               "initial_separation": np.zeros((m, 4), dt), "normal_impulse": np.zeros((m, 4), dt),
+               "total_impulse": np.zeros((m, 4), dt), "normal_effective_mass": np.zeros((m, 4), dt),
+               "tangent_impulse": np.zeros((m, 4, 2), dt), "tangent_effective_inverse_mass": np.zeros((m, 4, 3), dt),
+               "softness_non_dynamic": np.zeros(m, np.uint8)}
+        o = avn_constraints_out(*[_ptr(out[k]) for k, _ in avn_constraints_out._fields_])
+        self._check(self.lib.fn("constraints_download")(self.handle, C.byref(o)))
+        return out
+
+    # -- joints -------------------------------------------------------------------------------------
+    def distance_joints_upload(self, body1, body2, local_anchor1, local_anchor2, limit_min, limit_max, compliance,
+                               damping_linear=None, damping_angular=None, collision_disabled=None):
+        j = len(np.asarray(body1).reshape(-1))
+        keep = [self._i(body1, np.int32), self._i(body2, np.int32), self._s(local_anchor1, (j, 3)),
+                self._s(local_anchor2, (j, 3)), self._s(limit_min, (j,)), self._s(limit_max, (j,)),
+                self._s(compliance, (j,)), self._s(damping_linear), self._s(damping_angular),
+                self._i(collision_disabled, np.uint8)]
+        s = avn_distance_joints(j, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("distance_joints_upload")(self.handle, C.byref(s)))
+        self.n_joints = j
+
+    def joints_download(self):
+        j, dt = self.n_joints, self.dtype
+        out = {k: np.zeros((j, 3), dt) for k, _ in avn_joints_out._fields_}
+        o = avn_joints_out(*[_ptr(out[k]) for k, _ in avn_joints_out._fields_])
+        self._check(self.lib.fn("joints_download")(self.handle, C.byref(o)))
+        return out
+
+    # -- broad phase -----------------------------------------------------------------------------------
+    def colliders_upload(self, entity_index, body, shape, half_extents, memberships=None, filters=None,
+                         collider_flags=None, collision_margin=None, speculative_margin=None):
+        c = len(np.asarray(entity_index).reshape(-1))
+        keep = [self._i(entity_index, np.uint32), self._i(body, np.int32), self._i(shape, np.uint8),
+                self._s(half_extents, (c, 3)), self._i(memberships, np.uint32), self._i(filters, np.uint32),
+                self._i(collider_flags, np.uint8), self._s(collision_margin), self._s(speculative_margin)]
+        s = avn_colliders(c, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("colliders_upload")(self.handle, C.byref(s)))
+        self.n_colliders = c
+
+    def existing_pairs_upload(self, keys):
+        keys = np.ascontiguousarray(keys, dtype=np.uint64)
+        self._check(self.lib.fn("existing_pairs_upload")(self.handle, _ptr(keys), keys.size))
+
+    def pairs_get(self) -> np.ndarray:
+        p, n = vp(), C.c_size_t()
+        self._check(self.lib.fn("pairs_get")(self.handle, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, PAIR_DTYPE)
+        buf = (C.c_char * (n.value * PAIR_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=PAIR_DTYPE).copy()
+
+    def aabbs_download(self):
+        c, dt = self.n_colliders, self.dtype
+        mn, mx = np.zeros((c, 3), dt), np.zeros((c, 3), dt)
+        ents = np.zeros(c, np.uint32)
+        n = C.c_size_t()
+        self._check(self.lib.fn("aabbs_download")(self.handle, _ptr(mn), _ptr(mx), _ptr(ents), C.byref(n)))
+        return mn, mx, ents[: n.value]
+
+    # -- running -----------------------------------------------------------------------------------------
+    def run_system(self, name: str):
+        self._check(self.lib.fn("run_system")(self.handle, SYS[name]))
+
+    def step(self):
+        self._check(self.lib.fn("step")(self.handle))
+
+    def synchronize(self):
+        self._check(self.lib.fn("synchronize")(self.handle))
+
+    def timers(self) -> avn_timers:
+        t = avn_timers()
+        self._check(self.lib.fn("timers")(self.handle, C.byref(t)))
+        return t
+
+
+class ConstraintGraph:
+    """Host ``ConstraintGraph`` (constraint_graph.rs:163-296) behind the ABI."""
+
+    def __init__(self, lib: Library, body_capacity: int = 16):
+        self.lib = lib
+        h = vp()
+        st = lib.fn("constraint_graph_create")(body_capacity, C.byref(h))
+        if st != 0:
+            raise AvnError(st, "constraint_graph_create")
+        self.handle = h
+
+    def push(self, handle: int, body1: int, body2: int, is_static1: bool, is_static2: bool) -> int:
+        return int(self.lib.fn("constraint_graph_push")(self.handle, handle, body1, body2, int(is_static1), int(is_static2)))
+
+    def pop(self, handle: int):
+        st = self.lib.fn("constraint_graph_pop")(self.handle, handle)
+        if st != 0:
+            raise AvnError(st, "constraint_graph_pop")
+
+    def lists(self):
+        offsets = np.zeros(GRAPH_COLOR_COUNT + 1, np.uint32)
+        n = C.c_size_t()
+        self.lib.fn("constraint_graph_lists")(self.handle, _ptr(offsets), None, 0, C.byref(n))
+        handles = np.zeros(n.value, np.uint64)
+        st = self.lib.fn("constraint_graph_lists")(self.handle, _ptr(offsets), _ptr(handles), handles.size, C.byref(n))
+        if st != 0:
+            raise AvnError(st, "constraint_graph_lists")
+        return offsets, handles
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fn("constraint_graph_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

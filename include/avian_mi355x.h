@@ -1,0 +1,359 @@
+/*
+ * avian_mi355x.h — C ABI of the MI355X-native physics step for Avian's 3D hot path.
+ *
+ * This is the drop-in boundary.  The reference (avianphysics/avian, pure Rust)
+ * has NO foreign interface for this path: the path is reached through Bevy `Plugin`s
+ * (`BroadPhasePlugin`, `IntegratorPlugin`, `SolverPlugin`, `XpbdSolverPlugin`,
+ * `SolverBodyPlugin`) whose systems read/write ECS components and resources.  Every entry
+ * point below therefore cites the reference *system / resource / component* it replaces; the
+ * Rust shim a maintainer would write over this header is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - plain C, no torch / HIP types in signatures; every pointer is a HOST pointer that is
+ *    borrowed for the duration of the call only (the library copies into HBM).
+ *  - `scalar_bits` (32|64) selects the reference's `f32`/`f64` cargo feature; every `const void*`
+ *    scalar array is `float*` or `double*` accordingly.  Vectors are interleaved xyz (the ECS
+ *    table layout of `Vec3` components), quaternions xyzw, symmetric tensors
+ *    (m00,m01,m02,m11,m12,m22) (= glam_matrix_extras `SymmetricMat3` field order).
+ *  - no panics/exceptions cross the ABI: every call returns `avn_status`; a message is
+ *    available from `avn_last_error`.
+ *  - one caller thread per world (Bevy's PhysicsSchedule is single-threaded,
+ *    reference src/schedule/mod.rs:90).
+ *
+ * The SAME header is implemented twice: by the product (HIP, prefix `avn_`, libavian_mi355x.so)
+ * and by the CPU oracle (test infrastructure, prefix `avo_`, oracle/liboracle.so).  Define
+ * AVN_PREFIX_ORACLE before including to get the `avo_` names.
+ */
+#ifndef AVIAN_MI355X_H
+#define AVIAN_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#ifdef AVN_PREFIX_ORACLE
+#define AVN_FN(name) avo_##name
+#else
+#define AVN_FN(name) avn_##name
+#endif
+
+#if defined(__GNUC__)
+#define AVN_API __attribute__((visibility("default")))
+#else
+#define AVN_API
+#endif
+
+typedef int32_t avn_status;
+enum {
+    AVN_OK = 0,
+    AVN_ERR_BAD_ARG = 1,   /* null pointer, bad size, bad enum */
+    AVN_ERR_HIP = 2,       /* a HIP runtime call failed (message has the hipError name) */
+    AVN_ERR_OOM = 3,       /* host or device allocation failed */
+    AVN_ERR_CAPACITY = 4,  /* fixed capacity exceeded (e.g. pair buffer) */
+    AVN_ERR_NO_DEVICE = 5, /* no gfx950 device visible: the product NEVER falls back to CPU */
+    AVN_ERR_STATE = 6      /* call order violated (e.g. step before bodies upload) */
+};
+
+typedef struct avn_world avn_world; /* opaque */
+
+/* ---- constants mirrored from the reference ------------------------------------------------ */
+/* constraint_graph.rs:39-48 */
+#define AVN_GRAPH_COLOR_COUNT 24
+#define AVN_COLOR_OVERFLOW_INDEX 23
+#define AVN_DYNAMIC_COLOR_COUNT 20
+#define AVN_MAX_MANIFOLD_POINTS 4 /* 3D manifolds are pruned to <= 4 points, system_param.rs:761-763 */
+
+/* RigidBody (dynamics/rigid_body/mod.rs) */
+enum { AVN_RB_DYNAMIC = 0, AVN_RB_STATIC = 1, AVN_RB_KINEMATIC = 2 };
+/* body_flags */
+enum { AVN_BODY_SLEEPING = 1, AVN_BODY_DISABLED = 2, AVN_BODY_CUSTOM_VELOCITY_INTEGRATION = 4,
+       AVN_BODY_CUSTOM_POSITION_INTEGRATION = 8 };
+/* LockedAxes bits (dynamics/rigid_body/locked_axes.rs:36-40): 0b100_000 = translation X ... 0b000_001 = rotation Z */
+/* SolverBodyFlags (solver_body/mod.rs:132-157): bits 0-5 locked axes, 6 kinematic, 7 gyroscopic */
+enum { AVN_SB_KINEMATIC = 1u << 6, AVN_SB_GYROSCOPIC = 1u << 7 };
+/* AabbIntervalFlags (broad_phase.rs:190-201) */
+enum { AVN_AABB_IS_INACTIVE = 1, AVN_AABB_CONTACT_EVENTS = 2, AVN_AABB_GENERATE_CONSTRAINTS = 4,
+       AVN_AABB_CUSTOM_FILTER = 8, AVN_AABB_MODIFY_CONTACTS = 16 };
+/* collider_flags given by the host (sources of the interval flags, broad_phase.rs:214-280) */
+enum { AVN_COLLIDER_SENSOR = 1, AVN_COLLIDER_EVENTS = 2, AVN_COLLIDER_FILTER_PAIRS = 4,
+       AVN_COLLIDER_MODIFY_CONTACTS = 8, AVN_COLLIDER_SWEPT_CCD = 16 };
+enum { AVN_SHAPE_CUBOID = 0, AVN_SHAPE_BALL = 1 };
+/* manifold_flags */
+enum { AVN_MANIFOLD_GENERATES_CONSTRAINTS = 1 };
+/* pair flags returned by the broad phase (ContactEdgeFlags/ContactPairFlags set at broad_phase.rs:443-468) */
+enum { AVN_PAIR_CONTACT_EVENTS = 1, AVN_PAIR_MODIFY_CONTACTS = 2, AVN_PAIR_GENERATE_CONSTRAINTS = 4,
+       AVN_PAIR_NEEDS_CUSTOM_FILTER = 8 /* host must still run CollisionHooks::filter_pairs */ };
+
+/* ---- configuration = the ECS *resources* the systems read --------------------------------- */
+typedef struct avn_config {
+    uint32_t struct_size;   /* = sizeof(avn_config), for forward compatibility */
+    uint32_t scalar_bits;   /* 32 | 64  (cargo features f32 / f64) */
+    int32_t device;         /* HIP device ordinal (ignored by the oracle) */
+    uint32_t substeps;      /* SubstepCount, solver/schedule.rs:185-191 (default 6) */
+    uint64_t dt_ns;         /* Time<Physics>::delta() as integer nanoseconds (Duration) */
+    double gravity[3];      /* Gravity, integrator/mod.rs:156-162 (default 0,-9.81,0) */
+    double length_unit;     /* PhysicsLengthUnit, solver/plugin.rs:199-207 */
+    /* SolverConfig, solver/plugin.rs:216-302 */
+    double contact_damping_ratio;    /* 10 */
+    double contact_frequency_factor; /* 1.5 */
+    double max_overlap_solve_speed;  /* 4 */
+    double warm_start_coefficient;   /* 1 */
+    double restitution_threshold;    /* 1 */
+    uint32_t restitution_iterations; /* 1 */
+    /* NarrowPhaseConfig, narrow_phase/mod.rs:203-255 */
+    uint32_t match_contacts;            /* 1: warm starting enabled */
+    double default_speculative_margin;  /* Scalar::MAX  (pass a value >= FLT_MAX for "unbounded") */
+    double contact_tolerance;           /* 0.005 */
+    /* Declared extension (NOT in the reference, SURVEY.md header note 2): outer repeats of the
+       biased solve / relax / joint pass inside one substep.  1 = reference behaviour. */
+    uint32_t solver_iterations;
+    uint32_t use_graph; /* product only: replay the substep loop from a captured hipGraph */
+} avn_config;
+
+/* ---- rigid bodies = the per-entity components read by prepare_solver_bodies (a3),
+ *      pre_process_velocity_increments (a4), writeback_solver_bodies (a9) ------------------- */
+typedef struct avn_bodies {
+    uint32_t count;
+    const void* position;          /* [3n] Position */
+    const void* rotation;          /* [4n] Rotation (xyzw) */
+    const void* linear_velocity;   /* [3n] LinearVelocity */
+    const void* angular_velocity;  /* [3n] AngularVelocity */
+    const void* inv_mass;          /* [n]  ComputedMass::inverse() */
+    const void* inv_inertia_local; /* [6n] ComputedAngularInertia::inverse() (local space) */
+    const void* center_of_mass;    /* [3n] ComputedCenterOfMass; NULL = zero */
+    const void* linear_damping;    /* [n]  LinearDamping;  NULL = 0 */
+    const void* angular_damping;   /* [n]  AngularDamping; NULL = 0 */
+    const void* gravity_scale;     /* [n]  GravityScale;   NULL = 1 */
+    const void* accel_linear;      /* [3n] VelocityIntegrationData.linear_increment as left by ForcePlugin
+                                           (an acceleration, integrator/mod.rs:219-221); NULL = 0 */
+    const void* accel_angular;     /* [3n] likewise angular; NULL = 0 */
+    const void* max_linear_speed;  /* [n]  MaxLinearSpeed;  NULL or <0 = absent */
+    const void* max_angular_speed; /* [n]  MaxAngularSpeed; NULL or <0 = absent */
+    const uint8_t* rb_type;        /* [n]  AVN_RB_* */
+    const uint8_t* locked_axes;    /* [n]  LockedAxes::to_bits(); NULL = 0 */
+    const int8_t* dominance;       /* [n]  Dominance; NULL = 0 */
+    const uint8_t* body_flags;     /* [n]  AVN_BODY_*; NULL = 0 */
+} avn_bodies;
+
+typedef struct avn_bodies_out { /* any pointer may be NULL = not wanted */
+    void* position;         /* [3n] */
+    void* rotation;         /* [4n] */
+    void* linear_velocity;  /* [3n] */
+    void* angular_velocity; /* [3n] */
+} avn_bodies_out;
+
+/* SolverBody / SolverBodyInertia / VelocityIntegrationData (a1, a2, a4) — inspection only */
+typedef struct avn_solver_bodies_out {
+    void* linear_velocity;  /* [3n] */
+    void* angular_velocity; /* [3n] */
+    void* delta_position;   /* [3n] */
+    void* delta_rotation;   /* [4n] */
+    uint32_t* flags;        /* [n] SolverBodyFlags; bit 31 set = body has NO SolverBody (static/sleeping/disabled) */
+    void* inv_mass;         /* [n] */
+    void* inv_inertia_world;/* [6n] effective_inv_angular_inertia */
+    int16_t* dominance;     /* [n] */
+    void* linear_increment; /* [3n] */
+    void* angular_increment;/* [3n] */
+    void* linear_damping_rhs;  /* [n] */
+    void* angular_damping_rhs; /* [n] */
+} avn_solver_bodies_out;
+
+/* ---- contact manifolds = what prepare_contact_constraints reads from ContactGraph +
+ *      ConstraintGraph (solver/plugin.rs:363-448).  Manifolds are given colour-major:
+ *      colour c owns [color_offsets[c], color_offsets[c+1]) in `manifold_handles` order. ------ */
+typedef struct avn_manifolds {
+    uint32_t count;                 /* M */
+    const uint32_t* color_offsets;  /* [AVN_GRAPH_COLOR_COUNT + 1] */
+    const int32_t* body1;           /* [M] index into the body table (ContactPair::body1) */
+    const int32_t* body2;           /* [M] */
+    const void* normal;             /* [3M] ContactManifold::normal */
+    const void* friction;           /* [M] */
+    const void* restitution;        /* [M] */
+    const void* tangent_velocity;   /* [3M]; NULL = zero */
+    const uint8_t* point_count;     /* [M] 0..4 */
+    const uint8_t* manifold_flags;  /* [M] AVN_MANIFOLD_*; NULL = GENERATES_CONSTRAINTS */
+    /* contact points, slot = 4*m + p (ContactPoint, contact_types/mod.rs:603-660) */
+    const void* anchor1;            /* [3*4M] relative to centre of mass of body1, world space */
+    const void* anchor2;            /* [3*4M] */
+    const void* penetration;        /* [4M] */
+    const void* normal_speed;       /* [4M] */
+    const void* warm_start_normal_impulse;  /* [4M];   NULL = zero */
+    const void* warm_start_tangent_impulse; /* [2*4M]; NULL = zero */
+} avn_manifolds;
+
+/* store_contact_impulses output (solver/plugin.rs:744-749), slot = 4*m + p */
+typedef struct avn_impulses_out {
+    void* warm_start_normal_impulse;  /* [4M] */
+    void* warm_start_tangent_impulse; /* [2*4M] */
+    void* normal_impulse;             /* [4M] (= total_impulse) */
+} avn_impulses_out;
+
+/* ContactConstraint / ContactConstraintPoint (contact/mod.rs:32-106) — inspection only */
+typedef struct avn_constraints_out {
+    uint8_t* point_count;     /* [M] 0 = constraint absent (skipped by prepare) */
+    int16_t* relative_dominance; /* [M] */
+    void* tangent1;           /* [3M] */
+    void* anchor1;            /* [3*4M] (copied through) */
+    void* initial_separation; /* [4M] */
+    void* normal_impulse;     /* [4M] ContactNormalPart::impulse */
+    void* total_impulse;      /* [4M] */
+    void* normal_effective_mass; /* [4M] */
+    void* tangent_impulse;    /* [2*4M] */
+    void* tangent_effective_inverse_mass; /* [3*4M] */
+    uint8_t* softness_non_dynamic; /* [M] 1 = non_dynamic coefficients */
+} avn_constraints_out;
+
+/* ---- XPBD DistanceJoint (dynamics/joints/distance.rs:26-39 + xpbd/joints/distance.rs) ------ */
+typedef struct avn_distance_joints {
+    uint32_t count;
+    const int32_t* body1;          /* [J] */
+    const int32_t* body2;          /* [J] */
+    const void* local_anchor1;     /* [3J] JointAnchor::Local */
+    const void* local_anchor2;     /* [3J] */
+    const void* limit_min;         /* [J] DistanceLimit */
+    const void* limit_max;         /* [J] */
+    const void* compliance;        /* [J] */
+    const void* damping_linear;    /* [J] JointDamping; NULL = no JointDamping component */
+    const void* damping_angular;   /* [J] */
+    const uint8_t* collision_disabled; /* [J] JointCollisionDisabled; NULL = 0 */
+} avn_distance_joints;
+
+typedef struct avn_joints_out {
+    void* world_r1;          /* [3J] DistanceJointSolverData */
+    void* world_r2;          /* [3J] */
+    void* center_difference; /* [3J] */
+    void* total_lagrange;    /* [3J] */
+    void* force;             /* [3J] JointForces::force after writeback_joint_forces */
+} avn_joints_out;
+
+/* ---- colliders for the broad phase (a24-a27).  A collider sits on its rigid body entity
+ *      (no child-collider offset in this round). --------------------------------------------- */
+typedef struct avn_colliders {
+    uint32_t count;                 /* C */
+    const uint32_t* entity_index;   /* [C] Entity::index() used for PairKey; must be unique */
+    const int32_t* body;            /* [C] ColliderOf.body as body-table index */
+    const uint8_t* shape;           /* [C] AVN_SHAPE_* */
+    const void* half_extents;       /* [3C] cuboid half extents; ball: radius in x */
+    const uint32_t* memberships;    /* [C] CollisionLayers; NULL = default (1) */
+    const uint32_t* filters;        /* [C] NULL = default (0xFFFFFFFF) */
+    const uint8_t* collider_flags;  /* [C] AVN_COLLIDER_*; NULL = 0 */
+    const void* collision_margin;   /* [C] NULL = 0 */
+    const void* speculative_margin; /* [C] NULL or <0 = use config default */
+} avn_colliders;
+
+typedef struct avn_pair {
+    uint32_t collider1; /* Entity::index() of the collider earlier in sorted order (broad_phase.rs:443) */
+    uint32_t collider2;
+    int32_t body1;      /* body-table index */
+    int32_t body2;
+    uint32_t flags;     /* AVN_PAIR_* */
+    uint32_t reserved;
+} avn_pair;
+
+/* ---- systems (one id per reference system on the path; for schedule-faithful drivers and
+ *      per-kernel parity tests) ---------------------------------------------------------------- */
+typedef enum avn_system {
+    AVN_SYS_UPDATE_AABB = 0,                /* collider/backend.rs:498-624 */
+    AVN_SYS_COLLECT_COLLISION_PAIRS = 1,    /* broad_phase.rs:214-474 (update intervals + SAP) */
+    AVN_SYS_PREPARE_SOLVER_BODIES = 2,      /* solver_body/plugin.rs:173-251 */
+    AVN_SYS_PREPARE_JOINTS = 3,             /* xpbd/plugin.rs:125-142 */
+    AVN_SYS_PREPARE_CONTACT_CONSTRAINTS = 4,/* solver/plugin.rs:326-448 (softness + generate) */
+    AVN_SYS_PRE_PROCESS_VELOCITY_INCREMENTS = 5, /* integrator/mod.rs:260-313 */
+    AVN_SYS_INTEGRATE_VELOCITIES = 6,       /* integrator/mod.rs:343-500 (+ clamp_velocities) */
+    AVN_SYS_WARM_START = 7,                 /* solver/plugin.rs:453-515 */
+    AVN_SYS_SOLVE_CONTACTS_BIAS = 8,        /* solver/plugin.rs:531-619 USE_BIAS=true */
+    AVN_SYS_INTEGRATE_POSITIONS = 9,        /* integrator/mod.rs:503-535 + solver_body/plugin.rs:287-295 */
+    AVN_SYS_SOLVE_CONTACTS_RELAX = 10,      /* USE_BIAS=false */
+    AVN_SYS_XPBD_SOLVE = 11,                /* xpbd/plugin.rs:58-86 (snapshot + solve_xpbd_joint) */
+    AVN_SYS_XPBD_VELOCITY_PROJECTION = 12,  /* xpbd/plugin.rs:192-240 */
+    AVN_SYS_JOINT_DAMPING = 13,             /* solver/plugin.rs:759-806 */
+    AVN_SYS_CLEAR_VELOCITY_INCREMENTS = 14, /* integrator/mod.rs:316-328 */
+    AVN_SYS_SOLVE_RESTITUTION = 15,         /* solver/plugin.rs:630-718 */
+    AVN_SYS_WRITEBACK_SOLVER_BODIES = 16,   /* solver_body/plugin.rs:255-284 (+ writeback_joint_forces) */
+    AVN_SYS_STORE_CONTACT_IMPULSES = 17,    /* solver/plugin.rs:722-755 */
+    AVN_SYS_SUBSTEP = 18,                   /* one run of SubstepSchedule (systems 6..13 in order) */
+    AVN_SYS_SOLVER = 19,                    /* PhysicsStepSystems::Solver: 2..5, S x SUBSTEP, 14..17 */
+    AVN_SYS_COUNT_
+} avn_system;
+
+/* per-system device timers (mirrors SolverDiagnostics / CollisionDiagnostics,
+ * solver/diagnostics.rs:12-38, collision/diagnostics.rs:13-19); milliseconds of the last avn_step */
+typedef struct avn_timers {
+    double broad_phase_ms;
+    double prepare_ms;      /* prepare bodies + joints + constraints + increments */
+    double substeps_ms;     /* the whole substep loop */
+    double finalize_ms;     /* clear + restitution + writeback + store */
+    double step_ms;         /* all of the above */
+    uint32_t contact_constraint_count;
+    uint32_t pair_count;
+    uint32_t kernel_launches; /* launches issued (or replayed) in the last step */
+    uint32_t reserved;
+} avn_timers;
+
+/* ---- entry points --------------------------------------------------------------------------- */
+AVN_API avn_status AVN_FN(world_create)(const avn_config* cfg, avn_world** out);
+AVN_API void AVN_FN(world_destroy)(avn_world* w);
+AVN_API const char* AVN_FN(last_error)(const avn_world* w); /* w may be NULL: last create error */
+AVN_API avn_status AVN_FN(config_set)(avn_world* w, const avn_config* cfg); /* resources changed */
+
+/* replaces the reads of prepare_solver_bodies / pre_process_velocity_increments */
+AVN_API avn_status AVN_FN(bodies_upload)(avn_world* w, const avn_bodies* b);
+/* replaces the writes of writeback_solver_bodies */
+AVN_API avn_status AVN_FN(bodies_download)(avn_world* w, const avn_bodies_out* out);
+AVN_API avn_status AVN_FN(solver_bodies_download)(avn_world* w, const avn_solver_bodies_out* out);
+
+/* replaces the ContactGraph/ConstraintGraph reads of prepare_contact_constraints */
+AVN_API avn_status AVN_FN(manifolds_upload)(avn_world* w, const avn_manifolds* m);
+/* replaces the ContactGraph writes of store_contact_impulses */
+AVN_API avn_status AVN_FN(impulses_download)(avn_world* w, const avn_impulses_out* out);
+AVN_API avn_status AVN_FN(constraints_download)(avn_world* w, const avn_constraints_out* out);
+
+/* replaces the DistanceJoint queries of prepare_xpbd_joint / solve_xpbd_joint / joint_damping */
+AVN_API avn_status AVN_FN(distance_joints_upload)(avn_world* w, const avn_distance_joints* j);
+AVN_API avn_status AVN_FN(joints_download)(avn_world* w, const avn_joints_out* out);
+
+/* replaces add_new_aabb_intervals (broad_phase.rs:296-315): APPENDS colliders not yet known
+ * (by entity_index) at the end of the interval list and refreshes the data of known ones;
+ * colliders absent from the call are dropped in place (retain_mut, :230-279). */
+AVN_API avn_status AVN_FN(colliders_upload)(avn_world* w, const avn_colliders* c);
+/* existing PairKeys of ContactGraph::pair_set (broad_phase.rs:417-420); body pairs whose joints
+ * have collision_disabled come from the uploaded joints (:423-428). */
+AVN_API avn_status AVN_FN(existing_pairs_upload)(avn_world* w, const uint64_t* pair_keys, size_t n);
+/* result of the last COLLECT_COLLISION_PAIRS; buffer owned by the world, valid until the next call */
+AVN_API avn_status AVN_FN(pairs_get)(avn_world* w, const avn_pair** out, size_t* n_out);
+/* ColliderAabb min/max [3C each] in collider upload order, and the current interval order
+ * (entity_index per interval) — inspection */
+AVN_API avn_status AVN_FN(aabbs_download)(avn_world* w, void* aabb_min, void* aabb_max,
+                                          uint32_t* interval_entities, size_t* n_intervals);
+
+AVN_API avn_status AVN_FN(run_system)(avn_world* w, avn_system sys);
+/* one PhysicsSchedule pass over the path: (UPDATE_AABB + COLLECT_COLLISION_PAIRS if colliders were
+ * uploaded) then AVN_SYS_SOLVER.  Asynchronous on the world's stream in the product. */
+AVN_API avn_status AVN_FN(step)(avn_world* w);
+AVN_API avn_status AVN_FN(synchronize)(avn_world* w);
+AVN_API avn_status AVN_FN(timers)(avn_world* w, avn_timers* out);
+
+/* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
+AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);
+
+/* Host-side ConstraintGraph (constraint_graph.rs:163-296) for standalone drivers that do not
+ * have Avian's own graph: persistent greedy colouring over manifolds keyed by a caller handle. */
+typedef struct avn_constraint_graph avn_constraint_graph;
+AVN_API avn_status AVN_FN(constraint_graph_create)(uint32_t body_capacity, avn_constraint_graph** out);
+AVN_API void AVN_FN(constraint_graph_destroy)(avn_constraint_graph* g);
+/* push_manifold: returns the colour chosen; `handle` is an opaque caller id (e.g. contact_id<<2|manifold_index) */
+AVN_API int32_t AVN_FN(constraint_graph_push)(avn_constraint_graph* g, uint64_t handle, uint32_t body1,
+                                              uint32_t body2, int is_static1, int is_static2);
+/* pop_manifold (swap-remove) */
+AVN_API avn_status AVN_FN(constraint_graph_pop)(avn_constraint_graph* g, uint64_t handle);
+/* colour-major handle list: offsets[25], handles[count] in manifold_handles order */
+AVN_API avn_status AVN_FN(constraint_graph_lists)(const avn_constraint_graph* g, uint32_t* offsets,
+                                                  uint64_t* handles, size_t capacity, size_t* count);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVIAN_MI355X_H */

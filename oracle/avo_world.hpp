@@ -1,0 +1,1209 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or called by the product path
+// (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it).
+//
+// avo_world.hpp: single-threaded CPU restatement of Avian's 3D hot path, in the reference's own
+// operation order.  Every function cites the reference file:line it
+// follows (paths relative to /root/reference/src).
+//
+// PARITY PINNING: the reference cannot be built here (no cargo/rustc; bevy/glam/parry not
+// vendored), so this restatement is pinned only by the reference's own known-answer tests that
+// touch the path (integrator/mod.rs:562-629 `semi_implicit_euler`, tests/mod.rs:98-142
+// `body_with_velocity_moves`) — see tests/test_oracle_kat.py.  For contacts, colouring, broad
+// phase pair lists and XPBD joints the reference holds NO golden vectors: "parity unpinned" there;
+// the restatement is reviewed line by line against the cited source instead.
+#pragma once
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../include/avian_mi355x.h"
+#include "avo_math.hpp"
+
+namespace avo {
+
+// ---- softness (solver/softness_parameters/mod.rs:36-41,64-79) ----------------------------------
+template <class S> struct SoftnessCoefficients { S bias, mass_scale, impulse_scale; };
+template <class S> inline SoftnessCoefficients<S> softness_coefficients(S damping_ratio, S frequency_hz, S delta_secs) {
+    const S TAU = S(6.283185307179586476925286766559);
+    S double_damping_ratio = S(2) * damping_ratio;
+    S angular_frequency = TAU * frequency_hz;
+    S a1 = double_damping_ratio + angular_frequency * delta_secs;
+    S a2 = angular_frequency * delta_secs * a1;
+    S a3 = S(1) / (S(1) + a2);
+    return {angular_frequency / a1, a2 * a3, a3};
+}
+
+// ---- solver_body/mod.rs:59-91 ---------------------------------------------------------------------
+template <class S> struct SolverBody {
+    V3<S> linear_velocity{0, 0, 0}, angular_velocity{0, 0, 0}, delta_position{0, 0, 0};
+    Q4<S> delta_rotation{0, 0, 0, 1};
+    uint32_t flags = 0;
+    V3<S> velocity_at_point(V3<S> p) const { return linear_velocity + cross(angular_velocity, p); }  // :107-116
+    bool is_kinematic() const { return flags & AVN_SB_KINEMATIC; }
+    bool is_gyroscopic() const { return flags & AVN_SB_GYROSCOPIC; }
+};
+// solver_body/mod.rs:218-276
+template <class S> struct SolverBodyInertia {
+    S inv_mass = 0;
+    Sym3<S> inv_inertia{0, 0, 0, 0, 0, 0};
+    int16_t dominance = 128;  // DUMMY: i8::MAX + 1
+    uint16_t flags = 0xC0;    // InertiaFlags::STATIC
+    // :437-451
+    V3<S> effective_inv_mass() const {
+        V3<S> m{inv_mass, inv_mass, inv_mass};
+        if (flags & 0b100000) m.x = 0;
+        if (flags & 0b010000) m.y = 0;
+        if (flags & 0b001000) m.z = 0;
+        return m;
+    }
+};
+template <class S> inline void lock_rotation_axes(Sym3<S>& t, uint32_t locked) {  // :400-414 / :483-499
+    if (locked & 0b100) { t.m00 = 0; t.m01 = 0; t.m02 = 0; }
+    if (locked & 0b010) { t.m01 = 0; t.m11 = 0; t.m12 = 0; }
+    if (locked & 0b001) { t.m02 = 0; t.m12 = 0; t.m22 = 0; }
+}
+// integrator/mod.rs:216-233
+template <class S> struct VelocityIntegrationData {
+    V3<S> linear_increment{0, 0, 0}, angular_increment{0, 0, 0};
+    S linear_damping_rhs = 0, angular_damping_rhs = 0;  // #[derive(Default)]
+};
+
+template <class S> struct Body {
+    V3<S> position, linear_velocity, angular_velocity, center_of_mass;
+    Q4<S> rotation;
+    S inv_mass;
+    Sym3<S> inv_inertia_local;
+    S linear_damping, angular_damping, gravity_scale, max_linear_speed, max_angular_speed;
+    uint8_t rb_type, locked_axes, body_flags;
+    int8_t dominance;
+    // solver components
+    bool has_solver_body;  // SolverBody exists for awake, enabled dynamic/kinematic bodies (solver_body/plugin.rs:38-96)
+    SolverBody<S> sb;
+    SolverBodyInertia<S> si;
+    VelocityIntegrationData<S> vid;
+    V3<S> pre_solve_delta_position;
+    Q4<S> pre_solve_delta_rotation;
+    bool active() const { return !(body_flags & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED)); }  // RigidBodyActiveFilter
+};
+
+// ---- contacts -------------------------------------------------------------------------------------
+template <class S> struct ContactPoint {  // contact_types/mod.rs:603-660
+    V3<S> anchor1, anchor2;
+    S penetration, normal_speed, warm_start_normal_impulse, normal_impulse;
+    V2<S> warm_start_tangent_impulse;
+};
+template <class S> struct ContactManifold {  // contact_types/mod.rs:342-378 (+ pair body handles)
+    int32_t body1, body2;
+    V3<S> normal, tangent_velocity;
+    S friction, restitution;
+    uint8_t point_count, flags;
+    ContactPoint<S> points[AVN_MAX_MANIFOLD_POINTS];
+};
+template <class S> struct ContactNormalPart { S impulse, total_impulse, effective_mass; SoftnessCoefficients<S> softness; };
+template <class S> struct ContactTangentPart { V2<S> impulse; S effective_inverse_mass[3]; };
+template <class S> struct ContactConstraintPoint {  // contact/mod.rs:32-54
+    ContactNormalPart<S> normal_part;
+    bool has_tangent;
+    ContactTangentPart<S> tangent_part;
+    V3<S> anchor1, anchor2;
+    S normal_speed, initial_separation;
+};
+template <class S> struct ContactConstraint {  // contact/mod.rs:64-106
+    int32_t body1, body2;
+    int16_t relative_dominance;
+    S friction, restitution;
+    V3<S> tangent_velocity, normal, tangent1;
+    int point_count;
+    ContactConstraintPoint<S> points[AVN_MAX_MANIFOLD_POINTS];
+    uint32_t manifold;  // index of the source manifold (contact_id, manifold_index in the reference)
+    bool softness_non_dynamic;
+};
+
+// contact/normal_part.rs:39-112
+template <class S>
+inline ContactNormalPart<S> normal_part_generate(V3<S> w_sum, const Sym3<S>& i1, const Sym3<S>& i2, V3<S> r1, V3<S> r2,
+                                                 V3<S> normal, bool warm, S warm_impulse, SoftnessCoefficients<S> soft) {
+    V3<S> r1_cross_n = cross(r1, normal);
+    V3<S> r2_cross_n = cross(r2, normal);
+    S k_linear = dot(normal, cmul(w_sum, normal));
+    S k = k_linear + dot(r1_cross_n, smul(i1, r1_cross_n)) + dot(r2_cross_n, smul(i2, r2_cross_n));
+    return {warm ? warm_impulse : S(0), S(0), recip_or_zero(k), soft};
+}
+// contact/normal_part.rs:116-166
+template <class S>
+inline S normal_part_solve_impulse(ContactNormalPart<S>& p, S separation, V3<S> relative_velocity, V3<S> normal, bool use_bias,
+                                   S max_overlap_solve_speed, S delta_secs) {
+    S normal_speed = dot(relative_velocity, normal);
+    S impulse;
+    if (separation > S(0)) {
+        impulse = -p.effective_mass * (normal_speed + separation / delta_secs);
+    } else if (use_bias) {
+        S bias = smax(p.softness.bias * separation, -max_overlap_solve_speed);
+        S scaled_mass = p.softness.mass_scale * p.effective_mass;
+        S scaled_impulse = p.softness.impulse_scale * p.impulse;
+        impulse = -scaled_mass * (normal_speed + bias) - scaled_impulse;
+    } else {
+        impulse = -p.effective_mass * normal_speed;
+    }
+    S new_impulse = smax(p.impulse + impulse, S(0));
+    impulse = new_impulse - p.impulse;
+    p.impulse = new_impulse;
+    p.total_impulse += new_impulse;  // sic: adds the new ACCUMULATED value (:162)
+    return impulse;
+}
+// contact/tangent_part.rs:35-151 (3D)
+template <class S>
+inline ContactTangentPart<S> tangent_part_generate(V3<S> w_sum, const Sym3<S>& i1, const Sym3<S>& i2, V3<S> r1, V3<S> r2,
+                                                   V3<S> t0, V3<S> t1, bool warm, V2<S> warm_impulse) {
+    ContactTangentPart<S> part;
+    part.impulse = warm ? warm_impulse : V2<S>{0, 0};
+    V3<S> rt11 = cross(r1, t0), rt12 = cross(r2, t0), rt21 = cross(r1, t1), rt22 = cross(r2, t1);
+    V3<S> i1_rt11 = smul(i1, rt11), i2_rt12 = smul(i2, rt12), i1_rt21 = smul(i1, rt21), i2_rt22 = smul(i2, rt22);
+    S k_linear1 = dot(t0, cmul(w_sum, t0));
+    S k_linear2 = dot(t1, cmul(w_sum, t1));
+    S k1 = k_linear1 + dot(rt11, i1_rt11) + dot(rt12, i2_rt12);
+    S k2 = k_linear2 + dot(rt21, i1_rt21) + dot(rt22, i2_rt22);
+    part.effective_inverse_mass[0] = k1;
+    part.effective_inverse_mass[1] = k2;
+    part.effective_inverse_mass[2] = S(2) * (dot(rt11, i1_rt21) + dot(rt12, i2_rt22));
+    return part;
+}
+// contact/tangent_part.rs:155-244 (3D)
+template <class S>
+inline V3<S> tangent_part_solve_impulse(ContactTangentPart<S>& p, V3<S> t0, V3<S> t1, V3<S> relative_velocity,
+                                        V3<S> surface_velocity, S friction, S normal_impulse) {
+    S impulse_limit = friction * normal_impulse;
+    V3<S> rv = relative_velocity + surface_velocity;
+    S tangent_speed1 = dot(rv, t0);
+    S tangent_speed2 = dot(rv, t1);
+    S t11 = tangent_speed1 * tangent_speed1;  // powi(2)
+    S t22 = tangent_speed2 * tangent_speed2;
+    S t12 = tangent_speed1 * tangent_speed2;
+    S inv = t11 * p.effective_inverse_mass[0] + t22 * p.effective_inverse_mass[1] + t12 * p.effective_inverse_mass[2];
+    S effective_mass = (t11 + t22) * (S(1) / inv);
+    if (!std::isfinite(effective_mass)) return vzero<S>();
+    V2<S> delta_impulse{effective_mass * tangent_speed1, effective_mass * tangent_speed2};
+    V2<S> new_impulse = clamp_length_max(V2<S>{p.impulse.x - delta_impulse.x, p.impulse.y - delta_impulse.y}, impulse_limit);
+    V2<S> impulse{new_impulse.x - p.impulse.x, new_impulse.y - p.impulse.y};
+    p.impulse = new_impulse;
+    return impulse.x * t0 + impulse.y * t1;
+}
+// contact/mod.rs:427-449
+template <class S> inline void compute_tangent_directions(V3<S> normal, V3<S> velocity1, V3<S> velocity2, V3<S>& t0, V3<S>& t1) {
+    V3<S> force_direction = -normal;
+    V3<S> relative_velocity = velocity1 - velocity2;
+    V3<S> tangent_velocity = relative_velocity - force_direction * dot(force_direction, relative_velocity);
+    V3<S> tangent;
+    if (!try_normalize(tangent_velocity, tangent)) tangent = any_orthonormal_vector(force_direction);
+    t0 = tangent;
+    t1 = cross(force_direction, tangent);
+}
+
+// ---- XPBD -------------------------------------------------------------------------------------------
+template <class S> struct DistanceJoint {
+    int32_t body1, body2;
+    V3<S> local_anchor1, local_anchor2;
+    S limit_min, limit_max, compliance;
+    bool has_damping;
+    S damping_linear, damping_angular;
+    bool collision_disabled;
+    // DistanceJointSolverData (xpbd/joints/distance.rs:12-21)
+    V3<S> world_r1{0, 0, 0}, world_r2{0, 0, 0}, center_difference{0, 0, 0}, total_lagrange{0, 0, 0};
+    V3<S> force{0, 0, 0};
+};
+// xpbd/mod.rs:393-413
+template <class S> inline S compute_lagrange_update(S lagrange, S c, S w1, S w2, S compliance, S dt) {
+    S w_sum = S(0) + w1 + w2;  // iter().copied().sum() starts from 0.0
+    if (w_sum <= std::numeric_limits<S>::epsilon()) return S(0);
+    S tilde_compliance = compliance / (dt * dt);  // dt.powi(2)
+    return (-c - tilde_compliance * lagrange) / (w_sum + tilde_compliance);
+}
+
+// ---- broad phase --------------------------------------------------------------------------------------
+template <class S> struct ColliderAabb { V3<S> min, max; };
+template <class S> struct Collider {
+    uint32_t entity;
+    int32_t body;
+    uint8_t shape, cflags;
+    V3<S> half_extents;
+    uint32_t memberships, filters;
+    S collision_margin, speculative_margin;  // speculative < 0 = absent
+    ColliderAabb<S> aabb;
+};
+struct AabbInterval {  // broad_phase.rs:177-185 (aabb/layers looked up through the collider slot)
+    uint32_t collider;  // slot in `colliders`
+    uint8_t flags;
+};
+
+inline uint64_t pair_key(uint32_t a, uint32_t b) {  // data_structures/pair_key.rs:14-21
+    return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+}
+
+// ---- the world ------------------------------------------------------------------------------------------
+struct WorldBase {
+    std::string error;
+    virtual ~WorldBase() {}
+    virtual avn_status config_set(const avn_config*) = 0;
+    virtual avn_status bodies_upload(const avn_bodies*) = 0;
+    virtual avn_status bodies_download(const avn_bodies_out*) = 0;
+    virtual avn_status solver_bodies_download(const avn_solver_bodies_out*) = 0;
+    virtual avn_status manifolds_upload(const avn_manifolds*) = 0;
+    virtual avn_status impulses_download(const avn_impulses_out*) = 0;
+    virtual avn_status constraints_download(const avn_constraints_out*) = 0;
+    virtual avn_status distance_joints_upload(const avn_distance_joints*) = 0;
+    virtual avn_status joints_download(const avn_joints_out*) = 0;
+    virtual avn_status colliders_upload(const avn_colliders*) = 0;
+    virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;
+    virtual avn_status pairs_get(const avn_pair**, size_t*) = 0;
+    virtual avn_status aabbs_download(void*, void*, uint32_t*, size_t*) = 0;
+    virtual avn_status run_system(avn_system) = 0;
+    virtual avn_status step() = 0;
+    virtual avn_status timers(avn_timers*) = 0;
+};
+
+template <class S> struct World : WorldBase {
+    avn_config cfg;
+    // time scalars (SURVEY.md Appendix A addenda "Time scalars")
+    S dt_f64cast, h_f64cast;  // Duration::as_secs_f64() as Scalar   (integrator/mod.rs:275,354; plugin.rs:333-334)
+    S dt_adj, h_adj;          // delta_seconds_adjusted()            (schedule/time.rs:282-291)
+    SoftnessCoefficients<S> soft_dynamic, soft_non_dynamic;
+
+    std::vector<Body<S>> bodies;
+    std::vector<V3<S>> accel_linear, accel_angular;
+    std::vector<ContactManifold<S>> manifolds;
+    uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1];
+    std::vector<ContactConstraint<S>> color_constraints[AVN_GRAPH_COLOR_COUNT];  // GraphColor::contact_constraints
+    std::vector<DistanceJoint<S>> joints;
+    std::vector<Collider<S>> colliders;
+    std::unordered_map<uint32_t, uint32_t> collider_slot;  // entity -> slot
+    std::vector<AabbInterval> intervals;                    // AabbIntervals, kept sorted across frames
+    std::unordered_set<uint64_t> pair_set;
+    std::unordered_set<uint64_t> collision_disabled_bodies;
+    std::vector<avn_pair> pairs;
+    avn_timers last_timers;
+    bool have_colliders = false;
+
+    World() { std::memset(&last_timers, 0, sizeof last_timers); std::memset(color_offsets, 0, sizeof color_offsets); }
+
+    // -- time: Duration arithmetic of run_physics_schedule / run_substep_schedule (schedule/mod.rs:240-284,
+    //    solver/schedule.rs:194-200).  sub_delta = delta.div_f64(substeps) = from_secs_f64(secs/substeps)
+    //    (rounds to the nearest nanosecond).
+    static S as_secs_adjusted(uint64_t ns) {
+        if (sizeof(S) == 8) return (S)((double)(ns / 1000000000ull) + (double)(ns % 1000000000ull) / 1e9);
+        // Duration::as_secs_f32: (secs as f32) + (nanos as f32) / (NANOS_PER_SEC as f32)
+        return (S)((float)(ns / 1000000000ull) + (float)(ns % 1000000000ull) / 1e9f);
+    }
+    static double as_secs_f64(uint64_t ns) { return (double)(ns / 1000000000ull) + (double)(ns % 1000000000ull) / 1e9; }
+    avn_status config_set(const avn_config* c) override {
+        if (!c || c->substeps == 0 || c->dt_ns == 0) { error = "bad config"; return AVN_ERR_BAD_ARG; }
+        cfg = *c;
+        if (cfg.solver_iterations == 0) cfg.solver_iterations = 1;
+        uint64_t dt_ns = cfg.dt_ns;
+        double sub = as_secs_f64(dt_ns) / (double)cfg.substeps;
+        uint64_t h_ns = (uint64_t)std::llround(sub * 1e9);
+        dt_f64cast = (S)as_secs_f64(dt_ns);
+        h_f64cast = (S)as_secs_f64(h_ns);
+        dt_adj = as_secs_adjusted(dt_ns);
+        h_adj = as_secs_adjusted(h_ns);
+        update_contact_softness();
+        return AVN_OK;
+    }
+    // solver/plugin.rs:326-350
+    void update_contact_softness() {
+        S dt = dt_f64cast, h = h_f64cast;
+        S max_hz = S(1) / (dt * S(2));
+        S hz = (S)cfg.contact_frequency_factor * smin(max_hz, S(0.25) / h);
+        soft_dynamic = softness_coefficients<S>((S)cfg.contact_damping_ratio, hz, h);
+        soft_non_dynamic = softness_coefficients<S>((S)cfg.contact_damping_ratio, S(2) * hz, h);
+    }
+
+    // ---------------------------------------------------------------------------------------------
+    template <class T> static T rd(const void* p, size_t i, T dflt) { return p ? ((const T*)p)[i] : dflt; }
+    static V3<S> rd3(const void* p, size_t i) { if (!p) return vzero<S>(); const S* a = (const S*)p + 3 * i; return {a[0], a[1], a[2]}; }
+    static void wr3(void* p, size_t i, V3<S> v) { if (!p) return; S* a = (S*)p + 3 * i; a[0] = v.x; a[1] = v.y; a[2] = v.z; }
+
+    avn_status bodies_upload(const avn_bodies* b) override {
+        if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass ||
+                                !b->inv_inertia_local || !b->rb_type))) { error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG; }
+        size_t n = b->count;
+        bodies.resize(n);
+        accel_linear.resize(n);
+        accel_angular.resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            Body<S>& o = bodies[i];
+            o.position = rd3(b->position, i);
+            const S* q = (const S*)b->rotation + 4 * i;
+            o.rotation = {q[0], q[1], q[2], q[3]};
+            o.linear_velocity = rd3(b->linear_velocity, i);
+            o.angular_velocity = rd3(b->angular_velocity, i);
+            o.inv_mass = ((const S*)b->inv_mass)[i];
+            const S* t = (const S*)b->inv_inertia_local + 6 * i;
+            o.inv_inertia_local = {t[0], t[1], t[2], t[3], t[4], t[5]};
+            o.center_of_mass = rd3(b->center_of_mass, i);
+            o.linear_damping = rd<S>(b->linear_damping, i, 0);
+            o.angular_damping = rd<S>(b->angular_damping, i, 0);
+            o.gravity_scale = rd<S>(b->gravity_scale, i, 1);
+            o.max_linear_speed = rd<S>(b->max_linear_speed, i, -1);
+            o.max_angular_speed = rd<S>(b->max_angular_speed, i, -1);
+            o.rb_type = b->rb_type[i];
+            o.locked_axes = rd<uint8_t>(b->locked_axes, i, 0);
+            o.dominance = rd<int8_t>(b->dominance, i, 0);
+            o.body_flags = rd<uint8_t>(b->body_flags, i, 0);
+            o.has_solver_body = o.rb_type != AVN_RB_STATIC && o.active();
+            o.sb = SolverBody<S>();
+            o.si = SolverBodyInertia<S>();
+            o.vid = VelocityIntegrationData<S>();
+            o.pre_solve_delta_position = vzero<S>();
+            o.pre_solve_delta_rotation = qidentity<S>();
+            accel_linear[i] = rd3(b->accel_linear, i);
+            accel_angular[i] = rd3(b->accel_angular, i);
+        }
+        return AVN_OK;
+    }
+    avn_status bodies_download(const avn_bodies_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            wr3(o->position, i, bodies[i].position);
+            if (o->rotation) { S* q = (S*)o->rotation + 4 * i; Q4<S> r = bodies[i].rotation; q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w; }
+            wr3(o->linear_velocity, i, bodies[i].linear_velocity);
+            wr3(o->angular_velocity, i, bodies[i].angular_velocity);
+        }
+        return AVN_OK;
+    }
+    avn_status solver_bodies_download(const avn_solver_bodies_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            const Body<S>& b = bodies[i];
+            wr3(o->linear_velocity, i, b.sb.linear_velocity);
+            wr3(o->angular_velocity, i, b.sb.angular_velocity);
+            wr3(o->delta_position, i, b.sb.delta_position);
+            if (o->delta_rotation) { S* q = (S*)o->delta_rotation + 4 * i; Q4<S> r = b.sb.delta_rotation; q[0] = r.x; q[1] = r.y; q[2] = r.z; q[3] = r.w; }
+            if (o->flags) o->flags[i] = b.sb.flags | (b.has_solver_body ? 0u : 0x80000000u);
+            if (o->inv_mass) ((S*)o->inv_mass)[i] = b.si.inv_mass;
+            if (o->inv_inertia_world) { S* t = (S*)o->inv_inertia_world + 6 * i; const Sym3<S>& s = b.si.inv_inertia; t[0] = s.m00; t[1] = s.m01; t[2] = s.m02; t[3] = s.m11; t[4] = s.m12; t[5] = s.m22; }
+            if (o->dominance) o->dominance[i] = b.si.dominance;
+            wr3(o->linear_increment, i, b.vid.linear_increment);
+            wr3(o->angular_increment, i, b.vid.angular_increment);
+            if (o->linear_damping_rhs) ((S*)o->linear_damping_rhs)[i] = b.vid.linear_damping_rhs;
+            if (o->angular_damping_rhs) ((S*)o->angular_damping_rhs)[i] = b.vid.angular_damping_rhs;
+        }
+        return AVN_OK;
+    }
+
+    avn_status manifolds_upload(const avn_manifolds* m) override {
+        if (!m || !m->color_offsets || (m->count && (!m->body1 || !m->body2 || !m->normal || !m->friction || !m->restitution ||
+                                                    !m->point_count || !m->anchor1 || !m->anchor2 || !m->penetration || !m->normal_speed))) {
+            error = "manifolds_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        if (m->color_offsets[0] != 0 || m->color_offsets[AVN_GRAPH_COLOR_COUNT] != m->count) { error = "manifolds_upload: bad color_offsets"; return AVN_ERR_BAD_ARG; }
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            if (m->color_offsets[c] > m->color_offsets[c + 1]) { error = "manifolds_upload: color_offsets not monotone"; return AVN_ERR_BAD_ARG; }
+        std::memcpy(color_offsets, m->color_offsets, sizeof color_offsets);
+        manifolds.resize(m->count);
+        for (size_t i = 0; i < m->count; ++i) {
+            ContactManifold<S>& o = manifolds[i];
+            o.body1 = m->body1[i]; o.body2 = m->body2[i];
+            if (o.body1 < 0 || o.body2 < 0 || (size_t)o.body1 >= bodies.size() || (size_t)o.body2 >= bodies.size()) { error = "manifolds_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+            o.normal = rd3(m->normal, i);
+            o.tangent_velocity = rd3(m->tangent_velocity, i);
+            o.friction = ((const S*)m->friction)[i];
+            o.restitution = ((const S*)m->restitution)[i];
+            o.point_count = m->point_count[i];
+            if (o.point_count > AVN_MAX_MANIFOLD_POINTS) { error = "manifolds_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
+            o.flags = rd<uint8_t>(m->manifold_flags, i, AVN_MANIFOLD_GENERATES_CONSTRAINTS);
+            for (int p = 0; p < AVN_MAX_MANIFOLD_POINTS; ++p) {
+                size_t s = 4 * i + p;
+                ContactPoint<S>& cp = o.points[p];
+                cp.anchor1 = rd3(m->anchor1, s);
+                cp.anchor2 = rd3(m->anchor2, s);
+                cp.penetration = ((const S*)m->penetration)[s];
+                cp.normal_speed = ((const S*)m->normal_speed)[s];
+                cp.warm_start_normal_impulse = rd<S>(m->warm_start_normal_impulse, s, 0);
+                cp.normal_impulse = 0;
+                if (m->warm_start_tangent_impulse) { const S* t = (const S*)m->warm_start_tangent_impulse + 2 * s; cp.warm_start_tangent_impulse = {t[0], t[1]}; }
+                else cp.warm_start_tangent_impulse = {0, 0};
+            }
+        }
+        for (auto& v : color_constraints) v.clear();
+        return AVN_OK;
+    }
+    avn_status impulses_download(const avn_impulses_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < manifolds.size(); ++i)
+            for (int p = 0; p < AVN_MAX_MANIFOLD_POINTS; ++p) {
+                size_t s = 4 * i + p;
+                const ContactPoint<S>& cp = manifolds[i].points[p];
+                if (o->warm_start_normal_impulse) ((S*)o->warm_start_normal_impulse)[s] = cp.warm_start_normal_impulse;
+                if (o->warm_start_tangent_impulse) { S* t = (S*)o->warm_start_tangent_impulse + 2 * s; t[0] = cp.warm_start_tangent_impulse.x; t[1] = cp.warm_start_tangent_impulse.y; }
+                if (o->normal_impulse) ((S*)o->normal_impulse)[s] = cp.normal_impulse;
+            }
+        return AVN_OK;
+    }
+    avn_status constraints_download(const avn_constraints_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t M = manifolds.size();
+        if (o->point_count) std::memset(o->point_count, 0, M);
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            for (const ContactConstraint<S>& k : color_constraints[c]) {
+                size_t i = k.manifold;
+                if (o->point_count) o->point_count[i] = (uint8_t)k.point_count;
+                if (o->relative_dominance) o->relative_dominance[i] = k.relative_dominance;
+                wr3(o->tangent1, i, k.tangent1);
+                if (o->softness_non_dynamic) o->softness_non_dynamic[i] = k.softness_non_dynamic;
+                for (int p = 0; p < k.point_count; ++p) {
+                    size_t s = 4 * i + p;
+                    const ContactConstraintPoint<S>& cp = k.points[p];
+                    wr3(o->anchor1, s, cp.anchor1);
+                    if (o->initial_separation) ((S*)o->initial_separation)[s] = cp.initial_separation;
+                    if (o->normal_impulse) ((S*)o->normal_impulse)[s] = cp.normal_part.impulse;
+                    if (o->total_impulse) ((S*)o->total_impulse)[s] = cp.normal_part.total_impulse;
+                    if (o->normal_effective_mass) ((S*)o->normal_effective_mass)[s] = cp.normal_part.effective_mass;
+                    if (o->tangent_impulse) { S* t = (S*)o->tangent_impulse + 2 * s; t[0] = cp.tangent_part.impulse.x; t[1] = cp.tangent_part.impulse.y; }
+                    if (o->tangent_effective_inverse_mass) { S* t = (S*)o->tangent_effective_inverse_mass + 3 * s; for (int q = 0; q < 3; ++q) t[q] = cp.tangent_part.effective_inverse_mass[q]; }
+                }
+            }
+        return AVN_OK;
+    }
+
+    avn_status distance_joints_upload(const avn_distance_joints* j) override {
+        if (!j || (j->count && (!j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->limit_min || !j->limit_max || !j->compliance))) {
+            error = "distance_joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        joints.resize(j->count);
+        collision_disabled_bodies.clear();
+        for (size_t i = 0; i < j->count; ++i) {
+            DistanceJoint<S>& o = joints[i];
+            o = DistanceJoint<S>();
+            o.body1 = j->body1[i]; o.body2 = j->body2[i];
+            if (o.body1 < 0 || o.body2 < 0 || (size_t)o.body1 >= bodies.size() || (size_t)o.body2 >= bodies.size() || o.body1 == o.body2) { error = "distance_joints_upload: bad body index"; return AVN_ERR_BAD_ARG; }
+            o.local_anchor1 = rd3(j->local_anchor1, i);
+            o.local_anchor2 = rd3(j->local_anchor2, i);
+            o.limit_min = ((const S*)j->limit_min)[i];
+            o.limit_max = ((const S*)j->limit_max)[i];
+            o.compliance = ((const S*)j->compliance)[i];
+            o.has_damping = j->damping_linear && j->damping_angular;
+            o.damping_linear = rd<S>(j->damping_linear, i, 0);
+            o.damping_angular = rd<S>(j->damping_angular, i, 0);
+            o.collision_disabled = rd<uint8_t>(j->collision_disabled, i, 0) != 0;
+            if (o.collision_disabled) collision_disabled_bodies.insert(pair_key((uint32_t)o.body1, (uint32_t)o.body2));
+        }
+        return AVN_OK;
+    }
+    avn_status joints_download(const avn_joints_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < joints.size(); ++i) {
+            wr3(o->world_r1, i, joints[i].world_r1);
+            wr3(o->world_r2, i, joints[i].world_r2);
+            wr3(o->center_difference, i, joints[i].center_difference);
+            wr3(o->total_lagrange, i, joints[i].total_lagrange);
+            wr3(o->force, i, joints[i].force);
+        }
+        return AVN_OK;
+    }
+
+    // =============================================================================================
+    //                                      SOLVER BODIES
+    // =============================================================================================
+    // solver_body/plugin.rs:173-251
+    void prepare_solver_bodies() {
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            b.sb.linear_velocity = b.linear_velocity;
+            b.sb.angular_velocity = b.angular_velocity;
+            b.sb.delta_position = vzero<S>();
+            b.sb.delta_rotation = qidentity<S>();
+            // SolverBodyInertia::new (solver_body/mod.rs:378-423)
+            Sym3<S> inv_inertia = rotated_inverse_inertia(b.inv_inertia_local, b.rotation);
+            uint16_t flags = b.locked_axes;
+            if (b.inv_mass == S(0)) flags |= 1 << 6;
+            if (sym_is_zero(inv_inertia)) flags |= 1 << 7;
+            lock_rotation_axes(inv_inertia, b.locked_axes);
+            b.si.inv_mass = b.inv_mass;
+            b.si.inv_inertia = inv_inertia;
+            b.si.dominance = b.rb_type == AVN_RB_DYNAMIC ? (int16_t)b.dominance : (int16_t)128;
+            b.si.flags = flags;
+            b.sb.flags = b.locked_axes;
+            if (b.rb_type == AVN_RB_KINEMATIC) b.sb.flags |= AVN_SB_KINEMATIC;
+            bool rotation_locked = (b.locked_axes & 0b111) == 0b111;
+            bool is_gyroscopic = !rotation_locked && !sym_is_isotropic(b.inv_inertia_local, S(1e-6));
+            if (is_gyroscopic) b.sb.flags |= AVN_SB_GYROSCOPIC;
+        }
+    }
+    // integrator/mod.rs:260-313.  VelocityIntegrationData.{linear,angular}_increment hold the accumulated
+    // accelerations written by ForcePlugin before this system (here: the uploaded accel_* arrays).
+    void pre_process_velocity_increments() {
+        S delta_secs = h_f64cast;
+        V3<S> gravity{(S)cfg.gravity[0], (S)cfg.gravity[1], (S)cfg.gravity[2]};
+        for (size_t i = 0; i < bodies.size(); ++i) {
+            Body<S>& b = bodies[i];
+            if (b.rb_type != AVN_RB_DYNAMIC) continue;
+            b.vid.linear_increment = accel_linear[i];
+            b.vid.angular_increment = accel_angular[i];
+            b.vid.linear_damping_rhs = S(1) / (S(1) + delta_secs * b.linear_damping);
+            b.vid.angular_damping_rhs = S(1) / (S(1) + delta_secs * b.angular_damping);
+            b.vid.linear_increment = b.vid.linear_increment + gravity * b.gravity_scale;
+            if (b.locked_axes & 0b100000) b.vid.linear_increment.x = 0;
+            if (b.locked_axes & 0b010000) b.vid.linear_increment.y = 0;
+            if (b.locked_axes & 0b001000) b.vid.linear_increment.z = 0;
+            if (b.locked_axes & 0b000100) b.vid.angular_increment.x = 0;
+            if (b.locked_axes & 0b000010) b.vid.angular_increment.y = 0;
+            if (b.locked_axes & 0b000001) b.vid.angular_increment.z = 0;
+            b.vid.linear_increment = b.vid.linear_increment * delta_secs;
+            b.vid.angular_increment = b.vid.angular_increment * delta_secs;
+        }
+    }
+    // integrator/mod.rs:316-328
+    void clear_velocity_increments() {
+        for (Body<S>& b : bodies)
+            if (b.has_solver_body) { b.vid.linear_increment = vzero<S>(); b.vid.angular_increment = vzero<S>(); }
+    }
+    // integrator/mod.rs:403-460
+    static void solve_gyroscopic_torque(V3<S>& ang_vel, Q4<S> rotation, const Sym3<S>& local_inverse_inertia, S delta_secs) {
+        V3<S> local_ang_vel = qrot(qinverse(rotation), ang_vel);
+        Sym3<S> tensor = sym_inverse_or_zero(local_inverse_inertia);  // ComputedAngularInertia::tensor() :617-619
+        V3<S> local_momentum = smul(tensor, local_ang_vel);
+        V3<S> new_local_momentum = local_momentum - delta_secs * cross(local_ang_vel, local_momentum);
+        S new_len_sq = length_squared(new_local_momentum);
+        if (new_len_sq == S(0)) { ang_vel = vzero<S>(); return; }
+        new_local_momentum = new_local_momentum * std::sqrt(length_squared(local_momentum) / new_len_sq);
+        ang_vel = qrot(rotation, smul(local_inverse_inertia, new_local_momentum));
+    }
+    // integrator/mod.rs:343-391, then clamp_velocities :467-500
+    void integrate_velocities() {
+        S delta_secs = h_f64cast;
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) continue;
+            if (b.sb.is_kinematic()) continue;
+            b.sb.linear_velocity = b.sb.linear_velocity * b.vid.linear_damping_rhs;
+            b.sb.angular_velocity = b.sb.angular_velocity * b.vid.angular_damping_rhs;
+            b.sb.linear_velocity = b.sb.linear_velocity + b.vid.linear_increment;
+            b.sb.angular_velocity = b.sb.angular_velocity + b.vid.angular_increment;
+            if (b.sb.is_gyroscopic()) {
+                Q4<S> rotation = qmul(b.sb.delta_rotation, b.rotation);
+                solve_gyroscopic_torque(b.sb.angular_velocity, rotation, b.inv_inertia_local, delta_secs);
+            }
+        }
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            if (b.max_linear_speed >= S(0)) {
+                S sq = length_squared(b.sb.linear_velocity);
+                if (sq > b.max_linear_speed * b.max_linear_speed) b.sb.linear_velocity = b.sb.linear_velocity * (b.max_linear_speed / std::sqrt(sq));
+            }
+        }
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            if (b.max_angular_speed >= S(0)) {
+                S sq = length_squared(b.sb.angular_velocity);
+                if (sq > b.max_angular_speed * b.max_angular_speed) b.sb.angular_velocity = b.sb.angular_velocity * (b.max_angular_speed / std::sqrt(sq));
+            }
+        }
+    }
+    // integrator/mod.rs:503-535, then update_solver_body_angular_inertia solver_body/plugin.rs:287-295
+    void integrate_positions() {
+        S delta_secs = h_adj;
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_POSITION_INTEGRATION)) continue;
+            b.sb.delta_position = b.sb.delta_position + b.sb.linear_velocity * delta_secs;
+            b.sb.delta_rotation = qmul(from_scaled_axis(b.sb.angular_velocity * delta_secs), b.sb.delta_rotation);
+        }
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            // update_effective_inv_angular_inertia (solver_body/mod.rs:473-501): uses the step-start Rotation
+            Sym3<S> t = rotated_inverse_inertia(b.inv_inertia_local, b.rotation);
+            lock_rotation_axes(t, b.si.flags & 0x3F);
+            b.si.inv_inertia = t;
+        }
+    }
+    // solver_body/plugin.rs:255-284
+    void writeback_solver_bodies() {
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            V3<S> old_world_com = qrot(b.rotation, b.center_of_mass);
+            b.rotation = fast_renormalize(qmul(b.sb.delta_rotation, b.rotation));
+            V3<S> new_world_com = qrot(b.rotation, b.center_of_mass);
+            b.position = b.position + ((b.sb.delta_position + old_world_com) - new_world_com);
+            b.linear_velocity = b.sb.linear_velocity;
+            b.angular_velocity = b.sb.angular_velocity;
+        }
+    }
+
+    // =============================================================================================
+    //                                      CONTACT SOLVER
+    // =============================================================================================
+    // Dummy bodies (solver/plugin.rs:491-505): static/sleeping/missing bodies use a fresh local DUMMY.
+    struct BodyRef { SolverBody<S>* body; const SolverBodyInertia<S>* inertia; };
+    SolverBody<S> dummy_body[2];
+    SolverBodyInertia<S> dummy_inertia;
+    BodyRef solver_ref(int32_t idx, int which) {
+        Body<S>& b = bodies[idx];
+        if (b.has_solver_body) return {&b.sb, &b.si};
+        dummy_body[which] = SolverBody<S>();
+        return {&dummy_body[which], &dummy_inertia};
+    }
+
+    // ContactConstraint::generate, contact/mod.rs:110-220; driver solver/plugin.rs:363-448
+    void prepare_contact_constraints() {
+        update_contact_softness();  // runs .before(NarrowPhase) every step, plugin.rs:108,326-350
+        bool warm = cfg.match_contacts != 0;
+        uint32_t count = 0;
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+            color_constraints[c].clear();
+            for (uint32_t mi = color_offsets[c]; mi < color_offsets[c + 1]; ++mi) {
+                const ContactManifold<S>& m = manifolds[mi];
+                if (!(m.flags & AVN_MANIFOLD_GENERATES_CONSTRAINTS)) continue;
+                const Body<S>& b1 = bodies[m.body1];
+                const Body<S>& b2 = bodies[m.body2];
+                if (!b1.active() || !b2.active()) continue;  // bodies.get() with RigidBodyActiveFilter fails
+                if (b1.rb_type != AVN_RB_DYNAMIC && b2.rb_type != AVN_RB_DYNAMIC) continue;
+                static const SolverBodyInertia<S> DUMMY;
+                const SolverBodyInertia<S>& inertia1 = b1.has_solver_body ? b1.si : DUMMY;
+                const SolverBodyInertia<S>& inertia2 = b2.has_solver_body ? b2.si : DUMMY;
+                int16_t relative_dominance = inertia1.dominance - inertia2.dominance;
+                V3<S> inv_mass1, inv_mass2;
+                Sym3<S> i1, i2;
+                if (relative_dominance == 0) { inv_mass1 = inertia1.effective_inv_mass(); i1 = inertia1.inv_inertia; inv_mass2 = inertia2.effective_inv_mass(); i2 = inertia2.inv_inertia; }
+                else if (relative_dominance > 0) { inv_mass1 = vzero<S>(); i1 = sym_zero<S>(); inv_mass2 = inertia2.effective_inv_mass(); i2 = inertia2.inv_inertia; }
+                else { inv_mass1 = inertia1.effective_inv_mass(); i1 = inertia1.inv_inertia; inv_mass2 = vzero<S>(); i2 = sym_zero<S>(); }
+                SoftnessCoefficients<S> softness = relative_dominance != 0 ? soft_non_dynamic : soft_dynamic;
+                V3<S> w_sum = inv_mass1 + inv_mass2;
+                V3<S> t0, t1;
+                compute_tangent_directions(m.normal, b1.linear_velocity, b2.linear_velocity, t0, t1);
+                ContactConstraint<S> k;
+                k.body1 = m.body1; k.body2 = m.body2;
+                k.relative_dominance = relative_dominance;
+                k.friction = m.friction; k.restitution = m.restitution;
+                k.tangent_velocity = m.tangent_velocity;
+                k.normal = m.normal; k.tangent1 = t0;
+                k.point_count = m.point_count;
+                k.manifold = mi;
+                k.softness_non_dynamic = relative_dominance != 0;
+                for (int p = 0; p < m.point_count; ++p) {
+                    const ContactPoint<S>& cp = m.points[p];
+                    ContactConstraintPoint<S>& o = k.points[p];
+                    o.normal_part = normal_part_generate(w_sum, i1, i2, cp.anchor1, cp.anchor2, m.normal, warm, cp.warm_start_normal_impulse, softness);
+                    o.has_tangent = m.friction > S(0);
+                    if (o.has_tangent) o.tangent_part = tangent_part_generate(w_sum, i1, i2, cp.anchor1, cp.anchor2, t0, t1, warm, cp.warm_start_tangent_impulse);
+                    else o.tangent_part = ContactTangentPart<S>{{0, 0}, {0, 0, 0}};
+                    o.anchor1 = cp.anchor1; o.anchor2 = cp.anchor2;
+                    o.normal_speed = cp.normal_speed;
+                    o.initial_separation = -cp.penetration - dot(cp.anchor2 - cp.anchor1, m.normal);
+                }
+                if (k.point_count > 0) { color_constraints[c].push_back(k); ++count; }
+            }
+        }
+        last_timers.contact_constraint_count = count;
+    }
+
+    // Colour iteration order shared by warm_start / solve_contacts / solve_restitution:
+    // overflow colour serially FIRST, then colours 0..22 (solver/plugin.rs:461-479).
+    template <class F> void for_each_constraint_in_solver_order(F f) {
+        for (ContactConstraint<S>& k : color_constraints[AVN_COLOR_OVERFLOW_INDEX]) f(k);
+        for (int c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
+            for (ContactConstraint<S>& k : color_constraints[c]) f(k);
+    }
+    void resolve(ContactConstraint<S>& k, BodyRef& r1, BodyRef& r2) {
+        r1 = solver_ref(k.body1, 0);
+        r2 = solver_ref(k.body2, 1);
+        if (k.relative_dominance > 0) r1.inertia = &dummy_inertia;       // plugin.rs:508-512
+        else if (k.relative_dominance < 0) r2.inertia = &dummy_inertia;
+    }
+    static void tangent_directions(const ContactConstraint<S>& k, V3<S>& t0, V3<S>& t1) {  // contact/mod.rs:411-421
+        t0 = k.tangent1;
+        t1 = cross(k.tangent1, k.normal);
+    }
+    // contact/mod.rs:223-264
+    void warm_start() {
+        S coeff = (S)cfg.warm_start_coefficient;
+        for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
+            BodyRef r1, r2; resolve(k, r1, r2);
+            V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
+            const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
+            V3<S> t0, t1; tangent_directions(k, t0, t1);
+            for (int p = 0; p < k.point_count; ++p) {
+                ContactConstraintPoint<S>& pt = k.points[p];
+                V3<S> ra = pt.anchor1, rb = pt.anchor2;
+                V2<S> ti = pt.has_tangent ? pt.tangent_part.impulse : V2<S>{0, 0};
+                V3<S> imp = coeff * ((pt.normal_part.impulse * k.normal + ti.x * t0) + ti.y * t1);
+                r1.body->linear_velocity = r1.body->linear_velocity - cmul(imp, inv_mass1);
+                r1.body->angular_velocity = r1.body->angular_velocity - smul(ii1, cross(ra, imp));
+                r2.body->linear_velocity = r2.body->linear_velocity + cmul(imp, inv_mass2);
+                r2.body->angular_velocity = r2.body->angular_velocity + smul(ii2, cross(rb, imp));
+            }
+        });
+    }
+    // contact/mod.rs:267-354
+    void solve_contacts(bool use_bias) {
+        S delta_secs = h_adj;
+        S max_overlap_solve_speed = (S)cfg.max_overlap_solve_speed * (S)cfg.length_unit;
+        for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
+            BodyRef r1, r2; resolve(k, r1, r2);
+            SolverBody<S>& body1 = *r1.body; SolverBody<S>& body2 = *r2.body;
+            V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
+            const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
+            V3<S> delta_translation = body2.delta_position - body1.delta_position;
+            for (int p = 0; p < k.point_count; ++p) {
+                ContactConstraintPoint<S>& pt = k.points[p];
+                V3<S> r1w = qrot(body1.delta_rotation, pt.anchor1);
+                V3<S> r2w = qrot(body2.delta_rotation, pt.anchor2);
+                V3<S> delta_separation = delta_translation + (r2w - r1w);
+                S separation = dot(delta_separation, k.normal) + pt.initial_separation;
+                V3<S> ra = pt.anchor1, rb = pt.anchor2;
+                V3<S> relative_velocity = body2.velocity_at_point(rb) - body1.velocity_at_point(ra);
+                S mag = normal_part_solve_impulse(pt.normal_part, separation, relative_velocity, k.normal, use_bias, max_overlap_solve_speed, delta_secs);
+                V3<S> imp = mag * k.normal;
+                body1.linear_velocity = body1.linear_velocity - cmul(imp, inv_mass1);
+                body1.angular_velocity = body1.angular_velocity - smul(ii1, cross(ra, imp));
+                body2.linear_velocity = body2.linear_velocity + cmul(imp, inv_mass2);
+                body2.angular_velocity = body2.angular_velocity + smul(ii2, cross(rb, imp));
+            }
+            V3<S> t0, t1; tangent_directions(k, t0, t1);
+            for (int p = 0; p < k.point_count; ++p) {
+                ContactConstraintPoint<S>& pt = k.points[p];
+                if (!pt.has_tangent) continue;
+                V3<S> ra = pt.anchor1, rb = pt.anchor2;
+                V3<S> relative_velocity = body2.velocity_at_point(rb) - body1.velocity_at_point(ra);
+                V3<S> imp = tangent_part_solve_impulse(pt.tangent_part, t0, t1, relative_velocity, k.tangent_velocity, k.friction, pt.normal_part.impulse);
+                body1.linear_velocity = body1.linear_velocity - cmul(imp, inv_mass1);
+                body1.angular_velocity = body1.angular_velocity - smul(ii1, cross(ra, imp));
+                body2.linear_velocity = body2.linear_velocity + cmul(imp, inv_mass2);
+                body2.angular_velocity = body2.angular_velocity + smul(ii2, cross(rb, imp));
+            }
+        });
+    }
+    // contact/mod.rs:358-407; driver solver/plugin.rs:630-718
+    void solve_restitution() {
+        S threshold = (S)cfg.restitution_threshold * (S)cfg.length_unit;
+        for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
+            if (k.restitution == S(0)) return;
+            BodyRef r1, r2; resolve(k, r1, r2);
+            SolverBody<S>& body1 = *r1.body; SolverBody<S>& body2 = *r2.body;
+            V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
+            const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
+            uint32_t iterations = k.point_count > 1 ? cfg.restitution_iterations : 1;
+            for (uint32_t it = 0; it < iterations; ++it)
+                for (int p = 0; p < k.point_count; ++p) {
+                    ContactConstraintPoint<S>& pt = k.points[p];
+                    if (pt.normal_speed > -threshold || pt.normal_part.total_impulse == S(0)) continue;
+                    V3<S> ra = pt.anchor1, rb = pt.anchor2;
+                    V3<S> relative_velocity = body2.velocity_at_point(rb) - body1.velocity_at_point(ra);
+                    S normal_speed = dot(relative_velocity, k.normal);
+                    S impulse = -pt.normal_part.effective_mass * (normal_speed + k.restitution * pt.normal_speed);
+                    S new_impulse = smax(pt.normal_part.impulse + impulse, S(0));
+                    impulse = new_impulse - pt.normal_part.impulse;
+                    pt.normal_part.impulse = new_impulse;
+                    pt.normal_part.total_impulse += impulse;
+                    V3<S> imp = impulse * k.normal;
+                    body1.linear_velocity = body1.linear_velocity - cmul(imp, inv_mass1);
+                    body1.angular_velocity = body1.angular_velocity - smul(ii1, cross(ra, imp));
+                    body2.linear_velocity = body2.linear_velocity + cmul(imp, inv_mass2);
+                    body2.angular_velocity = body2.angular_velocity + smul(ii2, cross(rb, imp));
+                }
+        });
+    }
+    // solver/plugin.rs:722-755
+    void store_contact_impulses() {
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            for (ContactConstraint<S>& k : color_constraints[c]) {
+                ContactManifold<S>& m = manifolds[k.manifold];
+                for (int p = 0; p < k.point_count; ++p) {
+                    m.points[p].warm_start_normal_impulse = k.points[p].normal_part.impulse;
+                    m.points[p].warm_start_tangent_impulse = k.points[p].has_tangent ? k.points[p].tangent_part.impulse : V2<S>{0, 0};
+                    m.points[p].normal_impulse = k.points[p].normal_part.total_impulse;
+                }
+            }
+    }
+
+    // =============================================================================================
+    //                                      XPBD (DistanceJoint)
+    // =============================================================================================
+    // xpbd/plugin.rs:125-142 + xpbd/joints/distance.rs:36-59
+    void prepare_joints() {
+        for (DistanceJoint<S>& j : joints) {
+            j.total_lagrange = vzero<S>();
+            const Body<S>& b1 = bodies[j.body1];
+            const Body<S>& b2 = bodies[j.body2];
+            if ((b1.body_flags & AVN_BODY_DISABLED) || (b2.body_flags & AVN_BODY_DISABLED)) continue;  // Without<RigidBodyDisabled>
+            j.world_r1 = qrot(b1.rotation, j.local_anchor1 - b1.center_of_mass);
+            j.world_r2 = qrot(b2.rotation, j.local_anchor2 - b2.center_of_mass);
+            j.center_difference = (b2.position - b1.position) + (qrot(b2.rotation, b2.center_of_mass) - qrot(b1.rotation, b1.center_of_mass));
+        }
+    }
+    // XPBD queries use Without<RigidBodyDisabled> only (a sleeping body keeps no SolverBody anyway).
+    SolverBody<S> xpbd_dummy[2];  // declared outside the joint loop in the reference (xpbd/plugin.rs:155-156)
+    // xpbd/plugin.rs:61-76 (snapshot) + :145-189 + xpbd/joints/distance.rs:61-117
+    void xpbd_solve() {
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            b.pre_solve_delta_position = b.sb.delta_position;
+            b.pre_solve_delta_rotation = b.sb.delta_rotation;
+        }
+        S dt = h_adj;
+        static const SolverBodyInertia<S> DUMMY;
+        xpbd_dummy[0] = SolverBody<S>(); xpbd_dummy[1] = SolverBody<S>();
+        for (DistanceJoint<S>& j : joints) {
+            Body<S>& B1 = bodies[j.body1]; Body<S>& B2 = bodies[j.body2];
+            SolverBody<S>* body1 = &xpbd_dummy[0]; SolverBody<S>* body2 = &xpbd_dummy[1];
+            const SolverBodyInertia<S>* inertia1 = &DUMMY; const SolverBodyInertia<S>* inertia2 = &DUMMY;
+            if (B1.has_solver_body) { body1 = &B1.sb; inertia1 = &B1.si; }
+            if (B2.has_solver_body) { body2 = &B2.sb; inertia2 = &B2.si; }
+            int rel = (int)inertia1->dominance - (int)inertia2->dominance;
+            if (rel > 0) inertia1 = &DUMMY; else if (rel < 0) inertia2 = &DUMMY;
+            V3<S> inv_mass1 = inertia1->effective_inv_mass(), inv_mass2 = inertia2->effective_inv_mass();
+            const Sym3<S>& ii1 = inertia1->inv_inertia; const Sym3<S>& ii2 = inertia2->inv_inertia;
+            V3<S> world_r1 = qrot(body1->delta_rotation, j.world_r1);
+            V3<S> world_r2 = qrot(body2->delta_rotation, j.world_r2);
+            V3<S> separation = ((body2->delta_position - body1->delta_position) + (world_r2 - world_r1)) + j.center_difference;
+            // DistanceLimit::compute_correction, dynamics/joints/mod.rs:321-340
+            V3<S> dir = vzero<S>(); S distance = 0;
+            S dsq = length_squared(separation);
+            if (!(dsq <= std::numeric_limits<S>::epsilon())) {
+                S d = std::sqrt(dsq);
+                if (d < j.limit_min) { dir = separation / d; distance = j.limit_min - d; }
+                else if (d > j.limit_max) { dir = (-separation) / d; distance = d - j.limit_max; }
+            }
+            if (distance <= std::numeric_limits<S>::epsilon()) continue;
+            // compute_generalized_inverse_mass, positional_constraint.rs:68-82
+            V3<S> rc1 = cross(world_r1, dir); S w1 = max_element(inv_mass1) + dot(rc1, smul(ii1, rc1));
+            V3<S> rc2 = cross(world_r2, dir); S w2 = max_element(inv_mass2) + dot(rc2, smul(ii2, rc2));
+            S delta_lagrange = compute_lagrange_update<S>(S(0), distance, w1, w2, j.compliance, dt);
+            V3<S> impulse = delta_lagrange * dir;
+            j.total_lagrange = j.total_lagrange + impulse;
+            // apply_positional_impulse, positional_constraint.rs:10-51
+            body1->delta_position = body1->delta_position + cmul(impulse, inv_mass1);
+            body1->delta_rotation = qmul(from_scaled_axis(smul(ii1, cross(world_r1, impulse))), body1->delta_rotation);
+            body2->delta_position = body2->delta_position - cmul(impulse, inv_mass2);
+            body2->delta_rotation = qmul(from_scaled_axis(smul(ii2, cross(world_r2, -impulse))), body2->delta_rotation);
+        }
+    }
+    // xpbd/plugin.rs:192-240 (RigidBodyActiveFilter; runs over ALL active solver bodies)
+    void xpbd_velocity_projection() {
+        S delta_secs = h_adj;
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            V3<S> new_lin_vel = (b.sb.delta_position - b.pre_solve_delta_position) / delta_secs;
+            b.sb.linear_velocity = b.sb.linear_velocity + new_lin_vel;
+        }
+        for (Body<S>& b : bodies) {
+            if (!b.has_solver_body) continue;
+            Q4<S> delta_rot = qmul(b.sb.delta_rotation, qinverse(b.pre_solve_delta_rotation));
+            V3<S> new_ang_vel = (S(2) * V3<S>{delta_rot.x, delta_rot.y, delta_rot.z}) / delta_secs;
+            if (delta_rot.w < S(0)) new_ang_vel = -new_ang_vel;
+            b.sb.angular_velocity = b.sb.angular_velocity + new_ang_vel;
+        }
+    }
+    // solver/plugin.rs:759-806 (dummy bodies shared across the loop, no dominance swap here)
+    void joint_damping() {
+        S delta_secs = h_adj;
+        static const SolverBodyInertia<S> DUMMY;
+        SolverBody<S> d1, d2;
+        for (DistanceJoint<S>& j : joints) {
+            if (!j.has_damping) continue;
+            Body<S>& B1 = bodies[j.body1]; Body<S>& B2 = bodies[j.body2];
+            SolverBody<S>* body1 = &d1; SolverBody<S>* body2 = &d2;
+            const SolverBodyInertia<S>* inertia1 = &DUMMY; const SolverBodyInertia<S>* inertia2 = &DUMMY;
+            if (B1.has_solver_body) { body1 = &B1.sb; inertia1 = &B1.si; }
+            if (B2.has_solver_body) { body2 = &B2.sb; inertia2 = &B2.si; }
+            V3<S> delta_omega = (body2->angular_velocity - body1->angular_velocity) * smin(j.damping_angular * delta_secs, S(1));
+            if (!body1->is_kinematic()) body1->angular_velocity = body1->angular_velocity + delta_omega;
+            if (!body2->is_kinematic()) body2->angular_velocity = body2->angular_velocity - delta_omega;
+            V3<S> delta_v = (body2->linear_velocity - body1->linear_velocity) * smin(j.damping_linear * delta_secs, S(1));
+            V3<S> w1 = inertia1->effective_inv_mass(), w2 = inertia2->effective_inv_mass();
+            V3<S> p = cmul(delta_v, recip_or_zero(w1 + w2));
+            body1->linear_velocity = body1->linear_velocity + cmul(p, w1);
+            body2->linear_velocity = body2->linear_velocity - cmul(p, w2);
+        }
+    }
+    // xpbd/plugin.rs:242-260
+    void writeback_joint_forces() {
+        S delta_secs = dt_adj;  // Time is Time<Physics> again after the substep loop (solver/schedule.rs:209-212)
+        S rhs = recip_or_zero(delta_secs * delta_secs) * (S)cfg.substeps;
+        for (DistanceJoint<S>& j : joints) j.force = j.total_lagrange * rhs;
+    }
+
+    // =============================================================================================
+    //                                      BROAD PHASE
+    // =============================================================================================
+    avn_status colliders_upload(const avn_colliders* c) override {
+        if (!c || (c->count && (!c->entity_index || !c->body || !c->shape || !c->half_extents))) { error = "colliders_upload: null array"; return AVN_ERR_BAD_ARG; }
+        std::vector<Collider<S>> next(c->count);
+        std::unordered_map<uint32_t, uint32_t> next_slot;
+        for (uint32_t i = 0; i < c->count; ++i) {
+            Collider<S>& o = next[i];
+            o.entity = c->entity_index[i];
+            o.body = c->body[i];
+            if (o.body < 0 || (size_t)o.body >= bodies.size()) { error = "colliders_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+            o.shape = c->shape[i];
+            o.half_extents = rd3(c->half_extents, i);
+            o.memberships = rd<uint32_t>(c->memberships, i, 1u);
+            o.filters = rd<uint32_t>(c->filters, i, 0xFFFFFFFFu);
+            o.cflags = rd<uint8_t>(c->collider_flags, i, 0);
+            o.collision_margin = rd<S>(c->collision_margin, i, 0);
+            o.speculative_margin = rd<S>(c->speculative_margin, i, -1);
+            auto it = collider_slot.find(o.entity);
+            if (it != collider_slot.end()) o.aabb = colliders[it->second].aabb; else o.aabb = {{0, 0, 0}, {0, 0, 0}};
+            if (!next_slot.emplace(o.entity, i).second) { error = "colliders_upload: duplicate entity_index"; return AVN_ERR_BAD_ARG; }
+        }
+        // retain_mut (broad_phase.rs:230-279): drop intervals of colliders that no longer exist, in place
+        std::vector<AabbInterval> kept;
+        kept.reserve(intervals.size());
+        std::unordered_set<uint32_t> known;
+        for (const AabbInterval& iv : intervals) {
+            uint32_t ent = colliders[iv.collider].entity;
+            auto it = next_slot.find(ent);
+            if (it == next_slot.end()) continue;
+            kept.push_back({it->second, iv.flags});
+            known.insert(ent);
+        }
+        // add_new_aabb_intervals (broad_phase.rs:296-315): append the new ones at the END, in upload order
+        for (uint32_t i = 0; i < c->count; ++i)
+            if (!known.count(next[i].entity)) kept.push_back({i, 0});
+        colliders.swap(next);
+        collider_slot.swap(next_slot);
+        intervals.swap(kept);
+        have_colliders = true;
+        return AVN_OK;
+    }
+    avn_status existing_pairs_upload(const uint64_t* keys, size_t n) override {
+        if (n && !keys) return AVN_ERR_BAD_ARG;
+        pair_set.clear();
+        pair_set.insert(keys, keys + n);
+        return AVN_OK;
+    }
+    avn_status pairs_get(const avn_pair** out, size_t* n) override {
+        if (!out || !n) return AVN_ERR_BAD_ARG;
+        *out = pairs.data(); *n = pairs.size();
+        return AVN_OK;
+    }
+    avn_status aabbs_download(void* mn, void* mx, uint32_t* ents, size_t* n_iv) override {
+        for (size_t i = 0; i < colliders.size(); ++i) { wr3(mn, i, colliders[i].aabb.min); wr3(mx, i, colliders[i].aabb.max); }
+        if (ents) for (size_t i = 0; i < intervals.size(); ++i) ents[i] = colliders[intervals[i].collider].entity;
+        if (n_iv) *n_iv = intervals.size();
+        return AVN_OK;
+    }
+    // parry3d 0.25 Cuboid::aabb / Ball::aabb (third party, un-vendored; restated): centre +- |R| * half_extents
+    // with R from nalgebra UnitQuaternion::to_rotation_matrix and a column-major gemv.
+    static ColliderAabb<S> shape_aabb(const Collider<S>& c, V3<S> pos, Q4<S> q) {
+        V3<S> he;
+        if (c.shape == AVN_SHAPE_BALL) he = {c.half_extents.x, c.half_extents.x, c.half_extents.x};
+        else {
+            S i = q.x, j = q.y, k = q.z, w = q.w;
+            S ww = w * w, ii = i * i, jj = j * j, kk = k * k;
+            S ij = i * j * S(2), wk = w * k * S(2), wj = w * j * S(2), ik = i * k * S(2), jk = j * k * S(2), wi = w * i * S(2);
+            S m00 = std::fabs(ww + ii - jj - kk), m01 = std::fabs(ij - wk), m02 = std::fabs(wj + ik);
+            S m10 = std::fabs(wk + ij), m11 = std::fabs(ww - ii + jj - kk), m12 = std::fabs(jk - wi);
+            S m20 = std::fabs(ik - wj), m21 = std::fabs(wi + jk), m22 = std::fabs(ww - ii - jj + kk);
+            V3<S> h = c.half_extents;
+            he = {(m00 * h.x + m01 * h.y) + m02 * h.z, (m10 * h.x + m11 * h.y) + m12 * h.z, (m20 * h.x + m21 * h.y) + m22 * h.z};
+        }
+        return {pos - he, pos + he};
+    }
+    // collider/backend.rs:498-624 (collider on the rigid-body entity: Position/Rotation/velocities are the body's)
+    void update_aabb() {
+        S delta_secs = dt_adj;
+        S default_speculative_margin = (S)cfg.length_unit * (cfg.default_speculative_margin >= (double)std::numeric_limits<S>::max() ? std::numeric_limits<S>::max() : (S)cfg.default_speculative_margin);
+        S contact_tolerance = (S)cfg.length_unit * (S)cfg.contact_tolerance;
+        for (Collider<S>& c : colliders) {
+            const Body<S>& b = bodies[c.body];
+            S speculative_margin = (c.cflags & AVN_COLLIDER_SWEPT_CCD) ? std::numeric_limits<S>::max()
+                                   : (c.speculative_margin >= S(0) ? c.speculative_margin : default_speculative_margin);
+            S g = contact_tolerance + c.collision_margin;
+            if (speculative_margin <= S(0)) {
+                ColliderAabb<S> a = shape_aabb(c, b.position, b.rotation);
+                c.aabb = {a.min - V3<S>{g, g, g}, a.max + V3<S>{g, g, g}};
+                continue;
+            }
+            Q4<S> end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), b.rotation));
+            V3<S> end_pos = b.position + clamp_length_max(b.linear_velocity * delta_secs, smax(speculative_margin, contact_tolerance));
+            ColliderAabb<S> a0 = shape_aabb(c, b.position, b.rotation);
+            ColliderAabb<S> a1 = shape_aabb(c, end_pos, end_rot);
+            ColliderAabb<S> m{vmin(a0.min, a1.min), vmax(a0.max, a1.max)};
+            c.aabb = {m.min - V3<S>{g, g, g}, m.max + V3<S>{g, g, g}};
+        }
+    }
+    // broad_phase.rs:214-280 (flags refresh), :373-474 sweep_and_prune, :479-487 insertion_sort
+    void collect_collision_pairs() {
+        // update_aabb_intervals: drop non-finite AABBs, refresh flags
+        std::vector<AabbInterval> kept;
+        kept.reserve(intervals.size());
+        for (AabbInterval iv : intervals) {
+            const Collider<S>& c = colliders[iv.collider];
+            if (!is_finite(c.aabb.min) || !is_finite(c.aabb.max)) continue;
+            const Body<S>& b = bodies[c.body];
+            bool is_static = b.rb_type == AVN_RB_STATIC;
+            bool is_sleeping = b.body_flags & AVN_BODY_SLEEPING;
+            bool is_disabled = b.body_flags & AVN_BODY_DISABLED;
+            uint8_t f = 0;
+            if (is_static || is_sleeping) f |= AVN_AABB_IS_INACTIVE;
+            if (c.cflags & AVN_COLLIDER_EVENTS) f |= AVN_AABB_CONTACT_EVENTS;
+            if (!(c.cflags & AVN_COLLIDER_SENSOR) && !is_disabled) f |= AVN_AABB_GENERATE_CONSTRAINTS;
+            if (c.cflags & AVN_COLLIDER_FILTER_PAIRS) f |= AVN_AABB_CUSTOM_FILTER;
+            if (c.cflags & AVN_COLLIDER_MODIFY_CONTACTS) f |= AVN_AABB_MODIFY_CONTACTS;
+            kept.push_back({iv.collider, f});
+        }
+        intervals.swap(kept);
+        // insertion_sort(|a, b| a.min.x > b.min.x)
+        for (size_t i = 1; i < intervals.size(); ++i) {
+            size_t j = i;
+            while (j > 0 && colliders[intervals[j - 1].collider].aabb.min.x > colliders[intervals[j].collider].aabb.min.x) {
+                std::swap(intervals[j - 1], intervals[j]);
+                --j;
+            }
+        }
+        pairs.clear();
+        for (size_t i = 0; i < intervals.size(); ++i) {
+            const Collider<S>& c1 = colliders[intervals[i].collider];
+            uint8_t flags1 = intervals[i].flags;
+            for (size_t j = i + 1; j < intervals.size(); ++j) {
+                const Collider<S>& c2 = colliders[intervals[j].collider];
+                uint8_t flags2 = intervals[j].flags;
+                if (c2.aabb.min.x > c1.aabb.max.x) break;
+                if (c1.aabb.min.y > c2.aabb.max.y || c1.aabb.max.y < c2.aabb.min.y) continue;
+                if (c1.aabb.min.z > c2.aabb.max.z || c1.aabb.max.z < c2.aabb.min.z) continue;
+                bool interacts = (c1.memberships & c2.filters) != 0 && (c2.memberships & c1.filters) != 0;  // layers.rs:423-426
+                if ((flags1 & flags2 & AVN_AABB_IS_INACTIVE) || !interacts || c1.body == c2.body) continue;
+                uint64_t key = pair_key(c1.entity, c2.entity);
+                if (pair_set.count(key)) continue;
+                if (collision_disabled_bodies.count(pair_key((uint32_t)c1.body, (uint32_t)c2.body))) continue;
+                uint8_t u = flags1 | flags2;
+                avn_pair p;
+                p.collider1 = c1.entity; p.collider2 = c2.entity; p.body1 = c1.body; p.body2 = c2.body;
+                p.flags = 0; p.reserved = 0;
+                if (u & AVN_AABB_CONTACT_EVENTS) p.flags |= AVN_PAIR_CONTACT_EVENTS;
+                if (u & AVN_AABB_MODIFY_CONTACTS) p.flags |= AVN_PAIR_MODIFY_CONTACTS;
+                if (u & AVN_AABB_GENERATE_CONSTRAINTS) p.flags |= AVN_PAIR_GENERATE_CONSTRAINTS;
+                if (u & AVN_AABB_CUSTOM_FILTER) p.flags |= AVN_PAIR_NEEDS_CUSTOM_FILTER;
+                pairs.push_back(p);
+                // add_edge_and_key_with inserts the key (contact_graph.rs:521-566): a later duplicate is skipped
+                pair_set.insert(key);
+            }
+        }
+        last_timers.pair_count = (uint32_t)pairs.size();
+    }
+
+    // =============================================================================================
+    //                                      SCHEDULES
+    // =============================================================================================
+    void substep() {  // SubstepSchedule order, solver/schedule.rs:59-69 + xpbd/plugin.rs:30-40
+        integrate_velocities();
+        warm_start();
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(true);
+        integrate_positions();
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(false);
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve_iter(it);
+        xpbd_velocity_projection();
+        joint_damping();
+    }
+    // extension: extra joint iterations must not re-take the pre-solve snapshot
+    void xpbd_solve_iter(uint32_t it) {
+        if (it == 0) { xpbd_solve(); return; }
+        std::vector<V3<S>> sp; std::vector<Q4<S>> sq;
+        for (Body<S>& b : bodies) { sp.push_back(b.pre_solve_delta_position); sq.push_back(b.pre_solve_delta_rotation); }
+        xpbd_solve();
+        for (size_t i = 0; i < bodies.size(); ++i) { bodies[i].pre_solve_delta_position = sp[i]; bodies[i].pre_solve_delta_rotation = sq[i]; }
+    }
+    void solver() {  // SolverSystems, solver/schedule.rs:32-46
+        prepare_solver_bodies();
+        prepare_joints();
+        prepare_contact_constraints();
+        pre_process_velocity_increments();
+        for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+        clear_velocity_increments();
+        solve_restitution();
+        writeback_solver_bodies();
+        writeback_joint_forces();
+        store_contact_impulses();
+    }
+    avn_status run_system(avn_system sys) override {
+        switch (sys) {
+            case AVN_SYS_UPDATE_AABB: update_aabb(); break;
+            case AVN_SYS_COLLECT_COLLISION_PAIRS: collect_collision_pairs(); break;
+            case AVN_SYS_PREPARE_SOLVER_BODIES: prepare_solver_bodies(); break;
+            case AVN_SYS_PREPARE_JOINTS: prepare_joints(); break;
+            case AVN_SYS_PREPARE_CONTACT_CONSTRAINTS: prepare_contact_constraints(); break;
+            case AVN_SYS_PRE_PROCESS_VELOCITY_INCREMENTS: pre_process_velocity_increments(); break;
+            case AVN_SYS_INTEGRATE_VELOCITIES: integrate_velocities(); break;
+            case AVN_SYS_WARM_START: warm_start(); break;
+            case AVN_SYS_SOLVE_CONTACTS_BIAS: solve_contacts(true); break;
+            case AVN_SYS_INTEGRATE_POSITIONS: integrate_positions(); break;
+            case AVN_SYS_SOLVE_CONTACTS_RELAX: solve_contacts(false); break;
+            case AVN_SYS_XPBD_SOLVE: xpbd_solve(); break;
+            case AVN_SYS_XPBD_VELOCITY_PROJECTION: xpbd_velocity_projection(); break;
+            case AVN_SYS_JOINT_DAMPING: joint_damping(); break;
+            case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: clear_velocity_increments(); break;
+            case AVN_SYS_SOLVE_RESTITUTION: solve_restitution(); break;
+            case AVN_SYS_WRITEBACK_SOLVER_BODIES: writeback_solver_bodies(); writeback_joint_forces(); break;
+            case AVN_SYS_STORE_CONTACT_IMPULSES: store_contact_impulses(); break;
+            case AVN_SYS_SUBSTEP: substep(); break;
+            case AVN_SYS_SOLVER: solver(); break;
+            default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
+        }
+        return AVN_OK;
+    }
+    avn_status step() override {
+        if (have_colliders) { update_aabb(); collect_collision_pairs(); }
+        solver();
+        return AVN_OK;
+    }
+    avn_status timers(avn_timers* t) override { if (!t) return AVN_ERR_BAD_ARG; *t = last_timers; return AVN_OK; }
+};
+
+// ---- ConstraintGraph (solver/constraint_graph.rs:129-296) ------------------------------------------
+struct ConstraintGraph {
+    struct Handle { uint64_t handle; uint32_t body1, body2; };
+    struct Color { std::vector<bool> body_set; std::vector<Handle> manifold_handles; };
+    Color colors[AVN_GRAPH_COLOR_COUNT];
+    struct Loc { uint8_t color; uint32_t local_index; };
+    std::unordered_map<uint64_t, Loc> where;  // ContactEdge::constraint_handles
+    static bool get(const std::vector<bool>& s, uint32_t i) { return i < s.size() && s[i]; }
+    static void set_and_grow(std::vector<bool>& s, uint32_t i) { if (i >= s.size()) s.resize((size_t)i + 1, false); s[i] = true; }
+    static void unset(std::vector<bool>& s, uint32_t i) { if (i < s.size()) s[i] = false; }
+    int push_manifold(uint64_t handle, uint32_t body1, uint32_t body2, bool is_static1, bool is_static2) {
+        if (where.count(handle)) return -1;
+        int color_index = AVN_COLOR_OVERFLOW_INDEX;
+        if (!is_static1 && !is_static2) {
+            for (int i = 0; i < AVN_DYNAMIC_COLOR_COUNT; ++i) {
+                Color& c = colors[i];
+                if (get(c.body_set, body1) || get(c.body_set, body2)) continue;
+                set_and_grow(c.body_set, body1); set_and_grow(c.body_set, body2);
+                color_index = i; break;
+            }
+        } else if (!is_static1) {
+            for (int i = AVN_COLOR_OVERFLOW_INDEX - 1; i >= 1; --i) {
+                Color& c = colors[i];
+                if (get(c.body_set, body1)) continue;
+                set_and_grow(c.body_set, body1);
+                color_index = i; break;
+            }
+        } else if (!is_static2) {
+            for (int i = AVN_COLOR_OVERFLOW_INDEX - 1; i >= 1; --i) {
+                Color& c = colors[i];
+                if (get(c.body_set, body2)) continue;
+                set_and_grow(c.body_set, body2);
+                color_index = i; break;
+            }
+        }
+        Color& c = colors[color_index];
+        where[handle] = {(uint8_t)color_index, (uint32_t)c.manifold_handles.size()};
+        c.manifold_handles.push_back({handle, body1, body2});
+        return color_index;
+    }
+    bool pop_manifold(uint64_t handle) {
+        auto it = where.find(handle);
+        if (it == where.end()) return false;
+        Loc loc = it->second;
+        where.erase(it);
+        Color& c = colors[loc.color];
+        Handle h = c.manifold_handles[loc.local_index];
+        if (loc.color != AVN_COLOR_OVERFLOW_INDEX) { unset(c.body_set, h.body1); unset(c.body_set, h.body2); }
+        uint32_t moved_index = (uint32_t)c.manifold_handles.size() - 1;
+        c.manifold_handles[loc.local_index] = c.manifold_handles[moved_index];  // swap_remove
+        c.manifold_handles.pop_back();
+        if (moved_index != loc.local_index) where[c.manifold_handles[loc.local_index].handle].local_index = loc.local_index;
+        return true;
+    }
+};
+
+}  // namespace avo

@@ -1,0 +1,77 @@
+// ORACLE — TEST INFRASTRUCTURE ONLY (see avo_world.hpp).  Exports the SAME C ABI as the product
+// (include/avian_mi355x.h) under the `avo_` prefix so tests drive both with identical calls.
+#define AVN_PREFIX_ORACLE 1
+#include "avo_world.hpp"
+
+#include <new>
+
+struct avn_world { avo::WorldBase* impl; };
+struct avn_constraint_graph { avo::ConstraintGraph g; };
+static thread_local std::string g_create_error;
+
+extern "C" {
+
+avn_status avo_world_create(const avn_config* cfg, avn_world** out) {
+    if (!cfg || !out) { g_create_error = "world_create: null argument"; return AVN_ERR_BAD_ARG; }
+    if (cfg->struct_size != sizeof(avn_config)) { g_create_error = "world_create: struct_size mismatch"; return AVN_ERR_BAD_ARG; }
+    avo::WorldBase* w = nullptr;
+    if (cfg->scalar_bits == 32) w = new (std::nothrow) avo::World<float>();
+    else if (cfg->scalar_bits == 64) w = new (std::nothrow) avo::World<double>();
+    else { g_create_error = "world_create: scalar_bits must be 32 or 64"; return AVN_ERR_BAD_ARG; }
+    if (!w) return AVN_ERR_OOM;
+    avn_status st = w->config_set(cfg);
+    if (st != AVN_OK) { g_create_error = w->error; delete w; return st; }
+    *out = new avn_world{w};
+    return AVN_OK;
+}
+void avo_world_destroy(avn_world* w) { if (w) { delete w->impl; delete w; } }
+const char* avo_last_error(const avn_world* w) { return w ? w->impl->error.c_str() : g_create_error.c_str(); }
+#define FWD(call) do { if (!w) return AVN_ERR_BAD_ARG; return w->impl->call; } while (0)
+avn_status avo_config_set(avn_world* w, const avn_config* c) { FWD(config_set(c)); }
+avn_status avo_bodies_upload(avn_world* w, const avn_bodies* b) { FWD(bodies_upload(b)); }
+avn_status avo_bodies_download(avn_world* w, const avn_bodies_out* o) { FWD(bodies_download(o)); }
+avn_status avo_solver_bodies_download(avn_world* w, const avn_solver_bodies_out* o) { FWD(solver_bodies_download(o)); }
+avn_status avo_manifolds_upload(avn_world* w, const avn_manifolds* m) { FWD(manifolds_upload(m)); }
+avn_status avo_impulses_download(avn_world* w, const avn_impulses_out* o) { FWD(impulses_download(o)); }
+avn_status avo_constraints_download(avn_world* w, const avn_constraints_out* o) { FWD(constraints_download(o)); }
+avn_status avo_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { FWD(distance_joints_upload(j)); }
+avn_status avo_joints_download(avn_world* w, const avn_joints_out* o) { FWD(joints_download(o)); }
+avn_status avo_colliders_upload(avn_world* w, const avn_colliders* c) { FWD(colliders_upload(c)); }
+avn_status avo_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { FWD(existing_pairs_upload(k, n)); }
+avn_status avo_pairs_get(avn_world* w, const avn_pair** o, size_t* n) { FWD(pairs_get(o, n)); }
+avn_status avo_aabbs_download(avn_world* w, void* mn, void* mx, uint32_t* e, size_t* n) { FWD(aabbs_download(mn, mx, e, n)); }
+avn_status avo_run_system(avn_world* w, avn_system s) { FWD(run_system(s)); }
+avn_status avo_step(avn_world* w) { FWD(step()); }
+avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
+avn_status avo_timers(avn_world* w, avn_timers* t) { FWD(timers(t)); }
+uint64_t avo_pair_key(uint32_t a, uint32_t b) { return avo::pair_key(a, b); }
+
+avn_status avo_constraint_graph_create(uint32_t, avn_constraint_graph** out) {
+    if (!out) return AVN_ERR_BAD_ARG;
+    *out = new (std::nothrow) avn_constraint_graph();
+    return *out ? AVN_OK : AVN_ERR_OOM;
+}
+void avo_constraint_graph_destroy(avn_constraint_graph* g) { delete g; }
+int32_t avo_constraint_graph_push(avn_constraint_graph* g, uint64_t h, uint32_t b1, uint32_t b2, int s1, int s2) {
+    return g ? g->g.push_manifold(h, b1, b2, s1 != 0, s2 != 0) : -1;
+}
+avn_status avo_constraint_graph_pop(avn_constraint_graph* g, uint64_t h) {
+    if (!g) return AVN_ERR_BAD_ARG;
+    return g->g.pop_manifold(h) ? AVN_OK : AVN_ERR_STATE;
+}
+avn_status avo_constraint_graph_lists(const avn_constraint_graph* g, uint32_t* offsets, uint64_t* handles, size_t cap, size_t* count) {
+    if (!g || !offsets || !count) return AVN_ERR_BAD_ARG;
+    size_t n = 0;
+    for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        offsets[c] = (uint32_t)n;
+        for (const auto& h : g->g.colors[c].manifold_handles) { if (handles && n < cap) handles[n] = h.handle; ++n; }
+    }
+    offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+    *count = n;
+    return (handles && n > cap) ? AVN_ERR_CAPACITY : AVN_OK;
+}
+// test hook: switch the oracle's sin/cos to the host libm (to measure the deterministic kernel's deviation)
+void avo_use_libm_trig(int on) { avo::use_libm_trig() = on != 0; }
+void avo_sin_cos_f32(float a, float* s, float* c) { avo::sin_cos_det(a, *s, *c); }
+void avo_sin_cos_f64(double a, double* s, double* c) { avo::sin_cos_det(a, *s, *c); }
+}
