@@ -1,8 +1,9 @@
 """ctypes binding of the C ABI in ``include/avian_mi355x.h``.
 
-The same header is implemented by the HIP product (prefix ``avn_``) and by the CPU oracle
-(prefix ``avo_``, test infrastructure); :class:`Library` is parameterised by path + prefix so the
-tests drive both through identical calls.  Nothing in this module knows where the oracle lives.
+The header can be implemented by more than one library (the HIP product uses the prefix ``avn_``; the test
+suite loads a second, CPU implementation under another prefix); :class:`Library` is parameterised by
+path + prefix so that tests can drive both through identical calls.  Nothing in this package knows where
+any other implementation lives.
 """
 from __future__ import annotations
 
@@ -129,7 +130,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
 ]
 
@@ -152,7 +153,7 @@ class Library:
         f("last_error").restype = C.c_char_p
         for name in ("config_set", "bodies_upload", "bodies_download", "solver_bodies_download", "manifolds_upload",
                      "impulses_download", "constraints_download", "distance_joints_upload", "joints_download",
-                     "colliders_upload", "timers"):
+                     "colliders_upload", "timers_get"):
             f(name).argtypes = [vp, vp]
         f("existing_pairs_upload").argtypes = [vp, vp, C.c_size_t]
         f("pairs_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -398,7 +399,7 @@ class World:
 
     def timers(self) -> avn_timers:
         t = avn_timers()
-        self._check(self.lib.fn("timers")(self.handle, C.byref(t)))
+        self._check(self.lib.fn("timers_get")(self.handle, C.byref(t)))
         return t
 
 

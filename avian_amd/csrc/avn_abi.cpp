@@ -1,0 +1,84 @@
+// avn_abi.cpp — the extern "C" boundary (include/avian_mi355x.h) over the C++ host world.
+// No exception or HIP error crosses it: every entry point returns avn_status.
+#include <new>
+#include <string>
+
+#include "avn_world.hpp"
+
+struct avn_world { avn::WorldBase* impl; };
+struct avn_constraint_graph { avn::ConstraintGraphHost g; };
+static thread_local std::string g_create_error;
+
+#define GUARD(expr)                                                     \
+    do {                                                                \
+        if (!w || !w->impl) return AVN_ERR_BAD_ARG;                     \
+        try { return w->impl->expr; }                                   \
+        catch (const std::bad_alloc&) { w->impl->error = "out of host memory"; return AVN_ERR_OOM; } \
+        catch (...) { w->impl->error = "unexpected C++ exception"; return AVN_ERR_STATE; }           \
+    } while (0)
+
+extern "C" {
+
+AVN_API avn_status avn_world_create(const avn_config* cfg, avn_world** out) {
+    if (!cfg || !out) { g_create_error = "world_create: null argument"; return AVN_ERR_BAD_ARG; }
+    if (cfg->struct_size != sizeof(avn_config)) { g_create_error = "world_create: struct_size mismatch"; return AVN_ERR_BAD_ARG; }
+    *out = nullptr;
+    avn_status st = AVN_OK;
+    avn::WorldBase* w = nullptr;
+    try {
+        if (cfg->scalar_bits == 32) w = avn::make_world_f32(cfg, &st, &g_create_error);
+        else if (cfg->scalar_bits == 64) w = avn::make_world_f64(cfg, &st, &g_create_error);
+        else { g_create_error = "world_create: scalar_bits must be 32 or 64"; return AVN_ERR_BAD_ARG; }
+    } catch (...) { g_create_error = "world_create: unexpected C++ exception"; return AVN_ERR_OOM; }
+    if (!w) return st;
+    *out = new (std::nothrow) avn_world{w};
+    if (!*out) { delete w; return AVN_ERR_OOM; }
+    return AVN_OK;
+}
+AVN_API void avn_world_destroy(avn_world* w) { if (w) { delete w->impl; delete w; } }
+AVN_API const char* avn_last_error(const avn_world* w) { return (w && w->impl) ? w->impl->error.c_str() : g_create_error.c_str(); }
+AVN_API avn_status avn_config_set(avn_world* w, const avn_config* c) { GUARD(config_set(c)); }
+AVN_API avn_status avn_bodies_upload(avn_world* w, const avn_bodies* b) { GUARD(bodies_upload(b)); }
+AVN_API avn_status avn_bodies_download(avn_world* w, const avn_bodies_out* o) { GUARD(bodies_download(o)); }
+AVN_API avn_status avn_solver_bodies_download(avn_world* w, const avn_solver_bodies_out* o) { GUARD(solver_bodies_download(o)); }
+AVN_API avn_status avn_manifolds_upload(avn_world* w, const avn_manifolds* m) { GUARD(manifolds_upload(m)); }
+AVN_API avn_status avn_impulses_download(avn_world* w, const avn_impulses_out* o) { GUARD(impulses_download(o)); }
+AVN_API avn_status avn_constraints_download(avn_world* w, const avn_constraints_out* o) { GUARD(constraints_download(o)); }
+AVN_API avn_status avn_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { GUARD(distance_joints_upload(j)); }
+AVN_API avn_status avn_joints_download(avn_world* w, const avn_joints_out* o) { GUARD(joints_download(o)); }
+AVN_API avn_status avn_colliders_upload(avn_world* w, const avn_colliders* c) { GUARD(colliders_upload(c)); }
+AVN_API avn_status avn_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { GUARD(existing_pairs_upload(k, n)); }
+AVN_API avn_status avn_pairs_get(avn_world* w, const avn_pair** o, size_t* n) { GUARD(pairs_get(o, n)); }
+AVN_API avn_status avn_aabbs_download(avn_world* w, void* mn, void* mx, uint32_t* e, size_t* n) { GUARD(aabbs_download(mn, mx, e, n)); }
+AVN_API avn_status avn_run_system(avn_world* w, avn_system s) { GUARD(run_system(s)); }
+AVN_API avn_status avn_step(avn_world* w) { GUARD(step()); }
+AVN_API avn_status avn_synchronize(avn_world* w) { GUARD(synchronize()); }
+AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)); }
+AVN_API uint64_t avn_pair_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
+
+AVN_API avn_status avn_constraint_graph_create(uint32_t, avn_constraint_graph** out) {
+    if (!out) return AVN_ERR_BAD_ARG;
+    *out = new (std::nothrow) avn_constraint_graph();
+    return *out ? AVN_OK : AVN_ERR_OOM;
+}
+AVN_API void avn_constraint_graph_destroy(avn_constraint_graph* g) { delete g; }
+AVN_API int32_t avn_constraint_graph_push(avn_constraint_graph* g, uint64_t h, uint32_t b1, uint32_t b2, int s1, int s2) {
+    if (!g) return -1;
+    try { return g->g.push_manifold(h, b1, b2, s1 != 0, s2 != 0); } catch (...) { return -1; }
+}
+AVN_API avn_status avn_constraint_graph_pop(avn_constraint_graph* g, uint64_t h) {
+    if (!g) return AVN_ERR_BAD_ARG;
+    try { return g->g.pop_manifold(h) ? AVN_OK : AVN_ERR_STATE; } catch (...) { return AVN_ERR_STATE; }
+}
+AVN_API avn_status avn_constraint_graph_lists(const avn_constraint_graph* g, uint32_t* offsets, uint64_t* handles, size_t cap, size_t* count) {
+    if (!g || !offsets || !count) return AVN_ERR_BAD_ARG;
+    size_t n = 0;
+    for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        offsets[c] = (uint32_t)n;
+        for (const auto& h : g->g.colors[c].manifold_handles) { if (handles && n < cap) handles[n] = h.handle; ++n; }
+    }
+    offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+    *count = n;
+    return (handles && n > cap) ? AVN_ERR_CAPACITY : AVN_OK;
+}
+}

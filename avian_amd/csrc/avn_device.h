@@ -1,0 +1,120 @@
+// avn_device.h — the batched Structure-of-Arrays world resident in HBM, and the launch interface of
+// the hand-written gfx950 kernels.  Every record is a 16-byte (f32) / 32-byte (f64) Vec4 so that
+//  - streaming kernels (one thread per body / manifold / collider) issue one fully coalesced
+//    dwordx4 load per lane per record (16 B/lane x 64 lanes = 1 KiB per wave instruction), and
+//  - gather kernels (contacts, joints) fetch a body's state in 6 aligned vector loads that are served
+//    by L2 / Infinity Cache (100k bodies x 96 B = 9.6 MB).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/avian_mi355x.h"
+#include "avn_math.h"
+
+namespace avn {
+
+// body meta word
+//   bits 0-1  rb_type (AVN_RB_*)      bits 8-13 locked axes     bits 16-23 body_flags   bits 24-31 dominance (i8)
+AVN_HD uint32_t meta_rb_type(uint32_t m) { return m & 3u; }
+AVN_HD uint32_t meta_locked(uint32_t m) { return (m >> 8) & 0x3Fu; }
+AVN_HD uint32_t meta_flags(uint32_t m) { return (m >> 16) & 0xFFu; }
+AVN_HD int meta_dominance(uint32_t m) { return (int)(int8_t)(m >> 24); }
+AVN_HD bool meta_active(uint32_t m) { return (meta_flags(m) & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED)) == 0; }
+AVN_HD bool meta_has_solver_body(uint32_t m) { return meta_rb_type(m) != AVN_RB_STATIC && meta_active(m); }
+
+// SolverBodyFlags word kept per body: reference bits 0-7, plus
+#define AVN_SBF_NO_SOLVER_BODY 0x80000000u
+
+// constraint meta word (packed in the w lane of c_h1)
+//   bits 0-2 point count   bit 4 inertia1 is DUMMY (body1 dominant)   bit 5 inertia2 is DUMMY
+//   bit 6 non-dynamic softness   bit 7 has tangent part   bit 8 body1 has no SolverBody   bit 9 body2 has none
+#define AVN_CM_DOM1 0x10u
+#define AVN_CM_DOM2 0x20u
+#define AVN_CM_SOFT_ND 0x40u
+#define AVN_CM_TANGENT 0x80u
+#define AVN_CM_NOBODY1 0x100u
+#define AVN_CM_NOBODY2 0x200u
+
+template <class T> struct SoftCoef { T bias, mass_scale, impulse_scale; };
+
+template <class T> struct StepParams {
+    T dt_f64cast, h_f64cast;  // Duration::as_secs_f64() as Scalar
+    T dt_adj, h_adj;          // delta_seconds_adjusted()
+    T gravity[3];
+    T max_overlap_solve_speed;  // SolverConfig::max_overlap_solve_speed * length_unit
+    T warm_start_coefficient;
+    T restitution_threshold;    // * length_unit
+    T contact_tolerance;        // * length_unit
+    T default_speculative_margin;  // * length_unit (Limits::max = unbounded)
+    T substeps_as_scalar;
+    SoftCoef<T> soft_dynamic, soft_non_dynamic;
+    uint32_t restitution_iterations;
+    uint32_t match_contacts;
+};
+
+template <class T> struct DW {
+    using V = Vec4<T>;
+    // ---- rigid-body components (persist across steps) ----
+    uint32_t n_bodies;
+    V* pos;        // (position.xyz, inv_mass)
+    V* rot;        // rotation xyzw
+    V* lvel;       // (LinearVelocity.xyz, gravity_scale)
+    V* avel;       // (AngularVelocity.xyz, linear_damping)
+    V* com;        // (center_of_mass.xyz, angular_damping)
+    V* iloc_a;     // local inverse inertia (m00, m01, m02, m11)
+    V* iloc_b;     // (m12, m22, max_linear_speed, max_angular_speed)
+    V* acc_l;      // (accumulated linear acceleration.xyz, 0)
+    V* acc_a;      // (accumulated angular acceleration.xyz, 0)
+    uint32_t* bmeta;
+    // ---- solver bodies (SolverBody / SolverBodyInertia / VelocityIntegrationData) ----
+    V* sb_lin;     // (linear_velocity.xyz, 0)
+    V* sb_ang;     // (angular_velocity.xyz, 0)
+    V* sb_dp;      // (delta_position.xyz, 0)
+    V* sb_dq;      // delta_rotation xyzw
+    V* si_a;       // (inv_mass, m00, m01, m02)   world-space effective inverse inertia
+    V* si_b;       // (m11, m12, m22, bits(InertiaFlags | dominance << 16))
+    V* vid_l;      // (linear_increment.xyz, linear_damping_rhs)
+    V* vid_a;      // (angular_increment.xyz, angular_damping_rhs)
+    V* pre_dp;     // PreSolveDeltaPosition
+    V* pre_dq;     // PreSolveDeltaRotation
+    uint32_t* sb_flags;
+    // ---- contact manifolds (the ContactGraph side; colour-major) ----
+    uint32_t n_manifolds, m_stride;   // m_stride: element stride between point slots ([p][m] layout)
+    int2* m_bodies;
+    V* m_n;        // (normal.xyz, friction)            == constraint header H0
+    V* m_tv;       // (tangent_velocity.xyz, restitution) == constraint header H2
+    uint32_t* m_meta;   // point_count | manifold_flags << 8
+    V* mp_a1;      // [p][m] (anchor1.xyz, penetration)
+    V* mp_a2;      // [p][m] (anchor2.xyz, normal_speed)
+    V* mp_w;       // [p][m] (warm_start_normal, warm_start_tangent.x, .y, normal_impulse)
+    // ---- contact constraints (rebuilt every step) ----
+    V* c_h1;       // (tangent1.xyz, bits(constraint meta))
+    V* c_pa;       // [p][m] (anchor1.xyz, initial_separation)
+    V* c_pb;       // [p][m] (anchor2.xyz, normal effective_mass)
+    V* c_pc;       // [p][m] (tangent k0, k1, k2, normal_speed)
+    V* c_pd;       // [p][m] (normal impulse, total_impulse, tangent impulse.x, .y)
+    int16_t* c_reldom;  // inspection only
+    uint32_t* color_offsets;  // [25] device copy
+    uint32_t* constraint_count;  // [1]
+    // ---- distance joints ----
+    uint32_t n_joints;
+    int2* j_bodies;
+    V* j_a1;       // (local_anchor1.xyz, limit_min)
+    V* j_a2;       // (local_anchor2.xyz, limit_max)
+    V* j_par;      // (compliance, damping_linear, damping_angular, bits(flags: 1 has damping))
+    V* j_r1;       // (world_r1.xyz, 0)
+    V* j_r2;       // (world_r2.xyz, 0)
+    V* j_cd;       // (center_difference.xyz, 0)
+    V* j_lag;      // (total_lagrange.xyz, 0)
+    V* j_force;    // (force.xyz, 0)
+};
+
+// Block index remap so that each XCD (block b runs on XCD b % 8) walks one contiguous eighth of the
+// work: neighbouring work items share bodies / sweep ranges, and each XCD has a private 4 MiB L2.
+// Placement only changes speed, never results.
+__device__ __forceinline__ uint32_t xcd_block(uint32_t b, uint32_t nb) {
+    uint32_t per = (nb + 7u) >> 3;
+    return (b & 7u) * per + (b >> 3);
+}
+
+}  // namespace avn

@@ -1,0 +1,109 @@
+// avn_kernels.h — launch interface of the gfx950 kernels (implemented in k_*.hip).
+#pragma once
+#include <type_traits>
+
+#include "avn_device.h"
+
+namespace avn {
+
+// broad-phase state resident in HBM
+template <class T> struct BP {
+    using Key = typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type;
+    uint32_t n_colliders, n_intervals;
+    uint4* col_info;       // (entity index, body index, shape | collider_flags << 8, 0) per collider slot
+    Vec4<T>* col_he;       // (half_extents.xyz, collision_margin)
+    T* col_spec;           // SpeculativeMargin (< 0 = absent)
+    uint2* col_layers;     // (memberships, filters)
+    Vec4<T>* aabb_min;     // ColliderAabb per collider slot
+    Vec4<T>* aabb_max;
+    uint32_t* iv_collider; // AabbIntervals: collider slot per interval, persistent sorted order
+    Vec4<T>* s_min;        // sorted interval records
+    Vec4<T>* s_max;
+    uint4* s_info;         // (entity, body, memberships, filters)
+    uint32_t* s_flags;     // AabbIntervalFlags | AVN_IV_DROPPED
+    uint64_t* pair_set;    // ContactGraph::pair_set as an open-addressing hash set (EMPTY = ~0)
+    uint32_t pair_set_cap; // power of two, 0 = no set
+    uint64_t* disabled_set;  // body pairs whose joints disable collision
+    uint32_t disabled_cap;
+};
+#define AVN_IV_DROPPED 0x80000000u
+
+enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3 };
+
+// k_bodies.hip
+template <class T> void launch_prepare_solver_bodies(const DW<T>&, hipStream_t);
+template <class T> void launch_pre_process_increments(const DW<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_clear_increments(const DW<T>&, hipStream_t);
+template <class T> void launch_integrate_velocities(const DW<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_integrate_positions(const DW<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_writeback_solver_bodies(const DW<T>&, hipStream_t);
+template <class T> void launch_xpbd_snapshot(const DW<T>&, hipStream_t);
+template <class T> void launch_xpbd_velocity_projection(const DW<T>&, const StepParams<T>&, hipStream_t);
+// k_contacts.hip
+template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
+uint32_t color_grid_blocks(uint32_t count);
+// grid_blocks[c] = captured grid of colour c (0 = colour skipped); returns the number of launches issued
+template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, hipStream_t);
+// k_xpbd.hip
+template <class T> void launch_prepare_distance_joints(const DW<T>&, hipStream_t);
+template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,
+                                              const uint32_t* level_offsets, const uint32_t* order, hipStream_t);
+template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepParams<T>&, hipStream_t);
+// k_broadphase.hip
+template <class T> void launch_update_aabb(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t);
+uint32_t radix_blocks(uint32_t n);
+uint32_t scan_block_sums_needed(uint32_t n);
+template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums, hipStream_t);
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t);
+template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const uint32_t* sorted_collider, uint32_t n, hipStream_t);
+template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
+void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
+void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
+// k_transfer.hip: host-layout (interleaved xyz) <-> device Vec4 records
+template <class T> struct BodyStage {  // device staging copies of the avn_bodies arrays (nullptr = absent)
+    const T *position, *rotation, *linear_velocity, *angular_velocity, *inv_mass, *inv_inertia_local, *center_of_mass, *linear_damping,
+        *angular_damping, *gravity_scale, *accel_linear, *accel_angular, *max_linear_speed, *max_angular_speed;
+    const uint8_t *rb_type, *locked_axes, *body_flags;
+    const int8_t* dominance;
+};
+template <class T> void launch_pack_bodies(const DW<T>&, const BodyStage<T>&, hipStream_t);
+template <class T> struct ManifoldStage {
+    const int32_t *body1, *body2;
+    const T *normal, *friction, *restitution, *tangent_velocity, *anchor1, *anchor2, *penetration, *normal_speed, *warm_n, *warm_t;
+    const uint8_t *point_count, *manifold_flags;
+};
+template <class T> void launch_pack_manifolds(const DW<T>&, const ManifoldStage<T>&, hipStream_t);
+template <class T> struct JointStage {
+    const int32_t *body1, *body2;
+    const T *local_anchor1, *local_anchor2, *limit_min, *limit_max, *compliance, *damping_linear, *damping_angular;
+};
+template <class T> void launch_pack_joints(const DW<T>&, const JointStage<T>&, hipStream_t);
+template <class T> struct ColliderStage {
+    const uint32_t *entity, *memberships, *filters;
+    const int32_t* body;
+    const uint8_t *shape, *cflags;
+    const T *half_extents, *collision_margin, *speculative_margin;
+};
+template <class T> void launch_pack_colliders(const BP<T>&, const ColliderStage<T>&, hipStream_t);
+// unpack: device records -> planar staging arrays laid out like the *_out structs (nullptr = skip)
+template <class T> void launch_unpack_bodies(const DW<T>&, T* position, T* rotation, T* linear_velocity, T* angular_velocity, hipStream_t);
+template <class T> struct SolverBodiesStage {
+    T *linear_velocity, *angular_velocity, *delta_position, *delta_rotation, *inv_mass, *inv_inertia_world, *linear_increment, *angular_increment,
+        *linear_damping_rhs, *angular_damping_rhs;
+    uint32_t* flags;
+    int16_t* dominance;
+};
+template <class T> void launch_unpack_solver_bodies(const DW<T>&, const SolverBodiesStage<T>&, hipStream_t);
+template <class T> void launch_unpack_impulses(const DW<T>&, T* warm_n, T* warm_t, T* normal_impulse, hipStream_t);
+template <class T> struct ConstraintsStage {
+    uint8_t *point_count, *softness_non_dynamic;
+    int16_t* relative_dominance;
+    T *tangent1, *anchor1, *initial_separation, *normal_impulse, *total_impulse, *normal_effective_mass, *tangent_impulse, *tangent_k;
+};
+template <class T> void launch_unpack_constraints(const DW<T>&, const ConstraintsStage<T>&, hipStream_t);
+template <class T> void launch_unpack_joints(const DW<T>&, T* r1, T* r2, T* cd, T* lag, T* force, hipStream_t);
+template <class T> void launch_unpack_aabbs(const BP<T>&, T* mn, T* mx, uint32_t* interval_entities, hipStream_t);
+
+}  // namespace avn

@@ -1,0 +1,973 @@
+// avn_world.hip — host orchestration of the MI355X physics step (see avn_world.hpp).
+#include "avn_world.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <numeric>
+
+namespace avn {
+
+#define HIPCHK(call)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            error = std::string(#call) + ": " + hipGetErrorName(e_) + " (" + hipGetErrorString(e_) + ")"; \
+            return e_ == hipErrorOutOfMemory ? AVN_ERR_OOM : AVN_ERR_HIP;                      \
+        }                                                                                     \
+    } while (0)
+
+DevBuf::~DevBuf() { if (p) (void)hipFree(p); }
+bool DevBuf::ensure(size_t bytes, hipError_t& err, bool keep, hipStream_t s) {
+    err = hipSuccess;
+    if (bytes <= cap) return false;
+    size_t ncap = std::max(bytes, cap + cap / 2);
+    ncap = (ncap + 255) & ~(size_t)255;
+    void* np = nullptr;
+    err = hipMalloc(&np, ncap);
+    if (err != hipSuccess) return false;
+    if (p) {
+        if (keep) { err = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, s); if (err == hipSuccess) err = hipStreamSynchronize(s); }
+        (void)hipFree(p);
+    }
+    p = np;
+    cap = ncap;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+void JointSchedule::build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys) {
+    comp_level_begin.clear(); level_offsets.clear(); order.clear();
+    n_components = 0;
+    size_t J = joints.size();
+    if (J == 0) { comp_level_begin.push_back(0); level_offsets.push_back(0); return; }
+    // union-find over scheduling keys
+    std::vector<int32_t> parent(n_keys);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (size_t k = 0; k < J; ++k) {
+        int32_t a = key1[k], b = key2[k];
+        if (a >= 0 && b >= 0) { int32_t ra = find(a), rb = find(b); if (ra != rb) parent[ra] = rb; }
+    }
+    std::vector<uint32_t> comp(J), level(J);
+    std::vector<uint32_t> last(n_keys, 0);
+    std::unordered_map<int32_t, uint32_t> comp_of_root;
+    uint32_t max_level = 0;
+    for (size_t k = 0; k < J; ++k) {
+        int32_t a = key1[k], b = key2[k];
+        uint32_t lv = 1 + std::max(a >= 0 ? last[a] : 0u, b >= 0 ? last[b] : 0u);
+        if (a >= 0) last[a] = lv;
+        if (b >= 0) last[b] = lv;
+        level[k] = lv;
+        max_level = std::max(max_level, lv);
+        int32_t root = a >= 0 ? find(a) : (b >= 0 ? find(b) : -1);
+        if (root < 0) comp[k] = n_components++;  // touches no scheduled body: its own component
+        else {
+            auto it = comp_of_root.find(root);
+            if (it == comp_of_root.end()) { comp_of_root.emplace(root, n_components); comp[k] = n_components++; }
+            else comp[k] = it->second;
+        }
+    }
+    // sort joint slots by (component, level, original order)
+    std::vector<uint32_t> idx(J);
+    std::iota(idx.begin(), idx.end(), 0u);
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return comp[x] != comp[y] ? comp[x] < comp[y] : level[x] < level[y]; });
+    order.resize(J);
+    comp_level_begin.assign(1, 0u);
+    level_offsets.clear();
+    uint32_t cur_comp = comp[idx[0]], cur_level = 0;
+    for (size_t k = 0; k < J; ++k) {
+        uint32_t s = idx[k];
+        if (comp[s] != cur_comp) { comp_level_begin.push_back((uint32_t)level_offsets.size()); cur_comp = comp[s]; cur_level = 0; }
+        if (level[s] != cur_level) { level_offsets.push_back((uint32_t)k); cur_level = level[s]; }
+        order[k] = joints[s];
+    }
+    comp_level_begin.push_back((uint32_t)level_offsets.size());
+    level_offsets.push_back((uint32_t)J);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+template <class T> struct World : WorldBase {
+    using V = Vec4<T>;
+    using Key = typename BP<T>::Key;
+    avn_config cfg;
+    StepParams<T> params;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    DW<T> dw;
+    BP<T> bp;
+    // capacities
+    uint32_t cap_bodies = 0, cap_manifolds = 0, cap_joints = 0, cap_colliders = 0;
+    // body buffers (Vec4 each)
+    DevBuf b_pos, b_rot, b_lvel, b_avel, b_com, b_iloc_a, b_iloc_b, b_acc_l, b_acc_a, b_bmeta;
+    DevBuf b_sb_lin, b_sb_ang, b_sb_dp, b_sb_dq, b_si_a, b_si_b, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
+    DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
+    DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_force;
+    DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_min, b_s_max, b_s_info, b_s_flags;
+    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys;
+    DevBuf stage;  // staging arena for uploads/downloads
+    size_t stage_off = 0;
+    // host state
+    uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1];
+    uint32_t grid_blocks[AVN_GRAPH_COLOR_COUNT];      // launch grids (captured into the graph with slack)
+    std::vector<int32_t> h_j_body1, h_j_body2;
+    std::vector<uint8_t> h_j_damped, h_j_collision_disabled;
+    std::vector<uint8_t> h_body_has_sb;
+    bool joint_schedule_dirty = true;
+    JointSchedule sched_solve, sched_damp;
+    bool any_damped = false;
+    std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
+    uint32_t n_pair_keys = 0;           // keys currently in the device pair set
+    std::vector<avn_pair> h_pairs;
+    bool have_colliders = false, have_bodies = false;
+    avn_timers last_timers;
+    uint32_t launches = 0;
+    // graph
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    bool graph_valid = false;
+
+    World() {
+        std::memset(&dw, 0, sizeof dw);
+        std::memset(&bp, 0, sizeof bp);
+        std::memset(&last_timers, 0, sizeof last_timers);
+        std::memset(color_offsets, 0, sizeof color_offsets);
+        std::memset(grid_blocks, 0, sizeof grid_blocks);
+    }
+    ~World() override {
+        if (stream) (void)hipStreamSynchronize(stream);
+        drop_graph();
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+    void drop_graph() {
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
+        graph_valid = false;
+    }
+
+    avn_status init(const avn_config* c) {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev == 0) { error = "no HIP device visible: the MI355X path has no CPU fallback"; return AVN_ERR_NO_DEVICE; }
+        if (c->device < 0 || c->device >= ndev) { error = "config.device out of range"; return AVN_ERR_BAD_ARG; }
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+        hipError_t err;
+        b_misc.ensure(4096, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemsetAsync(b_misc.p, 0, 4096, stream));
+        // misc layout: [0..25) color offsets, [32] constraint count, [33] n_dropped, [34] pair total
+        dw.color_offsets = b_misc.as<uint32_t>();
+        dw.constraint_count = b_misc.as<uint32_t>() + 32;
+        return config_set(c);
+    }
+
+    static T as_secs_adjusted(uint64_t ns) {
+        if (sizeof(T) == 8) return (T)((double)(ns / 1000000000ull) + (double)(ns % 1000000000ull) / 1e9);
+        return (T)((float)(ns / 1000000000ull) + (float)(ns % 1000000000ull) / 1e9f);  // Duration::as_secs_f32
+    }
+    static double as_secs_f64(uint64_t ns) { return (double)(ns / 1000000000ull) + (double)(ns % 1000000000ull) / 1e9; }
+    // reference solver/softness_parameters/mod.rs:36-41,64-79
+    static SoftCoef<T> softness(T damping_ratio, T frequency_hz, T delta_secs) {
+        const T TAU = T(6.283185307179586476925286766559);
+        T double_damping_ratio = T(2) * damping_ratio;
+        T angular_frequency = TAU * frequency_hz;
+        T a1 = double_damping_ratio + angular_frequency * delta_secs;
+        T a2 = angular_frequency * delta_secs * a1;
+        T a3 = T(1) / (T(1) + a2);
+        return {angular_frequency / a1, a2 * a3, a3};
+    }
+    avn_status config_set(const avn_config* c) override {
+        if (!c || c->struct_size != sizeof(avn_config)) { error = "config: struct_size mismatch"; return AVN_ERR_BAD_ARG; }
+        if (c->substeps == 0 || c->dt_ns == 0) { error = "config: substeps and dt_ns must be > 0"; return AVN_ERR_BAD_ARG; }
+        if (c->scalar_bits != sizeof(T) * 8) { error = "config: scalar_bits cannot change after world creation"; return AVN_ERR_BAD_ARG; }
+        cfg = *c;
+        if (cfg.solver_iterations == 0) cfg.solver_iterations = 1;
+        // Duration arithmetic of run_physics_schedule / run_substep_schedule (reference schedule/mod.rs:240-284,
+        // solver/schedule.rs:194-200): sub_delta = delta.div_f64(substeps), rounded to the nearest nanosecond.
+        uint64_t dt_ns = cfg.dt_ns;
+        uint64_t h_ns = (uint64_t)std::llround(as_secs_f64(dt_ns) / (double)cfg.substeps * 1e9);
+        params.dt_f64cast = (T)as_secs_f64(dt_ns);
+        params.h_f64cast = (T)as_secs_f64(h_ns);
+        params.dt_adj = as_secs_adjusted(dt_ns);
+        params.h_adj = as_secs_adjusted(h_ns);
+        for (int k = 0; k < 3; ++k) params.gravity[k] = (T)cfg.gravity[k];
+        params.max_overlap_solve_speed = (T)cfg.max_overlap_solve_speed * (T)cfg.length_unit;
+        params.warm_start_coefficient = (T)cfg.warm_start_coefficient;
+        params.restitution_threshold = (T)cfg.restitution_threshold * (T)cfg.length_unit;
+        params.contact_tolerance = (T)cfg.length_unit * (T)cfg.contact_tolerance;
+        T dsm = cfg.default_speculative_margin >= (double)std::numeric_limits<T>::max() ? std::numeric_limits<T>::max() : (T)cfg.default_speculative_margin;
+        params.default_speculative_margin = (T)cfg.length_unit * dsm;
+        params.substeps_as_scalar = (T)cfg.substeps;
+        params.restitution_iterations = cfg.restitution_iterations;
+        params.match_contacts = cfg.match_contacts;
+        // update_contact_softness, reference solver/plugin.rs:326-350
+        T dt = params.dt_f64cast, h = params.h_f64cast;
+        T max_hz = T(1) / (dt * T(2));
+        T hz = (T)cfg.contact_frequency_factor * smin(max_hz, T(0.25) / h);
+        params.soft_dynamic = softness((T)cfg.contact_damping_ratio, hz, h);
+        params.soft_non_dynamic = softness((T)cfg.contact_damping_ratio, T(2) * hz, h);
+        graph_valid = false;
+        return AVN_OK;
+    }
+
+    // ---- staging arena ---------------------------------------------------------------------------------
+    avn_status stage_reserve(size_t bytes) {
+        hipError_t err;
+        HIPCHK(hipStreamSynchronize(stream));  // arena reuse: previous users must be done
+        stage.ensure(bytes + 4096, err);
+        if (err != hipSuccess) { error = "staging allocation failed"; return AVN_ERR_OOM; }
+        stage_off = 0;
+        return AVN_OK;
+    }
+    template <class U> U* stage_alloc(size_t count) {
+        stage_off = (stage_off + 63) & ~(size_t)63;
+        U* r = (U*)((char*)stage.p + stage_off);
+        stage_off += count * sizeof(U);
+        return r;
+    }
+    template <class U> avn_status stage_in(const void* host, size_t count, const U** out) {
+        if (!host || count == 0) { *out = nullptr; return AVN_OK; }
+        U* d = stage_alloc<U>(count);
+        HIPCHK(hipMemcpyAsync(d, host, count * sizeof(U), hipMemcpyHostToDevice, stream));
+        *out = d;
+        return AVN_OK;
+    }
+    template <class U> avn_status stage_out(void* host, const U* dev, size_t count) {
+        if (!host || !dev || count == 0) return AVN_OK;
+        HIPCHK(hipMemcpyAsync(host, dev, count * sizeof(U), hipMemcpyDeviceToHost, stream));
+        return AVN_OK;
+    }
+    static size_t al(size_t b) { return (b + 63) & ~(size_t)63; }
+
+    template <class U> avn_status grow(DevBuf& b, size_t count, U** field, bool& moved) {
+        hipError_t err;
+        if (b.ensure(count * sizeof(U), err)) moved = true;
+        if (err != hipSuccess) { error = std::string("hipMalloc: ") + hipGetErrorName(err); return AVN_ERR_OOM; }
+        *field = b.as<U>();
+        return AVN_OK;
+    }
+#define GROW(buf, count, field) do { avn_status s_ = grow(buf, count, &(field), moved); if (s_ != AVN_OK) return s_; } while (0)
+
+    // ---- bodies ------------------------------------------------------------------------------------------
+    avn_status bodies_upload(const avn_bodies* b) override {
+        if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass || !b->inv_inertia_local || !b->rb_type))) {
+            error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        uint32_t n = b->count;
+        bool moved = false;
+        if (n + 2 > cap_bodies || !have_bodies) {
+            HIPCHK(hipStreamSynchronize(stream));
+            size_t c = (size_t)std::max<uint32_t>(n + 2, cap_bodies + cap_bodies / 2);  // +2: virtual DUMMY bodies of joint_damping
+            GROW(b_pos, c, dw.pos); GROW(b_rot, c, dw.rot); GROW(b_lvel, c, dw.lvel); GROW(b_avel, c, dw.avel); GROW(b_com, c, dw.com);
+            GROW(b_iloc_a, c, dw.iloc_a); GROW(b_iloc_b, c, dw.iloc_b); GROW(b_acc_l, c, dw.acc_l); GROW(b_acc_a, c, dw.acc_a); GROW(b_bmeta, c, dw.bmeta);
+            GROW(b_sb_lin, c, dw.sb_lin); GROW(b_sb_ang, c, dw.sb_ang); GROW(b_sb_dp, c, dw.sb_dp); GROW(b_sb_dq, c, dw.sb_dq);
+            GROW(b_si_a, c, dw.si_a); GROW(b_si_b, c, dw.si_b); GROW(b_vid_l, c, dw.vid_l); GROW(b_vid_a, c, dw.vid_a);
+            GROW(b_pre_dp, c, dw.pre_dp); GROW(b_pre_dq, c, dw.pre_dq); GROW(b_sb_flags, c, dw.sb_flags);
+            cap_bodies = (uint32_t)c;
+        }
+        if (moved || dw.n_bodies != n) graph_valid = false;
+        dw.n_bodies = n;
+        size_t total = 0;
+        total += al(sizeof(T) * 3 * n) * 7 + al(sizeof(T) * 4 * n) + al(sizeof(T) * 6 * n) + al(sizeof(T) * n) * 6 + al(n) * 4;
+        avn_status st = stage_reserve(total + 64 * 32);
+        if (st != AVN_OK) return st;
+        BodyStage<T> s;
+        std::memset(&s, 0, sizeof s);
+#define SIN(field, src, cnt, U) do { st = stage_in<U>(src, cnt, &s.field); if (st != AVN_OK) return st; } while (0)
+        SIN(position, b->position, 3 * (size_t)n, T); SIN(rotation, b->rotation, 4 * (size_t)n, T);
+        SIN(linear_velocity, b->linear_velocity, 3 * (size_t)n, T); SIN(angular_velocity, b->angular_velocity, 3 * (size_t)n, T);
+        SIN(inv_mass, b->inv_mass, n, T); SIN(inv_inertia_local, b->inv_inertia_local, 6 * (size_t)n, T);
+        SIN(center_of_mass, b->center_of_mass, 3 * (size_t)n, T); SIN(linear_damping, b->linear_damping, n, T);
+        SIN(angular_damping, b->angular_damping, n, T); SIN(gravity_scale, b->gravity_scale, n, T);
+        SIN(accel_linear, b->accel_linear, 3 * (size_t)n, T); SIN(accel_angular, b->accel_angular, 3 * (size_t)n, T);
+        SIN(max_linear_speed, b->max_linear_speed, n, T); SIN(max_angular_speed, b->max_angular_speed, n, T);
+        SIN(rb_type, b->rb_type, n, uint8_t); SIN(locked_axes, b->locked_axes, n, uint8_t); SIN(body_flags, b->body_flags, n, uint8_t);
+        SIN(dominance, b->dominance, n, int8_t);
+        launch_pack_bodies<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+        // host copy of "has SolverBody" for the joint schedules
+        h_body_has_sb.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint8_t fl = b->body_flags ? b->body_flags[i] : 0;
+            h_body_has_sb[i] = b->rb_type[i] != AVN_RB_STATIC && !(fl & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED));
+        }
+        joint_schedule_dirty = true;
+        have_bodies = true;
+        HIPCHK(hipStreamSynchronize(stream));  // host arrays are only borrowed for the call
+        return AVN_OK;
+    }
+    avn_status bodies_download(const avn_bodies_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t n = dw.n_bodies;
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * n) * 3 + al(sizeof(T) * 4 * n) + 1024);
+        if (st != AVN_OK) return st;
+        T* p = o->position ? stage_alloc<T>(3 * n) : nullptr;
+        T* r = o->rotation ? stage_alloc<T>(4 * n) : nullptr;
+        T* l = o->linear_velocity ? stage_alloc<T>(3 * n) : nullptr;
+        T* a = o->angular_velocity ? stage_alloc<T>(3 * n) : nullptr;
+        launch_unpack_bodies<T>(dw, p, r, l, a, stream);
+        HIPCHK(hipGetLastError());
+        if ((st = stage_out<T>(o->position, p, 3 * n)) != AVN_OK) return st;
+        if ((st = stage_out<T>(o->rotation, r, 4 * n)) != AVN_OK) return st;
+        if ((st = stage_out<T>(o->linear_velocity, l, 3 * n)) != AVN_OK) return st;
+        if ((st = stage_out<T>(o->angular_velocity, a, 3 * n)) != AVN_OK) return st;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status solver_bodies_download(const avn_solver_bodies_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t n = dw.n_bodies;
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * n) * 5 + al(sizeof(T) * 4 * n) + al(sizeof(T) * 6 * n) + al(sizeof(T) * n) * 3 + al(4 * n) + al(2 * n) + 4096);
+        if (st != AVN_OK) return st;
+        SolverBodiesStage<T> s;
+        s.linear_velocity = o->linear_velocity ? stage_alloc<T>(3 * n) : nullptr;
+        s.angular_velocity = o->angular_velocity ? stage_alloc<T>(3 * n) : nullptr;
+        s.delta_position = o->delta_position ? stage_alloc<T>(3 * n) : nullptr;
+        s.delta_rotation = o->delta_rotation ? stage_alloc<T>(4 * n) : nullptr;
+        s.flags = o->flags ? stage_alloc<uint32_t>(n) : nullptr;
+        s.inv_mass = o->inv_mass ? stage_alloc<T>(n) : nullptr;
+        s.inv_inertia_world = o->inv_inertia_world ? stage_alloc<T>(6 * n) : nullptr;
+        s.dominance = o->dominance ? stage_alloc<int16_t>(n) : nullptr;
+        s.linear_increment = o->linear_increment ? stage_alloc<T>(3 * n) : nullptr;
+        s.angular_increment = o->angular_increment ? stage_alloc<T>(3 * n) : nullptr;
+        s.linear_damping_rhs = o->linear_damping_rhs ? stage_alloc<T>(n) : nullptr;
+        s.angular_damping_rhs = o->angular_damping_rhs ? stage_alloc<T>(n) : nullptr;
+        launch_unpack_solver_bodies<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+#define SOUT(dst, src, cnt, U) do { if ((st = stage_out<U>(dst, src, cnt)) != AVN_OK) return st; } while (0)
+        SOUT(o->linear_velocity, s.linear_velocity, 3 * n, T); SOUT(o->angular_velocity, s.angular_velocity, 3 * n, T);
+        SOUT(o->delta_position, s.delta_position, 3 * n, T); SOUT(o->delta_rotation, s.delta_rotation, 4 * n, T);
+        SOUT(o->flags, s.flags, n, uint32_t); SOUT(o->inv_mass, s.inv_mass, n, T); SOUT(o->inv_inertia_world, s.inv_inertia_world, 6 * n, T);
+        SOUT(o->dominance, s.dominance, n, int16_t); SOUT(o->linear_increment, s.linear_increment, 3 * n, T);
+        SOUT(o->angular_increment, s.angular_increment, 3 * n, T); SOUT(o->linear_damping_rhs, s.linear_damping_rhs, n, T);
+        SOUT(o->angular_damping_rhs, s.angular_damping_rhs, n, T);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+
+    // ---- manifolds ---------------------------------------------------------------------------------------
+    avn_status manifolds_upload(const avn_manifolds* m) override {
+        if (!have_bodies) { error = "manifolds_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!m || !m->color_offsets || (m->count && (!m->body1 || !m->body2 || !m->normal || !m->friction || !m->restitution || !m->point_count ||
+                                                    !m->anchor1 || !m->anchor2 || !m->penetration || !m->normal_speed))) {
+            error = "manifolds_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        uint32_t M = m->count;
+        if (m->color_offsets[0] != 0 || m->color_offsets[AVN_GRAPH_COLOR_COUNT] != M) { error = "manifolds_upload: bad color_offsets"; return AVN_ERR_BAD_ARG; }
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            if (m->color_offsets[c] > m->color_offsets[c + 1]) { error = "manifolds_upload: color_offsets not monotone"; return AVN_ERR_BAD_ARG; }
+        for (uint32_t i = 0; i < M; ++i) {
+            if (m->body1[i] < 0 || m->body2[i] < 0 || (uint32_t)m->body1[i] >= dw.n_bodies || (uint32_t)m->body2[i] >= dw.n_bodies) { error = "manifolds_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+            if (m->point_count[i] > AVN_MAX_MANIFOLD_POINTS) { error = "manifolds_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
+        }
+        bool moved = false;
+        if (M > cap_manifolds) {
+            HIPCHK(hipStreamSynchronize(stream));
+            size_t c = std::max<size_t>(M, cap_manifolds + cap_manifolds / 2);
+            c = (c + 63) & ~(size_t)63;  // keep every point plane 1 KiB aligned
+            GROW(b_m_bodies, c, dw.m_bodies); GROW(b_m_n, c, dw.m_n); GROW(b_m_tv, c, dw.m_tv); GROW(b_m_meta, c, dw.m_meta);
+            GROW(b_mp_a1, 4 * c, dw.mp_a1); GROW(b_mp_a2, 4 * c, dw.mp_a2); GROW(b_mp_w, 4 * c, dw.mp_w);
+            GROW(b_c_h1, c, dw.c_h1); GROW(b_c_pa, 4 * c, dw.c_pa); GROW(b_c_pb, 4 * c, dw.c_pb); GROW(b_c_pc, 4 * c, dw.c_pc); GROW(b_c_pd, 4 * c, dw.c_pd);
+            GROW(b_c_reldom, c, dw.c_reldom);
+            cap_manifolds = (uint32_t)c;
+            dw.m_stride = cap_manifolds;
+        }
+        if (moved) graph_valid = false;
+        dw.n_manifolds = M;
+        std::memcpy(color_offsets, m->color_offsets, sizeof color_offsets);
+        // launch grids per colour: the kernels read the live colour ranges from device memory, so a captured grid stays
+        // valid while it still covers the colour; grids are captured with 25 % slack and re-captured when outgrown
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+            uint32_t cnt = color_offsets[c + 1] - color_offsets[c];
+            if (c == AVN_COLOR_OVERFLOW_INDEX) {  // serial kernel: the "grid" is only an on/off flag
+                if (cnt && !grid_blocks[c]) { grid_blocks[c] = 8; graph_valid = false; }
+                continue;
+            }
+            uint32_t need = cnt ? color_grid_blocks(cnt) : 0u;
+            if (need > grid_blocks[c] || grid_blocks[c] > 4 * need + 64) {
+                grid_blocks[c] = cnt ? color_grid_blocks(cnt + cnt / 4 + 64) : 0u;
+                graph_valid = false;
+            }
+        }
+        size_t total = al(4 * (size_t)M) * 2 + al(sizeof(T) * 3 * M) * 2 + al(sizeof(T) * M) * 2 + al(M) * 2 + al(sizeof(T) * 12 * M) * 2 + al(sizeof(T) * 4 * M) * 3 + al(sizeof(T) * 8 * M);
+        avn_status st = stage_reserve(total + 64 * 32);
+        if (st != AVN_OK) return st;
+        HIPCHK(hipMemcpyAsync(dw.color_offsets, color_offsets, sizeof color_offsets, hipMemcpyHostToDevice, stream));
+        ManifoldStage<T> s;
+        std::memset(&s, 0, sizeof s);
+        SIN(body1, m->body1, M, int32_t); SIN(body2, m->body2, M, int32_t); SIN(normal, m->normal, 3 * (size_t)M, T);
+        SIN(friction, m->friction, M, T); SIN(restitution, m->restitution, M, T); SIN(tangent_velocity, m->tangent_velocity, 3 * (size_t)M, T);
+        SIN(point_count, m->point_count, M, uint8_t); SIN(manifold_flags, m->manifold_flags, M, uint8_t);
+        SIN(anchor1, m->anchor1, 12 * (size_t)M, T); SIN(anchor2, m->anchor2, 12 * (size_t)M, T);
+        SIN(penetration, m->penetration, 4 * (size_t)M, T); SIN(normal_speed, m->normal_speed, 4 * (size_t)M, T);
+        SIN(warm_n, m->warm_start_normal_impulse, 4 * (size_t)M, T); SIN(warm_t, m->warm_start_tangent_impulse, 8 * (size_t)M, T);
+        launch_pack_manifolds<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status impulses_download(const avn_impulses_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t M = dw.n_manifolds;
+        avn_status st = stage_reserve(al(sizeof(T) * 4 * M) * 2 + al(sizeof(T) * 8 * M) + 1024);
+        if (st != AVN_OK) return st;
+        T* a = o->warm_start_normal_impulse ? stage_alloc<T>(4 * M) : nullptr;
+        T* b = o->warm_start_tangent_impulse ? stage_alloc<T>(8 * M) : nullptr;
+        T* c = o->normal_impulse ? stage_alloc<T>(4 * M) : nullptr;
+        launch_unpack_impulses<T>(dw, a, b, c, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->warm_start_normal_impulse, a, 4 * M, T); SOUT(o->warm_start_tangent_impulse, b, 8 * M, T); SOUT(o->normal_impulse, c, 4 * M, T);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status constraints_download(const avn_constraints_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t M = dw.n_manifolds;
+        avn_status st = stage_reserve(al(M) * 2 + al(2 * M) + al(sizeof(T) * 3 * M) + al(sizeof(T) * 12 * M) * 2 + al(sizeof(T) * 4 * M) * 4 + al(sizeof(T) * 8 * M) + 4096);
+        if (st != AVN_OK) return st;
+        ConstraintsStage<T> s;
+        s.point_count = o->point_count ? stage_alloc<uint8_t>(M) : nullptr;
+        s.softness_non_dynamic = o->softness_non_dynamic ? stage_alloc<uint8_t>(M) : nullptr;
+        s.relative_dominance = o->relative_dominance ? stage_alloc<int16_t>(M) : nullptr;
+        s.tangent1 = o->tangent1 ? stage_alloc<T>(3 * M) : nullptr;
+        s.anchor1 = o->anchor1 ? stage_alloc<T>(12 * M) : nullptr;
+        s.initial_separation = o->initial_separation ? stage_alloc<T>(4 * M) : nullptr;
+        s.normal_impulse = o->normal_impulse ? stage_alloc<T>(4 * M) : nullptr;
+        s.total_impulse = o->total_impulse ? stage_alloc<T>(4 * M) : nullptr;
+        s.normal_effective_mass = o->normal_effective_mass ? stage_alloc<T>(4 * M) : nullptr;
+        s.tangent_impulse = o->tangent_impulse ? stage_alloc<T>(8 * M) : nullptr;
+        s.tangent_k = o->tangent_effective_inverse_mass ? stage_alloc<T>(12 * M) : nullptr;
+        if (stage_off) HIPCHK(hipMemsetAsync(stage.p, 0, stage_off, stream));  // absent constraints read back as zeros
+        launch_unpack_constraints<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->point_count, s.point_count, M, uint8_t); SOUT(o->softness_non_dynamic, s.softness_non_dynamic, M, uint8_t);
+        SOUT(o->relative_dominance, s.relative_dominance, M, int16_t); SOUT(o->tangent1, s.tangent1, 3 * M, T);
+        SOUT(o->anchor1, s.anchor1, 12 * M, T); SOUT(o->initial_separation, s.initial_separation, 4 * M, T);
+        SOUT(o->normal_impulse, s.normal_impulse, 4 * M, T); SOUT(o->total_impulse, s.total_impulse, 4 * M, T);
+        SOUT(o->normal_effective_mass, s.normal_effective_mass, 4 * M, T); SOUT(o->tangent_impulse, s.tangent_impulse, 8 * M, T);
+        SOUT(o->tangent_effective_inverse_mass, s.tangent_k, 12 * M, T);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+
+    // ---- joints ----------------------------------------------------------------------------------------
+    avn_status distance_joints_upload(const avn_distance_joints* j) override {
+        if (!have_bodies) { error = "distance_joints_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!j || (j->count && (!j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->limit_min || !j->limit_max || !j->compliance))) {
+            error = "distance_joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        uint32_t J = j->count;
+        for (uint32_t i = 0; i < J; ++i)
+            if (j->body1[i] < 0 || j->body2[i] < 0 || (uint32_t)j->body1[i] >= dw.n_bodies || (uint32_t)j->body2[i] >= dw.n_bodies || j->body1[i] == j->body2[i]) {
+                error = "distance_joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
+            }
+        bool moved = false;
+        if (J > cap_joints) {
+            HIPCHK(hipStreamSynchronize(stream));
+            size_t c = std::max<size_t>(J, cap_joints + cap_joints / 2);
+            GROW(b_j_bodies, c, dw.j_bodies); GROW(b_j_a1, c, dw.j_a1); GROW(b_j_a2, c, dw.j_a2); GROW(b_j_par, c, dw.j_par);
+            GROW(b_j_r1, c, dw.j_r1); GROW(b_j_r2, c, dw.j_r2); GROW(b_j_cd, c, dw.j_cd); GROW(b_j_lag, c, dw.j_lag); GROW(b_j_force, c, dw.j_force);
+            cap_joints = (uint32_t)c;
+        }
+        if (moved || dw.n_joints != J) graph_valid = false;
+        dw.n_joints = J;
+        avn_status st = stage_reserve(al(4 * (size_t)J) * 2 + al(sizeof(T) * 3 * J) * 2 + al(sizeof(T) * J) * 5 + 4096);
+        if (st != AVN_OK) return st;
+        JointStage<T> s;
+        std::memset(&s, 0, sizeof s);
+        SIN(body1, j->body1, J, int32_t); SIN(body2, j->body2, J, int32_t);
+        SIN(local_anchor1, j->local_anchor1, 3 * (size_t)J, T); SIN(local_anchor2, j->local_anchor2, 3 * (size_t)J, T);
+        SIN(limit_min, j->limit_min, J, T); SIN(limit_max, j->limit_max, J, T); SIN(compliance, j->compliance, J, T);
+        SIN(damping_linear, j->damping_linear, J, T); SIN(damping_angular, j->damping_angular, J, T);
+        launch_pack_joints<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+        h_j_body1.assign(j->body1, j->body1 + J);
+        h_j_body2.assign(j->body2, j->body2 + J);
+        bool damp = j->damping_linear && j->damping_angular;
+        h_j_damped.assign(J, damp ? 1 : 0);
+        any_damped = damp && J > 0;
+        // body pairs whose joints disable collision (reference broad_phase.rs:423-428)
+        std::vector<uint64_t> disabled;
+        for (uint32_t i = 0; i < J; ++i)
+            if (j->collision_disabled && j->collision_disabled[i]) {
+                uint32_t a = (uint32_t)j->body1[i], b = (uint32_t)j->body2[i];
+                disabled.push_back(a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a);
+            }
+        st = build_hash_set(b_disabled_set, bp.disabled_set, bp.disabled_cap, disabled.data(), (uint32_t)disabled.size());
+        if (st != AVN_OK) return st;
+        joint_schedule_dirty = true;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status joints_download(const avn_joints_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t J = dw.n_joints;
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * J) * 5 + 1024);
+        if (st != AVN_OK) return st;
+        T* a = o->world_r1 ? stage_alloc<T>(3 * J) : nullptr;
+        T* b = o->world_r2 ? stage_alloc<T>(3 * J) : nullptr;
+        T* c = o->center_difference ? stage_alloc<T>(3 * J) : nullptr;
+        T* d = o->total_lagrange ? stage_alloc<T>(3 * J) : nullptr;
+        T* e = o->force ? stage_alloc<T>(3 * J) : nullptr;
+        launch_unpack_joints<T>(dw, a, b, c, d, e, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->world_r1, a, 3 * J, T); SOUT(o->world_r2, b, 3 * J, T); SOUT(o->center_difference, c, 3 * J, T);
+        SOUT(o->total_lagrange, d, 3 * J, T); SOUT(o->force, e, 3 * J, T);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status upload_u32(DevBuf& b, const std::vector<uint32_t>& v) {
+        hipError_t err;
+        b.ensure(std::max<size_t>(v.size(), 1) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, stream));
+        return AVN_OK;
+    }
+    avn_status rebuild_joint_schedules() {
+        if (!joint_schedule_dirty) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t J = dw.n_joints, N = dw.n_bodies;
+        std::vector<uint32_t> all(J);
+        std::iota(all.begin(), all.end(), 0u);
+        std::vector<int32_t> k1(J), k2(J);
+        for (uint32_t i = 0; i < J; ++i) {
+            // bodies without a SolverBody are DUMMY in solve_xpbd_joint: never modified => they do not serialise joints
+            k1[i] = h_body_has_sb[h_j_body1[i]] ? h_j_body1[i] : -1;
+            k2[i] = h_body_has_sb[h_j_body2[i]] ? h_j_body2[i] : -1;
+        }
+        sched_solve.build(all, k1, k2, N);
+        std::vector<uint32_t> damped;
+        std::vector<int32_t> d1, d2;
+        sched_damp.touches_dummy = false;
+        for (uint32_t i = 0; i < J; ++i)
+            if (h_j_damped[i]) {
+                damped.push_back(i);
+                // joint_damping's DUMMY bodies are shared and mutable: virtual bodies N (side 1) and N+1 (side 2)
+                bool m1 = !h_body_has_sb[h_j_body1[i]], m2 = !h_body_has_sb[h_j_body2[i]];
+                d1.push_back(m1 ? (int32_t)N : h_j_body1[i]);
+                d2.push_back(m2 ? (int32_t)N + 1 : h_j_body2[i]);
+                if (m1 || m2) sched_damp.touches_dummy = true;
+            }
+        sched_damp.build(damped, d1, d2, N + 2);
+        avn_status st;
+        for (JointSchedule* s : {&sched_solve, &sched_damp}) {
+            if ((st = upload_u32(s->d_comp_level_begin, s->comp_level_begin)) != AVN_OK) return st;
+            if ((st = upload_u32(s->d_level_offsets, s->level_offsets)) != AVN_OK) return st;
+            if ((st = upload_u32(s->d_order, s->order)) != AVN_OK) return st;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        joint_schedule_dirty = false;
+        graph_valid = false;
+        return AVN_OK;
+    }
+
+    // ---- broad phase -------------------------------------------------------------------------------------
+    avn_status build_hash_set(DevBuf& buf, uint64_t*& tab, uint32_t& cap, const uint64_t* host_keys, uint32_t n) {
+        if (n == 0) { if (cap) graph_valid = false; cap = 0; return AVN_OK; }
+        uint32_t need = 64;
+        while (need < 2 * n + 16) need <<= 1;
+        hipError_t err;
+        buf.ensure((size_t)need * 8, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        tab = buf.as<uint64_t>();
+        cap = need;
+        avn_status st = stage_reserve((size_t)n * 8 + 1024);
+        if (st != AVN_OK) return st;
+        HIPCHK(hipMemsetAsync(tab, 0xFF, (size_t)cap * 8, stream));
+        const uint64_t* d;
+        if ((st = stage_in<uint64_t>(host_keys, n, &d)) != AVN_OK) return st;
+        launch_hs_insert(tab, cap, d, n, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status existing_pairs_upload(const uint64_t* keys, size_t n) override {
+        if (n && !keys) return AVN_ERR_BAD_ARG;
+        hipError_t err;
+        b_pair_keys.ensure(std::max<size_t>(n, 1) * 8, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (n) HIPCHK(hipMemcpyAsync(b_pair_keys.p, keys, n * 8, hipMemcpyHostToDevice, stream));
+        n_pair_keys = (uint32_t)n;
+        return rebuild_pair_set((uint32_t)n);
+    }
+    // (re)build the device pair set from the key list with room for `expect` keys
+    avn_status rebuild_pair_set(uint32_t expect) {
+        uint32_t need = 1024;
+        while (need < 2 * (expect + 16)) need <<= 1;
+        hipError_t err;
+        b_pair_set.ensure((size_t)need * 8, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        bp.pair_set = b_pair_set.as<uint64_t>();
+        bp.pair_set_cap = need;
+        HIPCHK(hipMemsetAsync(bp.pair_set, 0xFF, (size_t)need * 8, stream));
+        launch_hs_insert(bp.pair_set, need, b_pair_keys.as<uint64_t>(), n_pair_keys, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status colliders_upload(const avn_colliders* c) override {
+        if (!have_bodies) { error = "colliders_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!c || (c->count && (!c->entity_index || !c->body || !c->shape || !c->half_extents))) { error = "colliders_upload: null array"; return AVN_ERR_BAD_ARG; }
+        uint32_t C = c->count;
+        for (uint32_t i = 0; i < C; ++i)
+            if (c->body[i] < 0 || (uint32_t)c->body[i] >= dw.n_bodies) { error = "colliders_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+        HIPCHK(hipStreamSynchronize(stream));
+        bool same = slot_entity.size() == C && (C == 0 || std::memcmp(slot_entity.data(), c->entity_index, C * 4) == 0);
+        std::vector<uint32_t> new_iv;
+        std::vector<V> keep_min, keep_max;
+        if (!same) {
+            std::unordered_map<uint32_t, uint32_t> next_slot;
+            next_slot.reserve(C * 2);
+            for (uint32_t i = 0; i < C; ++i)
+                if (!next_slot.emplace(c->entity_index[i], i).second) { error = "colliders_upload: duplicate entity_index"; return AVN_ERR_BAD_ARG; }
+            // retain_mut (reference broad_phase.rs:230-279) on the current device order, then append the new ones
+            std::vector<uint32_t> old_iv(bp.n_intervals);
+            if (bp.n_intervals) HIPCHK(hipMemcpy(old_iv.data(), bp.iv_collider, (size_t)bp.n_intervals * 4, hipMemcpyDeviceToHost));
+            std::vector<uint8_t> known(C, 0);
+            // carry the ColliderAabb component of surviving colliders over to their new slot
+            std::vector<V> omin(bp.n_colliders), omax(bp.n_colliders);
+            if (bp.n_colliders) {
+                HIPCHK(hipMemcpy(omin.data(), bp.aabb_min, (size_t)bp.n_colliders * sizeof(V), hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(omax.data(), bp.aabb_max, (size_t)bp.n_colliders * sizeof(V), hipMemcpyDeviceToHost));
+            }
+            keep_min.assign(C, make4<T>(0, 0, 0, 0));
+            keep_max.assign(C, make4<T>(0, 0, 0, 0));
+            for (uint32_t s = 0; s < bp.n_colliders && s < slot_entity.size(); ++s) {
+                auto it = next_slot.find(slot_entity[s]);
+                if (it != next_slot.end()) { keep_min[it->second] = omin[s]; keep_max[it->second] = omax[s]; }
+            }
+            for (uint32_t iv : old_iv) {
+                auto it = next_slot.find(slot_entity[iv]);
+                if (it == next_slot.end()) continue;
+                new_iv.push_back(it->second);
+                known[it->second] = 1;
+            }
+            for (uint32_t i = 0; i < C; ++i)
+                if (!known[i]) new_iv.push_back(i);  // add_new_aabb_intervals: appended at the END in upload order
+            slot_entity.assign(c->entity_index, c->entity_index + C);
+        }
+        bool moved = false;
+        if (C > cap_colliders) {
+            size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
+            GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
+            GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
+            GROW(b_s_min, cc, bp.s_min); GROW(b_s_max, cc, bp.s_max); GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
+            Key* dummy_k; uint32_t* dummy_u;
+            GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
+            GROW(b_hist, (size_t)256 * radix_blocks((uint32_t)cc) + 256, dummy_u);
+            GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc)) + 16, dummy_u);
+            GROW(b_counts, cc + 1, dummy_u); GROW(b_offsets, cc + 1, dummy_u);
+            cap_colliders = (uint32_t)cc;
+        }
+        bp.n_colliders = C;
+        if (!same) {
+            bp.n_intervals = (uint32_t)new_iv.size();
+            if (!new_iv.empty()) HIPCHK(hipMemcpy(bp.iv_collider, new_iv.data(), new_iv.size() * 4, hipMemcpyHostToDevice));
+            if (C) {
+                HIPCHK(hipMemcpy(bp.aabb_min, keep_min.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+                HIPCHK(hipMemcpy(bp.aabb_max, keep_max.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+            }
+        }
+        avn_status st = stage_reserve(al(4 * (size_t)C) * 4 + al(C) * 2 + al(sizeof(T) * 3 * C) + al(sizeof(T) * C) * 2 + 4096);
+        if (st != AVN_OK) return st;
+        ColliderStage<T> s;
+        std::memset(&s, 0, sizeof s);
+        SIN(entity, c->entity_index, C, uint32_t); SIN(body, c->body, C, int32_t); SIN(shape, c->shape, C, uint8_t);
+        SIN(half_extents, c->half_extents, 3 * (size_t)C, T); SIN(memberships, c->memberships, C, uint32_t); SIN(filters, c->filters, C, uint32_t);
+        SIN(cflags, c->collider_flags, C, uint8_t); SIN(collision_margin, c->collision_margin, C, T); SIN(speculative_margin, c->speculative_margin, C, T);
+        launch_pack_colliders<T>(bp, s, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        have_colliders = true;
+        return AVN_OK;
+    }
+    avn_status pairs_get(const avn_pair** out, size_t* n) override {
+        if (!out || !n) return AVN_ERR_BAD_ARG;
+        *out = h_pairs.data();
+        *n = h_pairs.size();
+        return AVN_OK;
+    }
+    avn_status aabbs_download(void* mn, void* mx, uint32_t* ents, size_t* n_iv) override {
+        size_t C = bp.n_colliders, I = bp.n_intervals;
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * C) * 2 + al(4 * I) + 1024);
+        if (st != AVN_OK) return st;
+        T* a = mn ? stage_alloc<T>(3 * C) : nullptr;
+        T* b = mx ? stage_alloc<T>(3 * C) : nullptr;
+        uint32_t* e = ents ? stage_alloc<uint32_t>(I) : nullptr;
+        launch_unpack_aabbs<T>(bp, a, b, e, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(mn, a, 3 * C, T); SOUT(mx, b, 3 * C, T); SOUT(ents, e, I, uint32_t);
+        HIPCHK(hipStreamSynchronize(stream));
+        if (n_iv) *n_iv = I;
+        return AVN_OK;
+    }
+    avn_status update_aabb() {
+        launch_update_aabb<T>(dw, bp, params, stream);
+        ++launches;
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status collect_collision_pairs() {
+        uint32_t n = bp.n_intervals;
+        h_pairs.clear();
+        last_timers.pair_count = 0;
+        if (n == 0) return AVN_OK;
+        uint32_t* misc = b_misc.as<uint32_t>();
+        uint32_t* d_dropped = misc + 33;
+        uint32_t* d_total = misc + 34;
+        Key* keys_a = b_keys_a.as<Key>(); Key* keys_b = b_keys_b.as<Key>();
+        uint32_t* vals_a = b_vals_a.as<uint32_t>(); uint32_t* vals_b = b_vals_b.as<uint32_t>();
+        launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, stream);
+        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), stream);
+        launch_gather_sorted<T>(dw, bp, vals_a, n, stream);
+        launch_sweep<T>(bp, n, false, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
+        launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n, b_block_sums.as<uint32_t>(), d_total, stream);
+        launches += 5 + 5 * (uint32_t)sizeof(Key) + 3;
+        HIPCHK(hipGetLastError());
+        uint32_t rb[2] = {0, 0};
+        HIPCHK(hipMemcpyAsync(rb, d_dropped, 8, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t dropped = rb[0], total = rb[1];
+        if (total) {
+            hipError_t err;
+            b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
+            if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
+            launch_sweep<T>(bp, n, true, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), stream);
+            ++launches;
+            HIPCHK(hipGetLastError());
+            h_pairs.resize(total);
+            HIPCHK(hipMemcpyAsync(h_pairs.data(), b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, stream));
+            // add_edge_and_key_with (reference contact_graph.rs:521-566): the new keys join the pair set
+            HIPCHK(hipStreamSynchronize(stream));
+            std::vector<uint64_t> nk(total);
+            for (uint32_t i = 0; i < total; ++i) { uint32_t a = h_pairs[i].collider1, b = h_pairs[i].collider2; nk[i] = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
+            b_pair_keys.ensure(((size_t)n_pair_keys + total) * 8, err, true, stream);
+            if (err != hipSuccess) { error = "pair key list allocation failed"; return AVN_ERR_OOM; }
+            HIPCHK(hipMemcpyAsync(b_pair_keys.as<uint64_t>() + n_pair_keys, nk.data(), (size_t)total * 8, hipMemcpyHostToDevice, stream));
+            n_pair_keys += total;
+            if (bp.pair_set_cap < 2 * (n_pair_keys + 16)) { avn_status st = rebuild_pair_set(n_pair_keys + n_pair_keys / 2); if (st != AVN_OK) return st; }
+            else { launch_hs_insert(bp.pair_set, bp.pair_set_cap, b_pair_keys.as<uint64_t>() + (n_pair_keys - total), total, stream); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream)); }
+        }
+        bp.n_intervals = n - dropped;  // dropped intervals were sorted to the end
+        last_timers.pair_count = total;
+        return AVN_OK;
+    }
+
+    // ---- systems -------------------------------------------------------------------------------------------
+    avn_status need_bodies() { if (!have_bodies) { error = "no bodies uploaded"; return AVN_ERR_STATE; } return AVN_OK; }
+    void prepare_solver_bodies() { launch_prepare_solver_bodies<T>(dw, stream); ++launches; }
+    void prepare_joints() { if (dw.n_joints) { launch_prepare_distance_joints<T>(dw, stream); ++launches; } }
+    void prepare_contact_constraints() { launch_prepare_contact_constraints<T>(dw, params, stream); ++launches; }
+    void pre_process_velocity_increments() { launch_pre_process_increments<T>(dw, params, stream); ++launches; }
+    void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
+    void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
+    void contact_pass(int pass) { if (dw.n_manifolds) launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, stream); }
+    void xpbd_solve(bool snapshot) {
+        // the reference runs the snapshot and the velocity projection whenever XpbdSolverPlugin is installed; without
+        // joints both are arithmetic no-ops on v/omega only up to "+ 0": they are skipped only when there are no joints
+        if (!dw.n_joints) return;
+        if (snapshot) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
+        launch_joint_schedule<T>(dw, params, 0, (uint32_t)sched_solve.n_components, sched_solve.d_comp_level_begin.as<uint32_t>(),
+                                 sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_order.as<uint32_t>(), stream);
+        ++launches;
+    }
+    void xpbd_velocity_projection() { if (dw.n_joints) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
+    void joint_damping() {
+        if (!any_damped || !sched_damp.n_components) return;
+        if (sched_damp.touches_dummy) {
+            // reset the two virtual SolverBody::DUMMY slots (all-zero bit pattern = zero velocities)
+            (void)hipMemsetAsync(dw.sb_lin + dw.n_bodies, 0, 2 * sizeof(V), stream);
+            (void)hipMemsetAsync(dw.sb_ang + dw.n_bodies, 0, 2 * sizeof(V), stream);
+        }
+        launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp.n_components, sched_damp.d_comp_level_begin.as<uint32_t>(),
+                                 sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_order.as<uint32_t>(), stream);
+        ++launches;
+    }
+    void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)
+        integrate_velocities();
+        contact_pass(PASS_WARM_START);
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_BIAS);
+        integrate_positions();
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_RELAX);
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
+        xpbd_velocity_projection();
+        joint_damping();
+    }
+    avn_status run_substeps() {
+        if (!cfg.use_graph) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
+        if (!graph_valid) {
+            drop_graph();
+            uint32_t before = launches;
+            HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            HIPCHK(hipStreamEndCapture(stream, &graph));
+            graph_launches = launches - before;
+            launches = before;
+            HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+            graph_valid = true;
+        }
+        HIPCHK(hipGraphLaunch(graph_exec, stream));
+        launches += graph_launches;
+        return AVN_OK;
+    }
+    uint32_t graph_launches = 0;
+    avn_status solver() {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        prepare_solver_bodies();
+        prepare_joints();
+        prepare_contact_constraints();
+        pre_process_velocity_increments();
+        HIPCHK(hipEventRecord(ev[2], stream));
+        if ((st = run_substeps()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[3], stream));
+        launch_clear_increments<T>(dw, stream); ++launches;
+        contact_pass(PASS_RESTITUTION_);
+        launch_writeback_solver_bodies<T>(dw, stream); ++launches;
+        if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
+        launch_store_contact_impulses<T>(dw, stream); ++launches;
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status run_system(avn_system sys) override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        switch (sys) {
+            case AVN_SYS_UPDATE_AABB: if ((st = update_aabb()) != AVN_OK) return st; break;
+            case AVN_SYS_COLLECT_COLLISION_PAIRS: if ((st = collect_collision_pairs()) != AVN_OK) return st; break;
+            case AVN_SYS_PREPARE_SOLVER_BODIES: prepare_solver_bodies(); break;
+            case AVN_SYS_PREPARE_JOINTS: prepare_joints(); break;
+            case AVN_SYS_PREPARE_CONTACT_CONSTRAINTS: prepare_contact_constraints(); break;
+            case AVN_SYS_PRE_PROCESS_VELOCITY_INCREMENTS: pre_process_velocity_increments(); break;
+            case AVN_SYS_INTEGRATE_VELOCITIES: integrate_velocities(); break;
+            case AVN_SYS_WARM_START: contact_pass(PASS_WARM_START); break;
+            case AVN_SYS_SOLVE_CONTACTS_BIAS: contact_pass(PASS_SOLVE_BIAS); break;
+            case AVN_SYS_INTEGRATE_POSITIONS: integrate_positions(); break;
+            case AVN_SYS_SOLVE_CONTACTS_RELAX: contact_pass(PASS_SOLVE_RELAX); break;
+            case AVN_SYS_XPBD_SOLVE: xpbd_solve(true); break;
+            case AVN_SYS_XPBD_VELOCITY_PROJECTION: xpbd_velocity_projection(); break;
+            case AVN_SYS_JOINT_DAMPING: joint_damping(); break;
+            case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: launch_clear_increments<T>(dw, stream); break;
+            case AVN_SYS_SOLVE_RESTITUTION: contact_pass(PASS_RESTITUTION_); break;
+            case AVN_SYS_WRITEBACK_SOLVER_BODIES:
+                launch_writeback_solver_bodies<T>(dw, stream);
+                if (dw.n_joints) launch_writeback_joint_forces<T>(dw, params, stream);
+                break;
+            case AVN_SYS_STORE_CONTACT_IMPULSES: launch_store_contact_impulses<T>(dw, stream); break;
+            case AVN_SYS_SUBSTEP: substep(); break;
+            case AVN_SYS_SOLVER: {
+                HIPCHK(hipEventRecord(ev[0], stream)); HIPCHK(hipEventRecord(ev[1], stream));
+                if ((st = solver()) != AVN_OK) return st;
+                HIPCHK(hipEventRecord(ev[4], stream));
+                ev_valid = true;
+                break;
+            }
+            default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
+        }
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status step() override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        launches = 0;
+        HIPCHK(hipEventRecord(ev[0], stream));
+        if (have_colliders) {
+            if ((st = update_aabb()) != AVN_OK) return st;
+            if ((st = collect_collision_pairs()) != AVN_OK) return st;
+        }
+        HIPCHK(hipEventRecord(ev[1], stream));
+        if ((st = solver()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[4], stream));
+        ev_valid = true;
+        last_timers.kernel_launches = launches;
+        return AVN_OK;
+    }
+    avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); return AVN_OK; }
+    avn_status timers(avn_timers* t) override {
+        if (!t) return AVN_ERR_BAD_ARG;
+        HIPCHK(hipStreamSynchronize(stream));
+        if (ev_valid) {
+            float a = 0, b = 0, c = 0, d = 0;
+            HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
+            HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
+            HIPCHK(hipEventElapsedTime(&c, ev[2], ev[3]));
+            HIPCHK(hipEventElapsedTime(&d, ev[3], ev[4]));
+            last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;
+            last_timers.step_ms = (double)a + b + c + d;
+        }
+        uint32_t cc = 0;
+        HIPCHK(hipMemcpy(&cc, dw.constraint_count, 4, hipMemcpyDeviceToHost));
+        last_timers.contact_constraint_count = cc;
+        *t = last_timers;
+        return AVN_OK;
+    }
+};
+
+template <class T> static WorldBase* make_world(const avn_config* cfg, avn_status* st, std::string* err) {
+    World<T>* w = new (std::nothrow) World<T>();
+    if (!w) { *st = AVN_ERR_OOM; *err = "out of host memory"; return nullptr; }
+    *st = w->init(cfg);
+    if (*st != AVN_OK) { *err = w->error; delete w; return nullptr; }
+    return w;
+}
+WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err) { return make_world<float>(cfg, st, err); }
+WorldBase* make_world_f64(const avn_config* cfg, avn_status* st, std::string* err) { return make_world<double>(cfg, st, err); }
+
+// ---- ConstraintGraphHost (reference solver/constraint_graph.rs:163-296) ------------------------------------
+static inline bool bit_get(const std::vector<uint64_t>& s, uint32_t i) { return (i >> 6) < s.size() && ((s[i >> 6] >> (i & 63)) & 1ull); }
+static inline void bit_set_and_grow(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) >= s.size()) s.resize((i >> 6) + 1, 0ull); s[i >> 6] |= 1ull << (i & 63); }
+static inline void bit_unset(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) < s.size()) s[i >> 6] &= ~(1ull << (i & 63)); }
+int ConstraintGraphHost::push_manifold(uint64_t handle, uint32_t body1, uint32_t body2, bool is_static1, bool is_static2) {
+    if (where.count(handle)) return -1;
+    int color_index = AVN_COLOR_OVERFLOW_INDEX;
+    if (!is_static1 && !is_static2) {
+        // dynamic-vs-dynamic constraints only use colours 0..19
+        for (int i = 0; i < AVN_DYNAMIC_COLOR_COUNT; ++i) {
+            Color& c = colors[i];
+            if (bit_get(c.body_bits, body1) || bit_get(c.body_bits, body2)) continue;
+            bit_set_and_grow(c.body_bits, body1);
+            bit_set_and_grow(c.body_bits, body2);
+            color_index = i;
+            break;
+        }
+    } else if (!is_static1 || !is_static2) {
+        // static colours are filled from the end (22 down to 1); only the non-static body is marked
+        uint32_t body = !is_static1 ? body1 : body2;
+        for (int i = AVN_COLOR_OVERFLOW_INDEX - 1; i >= 1; --i) {
+            Color& c = colors[i];
+            if (bit_get(c.body_bits, body)) continue;
+            bit_set_and_grow(c.body_bits, body);
+            color_index = i;
+            break;
+        }
+    }
+    Color& c = colors[color_index];
+    where[handle] = Loc{(uint8_t)color_index, (uint32_t)c.manifold_handles.size()};
+    c.manifold_handles.push_back(Handle{handle, body1, body2});
+    return color_index;
+}
+bool ConstraintGraphHost::pop_manifold(uint64_t handle) {
+    auto it = where.find(handle);
+    if (it == where.end()) return false;
+    Loc loc = it->second;
+    where.erase(it);
+    Color& c = colors[loc.color];
+    Handle h = c.manifold_handles[loc.local_index];
+    if (loc.color != AVN_COLOR_OVERFLOW_INDEX) { bit_unset(c.body_bits, h.body1); bit_unset(c.body_bits, h.body2); }
+    uint32_t moved_index = (uint32_t)c.manifold_handles.size() - 1;
+    c.manifold_handles[loc.local_index] = c.manifold_handles[moved_index];
+    c.manifold_handles.pop_back();
+    if (moved_index != loc.local_index) where[c.manifold_handles[loc.local_index].handle].local_index = loc.local_index;
+    return true;
+}
+
+}  // namespace avn

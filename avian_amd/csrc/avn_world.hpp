@@ -1,0 +1,86 @@
+// avn_world.hpp — host side of the MI355X physics step (C++), mirroring the reference's plugin/system
+// structure for the hot path:
+//
+//   reference plugin (file)                                   here
+//   ---------------------------------------------------------+-----------------------------------------------
+//   SolverBodyPlugin   (solver/solver_body/plugin.rs:21-122)  World::prepare_solver_bodies / writeback_solver_bodies
+//   IntegratorPlugin   (integrator/mod.rs:45-88)              World::pre_process_velocity_increments / integrate_*
+//   SolverPlugin       (solver/plugin.rs:88-151)              World::prepare_contact_constraints / warm_start /
+//                                                             solve_contacts / solve_restitution / store_contact_impulses
+//   XpbdSolverPlugin   (solver/xpbd/plugin.rs:21-110)         World::prepare_joints / xpbd_solve / xpbd_velocity_projection
+//   BroadPhasePlugin   (collision/broad_phase.rs:33-170)      World::update_aabb / collect_collision_pairs
+//   SolverSchedulePlugin (solver/schedule.rs:17-72)           World::substep / World::solver (system ORDER only)
+//
+// Everything runs on one HIP stream owned by the world; the substep loop can be replayed from a hipGraph.
+// There is NO CPU fallback: without a gfx950 device world creation fails with AVN_ERR_NO_DEVICE.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "avn_kernels.h"
+
+namespace avn {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    ~DevBuf();
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    // grows (never shrinks); returns true when the pointer changed; contents are NOT preserved unless keep
+    bool ensure(size_t bytes, hipError_t& err, bool keep = false, hipStream_t s = nullptr);
+    template <class U> U* as() const { return (U*)p; }
+};
+
+// Host-built execution schedule that makes a serial joint loop parallel without changing its result
+// (see k_xpbd.hip header).
+struct JointSchedule {
+    std::vector<uint32_t> comp_level_begin, level_offsets, order;
+    uint32_t n_components = 0;
+    bool touches_dummy = false;
+    DevBuf d_comp_level_begin, d_level_offsets, d_order;
+    // bodies: per joint the two scheduling keys (body index, or -1 = does not serialise), in joint order
+    void build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys);
+};
+
+struct WorldBase {
+    std::string error;
+    virtual ~WorldBase() {}
+    virtual avn_status config_set(const avn_config*) = 0;
+    virtual avn_status bodies_upload(const avn_bodies*) = 0;
+    virtual avn_status bodies_download(const avn_bodies_out*) = 0;
+    virtual avn_status solver_bodies_download(const avn_solver_bodies_out*) = 0;
+    virtual avn_status manifolds_upload(const avn_manifolds*) = 0;
+    virtual avn_status impulses_download(const avn_impulses_out*) = 0;
+    virtual avn_status constraints_download(const avn_constraints_out*) = 0;
+    virtual avn_status distance_joints_upload(const avn_distance_joints*) = 0;
+    virtual avn_status joints_download(const avn_joints_out*) = 0;
+    virtual avn_status colliders_upload(const avn_colliders*) = 0;
+    virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;
+    virtual avn_status pairs_get(const avn_pair**, size_t*) = 0;
+    virtual avn_status aabbs_download(void*, void*, uint32_t*, size_t*) = 0;
+    virtual avn_status run_system(avn_system) = 0;
+    virtual avn_status step() = 0;
+    virtual avn_status synchronize() = 0;
+    virtual avn_status timers(avn_timers*) = 0;
+};
+
+WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err);
+WorldBase* make_world_f64(const avn_config* cfg, avn_status* st, std::string* err);
+
+// Host ConstraintGraph (reference solver/constraint_graph.rs:129-296)
+struct ConstraintGraphHost {
+    struct Handle { uint64_t handle; uint32_t body1, body2; };
+    struct Color { std::vector<uint64_t> body_bits; std::vector<Handle> manifold_handles; };
+    struct Loc { uint8_t color; uint32_t local_index; };
+    Color colors[AVN_GRAPH_COLOR_COUNT];
+    std::unordered_map<uint64_t, Loc> where;
+    int push_manifold(uint64_t handle, uint32_t body1, uint32_t body2, bool is_static1, bool is_static2);
+    bool pop_manifold(uint64_t handle);
+};
+
+}  // namespace avn

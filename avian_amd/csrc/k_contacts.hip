@@ -1,0 +1,389 @@
+// k_contacts.hip — TGS-Soft contact solver kernels (one thread per contact manifold).
+//
+// Parallel unit: a graph colour (reference constraint_graph.rs:36-48): within colours 0..22 no two
+// manifolds share a non-static body, so one launch per colour solves all its manifolds concurrently with
+// plain loads/stores (no atomics).  The overflow colour (23) is solved first and serially, in list order,
+// exactly like the reference (solver/plugin.rs:461-467).  The points of one manifold are solved
+// sequentially by the owning thread (Gauss-Seidel order inside ContactConstraint::solve).
+//
+// Memory: constraint records are [point][manifold] Vec4 arrays, so the 64 lanes of a wave (64 consecutive
+// manifolds of one colour) read 1 KiB contiguous per load instruction; body state is gathered with six
+// aligned Vec4 loads per body (L2 / Infinity-Cache resident) and scattered back with two.
+// Bound: HBM stream of the constraint records (248+88P B read/written per manifold pass).
+//
+// Reference functions replaced (paths relative to /root/reference/src/dynamics/solver):
+//   k_prepare_contact_constraints  plugin.rs:363-448, contact/mod.rs:110-220,427-449,
+//                                  contact/normal_part.rs:39-112, contact/tangent_part.rs:35-151
+//   k_warm_start                   plugin.rs:453-515, contact/mod.rs:223-264
+//   k_solve_contacts<USE_BIAS>     plugin.rs:531-619, contact/mod.rs:267-354,
+//                                  normal_part.rs:116-166, tangent_part.rs:155-244
+//   k_solve_restitution            plugin.rs:630-718, contact/mod.rs:358-407
+//   k_store_contact_impulses       plugin.rs:722-755
+#include "avn_kernels.h"
+
+namespace avn {
+
+#define CONTACT_THREADS 64
+
+template <class T> struct BodyRef {
+    V3<T> v, om, dp;
+    Q4<T> dq;
+    V3<T> inv_mass;  // effective_inv_mass()
+    Sym3<T> I;       // effective_inv_angular_inertia()
+    T lin_w, ang_w;  // pass-through w lanes
+};
+
+// Fetch SolverBody + SolverBodyInertia, substituting DUMMY for a missing body and a DUMMY inertia for a
+// dominant one (solver/plugin.rs:491-512).
+template <class T, bool WITH_DELTA>
+__device__ __forceinline__ void load_body(const DW<T>& w, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
+    if (no_body) {
+        b.v = vzero<T>(); b.om = vzero<T>(); b.dp = vzero<T>(); b.dq = qidentity<T>();
+        b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); b.lin_w = 0; b.ang_w = 0;
+        return;
+    }
+    Vec4<T> l = w.sb_lin[idx], a = w.sb_ang[idx];
+    b.v = xyz<T>(l); b.om = xyz<T>(a); b.lin_w = l.w; b.ang_w = a.w;
+    if (WITH_DELTA) { b.dp = xyz<T>(w.sb_dp[idx]); b.dq = quat<T>(w.sb_dq[idx]); }
+    else { b.dp = vzero<T>(); b.dq = qidentity<T>(); }
+    if (dummy_inertia) { b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); }
+    else {
+        Vec4<T> sa = w.si_a[idx], sb = w.si_b[idx];
+        b.inv_mass = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
+        b.I = Sym3<T>{sa.y, sa.z, sa.w, sb.x, sb.y, sb.z};
+    }
+}
+template <class T> __device__ __forceinline__ void store_body(const DW<T>& w, int idx, bool no_body, const BodyRef<T>& b) {
+    if (no_body) return;  // writes to a DUMMY body are discarded
+    w.sb_lin[idx] = make4<T>(b.v, b.lin_w);
+    w.sb_ang[idx] = make4<T>(b.om, b.ang_w);
+}
+template <class T> __device__ __forceinline__ void apply_impulse(BodyRef<T>& b1, BodyRef<T>& b2, V3<T> imp, V3<T> r1, V3<T> r2) {
+    b1.v = b1.v - cmul(imp, b1.inv_mass);
+    b1.om = b1.om - smul(b1.I, cross(r1, imp));
+    b2.v = b2.v + cmul(imp, b2.inv_mass);
+    b2.om = b2.om + smul(b2.I, cross(r2, imp));
+}
+template <class T> __device__ __forceinline__ V3<T> velocity_at_point(const BodyRef<T>& b, V3<T> p) { return b.v + cross(b.om, p); }
+
+// ------------------------------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, StepParams<T> p) {
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    bool generated = false;
+    if (m < w.n_manifolds) {
+        uint32_t mm = w.m_meta[m];
+        uint32_t np = mm & 7u, mflags = mm >> 8;
+        int2 b = w.m_bodies[m];
+        uint32_t meta1 = w.bmeta[b.x], meta2 = w.bmeta[b.y];
+        bool skip = !(mflags & AVN_MANIFOLD_GENERATES_CONSTRAINTS) || !meta_active(meta1) || !meta_active(meta2) ||
+                    (meta_rb_type(meta1) != AVN_RB_DYNAMIC && meta_rb_type(meta2) != AVN_RB_DYNAMIC) || np == 0;
+        if (skip) {
+            w.c_h1[m] = make4<T>(0, 0, 0, bits_to_scalar(0u, T(0)));
+            w.c_reldom[m] = 0;
+        } else {
+            bool nobody1 = !meta_has_solver_body(meta1), nobody2 = !meta_has_solver_body(meta2);
+            // SolverBodyInertia (DUMMY rows were written by k_prepare_solver_bodies for bodies without a SolverBody)
+            Vec4<T> sa1 = w.si_a[b.x], sb1 = w.si_b[b.x], sa2 = w.si_a[b.y], sb2 = w.si_b[b.y];
+            uint32_t if1 = scalar_to_bits(sb1.w), if2 = scalar_to_bits(sb2.w);
+            int dom1 = (int)(int16_t)(if1 >> 16), dom2 = (int)(int16_t)(if2 >> 16);
+            int relative_dominance = dom1 - dom2;
+            V3<T> inv_mass1 = effective_inv_mass<T>(sa1.x, if1), inv_mass2 = effective_inv_mass<T>(sa2.x, if2);
+            Sym3<T> i1{sa1.y, sa1.z, sa1.w, sb1.x, sb1.y, sb1.z}, i2{sa2.y, sa2.z, sa2.w, sb2.x, sb2.y, sb2.z};
+            if (relative_dominance > 0) { inv_mass1 = vzero<T>(); i1 = sym_zero<T>(); }
+            else if (relative_dominance < 0) { inv_mass2 = vzero<T>(); i2 = sym_zero<T>(); }
+            SoftCoef<T> soft = relative_dominance != 0 ? p.soft_non_dynamic : p.soft_dynamic;
+            (void)soft;  // coefficients are step constants: only the choice is stored per manifold
+            V3<T> w_sum = inv_mass1 + inv_mass2;
+            Vec4<T> n4 = w.m_n[m];
+            V3<T> normal = xyz<T>(n4);
+            T friction = n4.w;
+            // compute_tangent_directions (contact/mod.rs:427-449) from the LinearVelocity COMPONENTS
+            V3<T> force_direction = -normal;
+            V3<T> relative_velocity = xyz<T>(w.lvel[b.x]) - xyz<T>(w.lvel[b.y]);
+            V3<T> tangent_velocity = relative_velocity - force_direction * dot(force_direction, relative_velocity);
+            V3<T> t0;
+            if (!try_normalize(tangent_velocity, t0)) t0 = any_orthonormal_vector(force_direction);
+            V3<T> t1 = cross(force_direction, t0);
+            bool warm = p.match_contacts != 0;
+            bool has_tangent = friction > T(0);
+            uint32_t S = w.m_stride;
+            for (uint32_t k = 0; k < np; ++k) {
+                uint32_t s = k * S + m;
+                Vec4<T> a1 = w.mp_a1[s], a2 = w.mp_a2[s], ww = w.mp_w[s];
+                V3<T> r1 = xyz<T>(a1), r2 = xyz<T>(a2);
+                T penetration = a1.w, normal_speed = a2.w;
+                // ContactNormalPart::generate
+                V3<T> r1_cross_n = cross(r1, normal), r2_cross_n = cross(r2, normal);
+                T k_linear = dot(normal, cmul(w_sum, normal));
+                T kk = k_linear + dot(r1_cross_n, smul(i1, r1_cross_n)) + dot(r2_cross_n, smul(i2, r2_cross_n));
+                T eff_mass = recip_or_zero(kk);
+                T ni = warm ? ww.x : T(0);
+                T k0 = 0, k1 = 0, k2 = 0, tx = 0, ty = 0;
+                if (has_tangent) {  // ContactTangentPart::generate
+                    V3<T> rt11 = cross(r1, t0), rt12 = cross(r2, t0), rt21 = cross(r1, t1), rt22 = cross(r2, t1);
+                    V3<T> i1_rt11 = smul(i1, rt11), i2_rt12 = smul(i2, rt12), i1_rt21 = smul(i1, rt21), i2_rt22 = smul(i2, rt22);
+                    T k_linear1 = dot(t0, cmul(w_sum, t0));
+                    T k_linear2 = dot(t1, cmul(w_sum, t1));
+                    k0 = k_linear1 + dot(rt11, i1_rt11) + dot(rt12, i2_rt12);
+                    k1 = k_linear2 + dot(rt21, i1_rt21) + dot(rt22, i2_rt22);
+                    k2 = T(2) * (dot(rt11, i1_rt21) + dot(rt12, i2_rt22));
+                    if (warm) { tx = ww.y; ty = ww.z; }
+                }
+                T initial_separation = -penetration - dot(r2 - r1, normal);
+                w.c_pa[s] = make4<T>(r1, initial_separation);
+                w.c_pb[s] = make4<T>(r2, eff_mass);
+                w.c_pc[s] = make4<T>(k0, k1, k2, normal_speed);
+                w.c_pd[s] = make4<T>(ni, T(0), tx, ty);
+            }
+            uint32_t cm = np;
+            if (relative_dominance > 0) cm |= AVN_CM_DOM1;
+            if (relative_dominance < 0) cm |= AVN_CM_DOM2;
+            if (relative_dominance != 0) cm |= AVN_CM_SOFT_ND;
+            if (has_tangent) cm |= AVN_CM_TANGENT;
+            if (nobody1) cm |= AVN_CM_NOBODY1;
+            if (nobody2) cm |= AVN_CM_NOBODY2;
+            w.c_h1[m] = make4<T>(t0, bits_to_scalar(cm, T(0)));
+            w.c_reldom[m] = (int16_t)relative_dominance;
+            generated = true;
+        }
+    }
+    unsigned long long bal = __ballot(generated);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(w.constraint_count, (uint32_t)__popcll(bal));
+}
+
+// ------------------------------------------------------------------------------------------------------
+template <class T> __device__ __forceinline__ void warm_start_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    Vec4<T> h1 = w.c_h1[m];
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    if (np == 0) return;
+    int2 b = w.m_bodies[m];
+    V3<T> normal = xyz<T>(w.m_n[m]);
+    V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
+    BodyRef<T> b1, b2;
+    load_body<T, false>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    uint32_t S = w.m_stride;
+    T coeff = p.warm_start_coefficient;
+    for (uint32_t k = 0; k < np; ++k) {
+        uint32_t s = k * S + m;
+        V3<T> r1 = xyz<T>(w.c_pa[s]), r2 = xyz<T>(w.c_pb[s]);
+        Vec4<T> d = w.c_pd[s];
+        T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
+        V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
+        apply_impulse(b1, b2, imp, r1, r2);
+    }
+    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
+    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+}
+
+template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    Vec4<T> h1 = w.c_h1[m];
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    if (np == 0) return;
+    int2 b = w.m_bodies[m];
+    Vec4<T> h0 = w.m_n[m];
+    V3<T> normal = xyz<T>(h0);
+    T friction = h0.w;
+    BodyRef<T> b1, b2;
+    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    uint32_t S = w.m_stride;
+    // issue every record load of the manifold up front (memory-level parallelism: the kernel is latency-bound
+    // at one manifold per lane), then run the sequential impulse iteration out of registers
+    Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k < np) {
+            uint32_t s = k * S + m;
+            pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pd[k] = w.c_pd[s];
+            if (cm & AVN_CM_TANGENT) pc[k] = w.c_pc[s];
+        }
+    }
+    SoftCoef<T> soft = (cm & AVN_CM_SOFT_ND) ? p.soft_non_dynamic : p.soft_dynamic;
+    T delta_secs = p.h_adj;
+    V3<T> delta_translation = b2.dp - b1.dp;
+    // normal impulses
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k < np) {
+            V3<T> a1 = xyz<T>(pa[k]), a2 = xyz<T>(pb[k]);
+            V3<T> r1w = qrot(b1.dq, a1), r2w = qrot(b2.dq, a2);
+            V3<T> delta_separation = delta_translation + (r2w - r1w);
+            T separation = dot(delta_separation, normal) + pa[k].w;
+            V3<T> relative_velocity = velocity_at_point(b2, a2) - velocity_at_point(b1, a1);
+            // ContactNormalPart::solve_impulse
+            T normal_speed = dot(relative_velocity, normal);
+            T eff_mass = pb[k].w, acc = pd[k].x;
+            T impulse;
+            if (separation > T(0)) {
+                impulse = -eff_mass * (normal_speed + separation / delta_secs);
+            } else if (USE_BIAS) {
+                T bias = smax(soft.bias * separation, -p.max_overlap_solve_speed);
+                T scaled_mass = soft.mass_scale * eff_mass;
+                T scaled_impulse = soft.impulse_scale * acc;
+                impulse = -scaled_mass * (normal_speed + bias) - scaled_impulse;
+            } else {
+                impulse = -eff_mass * normal_speed;
+            }
+            T new_impulse = smax(acc + impulse, T(0));
+            impulse = new_impulse - acc;
+            pd[k].x = new_impulse;
+            pd[k].y = pd[k].y + new_impulse;  // total_impulse += new accumulated value (normal_part.rs:162)
+            apply_impulse(b1, b2, impulse * normal, a1, a2);
+        }
+    }
+    // friction
+    if (cm & AVN_CM_TANGENT) {
+        V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);
+        V3<T> surface_velocity = xyz<T>(w.m_tv[m]);
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            if (k < np) {
+                V3<T> a1 = xyz<T>(pa[k]), a2 = xyz<T>(pb[k]);
+                V3<T> relative_velocity = velocity_at_point(b2, a2) - velocity_at_point(b1, a1);
+                // ContactTangentPart::solve_impulse
+                T impulse_limit = friction * pd[k].x;
+                V3<T> rv = relative_velocity + surface_velocity;
+                T ts1 = dot(rv, t0), ts2 = dot(rv, t1);
+                T t11 = ts1 * ts1, t22 = ts2 * ts2, t12 = ts1 * ts2;
+                T inv = t11 * pc[k].x + t22 * pc[k].y + t12 * pc[k].z;
+                T effective_mass = (t11 + t22) * (T(1) / inv);
+                if (finite_t(effective_mass)) {
+                    V2<T> delta{effective_mass * ts1, effective_mass * ts2};
+                    V2<T> ni = clamp_length_max(V2<T>{pd[k].z - delta.x, pd[k].w - delta.y}, impulse_limit);
+                    V2<T> di{ni.x - pd[k].z, ni.y - pd[k].w};
+                    pd[k].z = ni.x; pd[k].w = ni.y;
+                    apply_impulse(b1, b2, di.x * t0 + di.y * t1, a1, a2);
+                } else {
+                    // returns Vector::ZERO; the reference still applies the zero impulse (v -= 0)
+                    apply_impulse(b1, b2, vzero<T>(), a1, a2);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
+        if (k < np) w.c_pd[k * S + m] = pd[k];
+    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
+    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+}
+
+template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    Vec4<T> h1 = w.c_h1[m];
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    if (np == 0) return;
+    T restitution = w.m_tv[m].w;
+    if (restitution == T(0)) return;
+    int2 b = w.m_bodies[m];
+    V3<T> normal = xyz<T>(w.m_n[m]);
+    BodyRef<T> b1, b2;
+    load_body<T, false>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    uint32_t S = w.m_stride;
+    uint32_t iterations = np > 1 ? p.restitution_iterations : 1u;
+    T threshold = p.restitution_threshold;
+    for (uint32_t it = 0; it < iterations; ++it)
+        for (uint32_t k = 0; k < np; ++k) {
+            uint32_t s = k * S + m;
+            Vec4<T> pa = w.c_pa[s], pb = w.c_pb[s], pc = w.c_pc[s], pd = w.c_pd[s];
+            T pre_normal_speed = pc.w;
+            if (pre_normal_speed > -threshold || pd.y == T(0)) continue;
+            V3<T> a1 = xyz<T>(pa), a2 = xyz<T>(pb);
+            V3<T> relative_velocity = velocity_at_point(b2, a2) - velocity_at_point(b1, a1);
+            T normal_speed = dot(relative_velocity, normal);
+            T impulse = -pb.w * (normal_speed + restitution * pre_normal_speed);
+            T new_impulse = smax(pd.x + impulse, T(0));
+            impulse = new_impulse - pd.x;
+            pd.x = new_impulse;
+            pd.y = pd.y + impulse;
+            w.c_pd[s] = pd;
+            apply_impulse(b1, b2, impulse * normal, a1, a2);
+        }
+    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
+    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+}
+
+enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
+template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    if (PASS == PASS_WARM) warm_start_one<T>(w, p, m);
+    else if (PASS == PASS_BIAS) solve_one<T, true>(w, p, m);
+    else if (PASS == PASS_RELAX) solve_one<T, false>(w, p, m);
+    else restitution_one<T>(w, p, m);
+}
+
+// One colour: manifolds [offsets[c], offsets[c+1]) read from device memory so that a captured graph stays
+// valid while the colour populations drift; the grid is a multiple of 8 blocks and remapped per XCD.
+template <class T, int PASS>
+__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepParams<T> p, uint32_t color) {
+    uint32_t base = w.color_offsets[color], end = w.color_offsets[color + 1];
+    uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    uint32_t m = base + blk * CONTACT_THREADS + threadIdx.x;
+    if (m >= end) return;
+    pass_one<T, PASS>(w, p, m);
+}
+// The overflow colour: strictly serial in manifold_handles order (solver/plugin.rs:461-467).
+template <class T, int PASS>
+__global__ __launch_bounds__(64) void k_overflow_pass(DW<T> w, StepParams<T> p) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t base = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX], end = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
+    for (uint32_t m = base; m < end; ++m) {
+        pass_one<T, PASS>(w, p, m);  // same thread: program order makes the previous manifold's body writes visible
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_store_contact_impulses(DW<T> w) {
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= w.n_manifolds) return;
+    uint32_t cm = scalar_to_bits(w.c_h1[m].w);
+    uint32_t np = cm & 7u;
+    uint32_t S = w.m_stride;
+    for (uint32_t k = 0; k < np; ++k) {
+        uint32_t s = k * S + m;
+        Vec4<T> d = w.c_pd[s];
+        bool t = cm & AVN_CM_TANGENT;
+        w.mp_w[s] = make4<T>(d.x, t ? d.z : T(0), t ? d.w : T(0), d.y);
+    }
+}
+
+// ---- launchers ------------------------------------------------------------------------------------------
+template <class T> void launch_prepare_contact_constraints(const DW<T>& w, const StepParams<T>& p, hipStream_t s) {
+    (void)hipMemsetAsync(w.constraint_count, 0, sizeof(uint32_t), s);
+    if (w.n_manifolds) hipLaunchKernelGGL(k_prepare_contact_constraints<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, p);
+}
+template <class T> void launch_store_contact_impulses(const DW<T>& w, hipStream_t s) {
+    if (w.n_manifolds) hipLaunchKernelGGL(k_store_contact_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w);
+}
+uint32_t color_grid_blocks(uint32_t count) {
+    uint32_t nb = (count + CONTACT_THREADS - 1) / CONTACT_THREADS;
+    return ((nb + 7u) / 8u) * 8u;
+}
+template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, hipStream_t s) {
+    uint32_t launches = 0;
+    if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX]) { hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(1), dim3(64), 0, s, w, p); ++launches; }
+    for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
+        if (grid_blocks[c]) { hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c); ++launches; }
+    return launches;
+}
+template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, hipStream_t s) {
+    switch (pass) {
+        case PASS_WARM: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, s);
+        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, s);
+        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, s);
+        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, s);
+    }
+}
+
+#define INST(T)                                                                                             \
+    template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
+    template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
+    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, hipStream_t);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace avn

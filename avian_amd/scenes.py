@@ -1,0 +1,223 @@
+"""Synthetic scenes (numpy) for tests and ``bench.py``: deterministic inputs of the shape the reference's
+benches use (``benches/src/dim3/large_pyramid.rs:15-40``, ``many_pyramids.rs:15-64``, ``src/tests/mod.rs:51-85``)
+and BASELINE.json's configs.
+
+The narrow phase is OUT of the hot path (parry3d): contact manifolds are produced here by a
+small axis-aligned box/box face-contact generator (unrotated cuboids only) purely as solver INPUT.  It is not a
+restatement of parry and nothing is claimed about its parity.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import _ffi as F
+
+
+@dataclass
+class Scene:
+    """Host-side ECS tables of one scene (float64 masters; converted to the world's scalar on upload)."""
+    position: np.ndarray
+    rotation: np.ndarray
+    linear_velocity: np.ndarray
+    angular_velocity: np.ndarray
+    inv_mass: np.ndarray
+    inv_inertia_local: np.ndarray
+    rb_type: np.ndarray
+    half_extents: np.ndarray            # cuboid half extents per body (one collider per body)
+    shape: np.ndarray
+    friction: float = 0.5               # Friction::default, combined with CoefficientCombine::Average
+    restitution: float = 0.0
+    extra: Dict[str, np.ndarray] = field(default_factory=dict)
+
+    @property
+    def n(self) -> int:
+        return len(self.inv_mass)
+
+    def body_kwargs(self):
+        kw = dict(position=self.position, rotation=self.rotation, linear_velocity=self.linear_velocity,
+                  angular_velocity=self.angular_velocity, inv_mass=self.inv_mass,
+                  inv_inertia_local=self.inv_inertia_local, rb_type=self.rb_type)
+        kw.update(self.extra)
+        return kw
+
+    def collider_kwargs(self):
+        n = self.n
+        return dict(entity_index=np.arange(n, dtype=np.uint32), body=np.arange(n, dtype=np.int32), shape=self.shape,
+                    half_extents=self.half_extents)
+
+
+def cuboid_mass_properties(hx, hy, hz, density=1.0):
+    """parry mass properties of a cuboid (collider/parry/mod.rs:509-522): m = rho*8hxhyhz, I = m/3*(hy²+hz², ...)."""
+    m = density * 8.0 * hx * hy * hz
+    ixx = m / 3.0 * (hy * hy + hz * hz)
+    iyy = m / 3.0 * (hx * hx + hz * hz)
+    izz = m / 3.0 * (hx * hx + hy * hy)
+    return m, (ixx, iyy, izz)
+
+
+def _assemble(centers, half, ground_center, ground_half) -> Scene:
+    """Static ground (body 0) + dynamic unit-density cuboids."""
+    n = len(centers) + 1
+    pos = np.zeros((n, 3))
+    pos[0] = ground_center
+    pos[1:] = centers
+    rot = np.zeros((n, 4)); rot[:, 3] = 1.0
+    he = np.zeros((n, 3)); he[0] = ground_half; he[1:] = half
+    m, (ixx, iyy, izz) = cuboid_mass_properties(*half)
+    inv_mass = np.full(n, 1.0 / m); inv_mass[0] = 0.0
+    inv_i = np.zeros((n, 6)); inv_i[1:, 0] = 1.0 / ixx; inv_i[1:, 3] = 1.0 / iyy; inv_i[1:, 5] = 1.0 / izz
+    rb = np.zeros(n, np.uint8); rb[0] = F.RB_STATIC
+    return Scene(pos, rot, np.zeros((n, 3)), np.zeros((n, 3)), inv_mass, inv_i, rb, he, np.zeros(n, np.uint8))
+
+
+def box_stack(nx: int, ny: int, nz: int, spacing_xz: float = 1.0, y_scale: float = 0.99) -> Scene:
+    """cfg2 of SURVEY.md §8d: nx*ny*nz unit cubes, y = (2j+1)*0.5*0.99 as large_pyramid.rs:28, ground 800x40x800."""
+    h = 0.5
+    ix, iy, iz = np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij")
+    x = (ix - (nx - 1) * 0.5) * spacing_xz
+    z = (iz - (nz - 1) * 0.5) * spacing_xz
+    y = (2.0 * iy + 1.0) * h * y_scale
+    centers = np.stack([x.ravel(), y.ravel(), z.ravel()], axis=1)
+    return _assemble(centers, (h, h, h), (0.0, -20.0, 0.0), (400.0, 20.0, 400.0))
+
+
+def falling_grid(n_side: int = 10, spacing: float = 1.5, lowest_y: float = 2.0) -> Scene:
+    """cfg1 of SURVEY.md §8d: n_side³ unit cuboids, grid spacing 1.5, ground cuboid(200,1,200) centred y=-0.5."""
+    ix, iy, iz = np.meshgrid(np.arange(n_side), np.arange(n_side), np.arange(n_side), indexing="ij")
+    c = np.stack([(ix.ravel() - (n_side - 1) * 0.5) * spacing, lowest_y + iy.ravel() * spacing,
+                  (iz.ravel() - (n_side - 1) * 0.5) * spacing], axis=1)
+    return _assemble(c, (0.5, 0.5, 0.5), (0.0, -0.5, 0.0), (100.0, 0.5, 100.0))
+
+
+def large_pyramid(base_count: int = 100) -> Scene:
+    """The reference's "Large Pyramid 3D" bench scene (benches/src/dim3/large_pyramid.rs:15-40), f32 arithmetic."""
+    h = np.float32(0.5)
+    cs = []
+    for i in range(base_count):
+        y = (np.float32(2.0) * np.float32(i) + np.float32(1.0)) * h * np.float32(0.99)
+        for j in range(i, base_count):
+            x = (np.float32(i) + np.float32(1.0)) * h + np.float32(2.0) * np.float32(j - i) * h - h * np.float32(base_count)
+            cs.append((float(x), float(y), 0.0))
+    return _assemble(np.array(cs), (0.5, 0.5, 0.5), (0.0, -20.0, 0.0), (400.0, 20.0, 400.0))
+
+
+def cubes_test_scene() -> Scene:
+    """src/tests/mod.rs:51-85: 4x4x4 cubes of side 2 dropped on an 80x1x80 floor."""
+    radius = 1.0
+    cs = []
+    for y in range(4):
+        for x in range(4):
+            for z in range(4):
+                cs.append(((x - 2.0) * 2.1 * radius, 10.0 * radius * y + 5.0, (z - 2.0) * 2.1 * radius))
+    return _assemble(np.array(cs), (1.0, 1.0, 1.0), (0.0, -1.0, 0.0), (40.0, 0.5, 40.0))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def axis_aligned_manifolds(scene: Scene, pairs: np.ndarray, prediction: float = 0.005):
+    """Face-contact manifolds between UNROTATED cuboids for the given (body1, body2) pairs.
+
+    Returns a dict of per-manifold arrays in ``pairs`` order (pairs without a face contact are dropped):
+    body1, body2, normal (from body1 to body2), point_count (=4), anchor1/2 [M,4,3], penetration [M,4],
+    normal_speed [M,4].  Synthetic solver input only (see module docstring).
+    """
+    b1 = pairs[:, 0].astype(np.int64); b2 = pairs[:, 1].astype(np.int64)
+    c1, c2 = scene.position[b1], scene.position[b2]
+    h1, h2 = scene.half_extents[b1], scene.half_extents[b2]
+    d = c2 - c1
+    # per-axis penetration (positive = overlapping)
+    pen = (h1 + h2) - np.abs(d)
+    # contact axis: smallest penetration among the axes (all must be > -prediction to touch at all)
+    touching = np.all(pen > -prediction, axis=1)
+    axis = np.argmin(pen, axis=1)
+    # the overlap rectangle in the two tangent axes must have positive area (face contact, not edge/corner)
+    lo = np.maximum(c1 - h1, c2 - h2); hi = np.minimum(c1 + h1, c2 + h2)
+    ext = hi - lo
+    rows = np.arange(len(b1))
+    t1 = (axis + 1) % 3; t2 = (axis + 2) % 3
+    face = (ext[rows, t1] > 1e-9) & (ext[rows, t2] > 1e-9)
+    keep = touching & face
+    b1, b2, c1, c2, h1, h2, d, pen, axis, lo, hi, t1, t2 = (a[keep] for a in (b1, b2, c1, c2, h1, h2, d, pen, axis, lo, hi, t1, t2))
+    m = len(b1); rows = np.arange(m)
+    sign = np.where(d[rows, axis] >= 0.0, 1.0, -1.0)
+    normal = np.zeros((m, 3)); normal[rows, axis] = sign
+    # 4 corners of the overlap rectangle (counter-clockwise in (t1, t2))
+    corner_t1 = np.stack([lo[rows, t1], hi[rows, t1], hi[rows, t1], lo[rows, t1]], axis=1)
+    corner_t2 = np.stack([lo[rows, t2], lo[rows, t2], hi[rows, t2], hi[rows, t2]], axis=1)
+    p1 = np.zeros((m, 4, 3)); p2 = np.zeros((m, 4, 3))
+    for k in range(4):
+        p1[rows, k, t1] = corner_t1[:, k]; p1[rows, k, t2] = corner_t2[:, k]
+        p2[rows, k, t1] = corner_t1[:, k]; p2[rows, k, t2] = corner_t2[:, k]
+        p1[rows, k, axis] = c1[rows, axis] + sign * h1[rows, axis]   # on the surface of body1
+        p2[rows, k, axis] = c2[rows, axis] - sign * h2[rows, axis]   # on the surface of body2
+    anchor1 = p1 - c1[:, None, :]   # centre of mass = body origin
+    anchor2 = p2 - c2[:, None, :]
+    penetration = np.repeat(pen[rows, axis][:, None], 4, axis=1)
+    v1, v2 = scene.linear_velocity[b1], scene.linear_velocity[b2]
+    w1, w2 = scene.angular_velocity[b1], scene.angular_velocity[b2]
+    rel = (v2[:, None, :] + np.cross(w2[:, None, :], anchor2)) - (v1[:, None, :] + np.cross(w1[:, None, :], anchor1))
+    normal_speed = np.einsum("mkc,mc->mk", rel, normal)
+    return dict(body1=b1.astype(np.int32), body2=b2.astype(np.int32), normal=normal,
+                point_count=np.full(m, 4, np.uint8), anchor1=anchor1, anchor2=anchor2, penetration=penetration,
+                normal_speed=normal_speed)
+
+
+def color_manifolds(lib: F.Library, mf: Dict[str, np.ndarray], rb_type: np.ndarray):
+    """Greedy persistent colouring in manifold order through the host ConstraintGraph of ``lib``
+    (constraint_graph.rs:163-236), then the colour-major permutation.  Returns (color_offsets, perm)."""
+    g = F.ConstraintGraph(lib, len(rb_type))
+    b1, b2 = mf["body1"], mf["body2"]
+    s1 = rb_type[b1] == F.RB_STATIC; s2 = rb_type[b2] == F.RB_STATIC
+    push = lib.fn("constraint_graph_push")
+    h = g.handle
+    for i in range(len(b1)):
+        push(h, i, int(b1[i]), int(b2[i]), int(s1[i]), int(s2[i]))
+    offsets, handles = g.lists()
+    g.close()
+    return offsets, handles.astype(np.int64)
+
+
+def permute_manifolds(mf: Dict[str, np.ndarray], perm: np.ndarray) -> Dict[str, np.ndarray]:
+    return {k: v[perm] for k, v in mf.items()}
+
+
+def upload_manifolds(world: F.World, mf: Dict[str, np.ndarray], color_offsets: np.ndarray, friction, restitution,
+                     warm_n: Optional[np.ndarray] = None, warm_t: Optional[np.ndarray] = None):
+    m = len(mf["body1"])
+    fr = np.broadcast_to(np.asarray(friction, dtype=np.float64), (m,))
+    re = np.broadcast_to(np.asarray(restitution, dtype=np.float64), (m,))
+    world.manifolds_upload(color_offsets=color_offsets, body1=mf["body1"], body2=mf["body2"], normal=mf["normal"],
+                           friction=fr, restitution=re, point_count=mf["point_count"], anchor1=mf["anchor1"],
+                           anchor2=mf["anchor2"], penetration=mf["penetration"], normal_speed=mf["normal_speed"],
+                           tangent_velocity=mf.get("tangent_velocity"), manifold_flags=mf.get("manifold_flags"),
+                           warm_start_normal_impulse=warm_n, warm_start_tangent_impulse=warm_t)
+
+
+def brute_force_pairs(scene: Scene, margin: float = 0.005) -> np.ndarray:
+    """All (i<j) body pairs whose margin-grown AABBs overlap (unrotated cuboids), by a uniform grid; order =
+    ascending (min.x-sorted i, j) like the broad phase would emit.  Host-side helper for scenes whose manifolds are
+    built without running the device broad phase."""
+    mn = scene.position - scene.half_extents - margin
+    mx = scene.position + scene.half_extents + margin
+    order = np.argsort(mn[:, 0], kind="stable")
+    smn, smx = mn[order], mx[order]
+    n = len(order)
+    out = []
+    # sweep in chunks with numpy searchsorted on the sorted min.x
+    ends = np.searchsorted(smn[:, 0], smx[:, 0], side="right")
+    for i in range(n):
+        j0, j1 = i + 1, ends[i]
+        if j1 <= j0:
+            continue
+        js = np.arange(j0, j1)
+        ok = ~((smn[i, 1] > smx[js, 1]) | (smx[i, 1] < smn[js, 1]) | (smn[i, 2] > smx[js, 2]) | (smx[i, 2] < smn[js, 2]))
+        js = js[ok]
+        if len(js):
+            out.append(np.stack([np.full(len(js), order[i]), order[js]], axis=1))
+    if not out:
+        return np.zeros((0, 2), np.int64)
+    p = np.concatenate(out)
+    both_static = (scene.rb_type[p[:, 0]] == F.RB_STATIC) & (scene.rb_type[p[:, 1]] == F.RB_STATIC)
+    return p[~both_static]

@@ -334,7 +334,7 @@ AVN_API avn_status AVN_FN(run_system)(avn_world* w, avn_system sys);
  * uploaded) then AVN_SYS_SOLVER.  Asynchronous on the world's stream in the product. */
 AVN_API avn_status AVN_FN(step)(avn_world* w);
 AVN_API avn_status AVN_FN(synchronize)(avn_world* w);
-AVN_API avn_status AVN_FN(timers)(avn_world* w, avn_timers* out);
+AVN_API avn_status AVN_FN(timers_get)(avn_world* w, avn_timers* out);
 
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);

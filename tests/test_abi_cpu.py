@@ -1,0 +1,75 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/*.h declares,
+and refuses to run (loudly) without a GPU — there is no CPU fallback in the product."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import F, REPO, hip_lib, oracle_lib
+
+
+def declared_symbols():
+    text = open(os.path.join(REPO, "include", "avian_mi355x.h")).read()
+    return sorted(set(re.findall(r"AVN_FN\((\w+)\)\s*\(", text)))
+
+
+def test_header_symbols_all_exported_by_both_libraries():
+    syms = declared_symbols()
+    assert len(syms) >= 26 and set(syms) == set(F.ABI_SYMBOLS)
+    import ctypes
+    for lib in (hip_lib(), oracle_lib()):
+        dll = ctypes.CDLL(lib.path)
+        for s in syms:
+            assert hasattr(dll, lib.prefix + s), f"{lib.path} does not export {lib.prefix}{s}"
+
+
+def test_product_has_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the -m gpu tests")
+    with pytest.raises(F.AvnError) as e:
+        F.World(hip_lib(), F.default_config(32))
+    assert e.value.status == 5 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    import subprocess
+    out = subprocess.run(["ldd", hip_lib().path], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    for root, _, files in os.walk(os.path.join(REPO, "avian_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".h", ".hpp")):
+                src = open(os.path.join(root, f)).read()
+                assert "liboracle" not in src and "avo_" not in src and "oracle/" not in src, f"{f} references the oracle"
+
+
+def test_pair_key_and_config_struct_layout():
+    lib = hip_lib()
+    assert lib.pair_key(5, 3) == (3 << 32) | 5 == oracle_lib().pair_key(3, 5)
+    import ctypes
+    assert ctypes.sizeof(F.avn_config) == 128
+    assert ctypes.sizeof(F.avn_pair) == 24 and F.PAIR_DTYPE.itemsize == 24
+
+
+def test_host_constraint_graph_matches_oracle_graph_cpu():
+    """Host-side colouring (integer work, runs without a GPU): product C++ vs oracle restatement, incl. pop."""
+    rng = np.random.default_rng(0)
+    n, m = 300, 3000
+    go, gh = F.ConstraintGraph(oracle_lib()), F.ConstraintGraph(hip_lib())
+    static = rng.random(n) < 0.1
+    live = []
+    for i in range(m):
+        a = int(rng.integers(0, n)); b = int((a + 1 + rng.integers(0, n - 1)) % n)
+        if static[a] and static[b]:
+            continue
+        co = go.push(i, a, b, bool(static[a]), bool(static[b]))
+        ch = gh.push(i, a, b, bool(static[a]), bool(static[b]))
+        assert co == ch
+        live.append(i)
+        if rng.random() < 0.3 and live:
+            h = live.pop(int(rng.integers(0, len(live))))
+            go.pop(h); gh.pop(h)
+    oo, ho = go.lists(); oh, hh = gh.lists()
+    assert np.array_equal(oo, oh) and np.array_equal(ho, hh)
+    assert oo[24] - oo[23] >= 0
