@@ -130,7 +130,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
 ]
 
@@ -159,6 +159,7 @@ class Library:
         f("pairs_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         f("aabbs_download").argtypes = [vp, vp, vp, vp, C.POINTER(C.c_size_t)]
         f("run_system").argtypes = [vp, C.c_int]
+        f("profile_system").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         f("step").argtypes = [vp]
         f("synchronize").argtypes = [vp]
         f("pair_key").argtypes = [C.c_uint32, C.c_uint32]
@@ -390,6 +391,12 @@ class World:
     # -- running -----------------------------------------------------------------------------------------
     def run_system(self, name: str):
         self._check(self.lib.fn("run_system")(self.handle, SYS[name]))
+
+    def profile_system(self, name: str, repeats: int):
+        """(total_ms, kernel_launches) of `repeats` back-to-back runs of a system, timed on the world's stream."""
+        ms, n = C.c_double(), C.c_uint32()
+        self._check(self.lib.fn("profile_system")(self.handle, SYS[name], repeats, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
 
     def step(self):
         self._check(self.lib.fn("step")(self.handle))

@@ -12,7 +12,7 @@ static thread_local std::string g_create_error;
 #define GUARD(expr)                                                     \
     do {                                                                \
         if (!w || !w->impl) return AVN_ERR_BAD_ARG;                     \
-        try { return w->impl->expr; }                                   \
+        try { w->impl->bind(); return w->impl->expr; }                                   \
         catch (const std::bad_alloc&) { w->impl->error = "out of host memory"; return AVN_ERR_OOM; } \
         catch (...) { w->impl->error = "unexpected C++ exception"; return AVN_ERR_STATE; }           \
     } while (0)
@@ -35,7 +35,7 @@ AVN_API avn_status avn_world_create(const avn_config* cfg, avn_world** out) {
     if (!*out) { delete w; return AVN_ERR_OOM; }
     return AVN_OK;
 }
-AVN_API void avn_world_destroy(avn_world* w) { if (w) { delete w->impl; delete w; } }
+AVN_API void avn_world_destroy(avn_world* w) { if (w) { if (w->impl) w->impl->bind(); delete w->impl; delete w; } }
 AVN_API const char* avn_last_error(const avn_world* w) { return (w && w->impl) ? w->impl->error.c_str() : g_create_error.c_str(); }
 AVN_API avn_status avn_config_set(avn_world* w, const avn_config* c) { GUARD(config_set(c)); }
 AVN_API avn_status avn_bodies_upload(avn_world* w, const avn_bodies* b) { GUARD(bodies_upload(b)); }
@@ -54,6 +54,7 @@ AVN_API avn_status avn_run_system(avn_world* w, avn_system s) { GUARD(run_system
 AVN_API avn_status avn_step(avn_world* w) { GUARD(step()); }
 AVN_API avn_status avn_synchronize(avn_world* w) { GUARD(synchronize()); }
 AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)); }
+AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD(profile_system(s, r, ms, l)); }
 AVN_API uint64_t avn_pair_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
 
 AVN_API avn_status avn_constraint_graph_create(uint32_t, avn_constraint_graph** out) {

@@ -58,7 +58,10 @@ uint32_t scan_block_sums_needed(uint32_t n);
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums, hipStream_t);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t);
 template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const uint32_t* sorted_collider, uint32_t n, hipStream_t);
-template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
+// long_items: n * sweep_long_item_bytes() bytes of scratch; n_long: device counter (reset by the count pass)
+template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, void* long_items,
+                                     uint32_t* n_long, hipStream_t);
+size_t sweep_long_item_bytes();
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
 // k_transfer.hip: host-layout (interleaved xyz) <-> device Vec4 records

@@ -106,7 +106,7 @@ template <class T> struct World : WorldBase {
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_force;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_min, b_s_max, b_s_info, b_s_flags;
-    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys;
+    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items;
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
     // host state
@@ -142,6 +142,7 @@ template <class T> struct World : WorldBase {
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
+    void bind() override { (void)hipSetDevice(cfg.device); }
     void drop_graph() {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
         if (graph) { (void)hipGraphDestroy(graph); graph = nullptr; }
@@ -154,6 +155,7 @@ template <class T> struct World : WorldBase {
         if (e != hipSuccess || ndev == 0) { error = "no HIP device visible: the MI355X path has no CPU fallback"; return AVN_ERR_NO_DEVICE; }
         if (c->device < 0 || c->device >= ndev) { error = "config.device out of range"; return AVN_ERR_BAD_ARG; }
         HIPCHK(hipSetDevice(c->device));
+        cfg.device = c->device;
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto& x : ev) HIPCHK(hipEventCreate(&x));
         hipError_t err;
@@ -662,6 +664,7 @@ template <class T> struct World : WorldBase {
             GROW(b_hist, (size_t)256 * radix_blocks((uint32_t)cc) + 256, dummy_u);
             GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc)) + 16, dummy_u);
             GROW(b_counts, cc + 1, dummy_u); GROW(b_offsets, cc + 1, dummy_u);
+            { uint8_t* dummy_b; GROW(b_long_items, (cc + 1) * sweep_long_item_bytes(), dummy_b); }
             cap_colliders = (uint32_t)cc;
         }
         bp.n_colliders = C;
@@ -725,7 +728,8 @@ template <class T> struct World : WorldBase {
         launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, stream);
         launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), stream);
         launch_gather_sorted<T>(dw, bp, vals_a, n, stream);
-        launch_sweep<T>(bp, n, false, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
+        uint32_t* d_nlong = misc + 35;
+        launch_sweep<T>(bp, n, false, b_counts.as<uint32_t>(), nullptr, nullptr, b_long_items.p, d_nlong, stream);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n, b_block_sums.as<uint32_t>(), d_total, stream);
         launches += 5 + 5 * (uint32_t)sizeof(Key) + 3;
         HIPCHK(hipGetLastError());
@@ -737,7 +741,7 @@ template <class T> struct World : WorldBase {
             hipError_t err;
             b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
             if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
-            launch_sweep<T>(bp, n, true, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), stream);
+            launch_sweep<T>(bp, n, true, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), b_long_items.p, d_nlong, stream);
             ++launches;
             HIPCHK(hipGetLastError());
             h_pairs.resize(total);
@@ -835,10 +839,8 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
-    avn_status run_system(avn_system sys) override {
-        avn_status st = need_bodies();
-        if (st != AVN_OK) return st;
-        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+    avn_status dispatch_system(avn_system sys) {
+        avn_status st = AVN_OK;
         switch (sys) {
             case AVN_SYS_UPDATE_AABB: if ((st = update_aabb()) != AVN_OK) return st; break;
             case AVN_SYS_COLLECT_COLLISION_PAIRS: if ((st = collect_collision_pairs()) != AVN_OK) return st; break;
@@ -854,13 +856,13 @@ template <class T> struct World : WorldBase {
             case AVN_SYS_XPBD_SOLVE: xpbd_solve(true); break;
             case AVN_SYS_XPBD_VELOCITY_PROJECTION: xpbd_velocity_projection(); break;
             case AVN_SYS_JOINT_DAMPING: joint_damping(); break;
-            case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: launch_clear_increments<T>(dw, stream); break;
+            case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: launch_clear_increments<T>(dw, stream); ++launches; break;
             case AVN_SYS_SOLVE_RESTITUTION: contact_pass(PASS_RESTITUTION_); break;
             case AVN_SYS_WRITEBACK_SOLVER_BODIES:
-                launch_writeback_solver_bodies<T>(dw, stream);
-                if (dw.n_joints) launch_writeback_joint_forces<T>(dw, params, stream);
+                launch_writeback_solver_bodies<T>(dw, stream); ++launches;
+                if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
                 break;
-            case AVN_SYS_STORE_CONTACT_IMPULSES: launch_store_contact_impulses<T>(dw, stream); break;
+            case AVN_SYS_STORE_CONTACT_IMPULSES: launch_store_contact_impulses<T>(dw, stream); ++launches; break;
             case AVN_SYS_SUBSTEP: substep(); break;
             case AVN_SYS_SOLVER: {
                 HIPCHK(hipEventRecord(ev[0], stream)); HIPCHK(hipEventRecord(ev[1], stream));
@@ -872,8 +874,35 @@ template <class T> struct World : WorldBase {
             default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
         }
         HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status run_system(avn_system sys) override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = dispatch_system(sys)) != AVN_OK) return st;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
+    }
+    avn_status profile_system(avn_system sys, uint32_t repeats, double* total_ms, uint32_t* n_launches) override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t before = launches;
+        HIPCHK(hipEventRecord(a, stream));  // events on the stream the kernels are launched on
+        for (uint32_t r = 0; r < repeats; ++r)
+            if ((st = dispatch_system(sys)) != AVN_OK) break;
+        HIPCHK(hipEventRecord(b, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (total_ms) *total_ms = ms;
+        if (n_launches) *n_launches = launches - before;
+        return st;
     }
     avn_status step() override {
         avn_status st = need_bodies();

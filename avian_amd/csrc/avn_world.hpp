@@ -50,6 +50,7 @@ struct JointSchedule {
 struct WorldBase {
     std::string error;
     virtual ~WorldBase() {}
+    virtual void bind() = 0;  // make the world's device current on the calling thread
     virtual avn_status config_set(const avn_config*) = 0;
     virtual avn_status bodies_upload(const avn_bodies*) = 0;
     virtual avn_status bodies_download(const avn_bodies_out*) = 0;
@@ -67,6 +68,7 @@ struct WorldBase {
     virtual avn_status step() = 0;
     virtual avn_status synchronize() = 0;
     virtual avn_status timers(avn_timers*) = 0;
+    virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
 };
 
 WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err);

@@ -306,11 +306,49 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 
 // ---------------------------------------------------------------------------------------------------------
 // sweep
+//
+// Load balance: with one lane per interval, an interval whose AABB spans the scene (a ground plane) would make a single
+// lane walk every later interval (100k serial iterations ~ 18 ms on cfg2).  Each lane therefore walks at most SW_CAP
+// candidates; the remainder of such a "long" interval is recorded as a LongItem and swept by k_sweep_long, where a whole
+// workgroup strides over the candidates of ONE interval (256 at a time, ballot + LDS scan for in-order positions).
+// Emission order per interval stays j ascending: [short part][long part], i.e. exactly the reference's order.
 #define SW_THREADS 256
+#define SW_CAP 8192u
+
+struct LongItem { uint32_t i, j_start, short_count, pad; };
+
+template <class T> struct SweepSelf { V3<T> mn, mx; uint4 info; uint32_t flags; };
+
+// all pair filters of broad_phase.rs:390-439 after the x test; returns true when (self, other) becomes a new pair
+template <class T>
+__device__ __forceinline__ bool pair_passes(const BP<T>& bp, const SweepSelf<T>& a, T miny, T minz, T maxy, T maxz, uint4 in2, uint32_t f2) {
+    if (a.mn.y > maxy || a.mx.y < miny) return false;                                        // y disjoint
+    if (a.mn.z > maxz || a.mx.z < minz) return false;                                        // z disjoint
+    bool interacts = (a.info.z & in2.w) != 0 && (in2.z & a.info.w) != 0;                     // CollisionLayers::interacts_with
+    if ((a.flags & f2 & AVN_AABB_IS_INACTIVE) || !interacts || a.info.y == in2.y) return false;
+    uint64_t key = a.info.x < in2.x ? ((uint64_t)a.info.x << 32) | in2.x : ((uint64_t)in2.x << 32) | a.info.x;
+    if (bp.pair_set_cap && hs_contains(bp.pair_set, bp.pair_set_cap - 1, key)) return false;
+    if (bp.disabled_cap) {
+        uint64_t bk = a.info.y < in2.y ? ((uint64_t)a.info.y << 32) | in2.y : ((uint64_t)in2.y << 32) | a.info.y;
+        if (hs_contains(bp.disabled_set, bp.disabled_cap - 1, bk)) return false;
+    }
+    return true;
+}
+__device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2, uint32_t f2) {
+    uint32_t u = f1 | f2;
+    avn_pair pr;
+    pr.collider1 = in1.x; pr.collider2 = in2.x; pr.body1 = (int)in1.y; pr.body2 = (int)in2.y;
+    pr.flags = ((u & AVN_AABB_CONTACT_EVENTS) ? AVN_PAIR_CONTACT_EVENTS : 0u) | ((u & AVN_AABB_MODIFY_CONTACTS) ? AVN_PAIR_MODIFY_CONTACTS : 0u) |
+               ((u & AVN_AABB_GENERATE_CONSTRAINTS) ? AVN_PAIR_GENERATE_CONSTRAINTS : 0u) | ((u & AVN_AABB_CUSTOM_FILTER) ? AVN_PAIR_NEEDS_CUSTOM_FILTER : 0u);
+    pr.reserved = 0;
+    return pr;
+}
+
 template <class T, bool EMIT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep(BP<T> bp, uint32_t n, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                       avn_pair* __restrict__ out) {
-    __shared__ T l_minx[SW_THREADS], l_miny[SW_THREADS], l_minz[SW_THREADS], l_maxy[SW_THREADS], l_maxz[SW_THREADS];
+                                                       avn_pair* __restrict__ out, LongItem* __restrict__ long_items, uint32_t* __restrict__ n_long) {
+    __shared__ Vec4<T> l_a[SW_THREADS];   // (min.x, min.y, min.z, max.y)
+    __shared__ T l_maxz[SW_THREADS];
     __shared__ uint4 l_info[SW_THREADS];
     __shared__ uint32_t l_flags[SW_THREADS];
     uint32_t t = threadIdx.x;
@@ -319,18 +357,19 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(BP<T> bp, uint32_t n, uint
     if (i0 >= n) return;  // uniform per block
     uint32_t i = i0 + t;
     bool valid = i < n;
-    V3<T> mn = vzero<T>(), mx = vzero<T>();
-    uint4 info = make_uint4(0, 0, 0, 0);
-    uint32_t flags = 0;
-    if (valid) { mn = xyz<T>(bp.s_min[i]); mx = xyz<T>(bp.s_max[i]); info = bp.s_info[i]; flags = bp.s_flags[i]; }
-    bool done = !valid || (flags & AVN_IV_DROPPED);
+    SweepSelf<T> self;
+    self.mn = vzero<T>(); self.mx = vzero<T>(); self.info = make_uint4(0, 0, 0, 0); self.flags = 0;
+    if (valid) { self.mn = xyz<T>(bp.s_min[i]); self.mx = xyz<T>(bp.s_max[i]); self.info = bp.s_info[i]; self.flags = bp.s_flags[i]; }
+    bool done = !valid || (self.flags & AVN_IV_DROPPED);
     uint32_t count = 0;
     uint32_t pos = (EMIT && valid) ? offsets[i] : 0u;
+    uint32_t j_cap = i + 1u + SW_CAP;  // first candidate NOT handled by this lane
     for (uint32_t j0 = i0; j0 < n; j0 += SW_THREADS) {
         uint32_t jl = j0 + t;
         if (jl < n) {
             Vec4<T> a = bp.s_min[jl], b = bp.s_max[jl];
-            l_minx[t] = a.x; l_miny[t] = a.y; l_minz[t] = a.z; l_maxy[t] = b.y; l_maxz[t] = b.z;
+            l_a[t] = make4<T>(a.x, a.y, a.z, b.y);
+            l_maxz[t] = b.z;
             l_info[t] = bp.s_info[jl];
             l_flags[t] = bp.s_flags[jl];
         }
@@ -339,30 +378,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(BP<T> bp, uint32_t n, uint
             uint32_t lim = min((uint32_t)SW_THREADS, n - j0);
             uint32_t jj = (j0 == i0) ? t + 1 : 0u;  // j > i
             for (; jj < lim; ++jj) {
-                if (l_minx[jj] > mx.x) { done = true; break; }                       // x: sweep ends
-                if (mn.y > l_maxy[jj] || mx.y < l_miny[jj]) continue;                 // y disjoint
-                if (mn.z > l_maxz[jj] || mx.z < l_minz[jj]) continue;                 // z disjoint
-                uint32_t f2 = l_flags[jj];
-                uint4 in2 = l_info[jj];
-                bool interacts = (info.z & in2.w) != 0 && (in2.z & info.w) != 0;       // CollisionLayers::interacts_with
-                if ((flags & f2 & AVN_AABB_IS_INACTIVE) || !interacts || info.y == in2.y) continue;
-                uint64_t key = info.x < in2.x ? ((uint64_t)info.x << 32) | in2.x : ((uint64_t)in2.x << 32) | info.x;
-                if (bp.pair_set_cap && hs_contains(bp.pair_set, bp.pair_set_cap - 1, key)) continue;
-                if (bp.disabled_cap) {
-                    uint64_t bk = info.y < in2.y ? ((uint64_t)info.y << 32) | in2.y : ((uint64_t)in2.y << 32) | info.y;
-                    if (hs_contains(bp.disabled_set, bp.disabled_cap - 1, bk)) continue;
+                if (j0 + jj >= j_cap) {  // hand the rest of a long interval to k_sweep_long
+                    if (!EMIT) { uint32_t k = atomicAdd(n_long, 1u); long_items[k] = LongItem{i, j_cap, count, 0u}; }
+                    done = true;
+                    break;
                 }
-                if (EMIT) {
-                    uint32_t u = flags | f2;
-                    avn_pair pr;
-                    pr.collider1 = info.x; pr.collider2 = in2.x; pr.body1 = (int)info.y; pr.body2 = (int)in2.y;
-                    pr.flags = ((u & AVN_AABB_CONTACT_EVENTS) ? AVN_PAIR_CONTACT_EVENTS : 0u) |
-                               ((u & AVN_AABB_MODIFY_CONTACTS) ? AVN_PAIR_MODIFY_CONTACTS : 0u) |
-                               ((u & AVN_AABB_GENERATE_CONSTRAINTS) ? AVN_PAIR_GENERATE_CONSTRAINTS : 0u) |
-                               ((u & AVN_AABB_CUSTOM_FILTER) ? AVN_PAIR_NEEDS_CUSTOM_FILTER : 0u);
-                    pr.reserved = 0;
-                    out[pos] = pr;
-                }
+                Vec4<T> a = l_a[jj];
+                if (a.x > self.mx.x) { done = true; break; }  // x: sweep ends (broad_phase.rs:390-392)
+                if (self.mn.y > a.w || self.mx.y < a.y) continue;  // cheap y reject before touching the other LDS arrays
+                if (!pair_passes<T>(bp, self, a.y, a.z, a.w, l_maxz[jj], l_info[jj], l_flags[jj])) continue;
+                if (EMIT) out[pos] = make_pair(self.info, self.flags, l_info[jj], l_flags[jj]);
                 ++pos;
                 ++count;
             }
@@ -370,6 +395,50 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(BP<T> bp, uint32_t n, uint
         if (__syncthreads_and(done ? 1 : 0)) break;
     }
     if (!EMIT && valid) counts[i] = count;
+}
+
+// One workgroup per long interval (grid-stride over the LongItem list).
+template <class T, bool EMIT>
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_long(BP<T> bp, uint32_t n, const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long,
+                                                            uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
+    __shared__ uint32_t wave_tot[SW_THREADS / 64];
+    uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
+    uint32_t nl = *n_long;
+    for (uint32_t it = blockIdx.x; it < nl; it += gridDim.x) {
+        LongItem item = items[it];
+        uint32_t i = item.i;
+        SweepSelf<T> self;
+        self.mn = xyz<T>(bp.s_min[i]); self.mx = xyz<T>(bp.s_max[i]); self.info = bp.s_info[i]; self.flags = bp.s_flags[i];
+        uint32_t running = 0;
+        uint32_t base = EMIT ? offsets[i] + item.short_count : 0u;
+        for (uint32_t j0 = item.j_start; j0 < n; j0 += SW_THREADS) {
+            uint32_t j = j0 + t;
+            bool beyond = true, ok = false;
+            uint4 in2 = make_uint4(0, 0, 0, 0);
+            uint32_t f2 = 0;
+            if (j < n) {
+                Vec4<T> a = bp.s_min[j];
+                beyond = a.x > self.mx.x;
+                if (!beyond) {
+                    Vec4<T> b = bp.s_max[j];
+                    in2 = bp.s_info[j]; f2 = bp.s_flags[j];
+                    ok = pair_passes<T>(bp, self, a.y, a.z, b.y, b.z, in2, f2);
+                }
+            }
+            unsigned long long bal = __ballot(ok);
+            if (lane == 0) wave_tot[wv] = (uint32_t)__popcll(bal);
+            __syncthreads();
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < SW_THREADS / 64; ++k) { uint32_t v = wave_tot[k]; if (k < wv) before += v; total += v; }
+            if (EMIT && ok) out[base + running + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_pair(self.info, self.flags, in2, f2);
+            running += total;
+            // sorted by min.x: once any candidate of this stride is beyond max.x, every later one is too
+            if (__syncthreads_or(beyond ? 1 : 0)) break;
+        }
+        if (!EMIT && t == 0) counts[i] += running;  // single writer per interval, after k_sweep<false> completed
+        __syncthreads();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -399,19 +468,28 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
 template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, const uint32_t* sorted_collider, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_gather_sorted<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bp, sorted_collider, n);
 }
-template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t s) {
+template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, void* long_items,
+                                     uint32_t* n_long, hipStream_t s) {
     if (!n) return;
     uint32_t nb = (n + SW_THREADS - 1) / SW_THREADS;
     nb = ((nb + 7) / 8) * 8;
-    if (emit) hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out);
-    else hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out);
+    LongItem* li = (LongItem*)long_items;
+    if (emit) {
+        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out, li, n_long);
+        hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(1024), dim3(SW_THREADS), 0, s, bp, n, li, n_long, counts, offsets, out);
+    } else {
+        (void)hipMemsetAsync(n_long, 0, sizeof(uint32_t), s);
+        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out, li, n_long);
+        hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(1024), dim3(SW_THREADS), 0, s, bp, n, li, n_long, counts, offsets, out);
+    }
 }
+size_t sweep_long_item_bytes() { return sizeof(LongItem); }
 
 #define INST(T)                                                                                          \
     template void launch_update_aabb<T>(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);  \
     template void launch_interval_keys<T>(const DW<T>&, const BP<T>&, typename BP<T>::Key*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_sorted<T>(const DW<T>&, const BP<T>&, const uint32_t*, uint32_t, hipStream_t); \
-    template void launch_sweep<T>(const BP<T>&, uint32_t, bool, uint32_t*, const uint32_t*, avn_pair*, hipStream_t);
+    template void launch_sweep<T>(const BP<T>&, uint32_t, bool, uint32_t*, const uint32_t*, avn_pair*, void*, uint32_t*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

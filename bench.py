@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""bench.py — physics substeps/second of the MI355X hot path on BASELINE.json's cfg2 (100k-cuboid box stack).
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 launched by torch.distributed.run with
+one rank per GPU.  Rank 0 prints ONE JSON line.
+
+A "step" = one pass of the hot path over the device-resident world (`avn_step`): AABB update + sweep-and-prune
+broad phase + solver-body/constraint preparation + S substeps (integrate, warm start, biased solve, integrate
+positions, relax, XPBD) + restitution + write-back + impulse store — everything SURVEY.md §8(d) counts in the
+"whole step".  Inputs are resident in HBM before the timed region; the narrow phase (parry, out of scope) is not
+part of the path, so the manifold set is fixed during the timed steps while body state evolves.
+
+  value      = N_gpus * K * substeps / max-over-ranks wall seconds   (physics substeps / second, whole step)
+  roofline   = the dominant kernel (k_color_pass<SOLVE_BIAS>: TGS-Soft biased contact solve, one launch per graph
+               colour): ALGORITHMIC bytes (248 + 88 P per manifold) / duration measured with HIP
+               events on the library's own stream (avn_profile_system), against the 8 TB/s HBM3E peak.
+  cpu_baseline = the CPU oracle (C++ restatement of the reference, 1 thread) on the same inputs, bounded sample.
+
+Multi-GPU (weak scaling): the path shards by independent contact islands — every rank owns a whole island
+(one 100k stack) with no data-path collective; torch.distributed (RCCL) is used only for the barrier / MAX.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+SCENES = {
+    # name: (nx, ny, nz, substeps)   — cfg2 is the configuration BASELINE.json's metric is quoted on
+    "cfg2_box_stack_100k": (50, 40, 50, 4),
+    "box_stack_12k": (25, 20, 25, 4),
+    "box_stack_1k": (10, 10, 10, 4),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def build_inputs(lib, scene_name):
+    """Scene + the solver inputs that the (out-of-scope) narrow phase would have produced."""
+    from avian_amd import _ffi as F, scenes
+    nx, ny, nz, substeps = SCENES[scene_name]
+    sc = scenes.box_stack(nx, ny, nz)
+    return sc, substeps
+
+
+def setup_world(world, lib, sc, pairs_from=None):
+    """Upload bodies + colliders, run the broad phase once to obtain the pair list, generate the synthetic face
+    manifolds for those pairs, colour them with the host ConstraintGraph and upload them.  Returns metadata."""
+    from avian_amd import scenes
+    world.bodies_upload(**sc.body_kwargs())
+    world.colliders_upload(**sc.collider_kwargs())
+    world.existing_pairs_upload(np.zeros(0, np.uint64))
+    world.run_system("UPDATE_AABB")
+    world.run_system("COLLECT_COLLISION_PAIRS")
+    pairs = world.pairs_get()
+    mf = scenes.axis_aligned_manifolds(sc, np.stack([pairs["body1"], pairs["body2"]], axis=1))
+    offs, perm = scenes.color_manifolds(lib, mf, sc.rb_type)
+    pm = scenes.permute_manifolds(mf, perm)
+    scenes.upload_manifolds(world, pm, offs, sc.friction, sc.restitution)
+    counts = np.diff(offs.astype(np.int64))
+    return dict(n_pairs=int(len(pairs)), n_manifolds=int(len(perm)), points=int(pm["point_count"].sum()),
+                colors_used=int((counts > 0).sum()), color_counts=[int(c) for c in counts if c > 0], manifolds=pm,
+                offsets=offs)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scene", default="cfg2_box_stack_100k", choices=sorted(SCENES))
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import avian_amd
+    from avian_amd import _ffi as F
+    lib = avian_amd.load_library()
+    sc, substeps = build_inputs(lib, args.scene)
+    cfg = F.default_config(32, substeps=substeps, device=local_rank, use_graph=0 if args.no_graph else 1)
+    w = F.World(lib, cfg)
+    meta = setup_world(w, lib, sc)
+
+    def barrier():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        w.step()
+    w.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        w.step()
+    w.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = w.timers()
+
+    # ---- roofline of the dominant kernel, measured live with HIP events on the library's stream ---------------
+    reps = 20
+    w.profile_system("SOLVE_CONTACTS_BIAS", 2)
+    ms, launches = w.profile_system("SOLVE_CONTACTS_BIAS", reps)
+    pts = meta["points"]
+    algo_bytes_per_pass = 248 * meta["n_manifolds"] + 88 * pts  # SURVEY.md §8d, biased solve pass
+    launches_per_pass = max(launches // reps, 1)
+    avg_launch_s = (ms / 1e3) / max(launches, 1)
+    achieved_gbs = (algo_bytes_per_pass / launches_per_pass) / avg_launch_s / 1e9
+    traffic = None
+    pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": "k_color_pass<float, SOLVE_BIAS>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
+                "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches_per_pass": launches_per_pass,
+                "algorithmic_bytes_per_launch": int(algo_bytes_per_pass / launches_per_pass)}
+
+    # ---- CPU baseline: the oracle on the same inputs, rank 0 at N=1 only, bounded sample -------------------------
+    cpu = None
+    if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from helpers import oracle_lib  # cpu_baseline leg: the oracle is the thing timed here, by contract
+        from avian_amd import scenes
+        wo = F.World(oracle_lib(), F.default_config(32, substeps=substeps))
+        wo.bodies_upload(**sc.body_kwargs())
+        wo.colliders_upload(**sc.collider_kwargs())
+        wo.existing_pairs_upload(np.zeros(0, np.uint64))
+        wo.run_system("UPDATE_AABB")
+        wo.run_system("COLLECT_COLLISION_PAIRS")
+        scenes.upload_manifolds(wo, meta["manifolds"], meta["offsets"], sc.friction, sc.restitution)
+        c0 = time.perf_counter(); wo.step(); first = time.perf_counter() - c0   # un-timed warm-up step (benches/src/cli.rs:358)
+        n_cpu = int(max(1, min(args.steps, args.cpu_seconds / max(first, 1e-6))))
+        c0 = time.perf_counter()
+        for _ in range(n_cpu):
+            wo.step()
+        cpu_s = time.perf_counter() - c0
+        sm, _ = wo.profile_system("SUBSTEP", 1)
+        cpu = {"value": round(n_cpu * substeps / cpu_s, 4), "unit": "substeps/s", "cores": 1, "kind": "port",
+               "sample": f"{n_cpu} whole steps ({n_cpu * substeps} substeps) of the same {args.scene} inputs after 1 warm-up step, "
+                         f"single-thread C++ oracle (g++ -O2 -ffp-contract=off) on {os.cpu_count()} host cores",
+               "ms_per_step": round(cpu_s / n_cpu * 1e3, 2), "substep_loop_only_ms": round(sm, 2)}
+
+    if rank == 0:
+        total_substeps = world_size * args.steps * substeps
+        out = {
+            "metric": "physics substeps/sec at N dynamic bodies (3D)",
+            "value": round(total_substeps / elapsed, 3),
+            "unit": "substeps/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": args.scene, "dynamic_bodies_per_gpu": sc.n - 1, "manifolds_per_gpu": meta["n_manifolds"],
+                       "contact_points_per_gpu": pts, "broadphase_pairs": meta["n_pairs"], "substeps": substeps,
+                       "solver_iterations": 1, "dt": 1.0 / 60.0, "colors_used": meta["colors_used"],
+                       "hip_graph": not args.no_graph, "sharding": "one independent island (stack) per GPU, no data-path collective",
+                       "narrow_phase": "out of path: fixed synthetic face manifolds"},
+            "device_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4),
+                          "substeps": round(tm.substeps_ms, 4), "finalize": round(tm.finalize_ms, 4),
+                          "kernel_launches_per_step": tm.kernel_launches},
+            "substep_loop_only_substeps_per_s": round(substeps / (tm.substeps_ms / 1e3), 2) if tm.substeps_ms > 0 else None,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

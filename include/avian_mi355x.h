@@ -335,6 +335,12 @@ AVN_API avn_status AVN_FN(run_system)(avn_world* w, avn_system sys);
 AVN_API avn_status AVN_FN(step)(avn_world* w);
 AVN_API avn_status AVN_FN(synchronize)(avn_world* w);
 AVN_API avn_status AVN_FN(timers_get)(avn_world* w, avn_timers* out);
+/* Measurement hook (bench.py roofline): run `sys` `repeats` times back to back on the world's stream, bracketed by
+ * events ON THAT STREAM; returns the total elapsed milliseconds and the number of kernel launches issued.
+ * (The oracle times the same calls with a host clock.)  The reference's equivalent is the per-system
+ * `Instant::now()/elapsed()` accumulation into SolverDiagnostics (solver/plugin.rs:459,481). */
+AVN_API avn_status AVN_FN(profile_system)(avn_world* w, avn_system sys, uint32_t repeats, double* total_ms,
+                                           uint32_t* kernel_launches);
 
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);

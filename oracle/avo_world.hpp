@@ -13,6 +13,7 @@
 // the restatement is reviewed line by line against the cited source instead.
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -262,6 +263,7 @@ struct WorldBase {
     virtual avn_status run_system(avn_system) = 0;
     virtual avn_status step() = 0;
     virtual avn_status timers(avn_timers*) = 0;
+    virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
 };
 
 template <class S> struct World : WorldBase {
@@ -1148,6 +1150,14 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status timers(avn_timers* t) override { if (!t) return AVN_ERR_BAD_ARG; *t = last_timers; return AVN_OK; }
+    avn_status profile_system(avn_system sys, uint32_t repeats, double* total_ms, uint32_t* launches) override {
+        auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t r = 0; r < repeats; ++r) { avn_status st = run_system(sys); if (st != AVN_OK) return st; }
+        auto t1 = std::chrono::steady_clock::now();
+        if (total_ms) *total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (launches) *launches = 0;
+        return AVN_OK;
+    }
 };
 
 // ---- ConstraintGraph (solver/constraint_graph.rs:129-296) ------------------------------------------

@@ -44,6 +44,7 @@ avn_status avo_run_system(avn_world* w, avn_system s) { FWD(run_system(s)); }
 avn_status avo_step(avn_world* w) { FWD(step()); }
 avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
+avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
 uint64_t avo_pair_key(uint32_t a, uint32_t b) { return avo::pair_key(a, b); }
 
 avn_status avo_constraint_graph_create(uint32_t, avn_constraint_graph** out) {

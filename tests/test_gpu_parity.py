@@ -157,6 +157,27 @@ def test_broadphase_pairs_bit_exact_over_frames(bits):
     assert total_pairs > 1500
 
 
+def test_broadphase_long_interval_path():
+    """An AABB that spans the scene (ground) has > SW_CAP (8192) sweep candidates: its tail is swept by the
+    workgroup-cooperative kernel; the pair sequence must still be the reference's (i asc, j asc) order."""
+    from avian_amd import scenes
+    sc = scenes.box_stack(30, 6, 60)   # 10 800 cubes on one big static ground, plus a second huge static slab
+    wo, wh = make_pair(32)
+    for w in (wo, wh):
+        w.bodies_upload(**sc.body_kwargs())
+        w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+    po, ph = wo.pairs_get(), wh.pairs_get()
+    assert len(po) == len(ph) and np.array_equal(po, ph)
+    ground_pairs = (po["body1"] == 0) | (po["body2"] == 0)
+    assert ground_pairs.sum() == 30 * 60, "every bottom cube pairs with the ground"
+    # second frame: nothing new
+    for w in (wo, wh):
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+        assert len(w.pairs_get()) == 0
+
+
 def test_broadphase_edge_cases():
     """Empty world, a single collider, identical min.x (stability), -0.0 vs +0.0 keys, touching AABBs, non-finite AABB."""
     wo, wh = make_pair(32)
