@@ -1,0 +1,113 @@
+"""Shared checkers for the committed golden fixtures (tests/golden/): run a library (oracle or HIP product) through
+the C ABI and compare with (a) the reference's own known-answer tests and (b) the frozen oracle vectors."""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+
+from helpers import F, color_and_upload, random_world
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_kats():
+    return json.load(open(os.path.join(GOLDEN, "reference_kats.json")))["cases"]
+
+
+def run_kat(lib, case, bits=32, **cfgkw):
+    """Drive one reference KAT through `lib`: bodies only (no contacts), `steps` x avn_step; returns bodies_download."""
+    c = case["config"]
+    cfg = F.default_config(bits, substeps=c["substeps"], dt=c["dt"], gravity=c["gravity"], **cfgkw)
+    w = F.World(lib, cfg)
+    bs = case["bodies"]
+    n = len(bs)
+    arr = lambda k, d: np.array([b.get(k, d) for b in bs], dtype=np.float64)
+    kw = dict(position=arr("position", None), rotation=arr("rotation", None), linear_velocity=arr("linear_velocity", None),
+              angular_velocity=arr("angular_velocity", None), inv_mass=arr("inv_mass", None),
+              inv_inertia_local=arr("inv_inertia_local", None), rb_type=np.zeros(n, np.uint8),
+              accel_linear=arr("accel_linear", [0, 0, 0]), accel_angular=arr("accel_angular", [0, 0, 0]))
+    w.bodies_upload(**kw)
+    for _ in range(case["steps"]):
+        # the reference's ForcePlugin re-applies the user's persistent force/acceleration every step and
+        # clear_velocity_increments (integrator/mod.rs:316-328) wipes it at the end of the step: re-upload like the ECS would
+        w.step()
+        if np.any(kw["accel_linear"]) or np.any(kw["accel_angular"]):
+            out = w.bodies_download()
+            kw.update(position=out["position"], rotation=out["rotation"], linear_velocity=out["linear_velocity"],
+                      angular_velocity=out["angular_velocity"])
+            w.bodies_upload(**kw)
+    w.synchronize()
+    out = w.bodies_download()
+    w.close()
+    return out
+
+
+def check_kat(out, case):
+    for e in case["expect"]:
+        b, field, eps = e["body"], e["field"], e["epsilon"]
+        if field == "rotation":  # assert_relative_eq!(rotation.0, Quaternion::from_rotation_z(a), epsilon): component-wise
+            a = e["value_rotation_z"]
+            want = np.array([0.0, 0.0, math.sin(a / 2), math.cos(a / 2)])
+            got = out["rotation"][b].astype(np.float64)
+            assert np.all(np.abs(got - want) <= eps), f"{case['name']}: rotation {got} vs {want} (eps {eps})"
+        elif field == "rotation_angle_between_z":  # glam Quat::angle_between = 2 acos(|dot|)
+            a = e["value_rotation_z"]
+            want = np.array([0.0, 0.0, math.sin(a / 2), math.cos(a / 2)])
+            got = out["rotation"][b].astype(np.float64)
+            diff = 2.0 * math.acos(min(1.0, abs(float(got @ want))))
+            assert diff < eps, f"{case['name']}: angle difference {diff} is not less than {eps}"
+        elif field.endswith(".y"):
+            got = float(out[field[:-2]][b][1])
+            assert abs(got - e["value"]) <= eps, f"{case['name']}: {field} {got} vs {e['value']} (eps {eps})"
+        else:
+            got = out[field][b].astype(np.float64)
+            want = np.array(e["value"])
+            assert np.all(np.abs(got - want) <= eps), f"{case['name']}: {field} {got} vs {want} (eps {eps})"
+
+
+def solver_vectors(lib, bits, graph_lib, **cfgkw):
+    """The exact procedure of golden/make_oracle_vectors.py:solver_case, against `lib`."""
+    wd = random_world(seed=2026, n_bodies=96, n_manifolds=260, n_joints=40, hub_degree=26)
+    w = F.World(lib, F.default_config(bits, substeps=3, **cfgkw))
+    color_and_upload(w, graph_lib, wd)
+    for _ in range(3):
+        w.step()
+    w.synchronize()
+    out = {}
+    for name, d in (("bodies", w.bodies_download()), ("impulses", w.impulses_download()), ("joints", w.joints_download())):
+        for k, v in d.items():
+            out[f"{name}.{k}"] = v
+    w.close()
+    return out
+
+
+def broadphase_vectors(lib, bits):
+    from avian_amd import scenes
+    sc = scenes.box_stack(6, 4, 5)
+    w = F.World(lib, F.default_config(bits, substeps=2))
+    w.bodies_upload(**sc.body_kwargs())
+    w.colliders_upload(**sc.collider_kwargs())
+    w.existing_pairs_upload(np.zeros(0, np.uint64))
+    w.run_system("UPDATE_AABB")
+    w.run_system("COLLECT_COLLISION_PAIRS")
+    mn, mx, ents = w.aabbs_download()
+    p = w.pairs_get()
+    out = {"bp.aabb_min": mn, "bp.aabb_max": mx, "bp.interval_entities": ents,
+           "bp.pairs": np.stack([p["collider1"], p["collider2"], p["body1"].astype(np.uint32), p["body2"].astype(np.uint32), p["flags"]], axis=1)}
+    w.close()
+    return out
+
+
+def check_vectors(got: dict, bits: int):
+    want = np.load(os.path.join(GOLDEN, f"oracle_vectors_f{bits}.npz"))
+    keys = [k for k in want.files if k in got]
+    assert keys, "no overlapping arrays"
+    for k in keys:
+        a, b = got[k], want[k]
+        assert a.shape == b.shape and a.dtype == b.dtype, f"{k}: {a.shape}/{a.dtype} vs {b.shape}/{b.dtype}"
+        same = (a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)
+        assert same.all(), f"{k}: {int((~same).sum())} of {same.size} values differ from the committed golden vector (bit-exact bar)"
+    return len(keys)
