@@ -17,16 +17,28 @@ template <class T> struct BP {
     Vec4<T>* aabb_min;     // ColliderAabb per collider slot
     Vec4<T>* aabb_max;
     uint32_t* iv_collider; // AabbIntervals: collider slot per interval, persistent sorted order
-    Vec4<T>* s_min;        // sorted interval records
-    Vec4<T>* s_max;
+    T* s_minx;             // sorted interval records: min.x (the sort key), max.x
+    T* s_maxx;
+    Vec4<T>* s_yz;         // (min.y, max.y, min.z, max.z)
+    uint32_t* s_end;       // end(i): first j > i with min_x[j] > max_x[i]  (i + 1 for dropped / long intervals)
     uint4* s_info;         // (entity, body, memberships, filters)
-    uint32_t* s_flags;     // AabbIntervalFlags | AVN_IV_DROPPED
+    uint32_t* s_flags;     // AabbIntervalFlags | AVN_IV_DROPPED | AVN_IV_LONG
     uint64_t* pair_set;    // ContactGraph::pair_set as an open-addressing hash set (EMPTY = ~0)
     uint32_t pair_set_cap; // power of two, 0 = no set
     uint64_t* disabled_set;  // body pairs whose joints disable collision
     uint32_t disabled_cap;
 };
 #define AVN_IV_DROPPED 0x80000000u
+#define AVN_IV_LONG 0x40000000u   // > SW_CAP sweep candidates: swept by k_sweep_long in chunks
+
+// scratch of the sweep's long-interval path
+struct SweepScratch {
+    void* long_items;       // LongItem[long_cap]
+    uint32_t* long_counts;  // [long_cap] pairs found per chunk
+    uint32_t* long_off;     // [long_cap] chunk offset inside its interval's output range
+    uint32_t* n_long;       // [2] device counters: chunks used, overflow flag
+    uint32_t long_cap;
+};
 
 enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3 };
 
@@ -55,13 +67,15 @@ template <class T> void launch_update_aabb(const DW<T>&, const BP<T>&, const Ste
 template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t);
 uint32_t radix_blocks(uint32_t n);
 uint32_t scan_block_sums_needed(uint32_t n);
-template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums, hipStream_t);
-void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t);
+// `enabled` (device flag, may be null): when it reads 0 every kernel of the call returns immediately
+template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
+                                          const uint32_t* enabled, hipStream_t);
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t, const uint32_t* enabled = nullptr);
 template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const uint32_t* sorted_collider, uint32_t n, hipStream_t);
-// long_items: n * sweep_long_item_bytes() bytes of scratch; n_long: device counter (reset by the count pass)
-template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, void* long_items,
-                                     uint32_t* n_long, hipStream_t);
+template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const SweepScratch&, hipStream_t);
+template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const SweepScratch&, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
 size_t sweep_long_item_bytes();
+uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
 // k_transfer.hip: host-layout (interleaved xyz) <-> device Vec4 records

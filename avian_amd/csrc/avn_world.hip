@@ -105,8 +105,9 @@ template <class T> struct World : WorldBase {
     DevBuf b_sb_lin, b_sb_ang, b_sb_dp, b_sb_dq, b_si_a, b_si_b, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_force;
-    DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_min, b_s_max, b_s_info, b_s_flags;
-    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items;
+    DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
+    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
+    SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
     // host state
@@ -162,7 +163,8 @@ template <class T> struct World : WorldBase {
         b_misc.ensure(4096, err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         HIPCHK(hipMemsetAsync(b_misc.p, 0, 4096, stream));
-        // misc layout: [0..25) color offsets, [32] constraint count, [33] n_dropped, [34] pair total
+        // misc layout: [0..25) color offsets, [32] constraint count, [33] n_dropped, [34] unsorted flag, [35] pair total,
+        // [36] long chunks used, [37] long chunk overflow
         dw.color_offsets = b_misc.as<uint32_t>();
         dw.constraint_count = b_misc.as<uint32_t>() + 32;
         return config_set(c);
@@ -658,13 +660,21 @@ template <class T> struct World : WorldBase {
             size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
             GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
             GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
-            GROW(b_s_min, cc, bp.s_min); GROW(b_s_max, cc, bp.s_max); GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
+            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc, bp.s_yz); GROW(b_s_end, cc, bp.s_end);
+            GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
             Key* dummy_k; uint32_t* dummy_u;
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
             GROW(b_hist, (size_t)256 * radix_blocks((uint32_t)cc) + 256, dummy_u);
-            GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc)) + 16, dummy_u);
-            GROW(b_counts, cc + 1, dummy_u); GROW(b_offsets, cc + 1, dummy_u);
-            { uint8_t* dummy_b; GROW(b_long_items, (cc + 1) * sweep_long_item_bytes(), dummy_b); }
+            GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc * sweep_count_slots())) + 16, dummy_u);
+            GROW(b_counts, cc * sweep_count_slots() + 1, dummy_u); GROW(b_offsets, cc * sweep_count_slots() + 1, dummy_u);
+            {   // long-interval chunks: every interval may need one slot, plus room for the chunks of scene-spanning ones
+                size_t lcap = cc + 65536;
+                uint8_t* dummy_b;
+                GROW(b_long_items, lcap * sweep_long_item_bytes(), dummy_b);
+                GROW(b_long_counts, lcap, dummy_u); GROW(b_long_off, lcap, dummy_u);
+                sweep_scratch.long_items = b_long_items.p; sweep_scratch.long_counts = b_long_counts.as<uint32_t>();
+                sweep_scratch.long_off = b_long_off.as<uint32_t>(); sweep_scratch.long_cap = (uint32_t)lcap;
+            }
             cap_colliders = (uint32_t)cc;
         }
         bp.n_colliders = C;
@@ -720,29 +730,32 @@ template <class T> struct World : WorldBase {
         h_pairs.clear();
         last_timers.pair_count = 0;
         if (n == 0) return AVN_OK;
+        if (n > (1u << 26)) { error = "collect_collision_pairs: more than 2^26 intervals"; return AVN_ERR_CAPACITY; }
         uint32_t* misc = b_misc.as<uint32_t>();
-        uint32_t* d_dropped = misc + 33;
-        uint32_t* d_total = misc + 34;
+        uint32_t* d_dropped = misc + 33;   // [33] dropped, [34] unsorted
+        uint32_t* d_total = misc + 35;
+        sweep_scratch.n_long = misc + 36;  // [36] chunks, [37] overflow
         Key* keys_a = b_keys_a.as<Key>(); Key* keys_b = b_keys_b.as<Key>();
         uint32_t* vals_a = b_vals_a.as<uint32_t>(); uint32_t* vals_b = b_vals_b.as<uint32_t>();
         launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, stream);
-        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), stream);
+        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), d_dropped + 1, stream);
         launch_gather_sorted<T>(dw, bp, vals_a, n, stream);
-        uint32_t* d_nlong = misc + 35;
-        launch_sweep<T>(bp, n, false, b_counts.as<uint32_t>(), nullptr, nullptr, b_long_items.p, d_nlong, stream);
-        launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n, b_block_sums.as<uint32_t>(), d_total, stream);
-        launches += 5 + 5 * (uint32_t)sizeof(Key) + 3;
+        launch_sweep_ranges<T>(bp, n, sweep_scratch, stream);
+        launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
+        launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, stream);
+        launches += 3 + 5 * (uint32_t)sizeof(Key) + 3 + 3;
         HIPCHK(hipGetLastError());
-        uint32_t rb[2] = {0, 0};
-        HIPCHK(hipMemcpyAsync(rb, d_dropped, 8, hipMemcpyDeviceToHost, stream));
+        uint32_t rb[5] = {0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyAsync(rb, d_dropped, sizeof rb, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
-        uint32_t dropped = rb[0], total = rb[1];
+        uint32_t dropped = rb[0], total = rb[2];
+        if (rb[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
         if (total) {
             hipError_t err;
             b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
             if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
-            launch_sweep<T>(bp, n, true, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), b_long_items.p, d_nlong, stream);
-            ++launches;
+            launch_sweep<T>(bp, n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), stream);
+            launches += 2;
             HIPCHK(hipGetLastError());
             h_pairs.resize(total);
             HIPCHK(hipMemcpyAsync(h_pairs.data(), b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, stream));

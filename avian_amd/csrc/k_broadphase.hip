@@ -9,13 +9,16 @@
 //                              (wave64 ballot match-any ranks).  A stable sort of the current order by the same
 //                              comparison yields exactly the permutation of the stable insertion sort.
 //   4. k_gather_sorted         interval records into sorted SoA
-//   5. k_sweep<EMIT=false>     per-interval pair COUNT; block = 256 consecutive i, candidate j staged through
-//                              LDS in tiles of 256 and broadcast-read (conflict-free), early-out per lane
-//   6. exclusive scan of the counts
-//   7. k_sweep<EMIT=true>      every lane re-walks its candidates and writes its pairs at its own offset
+//                              (skipped on device when the persistent order is still sorted)
+//   4. k_gather_sorted         interval records into sorted SoA (min.x | max.x | (min.y,max.y,min.z,max.z) | info | flags)
+//   5. k_sweep_ranges          end(i) by binary search; scene-spanning intervals are cut into chunks (LongItems)
+//   6. k_sweep<EMIT=false>     per-interval pair COUNT: wave = 64 consecutive i, candidate j wave-uniform and fetched by
+//      k_sweep_long<false>     SCALAR loads, hits compacted into an LDS queue and filtered 64 at a time (see "sweep")
+//   7. exclusive scan of the counts
+//   8. k_sweep<EMIT=true>      every lane re-walks its candidates and writes its pairs at its own offset
 //                              => output is already in the reference's emission order, no post-sort.
-// Integer/compare work only; HBM-bound on the sorted interval records, ALU-bound in the sweep for dense
-// scenes (every lane tests O(k) candidates out of LDS).
+// Integer/compare work only; VALU-bound in the sweep for dense scenes (O(k) tests per interval), HBM/L2 traffic is the
+// sorted records once per 64 intervals.
 #include "avn_kernels.h"
 
 namespace avn {
@@ -102,6 +105,16 @@ __global__ __launch_bounds__(256) void k_interval_keys(DW<T> w, BP<T> bp, typena
     keys[i] = k;
     vals[i] = c;
     if (!finite) atomicAdd(n_dropped, 1u);
+    // is the persistent order still sorted by this frame's keys?  (n_dropped[1] = "unsorted" flag; a dropped entry that is
+    // not already last also counts as unsorted because its key is MAX)
+    if (i > 0) {
+        uint32_t cp = bp.iv_collider[i - 1];
+        Vec4<T> pmn = bp.aabb_min[cp], pmx = bp.aabb_max[cp];
+        bool pfinite = is_finite(xyz<T>(pmn)) && is_finite(xyz<T>(pmx));
+        typename BP<T>::Key kp = pfinite ? order_key(pmn.x) : KeyMax<typename BP<T>::Key>::v;
+        if (pfinite && kp == KeyMax<typename BP<T>::Key>::v) kp -= 1;
+        if (kp > k) n_dropped[1] = 1u;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -110,8 +123,10 @@ __global__ __launch_bounds__(256) void k_interval_keys(DW<T> w, BP<T> bp, typena
 #define RS_ROUNDS 16
 
 template <class K>
-__global__ __launch_bounds__(64) void k_radix_hist(const K* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t* __restrict__ hist, uint32_t nblocks) {
+__global__ __launch_bounds__(64) void k_radix_hist(const K* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t* __restrict__ hist, uint32_t nblocks,
+                                                   const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t cnt[256];
+    if (enabled && *enabled == 0u) return;
     uint32_t lane = threadIdx.x, b = blockIdx.x;
     for (uint32_t d = lane; d < 256; d += 64) cnt[d] = 0;
     __syncthreads();
@@ -127,8 +142,9 @@ __global__ __launch_bounds__(64) void k_radix_hist(const K* __restrict__ keys, u
 template <class K>
 __global__ __launch_bounds__(64) void k_radix_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
                                                       uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift,
-                                                      const uint32_t* __restrict__ hist_scanned, uint32_t nblocks) {
+                                                      const uint32_t* __restrict__ hist_scanned, uint32_t nblocks, const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t run[256];
+    if (enabled && *enabled == 0u) return;
     uint32_t lane = threadIdx.x, b = blockIdx.x;
     for (uint32_t d = lane; d < 256; d += 64) run[d] = hist_scanned[d * nblocks + b];
     __syncthreads();
@@ -161,8 +177,9 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const K* __restrict__ keys
 // ---------------------------------------------------------------------------------------------------------
 // exclusive scan (uint32), three kernels; tile = 2048
 #define SC_TILE 2048
-__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums) {
+__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums, const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t red[256];
+    if (enabled && *enabled == 0u) return;
     uint32_t base = blockIdx.x * SC_TILE, t = threadIdx.x, s = 0;
     for (uint32_t k = 0; k < SC_TILE / 256; ++k) { uint32_t i = base + t * (SC_TILE / 256) + k; if (i < n) s += in[i]; }
     red[t] = s;
@@ -170,10 +187,11 @@ __global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ 
     for (uint32_t st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
     if (t == 0) sums[blockIdx.x] = red[0];
 }
-__global__ __launch_bounds__(256) void k_scan_top(uint32_t* sums, uint32_t nb, uint32_t* total) {
+__global__ __launch_bounds__(256) void k_scan_top(uint32_t* sums, uint32_t nb, uint32_t* total, const uint32_t* __restrict__ enabled) {
     // single block: sequential over chunks of 256 with a running carry
     __shared__ uint32_t buf[256];
     __shared__ uint32_t carry;
+    if (enabled && *enabled == 0u) return;
     uint32_t t = threadIdx.x;
     if (t == 0) carry = 0;
     __syncthreads();
@@ -196,8 +214,9 @@ __global__ __launch_bounds__(256) void k_scan_top(uint32_t* sums, uint32_t nb, u
     }
     if (t == 0 && total) *total = carry;
 }
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, const uint32_t* __restrict__ sums) {
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* __restrict__ sums, const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t buf[256];
+    if (enabled && *enabled == 0u) return;
     uint32_t base = blockIdx.x * SC_TILE, t = threadIdx.x;
     const uint32_t per = SC_TILE / 256;
     uint32_t v[per];
@@ -214,12 +233,12 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     uint32_t excl = buf[t] - s + sums[blockIdx.x];
     for (uint32_t k = 0; k < per; ++k) { uint32_t i = base + t * per + k; if (i < n) out[i] = excl; excl += v[k]; }
 }
-void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t s) {
+void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t s, const uint32_t* enabled) {
     if (n == 0) { if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s); return; }
     uint32_t nb = (n + SC_TILE - 1) / SC_TILE;
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, s, in, n, block_sums);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, nb, total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, block_sums);
+    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, s, in, n, block_sums, enabled);
+    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, nb, total, enabled);
+    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, block_sums, enabled);
 }
 uint32_t scan_block_sums_needed(uint32_t n) { return (n + SC_TILE - 1) / SC_TILE + 1; }
 
@@ -253,8 +272,9 @@ __global__ __launch_bounds__(256) void k_gather_sorted(DW<T> w, BP<T> bp, const 
         mx = make4<T>(-inf, -inf, -inf, 0);
         f = AVN_IV_DROPPED;
     }
-    bp.s_min[i] = mn;
-    bp.s_max[i] = mx;
+    bp.s_minx[i] = mn.x;
+    bp.s_maxx[i] = mx.x;
+    bp.s_yz[i] = make4<T>(mn.y, mx.y, mn.z, mx.z);
     bp.s_info[i] = make_uint4(ci.x, ci.y, layers.x, layers.y);
     bp.s_flags[i] = f;
 }
@@ -307,30 +327,40 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 // ---------------------------------------------------------------------------------------------------------
 // sweep
 //
-// Load balance: with one lane per interval, an interval whose AABB spans the scene (a ground plane) would make a single
-// lane walk every later interval (100k serial iterations ~ 18 ms on cfg2).  Each lane therefore walks at most SW_CAP
-// candidates; the remainder of such a "long" interval is recorded as a LongItem and swept by k_sweep_long, where a whole
-// workgroup strides over the candidates of ONE interval (256 at a time, ballot + LDS scan for in-order positions).
-// Emission order per interval stays j ascending: [short part][long part], i.e. exactly the reference's order.
-#define SW_THREADS 256
+// For interval i (sorted by min.x) the reference walks j = i+1.. until min_x[j] > max_x[i] (broad_phase.rs:387-392).
+// Because the list is sorted, that stop index end(i) is a pure function of the sorted keys: k_sweep_ranges finds it by
+// binary search, so the sweep itself has NO data-dependent loop exit.
+//
+// k_sweep: one WAVE owns 64 consecutive intervals (lane = i).  The candidate index j is wave-uniform, so the candidate's
+// (min.y, max.y, min.z, max.z) record is fetched with SCALAR loads (s_load_dwordx4/x8 through the scalar cache) eight at
+// a time and compared against the lane's own box held in VGPRs: ~7 VALU instructions per 64 tests, no LDS traffic, no
+// barriers.  Geometric hits are rare (a few per thousand tests); they are compacted with ballot/popcount into a
+// per-wave LDS queue of (lane, j) entries and filtered 64 at a time (layers, same body, inactive, ContactGraph pair set,
+// joint-disabled set: random 8-byte probes, latency amortised over the wave).  Entries of one lane stay in ascending j
+// order, so every lane emits at its own running offset => the output is already in the reference's (i asc, j asc) order.
+//
+// Intervals with more than SW_CAP candidates (a ground slab that spans the scene) would serialise a wave: they are cut
+// into chunks of SW_LCHUNK candidates by k_sweep_ranges and swept by k_sweep_long with a whole workgroup per chunk
+// (lane = j, coalesced vector loads); k_long_finish turns the chunk counts into in-interval offsets.
+#define SW_WAVES 4
+#define SW_THREADS (64 * SW_WAVES)
+#define SW_Q 1024   // ring slots per wave: < 64 carried + 8 x 64 appended per batch
 #define SW_CAP 8192u
+#define SW_LCHUNK 4096u
 
-struct LongItem { uint32_t i, j_start, short_count, pad; };
+struct LongItem { uint32_t i, j_start, j_end, n_chunks; };  // n_chunks != 0 only on the first chunk of an interval
 
-template <class T> struct SweepSelf { V3<T> mn, mx; uint4 info; uint32_t flags; };
+struct PairSets { const uint64_t* pair_set; uint32_t pair_set_cap; const uint64_t* disabled_set; uint32_t disabled_cap; };
 
-// all pair filters of broad_phase.rs:390-439 after the x test; returns true when (self, other) becomes a new pair
-template <class T>
-__device__ __forceinline__ bool pair_passes(const BP<T>& bp, const SweepSelf<T>& a, T miny, T minz, T maxy, T maxz, uint4 in2, uint32_t f2) {
-    if (a.mn.y > maxy || a.mx.y < miny) return false;                                        // y disjoint
-    if (a.mn.z > maxz || a.mx.z < minz) return false;                                        // z disjoint
-    bool interacts = (a.info.z & in2.w) != 0 && (in2.z & a.info.w) != 0;                     // CollisionLayers::interacts_with
-    if ((a.flags & f2 & AVN_AABB_IS_INACTIVE) || !interacts || a.info.y == in2.y) return false;
-    uint64_t key = a.info.x < in2.x ? ((uint64_t)a.info.x << 32) | in2.x : ((uint64_t)in2.x << 32) | a.info.x;
-    if (bp.pair_set_cap && hs_contains(bp.pair_set, bp.pair_set_cap - 1, key)) return false;
-    if (bp.disabled_cap) {
-        uint64_t bk = a.info.y < in2.y ? ((uint64_t)a.info.y << 32) | in2.y : ((uint64_t)in2.y << 32) | a.info.y;
-        if (hs_contains(bp.disabled_set, bp.disabled_cap - 1, bk)) return false;
+// pair filters of broad_phase.rs:407-439 (after the x / y / z tests); true when (1, 2) becomes a new pair
+__device__ __forceinline__ bool pair_filters(const PairSets& hs, uint4 in1, uint32_t f1, uint4 in2, uint32_t f2) {
+    bool interacts = (in1.z & in2.w) != 0 && (in2.z & in1.w) != 0;                         // CollisionLayers::interacts_with
+    if ((f1 & f2 & AVN_AABB_IS_INACTIVE) || !interacts || in1.y == in2.y) return false;
+    uint64_t key = in1.x < in2.x ? ((uint64_t)in1.x << 32) | in2.x : ((uint64_t)in2.x << 32) | in1.x;
+    if (hs.pair_set_cap && hs_contains(hs.pair_set, hs.pair_set_cap - 1, key)) return false;
+    if (hs.disabled_cap) {
+        uint64_t bk = in1.y < in2.y ? ((uint64_t)in1.y << 32) | in2.y : ((uint64_t)in2.y << 32) | in1.y;
+        if (hs_contains(hs.disabled_set, hs.disabled_cap - 1, bk)) return false;
     }
     return true;
 }
@@ -344,85 +374,175 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
     return pr;
 }
 
-template <class T, bool EMIT>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep(BP<T> bp, uint32_t n, uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets,
-                                                       avn_pair* __restrict__ out, LongItem* __restrict__ long_items, uint32_t* __restrict__ n_long) {
-    __shared__ Vec4<T> l_a[SW_THREADS];   // (min.x, min.y, min.z, max.y)
-    __shared__ T l_maxz[SW_THREADS];
-    __shared__ uint4 l_info[SW_THREADS];
-    __shared__ uint32_t l_flags[SW_THREADS];
-    uint32_t t = threadIdx.x;
-    uint32_t tile = xcd_block(blockIdx.x, gridDim.x);
-    uint32_t i0 = tile * SW_THREADS;
-    if (i0 >= n) return;  // uniform per block
-    uint32_t i = i0 + t;
-    bool valid = i < n;
-    SweepSelf<T> self;
-    self.mn = vzero<T>(); self.mx = vzero<T>(); self.info = make_uint4(0, 0, 0, 0); self.flags = 0;
-    if (valid) { self.mn = xyz<T>(bp.s_min[i]); self.mx = xyz<T>(bp.s_max[i]); self.info = bp.s_info[i]; self.flags = bp.s_flags[i]; }
-    bool done = !valid || (self.flags & AVN_IV_DROPPED);
-    uint32_t count = 0;
-    uint32_t pos = (EMIT && valid) ? offsets[i] : 0u;
-    uint32_t j_cap = i + 1u + SW_CAP;  // first candidate NOT handled by this lane
-    for (uint32_t j0 = i0; j0 < n; j0 += SW_THREADS) {
-        uint32_t jl = j0 + t;
-        if (jl < n) {
-            Vec4<T> a = bp.s_min[jl], b = bp.s_max[jl];
-            l_a[t] = make4<T>(a.x, a.y, a.z, b.y);
-            l_maxz[t] = b.z;
-            l_info[t] = bp.s_info[jl];
-            l_flags[t] = bp.s_flags[jl];
+// end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems
+template <class T>
+__global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __restrict__ s_minx, const T* __restrict__ s_maxx, uint32_t* __restrict__ s_end,
+                                                       uint32_t* __restrict__ s_flags, LongItem* __restrict__ items, uint32_t* __restrict__ n_long,
+                                                       uint32_t long_cap, uint32_t* __restrict__ overflow) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f = s_flags[i];
+    uint32_t end = i + 1;
+    if (!(f & AVN_IV_DROPPED)) {
+        T mx = s_maxx[i];
+        uint32_t lo = i + 1, hi = n;  // first index in [lo, hi] whose min.x > mx  (x test: `min_x[j] > max_x[i]` ends the sweep)
+        while (lo < hi) {
+            uint32_t mid = lo + ((hi - lo) >> 1);
+            if (s_minx[mid] > mx) hi = mid; else lo = mid + 1;
         }
-        __syncthreads();
-        if (!done) {
-            uint32_t lim = min((uint32_t)SW_THREADS, n - j0);
-            uint32_t jj = (j0 == i0) ? t + 1 : 0u;  // j > i
-            for (; jj < lim; ++jj) {
-                if (j0 + jj >= j_cap) {  // hand the rest of a long interval to k_sweep_long
-                    if (!EMIT) { uint32_t k = atomicAdd(n_long, 1u); long_items[k] = LongItem{i, j_cap, count, 0u}; }
-                    done = true;
-                    break;
-                }
-                Vec4<T> a = l_a[jj];
-                if (a.x > self.mx.x) { done = true; break; }  // x: sweep ends (broad_phase.rs:390-392)
-                if (self.mn.y > a.w || self.mx.y < a.y) continue;  // cheap y reject before touching the other LDS arrays
-                if (!pair_passes<T>(bp, self, a.y, a.z, a.w, l_maxz[jj], l_info[jj], l_flags[jj])) continue;
-                if (EMIT) out[pos] = make_pair(self.info, self.flags, l_info[jj], l_flags[jj]);
-                ++pos;
-                ++count;
-            }
-        }
-        if (__syncthreads_and(done ? 1 : 0)) break;
+        end = lo;
     }
-    if (!EMIT && valid) counts[i] = count;
+    uint32_t len = end - (i + 1);
+    if (len > SW_CAP) {
+        uint32_t nch = (len + SW_LCHUNK - 1) / SW_LCHUNK;
+        uint32_t k = atomicAdd(n_long, nch);
+        if (k + nch > long_cap) { *overflow = 1u; }
+        else
+            for (uint32_t c = 0; c < nch; ++c) {
+                uint32_t js = i + 1 + c * SW_LCHUNK;
+                items[k + c] = LongItem{i, js, min(js + SW_LCHUNK, end), c == 0 ? nch : 0u};
+            }
+        s_flags[i] = f | AVN_IV_LONG;
+        end = i + 1;  // nothing left for k_sweep
+    }
+    s_end[i] = end;
 }
 
-// One workgroup per long interval (grid-stride over the LongItem list).
 template <class T, bool EMIT>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep_long(BP<T> bp, uint32_t n, const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long,
-                                                            uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
-    __shared__ uint32_t wave_tot[SW_THREADS / 64];
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const uint32_t* __restrict__ s_end,
+                                                       const uint4* __restrict__ s_info, const uint32_t* __restrict__ s_flags, PairSets hs,
+                                                       uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
+    __shared__ uint32_t l_q[SW_WAVES][SW_Q];
+    __shared__ uint4 l_info[SW_WAVES][64];
+    __shared__ uint32_t l_flags[SW_WAVES][64];
+    __shared__ uint32_t l_cnt[SW_WAVES][64];  // count pass: pairs found; emit pass: running output position
+    const uint32_t lane = threadIdx.x & 63u;
+    // threadIdx.x >> 6 is wave-uniform, but the compiler cannot know: readfirstlane makes it (and i0, j) provably
+    // uniform so that the candidate records are fetched with scalar loads
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // a workgroup owns 64 consecutive intervals; its SW_WAVES waves each sweep one contiguous quarter of the candidate
+    // range (more waves in flight to hide the scalar-load latency, and 4x shorter serial loops).  Output stays ordered:
+    // counts/offsets are kept per (interval, quarter), quarter-major inside the interval.
+    const uint32_t i0 = xcd_block(blockIdx.x, gridDim.x) * 64u;
+    if (i0 >= n) return;  // workgroup-uniform; the kernel has no workgroup barrier
+    const uint32_t i = i0 + lane;
+    const bool valid = i < n;
+    Vec4<T> me = valid ? s_yz[i] : make4<T>(0, 0, 0, 0);  // (min.y, max.y, min.z, max.z)
+    const uint32_t end_i = valid ? s_end[i] : 0u;
+    const uint32_t my_flags = valid ? s_flags[i] : 0u;
+    l_info[wv][lane] = valid ? s_info[i] : make_uint4(0, 0, 0, 0);
+    l_flags[wv][lane] = my_flags;
+    l_cnt[wv][lane] = (EMIT && valid) ? offsets[i * SW_WAVES + wv] : 0u;
+    uint32_t je = end_i;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) je = max(je, (uint32_t)__shfl_xor((int)je, off));
+    je = (uint32_t)__builtin_amdgcn_readfirstlane((int)je);
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    uint32_t qn = 0;  // wave-uniform queue fill
+
+    // filter up to 64 queued (lane, j) entries at once; the queue is a ring of SW_Q slots starting at `head`
+    uint32_t head = 0;
+    auto drain = [&](uint32_t nq) {
+        bool act = lane < nq;
+        uint32_t e = act ? l_q[wv][(head + lane) & (SW_Q - 1u)] : 0u;
+        uint32_t src = e >> 26, jj = i0 + (e & 0x3FFFFFFu);
+        bool pass = false;
+        uint4 in1 = make_uint4(0, 0, 0, 0), in2 = in1;
+        uint32_t f1 = 0, f2 = 0;
+        if (act) {
+            in1 = l_info[wv][src]; f1 = l_flags[wv][src];
+            in2 = s_info[jj]; f2 = s_flags[jj];
+            pass = pair_filters(hs, in1, f1, in2, f2);
+        }
+        if (!EMIT) {
+            if (pass) atomicAdd(&l_cnt[wv][src], 1u);
+        } else {
+            // deterministic in-order positions: entries of one source lane are in ascending j (= ascending queue slot)
+            unsigned long long rem = __ballot(pass);
+            uint32_t pos = 0;
+            while (rem) {
+                int leader = __ffsll((long long)rem) - 1;
+                uint32_t s = (uint32_t)__shfl((int)src, leader);
+                unsigned long long m = __ballot(pass && src == s);
+                uint32_t base = l_cnt[wv][s];
+                if (pass && src == s) pos = base + (uint32_t)__popcll(m & lt_mask);
+                __builtin_amdgcn_wave_barrier();
+                if ((int)lane == leader) l_cnt[wv][s] = base + (uint32_t)__popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                rem &= ~m;
+            }
+            if (pass) out[pos] = make_pair(in1, f1, in2, f2);
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    constexpr uint32_t SW_BATCH = sizeof(T) == 4 ? 8u : 4u;  // candidates per scalar-load batch (SGPR budget)
+    // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je)
+    uint32_t qlen = (je - (i0 + 1u) + SW_WAVES - 1u) / SW_WAVES;
+    qlen = (qlen + SW_BATCH - 1u) / SW_BATCH * SW_BATCH;
+    const uint32_t jb = i0 + 1u + wv * qlen;
+    const uint32_t jq = min(je, jb + qlen);
+    for (uint32_t j = jb; j < jq; j += SW_BATCH) {
+        Vec4<T> c[SW_BATCH];
+#pragma unroll
+        for (uint32_t k = 0; k < SW_BATCH; ++k) c[k] = s_yz[min(j + k, n - 1u)];  // wave-uniform address: scalar load
+        unsigned long long hm[SW_BATCH], any = 0ull;
+#pragma unroll
+        for (uint32_t k = 0; k < SW_BATCH; ++k) {
+            uint32_t jj = j + k;
+            // y / z rejection exactly as broad_phase.rs:394-403 (strict compares: touching counts as overlapping);
+            // bitwise & keeps the test branch-free: six v_cmp whose SGPR masks are and-ed on the scalar unit
+            bool hit = (jj > i) & (jj < end_i) & (jj < jq) & !(me.x > c[k].y) & !(me.y < c[k].x) & !(me.z > c[k].w) & !(me.w < c[k].z);
+            hm[k] = __ballot(hit);
+            any |= hm[k];
+        }
+        if (any) {  // rare: compact the hits into the queue (j ascending, then lane ascending)
+#pragma unroll
+            for (uint32_t k = 0; k < SW_BATCH; ++k) {
+                if (hm[k]) {
+                    if ((hm[k] >> lane) & 1ull) l_q[wv][(head + qn + (uint32_t)__popcll(hm[k] & lt_mask)) & (SW_Q - 1u)] = (lane << 26) | (j + k - i0);
+                    qn += (uint32_t)__popcll(hm[k]);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= 64u) { drain(64u); head = (head + 64u) & (SW_Q - 1u); qn -= 64u; }
+        }
+    }
+    if (qn) drain(qn);
+    __builtin_amdgcn_wave_barrier();
+    if (!EMIT && valid) {
+        if (!(my_flags & AVN_IV_LONG)) counts[i * SW_WAVES + wv] = l_cnt[wv][lane];
+        else if (wv != 0) counts[i * SW_WAVES + wv] = 0u;  // slot 0 of a long interval is written by k_long_finish
+    }
+}
+
+// One workgroup per LongItem chunk (grid-stride): lane = candidate j.
+template <class T, bool EMIT>
+__global__ __launch_bounds__(SW_THREADS) void k_sweep_long(const Vec4<T>* __restrict__ s_yz, const uint4* __restrict__ s_info, const uint32_t* __restrict__ s_flags,
+                                                            PairSets hs, const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long,
+                                                            uint32_t* __restrict__ long_counts, const uint32_t* __restrict__ long_off,
+                                                            const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
+    __shared__ uint32_t wave_tot[SW_WAVES];
     uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
     uint32_t nl = *n_long;
     for (uint32_t it = blockIdx.x; it < nl; it += gridDim.x) {
         LongItem item = items[it];
         uint32_t i = item.i;
-        SweepSelf<T> self;
-        self.mn = xyz<T>(bp.s_min[i]); self.mx = xyz<T>(bp.s_max[i]); self.info = bp.s_info[i]; self.flags = bp.s_flags[i];
+        Vec4<T> me = s_yz[i];
+        uint4 in1 = s_info[i];
+        uint32_t f1 = s_flags[i];
         uint32_t running = 0;
-        uint32_t base = EMIT ? offsets[i] + item.short_count : 0u;
-        for (uint32_t j0 = item.j_start; j0 < n; j0 += SW_THREADS) {
+        uint32_t base = EMIT ? offsets[i * SW_WAVES] + long_off[it] : 0u;
+        for (uint32_t j0 = item.j_start; j0 < item.j_end; j0 += SW_THREADS) {
             uint32_t j = j0 + t;
-            bool beyond = true, ok = false;
+            bool ok = false;
             uint4 in2 = make_uint4(0, 0, 0, 0);
             uint32_t f2 = 0;
-            if (j < n) {
-                Vec4<T> a = bp.s_min[j];
-                beyond = a.x > self.mx.x;
-                if (!beyond) {
-                    Vec4<T> b = bp.s_max[j];
-                    in2 = bp.s_info[j]; f2 = bp.s_flags[j];
-                    ok = pair_passes<T>(bp, self, a.y, a.z, b.y, b.z, in2, f2);
+            if (j < item.j_end) {
+                Vec4<T> c = s_yz[j];
+                if (!(me.x > c.y || me.y < c.x) && !(me.z > c.w || me.w < c.z)) {
+                    in2 = s_info[j]; f2 = s_flags[j];
+                    ok = pair_filters(hs, in1, f1, in2, f2);
                 }
             }
             unsigned long long bal = __ballot(ok);
@@ -430,14 +550,25 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_long(BP<T> bp, uint32_t n,
             __syncthreads();
             uint32_t before = 0, total = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < SW_THREADS / 64; ++k) { uint32_t v = wave_tot[k]; if (k < wv) before += v; total += v; }
-            if (EMIT && ok) out[base + running + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_pair(self.info, self.flags, in2, f2);
+            for (uint32_t k = 0; k < SW_WAVES; ++k) { uint32_t v = wave_tot[k]; if (k < wv) before += v; total += v; }
+            if (EMIT && ok) out[base + running + before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = make_pair(in1, f1, in2, f2);
             running += total;
-            // sorted by min.x: once any candidate of this stride is beyond max.x, every later one is too
-            if (__syncthreads_or(beyond ? 1 : 0)) break;
+            __syncthreads();
         }
-        if (!EMIT && t == 0) counts[i] += running;  // single writer per interval, after k_sweep<false> completed
-        __syncthreads();
+        if (!EMIT && t == 0) long_counts[it] = running;
+    }
+}
+
+// per long interval: chunk counts -> in-interval chunk offsets, and the interval's total into counts[i]
+__global__ __launch_bounds__(256) void k_long_finish(const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long, const uint32_t* __restrict__ long_counts,
+                                                      uint32_t* __restrict__ long_off, uint32_t* __restrict__ counts) {
+    uint32_t nl = *n_long;
+    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nl; k += gridDim.x * 256) {
+        LongItem it = items[k];
+        if (!it.n_chunks) continue;
+        uint32_t run = 0;
+        for (uint32_t c = 0; c < it.n_chunks; ++c) { long_off[k + c] = run; run += long_counts[k + c]; }
+        counts[it.i * SW_WAVES] = run;
     }
 }
 
@@ -447,20 +578,23 @@ template <class T> void launch_update_aabb(const DW<T>& w, const BP<T>& bp, cons
     if (bp.n_colliders) hipLaunchKernelGGL(k_update_aabb<T>, dim3((bp.n_colliders + 255) / 256), dim3(256), 0, s, w, bp, p);
 }
 template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t s) {
-    (void)hipMemsetAsync(n_dropped, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(n_dropped, 0, 2 * sizeof(uint32_t), s);  // [n_dropped, unsorted]
     if (bp.n_intervals) hipLaunchKernelGGL(k_interval_keys<T>, dim3((bp.n_intervals + 255) / 256), dim3(256), 0, s, w, bp, keys, vals, n_dropped);
 }
 uint32_t radix_blocks(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
-template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums, hipStream_t s) {
-    // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even
+template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
+                                          const uint32_t* unsorted, hipStream_t s) {
+    // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even.  Every kernel
+    // returns at once when *unsorted == 0 (the persistent interval order is still sorted: the reference's insertion sort
+    // is O(n) then, ours is O(launch)).
     if (n == 0) return;
     uint32_t nb = radix_blocks(n);
     K* ki = keys_a; uint32_t* vi = vals_a; K* ko = keys_b; uint32_t* vo = vals_b;
     for (uint32_t pass = 0; pass < sizeof(K); ++pass) {
         uint32_t shift = pass * 8;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb);
-        launch_exclusive_scan(hist, hist, 256 * nb, block_sums, nullptr, s);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb);
+        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, unsorted);
+        launch_exclusive_scan(hist, hist, 256 * nb, block_sums, nullptr, s, unsorted);
+        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, unsorted);
         K* tk = ki; ki = ko; ko = tk;
         uint32_t* tv = vi; vi = vo; vo = tv;
     }
@@ -468,32 +602,43 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
 template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, const uint32_t* sorted_collider, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_gather_sorted<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bp, sorted_collider, n);
 }
-template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, uint32_t* counts, const uint32_t* offsets, avn_pair* out, void* long_items,
-                                     uint32_t* n_long, hipStream_t s) {
+template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s) {
     if (!n) return;
-    uint32_t nb = (n + SW_THREADS - 1) / SW_THREADS;
+    (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
+    hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
+                       sc.n_long, sc.long_cap, sc.n_long + 1);
+}
+template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, const SweepScratch& sc, uint32_t* counts, const uint32_t* offsets, avn_pair* out,
+                                     hipStream_t s) {
+    if (!n) return;
+    uint32_t nb = (n + 63u) / 64u;
     nb = ((nb + 7) / 8) * 8;
-    LongItem* li = (LongItem*)long_items;
+    LongItem* li = (LongItem*)sc.long_items;
+    PairSets hs{bp.pair_set, bp.pair_set_cap, bp.disabled_set, bp.disabled_cap};
     if (emit) {
-        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out, li, n_long);
-        hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(1024), dim3(SW_THREADS), 0, s, bp, n, li, n_long, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
+                           sc.long_off, offsets, out);
     } else {
-        (void)hipMemsetAsync(n_long, 0, sizeof(uint32_t), s);
-        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, bp, n, counts, offsets, out, li, n_long);
-        hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(1024), dim3(SW_THREADS), 0, s, bp, n, li, n_long, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
+                           sc.long_off, offsets, out);
+        hipLaunchKernelGGL(k_long_finish, dim3(64), dim3(256), 0, s, li, sc.n_long, sc.long_counts, sc.long_off, counts);
     }
 }
 size_t sweep_long_item_bytes() { return sizeof(LongItem); }
+uint32_t sweep_count_slots() { return SW_WAVES; }
 
 #define INST(T)                                                                                          \
     template void launch_update_aabb<T>(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);  \
     template void launch_interval_keys<T>(const DW<T>&, const BP<T>&, typename BP<T>::Key*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_sorted<T>(const DW<T>&, const BP<T>&, const uint32_t*, uint32_t, hipStream_t); \
-    template void launch_sweep<T>(const BP<T>&, uint32_t, bool, uint32_t*, const uint32_t*, avn_pair*, void*, uint32_t*, hipStream_t);
+    template void launch_sweep_ranges<T>(const BP<T>&, uint32_t, const SweepScratch&, hipStream_t);     \
+    template void launch_sweep<T>(const BP<T>&, uint32_t, bool, const SweepScratch&, uint32_t*, const uint32_t*, avn_pair*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST
-template void launch_radix_sort<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, hipStream_t);
-template void launch_radix_sort<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, hipStream_t);
+template void launch_radix_sort<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
+template void launch_radix_sort<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
 
 }  // namespace avn
