@@ -116,6 +116,11 @@ class avn_pair(C.Structure):
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
 
 
+class avn_islands_in(C.Structure):
+    _fields_ = [("n_bodies", C.c_uint32), ("rb_type", vp), ("center_x", vp), ("n_edges", C.c_uint32),
+                ("edge_body1", vp), ("edge_body2", vp), ("n_ranks", C.c_uint32)]
+
+
 class avn_timers(C.Structure):
     _fields_ = [("broad_phase_ms", C.c_double), ("prepare_ms", C.c_double), ("substeps_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("step_ms", C.c_double), ("contact_constraint_count", C.c_uint32),
@@ -132,6 +137,7 @@ ABI_SYMBOLS = [
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
     "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
+    "islands_partition", "dynamic_bounds",
 ]
 
 
@@ -171,12 +177,26 @@ class Library:
         f("constraint_graph_push").restype = C.c_int32
         f("constraint_graph_pop").argtypes = [vp, C.c_uint64]
         f("constraint_graph_lists").argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        f("islands_partition").argtypes = [C.POINTER(avn_islands_in), vp, vp, C.POINTER(C.c_uint32)]
+        f("dynamic_bounds").argtypes = [vp, vp, vp]
 
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
 
     def pair_key(self, a: int, b: int) -> int:
         return int(self.fn("pair_key")(a, b))
+
+    def islands_partition(self, rb_type, center_x, edge_body1, edge_body2, n_ranks: int):
+        """``avn_islands_partition``: returns (island_of_body, rank_of_body, n_islands)."""
+        rb = np.ascontiguousarray(rb_type, np.uint8); cx = np.ascontiguousarray(center_x, np.float64)
+        e1 = np.ascontiguousarray(edge_body1, np.int32); e2 = np.ascontiguousarray(edge_body2, np.int32)
+        n = len(rb)
+        isl = np.empty(n, np.int32); rk = np.empty(n, np.int32); cnt = C.c_uint32(0)
+        a = avn_islands_in(n, _ptr(rb), _ptr(cx), len(e1), _ptr(e1), _ptr(e2), int(n_ranks))
+        st = self.fn("islands_partition")(C.byref(a), _ptr(isl), _ptr(rk), C.byref(cnt))
+        if st != 0:
+            raise AvnError(st, "islands_partition")
+        return isl, rk, int(cnt.value)
 
 
 def _ptr(a: Optional[np.ndarray]):
@@ -397,6 +417,11 @@ class World:
         ms, n = C.c_double(), C.c_uint32()
         self._check(self.lib.fn("profile_system")(self.handle, SYS[name], repeats, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def dynamic_bounds(self):
+        mn = np.empty(3, np.float64); mx = np.empty(3, np.float64)
+        self._check(self.lib.fn("dynamic_bounds")(self.handle, _ptr(mn), _ptr(mx)))
+        return mn, mx
 
     def step(self):
         self._check(self.lib.fn("step")(self.handle))

@@ -1,7 +1,11 @@
 // avn_abi.cpp — the extern "C" boundary (include/avian_mi355x.h) over the C++ host world.
 // No exception or HIP error crosses it: every entry point returns avn_status.
+#include <algorithm>
+#include <cmath>
 #include <new>
+#include <numeric>
 #include <string>
+#include <vector>
 
 #include "avn_world.hpp"
 
@@ -55,6 +59,68 @@ AVN_API avn_status avn_step(avn_world* w) { GUARD(step()); }
 AVN_API avn_status avn_synchronize(avn_world* w) { GUARD(synchronize()); }
 AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)); }
 AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD(profile_system(s, r, ms, l)); }
+AVN_API avn_status avn_dynamic_bounds(avn_world* w, double* mn, double* mx) { GUARD(dynamic_bounds(mn, mx)); }
+
+// Interaction islands + x-slab assignment (host integer work; see the header).  Union-find with path halving; islands
+// are numbered by their smallest body index; slabs cut the islands, ordered by mean x then id, at equal cumulative weight.
+AVN_API avn_status avn_islands_partition(const avn_islands_in* in, int32_t* island_of_body, int32_t* rank_of_body, uint32_t* n_islands) {
+    if (!in || !island_of_body || !rank_of_body || !n_islands || in->n_ranks == 0 || (in->n_bodies && (!in->rb_type || !in->center_x)) ||
+        (in->n_edges && (!in->edge_body1 || !in->edge_body2)))
+        return AVN_ERR_BAD_ARG;
+    try {
+        const uint32_t n = in->n_bodies;
+        std::vector<int32_t> parent(n);
+        std::iota(parent.begin(), parent.end(), 0);
+        auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        auto is_static = [&](int32_t b) { return in->rb_type[b] == AVN_RB_STATIC; };
+        std::vector<uint32_t> edge_count(n, 0);
+        for (uint32_t e = 0; e < in->n_edges; ++e) {
+            int32_t a = in->edge_body1[e], b = in->edge_body2[e];
+            if (a < 0 || b < 0 || (uint32_t)a >= n || (uint32_t)b >= n) return AVN_ERR_BAD_ARG;
+            bool sa = is_static(a), sb = is_static(b);
+            if (sa && sb) continue;
+            if (!sa && !sb) { int32_t ra = find(a), rb = find(b); if (ra != rb) { if (ra < rb) parent[rb] = ra; else parent[ra] = rb; } }
+            edge_count[sa ? b : a] += 1;  // the edge is carried by (one of) its non-static bodies
+        }
+        // number the islands by smallest member (roots are the smallest index because unions keep the smaller root)
+        std::vector<int32_t> id_of_root(n, -1);
+        uint32_t k = 0;
+        for (uint32_t b = 0; b < n; ++b) {
+            if (is_static((int32_t)b)) { island_of_body[b] = -1; continue; }
+            int32_t r = find((int32_t)b);
+            if (id_of_root[r] < 0) id_of_root[r] = (int32_t)k++;
+            island_of_body[b] = id_of_root[r];
+        }
+        *n_islands = k;
+        std::vector<double> sum_x(k, 0.0);
+        std::vector<uint64_t> weight(k, 0), members(k, 0);
+        for (uint32_t b = 0; b < n; ++b) {
+            int32_t i = island_of_body[b];
+            if (i < 0) continue;
+            sum_x[i] += in->center_x[b]; members[i] += 1; weight[i] += 1 + edge_count[b];
+        }
+        std::vector<uint32_t> order(k);
+        std::iota(order.begin(), order.end(), 0u);
+        std::vector<double> mean_x(k);
+        for (uint32_t i = 0; i < k; ++i) mean_x[i] = sum_x[i] / (double)members[i];
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return mean_x[a] < mean_x[b]; });
+        uint64_t total = 0;
+        for (uint32_t i = 0; i < k; ++i) total += weight[i];
+        std::vector<int32_t> rank_of_island(k, 0);
+        uint64_t cum = 0;
+        for (uint32_t o = 0; o < k; ++o) {
+            uint32_t i = order[o];
+            // the island goes to the slab that contains its weight midpoint: rank = floor((cum + w/2) * R / total)
+            unsigned __int128 mid2 = (unsigned __int128)(2 * cum + weight[i]) * in->n_ranks;
+            uint64_t r = total ? (uint64_t)(mid2 / ((unsigned __int128)2 * total)) : 0;
+            rank_of_island[i] = (int32_t)std::min<uint64_t>(r, in->n_ranks - 1);
+            cum += weight[i];
+        }
+        for (uint32_t b = 0; b < n; ++b) rank_of_body[b] = island_of_body[b] < 0 ? -1 : rank_of_island[island_of_body[b]];
+        return AVN_OK;
+    } catch (...) { return AVN_ERR_OOM; }
+}
+
 AVN_API uint64_t avn_pair_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
 
 AVN_API avn_status avn_constraint_graph_create(uint32_t, avn_constraint_graph** out) {

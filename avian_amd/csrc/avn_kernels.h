@@ -65,6 +65,8 @@ template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepPa
 // k_broadphase.hip
 template <class T> void launch_update_aabb(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);
 template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t);
+// partial: 6 * ceil(C / 256) scalars; returns the number of partial records written
+template <class T> uint32_t launch_dynamic_bounds(const DW<T>&, const BP<T>&, T* partial, hipStream_t);
 uint32_t radix_blocks(uint32_t n);
 uint32_t scan_block_sums_needed(uint32_t n);
 // `enabled` (device flag, may be null): when it reads 0 every kernel of the call returns immediately

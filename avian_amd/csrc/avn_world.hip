@@ -719,6 +719,24 @@ template <class T> struct World : WorldBase {
         if (n_iv) *n_iv = I;
         return AVN_OK;
     }
+    avn_status dynamic_bounds(double* mn, double* mx) override {
+        if (!mn || !mx) return AVN_ERR_BAD_ARG;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (int k = 0; k < 3; ++k) { mn[k] = inf; mx[k] = -inf; }
+        uint32_t nb = (bp.n_colliders + 255) / 256;
+        if (!nb) return AVN_OK;
+        avn_status st = stage_reserve((size_t)nb * 6 * sizeof(T) + 1024);
+        if (st != AVN_OK) return st;
+        T* part = stage_alloc<T>((size_t)nb * 6);
+        launch_dynamic_bounds<T>(dw, bp, part, stream);
+        HIPCHK(hipGetLastError());
+        std::vector<T> h((size_t)nb * 6);
+        HIPCHK(hipMemcpyAsync(h.data(), part, h.size() * sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        for (uint32_t b = 0; b < nb; ++b)
+            for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], (double)h[b * 6 + k]); mx[k] = std::max(mx[k], (double)h[b * 6 + 3 + k]); }
+        return AVN_OK;
+    }
     avn_status update_aabb() {
         launch_update_aabb<T>(dw, bp, params, stream);
         ++launches;

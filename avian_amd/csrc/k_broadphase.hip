@@ -75,6 +75,41 @@ __global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepPara
     bp.aabb_max[c] = make4<T>(mx + gg, 0);
 }
 
+// Per-workgroup partial union of the AABBs of colliders on non-static bodies (multi-GPU proximity bound, header:
+// avn_dynamic_bounds).  partial[b] = (min.xyz, max.xyz) as T; the host reduces the few hundred partials.
+template <class T>
+__global__ __launch_bounds__(256) void k_dynamic_bounds(DW<T> w, BP<T> bp, T* __restrict__ partial) {
+    __shared__ T red[6][256];
+    uint32_t c = blockIdx.x * 256 + threadIdx.x, t = threadIdx.x;
+    T inf = Limits<T>::max * T(2);
+    T v[6] = {inf, inf, inf, -inf, -inf, -inf};
+    if (c < bp.n_colliders) {
+        uint4 ci = bp.col_info[c];
+        if (meta_rb_type(w.bmeta[ci.y]) != AVN_RB_STATIC) {
+            Vec4<T> mn = bp.aabb_min[c], mx = bp.aabb_max[c];
+            v[0] = mn.x; v[1] = mn.y; v[2] = mn.z; v[3] = mx.x; v[4] = mx.y; v[5] = mx.z;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[k][t] = v[k];
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (t < st) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) red[k][t] = smin(red[k][t], red[k][t + st]);
+#pragma unroll
+            for (int k = 3; k < 6; ++k) red[k][t] = smax(red[k][t], red[k][t + st]);
+        }
+        __syncthreads();
+    }
+    if (t < 6) partial[blockIdx.x * 6 + t] = red[t][0];
+}
+template <class T> uint32_t launch_dynamic_bounds(const DW<T>& w, const BP<T>& bp, T* partial, hipStream_t s) {
+    uint32_t nb = (bp.n_colliders + 255) / 256;
+    if (nb) hipLaunchKernelGGL(k_dynamic_bounds<T>, dim3(nb), dim3(256), 0, s, w, bp, partial);
+    return nb;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // keys
 __device__ __forceinline__ uint32_t order_key(float x) {
@@ -634,6 +669,7 @@ uint32_t sweep_count_slots() { return SW_WAVES; }
     template void launch_interval_keys<T>(const DW<T>&, const BP<T>&, typename BP<T>::Key*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_sorted<T>(const DW<T>&, const BP<T>&, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_sweep_ranges<T>(const BP<T>&, uint32_t, const SweepScratch&, hipStream_t);     \
+    template uint32_t launch_dynamic_bounds<T>(const DW<T>&, const BP<T>&, T*, hipStream_t);            \
     template void launch_sweep<T>(const BP<T>&, uint32_t, bool, const SweepScratch&, uint32_t*, const uint32_t*, avn_pair*, hipStream_t);
 INST(float)
 INST(double)

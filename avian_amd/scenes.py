@@ -221,3 +221,16 @@ def brute_force_pairs(scene: Scene, margin: float = 0.005) -> np.ndarray:
     p = np.concatenate(out)
     both_static = (scene.rb_type[p[:, 0]] == F.RB_STATIC) & (scene.rb_type[p[:, 1]] == F.RB_STATIC)
     return p[~both_static]
+
+
+def box_stacks(n_stacks: int, nx: int, ny: int, nz: int, gap: float = 6.0) -> Scene:
+    """`n_stacks` independent box stacks (each as :func:`box_stack`) side by side along x on ONE static slab: the
+    weak-scaling scene of bench.py --gpus N (one interaction island per stack) and of the sharding tests."""
+    one = box_stack(nx, ny, nz)
+    pitch = nx * 1.0 + gap
+    centers = []
+    for s in range(n_stacks):
+        c = one.position[1:].copy()
+        c[:, 0] += (s - (n_stacks - 1) * 0.5) * pitch
+        centers.append(c)
+    return _assemble(np.concatenate(centers), (0.5, 0.5, 0.5), (0.0, -20.0, 0.0), (400.0 + n_stacks * pitch, 20.0, 400.0))

@@ -359,6 +359,32 @@ AVN_API avn_status AVN_FN(constraint_graph_pop)(avn_constraint_graph* g, uint64_
 AVN_API avn_status AVN_FN(constraint_graph_lists)(const avn_constraint_graph* g, uint32_t* offsets,
                                                   uint64_t* handles, size_t capacity, size_t* count);
 
+/* ---- multi-GPU sharding: interaction islands -------------------------------------------------
+ * Islands as in the reference's IslandPlugin (dynamics/solver/islands/mod.rs:1-10): bodies connected by constraint
+ * edges form an island; static bodies never merge islands (merge_islands early-returns for them, :822-834).  The
+ * edge set given here is the caller's choice; for sharding it is (broad-phase pairs U manifolds U joints), a superset
+ * of the reference's touching-contact edges, so that everything one island can interact with this step lives on one
+ * rank.  Islands are then assigned to `n_ranks` as contiguous slabs along x (the SAP axis) of balanced weight
+ * (weight = bodies + edges, the reference's island statistics, islands/mod.rs:213-232).  Pure host integer work. */
+typedef struct avn_islands_in {
+    uint32_t n_bodies;
+    const uint8_t* rb_type;     /* [n] AVN_RB_*; static bodies get island -1 / rank -1 (replicated where needed) */
+    const double* center_x;     /* [n] x of the body position (slab ordering) */
+    uint32_t n_edges;
+    const int32_t* edge_body1;  /* [E] */
+    const int32_t* edge_body2;  /* [E] */
+    uint32_t n_ranks;
+} avn_islands_in;
+/* island_of_body[n]: island id (islands numbered by their smallest body index, ascending) or -1;
+ * rank_of_body[n]: owning rank or -1; *n_islands: number of islands */
+AVN_API avn_status AVN_FN(islands_partition)(const avn_islands_in* in, int32_t* island_of_body, int32_t* rank_of_body,
+                                              uint32_t* n_islands);
+
+/* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as
+ * doubles: the per-rank bound exchanged between ranks to detect islands of different ranks coming into AABB contact.
+ * Empty worlds return min = +inf, max = -inf. */
+AVN_API avn_status AVN_FN(dynamic_bounds)(avn_world* w, double aabb_min[3], double aabb_max[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -265,6 +265,7 @@ struct WorldBase {
     virtual avn_status step() = 0;
     virtual avn_status timers(avn_timers*) = 0;
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
+    virtual avn_status dynamic_bounds(double*, double*) = 0;
 };
 
 template <class S> struct World : WorldBase {
@@ -978,6 +979,19 @@ template <class S> struct World : WorldBase {
     avn_status pairs_get(const avn_pair** out, size_t* n) override {
         if (!out || !n) return AVN_ERR_BAD_ARG;
         *out = pairs.data(); *n = pairs.size();
+        return AVN_OK;
+    }
+    // header avn_dynamic_bounds: union of the ColliderAabbs of colliders on non-static bodies
+    avn_status dynamic_bounds(double* mn, double* mx) override {
+        if (!mn || !mx) return AVN_ERR_BAD_ARG;
+        const double inf = std::numeric_limits<double>::infinity();
+        for (int k = 0; k < 3; ++k) { mn[k] = inf; mx[k] = -inf; }
+        for (const Collider<S>& c : colliders) {
+            if (bodies[c.body].rb_type == AVN_RB_STATIC) continue;
+            const double lo[3] = {(double)c.aabb.min.x, (double)c.aabb.min.y, (double)c.aabb.min.z};
+            const double hi[3] = {(double)c.aabb.max.x, (double)c.aabb.max.y, (double)c.aabb.max.z};
+            for (int k = 0; k < 3; ++k) { if (lo[k] < mn[k]) mn[k] = lo[k]; if (hi[k] > mx[k]) mx[k] = hi[k]; }
+        }
         return AVN_OK;
     }
     avn_status aabbs_download(void* mn, void* mx, uint32_t* ents, size_t* n_iv) override {

@@ -45,6 +45,61 @@ avn_status avo_step(avn_world* w) { FWD(step()); }
 avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
 avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
+avn_status avo_dynamic_bounds(avn_world* w, double* mn, double* mx) { FWD(dynamic_bounds(mn, mx)); }
+// Checker for avn_islands_partition (header).  Deliberately a DIFFERENT algorithm from the product's union-find:
+// breadth-first flood fill over an adjacency list, islands discovered in ascending body index (= numbered by their
+// smallest member), then the same slab rule (reference island statistics: islands/mod.rs:213-232).
+avn_status avo_islands_partition(const avn_islands_in* in, int32_t* island_of_body, int32_t* rank_of_body, uint32_t* n_islands) {
+    if (!in || !island_of_body || !rank_of_body || !n_islands || in->n_ranks == 0) return AVN_ERR_BAD_ARG;
+    const uint32_t n = in->n_bodies;
+    std::vector<std::vector<int32_t>> adj(n);
+    std::vector<uint64_t> carried(n, 0);
+    for (uint32_t e = 0; e < in->n_edges; ++e) {
+        int32_t a = in->edge_body1[e], b = in->edge_body2[e];
+        if (a < 0 || b < 0 || (uint32_t)a >= n || (uint32_t)b >= n) return AVN_ERR_BAD_ARG;
+        bool sa = in->rb_type[a] == AVN_RB_STATIC, sb = in->rb_type[b] == AVN_RB_STATIC;
+        if (sa && sb) continue;
+        if (!sa && !sb) { adj[a].push_back(b); adj[b].push_back(a); }
+        carried[sa ? b : a] += 1;
+    }
+    for (uint32_t b = 0; b < n; ++b) island_of_body[b] = -1;
+    std::vector<double> sum_x; std::vector<uint64_t> weight, members;
+    uint32_t k = 0;
+    std::vector<int32_t> queue;
+    for (uint32_t s = 0; s < n; ++s) {
+        if (in->rb_type[s] == AVN_RB_STATIC || island_of_body[s] >= 0) continue;
+        sum_x.push_back(0); weight.push_back(0); members.push_back(0);
+        queue.assign(1, (int32_t)s); island_of_body[s] = (int32_t)k;
+        for (size_t q = 0; q < queue.size(); ++q) {
+            int32_t b = queue[q];
+            sum_x[k] += in->center_x[b]; members[k] += 1; weight[k] += 1 + carried[b];
+            for (int32_t o : adj[b]) if (island_of_body[o] < 0) { island_of_body[o] = (int32_t)k; queue.push_back(o); }
+        }
+        ++k;
+    }
+    // NOTE: sum_x accumulates in BFS order here and in index order in the product; the slab ORDER only needs the means to
+    // compare the same way, which tests guarantee by using scenes whose island means are well separated or equal by construction
+    // (ties are broken by island id in both).
+    *n_islands = k;
+    std::vector<uint32_t> order(k);
+    for (uint32_t i = 0; i < k; ++i) order[i] = i;
+    std::vector<double> mean(k);
+    for (uint32_t i = 0; i < k; ++i) mean[i] = sum_x[i] / (double)members[i];
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return mean[a] < mean[b]; });
+    unsigned __int128 total = 0;
+    for (uint32_t i = 0; i < k; ++i) total += weight[i];
+    std::vector<int32_t> rank_of_island(k, 0);
+    unsigned __int128 cum = 0;
+    for (uint32_t o = 0; o < k; ++o) {
+        uint32_t i = order[o];
+        unsigned __int128 r = total ? ((2 * cum + weight[i]) * in->n_ranks) / (2 * total) : 0;
+        if (r > in->n_ranks - 1) r = in->n_ranks - 1;
+        rank_of_island[i] = (int32_t)r;
+        cum += weight[i];
+    }
+    for (uint32_t b = 0; b < n; ++b) rank_of_body[b] = island_of_body[b] < 0 ? -1 : rank_of_island[island_of_body[b]];
+    return AVN_OK;
+}
 uint64_t avo_pair_key(uint32_t a, uint32_t b) { return avo::pair_key(a, b); }
 
 avn_status avo_constraint_graph_create(uint32_t, avn_constraint_graph** out) {

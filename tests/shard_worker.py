@@ -1,0 +1,115 @@
+"""Worker of tests/test_shard_gloo.py, launched by `python -m torch.distributed.run --nproc-per-node 2 …`:
+every rank builds the same global scene, plans the island partition, runs ONLY its own sub-world through the C ABI,
+exchanges per-step bounds, and rank 0 merges the bodies into <out>.npz.  backend lib = the CPU oracle (this is a CPU
+test of the N > 1 host path; on a GPU box the same worker runs the HIP product when AVN_SHARD_BACKEND=hip)."""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from avian_amd import _ffi as F, scenes, shard  # noqa: E402
+from helpers import hip_lib, oracle_lib  # noqa: E402
+
+
+def build_case(name):
+    """Global scene + joints (deterministic).  Returns (scene, joints or None, velocity tweak)."""
+    if name == "stacks":
+        sc = scenes.box_stacks(3, 3, 3, 3, gap=5.0)
+        rng = np.random.default_rng(5)
+        sc.linear_velocity[1:] = rng.normal(scale=0.3, size=(sc.n - 1, 3))   # make the solve non-trivial
+        # a few distance joints inside each stack (27 bodies per stack, bodies 1..81)
+        jb1, jb2 = [], []
+        for s in range(3):
+            base = 1 + 27 * s
+            for k in range(6):
+                jb1.append(base + k); jb2.append(base + 26 - k)
+        J = len(jb1)
+        joints = dict(body1=np.array(jb1, np.int32), body2=np.array(jb2, np.int32), local_anchor1=np.zeros((J, 3)),
+                      local_anchor2=np.zeros((J, 3)), limit_min=np.full(J, 0.5), limit_max=np.full(J, 2.5),
+                      compliance=np.full(J, 1e-5))
+        return sc, joints
+    if name == "approach":   # two stacks, one body of the left stack is thrown at the right stack
+        sc = scenes.box_stacks(2, 2, 2, 2, gap=3.0)
+        sc.linear_velocity[8] = [40.0, 2.0, 0.0]
+        return sc, None
+    raise KeyError(name)
+
+
+def run_world(lib, sc_bodies, sc_colliders, joints, friction, restitution, steps, substeps, dist_mod=None, rb_type=None):
+    """The per-rank flow (also used by the single-world reference run): broad phase -> synthetic manifolds for the new
+    pairs -> colour -> upload -> step, `steps` times; returns (bodies_download, list of per-step pair arrays, overlaps)."""
+    w = F.World(lib, F.default_config(32, substeps=substeps))
+    w.bodies_upload(**sc_bodies)
+    w.colliders_upload(**sc_colliders)
+    w.existing_pairs_upload(np.zeros(0, np.uint64))
+    if joints is not None and len(joints["body1"]):
+        w.distance_joints_upload(**joints)
+    sub = scenes.Scene(position=np.asarray(sc_bodies["position"]), rotation=np.asarray(sc_bodies["rotation"]),
+                       linear_velocity=np.asarray(sc_bodies["linear_velocity"]), angular_velocity=np.asarray(sc_bodies["angular_velocity"]),
+                       inv_mass=np.asarray(sc_bodies["inv_mass"]), inv_inertia_local=np.asarray(sc_bodies["inv_inertia_local"]),
+                       rb_type=np.asarray(sc_bodies["rb_type"]), half_extents=np.asarray(sc_colliders["half_extents"]),
+                       shape=np.asarray(sc_colliders["shape"]))
+    all_pairs, overlaps = [], []
+    known = np.zeros((0, 2), np.int64)
+    for s in range(steps):
+        w.run_system("UPDATE_AABB")
+        _, _, ov = shard.exchange_bounds(w, dist_mod)
+        overlaps.append(ov)
+        w.run_system("COLLECT_COLLISION_PAIRS")
+        p = w.pairs_get()
+        all_pairs.append(np.stack([p["collider1"], p["collider2"]], axis=1).astype(np.int64))
+        known = np.concatenate([known, np.stack([p["body1"], p["body2"]], axis=1).astype(np.int64)])
+        # the (out of path) narrow phase: face manifolds of the CURRENT positions for every known pair, in pair order
+        cur = w.bodies_download()
+        sub.position = cur["position"].astype(np.float64); sub.linear_velocity = cur["linear_velocity"].astype(np.float64)
+        sub.angular_velocity = cur["angular_velocity"].astype(np.float64)
+        mf = scenes.axis_aligned_manifolds(sub, known)
+        offs, perm = scenes.color_manifolds(lib, mf, sub.rb_type)
+        scenes.upload_manifolds(w, scenes.permute_manifolds(mf, perm), offs, friction, restitution)
+        w.run_system("SOLVER")
+    out = w.bodies_download()
+    w.close()
+    return out, all_pairs, overlaps
+
+
+def main():
+    case, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    backend = os.environ.get("AVN_SHARD_BACKEND", "oracle")
+    dist.init_process_group(backend="gloo" if backend == "oracle" else "nccl")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    lib = oracle_lib() if backend == "oracle" else hip_lib()
+    sc, joints = build_case(case)
+    edges = [scenes.brute_force_pairs(sc)]
+    if joints is not None:
+        edges.append(np.stack([joints["body1"], joints["body2"]], axis=1))
+    pl = shard.plan(lib, sc.rb_type, sc.position, np.concatenate(edges), world)
+    bodies, loc, g2l = shard.split_bodies(pl, rank, sc.body_kwargs())
+    cols = shard.split_colliders(g2l, sc.collider_kwargs())
+    jl = None
+    if joints is not None:
+        jl, _, _ = shard.split_pairwise(g2l, pl, rank, joints)
+    got, pairs, overlaps = run_world(lib, bodies, cols, jl, sc.friction, sc.restitution, steps, 2, dist)
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (loc, got, pairs, overlaps, int((pl.rank_of_body == rank).sum())))
+    if rank == 0:
+        template = {"position": sc.position.astype(np.float32), "rotation": sc.rotation.astype(np.float32),
+                    "linear_velocity": sc.linear_velocity.astype(np.float32), "angular_velocity": sc.angular_velocity.astype(np.float32)}
+        merged = shard.merge_bodies(pl, sc.n, [(g[0], g[1]) for g in gathered], template)
+        npairs = np.array([[len(ps) for ps in g[2]] for g in gathered])
+        pair_sets = {f"pairs_r{r}_s{s}": ps for r, g in enumerate(gathered) for s, ps in enumerate(g[2])}
+        first_overlap = next((s for s in range(steps) if any(len(g[3][s]) for g in gathered)), -1)
+        np.savez(out_path, rank_of_body=pl.rank_of_body, island_of_body=pl.island_of_body, n_islands=pl.n_islands,
+                 owned=np.array([g[4] for g in gathered]), npairs=npairs, first_overlap=first_overlap, **merged, **pair_sets)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
