@@ -31,6 +31,7 @@ class Scene:
     friction: float = 0.5               # Friction::default, combined with CoefficientCombine::Average
     restitution: float = 0.0
     extra: Dict[str, np.ndarray] = field(default_factory=dict)
+    entity_index: Optional[np.ndarray] = None   # Entity::index() per collider (default: the body index)
 
     @property
     def n(self) -> int:
@@ -45,8 +46,16 @@ class Scene:
 
     def collider_kwargs(self):
         n = self.n
-        return dict(entity_index=np.arange(n, dtype=np.uint32), body=np.arange(n, dtype=np.int32), shape=self.shape,
-                    half_extents=self.half_extents)
+        ent = self.entity_index if self.entity_index is not None else np.arange(n, dtype=np.uint32)
+        return dict(entity_index=ent, body=np.arange(n, dtype=np.int32), shape=self.shape, half_extents=self.half_extents)
+
+    def subset(self, idx: np.ndarray) -> "Scene":
+        """The sub-world of the bodies `idx` (ascending global indices): same relative order, GLOBAL entity indices
+        (PairKeys stay comparable across ranks) — what one rank of a sharded run uploads (avian_amd/shard.py)."""
+        ent = (self.entity_index if self.entity_index is not None else np.arange(self.n, dtype=np.uint32))[idx]
+        return Scene(self.position[idx], self.rotation[idx], self.linear_velocity[idx], self.angular_velocity[idx],
+                     self.inv_mass[idx], self.inv_inertia_local[idx], self.rb_type[idx], self.half_extents[idx], self.shape[idx],
+                     self.friction, self.restitution, {k: v[idx] for k, v in self.extra.items()}, ent)
 
 
 def cuboid_mass_properties(hx, hy, hz, density=1.0):
@@ -221,6 +230,15 @@ def brute_force_pairs(scene: Scene, margin: float = 0.005) -> np.ndarray:
     p = np.concatenate(out)
     both_static = (scene.rb_type[p[:, 0]] == F.RB_STATIC) & (scene.rb_type[p[:, 1]] == F.RB_STATIC)
     return p[~both_static]
+
+
+def lattice_edges(first_body: int, nx: int, ny: int, nz: int) -> np.ndarray:
+    """Face-neighbour body pairs of an nx*ny*nz lattice whose bodies are numbered (ix, iy, iz) row-major from
+    `first_body` — a cheap structural stand-in for the broad-phase pair list when planning a partition."""
+    idx = first_body + np.arange(nx * ny * nz).reshape(nx, ny, nz)
+    e = [np.stack([idx[:-1].ravel(), idx[1:].ravel()], 1), np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()], 1),
+         np.stack([idx[:, :, :-1].ravel(), idx[:, :, 1:].ravel()], 1)]
+    return np.concatenate(e)
 
 
 def box_stacks(n_stacks: int, nx: int, ny: int, nz: int, gap: float = 6.0) -> Scene:

@@ -16,8 +16,10 @@ part of the path, so the manifold set is fixed during the timed steps while body
                events on the library's own stream (avn_profile_system), against the 8 TB/s HBM3E peak.
   cpu_baseline = the CPU oracle (C++ restatement of the reference, 1 thread) on the same inputs, bounded sample.
 
-Multi-GPU (weak scaling): the path shards by independent contact islands — every rank owns a whole island
-(one 100k stack) with no data-path collective; torch.distributed (RCCL) is used only for the barrier / MAX.
+Multi-GPU (weak scaling): the path shards by interaction islands (avian_amd/shard.py).  With N ranks the global
+scene is N 100k-stacks side by side on one static slab; `avn_islands_partition` assigns one island (stack) to each
+rank, every rank uploads and steps ONLY its sub-world, and the only collective in the timed loop is the per-step
+all-gather of one AABB per rank (RCCL, 48 bytes) that detects islands of different ranks coming into AABB contact.
 """
 from __future__ import annotations
 
@@ -42,12 +44,19 @@ SCENES = {
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md)
 
 
-def build_inputs(lib, scene_name):
-    """Scene + the solver inputs that the (out-of-scope) narrow phase would have produced."""
-    from avian_amd import _ffi as F, scenes
+def build_inputs(lib, scene_name, rank=0, world_size=1):
+    """This rank's (sub-)scene.  N = 1: the whole cfg2 stack.  N > 1: the global N-stack scene is planned with
+    avn_islands_partition and only the rank's own islands (+ the static slab) are kept."""
+    from avian_amd import _ffi as F, scenes, shard
     nx, ny, nz, substeps = SCENES[scene_name]
-    sc = scenes.box_stack(nx, ny, nz)
-    return sc, substeps
+    if world_size == 1:
+        return scenes.box_stack(nx, ny, nz), substeps, None
+    glob = scenes.box_stacks(world_size, nx, ny, nz)
+    per = nx * ny * nz
+    edges = np.concatenate([scenes.lattice_edges(1 + s * per, nx, ny, nz) for s in range(world_size)])
+    pl = shard.plan(lib, glob.rb_type, glob.position, edges, world_size)
+    assert pl.n_islands == world_size and np.bincount(pl.rank_of_body[1:], minlength=world_size).tolist() == [per] * world_size
+    return glob.subset(pl.local_bodies(rank)), substeps, pl
 
 
 def setup_world(world, lib, sc, pairs_from=None):
@@ -88,15 +97,24 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the MI355X path has no CPU fallback")
+    # validation-only overrides (NOT used by the driver): run the N > 1 code path on a 1-GPU box with gloo
+    backend = os.environ.get("AVN_BENCH_DIST_BACKEND", "nccl")
+    if os.environ.get("AVN_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+    coll_device = "cuda" if backend == "nccl" else "cpu"
 
     import avian_amd
     from avian_amd import _ffi as F
     lib = avian_amd.load_library()
-    sc, substeps = build_inputs(lib, args.scene)
+    from avian_amd import shard
+    sc, substeps, plan = build_inputs(lib, args.scene, rank, world_size)
     cfg = F.default_config(32, substeps=substeps, device=local_rank, use_graph=0 if args.no_graph else 1)
     w = F.World(lib, cfg)
     meta = setup_world(w, lib, sc)
@@ -106,18 +124,41 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # N > 1: the per-step exchange of the sharded path — all-gather of each rank's dynamic-body bounds over RCCL.
+    # The gather of step s is checked at step s + 1 (bounds are swept AABBs, i.e. already one step conservative),
+    # so the collective overlaps the next step instead of stalling it.
+    pending = [None]
+    overlaps_seen = [0]
+
+    def exchange():
+        if world_size == 1:
+            return
+        if pending[0] is not None:
+            work, outs = pending[0]
+            work.wait()
+            a = torch.stack(outs).cpu().numpy()
+            overlaps_seen[0] += len(shard.bounds_overlap(a[:, :3], a[:, 3:]))
+        mn, mx = w.dynamic_bounds()
+        t = torch.tensor(np.concatenate([mn, mx]), dtype=torch.float64, device=coll_device)
+        outs = [torch.empty_like(t) for _ in range(world_size)]
+        pending[0] = (dist.all_gather(outs, t, async_op=True), outs)
+
     for _ in range(args.warmup):
         w.step()
+        exchange()
     w.synchronize()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         w.step()
+        exchange()
     w.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     if world_size > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        assert overlaps_seen[0] == 0, "independent stacks must not trigger a re-partition"
+    if world_size > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = w.timers()
@@ -186,7 +227,8 @@ def main():
             "config": {"workload": args.scene, "dynamic_bodies_per_gpu": sc.n - 1, "manifolds_per_gpu": meta["n_manifolds"],
                        "contact_points_per_gpu": pts, "broadphase_pairs": meta["n_pairs"], "substeps": substeps,
                        "solver_iterations": 1, "dt": 1.0 / 60.0, "colors_used": meta["colors_used"],
-                       "hip_graph": not args.no_graph, "sharding": "one independent island (stack) per GPU, no data-path collective",
+                       "hip_graph": not args.no_graph, "sharding": ("single world" if world_size == 1 else
+                                    "avn_islands_partition: one interaction island (100k stack) per rank; per-step RCCL all-gather of rank bounds only"),
                        "narrow_phase": "out of path: fixed synthetic face manifolds"},
             "device_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4),
                           "substeps": round(tm.substeps_ms, 4), "finalize": round(tm.finalize_ms, 4),
