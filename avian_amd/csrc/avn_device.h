@@ -52,6 +52,15 @@ template <class T> struct StepParams {
     uint32_t match_contacts;
 };
 
+// Two Vec4 records of a body that are always touched together (linear|angular velocity, delta position|rotation, the
+// two halves of SolverBodyInertia) share one 32-byte (f32) / 64-byte (f64) slot: a scatter of the pair dirties one
+// sector instead of two partial ones, and a gather of a body touches 3 cache lines instead of 6.  Indexing stays
+// `field[body]`.
+template <class V> struct Pair2 {
+    V* p;
+    __host__ __device__ __forceinline__ V& operator[](size_t i) const { return p[2 * i]; }
+};
+
 template <class T> struct DW {
     using V = Vec4<T>;
     // ---- rigid-body components (persist across steps) ----
@@ -67,12 +76,12 @@ template <class T> struct DW {
     V* acc_a;      // (accumulated angular acceleration.xyz, 0)
     uint32_t* bmeta;
     // ---- solver bodies (SolverBody / SolverBodyInertia / VelocityIntegrationData) ----
-    V* sb_lin;     // (linear_velocity.xyz, 0)
-    V* sb_ang;     // (angular_velocity.xyz, 0)
-    V* sb_dp;      // (delta_position.xyz, 0)
-    V* sb_dq;      // delta_rotation xyzw
-    V* si_a;       // (inv_mass, m00, m01, m02)   world-space effective inverse inertia
-    V* si_b;       // (m11, m12, m22, bits(InertiaFlags | dominance << 16))
+    Pair2<V> sb_lin;   // (linear_velocity.xyz, 0)      \ one 2-record slot per body
+    Pair2<V> sb_ang;   // (angular_velocity.xyz, 0)     /
+    Pair2<V> sb_dp;    // (delta_position.xyz, 0)       \ one slot
+    Pair2<V> sb_dq;    // delta_rotation xyzw           /
+    Pair2<V> si_a;     // (inv_mass, m00, m01, m02)   world-space effective inverse inertia   \ one slot
+    Pair2<V> si_b;     // (m11, m12, m22, bits(InertiaFlags | dominance << 16))               /
     V* vid_l;      // (linear_increment.xyz, linear_damping_rhs)
     V* vid_a;      // (angular_increment.xyz, angular_damping_rhs)
     V* pre_dp;     // PreSolveDeltaPosition

@@ -102,7 +102,7 @@ template <class T> struct World : WorldBase {
     uint32_t cap_bodies = 0, cap_manifolds = 0, cap_joints = 0, cap_colliders = 0;
     // body buffers (Vec4 each)
     DevBuf b_pos, b_rot, b_lvel, b_avel, b_com, b_iloc_a, b_iloc_b, b_acc_l, b_acc_a, b_bmeta;
-    DevBuf b_sb_lin, b_sb_ang, b_sb_dp, b_sb_dq, b_si_a, b_si_b, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
+    DevBuf b_sb_vel, b_sb_delta, b_si, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_force;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
@@ -269,8 +269,10 @@ template <class T> struct World : WorldBase {
             size_t c = (size_t)std::max<uint32_t>(n + 2, cap_bodies + cap_bodies / 2);  // +2: virtual DUMMY bodies of joint_damping
             GROW(b_pos, c, dw.pos); GROW(b_rot, c, dw.rot); GROW(b_lvel, c, dw.lvel); GROW(b_avel, c, dw.avel); GROW(b_com, c, dw.com);
             GROW(b_iloc_a, c, dw.iloc_a); GROW(b_iloc_b, c, dw.iloc_b); GROW(b_acc_l, c, dw.acc_l); GROW(b_acc_a, c, dw.acc_a); GROW(b_bmeta, c, dw.bmeta);
-            GROW(b_sb_lin, c, dw.sb_lin); GROW(b_sb_ang, c, dw.sb_ang); GROW(b_sb_dp, c, dw.sb_dp); GROW(b_sb_dq, c, dw.sb_dq);
-            GROW(b_si_a, c, dw.si_a); GROW(b_si_b, c, dw.si_b); GROW(b_vid_l, c, dw.vid_l); GROW(b_vid_a, c, dw.vid_a);
+            GROW(b_sb_vel, 2 * c, dw.sb_lin.p); dw.sb_ang.p = dw.sb_lin.p + 1;   // Pair2 slots (avn_device.h)
+            GROW(b_sb_delta, 2 * c, dw.sb_dp.p); dw.sb_dq.p = dw.sb_dp.p + 1;
+            GROW(b_si, 2 * c, dw.si_a.p); dw.si_b.p = dw.si_a.p + 1;
+            GROW(b_vid_l, c, dw.vid_l); GROW(b_vid_a, c, dw.vid_a);
             GROW(b_pre_dp, c, dw.pre_dp); GROW(b_pre_dq, c, dw.pre_dq); GROW(b_sb_flags, c, dw.sb_flags);
             cap_bodies = (uint32_t)c;
         }
@@ -816,8 +818,7 @@ template <class T> struct World : WorldBase {
         if (!any_damped || !sched_damp.n_components) return;
         if (sched_damp.touches_dummy) {
             // reset the two virtual SolverBody::DUMMY slots (all-zero bit pattern = zero velocities)
-            (void)hipMemsetAsync(dw.sb_lin + dw.n_bodies, 0, 2 * sizeof(V), stream);
-            (void)hipMemsetAsync(dw.sb_ang + dw.n_bodies, 0, 2 * sizeof(V), stream);
+            (void)hipMemsetAsync(&dw.sb_lin[dw.n_bodies], 0, 4 * sizeof(V), stream);  // 2 bodies x (lin | ang) slot
         }
         launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp.n_components, sched_damp.d_comp_level_begin.as<uint32_t>(),
                                  sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_order.as<uint32_t>(), stream);

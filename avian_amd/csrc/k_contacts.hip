@@ -37,21 +37,25 @@ template <class T> struct BodyRef {
 // dominant one (solver/plugin.rs:491-512).
 template <class T, bool WITH_DELTA>
 __device__ __forceinline__ void load_body(const DW<T>& w, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
-    if (no_body) {
-        b.v = vzero<T>(); b.om = vzero<T>(); b.dp = vzero<T>(); b.dq = qidentity<T>();
-        b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); b.lin_w = 0; b.ang_w = 0;
-        return;
-    }
+    // The six records are fetched UNCONDITIONALLY (every body index is a valid row; rows of bodies without a SolverBody
+    // hold DUMMY values) and the DUMMY substitution is a select afterwards: no load waits on the constraint's flag word,
+    // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
     Vec4<T> l = w.sb_lin[idx], a = w.sb_ang[idx];
-    b.v = xyz<T>(l); b.om = xyz<T>(a); b.lin_w = l.w; b.ang_w = a.w;
-    if (WITH_DELTA) { b.dp = xyz<T>(w.sb_dp[idx]); b.dq = quat<T>(w.sb_dq[idx]); }
-    else { b.dp = vzero<T>(); b.dq = qidentity<T>(); }
-    if (dummy_inertia) { b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); }
-    else {
-        Vec4<T> sa = w.si_a[idx], sb = w.si_b[idx];
-        b.inv_mass = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
-        b.I = Sym3<T>{sa.y, sa.z, sa.w, sb.x, sb.y, sb.z};
-    }
+    Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
+    if (WITH_DELTA) { dp = w.sb_dp[idx]; dq = w.sb_dq[idx]; }
+    Vec4<T> sa = w.si_a[idx], sb = w.si_b[idx];
+    // branch-free selects (v_cndmask): nothing for the compiler to sink the loads into
+    const T z = T(0);
+    b.v = V3<T>{no_body ? z : l.x, no_body ? z : l.y, no_body ? z : l.z};
+    b.om = V3<T>{no_body ? z : a.x, no_body ? z : a.y, no_body ? z : a.z};
+    b.lin_w = no_body ? z : l.w; b.ang_w = no_body ? z : a.w;
+    const bool nd = no_body || !WITH_DELTA;
+    b.dp = V3<T>{nd ? z : dp.x, nd ? z : dp.y, nd ? z : dp.z};
+    b.dq = Q4<T>{nd ? z : dq.x, nd ? z : dq.y, nd ? z : dq.z, nd ? T(1) : dq.w};
+    const bool ni = no_body || dummy_inertia;
+    V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
+    b.inv_mass = V3<T>{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
+    b.I = Sym3<T>{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
 }
 template <class T> __device__ __forceinline__ void store_body(const DW<T>& w, int idx, bool no_body, const BodyRef<T>& b) {
     if (no_body) return;  // writes to a DUMMY body are discarded
@@ -154,22 +158,30 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
 
 // ------------------------------------------------------------------------------------------------------
 template <class T> __device__ __forceinline__ void warm_start_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    // level 1: every load that only depends on m (the point planes are allocated for 4 points per manifold, so the
+    // fetch of unused points is in bounds and merely ignored)
     Vec4<T> h1 = w.c_h1[m];
+    int2 b = w.m_bodies[m];
+    Vec4<T> h0 = w.m_n[m];
+    uint32_t S = w.m_stride;
+    Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * S + m; pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pd[k] = w.c_pd[s]; }
+    // level 2: the body gathers
+    BodyRef<T> b1, b2;
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
-    if (np == 0) return;
-    int2 b = w.m_bodies[m];
-    V3<T> normal = xyz<T>(w.m_n[m]);
-    V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
-    BodyRef<T> b1, b2;
     load_body<T, false>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
     load_body<T, false>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
-    uint32_t S = w.m_stride;
+    if (np == 0) return;
+    V3<T> normal = xyz<T>(h0);
+    V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
     T coeff = p.warm_start_coefficient;
-    for (uint32_t k = 0; k < np; ++k) {
-        uint32_t s = k * S + m;
-        V3<T> r1 = xyz<T>(w.c_pa[s]), r2 = xyz<T>(w.c_pb[s]);
-        Vec4<T> d = w.c_pd[s];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k >= np) break;
+        V3<T> r1 = xyz<T>(pa[k]), r2 = xyz<T>(pb[k]);
+        Vec4<T> d = pd[k];
         T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
         V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
         apply_impulse(b1, b2, imp, r1, r2);
@@ -179,29 +191,28 @@ template <class T> __device__ __forceinline__ void warm_start_one(const DW<T>& w
 }
 
 template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+    // level 1: every load that only depends on m, issued up front and unconditionally (memory-level parallelism: the
+    // kernel is latency-bound at one manifold per lane; the point planes hold 4 slots per manifold, so unused points
+    // are in bounds and ignored); level 2: the body gathers; then the sequential impulse iteration out of registers
     Vec4<T> h1 = w.c_h1[m];
-    uint32_t cm = scalar_to_bits(h1.w);
-    uint32_t np = cm & 7u;
-    if (np == 0) return;
     int2 b = w.m_bodies[m];
     Vec4<T> h0 = w.m_n[m];
-    V3<T> normal = xyz<T>(h0);
-    T friction = h0.w;
-    BodyRef<T> b1, b2;
-    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    Vec4<T> h2 = w.m_tv[m];
     uint32_t S = w.m_stride;
-    // issue every record load of the manifold up front (memory-level parallelism: the kernel is latency-bound
-    // at one manifold per lane), then run the sequential impulse iteration out of registers
     Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
 #pragma unroll
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        if (k < np) {
-            uint32_t s = k * S + m;
-            pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pd[k] = w.c_pd[s];
-            if (cm & AVN_CM_TANGENT) pc[k] = w.c_pc[s];
-        }
+        uint32_t s = k * S + m;
+        pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
     }
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    BodyRef<T> b1, b2;
+    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    if (np == 0) return;
+    V3<T> normal = xyz<T>(h0);
+    T friction = h0.w;
     SoftCoef<T> soft = (cm & AVN_CM_SOFT_ND) ? p.soft_non_dynamic : p.soft_dynamic;
     T delta_secs = p.h_adj;
     V3<T> delta_translation = b2.dp - b1.dp;
@@ -238,7 +249,7 @@ template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(cons
     // friction
     if (cm & AVN_CM_TANGENT) {
         V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);
-        V3<T> surface_velocity = xyz<T>(w.m_tv[m]);
+        V3<T> surface_velocity = xyz<T>(h2);
 #pragma unroll
         for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
             if (k < np) {
