@@ -137,7 +137,7 @@ ABI_SYMBOLS = [
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
     "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
-    "islands_partition", "dynamic_bounds",
+    "islands_partition", "dynamic_bounds", "constraint_graph_push_batch",
 ]
 
 
@@ -175,6 +175,7 @@ class Library:
         f("constraint_graph_destroy").restype = None
         f("constraint_graph_push").argtypes = [vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_int]
         f("constraint_graph_push").restype = C.c_int32
+        f("constraint_graph_push_batch").argtypes = [vp, C.c_size_t, vp, vp, vp, vp, vp, vp]
         f("constraint_graph_pop").argtypes = [vp, C.c_uint64]
         f("constraint_graph_lists").argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         f("islands_partition").argtypes = [C.POINTER(avn_islands_in), vp, vp, C.POINTER(C.c_uint32)]

@@ -133,6 +133,18 @@ AVN_API int32_t avn_constraint_graph_push(avn_constraint_graph* g, uint64_t h, u
     if (!g) return -1;
     try { return g->g.push_manifold(h, b1, b2, s1 != 0, s2 != 0); } catch (...) { return -1; }
 }
+AVN_API avn_status avn_constraint_graph_push_batch(avn_constraint_graph* g, size_t n, const uint64_t* h, const uint32_t* b1, const uint32_t* b2,
+                                                 const uint8_t* s1, const uint8_t* s2, int8_t* colors) {
+    if (!g || (n && (!h || !b1 || !b2 || !s1 || !s2))) return AVN_ERR_BAD_ARG;
+    try {
+        for (size_t i = 0; i < n; ++i) {
+            int c = g->g.push_manifold(h[i], b1[i], b2[i], s1[i] != 0, s2[i] != 0);
+            if (colors) colors[i] = (int8_t)c;
+            if (c < 0) return AVN_ERR_STATE;  // duplicate handle
+        }
+    } catch (...) { return AVN_ERR_OOM; }
+    return AVN_OK;
+}
 AVN_API avn_status avn_constraint_graph_pop(avn_constraint_graph* g, uint64_t h) {
     if (!g) return AVN_ERR_BAD_ARG;
     try { return g->g.pop_manifold(h) ? AVN_OK : AVN_ERR_STATE; } catch (...) { return AVN_ERR_STATE; }

@@ -804,16 +804,21 @@ template <class T> struct World : WorldBase {
     void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
     void contact_pass(int pass) { if (dw.n_manifolds) launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, stream); }
+    // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
+    // installed (xpbd/plugin.rs:61-76,192-240).  With no joints the projection adds 2 * (dq * conj(dq)).xyz / h:
+    //  - f32 (glam's SIMD `Quat`, pairwise sums): every xyz component cancels exactly, e.g. y = (-wy + xz) + (yw - zx) is
+    //    a + (-a) = 0, so the two systems are exact no-ops (up to the sign of a zero) and are skipped;
+    //  - f64 (scalar `DQuat`, left-to-right sums): y = ((-wy + xz) + yw) - zx leaves a rounding residual of order
+    //    ulp(wy), so the reference really perturbs omega every substep — replicate, don't "fix" (found by the cfg5 test).
+    bool xpbd_body_passes_needed() const { return dw.n_joints != 0 || sizeof(T) == 8; }
     void xpbd_solve(bool snapshot) {
-        // the reference runs the snapshot and the velocity projection whenever XpbdSolverPlugin is installed; without
-        // joints both are arithmetic no-ops on v/omega only up to "+ 0": they are skipped only when there are no joints
+        if (snapshot && xpbd_body_passes_needed()) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
         if (!dw.n_joints) return;
-        if (snapshot) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
         launch_joint_schedule<T>(dw, params, 0, (uint32_t)sched_solve.n_components, sched_solve.d_comp_level_begin.as<uint32_t>(),
                                  sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_order.as<uint32_t>(), stream);
         ++launches;
     }
-    void xpbd_velocity_projection() { if (dw.n_joints) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
+    void xpbd_velocity_projection() { if (xpbd_body_passes_needed()) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
     void joint_damping() {
         if (!any_damped || !sched_damp.n_components) return;
         if (sched_damp.touches_dummy) {

@@ -179,10 +179,13 @@ def color_manifolds(lib: F.Library, mf: Dict[str, np.ndarray], rb_type: np.ndarr
     g = F.ConstraintGraph(lib, len(rb_type))
     b1, b2 = mf["body1"], mf["body2"]
     s1 = rb_type[b1] == F.RB_STATIC; s2 = rb_type[b2] == F.RB_STATIC
-    push = lib.fn("constraint_graph_push")
-    h = g.handle
-    for i in range(len(b1)):
-        push(h, i, int(b1[i]), int(b2[i]), int(s1[i]), int(s2[i]))
+    m = len(b1)
+    hs = np.arange(m, dtype=np.uint64)
+    a1 = np.ascontiguousarray(b1, np.uint32); a2 = np.ascontiguousarray(b2, np.uint32)
+    f1 = np.ascontiguousarray(s1, np.uint8); f2 = np.ascontiguousarray(s2, np.uint8)
+    st = lib.fn("constraint_graph_push_batch")(g.handle, m, F._ptr(hs), F._ptr(a1), F._ptr(a2), F._ptr(f1), F._ptr(f2), None)
+    if st != 0:
+        raise F.AvnError(st, "constraint_graph_push_batch")
     offsets, handles = g.lists()
     g.close()
     return offsets, handles.astype(np.int64)
@@ -252,3 +255,77 @@ def box_stacks(n_stacks: int, nx: int, ny: int, nz: int, gap: float = 6.0) -> Sc
         c[:, 0] += (s - (n_stacks - 1) * 0.5) * pitch
         centers.append(c)
     return _assemble(np.concatenate(centers), (0.5, 0.5, 0.5), (0.0, -20.0, 0.0), (400.0 + n_stacks * pitch, 20.0, 400.0))
+
+
+def _xorshift64star(seed: int, count: int) -> np.ndarray:
+    """xorshift64* stream (SURVEY.md §8d cfg4 seed 0x9E3779B97F4A7C15), vectorised per lane: lane k starts from
+    splitmix64(seed + k) so the generator is reproducible and O(count) in numpy."""
+    k = np.arange(count, dtype=np.uint64)
+    z = (np.uint64(seed) + (k + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    x = z ^ (z >> np.uint64(31))
+    x = np.where(x == 0, np.uint64(1), x)
+    x ^= x >> np.uint64(12); x ^= x << np.uint64(25); x ^= x >> np.uint64(27)
+    return x * np.uint64(0x2545F4914F6CDD1D)
+
+
+def _uniform01(bits: np.ndarray) -> np.ndarray:
+    return (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+
+
+def sparse_mixed(n: int = 1_000_000, side: float = 1000.0, seed: int = 0x9E3779B97F4A7C15) -> Scene:
+    """cfg4 of SURVEY.md §8d: `n` colliders alternating ball(r = 0.5) / cuboid(1, 1, 1), centres uniform in a cube of
+    the given side, velocities uniform in [-1, 1]^3, random unit quaternions; no ground.  Broad-phase dominant."""
+    with np.errstate(over="ignore"):
+        r = _uniform01(_xorshift64star(seed, 10 * n)).reshape(n, 10)
+    pos = (r[:, 0:3] - 0.5) * side
+    vel = r[:, 3:6] * 2.0 - 1.0
+    q = r[:, 6:10] * 2.0 - 1.0
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    shape = (np.arange(n) % 2 == 0).astype(np.uint8)      # even = ball, odd = cuboid
+    he = np.full((n, 3), 0.5)
+    m_c, (ixx, _, _) = cuboid_mass_properties(0.5, 0.5, 0.5)
+    m_b = 4.0 / 3.0 * np.pi * 0.5 ** 3
+    i_b = 0.4 * m_b * 0.25
+    inv_mass = np.where(shape == 1, 1.0 / m_b, 1.0 / m_c)
+    inv_i = np.zeros((n, 6))
+    ii = np.where(shape == 1, 1.0 / i_b, 1.0 / ixx)
+    inv_i[:, 0] = ii; inv_i[:, 3] = ii; inv_i[:, 5] = ii
+    return Scene(pos, q, vel, np.zeros((n, 3)), inv_mass, inv_i, np.zeros(n, np.uint8), he, shape)
+
+
+def stack_with_chains(nx: int = 50, ny: int = 20, nz: int = 50, n_chains: int = 100, links: int = 100):
+    """cfg3 of SURVEY.md §8d: an nx*ny*nz box stack (as cfg2) plus `n_chains` chains of `links` unit-density balls
+    (r = 0.06, mass properties as examples/chain_3d.rs:59) hanging beside the stack, spacing 0.132, joined by
+    DistanceJoints with_limits(0.132, 0.132), compliance 1e-5, anchors at the body centres, first link kinematic.
+    Returns (scene, joints dict).  Chain bodies carry no collider interaction with the stack (they hang clear of it)."""
+    base = box_stack(nx, ny, nz)
+    r = 0.06
+    spacing = 0.132
+    m = 4.0 / 3.0 * np.pi * r ** 3
+    inertia = 0.4 * m * r * r
+    n0 = base.n
+    nb = n_chains * links
+    pos = np.zeros((nb, 3))
+    cx = np.arange(n_chains) // 10; cz = np.arange(n_chains) % 10
+    top = 0.99 * ny + 30.0
+    for c in range(n_chains):
+        k = np.arange(links)
+        pos[c * links:(c + 1) * links, 0] = nx * 0.5 + 5.0 + cx[c] * 1.0
+        pos[c * links:(c + 1) * links, 1] = top - k * spacing
+        pos[c * links:(c + 1) * links, 2] = (cz[c] - 4.5) * 1.0
+    n = n0 + nb
+    sc = Scene(np.concatenate([base.position, pos]), np.concatenate([base.rotation, np.tile([0, 0, 0, 1.0], (nb, 1))]),
+               np.zeros((n, 3)), np.zeros((n, 3)), np.concatenate([base.inv_mass, np.full(nb, 1.0 / m)]),
+               np.concatenate([base.inv_inertia_local, np.tile([1.0 / inertia, 0, 0, 1.0 / inertia, 0, 1.0 / inertia], (nb, 1))]),
+               np.concatenate([base.rb_type, np.zeros(nb, np.uint8)]), np.concatenate([base.half_extents, np.full((nb, 3), r)]),
+               np.concatenate([base.shape, np.ones(nb, np.uint8)]))
+    first = n0 + np.arange(n_chains) * links
+    sc.rb_type[first] = F.RB_KINEMATIC
+    b1 = (n0 + np.arange(nb)).reshape(n_chains, links)[:, :-1].ravel()
+    J = len(b1)
+    joints = dict(body1=b1.astype(np.int32), body2=(b1 + 1).astype(np.int32), local_anchor1=np.zeros((J, 3)),
+                  local_anchor2=np.zeros((J, 3)), limit_min=np.full(J, spacing), limit_max=np.full(J, spacing),
+                  compliance=np.full(J, 1e-5))
+    return sc, joints

@@ -353,6 +353,10 @@ AVN_API void AVN_FN(constraint_graph_destroy)(avn_constraint_graph* g);
 /* push_manifold: returns the colour chosen; `handle` is an opaque caller id (e.g. contact_id<<2|manifold_index) */
 AVN_API int32_t AVN_FN(constraint_graph_push)(avn_constraint_graph* g, uint64_t handle, uint32_t body1,
                                               uint32_t body2, int is_static1, int is_static2);
+/* push_manifold for `n` manifolds in array order (identical to n calls of _push); colors_out may be NULL */
+AVN_API avn_status AVN_FN(constraint_graph_push_batch)(avn_constraint_graph* g, size_t n, const uint64_t* handles,
+                                                       const uint32_t* body1, const uint32_t* body2,
+                                                       const uint8_t* is_static1, const uint8_t* is_static2, int8_t* colors_out);
 /* pop_manifold (swap-remove) */
 AVN_API avn_status AVN_FN(constraint_graph_pop)(avn_constraint_graph* g, uint64_t handle);
 /* colour-major handle list: offsets[25], handles[count] in manifold_handles order */

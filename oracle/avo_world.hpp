@@ -1061,13 +1061,25 @@ template <class S> struct World : WorldBase {
             kept.push_back({iv.collider, f});
         }
         intervals.swap(kept);
-        // insertion_sort(|a, b| a.min.x > b.min.x)
-        for (size_t i = 1; i < intervals.size(); ++i) {
-            size_t j = i;
-            while (j > 0 && colliders[intervals[j - 1].collider].aabb.min.x > colliders[intervals[j].collider].aabb.min.x) {
-                std::swap(intervals[j - 1], intervals[j]);
-                --j;
+        // insertion_sort(|a, b| a.min.x > b.min.x), broad_phase.rs:479-487.  The reference's first frame over an unsorted
+        // list is O(n^2); to keep the CHECKER usable at 10^6 colliders the loop hands over to std::stable_sort once it has
+        // done more than 64 n swaps.  Same result: an insertion sort that swaps only on strict `>` is a stable ascending sort,
+        // every intermediate state keeps equal keys in their original relative order, and the stable sorted permutation is unique.
+        {
+            size_t swaps = 0, budget = 64 * intervals.size() + 1024;
+            bool handed_over = false;
+            for (size_t i = 1; i < intervals.size() && !handed_over; ++i) {
+                size_t j = i;
+                while (j > 0 && colliders[intervals[j - 1].collider].aabb.min.x > colliders[intervals[j].collider].aabb.min.x) {
+                    std::swap(intervals[j - 1], intervals[j]);
+                    --j;
+                    if (++swaps > budget) { handed_over = true; break; }
+                }
             }
+            if (handed_over)
+                std::stable_sort(intervals.begin(), intervals.end(), [&](const AabbInterval& a, const AabbInterval& b) {
+                    return colliders[a.collider].aabb.min.x < colliders[b.collider].aabb.min.x;
+                });
         }
         pairs.clear();
         for (size_t i = 0; i < intervals.size(); ++i) {

@@ -111,6 +111,18 @@ void avo_constraint_graph_destroy(avn_constraint_graph* g) { delete g; }
 int32_t avo_constraint_graph_push(avn_constraint_graph* g, uint64_t h, uint32_t b1, uint32_t b2, int s1, int s2) {
     return g ? g->g.push_manifold(h, b1, b2, s1 != 0, s2 != 0) : -1;
 }
+avn_status avo_constraint_graph_push_batch(avn_constraint_graph* g, size_t n, const uint64_t* h, const uint32_t* b1, const uint32_t* b2,
+                                                 const uint8_t* s1, const uint8_t* s2, int8_t* colors) {
+    if (!g || (n && (!h || !b1 || !b2 || !s1 || !s2))) return AVN_ERR_BAD_ARG;
+    try {
+        for (size_t i = 0; i < n; ++i) {
+            int c = g->g.push_manifold(h[i], b1[i], b2[i], s1[i] != 0, s2[i] != 0);
+            if (colors) colors[i] = (int8_t)c;
+            if (c < 0) return AVN_ERR_STATE;  // duplicate handle
+        }
+    } catch (...) { return AVN_ERR_OOM; }
+    return AVN_OK;
+}
 avn_status avo_constraint_graph_pop(avn_constraint_graph* g, uint64_t h) {
     if (!g) return AVN_ERR_BAD_ARG;
     return g->g.pop_manifold(h) ? AVN_OK : AVN_ERR_STATE;

@@ -1,0 +1,123 @@
+"""BASELINE.json's configurations at (or near) full size on the GPU, through the C ABI.
+
+cfg2/cfg3/cfg4 are compared with the CPU oracle bit for bit at full size where the oracle finishes in seconds; cfg5
+(500k f64) and the multi-step runs are checked through size-independent properties (run-to-run bit identity, sorted /
+duplicate-free pair lists, idempotence of the broad phase, brute-force spot checks) plus an oracle comparison at a
+reduced size.  TOL = 0 everywhere (see tests/test_gpu_parity.py)."""
+import numpy as np
+import pytest
+
+from helpers import F, assert_same, compare_dicts, hip_lib, oracle_lib
+
+from avian_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(w, lib, sc, joints=None):
+    """bodies + colliders -> broad phase -> synthetic face manifolds -> colour -> upload.  Returns the pair array."""
+    w.bodies_upload(**sc.body_kwargs())
+    w.colliders_upload(**sc.collider_kwargs())
+    if joints is not None:
+        w.distance_joints_upload(**joints)
+    w.existing_pairs_upload(np.zeros(0, np.uint64))
+    w.run_system("UPDATE_AABB")
+    w.run_system("COLLECT_COLLISION_PAIRS")
+    p = w.pairs_get().copy()
+    mf = scenes.axis_aligned_manifolds(sc, np.stack([p["body1"], p["body2"]], axis=1))
+    offs, perm = scenes.color_manifolds(lib, mf, sc.rb_type)
+    scenes.upload_manifolds(w, scenes.permute_manifolds(mf, perm), offs, sc.friction, sc.restitution)
+    return p
+
+
+def test_cfg4_one_million_sparse_mixed_pairs_bit_exact():
+    """cfg4: 1M alternating ball/cuboid colliders, random poses and velocities (swept AABBs), no ground."""
+    sc = scenes.sparse_mixed(1_000_000)
+    wo, wh = F.World(oracle_lib(), F.default_config(32)), F.World(hip_lib(), F.default_config(32))
+    for w in (wo, wh):
+        w.bodies_upload(**sc.body_kwargs())
+        w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        w.run_system("UPDATE_AABB")
+        w.run_system("COLLECT_COLLISION_PAIRS")
+    mo, xo, eo = wo.aabbs_download(); mh, xh, eh = wh.aabbs_download()
+    assert_same(mo, mh, "aabb.min"); assert_same(xo, xh, "aabb.max")
+    assert np.array_equal(eo, eh), "interval order (stable sort by min.x) differs"
+    po, ph = wo.pairs_get(), wh.pairs_get()
+    assert len(po) == len(ph) > 1000 and np.array_equal(po, ph), "pair SEQUENCE differs from the reference order"
+    # properties: emission order is (rank of collider1 asc, rank of collider2 asc); no duplicates; second frame finds nothing
+    rank = np.empty(len(eh), np.int64); rank[eh] = np.arange(len(eh))
+    r1, r2 = rank[ph["collider1"]], rank[ph["collider2"]]
+    assert (r1 < r2).all() and (np.diff(r1 * len(eh) + r2) > 0).all()
+    wh.run_system("UPDATE_AABB"); wh.run_system("COLLECT_COLLISION_PAIRS")
+    assert len(wh.pairs_get()) == 0
+    # brute-force spot check of 200 random colliders against everything (closed-interval overlap)
+    rng = np.random.default_rng(1)
+    have = set(zip(ph["collider1"].tolist(), ph["collider2"].tolist()))
+    for c in rng.choice(len(mh), 200, replace=False):
+        ov = np.flatnonzero(np.all(mh <= xh[c], axis=1) & np.all(xh >= mh[c], axis=1))
+        for o in ov:
+            if o != c:
+                assert (int(c), int(o)) in have or (int(o), int(c)) in have
+
+
+def test_cfg3_stack_with_distance_joint_chains_matches_oracle():
+    """cfg3: 50k cuboids + 10k DistanceJoints (100 chains x 100 links, first link kinematic), 4 substeps."""
+    sc, joints = scenes.stack_with_chains(50, 20, 50, 100, 100)
+    joints = dict(joints, collision_disabled=np.ones(len(joints["body1"]), np.uint8))
+    assert sc.n == 50_000 + 10_000 + 1 and len(joints["body1"]) == 9_900
+    wo = F.World(oracle_lib(), F.default_config(32, substeps=4))
+    wh = F.World(hip_lib(), F.default_config(32, substeps=4))
+    po = setup(wo, oracle_lib(), sc, joints); ph = setup(wh, hip_lib(), sc, joints)
+    assert np.array_equal(po, ph) and len(po) > 100_000
+    for s in range(2):
+        wo.step(); wh.step()
+        compare_dicts(wo.bodies_download(), wh.bodies_download(), f"cfg3 step {s}: bodies")
+        compare_dicts(wo.joints_download(), wh.joints_download(), f"cfg3 step {s}: joints")
+    j = wh.joints_download()
+    assert float(np.abs(j["total_lagrange"]).max()) > 0.0, "the chains must actually load their joints"
+    compare_dicts(wo.impulses_download(), wh.impulses_download(), "cfg3: impulses")
+
+
+def test_cfg2_full_size_one_step_matches_oracle():
+    """cfg2 (the bench workload): 100k-cuboid stack, 4 substeps; one whole step against the oracle, bit for bit."""
+    sc = scenes.box_stack(50, 40, 50)
+    wo = F.World(oracle_lib(), F.default_config(32, substeps=4))
+    wh = F.World(hip_lib(), F.default_config(32, substeps=4))
+    po = setup(wo, oracle_lib(), sc); ph = setup(wh, hip_lib(), sc)
+    assert np.array_equal(po, ph) and len(po) == 1_244_836
+    wo.step(); wh.step()
+    compare_dicts(wo.bodies_download(), wh.bodies_download(), "cfg2: bodies")
+    compare_dicts(wo.impulses_download(), wh.impulses_download(), "cfg2: impulses")
+    assert wh.timers().contact_constraint_count == wo.timers().contact_constraint_count == 678_200
+
+
+@pytest.mark.parametrize("size", [(40, 15, 40, "oracle"), (100, 50, 100, "properties")])
+def test_cfg5_f64_eight_substeps(size):
+    """cfg5: f64 (`Scalar = f64` build of the reference), 8 substeps.  24k bodies against the oracle; the full 500k
+    through properties: two independent worlds give bit-identical results, state stays finite, the stack does not explode."""
+    nx, ny, nz, mode = size
+    sc = scenes.box_stack(nx, ny, nz)
+    cfg = lambda: F.default_config(64, substeps=8)
+    wh = F.World(hip_lib(), cfg())
+    ph = setup(wh, hip_lib(), sc)
+    if mode == "oracle":
+        wo = F.World(oracle_lib(), cfg())
+        po = setup(wo, oracle_lib(), sc)
+        assert np.array_equal(po, ph)
+        for s in range(2):
+            wo.step(); wh.step()
+            compare_dicts(wo.bodies_download(), wh.bodies_download(), f"cfg5 step {s}")
+        return
+    assert sc.n == 500_001
+    wh2 = F.World(hip_lib(), cfg())
+    setup(wh2, hip_lib(), sc)
+    for _ in range(2):
+        wh.step(); wh2.step()
+    a, b = wh.bodies_download(), wh2.bodies_download()
+    for k in a:
+        assert a[k].dtype == np.float64 and np.array_equal(a[k], b[k]), f"{k}: two identical runs differ"
+        assert np.isfinite(a[k]).all()
+    assert float(np.abs(a["linear_velocity"]).max()) < 5.0 and float(np.abs(a["position"][1:] - sc.position[1:]).max()) < 0.1
+    tm = wh.timers()
+    assert tm.contact_constraint_count > 3_000_000 and tm.kernel_launches > 100
