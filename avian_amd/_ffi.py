@@ -102,7 +102,19 @@ class avn_distance_joints(C.Structure):
 
 
 class avn_joints_out(C.Structure):
-    _fields_ = [(n, vp) for n in ("world_r1", "world_r2", "center_difference", "total_lagrange", "force")]
+    _fields_ = [(n, vp) for n in ("world_r1", "world_r2", "center_difference", "total_lagrange", "force",
+                                  "total_rotation_lagrange", "torque")]
+
+
+JOINT_FIXED, JOINT_REVOLUTE, JOINT_SPHERICAL, JOINT_PRISMATIC, JOINT_DISTANCE = 0, 1, 2, 3, 4
+JOINT_HAS_LIMIT1, JOINT_HAS_LIMIT2 = 1, 2
+
+
+class avn_joints(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "joint_type", "body1", "body2", "local_anchor1", "local_anchor2", "local_basis1", "local_basis2", "axis",
+        "limit_min", "limit_max", "limit2_min", "limit2_max", "limit_flags", "compliance", "damping_linear",
+        "damping_angular", "collision_disabled")]
 
 
 class avn_colliders(C.Structure):
@@ -137,7 +149,7 @@ ABI_SYMBOLS = [
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
     "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
-    "islands_partition", "dynamic_bounds", "constraint_graph_push_batch",
+    "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload",
 ]
 
 
@@ -158,7 +170,7 @@ class Library:
         f("last_error").argtypes = [vp]
         f("last_error").restype = C.c_char_p
         for name in ("config_set", "bodies_upload", "bodies_download", "solver_bodies_download", "manifolds_upload",
-                     "impulses_download", "constraints_download", "distance_joints_upload", "joints_download",
+                     "impulses_download", "constraints_download", "distance_joints_upload", "joints_upload", "joints_download",
                      "colliders_upload", "timers_get"):
             f(name).argtypes = [vp, vp]
         f("existing_pairs_upload").argtypes = [vp, vp, C.c_size_t]
@@ -369,6 +381,20 @@ class World:
                 self._i(collision_disabled, np.uint8)]
         s = avn_distance_joints(j, *[_ptr(a) for a in keep])
         self._check(self.lib.fn("distance_joints_upload")(self.handle, C.byref(s)))
+        self.n_joints = j
+
+    def joints_upload(self, joint_type, body1, body2, local_anchor1, local_anchor2, compliance, local_basis1=None,
+                      local_basis2=None, axis=None, limit_min=None, limit_max=None, limit2_min=None, limit2_max=None,
+                      limit_flags=None, damping_linear=None, damping_angular=None, collision_disabled=None):
+        """``avn_joints_upload``: every XPBD joint type (``compliance`` is [J, 3], see the header)."""
+        j = len(np.asarray(body1).reshape(-1))
+        keep = [self._i(joint_type, np.uint8), self._i(body1, np.int32), self._i(body2, np.int32),
+                self._s(local_anchor1, (j, 3)), self._s(local_anchor2, (j, 3)), self._s(local_basis1), self._s(local_basis2),
+                self._s(axis), self._s(limit_min), self._s(limit_max), self._s(limit2_min), self._s(limit2_max),
+                self._i(limit_flags, np.uint8), self._s(compliance, (j, 3)), self._s(damping_linear), self._s(damping_angular),
+                self._i(collision_disabled, np.uint8)]
+        s = avn_joints(j, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("joints_upload")(self.handle, C.byref(s)))
         self.n_joints = j
 
     def joints_download(self):

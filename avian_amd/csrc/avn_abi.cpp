@@ -49,6 +49,7 @@ AVN_API avn_status avn_manifolds_upload(avn_world* w, const avn_manifolds* m) { 
 AVN_API avn_status avn_impulses_download(avn_world* w, const avn_impulses_out* o) { GUARD(impulses_download(o)); }
 AVN_API avn_status avn_constraints_download(avn_world* w, const avn_constraints_out* o) { GUARD(constraints_download(o)); }
 AVN_API avn_status avn_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { GUARD(distance_joints_upload(j)); }
+AVN_API avn_status avn_joints_upload(avn_world* w, const avn_joints* j) { GUARD(joints_upload(j)); }
 AVN_API avn_status avn_joints_download(avn_world* w, const avn_joints_out* o) { GUARD(joints_download(o)); }
 AVN_API avn_status avn_colliders_upload(avn_world* w, const avn_colliders* c) { GUARD(colliders_upload(c)); }
 AVN_API avn_status avn_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { GUARD(existing_pairs_upload(k, n)); }

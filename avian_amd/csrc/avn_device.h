@@ -105,17 +105,28 @@ template <class T> struct DW {
     int16_t* c_reldom;  // inspection only
     uint32_t* color_offsets;  // [25] device copy
     uint32_t* constraint_count;  // [1]
-    // ---- distance joints ----
+    // ---- XPBD joints (all five types; the reference's per-type components + solver data) ----
     uint32_t n_joints;
     int2* j_bodies;
     V* j_a1;       // (local_anchor1.xyz, limit_min)
     V* j_a2;       // (local_anchor2.xyz, limit_max)
-    V* j_par;      // (compliance, damping_linear, damping_angular, bits(flags: 1 has damping))
+    V* j_par;      // (compliance0, damping_linear, damping_angular, bits(1 has damping | type << 8 | limit_flags << 16))
+    V* j_b1;       // local_basis1 quaternion
+    V* j_b2;       // local_basis2 quaternion
+    V* j_ax;       // (hinge | twist | slider axis.xyz, compliance1)
+    V* j_l2;       // (limit2_min, limit2_max, compliance2, 0)
     V* j_r1;       // (world_r1.xyz, 0)
     V* j_r2;       // (world_r2.xyz, 0)
     V* j_cd;       // (center_difference.xyz, 0)
-    V* j_lag;      // (total_lagrange.xyz, 0)
+    V* j_lag;      // (total position lagrange.xyz, 0)
+    V* j_s0;       // fixed/prismatic: rotation_difference quat | revolute: a1 | spherical: swing_axis1
+    V* j_s1;       // prismatic: free_axis1 | revolute: a2 | spherical: swing_axis2
+    V* j_s2;       // revolute: b1 | spherical: twist_axis1
+    V* j_s3;       // revolute: b2 | spherical: twist_axis2
+    V* j_rl0;      // total align | swing | angle lagrange
+    V* j_rl1;      // total limit | twist lagrange
     V* j_force;    // (force.xyz, 0)
+    V* j_torque;   // (torque.xyz, 0)
 };
 
 // Block index remap so that each XCD (block b runs on XCD b % 8) walks one contiguous eighth of the

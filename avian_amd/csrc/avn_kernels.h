@@ -58,7 +58,7 @@ uint32_t color_grid_blocks(uint32_t count);
 // grid_blocks[c] = captured grid of colour c (0 = colour skipped); returns the number of launches issued
 template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, hipStream_t);
 // k_xpbd.hip
-template <class T> void launch_prepare_distance_joints(const DW<T>&, hipStream_t);
+template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);
 template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,
                                               const uint32_t* level_offsets, const uint32_t* order, hipStream_t);
 template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepParams<T>&, hipStream_t);
@@ -94,9 +94,11 @@ template <class T> struct ManifoldStage {
     const uint8_t *point_count, *manifold_flags;
 };
 template <class T> void launch_pack_manifolds(const DW<T>&, const ManifoldStage<T>&, hipStream_t);
-template <class T> struct JointStage {
+template <class T> struct JointStage {  // device staging copies of the avn_joints arrays (nullptr = absent)
+    const uint8_t *joint_type, *limit_flags;
     const int32_t *body1, *body2;
-    const T *local_anchor1, *local_anchor2, *limit_min, *limit_max, *compliance, *damping_linear, *damping_angular;
+    const T *local_anchor1, *local_anchor2, *local_basis1, *local_basis2, *axis, *limit_min, *limit_max, *limit2_min, *limit2_max,
+        *compliance /* [3J] */, *damping_linear, *damping_angular;
 };
 template <class T> void launch_pack_joints(const DW<T>&, const JointStage<T>&, hipStream_t);
 template <class T> struct ColliderStage {
@@ -122,7 +124,7 @@ template <class T> struct ConstraintsStage {
     T *tangent1, *anchor1, *initial_separation, *normal_impulse, *total_impulse, *normal_effective_mass, *tangent_impulse, *tangent_k;
 };
 template <class T> void launch_unpack_constraints(const DW<T>&, const ConstraintsStage<T>&, hipStream_t);
-template <class T> void launch_unpack_joints(const DW<T>&, T* r1, T* r2, T* cd, T* lag, T* force, hipStream_t);
+template <class T> void launch_unpack_joints(const DW<T>&, T* r1, T* r2, T* cd, T* lag, T* force, T* rot_lag, T* torque, hipStream_t);
 template <class T> void launch_unpack_aabbs(const BP<T>&, T* mn, T* mx, uint32_t* interval_entities, hipStream_t);
 
 }  // namespace avn

@@ -100,7 +100,8 @@ AVN_HD void sin_cos_t(float a, float& s, float& c) {
     float z = r * r;
     float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
     float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z - 0.5f * z + 1.0f;
-    int q = (int)((long long)kf & 3);
+    float qf = kf - 4.0f * __builtin_floorf(kf * 0.25f);  // kf mod 4, exact for every finite kf (no float->int conversion: UB-free for huge arguments)
+    int q = qf == 1.0f ? 1 : qf == 2.0f ? 2 : qf == 3.0f ? 3 : 0;
     if (q == 0) { s = sp; c = cp; }
     else if (q == 1) { s = cp; c = -sp; }
     else if (q == 2) { s = -sp; c = -cp; }
@@ -117,7 +118,8 @@ AVN_HD void sin_cos_t(double a, double& s, double& c) {
     double cp = (((((-1.13585365213876817300e-11 * z + 2.08757008419747316778e-9) * z - 2.75573141792967388112e-7) * z
                    + 2.48015872888517045348e-5) * z - 1.38888888888730564116e-3) * z + 4.16666666666665929218e-2) * z * z
                 - 0.5 * z + 1.0;
-    int q = (int)((long long)kf & 3);
+    double qf = kf - 4.0 * __builtin_floor(kf * 0.25);
+    int q = qf == 1.0 ? 1 : qf == 2.0 ? 2 : qf == 3.0 ? 3 : 0;
     if (q == 0) { s = sp; c = cp; }
     else if (q == 1) { s = cp; c = -sp; }
     else if (q == 2) { s = -sp; c = -cp; }
@@ -134,6 +136,40 @@ template <class T> AVN_HD Q4<T> from_scaled_axis(V3<T> v) {
     V3<T> a = axis * s;
     return {a.x, a.y, a.z, c};
 }
+// Deterministic asin (used by AngleLimit::compute_correction, dynamics/joints/mod.rs:427-472): the fdlibm e_asin.c
+// rational approximation R(z) = p(z)/q(z) evaluated in T with plain IEEE ops, without fdlibm's high/low split of the
+// square root: asin(x) = x + x R(x^2) for |x| < 0.5, pi/2 - 2 (s + s R(z)) with z = (1 - |x|)/2, s = sqrt(z) otherwise;
+// |x| > 1 -> NaN like Rust's asin.  Like sin_cos_t it is "the platform libm" of this build (<= 2 ulp f32, tests).
+template <class T> AVN_HD T asin_rational(T z) {
+    T p = z * (T(1.66666666666666657415e-01) + z * (T(-3.25565818622400915405e-01) + z * (T(2.01212532134862925881e-01) +
+          z * (T(-4.00555345006794114027e-02) + z * (T(7.91534994289814532176e-04) + z * T(3.47933107596021167570e-05))))));
+    T q = T(1) + z * (T(-2.40339491173441421878e+00) + z * (T(2.02094576023350569471e+00) + z * (T(-6.88283971605453293030e-01) +
+          z * T(7.70381505559019352791e-02))));
+    return p / q;
+}
+template <class T> AVN_HD T asin_t(T x) {
+    T ax = fabs_t(x);
+    if (!(ax <= T(1))) return (x - x) / (x - x);  // NaN for |x| > 1 and for NaN
+    if (ax < T(0.5)) return x + x * asin_rational<T>(x * x);
+    T z = (T(1) - ax) * T(0.5);
+    T s = sqrt_t(z);
+    T r = T(1.57079632679489661923) - T(2) * (s + s * asin_rational<T>(z));
+    return x < T(0) ? -r : r;
+}
+// glam Quat::from_axis_angle (axis must be unit)
+template <class T> AVN_HD Q4<T> from_axis_angle(V3<T> axis, T angle) {
+    T s, c;
+    sin_cos_t(angle * T(0.5), s, c);
+    V3<T> v = axis * s;
+    return {v.x, v.y, v.z, c};
+}
+// glam Vec3::any_orthogonal_vector
+template <class T> AVN_HD V3<T> any_orthogonal_vector(V3<T> v) {
+    if (fabs_t(v.x) > fabs_t(v.y)) return {-v.z, T(0), v.x};
+    return {T(0), v.z, -v.y};
+}
+// f32::clamp (min <= max assumed, like the reference's AngleLimit)
+template <class T> AVN_HD T clamp_t(T x, T lo, T hi) { T r = x; if (r < lo) r = lo; if (r > hi) r = hi; return r; }
 // glam Quat*Quat: f32 follows the SSE2 (rtm::quat_mul) association, f64 the scalar one.
 AVN_HD Q4<float> qmul(Q4<float> l, Q4<float> r) {
     return {(l.w * r.x + l.x * r.w) + (l.y * r.z + -(l.z * r.y)),

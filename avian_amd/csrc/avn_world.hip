@@ -104,7 +104,8 @@ template <class T> struct World : WorldBase {
     DevBuf b_pos, b_rot, b_lvel, b_avel, b_com, b_iloc_a, b_iloc_b, b_acc_l, b_acc_a, b_bmeta;
     DevBuf b_sb_vel, b_sb_delta, b_si, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
-    DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_force;
+    DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_b1, b_j_b2, b_j_ax, b_j_l2, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_s0, b_j_s1, b_j_s2, b_j_s3, b_j_rl0, b_j_rl1, b_j_force,
+        b_j_torque;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
     DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
@@ -114,7 +115,7 @@ template <class T> struct World : WorldBase {
     uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1];
     uint32_t grid_blocks[AVN_GRAPH_COLOR_COUNT];      // launch grids (captured into the graph with slack)
     std::vector<int32_t> h_j_body1, h_j_body2;
-    std::vector<uint8_t> h_j_damped, h_j_collision_disabled;
+    std::vector<uint8_t> h_j_damped, h_j_collision_disabled, h_j_type;
     std::vector<uint8_t> h_body_has_sb;
     bool joint_schedule_dirty = true;
     JointSchedule sched_solve, sched_damp;
@@ -258,15 +259,16 @@ template <class T> struct World : WorldBase {
 #define GROW(buf, count, field) do { avn_status s_ = grow(buf, count, &(field), moved); if (s_ != AVN_OK) return s_; } while (0)
 
     // ---- bodies ------------------------------------------------------------------------------------------
+    static constexpr uint32_t DUMMY_SLOTS = 2 * AVN_JOINT_TYPE_COUNT;  // joint_damping::<T>: two fresh DUMMY SolverBodies per joint type
     avn_status bodies_upload(const avn_bodies* b) override {
         if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass || !b->inv_inertia_local || !b->rb_type))) {
             error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG;
         }
         uint32_t n = b->count;
         bool moved = false;
-        if (n + 2 > cap_bodies || !have_bodies) {
+        if (n + DUMMY_SLOTS > cap_bodies || !have_bodies) {
             HIPCHK(hipStreamSynchronize(stream));
-            size_t c = (size_t)std::max<uint32_t>(n + 2, cap_bodies + cap_bodies / 2);  // +2: virtual DUMMY bodies of joint_damping
+            size_t c = (size_t)std::max<uint32_t>(n + DUMMY_SLOTS, cap_bodies + cap_bodies / 2);  // + the virtual DUMMY bodies of joint_damping
             GROW(b_pos, c, dw.pos); GROW(b_rot, c, dw.rot); GROW(b_lvel, c, dw.lvel); GROW(b_avel, c, dw.avel); GROW(b_com, c, dw.com);
             GROW(b_iloc_a, c, dw.iloc_a); GROW(b_iloc_b, c, dw.iloc_b); GROW(b_acc_l, c, dw.acc_l); GROW(b_acc_a, c, dw.acc_a); GROW(b_bmeta, c, dw.bmeta);
             GROW(b_sb_vel, 2 * c, dw.sb_lin.p); dw.sb_ang.p = dw.sb_lin.p + 1;   // Pair2 slots (avn_device.h)
@@ -463,37 +465,63 @@ template <class T> struct World : WorldBase {
 
     // ---- joints ----------------------------------------------------------------------------------------
     avn_status distance_joints_upload(const avn_distance_joints* j) override {
-        if (!have_bodies) { error = "distance_joints_upload before bodies_upload"; return AVN_ERR_STATE; }
         if (!j || (j->count && (!j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->limit_min || !j->limit_max || !j->compliance))) {
             error = "distance_joints_upload: null array"; return AVN_ERR_BAD_ARG;
         }
+        // the special case joint_type = DISTANCE of joints_upload
+        std::vector<uint8_t> types(j->count, (uint8_t)AVN_JOINT_DISTANCE);
+        std::vector<T> comp(3 * (size_t)j->count, T(0));
+        for (size_t i = 0; i < j->count; ++i) comp[3 * i] = ((const T*)j->compliance)[i];
+        avn_joints g;
+        std::memset(&g, 0, sizeof g);
+        g.count = j->count; g.joint_type = types.data(); g.body1 = j->body1; g.body2 = j->body2;
+        g.local_anchor1 = j->local_anchor1; g.local_anchor2 = j->local_anchor2; g.limit_min = j->limit_min; g.limit_max = j->limit_max;
+        g.compliance = comp.data(); g.damping_linear = j->damping_linear; g.damping_angular = j->damping_angular;
+        g.collision_disabled = j->collision_disabled;
+        return joints_upload(&g);
+    }
+    avn_status joints_upload(const avn_joints* j) override {
+        if (!have_bodies) { error = "joints_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!j || (j->count && (!j->joint_type || !j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->compliance))) {
+            error = "joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
         uint32_t J = j->count;
-        for (uint32_t i = 0; i < J; ++i)
+        for (uint32_t i = 0; i < J; ++i) {
+            if (j->joint_type[i] >= AVN_JOINT_TYPE_COUNT) { error = "joints_upload: bad joint_type"; return AVN_ERR_BAD_ARG; }
             if (j->body1[i] < 0 || j->body2[i] < 0 || (uint32_t)j->body1[i] >= dw.n_bodies || (uint32_t)j->body2[i] >= dw.n_bodies || j->body1[i] == j->body2[i]) {
-                error = "distance_joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
+                error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
             }
+        }
         bool moved = false;
         if (J > cap_joints) {
             HIPCHK(hipStreamSynchronize(stream));
             size_t c = std::max<size_t>(J, cap_joints + cap_joints / 2);
             GROW(b_j_bodies, c, dw.j_bodies); GROW(b_j_a1, c, dw.j_a1); GROW(b_j_a2, c, dw.j_a2); GROW(b_j_par, c, dw.j_par);
-            GROW(b_j_r1, c, dw.j_r1); GROW(b_j_r2, c, dw.j_r2); GROW(b_j_cd, c, dw.j_cd); GROW(b_j_lag, c, dw.j_lag); GROW(b_j_force, c, dw.j_force);
+            GROW(b_j_b1, c, dw.j_b1); GROW(b_j_b2, c, dw.j_b2); GROW(b_j_ax, c, dw.j_ax); GROW(b_j_l2, c, dw.j_l2);
+            GROW(b_j_r1, c, dw.j_r1); GROW(b_j_r2, c, dw.j_r2); GROW(b_j_cd, c, dw.j_cd); GROW(b_j_lag, c, dw.j_lag);
+            GROW(b_j_s0, c, dw.j_s0); GROW(b_j_s1, c, dw.j_s1); GROW(b_j_s2, c, dw.j_s2); GROW(b_j_s3, c, dw.j_s3);
+            GROW(b_j_rl0, c, dw.j_rl0); GROW(b_j_rl1, c, dw.j_rl1); GROW(b_j_force, c, dw.j_force); GROW(b_j_torque, c, dw.j_torque);
             cap_joints = (uint32_t)c;
         }
         if (moved || dw.n_joints != J) graph_valid = false;
         dw.n_joints = J;
-        avn_status st = stage_reserve(al(4 * (size_t)J) * 2 + al(sizeof(T) * 3 * J) * 2 + al(sizeof(T) * J) * 5 + 4096);
+        avn_status st = stage_reserve(al(4 * (size_t)J) * 2 + al(J) * 2 + al(sizeof(T) * 3 * J) * 4 + al(sizeof(T) * 4 * J) * 2 + al(sizeof(T) * J) * 6 + 8192);
         if (st != AVN_OK) return st;
         JointStage<T> s;
         std::memset(&s, 0, sizeof s);
+        SIN(joint_type, j->joint_type, J, uint8_t); SIN(limit_flags, j->limit_flags, J, uint8_t);
         SIN(body1, j->body1, J, int32_t); SIN(body2, j->body2, J, int32_t);
         SIN(local_anchor1, j->local_anchor1, 3 * (size_t)J, T); SIN(local_anchor2, j->local_anchor2, 3 * (size_t)J, T);
-        SIN(limit_min, j->limit_min, J, T); SIN(limit_max, j->limit_max, J, T); SIN(compliance, j->compliance, J, T);
+        SIN(local_basis1, j->local_basis1, 4 * (size_t)J, T); SIN(local_basis2, j->local_basis2, 4 * (size_t)J, T);
+        SIN(axis, j->axis, 3 * (size_t)J, T);
+        SIN(limit_min, j->limit_min, J, T); SIN(limit_max, j->limit_max, J, T); SIN(limit2_min, j->limit2_min, J, T); SIN(limit2_max, j->limit2_max, J, T);
+        SIN(compliance, j->compliance, 3 * (size_t)J, T);
         SIN(damping_linear, j->damping_linear, J, T); SIN(damping_angular, j->damping_angular, J, T);
         launch_pack_joints<T>(dw, s, stream);
         HIPCHK(hipGetLastError());
         h_j_body1.assign(j->body1, j->body1 + J);
         h_j_body2.assign(j->body2, j->body2 + J);
+        h_j_type.assign(j->joint_type, j->joint_type + J);
         bool damp = j->damping_linear && j->damping_angular;
         h_j_damped.assign(J, damp ? 1 : 0);
         any_damped = damp && J > 0;
@@ -513,17 +541,20 @@ template <class T> struct World : WorldBase {
     avn_status joints_download(const avn_joints_out* o) override {
         if (!o) return AVN_ERR_BAD_ARG;
         size_t J = dw.n_joints;
-        avn_status st = stage_reserve(al(sizeof(T) * 3 * J) * 5 + 1024);
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * J) * 7 + 1024);
         if (st != AVN_OK) return st;
         T* a = o->world_r1 ? stage_alloc<T>(3 * J) : nullptr;
         T* b = o->world_r2 ? stage_alloc<T>(3 * J) : nullptr;
         T* c = o->center_difference ? stage_alloc<T>(3 * J) : nullptr;
         T* d = o->total_lagrange ? stage_alloc<T>(3 * J) : nullptr;
         T* e = o->force ? stage_alloc<T>(3 * J) : nullptr;
-        launch_unpack_joints<T>(dw, a, b, c, d, e, stream);
+        T* f = o->total_rotation_lagrange ? stage_alloc<T>(3 * J) : nullptr;
+        T* g = o->torque ? stage_alloc<T>(3 * J) : nullptr;
+        launch_unpack_joints<T>(dw, a, b, c, d, e, f, g, stream);
         HIPCHK(hipGetLastError());
         SOUT(o->world_r1, a, 3 * J, T); SOUT(o->world_r2, b, 3 * J, T); SOUT(o->center_difference, c, 3 * J, T);
         SOUT(o->total_lagrange, d, 3 * J, T); SOUT(o->force, e, 3 * J, T);
+        SOUT(o->total_rotation_lagrange, f, 3 * J, T); SOUT(o->torque, g, 3 * J, T);
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
@@ -538,28 +569,34 @@ template <class T> struct World : WorldBase {
         if (!joint_schedule_dirty) return AVN_OK;
         HIPCHK(hipStreamSynchronize(stream));
         uint32_t J = dw.n_joints, N = dw.n_bodies;
+        // the reference's serial order: one system per joint type in the order of xpbd/plugin.rs:77-82 (= the AVN_JOINT_* ids),
+        // each iterating its joints in array (= spawn) order
         std::vector<uint32_t> all(J);
         std::iota(all.begin(), all.end(), 0u);
+        std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return h_j_type[a] < h_j_type[b]; });
         std::vector<int32_t> k1(J), k2(J);
-        for (uint32_t i = 0; i < J; ++i) {
+        for (uint32_t k = 0; k < J; ++k) {
+            uint32_t i = all[k];
             // bodies without a SolverBody are DUMMY in solve_xpbd_joint: never modified => they do not serialise joints
-            k1[i] = h_body_has_sb[h_j_body1[i]] ? h_j_body1[i] : -1;
-            k2[i] = h_body_has_sb[h_j_body2[i]] ? h_j_body2[i] : -1;
+            k1[k] = h_body_has_sb[h_j_body1[i]] ? h_j_body1[i] : -1;
+            k2[k] = h_body_has_sb[h_j_body2[i]] ? h_j_body2[i] : -1;
         }
         sched_solve.build(all, k1, k2, N);
         std::vector<uint32_t> damped;
         std::vector<int32_t> d1, d2;
         sched_damp.touches_dummy = false;
-        for (uint32_t i = 0; i < J; ++i)
+        for (uint32_t k = 0; k < J; ++k) {
+            uint32_t i = all[k];
             if (h_j_damped[i]) {
                 damped.push_back(i);
-                // joint_damping's DUMMY bodies are shared and mutable: virtual bodies N (side 1) and N+1 (side 2)
+                // joint_damping's DUMMY bodies are shared by the joints of ONE type and mutable: virtual bodies N + 2t, N + 2t + 1
                 bool m1 = !h_body_has_sb[h_j_body1[i]], m2 = !h_body_has_sb[h_j_body2[i]];
-                d1.push_back(m1 ? (int32_t)N : h_j_body1[i]);
-                d2.push_back(m2 ? (int32_t)N + 1 : h_j_body2[i]);
+                d1.push_back(m1 ? (int32_t)(N + 2u * h_j_type[i]) : h_j_body1[i]);
+                d2.push_back(m2 ? (int32_t)(N + 2u * h_j_type[i] + 1u) : h_j_body2[i]);
                 if (m1 || m2) sched_damp.touches_dummy = true;
             }
-        sched_damp.build(damped, d1, d2, N + 2);
+        }
+        sched_damp.build(damped, d1, d2, N + DUMMY_SLOTS);
         avn_status st;
         for (JointSchedule* s : {&sched_solve, &sched_damp}) {
             if ((st = upload_u32(s->d_comp_level_begin, s->comp_level_begin)) != AVN_OK) return st;
@@ -798,7 +835,7 @@ template <class T> struct World : WorldBase {
     // ---- systems -------------------------------------------------------------------------------------------
     avn_status need_bodies() { if (!have_bodies) { error = "no bodies uploaded"; return AVN_ERR_STATE; } return AVN_OK; }
     void prepare_solver_bodies() { launch_prepare_solver_bodies<T>(dw, stream); ++launches; }
-    void prepare_joints() { if (dw.n_joints) { launch_prepare_distance_joints<T>(dw, stream); ++launches; } }
+    void prepare_joints() { if (dw.n_joints) { launch_prepare_joints<T>(dw, stream); ++launches; } }
     void prepare_contact_constraints() { launch_prepare_contact_constraints<T>(dw, params, stream); ++launches; }
     void pre_process_velocity_increments() { launch_pre_process_increments<T>(dw, params, stream); ++launches; }
     void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
@@ -823,7 +860,7 @@ template <class T> struct World : WorldBase {
         if (!any_damped || !sched_damp.n_components) return;
         if (sched_damp.touches_dummy) {
             // reset the two virtual SolverBody::DUMMY slots (all-zero bit pattern = zero velocities)
-            (void)hipMemsetAsync(&dw.sb_lin[dw.n_bodies], 0, 4 * sizeof(V), stream);  // 2 bodies x (lin | ang) slot
+            (void)hipMemsetAsync(&dw.sb_lin[dw.n_bodies], 0, 2 * DUMMY_SLOTS * sizeof(V), stream);  // DUMMY_SLOTS bodies x (lin | ang) slot
         }
         launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp.n_components, sched_damp.d_comp_level_begin.as<uint32_t>(),
                                  sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_order.as<uint32_t>(), stream);

@@ -59,6 +59,7 @@ struct WorldBase {
     virtual avn_status impulses_download(const avn_impulses_out*) = 0;
     virtual avn_status constraints_download(const avn_constraints_out*) = 0;
     virtual avn_status distance_joints_upload(const avn_distance_joints*) = 0;
+    virtual avn_status joints_upload(const avn_joints*) = 0;
     virtual avn_status joints_download(const avn_joints_out*) = 0;
     virtual avn_status colliders_upload(const avn_colliders*) = 0;
     virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;

@@ -67,15 +67,22 @@ __global__ __launch_bounds__(256) void k_pack_joints(DW<T> w, JointStage<T> s) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= w.n_joints) return;
     w.j_bodies[j] = make_int2(s.body1[j], s.body2[j]);
-    w.j_a1[j] = make4<T>(ld3(s.local_anchor1, j), s.limit_min[j]);
-    w.j_a2[j] = make4<T>(ld3(s.local_anchor2, j), s.limit_max[j]);
+    uint32_t type = s.joint_type[j], lf = s.limit_flags ? s.limit_flags[j] : 0u;
+    w.j_a1[j] = make4<T>(ld3(s.local_anchor1, j), s.limit_min ? s.limit_min[j] : T(0));
+    w.j_a2[j] = make4<T>(ld3(s.local_anchor2, j), s.limit_max ? s.limit_max[j] : T(0));
     bool damp = s.damping_linear && s.damping_angular;
-    w.j_par[j] = make4<T>(s.compliance[j], damp ? s.damping_linear[j] : T(0), damp ? s.damping_angular[j] : T(0), bits_to_scalar(damp ? 1u : 0u, T(0)));
-    w.j_r1[j] = make4<T>(0, 0, 0, 0);
-    w.j_r2[j] = make4<T>(0, 0, 0, 0);
-    w.j_cd[j] = make4<T>(0, 0, 0, 0);
-    w.j_lag[j] = make4<T>(0, 0, 0, 0);
-    w.j_force[j] = make4<T>(0, 0, 0, 0);
+    w.j_par[j] = make4<T>(s.compliance[3 * j], damp ? s.damping_linear[j] : T(0), damp ? s.damping_angular[j] : T(0),
+                          bits_to_scalar((damp ? 1u : 0u) | (type << 8) | (lf << 16), T(0)));
+    w.j_b1[j] = s.local_basis1 ? make4<T>(s.local_basis1[4 * j], s.local_basis1[4 * j + 1], s.local_basis1[4 * j + 2], s.local_basis1[4 * j + 3]) : make4<T>(0, 0, 0, 1);
+    w.j_b2[j] = s.local_basis2 ? make4<T>(s.local_basis2[4 * j], s.local_basis2[4 * j + 1], s.local_basis2[4 * j + 2], s.local_basis2[4 * j + 3]) : make4<T>(0, 0, 0, 1);
+    V3<T> ax = s.axis ? ld3(s.axis, j)
+                      : (type == AVN_JOINT_REVOLUTE ? V3<T>{T(0), T(0), T(1)} : type == AVN_JOINT_SPHERICAL ? V3<T>{T(0), T(1), T(0)} : V3<T>{T(1), T(0), T(0)});
+    w.j_ax[j] = make4<T>(ax, s.compliance[3 * j + 1]);
+    w.j_l2[j] = make4<T>(s.limit2_min ? s.limit2_min[j] : T(0), s.limit2_max ? s.limit2_max[j] : T(0), s.compliance[3 * j + 2], T(0));
+    Vec4<T> z = make4<T>(0, 0, 0, 0);
+    w.j_r1[j] = z; w.j_r2[j] = z; w.j_cd[j] = z; w.j_lag[j] = z;
+    w.j_s0[j] = make4<T>(0, 0, 0, 1); w.j_s1[j] = z; w.j_s2[j] = z; w.j_s3[j] = z;
+    w.j_rl0[j] = z; w.j_rl1[j] = z; w.j_force[j] = z; w.j_torque[j] = z;
 }
 
 template <class T>
@@ -157,7 +164,7 @@ __global__ __launch_bounds__(256) void k_unpack_constraints(DW<T> w, Constraints
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_unpack_joints(DW<T> w, T* r1, T* r2, T* cd, T* lag, T* force) {
+__global__ __launch_bounds__(256) void k_unpack_joints(DW<T> w, T* r1, T* r2, T* cd, T* lag, T* force, T* rot_lag, T* torque) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= w.n_joints) return;
     st3(r1, j, xyz<T>(w.j_r1[j]));
@@ -165,6 +172,8 @@ __global__ __launch_bounds__(256) void k_unpack_joints(DW<T> w, T* r1, T* r2, T*
     st3(cd, j, xyz<T>(w.j_cd[j]));
     st3(lag, j, xyz<T>(w.j_lag[j]));
     st3(force, j, xyz<T>(w.j_force[j]));
+    st3(rot_lag, j, xyz<T>(w.j_rl0[j]) + xyz<T>(w.j_rl1[j]));
+    st3(torque, j, xyz<T>(w.j_torque[j]));
 }
 
 template <class T>
@@ -183,7 +192,7 @@ template <class T> void launch_unpack_bodies(const DW<T>& w, T* p, T* r, T* l, T
 template <class T> void launch_unpack_solver_bodies(const DW<T>& w, const SolverBodiesStage<T>& o, hipStream_t st) { if (w.n_bodies) hipLaunchKernelGGL(k_unpack_solver_bodies<T>, g256(w.n_bodies), dim3(256), 0, st, w, o); }
 template <class T> void launch_unpack_impulses(const DW<T>& w, T* a, T* b, T* c, hipStream_t st) { if (w.n_manifolds) hipLaunchKernelGGL(k_unpack_impulses<T>, g256(w.n_manifolds), dim3(256), 0, st, w, a, b, c); }
 template <class T> void launch_unpack_constraints(const DW<T>& w, const ConstraintsStage<T>& o, hipStream_t st) { if (w.n_manifolds) hipLaunchKernelGGL(k_unpack_constraints<T>, g256(w.n_manifolds), dim3(256), 0, st, w, o); }
-template <class T> void launch_unpack_joints(const DW<T>& w, T* a, T* b, T* c, T* d, T* e, hipStream_t st) { if (w.n_joints) hipLaunchKernelGGL(k_unpack_joints<T>, g256(w.n_joints), dim3(256), 0, st, w, a, b, c, d, e); }
+template <class T> void launch_unpack_joints(const DW<T>& w, T* a, T* b, T* c, T* d, T* e, T* f, T* g, hipStream_t st) { if (w.n_joints) hipLaunchKernelGGL(k_unpack_joints<T>, g256(w.n_joints), dim3(256), 0, st, w, a, b, c, d, e, f, g); }
 template <class T> void launch_unpack_aabbs(const BP<T>& bp, T* mn, T* mx, uint32_t* ents, hipStream_t st) {
     uint32_t n = bp.n_colliders > bp.n_intervals ? bp.n_colliders : bp.n_intervals;
     if (n) hipLaunchKernelGGL(k_unpack_aabbs<T>, g256(n), dim3(256), 0, st, bp, mn, mx, ents);
@@ -198,7 +207,7 @@ template <class T> void launch_unpack_aabbs(const BP<T>& bp, T* mn, T* mx, uint3
     template void launch_unpack_solver_bodies<T>(const DW<T>&, const SolverBodiesStage<T>&, hipStream_t); \
     template void launch_unpack_impulses<T>(const DW<T>&, T*, T*, T*, hipStream_t);                 \
     template void launch_unpack_constraints<T>(const DW<T>&, const ConstraintsStage<T>&, hipStream_t); \
-    template void launch_unpack_joints<T>(const DW<T>&, T*, T*, T*, T*, T*, hipStream_t);           \
+    template void launch_unpack_joints<T>(const DW<T>&, T*, T*, T*, T*, T*, T*, T*, hipStream_t);           \
     template void launch_unpack_aabbs<T>(const BP<T>&, T*, T*, uint32_t*, hipStream_t);
 INST(float)
 INST(double)

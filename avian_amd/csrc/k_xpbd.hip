@@ -1,4 +1,4 @@
-// k_xpbd.hip — XPBD DistanceJoint projection, joint damping, joint forces.
+// k_xpbd.hip — XPBD joint projection (fixed, revolute, spherical, prismatic, distance), joint damping, joint forces.
 //
 // The reference solves joints in ONE serial loop in query order (xpbd/plugin.rs:145-189) — a Gauss-Seidel
 // sweep whose result depends on that order.  To stay bit-identical AND parallel, joints are scheduled on
@@ -12,9 +12,10 @@
 // the CU's vector L1 (workgroup-scope coherence), so no agent-scope fences are needed.
 //
 // Reference functions replaced (paths relative to /root/reference/src/dynamics):
-//   k_prepare_distance_joints   solver/xpbd/plugin.rs:125-142, solver/xpbd/joints/distance.rs:36-59
-//   k_xpbd_distance_joints      solver/xpbd/plugin.rs:145-189, joints/distance.rs:61-117,
-//                               joints/mod.rs:321-340, xpbd/mod.rs:393-413, xpbd/positional_constraint.rs:10-93
+//   k_prepare_joints            solver/xpbd/plugin.rs:125-142 + prepare() of solver/xpbd/joints/{fixed,revolute,spherical,
+//                               prismatic,distance}.rs and joints/shared/{point_constraint,fixed_angle_constraint}.rs
+//   k_joint_schedule<0>         solver/xpbd/plugin.rs:145-189 + solve() of the same files, joints/mod.rs:321-357,427-472,
+//                               xpbd/mod.rs:393-413, xpbd/positional_constraint.rs:10-93, xpbd/angular_constraint.rs:50-184
 //   k_joint_damping             solver/plugin.rs:759-806
 //   k_writeback_joint_forces    solver/xpbd/plugin.rs:242-260
 #include "avn_kernels.h"
@@ -23,23 +24,55 @@ namespace avn {
 
 #define JOINT_THREADS 64
 
+// joint meta word (w lane of j_par): bit 0 has JointDamping, bits 8-15 AVN_JOINT_* type, bits 16-23 AVN_JOINT_HAS_LIMIT*
+__device__ __forceinline__ uint32_t jm_type(uint32_t m) { return (m >> 8) & 0xFFu; }
+__device__ __forceinline__ uint32_t jm_limits(uint32_t m) { return (m >> 16) & 0xFFu; }
+
+// prepare_xpbd_joint<T> (xpbd/plugin.rs:125-142) + the per-type prepare():
+//   point constraint  xpbd/joints/shared/point_constraint.rs:38-53     fixed angle  shared/fixed_angle_constraint.rs:38-57
+//   fixed fixed.rs:39-72   revolute revolute.rs:48-90   spherical spherical.rs:44-83   prismatic prismatic.rs:43-81
+//   distance distance.rs:36-59
 template <class T>
-__global__ __launch_bounds__(256) void k_prepare_distance_joints(DW<T> w) {
+__global__ __launch_bounds__(256) void k_prepare_joints(DW<T> w) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
     if (j >= w.n_joints) return;
-    w.j_lag[j] = make4<T>(0, 0, 0, 0);  // clear_lagrange_multipliers
+    Vec4<T> z = make4<T>(0, 0, 0, 0);
+    w.j_lag[j] = z; w.j_rl0[j] = z; w.j_rl1[j] = z;  // clear_lagrange_multipliers
     int2 b = w.j_bodies[j];
     uint32_t m1 = w.bmeta[b.x], m2 = w.bmeta[b.y];
     if ((meta_flags(m1) | meta_flags(m2)) & AVN_BODY_DISABLED) return;  // bodies.get_many fails: solver data untouched
+    uint32_t type = jm_type(scalar_to_bits(w.j_par[j].w));
     Q4<T> q1 = quat<T>(w.rot[b.x]), q2 = quat<T>(w.rot[b.y]);
     V3<T> com1 = xyz<T>(w.com[b.x]), com2 = xyz<T>(w.com[b.y]);
     V3<T> p1 = xyz<T>(w.pos[b.x]), p2 = xyz<T>(w.pos[b.y]);
-    V3<T> world_r1 = qrot(q1, xyz<T>(w.j_a1[j]) - com1);
-    V3<T> world_r2 = qrot(q2, xyz<T>(w.j_a2[j]) - com2);
+    V3<T> anchor1 = xyz<T>(w.j_a1[j]), anchor2 = xyz<T>(w.j_a2[j]);
     V3<T> cd = (p2 - p1) + (qrot(q2, com2) - qrot(q1, com1));
-    w.j_r1[j] = make4<T>(world_r1, 0);
-    w.j_r2[j] = make4<T>(world_r2, 0);
+    Q4<T> basis1 = quat<T>(w.j_b1[j]), basis2 = quat<T>(w.j_b2[j]);
+    V3<T> axis = xyz<T>(w.j_ax[j]);
+    if (type == AVN_JOINT_SPHERICAL) {  // rotation MATRICES here, like the reference (spherical.rs:66-82)
+        M3<T> r1m = mat3_from_quat(q1), r2m = mat3_from_quat(q2);
+        w.j_r1[j] = make4<T>(mmul(r1m, anchor1 - com1), 0);
+        w.j_r2[j] = make4<T>(mmul(r2m, anchor2 - com2), 0);
+        w.j_cd[j] = make4<T>(cd, 0);
+        V3<T> swing_axis = any_orthonormal_vector(axis);
+        w.j_s0[j] = make4<T>(mmul(r1m, qrot(basis1, swing_axis)), 0);
+        w.j_s1[j] = make4<T>(mmul(r2m, qrot(basis2, swing_axis)), 0);
+        w.j_s2[j] = make4<T>(mmul(r1m, qrot(basis1, axis)), 0);
+        w.j_s3[j] = make4<T>(mmul(r2m, qrot(basis2, axis)), 0);
+        return;
+    }
+    w.j_r1[j] = make4<T>(qrot(q1, anchor1 - com1), 0);
+    w.j_r2[j] = make4<T>(qrot(q2, anchor2 - com2), 0);
     w.j_cd[j] = make4<T>(cd, 0);
+    if (type == AVN_JOINT_FIXED || type == AVN_JOINT_PRISMATIC)
+        w.j_s0[j] = make4<T>(qmul(qmul(q1, basis1), qinverse(qmul(q2, basis2))));
+    if (type == AVN_JOINT_PRISMATIC) w.j_s1[j] = make4<T>(qrot(qmul(q1, basis1), axis), 0);  // free_axis1
+    if (type == AVN_JOINT_REVOLUTE) {
+        Q4<T> f1 = qmul(q1, basis1), f2 = qmul(q2, basis2);
+        V3<T> ortho = any_orthonormal_vector(axis);
+        w.j_s0[j] = make4<T>(qrot(f1, axis), 0); w.j_s1[j] = make4<T>(qrot(f2, axis), 0);    // a1, a2
+        w.j_s2[j] = make4<T>(qrot(f1, ortho), 0); w.j_s3[j] = make4<T>(qrot(f2, ortho), 0);  // b1, b2
+    }
 }
 
 template <class T> struct JBody {
@@ -57,7 +90,87 @@ template <class T> __device__ __forceinline__ void jload(const DW<T>& w, int idx
     }
 }
 
-template <class T> __device__ __forceinline__ void distance_joint_solve(const DW<T>& w, const StepParams<T>& p, uint32_t j) {
+// xpbd/mod.rs:393-413 compute_lagrange_update (w = [w1, w2]; `iter().sum()` starts from 0.0)
+template <class T> __device__ __forceinline__ T compute_lagrange_update(T lagrange, T c, T w1, T w2, T compliance, T dt) {
+    T w_sum = T(0) + w1 + w2;
+    if (w_sum <= Limits<T>::eps) return T(0);
+    T tilde_compliance = compliance / (dt * dt);
+    return (-c - tilde_compliance * lagrange) / (w_sum + tilde_compliance);
+}
+// positional_constraint.rs:10-51 / :68-82
+template <class T> __device__ __forceinline__ void apply_positional_impulse(JBody<T>& b1, JBody<T>& b2, V3<T> impulse, V3<T> r1, V3<T> r2) {
+    b1.dp = b1.dp + cmul(impulse, b1.inv_mass);
+    b1.dq = qmul(from_scaled_axis(smul(b1.I, cross(r1, impulse))), b1.dq);
+    b2.dp = b2.dp - cmul(impulse, b2.inv_mass);
+    b2.dq = qmul(from_scaled_axis(smul(b2.I, cross(r2, -impulse))), b2.dq);
+}
+template <class T> __device__ __forceinline__ T positional_w(T inv_mass_max, const Sym3<T>& I, V3<T> r, V3<T> dir) {
+    V3<T> rc = cross(r, dir);
+    return inv_mass_max + dot(rc, smul(I, rc));
+}
+// the per-joint solver data a solve touches, held in registers for the duration of the joint
+template <class T> struct JData { V3<T> r1, r2, cd, lag, rl0, rl1; };
+
+// shared/point_constraint.rs:56-108
+template <class T> __device__ __forceinline__ void point_constraint_solve(JData<T>& d, JBody<T>& b1, JBody<T>& b2, T compliance, T dt) {
+    V3<T> world_r1 = qrot(b1.dq, d.r1), world_r2 = qrot(b2.dq, d.r2);
+    V3<T> separation = ((b2.dp - b1.dp) + (world_r2 - world_r1)) + d.cd;
+    T magnitude_squared = length_squared(separation);
+    if (magnitude_squared == T(0)) return;
+    T magnitude = sqrt_t(magnitude_squared);
+    V3<T> dir = (-separation) / magnitude;
+    T w1 = positional_w(max_element(b1.inv_mass), b1.I, world_r1, dir);
+    T w2 = positional_w(max_element(b2.inv_mass), b2.I, world_r2, dir);
+    T delta_lagrange = compute_lagrange_update<T>(T(0), magnitude, w1, w2, compliance, dt);
+    V3<T> impulse = delta_lagrange * dir;
+    d.lag = d.lag + impulse;
+    apply_positional_impulse(b1, b2, impulse, world_r1, world_r2);
+}
+// angular_constraint.rs:146-184 align_orientation + :50-93 apply_angular_lagrange_update / apply_angular_impulse (3D)
+template <class T> __device__ __forceinline__ V3<T> align_orientation(JBody<T>& b1, JBody<T>& b2, V3<T> rotation_difference, T lagrange, T compliance, T dt) {
+    T angle = length(rotation_difference);
+    if (angle <= Limits<T>::eps) return vzero<T>();
+    V3<T> axis = rotation_difference / angle;
+    T w1 = dot(axis, smul(b1.I, axis)), w2 = dot(axis, smul(b2.I, axis));
+    T delta_lagrange = compute_lagrange_update<T>(lagrange, angle, w1, w2, compliance, dt);
+    if (!(fabs_t(delta_lagrange) <= Limits<T>::eps)) {
+        V3<T> impulse = (-delta_lagrange) * axis;
+        b1.dq = qmul(from_scaled_axis(smul(b1.I, impulse)), b1.dq);
+        b2.dq = qmul(from_scaled_axis(smul(b2.I, -impulse)), b2.dq);
+    }
+    return delta_lagrange * axis;
+}
+// shared/fixed_angle_constraint.rs:60-95
+template <class T> __device__ __forceinline__ void fixed_angle_solve(JData<T>& d, Q4<T> rotation_difference, JBody<T>& b1, JBody<T>& b2, T compliance, T dt) {
+    Q4<T> q = qmul(qmul(rotation_difference, b1.dq), qinverse(b2.dq));
+    V3<T> difference = T(-2) * V3<T>{q.x, q.y, q.z};
+    d.rl0 = d.rl0 + align_orientation(b1, b2, difference, T(0), compliance, dt);
+}
+// dynamics/joints/mod.rs:427-472 AngleLimit::compute_correction (3D)
+template <class T> __device__ __forceinline__ bool angle_limit_correction(T lim_min, T lim_max, V3<T> limit_axis, V3<T> axis1, V3<T> axis2, T max_correction, V3<T>& out) {
+    const T PI = T(3.14159265358979323846264338327950288), TAU = T(6.28318530717958647692528676655900577);
+    T phi = asin_t(dot(cross(axis1, axis2), limit_axis));
+    if (dot(axis1, axis2) < T(0)) phi = PI - phi;
+    if (phi > PI) phi -= TAU;
+    if (phi < lim_min || phi > lim_max) {
+        phi = clamp_t(phi, lim_min, lim_max);
+        Q4<T> rot = from_axis_angle(limit_axis, phi);
+        out = clamp_length_max(cross(qrot(rot, axis1), axis2), max_correction);
+        return true;
+    }
+    return false;
+}
+// dynamics/joints/mod.rs:345-357 DistanceLimit::compute_correction_along_axis
+template <class T> __device__ __forceinline__ V3<T> correction_along_axis(T lim_min, T lim_max, V3<T> separation, V3<T> axis) {
+    T a = dot(separation, axis);
+    if (a < lim_min) return axis * (lim_min - a);
+    if (a > lim_max) return (-axis) * (a - lim_max);
+    return vzero<T>();
+}
+
+// solve_xpbd_joint<T> (xpbd/plugin.rs:145-189) for one joint of any type: fixed.rs:74-91, revolute.rs:92-183,
+// spherical.rs:85-209, prismatic.rs:83-192, distance.rs:61-117
+template <class T> __device__ __forceinline__ void joint_solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t j) {
     int2 b = w.j_bodies[j];
     uint32_t f1 = w.sb_flags[b.x], f2 = w.sb_flags[b.y];
     bool nobody1 = f1 & AVN_SBF_NO_SOLVER_BODY, nobody2 = f2 & AVN_SBF_NO_SOLVER_BODY;
@@ -67,41 +180,112 @@ template <class T> __device__ __forceinline__ void distance_joint_solve(const DW
     JBody<T> b1, b2;
     jload<T>(w, b.x, nobody1, rel > 0, b1);
     jload<T>(w, b.y, nobody2, rel < 0, b2);
-    Vec4<T> a1 = w.j_a1[j], a2 = w.j_a2[j];
-    T limit_min = a1.w, limit_max = a2.w, compliance = w.j_par[j].x;
-    V3<T> world_r1 = qrot(b1.dq, xyz<T>(w.j_r1[j]));
-    V3<T> world_r2 = qrot(b2.dq, xyz<T>(w.j_r2[j]));
-    V3<T> separation = ((b2.dp - b1.dp) + (world_r2 - world_r1)) + xyz<T>(w.j_cd[j]);
-    // DistanceLimit::compute_correction
-    V3<T> dir = vzero<T>();
-    T distance = 0;
-    T dsq = length_squared(separation);
-    if (!(dsq <= Limits<T>::eps)) {
-        T d = sqrt_t(dsq);
-        if (d < limit_min) { dir = separation / d; distance = limit_min - d; }
-        else if (d > limit_max) { dir = (-separation) / d; distance = d - limit_max; }
+    Vec4<T> a1v = w.j_a1[j], a2v = w.j_a2[j], par = w.j_par[j];
+    uint32_t meta = scalar_to_bits(par.w);
+    uint32_t type = jm_type(meta), limits = jm_limits(meta);
+    T limit_min = a1v.w, limit_max = a2v.w, c0 = par.x;
+    T dt = p.h_adj;
+    const T PI = T(3.14159265358979323846264338327950288), EPS = Limits<T>::eps;
+    JData<T> d;
+    d.r1 = xyz<T>(w.j_r1[j]); d.r2 = xyz<T>(w.j_r2[j]); d.cd = xyz<T>(w.j_cd[j]);
+    d.lag = xyz<T>(w.j_lag[j]);
+    d.rl0 = vzero<T>(); d.rl1 = vzero<T>();
+    bool angular = type != AVN_JOINT_DISTANCE;
+    T c1 = 0, c2 = 0;
+    if (angular) { d.rl0 = xyz<T>(w.j_rl0[j]); d.rl1 = xyz<T>(w.j_rl1[j]); c1 = w.j_ax[j].w; c2 = w.j_l2[j].z; }
+
+    if (type == AVN_JOINT_DISTANCE) {
+        V3<T> world_r1 = qrot(b1.dq, d.r1), world_r2 = qrot(b2.dq, d.r2);
+        V3<T> separation = ((b2.dp - b1.dp) + (world_r2 - world_r1)) + d.cd;
+        // DistanceLimit::compute_correction (dynamics/joints/mod.rs:321-340)
+        V3<T> dir = vzero<T>();
+        T distance = 0;
+        T dsq = length_squared(separation);
+        if (!(dsq <= EPS)) {
+            T dd = sqrt_t(dsq);
+            if (dd < limit_min) { dir = separation / dd; distance = limit_min - dd; }
+            else if (dd > limit_max) { dir = (-separation) / dd; distance = dd - limit_max; }
+        }
+        if (distance <= EPS) return;  // nothing was modified
+        T w1 = positional_w(max_element(b1.inv_mass), b1.I, world_r1, dir);
+        T w2 = positional_w(max_element(b2.inv_mass), b2.I, world_r2, dir);
+        T delta_lagrange = compute_lagrange_update<T>(T(0), distance, w1, w2, c0, dt);
+        V3<T> impulse = delta_lagrange * dir;
+        d.lag = d.lag + impulse;
+        apply_positional_impulse(b1, b2, impulse, world_r1, world_r2);
+    } else if (type == AVN_JOINT_FIXED) {
+        fixed_angle_solve(d, quat<T>(w.j_s0[j]), b1, b2, c1, dt);
+        point_constraint_solve(d, b1, b2, c0, dt);
+    } else if (type == AVN_JOINT_REVOLUTE) {
+        V3<T> sa1 = xyz<T>(w.j_s0[j]), sa2 = xyz<T>(w.j_s1[j]);
+        {
+            V3<T> a1 = qrot(b1.dq, sa1), a2 = qrot(b2.dq, sa2);
+            d.rl0 = d.rl0 + align_orientation(b1, b2, cross(a1, a2), T(0), c1, dt);
+        }
+        if (limits & AVN_JOINT_HAS_LIMIT1) {
+            V3<T> a1 = qrot(b1.dq, sa1), bb1 = qrot(b1.dq, xyz<T>(w.j_s2[j])), bb2 = qrot(b2.dq, xyz<T>(w.j_s3[j]));
+            V3<T> correction;
+            if (angle_limit_correction(limit_min, limit_max, a1, bb1, bb2, PI, correction))
+                d.rl1 = d.rl1 + align_orientation(b1, b2, correction, T(0), c2, dt);
+        }
+        point_constraint_solve(d, b1, b2, c0, dt);
+    } else if (type == AVN_JOINT_SPHERICAL) {
+        point_constraint_solve(d, b1, b2, c0, dt);
+        V3<T> sw1 = xyz<T>(w.j_s0[j]), sw2 = xyz<T>(w.j_s1[j]);
+        if (limits & AVN_JOINT_HAS_LIMIT1) {  // apply_swing_limits
+            V3<T> a1 = qrot(b1.dq, sw1), a2 = qrot(b2.dq, sw2);
+            V3<T> n = cross(a1, a2);
+            T n_magnitude = length(n);
+            if (!(n_magnitude <= EPS)) {
+                n = n / n_magnitude;
+                V3<T> correction;
+                if (angle_limit_correction(limit_min, limit_max, n, a1, a2, PI, correction))
+                    d.rl0 = d.rl0 + align_orientation(b1, b2, correction, T(0), c1, dt);
+            }
+        }
+        if (limits & AVN_JOINT_HAS_LIMIT2) {  // apply_twist_limits (every early `return` there only skips the rest of this block)
+            V3<T> a1 = qrot(b1.dq, sw1), a2 = qrot(b2.dq, sw2);
+            V3<T> n = a1 + a2;
+            T n_magnitude = length(n);
+            if (!(n_magnitude <= EPS)) {
+                V3<T> tb1 = qrot(b1.dq, xyz<T>(w.j_s2[j])), tb2 = qrot(b2.dq, xyz<T>(w.j_s3[j]));
+                n = n / n_magnitude;
+                V3<T> n1 = tb1 - dot(n, tb1) * n, n2 = tb2 - dot(n, tb2) * n;
+                T n1_magnitude = length(n1), n2_magnitude = length(n2);
+                if (!(n1_magnitude <= EPS || n2_magnitude <= EPS)) {
+                    n1 = n1 / n1_magnitude; n2 = n2 / n2_magnitude;
+                    T max_correction = dot(a1, a2) > T(-0.5) ? T(2) * PI : dt;
+                    Vec4<T> l2 = w.j_l2[j];
+                    V3<T> correction;
+                    if (angle_limit_correction(l2.x, l2.y, n, n1, n2, max_correction, correction))
+                        d.rl1 = d.rl1 + align_orientation(b1, b2, correction, T(0), c2, dt);
+                }
+            }
+        }
+    } else {  // AVN_JOINT_PRISMATIC
+        fixed_angle_solve(d, quat<T>(w.j_s0[j]), b1, b2, c1, dt);
+        V3<T> world_r1 = qrot(b1.dq, d.r1), world_r2 = qrot(b2.dq, d.r2);
+        V3<T> delta_x = vzero<T>();
+        V3<T> axis1 = qrot(b1.dq, xyz<T>(w.j_s1[j]));
+        V3<T> separation = ((b2.dp - b1.dp) + (world_r2 - world_r1)) + d.cd;
+        if (limits & AVN_JOINT_HAS_LIMIT1) delta_x = delta_x + correction_along_axis(limit_min, limit_max, separation, axis1);
+        V3<T> axis2 = any_orthogonal_vector(axis1);
+        V3<T> axis3 = cross(axis1, axis2);
+        delta_x = delta_x + correction_along_axis(T(0), T(0), separation, axis2);  // DistanceLimit::ZERO
+        delta_x = delta_x + correction_along_axis(T(0), T(0), separation, axis3);
+        T magnitude = length(delta_x);
+        if (!(magnitude <= EPS)) {
+            V3<T> dir = delta_x / magnitude;
+            T w1 = positional_w(max_element(b1.inv_mass), b1.I, world_r1, dir);
+            T w2 = positional_w(max_element(b2.inv_mass), b2.I, world_r2, dir);
+            T delta_lagrange = compute_lagrange_update<T>(T(0), magnitude, w1, w2, c0, dt);
+            V3<T> impulse = delta_lagrange * dir;
+            d.lag = d.lag + impulse;
+            apply_positional_impulse(b1, b2, impulse, world_r1, world_r2);
+        }
     }
-    if (distance <= Limits<T>::eps) return;
-    V3<T> rc1 = cross(world_r1, dir);
-    T w1 = max_element(b1.inv_mass) + dot(rc1, smul(b1.I, rc1));
-    V3<T> rc2 = cross(world_r2, dir);
-    T w2 = max_element(b2.inv_mass) + dot(rc2, smul(b2.I, rc2));
-    // compute_lagrange_update(lagrange = 0, c = distance, [w1, w2], compliance, dt)
-    T w_sum = T(0) + w1 + w2;
-    T delta_lagrange = T(0);
-    if (!(w_sum <= Limits<T>::eps)) {
-        T dt = p.h_adj;
-        T tilde_compliance = compliance / (dt * dt);
-        delta_lagrange = (-distance - tilde_compliance * T(0)) / (w_sum + tilde_compliance);
-    }
-    V3<T> impulse = delta_lagrange * dir;
-    Vec4<T> lag = w.j_lag[j];
-    w.j_lag[j] = make4<T>(xyz<T>(lag) + impulse, lag.w);
-    // apply_positional_impulse
-    b1.dp = b1.dp + cmul(impulse, b1.inv_mass);
-    b1.dq = qmul(from_scaled_axis(smul(b1.I, cross(world_r1, impulse))), b1.dq);
-    b2.dp = b2.dp - cmul(impulse, b2.inv_mass);
-    b2.dq = qmul(from_scaled_axis(smul(b2.I, cross(world_r2, -impulse))), b2.dq);
+    w.j_lag[j] = make4<T>(d.lag, 0);
+    if (angular) { w.j_rl0[j] = make4<T>(d.rl0, 0); w.j_rl1[j] = make4<T>(d.rl1, 0); }
     if (!nobody1) { w.sb_dp[b.x] = make4<T>(b1.dp, b1.dp_w); w.sb_dq[b.x] = make4<T>(b1.dq); }
     if (!nobody2) { w.sb_dp[b.y] = make4<T>(b2.dp, b2.dp_w); w.sb_dq[b.y] = make4<T>(b2.dq); }
 }
@@ -115,9 +299,11 @@ template <class T> __device__ __forceinline__ void joint_damping_one(const DW<T>
     T delta_secs = p.h_adj;
     // Missing bodies use the two DUMMY SolverBodies that the reference declares OUTSIDE its joint loop
     // (solver/plugin.rs:766-767): they are shared by all joints and their angular velocity is mutated, so they
-    // live in two virtual body slots (n_bodies, n_bodies + 1) that the host resets before every launch and that
-    // the damping schedule treats as ordinary bodies (=> joints touching them are serialised, as in the reference).
-    int i1 = nobody1 ? (int)w.n_bodies : b.x, i2 = nobody2 ? (int)w.n_bodies + 1 : b.y;
+    // live in virtual body slots behind the real bodies that the host resets before every launch and that the damping
+    // schedule treats as ordinary bodies (=> joints touching them are serialised, as in the reference).  joint_damping::<T>
+    // is one system per joint type with FRESH dummies (plugin.rs:139-150): slots n_bodies + 2 * type, + 2 * type + 1.
+    uint32_t jtype = jm_type(scalar_to_bits(par.w));
+    int i1 = nobody1 ? (int)(w.n_bodies + 2u * jtype) : b.x, i2 = nobody2 ? (int)(w.n_bodies + 2u * jtype + 1u) : b.y;
     Vec4<T> l1 = w.sb_lin[i1], g1 = w.sb_ang[i1], l2 = w.sb_lin[i2], g2 = w.sb_ang[i2];
     V3<T> v1 = xyz<T>(l1), om1 = xyz<T>(g1), v2 = xyz<T>(l2), om2 = xyz<T>(g2);
     V3<T> delta_omega = (om2 - om1) * smin(par.z * delta_secs, T(1));
@@ -147,7 +333,7 @@ __global__ __launch_bounds__(JOINT_THREADS) void k_joint_schedule(DW<T> w, StepP
         uint32_t j0 = level_offsets[l], j1 = level_offsets[l + 1];
         for (uint32_t k = j0 + threadIdx.x; k < j1; k += JOINT_THREADS) {
             uint32_t j = order[k];
-            if (OP == 0) distance_joint_solve<T>(w, p, j);
+            if (OP == 0) joint_solve_one<T>(w, p, j);
             else joint_damping_one<T>(w, p, j);
         }
         __syncthreads();
@@ -161,10 +347,11 @@ __global__ __launch_bounds__(256) void k_writeback_joint_forces(DW<T> w, StepPar
     T delta_secs = p.dt_adj;
     T rhs = recip_or_zero(delta_secs * delta_secs) * p.substeps_as_scalar;
     w.j_force[j] = make4<T>(xyz<T>(w.j_lag[j]) * rhs, 0);
+    w.j_torque[j] = make4<T>((xyz<T>(w.j_rl0[j]) + xyz<T>(w.j_rl1[j])) * rhs, 0);  // total_rotation_lagrange() * rhs
 }
 
-template <class T> void launch_prepare_distance_joints(const DW<T>& w, hipStream_t s) {
-    if (w.n_joints) hipLaunchKernelGGL(k_prepare_distance_joints<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w);
+template <class T> void launch_prepare_joints(const DW<T>& w, hipStream_t s) {
+    if (w.n_joints) hipLaunchKernelGGL(k_prepare_joints<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w);
 }
 template <class T> void launch_joint_schedule(const DW<T>& w, const StepParams<T>& p, int op, uint32_t n_components,
                                               const uint32_t* comp_level_begin, const uint32_t* level_offsets, const uint32_t* order, hipStream_t s) {
@@ -177,7 +364,7 @@ template <class T> void launch_writeback_joint_forces(const DW<T>& w, const Step
 }
 
 #define INST(T)                                                                                    \
-    template void launch_prepare_distance_joints<T>(const DW<T>&, hipStream_t);                    \
+    template void launch_prepare_joints<T>(const DW<T>&, hipStream_t);                    \
     template void launch_joint_schedule<T>(const DW<T>&, const StepParams<T>&, int, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, hipStream_t); \
     template void launch_writeback_joint_forces<T>(const DW<T>&, const StepParams<T>&, hipStream_t);
 INST(float)

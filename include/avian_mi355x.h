@@ -222,12 +222,44 @@ typedef struct avn_distance_joints {
 } avn_distance_joints;
 
 typedef struct avn_joints_out {
-    void* world_r1;          /* [3J] DistanceJointSolverData */
+    void* world_r1;          /* [3J] PointConstraintShared / Distance / Prismatic solver data */
     void* world_r2;          /* [3J] */
     void* center_difference; /* [3J] */
-    void* total_lagrange;    /* [3J] */
+    void* total_lagrange;    /* [3J] XpbdConstraintSolverData::total_position_lagrange */
     void* force;             /* [3J] JointForces::force after writeback_joint_forces */
+    void* total_rotation_lagrange; /* [3J] total_rotation_lagrange (align+limit / swing+twist / angle); NULL = skip */
+    void* torque;            /* [3J] JointForces::torque; NULL = skip */
 } avn_joints_out;
+
+/* ---- all XPBD joint types (dynamics/joints/{fixed,revolute,spherical,prismatic,distance}.rs +
+ *      solver/xpbd/joints/<type>.rs).  The type ids are the reference's SOLVE ORDER (xpbd/plugin.rs:77-82): all fixed joints
+ *      in array order, then revolute, spherical, prismatic, distance.  Local frames are given resolved (JointFrame with
+ *      JointAnchor::Local / JointBasis::Local, i.e. after the reference's joint-frame system). ------------------------- */
+enum { AVN_JOINT_FIXED = 0, AVN_JOINT_REVOLUTE = 1, AVN_JOINT_SPHERICAL = 2, AVN_JOINT_PRISMATIC = 3, AVN_JOINT_DISTANCE = 4,
+       AVN_JOINT_TYPE_COUNT = 5 };
+enum { AVN_JOINT_HAS_LIMIT1 = 1, /* revolute angle_limit / spherical swing_limit / prismatic limits are Some(..) */
+       AVN_JOINT_HAS_LIMIT2 = 2  /* spherical twist_limit is Some(..) */ };
+typedef struct avn_joints {
+    uint32_t count;
+    const uint8_t* joint_type;     /* [J] AVN_JOINT_* */
+    const int32_t* body1;          /* [J] */
+    const int32_t* body2;          /* [J] */
+    const void* local_anchor1;     /* [3J] */
+    const void* local_anchor2;     /* [3J] */
+    const void* local_basis1;      /* [4J] quaternion xyzw; NULL = identity */
+    const void* local_basis2;      /* [4J] */
+    const void* axis;              /* [3J] hinge_axis (revolute, default Z) / twist_axis (spherical, Y) / slider_axis (prismatic, X) */
+    const void* limit_min;         /* [J] DistanceLimit (distance, prismatic) or AngleLimit (revolute angle, spherical swing) */
+    const void* limit_max;         /* [J] */
+    const void* limit2_min;        /* [J] spherical twist_limit; NULL = 0 */
+    const void* limit2_max;        /* [J] */
+    const uint8_t* limit_flags;    /* [J] AVN_JOINT_HAS_LIMIT*; NULL = 0 (distance joints always use their limit) */
+    const void* compliance;        /* [3J] fixed: (point, angle, -)   revolute: (point, align, limit)   spherical: (point, swing, twist)
+                                           prismatic: (align, angle, limit)   distance: (compliance, -, -) */
+    const void* damping_linear;    /* [J] JointDamping; NULL = no JointDamping component on any joint */
+    const void* damping_angular;   /* [J] */
+    const uint8_t* collision_disabled; /* [J] NULL = 0 */
+} avn_joints;
 
 /* ---- colliders for the broad phase (a24-a27).  A collider sits on its rigid body entity
  *      (no child-collider offset in this round). --------------------------------------------- */
@@ -313,6 +345,9 @@ AVN_API avn_status AVN_FN(constraints_download)(avn_world* w, const avn_constrai
 
 /* replaces the DistanceJoint queries of prepare_xpbd_joint / solve_xpbd_joint / joint_damping */
 AVN_API avn_status AVN_FN(distance_joints_upload)(avn_world* w, const avn_distance_joints* j);
+/* replaces the joint queries of prepare_xpbd_joint<T> / solve_xpbd_joint<T> / joint_damping<T> / writeback_joint_forces<T>
+ * for every T; supersedes distance_joints_upload (which is the special case joint_type = DISTANCE) */
+AVN_API avn_status AVN_FN(joints_upload)(avn_world* w, const avn_joints* j);
 AVN_API avn_status AVN_FN(joints_download)(avn_world* w, const avn_joints_out* out);
 
 /* replaces add_new_aabb_intervals (broad_phase.rs:296-315): APPENDS colliders not yet known

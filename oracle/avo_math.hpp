@@ -96,7 +96,8 @@ inline void sin_cos_det(float a, float& s, float& c) {
     float sp = ((-1.9515295891e-4f * z + 8.3321608736e-3f) * z - 1.6666654611e-1f) * z * r + r;
     float cp = ((2.443315711809948e-5f * z - 1.388731625493765e-3f) * z + 4.166664568298827e-2f) * z * z
                - 0.5f * z + 1.0f;
-    int q = (int)((long long)kf & 3);
+    float qf = kf - 4.0f * std::floor(kf * 0.25f);  // kf mod 4, exact for every finite kf (no float->int conversion: UB-free for huge arguments)
+    int q = qf == 1.0f ? 1 : qf == 2.0f ? 2 : qf == 3.0f ? 3 : 0;
     switch (q) {
         case 0: s = sp; c = cp; break;
         case 1: s = cp; c = -sp; break;
@@ -115,7 +116,8 @@ inline void sin_cos_det(double a, double& s, double& c) {
     double cp = (((((-1.13585365213876817300e-11 * z + 2.08757008419747316778e-9) * z - 2.75573141792967388112e-7) * z
                    + 2.48015872888517045348e-5) * z - 1.38888888888730564116e-3) * z + 4.16666666666665929218e-2) * z * z
                 - 0.5 * z + 1.0;
-    int q = (int)((long long)kf & 3);
+    double qf = kf - 4.0 * std::floor(kf * 0.25);
+    int q = qf == 1.0 ? 1 : qf == 2.0 ? 2 : qf == 3.0 ? 3 : 0;
     switch (q) {
         case 0: s = sp; c = cp; break;
         case 1: s = cp; c = -sp; break;
@@ -140,6 +142,39 @@ template <class S> inline Q4<S> from_scaled_axis(V3<S> v) {
     V3<S> a = axis * s;
     return {a.x, a.y, a.z, c};
 }
+// Deterministic asin for AngleLimit::compute_correction (dynamics/joints/mod.rs:437): Rust's f32/f64::asin is the platform
+// libm; this restatement fixes ONE algorithm (fdlibm e_asin.c rational R = p/q, no high/low sqrt split) so that results
+// do not depend on the host libm.  |x| > 1 -> NaN (as libm).  With use_libm_trig() the host libm is used instead.
+template <class S> inline S asin_rational(S z) {
+    S p = z * (S(1.66666666666666657415e-01) + z * (S(-3.25565818622400915405e-01) + z * (S(2.01212532134862925881e-01) +
+          z * (S(-4.00555345006794114027e-02) + z * (S(7.91534994289814532176e-04) + z * S(3.47933107596021167570e-05))))));
+    S q = S(1) + z * (S(-2.40339491173441421878e+00) + z * (S(2.02094576023350569471e+00) + z * (S(-6.88283971605453293030e-01) +
+          z * S(7.70381505559019352791e-02))));
+    return p / q;
+}
+template <class S> inline S asin_det(S x) {
+    S ax = std::fabs(x);
+    if (!(ax <= S(1))) return (x - x) / (x - x);
+    if (ax < S(0.5)) return x + x * asin_rational<S>(x * x);
+    S z = (S(1) - ax) * S(0.5);
+    S s = std::sqrt(z);
+    S r = S(1.57079632679489661923) - S(2) * (s + s * asin_rational<S>(z));
+    return x < S(0) ? -r : r;
+}
+template <class S> inline S asin_s(S x) { return use_libm_trig() ? std::asin(x) : asin_det(x); }
+// glam Quat::from_axis_angle
+template <class S> inline Q4<S> from_axis_angle(V3<S> axis, S angle) {
+    S s, c;
+    sin_cos(angle * S(0.5), s, c);
+    V3<S> v = axis * s;
+    return {v.x, v.y, v.z, c};
+}
+// glam Vec3::any_orthogonal_vector: |x| > |y| ? (-z, 0, x) : (0, z, -y)
+template <class S> inline V3<S> any_orthogonal_vector(V3<S> v) {
+    if (std::fabs(v.x) > std::fabs(v.y)) return {-v.z, S(0), v.x};
+    return {S(0), v.z, -v.y};
+}
+template <class S> inline S clamp_s(S x, S lo, S hi) { S r = x; if (r < lo) r = lo; if (r > hi) r = hi; return r; }
 // glam Quat * Quat.  f32 `Quat` is SSE2-backed on x86_64 (rtm::quat_mul association):
 //   (w_l*rhs + x_l*rhs.wzyx*[+,-,+,-]) + (y_l*rhs.zwxy*[+,+,-,-] + z_l*rhs.yxwz*[-,+,+,-])
 // f64 `DQuat` is the scalar implementation (left-to-right sums).

@@ -205,16 +205,30 @@ template <class S> inline void compute_tangent_directions(V3<S> normal, V3<S> ve
 }
 
 // ---- XPBD -------------------------------------------------------------------------------------------
-template <class S> struct DistanceJoint {
+// One struct for the five XPBD joint types (dynamics/joints/{fixed,revolute,spherical,prismatic,distance}.rs) and their
+// solver data (solver/xpbd/joints/*.rs).
+template <class S> struct Joint {
+    uint8_t type = AVN_JOINT_DISTANCE;
     int32_t body1, body2;
     V3<S> local_anchor1, local_anchor2;
-    S limit_min, limit_max, compliance;
+    Q4<S> local_basis1{0, 0, 0, 1}, local_basis2{0, 0, 0, 1};
+    V3<S> axis{0, 0, 0};               // hinge_axis / twist_axis / slider_axis
+    S limit_min = 0, limit_max = 0;    // DistanceLimit or AngleLimit (revolute angle_limit, spherical swing_limit)
+    S limit2_min = 0, limit2_max = 0;  // spherical twist_limit
+    uint8_t limit_flags = 0;           // AVN_JOINT_HAS_LIMIT*
+    S compliance = 0, compliance1 = 0, compliance2 = 0;  // see avn_joints.compliance
     bool has_damping;
     S damping_linear, damping_angular;
     bool collision_disabled;
-    // DistanceJointSolverData (xpbd/joints/distance.rs:12-21)
+    // PointConstraintShared / DistanceJointSolverData / PrismaticJointSolverData
     V3<S> world_r1{0, 0, 0}, world_r2{0, 0, 0}, center_difference{0, 0, 0}, total_lagrange{0, 0, 0};
-    V3<S> force{0, 0, 0};
+    // FixedAngleConstraintShared (fixed, prismatic)
+    Q4<S> rotation_difference{0, 0, 0, 1};
+    // RevoluteJointSolverData a1,a2,b1,b2 / SphericalJointSolverData swing_axis1,2 twist_axis1,2 / prismatic free_axis1 (in v0)
+    V3<S> v0{0, 0, 0}, v1{0, 0, 0}, v2{0, 0, 0}, v3{0, 0, 0};
+    // total_align|swing|angle lagrange, total_limit|twist lagrange
+    V3<S> total_rot0{0, 0, 0}, total_rot1{0, 0, 0};
+    V3<S> force{0, 0, 0}, torque{0, 0, 0};
 };
 // xpbd/mod.rs:393-413
 template <class S> inline S compute_lagrange_update(S lagrange, S c, S w1, S w2, S compliance, S dt) {
@@ -256,6 +270,7 @@ struct WorldBase {
     virtual avn_status impulses_download(const avn_impulses_out*) = 0;
     virtual avn_status constraints_download(const avn_constraints_out*) = 0;
     virtual avn_status distance_joints_upload(const avn_distance_joints*) = 0;
+    virtual avn_status joints_upload(const avn_joints*) = 0;
     virtual avn_status joints_download(const avn_joints_out*) = 0;
     virtual avn_status colliders_upload(const avn_colliders*) = 0;
     virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;
@@ -280,7 +295,8 @@ template <class S> struct World : WorldBase {
     std::vector<ContactManifold<S>> manifolds;
     uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1];
     std::vector<ContactConstraint<S>> color_constraints[AVN_GRAPH_COLOR_COUNT];  // GraphColor::contact_constraints
-    std::vector<DistanceJoint<S>> joints;
+    std::vector<Joint<S>> joints;
+    std::vector<uint32_t> joint_order;  // solve order: stable by type (xpbd/plugin.rs:77-82), then array (= spawn) order
     std::vector<Collider<S>> colliders;
     std::unordered_map<uint32_t, uint32_t> collider_slot;  // entity -> slot
     std::vector<AabbInterval> intervals;                    // AabbIntervals, kept sorted across frames
@@ -476,24 +492,50 @@ template <class S> struct World : WorldBase {
         if (!j || (j->count && (!j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->limit_min || !j->limit_max || !j->compliance))) {
             error = "distance_joints_upload: null array"; return AVN_ERR_BAD_ARG;
         }
+        std::vector<uint8_t> types(j->count, (uint8_t)AVN_JOINT_DISTANCE);
+        std::vector<S> comp(3 * (size_t)j->count, S(0));
+        for (size_t i = 0; i < j->count; ++i) comp[3 * i] = ((const S*)j->compliance)[i];
+        avn_joints g;
+        std::memset(&g, 0, sizeof g);
+        g.count = j->count; g.joint_type = types.data(); g.body1 = j->body1; g.body2 = j->body2;
+        g.local_anchor1 = j->local_anchor1; g.local_anchor2 = j->local_anchor2; g.limit_min = j->limit_min; g.limit_max = j->limit_max;
+        g.compliance = comp.data(); g.damping_linear = j->damping_linear; g.damping_angular = j->damping_angular;
+        g.collision_disabled = j->collision_disabled;
+        return joints_upload(&g);
+    }
+    avn_status joints_upload(const avn_joints* j) override {
+        if (!j || (j->count && (!j->joint_type || !j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->compliance))) {
+            error = "joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
         joints.resize(j->count);
         collision_disabled_bodies.clear();
         for (size_t i = 0; i < j->count; ++i) {
-            DistanceJoint<S>& o = joints[i];
-            o = DistanceJoint<S>();
+            Joint<S>& o = joints[i];
+            o = Joint<S>();
+            o.type = j->joint_type[i];
+            if (o.type >= AVN_JOINT_TYPE_COUNT) { error = "joints_upload: bad joint_type"; return AVN_ERR_BAD_ARG; }
             o.body1 = j->body1[i]; o.body2 = j->body2[i];
-            if (o.body1 < 0 || o.body2 < 0 || (size_t)o.body1 >= bodies.size() || (size_t)o.body2 >= bodies.size() || o.body1 == o.body2) { error = "distance_joints_upload: bad body index"; return AVN_ERR_BAD_ARG; }
+            if (o.body1 < 0 || o.body2 < 0 || (size_t)o.body1 >= bodies.size() || (size_t)o.body2 >= bodies.size() || o.body1 == o.body2) { error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG; }
             o.local_anchor1 = rd3(j->local_anchor1, i);
             o.local_anchor2 = rd3(j->local_anchor2, i);
-            o.limit_min = ((const S*)j->limit_min)[i];
-            o.limit_max = ((const S*)j->limit_max)[i];
-            o.compliance = ((const S*)j->compliance)[i];
+            if (j->local_basis1) { const S* q = (const S*)j->local_basis1 + 4 * i; o.local_basis1 = {q[0], q[1], q[2], q[3]}; }
+            if (j->local_basis2) { const S* q = (const S*)j->local_basis2 + 4 * i; o.local_basis2 = {q[0], q[1], q[2], q[3]}; }
+            if (j->axis) o.axis = rd3(j->axis, i);
+            else o.axis = o.type == AVN_JOINT_REVOLUTE ? V3<S>{0, 0, 1} : o.type == AVN_JOINT_SPHERICAL ? V3<S>{0, 1, 0} : V3<S>{1, 0, 0};  // DEFAULT_*_AXIS
+            o.limit_min = rd<S>(j->limit_min, i, 0); o.limit_max = rd<S>(j->limit_max, i, 0);
+            o.limit2_min = rd<S>(j->limit2_min, i, 0); o.limit2_max = rd<S>(j->limit2_max, i, 0);
+            o.limit_flags = rd<uint8_t>(j->limit_flags, i, 0);
+            const S* c = (const S*)j->compliance + 3 * i;
+            o.compliance = c[0]; o.compliance1 = c[1]; o.compliance2 = c[2];
             o.has_damping = j->damping_linear && j->damping_angular;
             o.damping_linear = rd<S>(j->damping_linear, i, 0);
             o.damping_angular = rd<S>(j->damping_angular, i, 0);
             o.collision_disabled = rd<uint8_t>(j->collision_disabled, i, 0) != 0;
             if (o.collision_disabled) collision_disabled_bodies.insert(pair_key((uint32_t)o.body1, (uint32_t)o.body2));
         }
+        joint_order.resize(j->count);
+        for (uint32_t i = 0; i < j->count; ++i) joint_order[i] = i;
+        std::stable_sort(joint_order.begin(), joint_order.end(), [&](uint32_t a, uint32_t b) { return joints[a].type < joints[b].type; });
         return AVN_OK;
     }
     avn_status joints_download(const avn_joints_out* o) override {
@@ -503,6 +545,8 @@ template <class S> struct World : WorldBase {
             wr3(o->world_r2, i, joints[i].world_r2);
             wr3(o->center_difference, i, joints[i].center_difference);
             wr3(o->total_lagrange, i, joints[i].total_lagrange);
+            wr3(o->total_rotation_lagrange, i, joints[i].total_rot0 + joints[i].total_rot1);
+            wr3(o->torque, i, joints[i].torque);
             wr3(o->force, i, joints[i].force);
         }
         return AVN_OK;
@@ -823,21 +867,211 @@ template <class S> struct World : WorldBase {
     // =============================================================================================
     //                                      XPBD (DistanceJoint)
     // =============================================================================================
-    // xpbd/plugin.rs:125-142 + xpbd/joints/distance.rs:36-59
+    // xpbd/plugin.rs:125-142 prepare_xpbd_joint<T> + the per-type prepare():
+    //   point constraint  xpbd/joints/shared/point_constraint.rs:38-53     fixed angle  shared/fixed_angle_constraint.rs:38-57
+    //   fixed fixed.rs:39-72   revolute revolute.rs:48-90   spherical spherical.rs:44-83   prismatic prismatic.rs:43-81
+    //   distance distance.rs:36-59
     void prepare_joints() {
-        for (DistanceJoint<S>& j : joints) {
-            j.total_lagrange = vzero<S>();
+        for (Joint<S>& j : joints) {
+            j.total_lagrange = vzero<S>(); j.total_rot0 = vzero<S>(); j.total_rot1 = vzero<S>();  // clear_lagrange_multipliers
             const Body<S>& b1 = bodies[j.body1];
             const Body<S>& b2 = bodies[j.body2];
             if ((b1.body_flags & AVN_BODY_DISABLED) || (b2.body_flags & AVN_BODY_DISABLED)) continue;  // Without<RigidBodyDisabled>
+            V3<S> cd = (b2.position - b1.position) + (qrot(b2.rotation, b2.center_of_mass) - qrot(b1.rotation, b1.center_of_mass));
+            if (j.type == AVN_JOINT_SPHERICAL) {
+                M3<S> rot1_mat = mat3_from_quat(b1.rotation), rot2_mat = mat3_from_quat(b2.rotation);
+                j.world_r1 = mmul(rot1_mat, j.local_anchor1 - b1.center_of_mass);
+                j.world_r2 = mmul(rot2_mat, j.local_anchor2 - b2.center_of_mass);
+                j.center_difference = cd;
+                V3<S> swing_axis = any_orthonormal_vector(j.axis);
+                j.v0 = mmul(rot1_mat, qrot(j.local_basis1, swing_axis));   // swing_axis1
+                j.v1 = mmul(rot2_mat, qrot(j.local_basis2, swing_axis));   // swing_axis2
+                j.v2 = mmul(rot1_mat, qrot(j.local_basis1, j.axis));       // twist_axis1
+                j.v3 = mmul(rot2_mat, qrot(j.local_basis2, j.axis));       // twist_axis2
+                continue;
+            }
             j.world_r1 = qrot(b1.rotation, j.local_anchor1 - b1.center_of_mass);
             j.world_r2 = qrot(b2.rotation, j.local_anchor2 - b2.center_of_mass);
-            j.center_difference = (b2.position - b1.position) + (qrot(b2.rotation, b2.center_of_mass) - qrot(b1.rotation, b1.center_of_mass));
+            j.center_difference = cd;
+            if (j.type == AVN_JOINT_FIXED || j.type == AVN_JOINT_PRISMATIC)
+                j.rotation_difference = qmul(qmul(b1.rotation, j.local_basis1), qinverse(qmul(b2.rotation, j.local_basis2)));
+            if (j.type == AVN_JOINT_PRISMATIC) j.v0 = qrot(qmul(b1.rotation, j.local_basis1), j.axis);  // free_axis1
+            if (j.type == AVN_JOINT_REVOLUTE) {
+                Q4<S> q1 = qmul(b1.rotation, j.local_basis1), q2 = qmul(b2.rotation, j.local_basis2);
+                V3<S> ortho = any_orthonormal_vector(j.axis);
+                j.v0 = qrot(q1, j.axis); j.v1 = qrot(q2, j.axis); j.v2 = qrot(q1, ortho); j.v3 = qrot(q2, ortho);  // a1, a2, b1, b2
+            }
         }
     }
     // XPBD queries use Without<RigidBodyDisabled> only (a sleeping body keeps no SolverBody anyway).
     SolverBody<S> xpbd_dummy[2];  // declared outside the joint loop in the reference (xpbd/plugin.rs:155-156)
-    // xpbd/plugin.rs:61-76 (snapshot) + :145-189 + xpbd/joints/distance.rs:61-117
+
+    struct JointCtx {  // the [body1, body2] / [inertia1, inertia2] of one solve call
+        SolverBody<S>* body1; SolverBody<S>* body2;
+        V3<S> inv_mass1, inv_mass2;
+        Sym3<S> ii1, ii2;
+    };
+    // positional_constraint.rs:10-51 apply_positional_impulse
+    static void apply_positional_impulse(JointCtx& c, V3<S> impulse, V3<S> r1, V3<S> r2) {
+        c.body1->delta_position = c.body1->delta_position + cmul(impulse, c.inv_mass1);
+        c.body1->delta_rotation = qmul(from_scaled_axis(smul(c.ii1, cross(r1, impulse))), c.body1->delta_rotation);
+        c.body2->delta_position = c.body2->delta_position - cmul(impulse, c.inv_mass2);
+        c.body2->delta_rotation = qmul(from_scaled_axis(smul(c.ii2, cross(r2, -impulse))), c.body2->delta_rotation);
+    }
+    // positional_constraint.rs:68-82 compute_generalized_inverse_mass
+    static S positional_w(S inv_mass_max, const Sym3<S>& ii, V3<S> r, V3<S> dir) {
+        V3<S> rc = cross(r, dir);
+        return inv_mass_max + dot(rc, smul(ii, rc));
+    }
+    // shared/point_constraint.rs:56-108 PointConstraintShared::solve
+    void point_constraint_solve(Joint<S>& j, JointCtx& c, S compliance, S dt) {
+        V3<S> world_r1 = qrot(c.body1->delta_rotation, j.world_r1);
+        V3<S> world_r2 = qrot(c.body2->delta_rotation, j.world_r2);
+        V3<S> separation = ((c.body2->delta_position - c.body1->delta_position) + (world_r2 - world_r1)) + j.center_difference;
+        S magnitude_squared = length_squared(separation);
+        if (magnitude_squared == S(0)) return;
+        S magnitude = std::sqrt(magnitude_squared);
+        V3<S> dir = (-separation) / magnitude;
+        S w1 = positional_w(max_element(c.inv_mass1), c.ii1, world_r1, dir);
+        S w2 = positional_w(max_element(c.inv_mass2), c.ii2, world_r2, dir);
+        S delta_lagrange = compute_lagrange_update<S>(S(0), magnitude, w1, w2, compliance, dt);
+        V3<S> impulse = delta_lagrange * dir;
+        j.total_lagrange = j.total_lagrange + impulse;
+        apply_positional_impulse(c, impulse, world_r1, world_r2);
+    }
+    // angular_constraint.rs:146-184 align_orientation (3D) with :50-93 apply_angular_lagrange_update / apply_angular_impulse
+    static V3<S> align_orientation(JointCtx& c, V3<S> rotation_difference, S lagrange, S compliance, S dt) {
+        S angle = length(rotation_difference);
+        if (angle <= std::numeric_limits<S>::epsilon()) return vzero<S>();
+        V3<S> axis = rotation_difference / angle;
+        S w1 = dot(axis, smul(c.ii1, axis)), w2 = dot(axis, smul(c.ii2, axis));
+        S delta_lagrange = compute_lagrange_update<S>(lagrange, angle, w1, w2, compliance, dt);
+        if (!(std::fabs(delta_lagrange) <= std::numeric_limits<S>::epsilon())) {
+            V3<S> impulse = (-delta_lagrange) * axis;
+            c.body1->delta_rotation = qmul(from_scaled_axis(smul(c.ii1, impulse)), c.body1->delta_rotation);
+            c.body2->delta_rotation = qmul(from_scaled_axis(smul(c.ii2, -impulse)), c.body2->delta_rotation);
+        }
+        return delta_lagrange * axis;
+    }
+    // shared/fixed_angle_constraint.rs:60-95 FixedAngleConstraintShared::solve (3D)
+    void fixed_angle_solve(Joint<S>& j, JointCtx& c, S compliance, S dt) {
+        Q4<S> q = qmul(qmul(j.rotation_difference, c.body1->delta_rotation), qinverse(c.body2->delta_rotation));
+        V3<S> difference = S(-2) * V3<S>{q.x, q.y, q.z};
+        j.total_rot0 = j.total_rot0 + align_orientation(c, difference, S(0), compliance, dt);
+    }
+    // dynamics/joints/mod.rs:427-472 AngleLimit::compute_correction (3D)
+    static bool angle_limit_correction(S lim_min, S lim_max, V3<S> limit_axis, V3<S> axis1, V3<S> axis2, S max_correction, V3<S>& out) {
+        const S PI = S(3.14159265358979323846264338327950288), TAU = S(6.28318530717958647692528676655900577);
+        S phi = asin_s(dot(cross(axis1, axis2), limit_axis));
+        if (dot(axis1, axis2) < S(0)) phi = PI - phi;
+        if (phi > PI) phi -= TAU;
+        if (phi < lim_min || phi > lim_max) {
+            phi = clamp_s(phi, lim_min, lim_max);
+            Q4<S> rot = from_axis_angle(limit_axis, phi);
+            out = clamp_length_max(cross(qrot(rot, axis1), axis2), max_correction);
+            return true;
+        }
+        return false;
+    }
+    // dynamics/joints/mod.rs:345-357 DistanceLimit::compute_correction_along_axis
+    static V3<S> correction_along_axis(S lim_min, S lim_max, V3<S> separation, V3<S> axis) {
+        S a = dot(separation, axis);
+        if (a < lim_min) return axis * (lim_min - a);
+        if (a > lim_max) return (-axis) * (a - lim_max);
+        return vzero<S>();
+    }
+    void solve_fixed(Joint<S>& j, JointCtx& c, S dt) {      // fixed.rs:74-91: angle, then point
+        fixed_angle_solve(j, c, j.compliance1, dt);
+        point_constraint_solve(j, c, j.compliance, dt);
+    }
+    void solve_revolute(Joint<S>& j, JointCtx& c, S dt) {   // revolute.rs:92-183
+        const S PI = S(3.14159265358979323846264338327950288);
+        {
+            V3<S> a1 = qrot(c.body1->delta_rotation, j.v0), a2 = qrot(c.body2->delta_rotation, j.v1);
+            j.total_rot0 = j.total_rot0 + align_orientation(c, cross(a1, a2), S(0), j.compliance1, dt);
+        }
+        if (j.limit_flags & AVN_JOINT_HAS_LIMIT1) {
+            V3<S> a1 = qrot(c.body1->delta_rotation, j.v0), b1 = qrot(c.body1->delta_rotation, j.v2), b2 = qrot(c.body2->delta_rotation, j.v3);
+            V3<S> correction;
+            if (angle_limit_correction(j.limit_min, j.limit_max, a1, b1, b2, PI, correction))
+                j.total_rot1 = j.total_rot1 + align_orientation(c, correction, S(0), j.compliance2, dt);
+        }
+        point_constraint_solve(j, c, j.compliance, dt);
+    }
+    void solve_spherical(Joint<S>& j, JointCtx& c, S dt) {  // spherical.rs:85-209
+        const S PI = S(3.14159265358979323846264338327950288), EPS = std::numeric_limits<S>::epsilon();
+        point_constraint_solve(j, c, j.compliance, dt);
+        if (j.limit_flags & AVN_JOINT_HAS_LIMIT1) {             // apply_swing_limits
+            V3<S> a1 = qrot(c.body1->delta_rotation, j.v0), a2 = qrot(c.body2->delta_rotation, j.v1);
+            V3<S> n = cross(a1, a2);
+            S n_magnitude = length(n);
+            if (!(n_magnitude <= EPS)) {
+                n = n / n_magnitude;
+                V3<S> correction;
+                if (angle_limit_correction(j.limit_min, j.limit_max, n, a1, a2, PI, correction))
+                    j.total_rot0 = j.total_rot0 + align_orientation(c, correction, S(0), j.compliance1, dt);
+            }
+        }
+        if (j.limit_flags & AVN_JOINT_HAS_LIMIT2) {             // apply_twist_limits
+            V3<S> a1 = qrot(c.body1->delta_rotation, j.v0), a2 = qrot(c.body2->delta_rotation, j.v1);
+            V3<S> n = a1 + a2;
+            S n_magnitude = length(n);
+            if (n_magnitude <= EPS) return;
+            V3<S> b1 = qrot(c.body1->delta_rotation, j.v2), b2 = qrot(c.body2->delta_rotation, j.v3);
+            n = n / n_magnitude;
+            V3<S> n1 = b1 - dot(n, b1) * n, n2 = b2 - dot(n, b2) * n;
+            S n1_magnitude = length(n1), n2_magnitude = length(n2);
+            if (n1_magnitude <= EPS || n2_magnitude <= EPS) return;
+            n1 = n1 / n1_magnitude; n2 = n2 / n2_magnitude;
+            S max_correction = dot(a1, a2) > S(-0.5) ? S(2) * PI : dt;
+            V3<S> correction;
+            if (angle_limit_correction(j.limit2_min, j.limit2_max, n, n1, n2, max_correction, correction))
+                j.total_rot1 = j.total_rot1 + align_orientation(c, correction, S(0), j.compliance2, dt);
+        }
+    }
+    void solve_prismatic(Joint<S>& j, JointCtx& c, S dt) {  // prismatic.rs:83-192
+        fixed_angle_solve(j, c, j.compliance1, dt);
+        V3<S> world_r1 = qrot(c.body1->delta_rotation, j.world_r1);
+        V3<S> world_r2 = qrot(c.body2->delta_rotation, j.world_r2);
+        V3<S> delta_x = vzero<S>();
+        V3<S> axis1 = qrot(c.body1->delta_rotation, j.v0);
+        V3<S> separation = ((c.body2->delta_position - c.body1->delta_position) + (world_r2 - world_r1)) + j.center_difference;
+        if (j.limit_flags & AVN_JOINT_HAS_LIMIT1) delta_x = delta_x + correction_along_axis(j.limit_min, j.limit_max, separation, axis1);
+        V3<S> axis2 = any_orthogonal_vector(axis1);
+        V3<S> axis3 = cross(axis1, axis2);
+        delta_x = delta_x + correction_along_axis(S(0), S(0), separation, axis2);   // DistanceLimit::ZERO
+        delta_x = delta_x + correction_along_axis(S(0), S(0), separation, axis3);
+        S magnitude = length(delta_x);
+        if (magnitude <= std::numeric_limits<S>::epsilon()) return;
+        V3<S> dir = delta_x / magnitude;
+        S w1 = positional_w(max_element(c.inv_mass1), c.ii1, world_r1, dir);
+        S w2 = positional_w(max_element(c.inv_mass2), c.ii2, world_r2, dir);
+        S delta_lagrange = compute_lagrange_update<S>(S(0), magnitude, w1, w2, j.compliance, dt);
+        V3<S> impulse = delta_lagrange * dir;
+        j.total_lagrange = j.total_lagrange + impulse;
+        apply_positional_impulse(c, impulse, world_r1, world_r2);
+    }
+    void solve_distance(Joint<S>& j, JointCtx& c, S dt) {   // distance.rs:61-117
+        V3<S> world_r1 = qrot(c.body1->delta_rotation, j.world_r1);
+        V3<S> world_r2 = qrot(c.body2->delta_rotation, j.world_r2);
+        V3<S> separation = ((c.body2->delta_position - c.body1->delta_position) + (world_r2 - world_r1)) + j.center_difference;
+        // DistanceLimit::compute_correction, dynamics/joints/mod.rs:321-340
+        V3<S> dir = vzero<S>(); S distance = 0;
+        S dsq = length_squared(separation);
+        if (!(dsq <= std::numeric_limits<S>::epsilon())) {
+            S d = std::sqrt(dsq);
+            if (d < j.limit_min) { dir = separation / d; distance = j.limit_min - d; }
+            else if (d > j.limit_max) { dir = (-separation) / d; distance = d - j.limit_max; }
+        }
+        if (distance <= std::numeric_limits<S>::epsilon()) return;
+        S w1 = positional_w(max_element(c.inv_mass1), c.ii1, world_r1, dir);
+        S w2 = positional_w(max_element(c.inv_mass2), c.ii2, world_r2, dir);
+        S delta_lagrange = compute_lagrange_update<S>(S(0), distance, w1, w2, j.compliance, dt);
+        V3<S> impulse = delta_lagrange * dir;
+        j.total_lagrange = j.total_lagrange + impulse;
+        apply_positional_impulse(c, impulse, world_r1, world_r2);
+    }
+    // xpbd/plugin.rs:61-76 (snapshot) + :145-189 solve_xpbd_joint<T> for T in the order of :77-82
     void xpbd_solve() {
         for (Body<S>& b : bodies) {
             if (!b.has_solver_body) continue;
@@ -846,8 +1080,10 @@ template <class S> struct World : WorldBase {
         }
         S dt = h_adj;
         static const SolverBodyInertia<S> DUMMY;
-        xpbd_dummy[0] = SolverBody<S>(); xpbd_dummy[1] = SolverBody<S>();
-        for (DistanceJoint<S>& j : joints) {
+        int cur_type = -1;
+        for (uint32_t idx : joint_order) {
+            Joint<S>& j = joints[idx];
+            if ((int)j.type != cur_type) { cur_type = j.type; xpbd_dummy[0] = SolverBody<S>(); xpbd_dummy[1] = SolverBody<S>(); }  // one system per type
             Body<S>& B1 = bodies[j.body1]; Body<S>& B2 = bodies[j.body2];
             SolverBody<S>* body1 = &xpbd_dummy[0]; SolverBody<S>* body2 = &xpbd_dummy[1];
             const SolverBodyInertia<S>* inertia1 = &DUMMY; const SolverBodyInertia<S>* inertia2 = &DUMMY;
@@ -855,31 +1091,14 @@ template <class S> struct World : WorldBase {
             if (B2.has_solver_body) { body2 = &B2.sb; inertia2 = &B2.si; }
             int rel = (int)inertia1->dominance - (int)inertia2->dominance;
             if (rel > 0) inertia1 = &DUMMY; else if (rel < 0) inertia2 = &DUMMY;
-            V3<S> inv_mass1 = inertia1->effective_inv_mass(), inv_mass2 = inertia2->effective_inv_mass();
-            const Sym3<S>& ii1 = inertia1->inv_inertia; const Sym3<S>& ii2 = inertia2->inv_inertia;
-            V3<S> world_r1 = qrot(body1->delta_rotation, j.world_r1);
-            V3<S> world_r2 = qrot(body2->delta_rotation, j.world_r2);
-            V3<S> separation = ((body2->delta_position - body1->delta_position) + (world_r2 - world_r1)) + j.center_difference;
-            // DistanceLimit::compute_correction, dynamics/joints/mod.rs:321-340
-            V3<S> dir = vzero<S>(); S distance = 0;
-            S dsq = length_squared(separation);
-            if (!(dsq <= std::numeric_limits<S>::epsilon())) {
-                S d = std::sqrt(dsq);
-                if (d < j.limit_min) { dir = separation / d; distance = j.limit_min - d; }
-                else if (d > j.limit_max) { dir = (-separation) / d; distance = d - j.limit_max; }
+            JointCtx c{body1, body2, inertia1->effective_inv_mass(), inertia2->effective_inv_mass(), inertia1->inv_inertia, inertia2->inv_inertia};
+            switch (j.type) {
+                case AVN_JOINT_FIXED: solve_fixed(j, c, dt); break;
+                case AVN_JOINT_REVOLUTE: solve_revolute(j, c, dt); break;
+                case AVN_JOINT_SPHERICAL: solve_spherical(j, c, dt); break;
+                case AVN_JOINT_PRISMATIC: solve_prismatic(j, c, dt); break;
+                default: solve_distance(j, c, dt); break;
             }
-            if (distance <= std::numeric_limits<S>::epsilon()) continue;
-            // compute_generalized_inverse_mass, positional_constraint.rs:68-82
-            V3<S> rc1 = cross(world_r1, dir); S w1 = max_element(inv_mass1) + dot(rc1, smul(ii1, rc1));
-            V3<S> rc2 = cross(world_r2, dir); S w2 = max_element(inv_mass2) + dot(rc2, smul(ii2, rc2));
-            S delta_lagrange = compute_lagrange_update<S>(S(0), distance, w1, w2, j.compliance, dt);
-            V3<S> impulse = delta_lagrange * dir;
-            j.total_lagrange = j.total_lagrange + impulse;
-            // apply_positional_impulse, positional_constraint.rs:10-51
-            body1->delta_position = body1->delta_position + cmul(impulse, inv_mass1);
-            body1->delta_rotation = qmul(from_scaled_axis(smul(ii1, cross(world_r1, impulse))), body1->delta_rotation);
-            body2->delta_position = body2->delta_position - cmul(impulse, inv_mass2);
-            body2->delta_rotation = qmul(from_scaled_axis(smul(ii2, cross(world_r2, -impulse))), body2->delta_rotation);
         }
     }
     // xpbd/plugin.rs:192-240 (RigidBodyActiveFilter; runs over ALL active solver bodies)
@@ -903,7 +1122,10 @@ template <class S> struct World : WorldBase {
         S delta_secs = h_adj;
         static const SolverBodyInertia<S> DUMMY;
         SolverBody<S> d1, d2;
-        for (DistanceJoint<S>& j : joints) {
+        int cur_type = -1;
+        for (uint32_t idx : joint_order) {   // joint_damping::<T> for T in type order (solver/plugin.rs:139-150), fresh DUMMYs per system
+            Joint<S>& j = joints[idx];
+            if ((int)j.type != cur_type) { cur_type = j.type; d1 = SolverBody<S>(); d2 = SolverBody<S>(); }
             if (!j.has_damping) continue;
             Body<S>& B1 = bodies[j.body1]; Body<S>& B2 = bodies[j.body2];
             SolverBody<S>* body1 = &d1; SolverBody<S>* body2 = &d2;
@@ -924,7 +1146,7 @@ template <class S> struct World : WorldBase {
     void writeback_joint_forces() {
         S delta_secs = dt_adj;  // Time is Time<Physics> again after the substep loop (solver/schedule.rs:209-212)
         S rhs = recip_or_zero(delta_secs * delta_secs) * (S)cfg.substeps;
-        for (DistanceJoint<S>& j : joints) j.force = j.total_lagrange * rhs;
+        for (Joint<S>& j : joints) { j.force = j.total_lagrange * rhs; j.torque = (j.total_rot0 + j.total_rot1) * rhs; }
     }
 
     // =============================================================================================

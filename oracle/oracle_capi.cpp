@@ -35,6 +35,7 @@ avn_status avo_manifolds_upload(avn_world* w, const avn_manifolds* m) { FWD(mani
 avn_status avo_impulses_download(avn_world* w, const avn_impulses_out* o) { FWD(impulses_download(o)); }
 avn_status avo_constraints_download(avn_world* w, const avn_constraints_out* o) { FWD(constraints_download(o)); }
 avn_status avo_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { FWD(distance_joints_upload(j)); }
+avn_status avo_joints_upload(avn_world* w, const avn_joints* j) { FWD(joints_upload(j)); }
 avn_status avo_joints_download(avn_world* w, const avn_joints_out* o) { FWD(joints_download(o)); }
 avn_status avo_colliders_upload(avn_world* w, const avn_colliders* c) { FWD(colliders_upload(c)); }
 avn_status avo_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { FWD(existing_pairs_upload(k, n)); }
@@ -142,4 +143,6 @@ avn_status avo_constraint_graph_lists(const avn_constraint_graph* g, uint32_t* o
 void avo_use_libm_trig(int on) { avo::use_libm_trig() = on != 0; }
 void avo_sin_cos_f32(float a, float* s, float* c) { avo::sin_cos_det(a, *s, *c); }
 void avo_sin_cos_f64(double a, double* s, double* c) { avo::sin_cos_det(a, *s, *c); }
+float avo_asin_f32(float x) { return avo::asin_det(x); }
+double avo_asin_f64(double x) { return avo::asin_det(x); }
 }

@@ -14,7 +14,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from helpers import F, color_and_upload, oracle_lib, random_world  # noqa: E402
+from helpers import F, color_and_upload, oracle_lib, random_joints, random_world  # noqa: E402
 
 from avian_amd import scenes  # noqa: E402
 
@@ -27,6 +27,21 @@ def solver_case(bits, seed):
         w.step()
     out = {}
     for name, d in (("bodies", w.bodies_download()), ("impulses", w.impulses_download()), ("joints", w.joints_download())):
+        for k, v in d.items():
+            out[f"{name}.{k}"] = v
+    return out
+
+
+def joints_case(bits):
+    """All five XPBD joint types (fixed / revolute / spherical / prismatic / distance) + contacts, 2 steps."""
+    wd = random_world(seed=77, n_bodies=80, n_manifolds=150, n_joints=0)
+    wd["joints_generic"] = random_joints(np.random.default_rng(77), 80, 90)
+    w = F.World(oracle_lib(), F.default_config(bits, substeps=3))
+    color_and_upload(w, oracle_lib(), wd)
+    for _ in range(2):
+        w.step()
+    out = {}
+    for name, d in (("gj.bodies", w.bodies_download()), ("gj.joints", w.joints_download())):
         for k, v in d.items():
             out[f"{name}.{k}"] = v
     return out
@@ -51,6 +66,7 @@ def main():
         out = {}
         out.update(solver_case(bits, seed=2026))
         out.update(broadphase_case(bits))
+        out.update(joints_case(bits))
         path = os.path.join(HERE, f"oracle_vectors_f{bits}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path), "bytes", len(out), "arrays")

@@ -8,7 +8,7 @@ import os
 
 import numpy as np
 
-from helpers import F, color_and_upload, random_world
+from helpers import F, color_and_upload, random_joints, random_world
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -78,6 +78,23 @@ def solver_vectors(lib, bits, graph_lib, **cfgkw):
     w.synchronize()
     out = {}
     for name, d in (("bodies", w.bodies_download()), ("impulses", w.impulses_download()), ("joints", w.joints_download())):
+        for k, v in d.items():
+            out[f"{name}.{k}"] = v
+    w.close()
+    return out
+
+
+def joints_vectors(lib, bits, graph_lib, **cfgkw):
+    """The exact procedure of golden/make_oracle_vectors.py:joints_case, against `lib`."""
+    wd = random_world(seed=77, n_bodies=80, n_manifolds=150, n_joints=0)
+    wd["joints_generic"] = random_joints(np.random.default_rng(77), 80, 90)
+    w = F.World(lib, F.default_config(bits, substeps=3, **cfgkw))
+    color_and_upload(w, graph_lib, wd)
+    for _ in range(2):
+        w.step()
+    w.synchronize()
+    out = {}
+    for name, d in (("gj.bodies", w.bodies_download()), ("gj.joints", w.joints_download())):
         for k, v in d.items():
             out[f"{name}.{k}"] = v
     w.close()

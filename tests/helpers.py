@@ -135,6 +135,30 @@ def random_world(seed=0, n_bodies=200, n_manifolds=600, n_joints=0, n_static=5, 
                 joints=joints)
 
 
+def random_joints(rng, n_bodies, n_joints, with_damping=True):
+    """Random joints of ALL five XPBD types (avn_joints arrays): random frames, axes, limits (some absent), compliances.
+    Like random_world the configuration is not physically consistent on purpose — every branch of every solve() runs."""
+    J = n_joints
+    jb1 = rng.integers(0, n_bodies, J)
+    jb2 = (jb1 + 1 + rng.integers(0, n_bodies - 1, J)) % n_bodies
+    jt = rng.integers(0, 5, J).astype(np.uint8)
+    axis = rng.normal(size=(J, 3)); axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    axis[rng.random(J) < 0.2] = [0.0, 0.0, 1.0]; axis[rng.random(J) < 0.1] = [0.0, 1.0, 0.0]; axis[rng.random(J) < 0.1] = [1.0, 0.0, 0.0]
+    lo = np.where(jt == F.JOINT_DISTANCE, rng.uniform(0.0, 2.0, J), np.where(jt == F.JOINT_PRISMATIC, rng.uniform(-1.0, 0.2, J), rng.uniform(-2.0, 0.5, J)))
+    hi = lo + np.where(jt == F.JOINT_DISTANCE, rng.uniform(0.0, 1.0, J), rng.uniform(0.0, 1.5, J))
+    lo2 = rng.uniform(-2.5, 0.2, J); hi2 = lo2 + rng.uniform(0.0, 2.0, J)
+    flags = rng.integers(0, 4, J).astype(np.uint8)
+    comp = np.where(rng.random((J, 3)) < 0.5, 0.0, rng.uniform(0, 1e-3, (J, 3)))
+    out = dict(joint_type=jt, body1=jb1.astype(np.int32), body2=jb2.astype(np.int32),
+               local_anchor1=rng.normal(scale=0.3, size=(J, 3)), local_anchor2=rng.normal(scale=0.3, size=(J, 3)),
+               local_basis1=random_unit_quats(rng, J), local_basis2=random_unit_quats(rng, J), axis=axis,
+               limit_min=lo, limit_max=hi, limit2_min=lo2, limit2_max=hi2, limit_flags=flags, compliance=comp,
+               collision_disabled=(rng.random(J) < 0.2).astype(np.uint8))
+    if with_damping:
+        out["damping_linear"] = rng.uniform(0, 3, J); out["damping_angular"] = rng.uniform(0, 3, J)
+    return out
+
+
 def color_and_upload(world: F.World, lib_for_graph: F.Library, wd: dict):
     """Colour the manifolds (persistent greedy, in manifold order) and upload everything to `world`.
     Returns the colour-major permutation so that results can be mapped back."""
@@ -145,7 +169,9 @@ def color_and_upload(world: F.World, lib_for_graph: F.Library, wd: dict):
     pm = scenes.permute_manifolds(mf, perm)
     scenes.upload_manifolds(world, pm, offsets, wd["friction"][perm], wd["restitution"][perm],
                             warm_n=wd["warm_n"][perm], warm_t=wd["warm_t"][perm])
-    if wd.get("joints"):
+    if wd.get("joints_generic"):
+        world.joints_upload(**wd["joints_generic"])
+    elif wd.get("joints"):
         world.distance_joints_upload(**wd["joints"])
     return offsets, perm
 

@@ -20,7 +20,8 @@ def test_hip_meets_reference_kat(case, bits):
 def test_hip_matches_frozen_vectors(bits, use_graph):
     got = G.solver_vectors(hip_lib(), bits, hip_lib(), use_graph=use_graph)   # product colouring, product solver
     got.update(G.broadphase_vectors(hip_lib(), bits))
-    assert G.check_vectors(got, bits) == 16
+    got.update(G.joints_vectors(hip_lib(), bits, hip_lib(), use_graph=use_graph))
+    assert G.check_vectors(got, bits) == 27
 
 
 def test_hip_is_deterministic_run_to_run():

@@ -8,7 +8,7 @@ div/sqrt, one shared deterministic sin/cos algorithm), the dynamics are in fact 
 import numpy as np
 import pytest
 
-from helpers import F, assert_same, color_and_upload, compare_dicts, hip_lib, oracle_lib, random_world
+from helpers import F, assert_same, color_and_upload, compare_dicts, hip_lib, oracle_lib, random_joints, random_world
 
 pytestmark = pytest.mark.gpu
 TOL = 0.0  # bit-exact
@@ -64,6 +64,33 @@ def test_multi_step_matches_oracle(bits, use_graph):
         wh.synchronize()
         compare_all(wo, wh, f"step {s}", joints=True)
     assert wh.timers().kernel_launches > 0
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_all_joint_types_match_oracle_system_by_system(bits, seed):
+    """Fixed / revolute / spherical / prismatic / distance joints with random frames, axes, limits and compliances
+    (SURVEY.md §8 row a23), plus contacts: every system of the schedule compared bit for bit, then whole steps."""
+    wd = random_world(seed=100 + seed, n_bodies=260, n_manifolds=500, n_joints=0, hub_degree=0)
+    wd["joints_generic"] = random_joints(np.random.default_rng(seed), 260, 240, with_damping=(seed != 1))
+    wo, wh = make_pair(bits, substeps=3)
+    color_and_upload(wo, oracle_lib(), wd)
+    color_and_upload(wh, oracle_lib(), wd)
+    order = ["PREPARE_SOLVER_BODIES", "PREPARE_JOINTS", "PREPARE_CONTACT_CONSTRAINTS", "PRE_PROCESS_VELOCITY_INCREMENTS"]
+    order += SUBSTEP_SYSTEMS * 3
+    order += ["CLEAR_VELOCITY_INCREMENTS", "SOLVE_RESTITUTION", "WRITEBACK_SOLVER_BODIES", "STORE_CONTACT_IMPULSES"]
+    for k, name in enumerate(order):
+        wo.run_system(name)
+        wh.run_system(name)
+        compare_all(wo, wh, f"after[{k}] {name}", joints=True)
+    jd = wh.joints_download()
+    jt = wd["joints_generic"]["joint_type"]
+    for t in range(5):   # every type did real work
+        assert float(np.abs(jd["total_lagrange"][jt == t]).max()) > 0.0, f"joint type {t} never produced a position impulse"
+    assert float(np.abs(jd["total_rotation_lagrange"][jt != F.JOINT_DISTANCE]).max()) > 0.0 and float(np.abs(jd["torque"]).max()) > 0.0
+    for s_ in range(2):   # (the inconsistent random joint configuration gains ~1000x velocity per step: stop before overflow)
+        wo.step(); wh.step()
+        compare_all(wo, wh, f"step {s_}", joints=True)
 
 
 def test_solver_iterations_extension_matches_oracle():
