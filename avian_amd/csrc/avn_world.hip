@@ -120,6 +120,7 @@ template <class T> struct World : WorldBase {
     bool joint_schedule_dirty = true;
     JointSchedule sched_solve, sched_damp;
     bool any_damped = false;
+    bool any_restitution = false;  // some manifold has restitution != 0 (else apply_restitution early-outs for all, contact/mod.rs:366-369)
     std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
     uint32_t n_pair_keys = 0;           // keys currently in the device pair set
     std::vector<avn_pair> h_pairs;
@@ -142,6 +143,8 @@ template <class T> struct World : WorldBase {
         if (stream) (void)hipStreamSynchronize(stream);
         drop_graph();
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (ev_counters) (void)hipEventDestroy(ev_counters);
+        if (h_counters) (void)hipHostFree(h_counters);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void bind() override { (void)hipSetDevice(cfg.device); }
@@ -373,6 +376,8 @@ template <class T> struct World : WorldBase {
             if (m->body1[i] < 0 || m->body2[i] < 0 || (uint32_t)m->body1[i] >= dw.n_bodies || (uint32_t)m->body2[i] >= dw.n_bodies) { error = "manifolds_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
             if (m->point_count[i] > AVN_MAX_MANIFOLD_POINTS) { error = "manifolds_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
         }
+        any_restitution = false;
+        for (uint32_t i = 0; i < M && !any_restitution; ++i) any_restitution = !(((const T*)m->restitution)[i] == T(0));
         bool moved = false;
         if (M > cap_manifolds) {
             HIPCHK(hipStreamSynchronize(stream));
@@ -782,12 +787,25 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
-    avn_status collect_collision_pairs() {
+    // COLLECT_COLLISION_PAIRS is split in two so that avn_step can overlap the host round trip of the pair count with the
+    // solver launches: collect_launch() enqueues sort + ranges + count pass + scan and an async read-back of the counters
+    // into pinned memory (event-tracked); collect_finish() waits for THAT copy only, and runs the emit pass when new pairs exist.
+    uint32_t* h_counters = nullptr;  // pinned: [dropped, unsorted, total, long chunks, long overflow]
+    hipEvent_t ev_counters = nullptr;
+    uint32_t collect_n = 0;
+    bool collect_pending = false;
+    avn_status collect_launch() {
         uint32_t n = bp.n_intervals;
         h_pairs.clear();
         last_timers.pair_count = 0;
+        collect_n = n;
+        collect_pending = false;
         if (n == 0) return AVN_OK;
         if (n > (1u << 26)) { error = "collect_collision_pairs: more than 2^26 intervals"; return AVN_ERR_CAPACITY; }
+        if (!h_counters) {
+            HIPCHK(hipHostMalloc((void**)&h_counters, 8 * sizeof(uint32_t), hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ev_counters, hipEventDisableTiming));
+        }
         uint32_t* misc = b_misc.as<uint32_t>();
         uint32_t* d_dropped = misc + 33;   // [33] dropped, [34] unsorted
         uint32_t* d_total = misc + 35;
@@ -802,11 +820,18 @@ template <class T> struct World : WorldBase {
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, stream);
         launches += 3 + 5 * (uint32_t)sizeof(Key) + 3 + 3;
         HIPCHK(hipGetLastError());
-        uint32_t rb[5] = {0, 0, 0, 0, 0};
-        HIPCHK(hipMemcpyAsync(rb, d_dropped, sizeof rb, hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipStreamSynchronize(stream));
-        uint32_t dropped = rb[0], total = rb[2];
-        if (rb[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+        HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipEventRecord(ev_counters, stream));
+        collect_pending = true;
+        return AVN_OK;
+    }
+    avn_status collect_finish() {
+        if (!collect_pending) return AVN_OK;
+        collect_pending = false;
+        uint32_t n = collect_n;
+        HIPCHK(hipEventSynchronize(ev_counters));
+        uint32_t dropped = h_counters[0], total = h_counters[2];
+        if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
         if (total) {
             hipError_t err;
             b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
@@ -830,6 +855,11 @@ template <class T> struct World : WorldBase {
         bp.n_intervals = n - dropped;  // dropped intervals were sorted to the end
         last_timers.pair_count = total;
         return AVN_OK;
+    }
+    avn_status collect_collision_pairs() {
+        avn_status st = collect_launch();
+        if (st != AVN_OK) return st;
+        return collect_finish();
     }
 
     // ---- systems -------------------------------------------------------------------------------------------
@@ -906,7 +936,7 @@ template <class T> struct World : WorldBase {
         if ((st = run_substeps()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[3], stream));
         launch_clear_increments<T>(dw, stream); ++launches;
-        contact_pass(PASS_RESTITUTION_);
+        if (any_restitution) contact_pass(PASS_RESTITUTION_);  // restitution == 0 everywhere: every manifold would early-out
         launch_writeback_solver_bodies<T>(dw, stream); ++launches;
         if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
         launch_store_contact_impulses<T>(dw, stream); ++launches;
@@ -931,7 +961,7 @@ template <class T> struct World : WorldBase {
             case AVN_SYS_XPBD_VELOCITY_PROJECTION: xpbd_velocity_projection(); break;
             case AVN_SYS_JOINT_DAMPING: joint_damping(); break;
             case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: launch_clear_increments<T>(dw, stream); ++launches; break;
-            case AVN_SYS_SOLVE_RESTITUTION: contact_pass(PASS_RESTITUTION_); break;
+            case AVN_SYS_SOLVE_RESTITUTION: if (any_restitution) contact_pass(PASS_RESTITUTION_); break;
             case AVN_SYS_WRITEBACK_SOLVER_BODIES:
                 launch_writeback_solver_bodies<T>(dw, stream); ++launches;
                 if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
@@ -985,11 +1015,12 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventRecord(ev[0], stream));
         if (have_colliders) {
             if ((st = update_aabb()) != AVN_OK) return st;
-            if ((st = collect_collision_pairs()) != AVN_OK) return st;
+            if ((st = collect_launch()) != AVN_OK) return st;
         }
         HIPCHK(hipEventRecord(ev[1], stream));
-        if ((st = solver()) != AVN_OK) return st;
+        if ((st = solver()) != AVN_OK) return st;   // enqueued while the pair counters travel back
         HIPCHK(hipEventRecord(ev[4], stream));
+        if ((st = collect_finish()) != AVN_OK) return st;  // (emit pass only when the step found new pairs)
         ev_valid = true;
         last_timers.kernel_launches = launches;
         return AVN_OK;
