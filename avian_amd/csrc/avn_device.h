@@ -105,6 +105,10 @@ template <class T> struct DW {
     int16_t* c_reldom;  // inspection only
     uint32_t* color_offsets;  // [25] device copy
     uint32_t* constraint_count;  // [1]
+    // body -> incident (manifold, side) list in SOLVE order (overflow colour first, then colours 0..22; list order inside
+    // a colour) for the body-centric warm start: CSR over bodies; only bodies that have a SolverBody own entries
+    const uint32_t* inc_off;   // [n_bodies + 1]
+    const uint2* inc_ent;      // (manifold | side << 31, body)
     // ---- XPBD joints (all five types; the reference's per-type components + solver data) ----
     uint32_t n_joints;
     int2* j_bodies;

@@ -54,6 +54,8 @@ template <class T> void launch_xpbd_velocity_projection(const DW<T>&, const Step
 // k_contacts.hip
 template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t);
 template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
+// body-centric warm start over the incidence CSR (DW::inc_off / inc_ent), optionally preceded by integrate_velocities
+template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);
 uint32_t color_grid_blocks(uint32_t count);
 // grid_blocks[c] = captured grid of colour c (0 = colour skipped); returns the number of launches issued
 template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, hipStream_t);

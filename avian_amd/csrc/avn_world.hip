@@ -108,6 +108,7 @@ template <class T> struct World : WorldBase {
         b_j_torque;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
     DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
+    DevBuf b_inc_off, b_inc_ent;
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
@@ -117,6 +118,8 @@ template <class T> struct World : WorldBase {
     std::vector<int32_t> h_j_body1, h_j_body2;
     std::vector<uint8_t> h_j_damped, h_j_collision_disabled, h_j_type;
     std::vector<uint8_t> h_body_has_sb;
+    std::vector<int32_t> h_m_body1, h_m_body2;  // ContactPair bodies of the uploaded manifolds (incidence CSR source)
+    bool incidence_dirty = true;
     bool joint_schedule_dirty = true;
     JointSchedule sched_solve, sched_damp;
     bool any_damped = false;
@@ -308,6 +311,7 @@ template <class T> struct World : WorldBase {
             h_body_has_sb[i] = b->rb_type[i] != AVN_RB_STATIC && !(fl & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED));
         }
         joint_schedule_dirty = true;
+        incidence_dirty = true;
         have_bodies = true;
         HIPCHK(hipStreamSynchronize(stream));  // host arrays are only borrowed for the call
         return AVN_OK;
@@ -421,7 +425,47 @@ template <class T> struct World : WorldBase {
         SIN(warm_n, m->warm_start_normal_impulse, 4 * (size_t)M, T); SIN(warm_t, m->warm_start_tangent_impulse, 8 * (size_t)M, T);
         launch_pack_manifolds<T>(dw, s, stream);
         HIPCHK(hipGetLastError());
+        h_m_body1.assign(m->body1, m->body1 + M);
+        h_m_body2.assign(m->body2, m->body2 + M);
+        incidence_dirty = true;
         HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    // Incidence CSR of the body-centric warm start: per body that has a SolverBody, its (manifold, side) entries in SOLVE
+    // order = overflow colour first, then colours 0..22 (reference plugin.rs:461-470), list order inside a colour.
+    avn_status rebuild_incidence() {
+        if (!incidence_dirty) return AVN_OK;
+        uint32_t N = dw.n_bodies, M = dw.n_manifolds;
+        if (M == 0) { incidence_dirty = false; return AVN_OK; }
+        if (h_body_has_sb.size() != N || h_m_body1.size() != M) { error = "incidence: bodies / manifolds out of sync"; return AVN_ERR_STATE; }
+        HIPCHK(hipStreamSynchronize(stream));
+        std::vector<uint32_t> off((size_t)N + 1, 0u);
+        for (uint32_t m = 0; m < M; ++m) {
+            if (h_body_has_sb[h_m_body1[m]]) ++off[(size_t)h_m_body1[m] + 1];
+            if (h_body_has_sb[h_m_body2[m]]) ++off[(size_t)h_m_body2[m] + 1];
+        }
+        for (uint32_t i = 0; i < N; ++i) off[i + 1] += off[i];
+        std::vector<uint32_t> cursor(off.begin(), off.end() - 1);
+        std::vector<uint2> ent(off[N]);
+        auto visit = [&](uint32_t m) {
+            uint32_t a = (uint32_t)h_m_body1[m], b = (uint32_t)h_m_body2[m];
+            if (h_body_has_sb[a]) ent[cursor[a]++] = make_uint2(m, a);
+            if (h_body_has_sb[b]) ent[cursor[b]++] = make_uint2(m | 0x80000000u, b);
+        };
+        for (uint32_t m = color_offsets[AVN_COLOR_OVERFLOW_INDEX]; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1]; ++m) visit(m);
+        for (uint32_t m = 0; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX]; ++m) visit(m);
+        hipError_t err;
+        bool moved = b_inc_off.ensure(((size_t)N + 1) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        moved |= b_inc_ent.ensure(std::max<size_t>(ent.size(), 1) * sizeof(uint2), err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (moved || !dw.inc_off) graph_valid = false;
+        dw.inc_off = b_inc_off.as<uint32_t>();
+        dw.inc_ent = b_inc_ent.as<uint2>();
+        HIPCHK(hipMemcpyAsync(b_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, stream));
+        if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));  // `off` / `ent` are locals
+        incidence_dirty = false;
         return AVN_OK;
     }
     avn_status impulses_download(const avn_impulses_out* o) override {
@@ -869,6 +913,11 @@ template <class T> struct World : WorldBase {
     void prepare_contact_constraints() { launch_prepare_contact_constraints<T>(dw, params, stream); ++launches; }
     void pre_process_velocity_increments() { launch_pre_process_increments<T>(dw, params, stream); ++launches; }
     void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
+    // warm start of ALL colours in one body-centric launch; `fused` also runs integrate_velocities for the body first
+    void warm_start(bool fused) {
+        if (dw.n_manifolds) { launch_body_warm_start<T>(dw, params, fused, stream); ++launches; }
+        else if (fused) integrate_velocities();
+    }
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
     void contact_pass(int pass) { if (dw.n_manifolds) launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, stream); }
     // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
@@ -897,8 +946,7 @@ template <class T> struct World : WorldBase {
         ++launches;
     }
     void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)
-        integrate_velocities();
-        contact_pass(PASS_WARM_START);
+        warm_start(true);  // integrate_velocities + warm_start
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_BIAS);
         integrate_positions();
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_RELAX);
@@ -928,6 +976,7 @@ template <class T> struct World : WorldBase {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
         prepare_solver_bodies();
         prepare_joints();
         prepare_contact_constraints();
@@ -953,7 +1002,7 @@ template <class T> struct World : WorldBase {
             case AVN_SYS_PREPARE_CONTACT_CONSTRAINTS: prepare_contact_constraints(); break;
             case AVN_SYS_PRE_PROCESS_VELOCITY_INCREMENTS: pre_process_velocity_increments(); break;
             case AVN_SYS_INTEGRATE_VELOCITIES: integrate_velocities(); break;
-            case AVN_SYS_WARM_START: contact_pass(PASS_WARM_START); break;
+            case AVN_SYS_WARM_START: warm_start(false); break;
             case AVN_SYS_SOLVE_CONTACTS_BIAS: contact_pass(PASS_SOLVE_BIAS); break;
             case AVN_SYS_INTEGRATE_POSITIONS: integrate_positions(); break;
             case AVN_SYS_SOLVE_CONTACTS_RELAX: contact_pass(PASS_SOLVE_RELAX); break;
@@ -984,6 +1033,7 @@ template <class T> struct World : WorldBase {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
         if ((st = dispatch_system(sys)) != AVN_OK) return st;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
@@ -992,6 +1042,7 @@ template <class T> struct World : WorldBase {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipStreamSynchronize(stream));

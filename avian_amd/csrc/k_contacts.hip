@@ -20,6 +20,7 @@
 //   k_solve_restitution            plugin.rs:630-718, contact/mod.rs:358-407
 //   k_store_contact_impulses       plugin.rs:722-755
 #include "avn_kernels.h"
+#include "avn_body_ops.h"
 
 namespace avn {
 
@@ -157,37 +158,115 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
 }
 
 // ------------------------------------------------------------------------------------------------------
-template <class T> __device__ __forceinline__ void warm_start_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
-    // level 1: every load that only depends on m (the point planes are allocated for 4 points per manifold, so the
-    // fetch of unused points is in bounds and merely ignored)
-    Vec4<T> h1 = w.c_h1[m];
-    int2 b = w.m_bodies[m];
-    Vec4<T> h0 = w.m_n[m];
-    uint32_t S = w.m_stride;
-    Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
-#pragma unroll
-    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * S + m; pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pd[k] = w.c_pd[s]; }
-    // level 2: the body gathers
-    BodyRef<T> b1, b2;
-    uint32_t cm = scalar_to_bits(h1.w);
-    uint32_t np = cm & 7u;
-    load_body<T, false>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, false>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
-    if (np == 0) return;
-    V3<T> normal = xyz<T>(h0);
-    V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
-    T coeff = p.warm_start_coefficient;
-#pragma unroll
-    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        if (k >= np) break;
-        V3<T> r1 = xyz<T>(pa[k]), r2 = xyz<T>(pb[k]);
-        Vec4<T> d = pd[k];
-        T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
-        V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
-        apply_impulse(b1, b2, imp, r1, r2);
+// Warm start, BODY-centric (reference plugin.rs:453-515, contact/mod.rs:223-264), fused with integrate_velocities.
+//
+// A warm-start impulse does not depend on the velocities: p = c (l_n n + l_t.x t1 + l_t.y t2) per point, applied as
+// v1 -= p * w1, om1 -= I1 (r1 x p), v2 += p * w2, om2 += I2 (r2 x p).  The only order-dependent part is the sequence of
+// floating-point additions on each body, and that sequence is the body's incident manifolds in solve order (overflow
+// colour first, then colours 0..22) with the points of a manifold in order.  So instead of one launch per colour
+// (15 launches whose ~5 us latency floors dominate at 45k manifolds each), ONE launch does it for all colours:
+//   phase 1  one lane per (body, incident manifold side) entry of the incidence CSR: gather the manifold's records,
+//            evaluate the four per-point velocity deltas (the SAME expressions as the manifold-centric form) -> LDS;
+//   phase 2  one lane per body adds its entries' deltas in solve order -- bit-identical to the colour-by-colour result.
+// The body lane first applies integrate_velocities (the system that precedes warm start in the SubstepSchedule).
+#define WS_THREADS 256
+#define WS_BODIES 16
+template <class T, bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepParams<T> p) {
+    __shared__ Vec4<T> l_d[6][WS_THREADS];  // per entry: 4 points x (dv.xyz, dw.xyz) = 24 scalars, as 6 Vec4 planes
+    __shared__ uint32_t l_np[WS_THREADS];   // points to apply | side << 8
+    const uint32_t t = threadIdx.x;
+    const uint32_t b0 = xcd_block(blockIdx.x, gridDim.x) * WS_BODIES;
+    if (b0 >= w.n_bodies) return;  // workgroup-uniform
+    const uint32_t b1 = min(b0 + WS_BODIES, w.n_bodies);
+    const uint32_t e_begin = w.inc_off[b0], e_end = w.inc_off[b1];
+    // body lanes
+    const uint32_t body = b0 + t;
+    bool owner = false, touched = false;
+    V3<T> v = vzero<T>(), om = vzero<T>();
+    T lin_w = T(0), ang_w = T(0);
+    uint32_t my_beg = 0, my_end = 0;
+    if (body < b1) {
+        uint32_t sbf = w.sb_flags[body];
+        if (!(sbf & AVN_SBF_NO_SOLVER_BODY)) {
+            owner = true;
+            Vec4<T> l4 = w.sb_lin[body], a4 = w.sb_ang[body];
+            v = xyz<T>(l4); om = xyz<T>(a4); lin_w = l4.w; ang_w = a4.w;
+            my_beg = w.inc_off[body]; my_end = w.inc_off[body + 1];
+            if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om);
+        }
     }
-    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
-    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+    const uint32_t S = w.m_stride;
+    const T coeff = p.warm_start_coefficient;
+    for (uint32_t chunk = e_begin; chunk < e_end; chunk += WS_THREADS) {
+        const uint32_t e = chunk + t;
+        if (e < e_end) {
+            uint2 ent = w.inc_ent[e];
+            uint32_t m = ent.x & 0x7FFFFFFFu, side = ent.x >> 31;
+            Vec4<T> h1 = w.c_h1[m], h0 = w.m_n[m];
+            Vec4<T> sa = w.si_a[ent.y], sb = w.si_b[ent.y];
+            Vec4<T> pr[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                uint32_t s = k * S + m;
+                pr[k] = side ? w.c_pb[s] : w.c_pa[s];
+                pd[k] = w.c_pd[s];
+            }
+            uint32_t cm = scalar_to_bits(h1.w);
+            uint32_t np = cm & 7u;
+            if (cm & (side ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1)) np = 0;  // (stale incidence: the body lost its SolverBody)
+            // SolverBodyInertia, or DUMMY for the dominant body (plugin.rs:508-512)
+            const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
+            const T z = T(0);
+            V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
+            V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
+            Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
+            V3<T> normal = xyz<T>(h0);
+            V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
+            T d[24];
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                V3<T> r = xyz<T>(pr[k]);
+                T tx = (cm & AVN_CM_TANGENT) ? pd[k].z : T(0), ty = (cm & AVN_CM_TANGENT) ? pd[k].w : T(0);
+                V3<T> imp = coeff * ((pd[k].x * normal + tx * t0) + ty * t1);
+                V3<T> dv = cmul(imp, inv_mass);
+                V3<T> dw = smul(I, cross(r, imp));
+                d[6 * k + 0] = dv.x; d[6 * k + 1] = dv.y; d[6 * k + 2] = dv.z;
+                d[6 * k + 3] = dw.x; d[6 * k + 4] = dw.y; d[6 * k + 5] = dw.z;
+            }
+#pragma unroll
+            for (uint32_t q = 0; q < 6; ++q) l_d[q][t] = make4<T>(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
+            l_np[t] = np | (side << 8);
+        }
+        __syncthreads();
+        if (owner) {
+            uint32_t lo = max(my_beg, chunk), hi = min(my_end, chunk + WS_THREADS);
+            for (uint32_t ee = lo; ee < hi; ++ee) {
+                uint32_t s = ee - chunk;
+                uint32_t info = l_np[s];
+                uint32_t np = info & 0xFFu;
+                if (np == 0) continue;
+                const bool second = info >> 8;
+                T d[24];
+#pragma unroll
+                for (uint32_t q = 0; q < 6; ++q) { Vec4<T> x = l_d[q][s]; d[4 * q] = x.x; d[4 * q + 1] = x.y; d[4 * q + 2] = x.z; d[4 * q + 3] = x.w; }
+#pragma unroll
+                for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                    if (k < np) {
+                        V3<T> dv{d[6 * k], d[6 * k + 1], d[6 * k + 2]}, dw{d[6 * k + 3], d[6 * k + 4], d[6 * k + 5]};
+                        if (second) { v = v + dv; om = om + dw; }   // body2: v += p * w2 ...
+                        else { v = v - dv; om = om - dw; }           // body1: v -= p * w1 ...
+                    }
+                }
+                touched = true;
+            }
+        }
+        __syncthreads();
+    }
+    if (owner && touched) {
+        w.sb_lin[body] = make4<T>(v, lin_w);
+        w.sb_ang[body] = make4<T>(om, ang_w);
+    }
 }
 
 template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
@@ -320,8 +399,7 @@ template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& 
 
 enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
 template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
-    if (PASS == PASS_WARM) warm_start_one<T>(w, p, m);
-    else if (PASS == PASS_BIAS) solve_one<T, true>(w, p, m);
+    if (PASS == PASS_BIAS) solve_one<T, true>(w, p, m);
     else if (PASS == PASS_RELAX) solve_one<T, false>(w, p, m);
     else restitution_one<T>(w, p, m);
 }
@@ -380,9 +458,16 @@ template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const S
         if (grid_blocks[c]) { hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c); ++launches; }
     return launches;
 }
+template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
+    if (!w.n_bodies) return;
+    uint32_t nb = (w.n_bodies + WS_BODIES - 1) / WS_BODIES;
+    nb = ((nb + 7u) / 8u) * 8u;
+    if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
+    else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
+}
 template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, hipStream_t s) {
     switch (pass) {
-        case PASS_WARM: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, s);
+        case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
         case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, s);
         case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, s);
         default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, s);
@@ -392,6 +477,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
 #define INST(T)                                                                                             \
     template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
+    template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
     template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, hipStream_t);
 INST(float)
 INST(double)
