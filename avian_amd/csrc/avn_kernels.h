@@ -71,6 +71,7 @@ template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typenam
 template <class T> uint32_t launch_dynamic_bounds(const DW<T>&, const BP<T>&, T* partial, hipStream_t);
 uint32_t radix_blocks(uint32_t n);
 uint32_t scan_block_sums_needed(uint32_t n);
+uint32_t exclusive_scan_launches(uint32_t n);  // kernels launch_exclusive_scan issues for n items
 // `enabled` (device flag, may be null): when it reads 0 every kernel of the call returns immediately
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
                                           const uint32_t* enabled, hipStream_t);
@@ -79,6 +80,7 @@ template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const u
 template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const SweepScratch&, hipStream_t);
 template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const SweepScratch&, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
 size_t sweep_long_item_bytes();
+uint32_t sweep_pad_records();
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);

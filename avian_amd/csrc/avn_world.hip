@@ -748,7 +748,7 @@ template <class T> struct World : WorldBase {
             size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
             GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
             GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
-            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc, bp.s_yz); GROW(b_s_end, cc, bp.s_end);
+            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_end, cc, bp.s_end);
             GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
             Key* dummy_k; uint32_t* dummy_u;
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
@@ -862,7 +862,7 @@ template <class T> struct World : WorldBase {
         launch_sweep_ranges<T>(bp, n, sweep_scratch, stream);
         launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, stream);
-        launches += 3 + 5 * (uint32_t)sizeof(Key) + 3 + 3;
+        launches += 3 + (uint32_t)sizeof(Key) * (2 + exclusive_scan_launches(256 * radix_blocks(n))) + 3 + exclusive_scan_launches(n * sweep_count_slots());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipEventRecord(ev_counters, stream));

@@ -275,6 +275,7 @@ void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32
     hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, nb, total, enabled);
     hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, block_sums, enabled);
 }
+uint32_t exclusive_scan_launches(uint32_t n) { return n == 0 ? 0u : 3u; }
 uint32_t scan_block_sums_needed(uint32_t n) { return (n + SC_TILE - 1) / SC_TILE + 1; }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -383,6 +384,12 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 #define SW_CAP 8192u
 #define SW_LCHUNK 4096u
 
+// wave-wide compare masks (LLVM fcmp predicates: UGE = 11, ULE = 13); inactive lanes read 0
+__device__ __forceinline__ unsigned long long lane_mask_ule(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 13); }
+__device__ __forceinline__ unsigned long long lane_mask_uge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 11); }
+__device__ __forceinline__ unsigned long long lane_mask_ule(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 13); }
+__device__ __forceinline__ unsigned long long lane_mask_uge(double a, double b) { return __builtin_amdgcn_fcmp(a, b, 11); }
+
 struct LongItem { uint32_t i, j_start, j_end, n_chunks; };  // n_chunks != 0 only on the first chunk of an interval
 
 struct PairSets { const uint64_t* pair_set; uint32_t pair_set_cap; const uint64_t* disabled_set; uint32_t disabled_cap; };
@@ -464,6 +471,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     const bool valid = i < n;
     Vec4<T> me = valid ? s_yz[i] : make4<T>(0, 0, 0, 0);  // (min.y, max.y, min.z, max.z)
     const uint32_t end_i = valid ? s_end[i] : 0u;
+    // lanes without candidates (padding, dropped, long intervals: end = i + 1) get a box nothing overlaps, so that the
+    // fast path below can leave out the per-lane index tests
+    const bool has_candidates = valid && end_i > i + 1u;
+    if (!has_candidates) { const T inf = Limits<T>::max * T(2); me = make4<T>(inf, -inf, inf, -inf); }
     const uint32_t my_flags = valid ? s_flags[i] : 0u;
     l_info[wv][lane] = valid ? s_info[i] : make_uint4(0, 0, 0, 0);
     l_flags[wv][lane] = my_flags;
@@ -472,6 +483,10 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) je = max(je, (uint32_t)__shfl_xor((int)je, off));
     je = (uint32_t)__builtin_amdgcn_readfirstlane((int)je);
+    uint32_t min_end = has_candidates ? end_i : 0xFFFFFFFFu;  // every candidate below it is inside EVERY active lane's range
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) min_end = min(min_end, (uint32_t)__shfl_xor((int)min_end, off));
+    min_end = (uint32_t)__builtin_amdgcn_readfirstlane((int)min_end);
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
     uint32_t qn = 0;  // wave-uniform queue fill
 
@@ -520,16 +535,27 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     for (uint32_t j = jb; j < jq; j += SW_BATCH) {
         Vec4<T> c[SW_BATCH];
 #pragma unroll
-        for (uint32_t k = 0; k < SW_BATCH; ++k) c[k] = s_yz[min(j + k, n - 1u)];  // wave-uniform address: scalar load
+        for (uint32_t k = 0; k < SW_BATCH; ++k) c[k] = s_yz[j + k];  // wave-uniform, contiguous: wide scalar loads (s_yz is padded by sweep_pad_records())
         unsigned long long hm[SW_BATCH], any = 0ull;
+        // y / z rejection exactly as broad_phase.rs:394-403 (strict compares: touching counts as overlapping);
+        // bitwise & keeps the test branch-free: v_cmp whose SGPR masks are and-ed on the scalar unit
+        if (j >= i0 + 64u && j + SW_BATCH <= min_end && j + SW_BATCH <= jq) {
+            // interior batch (the common case): every candidate is after every lane's own index and inside every active
+            // lane's [i + 1, end) range -> only the four box compares remain
 #pragma unroll
-        for (uint32_t k = 0; k < SW_BATCH; ++k) {
-            uint32_t jj = j + k;
-            // y / z rejection exactly as broad_phase.rs:394-403 (strict compares: touching counts as overlapping);
-            // bitwise & keeps the test branch-free: six v_cmp whose SGPR masks are and-ed on the scalar unit
-            bool hit = (jj > i) & (jj < end_i) & (jj < jq) & !(me.x > c[k].y) & !(me.y < c[k].x) & !(me.z > c[k].w) & !(me.w < c[k].z);
-            hm[k] = __ballot(hit);
-            any |= hm[k];
+            for (uint32_t k = 0; k < SW_BATCH; ++k) {
+                // v_cmp straight into SGPR lane masks (no bool round trip through a VGPR): !(a > b) == ULE, !(a < b) == UGE
+                hm[k] = lane_mask_ule(me.x, c[k].y) & lane_mask_uge(me.y, c[k].x) & lane_mask_ule(me.z, c[k].w) & lane_mask_uge(me.w, c[k].z);
+                any |= hm[k];
+            }
+        } else {
+#pragma unroll
+            for (uint32_t k = 0; k < SW_BATCH; ++k) {
+                uint32_t jj = j + k;
+                bool hit = (jj > i) & (jj < end_i) & (jj < jq) & !(me.x > c[k].y) & !(me.y < c[k].x) & !(me.z > c[k].w) & !(me.w < c[k].z);
+                hm[k] = __ballot(hit);
+                any |= hm[k];
+            }
         }
         if (any) {  // rare: compact the hits into the queue (j ascending, then lane ascending)
 #pragma unroll
@@ -663,6 +689,7 @@ template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, con
 }
 size_t sweep_long_item_bytes() { return sizeof(LongItem); }
 uint32_t sweep_count_slots() { return SW_WAVES; }
+uint32_t sweep_pad_records() { return 8u; }  // k_sweep reads whole candidate batches: s_yz needs this many records past n
 
 #define INST(T)                                                                                          \
     template void launch_update_aabb<T>(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);  \
