@@ -361,6 +361,146 @@ template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(cons
     store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
 }
 
+// ---- f32: the two bodies of a manifold as the two halves of PACKED-f32 registers -----------------------------------------
+// qrot of the anchors, velocity_at_point and apply_impulse evaluate the SAME expression once for body1 and once for
+// body2; with (body1, body2) held in the (lo, hi) halves of 64-bit VGPR pairs every such operation is ONE v_pk_mul_f32 /
+// v_pk_add_f32 for both bodies.  Each half goes through exactly the expression tree of the scalar form (the math
+// templates of avn_math.h are instantiated with T = F2), so the results are bit-identical; the kernel's in-lane
+// dependent chain -- the latency floor of a colour launch at one wave per SIMD -- loses about 40 % of its VALU issues.
+typedef float f2raw __attribute__((ext_vector_type(2)));
+struct F2 {
+    f2raw v;
+    F2() = default;
+    __device__ __forceinline__ F2(float a) : v{a, a} {}
+    __device__ __forceinline__ F2(float lo, float hi) : v{lo, hi} {}
+    __device__ __forceinline__ explicit F2(f2raw x) : v(x) {}
+};
+__device__ __forceinline__ F2 operator+(F2 a, F2 b) { return F2(a.v + b.v); }
+__device__ __forceinline__ F2 operator-(F2 a, F2 b) { return F2(a.v - b.v); }
+__device__ __forceinline__ F2 operator*(F2 a, F2 b) { return F2(a.v * b.v); }
+__device__ __forceinline__ F2 operator-(F2 a) { return F2(-a.v); }
+// body1 (lo): a - b; body2 (hi): a + b   (apply_impulse's  v1 -= ..., v2 += ...)
+__device__ __forceinline__ F2 sub_lo_add_hi(F2 a, F2 b) { return F2(a.v + f2raw{-b.v.x, b.v.y}); }  // a - b == a + (-b) bit for bit: one v_pk_add_f32 with neg_lo
+__device__ __forceinline__ V3<F2> sub_lo_add_hi(V3<F2> a, V3<F2> b) { return {sub_lo_add_hi(a.x, b.x), sub_lo_add_hi(a.y, b.y), sub_lo_add_hi(a.z, b.z)}; }
+__device__ __forceinline__ V3<F2> pair3(V3<float> lo, V3<float> hi) { return {F2(lo.x, hi.x), F2(lo.y, hi.y), F2(lo.z, hi.z)}; }
+__device__ __forceinline__ V3<F2> splat3(V3<float> a) { return {F2(a.x), F2(a.y), F2(a.z)}; }
+__device__ __forceinline__ V3<float> lo3(V3<F2> a) { return {a.x.v.x, a.y.v.x, a.z.v.x}; }
+__device__ __forceinline__ V3<float> hi3(V3<F2> a) { return {a.x.v.y, a.y.v.y, a.z.v.y}; }
+
+struct BodyPair {
+    V3<F2> v, om, inv_mass;
+    Sym3<F2> I;
+};
+__device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2> anchors) {
+    V3<F2> p = splat3(imp);
+    b.v = sub_lo_add_hi(b.v, cmul(p, b.inv_mass));
+    b.om = sub_lo_add_hi(b.om, smul(b.I, cross(anchors, p)));
+}
+
+template <bool USE_BIAS> __device__ __forceinline__ void solve_one_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m) {
+    typedef float T;
+    // memory levels exactly as solve_one: (headers + point records) | body gathers
+    Vec4<T> h1 = w.c_h1[m];
+    int2 b = w.m_bodies[m];
+    Vec4<T> h0 = w.m_n[m];
+    Vec4<T> h2 = w.m_tv[m];
+    uint32_t S = w.m_stride;
+    Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        uint32_t s = k * S + m;
+        pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
+    }
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    BodyRef<T> b1, b2;
+    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    if (np == 0) return;
+    BodyPair bp;
+    bp.v = pair3(b1.v, b2.v); bp.om = pair3(b1.om, b2.om); bp.inv_mass = pair3(b1.inv_mass, b2.inv_mass);
+    bp.I = Sym3<F2>{F2(b1.I.m00, b2.I.m00), F2(b1.I.m01, b2.I.m01), F2(b1.I.m02, b2.I.m02), F2(b1.I.m11, b2.I.m11), F2(b1.I.m12, b2.I.m12), F2(b1.I.m22, b2.I.m22)};
+    Q4<F2> dq{F2(b1.dq.x, b2.dq.x), F2(b1.dq.y, b2.dq.y), F2(b1.dq.z, b2.dq.z), F2(b1.dq.w, b2.dq.w)};
+    V3<T> normal = xyz<T>(h0);
+    T friction = h0.w;
+    SoftCoef<T> soft = (cm & AVN_CM_SOFT_ND) ? p.soft_non_dynamic : p.soft_dynamic;
+    T delta_secs = p.h_adj;
+    V3<T> delta_translation = b2.dp - b1.dp;
+    // normal impulses
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k < np) {
+            V3<F2> anchors = pair3(xyz<T>(pa[k]), xyz<T>(pb[k]));
+            V3<F2> rw = qrot(dq, anchors);
+            V3<T> delta_separation = delta_translation + (hi3(rw) - lo3(rw));
+            T separation = dot(delta_separation, normal) + pa[k].w;
+            V3<F2> vap = bp.v + cross(bp.om, anchors);  // velocity_at_point of both bodies
+            V3<T> relative_velocity = hi3(vap) - lo3(vap);
+            // ContactNormalPart::solve_impulse
+            T normal_speed = dot(relative_velocity, normal);
+            T eff_mass = pb[k].w, acc = pd[k].x;
+            T impulse;
+            if (separation > T(0)) {
+                impulse = -eff_mass * (normal_speed + separation / delta_secs);
+            } else if (USE_BIAS) {
+                T bias = smax(soft.bias * separation, -p.max_overlap_solve_speed);
+                T scaled_mass = soft.mass_scale * eff_mass;
+                T scaled_impulse = soft.impulse_scale * acc;
+                impulse = -scaled_mass * (normal_speed + bias) - scaled_impulse;
+            } else {
+                impulse = -eff_mass * normal_speed;
+            }
+            T new_impulse = smax(acc + impulse, T(0));
+            impulse = new_impulse - acc;
+            pd[k].x = new_impulse;
+            pd[k].y = pd[k].y + new_impulse;  // total_impulse += new accumulated value (normal_part.rs:162)
+            apply_impulse(bp, impulse * normal, anchors);
+        }
+    }
+    // friction
+    if (cm & AVN_CM_TANGENT) {
+        V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);
+        V3<T> surface_velocity = xyz<T>(h2);
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            if (k < np) {
+                V3<F2> anchors = pair3(xyz<T>(pa[k]), xyz<T>(pb[k]));
+                V3<F2> vap = bp.v + cross(bp.om, anchors);
+                V3<T> relative_velocity = hi3(vap) - lo3(vap);
+                // ContactTangentPart::solve_impulse
+                T impulse_limit = friction * pd[k].x;
+                V3<T> rv = relative_velocity + surface_velocity;
+                T ts1 = dot(rv, t0), ts2 = dot(rv, t1);
+                T t11 = ts1 * ts1, t22 = ts2 * ts2, t12 = ts1 * ts2;
+                T inv = t11 * pc[k].x + t22 * pc[k].y + t12 * pc[k].z;
+                T effective_mass = (t11 + t22) * (T(1) / inv);
+                if (finite_t(effective_mass)) {
+                    V2<T> delta{effective_mass * ts1, effective_mass * ts2};
+                    V2<T> ni = clamp_length_max(V2<T>{pd[k].z - delta.x, pd[k].w - delta.y}, impulse_limit);
+                    V2<T> di{ni.x - pd[k].z, ni.y - pd[k].w};
+                    pd[k].z = ni.x; pd[k].w = ni.y;
+                    apply_impulse(bp, di.x * t0 + di.y * t1, anchors);
+                } else {
+                    // returns Vector::ZERO; the reference still applies the zero impulse (v -= 0)
+                    apply_impulse(bp, vzero<T>(), anchors);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
+        if (k < np) w.c_pd[k * S + m] = pd[k];
+    b1.v = lo3(bp.v); b1.om = lo3(bp.om); b2.v = hi3(bp.v); b2.om = hi3(bp.om);
+    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
+    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+}
+template <class T, bool USE_BIAS> struct SolveDispatch {
+    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m) { solve_one<T, USE_BIAS>(w, p, m); }
+};
+template <bool USE_BIAS> struct SolveDispatch<float, USE_BIAS> {
+    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m) { solve_one_packed<USE_BIAS>(w, p, m); }
+};
+
 template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
     Vec4<T> h1 = w.c_h1[m];
     uint32_t cm = scalar_to_bits(h1.w);
@@ -399,8 +539,8 @@ template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& 
 
 enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
 template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
-    if (PASS == PASS_BIAS) solve_one<T, true>(w, p, m);
-    else if (PASS == PASS_RELAX) solve_one<T, false>(w, p, m);
+    if (PASS == PASS_BIAS) SolveDispatch<T, true>::run(w, p, m);
+    else if (PASS == PASS_RELAX) SolveDispatch<T, false>::run(w, p, m);
     else restitution_one<T>(w, p, m);
 }
 
