@@ -862,7 +862,7 @@ template <class T> struct World : WorldBase {
         launch_sweep_ranges<T>(bp, n, sweep_scratch, stream);
         launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, stream);
-        launches += 3 + (uint32_t)sizeof(Key) * (2 + exclusive_scan_launches(256 * radix_blocks(n))) + 3 + exclusive_scan_launches(n * sweep_count_slots());
+        launches += 3 + (uint32_t)sizeof(Key) * radix_pass_launches(n) + 3 + exclusive_scan_launches(n * sweep_count_slots());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipEventRecord(ev_counters, stream));

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_interval_keys(DW<T> w, BP<T> bp, typena
 #define RS_TILE 1024
 #define RS_ROUNDS 16
 
-template <class K>
+template <class K, bool BLOCK_MAJOR>
 __global__ __launch_bounds__(64) void k_radix_hist(const K* __restrict__ keys, uint32_t n, uint32_t shift, uint32_t* __restrict__ hist, uint32_t nblocks,
                                                    const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t cnt[256];
@@ -171,17 +171,43 @@ __global__ __launch_bounds__(64) void k_radix_hist(const K* __restrict__ keys, u
         if (idx < n) atomicAdd(&cnt[(uint32_t)(keys[idx] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    for (uint32_t d = lane; d < 256; d += 64) hist[d * nblocks + b] = cnt[d];
+    for (uint32_t d = lane; d < 256; d += 64) hist[BLOCK_MAJOR ? b * 256u + d : d * nblocks + b] = cnt[d];
 }
 
-template <class K>
+// SELF_OFFSETS = false: `hist` is the exclusive scan of the digit-major [256][nblocks] histogram (three scan launches
+// between hist and scatter).  SELF_OFFSETS = true (small sorts, nblocks <= RS_FUSED_MAX_BLOCKS): `hist` is the raw
+// block-major [nblocks][256] histogram and every tile derives its own 256 start offsets from it -- per digit the total
+// over all tiles (-> exclusive scan over the digits inside the wave) plus the counts of the tiles before it -- so a pass
+// is two launches instead of five: at 100k keys the sort is launch-latency bound, not bandwidth bound.
+#define RS_FUSED_MAX_BLOCKS 128u
+template <class K, bool SELF_OFFSETS>
 __global__ __launch_bounds__(64) void k_radix_scatter(const K* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, K* __restrict__ keys_out,
                                                       uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift,
-                                                      const uint32_t* __restrict__ hist_scanned, uint32_t nblocks, const uint32_t* __restrict__ enabled) {
+                                                      const uint32_t* __restrict__ hist, uint32_t nblocks, const uint32_t* __restrict__ enabled) {
     __shared__ uint32_t run[256];
     if (enabled && *enabled == 0u) return;
     uint32_t lane = threadIdx.x, b = blockIdx.x;
-    for (uint32_t d = lane; d < 256; d += 64) run[d] = hist_scanned[d * nblocks + b];
+    if (!SELF_OFFSETS) {
+        for (uint32_t d = lane; d < 256; d += 64) run[d] = hist[d * nblocks + b];
+    } else {
+        // lane owns digits 4 * lane .. 4 * lane + 3: one coalesced 16-byte load per tile row
+        const uint4* __restrict__ h4 = reinterpret_cast<const uint4*>(hist);
+        uint4 pre = make_uint4(0, 0, 0, 0), tot = make_uint4(0, 0, 0, 0);
+#pragma unroll 8
+        for (uint32_t bb = 0; bb < nblocks; ++bb) {
+            uint4 h = h4[bb * 64u + lane];
+            tot.x += h.x; tot.y += h.y; tot.z += h.z; tot.w += h.w;
+            if (bb < b) { pre.x += h.x; pre.y += h.y; pre.z += h.z; pre.w += h.w; }
+        }
+        uint32_t mine = tot.x + tot.y + tot.z + tot.w, incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += v; }
+        uint32_t excl = incl - mine;
+        run[4 * lane + 0] = excl + pre.x;
+        run[4 * lane + 1] = excl + tot.x + pre.y;
+        run[4 * lane + 2] = excl + tot.x + tot.y + pre.z;
+        run[4 * lane + 3] = excl + tot.x + tot.y + tot.z + pre.w;
+    }
     __syncthreads();
     uint32_t base = b * RS_TILE;
     unsigned long long lt_mask = (1ull << lane) - 1ull;
@@ -643,6 +669,7 @@ template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, ty
     if (bp.n_intervals) hipLaunchKernelGGL(k_interval_keys<T>, dim3((bp.n_intervals + 255) / 256), dim3(256), 0, s, w, bp, keys, vals, n_dropped);
 }
 uint32_t radix_blocks(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+uint32_t radix_pass_launches(uint32_t n) { uint32_t nb = radix_blocks(n); return nb <= RS_FUSED_MAX_BLOCKS ? 2u : 2u + exclusive_scan_launches(256 * nb); }
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
                                           const uint32_t* unsorted, hipStream_t s) {
     // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even.  Every kernel
@@ -653,9 +680,14 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
     K* ki = keys_a; uint32_t* vi = vals_a; K* ko = keys_b; uint32_t* vo = vals_b;
     for (uint32_t pass = 0; pass < sizeof(K); ++pass) {
         uint32_t shift = pass * 8;
-        hipLaunchKernelGGL(k_radix_hist<K>, dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, unsorted);
-        launch_exclusive_scan(hist, hist, 256 * nb, block_sums, nullptr, s, unsorted);
-        hipLaunchKernelGGL(k_radix_scatter<K>, dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, unsorted);
+        if (nb <= RS_FUSED_MAX_BLOCKS) {
+            hipLaunchKernelGGL((k_radix_hist<K, true>), dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, unsorted);
+            hipLaunchKernelGGL((k_radix_scatter<K, true>), dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, unsorted);
+        } else {
+            hipLaunchKernelGGL((k_radix_hist<K, false>), dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, unsorted);
+            launch_exclusive_scan(hist, hist, 256 * nb, block_sums, nullptr, s, unsorted);
+            hipLaunchKernelGGL((k_radix_scatter<K, false>), dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, unsorted);
+        }
         K* tk = ki; ki = ko; ko = tk;
         uint32_t* tv = vi; vi = vo; vo = tv;
     }

@@ -113,9 +113,16 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
             bool warm = p.match_contacts != 0;
             bool has_tangent = friction > T(0);
             uint32_t S = w.m_stride;
-            for (uint32_t k = 0; k < np; ++k) {
+            // all twelve point records up front (slots >= np are allocated, merely unused): one memory level for the
+            // whole manifold instead of one per point iteration
+            Vec4<T> pa1[AVN_MAX_MANIFOLD_POINTS], pa2[AVN_MAX_MANIFOLD_POINTS], pww[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * S + m; pa1[k] = w.mp_a1[s]; pa2[k] = w.mp_a2[s]; pww[k] = w.mp_w[s]; }
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                if (k >= np) break;
                 uint32_t s = k * S + m;
-                Vec4<T> a1 = w.mp_a1[s], a2 = w.mp_a2[s], ww = w.mp_w[s];
+                Vec4<T> a1 = pa1[k], a2 = pa2[k], ww = pww[k];
                 V3<T> r1 = xyz<T>(a1), r2 = xyz<T>(a2);
                 T penetration = a1.w, normal_speed = a2.w;
                 // ContactNormalPart::generate
