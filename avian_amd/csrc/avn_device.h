@@ -108,7 +108,7 @@ template <class T> struct DW {
     // body -> incident (manifold, side) list in SOLVE order (overflow colour first, then colours 0..22; list order inside
     // a colour) for the body-centric warm start: CSR over bodies; only bodies that have a SolverBody own entries
     const uint32_t* inc_off;   // [n_bodies + 1]
-    const uint2* inc_ent;      // (manifold | side << 31, body)
+    const uint32_t* inc_ent;   // manifold | side << 31  (side 0: the body is the manifold's body1, 1: body2)
     // ---- XPBD joints (all five types; the reference's per-type components + solver data) ----
     uint32_t n_joints;
     int2* j_bodies;

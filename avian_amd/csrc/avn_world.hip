@@ -446,24 +446,24 @@ template <class T> struct World : WorldBase {
         }
         for (uint32_t i = 0; i < N; ++i) off[i + 1] += off[i];
         std::vector<uint32_t> cursor(off.begin(), off.end() - 1);
-        std::vector<uint2> ent(off[N]);
+        std::vector<uint32_t> ent(off[N]);
         auto visit = [&](uint32_t m) {
             uint32_t a = (uint32_t)h_m_body1[m], b = (uint32_t)h_m_body2[m];
-            if (h_body_has_sb[a]) ent[cursor[a]++] = make_uint2(m, a);
-            if (h_body_has_sb[b]) ent[cursor[b]++] = make_uint2(m | 0x80000000u, b);
+            if (h_body_has_sb[a]) ent[cursor[a]++] = m;
+            if (h_body_has_sb[b]) ent[cursor[b]++] = m | 0x80000000u;
         };
         for (uint32_t m = color_offsets[AVN_COLOR_OVERFLOW_INDEX]; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1]; ++m) visit(m);
         for (uint32_t m = 0; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX]; ++m) visit(m);
         hipError_t err;
         bool moved = b_inc_off.ensure(((size_t)N + 1) * 4, err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-        moved |= b_inc_ent.ensure(std::max<size_t>(ent.size(), 1) * sizeof(uint2), err);
+        moved |= b_inc_ent.ensure(std::max<size_t>(ent.size(), 1) * sizeof(uint32_t), err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         if (moved || !dw.inc_off) graph_valid = false;
         dw.inc_off = b_inc_off.as<uint32_t>();
-        dw.inc_ent = b_inc_ent.as<uint2>();
+        dw.inc_ent = b_inc_ent.as<uint32_t>();
         HIPCHK(hipMemcpyAsync(b_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, stream));
-        if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint2), hipMemcpyHostToDevice, stream));
+        if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));  // `off` / `ent` are locals
         incidence_dirty = false;
         return AVN_OK;

@@ -171,108 +171,82 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
 // v1 -= p * w1, om1 -= I1 (r1 x p), v2 += p * w2, om2 += I2 (r2 x p).  The only order-dependent part is the sequence of
 // floating-point additions on each body, and that sequence is the body's incident manifolds in solve order (overflow
 // colour first, then colours 0..22) with the points of a manifold in order.  So instead of one launch per colour
-// (15 launches whose ~5 us latency floors dominate at 45k manifolds each), ONE launch does it for all colours:
-//   phase 1  one lane per (body, incident manifold side) entry of the incidence CSR: gather the manifold's records,
-//            evaluate the four per-point velocity deltas (the SAME expressions as the manifold-centric form) -> LDS;
-//   phase 2  one lane per body adds its entries' deltas in solve order -- bit-identical to the colour-by-colour result.
-// The body lane first applies integrate_velocities (the system that precedes warm start in the SubstepSchedule).
-#define WS_THREADS 256
-#define WS_BODIES 16
+// (15 launches whose ~5 us latency floors dominate at 45k manifolds each), ONE launch does it for all colours: one lane
+// per body walks the body's incidence list (CSR, solve order) and applies the SAME expressions as the manifold-centric
+// form, in the same order -- bit-identical to the colour-by-colour result.  Neighbouring lanes are neighbouring bodies,
+// whose j-th incident manifolds are neighbours in the colour-major arrays, so the record gathers of a wave coalesce; the
+// next entry's ten records are in flight while the current one is applied.  The lane first runs integrate_velocities
+// (the system that precedes warm start in the SubstepSchedule) on its body.
+#define WS_THREADS 64
+template <class T> struct WarmRecords { Vec4<T> h1, h0, pr[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS]; };
+template <class T> __device__ __forceinline__ void warm_fetch(const DW<T>& w, uint32_t ent, WarmRecords<T>& r) {
+    const uint32_t m = ent & 0x7FFFFFFFu;
+    const Vec4<T>* __restrict__ anchors = (ent >> 31) ? w.c_pb : w.c_pa;  // this body's side of the manifold
+    r.h1 = w.c_h1[m];
+    r.h0 = w.m_n[m];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * w.m_stride + m; r.pr[k] = anchors[s]; r.pd[k] = w.c_pd[s]; }
+}
 template <class T, bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepParams<T> p) {
-    __shared__ Vec4<T> l_d[6][WS_THREADS];  // per entry: 4 points x (dv.xyz, dw.xyz) = 24 scalars, as 6 Vec4 planes
-    __shared__ uint32_t l_np[WS_THREADS];   // points to apply | side << 8
-    const uint32_t t = threadIdx.x;
-    const uint32_t b0 = xcd_block(blockIdx.x, gridDim.x) * WS_BODIES;
-    if (b0 >= w.n_bodies) return;  // workgroup-uniform
-    const uint32_t b1 = min(b0 + WS_BODIES, w.n_bodies);
-    const uint32_t e_begin = w.inc_off[b0], e_end = w.inc_off[b1];
-    // body lanes
-    const uint32_t body = b0 + t;
-    bool owner = false, touched = false;
-    V3<T> v = vzero<T>(), om = vzero<T>();
-    T lin_w = T(0), ang_w = T(0);
-    uint32_t my_beg = 0, my_end = 0;
-    if (body < b1) {
-        uint32_t sbf = w.sb_flags[body];
-        if (!(sbf & AVN_SBF_NO_SOLVER_BODY)) {
-            owner = true;
-            Vec4<T> l4 = w.sb_lin[body], a4 = w.sb_ang[body];
-            v = xyz<T>(l4); om = xyz<T>(a4); lin_w = l4.w; ang_w = a4.w;
-            my_beg = w.inc_off[body]; my_end = w.inc_off[body + 1];
-            if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om);
-        }
-    }
-    const uint32_t S = w.m_stride;
+    const uint32_t body = xcd_block(blockIdx.x, gridDim.x) * WS_THREADS + threadIdx.x;
+    if (body >= w.n_bodies) return;
+    const uint32_t sbf = w.sb_flags[body];
+    if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
+    uint32_t e = w.inc_off[body];
+    const uint32_t end = w.inc_off[body + 1];
+    Vec4<T> l4 = w.sb_lin[body], a4 = w.sb_ang[body];
+    Vec4<T> sa = w.si_a[body], sb = w.si_b[body];
+    WarmRecords<T> cur, nxt;
+    uint32_t ent_cur = 0, ent_nxt = 0;
+    if (e < end) { ent_cur = w.inc_ent[e]; warm_fetch<T>(w, ent_cur, cur); }
+    if (e + 1 < end) ent_nxt = w.inc_ent[e + 1];
+    V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
+    bool touched = false;
+    if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om);
+    const V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
     const T coeff = p.warm_start_coefficient;
-    for (uint32_t chunk = e_begin; chunk < e_end; chunk += WS_THREADS) {
-        const uint32_t e = chunk + t;
-        if (e < e_end) {
-            uint2 ent = w.inc_ent[e];
-            uint32_t m = ent.x & 0x7FFFFFFFu, side = ent.x >> 31;
-            Vec4<T> h1 = w.c_h1[m], h0 = w.m_n[m];
-            Vec4<T> sa = w.si_a[ent.y], sb = w.si_b[ent.y];
-            Vec4<T> pr[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
-#pragma unroll
-            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-                uint32_t s = k * S + m;
-                pr[k] = side ? w.c_pb[s] : w.c_pa[s];
-                pd[k] = w.c_pd[s];
-            }
-            uint32_t cm = scalar_to_bits(h1.w);
+    const T z = T(0);
+    for (; e < end; ++e) {
+        const bool has_next = e + 1 < end;
+        uint32_t ent_nn = 0;
+        if (has_next) {
+            warm_fetch<T>(w, ent_nxt, nxt);
+            if (e + 2 < end) ent_nn = w.inc_ent[e + 2];
+        }
+        {
+            const uint32_t side = ent_cur >> 31;
+            const uint32_t cm = scalar_to_bits(cur.h1.w);
             uint32_t np = cm & 7u;
             if (cm & (side ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1)) np = 0;  // (stale incidence: the body lost its SolverBody)
-            // SolverBodyInertia, or DUMMY for the dominant body (plugin.rs:508-512)
-            const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
-            const T z = T(0);
-            V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
-            V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
-            Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
-            V3<T> normal = xyz<T>(h0);
-            V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
-            T d[24];
-#pragma unroll
-            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-                V3<T> r = xyz<T>(pr[k]);
-                T tx = (cm & AVN_CM_TANGENT) ? pd[k].z : T(0), ty = (cm & AVN_CM_TANGENT) ? pd[k].w : T(0);
-                V3<T> imp = coeff * ((pd[k].x * normal + tx * t0) + ty * t1);
-                V3<T> dv = cmul(imp, inv_mass);
-                V3<T> dw = smul(I, cross(r, imp));
-                d[6 * k + 0] = dv.x; d[6 * k + 1] = dv.y; d[6 * k + 2] = dv.z;
-                d[6 * k + 3] = dw.x; d[6 * k + 4] = dw.y; d[6 * k + 5] = dw.z;
-            }
-#pragma unroll
-            for (uint32_t q = 0; q < 6; ++q) l_d[q][t] = make4<T>(d[4 * q], d[4 * q + 1], d[4 * q + 2], d[4 * q + 3]);
-            l_np[t] = np | (side << 8);
-        }
-        __syncthreads();
-        if (owner) {
-            uint32_t lo = max(my_beg, chunk), hi = min(my_end, chunk + WS_THREADS);
-            for (uint32_t ee = lo; ee < hi; ++ee) {
-                uint32_t s = ee - chunk;
-                uint32_t info = l_np[s];
-                uint32_t np = info & 0xFFu;
-                if (np == 0) continue;
-                const bool second = info >> 8;
-                T d[24];
-#pragma unroll
-                for (uint32_t q = 0; q < 6; ++q) { Vec4<T> x = l_d[q][s]; d[4 * q] = x.x; d[4 * q + 1] = x.y; d[4 * q + 2] = x.z; d[4 * q + 3] = x.w; }
+            if (np) {
+                // SolverBodyInertia, or DUMMY for the dominant body (plugin.rs:508-512)
+                const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
+                const V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
+                const Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
+                const V3<T> normal = xyz<T>(cur.h0);
+                const V3<T> t0 = xyz<T>(cur.h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
 #pragma unroll
                 for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
                     if (k < np) {
-                        V3<T> dv{d[6 * k], d[6 * k + 1], d[6 * k + 2]}, dw{d[6 * k + 3], d[6 * k + 4], d[6 * k + 5]};
-                        if (second) { v = v + dv; om = om + dw; }   // body2: v += p * w2 ...
-                        else { v = v - dv; om = om - dw; }           // body1: v -= p * w1 ...
+                        const V3<T> r = xyz<T>(cur.pr[k]);
+                        const Vec4<T> d = cur.pd[k];
+                        const T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
+                        const V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
+                        const V3<T> dv = cmul(imp, inv_mass);
+                        const V3<T> dw = smul(I, cross(r, imp));
+                        if (side) { v = v + dv; om = om + dw; }   // body2: v += p * w2, om += I2 (r2 x p)
+                        else { v = v - dv; om = om - dw; }         // body1: v -= p * w1, om -= I1 (r1 x p)
                     }
                 }
                 touched = true;
             }
         }
-        __syncthreads();
+        cur = nxt; ent_cur = ent_nxt; ent_nxt = ent_nn;
     }
-    if (owner && touched) {
-        w.sb_lin[body] = make4<T>(v, lin_w);
-        w.sb_ang[body] = make4<T>(om, ang_w);
+    if (touched) {
+        w.sb_lin[body] = make4<T>(v, l4.w);
+        w.sb_ang[body] = make4<T>(om, a4.w);
     }
 }
 
@@ -607,7 +581,7 @@ template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const S
 }
 template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
     if (!w.n_bodies) return;
-    uint32_t nb = (w.n_bodies + WS_BODIES - 1) / WS_BODIES;
+    uint32_t nb = (w.n_bodies + WS_THREADS - 1) / WS_THREADS;
     nb = ((nb + 7u) / 8u) * 8u;
     if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
     else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
