@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--scene", default="cfg2_box_stack_100k", choices=sorted(SCENES))
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample")
     args = ap.parse_args()
 
@@ -184,6 +185,27 @@ def main():
                 "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches_per_pass": launches_per_pass,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_pass / launches_per_pass)}
 
+    # ---- PCIe-inclusive step (reported next to `value`, never as `value`): what a host-resident ECS pays when the boundary
+    # hands over host buffers every step — re-upload bodies + the colour-major manifold set, step, download bodies + impulses
+    pcie = None
+    if rank == 0 and world_size == 1 and not args.no_pcie:
+        from avian_amd import scenes
+        n_p = 3
+        w.synchronize()
+        c0 = time.perf_counter()
+        for _ in range(n_p):
+            w.bodies_upload(**sc.body_kwargs())
+            scenes.upload_manifolds(w, meta["manifolds"], meta["offsets"], sc.friction, sc.restitution)
+            w.step()
+            w.bodies_download(); w.impulses_download()
+        w.synchronize()
+        ms_p = (time.perf_counter() - c0) / n_p * 1e3
+        host_bytes = sum(int(np.asarray(v).nbytes) for v in sc.body_kwargs().values() if v is not None) + \
+            sum(int(np.asarray(v).nbytes) for v in meta["manifolds"].values() if hasattr(v, "nbytes"))
+        pcie = {"ms_per_step": round(ms_p, 3), "substeps_per_s": round(substeps / (ms_p / 1e3), 2), "host_bytes_up_per_step": host_bytes,
+                "note": "pageable host arrays through avn_bodies_upload / avn_manifolds_upload / *_download every step (incidence CSR rebuilt on the host); "
+                        "the device-resident path above keeps everything in HBM"}
+
     # ---- CPU baseline: the oracle on the same inputs, rank 0 at N=1 only, bounded sample -------------------------
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -235,6 +257,7 @@ def main():
                           "kernel_launches_per_step": tm.kernel_launches},
             "substep_loop_only_substeps_per_s": round(substeps / (tm.substeps_ms / 1e3), 2) if tm.substeps_ms > 0 else None,
             "roofline": roofline,
+            "pcie_inclusive": pcie,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
