@@ -123,6 +123,19 @@ class avn_colliders(C.Structure):
         "collision_margin", "speculative_margin")]
 
 
+MAX_QUERY_POINTS = 16
+
+
+class avn_shape_pairs(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in (
+        "shape1", "half_extents1", "position1", "rotation1", "shape2", "half_extents2", "position2", "rotation2",
+        "prediction_distance")]
+
+
+class avn_query_manifolds_out(C.Structure):
+    _fields_ = [(n, vp) for n in ("point_count", "normal", "anchor1", "anchor2", "point", "penetration", "feature_id1", "feature_id2")]
+
+
 class avn_pair(C.Structure):
     _fields_ = [("collider1", C.c_uint32), ("collider2", C.c_uint32), ("body1", C.c_int32), ("body2", C.c_int32),
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
@@ -149,7 +162,7 @@ ABI_SYMBOLS = [
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
     "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
-    "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload",
+    "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
 ]
 
 
@@ -192,6 +205,7 @@ class Library:
         f("constraint_graph_lists").argtypes = [vp, vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
         f("islands_partition").argtypes = [C.POINTER(avn_islands_in), vp, vp, C.POINTER(C.c_uint32)]
         f("dynamic_bounds").argtypes = [vp, vp, vp]
+        f("contact_manifolds").argtypes = [vp, vp, vp]
 
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
@@ -434,6 +448,27 @@ class World:
         n = C.c_size_t()
         self._check(self.lib.fn("aabbs_download")(self.handle, _ptr(mn), _ptr(mx), _ptr(ents), C.byref(n)))
         return mn, mx, ents[: n.value]
+
+    def contact_manifolds(self, shape1, half_extents1, position1, rotation1, shape2, half_extents2, position2, rotation2,
+                          prediction_distance):
+        """Batch ``contact_query::contact_manifolds``: dict of point_count [n], normal [n,3], anchor1/anchor2/point
+        [n,16,3], penetration [n,16], feature_id1/2 [n,16]."""
+        dt = self.dtype
+        n = len(shape1)
+        a = lambda x, w: np.ascontiguousarray(np.asarray(x, dt).reshape(n, w))
+        s1 = np.ascontiguousarray(shape1, np.uint8); s2 = np.ascontiguousarray(shape2, np.uint8)
+        h1, p1, r1 = a(half_extents1, 3), a(position1, 3), a(rotation1, 4)
+        h2, p2, r2 = a(half_extents2, 3), a(position2, 3), a(rotation2, 4)
+        pd = np.ascontiguousarray(np.broadcast_to(np.asarray(prediction_distance, dt), (n,)))
+        out = dict(point_count=np.zeros(n, np.uint8), normal=np.zeros((n, 3), dt), anchor1=np.zeros((n, MAX_QUERY_POINTS, 3), dt),
+                   anchor2=np.zeros((n, MAX_QUERY_POINTS, 3), dt), point=np.zeros((n, MAX_QUERY_POINTS, 3), dt),
+                   penetration=np.zeros((n, MAX_QUERY_POINTS), dt), feature_id1=np.zeros((n, MAX_QUERY_POINTS), np.uint32),
+                   feature_id2=np.zeros((n, MAX_QUERY_POINTS), np.uint32))
+        pin = avn_shape_pairs(n, _ptr(s1), _ptr(h1), _ptr(p1), _ptr(r1), _ptr(s2), _ptr(h2), _ptr(p2), _ptr(r2), _ptr(pd))
+        pout = avn_query_manifolds_out(*[_ptr(out[k]) for k in ("point_count", "normal", "anchor1", "anchor2", "point", "penetration",
+                                                               "feature_id1", "feature_id2")])
+        self._check(self.lib.fn("contact_manifolds")(self.handle, C.byref(pin), C.byref(pout)))
+        return out
 
     # -- running -----------------------------------------------------------------------------------------
     def run_system(self, name: str):

@@ -85,6 +85,15 @@ uint32_t sweep_pad_records();
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
+// k_narrow.hip: device staging copies of avn_shape_pairs / avn_query_manifolds_out (host layout, nullptr = not wanted)
+template <class T> struct QueryStage {
+    const uint8_t *shape1, *shape2;
+    const T *half_extents1, *position1, *rotation1, *half_extents2, *position2, *rotation2, *prediction;
+    uint8_t* point_count;
+    T *normal, *anchor1, *anchor2, *point, *penetration;
+    uint32_t *feature_id1, *feature_id2;
+};
+template <class T> void launch_contact_manifolds_query(const QueryStage<T>&, uint32_t n, hipStream_t);
 // k_transfer.hip: host-layout (interleaved xyz) <-> device Vec4 records
 template <class T> struct BodyStage {  // device staging copies of the avn_bodies arrays (nullptr = absent)
     const T *position, *rotation, *linear_velocity, *angular_velocity, *inv_mass, *inv_inertia_local, *center_of_mass, *linear_damping,

@@ -825,6 +825,39 @@ template <class T> struct World : WorldBase {
             for (int k = 0; k < 3; ++k) { mn[k] = std::min(mn[k], (double)h[b * 6 + k]); mx[k] = std::max(mx[k], (double)h[b * 6 + 3 + k]); }
         return AVN_OK;
     }
+    // batch contact_query::contact_manifolds (k_narrow.hip)
+    avn_status contact_manifolds(const avn_shape_pairs* p, const avn_query_manifolds_out* o) override {
+        if (!p || !o || (p->count && (!p->shape1 || !p->shape2 || !p->half_extents1 || !p->half_extents2 || !p->position1 || !p->position2 ||
+                                      !p->rotation1 || !p->rotation2 || !p->prediction_distance))) { error = "contact_manifolds: null array"; return AVN_ERR_BAD_ARG; }
+        size_t n = p->count;
+        for (size_t i = 0; i < n; ++i)
+            if (p->shape1[i] > AVN_SHAPE_BALL || p->shape2[i] > AVN_SHAPE_BALL) { error = "contact_manifolds: unknown shape"; return AVN_ERR_BAD_ARG; }
+        const size_t Q = AVN_MAX_QUERY_POINTS;
+        avn_status st = stage_reserve(al(n) * 3 + al(sizeof(T) * 3 * n) * 5 + al(sizeof(T) * 4 * n) * 2 + al(sizeof(T) * n) + al(sizeof(T) * 3 * Q * n) * 3 +
+                                      al(sizeof(T) * Q * n) + al(4 * Q * n) * 2 + 64 * 32);
+        if (st != AVN_OK) return st;
+        QueryStage<T> s;
+        std::memset(&s, 0, sizeof s);
+        SIN(shape1, p->shape1, n, uint8_t); SIN(shape2, p->shape2, n, uint8_t);
+        SIN(half_extents1, p->half_extents1, 3 * n, T); SIN(position1, p->position1, 3 * n, T); SIN(rotation1, p->rotation1, 4 * n, T);
+        SIN(half_extents2, p->half_extents2, 3 * n, T); SIN(position2, p->position2, 3 * n, T); SIN(rotation2, p->rotation2, 4 * n, T);
+        SIN(prediction, p->prediction_distance, n, T);
+        s.point_count = o->point_count ? stage_alloc<uint8_t>(n) : nullptr;
+        s.normal = o->normal ? stage_alloc<T>(3 * n) : nullptr;
+        s.anchor1 = o->anchor1 ? stage_alloc<T>(3 * Q * n) : nullptr;
+        s.anchor2 = o->anchor2 ? stage_alloc<T>(3 * Q * n) : nullptr;
+        s.point = o->point ? stage_alloc<T>(3 * Q * n) : nullptr;
+        s.penetration = o->penetration ? stage_alloc<T>(Q * n) : nullptr;
+        s.feature_id1 = o->feature_id1 ? stage_alloc<uint32_t>(Q * n) : nullptr;
+        s.feature_id2 = o->feature_id2 ? stage_alloc<uint32_t>(Q * n) : nullptr;
+        launch_contact_manifolds_query<T>(s, (uint32_t)n, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->point_count, s.point_count, n, uint8_t); SOUT(o->normal, s.normal, 3 * n, T);
+        SOUT(o->anchor1, s.anchor1, 3 * Q * n, T); SOUT(o->anchor2, s.anchor2, 3 * Q * n, T); SOUT(o->point, s.point, 3 * Q * n, T);
+        SOUT(o->penetration, s.penetration, Q * n, T); SOUT(o->feature_id1, s.feature_id1, Q * n, uint32_t); SOUT(o->feature_id2, s.feature_id2, Q * n, uint32_t);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
     avn_status update_aabb() {
         launch_update_aabb<T>(dw, bp, params, stream);
         ++launches;

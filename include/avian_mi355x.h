@@ -285,6 +285,37 @@ typedef struct avn_pair {
     uint32_t reserved;
 } avn_pair;
 
+/* ---- narrow phase, part 1: contact_query::contact_manifolds
+ *      (collision/collider/parry/contact_query.rs:156-261, a public function of the reference) for a BATCH of shape pairs.
+ *      Shapes are parry3d Ball / Cuboid; a convex pair yields at most ONE manifold.  Points are returned as the reference
+ *      returns them (before the narrow phase prunes them to 4): anchors in world orientation relative to the collider
+ *      origins, the world-space midpoint, the penetration (negative = separated but within prediction_distance) and
+ *      parry's PackedFeatureIds (collision/contact_types/feature_id.rs).  parry3d / nalgebra are third-party and not
+ *      vendored in the reference tree: their part is implemented from the published algorithm (parity unpinned). ------ */
+#define AVN_MAX_QUERY_POINTS 16
+typedef struct avn_shape_pairs {
+    uint32_t count;
+    const uint8_t* shape1;        /* [n] AVN_SHAPE_* */
+    const void* half_extents1;    /* [3n] cuboid half extents; ball: radius in x */
+    const void* position1;        /* [3n] collider Position */
+    const void* rotation1;        /* [4n] collider Rotation (xyzw) */
+    const uint8_t* shape2;
+    const void* half_extents2;
+    const void* position2;
+    const void* rotation2;
+    const void* prediction_distance; /* [n] */
+} avn_shape_pairs;
+typedef struct avn_query_manifolds_out { /* slot = AVN_MAX_QUERY_POINTS * pair + point; any pointer may be NULL */
+    uint8_t* point_count;   /* [n] 0 = no manifold */
+    void* normal;           /* [3n] world space, from shape 1 towards shape 2 */
+    void* anchor1;          /* [3 * 16n] */
+    void* anchor2;          /* [3 * 16n] */
+    void* point;            /* [3 * 16n] */
+    void* penetration;      /* [16n] */
+    uint32_t* feature_id1;  /* [16n] */
+    uint32_t* feature_id2;  /* [16n] */
+} avn_query_manifolds_out;
+
 /* ---- systems (one id per reference system on the path; for schedule-faithful drivers and
  *      per-kernel parity tests) ---------------------------------------------------------------- */
 typedef enum avn_system {
@@ -376,6 +407,9 @@ AVN_API avn_status AVN_FN(timers_get)(avn_world* w, avn_timers* out);
  * `Instant::now()/elapsed()` accumulation into SolverDiagnostics (solver/plugin.rs:459,481). */
 AVN_API avn_status AVN_FN(profile_system)(avn_world* w, avn_system sys, uint32_t repeats, double* total_ms,
                                            uint32_t* kernel_launches);
+
+/* batch form of contact_query::contact_manifolds (see avn_shape_pairs); scalar type = the world's */
+AVN_API avn_status AVN_FN(contact_manifolds)(avn_world* w, const avn_shape_pairs* pairs, const avn_query_manifolds_out* out);
 
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);

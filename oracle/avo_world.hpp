@@ -23,6 +23,7 @@
 
 #include "../include/avian_mi355x.h"
 #include "avo_math.hpp"
+#include "avo_narrow.hpp"
 
 namespace avo {
 
@@ -281,6 +282,7 @@ struct WorldBase {
     virtual avn_status timers(avn_timers*) = 0;
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
+    virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;
 };
 
 template <class S> struct World : WorldBase {
@@ -1213,6 +1215,32 @@ template <class S> struct World : WorldBase {
             const double lo[3] = {(double)c.aabb.min.x, (double)c.aabb.min.y, (double)c.aabb.min.z};
             const double hi[3] = {(double)c.aabb.max.x, (double)c.aabb.max.y, (double)c.aabb.max.z};
             for (int k = 0; k < 3; ++k) { if (lo[k] < mn[k]) mn[k] = lo[k]; if (hi[k] > mx[k]) mx[k] = hi[k]; }
+        }
+        return AVN_OK;
+    }
+    // contact_query::contact_manifolds for a batch of pairs (avo_narrow.hpp)
+    avn_status contact_manifolds(const avn_shape_pairs* p, const avn_query_manifolds_out* o) override {
+        if (!p || !o || (p->count && (!p->shape1 || !p->shape2 || !p->half_extents1 || !p->half_extents2 || !p->position1 || !p->position2 ||
+                                      !p->rotation1 || !p->rotation2 || !p->prediction_distance))) { error = "contact_manifolds: null array"; return AVN_ERR_BAD_ARG; }
+        auto rdq = [](const void* a, size_t i) { const S* q = (const S*)a + 4 * i; return Q4<S>{q[0], q[1], q[2], q[3]}; };
+        for (size_t i = 0; i < p->count; ++i) {
+            if (p->shape1[i] > AVN_SHAPE_BALL || p->shape2[i] > AVN_SHAPE_BALL) { error = "contact_manifolds: unknown shape"; return AVN_ERR_BAD_ARG; }
+            QueryManifold<S> m;
+            bool has = contact_manifolds_pair<S>(p->shape1[i], rd3(p->half_extents1, i), rd3(p->position1, i), rdq(p->rotation1, i), p->shape2[i],
+                                                 rd3(p->half_extents2, i), rd3(p->position2, i), rdq(p->rotation2, i), ((const S*)p->prediction_distance)[i], m);
+            int n = has ? m.n : 0;
+            if (o->point_count) o->point_count[i] = (uint8_t)n;
+            wr3(o->normal, i, has ? m.normal : vzero<S>());
+            for (int k = 0; k < AVN_MAX_QUERY_POINTS; ++k) {
+                size_t s = (size_t)AVN_MAX_QUERY_POINTS * i + k;
+                bool live = k < n;
+                wr3(o->anchor1, s, live ? m.pts[k].anchor1 : vzero<S>());
+                wr3(o->anchor2, s, live ? m.pts[k].anchor2 : vzero<S>());
+                wr3(o->point, s, live ? m.pts[k].point : vzero<S>());
+                if (o->penetration) ((S*)o->penetration)[s] = live ? m.pts[k].penetration : S(0);
+                if (o->feature_id1) o->feature_id1[s] = live ? m.pts[k].fid1 : 0u;
+                if (o->feature_id2) o->feature_id2[s] = live ? m.pts[k].fid2 : 0u;
+            }
         }
         return AVN_OK;
     }
