@@ -34,7 +34,7 @@ SYSTEMS = [
     "PREPARE_CONTACT_CONSTRAINTS", "PRE_PROCESS_VELOCITY_INCREMENTS", "INTEGRATE_VELOCITIES", "WARM_START",
     "SOLVE_CONTACTS_BIAS", "INTEGRATE_POSITIONS", "SOLVE_CONTACTS_RELAX", "XPBD_SOLVE",
     "XPBD_VELOCITY_PROJECTION", "JOINT_DAMPING", "CLEAR_VELOCITY_INCREMENTS", "SOLVE_RESTITUTION",
-    "WRITEBACK_SOLVER_BODIES", "STORE_CONTACT_IMPULSES", "SUBSTEP", "SOLVER",
+    "WRITEBACK_SOLVER_BODIES", "STORE_CONTACT_IMPULSES", "SUBSTEP", "SOLVER", "NARROW_PHASE",
 ]
 SYS = {name: i for i, name in enumerate(SYSTEMS)}
 
@@ -136,6 +136,27 @@ class avn_query_manifolds_out(C.Structure):
     _fields_ = [(n, vp) for n in ("point_count", "normal", "anchor1", "anchor2", "point", "penetration", "feature_id1", "feature_id2")]
 
 
+CP_TOUCHING, CP_GENERATE_CONSTRAINTS, CP_STATIC1, CP_STATIC2, CP_MODIFY_CONTACTS, CP_CONTACT_EVENTS = 1, 2, 4, 8, 16, 32
+CP_DISJOINT_AABB, CP_STARTED_TOUCHING, CP_STOPPED_TOUCHING, CP_STARTED_GENERATING_CONSTRAINTS = 1 << 8, 1 << 9, 1 << 10, 1 << 11
+COMBINE_AVERAGE, COMBINE_GEOMETRIC_MEAN, COMBINE_MIN, COMBINE_MULTIPLY, COMBINE_MAX = 1, 2, 3, 4, 5
+
+
+class avn_collider_materials(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in ("friction", "restitution", "friction_combine", "restitution_combine")]
+
+
+class avn_contact_pairs(C.Structure):
+    _fields_ = [("count", C.c_uint32)] + [(n, vp) for n in ("contact_id", "collider1", "collider2", "pair_flags")]
+
+
+class avn_contacts_out(C.Structure):
+    _fields_ = [(n, vp) for n in ("flags", "point_count", "normal", "friction", "restitution", "anchor1", "anchor2", "penetration", "normal_speed",
+                                  "warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse", "feature_id1", "feature_id2")]
+
+
+CHANGE_DTYPE = np.dtype([("contact_id", "<u4"), ("flags", "<u4"), ("manifold_count_change", "<i4"), ("manifold_count", "<u4")])
+
+
 class avn_pair(C.Structure):
     _fields_ = [("collider1", C.c_uint32), ("collider2", C.c_uint32), ("body1", C.c_int32), ("body2", C.c_int32),
                 ("flags", C.c_uint32), ("reserved", C.c_uint32)]
@@ -163,6 +184,8 @@ ABI_SYMBOLS = [
     "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
+    "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
+    "contacts_download",
 ]
 
 
@@ -206,6 +229,13 @@ class Library:
         f("islands_partition").argtypes = [C.POINTER(avn_islands_in), vp, vp, C.POINTER(C.c_uint32)]
         f("dynamic_bounds").argtypes = [vp, vp, vp]
         f("contact_manifolds").argtypes = [vp, vp, vp]
+        f("collider_materials_upload").argtypes = [vp, vp]
+        f("contact_pairs_add").argtypes = [vp, vp]
+        f("contact_pairs_remove").argtypes = [vp, vp, C.c_size_t]
+        f("active_pairs_set").argtypes = [vp, vp, C.c_size_t]
+        f("contact_changes_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("manifold_handles_upload").argtypes = [vp, vp, vp]
+        f("contacts_download").argtypes = [vp, vp, C.c_size_t, vp]
 
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
@@ -448,6 +478,54 @@ class World:
         n = C.c_size_t()
         self._check(self.lib.fn("aabbs_download")(self.handle, _ptr(mn), _ptr(mx), _ptr(ents), C.byref(n)))
         return mn, mx, ents[: n.value]
+
+    # -- narrow phase, part 2: the ContactGraph side -----------------------------------------------------------------
+    def collider_materials_upload(self, friction=None, restitution=None, friction_combine=None, restitution_combine=None):
+        dt, c = self.dtype, self.n_colliders
+        a = lambda x, t: None if x is None else np.ascontiguousarray(np.broadcast_to(np.asarray(x, t), (c,)))
+        fr, re, fc, rc = a(friction, dt), a(restitution, dt), a(friction_combine, np.uint8), a(restitution_combine, np.uint8)
+        m = avn_collider_materials(c, _ptr(fr), _ptr(re), _ptr(fc), _ptr(rc))
+        self._check(self.lib.fn("collider_materials_upload")(self.handle, C.byref(m)))
+
+    def contact_pairs_add(self, contact_id, collider1, collider2, pair_flags):
+        ids, c1, c2, fl = (np.ascontiguousarray(x, np.uint32) for x in (contact_id, collider1, collider2, pair_flags))
+        p = avn_contact_pairs(len(ids), _ptr(ids), _ptr(c1), _ptr(c2), _ptr(fl))
+        self._check(self.lib.fn("contact_pairs_add")(self.handle, C.byref(p)))
+
+    def contact_pairs_remove(self, contact_id):
+        ids = np.ascontiguousarray(contact_id, np.uint32)
+        self._check(self.lib.fn("contact_pairs_remove")(self.handle, _ptr(ids), ids.size))
+
+    def active_pairs_set(self, contact_id):
+        ids = np.ascontiguousarray(contact_id, np.uint32)
+        self._check(self.lib.fn("active_pairs_set")(self.handle, _ptr(ids), ids.size))
+
+    def contact_changes_get(self) -> np.ndarray:
+        p, n = vp(), C.c_size_t()
+        self._check(self.lib.fn("contact_changes_get")(self.handle, C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return np.zeros(0, CHANGE_DTYPE)
+        buf = (C.c_char * (n.value * CHANGE_DTYPE.itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=CHANGE_DTYPE).copy()
+
+    def manifold_handles_upload(self, color_offsets, contact_id):
+        off = np.ascontiguousarray(color_offsets, np.uint32); ids = np.ascontiguousarray(contact_id, np.uint32)
+        assert off.size == GRAPH_COLOR_COUNT + 1 and int(off[-1]) == ids.size
+        self._check(self.lib.fn("manifold_handles_upload")(self.handle, _ptr(off), _ptr(ids)))
+        self.n_manifolds = ids.size
+
+    def contacts_download(self, contact_id):
+        ids = np.ascontiguousarray(contact_id, np.uint32)
+        n, dt = ids.size, self.dtype
+        out = dict(flags=np.zeros(n, np.uint32), point_count=np.zeros(n, np.uint8), normal=np.zeros((n, 3), dt), friction=np.zeros(n, dt),
+                   restitution=np.zeros(n, dt), anchor1=np.zeros((n, 4, 3), dt), anchor2=np.zeros((n, 4, 3), dt), penetration=np.zeros((n, 4), dt),
+                   normal_speed=np.zeros((n, 4), dt), warm_start_normal_impulse=np.zeros((n, 4), dt), warm_start_tangent_impulse=np.zeros((n, 4, 2), dt),
+                   normal_impulse=np.zeros((n, 4), dt), feature_id1=np.zeros((n, 4), np.uint32), feature_id2=np.zeros((n, 4), np.uint32))
+        o = avn_contacts_out(*[_ptr(out[k]) for k in ("flags", "point_count", "normal", "friction", "restitution", "anchor1", "anchor2", "penetration",
+                                                      "normal_speed", "warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse",
+                                                      "feature_id1", "feature_id2")])
+        self._check(self.lib.fn("contacts_download")(self.handle, _ptr(ids), n, C.byref(o)))
+        return out
 
     def contact_manifolds(self, shape1, half_extents1, position1, rotation1, shape2, half_extents2, position2, rotation2,
                           prediction_distance):

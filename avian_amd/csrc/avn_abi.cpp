@@ -62,6 +62,13 @@ AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)
 AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD(profile_system(s, r, ms, l)); }
 AVN_API avn_status avn_dynamic_bounds(avn_world* w, double* mn, double* mx) { GUARD(dynamic_bounds(mn, mx)); }
 AVN_API avn_status avn_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { GUARD(contact_manifolds(p, o)); }
+AVN_API avn_status avn_collider_materials_upload(avn_world* w, const avn_collider_materials* m) { GUARD(collider_materials_upload(m)); }
+AVN_API avn_status avn_contact_pairs_add(avn_world* w, const avn_contact_pairs* p) { GUARD(contact_pairs_add(p)); }
+AVN_API avn_status avn_contact_pairs_remove(avn_world* w, const uint32_t* ids, size_t n) { GUARD(contact_pairs_remove(ids, n)); }
+AVN_API avn_status avn_active_pairs_set(avn_world* w, const uint32_t* ids, size_t n) { GUARD(active_pairs_set(ids, n)); }
+AVN_API avn_status avn_contact_changes_get(avn_world* w, const avn_contact_change** o, size_t* n) { GUARD(contact_changes_get(o, n)); }
+AVN_API avn_status avn_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { GUARD(manifold_handles_upload(off, ids)); }
+AVN_API avn_status avn_contacts_download(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_out* o) { GUARD(contacts_download(ids, n, o)); }
 
 // Interaction islands + x-slab assignment (host integer work; see the header).  Union-find with path halving; islands
 // are numbered by their smallest body index; slabs cut the islands, ordered by mean x then id, at equal cumulative weight.

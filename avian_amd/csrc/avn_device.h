@@ -47,6 +47,7 @@ template <class T> struct StepParams {
     T contact_tolerance;        // * length_unit
     T default_speculative_margin;  // * length_unit (Limits::max = unbounded)
     T substeps_as_scalar;
+    T length_unit;              // PhysicsLengthUnit
     SoftCoef<T> soft_dynamic, soft_non_dynamic;
     uint32_t restitution_iterations;
     uint32_t match_contacts;

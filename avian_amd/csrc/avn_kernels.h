@@ -85,6 +85,37 @@ uint32_t sweep_pad_records();
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
+// The ContactGraph side of the narrow phase in HBM: rows indexed by ContactId, one manifold per (convex) pair; the point
+// planes use the same record formats as the solver-side manifold arrays (DW::mp_a1 / mp_a2 / mp_w), so gathering a colour's
+// manifolds by handle is a record copy.
+template <class T> struct CT {
+    uint32_t cap;      // rows allocated = element stride between point planes ([p][row])
+    uint4* meta;       // (collider slot 1, collider slot 2, AVN_CP_* flags, n_manifolds | point_count << 8)
+    int32_t* dcount;   // ContactPair::manifold_count_change
+    Vec4<T>* n;        // (normal.xyz, friction)
+    Vec4<T>* tv;       // (tangent_velocity.xyz, restitution)
+    Vec4<T>* a1;       // [p][row] (anchor1.xyz, penetration)
+    Vec4<T>* a2;       // [p][row] (anchor2.xyz, normal_speed)
+    Vec4<T>* w;        // [p][row] (warm_start_normal, warm_start_tangent.x, .y, normal_impulse)
+    uint2* fid;        // [p][row] (feature_id1, feature_id2)
+    Vec4<T>* col_mat;  // per collider slot: (friction, restitution, bits(friction_combine | restitution_combine << 8), 0)
+};
+template <class T> void launch_init_contact_rows(const CT<T>&, const uint32_t* ids, const uint32_t* slot1, const uint32_t* slot2, const uint32_t* pair_flags, uint32_t n, hipStream_t);
+template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* ids, uint32_t n, hipStream_t);
+// NarrowPhase::update_contacts over the active pairs; changes[0..*n_changes) in arbitrary order (the host sorts by id)
+template <class T> void launch_narrow_phase(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* active, uint32_t n_active,
+                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t);
+// manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
+template <class T> void launch_gather_manifolds(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
+// store_contact_impulses' write into the ContactGraph (plugin.rs:744-749): table row <- DW::mp_w
+template <class T> void launch_scatter_impulses(const DW<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
+template <class T> struct ContactsStage {
+    uint32_t* flags; uint8_t* point_count;
+    T *normal, *friction, *restitution, *anchor1, *anchor2, *penetration, *normal_speed, *warm_n, *warm_t, *normal_impulse;
+    uint32_t *feature_id1, *feature_id2;
+};
+template <class T> void launch_unpack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);
+void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 // k_narrow.hip: device staging copies of avn_shape_pairs / avn_query_manifolds_out (host layout, nullptr = not wanted)
 template <class T> struct QueryStage {
     const uint8_t *shape1, *shape2;

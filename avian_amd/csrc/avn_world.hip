@@ -6,6 +6,7 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <unordered_set>
 
 namespace avn {
 
@@ -109,6 +110,17 @@ template <class T> struct World : WorldBase {
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
     DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
     DevBuf b_inc_off, b_inc_ent;
+    // ---- narrow phase: the ContactGraph side on device (CT) + host mirrors of what the host structures of the reference hold ----
+    CT<T> ct;
+    DevBuf b_ct_meta, b_ct_dcount, b_ct_n, b_ct_tv, b_ct_a1, b_ct_a2, b_ct_w, b_ct_fid, b_col_mat, b_active, b_changes, b_handles;
+    std::unordered_map<uint32_t, uint32_t> entity_slot;   // collider Entity::index() -> slot (last colliders_upload)
+    std::vector<int32_t> h_col_body;                       // body of each collider slot
+    std::vector<uint8_t> h_ct_used;
+    std::vector<uint32_t> h_ct_c1, h_ct_c2;                // collider entities of each row
+    std::vector<avn_contact_change> h_changes;
+    uint32_t n_active = 0;
+    bool use_handles = false, materials_restitution = false, contact_keys_live = false;
+    std::unordered_set<uint64_t> h_live_keys;              // pair keys of the live rows (pair-set rebuilds after removals)
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
@@ -138,6 +150,7 @@ template <class T> struct World : WorldBase {
     World() {
         std::memset(&dw, 0, sizeof dw);
         std::memset(&bp, 0, sizeof bp);
+        std::memset(&ct, 0, sizeof ct);
         std::memset(&last_timers, 0, sizeof last_timers);
         std::memset(color_offsets, 0, sizeof color_offsets);
         std::memset(grid_blocks, 0, sizeof grid_blocks);
@@ -214,6 +227,7 @@ template <class T> struct World : WorldBase {
         T dsm = cfg.default_speculative_margin >= (double)std::numeric_limits<T>::max() ? std::numeric_limits<T>::max() : (T)cfg.default_speculative_margin;
         params.default_speculative_margin = (T)cfg.length_unit * dsm;
         params.substeps_as_scalar = (T)cfg.substeps;
+        params.length_unit = (T)cfg.length_unit;
         params.restitution_iterations = cfg.restitution_iterations;
         params.match_contacts = cfg.match_contacts;
         // update_contact_softness, reference solver/plugin.rs:326-350
@@ -382,35 +396,12 @@ template <class T> struct World : WorldBase {
         }
         any_restitution = false;
         for (uint32_t i = 0; i < M && !any_restitution; ++i) any_restitution = !(((const T*)m->restitution)[i] == T(0));
-        bool moved = false;
-        if (M > cap_manifolds) {
-            HIPCHK(hipStreamSynchronize(stream));
-            size_t c = std::max<size_t>(M, cap_manifolds + cap_manifolds / 2);
-            c = (c + 63) & ~(size_t)63;  // keep every point plane 1 KiB aligned
-            GROW(b_m_bodies, c, dw.m_bodies); GROW(b_m_n, c, dw.m_n); GROW(b_m_tv, c, dw.m_tv); GROW(b_m_meta, c, dw.m_meta);
-            GROW(b_mp_a1, 4 * c, dw.mp_a1); GROW(b_mp_a2, 4 * c, dw.mp_a2); GROW(b_mp_w, 4 * c, dw.mp_w);
-            GROW(b_c_h1, c, dw.c_h1); GROW(b_c_pa, 4 * c, dw.c_pa); GROW(b_c_pb, 4 * c, dw.c_pb); GROW(b_c_pc, 4 * c, dw.c_pc); GROW(b_c_pd, 4 * c, dw.c_pd);
-            GROW(b_c_reldom, c, dw.c_reldom);
-            cap_manifolds = (uint32_t)c;
-            dw.m_stride = cap_manifolds;
-        }
-        if (moved) graph_valid = false;
+        use_handles = false;  // the manifolds come from the host again
+        avn_status st0 = ensure_manifold_capacity(M);
+        if (st0 != AVN_OK) return st0;
+        if (dw.n_manifolds != M) graph_valid = false;
         dw.n_manifolds = M;
-        std::memcpy(color_offsets, m->color_offsets, sizeof color_offsets);
-        // launch grids per colour: the kernels read the live colour ranges from device memory, so a captured grid stays
-        // valid while it still covers the colour; grids are captured with 25 % slack and re-captured when outgrown
-        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
-            uint32_t cnt = color_offsets[c + 1] - color_offsets[c];
-            if (c == AVN_COLOR_OVERFLOW_INDEX) {  // serial kernel: the "grid" is only an on/off flag
-                if (cnt && !grid_blocks[c]) { grid_blocks[c] = 8; graph_valid = false; }
-                continue;
-            }
-            uint32_t need = cnt ? color_grid_blocks(cnt) : 0u;
-            if (need > grid_blocks[c] || grid_blocks[c] > 4 * need + 64) {
-                grid_blocks[c] = cnt ? color_grid_blocks(cnt + cnt / 4 + 64) : 0u;
-                graph_valid = false;
-            }
-        }
+        set_color_offsets(m->color_offsets);
         size_t total = al(4 * (size_t)M) * 2 + al(sizeof(T) * 3 * M) * 2 + al(sizeof(T) * M) * 2 + al(M) * 2 + al(sizeof(T) * 12 * M) * 2 + al(sizeof(T) * 4 * M) * 3 + al(sizeof(T) * 8 * M);
         avn_status st = stage_reserve(total + 64 * 32);
         if (st != AVN_OK) return st;
@@ -689,6 +680,17 @@ template <class T> struct World : WorldBase {
     }
     // (re)build the device pair set from the key list with room for `expect` keys
     avn_status rebuild_pair_set(uint32_t expect) {
+        if (contact_keys_live) {
+            // rows have been removed since the key list was built (contact_pairs_remove): rebuild from the live keys only
+            std::vector<uint64_t> keys(h_live_keys.begin(), h_live_keys.end());
+            hipError_t e2;
+            b_pair_keys.ensure(std::max<size_t>(keys.size(), 1) * 8, e2);
+            if (e2 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            HIPCHK(hipStreamSynchronize(stream));
+            if (!keys.empty()) HIPCHK(hipMemcpy(b_pair_keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+            n_pair_keys = (uint32_t)keys.size();
+            expect = std::max(expect, n_pair_keys + n_pair_keys / 2);
+        }
         uint32_t need = 1024;
         while (need < 2 * (expect + 16)) need <<= 1;
         hipError_t err;
@@ -784,7 +786,254 @@ template <class T> struct World : WorldBase {
         launch_pack_colliders<T>(bp, s, stream);
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
+        entity_slot.clear();
+        entity_slot.reserve((size_t)C * 2);
+        h_col_body.assign(c->body, c->body + C);
+        for (uint32_t i = 0; i < C; ++i) entity_slot.emplace(c->entity_index[i], i);
+        {   // Friction / Restitution defaults until collider_materials_upload: DefaultFriction 0.5, DefaultRestitution 0, Average
+            hipError_t err;
+            b_col_mat.ensure(std::max<size_t>(C, 1) * sizeof(V), err);
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            ct.col_mat = b_col_mat.as<V>();
+            std::vector<V> mats(C, make4<T>(T(0.5), T(0), bits_to_scalar((uint32_t)AVN_COMBINE_AVERAGE | ((uint32_t)AVN_COMBINE_AVERAGE << 8), T(0)), T(0)));
+            if (C) HIPCHK(hipMemcpy(ct.col_mat, mats.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+            materials_restitution = false;
+        }
         have_colliders = true;
+        return AVN_OK;
+    }
+    // ---- narrow phase, part 2 ------------------------------------------------------------------------------------------
+    avn_status collider_materials_upload(const avn_collider_materials* m) override {
+        if (!m || m->count != bp.n_colliders) { error = "collider_materials_upload: count must equal the collider count"; return AVN_ERR_BAD_ARG; }
+        uint32_t C = m->count;
+        std::vector<V> mats(C);
+        materials_restitution = false;
+        for (uint32_t i = 0; i < C; ++i) {
+            T fr = m->friction ? ((const T*)m->friction)[i] : T(0.5), re = m->restitution ? ((const T*)m->restitution)[i] : T(0);
+            uint32_t fc = m->friction_combine ? m->friction_combine[i] : (uint32_t)AVN_COMBINE_AVERAGE, rc = m->restitution_combine ? m->restitution_combine[i] : (uint32_t)AVN_COMBINE_AVERAGE;
+            if (fc < AVN_COMBINE_AVERAGE || fc > AVN_COMBINE_MAX || rc < AVN_COMBINE_AVERAGE || rc > AVN_COMBINE_MAX) { error = "collider_materials_upload: bad combine rule"; return AVN_ERR_BAD_ARG; }
+            mats[i] = make4<T>(fr, re, bits_to_scalar(fc | (rc << 8), T(0)), T(0));
+            if (!(re == T(0))) materials_restitution = true;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        if (C) HIPCHK(hipMemcpy(ct.col_mat, mats.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+        if (use_handles) any_restitution = materials_restitution;
+        return AVN_OK;
+    }
+    avn_status ensure_contact_rows(uint32_t rows) {
+        if (rows <= ct.cap) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t old = ct.cap;
+        size_t c = std::max<size_t>(rows, (size_t)old + old / 2);
+        c = (c + 63) & ~(size_t)63;
+        // grow with contents: the rows are persistent state.  The point planes are [p][row]: re-lay them out for the new stride.
+        auto grow_flat = [&](DevBuf& b, size_t elem, void** field) -> avn_status {
+            hipError_t err;
+            b.ensure(c * elem, err, true, stream);
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            *field = b.p;
+            return AVN_OK;
+        };
+        auto grow_planes = [&](DevBuf& b, size_t elem, void** field) -> avn_status {
+            void* np = nullptr;
+            if (hipMalloc(&np, 4 * c * elem) != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            for (int k = 0; k < 4 && old; ++k)
+                if (hipMemcpy((char*)np + (size_t)k * c * elem, (char*)b.p + (size_t)k * old * elem, (size_t)old * elem, hipMemcpyDeviceToDevice) != hipSuccess) { error = "hipMemcpy failed"; return AVN_ERR_HIP; }
+            if (b.p) (void)hipFree(b.p);
+            b.p = np; b.cap = 4 * c * elem;
+            *field = np;
+            return AVN_OK;
+        };
+        avn_status st;
+        if ((st = grow_flat(b_ct_meta, sizeof(uint4), (void**)&ct.meta)) != AVN_OK) return st;
+        if ((st = grow_flat(b_ct_dcount, sizeof(int32_t), (void**)&ct.dcount)) != AVN_OK) return st;
+        if ((st = grow_flat(b_ct_n, sizeof(V), (void**)&ct.n)) != AVN_OK) return st;
+        if ((st = grow_flat(b_ct_tv, sizeof(V), (void**)&ct.tv)) != AVN_OK) return st;
+        if ((st = grow_planes(b_ct_a1, sizeof(V), (void**)&ct.a1)) != AVN_OK) return st;
+        if ((st = grow_planes(b_ct_a2, sizeof(V), (void**)&ct.a2)) != AVN_OK) return st;
+        if ((st = grow_planes(b_ct_w, sizeof(V), (void**)&ct.w)) != AVN_OK) return st;
+        if ((st = grow_planes(b_ct_fid, sizeof(uint2), (void**)&ct.fid)) != AVN_OK) return st;
+        HIPCHK(hipMemset((char*)ct.meta + (size_t)old * sizeof(uint4), 0, (c - old) * sizeof(uint4)));
+        ct.cap = (uint32_t)c;
+        h_ct_used.resize(c, 0); h_ct_c1.resize(c, 0); h_ct_c2.resize(c, 0);
+        return AVN_OK;
+    }
+    avn_status contact_pairs_add(const avn_contact_pairs* p) override {
+        if (!p || (p->count && (!p->contact_id || !p->collider1 || !p->collider2 || !p->pair_flags))) { error = "contact_pairs_add: null array"; return AVN_ERR_BAD_ARG; }
+        uint32_t n = p->count;
+        if (!n) return AVN_OK;
+        uint32_t max_id = 0;
+        for (uint32_t i = 0; i < n; ++i) max_id = std::max(max_id, p->contact_id[i]);
+        avn_status st = ensure_contact_rows(max_id + 1);
+        if (st != AVN_OK) return st;
+        std::vector<uint32_t> s1(n), s2(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            auto a = entity_slot.find(p->collider1[i]), b = entity_slot.find(p->collider2[i]);
+            if (a == entity_slot.end() || b == entity_slot.end()) { error = "contact_pairs_add: unknown collider"; return AVN_ERR_BAD_ARG; }
+            if (h_ct_used[p->contact_id[i]]) { error = "contact_pairs_add: contact id in use"; return AVN_ERR_STATE; }
+            s1[i] = a->second; s2[i] = b->second;
+        }
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t id = p->contact_id[i];
+            h_ct_used[id] = 1; h_ct_c1[id] = p->collider1[i]; h_ct_c2[id] = p->collider2[i];
+            uint32_t x = p->collider1[i], y = p->collider2[i];
+            h_live_keys.insert(x < y ? ((uint64_t)x << 32) | y : ((uint64_t)y << 32) | x);
+        }
+        contact_keys_live = true;
+        if ((st = stage_reserve(al(4 * (size_t)n) * 4 + 1024)) != AVN_OK) return st;
+        const uint32_t *d_id, *d_s1, *d_s2, *d_pf;
+        if ((st = stage_in<uint32_t>(p->contact_id, n, &d_id)) != AVN_OK) return st;
+        if ((st = stage_in<uint32_t>(s1.data(), n, &d_s1)) != AVN_OK) return st;
+        if ((st = stage_in<uint32_t>(s2.data(), n, &d_s2)) != AVN_OK) return st;
+        if ((st = stage_in<uint32_t>(p->pair_flags, n, &d_pf)) != AVN_OK) return st;
+        launch_init_contact_rows<T>(ct, d_id, d_s1, d_s2, d_pf, n, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status contact_pairs_remove(const uint32_t* ids, size_t n) override {
+        if (n && !ids) return AVN_ERR_BAD_ARG;
+        if (!n) return AVN_OK;
+        std::vector<uint64_t> keys(n);
+        for (size_t i = 0; i < n; ++i) {
+            if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "contact_pairs_remove: no such contact"; return AVN_ERR_STATE; }
+            uint32_t x = h_ct_c1[ids[i]], y = h_ct_c2[ids[i]];
+            keys[i] = x < y ? ((uint64_t)x << 32) | y : ((uint64_t)y << 32) | x;
+        }
+        for (size_t i = 0; i < n; ++i) { h_ct_used[ids[i]] = 0; h_live_keys.erase(keys[i]); }
+        avn_status st = stage_reserve(al(4 * n) + al(8 * n) + 1024);
+        if (st != AVN_OK) return st;
+        const uint32_t* d_id; const uint64_t* d_keys;
+        if ((st = stage_in<uint32_t>(ids, n, &d_id)) != AVN_OK) return st;
+        if ((st = stage_in<uint64_t>(keys.data(), n, &d_keys)) != AVN_OK) return st;
+        launch_clear_contact_rows<T>(ct, d_id, (uint32_t)n, stream);
+        launch_hs_remove(bp.pair_set, bp.pair_set_cap, d_keys, (uint32_t)n, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status active_pairs_set(const uint32_t* ids, size_t n) override {
+        if (n && !ids) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < n; ++i)
+            if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "active_pairs_set: no such contact"; return AVN_ERR_STATE; }
+        HIPCHK(hipStreamSynchronize(stream));
+        hipError_t err;
+        b_active.ensure(std::max<size_t>(n, 1) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_changes.ensure(std::max<size_t>(n, 1) * sizeof(avn_contact_change) + 64, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (n) HIPCHK(hipMemcpy(b_active.p, ids, n * 4, hipMemcpyHostToDevice));
+        n_active = (uint32_t)n;
+        return AVN_OK;
+    }
+    avn_status narrow_phase() {
+        h_changes.clear();
+        if (!n_active) return AVN_OK;
+        uint32_t* d_count = b_misc.as<uint32_t>() + 40;
+        launch_narrow_phase<T>(dw, bp, ct, params, b_active.as<uint32_t>(), n_active, b_changes.as<avn_contact_change>(), d_count, stream);
+        ++launches;
+        HIPCHK(hipGetLastError());
+        uint32_t cnt = 0;
+        HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (cnt) {
+            h_changes.resize(cnt);
+            HIPCHK(hipMemcpy(h_changes.data(), b_changes.p, (size_t)cnt * sizeof(avn_contact_change), hipMemcpyDeviceToHost));
+            // ContactStatusBits are walked in ascending contact id (system_param.rs:141-145)
+            std::sort(h_changes.begin(), h_changes.end(), [](const avn_contact_change& a, const avn_contact_change& b) { return a.contact_id < b.contact_id; });
+        }
+        return AVN_OK;
+    }
+    avn_status contact_changes_get(const avn_contact_change** out, size_t* n) override {
+        if (!out || !n) return AVN_ERR_BAD_ARG;
+        *out = h_changes.data(); *n = h_changes.size();
+        return AVN_OK;
+    }
+    avn_status ensure_manifold_capacity(uint32_t M) {
+        bool moved = false;
+        if (M > cap_manifolds) {
+            HIPCHK(hipStreamSynchronize(stream));
+            size_t c = std::max<size_t>(M, cap_manifolds + cap_manifolds / 2);
+            c = (c + 63) & ~(size_t)63;  // keep every point plane 1 KiB aligned
+            GROW(b_m_bodies, c, dw.m_bodies); GROW(b_m_n, c, dw.m_n); GROW(b_m_tv, c, dw.m_tv); GROW(b_m_meta, c, dw.m_meta);
+            GROW(b_mp_a1, 4 * c, dw.mp_a1); GROW(b_mp_a2, 4 * c, dw.mp_a2); GROW(b_mp_w, 4 * c, dw.mp_w);
+            GROW(b_c_h1, c, dw.c_h1); GROW(b_c_pa, 4 * c, dw.c_pa); GROW(b_c_pb, 4 * c, dw.c_pb); GROW(b_c_pc, 4 * c, dw.c_pc); GROW(b_c_pd, 4 * c, dw.c_pd);
+            GROW(b_c_reldom, c, dw.c_reldom);
+            cap_manifolds = (uint32_t)c;
+            dw.m_stride = cap_manifolds;
+        }
+        if (moved) graph_valid = false;
+        return AVN_OK;
+    }
+    void set_color_offsets(const uint32_t* offsets) {
+        std::memcpy(color_offsets, offsets, sizeof color_offsets);
+        // launch grids per colour: the kernels read the live colour ranges from device memory, so a captured grid stays
+        // valid while it still covers the colour; grids are captured with 25 % slack and re-captured when outgrown
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+            uint32_t cnt = color_offsets[c + 1] - color_offsets[c];
+            if (c == AVN_COLOR_OVERFLOW_INDEX) {  // serial kernel: the "grid" is only an on/off flag
+                if (cnt && !grid_blocks[c]) { grid_blocks[c] = 8; graph_valid = false; }
+                continue;
+            }
+            uint32_t need = cnt ? color_grid_blocks(cnt) : 0u;
+            if (need > grid_blocks[c] || grid_blocks[c] > 4 * need + 64) {
+                grid_blocks[c] = cnt ? color_grid_blocks(cnt + cnt / 4 + 64) : 0u;
+                graph_valid = false;
+            }
+        }
+    }
+    avn_status manifold_handles_upload(const uint32_t* offsets, const uint32_t* ids) override {
+        if (!have_bodies) { error = "manifold_handles_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!offsets || offsets[0] != 0) { error = "manifold_handles_upload: bad offsets"; return AVN_ERR_BAD_ARG; }
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (offsets[c] > offsets[c + 1]) { error = "manifold_handles_upload: offsets not monotone"; return AVN_ERR_BAD_ARG; }
+        uint32_t M = offsets[AVN_GRAPH_COLOR_COUNT];
+        if (M && !ids) return AVN_ERR_BAD_ARG;
+        h_m_body1.resize(M); h_m_body2.resize(M);
+        for (uint32_t i = 0; i < M; ++i) {
+            if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "manifold_handles_upload: no such contact"; return AVN_ERR_STATE; }
+            h_m_body1[i] = h_col_body[entity_slot.at(h_ct_c1[ids[i]])];
+            h_m_body2[i] = h_col_body[entity_slot.at(h_ct_c2[ids[i]])];
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        avn_status st = ensure_manifold_capacity(M);
+        if (st != AVN_OK) return st;
+        if (dw.n_manifolds != M) graph_valid = false;
+        dw.n_manifolds = M;
+        set_color_offsets(offsets);
+        hipError_t err;
+        if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemcpy(dw.color_offsets, color_offsets, sizeof color_offsets, hipMemcpyHostToDevice));
+        if (M) HIPCHK(hipMemcpy(b_handles.p, ids, (size_t)M * 4, hipMemcpyHostToDevice));
+        use_handles = true;
+        any_restitution = materials_restitution;
+        incidence_dirty = true;
+        return AVN_OK;
+    }
+    avn_status contacts_download(const uint32_t* ids, size_t n, const avn_contacts_out* o) override {
+        if (!o || (n && !ids)) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < n; ++i)
+            if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "contacts_download: no such contact"; return AVN_ERR_STATE; }
+        avn_status st = stage_reserve(al(4 * n) * 4 + al(n) + al(sizeof(T) * 3 * n) + al(sizeof(T) * n) * 2 + al(sizeof(T) * 12 * n) * 2 + al(sizeof(T) * 4 * n) * 4 + al(sizeof(T) * 8 * n) + al(16 * n) * 2 + 4096);
+        if (st != AVN_OK) return st;
+        const uint32_t* d_id;
+        if ((st = stage_in<uint32_t>(ids, n, &d_id)) != AVN_OK) return st;
+        ContactsStage<T> s;
+        s.flags = o->flags ? stage_alloc<uint32_t>(n) : nullptr; s.point_count = o->point_count ? stage_alloc<uint8_t>(n) : nullptr;
+        s.normal = o->normal ? stage_alloc<T>(3 * n) : nullptr; s.friction = o->friction ? stage_alloc<T>(n) : nullptr; s.restitution = o->restitution ? stage_alloc<T>(n) : nullptr;
+        s.anchor1 = o->anchor1 ? stage_alloc<T>(12 * n) : nullptr; s.anchor2 = o->anchor2 ? stage_alloc<T>(12 * n) : nullptr;
+        s.penetration = o->penetration ? stage_alloc<T>(4 * n) : nullptr; s.normal_speed = o->normal_speed ? stage_alloc<T>(4 * n) : nullptr;
+        s.warm_n = o->warm_start_normal_impulse ? stage_alloc<T>(4 * n) : nullptr; s.warm_t = o->warm_start_tangent_impulse ? stage_alloc<T>(8 * n) : nullptr;
+        s.normal_impulse = o->normal_impulse ? stage_alloc<T>(4 * n) : nullptr;
+        s.feature_id1 = o->feature_id1 ? stage_alloc<uint32_t>(4 * n) : nullptr; s.feature_id2 = o->feature_id2 ? stage_alloc<uint32_t>(4 * n) : nullptr;
+        launch_unpack_contacts<T>(ct, d_id, (uint32_t)n, s, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->flags, s.flags, n, uint32_t); SOUT(o->point_count, s.point_count, n, uint8_t); SOUT(o->normal, s.normal, 3 * n, T);
+        SOUT(o->friction, s.friction, n, T); SOUT(o->restitution, s.restitution, n, T); SOUT(o->anchor1, s.anchor1, 12 * n, T); SOUT(o->anchor2, s.anchor2, 12 * n, T);
+        SOUT(o->penetration, s.penetration, 4 * n, T); SOUT(o->normal_speed, s.normal_speed, 4 * n, T); SOUT(o->warm_start_normal_impulse, s.warm_n, 4 * n, T);
+        SOUT(o->warm_start_tangent_impulse, s.warm_t, 8 * n, T); SOUT(o->normal_impulse, s.normal_impulse, 4 * n, T);
+        SOUT(o->feature_id1, s.feature_id1, 4 * n, uint32_t); SOUT(o->feature_id2, s.feature_id2, 4 * n, uint32_t);
+        HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
     avn_status pairs_get(const avn_pair** out, size_t* n) override {
@@ -922,6 +1171,7 @@ template <class T> struct World : WorldBase {
             HIPCHK(hipStreamSynchronize(stream));
             std::vector<uint64_t> nk(total);
             for (uint32_t i = 0; i < total; ++i) { uint32_t a = h_pairs[i].collider1, b = h_pairs[i].collider2; nk[i] = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
+            if (contact_keys_live) h_live_keys.insert(nk.begin(), nk.end());
             b_pair_keys.ensure(((size_t)n_pair_keys + total) * 8, err, true, stream);
             if (err != hipSuccess) { error = "pair key list allocation failed"; return AVN_ERR_OOM; }
             HIPCHK(hipMemcpyAsync(b_pair_keys.as<uint64_t>() + n_pair_keys, nk.data(), (size_t)total * 8, hipMemcpyHostToDevice, stream));
@@ -943,7 +1193,15 @@ template <class T> struct World : WorldBase {
     avn_status need_bodies() { if (!have_bodies) { error = "no bodies uploaded"; return AVN_ERR_STATE; } return AVN_OK; }
     void prepare_solver_bodies() { launch_prepare_solver_bodies<T>(dw, stream); ++launches; }
     void prepare_joints() { if (dw.n_joints) { launch_prepare_joints<T>(dw, stream); ++launches; } }
-    void prepare_contact_constraints() { launch_prepare_contact_constraints<T>(dw, params, stream); ++launches; }
+    void prepare_contact_constraints() {
+        // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
+        if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+        launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
+    }
+    void store_contact_impulses() {
+        launch_store_contact_impulses<T>(dw, stream); ++launches;
+        if (use_handles && dw.n_manifolds) { launch_scatter_impulses<T>(dw, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+    }
     void pre_process_velocity_increments() { launch_pre_process_increments<T>(dw, params, stream); ++launches; }
     void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
     // warm start of ALL colours in one body-centric launch; `fused` also runs integrate_velocities for the body first
@@ -1021,7 +1279,7 @@ template <class T> struct World : WorldBase {
         if (any_restitution) contact_pass(PASS_RESTITUTION_);  // restitution == 0 everywhere: every manifold would early-out
         launch_writeback_solver_bodies<T>(dw, stream); ++launches;
         if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
-        launch_store_contact_impulses<T>(dw, stream); ++launches;
+        store_contact_impulses();
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
@@ -1048,7 +1306,8 @@ template <class T> struct World : WorldBase {
                 launch_writeback_solver_bodies<T>(dw, stream); ++launches;
                 if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
                 break;
-            case AVN_SYS_STORE_CONTACT_IMPULSES: launch_store_contact_impulses<T>(dw, stream); ++launches; break;
+            case AVN_SYS_STORE_CONTACT_IMPULSES: store_contact_impulses(); break;
+            case AVN_SYS_NARROW_PHASE: if ((st = narrow_phase()) != AVN_OK) return st; break;
             case AVN_SYS_SUBSTEP: substep(); break;
             case AVN_SYS_SOLVER: {
                 HIPCHK(hipEventRecord(ev[0], stream)); HIPCHK(hipEventRecord(ev[1], stream));

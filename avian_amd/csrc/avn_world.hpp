@@ -72,6 +72,13 @@ struct WorldBase {
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
     virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;
+    virtual avn_status collider_materials_upload(const avn_collider_materials*) = 0;
+    virtual avn_status contact_pairs_add(const avn_contact_pairs*) = 0;
+    virtual avn_status contact_pairs_remove(const uint32_t*, size_t) = 0;
+    virtual avn_status active_pairs_set(const uint32_t*, size_t) = 0;
+    virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
+    virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
+    virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
 };
 
 WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err);

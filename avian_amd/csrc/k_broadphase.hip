@@ -379,6 +379,22 @@ __global__ __launch_bounds__(256) void k_hs_insert_pairs(uint64_t* tab, uint32_t
         h = (h + 1) & cap_mask;
     }
 }
+// removal leaves a tombstone (~0 - 1): probes walk over it, inserts do not reuse it (the host rebuilds the set when it fills)
+__global__ __launch_bounds__(256) void k_hs_remove(uint64_t* tab, uint32_t cap_mask, const uint64_t* __restrict__ keys, uint32_t n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint64_t key = keys[i];
+    uint32_t h = (uint32_t)hs_mix(key) & cap_mask;
+    for (;;) {
+        uint64_t v = tab[h];
+        if (v == key) { tab[h] = ~0ull - 1ull; return; }
+        if (v == ~0ull) return;
+        h = (h + 1) & cap_mask;
+    }
+}
+void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t s) {
+    if (n && cap) hipLaunchKernelGGL(k_hs_remove, dim3((n + 255) / 256), dim3(256), 0, s, tab, cap - 1, keys, n);
+}
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_hs_insert, dim3((n + 255) / 256), dim3(256), 0, s, tab, cap - 1, keys, n);
 }

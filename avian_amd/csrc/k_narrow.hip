@@ -41,3 +41,305 @@ template void launch_contact_manifolds_query<float>(const QueryStage<float>&, ui
 template void launch_contact_manifolds_query<double>(const QueryStage<double>&, uint32_t, hipStream_t);
 
 }  // namespace avn
+
+// =====================================================================================================================
+// Part 2: NarrowPhase::update_contacts over the device-resident contact table
+// (reference collision/narrow_phase/system_param.rs:437-830; ContactManifold::{prune_points, match_contacts}
+//  collision/contact_types/mod.rs:425-566; CoefficientCombine dynamics/rigid_body/physics_material.rs:28-36,205-214,372-380)
+// =====================================================================================================================
+namespace avn {
+
+template <class T> struct NpPt {  // ContactPoint being built
+    V3<T> anchor1, anchor2;
+    T penetration, normal_speed, warm_n, warm_tx, warm_ty;
+    uint32_t fid1, fid2;
+};
+
+template <class T> __device__ __forceinline__ T np_combine(T a, uint32_t ra, T b, uint32_t rb) {
+    uint32_t rule = ra > rb ? ra : rb;
+    if (rule == AVN_COMBINE_GEOMETRIC_MEAN) return sqrt_t(a * b);
+    if (rule == AVN_COMBINE_MIN) return smin(a, b);
+    if (rule == AVN_COMBINE_MULTIPLY) return a * b;
+    if (rule == AVN_COMBINE_MAX) return smax(a, b);
+    return (a + b) * T(0.5);
+}
+
+// ContactManifold::prune_points: indices of the (up to four) points to keep, in the reference's output order
+template <class T> __device__ int np_prune_points(const NpPt<T>* pts, V3<T> normal, int n, int* keep) {
+    const T MIN_DISTANCE_SQUARED = T(1e-6);
+    V3<T> projected[AVN_NP_MAX_RAW];
+    T pen_sq[AVN_NP_MAX_RAW];
+    for (int i = 0; i < n; ++i) {
+        projected[i] = pts[i].anchor1 - normal * dot(pts[i].anchor1, normal);
+        pen_sq[i] = smax(pts[i].penetration * pts[i].penetration, MIN_DISTANCE_SQUARED);
+    }
+    int p1 = 0;
+    T value = -Limits<T>::max;
+    for (int i = 0; i < n; ++i) {
+        T v = smax(length_squared(projected[i]), MIN_DISTANCE_SQUARED) * pen_sq[i];
+        if (v > value) { value = v; p1 = i; }
+    }
+    int p2 = -1;
+    T max_distance = -Limits<T>::max;
+    for (int i = 0; i < n; ++i) {
+        if (i == p1) continue;
+        T v = smax(length_squared(projected[i] - projected[p1]), MIN_DISTANCE_SQUARED) * pen_sq[i];
+        if (v > max_distance) { max_distance = v; p2 = i; }
+    }
+    int p3 = -1, p4 = -1;
+    T min_value = T(0), max_value = T(0);
+    V3<T> perp = cross(projected[p2] - projected[p1], normal);
+    for (int i = 0; i < n; ++i) {
+        if (i == p1 || i == p2) continue;
+        T v = dot(perp, projected[i] - projected[p1]);
+        if (v < min_value) { min_value = v; p3 = i; }
+        else if (v > max_value) { max_value = v; p4 = i; }
+    }
+    int k = 0;
+    keep[k++] = p1;
+    if (p3 >= 0) keep[k++] = p3;
+    keep[k++] = p2;
+    if (p4 >= 0) keep[k++] = p4;
+    return k;
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
+                                                     avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes) {
+    uint32_t a = blockIdx.x * 64 + threadIdx.x;
+    if (a >= n_active) return;
+    const uint32_t c = active[a];
+    uint4 meta = ct.meta[c];
+    const uint32_t slot1 = meta.x, slot2 = meta.y;
+    uint32_t flags = meta.z;
+    const uint32_t old_nman = meta.w & 0xFFu, old_pc = (meta.w >> 8) & 0xFFu;
+    bool status = false;
+    int32_t dcount = ct.dcount[c];
+    uint32_t n_manifolds = old_nman, point_count = old_pc;
+    const uint4 ci1 = bp.col_info[slot1], ci2 = bp.col_info[slot2];  // (entity, body, shape | cflags << 8, -)
+    const uint2 ly1 = bp.col_layers[slot1], ly2 = bp.col_layers[slot2];
+    const Vec4<T> mn1 = bp.aabb_min[slot1], mx1 = bp.aabb_max[slot1], mn2 = bp.aabb_min[slot2], mx2 = bp.aabb_max[slot2];
+    const bool overlap = mn1.x <= mx2.x && mx1.x >= mn2.x && mn1.y <= mx2.y && mx1.y >= mn2.y && mn1.z <= mx2.z && mx1.z >= mn2.z;
+    const bool interacts = (ly1.x & ly2.y) != 0 && (ly2.x & ly1.y) != 0;
+    if (!overlap || !interacts) {
+        flags |= AVN_CP_DISJOINT_AABB;
+        status = true;
+    } else {
+        const int body1 = (int)ci1.y, body2 = (int)ci2.y;
+        const uint32_t bm1 = w.bmeta[body1], bm2 = w.bmeta[body2];
+        const bool have1 = !(meta_flags(bm1) & AVN_BODY_DISABLED), have2 = !(meta_flags(bm2) & AVN_BODY_DISABLED);
+        const Vec4<T> pos1 = w.pos[body1], pos2 = w.pos[body2], rot1 = w.rot[body1], rot2 = w.rot[body2];
+        const bool is_static1 = have1 && meta_rb_type(bm1) == AVN_RB_STATIC, is_static2 = have2 && meta_rb_type(bm2) == AVN_RB_STATIC;
+        const V3<T> x1 = xyz<T>(pos1), x2 = xyz<T>(pos2);
+        const Q4<T> q1 = quat<T>(rot1), q2 = quat<T>(rot2);
+        // the collider sits on the body entity: collider.position - body.position
+        const V3<T> collider_offset1 = have1 ? x1 - x1 : vzero<T>(), collider_offset2 = have2 ? x2 - x2 : vzero<T>();
+        const V3<T> world_com1 = have1 ? qrot(q1, xyz<T>(w.com[body1])) : vzero<T>(), world_com2 = have2 ? qrot(q2, xyz<T>(w.com[body2])) : vzero<T>();
+        V3<T> lin_vel1 = have1 ? xyz<T>(w.lvel[body1]) : vzero<T>(), lin_vel2 = have2 ? xyz<T>(w.lvel[body2]) : vzero<T>();
+        const V3<T> ang_vel1 = have1 ? xyz<T>(w.avel[body1]) : vzero<T>(), ang_vel2 = have2 ? xyz<T>(w.avel[body2]) : vzero<T>();
+        flags = (flags & ~(uint32_t)(AVN_CP_STATIC1 | AVN_CP_STATIC2)) | (is_static1 ? (uint32_t)AVN_CP_STATIC1 : 0u) | (is_static2 ? (uint32_t)AVN_CP_STATIC2 : 0u);
+        const uint32_t cf1 = (ci1.z >> 8) & 0xFFu, cf2 = (ci2.z >> 8) & 0xFFu;
+        const bool is_disabled = !have1 || !have2 || (cf1 & AVN_COLLIDER_SENSOR) || (cf2 & AVN_COLLIDER_SENSOR);
+        if (!is_disabled && !(flags & AVN_CP_GENERATE_CONSTRAINTS)) { flags |= AVN_CP_STARTED_GENERATING_CONSTRAINTS; status = true; }
+        flags = is_disabled ? (flags & ~(uint32_t)AVN_CP_GENERATE_CONSTRAINTS) : (flags | AVN_CP_GENERATE_CONSTRAINTS);
+        const Vec4<T> m1 = ct.col_mat[slot1], m2 = ct.col_mat[slot2];
+        const uint32_t r1 = scalar_to_bits(m1.z), r2 = scalar_to_bits(m2.z);
+        const T friction = np_combine<T>(m1.x, r1 & 0xFFu, m2.x, r2 & 0xFFu);
+        const T restitution = np_combine<T>(m1.y, (r1 >> 8) & 0xFFu, m2.y, (r2 >> 8) & 0xFFu);
+        const Vec4<T> he1 = bp.col_he[slot1], he2 = bp.col_he[slot2];  // (half_extents, collision_margin)
+        const T collision_margin_sum = he1.w + he2.w;
+        const T sp1 = bp.col_spec[slot1], sp2 = bp.col_spec[slot2];
+        const T speculative_margin1 = sp1 >= T(0) ? sp1 : p.default_speculative_margin, speculative_margin2 = sp2 >= T(0) ? sp2 : p.default_speculative_margin;
+        const T delta_secs = p.dt_adj;
+        const T inv_delta_secs = T(1) / delta_secs;
+        if (speculative_margin1 < Limits<T>::max) lin_vel1 = clamp_length_max(lin_vel1, speculative_margin1 * inv_delta_secs);
+        if (speculative_margin2 < Limits<T>::max) lin_vel2 = clamp_length_max(lin_vel2, speculative_margin2 * inv_delta_secs);
+        const V3<T> relative_linear_velocity = lin_vel2 - lin_vel1;
+        const T effective_speculative_margin = delta_secs * length(relative_linear_velocity);
+        const T max_contact_distance = smax(effective_speculative_margin, p.contact_tolerance) + collision_margin_sum;
+        const bool was_touching = flags & AVN_CP_TOUCHING;
+        // old_manifolds = contacts.manifolds.clone(): only what match_contacts reads
+        V3<T> old_a1[AVN_MAX_MANIFOLD_POINTS], old_a2[AVN_MAX_MANIFOLD_POINTS];
+        T old_wn[AVN_MAX_MANIFOLD_POINTS], old_wx[AVN_MAX_MANIFOLD_POINTS], old_wy[AVN_MAX_MANIFOLD_POINTS];
+        uint2 old_fid[AVN_MAX_MANIFOLD_POINTS];
+        const uint32_t old_n = old_nman ? old_pc : 0u;
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
+            if (k < old_n) {
+                size_t s = (size_t)k * ct.cap + c;
+                Vec4<T> oa = ct.a1[s], ob = ct.a2[s], ow = ct.w[s];
+                old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid[s];
+            }
+        NpManifold<T> qm;
+        const bool has = contact_manifolds_pair<T>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, qm);
+        NpPt<T> kept[AVN_NP_MAX_RAW];
+        int nk = 0;
+        if (has)
+            for (int k = 0; k < qm.n; ++k) {
+                NpPt<T> pt;
+                pt.anchor1 = (qm.pts[k].anchor1 + collider_offset1) - world_com1;
+                pt.anchor2 = (qm.pts[k].anchor2 + collider_offset2) - world_com2;
+                pt.penetration = qm.pts[k].penetration + collision_margin_sum;
+                V3<T> relative_velocity = (relative_linear_velocity + cross(ang_vel2, pt.anchor2)) - cross(ang_vel1, pt.anchor1);
+                pt.normal_speed = dot(relative_velocity, qm.normal);
+                pt.warm_n = T(0); pt.warm_tx = T(0); pt.warm_ty = T(0);
+                pt.fid1 = qm.pts[k].fid1; pt.fid2 = qm.pts[k].fid2;
+                bool keep = -pt.penetration < effective_speculative_margin || (pt.normal_speed * delta_secs - pt.penetration < effective_speculative_margin);
+                if (keep) kept[nk++] = pt;
+            }
+        int order[AVN_MAX_MANIFOLD_POINTS] = {0, 1, 2, 3};
+        n_manifolds = 0; point_count = 0;
+        if (nk > 0) {
+            point_count = nk > 4 ? (uint32_t)np_prune_points<T>(kept, qm.normal, nk, order) : (uint32_t)nk;
+            n_manifolds = 1;
+        }
+        const bool touching = n_manifolds != 0;
+        flags = touching ? (flags | AVN_CP_TOUCHING) : (flags & ~(uint32_t)AVN_CP_TOUCHING);
+        if (touching) {
+            const T thr = T(0.1) * p.length_unit;
+            const T thr2 = thr * thr;
+            ct.n[c] = make4<T>(qm.normal, friction);
+            ct.tv[c] = make4<T>(T(0), T(0), T(0), restitution);
+            for (uint32_t k = 0; k < point_count; ++k) {
+                NpPt<T> pt = kept[order[k]];
+                if (p.match_contacts && old_n) {  // ContactManifold::match_contacts
+                    for (uint32_t j = 0; j < old_n; ++j) {
+                        if ((pt.fid1 == old_fid[j].x && pt.fid2 == old_fid[j].y) || (pt.fid2 == old_fid[j].x && pt.fid1 == old_fid[j].y)) {
+                            pt.warm_n = old_wn[j]; pt.warm_tx = old_wx[j]; pt.warm_ty = old_wy[j];
+                            break;
+                        }
+                        const bool unknown = pt.fid1 == 0u || pt.fid2 == 0u;
+                        if ((unknown && (length_squared(pt.anchor1 - old_a1[j]) < thr2 && length_squared(pt.anchor2 - old_a2[j]) < thr2)) ||
+                            (length_squared(pt.anchor1 - old_a2[j]) < thr2 && length_squared(pt.anchor2 - old_a1[j]) < thr2)) {
+                            pt.warm_n = old_wn[j]; pt.warm_tx = old_wx[j]; pt.warm_ty = old_wy[j];
+                            break;
+                        }
+                    }
+                }
+                size_t s = (size_t)k * ct.cap + c;
+                ct.a1[s] = make4<T>(pt.anchor1, pt.penetration);
+                ct.a2[s] = make4<T>(pt.anchor2, pt.normal_speed);
+                ct.w[s] = make4<T>(pt.warm_n, pt.warm_tx, pt.warm_ty, T(0));  // ContactPoint::new: normal_impulse = 0
+                ct.fid[s] = make_uint2(pt.fid1, pt.fid2);
+            }
+        }
+        dcount = (int32_t)n_manifolds - (int32_t)old_nman;
+        if (touching && !was_touching) { flags |= AVN_CP_STARTED_TOUCHING; status = true; }
+        else if (!touching && was_touching) { flags |= AVN_CP_STOPPED_TOUCHING; status = true; }
+        else if (dcount != 0) status = true;
+    }
+    if (status) {
+        uint32_t slot = atomicAdd(n_changes, 1u);
+        avn_contact_change ch;
+        ch.contact_id = c; ch.flags = flags; ch.manifold_count_change = dcount; ch.manifold_count = n_manifolds;
+        changes[slot] = ch;
+    }
+    // the transient status flags are handled (and cleared) by the host's status processing, system_param.rs:141-389
+    const uint32_t kept_flags = flags & ~(uint32_t)(AVN_CP_STARTED_TOUCHING | AVN_CP_STOPPED_TOUCHING | AVN_CP_STARTED_GENERATING_CONSTRAINTS);
+    ct.meta[c] = make_uint4(slot1, slot2, kept_flags, n_manifolds | (point_count << 8));
+    ct.dcount[c] = dcount;
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_init_contact_rows(CT<T> ct, const uint32_t* __restrict__ ids, const uint32_t* __restrict__ s1, const uint32_t* __restrict__ s2,
+                                                           const uint32_t* __restrict__ pf, uint32_t n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f = pf[i];
+    uint32_t flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
+                     ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u);
+    ct.meta[ids[i]] = make_uint4(s1[i], s2[i], flags, 0u);
+    ct.dcount[ids[i]] = 0;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_clear_contact_rows(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ct.meta[ids[i]] = make_uint4(0u, 0u, 0u, 0u);
+    ct.dcount[ids[i]] = 0;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_gather_manifolds(DW<T> w, BP<T> bp, CT<T> ct, const uint32_t* __restrict__ handles) {
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= w.n_manifolds) return;
+    const uint32_t c = handles[m];
+    const uint4 meta = ct.meta[c];
+    const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
+    w.m_bodies[m] = make_int2((int)bp.col_info[meta.x].y, (int)bp.col_info[meta.y].y);
+    w.m_n[m] = ct.n[c];
+    w.m_tv[m] = ct.tv[c];
+    w.m_meta[m] = np | (((meta.z & AVN_CP_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0u) << 8);
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        size_t s = (size_t)k * ct.cap + c, d = (size_t)k * w.m_stride + m;
+        w.mp_a1[d] = ct.a1[s]; w.mp_a2[d] = ct.a2[s]; w.mp_w[d] = ct.w[s];
+    }
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_scatter_impulses(DW<T> w, CT<T> ct, const uint32_t* __restrict__ handles) {
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= w.n_manifolds) return;
+    const uint32_t c = handles[m];
+    const uint32_t np = scalar_to_bits(w.c_h1[m].w) & 7u;  // points the constraint has (0 = constraint absent: nothing stored)
+    for (uint32_t k = 0; k < np; ++k) ct.w[(size_t)k * ct.cap + c] = w.mp_w[(size_t)k * w.m_stride + m];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n, ContactsStage<T> o) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = ids[i];
+    const uint4 meta = ct.meta[c];
+    const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
+    if (o.flags) o.flags[i] = meta.z;
+    if (o.point_count) o.point_count[i] = (uint8_t)np;
+    Vec4<T> n4 = np ? ct.n[c] : make4<T>(0, 0, 0, 0), tv = np ? ct.tv[c] : make4<T>(0, 0, 0, 0);
+    st3(o.normal, i, xyz<T>(n4));
+    if (o.friction) o.friction[i] = n4.w;
+    if (o.restitution) o.restitution[i] = tv.w;
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        size_t s = (size_t)k * ct.cap + c, d = 4 * (size_t)i + k;
+        const bool live = k < np;
+        Vec4<T> a1 = live ? ct.a1[s] : make4<T>(0, 0, 0, 0), a2 = live ? ct.a2[s] : make4<T>(0, 0, 0, 0), ww = live ? ct.w[s] : make4<T>(0, 0, 0, 0);
+        uint2 f = live ? ct.fid[s] : make_uint2(0u, 0u);
+        st3(o.anchor1, d, xyz<T>(a1)); st3(o.anchor2, d, xyz<T>(a2));
+        if (o.penetration) o.penetration[d] = a1.w;
+        if (o.normal_speed) o.normal_speed[d] = a2.w;
+        if (o.warm_n) o.warm_n[d] = ww.x;
+        if (o.warm_t) { o.warm_t[2 * d] = ww.y; o.warm_t[2 * d + 1] = ww.z; }
+        if (o.normal_impulse) o.normal_impulse[d] = ww.w;
+        if (o.feature_id1) o.feature_id1[d] = f.x;
+        if (o.feature_id2) o.feature_id2[d] = f.y;
+    }
+}
+
+template <class T> void launch_init_contact_rows(const CT<T>& ct, const uint32_t* ids, const uint32_t* s1, const uint32_t* s2, const uint32_t* pf, uint32_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_init_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, s1, s2, pf, n);
+}
+template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_t* ids, uint32_t n, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_clear_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n);
+}
+template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
+                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
+    (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
+    if (n_active) hipLaunchKernelGGL(k_narrow_phase<T>, dim3((n_active + 63) / 64), dim3(64), 0, st, w, bp, ct, p, active, n_active, changes, n_changes);
+}
+template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
+    if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);
+}
+template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
+    if (w.n_manifolds) hipLaunchKernelGGL(k_scatter_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, ct, handles);
+}
+template <class T> void launch_unpack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& o, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_unpack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, o);
+}
+#define INST(T)                                                                                                                                      \
+    template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
+    template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
+    template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
+    template void launch_gather_manifolds<T>(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                  \
+    template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
+    template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace avn

@@ -316,6 +316,64 @@ typedef struct avn_query_manifolds_out { /* slot = AVN_MAX_QUERY_POINTS * pair +
     uint32_t* feature_id2;  /* [16n] */
 } avn_query_manifolds_out;
 
+/* ---- narrow phase, part 2: the ContactGraph side kept on device ----------------------------
+ *      NarrowPhase::update_contacts (collision/narrow_phase/system_param.rs:437-830) runs as AVN_SYS_NARROW_PHASE over a
+ *      device-resident table of contact pairs indexed by the reference's ContactId (contact_graph.rs, id_pool.rs); the
+ *      manifolds it produces stay in HBM and feed prepare_contact_constraints through a colour-major list of handles
+ *      (= GraphColor::manifold_handles, constraint_graph.rs:66-80), so that per step only STATUS CHANGES cross the bus.
+ *      The host keeps what the reference keeps in host structures: ContactId allocation, the ConstraintGraph, events.
+ *      Convex pairs only (Ball / Cuboid): one manifold per pair, manifold index 0.  CollisionHooks::modify_contacts is not
+ *      called (the library cannot call back): pairs flagged AVN_PAIR_MODIFY_CONTACTS are processed unmodified. */
+/* ContactPairFlags (contact_types/mod.rs) as stored per table row; bits 8.. are this step's status outputs */
+enum { AVN_CP_TOUCHING = 1, AVN_CP_GENERATE_CONSTRAINTS = 2, AVN_CP_STATIC1 = 4, AVN_CP_STATIC2 = 8, AVN_CP_MODIFY_CONTACTS = 16,
+       AVN_CP_CONTACT_EVENTS = 32,
+       AVN_CP_DISJOINT_AABB = 1 << 8, AVN_CP_STARTED_TOUCHING = 1 << 9, AVN_CP_STOPPED_TOUCHING = 1 << 10,
+       AVN_CP_STARTED_GENERATING_CONSTRAINTS = 1 << 11 };
+/* CoefficientCombine (dynamics/rigid_body/physics_material.rs:13-24) */
+enum { AVN_COMBINE_AVERAGE = 1, AVN_COMBINE_GEOMETRIC_MEAN = 2, AVN_COMBINE_MIN = 3, AVN_COMBINE_MULTIPLY = 4, AVN_COMBINE_MAX = 5 };
+/* Friction / Restitution per collider, RESOLVED by the host (collider component, else the body's, else the Default*
+ * resource: system_param.rs:596-620), in collider upload order */
+typedef struct avn_collider_materials {
+    uint32_t count;                     /* must equal the collider count */
+    const void* friction;               /* [C] dynamic_coefficient; NULL = 0.5 */
+    const void* restitution;            /* [C] coefficient; NULL = 0.0 */
+    const uint8_t* friction_combine;    /* [C] AVN_COMBINE_*; NULL = AVERAGE */
+    const uint8_t* restitution_combine; /* [C] NULL = AVERAGE */
+} avn_collider_materials;
+/* ContactGraph::add_edge_and_key_with (contact_types/contact_graph.rs:521-566): new rows, not touching, no manifolds */
+typedef struct avn_contact_pairs {
+    uint32_t count;
+    const uint32_t* contact_id;  /* [n] ContactId chosen by the host (lowest free, id_pool.rs:31-40) */
+    const uint32_t* collider1;   /* [n] Entity::index() */
+    const uint32_t* collider2;
+    const uint32_t* pair_flags;  /* [n] AVN_PAIR_* as returned by the broad phase */
+} avn_contact_pairs;
+/* one entry per contact pair whose ContactStatusBits bit is set after AVN_SYS_NARROW_PHASE, ascending contact_id
+ * (the order system_param.rs:141-145 processes them in) */
+typedef struct avn_contact_change {
+    uint32_t contact_id;
+    uint32_t flags;                 /* AVN_CP_* */
+    int32_t manifold_count_change;  /* ContactPair::manifold_count_change */
+    uint32_t manifold_count;        /* manifolds the pair has now (0 | 1) */
+} avn_contact_change;
+/* inspection of table rows (ContactPair::manifolds[0] + flags), slot = 4 * i + p */
+typedef struct avn_contacts_out {
+    uint32_t* flags;          /* [n] AVN_CP_* */
+    uint8_t* point_count;     /* [n] */
+    void* normal;             /* [3n] */
+    void* friction;           /* [n] */
+    void* restitution;        /* [n] */
+    void* anchor1;            /* [3*4n] relative to the centre of mass of body1 */
+    void* anchor2;            /* [3*4n] */
+    void* penetration;        /* [4n] */
+    void* normal_speed;       /* [4n] */
+    void* warm_start_normal_impulse;   /* [4n] */
+    void* warm_start_tangent_impulse;  /* [2*4n] */
+    void* normal_impulse;     /* [4n] */
+    uint32_t* feature_id1;    /* [4n] */
+    uint32_t* feature_id2;    /* [4n] */
+} avn_contacts_out;
+
 /* ---- systems (one id per reference system on the path; for schedule-faithful drivers and
  *      per-kernel parity tests) ---------------------------------------------------------------- */
 typedef enum avn_system {
@@ -339,6 +397,7 @@ typedef enum avn_system {
     AVN_SYS_STORE_CONTACT_IMPULSES = 17,    /* solver/plugin.rs:722-755 */
     AVN_SYS_SUBSTEP = 18,                   /* one run of SubstepSchedule (systems 6..13 in order) */
     AVN_SYS_SOLVER = 19,                    /* PhysicsStepSystems::Solver: 2..5, S x SUBSTEP, 14..17 */
+    AVN_SYS_NARROW_PHASE = 20,              /* NarrowPhase::update_contacts, narrow_phase/system_param.rs:437-830 */
     AVN_SYS_COUNT_
 } avn_system;
 
@@ -410,6 +469,22 @@ AVN_API avn_status AVN_FN(profile_system)(avn_world* w, avn_system sys, uint32_t
 
 /* batch form of contact_query::contact_manifolds (see avn_shape_pairs); scalar type = the world's */
 AVN_API avn_status AVN_FN(contact_manifolds)(avn_world* w, const avn_shape_pairs* pairs, const avn_query_manifolds_out* out);
+
+AVN_API avn_status AVN_FN(collider_materials_upload)(avn_world* w, const avn_collider_materials* m);
+AVN_API avn_status AVN_FN(contact_pairs_add)(avn_world* w, const avn_contact_pairs* p);
+/* ContactGraph::remove_edge_by_id: the rows are freed (ids may be reused by a later _add) and the pairs' keys leave the
+ * broad phase's pair set */
+AVN_API avn_status AVN_FN(contact_pairs_remove)(avn_world* w, const uint32_t* contact_id, size_t n);
+/* ContactGraph::active_pairs (the pairs update_contacts iterates) */
+AVN_API avn_status AVN_FN(active_pairs_set)(avn_world* w, const uint32_t* contact_id, size_t n);
+/* status changes of the last AVN_SYS_NARROW_PHASE; buffer owned by the world, valid until the next call */
+AVN_API avn_status AVN_FN(contact_changes_get)(avn_world* w, const avn_contact_change** out, size_t* n_out);
+/* GraphColor::manifold_handles of all colours (colour-major, manifold index 0 implied): from now on
+ * prepare_contact_constraints reads its manifolds from the contact table through these handles, and
+ * store_contact_impulses writes the impulses back to it.  Replaces avn_manifolds_upload for worlds that run the device
+ * narrow phase; n = color_offsets[24]. */
+AVN_API avn_status AVN_FN(manifold_handles_upload)(avn_world* w, const uint32_t* color_offsets, const uint32_t* contact_id);
+AVN_API avn_status AVN_FN(contacts_download)(avn_world* w, const uint32_t* contact_id, size_t n, const avn_contacts_out* out);
 
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);

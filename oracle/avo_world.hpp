@@ -283,6 +283,13 @@ struct WorldBase {
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
     virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;
+    virtual avn_status collider_materials_upload(const avn_collider_materials*) = 0;
+    virtual avn_status contact_pairs_add(const avn_contact_pairs*) = 0;
+    virtual avn_status contact_pairs_remove(const uint32_t*, size_t) = 0;
+    virtual avn_status active_pairs_set(const uint32_t*, size_t) = 0;
+    virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
+    virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
+    virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
 };
 
 template <class S> struct World : WorldBase {
@@ -307,6 +314,31 @@ template <class S> struct World : WorldBase {
     std::vector<avn_pair> pairs;
     avn_timers last_timers;
     bool have_colliders = false;
+    // ---- the ContactGraph side of the narrow phase (rows indexed by ContactId) ----
+    struct CtPoint {  // ContactPoint, contact_types/mod.rs:603-660
+        V3<S> anchor1, anchor2;
+        S penetration, normal_speed, warm_start_normal_impulse, normal_impulse;
+        V2<S> warm_start_tangent_impulse;
+        uint32_t feature_id1, feature_id2;
+    };
+    struct CtRow {    // ContactPair (+ its single manifold: convex shapes)
+        bool used = false;
+        uint32_t collider1 = 0, collider2 = 0;  // Entity::index()
+        uint32_t flags = 0;                      // AVN_CP_*
+        int32_t manifold_count_change = 0;
+        uint32_t n_manifolds = 0;                // 0 | 1
+        V3<S> normal{0, 0, 0};
+        S friction = 0, restitution = 0;
+        int point_count = 0;
+        CtPoint pts[AVN_MAX_MANIFOLD_POINTS];
+    };
+    std::vector<CtRow> contact_rows;
+    std::vector<uint32_t> active_pairs;
+    std::vector<avn_contact_change> contact_changes;
+    std::vector<uint32_t> manifold_handles;  // colour-major contact ids; empty = manifolds come from manifolds_upload
+    bool use_handles = false;
+    struct Material { S friction, restitution; uint8_t friction_combine, restitution_combine; };
+    std::vector<Material> materials;         // per collider slot
 
     World() { std::memset(&last_timers, 0, sizeof last_timers); std::memset(color_offsets, 0, sizeof color_offsets); }
 
@@ -696,6 +728,7 @@ template <class S> struct World : WorldBase {
 
     // ContactConstraint::generate, contact/mod.rs:110-220; driver solver/plugin.rs:363-448
     void prepare_contact_constraints() {
+        if (use_handles) gather_manifolds_from_handles();
         update_contact_softness();  // runs .before(NarrowPhase) every step, plugin.rs:108,326-350
         bool warm = cfg.match_contacts != 0;
         uint32_t count = 0;
@@ -855,6 +888,10 @@ template <class S> struct World : WorldBase {
     }
     // solver/plugin.rs:722-755
     void store_contact_impulses() {
+        store_contact_impulses_to_manifolds();
+        if (use_handles) scatter_impulses_to_contacts();
+    }
+    void store_contact_impulses_to_manifolds() {
         for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
             for (ContactConstraint<S>& k : color_constraints[c]) {
                 ContactManifold<S>& m = manifolds[k.manifold];
@@ -1244,6 +1281,284 @@ template <class S> struct World : WorldBase {
         }
         return AVN_OK;
     }
+    // ---- narrow phase, part 2 ------------------------------------------------------------------------------------------
+    avn_status collider_materials_upload(const avn_collider_materials* m) override {
+        if (!m || m->count != colliders.size()) { error = "collider_materials_upload: count must equal the collider count"; return AVN_ERR_BAD_ARG; }
+        materials.resize(m->count);
+        for (uint32_t i = 0; i < m->count; ++i)
+            materials[i] = {rd<S>(m->friction, i, S(0.5)), rd<S>(m->restitution, i, S(0)), rd<uint8_t>(m->friction_combine, i, AVN_COMBINE_AVERAGE),
+                            rd<uint8_t>(m->restitution_combine, i, AVN_COMBINE_AVERAGE)};
+        return AVN_OK;
+    }
+    Material material_of(uint32_t slot) const { return slot < materials.size() ? materials[slot] : Material{S(0.5), S(0), AVN_COMBINE_AVERAGE, AVN_COMBINE_AVERAGE}; }
+    // CoefficientCombine::mix (physics_material.rs:28-36) under the higher-priority rule (:205-214, :372-380)
+    static S combine(S a, uint8_t ra, S b, uint8_t rb) {
+        uint8_t rule = ra > rb ? ra : rb;
+        switch (rule) {
+            case AVN_COMBINE_GEOMETRIC_MEAN: return std::sqrt(a * b);
+            case AVN_COMBINE_MIN: return smin(a, b);
+            case AVN_COMBINE_MULTIPLY: return a * b;
+            case AVN_COMBINE_MAX: return smax(a, b);
+            default: return (a + b) * S(0.5);
+        }
+    }
+    avn_status contact_pairs_add(const avn_contact_pairs* p) override {  // contact_graph.rs:521-566
+        if (!p || (p->count && (!p->contact_id || !p->collider1 || !p->collider2 || !p->pair_flags))) { error = "contact_pairs_add: null array"; return AVN_ERR_BAD_ARG; }
+        for (uint32_t i = 0; i < p->count; ++i) {
+            if (!collider_slot.count(p->collider1[i]) || !collider_slot.count(p->collider2[i])) { error = "contact_pairs_add: unknown collider"; return AVN_ERR_BAD_ARG; }
+            uint32_t id = p->contact_id[i];
+            if (id >= contact_rows.size()) contact_rows.resize((size_t)id + 1);
+            if (contact_rows[id].used) { error = "contact_pairs_add: contact id in use"; return AVN_ERR_STATE; }
+            CtRow r;
+            r.used = true; r.collider1 = p->collider1[i]; r.collider2 = p->collider2[i];
+            uint32_t f = p->pair_flags[i];
+            r.flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
+                      ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u);
+            contact_rows[id] = r;
+        }
+        return AVN_OK;
+    }
+    avn_status contact_pairs_remove(const uint32_t* ids, size_t n) override {
+        if (n && !ids) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < n; ++i) {
+            if (ids[i] >= contact_rows.size() || !contact_rows[ids[i]].used) { error = "contact_pairs_remove: no such contact"; return AVN_ERR_STATE; }
+            CtRow& r = contact_rows[ids[i]];
+            pair_set.erase(pair_key(r.collider1, r.collider2));
+            r = CtRow();
+        }
+        return AVN_OK;
+    }
+    avn_status active_pairs_set(const uint32_t* ids, size_t n) override {
+        if (n && !ids) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < n; ++i)
+            if (ids[i] >= contact_rows.size() || !contact_rows[ids[i]].used) { error = "active_pairs_set: no such contact"; return AVN_ERR_STATE; }
+        active_pairs.assign(ids, ids + n);
+        return AVN_OK;
+    }
+    avn_status contact_changes_get(const avn_contact_change** out, size_t* n) override {
+        if (!out || !n) return AVN_ERR_BAD_ARG;
+        *out = contact_changes.data(); *n = contact_changes.size();
+        return AVN_OK;
+    }
+    avn_status manifold_handles_upload(const uint32_t* offsets, const uint32_t* ids) override {
+        if (!offsets || offsets[0] != 0) { error = "manifold_handles_upload: bad offsets"; return AVN_ERR_BAD_ARG; }
+        uint32_t M = offsets[AVN_GRAPH_COLOR_COUNT];
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (offsets[c] > offsets[c + 1]) { error = "manifold_handles_upload: offsets not monotone"; return AVN_ERR_BAD_ARG; }
+        if (M && !ids) return AVN_ERR_BAD_ARG;
+        for (uint32_t i = 0; i < M; ++i)
+            if (ids[i] >= contact_rows.size() || !contact_rows[ids[i]].used) { error = "manifold_handles_upload: no such contact"; return AVN_ERR_STATE; }
+        manifold_handles.assign(ids, ids + M);
+        std::memcpy(color_offsets, offsets, sizeof color_offsets);
+        use_handles = true;
+        return AVN_OK;
+    }
+    avn_status contacts_download(const uint32_t* ids, size_t n, const avn_contacts_out* o) override {
+        if (!o || (n && !ids)) return AVN_ERR_BAD_ARG;
+        for (size_t i = 0; i < n; ++i) {
+            if (ids[i] >= contact_rows.size() || !contact_rows[ids[i]].used) { error = "contacts_download: no such contact"; return AVN_ERR_STATE; }
+            const CtRow& r = contact_rows[ids[i]];
+            int np = r.n_manifolds ? r.point_count : 0;
+            if (o->flags) o->flags[i] = r.flags;
+            if (o->point_count) o->point_count[i] = (uint8_t)np;
+            wr3(o->normal, i, np ? r.normal : vzero<S>());
+            if (o->friction) ((S*)o->friction)[i] = np ? r.friction : S(0);
+            if (o->restitution) ((S*)o->restitution)[i] = np ? r.restitution : S(0);
+            for (int k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                size_t s = 4 * i + k;
+                bool live = k < np;
+                const CtPoint& c = r.pts[k];
+                wr3(o->anchor1, s, live ? c.anchor1 : vzero<S>()); wr3(o->anchor2, s, live ? c.anchor2 : vzero<S>());
+                if (o->penetration) ((S*)o->penetration)[s] = live ? c.penetration : S(0);
+                if (o->normal_speed) ((S*)o->normal_speed)[s] = live ? c.normal_speed : S(0);
+                if (o->warm_start_normal_impulse) ((S*)o->warm_start_normal_impulse)[s] = live ? c.warm_start_normal_impulse : S(0);
+                if (o->warm_start_tangent_impulse) { ((S*)o->warm_start_tangent_impulse)[2 * s] = live ? c.warm_start_tangent_impulse.x : S(0); ((S*)o->warm_start_tangent_impulse)[2 * s + 1] = live ? c.warm_start_tangent_impulse.y : S(0); }
+                if (o->normal_impulse) ((S*)o->normal_impulse)[s] = live ? c.normal_impulse : S(0);
+                if (o->feature_id1) o->feature_id1[s] = live ? c.feature_id1 : 0u;
+                if (o->feature_id2) o->feature_id2[s] = live ? c.feature_id2 : 0u;
+            }
+        }
+        return AVN_OK;
+    }
+    // ContactManifold::prune_points (contact_types/mod.rs:477-566) on the index set `idx` (n > 4): returns the kept order
+    static int prune_points(const CtPoint* pts, V3<S> normal, int n, int* keep) {
+        const S MIN_DISTANCE_SQUARED = S(1e-6);
+        V3<S> projected[AVO_MAX_RAW_POINTS];
+        S pen_sq[AVO_MAX_RAW_POINTS];
+        for (int i = 0; i < n; ++i) {
+            projected[i] = pts[i].anchor1 - normal * dot(pts[i].anchor1, normal);  // reject_from_normalized
+            pen_sq[i] = smax(pts[i].penetration * pts[i].penetration, MIN_DISTANCE_SQUARED);
+        }
+        int p1 = 0;
+        S value = -std::numeric_limits<S>::max();  // Scalar::MIN
+        for (int i = 0; i < n; ++i) {
+            S v = smax(length_squared(projected[i]), MIN_DISTANCE_SQUARED) * pen_sq[i];
+            if (v > value) { value = v; p1 = i; }
+        }
+        int p2 = -1;
+        S max_distance = -std::numeric_limits<S>::max();
+        for (int i = 0; i < n; ++i) {
+            if (i == p1) continue;
+            S v = smax(length_squared(projected[i] - projected[p1]), MIN_DISTANCE_SQUARED) * pen_sq[i];
+            if (v > max_distance) { max_distance = v; p2 = i; }
+        }
+        int p3 = -1, p4 = -1;
+        S min_value = S(0), max_value = S(0);
+        V3<S> perp = cross(projected[p2] - projected[p1], normal);
+        for (int i = 0; i < n; ++i) {
+            if (i == p1 || i == p2) continue;
+            S v = dot(perp, projected[i] - projected[p1]);
+            if (v < min_value) { min_value = v; p3 = i; }
+            else if (v > max_value) { max_value = v; p4 = i; }
+        }
+        int k = 0;
+        keep[k++] = p1;
+        if (p3 >= 0) keep[k++] = p3;
+        keep[k++] = p2;
+        if (p4 >= 0) keep[k++] = p4;
+        return k;
+    }
+    // NarrowPhase::update_contacts, narrow_phase/system_param.rs:437-830 (hooks are not called; no islands / events here)
+    void narrow_phase() {
+        contact_changes.clear();
+        const S delta_secs = dt_adj;
+        const S default_speculative_margin = (S)cfg.length_unit * (cfg.default_speculative_margin >= (double)std::numeric_limits<S>::max() ? std::numeric_limits<S>::max() : (S)cfg.default_speculative_margin);
+        const S contact_tolerance = (S)cfg.length_unit * (S)cfg.contact_tolerance;
+        for (uint32_t id : active_pairs) {
+            CtRow& r = contact_rows[id];
+            bool status = false;
+            auto i1 = collider_slot.find(r.collider1), i2 = collider_slot.find(r.collider2);
+            if (i1 == collider_slot.end() || i2 == collider_slot.end()) continue;  // collider_query.get_many failed
+            const Collider<S>& c1 = colliders[i1->second]; const Collider<S>& c2 = colliders[i2->second];
+            bool overlap = c1.aabb.min.x <= c2.aabb.max.x && c1.aabb.max.x >= c2.aabb.min.x && c1.aabb.min.y <= c2.aabb.max.y && c1.aabb.max.y >= c2.aabb.min.y &&
+                           c1.aabb.min.z <= c2.aabb.max.z && c1.aabb.max.z >= c2.aabb.min.z;  // ColliderAabb::intersects, collider/mod.rs:539-544
+            bool interacts = (c1.memberships & c2.filters) != 0 && (c2.memberships & c1.filters) != 0;
+            if (!overlap || !interacts) {
+                r.flags |= AVN_CP_DISJOINT_AABB;
+                status = true;
+            } else {
+                const Body<S>& b1 = bodies[c1.body]; const Body<S>& b2 = bodies[c2.body];
+                const bool have1 = !(b1.body_flags & AVN_BODY_DISABLED), have2 = !(b2.body_flags & AVN_BODY_DISABLED);  // Without<RigidBodyDisabled>
+                // the collider sits on the body entity: collider.position = body.position
+                bool is_static1 = have1 && b1.rb_type == AVN_RB_STATIC, is_static2 = have2 && b2.rb_type == AVN_RB_STATIC;
+                V3<S> collider_offset1 = have1 ? b1.position - b1.position : vzero<S>(), collider_offset2 = have2 ? b2.position - b2.position : vzero<S>();
+                V3<S> world_com1 = have1 ? qrot(b1.rotation, b1.center_of_mass) : vzero<S>(), world_com2 = have2 ? qrot(b2.rotation, b2.center_of_mass) : vzero<S>();
+                V3<S> lin_vel1 = have1 ? b1.linear_velocity : vzero<S>(), lin_vel2 = have2 ? b2.linear_velocity : vzero<S>();
+                V3<S> ang_vel1 = have1 ? b1.angular_velocity : vzero<S>(), ang_vel2 = have2 ? b2.angular_velocity : vzero<S>();
+                r.flags = (r.flags & ~(uint32_t)(AVN_CP_STATIC1 | AVN_CP_STATIC2)) | (is_static1 ? (uint32_t)AVN_CP_STATIC1 : 0u) | (is_static2 ? (uint32_t)AVN_CP_STATIC2 : 0u);
+                bool is_disabled = !have1 || !have2 || (c1.cflags & AVN_COLLIDER_SENSOR) || (c2.cflags & AVN_COLLIDER_SENSOR);
+                if (!is_disabled && !(r.flags & AVN_CP_GENERATE_CONSTRAINTS)) { r.flags |= AVN_CP_STARTED_GENERATING_CONSTRAINTS; status = true; }
+                r.flags = is_disabled ? (r.flags & ~(uint32_t)AVN_CP_GENERATE_CONSTRAINTS) : (r.flags | AVN_CP_GENERATE_CONSTRAINTS);
+                Material m1 = material_of(i1->second), m2 = material_of(i2->second);
+                S friction = combine(m1.friction, m1.friction_combine, m2.friction, m2.friction_combine);
+                S restitution = combine(m1.restitution, m1.restitution_combine, m2.restitution, m2.restitution_combine);
+                S collision_margin_sum = c1.collision_margin + c2.collision_margin;
+                S speculative_margin1 = c1.speculative_margin >= S(0) ? c1.speculative_margin : default_speculative_margin;
+                S speculative_margin2 = c2.speculative_margin >= S(0) ? c2.speculative_margin : default_speculative_margin;
+                S inv_delta_secs = S(1) / delta_secs;
+                if (speculative_margin1 < std::numeric_limits<S>::max()) lin_vel1 = clamp_length_max(lin_vel1, speculative_margin1 * inv_delta_secs);
+                if (speculative_margin2 < std::numeric_limits<S>::max()) lin_vel2 = clamp_length_max(lin_vel2, speculative_margin2 * inv_delta_secs);
+                V3<S> relative_linear_velocity = lin_vel2 - lin_vel1;
+                S effective_speculative_margin = delta_secs * length(relative_linear_velocity);
+                S max_contact_distance = smax(effective_speculative_margin, contact_tolerance) + collision_margin_sum;
+                bool was_touching = r.flags & AVN_CP_TOUCHING;
+                CtRow old = r;  // old_manifolds = contacts.manifolds.clone()
+                QueryManifold<S> qm;
+                bool has = contact_manifolds_pair<S>(c1.shape, c1.half_extents, b1.position, b1.rotation, c2.shape, c2.half_extents, b2.position, b2.rotation, max_contact_distance, qm);
+                // retain_mut over the (at most one) manifold
+                CtPoint kept[AVO_MAX_RAW_POINTS];
+                int nk = 0;
+                if (has) {
+                    for (int k = 0; k < qm.n; ++k) {
+                        CtPoint pt;
+                        pt.anchor1 = (qm.pts[k].anchor1 + collider_offset1) - world_com1;
+                        pt.anchor2 = (qm.pts[k].anchor2 + collider_offset2) - world_com2;
+                        pt.penetration = qm.pts[k].penetration + collision_margin_sum;
+                        V3<S> relative_velocity = (relative_linear_velocity + cross(ang_vel2, pt.anchor2)) - cross(ang_vel1, pt.anchor1);
+                        pt.normal_speed = dot(relative_velocity, qm.normal);
+                        pt.warm_start_normal_impulse = 0; pt.normal_impulse = 0; pt.warm_start_tangent_impulse = {0, 0};
+                        pt.feature_id1 = qm.pts[k].fid1; pt.feature_id2 = qm.pts[k].fid2;
+                        bool keep = -pt.penetration < effective_speculative_margin || (pt.normal_speed * delta_secs - pt.penetration < effective_speculative_margin);
+                        if (keep) kept[nk++] = pt;
+                    }
+                }
+                r.n_manifolds = 0; r.point_count = 0;
+                if (nk > 0) {
+                    r.normal = qm.normal; r.friction = friction; r.restitution = restitution;
+                    if (nk > 4) {
+                        int keep[4];
+                        int k4 = prune_points(kept, qm.normal, nk, keep);
+                        for (int k = 0; k < k4; ++k) r.pts[k] = kept[keep[k]];
+                        r.point_count = k4;
+                    } else {
+                        for (int k = 0; k < nk; ++k) r.pts[k] = kept[k];
+                        r.point_count = nk;
+                    }
+                    r.n_manifolds = 1;
+                }
+                bool touching = r.n_manifolds != 0;
+                r.flags = touching ? (r.flags | AVN_CP_TOUCHING) : (r.flags & ~(uint32_t)AVN_CP_TOUCHING);
+                if (r.n_manifolds <= 4 && cfg.match_contacts && touching && old.n_manifolds) {
+                    // ContactManifold::match_contacts (contact_types/mod.rs:425-475)
+                    S thr = S(0.1) * (S)cfg.length_unit;
+                    S thr2 = thr * thr;  // distance_threshold.powi(2)
+                    for (int k = 0; k < r.point_count; ++k) {
+                        CtPoint& c = r.pts[k];
+                        for (int j = 0; j < old.point_count; ++j) {
+                            const CtPoint& pc = old.pts[j];
+                            if ((c.feature_id1 == pc.feature_id1 && c.feature_id2 == pc.feature_id2) || (c.feature_id2 == pc.feature_id1 && c.feature_id1 == pc.feature_id2)) {
+                                c.warm_start_normal_impulse = pc.warm_start_normal_impulse; c.warm_start_tangent_impulse = pc.warm_start_tangent_impulse;
+                                break;
+                            }
+                            bool unknown = c.feature_id1 == 0u || c.feature_id2 == 0u;
+                            if ((unknown && (length_squared(c.anchor1 - pc.anchor1) < thr2 && length_squared(c.anchor2 - pc.anchor2) < thr2)) ||
+                                (length_squared(c.anchor1 - pc.anchor2) < thr2 && length_squared(c.anchor2 - pc.anchor1) < thr2)) {
+                                c.warm_start_normal_impulse = pc.warm_start_normal_impulse; c.warm_start_tangent_impulse = pc.warm_start_tangent_impulse;
+                                break;
+                            }
+                        }
+                    }
+                }
+                r.manifold_count_change = (int32_t)r.n_manifolds - (int32_t)old.n_manifolds;
+                if (touching && !was_touching) { r.flags |= AVN_CP_STARTED_TOUCHING; status = true; }
+                else if (!touching && was_touching) { r.flags |= AVN_CP_STOPPED_TOUCHING; status = true; }
+                else if (r.manifold_count_change != 0) status = true;
+            }
+            if (status) contact_changes.push_back({id, r.flags, r.manifold_count_change, r.n_manifolds});
+        }
+        std::sort(contact_changes.begin(), contact_changes.end(), [](const avn_contact_change& a, const avn_contact_change& b) { return a.contact_id < b.contact_id; });
+        // the status processing of system_param.rs:141-389 clears these once handled (host side); here they are per-step outputs
+        for (const avn_contact_change& c : contact_changes)
+            contact_rows[c.contact_id].flags &= ~(uint32_t)(AVN_CP_STARTED_TOUCHING | AVN_CP_STOPPED_TOUCHING | AVN_CP_STARTED_GENERATING_CONSTRAINTS);
+    }
+    // the manifolds prepare_contact_constraints reads through GraphColor::manifold_handles (plugin.rs:389-398)
+    void gather_manifolds_from_handles() {
+        manifolds.resize(manifold_handles.size());
+        for (size_t i = 0; i < manifold_handles.size(); ++i) {
+            const CtRow& r = contact_rows[manifold_handles[i]];
+            ContactManifold<S>& m = manifolds[i];
+            m.body1 = colliders[collider_slot.at(r.collider1)].body;
+            m.body2 = colliders[collider_slot.at(r.collider2)].body;
+            m.normal = r.normal; m.tangent_velocity = vzero<S>();
+            m.friction = r.friction; m.restitution = r.restitution;
+            m.point_count = (uint8_t)(r.n_manifolds ? r.point_count : 0);
+            m.flags = (r.flags & AVN_CP_GENERATE_CONSTRAINTS) ? AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0;
+            for (int k = 0; k < m.point_count; ++k) {
+                const CtPoint& c = r.pts[k];
+                m.points[k] = {c.anchor1, c.anchor2, c.penetration, c.normal_speed, c.warm_start_normal_impulse, c.normal_impulse, c.warm_start_tangent_impulse};
+            }
+        }
+    }
+    void scatter_impulses_to_contacts() {
+        for (size_t i = 0; i < manifold_handles.size(); ++i) {
+            CtRow& r = contact_rows[manifold_handles[i]];
+            const ContactManifold<S>& m = manifolds[i];
+            for (int k = 0; k < m.point_count; ++k) {
+                r.pts[k].warm_start_normal_impulse = m.points[k].warm_start_normal_impulse;
+                r.pts[k].warm_start_tangent_impulse = m.points[k].warm_start_tangent_impulse;
+                r.pts[k].normal_impulse = m.points[k].normal_impulse;
+            }
+        }
+    }
     avn_status aabbs_download(void* mn, void* mx, uint32_t* ents, size_t* n_iv) override {
         for (size_t i = 0; i < colliders.size(); ++i) { wr3(mn, i, colliders[i].aabb.min); wr3(mx, i, colliders[i].aabb.max); }
         if (ents) for (size_t i = 0; i < intervals.size(); ++i) ents[i] = colliders[intervals[i].collider].entity;
@@ -1417,6 +1732,7 @@ template <class S> struct World : WorldBase {
             case AVN_SYS_STORE_CONTACT_IMPULSES: store_contact_impulses(); break;
             case AVN_SYS_SUBSTEP: substep(); break;
             case AVN_SYS_SOLVER: solver(); break;
+            case AVN_SYS_NARROW_PHASE: narrow_phase(); break;
             default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
         }
         return AVN_OK;

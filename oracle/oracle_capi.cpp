@@ -48,6 +48,13 @@ avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
 avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
 avn_status avo_dynamic_bounds(avn_world* w, double* mn, double* mx) { FWD(dynamic_bounds(mn, mx)); }
 avn_status avo_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { FWD(contact_manifolds(p, o)); }
+avn_status avo_collider_materials_upload(avn_world* w, const avn_collider_materials* m) { FWD(collider_materials_upload(m)); }
+avn_status avo_contact_pairs_add(avn_world* w, const avn_contact_pairs* p) { FWD(contact_pairs_add(p)); }
+avn_status avo_contact_pairs_remove(avn_world* w, const uint32_t* ids, size_t n) { FWD(contact_pairs_remove(ids, n)); }
+avn_status avo_active_pairs_set(avn_world* w, const uint32_t* ids, size_t n) { FWD(active_pairs_set(ids, n)); }
+avn_status avo_contact_changes_get(avn_world* w, const avn_contact_change** o, size_t* n) { FWD(contact_changes_get(o, n)); }
+avn_status avo_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { FWD(manifold_handles_upload(off, ids)); }
+avn_status avo_contacts_download(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_out* o) { FWD(contacts_download(ids, n, o)); }
 // Checker for avn_islands_partition (header).  Deliberately a DIFFERENT algorithm from the product's union-find:
 // breadth-first flood fill over an adjacency list, islands discovered in ascending body index (= numbered by their
 // smallest member), then the same slab rule (reference island statistics: islands/mod.rs:213-232).
