@@ -133,7 +133,7 @@ template <class T> struct World : WorldBase {
     std::vector<int32_t> h_m_body1, h_m_body2;  // ContactPair bodies of the uploaded manifolds (incidence CSR source)
     bool incidence_dirty = true;
     bool joint_schedule_dirty = true;
-    JointSchedule sched_solve, sched_damp;
+    JointSchedule sched_solve, sched_damp, sched_overflow;
     bool any_damped = false;
     bool any_restitution = false;  // some manifold has restitution != 0 (else apply_restitution early-outs for all, contact/mod.rs:366-369)
     std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
@@ -456,6 +456,25 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipMemcpyAsync(b_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, stream));
         if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));  // `off` / `ent` are locals
+        {   // level schedule of the overflow colour (k_overflow_pass): keys = the bodies a manifold can modify
+            uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], o1 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
+            std::vector<uint32_t> ms(o1 - o0);
+            std::vector<int32_t> k1(o1 - o0), k2(o1 - o0);
+            for (uint32_t m = o0; m < o1; ++m) {
+                ms[m - o0] = m;
+                k1[m - o0] = h_body_has_sb[h_m_body1[m]] ? h_m_body1[m] : -1;
+                k2[m - o0] = h_body_has_sb[h_m_body2[m]] ? h_m_body2[m] : -1;
+            }
+            uint32_t before = sched_overflow.n_components;
+            sched_overflow.build(ms, k1, k2, N);
+            void* p0 = sched_overflow.d_order.p; void* p1 = sched_overflow.d_level_offsets.p; void* p2 = sched_overflow.d_comp_level_begin.p;
+            avn_status st;
+            if ((st = upload_u32(sched_overflow.d_comp_level_begin, sched_overflow.comp_level_begin)) != AVN_OK) return st;
+            if ((st = upload_u32(sched_overflow.d_level_offsets, sched_overflow.level_offsets)) != AVN_OK) return st;
+            if ((st = upload_u32(sched_overflow.d_order, sched_overflow.order)) != AVN_OK) return st;
+            HIPCHK(hipStreamSynchronize(stream));
+            if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p) graph_valid = false;
+        }
         incidence_dirty = false;
         return AVN_OK;
     }
@@ -1210,7 +1229,12 @@ template <class T> struct World : WorldBase {
         else if (fused) integrate_velocities();
     }
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
-    void contact_pass(int pass) { if (dw.n_manifolds) launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, stream); }
+    void contact_pass(int pass) {
+        if (!dw.n_manifolds) return;
+        OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
+                             sched_overflow.d_order.as<uint32_t>()};
+        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, ovf, stream);
+    }
     // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
     // installed (xpbd/plugin.rs:61-76,192-240).  With no joints the projection adds 2 * (dq * conj(dq)).xyz / h:
     //  - f32 (glam's SIMD `Quat`, pairwise sums): every xyz component cancels exactly, e.g. y = (-wy + xz) + (yw - zx) is

@@ -535,13 +535,22 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepPar
     if (m >= end) return;
     pass_one<T, PASS>(w, p, m);
 }
-// The overflow colour: strictly serial in manifold_handles order (solver/plugin.rs:461-467).
+// The overflow colour: the reference solves it strictly serially in manifold_handles order (solver/plugin.rs:461-467).
+// Only the relative order of manifolds that SHARE A BODY can change a result, so the host turns the list into a level
+// schedule (JointSchedule: level(m) = 1 + max level of the earlier overflow manifolds that share a body with m; connected
+// components are independent): one workgroup per component walks its levels in order, the manifolds of a level run in
+// parallel, a workgroup barrier separates levels.  Every body still sees its overflow manifolds in list order: the result is
+// bit-identical to the serial loop, without serialising a dense pile's few thousand overflow contacts on one lane.
+#define OVERFLOW_THREADS 256
 template <class T, int PASS>
-__global__ __launch_bounds__(64) void k_overflow_pass(DW<T> w, StepParams<T> p) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    uint32_t base = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX], end = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
-    for (uint32_t m = base; m < end; ++m) {
-        pass_one<T, PASS>(w, p, m);  // same thread: program order makes the previous manifold's body writes visible
+__global__ __launch_bounds__(OVERFLOW_THREADS) void k_overflow_pass(DW<T> w, StepParams<T> p, const uint32_t* __restrict__ comp_level_begin,
+                                                                    const uint32_t* __restrict__ level_offsets, const uint32_t* __restrict__ order) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t l0 = comp_level_begin[c], l1 = comp_level_begin[c + 1];
+    for (uint32_t l = l0; l < l1; ++l) {
+        const uint32_t k0 = level_offsets[l], k1 = level_offsets[l + 1];
+        for (uint32_t k = k0 + threadIdx.x; k < k1; k += OVERFLOW_THREADS) pass_one<T, PASS>(w, p, order[k]);
+        __syncthreads();  // same CU: the level's body writes are in its L1 / L2 before the next level gathers them
     }
 }
 
@@ -572,9 +581,12 @@ uint32_t color_grid_blocks(uint32_t count) {
     uint32_t nb = (count + CONTACT_THREADS - 1) / CONTACT_THREADS;
     return ((nb + 7u) / 8u) * 8u;
 }
-template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, hipStream_t s) {
+template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const OverflowSchedule& ovf, hipStream_t s) {
     uint32_t launches = 0;
-    if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX]) { hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(1), dim3(64), 0, s, w, p); ++launches; }
+    if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_components) {
+        hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(ovf.n_components), dim3(OVERFLOW_THREADS), 0, s, w, p, ovf.comp_level_begin, ovf.level_offsets, ovf.order);
+        ++launches;
+    }
     for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
         if (grid_blocks[c]) { hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c); ++launches; }
     return launches;
@@ -586,12 +598,12 @@ template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<
     if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
     else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
 }
-template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, hipStream_t s) {
+template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const OverflowSchedule& ovf, hipStream_t s) {
     switch (pass) {
         case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
-        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, s);
-        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, s);
-        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, s);
+        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, ovf, s);
+        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, ovf, s);
+        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, ovf, s);
     }
 }
 
@@ -599,7 +611,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
-    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, hipStream_t);
+    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const OverflowSchedule&, hipStream_t);
 INST(float)
 INST(double)
 #undef INST
