@@ -59,8 +59,9 @@ template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>
 uint32_t color_grid_blocks(uint32_t count);
 // level schedule of the overflow colour (device arrays; see k_overflow_pass): manifold indices in `order`
 struct OverflowSchedule { uint32_t n_components; const uint32_t *comp_level_begin, *level_offsets, *order; };
-// grid_blocks[c] = captured grid of colour c (0 = colour skipped); returns the number of launches issued
-template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const OverflowSchedule&, hipStream_t);
+// grid_blocks[c] = captured grid of colour c (0 = colour skipped); arg_offsets: the 25 colour offsets to pass in the kernel
+// arguments, or nullptr = the kernels read the live ranges from DW::color_offsets; returns the number of launches issued
+template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule&, hipStream_t);
 // k_xpbd.hip
 template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);
 template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,

@@ -396,6 +396,7 @@ template <class T> struct World : WorldBase {
         }
         any_restitution = false;
         for (uint32_t i = 0; i < M && !any_restitution; ++i) any_restitution = !(((const T*)m->restitution)[i] == T(0));
+        if (use_handles) graph_valid = false;
         use_handles = false;  // the manifolds come from the host again
         avn_status st0 = ensure_manifold_capacity(M);
         if (st0 != AVN_OK) return st0;
@@ -985,6 +986,7 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     void set_color_offsets(const uint32_t* offsets) {
+        if (std::memcmp(color_offsets, offsets, sizeof color_offsets) != 0) graph_valid = false;  // (ranges captured as kernel arguments)
         std::memcpy(color_offsets, offsets, sizeof color_offsets);
         // launch grids per colour: the kernels read the live colour ranges from device memory, so a captured grid stays
         // valid while it still covers the colour; grids are captured with 25 % slack and re-captured when outgrown
@@ -1024,6 +1026,7 @@ template <class T> struct World : WorldBase {
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         HIPCHK(hipMemcpy(dw.color_offsets, color_offsets, sizeof color_offsets, hipMemcpyHostToDevice));
         if (M) HIPCHK(hipMemcpy(b_handles.p, ids, (size_t)M * 4, hipMemcpyHostToDevice));
+        if (!use_handles) graph_valid = false;
         use_handles = true;
         any_restitution = materials_restitution;
         incidence_dirty = true;
@@ -1233,7 +1236,7 @@ template <class T> struct World : WorldBase {
         if (!dw.n_manifolds) return;
         OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
                              sched_overflow.d_order.as<uint32_t>()};
-        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, ovf, stream);
+        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, use_handles ? nullptr : color_offsets, ovf, stream);
     }
     // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
     // installed (xpbd/plugin.rs:61-76,192-240).  With no joints the projection adds 2 * (dq * conj(dq)).xyz / h:

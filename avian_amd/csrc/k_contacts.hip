@@ -528,8 +528,12 @@ template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T
 // One colour: manifolds [offsets[c], offsets[c+1]) read from device memory so that a captured graph stays
 // valid while the colour populations drift; the grid is a multiple of 8 blocks and remapped per XCD.
 template <class T, int PASS>
-__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepParams<T> p, uint32_t color) {
-    uint32_t base = w.color_offsets[color], end = w.color_offsets[color + 1];
+__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepParams<T> p, uint32_t color, uint32_t arg_base, uint32_t arg_end) {
+    // arg_end != 0: the colour range travels in the kernel arguments (one dependent scalar load less in a latency-bound
+    // launch; the host re-captures the graph when the ranges change) -- used for host-uploaded manifold sets, which are
+    // static between uploads.  arg_end == 0: read the live range from device memory (handle mode: colours drift every step).
+    uint32_t base = arg_base, end = arg_end;
+    if (arg_end == 0u) { base = w.color_offsets[color]; end = w.color_offsets[color + 1]; }
     uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
     uint32_t m = base + blk * CONTACT_THREADS + threadIdx.x;
     if (m >= end) return;
@@ -581,14 +585,19 @@ uint32_t color_grid_blocks(uint32_t count) {
     uint32_t nb = (count + CONTACT_THREADS - 1) / CONTACT_THREADS;
     return ((nb + 7u) / 8u) * 8u;
 }
-template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const OverflowSchedule& ovf, hipStream_t s) {
+template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
     uint32_t launches = 0;
     if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_components) {
         hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(ovf.n_components), dim3(OVERFLOW_THREADS), 0, s, w, p, ovf.comp_level_begin, ovf.level_offsets, ovf.order);
         ++launches;
     }
     for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
-        if (grid_blocks[c]) { hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c); ++launches; }
+        if (grid_blocks[c]) {
+            uint32_t b = arg_offsets ? arg_offsets[c] : 0u, e = arg_offsets ? arg_offsets[c + 1] : 0u;
+            if (arg_offsets && e == b) continue;  // (a captured range is exact: an empty colour needs no launch)
+            hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e);
+            ++launches;
+        }
     return launches;
 }
 template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
@@ -598,12 +607,12 @@ template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<
     if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
     else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
 }
-template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const OverflowSchedule& ovf, hipStream_t s) {
+template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
     switch (pass) {
         case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
-        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, ovf, s);
-        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, ovf, s);
-        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, ovf, s);
+        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, arg_offsets, ovf, s);
+        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, arg_offsets, ovf, s);
+        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, arg_offsets, ovf, s);
     }
 }
 
@@ -611,7 +620,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
-    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const OverflowSchedule&, hipStream_t);
+    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t);
 INST(float)
 INST(double)
 #undef INST
