@@ -154,6 +154,12 @@ class avn_contacts_out(C.Structure):
                                   "warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse", "feature_id1", "feature_id2")]
 
 
+class avn_pipeline_stats(C.Structure):
+    _fields_ = [("pairs_added", C.c_uint64), ("pairs_removed", C.c_uint64), ("manifolds_pushed", C.c_uint64), ("manifolds_popped", C.c_uint64),
+                ("active_pairs", C.c_uint32), ("manifolds", C.c_uint32), ("last_status_changes", C.c_uint32), ("last_overflow_manifolds", C.c_uint32),
+                ("last_host_ms", C.c_double)]
+
+
 CHANGE_DTYPE = np.dtype([("contact_id", "<u4"), ("flags", "<u4"), ("manifold_count_change", "<i4"), ("manifold_count", "<u4")])
 
 
@@ -185,7 +191,7 @@ ABI_SYMBOLS = [
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
-    "contacts_download",
+    "contacts_download", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
 ]
 
 
@@ -236,6 +242,9 @@ class Library:
         f("contact_changes_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         f("manifold_handles_upload").argtypes = [vp, vp, vp]
         f("contacts_download").argtypes = [vp, vp, C.c_size_t, vp]
+        f("pipeline_enable").argtypes = [vp, C.c_int]
+        f("pipeline_stats_get").argtypes = [vp, vp]
+        f("pipeline_handles_get").argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
 
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
@@ -526,6 +535,24 @@ class World:
                                                       "feature_id1", "feature_id2")])
         self._check(self.lib.fn("contacts_download")(self.handle, _ptr(ids), n, C.byref(o)))
         return out
+
+    # -- standalone closed loop (the library keeps IdPool / ContactGraph bookkeeping / ConstraintGraph itself) ------------
+    def pipeline_enable(self, on: bool = True):
+        self._check(self.lib.fn("pipeline_enable")(self.handle, int(on)))
+
+    def pipeline_stats(self) -> avn_pipeline_stats:
+        st = avn_pipeline_stats()
+        self._check(self.lib.fn("pipeline_stats_get")(self.handle, C.byref(st)))
+        return st
+
+    def pipeline_handles(self):
+        off = np.zeros(GRAPH_COLOR_COUNT + 1, np.uint32)
+        p, n = vp(), C.c_size_t()
+        self._check(self.lib.fn("pipeline_handles_get")(self.handle, _ptr(off), C.byref(p), C.byref(n)))
+        if n.value == 0:
+            return off, np.zeros(0, np.uint32)
+        buf = (C.c_uint32 * n.value).from_address(p.value)
+        return off, np.frombuffer(buf, dtype=np.uint32).copy()
 
     def contact_manifolds(self, shape1, half_extents1, position1, rotation1, shape2, half_extents2, position2, rotation2,
                           prediction_distance):

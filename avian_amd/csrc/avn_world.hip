@@ -6,6 +6,8 @@
 #include <cstring>
 #include <limits>
 #include <numeric>
+#include <chrono>
+#include <queue>
 #include <unordered_set>
 
 namespace avn {
@@ -121,6 +123,17 @@ template <class T> struct World : WorldBase {
     uint32_t n_active = 0;
     bool use_handles = false, materials_restitution = false, contact_keys_live = false;
     std::unordered_set<uint64_t> h_live_keys;              // pair keys of the live rows (pair-set rebuilds after removals)
+    // ---- standalone closed loop (avn_pipeline_enable): the host structures an Avian integration would own ----
+    struct PipePair { uint32_t c1 = 0, c2 = 0; int32_t b1 = -1, b2 = -1; uint32_t n_handles = 0; uint32_t active_pos = 0; bool used = false; };
+    bool pipe_on = false, pipe_handles_dirty = true, pipe_active_dirty = false;
+    std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> pipe_free_ids;  // IdPool: lowest free id first
+    uint32_t pipe_next_id = 0;
+    std::vector<PipePair> pipe_pairs;          // indexed by ContactId
+    std::vector<uint32_t> pipe_active;         // ContactGraph::active_pairs (iteration order is irrelevant to results)
+    ConstraintGraphHost pipe_graph;
+    std::vector<uint32_t> pipe_handles;        // colour-major contact ids (GraphColor::manifold_handles)
+    uint32_t pipe_offsets[AVN_GRAPH_COLOR_COUNT + 1];
+    avn_pipeline_stats pipe_stats;
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
@@ -151,6 +164,8 @@ template <class T> struct World : WorldBase {
         std::memset(&dw, 0, sizeof dw);
         std::memset(&bp, 0, sizeof bp);
         std::memset(&ct, 0, sizeof ct);
+        std::memset(&pipe_stats, 0, sizeof pipe_stats);
+        std::memset(pipe_offsets, 0, sizeof pipe_offsets);
         std::memset(&last_timers, 0, sizeof last_timers);
         std::memset(color_offsets, 0, sizeof color_offsets);
         std::memset(grid_blocks, 0, sizeof grid_blocks);
@@ -1129,6 +1144,136 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
+    // ---- standalone closed loop ------------------------------------------------------------------------------------------
+    avn_status pipeline_enable(int on) override {
+        if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
+        if (on && pipe_on) return AVN_OK;
+        pipe_on = on != 0;
+        // a fresh ContactGraph / ConstraintGraph: rows, ids, colour lists and the broad phase's pair set start empty
+        for (uint32_t id = 0; id < pipe_pairs.size(); ++id)
+            if (pipe_pairs[id].used) { uint32_t cid = id; avn_status st = contact_pairs_remove(&cid, 1); if (st != AVN_OK) return st; }
+        pipe_pairs.clear(); pipe_active.clear(); pipe_graph.clear(); pipe_handles.clear();
+        pipe_free_ids = decltype(pipe_free_ids)();
+        pipe_next_id = 0; pipe_handles_dirty = true; pipe_active_dirty = true;
+        std::memset(&pipe_stats, 0, sizeof pipe_stats);
+        std::memset(pipe_offsets, 0, sizeof pipe_offsets);
+        return AVN_OK;
+    }
+    avn_status pipeline_stats_get(avn_pipeline_stats* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        pipe_stats.active_pairs = (uint32_t)pipe_active.size();
+        pipe_stats.manifolds = (uint32_t)pipe_handles.size();
+        *o = pipe_stats;
+        return AVN_OK;
+    }
+    avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override {
+        if (!off || !ids || !n) return AVN_ERR_BAD_ARG;
+        std::memcpy(off, pipe_offsets, sizeof pipe_offsets);
+        *ids = pipe_handles.data(); *n = pipe_handles.size();
+        return AVN_OK;
+    }
+    void pipe_push(uint32_t cid, uint32_t flags) {   // ConstraintGraph::push_manifold(contact_edge, contact_pair)
+        PipePair& p = pipe_pairs[cid];
+        pipe_graph.push_manifold(((uint64_t)cid << 8) | p.n_handles, (uint32_t)p.b1, (uint32_t)p.b2, flags & AVN_CP_STATIC1, flags & AVN_CP_STATIC2);
+        ++p.n_handles; pipe_handles_dirty = true; ++pipe_stats.manifolds_pushed;
+    }
+    void pipe_pop(uint32_t cid) {                      // pop_manifold: the edge's LAST constraint handle
+        PipePair& p = pipe_pairs[cid];
+        if (!p.n_handles) return;
+        --p.n_handles;
+        pipe_graph.pop_manifold(((uint64_t)cid << 8) | p.n_handles);
+        pipe_handles_dirty = true; ++pipe_stats.manifolds_popped;
+    }
+    avn_status pipeline_step() {
+        avn_status st;
+        launches = 0;
+        HIPCHK(hipEventRecord(ev[0], stream));
+        if ((st = update_aabb()) != AVN_OK) return st;
+        if ((st = collect_collision_pairs()) != AVN_OK) return st;   // new pairs in h_pairs (emission order)
+        HIPCHK(hipEventRecord(ev[1], stream));
+        auto t0 = std::chrono::steady_clock::now();
+        // ContactGraph::add_edge_and_key_with + IdPool::alloc_id for every new pair, in emission order
+        if (!h_pairs.empty()) {
+            size_t n = h_pairs.size();
+            std::vector<uint32_t> ids(n), c1(n), c2(n), fl(n);
+            for (size_t i = 0; i < n; ++i) {
+                uint32_t id;
+                if (!pipe_free_ids.empty()) { id = pipe_free_ids.top(); pipe_free_ids.pop(); } else id = pipe_next_id++;
+                if (id >= pipe_pairs.size()) pipe_pairs.resize(std::max<size_t>((size_t)id + 1, pipe_pairs.size() + pipe_pairs.size() / 2));
+                const avn_pair& pr = h_pairs[i];
+                PipePair& p = pipe_pairs[id];
+                p.c1 = pr.collider1; p.c2 = pr.collider2; p.b1 = pr.body1; p.b2 = pr.body2; p.n_handles = 0; p.used = true;
+                p.active_pos = (uint32_t)pipe_active.size();
+                pipe_active.push_back(id);
+                ids[i] = id; c1[i] = pr.collider1; c2[i] = pr.collider2; fl[i] = pr.flags;
+            }
+            avn_contact_pairs cp{(uint32_t)n, ids.data(), c1.data(), c2.data(), fl.data()};
+            if ((st = contact_pairs_add(&cp)) != AVN_OK) return st;
+            pipe_stats.pairs_added += n;
+            pipe_active_dirty = true;
+        }
+        if (pipe_active_dirty) {
+            if ((st = active_pairs_set(pipe_active.data(), pipe_active.size())) != AVN_OK) return st;
+            pipe_active_dirty = false;
+        }
+        double host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if ((st = narrow_phase()) != AVN_OK) return st;
+        t0 = std::chrono::steady_clock::now();
+        // the status-change loop of NarrowPhase::update (system_param.rs:141-389), ascending ContactId
+        std::vector<uint32_t> removed;
+        for (const avn_contact_change& c : h_changes) {
+            const uint32_t cid = c.contact_id, flags = c.flags;
+            const bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+            PipePair& p = pipe_pairs[cid];
+            if (flags & AVN_CP_DISJOINT_AABB) {
+                if (generates) while (p.n_handles) pipe_pop(cid);
+                removed.push_back(cid);
+            } else if (flags & AVN_CP_STARTED_TOUCHING) {
+                if (generates) for (uint32_t k = 0; k < c.manifold_count; ++k) pipe_push(cid, flags);
+            } else if (flags & AVN_CP_STOPPED_TOUCHING) {
+                if (generates) while (p.n_handles) pipe_pop(cid);
+            } else if (touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) {
+                for (uint32_t k = 0; k < c.manifold_count; ++k) pipe_push(cid, flags);
+            } else if (touching && generates && c.manifold_count_change > 0) {
+                for (int32_t k = 0; k < c.manifold_count_change; ++k) pipe_push(cid, flags);
+            } else if (touching && generates && c.manifold_count_change < 0) {
+                for (int32_t k = 0; k < -c.manifold_count_change; ++k) pipe_pop(cid);
+            }
+        }
+        pipe_stats.last_status_changes = (uint32_t)h_changes.size();
+        if (!removed.empty()) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
+            if ((st = contact_pairs_remove(removed.data(), removed.size())) != AVN_OK) return st;
+            for (uint32_t cid : removed) {
+                PipePair& p = pipe_pairs[cid];
+                uint32_t last = pipe_active.back();
+                pipe_active[p.active_pos] = last; pipe_pairs[last].active_pos = p.active_pos; pipe_active.pop_back();
+                p = PipePair();
+                pipe_free_ids.push(cid);
+            }
+            pipe_stats.pairs_removed += removed.size();
+            pipe_active_dirty = true;
+        }
+        if (pipe_handles_dirty) {
+            size_t n = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pipe_offsets[c] = (uint32_t)n; n += pipe_graph.colors[c].manifold_handles.size(); }
+            pipe_offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+            pipe_handles.resize(n);
+            size_t k = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+                for (const auto& h : pipe_graph.colors[c].manifold_handles) pipe_handles[k++] = (uint32_t)(h.handle >> 8);
+            if ((st = manifold_handles_upload(pipe_offsets, pipe_handles.data())) != AVN_OK) return st;
+            pipe_handles_dirty = false;
+        }
+        pipe_stats.last_overflow_manifolds = pipe_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - pipe_offsets[AVN_COLOR_OVERFLOW_INDEX];
+        pipe_stats.last_host_ms = host_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        uint32_t before = launches;
+        (void)before;
+        if ((st = solver()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[4], stream));
+        ev_valid = true;
+        last_timers.kernel_launches = launches;
+        return AVN_OK;
+    }
     avn_status update_aabb() {
         launch_update_aabb<T>(dw, bp, params, stream);
         ++launches;
@@ -1381,6 +1526,7 @@ template <class T> struct World : WorldBase {
     avn_status step() override {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
+        if (pipe_on) return pipeline_step();
         launches = 0;
         HIPCHK(hipEventRecord(ev[0], stream));
         if (have_colliders) {

@@ -79,6 +79,9 @@ struct WorldBase {
     virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
     virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
     virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
+    virtual avn_status pipeline_enable(int) = 0;
+    virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
+    virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
 };
 
 WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err);
@@ -93,6 +96,7 @@ struct ConstraintGraphHost {
     std::unordered_map<uint64_t, Loc> where;
     int push_manifold(uint64_t handle, uint32_t body1, uint32_t body2, bool is_static1, bool is_static2);
     bool pop_manifold(uint64_t handle);
+    void clear() { for (auto& c : colors) { c.body_bits.clear(); c.manifold_handles.clear(); } where.clear(); }
 };
 
 }  // namespace avn

@@ -486,6 +486,25 @@ AVN_API avn_status AVN_FN(contact_changes_get)(avn_world* w, const avn_contact_c
 AVN_API avn_status AVN_FN(manifold_handles_upload)(avn_world* w, const uint32_t* color_offsets, const uint32_t* contact_id);
 AVN_API avn_status AVN_FN(contacts_download)(avn_world* w, const uint32_t* contact_id, size_t n, const avn_contacts_out* out);
 
+/* ---- standalone closed loop -----------------------------------------------------------------------------------------
+ * For drivers WITHOUT Avian's host structures (benches, demos, tests): the library keeps them itself — IdPool
+ * (data_structures/id_pool.rs:31-40), the ContactGraph edge list / active pairs (contact_graph.rs:521-566), the status-change
+ * processing of NarrowPhase::update (narrow_phase/system_param.rs:141-389) and the ConstraintGraph
+ * (solver/constraint_graph.rs:163-296) — and avn_step becomes the whole PhysicsSchedule pass over the path:
+ *   UPDATE_AABB -> COLLECT_COLLISION_PAIRS -> (new rows) -> NARROW_PHASE -> (status changes -> push / pop -> handles) -> SOLVER.
+ * An Avian integration does NOT use this: it forwards its own structures' changes through the calls above. */
+typedef struct avn_pipeline_stats {
+    uint64_t pairs_added, pairs_removed, manifolds_pushed, manifolds_popped;  /* since avn_pipeline_enable */
+    uint32_t active_pairs, manifolds;      /* now */
+    uint32_t last_status_changes;          /* in the last step */
+    uint32_t last_overflow_manifolds;      /* manifolds in colour 23 in the last step */
+    double last_host_ms;                   /* host bookkeeping time of the last step (status processing + uploads) */
+} avn_pipeline_stats;
+AVN_API avn_status AVN_FN(pipeline_enable)(avn_world* w, int on);
+AVN_API avn_status AVN_FN(pipeline_stats_get)(avn_world* w, avn_pipeline_stats* out);
+/* the colour lists the pipeline holds: offsets[25] and the contact ids (buffer owned by the world) */
+AVN_API avn_status AVN_FN(pipeline_handles_get)(avn_world* w, uint32_t* color_offsets, const uint32_t** contact_id, size_t* n_out);
+
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);
 

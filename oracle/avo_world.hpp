@@ -17,6 +17,8 @@
 #include <chrono>
 #include <cstring>
 #include <string>
+#include <map>
+#include <set>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -290,7 +292,15 @@ struct WorldBase {
     virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
     virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
     virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
+    virtual avn_status pipeline_enable(int) = 0;
+    virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
+    virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
 };
+
+struct ConstraintGraph;  // defined below (solver/constraint_graph.rs restatement)
+struct PipelineState;    // standalone closed-loop bookkeeping (defined after ConstraintGraph)
+PipelineState* pipeline_new();
+void pipeline_delete(PipelineState*);
 
 template <class S> struct World : WorldBase {
     avn_config cfg;
@@ -340,7 +350,13 @@ template <class S> struct World : WorldBase {
     struct Material { S friction, restitution; uint8_t friction_combine, restitution_combine; };
     std::vector<Material> materials;         // per collider slot
 
+    PipelineState* pipe = nullptr;
     World() { std::memset(&last_timers, 0, sizeof last_timers); std::memset(color_offsets, 0, sizeof color_offsets); }
+    ~World() override { pipeline_delete(pipe); }
+    avn_status pipeline_enable(int on) override;
+    avn_status pipeline_stats_get(avn_pipeline_stats* o) override;
+    avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override;
+    avn_status pipeline_step();
 
     // -- time: Duration arithmetic of run_physics_schedule / run_substep_schedule (schedule/mod.rs:240-284,
     //    solver/schedule.rs:194-200).  sub_delta = delta.div_f64(substeps) = from_secs_f64(secs/substeps)
@@ -1738,6 +1754,7 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status step() override {
+        if (pipe) return pipeline_step();
         if (have_colliders) { update_aabb(); collect_collision_pairs(); }
         solver();
         return AVN_OK;
@@ -1808,5 +1825,130 @@ struct ConstraintGraph {
         return true;
     }
 };
+
+// ---- standalone closed loop (header: avn_pipeline_enable): IdPool (id_pool.rs:31-40), ContactGraph edge bookkeeping
+//      (contact_graph.rs:521-566), the status-change loop of NarrowPhase::update (system_param.rs:141-389) ----------------
+struct PipelineState {
+    std::set<uint32_t> free_ids;  // lowest free id first
+    uint32_t next_id = 0;
+    struct Pair { uint32_t c1, c2; int32_t b1, b2; uint32_t n_handles; };
+    std::map<uint32_t, Pair> pairs;
+    std::vector<uint32_t> active;
+    ConstraintGraph graph;
+    std::vector<uint32_t> handles;
+    uint32_t offsets[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+    avn_pipeline_stats stats;
+    bool handles_dirty = true;
+    PipelineState() { std::memset(&stats, 0, sizeof stats); }
+};
+inline PipelineState* pipeline_new() { return new PipelineState(); }
+inline void pipeline_delete(PipelineState* p) { delete p; }
+
+template <class S> avn_status World<S>::pipeline_enable(int on) {
+    if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
+    if (on && pipe) return AVN_OK;
+    if (pipe) {
+        for (auto& kv : pipe->pairs) { uint32_t id = kv.first; contact_pairs_remove(&id, 1); }
+        pipeline_delete(pipe); pipe = nullptr;
+    }
+    active_pairs.clear();
+    if (on) pipe = pipeline_new();
+    return AVN_OK;
+}
+template <class S> avn_status World<S>::pipeline_stats_get(avn_pipeline_stats* o) {
+    if (!o) return AVN_ERR_BAD_ARG;
+    if (!pipe) { std::memset(o, 0, sizeof *o); return AVN_OK; }
+    pipe->stats.active_pairs = (uint32_t)pipe->active.size();
+    pipe->stats.manifolds = (uint32_t)pipe->handles.size();
+    *o = pipe->stats;
+    return AVN_OK;
+}
+template <class S> avn_status World<S>::pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) {
+    if (!off || !ids || !n) return AVN_ERR_BAD_ARG;
+    static const uint32_t none = 0;
+    if (!pipe) { std::memset(off, 0, sizeof(uint32_t) * (AVN_GRAPH_COLOR_COUNT + 1)); *ids = &none; *n = 0; return AVN_OK; }
+    std::memcpy(off, pipe->offsets, sizeof pipe->offsets);
+    *ids = pipe->handles.data(); *n = pipe->handles.size();
+    return AVN_OK;
+}
+template <class S> avn_status World<S>::pipeline_step() {
+    PipelineState& P = *pipe;
+    update_aabb();
+    collect_collision_pairs();
+    if (!pairs.empty()) {
+        std::vector<uint32_t> ids, c1, c2, fl;
+        for (const avn_pair& pr : pairs) {
+            uint32_t id;
+            if (!P.free_ids.empty()) { id = *P.free_ids.begin(); P.free_ids.erase(P.free_ids.begin()); } else id = P.next_id++;
+            P.pairs[id] = {pr.collider1, pr.collider2, pr.body1, pr.body2, 0u};
+            P.active.push_back(id);
+            ids.push_back(id); c1.push_back(pr.collider1); c2.push_back(pr.collider2); fl.push_back(pr.flags);
+        }
+        avn_contact_pairs cp{(uint32_t)ids.size(), ids.data(), c1.data(), c2.data(), fl.data()};
+        avn_status st = contact_pairs_add(&cp);
+        if (st != AVN_OK) return st;
+        P.stats.pairs_added += ids.size();
+    }
+    avn_status st = active_pairs_set(P.active.data(), P.active.size());
+    if (st != AVN_OK) return st;
+    narrow_phase();
+    auto push = [&](uint32_t cid, uint32_t flags) {
+        PipelineState::Pair& p = P.pairs[cid];
+        P.graph.push_manifold(((uint64_t)cid << 8) | p.n_handles, (uint32_t)p.b1, (uint32_t)p.b2, flags & AVN_CP_STATIC1, flags & AVN_CP_STATIC2);
+        ++p.n_handles; P.handles_dirty = true; ++P.stats.manifolds_pushed;
+    };
+    auto pop = [&](uint32_t cid) {
+        PipelineState::Pair& p = P.pairs[cid];
+        if (!p.n_handles) return;
+        --p.n_handles;
+        P.graph.pop_manifold(((uint64_t)cid << 8) | p.n_handles);
+        P.handles_dirty = true; ++P.stats.manifolds_popped;
+    };
+    std::vector<uint32_t> removed;
+    for (const avn_contact_change& c : contact_changes) {
+        uint32_t cid = c.contact_id, flags = c.flags;
+        bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+        if (flags & AVN_CP_DISJOINT_AABB) {
+            if (generates) while (P.pairs[cid].n_handles) pop(cid);
+            removed.push_back(cid);
+        } else if (flags & AVN_CP_STARTED_TOUCHING) {
+            if (generates) for (uint32_t k = 0; k < c.manifold_count; ++k) push(cid, flags);
+        } else if (flags & AVN_CP_STOPPED_TOUCHING) {
+            if (generates) while (P.pairs[cid].n_handles) pop(cid);
+        } else if (touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) {
+            for (uint32_t k = 0; k < c.manifold_count; ++k) push(cid, flags);
+        } else if (touching && generates && c.manifold_count_change > 0) {
+            for (int32_t k = 0; k < c.manifold_count_change; ++k) push(cid, flags);
+        } else if (touching && generates && c.manifold_count_change < 0) {
+            for (int32_t k = 0; k < -c.manifold_count_change; ++k) pop(cid);
+        }
+    }
+    P.stats.last_status_changes = (uint32_t)contact_changes.size();
+    if (!removed.empty()) {
+        st = contact_pairs_remove(removed.data(), removed.size());
+        if (st != AVN_OK) return st;
+        std::set<uint32_t> gone(removed.begin(), removed.end());
+        std::vector<uint32_t> keep;
+        for (uint32_t a : P.active) if (!gone.count(a)) keep.push_back(a);
+        P.active.swap(keep);
+        for (uint32_t cid : removed) { P.pairs.erase(cid); P.free_ids.insert(cid); }
+        P.stats.pairs_removed += removed.size();
+    }
+    if (P.handles_dirty) {
+        size_t n = 0;
+        P.handles.clear();
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+            P.offsets[c] = (uint32_t)n;
+            for (const auto& h : P.graph.colors[c].manifold_handles) { P.handles.push_back((uint32_t)(h.handle >> 8)); ++n; }
+        }
+        P.offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+        st = manifold_handles_upload(P.offsets, P.handles.data());
+        if (st != AVN_OK) return st;
+        P.handles_dirty = false;
+    }
+    P.stats.last_overflow_manifolds = P.offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - P.offsets[AVN_COLOR_OVERFLOW_INDEX];
+    solver();
+    return AVN_OK;
+}
 
 }  // namespace avo

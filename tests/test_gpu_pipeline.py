@@ -70,3 +70,25 @@ def test_box_stack_1000_closed_loop_settles():
     assert np.isfinite(b["position"]).all()
     assert float(np.abs(b["position"][1:] - sc.position[1:]).max()) < 0.2 and float(np.abs(b["linear_velocity"]).max()) < 1.0
     assert w.n_manifolds > 2000
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_library_pipeline_hip_matches_oracle_and_python_driver(bits):
+    """avn_pipeline_enable + avn_step on the HIP product == the oracle's own pipeline == the Python driver, bit for bit."""
+    bodies, colliders = dropped_boxes(seed=21, n=80)
+    wo, _ = make(oracle_lib(), bits, bodies, colliders); wo.pipeline_enable()
+    wh, _ = make(hip_lib(), bits, bodies, colliders); wh.pipeline_enable()
+    wp, pp = make(hip_lib(), bits, bodies, colliders)
+    for s in range(50):
+        wo.step(); wh.step(); pp.step()
+        oo, oh = wo.pipeline_handles(), wh.pipeline_handles()
+        assert np.array_equal(oo[0], oh[0]) and np.array_equal(oo[1], oh[1]), f"step {s}: colour lists"
+        op = pp.graph.lists()
+        assert np.array_equal(op[0], oh[0]) and np.array_equal(op[1].astype(np.uint32), oh[1])
+        bo, bh, bp = wo.bodies_download(), wh.bodies_download(), wp.bodies_download()
+        for k in bo:
+            assert np.array_equal(bo[k], bh[k]) and np.array_equal(bp[k], bh[k]), f"step {s}: bodies.{k}"
+    so, sh = wo.pipeline_stats(), wh.pipeline_stats()
+    for f in ("pairs_added", "pairs_removed", "manifolds_pushed", "manifolds_popped", "active_pairs", "manifolds", "last_status_changes"):
+        assert getattr(so, f) == getattr(sh, f), f
+    assert sh.manifolds_pushed > 80 and sh.manifolds_popped > 0

@@ -53,3 +53,24 @@ def test_pairs_are_removed_when_aabbs_separate_and_ids_are_reused():
         ids_seen |= set(pl.pairs)
     assert pl.stats["pairs_removed"] > 0
     assert max(ids_seen) < pl.stats["pairs_added"], "freed ContactIds are reused lowest-first"
+
+
+def test_library_pipeline_equals_the_python_driver():
+    """avn_pipeline_enable (the library's own host bookkeeping, C++) gives the same colour lists and body state as the
+    Python driver over the low-level calls — two independent implementations of the status-change loop."""
+    lib = oracle_lib()
+    bodies, colliders = dropped_boxes(seed=9, n=30)
+    wa, pa = make(lib, 32, bodies, colliders)
+    wb, _ = make(lib, 32, bodies, colliders)
+    wb.pipeline_enable()
+    for s in range(60):
+        pa.step(); wb.step()
+        offa, ha = pa.graph.lists()
+        offb, hb = wb.pipeline_handles()
+        assert np.array_equal(offa, offb) and np.array_equal(ha.astype(np.uint32), hb), f"step {s}"
+        ba, bb = wa.bodies_download(), wb.bodies_download()
+        for k in ba:
+            assert np.array_equal(ba[k], bb[k]), f"step {s}: {k}"
+    st = wb.pipeline_stats()
+    assert st.pairs_added == pa.stats["pairs_added"] and st.manifolds_pushed == pa.stats["pushes"] and st.manifolds_popped == pa.stats["pops"]
+    assert st.active_pairs == len(pa.active) and st.manifolds == len(ha)

@@ -47,6 +47,25 @@ def main():
     print(f"bodies {sc.n - 1}, active pairs {len(pl.active)}, manifolds {w.n_manifolds}, status changes/step {n_changes / steps:.1f}")
     print(f"NARROW_PHASE (kernel + count read-back): {ms / 5:.3f} ms; wall per step: narrow {t_np / steps * 1e3:.3f} ms, host status {t_host / steps * 1e3:.3f} ms, "
           f"whole closed-loop step {t_all / steps * 1e3:.3f} ms (solver device {tm.prepare_ms + tm.substeps_ms + tm.finalize_ms:.3f} ms)")
+    # the same scene through the library's own closed loop (avn_pipeline_enable: C++ bookkeeping, no Python in the step)
+    w2 = F.World(lib, F.default_config(32, substeps=4))
+    w2.bodies_upload(**sc.body_kwargs()); w2.colliders_upload(**sc.collider_kwargs())
+    w2.existing_pairs_upload(np.zeros(0, np.uint64)); w2.collider_materials_upload(friction=0.5)
+    w2.pipeline_enable()
+    t0 = time.perf_counter(); w2.step(); w2.synchronize(); first = time.perf_counter() - t0
+    for _ in range(3):
+        w2.step()
+    w2.synchronize()
+    t0 = time.perf_counter()
+    host = 0.0; ch = 0; ovf = 0
+    for _ in range(steps):
+        w2.step()
+        st = w2.pipeline_stats(); host += st.last_host_ms; ch += st.last_status_changes; ovf += st.last_overflow_manifolds
+    w2.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    tm2 = w2.timers()
+    print(f"library pipeline: first step {first:.2f} s; {dt * 1e3:.3f} ms/step = {4 / dt:.1f} substeps/s closed loop; host bookkeeping {host / steps:.3f} ms/step, "
+          f"status changes/step {ch / steps:.0f}, overflow manifolds {ovf / steps:.0f}, substeps device {tm2.substeps_ms:.3f} ms, manifolds {st.manifolds}")
     b = w.bodies_download()
     print("max |v|", float(np.abs(b["linear_velocity"]).max()), "max drift", float(np.abs(b["position"][1:] - sc.position[1:]).max()))
 
