@@ -58,7 +58,10 @@ template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t)
 template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);
 uint32_t color_grid_blocks(uint32_t count);
 // level schedule of the overflow colour (device arrays; see k_overflow_pass): manifold indices in `order`
-struct OverflowSchedule { uint32_t n_components; const uint32_t *comp_level_begin, *level_offsets, *order; };
+struct OverflowSchedule {
+    uint32_t n_components; const uint32_t *comp_level_begin, *level_offsets, *order;   // one workgroup per component (device arrays)
+    const uint32_t* gorder; const uint32_t* glevel_offsets /* HOST array */; uint32_t n_glevels;  // or: one launch per level (n_glevels != 0)
+};
 // grid_blocks[c] = captured grid of colour c (0 = colour skipped); arg_offsets: the 25 colour offsets to pass in the kernel
 // arguments, or nullptr = the kernels read the live ranges from DW::color_offsets; returns the number of launches issued
 template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule&, hipStream_t);

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <numeric>
@@ -40,22 +41,14 @@ bool DevBuf::ensure(size_t bytes, hipError_t& err, bool keep, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-void JointSchedule::build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys) {
-    comp_level_begin.clear(); level_offsets.clear(); order.clear();
+void JointSchedule::build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys, bool levels_only) {
+    comp_level_begin.clear(); level_offsets.clear(); order.clear(); glevel_offsets.clear(); gorder.clear();
     n_components = 0;
     size_t J = joints.size();
-    if (J == 0) { comp_level_begin.push_back(0); level_offsets.push_back(0); return; }
-    // union-find over scheduling keys
-    std::vector<int32_t> parent(n_keys);
-    std::iota(parent.begin(), parent.end(), 0);
-    auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-    for (size_t k = 0; k < J; ++k) {
-        int32_t a = key1[k], b = key2[k];
-        if (a >= 0 && b >= 0) { int32_t ra = find(a), rb = find(b); if (ra != rb) parent[ra] = rb; }
-    }
-    std::vector<uint32_t> comp(J), level(J);
+    if (J == 0) { comp_level_begin.push_back(0); level_offsets.push_back(0); glevel_offsets.push_back(0); return; }
+    // level(k) = 1 + max level of the earlier items that share a key with k
+    std::vector<uint32_t> level(J);
     std::vector<uint32_t> last(n_keys, 0);
-    std::unordered_map<int32_t, uint32_t> comp_of_root;
     uint32_t max_level = 0;
     for (size_t k = 0; k < J; ++k) {
         int32_t a = key1[k], b = key2[k];
@@ -64,21 +57,41 @@ void JointSchedule::build(const std::vector<uint32_t>& joints, const std::vector
         if (b >= 0) last[b] = lv;
         level[k] = lv;
         max_level = std::max(max_level, lv);
+    }
+    // by level only: counting sort (levels are 1..max_level), stable in the original order
+    glevel_offsets.assign((size_t)max_level + 1, 0u);
+    for (size_t k = 0; k < J; ++k) ++glevel_offsets[level[k]];
+    { uint32_t run = 0; for (uint32_t l = 1; l <= max_level; ++l) { uint32_t c = glevel_offsets[l]; glevel_offsets[l] = run; run += c; } glevel_offsets[0] = 0; }
+    gorder.resize(J);
+    { std::vector<uint32_t> cur(glevel_offsets.begin(), glevel_offsets.end()); for (size_t k = 0; k < J; ++k) gorder[cur[level[k]]++] = joints[k]; }
+    glevel_offsets.erase(glevel_offsets.begin());   // offsets of levels 1..max_level, then the end
+    glevel_offsets.push_back((uint32_t)J);
+    if (levels_only) { comp_level_begin.push_back(0); level_offsets.push_back(0); return; }
+    // connected components (union-find over the keys), numbered in order of first appearance
+    std::vector<int32_t> parent(n_keys);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (size_t k = 0; k < J; ++k) {
+        int32_t a = key1[k], b = key2[k];
+        if (a >= 0 && b >= 0) { int32_t ra = find(a), rb = find(b); if (ra != rb) parent[ra] = rb; }
+    }
+    std::vector<uint32_t> comp(J);
+    std::vector<uint32_t> comp_of_root(n_keys, 0xFFFFFFFFu);
+    for (size_t k = 0; k < J; ++k) {
+        int32_t a = key1[k], b = key2[k];
         int32_t root = a >= 0 ? find(a) : (b >= 0 ? find(b) : -1);
-        if (root < 0) comp[k] = n_components++;  // touches no scheduled body: its own component
+        if (root < 0) comp[k] = n_components++;  // touches no scheduled key: its own component
         else {
-            auto it = comp_of_root.find(root);
-            if (it == comp_of_root.end()) { comp_of_root.emplace(root, n_components); comp[k] = n_components++; }
-            else comp[k] = it->second;
+            if (comp_of_root[root] == 0xFFFFFFFFu) comp_of_root[root] = n_components++;
+            comp[k] = comp_of_root[root];
         }
     }
-    // sort joint slots by (component, level, original order)
+    // sort item slots by (component, level, original order)
     std::vector<uint32_t> idx(J);
     std::iota(idx.begin(), idx.end(), 0u);
     std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return comp[x] != comp[y] ? comp[x] < comp[y] : level[x] < level[y]; });
     order.resize(J);
     comp_level_begin.assign(1, 0u);
-    level_offsets.clear();
     uint32_t cur_comp = comp[idx[0]], cur_level = 0;
     for (size_t k = 0; k < J; ++k) {
         uint32_t s = idx[k];
@@ -119,18 +132,22 @@ template <class T> struct World : WorldBase {
     std::vector<int32_t> h_col_body;                       // body of each collider slot
     std::vector<uint8_t> h_ct_used;
     std::vector<uint32_t> h_ct_c1, h_ct_c2;                // collider entities of each row
+    std::vector<int32_t> h_ct_b1, h_ct_b2;                 // ... and the bodies they sit on
     std::vector<avn_contact_change> h_changes;
     uint32_t n_active = 0;
     bool use_handles = false, materials_restitution = false, contact_keys_live = false;
     std::unordered_set<uint64_t> h_live_keys;              // pair keys of the live rows (pair-set rebuilds after removals)
     // ---- standalone closed loop (avn_pipeline_enable): the host structures an Avian integration would own ----
-    struct PipePair { uint32_t c1 = 0, c2 = 0; int32_t b1 = -1, b2 = -1; uint32_t n_handles = 0; uint32_t active_pos = 0; bool used = false; };
+    struct PipePair { uint32_t c1 = 0, c2 = 0; int32_t b1 = -1, b2 = -1; uint32_t n_handles = 0; uint32_t active_pos = 0; uint32_t color_pos = 0; int8_t color = -1; bool used = false; };
     bool pipe_on = false, pipe_handles_dirty = true, pipe_active_dirty = false;
     std::priority_queue<uint32_t, std::vector<uint32_t>, std::greater<uint32_t>> pipe_free_ids;  // IdPool: lowest free id first
     uint32_t pipe_next_id = 0;
     std::vector<PipePair> pipe_pairs;          // indexed by ContactId
     std::vector<uint32_t> pipe_active;         // ContactGraph::active_pairs (iteration order is irrelevant to results)
-    ConstraintGraphHost pipe_graph;
+    // ConstraintGraph (constraint_graph.rs:163-296) with dense per-contact bookkeeping: one manifold per pair, so the handle
+    // is the ContactId and (colour, index in the colour's list) live in PipePair
+    struct PipeColor { std::vector<uint64_t> body_bits; std::vector<uint32_t> handles; };
+    PipeColor pipe_colors[AVN_GRAPH_COLOR_COUNT];
     std::vector<uint32_t> pipe_handles;        // colour-major contact ids (GraphColor::manifold_handles)
     uint32_t pipe_offsets[AVN_GRAPH_COLOR_COUNT + 1];
     avn_pipeline_stats pipe_stats;
@@ -145,8 +162,10 @@ template <class T> struct World : WorldBase {
     std::vector<uint8_t> h_body_has_sb;
     std::vector<int32_t> h_m_body1, h_m_body2;  // ContactPair bodies of the uploaded manifolds (incidence CSR source)
     bool incidence_dirty = true;
+    std::vector<uint32_t> inc_off_h, inc_cursor_h, inc_ent_h;  // host scratch of rebuild_incidence (kept: the closed loop rebuilds every step)
     bool joint_schedule_dirty = true;
     JointSchedule sched_solve, sched_damp, sched_overflow;
+    size_t overflow_level_threshold = 4096;  // overflow manifolds above which the colour runs one launch per level (AVN_OVERFLOW_LEVEL_THRESHOLD overrides: tests)
     bool any_damped = false;
     bool any_restitution = false;  // some manifold has restitution != 0 (else apply_restitution early-outs for all, contact/mod.rs:366-369)
     std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
@@ -192,6 +211,7 @@ template <class T> struct World : WorldBase {
         if (c->device < 0 || c->device >= ndev) { error = "config.device out of range"; return AVN_ERR_BAD_ARG; }
         HIPCHK(hipSetDevice(c->device));
         cfg.device = c->device;
+        if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         for (auto& x : ev) HIPCHK(hipEventCreate(&x));
         hipError_t err;
@@ -446,14 +466,15 @@ template <class T> struct World : WorldBase {
         if (M == 0) { incidence_dirty = false; return AVN_OK; }
         if (h_body_has_sb.size() != N || h_m_body1.size() != M) { error = "incidence: bodies / manifolds out of sync"; return AVN_ERR_STATE; }
         HIPCHK(hipStreamSynchronize(stream));
-        std::vector<uint32_t> off((size_t)N + 1, 0u);
+        std::vector<uint32_t>& off = inc_off_h; std::vector<uint32_t>& cursor = inc_cursor_h; std::vector<uint32_t>& ent = inc_ent_h;
+        off.assign((size_t)N + 1, 0u);
         for (uint32_t m = 0; m < M; ++m) {
             if (h_body_has_sb[h_m_body1[m]]) ++off[(size_t)h_m_body1[m] + 1];
             if (h_body_has_sb[h_m_body2[m]]) ++off[(size_t)h_m_body2[m] + 1];
         }
         for (uint32_t i = 0; i < N; ++i) off[i + 1] += off[i];
-        std::vector<uint32_t> cursor(off.begin(), off.end() - 1);
-        std::vector<uint32_t> ent(off[N]);
+        cursor.assign(off.begin(), off.end() - 1);
+        ent.resize(off[N]);
         auto visit = [&](uint32_t m) {
             uint32_t a = (uint32_t)h_m_body1[m], b = (uint32_t)h_m_body2[m];
             if (h_body_has_sb[a]) ent[cursor[a]++] = m;
@@ -482,13 +503,15 @@ template <class T> struct World : WorldBase {
                 k2[m - o0] = h_body_has_sb[h_m_body2[m]] ? h_m_body2[m] : -1;
             }
             uint32_t before = sched_overflow.n_components;
-            sched_overflow.build(ms, k1, k2, N);
+            sched_overflow.build(ms, k1, k2, N, ms.size() > overflow_level_threshold);
             void* p0 = sched_overflow.d_order.p; void* p1 = sched_overflow.d_level_offsets.p; void* p2 = sched_overflow.d_comp_level_begin.p;
             avn_status st;
             if ((st = upload_u32(sched_overflow.d_comp_level_begin, sched_overflow.comp_level_begin)) != AVN_OK) return st;
             if ((st = upload_u32(sched_overflow.d_level_offsets, sched_overflow.level_offsets)) != AVN_OK) return st;
             if ((st = upload_u32(sched_overflow.d_order, sched_overflow.order)) != AVN_OK) return st;
+            if ((st = upload_u32(sched_overflow.d_gorder, sched_overflow.gorder)) != AVN_OK) return st;
             HIPCHK(hipStreamSynchronize(stream));
+            if (o1 > o0) graph_valid = false;  // level sizes are captured launch parameters
             if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p) graph_valid = false;
         }
         incidence_dirty = false;
@@ -890,7 +913,7 @@ template <class T> struct World : WorldBase {
         if ((st = grow_planes(b_ct_fid, sizeof(uint2), (void**)&ct.fid)) != AVN_OK) return st;
         HIPCHK(hipMemset((char*)ct.meta + (size_t)old * sizeof(uint4), 0, (c - old) * sizeof(uint4)));
         ct.cap = (uint32_t)c;
-        h_ct_used.resize(c, 0); h_ct_c1.resize(c, 0); h_ct_c2.resize(c, 0);
+        h_ct_used.resize(c, 0); h_ct_c1.resize(c, 0); h_ct_c2.resize(c, 0); h_ct_b1.resize(c, -1); h_ct_b2.resize(c, -1);
         return AVN_OK;
     }
     avn_status contact_pairs_add(const avn_contact_pairs* p) override {
@@ -911,6 +934,7 @@ template <class T> struct World : WorldBase {
         for (uint32_t i = 0; i < n; ++i) {
             uint32_t id = p->contact_id[i];
             h_ct_used[id] = 1; h_ct_c1[id] = p->collider1[i]; h_ct_c2[id] = p->collider2[i];
+            h_ct_b1[id] = h_col_body[s1[i]]; h_ct_b2[id] = h_col_body[s2[i]];
             uint32_t x = p->collider1[i], y = p->collider2[i];
             h_live_keys.insert(x < y ? ((uint64_t)x << 32) | y : ((uint64_t)y << 32) | x);
         }
@@ -1027,8 +1051,8 @@ template <class T> struct World : WorldBase {
         h_m_body1.resize(M); h_m_body2.resize(M);
         for (uint32_t i = 0; i < M; ++i) {
             if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "manifold_handles_upload: no such contact"; return AVN_ERR_STATE; }
-            h_m_body1[i] = h_col_body[entity_slot.at(h_ct_c1[ids[i]])];
-            h_m_body2[i] = h_col_body[entity_slot.at(h_ct_c2[ids[i]])];
+            h_m_body1[i] = h_ct_b1[ids[i]];
+            h_m_body2[i] = h_ct_b2[ids[i]];
         }
         HIPCHK(hipStreamSynchronize(stream));
         avn_status st = ensure_manifold_capacity(M);
@@ -1152,7 +1176,8 @@ template <class T> struct World : WorldBase {
         // a fresh ContactGraph / ConstraintGraph: rows, ids, colour lists and the broad phase's pair set start empty
         for (uint32_t id = 0; id < pipe_pairs.size(); ++id)
             if (pipe_pairs[id].used) { uint32_t cid = id; avn_status st = contact_pairs_remove(&cid, 1); if (st != AVN_OK) return st; }
-        pipe_pairs.clear(); pipe_active.clear(); pipe_graph.clear(); pipe_handles.clear();
+        pipe_pairs.clear(); pipe_active.clear(); pipe_handles.clear();
+        for (auto& c : pipe_colors) { c.body_bits.clear(); c.handles.clear(); }
         pipe_free_ids = decltype(pipe_free_ids)();
         pipe_next_id = 0; pipe_handles_dirty = true; pipe_active_dirty = true;
         std::memset(&pipe_stats, 0, sizeof pipe_stats);
@@ -1172,17 +1197,46 @@ template <class T> struct World : WorldBase {
         *ids = pipe_handles.data(); *n = pipe_handles.size();
         return AVN_OK;
     }
-    void pipe_push(uint32_t cid, uint32_t flags) {   // ConstraintGraph::push_manifold(contact_edge, contact_pair)
+    static bool pbit_get(const std::vector<uint64_t>& s, uint32_t i) { return (i >> 6) < s.size() && ((s[i >> 6] >> (i & 63)) & 1ull); }
+    static void pbit_set(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) >= s.size()) s.resize((i >> 6) + 1, 0ull); s[i >> 6] |= 1ull << (i & 63); }
+    static void pbit_unset(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) < s.size()) s[i >> 6] &= ~(1ull << (i & 63)); }
+    void pipe_push(uint32_t cid, uint32_t flags) {   // ConstraintGraph::push_manifold (constraint_graph.rs:163-236)
         PipePair& p = pipe_pairs[cid];
-        pipe_graph.push_manifold(((uint64_t)cid << 8) | p.n_handles, (uint32_t)p.b1, (uint32_t)p.b2, flags & AVN_CP_STATIC1, flags & AVN_CP_STATIC2);
-        ++p.n_handles; pipe_handles_dirty = true; ++pipe_stats.manifolds_pushed;
+        if (p.n_handles) return;  // (one manifold per convex pair)
+        const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
+        const uint32_t b1 = (uint32_t)p.b1, b2 = (uint32_t)p.b2;
+        int color = AVN_COLOR_OVERFLOW_INDEX;
+        if (!s1 && !s2) {
+            for (int i = 0; i < AVN_DYNAMIC_COLOR_COUNT; ++i) {
+                PipeColor& c = pipe_colors[i];
+                if (pbit_get(c.body_bits, b1) || pbit_get(c.body_bits, b2)) continue;
+                pbit_set(c.body_bits, b1); pbit_set(c.body_bits, b2);
+                color = i;
+                break;
+            }
+        } else if (!s1 || !s2) {
+            const uint32_t body = !s1 ? b1 : b2;
+            for (int i = AVN_COLOR_OVERFLOW_INDEX - 1; i >= 1; --i) {
+                PipeColor& c = pipe_colors[i];
+                if (pbit_get(c.body_bits, body)) continue;
+                pbit_set(c.body_bits, body);
+                color = i;
+                break;
+            }
+        }
+        p.color = (int8_t)color; p.color_pos = (uint32_t)pipe_colors[color].handles.size();
+        pipe_colors[color].handles.push_back(cid);
+        p.n_handles = 1; pipe_handles_dirty = true; ++pipe_stats.manifolds_pushed;
     }
-    void pipe_pop(uint32_t cid) {                      // pop_manifold: the edge's LAST constraint handle
+    void pipe_pop(uint32_t cid) {                      // ConstraintGraph::pop_manifold (:245-296): swap-remove
         PipePair& p = pipe_pairs[cid];
         if (!p.n_handles) return;
-        --p.n_handles;
-        pipe_graph.pop_manifold(((uint64_t)cid << 8) | p.n_handles);
-        pipe_handles_dirty = true; ++pipe_stats.manifolds_popped;
+        PipeColor& c = pipe_colors[p.color];
+        if (p.color != AVN_COLOR_OVERFLOW_INDEX) { pbit_unset(c.body_bits, (uint32_t)p.b1); pbit_unset(c.body_bits, (uint32_t)p.b2); }
+        uint32_t moved = c.handles.back();
+        c.handles[p.color_pos] = moved; pipe_pairs[moved].color_pos = p.color_pos;
+        c.handles.pop_back();
+        p.n_handles = 0; p.color = -1; pipe_handles_dirty = true; ++pipe_stats.manifolds_popped;
     }
     avn_status pipeline_step() {
         avn_status st;
@@ -1255,12 +1309,11 @@ template <class T> struct World : WorldBase {
         }
         if (pipe_handles_dirty) {
             size_t n = 0;
-            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pipe_offsets[c] = (uint32_t)n; n += pipe_graph.colors[c].manifold_handles.size(); }
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pipe_offsets[c] = (uint32_t)n; n += pipe_colors[c].handles.size(); }
             pipe_offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
             pipe_handles.resize(n);
-            size_t k = 0;
             for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
-                for (const auto& h : pipe_graph.colors[c].manifold_handles) pipe_handles[k++] = (uint32_t)(h.handle >> 8);
+                if (!pipe_colors[c].handles.empty()) std::memcpy(pipe_handles.data() + pipe_offsets[c], pipe_colors[c].handles.data(), pipe_colors[c].handles.size() * 4);
             if ((st = manifold_handles_upload(pipe_offsets, pipe_handles.data())) != AVN_OK) return st;
             pipe_handles_dirty = false;
         }
@@ -1380,7 +1433,12 @@ template <class T> struct World : WorldBase {
     void contact_pass(int pass) {
         if (!dw.n_manifolds) return;
         OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
-                             sched_overflow.d_order.as<uint32_t>()};
+                             sched_overflow.d_order.as<uint32_t>(), nullptr, nullptr, 0};
+        if (sched_overflow.gorder.size() > overflow_level_threshold) {  // a big overflow colour: one device-wide launch per level instead of one workgroup per component
+            ovf.gorder = sched_overflow.d_gorder.as<uint32_t>();
+            ovf.glevel_offsets = sched_overflow.glevel_offsets.data();
+            ovf.n_glevels = (uint32_t)sched_overflow.glevel_offsets.size() - 1;
+        }
         launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, use_handles ? nullptr : color_offsets, ovf, stream);
     }
     // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is

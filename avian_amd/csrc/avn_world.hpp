@@ -40,11 +40,16 @@ struct DevBuf {
 // (see k_xpbd.hip header).
 struct JointSchedule {
     std::vector<uint32_t> comp_level_begin, level_offsets, order;
+    // the same items ordered by LEVEL only (items of one level never share a key, whatever their component): for kernels
+    // that run one launch per level over the whole device instead of one workgroup per component
+    std::vector<uint32_t> glevel_offsets, gorder;
+    DevBuf d_gorder;
     uint32_t n_components = 0;
     bool touches_dummy = false;
     DevBuf d_comp_level_begin, d_level_offsets, d_order;
     // bodies: per joint the two scheduling keys (body index, or -1 = does not serialise), in joint order
-    void build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys);
+    // levels_only: fill glevel_offsets / gorder only (no components: n_components stays 0)
+    void build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys, bool levels_only = false);
 };
 
 struct WorldBase {

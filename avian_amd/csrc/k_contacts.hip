@@ -585,9 +585,23 @@ uint32_t color_grid_blocks(uint32_t count) {
     uint32_t nb = (count + CONTACT_THREADS - 1) / CONTACT_THREADS;
     return ((nb + 7u) / 8u) * 8u;
 }
+// one level of a big overflow colour, device-wide: lane -> manifold order[first + i]
+template <class T, int PASS>
+__global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_level(DW<T> w, StepParams<T> p, const uint32_t* __restrict__ order, uint32_t first, uint32_t count) {
+    uint32_t i = xcd_block(blockIdx.x, gridDim.x) * CONTACT_THREADS + threadIdx.x;
+    if (i >= count) return;
+    pass_one<T, PASS>(w, p, order[first + i]);
+}
 template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
     uint32_t launches = 0;
-    if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_components) {
+    if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_glevels) {
+        for (uint32_t l = 0; l < ovf.n_glevels; ++l) {
+            uint32_t first = ovf.glevel_offsets[l], count = ovf.glevel_offsets[l + 1] - first;
+            if (!count) continue;
+            hipLaunchKernelGGL((k_overflow_level<T, PASS>), dim3(color_grid_blocks(count)), dim3(CONTACT_THREADS), 0, s, w, p, ovf.gorder, first, count);
+            ++launches;
+        }
+    } else if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_components) {
         hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(ovf.n_components), dim3(OVERFLOW_THREADS), 0, s, w, p, ovf.comp_level_begin, ovf.level_offsets, ovf.order);
         ++launches;
     }

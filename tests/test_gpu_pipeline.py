@@ -92,3 +92,26 @@ def test_library_pipeline_hip_matches_oracle_and_python_driver(bits):
     for f in ("pairs_added", "pairs_removed", "manifolds_pushed", "manifolds_popped", "active_pairs", "manifolds", "last_status_changes"):
         assert getattr(so, f) == getattr(sh, f), f
     assert sh.manifolds_pushed > 80 and sh.manifolds_popped > 0
+
+
+def test_overflow_colour_per_level_launches_match_oracle(monkeypatch):
+    """A pile dense enough to overflow the 23 colours, with the per-level launch path forced (threshold 0) — the same
+    bits as the oracle's serial overflow loop."""
+    monkeypatch.setenv("AVN_OVERFLOW_LEVEL_THRESHOLD", "0")
+    sc = scenes.box_stack(7, 7, 7)
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(32, substeps=4))
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable()
+        worlds.append(w)
+    wo, wh = worlds
+    seen_overflow = 0
+    for s in range(8):
+        wo.step(); wh.step()
+        seen_overflow = max(seen_overflow, wh.pipeline_stats().last_overflow_manifolds)
+        bo, bh = wo.bodies_download(), wh.bodies_download()
+        for k in bo:
+            assert np.array_equal(bo[k], bh[k]), f"step {s}: bodies.{k}"
+    assert seen_overflow > 50, "the scene must actually use colour 23"
