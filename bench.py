@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
+    ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (device narrow phase) leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample")
     args = ap.parse_args()
 
@@ -206,6 +207,33 @@ def main():
                 "note": "pageable host arrays through avn_bodies_upload / avn_manifolds_upload / *_download every step (incidence CSR rebuilt on the host); "
                         "the device-resident path above keeps everything in HBM"}
 
+    # ---- closed loop (secondary figure, never `value`): the same bodies with the DEVICE narrow phase instead of the fixed
+    # manifold set — broad phase -> narrow phase -> status changes -> ConstraintGraph -> solver, all behind avn_step
+    closed = None
+    if rank == 0 and world_size == 1 and not args.no_closed_loop:
+        wc = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
+        wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
+        wc.existing_pairs_upload(np.zeros(0, np.uint64))
+        wc.collider_materials_upload(friction=sc.friction, restitution=sc.restitution)
+        wc.pipeline_enable()
+        for _ in range(4):
+            wc.step()
+        wc.synchronize()
+        n_c = 10
+        c0 = time.perf_counter()
+        host_ms = changes = 0.0
+        for _ in range(n_c):
+            wc.step()
+            ps = wc.pipeline_stats(); host_ms += ps.last_host_ms; changes += ps.last_status_changes
+        wc.synchronize()
+        ms_c = (time.perf_counter() - c0) / n_c * 1e3
+        ps = wc.pipeline_stats()
+        closed = {"ms_per_step": round(ms_c, 3), "substeps_per_s": round(substeps / (ms_c / 1e3), 2), "active_pairs": ps.active_pairs,
+                  "manifolds": ps.manifolds, "overflow_manifolds": ps.last_overflow_manifolds, "status_changes_per_step": round(changes / n_c, 1),
+                  "host_bookkeeping_ms": round(host_ms / n_c, 3),
+                  "note": "avn_pipeline_enable: Ball/Cuboid narrow phase on device (parry part parity-unpinned), host status processing in the library"}
+        del wc
+
     # ---- CPU baseline: the oracle on the same inputs, rank 0 at N=1 only, bounded sample -------------------------
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:
@@ -258,6 +286,7 @@ def main():
             "substep_loop_only_substeps_per_s": round(substeps / (tm.substeps_ms / 1e3), 2) if tm.substeps_ms > 0 else None,
             "roofline": roofline,
             "pcie_inclusive": pcie,
+            "closed_loop": closed,
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
