@@ -110,6 +110,12 @@ template <class T> struct World : WorldBase {
     avn_config cfg;
     StepParams<T> params;
     hipStream_t stream = nullptr;
+    // The broad phase of a step only READS the body components, which the solver rewrites at the very end (write-back): with
+    // host-uploaded manifolds the two are independent until then, so avn_step runs the broad phase on a second stream next
+    // to the solver's latency-bound colour launches (which leave most of the chip idle) and joins before the write-back.
+    hipStream_t stream_bp = nullptr, bs = nullptr;  // bs: the stream the broad-phase functions launch on (stream | stream_bp)
+    hipEvent_t ev_bp_done = nullptr, ev_bp_t0 = nullptr, ev_bp_t1 = nullptr;
+    bool overlap_bp = true, bp_timed = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     DW<T> dw;
@@ -191,7 +197,10 @@ template <class T> struct World : WorldBase {
     }
     ~World() override {
         if (stream) (void)hipStreamSynchronize(stream);
+        if (stream_bp) (void)hipStreamSynchronize(stream_bp);
         drop_graph();
+        for (hipEvent_t e : {ev_bp_done, ev_bp_t0, ev_bp_t1}) if (e) (void)hipEventDestroy(e);
+        if (stream_bp) (void)hipStreamDestroy(stream_bp);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         if (ev_counters) (void)hipEventDestroy(ev_counters);
         if (h_counters) (void)hipHostFree(h_counters);
@@ -213,6 +222,11 @@ template <class T> struct World : WorldBase {
         cfg.device = c->device;
         if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&stream_bp, hipStreamNonBlocking));  // (a low stream priority made no measurable difference)
+        bs = stream;
+        HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreate(&ev_bp_t0)); HIPCHK(hipEventCreate(&ev_bp_t1));
+        if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
         for (auto& x : ev) HIPCHK(hipEventCreate(&x));
         hipError_t err;
         b_misc.ensure(4096, err);
@@ -279,6 +293,7 @@ template <class T> struct World : WorldBase {
     avn_status stage_reserve(size_t bytes) {
         hipError_t err;
         HIPCHK(hipStreamSynchronize(stream));  // arena reuse: previous users must be done
+        if (stream_bp) HIPCHK(hipStreamSynchronize(stream_bp));
         stage.ensure(bytes + 4096, err);
         if (err != hipSuccess) { error = "staging allocation failed"; return AVN_ERR_OOM; }
         stage_off = 0;
@@ -744,7 +759,7 @@ template <class T> struct World : WorldBase {
             hipError_t e2;
             b_pair_keys.ensure(std::max<size_t>(keys.size(), 1) * 8, e2);
             if (e2 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipStreamSynchronize(bs));
             if (!keys.empty()) HIPCHK(hipMemcpy(b_pair_keys.p, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
             n_pair_keys = (uint32_t)keys.size();
             expect = std::max(expect, n_pair_keys + n_pair_keys / 2);
@@ -756,10 +771,10 @@ template <class T> struct World : WorldBase {
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         bp.pair_set = b_pair_set.as<uint64_t>();
         bp.pair_set_cap = need;
-        HIPCHK(hipMemsetAsync(bp.pair_set, 0xFF, (size_t)need * 8, stream));
-        launch_hs_insert(bp.pair_set, need, b_pair_keys.as<uint64_t>(), n_pair_keys, stream);
+        HIPCHK(hipMemsetAsync(bp.pair_set, 0xFF, (size_t)need * 8, bs));
+        launch_hs_insert(bp.pair_set, need, b_pair_keys.as<uint64_t>(), n_pair_keys, bs);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(bs));
         return AVN_OK;
     }
     avn_status colliders_upload(const avn_colliders* c) override {
@@ -769,6 +784,7 @@ template <class T> struct World : WorldBase {
         for (uint32_t i = 0; i < C; ++i)
             if (c->body[i] < 0 || (uint32_t)c->body[i] >= dw.n_bodies) { error = "colliders_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
         HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(stream_bp));
         bool same = slot_entity.size() == C && (C == 0 || std::memcmp(slot_entity.data(), c->entity_index, C * 4) == 0);
         std::vector<uint32_t> new_iv;
         std::vector<V> keep_min, keep_max;
@@ -1328,7 +1344,7 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status update_aabb() {
-        launch_update_aabb<T>(dw, bp, params, stream);
+        launch_update_aabb<T>(dw, bp, params, bs);
         ++launches;
         HIPCHK(hipGetLastError());
         return AVN_OK;
@@ -1358,16 +1374,16 @@ template <class T> struct World : WorldBase {
         sweep_scratch.n_long = misc + 36;  // [36] chunks, [37] overflow
         Key* keys_a = b_keys_a.as<Key>(); Key* keys_b = b_keys_b.as<Key>();
         uint32_t* vals_a = b_vals_a.as<uint32_t>(); uint32_t* vals_b = b_vals_b.as<uint32_t>();
-        launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, stream);
-        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), d_dropped + 1, stream);
-        launch_gather_sorted<T>(dw, bp, vals_a, n, stream);
-        launch_sweep_ranges<T>(bp, n, sweep_scratch, stream);
-        launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, stream);
-        launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, stream);
+        launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, bs);
+        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), d_dropped + 1, bs);
+        launch_gather_sorted<T>(dw, bp, vals_a, n, bs);
+        launch_sweep_ranges<T>(bp, n, sweep_scratch, bs);
+        launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, bs);
+        launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, bs);
         launches += 3 + (uint32_t)sizeof(Key) * radix_pass_launches(n) + 3 + exclusive_scan_launches(n * sweep_count_slots());
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-        HIPCHK(hipEventRecord(ev_counters, stream));
+        HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
+        HIPCHK(hipEventRecord(ev_counters, bs));
         collect_pending = true;
         return AVN_OK;
     }
@@ -1382,22 +1398,22 @@ template <class T> struct World : WorldBase {
             hipError_t err;
             b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
             if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
-            launch_sweep<T>(bp, n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), stream);
+            launch_sweep<T>(bp, n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), bs);
             launches += 2;
             HIPCHK(hipGetLastError());
             h_pairs.resize(total);
-            HIPCHK(hipMemcpyAsync(h_pairs.data(), b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h_pairs.data(), b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, bs));
             // add_edge_and_key_with (reference contact_graph.rs:521-566): the new keys join the pair set
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(hipStreamSynchronize(bs));
             std::vector<uint64_t> nk(total);
             for (uint32_t i = 0; i < total; ++i) { uint32_t a = h_pairs[i].collider1, b = h_pairs[i].collider2; nk[i] = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
             if (contact_keys_live) h_live_keys.insert(nk.begin(), nk.end());
-            b_pair_keys.ensure(((size_t)n_pair_keys + total) * 8, err, true, stream);
+            b_pair_keys.ensure(((size_t)n_pair_keys + total) * 8, err, true, bs);
             if (err != hipSuccess) { error = "pair key list allocation failed"; return AVN_ERR_OOM; }
-            HIPCHK(hipMemcpyAsync(b_pair_keys.as<uint64_t>() + n_pair_keys, nk.data(), (size_t)total * 8, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipMemcpyAsync(b_pair_keys.as<uint64_t>() + n_pair_keys, nk.data(), (size_t)total * 8, hipMemcpyHostToDevice, bs));
             n_pair_keys += total;
             if (bp.pair_set_cap < 2 * (n_pair_keys + 16)) { avn_status st = rebuild_pair_set(n_pair_keys + n_pair_keys / 2); if (st != AVN_OK) return st; }
-            else { launch_hs_insert(bp.pair_set, bp.pair_set_cap, b_pair_keys.as<uint64_t>() + (n_pair_keys - total), total, stream); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(stream)); }
+            else { launch_hs_insert(bp.pair_set, bp.pair_set_cap, b_pair_keys.as<uint64_t>() + (n_pair_keys - total), total, bs); HIPCHK(hipGetLastError()); HIPCHK(hipStreamSynchronize(bs)); }
         }
         bp.n_intervals = n - dropped;  // dropped intervals were sorted to the end
         last_timers.pair_count = total;
@@ -1493,7 +1509,7 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     uint32_t graph_launches = 0;
-    avn_status solver() {
+    avn_status solver_front() {   // everything that only READS the rigid-body components
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
@@ -1507,11 +1523,20 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventRecord(ev[3], stream));
         launch_clear_increments<T>(dw, stream); ++launches;
         if (any_restitution) contact_pass(PASS_RESTITUTION_);  // restitution == 0 everywhere: every manifold would early-out
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status solver_back() {    // the write-back into Position / Rotation / velocities and the ContactGraph
         launch_writeback_solver_bodies<T>(dw, stream); ++launches;
         if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
         store_contact_impulses();
         HIPCHK(hipGetLastError());
         return AVN_OK;
+    }
+    avn_status solver() {
+        avn_status st = solver_front();
+        if (st != AVN_OK) return st;
+        return solver_back();
     }
     avn_status dispatch_system(avn_system sys) {
         avn_status st = AVN_OK;
@@ -1587,30 +1612,50 @@ template <class T> struct World : WorldBase {
         if (pipe_on) return pipeline_step();
         launches = 0;
         HIPCHK(hipEventRecord(ev[0], stream));
+        const bool overlap = overlap_bp && have_colliders;
+        bp_timed = false;
         if (have_colliders) {
-            if ((st = update_aabb()) != AVN_OK) return st;
-            if ((st = collect_launch()) != AVN_OK) return st;
+            if (overlap) {
+                HIPCHK(hipStreamWaitEvent(stream_bp, ev[0], 0));  // after the previous step's write-back
+                bs = stream_bp;
+                HIPCHK(hipEventRecord(ev_bp_t0, stream_bp));
+            }
+            st = update_aabb();
+            if (st == AVN_OK) st = collect_launch();
+            if (overlap) { (void)hipEventRecord(ev_bp_t1, stream_bp); bp_timed = true; }
+            if (st != AVN_OK) { bs = stream; return st; }
         }
         HIPCHK(hipEventRecord(ev[1], stream));
-        if ((st = solver()) != AVN_OK) return st;   // enqueued while the pair counters travel back
+        st = solver_front();                              // enqueued while the broad phase runs / its pair counters travel back
+        if (st == AVN_OK) st = collect_finish();          // (emit pass only when the step found new pairs)
+        if (overlap) {
+            (void)hipEventRecord(ev_bp_done, stream_bp);
+            (void)hipStreamWaitEvent(stream, ev_bp_done, 0);  // the write-back must not overtake k_update_aabb's reads
+            bs = stream;
+        }
+        if (st != AVN_OK) return st;
+        if ((st = solver_back()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[4], stream));
-        if ((st = collect_finish()) != AVN_OK) return st;  // (emit pass only when the step found new pairs)
         ev_valid = true;
         last_timers.kernel_launches = launches;
         return AVN_OK;
     }
-    avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); return AVN_OK; }
+    avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp)); return AVN_OK; }
     avn_status timers(avn_timers* t) override {
         if (!t) return AVN_ERR_BAD_ARG;
         HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(stream_bp));
         if (ev_valid) {
-            float a = 0, b = 0, c = 0, d = 0;
+            float a = 0, b = 0, c = 0, d = 0, e = 0;
             HIPCHK(hipEventElapsedTime(&a, ev[0], ev[1]));
             HIPCHK(hipEventElapsedTime(&b, ev[1], ev[2]));
             HIPCHK(hipEventElapsedTime(&c, ev[2], ev[3]));
             HIPCHK(hipEventElapsedTime(&d, ev[3], ev[4]));
+            HIPCHK(hipEventElapsedTime(&e, ev[0], ev[4]));
+            // overlapped broad phase: its own duration on its own stream (it is NOT a term of step_ms then)
+            if (bp_timed) HIPCHK(hipEventElapsedTime(&a, ev_bp_t0, ev_bp_t1));
             last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;
-            last_timers.step_ms = (double)a + b + c + d;
+            last_timers.step_ms = e;
         }
         uint32_t cc = 0;
         HIPCHK(hipMemcpy(&cc, dw.constraint_count, 4, hipMemcpyDeviceToHost));

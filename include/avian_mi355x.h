@@ -408,7 +408,9 @@ typedef struct avn_timers {
     double prepare_ms;      /* prepare bodies + joints + constraints + increments */
     double substeps_ms;     /* the whole substep loop */
     double finalize_ms;     /* clear + restitution + writeback + store */
-    double step_ms;         /* all of the above */
+    double step_ms;         /* the whole step on the main stream.  In avn_step with host-uploaded manifolds the broad phase
+                               runs on a second stream next to the solver (it only reads what the solver rewrites at the very
+                               end): broad_phase_ms is then its own duration and NOT a term of step_ms */
     uint32_t contact_constraint_count;
     uint32_t pair_count;
     uint32_t kernel_launches; /* launches issued (or replayed) in the last step */
