@@ -8,7 +8,9 @@ A "step" = one pass of the hot path over the device-resident world (`avn_step`):
 broad phase + solver-body/constraint preparation + S substeps (integrate, warm start, biased solve, integrate
 positions, relax, XPBD) + restitution + write-back + impulse store — everything SURVEY.md §8(d) counts in the
 "whole step".  Inputs are resident in HBM before the timed region; the narrow phase (parry, out of scope) is not
-part of the path, so the manifold set is fixed during the timed steps while body state evolves.
+part of the path, so the manifold set is fixed during the timed steps while body state evolves.  Inside avn_step the
+broad phase runs on a second stream next to the solver (it only reads what the solver rewrites at the very end), so
+`device_ms.broad_phase` is its own duration and the four device_ms figures do not add up to ms_per_step.
 
   value      = N_gpus * K * substeps / max-over-ranks wall seconds   (physics substeps / second, whole step)
   roofline   = the dominant kernel (k_color_pass<SOLVE_BIAS>: TGS-Soft biased contact solve, one launch per graph
