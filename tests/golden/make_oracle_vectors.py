@@ -67,6 +67,9 @@ def main():
         out.update(solver_case(bits, seed=2026))
         out.update(broadphase_case(bits))
         out.update(joints_case(bits))
+        sys.path.insert(0, os.path.dirname(HERE))
+        import golden_checks  # the narrow-phase / closed-loop case lives there (one definition for generator and checkers)
+        out.update(golden_checks.narrow_vectors(oracle_lib(), bits))
         path = os.path.join(HERE, f"oracle_vectors_f{bits}.npz")
         np.savez_compressed(path, **out)
         print(path, os.path.getsize(path), "bytes", len(out), "arrays")

@@ -118,6 +118,34 @@ def broadphase_vectors(lib, bits):
     return out
 
 
+def narrow_vectors(lib, bits):
+    """contact_query::contact_manifolds on 300 seeded shape pairs + a closed-loop pile (device narrow phase) after 12 steps."""
+    from narrow_scenes import random_pairs
+    from pipeline_scenes import dropped_boxes
+    w = F.World(lib, F.default_config(bits))
+    q = w.contact_manifolds(**random_pairs(5, 300))
+    out = {f"np.query.{k}": v for k, v in q.items()}
+    w.close()
+    bodies, colliders = dropped_boxes(seed=13, n=36)
+    w = F.World(lib, F.default_config(bits, substeps=3))
+    w.bodies_upload(**bodies); w.colliders_upload(**colliders)
+    w.existing_pairs_upload(np.zeros(0, np.uint64))
+    w.collider_materials_upload(friction=0.7, restitution=0.1)
+    w.pipeline_enable()
+    for _ in range(12):
+        w.step()
+    w.synchronize()
+    off, handles = w.pipeline_handles()
+    out["np.loop.color_offsets"] = off
+    out["np.loop.handles"] = handles
+    for k, v in w.contacts_download(np.sort(handles)).items():
+        out[f"np.loop.contacts.{k}"] = v
+    for k, v in w.bodies_download().items():
+        out[f"np.loop.bodies.{k}"] = v
+    w.close()
+    return out
+
+
 def check_vectors(got: dict, bits: int):
     want = np.load(os.path.join(GOLDEN, f"oracle_vectors_f{bits}.npz"))
     keys = [k for k in want.files if k in got]

@@ -21,7 +21,8 @@ def test_hip_matches_frozen_vectors(bits, use_graph):
     got = G.solver_vectors(hip_lib(), bits, hip_lib(), use_graph=use_graph)   # product colouring, product solver
     got.update(G.broadphase_vectors(hip_lib(), bits))
     got.update(G.joints_vectors(hip_lib(), bits, hip_lib(), use_graph=use_graph))
-    assert G.check_vectors(got, bits) == 29
+    got.update(G.narrow_vectors(hip_lib(), bits))
+    assert G.check_vectors(got, bits) == 57
 
 
 def test_hip_is_deterministic_run_to_run():

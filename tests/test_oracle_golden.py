@@ -17,7 +17,8 @@ def test_oracle_matches_frozen_vectors(bits):
     got = G.solver_vectors(oracle_lib(), bits, oracle_lib())
     got.update(G.broadphase_vectors(oracle_lib(), bits))
     got.update(G.joints_vectors(oracle_lib(), bits, oracle_lib()))
-    assert G.check_vectors(got, bits) == 29
+    got.update(G.narrow_vectors(oracle_lib(), bits))
+    assert G.check_vectors(got, bits) == 57
 
 
 def test_oracle_is_deterministic_run_to_run():
