@@ -117,6 +117,10 @@ template <class T> struct World : WorldBase {
     hipEvent_t ev_bp_done = nullptr, ev_bp_t0 = nullptr, ev_bp_t1 = nullptr;
     bool overlap_bp = true, bp_timed = false;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    static constexpr uint32_t BIAS_EV = 16;      // substeps whose biased-solve pass is bracketed by events (direct launches only)
+    hipEvent_t ev_bias[2 * BIAS_EV] = {nullptr};
+    uint32_t bias_timed = 0, bias_launches = 0;  // substeps timed in the last step; launches of one pass
+    uint32_t substep_index = 0;
     bool ev_valid = false;
     DW<T> dw;
     BP<T> bp;
@@ -202,6 +206,7 @@ template <class T> struct World : WorldBase {
         for (hipEvent_t e : {ev_bp_done, ev_bp_t0, ev_bp_t1}) if (e) (void)hipEventDestroy(e);
         if (stream_bp) (void)hipStreamDestroy(stream_bp);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_bias) if (e) (void)hipEventDestroy(e);
         if (ev_counters) (void)hipEventDestroy(ev_counters);
         if (h_counters) (void)hipHostFree(h_counters);
         if (stream) (void)hipStreamDestroy(stream);
@@ -221,13 +226,16 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipSetDevice(c->device));
         cfg.device = c->device;
         if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
+        // (CU masks -- 64 CUs for the broad phase, 192 for the solver -- were tried for the overlap below and lost: a colour launch
+        //  on 192 CUs is 12 % slower than on 256, more than the contention it avoids; tools/cumask_probe.hip)
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-        HIPCHK(hipStreamCreateWithFlags(&stream_bp, hipStreamNonBlocking));  // (a low stream priority made no measurable difference)
+        HIPCHK(hipStreamCreateWithFlags(&stream_bp, hipStreamNonBlocking));
         bs = stream;
         HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming));
         HIPCHK(hipEventCreate(&ev_bp_t0)); HIPCHK(hipEventCreate(&ev_bp_t1));
         if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
         for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+        for (auto& x : ev_bias) HIPCHK(hipEventCreate(&x));
         hipError_t err;
         b_misc.ensure(4096, err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
@@ -1484,7 +1492,13 @@ template <class T> struct World : WorldBase {
     }
     void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)
         warm_start(true);  // integrate_velocities + warm_start
+        // measurement hook: the dominant kernel's launches inside the step.  Direct launches only: events recorded as nodes of a
+        // captured graph cannot be read back with hipEventElapsedTime on this runtime (hipErrorInvalidHandle).
+        const bool timed = substep_index < BIAS_EV && dw.n_manifolds != 0 && !cfg.use_graph;
+        if (timed) { (void)hipEventRecord(ev_bias[2 * substep_index], stream); bias_launches = launches; }
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_BIAS);
+        if (timed) { (void)hipEventRecord(ev_bias[2 * substep_index + 1], stream); bias_launches = launches - bias_launches; bias_timed = substep_index + 1; }
+        ++substep_index;
         integrate_positions();
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_RELAX);
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
@@ -1492,6 +1506,8 @@ template <class T> struct World : WorldBase {
         joint_damping();
     }
     avn_status run_substeps() {
+        substep_index = 0;
+        bias_timed = 0;
         if (!cfg.use_graph) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
         if (!graph_valid) {
             drop_graph();
@@ -1656,6 +1672,12 @@ template <class T> struct World : WorldBase {
             if (bp_timed) HIPCHK(hipEventElapsedTime(&a, ev_bp_t0, ev_bp_t1));
             last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;
             last_timers.step_ms = e;
+            last_timers.bias_pass_ms = 0; last_timers.bias_pass_launches = 0;
+            if (bias_timed) {   // mean over the step's substeps
+                double sum = 0;
+                for (uint32_t k = 0; k < bias_timed; ++k) { float f = 0; HIPCHK(hipEventElapsedTime(&f, ev_bias[2 * k], ev_bias[2 * k + 1])); sum += f; }
+                last_timers.bias_pass_ms = sum / bias_timed; last_timers.bias_pass_launches = bias_launches;
+            }
         }
         uint32_t cc = 0;
         HIPCHK(hipMemcpy(&cc, dw.constraint_count, 4, hipMemcpyDeviceToHost));

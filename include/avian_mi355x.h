@@ -414,7 +414,10 @@ typedef struct avn_timers {
     uint32_t contact_constraint_count;
     uint32_t pair_count;
     uint32_t kernel_launches; /* launches issued (or replayed) in the last step */
-    uint32_t reserved;
+    uint32_t bias_pass_launches; /* colour launches of ONE biased-solve pass (solve_contacts<true>) */
+    double bias_pass_ms;      /* device time of that pass, MEAN over the last step's substeps, each bracketed by events on the world's
+                                 stream: the in-step duration of the dominant kernel for the roofline.  Only with use_graph = 0
+                                 (0 otherwise: events captured into a hipGraph cannot be read back) */
 } avn_timers;
 
 /* ---- entry points --------------------------------------------------------------------------- */
