@@ -106,10 +106,15 @@ template <class T> struct DW {
     int16_t* c_reldom;  // inspection only
     uint32_t* color_offsets;  // [25] device copy
     uint32_t* constraint_count;  // [1]
-    // body -> incident (manifold, side) list in SOLVE order (overflow colour first, then colours 0..22; list order inside
-    // a colour) for the body-centric warm start: CSR over bodies; only bodies that have a SolverBody own entries
-    const uint32_t* inc_off;   // [n_bodies + 1]
-    const uint32_t* inc_ent;   // manifold | side << 31  (side 0: the body is the manifold's body1, 1: body2)
+    // body -> incident (manifold, side) entries for the body-centric warm start, in SOLVE order:
+    //  - colours 0..22: a body is in at most ONE manifold per colour, so the incidence is a slot table inc_slot[colour][body]
+    //    (colour-major planes of inc_stride entries; EMPTY = ~0), built on the device from the manifold arrays;
+    //  - the overflow colour (solved first, list order): a small CSR over bodies, built by the host.
+    //  entry = manifold | side << 31  (side 0: the body is the manifold's body1, 1: body2)
+    const uint32_t* inc_off;   // [n_bodies + 1]  overflow entries only
+    const uint32_t* inc_ent;
+    uint32_t* inc_slot;        // [AVN_COLOR_OVERFLOW_INDEX][inc_stride]
+    uint32_t inc_stride;
     // ---- XPBD joints (all five types; the reference's per-type components + solver data) ----
     uint32_t n_joints;
     int2* j_bodies;

@@ -56,6 +56,8 @@ template <class T> void launch_prepare_contact_constraints(const DW<T>&, const S
 template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
 // body-centric warm start over the incidence CSR (DW::inc_off / inc_ent), optionally preceded by integrate_velocities
 template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);
+// (re)build DW::inc_slot from DW::m_bodies / color_offsets (memset + one kernel)
+template <class T> void launch_build_incidence_slots(const DW<T>&, hipStream_t);
 uint32_t color_grid_blocks(uint32_t count);
 // level schedule of the overflow colour (device arrays; see k_overflow_pass): manifold indices in `order`
 struct OverflowSchedule {

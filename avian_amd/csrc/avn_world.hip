@@ -134,7 +134,9 @@ template <class T> struct World : WorldBase {
         b_j_torque;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
     DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
-    DevBuf b_inc_off, b_inc_ent;
+    DevBuf b_inc_off, b_inc_ent, b_inc_slot;
+    bool overflow_csr_nonzero = true;  // the device CSR offsets may be non-zero (first build uploads them)
+    uint32_t overflow_csr_bodies = 0;
     // ---- narrow phase: the ContactGraph side on device (CT) + host mirrors of what the host structures of the reference hold ----
     CT<T> ct;
     DevBuf b_ct_meta, b_ct_dcount, b_ct_n, b_ct_tv, b_ct_a1, b_ct_a2, b_ct_w, b_ct_fid, b_col_mat, b_active, b_changes, b_handles;
@@ -483,29 +485,40 @@ template <class T> struct World : WorldBase {
     }
     // Incidence CSR of the body-centric warm start: per body that has a SolverBody, its (manifold, side) entries in SOLVE
     // order = overflow colour first, then colours 0..22 (reference plugin.rs:461-470), list order inside a colour.
+    // Incidence of the body-centric warm start.  Colours 0..22: the slot table is (re)built ON THE DEVICE from the manifold arrays
+    // (launch_build_incidence_slots, run after the manifolds are in place).  Host part: only the overflow colour -- its
+    // per-body entry lists (CSR, list order) and its level schedule.
+    bool slots_dirty = true;
     avn_status rebuild_incidence() {
         if (!incidence_dirty) return AVN_OK;
         uint32_t N = dw.n_bodies, M = dw.n_manifolds;
         if (M == 0) { incidence_dirty = false; return AVN_OK; }
         if (h_body_has_sb.size() != N || h_m_body1.size() != M) { error = "incidence: bodies / manifolds out of sync"; return AVN_ERR_STATE; }
         HIPCHK(hipStreamSynchronize(stream));
+        hipError_t err;
+        {   // slot table storage: 23 colour planes of cap_bodies entries
+            bool moved = b_inc_slot.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * cap_bodies * sizeof(uint32_t), err);
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            if (moved || dw.inc_stride != cap_bodies) graph_valid = false;
+            dw.inc_slot = b_inc_slot.as<uint32_t>();
+            dw.inc_stride = cap_bodies;
+            slots_dirty = true;
+        }
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], o1 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
         std::vector<uint32_t>& off = inc_off_h; std::vector<uint32_t>& cursor = inc_cursor_h; std::vector<uint32_t>& ent = inc_ent_h;
         off.assign((size_t)N + 1, 0u);
-        for (uint32_t m = 0; m < M; ++m) {
+        for (uint32_t m = o0; m < o1; ++m) {
             if (h_body_has_sb[h_m_body1[m]]) ++off[(size_t)h_m_body1[m] + 1];
             if (h_body_has_sb[h_m_body2[m]]) ++off[(size_t)h_m_body2[m] + 1];
         }
         for (uint32_t i = 0; i < N; ++i) off[i + 1] += off[i];
         cursor.assign(off.begin(), off.end() - 1);
         ent.resize(off[N]);
-        auto visit = [&](uint32_t m) {
+        for (uint32_t m = o0; m < o1; ++m) {
             uint32_t a = (uint32_t)h_m_body1[m], b = (uint32_t)h_m_body2[m];
             if (h_body_has_sb[a]) ent[cursor[a]++] = m;
             if (h_body_has_sb[b]) ent[cursor[b]++] = m | 0x80000000u;
-        };
-        for (uint32_t m = color_offsets[AVN_COLOR_OVERFLOW_INDEX]; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1]; ++m) visit(m);
-        for (uint32_t m = 0; m < color_offsets[AVN_COLOR_OVERFLOW_INDEX]; ++m) visit(m);
-        hipError_t err;
+        }
         bool moved = b_inc_off.ensure(((size_t)N + 1) * 4, err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         moved |= b_inc_ent.ensure(std::max<size_t>(ent.size(), 1) * sizeof(uint32_t), err);
@@ -513,11 +526,16 @@ template <class T> struct World : WorldBase {
         if (moved || !dw.inc_off) graph_valid = false;
         dw.inc_off = b_inc_off.as<uint32_t>();
         dw.inc_ent = b_inc_ent.as<uint32_t>();
-        HIPCHK(hipMemcpyAsync(b_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, stream));
-        if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipStreamSynchronize(stream));  // `off` / `ent` are locals
+        if (o1 > o0 || overflow_csr_nonzero) {   // an all-zero offset array stays valid while the overflow colour is empty
+            HIPCHK(hipMemcpyAsync(b_inc_off.p, off.data(), off.size() * 4, hipMemcpyHostToDevice, stream));
+            if (!ent.empty()) HIPCHK(hipMemcpyAsync(b_inc_ent.p, ent.data(), ent.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            overflow_csr_nonzero = o1 > o0;
+        } else if (moved || overflow_csr_bodies != N) {
+            HIPCHK(hipMemsetAsync(b_inc_off.p, 0, ((size_t)N + 1) * 4, stream));
+        }
+        overflow_csr_bodies = N;
         {   // level schedule of the overflow colour (k_overflow_pass): keys = the bodies a manifold can modify
-            uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], o1 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
             std::vector<uint32_t> ms(o1 - o0);
             std::vector<int32_t> k1(o1 - o0), k2(o1 - o0);
             for (uint32_t m = o0; m < o1; ++m) {
@@ -1073,11 +1091,11 @@ template <class T> struct World : WorldBase {
         uint32_t M = offsets[AVN_GRAPH_COLOR_COUNT];
         if (M && !ids) return AVN_ERR_BAD_ARG;
         h_m_body1.resize(M); h_m_body2.resize(M);
-        for (uint32_t i = 0; i < M; ++i) {
+        for (uint32_t i = 0; i < M; ++i)
             if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "manifold_handles_upload: no such contact"; return AVN_ERR_STATE; }
-            h_m_body1[i] = h_ct_b1[ids[i]];
-            h_m_body2[i] = h_ct_b2[ids[i]];
-        }
+        // the host only needs the bodies of the OVERFLOW colour's manifolds (entry lists + level schedule); the incidence of
+        // colours 0..22 is built on the device
+        for (uint32_t i = offsets[AVN_COLOR_OVERFLOW_INDEX]; i < M; ++i) { h_m_body1[i] = h_ct_b1[ids[i]]; h_m_body2[i] = h_ct_b2[ids[i]]; }
         HIPCHK(hipStreamSynchronize(stream));
         avn_status st = ensure_manifold_capacity(M);
         if (st != AVN_OK) return st;
@@ -1440,6 +1458,7 @@ template <class T> struct World : WorldBase {
     void prepare_contact_constraints() {
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+        if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
         launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
     }
     void store_contact_impulses() {
@@ -1450,7 +1469,10 @@ template <class T> struct World : WorldBase {
     void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
     // warm start of ALL colours in one body-centric launch; `fused` also runs integrate_velocities for the body first
     void warm_start(bool fused) {
-        if (dw.n_manifolds) { launch_body_warm_start<T>(dw, params, fused, stream); ++launches; }
+        if (dw.n_manifolds) {
+            if (slots_dirty && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }  // (normally done by prepare)
+            launch_body_warm_start<T>(dw, params, fused, stream); ++launches;
+        }
         else if (fused) integrate_velocities();
     }
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }

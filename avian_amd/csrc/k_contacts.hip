@@ -193,57 +193,65 @@ __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepPar
     if (body >= w.n_bodies) return;
     const uint32_t sbf = w.sb_flags[body];
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
+    // the 23 colour slots of this body: coalesced across the wave (neighbouring lanes = neighbouring bodies), issued up front
+    uint32_t slot0 = w.inc_slot[body];
     uint32_t e = w.inc_off[body];
     const uint32_t end = w.inc_off[body + 1];
     Vec4<T> l4 = w.sb_lin[body], a4 = w.sb_ang[body];
     Vec4<T> sa = w.si_a[body], sb = w.si_b[body];
-    WarmRecords<T> cur, nxt;
-    uint32_t ent_cur = 0, ent_nxt = 0;
-    if (e < end) { ent_cur = w.inc_ent[e]; warm_fetch<T>(w, ent_cur, cur); }
-    if (e + 1 < end) ent_nxt = w.inc_ent[e + 1];
     V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
     bool touched = false;
     if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om);
     const V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
     const T coeff = p.warm_start_coefficient;
     const T z = T(0);
-    for (; e < end; ++e) {
-        const bool has_next = e + 1 < end;
-        uint32_t ent_nn = 0;
-        if (has_next) {
-            warm_fetch<T>(w, ent_nxt, nxt);
-            if (e + 2 < end) ent_nn = w.inc_ent[e + 2];
-        }
-        {
-            const uint32_t side = ent_cur >> 31;
-            const uint32_t cm = scalar_to_bits(cur.h1.w);
-            uint32_t np = cm & 7u;
-            if (cm & (side ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1)) np = 0;  // (stale incidence: the body lost its SolverBody)
-            if (np) {
-                // SolverBodyInertia, or DUMMY for the dominant body (plugin.rs:508-512)
-                const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
-                const V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
-                const Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
-                const V3<T> normal = xyz<T>(cur.h0);
-                const V3<T> t0 = xyz<T>(cur.h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
+    auto apply = [&](const WarmRecords<T>& r, uint32_t ent) {
+        const uint32_t side = ent >> 31;
+        const uint32_t cm = scalar_to_bits(r.h1.w);
+        uint32_t np = cm & 7u;
+        if (cm & (side ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1)) np = 0;  // (stale incidence: the body lost its SolverBody)
+        if (!np) return;
+        // SolverBodyInertia, or DUMMY for the dominant body (plugin.rs:508-512)
+        const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
+        const V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
+        const Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
+        const V3<T> normal = xyz<T>(r.h0);
+        const V3<T> t0 = xyz<T>(r.h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
 #pragma unroll
-                for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-                    if (k < np) {
-                        const V3<T> r = xyz<T>(cur.pr[k]);
-                        const Vec4<T> d = cur.pd[k];
-                        const T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
-                        const V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
-                        const V3<T> dv = cmul(imp, inv_mass);
-                        const V3<T> dw = smul(I, cross(r, imp));
-                        if (side) { v = v + dv; om = om + dw; }   // body2: v += p * w2, om += I2 (r2 x p)
-                        else { v = v - dv; om = om - dw; }         // body1: v -= p * w1, om -= I1 (r1 x p)
-                    }
-                }
-                touched = true;
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            if (k < np) {
+                const V3<T> rr = xyz<T>(r.pr[k]);
+                const Vec4<T> d = r.pd[k];
+                const T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
+                const V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
+                const V3<T> dv = cmul(imp, inv_mass);
+                const V3<T> dw = smul(I, cross(rr, imp));
+                if (side) { v = v + dv; om = om + dw; }   // body2: v += p * w2, om += I2 (r2 x p)
+                else { v = v - dv; om = om - dw; }         // body1: v -= p * w1, om -= I1 (r1 x p)
             }
         }
-        cur = nxt; ent_cur = ent_nxt; ent_nxt = ent_nn;
+        touched = true;
+    };
+    WarmRecords<T> cur, nxt;
+    // (1) the overflow colour's entries, in list order (solved FIRST, plugin.rs:461-467); usually none
+    for (; e < end; ++e) {
+        uint32_t ent = w.inc_ent[e];
+        warm_fetch<T>(w, ent, cur);
+        apply(cur, ent);
     }
+    // (2) colours 0..22 through the slot table; the next colour's ten records are in flight while the current one is applied
+    bool cur_valid = false;
+    uint32_t ent_cur = 0, slot_next = slot0;
+    for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) {
+        const uint32_t sc = slot_next;
+        slot_next = c + 1 < AVN_COLOR_OVERFLOW_INDEX ? w.inc_slot[(size_t)(c + 1) * w.inc_stride + body] : 0xFFFFFFFFu;
+        const bool valid = sc != 0xFFFFFFFFu;
+        if (valid) warm_fetch<T>(w, sc, nxt);
+        if (cur_valid) apply(cur, ent_cur);
+        cur_valid = valid;
+        if (valid) { cur = nxt; ent_cur = sc; }
+    }
+    if (cur_valid) apply(cur, ent_cur);
     if (touched) {
         w.sb_lin[body] = make4<T>(v, l4.w);
         w.sb_ang[body] = make4<T>(om, a4.w);
@@ -614,6 +622,23 @@ template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const S
         }
     return launches;
 }
+// inc_slot[colour][body] <- manifold | side << 31 for the manifolds of colours 0..22 (the table was cleared to EMPTY before).
+// A dynamic body is in at most one manifold per colour (constraint_graph.rs:36-48): no two lanes write the same slot of a
+// body that ever reads it (static bodies collect many writes per colour, and never run the warm start).
+template <class T>
+__global__ __launch_bounds__(256) void k_build_incidence_slots(DW<T> w) {
+    uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= w.color_offsets[AVN_COLOR_OVERFLOW_INDEX]) return;
+    uint32_t lo = 0, hi = AVN_COLOR_OVERFLOW_INDEX;  // colour c: offsets[c] <= m < offsets[c + 1]
+    while (hi - lo > 1) { uint32_t mid = (lo + hi) >> 1; if (w.color_offsets[mid] <= m) lo = mid; else hi = mid; }
+    int2 b = w.m_bodies[m];
+    w.inc_slot[(size_t)lo * w.inc_stride + (uint32_t)b.x] = m;
+    w.inc_slot[(size_t)lo * w.inc_stride + (uint32_t)b.y] = m | 0x80000000u;
+}
+template <class T> void launch_build_incidence_slots(const DW<T>& w, hipStream_t s) {
+    (void)hipMemsetAsync(w.inc_slot, 0xFF, (size_t)AVN_COLOR_OVERFLOW_INDEX * w.inc_stride * sizeof(uint32_t), s);
+    if (w.n_manifolds) hipLaunchKernelGGL(k_build_incidence_slots<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w);
+}
 template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
     if (!w.n_bodies) return;
     uint32_t nb = (w.n_bodies + WS_THREADS - 1) / WS_THREADS;
@@ -634,6 +659,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
+    template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t);                               \
     template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t);
 INST(float)
 INST(double)
