@@ -469,6 +469,7 @@ template <class S> struct World : WorldBase {
             error = "manifolds_upload: null array"; return AVN_ERR_BAD_ARG;
         }
         if (m->color_offsets[0] != 0 || m->color_offsets[AVN_GRAPH_COLOR_COUNT] != m->count) { error = "manifolds_upload: bad color_offsets"; return AVN_ERR_BAD_ARG; }
+        use_handles = false;  // the manifolds come from the host again (not from the contact table)
         for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
             if (m->color_offsets[c] > m->color_offsets[c + 1]) { error = "manifolds_upload: color_offsets not monotone"; return AVN_ERR_BAD_ARG; }
         std::memcpy(color_offsets, m->color_offsets, sizeof color_offsets);
