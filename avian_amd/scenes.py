@@ -113,6 +113,40 @@ def large_pyramid(base_count: int = 100) -> Scene:
     return _assemble(np.array(cs), (0.5, 0.5, 0.5), (0.0, -20.0, 0.0), (400.0, 20.0, 400.0))
 
 
+def many_pyramids(base_count: int = 10, row_count: int = 10, column_count: int = 10) -> Scene:
+    """The reference's "Many Pyramids 3D" bench scene (benches/src/dim3/many_pyramids.rs:15-64): `row_count` static ground
+    plates cuboid(w, 0.01, w) stacked `ground_delta_y` apart, each carrying `column_count` small pyramids; f32 arithmetic.
+    Bodies 0..row_count-1 are the grounds (spawned first, like the reference)."""
+    f = np.float32
+    h = f(0.5)
+    ground_delta_y = f(2.0) * h * f(base_count + 1)
+    ground_width = f(2.0) * h * f(column_count) * f(base_count + 1)
+    base_width = f(2.0) * h * f(base_count)
+    centers = []
+    for i in range(row_count):
+        base_y = f(i) * ground_delta_y
+        for j in range(column_count):
+            center_x = -ground_width / f(2.0) + f(j) * (base_width + f(2.0) * h) + h
+            for a in range(base_count):
+                y = f(2 * a + 1) * h + base_y
+                for b in range(a, base_count):
+                    x = f(a + 1) * h + f(2.0) * f(b - a) * h + center_x - f(0.5)
+                    centers.append((float(x), float(y), 0.0))
+    nd = len(centers)
+    n = row_count + nd
+    pos = np.zeros((n, 3)); he = np.zeros((n, 3))
+    for i in range(row_count):
+        pos[i] = (0.0, float(f(i) * ground_delta_y), 0.0)
+        he[i] = (float(ground_width) / 2, 0.005, float(ground_width) / 2)
+    pos[row_count:] = centers; he[row_count:] = 0.5
+    rot = np.zeros((n, 4)); rot[:, 3] = 1.0
+    m, (ixx, iyy, izz) = cuboid_mass_properties(0.5, 0.5, 0.5)
+    inv_mass = np.full(n, 1.0 / m); inv_mass[:row_count] = 0.0
+    inv_i = np.zeros((n, 6)); inv_i[row_count:, 0] = 1.0 / ixx; inv_i[row_count:, 3] = 1.0 / iyy; inv_i[row_count:, 5] = 1.0 / izz
+    rb = np.zeros(n, np.uint8); rb[:row_count] = F.RB_STATIC
+    return Scene(pos, rot, np.zeros((n, 3)), np.zeros((n, 3)), inv_mass, inv_i, rb, he, np.zeros(n, np.uint8))
+
+
 def cubes_test_scene() -> Scene:
     """src/tests/mod.rs:51-85: 4x4x4 cubes of side 2 dropped on an 80x1x80 floor."""
     radius = 1.0
