@@ -176,7 +176,8 @@ class avn_islands_in(C.Structure):
 class avn_timers(C.Structure):
     _fields_ = [("broad_phase_ms", C.c_double), ("prepare_ms", C.c_double), ("substeps_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("step_ms", C.c_double), ("contact_constraint_count", C.c_uint32),
-                ("pair_count", C.c_uint32), ("kernel_launches", C.c_uint32), ("bias_pass_launches", C.c_uint32), ("bias_pass_ms", C.c_double)]
+                ("pair_count", C.c_uint32), ("kernel_launches", C.c_uint32), ("bias_pass_launches", C.c_uint32), ("bias_pass_ms", C.c_double),
+                ("island_blocks", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
 PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),

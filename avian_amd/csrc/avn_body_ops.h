@@ -20,8 +20,9 @@ __device__ __forceinline__ V3<T> solve_gyroscopic_torque(V3<T> ang_vel, Q4<T> ro
 
 // integrate_velocities + clamp_velocities for ONE body that has a SolverBody (reference dynamics/integrator/mod.rs:343-391,
 // 467-500); v / om are the SolverBody velocities, updated in place; returns true when they were (re)written.
+// `dq`: where the body's current SolverBody::delta_rotation lives (HBM or an LDS block); only the gyroscopic branch reads it.
 template <class T>
-__device__ __forceinline__ bool integrate_velocities_one(const DW<T>& w, const StepParams<T>& p, uint32_t i, uint32_t sbf, V3<T>& v, V3<T>& om) {
+__device__ __forceinline__ bool integrate_velocities_one(const DW<T>& w, const StepParams<T>& p, uint32_t i, uint32_t sbf, V3<T>& v, V3<T>& om, const Vec4<T>* dq) {
     uint32_t meta = w.bmeta[i];
     bool touched = false;
     if (!(meta_flags(meta) & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION) && !(sbf & AVN_SB_KINEMATIC)) {
@@ -33,7 +34,7 @@ __device__ __forceinline__ bool integrate_velocities_one(const DW<T>& w, const S
         if (sbf & AVN_SB_GYROSCOPIC) {
             Vec4<T> la = w.iloc_a[i], lb = w.iloc_b[i];
             Sym3<T> local{la.x, la.y, la.z, la.w, lb.x, lb.y};
-            Q4<T> rotation = qmul(quat<T>(w.sb_dq[i]), quat<T>(w.rot[i]));
+            Q4<T> rotation = qmul(quat<T>(*dq), quat<T>(w.rot[i]));
             om = solve_gyroscopic_torque(om, rotation, local, p.h_f64cast);
         }
         touched = true;
@@ -50,6 +51,29 @@ __device__ __forceinline__ bool integrate_velocities_one(const DW<T>& w, const S
         if (sq > max_ang * max_ang) { om = om * (max_ang / sqrt_t(sq)); touched = true; }
     }
     return touched;
+}
+
+// integrate_positions (reference dynamics/integrator/mod.rs:503-535) + update_solver_body_angular_inertia
+// (solver/solver_body/plugin.rs:287-295: recomputed from the STEP-START Rotation every substep) for one body that has a
+// SolverBody; all four records are updated in place (the caller stores them where they live).
+template <class T>
+__device__ __forceinline__ void integrate_positions_one(const DW<T>& w, const StepParams<T>& p, uint32_t i, V3<T> v, V3<T> om, Vec4<T>& dp4, Vec4<T>& dq4,
+                                                        Vec4<T>& sa, Vec4<T>& sb) {
+    uint32_t meta = w.bmeta[i];
+    T delta_secs = p.h_adj;
+    if (!(meta_flags(meta) & AVN_BODY_CUSTOM_POSITION_INTEGRATION)) {
+        V3<T> dp = xyz<T>(dp4) + v * delta_secs;
+        Q4<T> dq = qmul(from_scaled_axis(om * delta_secs), quat<T>(dq4));
+        dp4 = make4<T>(dp, dp4.w);
+        dq4 = make4<T>(dq);
+    }
+    Vec4<T> la = w.iloc_a[i], lb = w.iloc_b[i];
+    Sym3<T> local{la.x, la.y, la.z, la.w, lb.x, lb.y};
+    Sym3<T> t = rotated_inverse_inertia(local, quat<T>(w.rot[i]));
+    uint32_t iflags = scalar_to_bits(sb.w);
+    lock_rotation_axes(t, iflags & 0x3Fu);
+    sa = make4<T>(sa.x, t.m00, t.m01, t.m02);
+    sb = make4<T>(t.m11, t.m12, t.m22, sb.w);
 }
 
 }  // namespace avn

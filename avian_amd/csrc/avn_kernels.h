@@ -67,6 +67,14 @@ struct OverflowSchedule {
 // grid_blocks[c] = captured grid of colour c (0 = colour skipped); arg_offsets: the 25 colour offsets to pass in the kernel
 // arguments, or nullptr = the kernels read the live ranges from DW::color_offsets; returns the number of launches issued
 template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule&, hipStream_t);
+// Island blocks (k_island_substeps): block b owns bodies[body_off[b] .. body_off[b+1]) (world body indices; LDS slot = position in
+// the range) and, per colour slot (0 = the overflow colour, 1 + c = colour c: solve order), the entries
+// ent[col_off[24 b + slot] .. col_off[24 b + slot + 1]) = (manifold index, LDS slot of body1 | LDS slot of body2 << 16); a side
+// without a SolverBody points at slot 0 and is masked by the constraint's NOBODY flag.
+#define ISLAND_THREADS 256
+#define ISLAND_MAX_BODIES 512
+struct IslandBlocks { const uint32_t *body_off, *bodies, *col_off; const uint2* ent; uint32_t n_blocks; };
+void launch_island_substeps(const DW<float>&, const StepParams<float>&, const IslandBlocks&, uint32_t substeps, uint32_t iterations, hipStream_t);
 // k_xpbd.hip
 template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);
 template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,

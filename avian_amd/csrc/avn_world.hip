@@ -178,6 +178,13 @@ template <class T> struct World : WorldBase {
     bool joint_schedule_dirty = true;
     JointSchedule sched_solve, sched_damp, sched_overflow;
     size_t overflow_level_threshold = 4096;  // overflow manifolds above which the colour runs one launch per level (AVN_OVERFLOW_LEVEL_THRESHOLD overrides: tests)
+    // island blocks (k_island_substeps): the whole substep loop in one launch when the contact graph is many small islands
+    bool island_enabled = true, island_mode = false;
+    size_t island_max_manifolds = 65536;  // above this the colour launches are throughput- not latency-bound (1 wave per SIMD = 65k manifolds): keep the device-wide path
+    uint32_t island_pack_bodies = 256;    // islands are packed into one block up to this many bodies (a single island may reach ISLAND_MAX_BODIES)
+    std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent;
+    DevBuf b_isl_body_off, b_isl_bodies, b_isl_col_off, b_isl_ent;
+    IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0};
     bool any_damped = false;
     bool any_restitution = false;  // some manifold has restitution != 0 (else apply_restitution early-outs for all, contact/mod.rs:366-369)
     std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
@@ -228,6 +235,9 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipSetDevice(c->device));
         cfg.device = c->device;
         if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = getenv("AVN_ISLAND_BLOCKS")) island_enabled = atoi(e) != 0;                                  // 0: always the device-wide colour launches
+        if (const char* e = getenv("AVN_ISLAND_MAX_MANIFOLDS")) island_max_manifolds = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = getenv("AVN_ISLAND_PACK_BODIES")) island_pack_bodies = std::min<uint32_t>(ISLAND_MAX_BODIES, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));
         // (CU masks -- 64 CUs for the broad phase, 192 for the solver -- were tried for the overlap below and lost: a colour launch
         //  on 192 CUs is 12 % slower than on 256, more than the contention it avoids; tools/cumask_probe.hip)
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -555,7 +565,99 @@ template <class T> struct World : WorldBase {
             if (o1 > o0) graph_valid = false;  // level sizes are captured launch parameters
             if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p) graph_valid = false;
         }
+        avn_status ist = rebuild_island_blocks();
+        if (ist != AVN_OK) return ist;
         incidence_dirty = false;
+        return AVN_OK;
+    }
+    // Island blocks (k_island_substeps).  Islands = connected components of the bodies that have a SolverBody under "share a
+    // manifold" (a body without one -- static, sleeping, disabled -- is never written by the solver and joins nothing;
+    // kinematic bodies DO have a SolverBody that the solver reads and re-writes, so they merge like dynamic ones).  Eligible
+    // when f32, no joints, few enough manifolds for the colour launches to be latency-bound and every island fits a block.
+    bool island_candidate(size_t M) const { return sizeof(T) == 4 && island_enabled && M != 0 && M <= island_max_manifolds; }
+    avn_status rebuild_island_blocks() {
+        island_mode = false;
+        const uint32_t N = dw.n_bodies, M = dw.n_manifolds;
+        if (!island_candidate(M) || dw.n_joints) return AVN_OK;
+        auto has_sb = [&](int32_t b) { return b >= 0 && (uint32_t)b < N && h_body_has_sb[(uint32_t)b]; };
+        std::vector<uint32_t>& parent = isl_parent;
+        parent.resize(N);
+        for (uint32_t i = 0; i < N; ++i) parent[i] = i;
+        auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        for (uint32_t m = 0; m < M; ++m) {
+            int32_t a = h_m_body1[m], b = h_m_body2[m];
+            if (has_sb(a) && has_sb(b)) { uint32_t ra = find((uint32_t)a), rb = find((uint32_t)b); if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); }
+        }
+        // islands numbered by their lowest body (the root: unions keep the smaller index on top), bodies inside in index order
+        std::vector<uint32_t>& island_of = isl_island_of; std::vector<uint32_t>& count = isl_count;
+        island_of.assign(N, 0xFFFFFFFFu);
+        count.clear();
+        for (uint32_t i = 0; i < N; ++i) {
+            if (!h_body_has_sb[i]) continue;
+            uint32_t r = find(i);
+            if (r == i) { island_of[i] = (uint32_t)count.size(); count.push_back(0u); }
+            island_of[i] = island_of[r];   // r <= i: already numbered
+            if (++count[island_of[i]] > ISLAND_MAX_BODIES) return AVN_OK;   // an island too big for one workgroup's LDS: device-wide path
+        }
+        const uint32_t n_islands = (uint32_t)count.size();
+        if (!n_islands) return AVN_OK;
+        // blocks = runs of consecutive islands of at most island_pack_bodies bodies (one island may exceed that, up to the LDS cap)
+        std::vector<uint32_t>& block_of = isl_block_of_island; std::vector<uint32_t>& body_off = isl_body_off;
+        block_of.resize(n_islands);
+        body_off.assign(1, 0u);
+        std::vector<uint32_t>& cursor = isl_cursor;   // per island: next LDS slot
+        cursor.resize(n_islands);
+        // pack target: enough blocks to cover the 256 CUs before blocks grow (a block's pass time is flat up to ~256 manifolds per colour)
+        uint32_t n_sb = 0;
+        for (uint32_t k = 0; k < n_islands; ++k) n_sb += count[k];
+        const uint32_t pack = std::min<uint32_t>(island_pack_bodies, std::max<uint32_t>(64u, (n_sb + 255u) / 256u));
+        uint32_t in_block = 0;
+        for (uint32_t k = 0; k < n_islands; ++k) {
+            if (in_block && in_block + count[k] > pack) { body_off.push_back(body_off.back() + in_block); in_block = 0; }
+            block_of[k] = (uint32_t)body_off.size() - 1;
+            cursor[k] = in_block;
+            in_block += count[k];
+        }
+        body_off.push_back(body_off.back() + in_block);
+        const uint32_t n_blocks = (uint32_t)body_off.size() - 1;
+        std::vector<uint32_t>& slot = isl_slot; std::vector<uint32_t>& bodies = isl_bodies;
+        slot.assign(N, 0u);
+        bodies.resize(body_off.back());
+        for (uint32_t i = 0; i < N; ++i) {
+            uint32_t k = island_of[i];
+            if (k == 0xFFFFFFFFu) continue;
+            slot[i] = cursor[k]++;
+            bodies[body_off[block_of[k]] + slot[i]] = i;
+        }
+        // entries: counting sort of the manifolds by (block, colour slot), ascending manifold index inside (= list order: the
+        // overflow colour's serial order); colour slot 0 = overflow (solved first), 1 + c = colour c
+        std::vector<uint32_t>& col_off = isl_col_off; std::vector<uint32_t>& ent = isl_ent;
+        col_off.assign((size_t)n_blocks * AVN_GRAPH_COLOR_COUNT + 1, 0u);
+        auto key_of = [&](uint32_t m, uint32_t c) -> size_t {
+            int32_t a = h_m_body1[m], b = h_m_body2[m];
+            uint32_t blk = has_sb(a) ? block_of[island_of[(uint32_t)a]] : has_sb(b) ? block_of[island_of[(uint32_t)b]] : 0u;  // (no SolverBody on either side: touches no body, any block)
+            return (size_t)blk * AVN_GRAPH_COLOR_COUNT + (c == AVN_COLOR_OVERFLOW_INDEX ? 0u : c + 1u);
+        };
+        for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            for (uint32_t m = color_offsets[c]; m < color_offsets[c + 1]; ++m) ++col_off[key_of(m, c) + 1];
+        for (size_t i = 1; i < col_off.size(); ++i) col_off[i] += col_off[i - 1];
+        std::vector<uint32_t> next(col_off.begin(), col_off.end() - 1);
+        ent.resize((size_t)M * 2);
+        for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
+            for (uint32_t m = color_offsets[c]; m < color_offsets[c + 1]; ++m) {
+                int32_t a = h_m_body1[m], b = h_m_body2[m];
+                uint32_t e = next[key_of(m, c)]++;
+                ent[2 * (size_t)e] = m;
+                ent[2 * (size_t)e + 1] = (has_sb(a) ? slot[(uint32_t)a] : 0u) | (has_sb(b) ? slot[(uint32_t)b] : 0u) << 16;
+            }
+        avn_status st;
+        if ((st = upload_u32(b_isl_body_off, body_off)) != AVN_OK) return st;
+        if ((st = upload_u32(b_isl_bodies, bodies)) != AVN_OK) return st;
+        if ((st = upload_u32(b_isl_col_off, col_off)) != AVN_OK) return st;
+        if ((st = upload_u32(b_isl_ent, ent)) != AVN_OK) return st;
+        HIPCHK(hipStreamSynchronize(stream));
+        islands = IslandBlocks{b_isl_body_off.as<uint32_t>(), b_isl_bodies.as<uint32_t>(), b_isl_col_off.as<uint32_t>(), b_isl_ent.as<uint2>(), n_blocks};
+        island_mode = true;
         return AVN_OK;
     }
     avn_status impulses_download(const avn_impulses_out* o) override {
@@ -1095,7 +1197,8 @@ template <class T> struct World : WorldBase {
             if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "manifold_handles_upload: no such contact"; return AVN_ERR_STATE; }
         // the host only needs the bodies of the OVERFLOW colour's manifolds (entry lists + level schedule); the incidence of
         // colours 0..22 is built on the device
-        for (uint32_t i = offsets[AVN_COLOR_OVERFLOW_INDEX]; i < M; ++i) { h_m_body1[i] = h_ct_b1[ids[i]]; h_m_body2[i] = h_ct_b2[ids[i]]; }
+        // (... and ALL of them when the set is small enough for the island blocks, whose entry lists are host-built)
+        for (uint32_t i = island_candidate(M) ? 0u : offsets[AVN_COLOR_OVERFLOW_INDEX]; i < M; ++i) { h_m_body1[i] = h_ct_b1[ids[i]]; h_m_body2[i] = h_ct_b2[ids[i]]; }
         HIPCHK(hipStreamSynchronize(stream));
         avn_status st = ensure_manifold_capacity(M);
         if (st != AVN_OK) return st;
@@ -1458,7 +1561,7 @@ template <class T> struct World : WorldBase {
     void prepare_contact_constraints() {
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
-        if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
+        if (slots_dirty && dw.n_manifolds && dw.inc_slot && !islands_active()) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
         launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
     }
     void store_contact_impulses() {
@@ -1527,9 +1630,16 @@ template <class T> struct World : WorldBase {
         xpbd_velocity_projection();
         joint_damping();
     }
+    bool islands_active() const { return island_mode && dw.n_joints == 0 && dw.n_manifolds != 0; }
     avn_status run_substeps() {
         substep_index = 0;
         bias_timed = 0;
+        if constexpr (sizeof(T) == 4) {
+            if (islands_active()) {   // every substep of every island block in ONE launch (k_island_substeps)
+                launch_island_substeps(dw, params, islands, cfg.substeps, cfg.solver_iterations, stream); ++launches;
+                return AVN_OK;
+            }
+        }
         if (!cfg.use_graph) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
         if (!graph_valid) {
             drop_graph();
@@ -1695,6 +1805,7 @@ template <class T> struct World : WorldBase {
             last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;
             last_timers.step_ms = e;
             last_timers.bias_pass_ms = 0; last_timers.bias_pass_launches = 0;
+            last_timers.island_blocks = islands_active() ? islands.n_blocks : 0u; last_timers.reserved0 = 0;
             if (bias_timed) {   // mean over the step's substeps
                 double sum = 0;
                 for (uint32_t k = 0; k < bias_timed; ++k) { float f = 0; HIPCHK(hipEventElapsedTime(&f, ev_bias[2 * k], ev_bias[2 * k + 1])); sum += f; }

@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BODY_THREADS) void k_integrate_velocities(DW<T> w, 
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
     Vec4<T> l4 = w.sb_lin[i], a4 = w.sb_ang[i];
     V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
-    if (integrate_velocities_one<T>(w, p, i, sbf, v, om)) {
+    if (integrate_velocities_one<T>(w, p, i, sbf, v, om, &w.sb_dq[i])) {
         w.sb_lin[i] = make4<T>(v, l4.w);
         w.sb_ang[i] = make4<T>(om, a4.w);
     }
@@ -114,25 +114,11 @@ __global__ __launch_bounds__(BODY_THREADS) void k_integrate_positions(DW<T> w, S
     if (i >= w.n_bodies) return;
     uint32_t sbf = w.sb_flags[i];
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
-    uint32_t meta = w.bmeta[i];
-    T delta_secs = p.h_adj;
-    if (!(meta_flags(meta) & AVN_BODY_CUSTOM_POSITION_INTEGRATION)) {
-        V3<T> v = xyz<T>(w.sb_lin[i]), om = xyz<T>(w.sb_ang[i]);
-        Vec4<T> dp4 = w.sb_dp[i];
-        V3<T> dp = xyz<T>(dp4) + v * delta_secs;
-        Q4<T> dq = qmul(from_scaled_axis(om * delta_secs), quat<T>(w.sb_dq[i]));
-        w.sb_dp[i] = make4<T>(dp, dp4.w);
-        w.sb_dq[i] = make4<T>(dq);
-    }
-    // update_solver_body_angular_inertia: recomputed from the STEP-START Rotation every substep
-    Vec4<T> la = w.iloc_a[i], lb = w.iloc_b[i];
-    Sym3<T> local{la.x, la.y, la.z, la.w, lb.x, lb.y};
-    Sym3<T> t = rotated_inverse_inertia(local, quat<T>(w.rot[i]));
-    Vec4<T> sa = w.si_a[i], sbv = w.si_b[i];
-    uint32_t iflags = scalar_to_bits(sbv.w);
-    lock_rotation_axes(t, iflags & 0x3Fu);
-    w.si_a[i] = make4<T>(sa.x, t.m00, t.m01, t.m02);
-    w.si_b[i] = make4<T>(t.m11, t.m12, t.m22, sbv.w);
+    V3<T> v = xyz<T>(w.sb_lin[i]), om = xyz<T>(w.sb_ang[i]);
+    Vec4<T> dp4 = w.sb_dp[i], dq4 = w.sb_dq[i], sa = w.si_a[i], sbv = w.si_b[i];
+    integrate_positions_one<T>(w, p, i, v, om, dp4, dq4, sa, sbv);
+    w.sb_dp[i] = dp4; w.sb_dq[i] = dq4;
+    w.si_a[i] = sa; w.si_b[i] = sbv;
 }
 
 template <class T>

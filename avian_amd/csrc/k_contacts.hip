@@ -34,17 +34,23 @@ template <class T> struct BodyRef {
     T lin_w, ang_w;  // pass-through w lanes
 };
 
+// Where the SolverBody / SolverBodyInertia records of a pass live: the world's HBM arrays (paired slots: record i at
+// base[2 i], STRIDE = 2) or an island's block staged in LDS (STRIDE = 1, indices local to the block; k_island_substeps).
+template <class T> struct BodyView { Vec4<T> *lin, *ang, *dp, *dq, *sia, *sib; };
+template <class T> __device__ __forceinline__ BodyView<T> global_bodies(const DW<T>& w) { return {w.sb_lin.p, w.sb_ang.p, w.sb_dp.p, w.sb_dq.p, w.si_a.p, w.si_b.p}; }
+
 // Fetch SolverBody + SolverBodyInertia, substituting DUMMY for a missing body and a DUMMY inertia for a
 // dominant one (solver/plugin.rs:491-512).
-template <class T, bool WITH_DELTA>
-__device__ __forceinline__ void load_body(const DW<T>& w, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
+template <class T, bool WITH_DELTA, int STRIDE>
+__device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
     // The six records are fetched UNCONDITIONALLY (every body index is a valid row; rows of bodies without a SolverBody
     // hold DUMMY values) and the DUMMY substitution is a select afterwards: no load waits on the constraint's flag word,
     // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
-    Vec4<T> l = w.sb_lin[idx], a = w.sb_ang[idx];
+    const size_t o = (size_t)idx * STRIDE;
+    Vec4<T> l = bv.lin[o], a = bv.ang[o];
     Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
-    if (WITH_DELTA) { dp = w.sb_dp[idx]; dq = w.sb_dq[idx]; }
-    Vec4<T> sa = w.si_a[idx], sb = w.si_b[idx];
+    if (WITH_DELTA) { dp = bv.dp[o]; dq = bv.dq[o]; }
+    Vec4<T> sa = bv.sia[o], sb = bv.sib[o];
     // branch-free selects (v_cndmask): nothing for the compiler to sink the loads into
     const T z = T(0);
     b.v = V3<T>{no_body ? z : l.x, no_body ? z : l.y, no_body ? z : l.z};
@@ -58,10 +64,10 @@ __device__ __forceinline__ void load_body(const DW<T>& w, int idx, bool no_body,
     b.inv_mass = V3<T>{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
     b.I = Sym3<T>{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
 }
-template <class T> __device__ __forceinline__ void store_body(const DW<T>& w, int idx, bool no_body, const BodyRef<T>& b) {
+template <class T, int STRIDE> __device__ __forceinline__ void store_body(const BodyView<T>& bv, int idx, bool no_body, const BodyRef<T>& b) {
     if (no_body) return;  // writes to a DUMMY body are discarded
-    w.sb_lin[idx] = make4<T>(b.v, b.lin_w);
-    w.sb_ang[idx] = make4<T>(b.om, b.ang_w);
+    bv.lin[(size_t)idx * STRIDE] = make4<T>(b.v, b.lin_w);
+    bv.ang[(size_t)idx * STRIDE] = make4<T>(b.om, b.ang_w);
 }
 template <class T> __device__ __forceinline__ void apply_impulse(BodyRef<T>& b1, BodyRef<T>& b2, V3<T> imp, V3<T> r1, V3<T> r2) {
     b1.v = b1.v - cmul(imp, b1.inv_mass);
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepPar
     Vec4<T> sa = w.si_a[body], sb = w.si_b[body];
     V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
     bool touched = false;
-    if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om);
+    if (FUSE_INTEGRATE) touched = integrate_velocities_one<T>(w, p, body, sbf, v, om, &w.sb_dq[body]);
     const V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
     const T coeff = p.warm_start_coefficient;
     const T z = T(0);
@@ -258,12 +264,44 @@ __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepPar
     }
 }
 
-template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+// Warm start of ONE manifold against a BodyView (the manifold-centric form of the same arithmetic: applied colour by colour in
+// solve order every body sees the additions of k_body_warm_start in the same sequence).  Used by the island blocks, whose
+// bodies live in LDS where a colour sweep costs a workgroup barrier instead of a launch.
+template <class T, int STRIDE>
+__device__ __forceinline__ void warm_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
+    Vec4<T> h1 = w.c_h1[m], h0 = w.m_n[m];
+    const uint32_t S = w.m_stride;
+    Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * S + m; pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pd[k] = w.c_pd[s]; }
+    const uint32_t cm = scalar_to_bits(h1.w);
+    const uint32_t np = cm & 7u;
+    BodyRef<T> b1, b2;
+    load_body<T, false, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    if (np == 0) return;
+    const V3<T> normal = xyz<T>(h0);
+    const V3<T> t0 = xyz<T>(h1), t1 = cross(t0, normal);  // tangent_directions(), contact/mod.rs:411-421
+    const T coeff = p.warm_start_coefficient;
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k < np) {
+            const Vec4<T> d = pd[k];
+            const T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
+            const V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
+            apply_impulse(b1, b2, imp, xyz<T>(pa[k]), xyz<T>(pb[k]));
+        }
+    }
+    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
+}
+
+template <class T, bool USE_BIAS, int STRIDE>
+__device__ __forceinline__ void solve_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
     // level 1: every load that only depends on m, issued up front and unconditionally (memory-level parallelism: the
     // kernel is latency-bound at one manifold per lane; the point planes hold 4 slots per manifold, so unused points
     // are in bounds and ignored); level 2: the body gathers; then the sequential impulse iteration out of registers
     Vec4<T> h1 = w.c_h1[m];
-    int2 b = w.m_bodies[m];
     Vec4<T> h0 = w.m_n[m];
     Vec4<T> h2 = w.m_tv[m];
     uint32_t S = w.m_stride;
@@ -276,8 +314,8 @@ template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(cons
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
-    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, true, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     if (np == 0) return;
     V3<T> normal = xyz<T>(h0);
     T friction = h0.w;
@@ -346,8 +384,8 @@ template <class T, bool USE_BIAS> __device__ __forceinline__ void solve_one(cons
 #pragma unroll
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
         if (k < np) w.c_pd[k * S + m] = pd[k];
-    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
-    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
 
 // ---- f32: the two bodies of a manifold as the two halves of PACKED-f32 registers -----------------------------------------
@@ -386,11 +424,11 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
     b.om = sub_lo_add_hi(b.om, smul(b.I, cross(anchors, p)));
 }
 
-template <bool USE_BIAS> __device__ __forceinline__ void solve_one_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m) {
+template <bool USE_BIAS, int STRIDE>
+__device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
     // memory levels exactly as solve_one: (headers + point records) | body gathers
     Vec4<T> h1 = w.c_h1[m];
-    int2 b = w.m_bodies[m];
     Vec4<T> h0 = w.m_n[m];
     Vec4<T> h2 = w.m_tv[m];
     uint32_t S = w.m_stride;
@@ -403,8 +441,8 @@ template <bool USE_BIAS> __device__ __forceinline__ void solve_one_packed(const 
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
-    load_body<T, true>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, true, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     if (np == 0) return;
     BodyPair bp;
     bp.v = pair3(b1.v, b2.v); bp.om = pair3(b1.om, b2.om); bp.inv_mass = pair3(b1.inv_mass, b2.inv_mass);
@@ -480,28 +518,28 @@ template <bool USE_BIAS> __device__ __forceinline__ void solve_one_packed(const 
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
         if (k < np) w.c_pd[k * S + m] = pd[k];
     b1.v = lo3(bp.v); b1.om = lo3(bp.om); b2.v = hi3(bp.v); b2.om = hi3(bp.om);
-    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
-    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
-template <class T, bool USE_BIAS> struct SolveDispatch {
-    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m) { solve_one<T, USE_BIAS>(w, p, m); }
+template <class T, bool USE_BIAS, int STRIDE> struct SolveDispatch {
+    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) { solve_core<T, USE_BIAS, STRIDE>(w, p, m, bv, i1, i2); }
 };
-template <bool USE_BIAS> struct SolveDispatch<float, USE_BIAS> {
-    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m) { solve_one_packed<USE_BIAS>(w, p, m); }
+template <bool USE_BIAS, int STRIDE> struct SolveDispatch<float, USE_BIAS, STRIDE> {
+    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) { solve_core_packed<USE_BIAS, STRIDE>(w, p, m, bv, i1, i2); }
 };
 
-template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+template <class T, int STRIDE>
+__device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
     Vec4<T> h1 = w.c_h1[m];
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     if (np == 0) return;
     T restitution = w.m_tv[m].w;
     if (restitution == T(0)) return;
-    int2 b = w.m_bodies[m];
     V3<T> normal = xyz<T>(w.m_n[m]);
     BodyRef<T> b1, b2;
-    load_body<T, false>(w, b.x, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, false>(w, b.y, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, false, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     uint32_t S = w.m_stride;
     uint32_t iterations = np > 1 ? p.restitution_iterations : 1u;
     T threshold = p.restitution_threshold;
@@ -522,15 +560,18 @@ template <class T> __device__ __forceinline__ void restitution_one(const DW<T>& 
             w.c_pd[s] = pd;
             apply_impulse(b1, b2, impulse * normal, a1, a2);
         }
-    store_body(w, b.x, cm & AVN_CM_NOBODY1, b1);
-    store_body(w, b.y, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
 
 enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
+// one manifold of a pass against the world's HBM body arrays
 template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
-    if (PASS == PASS_BIAS) SolveDispatch<T, true>::run(w, p, m);
-    else if (PASS == PASS_RELAX) SolveDispatch<T, false>::run(w, p, m);
-    else restitution_one<T>(w, p, m);
+    const int2 b = w.m_bodies[m];   // (a level-1 load like the constraint records: the body gathers depend on it)
+    const BodyView<T> bv = global_bodies(w);
+    if (PASS == PASS_BIAS) SolveDispatch<T, true, 2>::run(w, p, m, bv, b.x, b.y);
+    else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2>::run(w, p, m, bv, b.x, b.y);
+    else restitution_core<T, 2>(w, p, m, bv, b.x, b.y);
 }
 
 // One colour: manifolds [offsets[c], offsets[c+1]) read from device memory so that a captured graph stays
@@ -638,6 +679,81 @@ __global__ __launch_bounds__(256) void k_build_incidence_slots(DW<T> w) {
 template <class T> void launch_build_incidence_slots(const DW<T>& w, hipStream_t s) {
     (void)hipMemsetAsync(w.inc_slot, 0xFF, (size_t)AVN_COLOR_OVERFLOW_INDEX * w.inc_stride * sizeof(uint32_t), s);
     if (w.n_manifolds) hipLaunchKernelGGL(k_build_incidence_slots<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w);
+}
+// ------------------------------------------------------------------------------------------------------
+// Island blocks: the WHOLE substep loop of a block of contact islands in one workgroup, bodies staged in LDS.
+//
+// A colour launch over a few thousand manifolds is pure latency (launch + two dependent memory levels + the in-lane chain:
+// ~5.5 us whatever the size), and a scene of many small islands (the reference's "Many Pyramids" bench) pays that floor
+// colours x passes x substeps times.  Islands never exchange data inside the solver: a block = a set of whole islands (host:
+// World::rebuild_island_blocks) owns its bodies for the entire substep loop, so one workgroup stages their six
+// SolverBody / SolverBodyInertia records in LDS once, runs every system of every substep on them -- integrate_velocities,
+// warm start, biased solve, integrate_positions + inertia refresh, relax -- with a workgroup barrier where the device-wide
+// path has a kernel boundary, and writes the records back once.  Constraint records stay in HBM/L2 (read-mostly, 300 B per
+// manifold); the per-body dependent gathers, the part a colour pass waits on, become LDS reads.
+// Order: within the block the entries of a colour touch disjoint bodies (the reference's colouring invariant), colours run
+// in solve order (overflow first, serially in list order on one lane, then 0..22) -- every body sees exactly the operation
+// sequence of the device-wide path, hence of the reference: bit-identical.
+template <class T, int PASS>
+__device__ __forceinline__ void island_colours(const DW<T>& w, const StepParams<T>& p, const IslandBlocks& ib, const BodyView<T>& bv, const uint32_t* col) {
+    const uint32_t t = threadIdx.x;
+    for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        const uint32_t begin = col[c], end = col[c + 1];
+        if (begin == end) continue;  // workgroup-uniform
+        // slot 0 = the overflow colour: one lane walks it in list order; every other colour: one lane per manifold
+        const bool serial = c == 0;
+        for (uint32_t e = begin + (serial ? 0u : t); e < end; e += serial ? 1u : ISLAND_THREADS) {
+            if (serial && t != 0) continue;
+            const uint2 ent = ib.ent[e];
+            const int i1 = (int)(ent.y & 0xFFFFu), i2 = (int)(ent.y >> 16);
+            if (PASS == PASS_WARM) warm_core<T, 1>(w, p, ent.x, bv, i1, i2);
+            else if (PASS == PASS_BIAS) SolveDispatch<T, true, 1>::run(w, p, ent.x, bv, i1, i2);
+            else SolveDispatch<T, false, 1>::run(w, p, ent.x, bv, i1, i2);
+        }
+        __syncthreads();
+    }
+}
+template <class T>
+__global__ __launch_bounds__(ISLAND_THREADS) void k_island_substeps(DW<T> w, StepParams<T> p, IslandBlocks ib, uint32_t substeps, uint32_t iterations) {
+    __shared__ Vec4<T> l_lin[ISLAND_MAX_BODIES], l_ang[ISLAND_MAX_BODIES], l_dp[ISLAND_MAX_BODIES], l_dq[ISLAND_MAX_BODIES], l_sia[ISLAND_MAX_BODIES],
+        l_sib[ISLAND_MAX_BODIES];
+    __shared__ uint32_t l_col[AVN_GRAPH_COLOR_COUNT + 1];
+    const uint32_t t = threadIdx.x, blk = blockIdx.x;
+    const uint32_t b0 = ib.body_off[blk], nb = ib.body_off[blk + 1] - b0;
+    if (t <= AVN_GRAPH_COLOR_COUNT) l_col[t] = ib.col_off[(size_t)blk * AVN_GRAPH_COLOR_COUNT + t];
+    for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {
+        const uint32_t g = ib.bodies[b0 + l];
+        l_lin[l] = w.sb_lin[g]; l_ang[l] = w.sb_ang[g]; l_dp[l] = w.sb_dp[g]; l_dq[l] = w.sb_dq[g]; l_sia[l] = w.si_a[g]; l_sib[l] = w.si_b[g];
+    }
+    __syncthreads();
+    const BodyView<T> bv{l_lin, l_ang, l_dp, l_dq, l_sia, l_sib};
+    for (uint32_t s = 0; s < substeps; ++s) {   // SubstepSchedule order, as World::substep()
+        for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {   // integrate_velocities
+            const uint32_t g = ib.bodies[b0 + l];
+            const Vec4<T> l4 = l_lin[l], a4 = l_ang[l];
+            V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
+            if (integrate_velocities_one<T>(w, p, g, w.sb_flags[g], v, om, &l_dq[l])) { l_lin[l] = make4<T>(v, l4.w); l_ang[l] = make4<T>(om, a4.w); }
+        }
+        __syncthreads();
+        island_colours<T, PASS_WARM>(w, p, ib, bv, l_col);
+        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_BIAS>(w, p, ib, bv, l_col);
+        for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {   // integrate_positions + update_solver_body_angular_inertia
+            const uint32_t g = ib.bodies[b0 + l];
+            Vec4<T> dp4 = l_dp[l], dq4 = l_dq[l], sa = l_sia[l], sb = l_sib[l];
+            integrate_positions_one<T>(w, p, g, xyz<T>(l_lin[l]), xyz<T>(l_ang[l]), dp4, dq4, sa, sb);
+            l_dp[l] = dp4; l_dq[l] = dq4; l_sia[l] = sa; l_sib[l] = sb;
+        }
+        __syncthreads();
+        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_RELAX>(w, p, ib, bv, l_col);
+    }
+    for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {
+        const uint32_t g = ib.bodies[b0 + l];
+        w.sb_lin[g] = l_lin[l]; w.sb_ang[g] = l_ang[l]; w.sb_dp[g] = l_dp[l]; w.sb_dq[g] = l_dq[l]; w.si_a[g] = l_sia[l]; w.si_b[g] = l_sib[l];
+    }
+}
+void launch_island_substeps(const DW<float>& w, const StepParams<float>& p, const IslandBlocks& ib, uint32_t substeps, uint32_t iterations, hipStream_t s) {
+    if (!ib.n_blocks) return;
+    hipLaunchKernelGGL(k_island_substeps<float>, dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
 }
 template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
     if (!w.n_bodies) return;

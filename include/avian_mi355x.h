@@ -418,6 +418,9 @@ typedef struct avn_timers {
     double bias_pass_ms;      /* device time of that pass, MEAN over the last step's substeps, each bracketed by events on the world's
                                  stream: the in-step duration of the dominant kernel for the roofline.  Only with use_graph = 0
                                  (0 otherwise: events captured into a hipGraph cannot be read back) */
+    uint32_t island_blocks;   /* workgroups of the island-block substep kernel in the last step; 0 = the substeps ran as
+                                 device-wide colour launches (big islands, joints, f64, or AVN_ISLAND_BLOCKS=0) */
+    uint32_t reserved0;
 } avn_timers;
 
 /* ---- entry points --------------------------------------------------------------------------- */

@@ -45,14 +45,19 @@ def main():
         same = all(np.array_equal(bh[k], bo[k]) for k in bh)
         st = wh.pipeline_stats()
         n_dyn = int((sc.rb_type == F.RB_DYNAMIC).sum())
+        tm = wh.timers()
         results.append({"scene": name, "dynamic_bodies": n_dyn, "substeps": substeps, "steps": steps, "mi355x_ms_per_step": round(th * 1e3, 4),
                         "mi355x_substeps_per_s": round(substeps / th, 1), "cpu_oracle_1_thread_ms_per_step": round(to * 1e3, 3),
                         "cpu_oracle_substeps_per_s": round(substeps / to, 2), "bodies_bit_identical": bool(same), "manifolds": int(st.manifolds),
                         "active_pairs": int(st.active_pairs), "host_cores": os.cpu_count(),
+                        "island_blocks": int(tm.island_blocks), "kernel_launches_per_step": int(tm.kernel_launches),
+                        "last_step_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4), "substeps": round(tm.substeps_ms, 4),
+                                         "finalize": round(tm.finalize_ms, 4), "step": round(tm.step_ms, 4)},
                         "path": "closed loop: device broad phase + device narrow phase (Ball/Cuboid) + library host bookkeeping + solver (avn_pipeline_enable)"})
         print(f"{name}: {n_dyn} boxes, {substeps} substeps, {steps} steps | MI355X {th * 1e3:.3f} ms/step ({substeps / th:.0f} substeps/s) | "
               f"CPU oracle 1 thread {to * 1e3:.2f} ms/step ({substeps / to:.1f} substeps/s) | x{to / th:.0f} | bodies bit-identical after {steps + 1} steps: {same} | "
-              f"manifolds {st.manifolds}, active pairs {st.active_pairs}, status changes last step {st.last_status_changes}, max |v| {float(np.abs(bh['linear_velocity']).max()):.3f}")
+              f"manifolds {st.manifolds}, active pairs {st.active_pairs}, status changes last step {st.last_status_changes}, max |v| {float(np.abs(bh['linear_velocity']).max()):.3f} | "
+              f"island blocks {tm.island_blocks}, launches {tm.kernel_launches}, bp {tm.broad_phase_ms:.3f} prep {tm.prepare_ms:.3f} sub {tm.substeps_ms:.3f} fin {tm.finalize_ms:.3f} ms")
     if out_path:
         import json
         json.dump(results, open(out_path, "w"), indent=1)
