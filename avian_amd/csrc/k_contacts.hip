@@ -194,9 +194,7 @@ template <class T> __device__ __forceinline__ void warm_fetch(const DW<T>& w, ui
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * w.m_stride + m; r.pr[k] = anchors[s]; r.pd[k] = w.c_pd[s]; }
 }
 template <class T, bool FUSE_INTEGRATE>
-__global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepParams<T> p) {
-    const uint32_t body = xcd_block(blockIdx.x, gridDim.x) * WS_THREADS + threadIdx.x;
-    if (body >= w.n_bodies) return;
+__device__ __forceinline__ void body_warm_start_one(const DW<T>& w, const StepParams<T>& p, uint32_t body) {
     const uint32_t sbf = w.sb_flags[body];
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
     // the 23 colour slots of this body: coalesced across the wave (neighbouring lanes = neighbouring bodies), issued up front
@@ -262,6 +260,12 @@ __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepPar
         w.sb_lin[body] = make4<T>(v, l4.w);
         w.sb_ang[body] = make4<T>(om, a4.w);
     }
+}
+template <class T, bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepParams<T> p) {
+    const uint32_t body = xcd_block(blockIdx.x, gridDim.x) * WS_THREADS + threadIdx.x;
+    if (body >= w.n_bodies) return;
+    body_warm_start_one<T, FUSE_INTEGRATE>(w, p, body);
 }
 
 // Warm start of ONE manifold against a BodyView (the manifold-centric form of the same arithmetic: applied colour by colour in
@@ -574,6 +578,11 @@ template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T
     else restitution_core<T, 2>(w, p, m, bv, b.x, b.y);
 }
 
+// (Tried and rejected: the whole substep loop as ONE persistent launch, <= 1 workgroup per CU, with a device-wide barrier --
+//  agent-scope release (buffer_wbl2 sc1), one arrival atomic per workgroup, bounded spin, acquire (buffer_inv sc1) -- where
+//  the kernel boundaries are.  Bit-exact, but 3.27-3.63 ms per cfg2 step against 1.68 ms for the replayed launches: a
+//  software barrier across the eight non-coherent XCD L2s costs ~25 us, five times the ~5.5 us launch-to-launch floor it was
+//  meant to remove.  The in-kernel-barrier idea survives where the barrier is a workgroup one: k_island_substeps.)
 // One colour: manifolds [offsets[c], offsets[c+1]) read from device memory so that a captured graph stays
 // valid while the colour populations drift; the grid is a multiple of 8 blocks and remapped per XCD.
 template <class T, int PASS>
