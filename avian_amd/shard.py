@@ -111,3 +111,124 @@ def exchange_bounds(world: F.World, dist=None, device=None):
     dist.all_gather(outs, t)
     a = torch.stack(outs).cpu().numpy()
     return a[:, :3], a[:, 3:], bounds_overlap(a[:, :3], a[:, 3:])
+
+
+# ---- x-slab sharding of the broad phase ("each GPU sorts/sweeps its slab (+halo)") -----------------------
+#
+# The sweep-and-prune emits pairs i-major over the intervals sorted by min.x: pair (i, j) belongs to the EARLIER interval i
+# (collision/broad_phase.rs:400-475).  Cut the sorted order into contiguous slabs by min.x and give rank r
+#   owned(r) = { c : s_r <= min.x(c) < s_{r+1} }                       -- the pairs whose earlier member lies here are r's
+#   halo(r)  = { c : min.x(c) >= s_{r+1} and min.x(c) <= max over owned(r) of max.x }   -- everything an owned interval can reach
+# as a sub-world that keeps the global relative order of its colliders (ascending upload index, so the stable sort and the
+# candidate order of every owned interval are the global ones).  The rank sweeps the sub-world with the unchanged single-GPU
+# broad phase, drops the pairs whose earlier member is a halo collider, and the concatenation of the ranks' lists in slab
+# order IS the single-world list, bit for bit -- no merge, one all-gather of pair records per step.
+# (A collider that spans the scene, e.g. a ground slab, has min.x in slab 0 and pulls every collider into rank 0's halo:
+#  correct, unbalanced -- such colliders are better replicated and swept against each slab separately; not done here.)
+
+@dataclass
+class SlabPlan:
+    world_size: int
+    splits: np.ndarray          # [R + 1] slab boundaries on min.x (splits[0] = -inf, splits[R] = +inf)
+    slab_of_collider: np.ndarray  # [C] int32
+
+
+def slab_plan(aabb_min_x: np.ndarray, world_size: int) -> SlabPlan:
+    """Balanced contiguous slabs of the sorted-by-min.x order.  Boundaries sit on values of min.x, and colliders with EQUAL
+    min.x always share a slab (a tie never straddles a boundary, so "earlier in sorted order" never depends on the cut)."""
+    x = np.asarray(aabb_min_x, np.float64)
+    n = len(x)
+    xs = np.sort(x, kind="stable")
+    splits = np.full(world_size + 1, np.inf)
+    splits[0] = -np.inf
+    for r in range(1, world_size):
+        splits[r] = xs[min(n - 1, (n * r) // world_size)] if n else np.inf
+    splits = np.maximum.accumulate(splits)
+    slab = (np.searchsorted(splits, x, side="right") - 1).astype(np.int32)   # splits[r] <= x < splits[r + 1]
+    return SlabPlan(world_size, splits, np.clip(slab, 0, world_size - 1))
+
+
+def slab_colliders(p: SlabPlan, rank: int, aabb_min_x: np.ndarray, aabb_max_x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (local: ascending global collider indices of rank's sub-world = owned + halo, owned_mask over `local`)."""
+    mn = np.asarray(aabb_min_x, np.float64); mx = np.asarray(aabb_max_x, np.float64)
+    owned = p.slab_of_collider == rank
+    if not owned.any():
+        return np.zeros(0, np.int64), np.zeros(0, bool)
+    reach = mx[owned].max()
+    halo = (p.slab_of_collider > rank) & (mn <= reach)
+    local = np.flatnonzero(owned | halo)
+    return local, owned[local]
+
+
+def slab_filter_pairs(pairs: np.ndarray, entity_index: np.ndarray, owned_mask: np.ndarray) -> np.ndarray:
+    """Keep the pairs whose EARLIER member (avn_pair.collider1, broad_phase.rs:443) is owned.  entity_index / owned_mask:
+    the sub-world's colliders."""
+    if len(pairs) == 0:
+        return pairs
+    order = np.argsort(entity_index, kind="stable")
+    pos = order[np.searchsorted(entity_index[order], pairs["collider1"])]
+    return pairs[owned_mask[pos]]
+
+
+def gather_pairs(pairs: np.ndarray, dist=None, device=None) -> np.ndarray:
+    """The per-step exchange of the slab-sharded broad phase: all-gather of the ranks' (collider1, collider2, flags) records,
+    concatenated in rank (= slab) order.  Returns a [P, 3] uint32 array.  `dist` = torch.distributed (None = single rank)."""
+    rec = np.stack([pairs["collider1"], pairs["collider2"], pairs["flags"]], axis=1).astype(np.uint32) if len(pairs) else np.zeros((0, 3), np.uint32)
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return rec
+    import torch
+    dev = device or "cpu"
+    world = dist.get_world_size()
+    cnt = torch.tensor([len(rec)], dtype=torch.int64, device=dev)
+    cnts = [torch.zeros_like(cnt) for _ in range(world)]
+    dist.all_gather(cnts, cnt)
+    sizes = [int(c.item()) for c in cnts]
+    cap = max(max(sizes), 1)
+    buf = torch.zeros((cap, 3), dtype=torch.int64, device=dev)   # (int64 carrier: gloo and RCCL both move it; values are uint32)
+    if len(rec):
+        buf[: len(rec)] = torch.from_numpy(rec.astype(np.int64)).to(dev)
+    outs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(outs, buf)
+    return np.concatenate([o[:s].cpu().numpy().astype(np.uint32) for o, s in zip(outs, sizes)], axis=0)
+
+
+def slab_subworld(bodies: Dict[str, np.ndarray], colliders: Dict[str, np.ndarray], local: np.ndarray):
+    """Body / collider arrays of the sub-world made of the colliders `local` (ascending global collider indices) and the bodies
+    they belong to (ascending global body index; ColliderOf.body re-indexed).  Returns (bodies, colliders, global body indices)."""
+    body = np.asarray(colliders["body"])[local]
+    ub = np.unique(body[body >= 0])
+    g2l = np.full(len(np.asarray(bodies["rb_type"])), -1, np.int64)
+    g2l[ub] = np.arange(len(ub))
+    cols = _take(colliders, local)
+    cols["body"] = np.where(body >= 0, g2l[np.maximum(body, 0)], -1).astype(np.int32)
+    return _take(bodies, ub), cols, ub
+
+
+def pair_keys(rec: np.ndarray) -> np.ndarray:
+    """PairKey (data_structures/pair_key.rs: smaller entity index in the high word) of [P, >= 2] (collider1, collider2) records."""
+    a = rec[:, 0].astype(np.uint64); b = rec[:, 1].astype(np.uint64)
+    lo, hi = np.minimum(a, b), np.maximum(a, b)
+    return (lo << np.uint64(32)) | hi
+
+
+def slab_broad_phase_step(lib: F.Library, bits: int, bodies: Dict[str, np.ndarray], colliders: Dict[str, np.ndarray], aabb_min_x: np.ndarray,
+                          aabb_max_x: np.ndarray, known_keys: np.ndarray, rank: int, world_size: int, dist=None, device=None) -> np.ndarray:
+    """One frame of the slab-sharded broad phase on this rank: plan the slabs from the (replicated) AABB extents, sweep this
+    rank's slab + halo with the single-GPU broad phase, drop halo-owned pairs, all-gather.  known_keys = PairKeys already in
+    the contact graph (globally).  Returns the step's NEW pairs of the whole world, [P, 3] uint32, in the single-world order."""
+    pl = slab_plan(aabb_min_x, world_size)
+    local, owned = slab_colliders(pl, rank, aabb_min_x, aabb_max_x)
+    mine = np.zeros(0, PAIR_DTYPE_LOCAL)
+    if len(local):
+        b, c, _ = slab_subworld(bodies, colliders, local)
+        w = F.World(lib, F.default_config(bits, substeps=1))
+        try:
+            w.bodies_upload(**b); w.colliders_upload(**c); w.existing_pairs_upload(np.asarray(known_keys, np.uint64))
+            w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+            mine = slab_filter_pairs(w.pairs_get(), np.asarray(c["entity_index"]), owned)
+        finally:
+            w.close()
+    return gather_pairs(mine, dist, device)
+
+
+PAIR_DTYPE_LOCAL = F.PAIR_DTYPE

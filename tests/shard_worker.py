@@ -79,12 +79,49 @@ def run_world(lib, sc_bodies, sc_colliders, joints, friction, restitution, steps
     return out, all_pairs, overlaps
 
 
+def slab_scene():
+    sc = scenes.sparse_mixed(6000, side=26.0)
+    sc.linear_velocity *= 6.0   # colliders cross slab boundaries within a few frames
+    return sc
+
+
+def moved(sc, step, dt=1.0 / 60.0):
+    """Bodies of frame `step` (free flight, host-integrated in f64: the broad phase is the system under test)."""
+    b = sc.body_kwargs()
+    b["position"] = sc.position + sc.linear_velocity * (dt * step)
+    return b
+
+
+def run_slabs(lib, rank, world, steps, out_path, device=None):
+    """Slab-sharded broad phase over `steps` frames: every rank sweeps its x-slab + halo, all-gathers the pair records."""
+    sc = slab_scene()
+    cols = sc.collider_kwargs()
+    full = F.World(lib, F.default_config(32, substeps=1))   # replicated AABB update (no sweep): the slab planner's input
+    full.bodies_upload(**sc.body_kwargs()); full.colliders_upload(**cols)
+    known = np.zeros(0, np.uint64)
+    per_step = []
+    for s in range(steps):
+        b = moved(sc, s)
+        full.bodies_upload(**b); full.run_system("UPDATE_AABB")
+        mn, mx, _ = full.aabbs_download()
+        rec = shard.slab_broad_phase_step(lib, 32, b, cols, mn[:, 0], mx[:, 0], known, rank, world, dist if world > 1 else None, device)
+        known = np.concatenate([known, shard.pair_keys(rec)])
+        per_step.append(rec)
+    if rank == 0:
+        np.savez(out_path, **{f"pairs_s{s}": r for s, r in enumerate(per_step)})
+
+
 def main():
     case, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     backend = os.environ.get("AVN_SHARD_BACKEND", "oracle")
     dist.init_process_group(backend="gloo" if backend == "oracle" else "nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = oracle_lib() if backend == "oracle" else hip_lib()
+    if case == "slabs":
+        run_slabs(lib, rank, world, steps, out_path, None if backend == "oracle" else f"cuda:{os.environ.get('LOCAL_RANK', '0')}")
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     sc, joints = build_case(case)
     edges = [scenes.brute_force_pairs(sc)]
     if joints is not None:

@@ -98,3 +98,62 @@ def test_bounds_overlap_predicate():
     assert shard.bounds_overlap(mn, mx) == [(0, 1)]          # touching counts, like ColliderAabb::intersects
     inf = np.inf
     assert shard.bounds_overlap(np.array([[inf] * 3, [0, 0, 0.0]]), np.array([[-inf] * 3, [1, 1, 1.0]])) == []
+
+
+# ---- x-slab sharding of the broad phase (cfg4's multi-GPU shape) ----------------------------------------
+
+def single_world_pairs(lib, sc, bodies_per_step):
+    """One persistent world over the frames: the reference flow (pairs already in the contact graph are not re-emitted)."""
+    w = F.World(lib, F.default_config(32, substeps=1))
+    w.bodies_upload(**bodies_per_step[0]); w.colliders_upload(**sc.collider_kwargs()); w.existing_pairs_upload(np.zeros(0, np.uint64))
+    out = []
+    for b in bodies_per_step:
+        w.bodies_upload(**b)
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+        p = w.pairs_get()
+        out.append(np.stack([p["collider1"], p["collider2"], p["flags"]], axis=1).astype(np.uint32))
+    mn, mx, _ = w.aabbs_download()
+    w.close()
+    return out, mn, mx
+
+
+@pytest.mark.parametrize("scene", ["lattice_with_ground", "sparse"])
+def test_slab_sharded_broad_phase_equals_single_world(scene):
+    """Every rank sweeps its x-slab + halo with the unchanged broad phase; the concatenation of the ranks' owned pairs in slab
+    order must BE the single-world pair list (same pairs, same order, same flags) -- including lattices full of equal min.x
+    keys and a ground slab that spans every slab."""
+    lib = oracle_lib()
+    sc = scenes.box_stack(6, 6, 6) if scene == "lattice_with_ground" else scenes.sparse_mixed(3000, side=20.0)
+    ref, mn, mx = single_world_pairs(lib, sc, [sc.body_kwargs()])
+    assert len(ref[0]) > 1000
+    none = np.zeros(0, np.uint64)
+    for R in (1, 2, 3, 8):
+        parts = [shard.slab_broad_phase_step(lib, 32, sc.body_kwargs(), sc.collider_kwargs(), mn[:, 0], mx[:, 0], none, r, R) for r in range(R)]
+        assert np.array_equal(np.concatenate(parts), ref[0]), f"{scene}: {R} slabs"
+        if scene == "sparse" and R > 1:
+            assert max(len(p) for p in parts) < 0.8 * len(ref[0]), "the work is actually split"
+    # the plan: ties never straddle a boundary, slabs are contiguous in min.x, every collider has exactly one owner
+    pl = shard.slab_plan(mn[:, 0], 4)
+    assert pl.slab_of_collider.min() == 0 and pl.slab_of_collider.max() <= 3
+    order = np.argsort(mn[:, 0], kind="stable")
+    assert np.all(np.diff(pl.slab_of_collider[order]) >= 0)
+    for v in np.unique(mn[:, 0]):
+        assert len(np.unique(pl.slab_of_collider[mn[:, 0] == v])) == 1
+    # degenerate inputs: no colliders, more ranks than distinct keys
+    e = shard.slab_plan(np.zeros(0), 4)
+    assert len(e.slab_of_collider) == 0
+    loc, own = shard.slab_colliders(shard.slab_plan(np.zeros(5), 4), 2, np.zeros(5), np.ones(5))
+    assert len(loc) == 0 or own.all()
+
+
+def test_slab_sharded_broad_phase_gloo_world_size_2_over_frames(tmp_path):
+    """world_size 2 on gloo, three frames of colliders in free flight (they cross the slab boundary): the all-gathered pair
+    records of every frame equal the single persistent world's new pairs, bit for bit and in order."""
+    out = str(tmp_path / "slabs.npz")
+    launch("slabs", out, 3)
+    got = np.load(out)
+    sc = SW.slab_scene()
+    ref, _, _ = single_world_pairs(oracle_lib(), sc, [SW.moved(sc, s) for s in range(3)])
+    for s in range(3):
+        assert np.array_equal(got[f"pairs_s{s}"], ref[s]), f"frame {s}"
+    assert len(ref[0]) > 500 and len(ref[1]) > 0 and len(ref[2]) > 0
