@@ -16,7 +16,8 @@ broad phase runs on a second stream next to the solver (it only reads what the s
   roofline   = the dominant kernel (k_color_pass<SOLVE_BIAS>: TGS-Soft biased contact solve, one launch per graph
                colour): ALGORITHMIC bytes (248 + 88 P per manifold) / duration measured with HIP
                events on the library's own stream (avn_profile_system), against the 8 TB/s HBM3E peak.
-  cpu_baseline = the CPU oracle (C++ restatement of the reference, 1 thread) on the same inputs, bounded sample.
+  cpu_baseline = the CPU oracle (C++ restatement of the reference) on the same inputs, bounded sample: 1 thread and
+                 min(64, host cores) threads running the reference's own parallel loops; `value` is the better of the two.
 
 Multi-GPU (weak scaling): the path shards by interaction islands (avian_amd/shard.py).  With N ranks the global
 scene is N 100k-stacks side by side on one static slab; `avn_islands_partition` assigns one island (stack) to each
@@ -91,7 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (device narrow phase) leg")
-    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample (split between the 1-thread and the multi-thread run)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-thread CPU sample (default min(64, host cores))")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -263,24 +265,43 @@ def main():
         sys.path.insert(0, os.path.join(REPO, "tests"))
         from helpers import oracle_lib  # cpu_baseline leg: the oracle is the thing timed here, by contract
         from avian_amd import scenes
-        wo = F.World(oracle_lib(), F.default_config(32, substeps=substeps))
-        wo.bodies_upload(**sc.body_kwargs())
-        wo.colliders_upload(**sc.collider_kwargs())
-        wo.existing_pairs_upload(np.zeros(0, np.uint64))
-        wo.run_system("UPDATE_AABB")
-        wo.run_system("COLLECT_COLLISION_PAIRS")
-        scenes.upload_manifolds(wo, meta["manifolds"], meta["offsets"], sc.friction, sc.restitution)
-        c0 = time.perf_counter(); wo.step(); first = time.perf_counter() - c0   # un-timed warm-up step (benches/src/cli.rs:358)
-        n_cpu = int(max(1, min(args.steps, args.cpu_seconds / max(first, 1e-6))))
-        c0 = time.perf_counter()
-        for _ in range(n_cpu):
-            wo.step()
-        cpu_s = time.perf_counter() - c0
-        sm, _ = wo.profile_system("SUBSTEP", 1)
-        cpu = {"value": round(n_cpu * substeps / cpu_s, 4), "unit": "substeps/s", "cores": 1, "kind": "port",
-               "sample": f"{n_cpu} whole steps ({n_cpu * substeps} substeps) of the same {args.scene} inputs after 1 warm-up step, "
-                         f"single-thread C++ oracle (g++ -O2 -ffp-contract=off) on {os.cpu_count()} host cores",
-               "ms_per_step": round(cpu_s / n_cpu * 1e3, 2), "substep_loop_only_ms": round(sm, 2)}
+        def cpu_sample(threads, seconds):
+            """One bounded sample of the oracle with `threads` pool threads (oracle/avo_parallel.hpp: the reference's own
+            par_for_each / par_iter_mut loops); protocol of benches/src/cli.rs:358-405: one un-timed step, then the mean."""
+            os.environ["AVO_THREADS"] = str(threads)   # read once, at world creation
+            try:
+                wo = F.World(oracle_lib(), F.default_config(32, substeps=substeps))
+            finally:
+                del os.environ["AVO_THREADS"]
+            wo.bodies_upload(**sc.body_kwargs())
+            wo.colliders_upload(**sc.collider_kwargs())
+            wo.existing_pairs_upload(np.zeros(0, np.uint64))
+            wo.run_system("UPDATE_AABB")
+            wo.run_system("COLLECT_COLLISION_PAIRS")
+            scenes.upload_manifolds(wo, meta["manifolds"], meta["offsets"], sc.friction, sc.restitution)
+            c0 = time.perf_counter(); wo.step(); first = time.perf_counter() - c0
+            n_cpu = int(max(1, min(args.steps, seconds / max(first, 1e-6))))
+            c0 = time.perf_counter()
+            for _ in range(n_cpu):
+                wo.step()
+            cpu_s = time.perf_counter() - c0
+            sm, _ = wo.profile_system("SUBSTEP", 1)
+            wo.close()
+            return {"value": round(n_cpu * substeps / cpu_s, 4), "unit": "substeps/s", "cores": threads, "kind": "port",
+                    "sample": f"{n_cpu} whole steps ({n_cpu * substeps} substeps) of the same {args.scene} inputs after 1 warm-up step, "
+                              f"C++ oracle (g++ -O2 -ffp-contract=off) with {threads} thread(s) on {os.cpu_count()} host cores"
+                              + ("" if threads == 1 else "; threads follow the reference's own parallel loops (par_for_each over a colour's constraints, "
+                                                          "chunk = len / threads, min_len 64; par_iter_mut over bodies); the broad phase is serial as in the reference"),
+                    "ms_per_step": round(cpu_s / n_cpu * 1e3, 2), "substep_loop_only_ms": round(sm, 2)}
+
+        threads = max(1, min(args.cpu_threads or 64, os.cpu_count() or 1))
+        single = cpu_sample(1, args.cpu_seconds / 2 if threads > 1 else args.cpu_seconds)
+        cpu = single
+        if threads > 1:
+            multi = cpu_sample(threads, args.cpu_seconds / 2)
+            cpu = multi if multi["value"] >= single["value"] else single    # the baseline is the CPU's best
+            cpu = dict(cpu, single_thread={k: single[k] for k in ("value", "ms_per_step", "substep_loop_only_ms")},
+                       multi_thread={k: multi[k] for k in ("value", "cores", "ms_per_step", "substep_loop_only_ms")})
 
     if rank == 0:
         total_substeps = world_size * args.steps * substeps

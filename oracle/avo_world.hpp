@@ -1,8 +1,9 @@
 // ORACLE — TEST INFRASTRUCTURE ONLY.  Never linked, imported or called by the product path
 // (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it).
 //
-// avo_world.hpp: single-threaded CPU restatement of Avian's 3D hot path, in the reference's own
-// operation order.  Every function cites the reference file:line it
+// avo_world.hpp: CPU restatement of Avian's 3D hot path, in the reference's own operation order
+// (SURVEY.md §3.2, Appendix A).  Serial by default; AVO_THREADS=n runs the loops the reference itself
+// parallelises (avo_parallel.hpp) on n threads with bit-identical results.  Every function cites the reference file:line it
 // follows (paths relative to /root/reference/src).
 //
 // PARITY PINNING: the reference cannot be built here (no cargo/rustc; bevy/glam/parry not
@@ -24,6 +25,7 @@
 #include <vector>
 
 #include "../include/avian_mi355x.h"
+#include "avo_parallel.hpp"
 #include "avo_math.hpp"
 #include "avo_narrow.hpp"
 
@@ -304,6 +306,7 @@ void pipeline_delete(PipelineState*);
 
 template <class S> struct World : WorldBase {
     avn_config cfg;
+    Pool pool{Pool::from_env()};   // CPU-baseline threads (AVO_THREADS; 1 = the plain serial restatement)
     // time scalars (SURVEY.md Appendix A addenda "Time scalars")
     S dt_f64cast, h_f64cast;  // Duration::as_secs_f64() as Scalar   (integrator/mod.rs:275,354; plugin.rs:333-334)
     S dt_adj, h_adj;          // delta_seconds_adjusted()            (schedule/time.rs:282-291)
@@ -607,9 +610,13 @@ template <class S> struct World : WorldBase {
     //                                      SOLVER BODIES
     // =============================================================================================
     // solver_body/plugin.rs:173-251
+    // Query::par_iter_mut of the per-body systems: disjoint bodies, any order
+    template <class F> void par_bodies(F f) {
+        pool.par_for_each(bodies.size(), 64, [&](size_t b0, size_t b1) { for (size_t i = b0; i < b1; ++i) f(i, bodies[i]); });
+    }
     void prepare_solver_bodies() {
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body) continue;
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body) return;
             b.sb.linear_velocity = b.linear_velocity;
             b.sb.angular_velocity = b.angular_velocity;
             b.sb.delta_position = vzero<S>();
@@ -629,16 +636,15 @@ template <class S> struct World : WorldBase {
             bool rotation_locked = (b.locked_axes & 0b111) == 0b111;
             bool is_gyroscopic = !rotation_locked && !sym_is_isotropic(b.inv_inertia_local, S(1e-6));
             if (is_gyroscopic) b.sb.flags |= AVN_SB_GYROSCOPIC;
-        }
+        });
     }
     // integrator/mod.rs:260-313.  VelocityIntegrationData.{linear,angular}_increment hold the accumulated
     // accelerations written by ForcePlugin before this system (here: the uploaded accel_* arrays).
     void pre_process_velocity_increments() {
         S delta_secs = h_f64cast;
         V3<S> gravity{(S)cfg.gravity[0], (S)cfg.gravity[1], (S)cfg.gravity[2]};
-        for (size_t i = 0; i < bodies.size(); ++i) {
-            Body<S>& b = bodies[i];
-            if (b.rb_type != AVN_RB_DYNAMIC) continue;
+        par_bodies([&](size_t i, Body<S>& b) {
+            if (b.rb_type != AVN_RB_DYNAMIC) return;
             b.vid.linear_increment = accel_linear[i];
             b.vid.angular_increment = accel_angular[i];
             b.vid.linear_damping_rhs = S(1) / (S(1) + delta_secs * b.linear_damping);
@@ -652,12 +658,13 @@ template <class S> struct World : WorldBase {
             if (b.locked_axes & 0b000001) b.vid.angular_increment.z = 0;
             b.vid.linear_increment = b.vid.linear_increment * delta_secs;
             b.vid.angular_increment = b.vid.angular_increment * delta_secs;
-        }
+        });
     }
     // integrator/mod.rs:316-328
     void clear_velocity_increments() {
-        for (Body<S>& b : bodies)
+        par_bodies([&](size_t, Body<S>& b) {
             if (b.has_solver_body) { b.vid.linear_increment = vzero<S>(); b.vid.angular_increment = vzero<S>(); }
+        });
     }
     // integrator/mod.rs:403-460
     static void solve_gyroscopic_torque(V3<S>& ang_vel, Q4<S> rotation, const Sym3<S>& local_inverse_inertia, S delta_secs) {
@@ -673,9 +680,9 @@ template <class S> struct World : WorldBase {
     // integrator/mod.rs:343-391, then clamp_velocities :467-500
     void integrate_velocities() {
         S delta_secs = h_f64cast;
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) continue;
-            if (b.sb.is_kinematic()) continue;
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) return;
+            if (b.sb.is_kinematic()) return;
             b.sb.linear_velocity = b.sb.linear_velocity * b.vid.linear_damping_rhs;
             b.sb.angular_velocity = b.sb.angular_velocity * b.vid.angular_damping_rhs;
             b.sb.linear_velocity = b.sb.linear_velocity + b.vid.linear_increment;
@@ -684,49 +691,49 @@ template <class S> struct World : WorldBase {
                 Q4<S> rotation = qmul(b.sb.delta_rotation, b.rotation);
                 solve_gyroscopic_torque(b.sb.angular_velocity, rotation, b.inv_inertia_local, delta_secs);
             }
-        }
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body) continue;
+        });
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body) return;
             if (b.max_linear_speed >= S(0)) {
                 S sq = length_squared(b.sb.linear_velocity);
                 if (sq > b.max_linear_speed * b.max_linear_speed) b.sb.linear_velocity = b.sb.linear_velocity * (b.max_linear_speed / std::sqrt(sq));
             }
-        }
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body) continue;
+        });
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body) return;
             if (b.max_angular_speed >= S(0)) {
                 S sq = length_squared(b.sb.angular_velocity);
                 if (sq > b.max_angular_speed * b.max_angular_speed) b.sb.angular_velocity = b.sb.angular_velocity * (b.max_angular_speed / std::sqrt(sq));
             }
-        }
+        });
     }
     // integrator/mod.rs:503-535, then update_solver_body_angular_inertia solver_body/plugin.rs:287-295
     void integrate_positions() {
         S delta_secs = h_adj;
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_POSITION_INTEGRATION)) continue;
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_POSITION_INTEGRATION)) return;
             b.sb.delta_position = b.sb.delta_position + b.sb.linear_velocity * delta_secs;
             b.sb.delta_rotation = qmul(from_scaled_axis(b.sb.angular_velocity * delta_secs), b.sb.delta_rotation);
-        }
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body) continue;
+        });
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body) return;
             // update_effective_inv_angular_inertia (solver_body/mod.rs:473-501): uses the step-start Rotation
             Sym3<S> t = rotated_inverse_inertia(b.inv_inertia_local, b.rotation);
             lock_rotation_axes(t, b.si.flags & 0x3F);
             b.si.inv_inertia = t;
-        }
+        });
     }
     // solver_body/plugin.rs:255-284
     void writeback_solver_bodies() {
-        for (Body<S>& b : bodies) {
-            if (!b.has_solver_body) continue;
+        par_bodies([&](size_t, Body<S>& b) {
+            if (!b.has_solver_body) return;
             V3<S> old_world_com = qrot(b.rotation, b.center_of_mass);
             b.rotation = fast_renormalize(qmul(b.sb.delta_rotation, b.rotation));
             V3<S> new_world_com = qrot(b.rotation, b.center_of_mass);
             b.position = b.position + ((b.sb.delta_position + old_world_com) - new_world_com);
             b.linear_velocity = b.sb.linear_velocity;
             b.angular_velocity = b.sb.angular_velocity;
-        }
+        });
     }
 
     // =============================================================================================
@@ -734,13 +741,13 @@ template <class S> struct World : WorldBase {
     // =============================================================================================
     // Dummy bodies (solver/plugin.rs:491-505): static/sleeping/missing bodies use a fresh local DUMMY.
     struct BodyRef { SolverBody<S>* body; const SolverBodyInertia<S>* inertia; };
-    SolverBody<S> dummy_body[2];
+    struct Dummies { SolverBody<S> body[2]; };   // the caller's two local `let mut dummy = SolverBody::DUMMY` (plugin.rs:491-505)
     SolverBodyInertia<S> dummy_inertia;
-    BodyRef solver_ref(int32_t idx, int which) {
+    BodyRef solver_ref(int32_t idx, int which, Dummies& d) {
         Body<S>& b = bodies[idx];
         if (b.has_solver_body) return {&b.sb, &b.si};
-        dummy_body[which] = SolverBody<S>();
-        return {&dummy_body[which], &dummy_inertia};
+        d.body[which] = SolverBody<S>();
+        return {&d.body[which], &dummy_inertia};
     }
 
     // ContactConstraint::generate, contact/mod.rs:110-220; driver solver/plugin.rs:363-448
@@ -748,8 +755,11 @@ template <class S> struct World : WorldBase {
         if (use_handles) gather_manifolds_from_handles();
         update_contact_softness();  // runs .before(NarrowPhase) every step, plugin.rs:108,326-350
         bool warm = cfg.match_contacts != 0;
-        uint32_t count = 0;
-        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        uint32_t counts[AVN_GRAPH_COLOR_COUNT] = {};
+        // "parallelizing over graph colors": par_for_each(&mut active_colors, 2, ..) (plugin.rs:387-388) -- one task per colour chunk
+        pool.par_for_each(AVN_GRAPH_COLOR_COUNT, 2, [&](size_t c0, size_t c1) {
+        for (int c = (int)c0; c < (int)c1; ++c) {
+            uint32_t count = 0;
             color_constraints[c].clear();
             for (uint32_t mi = color_offsets[c]; mi < color_offsets[c + 1]; ++mi) {
                 const ContactManifold<S>& m = manifolds[mi];
@@ -793,20 +803,28 @@ template <class S> struct World : WorldBase {
                 }
                 if (k.point_count > 0) { color_constraints[c].push_back(k); ++count; }
             }
+            counts[c] = count;
         }
+        });
+        uint32_t count = 0;
+        for (uint32_t n : counts) count += n;
         last_timers.contact_constraint_count = count;
     }
 
     // Colour iteration order shared by warm_start / solve_contacts / solve_restitution:
     // overflow colour serially FIRST, then colours 0..22 (solver/plugin.rs:461-479).
+    // ... the constraints of one colour 0..22 touch disjoint bodies: par_for_each(&mut color.contact_constraints, 64, ..)
+    // (plugin.rs:476,564,662)
     template <class F> void for_each_constraint_in_solver_order(F f) {
         for (ContactConstraint<S>& k : color_constraints[AVN_COLOR_OVERFLOW_INDEX]) f(k);
-        for (int c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
-            for (ContactConstraint<S>& k : color_constraints[c]) f(k);
+        for (int c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) {
+            std::vector<ContactConstraint<S>>& v = color_constraints[c];
+            pool.par_for_each(v.size(), 64, [&](size_t b0, size_t b1) { for (size_t i = b0; i < b1; ++i) f(v[i]); });
+        }
     }
-    void resolve(ContactConstraint<S>& k, BodyRef& r1, BodyRef& r2) {
-        r1 = solver_ref(k.body1, 0);
-        r2 = solver_ref(k.body2, 1);
+    void resolve(ContactConstraint<S>& k, BodyRef& r1, BodyRef& r2, Dummies& d) {
+        r1 = solver_ref(k.body1, 0, d);
+        r2 = solver_ref(k.body2, 1, d);
         if (k.relative_dominance > 0) r1.inertia = &dummy_inertia;       // plugin.rs:508-512
         else if (k.relative_dominance < 0) r2.inertia = &dummy_inertia;
     }
@@ -818,7 +836,7 @@ template <class S> struct World : WorldBase {
     void warm_start() {
         S coeff = (S)cfg.warm_start_coefficient;
         for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
-            BodyRef r1, r2; resolve(k, r1, r2);
+            Dummies dm; BodyRef r1, r2; resolve(k, r1, r2, dm);
             V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
             const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
             V3<S> t0, t1; tangent_directions(k, t0, t1);
@@ -839,7 +857,7 @@ template <class S> struct World : WorldBase {
         S delta_secs = h_adj;
         S max_overlap_solve_speed = (S)cfg.max_overlap_solve_speed * (S)cfg.length_unit;
         for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
-            BodyRef r1, r2; resolve(k, r1, r2);
+            Dummies dm; BodyRef r1, r2; resolve(k, r1, r2, dm);
             SolverBody<S>& body1 = *r1.body; SolverBody<S>& body2 = *r2.body;
             V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
             const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
@@ -878,7 +896,7 @@ template <class S> struct World : WorldBase {
         S threshold = (S)cfg.restitution_threshold * (S)cfg.length_unit;
         for_each_constraint_in_solver_order([&](ContactConstraint<S>& k) {
             if (k.restitution == S(0)) return;
-            BodyRef r1, r2; resolve(k, r1, r2);
+            Dummies dm; BodyRef r1, r2; resolve(k, r1, r2, dm);
             SolverBody<S>& body1 = *r1.body; SolverBody<S>& body2 = *r2.body;
             V3<S> inv_mass1 = r1.inertia->effective_inv_mass(), inv_mass2 = r2.inertia->effective_inv_mass();
             const Sym3<S>& ii1 = r1.inertia->inv_inertia; const Sym3<S>& ii2 = r2.inertia->inv_inertia;
@@ -909,15 +927,20 @@ template <class S> struct World : WorldBase {
         if (use_handles) scatter_impulses_to_contacts();
     }
     void store_contact_impulses_to_manifolds() {
-        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
-            for (ContactConstraint<S>& k : color_constraints[c]) {
-                ContactManifold<S>& m = manifolds[k.manifold];
-                for (int p = 0; p < k.point_count; ++p) {
-                    m.points[p].warm_start_normal_impulse = k.points[p].normal_part.impulse;
-                    m.points[p].warm_start_tangent_impulse = k.points[p].has_tangent ? k.points[p].tangent_part.impulse : V2<S>{0, 0};
-                    m.points[p].normal_impulse = k.points[p].normal_part.total_impulse;
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+            std::vector<ContactConstraint<S>>& v = color_constraints[c];
+            pool.par_for_each(v.size(), 64, [&](size_t b0, size_t b1) {
+                for (size_t i = b0; i < b1; ++i) {
+                    ContactConstraint<S>& k = v[i];
+                    ContactManifold<S>& m = manifolds[k.manifold];
+                    for (int p = 0; p < k.point_count; ++p) {
+                        m.points[p].warm_start_normal_impulse = k.points[p].normal_part.impulse;
+                        m.points[p].warm_start_tangent_impulse = k.points[p].has_tangent ? k.points[p].tangent_part.impulse : V2<S>{0, 0};
+                        m.points[p].normal_impulse = k.points[p].normal_part.total_impulse;
+                    }
                 }
-            }
+            });
+        }
     }
 
     // =============================================================================================
