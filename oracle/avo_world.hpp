@@ -1463,11 +1463,13 @@ template <class S> struct World : WorldBase {
         const S delta_secs = dt_adj;
         const S default_speculative_margin = (S)cfg.length_unit * (cfg.default_speculative_margin >= (double)std::numeric_limits<S>::max() ? std::numeric_limits<S>::max() : (S)cfg.default_speculative_margin);
         const S contact_tolerance = (S)cfg.length_unit * (S)cfg.contact_tolerance;
-        for (uint32_t id : active_pairs) {
+        // one contact pair; pairs own disjoint rows, so the reference runs them on the ComputeTaskPool with thread-local
+        // status-change bit vectors (system_param.rs:454-475, feature "parallel"); here: per-chunk change lists
+        auto update_pair = [&](uint32_t id, std::vector<avn_contact_change>& changes) {
             CtRow& r = contact_rows[id];
             bool status = false;
             auto i1 = collider_slot.find(r.collider1), i2 = collider_slot.find(r.collider2);
-            if (i1 == collider_slot.end() || i2 == collider_slot.end()) continue;  // collider_query.get_many failed
+            if (i1 == collider_slot.end() || i2 == collider_slot.end()) return;  // collider_query.get_many failed
             const Collider<S>& c1 = colliders[i1->second]; const Collider<S>& c2 = colliders[i2->second];
             bool overlap = c1.aabb.min.x <= c2.aabb.max.x && c1.aabb.max.x >= c2.aabb.min.x && c1.aabb.min.y <= c2.aabb.max.y && c1.aabb.max.y >= c2.aabb.min.y &&
                            c1.aabb.min.z <= c2.aabb.max.z && c1.aabb.max.z >= c2.aabb.min.z;  // ColliderAabb::intersects, collider/mod.rs:539-544
@@ -1563,7 +1565,14 @@ template <class S> struct World : WorldBase {
                 else if (!touching && was_touching) { r.flags |= AVN_CP_STOPPED_TOUCHING; status = true; }
                 else if (r.manifold_count_change != 0) status = true;
             }
-            if (status) contact_changes.push_back({id, r.flags, r.manifold_count_change, r.n_manifolds});
+            if (status) changes.push_back({id, r.flags, r.manifold_count_change, r.n_manifolds});
+        };
+        {
+            const size_t n = active_pairs.size(), chunk = std::max<size_t>(n / pool.threads, 1), chunks = n ? (n + chunk - 1) / chunk : 0;
+            std::vector<std::vector<avn_contact_change>> per_chunk(pool.threads == 1 || n < 64 ? 1 : chunks);
+            if (per_chunk.size() == 1) { for (uint32_t id : active_pairs) update_pair(id, per_chunk[0]); }
+            else pool.par_for_each(n, 64, [&](size_t b0, size_t b1) { std::vector<avn_contact_change>& out = per_chunk[b0 / chunk]; for (size_t i = b0; i < b1; ++i) update_pair(active_pairs[i], out); });
+            for (const std::vector<avn_contact_change>& v : per_chunk) contact_changes.insert(contact_changes.end(), v.begin(), v.end());
         }
         std::sort(contact_changes.begin(), contact_changes.end(), [](const avn_contact_change& a, const avn_contact_change& b) { return a.contact_id < b.contact_id; });
         // the status processing of system_param.rs:141-389 clears these once handled (host side); here they are per-step outputs
@@ -1573,7 +1582,9 @@ template <class S> struct World : WorldBase {
     // the manifolds prepare_contact_constraints reads through GraphColor::manifold_handles (plugin.rs:389-398)
     void gather_manifolds_from_handles() {
         manifolds.resize(manifold_handles.size());
-        for (size_t i = 0; i < manifold_handles.size(); ++i) {
+        // (a copy of the reference's in-place access through get_by_id: an artefact of this restatement, run on the pool)
+        pool.par_for_each(manifold_handles.size(), 64, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
             const CtRow& r = contact_rows[manifold_handles[i]];
             ContactManifold<S>& m = manifolds[i];
             m.body1 = colliders[collider_slot.at(r.collider1)].body;
@@ -1587,9 +1598,11 @@ template <class S> struct World : WorldBase {
                 m.points[k] = {c.anchor1, c.anchor2, c.penetration, c.normal_speed, c.warm_start_normal_impulse, c.normal_impulse, c.warm_start_tangent_impulse};
             }
         }
+        });
     }
     void scatter_impulses_to_contacts() {
-        for (size_t i = 0; i < manifold_handles.size(); ++i) {
+        pool.par_for_each(manifold_handles.size(), 64, [&](size_t i0, size_t i1) {
+        for (size_t i = i0; i < i1; ++i) {
             CtRow& r = contact_rows[manifold_handles[i]];
             const ContactManifold<S>& m = manifolds[i];
             for (int k = 0; k < m.point_count; ++k) {
@@ -1598,6 +1611,7 @@ template <class S> struct World : WorldBase {
                 r.pts[k].normal_impulse = m.points[k].normal_impulse;
             }
         }
+        });
     }
     avn_status aabbs_download(void* mn, void* mx, uint32_t* ents, size_t* n_iv) override {
         for (size_t i = 0; i < colliders.size(); ++i) { wr3(mn, i, colliders[i].aabb.min); wr3(mx, i, colliders[i].aabb.max); }
