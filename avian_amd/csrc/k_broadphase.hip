@@ -424,6 +424,7 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 #define SW_THREADS (64 * SW_WAVES)
 #define SW_Q 1024   // ring slots per wave: < 64 carried + 8 x 64 appended per batch
 #define SW_CAP 8192u
+#define SW_LONG_MIN 256u   // relative long-interval rule (k_sweep_ranges): never below this many candidates
 #define SW_LCHUNK 4096u
 
 // wave-wide compare masks (LLVM fcmp predicates: UGE = 11, ULE = 13); inactive lanes read 0
@@ -458,16 +459,22 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
     return pr;
 }
 
-// end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems
+// end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems.
+// "Long" is absolute (more than SW_CAP candidates) or RELATIVE: a wave of k_sweep walks the union of its 64 lanes' candidate
+// ranges, so one interval that reaches much further than its 63 neighbours (a ground plate among boxes: 5 500 candidates
+// against ~200 in the reference's pyramid scenes) drags the whole wave through its range on the slow per-lane-bounds path --
+// 160 us of a 5 k-box step.  An interval with more than SW_LONG_MIN candidates and more than 4x the mean of the other lanes
+// of its wave goes to the long path too (at most 16 lanes of a wave can satisfy that, so the item capacity holds).  The
+// split only moves work between two order-exact paths: the pair list does not change.
 template <class T>
 __global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __restrict__ s_minx, const T* __restrict__ s_maxx, uint32_t* __restrict__ s_end,
                                                        uint32_t* __restrict__ s_flags, LongItem* __restrict__ items, uint32_t* __restrict__ n_long,
                                                        uint32_t long_cap, uint32_t* __restrict__ overflow) {
-    uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t f = s_flags[i];
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;   // wave w of the block = the 64 intervals of one k_sweep wave
+    const bool valid = i < n;
+    const uint32_t f = valid ? s_flags[i] : 0u;
     uint32_t end = i + 1;
-    if (!(f & AVN_IV_DROPPED)) {
+    if (valid && !(f & AVN_IV_DROPPED)) {
         T mx = s_maxx[i];
         uint32_t lo = i + 1, hi = n;  // first index in [lo, hi] whose min.x > mx  (x test: `min_x[j] > max_x[i]` ends the sweep)
         while (lo < hi) {
@@ -476,8 +483,13 @@ __global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __res
         }
         end = lo;
     }
-    uint32_t len = end - (i + 1);
-    if (len > SW_CAP) {
+    const uint32_t len = valid ? end - (i + 1) : 0u;
+    uint32_t sum = len;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += (uint32_t)__shfl_xor((int)sum, off);
+    const uint32_t others = (sum - len) / 63u;
+    if (!valid) return;
+    if (len > SW_CAP || (len > SW_LONG_MIN && len > 4u * others)) {
         uint32_t nch = (len + SW_LCHUNK - 1) / SW_LCHUNK;
         uint32_t k = atomicAdd(n_long, nch);
         if (k + nch > long_cap) { *overflow = 1u; }
