@@ -183,8 +183,25 @@ template <class T> struct World : WorldBase {
     size_t island_max_manifolds = 65536;  // above this the colour launches are throughput- not latency-bound (1 wave per SIMD = 65k manifolds): keep the device-wide path
     uint32_t island_pack_bodies = 256;    // islands are packed into one block up to this many bodies (a single island may reach ISLAND_MAX_BODIES)
     std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent;
-    DevBuf b_isl_body_off, b_isl_bodies, b_isl_col_off, b_isl_ent;
+    DevBuf b_isl_bodies;   // [body_off | bodies | col_off | ent], 256-byte aligned parts
     IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0};
+    bool islands_dirty = false;          // the manifold set changed since the blocks were built
+    // pinned host staging (grow-only): island block arrays on their way up, narrow-phase change list on its way down
+    struct Pinned {
+        void* p = nullptr; size_t cap = 0;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+        hipError_t ensure(size_t bytes) {
+            if (bytes <= cap) return hipSuccess;
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            size_t c = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
+            hipError_t e = hipHostMalloc(&p, c, hipHostMallocDefault);
+            if (e == hipSuccess) cap = c;
+            return e;
+        }
+    };
+    Pinned pin_islands, pin_changes;
+    static constexpr uint32_t CHANGES_PREFIX = 2048;   // status changes fetched together with their count (one round trip)
     bool any_damped = false;
     bool any_restitution = false;  // some manifold has restitution != 0 (else apply_restitution early-outs for all, contact/mod.rs:366-369)
     std::vector<uint32_t> slot_entity;  // collider entity per slot (last upload)
@@ -502,7 +519,7 @@ template <class T> struct World : WorldBase {
     avn_status rebuild_incidence() {
         if (!incidence_dirty) return AVN_OK;
         uint32_t N = dw.n_bodies, M = dw.n_manifolds;
-        if (M == 0) { incidence_dirty = false; return AVN_OK; }
+        if (M == 0) { incidence_dirty = false; island_mode = false; islands_dirty = false; return AVN_OK; }
         if (h_body_has_sb.size() != N || h_m_body1.size() != M) { error = "incidence: bodies / manifolds out of sync"; return AVN_ERR_STATE; }
         HIPCHK(hipStreamSynchronize(stream));
         hipError_t err;
@@ -565,8 +582,7 @@ template <class T> struct World : WorldBase {
             if (o1 > o0) graph_valid = false;  // level sizes are captured launch parameters
             if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p) graph_valid = false;
         }
-        avn_status ist = rebuild_island_blocks();
-        if (ist != AVN_OK) return ist;
+        islands_dirty = true;   // rebuilt by solver_front AFTER the prepare kernels are enqueued (host work overlaps them)
         incidence_dirty = false;
         return AVN_OK;
     }
@@ -650,13 +666,21 @@ template <class T> struct World : WorldBase {
                 ent[2 * (size_t)e] = m;
                 ent[2 * (size_t)e + 1] = (has_sb(a) ? slot[(uint32_t)a] : 0u) | (has_sb(b) ? slot[(uint32_t)b] : 0u) << 16;
             }
-        avn_status st;
-        if ((st = upload_u32(b_isl_body_off, body_off)) != AVN_OK) return st;
-        if ((st = upload_u32(b_isl_bodies, bodies)) != AVN_OK) return st;
-        if ((st = upload_u32(b_isl_col_off, col_off)) != AVN_OK) return st;
-        if ((st = upload_u32(b_isl_ent, ent)) != AVN_OK) return st;
-        HIPCHK(hipStreamSynchronize(stream));
-        islands = IslandBlocks{b_isl_body_off.as<uint32_t>(), b_isl_bodies.as<uint32_t>(), b_isl_col_off.as<uint32_t>(), b_isl_ent.as<uint2>(), n_blocks};
+        // one pinned staging block -> one async copy on the solver's stream (the consumer); no synchronisation: the stream
+        // was idle when the previous block went up (rebuild_incidence / the narrow-phase read-back synchronise it every step)
+        const size_t w0 = body_off.size(), w1 = bodies.size(), w2 = col_off.size(), w3 = ent.size();
+        const size_t o1 = (w0 + 63) & ~(size_t)63, o2 = o1 + ((w1 + 63) & ~(size_t)63), o3 = o2 + ((w2 + 63) & ~(size_t)63), words = o3 + w3;
+        if (pin_islands.ensure(words * 4) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        uint32_t* h = (uint32_t*)pin_islands.p;
+        std::memcpy(h, body_off.data(), w0 * 4); std::memcpy(h + o1, bodies.data(), w1 * 4);
+        std::memcpy(h + o2, col_off.data(), w2 * 4); std::memcpy(h + o3, ent.data(), w3 * 4);
+        if (words * 4 > b_isl_bodies.cap) HIPCHK(hipStreamSynchronize(stream));   // growing frees the old block: nothing may still read it
+        hipError_t err;
+        b_isl_bodies.ensure(words * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemcpyAsync(b_isl_bodies.p, h, words * 4, hipMemcpyHostToDevice, stream));
+        uint32_t* d = b_isl_bodies.as<uint32_t>();
+        islands = IslandBlocks{d, d + o1, d + o2, (const uint2*)(d + o3), n_blocks};
         island_mode = true;
         return AVN_OK;
     }
@@ -1136,12 +1160,21 @@ template <class T> struct World : WorldBase {
         launch_narrow_phase<T>(dw, bp, ct, params, b_active.as<uint32_t>(), n_active, b_changes.as<avn_contact_change>(), d_count, stream);
         ++launches;
         HIPCHK(hipGetLastError());
-        uint32_t cnt = 0;
-        HIPCHK(hipMemcpyAsync(&cnt, d_count, 4, hipMemcpyDeviceToHost, stream));
+        // the count and the first CHANGES_PREFIX changes come back in one round trip (pinned memory, one synchronisation);
+        // only a step with more changes than that pays a second copy
+        const uint32_t prefix = std::min<uint32_t>(CHANGES_PREFIX, n_active);
+        HIPCHK(pin_changes.ensure(64 + (size_t)CHANGES_PREFIX * sizeof(avn_contact_change)));
+        uint32_t* h_cnt = (uint32_t*)pin_changes.p;
+        avn_contact_change* h_pre = (avn_contact_change*)((char*)pin_changes.p + 64);
+        HIPCHK(hipMemcpyAsync(h_cnt, d_count, 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_pre, b_changes.p, (size_t)prefix * sizeof(avn_contact_change), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
+        const uint32_t cnt = *h_cnt;
         if (cnt) {
             h_changes.resize(cnt);
-            HIPCHK(hipMemcpy(h_changes.data(), b_changes.p, (size_t)cnt * sizeof(avn_contact_change), hipMemcpyDeviceToHost));
+            std::memcpy(h_changes.data(), h_pre, (size_t)std::min(cnt, prefix) * sizeof(avn_contact_change));
+            if (cnt > prefix)
+                HIPCHK(hipMemcpy(h_changes.data() + prefix, b_changes.as<avn_contact_change>() + prefix, (size_t)(cnt - prefix) * sizeof(avn_contact_change), hipMemcpyDeviceToHost));
             // ContactStatusBits are walked in ascending contact id (system_param.rs:141-145)
             std::sort(h_changes.begin(), h_changes.end(), [](const avn_contact_change& a, const avn_contact_change& b) { return a.contact_id < b.contact_id; });
         }
@@ -1561,7 +1594,6 @@ template <class T> struct World : WorldBase {
     void prepare_contact_constraints() {
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
-        if (slots_dirty && dw.n_manifolds && dw.inc_slot && !islands_active()) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
         launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
     }
     void store_contact_impulses() {
@@ -1640,6 +1672,8 @@ template <class T> struct World : WorldBase {
                 return AVN_OK;
             }
         }
+        // the body-centric warm start's slot table (not needed by the island blocks); outside the capture below
+        if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
         if (!cfg.use_graph) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
         if (!graph_valid) {
             drop_graph();
@@ -1666,6 +1700,8 @@ template <class T> struct World : WorldBase {
         prepare_joints();
         prepare_contact_constraints();
         pre_process_velocity_increments();
+        // host work that only the substep loop needs, done while the prepare kernels above run
+        if (islands_dirty) { islands_dirty = false; if ((st = rebuild_island_blocks()) != AVN_OK) return st; }
         HIPCHK(hipEventRecord(ev[2], stream));
         if ((st = run_substeps()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[3], stream));
