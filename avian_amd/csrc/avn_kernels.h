@@ -87,6 +87,7 @@ template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typenam
 template <class T> uint32_t launch_dynamic_bounds(const DW<T>&, const BP<T>&, T* partial, hipStream_t);
 uint32_t radix_blocks(uint32_t n);
 uint32_t radix_pass_launches(uint32_t n);  // kernels per 8-bit pass of launch_radix_sort
+uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes);  // kernels launch_radix_sort issues in total
 uint32_t scan_block_sums_needed(uint32_t n);
 uint32_t exclusive_scan_launches(uint32_t n);  // kernels launch_exclusive_scan issues for n items
 // `enabled` (device flag, may be null): when it reads 0 every kernel of the call returns immediately

@@ -698,12 +698,50 @@ template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, ty
 }
 uint32_t radix_blocks(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 uint32_t radix_pass_launches(uint32_t n) { uint32_t nb = radix_blocks(n); return nb <= RS_FUSED_MAX_BLOCKS ? 2u : 2u + exclusive_scan_launches(256 * nb); }
+// Small scenes (the reference's own 5 k-box benches): the whole sort in ONE workgroup.  Four to eight radix passes of two
+// launches each cost ~75 us at 5.6 k keys -- every launch on its latency floor -- so up to SS_MAX 32-bit keys are sorted by a
+// bitonic network in LDS instead.  Stability (equal min.x keep their previous relative order: what the reference's
+// insertion sort guarantees and the pair order depends on) comes from sorting the UNIQUE composites key << 32 | position.
+#define SS_MAX 8192u
+#define SS_THREADS 1024
+__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, const uint32_t* __restrict__ unsorted) {
+    if (unsorted && *unsorted == 0u) return;   // the persistent order is still sorted
+    __shared__ uint64_t l[SS_MAX];
+    const uint32_t t = threadIdx.x;
+    uint32_t m = 2;
+    while (m < n) m <<= 1;
+    for (uint32_t i = t; i < m; i += SS_THREADS) l[i] = i < n ? ((uint64_t)keys[i] << 32) | i : ~0ull;   // padding sorts last
+    __syncthreads();
+    for (uint32_t k = 2; k <= m; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            for (uint32_t p = t; p < (m >> 1); p += SS_THREADS) {
+                const uint32_t lo = ((p & ~(j - 1u)) << 1) | (p & (j - 1u));   // p with a zero bit inserted at bit log2(j)
+                const uint32_t hi = lo | j;
+                const bool up = (lo & k) == 0u;
+                const uint64_t a = l[lo], b = l[hi];
+                if ((a > b) == up) { l[lo] = b; l[hi] = a; }
+            }
+            __syncthreads();
+        }
+    // permute the values through LDS (every gather lands before any element is overwritten)
+    for (uint32_t i = t; i < n; i += SS_THREADS) { const uint64_t c = l[i]; l[i] = (c & 0xFFFFFFFF00000000ull) | vals[(uint32_t)c]; }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += SS_THREADS) { const uint64_t c = l[i]; keys[i] = (uint32_t)(c >> 32); vals[i] = (uint32_t)c; }
+}
+template <class K> static bool sort_small(K*, uint32_t*, uint32_t, const uint32_t*, hipStream_t) { return false; }
+template <> bool sort_small<uint32_t>(uint32_t* keys, uint32_t* vals, uint32_t n, const uint32_t* unsorted, hipStream_t s) {
+    if (n > SS_MAX) return false;
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys, vals, n, unsorted);
+    return true;
+}
+uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes) { return key_bytes == 4 && n <= SS_MAX ? 1u : key_bytes * radix_pass_launches(n); }
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
                                           const uint32_t* unsorted, hipStream_t s) {
     // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even.  Every kernel
     // returns at once when *unsorted == 0 (the persistent interval order is still sorted: the reference's insertion sort
     // is O(n) then, ours is O(launch)).
     if (n == 0) return;
+    if (sort_small<K>(keys_a, vals_a, n, unsorted, s)) return;   // one workgroup, in place
     uint32_t nb = radix_blocks(n);
     K* ki = keys_a; uint32_t* vi = vals_a; K* ko = keys_b; uint32_t* vo = vals_b;
     for (uint32_t pass = 0; pass < sizeof(K); ++pass) {
