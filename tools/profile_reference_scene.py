@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""120 closed-loop steps of one of the reference's bench scenes (many | large), for `rocprofv3 --kernel-trace --stats`
+(tools/final_measure.sh): per-kernel time of the island-block path (Many Pyramids) and the colour-launch path (Large Pyramid)."""
 import sys, os, numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
