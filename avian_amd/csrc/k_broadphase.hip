@@ -698,40 +698,86 @@ template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, ty
 }
 uint32_t radix_blocks(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 uint32_t radix_pass_launches(uint32_t n) { uint32_t nb = radix_blocks(n); return nb <= RS_FUSED_MAX_BLOCKS ? 2u : 2u + exclusive_scan_launches(256 * nb); }
-// Small scenes (the reference's own 5 k-box benches): the whole sort in ONE workgroup.  Four to eight radix passes of two
-// launches each cost ~75 us at 5.6 k keys -- every launch on its latency floor -- so up to SS_MAX 32-bit keys are sorted by a
-// bitonic network in LDS instead.  Stability (equal min.x keep their previous relative order: what the reference's
-// insertion sort guarantees and the pair order depends on) comes from sorting the UNIQUE composites key << 32 | position.
+// Small scenes (the reference's own 5 k-box benches): the whole sort in ONE launch.  Four radix passes of two launches each
+// cost ~75 us at 5.6 k keys -- every launch on its latency floor -- so up to SS_MAX 32-bit keys are sorted by one workgroup
+// whose 8 waves play the tiles of the multi-launch sort: per pass a per-wave digit histogram in LDS, the (digit-major,
+// wave-minor) exclusive scan, the same ballot-ranked stable scatter as k_radix_scatter, a workgroup barrier where the
+// launches had a kernel boundary.  (A one-workgroup bitonic network over key << 32 | position composites was tried first:
+// 61-68 us -- 373 k 64-bit compare-exchanges are ~50 us of VALU time on ONE CU however they are scheduled.)
 #define SS_MAX 8192u
-#define SS_THREADS 1024
-__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t n, const uint32_t* __restrict__ unsorted) {
+#define SS_WAVES 8
+#define SS_THREADS (64 * SS_WAVES)
+__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted) {
     if (unsorted && *unsorted == 0u) return;   // the persistent order is still sorted
-    __shared__ uint64_t l[SS_MAX];
-    const uint32_t t = threadIdx.x;
-    uint32_t m = 2;
-    while (m < n) m <<= 1;
-    for (uint32_t i = t; i < m; i += SS_THREADS) l[i] = i < n ? ((uint64_t)keys[i] << 32) | i : ~0ull;   // padding sorts last
-    __syncthreads();
-    for (uint32_t k = 2; k <= m; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            for (uint32_t p = t; p < (m >> 1); p += SS_THREADS) {
-                const uint32_t lo = ((p & ~(j - 1u)) << 1) | (p & (j - 1u));   // p with a zero bit inserted at bit log2(j)
-                const uint32_t hi = lo | j;
-                const bool up = (lo & k) == 0u;
-                const uint64_t a = l[lo], b = l[hi];
-                if ((a > b) == up) { l[lo] = b; l[hi] = a; }
-            }
-            __syncthreads();
+    __shared__ uint32_t cnt[SS_WAVES][256];    // per-wave digit counts, then the wave's running output offsets
+    __shared__ uint32_t tot[256];
+    const uint32_t t = threadIdx.x, lane = t & 63u;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    const uint32_t base = wv * RS_TILE;
+    uint32_t* ki = keys_a; uint32_t* vi = vals_a; uint32_t* ko = keys_b; uint32_t* vo = vals_b;
+    for (uint32_t shift = 0; shift < 32u; shift += 8u) {
+        uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
+#pragma unroll
+        for (uint32_t r = 0; r < RS_ROUNDS; ++r) {   // the wave's tile, all loads in flight at once
+            const uint32_t idx = base + r * 64u + lane;
+            key[r] = idx < n ? ki[idx] : 0u;
+            val[r] = idx < n ? vi[idx] : 0u;
         }
-    // permute the values through LDS (every gather lands before any element is overwritten)
-    for (uint32_t i = t; i < n; i += SS_THREADS) { const uint64_t c = l[i]; l[i] = (c & 0xFFFFFFFF00000000ull) | vals[(uint32_t)c]; }
-    __syncthreads();
-    for (uint32_t i = t; i < n; i += SS_THREADS) { const uint64_t c = l[i]; keys[i] = (uint32_t)(c >> 32); vals[i] = (uint32_t)c; }
+        for (uint32_t d = lane; d < 256u; d += 64u) cnt[wv][d] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < RS_ROUNDS; ++r)
+            if (base + r * 64u + lane < n) atomicAdd(&cnt[wv][(key[r] >> shift) & 255u], 1u);
+        __syncthreads();
+        // thread d < 256: digit total, and the exclusive prefix over the waves (the tiles before this one)
+        if (t < 256u) {
+            uint32_t run = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < SS_WAVES; ++w) { const uint32_t c = cnt[w][t]; cnt[w][t] = run; run += c; }
+            tot[t] = run;
+        }
+        __syncthreads();
+        if (t < 64u) {   // exclusive scan over the 256 digits: lane owns digits 4 lane .. 4 lane + 3
+            const uint32_t a0 = tot[4 * t], a1 = tot[4 * t + 1], a2 = tot[4 * t + 2], a3 = tot[4 * t + 3];
+            const uint32_t mine = a0 + a1 + a2 + a3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t v = (uint32_t)__shfl_up((int)incl, off); if ((int)t >= off) incl += v; }
+            const uint32_t excl = incl - mine;
+            tot[4 * t] = excl; tot[4 * t + 1] = excl + a0; tot[4 * t + 2] = excl + a0 + a1; tot[4 * t + 3] = excl + a0 + a1 + a2;
+        }
+        __syncthreads();
+        for (uint32_t d = lane; d < 256u; d += 64u) cnt[wv][d] += tot[d];   // the wave's start offset per digit
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+            const bool valid = base + r * 64u + lane < n;
+            const uint32_t digit = (key[r] >> shift) & 255u;
+            unsigned long long peers = __ballot(valid);   // match-any over the 8 digit bits
+#pragma unroll
+            for (uint32_t bit = 0; bit < 8; ++bit) {
+                const bool set = (digit >> bit) & 1u;
+                const unsigned long long m = __ballot(set);
+                peers &= set ? m : ~m;
+            }
+            const uint32_t rank = (uint32_t)__popcll(peers & lt_mask);
+            uint32_t pos = 0;
+            if (valid) pos = cnt[wv][digit] + rank;   // all peers read the running offset before the leader bumps it
+            __builtin_amdgcn_wave_barrier();
+            if (valid && rank == 0) cnt[wv][digit] += (uint32_t)__popcll(peers);
+            __builtin_amdgcn_wave_barrier();
+            if (valid) { ko[pos] = key[r]; vo[pos] = val[r]; }
+        }
+        __syncthreads();   // (workgroup-scope release/acquire: the next pass reads what other waves wrote)
+        uint32_t* tk = ki; ki = ko; ko = tk;
+        uint32_t* tv = vi; vi = vo; vo = tv;
+    }
 }
-template <class K> static bool sort_small(K*, uint32_t*, uint32_t, const uint32_t*, hipStream_t) { return false; }
-template <> bool sort_small<uint32_t>(uint32_t* keys, uint32_t* vals, uint32_t n, const uint32_t* unsorted, hipStream_t s) {
+template <class K> static bool sort_small(K*, uint32_t*, K*, uint32_t*, uint32_t, const uint32_t*, hipStream_t) { return false; }
+template <> bool sort_small<uint32_t>(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* unsorted, hipStream_t s) {
     if (n > SS_MAX) return false;
-    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys, vals, n, unsorted);
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted);   // four passes: ends in (keys_a, vals_a)
     return true;
 }
 uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes) { return key_bytes == 4 && n <= SS_MAX ? 1u : key_bytes * radix_pass_launches(n); }
@@ -741,7 +787,7 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
     // returns at once when *unsorted == 0 (the persistent interval order is still sorted: the reference's insertion sort
     // is O(n) then, ours is O(launch)).
     if (n == 0) return;
-    if (sort_small<K>(keys_a, vals_a, n, unsorted, s)) return;   // one workgroup, in place
+    if (sort_small<K>(keys_a, vals_a, keys_b, vals_b, n, unsorted, s)) return;   // one workgroup, one launch
     uint32_t nb = radix_blocks(n);
     K* ki = keys_a; uint32_t* vi = vals_a; K* ko = keys_b; uint32_t* vo = vals_b;
     for (uint32_t pass = 0; pass < sizeof(K); ++pass) {
