@@ -73,7 +73,10 @@ template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T
 // without a SolverBody points at slot 0 and is masked by the constraint's NOBODY flag.
 #define ISLAND_THREADS 256
 #define ISLAND_MAX_BODIES 512
-struct IslandBlocks { const uint32_t *body_off, *bodies, *col_off; const uint2* ent; uint32_t n_blocks; };
+#define ISLAND_LDS_VEC4 4088u   // 64 KB of f32 Vec4: 6 records per body (+ 20 per manifold when the constraint records are staged too)
+// cache_records: every block satisfies 6 max_bodies + 20 max_manifolds <= ISLAND_LDS_VEC4 (max_* = the largest block's counts; the LDS
+// layout is the same for all blocks): the kernel then stages the block's constraint records and entries in LDS as well
+struct IslandBlocks { const uint32_t *body_off, *bodies, *col_off; const uint2* ent; uint32_t n_blocks, max_bodies, max_manifolds, cache_records; };
 void launch_island_substeps(const DW<float>&, const StepParams<float>&, const IslandBlocks&, uint32_t substeps, uint32_t iterations, hipStream_t);
 // k_xpbd.hip
 template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);

@@ -182,9 +182,10 @@ template <class T> struct World : WorldBase {
     bool island_enabled = true, island_mode = false;
     size_t island_max_manifolds = 65536;  // above this the colour launches are throughput- not latency-bound (1 wave per SIMD = 65k manifolds): keep the device-wide path
     uint32_t island_pack_bodies = 256;    // islands are packed into one block up to this many bodies (a single island may reach ISLAND_MAX_BODIES)
-    std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent;
+    std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent, isl_mcount;
     DevBuf b_isl_bodies;   // [body_off | bodies | col_off | ent], 256-byte aligned parts
-    IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0};
+    IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+    bool island_cache_records = true;    // AVN_ISLAND_CACHE_RECORDS=0: bodies only in LDS (A/B runs, tests)
     bool islands_dirty = false;          // the manifold set changed since the blocks were built
     // pinned host staging (grow-only): island block arrays on their way up, narrow-phase change list on its way down
     struct Pinned {
@@ -253,6 +254,7 @@ template <class T> struct World : WorldBase {
         cfg.device = c->device;
         if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
         if (const char* e = getenv("AVN_ISLAND_BLOCKS")) island_enabled = atoi(e) != 0;                                  // 0: always the device-wide colour launches
+        if (const char* e = getenv("AVN_ISLAND_CACHE_RECORDS")) island_cache_records = atoi(e) != 0;
         if (const char* e = getenv("AVN_ISLAND_MAX_MANIFOLDS")) island_max_manifolds = (size_t)strtoull(e, nullptr, 10);
         if (const char* e = getenv("AVN_ISLAND_PACK_BODIES")) island_pack_bodies = std::min<uint32_t>(ISLAND_MAX_BODIES, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));
         // (CU masks -- 64 CUs for the broad phase, 192 for the solver -- were tried for the overlap below and lost: a colour launch
@@ -617,7 +619,15 @@ template <class T> struct World : WorldBase {
         }
         const uint32_t n_islands = (uint32_t)count.size();
         if (!n_islands) return AVN_OK;
-        // blocks = runs of consecutive islands of at most island_pack_bodies bodies (one island may exceed that, up to the LDS cap)
+        // manifolds per island (a manifold belongs to the island of its body that has a SolverBody)
+        std::vector<uint32_t>& mcount = isl_mcount;
+        mcount.assign(n_islands, 0u);
+        for (uint32_t m = 0; m < M; ++m) {
+            int32_t a = h_m_body1[m], b = h_m_body2[m];
+            if (has_sb(a)) ++mcount[island_of[(uint32_t)a]]; else if (has_sb(b)) ++mcount[island_of[(uint32_t)b]]; else ++mcount[0];
+        }
+        // blocks = runs of consecutive islands of at most island_pack_bodies bodies (one island may exceed that, up to the LDS cap);
+        // a run is also closed when its bodies + constraint records would no longer fit the LDS staging of the kernel's CACHE variant
         std::vector<uint32_t>& block_of = isl_block_of_island; std::vector<uint32_t>& body_off = isl_body_off;
         block_of.resize(n_islands);
         body_off.assign(1, 0u);
@@ -627,14 +637,19 @@ template <class T> struct World : WorldBase {
         uint32_t n_sb = 0;
         for (uint32_t k = 0; k < n_islands; ++k) n_sb += count[k];
         const uint32_t pack = std::min<uint32_t>(island_pack_bodies, std::max<uint32_t>(64u, (n_sb + 255u) / 256u));
-        uint32_t in_block = 0;
+        uint32_t in_block = 0, m_in_block = 0, max_bodies = 0, max_manifolds = 0;
+        auto close_block = [&]() { max_bodies = std::max(max_bodies, in_block); max_manifolds = std::max(max_manifolds, m_in_block); body_off.push_back(body_off.back() + in_block); in_block = 0; m_in_block = 0; };
         for (uint32_t k = 0; k < n_islands; ++k) {
-            if (in_block && in_block + count[k] > pack) { body_off.push_back(body_off.back() + in_block); in_block = 0; }
+            if (in_block && (in_block + count[k] > pack || 6u * (in_block + count[k]) + 20u * (m_in_block + mcount[k]) > ISLAND_LDS_VEC4)) close_block();
             block_of[k] = (uint32_t)body_off.size() - 1;
             cursor[k] = in_block;
             in_block += count[k];
+            m_in_block += mcount[k];
         }
-        body_off.push_back(body_off.back() + in_block);
+        close_block();
+        // the LDS layout is the same for every block (sized by the largest body and manifold counts)
+        const uint32_t lm_pad = (max_manifolds + 1u) & ~1u;   // (the entry list behind the records is uint2: keep it 16-byte aligned)
+        const bool cache_records = island_cache_records && 6u * max_bodies + 20u * lm_pad <= ISLAND_LDS_VEC4;
         const uint32_t n_blocks = (uint32_t)body_off.size() - 1;
         std::vector<uint32_t>& slot = isl_slot; std::vector<uint32_t>& bodies = isl_bodies;
         slot.assign(N, 0u);
@@ -680,7 +695,7 @@ template <class T> struct World : WorldBase {
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         HIPCHK(hipMemcpyAsync(b_isl_bodies.p, h, words * 4, hipMemcpyHostToDevice, stream));
         uint32_t* d = b_isl_bodies.as<uint32_t>();
-        islands = IslandBlocks{d, d + o1, d + o2, (const uint2*)(d + o3), n_blocks};
+        islands = IslandBlocks{d, d + o1, d + o2, (const uint2*)(d + o3), n_blocks, max_bodies, lm_pad, cache_records ? 1u : 0u};
         island_mode = true;
         return AVN_OK;
     }

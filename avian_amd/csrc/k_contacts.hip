@@ -703,8 +703,8 @@ template <class T> void launch_build_incidence_slots(const DW<T>& w, hipStream_t
 // Order: within the block the entries of a colour touch disjoint bodies (the reference's colouring invariant), colours run
 // in solve order (overflow first, serially in list order on one lane, then 0..22) -- every body sees exactly the operation
 // sequence of the device-wide path, hence of the reference: bit-identical.
-template <class T, int PASS>
-__device__ __forceinline__ void island_colours(const DW<T>& w, const StepParams<T>& p, const IslandBlocks& ib, const BodyView<T>& bv, const uint32_t* col) {
+template <class T, int PASS, bool CACHE>
+__device__ __forceinline__ void island_colours(const DW<T>& w, const StepParams<T>& p, const uint2* ent, uint32_t e0, const BodyView<T>& bv, const uint32_t* col) {
     const uint32_t t = threadIdx.x;
     for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
         const uint32_t begin = col[c], end = col[c + 1];
@@ -713,26 +713,54 @@ __device__ __forceinline__ void island_colours(const DW<T>& w, const StepParams<
         const bool serial = c == 0;
         for (uint32_t e = begin + (serial ? 0u : t); e < end; e += serial ? 1u : ISLAND_THREADS) {
             if (serial && t != 0) continue;
-            const uint2 ent = ib.ent[e];
-            const int i1 = (int)(ent.y & 0xFFFFu), i2 = (int)(ent.y >> 16);
-            if (PASS == PASS_WARM) warm_core<T, 1>(w, p, ent.x, bv, i1, i2);
-            else if (PASS == PASS_BIAS) SolveDispatch<T, true, 1>::run(w, p, ent.x, bv, i1, i2);
-            else SolveDispatch<T, false, 1>::run(w, p, ent.x, bv, i1, i2);
+            const uint2 en = ent[CACHE ? e - e0 : e];
+            const uint32_t m = CACHE ? e - e0 : en.x;   // CACHE: `w` is the block's LDS copy of the constraint records, indexed by entry
+            const int i1 = (int)(en.y & 0xFFFFu), i2 = (int)(en.y >> 16);
+            if (PASS == PASS_WARM) warm_core<T, 1>(w, p, m, bv, i1, i2);
+            else if (PASS == PASS_BIAS) SolveDispatch<T, true, 1>::run(w, p, m, bv, i1, i2);
+            else SolveDispatch<T, false, 1>::run(w, p, m, bv, i1, i2);
         }
         __syncthreads();
     }
 }
-template <class T>
+// CACHE = true: the block's constraint records (19 Vec4 per manifold) and its entry list are staged in LDS next to the bodies
+// (host: every block fits ISLAND_LDS_VEC4), so a colour pass touches no global memory at all -- on a block whose colours hold
+// ~17 manifolds the two dependent L2 round trips (entry -> records) were ~45 % of a 3.3 us pass.  The accumulated impulses go
+// back to HBM once, after the last substep.  CACHE = false: bodies only (any block up to ISLAND_MAX_BODIES bodies).
+template <class T, bool CACHE>
 __global__ __launch_bounds__(ISLAND_THREADS) void k_island_substeps(DW<T> w, StepParams<T> p, IslandBlocks ib, uint32_t substeps, uint32_t iterations) {
-    __shared__ Vec4<T> l_lin[ISLAND_MAX_BODIES], l_ang[ISLAND_MAX_BODIES], l_dp[ISLAND_MAX_BODIES], l_dq[ISLAND_MAX_BODIES], l_sia[ISLAND_MAX_BODIES],
-        l_sib[ISLAND_MAX_BODIES];
+    __shared__ Vec4<T> lds[ISLAND_LDS_VEC4];
     __shared__ uint32_t l_col[AVN_GRAPH_COLOR_COUNT + 1];
     const uint32_t t = threadIdx.x, blk = blockIdx.x;
     const uint32_t b0 = ib.body_off[blk], nb = ib.body_off[blk + 1] - b0;
+    const uint32_t nbmax = CACHE ? ib.max_bodies : ISLAND_MAX_BODIES, LM = ib.max_manifolds;
+    Vec4<T>* const l_lin = lds, *const l_ang = lds + nbmax, *const l_dp = lds + 2 * nbmax, *const l_dq = lds + 3 * nbmax, *const l_sia = lds + 4 * nbmax,
+                   *const l_sib = lds + 5 * nbmax;
+    Vec4<T>* const R = lds + 6 * nbmax;   // CACHE: h1[LM] n[LM] tv[LM] pa[4 LM] pb[4 LM] pc[4 LM] pd[4 LM] ent[LM / 2]
     if (t <= AVN_GRAPH_COLOR_COUNT) l_col[t] = ib.col_off[(size_t)blk * AVN_GRAPH_COLOR_COUNT + t];
     for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {
         const uint32_t g = ib.bodies[b0 + l];
         l_lin[l] = w.sb_lin[g]; l_ang[l] = w.sb_ang[g]; l_dp[l] = w.sb_dp[g]; l_dq[l] = w.sb_dq[g]; l_sia[l] = w.si_a[g]; l_sib[l] = w.si_b[g];
+    }
+    const uint32_t e0 = ib.col_off[(size_t)blk * AVN_GRAPH_COLOR_COUNT], e1 = ib.col_off[(size_t)(blk + 1) * AVN_GRAPH_COLOR_COUNT];
+    DW<T> wl = w;
+    const uint2* ent = ib.ent;
+    if (CACHE) {
+        wl.c_h1 = R; wl.m_n = R + LM; wl.m_tv = R + 2 * LM; wl.c_pa = R + 3 * LM; wl.c_pb = R + 7 * LM; wl.c_pc = R + 11 * LM; wl.c_pd = R + 15 * LM;
+        wl.m_stride = LM;
+        uint2* l_ent = reinterpret_cast<uint2*>(R + 19 * LM);
+        ent = l_ent;
+        for (uint32_t e = e0 + t; e < e1; e += ISLAND_THREADS) {
+            const uint2 en = ib.ent[e];
+            const uint32_t m = en.x, lm = e - e0;
+            l_ent[lm] = en;
+            wl.c_h1[lm] = w.c_h1[m]; wl.m_n[lm] = w.m_n[m]; wl.m_tv[lm] = w.m_tv[m];
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                const size_t s = (size_t)k * w.m_stride + m; const uint32_t d = k * LM + lm;
+                wl.c_pa[d] = w.c_pa[s]; wl.c_pb[d] = w.c_pb[s]; wl.c_pc[d] = w.c_pc[s]; wl.c_pd[d] = w.c_pd[s];
+            }
+        }
     }
     __syncthreads();
     const BodyView<T> bv{l_lin, l_ang, l_dp, l_dq, l_sia, l_sib};
@@ -744,8 +772,8 @@ __global__ __launch_bounds__(ISLAND_THREADS) void k_island_substeps(DW<T> w, Ste
             if (integrate_velocities_one<T>(w, p, g, w.sb_flags[g], v, om, &l_dq[l])) { l_lin[l] = make4<T>(v, l4.w); l_ang[l] = make4<T>(om, a4.w); }
         }
         __syncthreads();
-        island_colours<T, PASS_WARM>(w, p, ib, bv, l_col);
-        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_BIAS>(w, p, ib, bv, l_col);
+        island_colours<T, PASS_WARM, CACHE>(wl, p, ent, e0, bv, l_col);
+        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_BIAS, CACHE>(wl, p, ent, e0, bv, l_col);
         for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {   // integrate_positions + update_solver_body_angular_inertia
             const uint32_t g = ib.bodies[b0 + l];
             Vec4<T> dp4 = l_dp[l], dq4 = l_dq[l], sa = l_sia[l], sb = l_sib[l];
@@ -753,16 +781,24 @@ __global__ __launch_bounds__(ISLAND_THREADS) void k_island_substeps(DW<T> w, Ste
             l_dp[l] = dp4; l_dq[l] = dq4; l_sia[l] = sa; l_sib[l] = sb;
         }
         __syncthreads();
-        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_RELAX>(w, p, ib, bv, l_col);
+        for (uint32_t it = 0; it < iterations; ++it) island_colours<T, PASS_RELAX, CACHE>(wl, p, ent, e0, bv, l_col);
     }
     for (uint32_t l = t; l < nb; l += ISLAND_THREADS) {
         const uint32_t g = ib.bodies[b0 + l];
         w.sb_lin[g] = l_lin[l]; w.sb_ang[g] = l_ang[l]; w.sb_dp[g] = l_dp[l]; w.sb_dq[g] = l_dq[l]; w.si_a[g] = l_sia[l]; w.si_b[g] = l_sib[l];
     }
+    if (CACHE) {   // the accumulated impulses (the only constraint records the passes write)
+        for (uint32_t e = e0 + t; e < e1; e += ISLAND_THREADS) {
+            const uint32_t lm = e - e0, m = ent[lm].x;
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) w.c_pd[(size_t)k * w.m_stride + m] = wl.c_pd[k * LM + lm];
+        }
+    }
 }
 void launch_island_substeps(const DW<float>& w, const StepParams<float>& p, const IslandBlocks& ib, uint32_t substeps, uint32_t iterations, hipStream_t s) {
     if (!ib.n_blocks) return;
-    hipLaunchKernelGGL(k_island_substeps<float>, dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
+    if (ib.cache_records) hipLaunchKernelGGL((k_island_substeps<float, true>), dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
+    else hipLaunchKernelGGL((k_island_substeps<float, false>), dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
 }
 template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
     if (!w.n_bodies) return;
