@@ -73,3 +73,26 @@ def test_host_constraint_graph_matches_oracle_graph_cpu():
     oo, ho = go.lists(); oh, hh = gh.lists()
     assert np.array_equal(oo, oh) and np.array_equal(ho, hh)
     assert oo[24] - oo[23] >= 0
+
+
+def test_every_ctypes_struct_has_the_size_the_c_compiler_gives_the_header_struct(tmp_path):
+    """The binding mirrors the header by hand: compile the header with gcc (as C) and compare sizeof() of every avn_* struct
+    the binding declares.  Catches a field added on one side only (e.g. avn_timers.island_blocks)."""
+    import ctypes
+    import inspect
+    import subprocess
+    names = sorted(n for n, c in inspect.getmembers(F, inspect.isclass) if issubclass(c, ctypes.Structure) and n.startswith("avn_"))
+    assert len(names) >= 15
+    header = os.path.join(REPO, "include", "avian_mi355x.h")
+    declared = open(header).read()
+    names = [n for n in names if f"}} {n};" in declared or f"struct {n} " in declared]
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "avian_mi355x.h"\nint main(void) {\n' +
+                   "".join(f'  printf("{n} %zu\\n", sizeof({n}));\n' for n in names) + "  return 0;\n}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout
+    got = dict(line.split() for line in out.strip().splitlines())
+    assert len(got) >= 15
+    for n in names:
+        assert int(got[n]) == ctypes.sizeof(getattr(F, n)), f"{n}: header {got[n]} B, binding {ctypes.sizeof(getattr(F, n))} B"
