@@ -592,7 +592,12 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepPar
     // static between uploads.  arg_end == 0: read the live range from device memory (handle mode: colours drift every step).
     uint32_t base = arg_base, end = arg_end;
     if (arg_end == 0u) { base = w.color_offsets[color]; end = w.color_offsets[color + 1]; }
-    uint32_t blk = xcd_block(blockIdx.x, gridDim.x);
+    // block b runs on XCD b % 8; each XCD walks one contiguous eighth of the colour.  The eighths are cut from the colour's REAL
+    // tile count, not from the launched grid: grids carry up to 25 % slack (colours drift between re-captures), and an eighth of
+    // the padded grid would leave the last XCDs with the empty tail while the first ones carry 110 tiles instead of 88.
+    const uint32_t tiles = (end - base + CONTACT_THREADS - 1u) / CONTACT_THREADS, per = (tiles + 7u) >> 3, row = blockIdx.x >> 3;
+    if (row >= per) return;
+    const uint32_t blk = (blockIdx.x & 7u) * per + row;
     uint32_t m = base + blk * CONTACT_THREADS + threadIdx.x;
     if (m >= end) return;
     pass_one<T, PASS>(w, p, m);
