@@ -1512,8 +1512,6 @@ template <class T> struct World : WorldBase {
         }
         pipe_stats.last_overflow_manifolds = pipe_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - pipe_offsets[AVN_COLOR_OVERFLOW_INDEX];
         pipe_stats.last_host_ms = host_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        uint32_t before = launches;
-        (void)before;
         if ((st = solver()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
