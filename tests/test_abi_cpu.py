@@ -96,3 +96,28 @@ def test_every_ctypes_struct_has_the_size_the_c_compiler_gives_the_header_struct
     assert len(got) >= 15
     for n in names:
         assert int(got[n]) == ctypes.sizeof(getattr(F, n)), f"{n}: header {got[n]} B, binding {ctypes.sizeof(getattr(F, n))} B"
+
+
+def test_generated_rust_bindings_are_current_and_complete():
+    """integration/rust/avian_mi355x-sys/src/lib.rs (what a maintainer's Rust shim links against) is generated from the header:
+    it must be up to date, declare every exported symbol, and give every struct exactly the fields of the ctypes mirror, in order."""
+    import ctypes
+    import inspect
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "gen_rust_bindings.py"), "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rs = open(os.path.join(REPO, "integration", "rust", "avian_mi355x-sys", "src", "lib.rs")).read()
+    for sym in declared_symbols():
+        assert re.search(rf"pub fn avn_{sym}\(", rs), f"avn_{sym} missing from the Rust declarations"
+    assert len(re.findall(r"pub fn avn_", rs)) == len(declared_symbols())
+    structs = {n: c for n, c in inspect.getmembers(F, inspect.isclass) if issubclass(c, ctypes.Structure) and n.startswith("avn_")}
+    checked = 0
+    for n, c in structs.items():
+        m = re.search(rf"pub struct {n} \{{(.*?)\n\}}", rs, flags=re.S)
+        if not m:
+            continue
+        rust_fields = re.findall(r"pub (\w+):", m.group(1))
+        assert rust_fields == [f[0] for f in c._fields_], f"{n}: Rust fields {rust_fields} != binding fields {[f[0] for f in c._fields_]}"
+        checked += 1
+    assert checked >= 15
