@@ -9,7 +9,8 @@
 // PARITY PINNING: the reference cannot be built here (no cargo/rustc; bevy/glam/parry not
 // vendored), so this restatement is pinned only by the reference's own known-answer tests that
 // touch the path (integrator/mod.rs:561-629 `semi_implicit_euler`, tests/mod.rs:93-142
-// `body_with_velocity_moves`, forces/tests.rs:53-96,249-292,552-601) — transcribed in
+// `body_with_velocity_moves`, forces/tests.rs:53-96,249-292,552-601, solver_body/plugin.rs:318-353 `add_remove_solver_bodies`,
+// physics_material.rs:398-446 `coefficient_combine_works`) — transcribed in
 // tests/golden/reference_kats.json and checked by tests/test_oracle_golden.py.  For contacts, colouring,
 // broad phase pair lists and XPBD joints the reference holds NO golden vectors: "parity unpinned" there;
 // the restatement is reviewed line by line against the cited source instead.

@@ -156,3 +156,60 @@ def check_vectors(got: dict, bits: int):
         same = (a == b) | ((a != a) & (b != b)) if a.dtype.kind == "f" else (a == b)
         assert same.all(), f"{k}: {int((~same).sum())} of {same.size} values differ from the committed golden vector (bit-exact bar)"
     return len(keys)
+
+
+# ---- two more known-answer tests of the reference that touch the path (beyond the stepping KATs in reference_kats.json) ----
+
+def check_coefficient_combine(lib, bits=32):
+    """src/dynamics/rigid_body/physics_material.rs:398-446 `coefficient_combine_works`: Restitution(0.3, Average) combined with
+    Restitution(0.7, rule) for every CoefficientCombine rule -- the rule of the pair is the LARGER of the two (:205-214, :372-380), the
+    expected coefficients are the reference test's (epsilon 1e-4 where it uses assert_relative_eq!, exact for Min / Max).
+    Here the combination happens where the reference does it on the path: in NarrowPhase::update_contacts, for the friction and the
+    restitution of a touching pair (system_param.rs:596-640).  Two overlapping unit cuboids, one contact pair, one narrow-phase run."""
+    expected = {F.COMBINE_AVERAGE: (0.5, 1e-4), F.COMBINE_GEOMETRIC_MEAN: (0.458_257_56, 1e-4), F.COMBINE_MIN: (0.3, 1e-6),
+                F.COMBINE_MULTIPLY: (0.21, 1e-4), F.COMBINE_MAX: (0.7, 1e-6)}
+    for rule, (want, eps) in expected.items():
+        w = F.World(lib, F.default_config(bits, substeps=1))
+        n = 2
+        rot = np.zeros((n, 4)); rot[:, 3] = 1.0
+        w.bodies_upload(position=np.array([[0.0, 0.0, 0.0], [0.0, 0.9, 0.0]]), rotation=rot, linear_velocity=np.zeros((n, 3)),
+                        angular_velocity=np.zeros((n, 3)), inv_mass=np.ones(n), inv_inertia_local=np.tile([6.0, 0, 0, 6.0, 0, 6.0], (n, 1)),
+                        rb_type=np.zeros(n, np.uint8))
+        w.colliders_upload(entity_index=np.array([10, 11], np.uint32), body=np.array([0, 1], np.int32), shape=np.zeros(n, np.uint8),
+                           half_extents=np.full((n, 3), 0.5))
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        both = np.array([F.COMBINE_AVERAGE, rule], np.uint8)
+        w.collider_materials_upload(friction=np.array([0.3, 0.7]), restitution=np.array([0.3, 0.7]), friction_combine=both, restitution_combine=both)
+        w.run_system("UPDATE_AABB")
+        w.contact_pairs_add(np.array([0], np.uint32), np.array([10], np.uint32), np.array([11], np.uint32),
+                            np.array([F.PAIR_GENERATE_CONSTRAINTS], np.uint32))
+        w.active_pairs_set(np.array([0], np.uint32))
+        w.run_system("NARROW_PHASE")
+        row = w.contacts_download(np.array([0], np.uint32))
+        assert row["flags"][0] & F.CP_TOUCHING and row["point_count"][0] > 0, "the cuboids overlap by 0.1: the pair must touch"
+        for field in ("restitution", "friction"):
+            got = float(row[field][0])
+            assert abs(got - want) <= eps, f"combine rule {rule}: {field} {got} != {want} (reference test value)"
+        w.close()
+
+
+def check_solver_body_membership(lib, bits=32):
+    """src/dynamics/solver/solver_body/plugin.rs:318-353 `add_remove_solver_bodies`: dynamic and kinematic bodies have a SolverBody,
+    static ones do not; RigidBodyDisabled removes it, removing the marker brings it back; so does Sleeping (:38-96)."""
+    n = 4
+    rot = np.zeros((n, 4)); rot[:, 3] = 1.0
+    base = dict(position=np.zeros((n, 3)), rotation=rot, linear_velocity=np.zeros((n, 3)), angular_velocity=np.zeros((n, 3)), inv_mass=np.ones(n),
+                inv_inertia_local=np.tile([1.0, 0, 0, 1.0, 0, 1.0], (n, 1)),
+                rb_type=np.array([F.RB_DYNAMIC, F.RB_KINEMATIC, F.RB_STATIC, F.RB_DYNAMIC], np.uint8))
+
+    def membership(flags):
+        w = F.World(lib, F.default_config(bits, substeps=1))
+        w.bodies_upload(**base, body_flags=np.asarray(flags, np.uint8))
+        w.run_system("PREPARE_SOLVER_BODIES")
+        has = (w.solver_bodies_download()["flags"] >> 31) == 0
+        w.close()
+        return has.tolist()
+    assert membership([0, 0, 0, 0]) == [True, True, False, True]
+    assert membership([F.BODY_DISABLED, 0, 0, 0]) == [False, True, False, True]          # insert(RigidBodyDisabled)
+    assert membership([0, 0, 0, 0]) == [True, True, False, True]                           # remove::<RigidBodyDisabled>()
+    assert membership([0, F.BODY_SLEEPING, 0, F.BODY_DISABLED]) == [True, False, False, False]

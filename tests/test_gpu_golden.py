@@ -31,3 +31,10 @@ def test_hip_is_deterministic_run_to_run():
     for r in runs[1:]:
         for k in runs[0]:
             assert np.array_equal(runs[0][k], r[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_hip_meets_reference_coefficient_combine_and_solver_body_kats(bits):
+    """physics_material.rs:398-446 and solver_body/plugin.rs:318-353 (see golden_checks)."""
+    G.check_coefficient_combine(hip_lib(), bits)
+    G.check_solver_body_membership(hip_lib(), bits)

@@ -28,3 +28,9 @@ def test_oracle_is_deterministic_run_to_run():
     for r in runs[1:]:
         for k in runs[0]:
             assert np.array_equal(runs[0][k], r[k], equal_nan=True), k
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_oracle_meets_reference_coefficient_combine_and_solver_body_kats(bits):
+    G.check_coefficient_combine(oracle_lib(), bits)
+    G.check_solver_body_membership(oracle_lib(), bits)
