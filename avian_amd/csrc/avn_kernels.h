@@ -27,6 +27,7 @@ template <class T> struct BP {
     uint32_t pair_set_cap; // power of two, 0 = no set
     uint64_t* disabled_set;  // body pairs whose joints disable collision
     uint32_t disabled_cap;
+    Vec4<T>* s_bb;         // per group of 8 consecutive sorted records: (min of min.y, max of max.y, min of min.z, max of max.z) -- the sweep's batch cull
 };
 #define AVN_IV_DROPPED 0x80000000u
 #define AVN_IV_LONG 0x40000000u   // > SW_CAP sweep candidates: swept by k_sweep_long in chunks

@@ -132,7 +132,7 @@ template <class T> struct World : WorldBase {
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_b1, b_j_b2, b_j_ax, b_j_l2, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_s0, b_j_s1, b_j_s2, b_j_s3, b_j_rl0, b_j_rl1, b_j_force,
         b_j_torque;
-    DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_end, b_s_info, b_s_flags;
+    DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_bb, b_s_end, b_s_info, b_s_flags;
     DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
     DevBuf b_inc_off, b_inc_ent, b_inc_slot;
     bool overflow_csr_nonzero = true;  // the device CSR offsets may be non-zero (first build uploads them)
@@ -991,7 +991,7 @@ template <class T> struct World : WorldBase {
             size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
             GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
             GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
-            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_end, cc, bp.s_end);
+            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_bb, cc / 8 + 2, bp.s_bb); GROW(b_s_end, cc, bp.s_end);
             GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
             Key* dummy_k; uint32_t* dummy_u;
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
@@ -1555,7 +1555,7 @@ template <class T> struct World : WorldBase {
         launch_sweep_ranges<T>(bp, n, sweep_scratch, bs);
         launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, bs);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, bs);
-        launches += 3 + radix_sort_launches(n, (uint32_t)sizeof(Key)) + 3 + exclusive_scan_launches(n * sweep_count_slots());
+        launches += 3 + radix_sort_launches(n, (uint32_t)sizeof(Key)) + 4 + exclusive_scan_launches(n * sweep_count_slots());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
         HIPCHK(hipEventRecord(ev_counters, bs));

@@ -459,6 +459,29 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
     return pr;
 }
 
+// Batch cull of the sweep: the y/z bounds of every group of 8 consecutive sorted records.  A wave tests its 64 boxes against a
+// group's bounds before it loads the group's records; on a lattice consecutive records share a y row, so most groups of the
+// ~6 000 x-overlapping candidates of an interval are rejected with 4 compares instead of 32.  Conservative by construction
+// (a record that overlaps a lane overlaps the union of its group; a NaN anywhere in a group disables the cull for it, because the
+// reference's negated compares let NaN boxes through): the emitted pairs and their order do not change.
+template <class T>
+__global__ __launch_bounds__(256) void k_batch_bounds(const Vec4<T>* __restrict__ s_yz, uint32_t n, Vec4<T>* __restrict__ s_bb) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g * 8u >= n) return;
+    const T inf = Limits<T>::max * T(2);
+    T lo_y = inf, hi_y = -inf, lo_z = inf, hi_z = -inf;
+    bool nan = false;
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t idx = g * 8u + k;
+        if (idx >= n) break;
+        const Vec4<T> r = s_yz[idx];
+        nan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
+        lo_y = r.x < lo_y ? r.x : lo_y; hi_y = r.y > hi_y ? r.y : hi_y;
+        lo_z = r.z < lo_z ? r.z : lo_z; hi_z = r.w > hi_z ? r.w : hi_z;
+    }
+    s_bb[g] = nan ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
+}
+
 // end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems.
 // "Long" is absolute (more than SW_CAP candidates) or RELATIVE: a wave of k_sweep walks the union of its 64 lanes' candidate
 // ranges, so one interval that reaches much further than its 63 neighbours (a ground plate among boxes: 5 500 candidates
@@ -505,7 +528,7 @@ __global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __res
 }
 
 template <class T, bool EMIT>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const uint32_t* __restrict__ s_end,
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const Vec4<T>* __restrict__ s_bb, const uint32_t* __restrict__ s_end,
                                                        const uint4* __restrict__ s_info, const uint32_t* __restrict__ s_flags, PairSets hs,
                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
     __shared__ uint32_t l_q[SW_WAVES][SW_Q];
@@ -581,12 +604,16 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     };
 
     constexpr uint32_t SW_BATCH = sizeof(T) == 4 ? 8u : 4u;  // candidates per scalar-load batch (SGPR budget)
-    // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je)
-    uint32_t qlen = (je - (i0 + 1u) + SW_WAVES - 1u) / SW_WAVES;
+    // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je), cut at batch-aligned positions so that every
+    // batch lies inside one group of k_batch_bounds (the few records before i0 + 1 this adds fail every lane's `jj > i` test)
+    const uint32_t j_first = (i0 + 1u) & ~(SW_BATCH - 1u);
+    uint32_t qlen = (je - j_first + SW_WAVES - 1u) / SW_WAVES;
     qlen = (qlen + SW_BATCH - 1u) / SW_BATCH * SW_BATCH;
-    const uint32_t jb = i0 + 1u + wv * qlen;
+    const uint32_t jb = j_first + wv * qlen;
     const uint32_t jq = min(je, jb + qlen);
     for (uint32_t j = jb; j < jq; j += SW_BATCH) {
+        const Vec4<T> bb = s_bb[j >> 3];   // wave-uniform: one scalar load
+        if (!(lane_mask_ule(me.x, bb.y) & lane_mask_uge(me.y, bb.x) & lane_mask_ule(me.z, bb.w) & lane_mask_uge(me.w, bb.z))) continue;
         Vec4<T> c[SW_BATCH];
 #pragma unroll
         for (uint32_t k = 0; k < SW_BATCH; ++k) c[k] = s_yz[j + k];  // wave-uniform, contiguous: wide scalar loads (s_yz is padded by sweep_pad_records())
@@ -810,6 +837,7 @@ template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, co
 template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s) {
     if (!n) return;
     (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
+    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / 8u + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb);
     hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
                        sc.n_long, sc.long_cap, sc.n_long + 1);
 }
@@ -821,11 +849,11 @@ template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, con
     LongItem* li = (LongItem*)sc.long_items;
     PairSets hs{bp.pair_set, bp.pair_set_cap, bp.disabled_set, bp.disabled_cap};
     if (emit) {
-        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
         hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
     } else {
-        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
         hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
         hipLaunchKernelGGL(k_long_finish, dim3(64), dim3(256), 0, s, li, sc.n_long, sc.long_counts, sc.long_off, counts);
