@@ -157,3 +157,17 @@ def test_slab_sharded_broad_phase_gloo_world_size_2_over_frames(tmp_path):
     for s in range(3):
         assert np.array_equal(got[f"pairs_s{s}"], ref[s]), f"frame {s}"
     assert len(ref[0]) > 500 and len(ref[1]) > 0 and len(ref[2]) > 0
+
+
+def test_slab_sharded_broad_phase_f64_world():
+    """Same property in the f64 build of the path (Scalar = f64: 64-bit sort keys, 4-candidate sweep batches)."""
+    lib = oracle_lib()
+    sc = scenes.sparse_mixed(2500, side=18.0)
+    w = F.World(lib, F.default_config(64, substeps=1))
+    w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs()); w.existing_pairs_upload(np.zeros(0, np.uint64))
+    w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+    p = w.pairs_get(); mn, mx, _ = w.aabbs_download()
+    ref = np.stack([p["collider1"], p["collider2"], p["flags"]], axis=1).astype(np.uint32)
+    assert mn.dtype == np.float64 and len(ref) > 1000
+    parts = [shard.slab_broad_phase_step(lib, 64, sc.body_kwargs(), sc.collider_kwargs(), mn[:, 0], mx[:, 0], np.zeros(0, np.uint64), r, 3) for r in range(3)]
+    assert np.array_equal(np.concatenate(parts), ref)
