@@ -538,8 +538,10 @@ class World:
         return out
 
     # -- standalone closed loop (the library keeps IdPool / ContactGraph bookkeeping / ConstraintGraph itself) ------------
-    def pipeline_enable(self, on: bool = True):
-        self._check(self.lib.fn("pipeline_enable")(self.handle, int(on)))
+    def pipeline_enable(self, on: bool = True, host_bookkeeping: bool = False):
+        """avn_pipeline_enable: 1 = the closed loop with the ContactGraph / ConstraintGraph bookkeeping on the device (k_graph.hip),
+        2 = the same loop with the host-side structures (kept for A/B runs), 0 = off."""
+        self._check(self.lib.fn("pipeline_enable")(self.handle, (2 if host_bookkeeping else 1) if on else 0))
 
     def pipeline_stats(self) -> avn_pipeline_stats:
         st = avn_pipeline_stats()

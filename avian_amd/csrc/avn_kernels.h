@@ -126,6 +126,10 @@ template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* 
 // NarrowPhase::update_contacts over the active pairs; changes[0..*n_changes) in arbitrary order (the host sorts by id)
 template <class T> void launch_narrow_phase(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t);
+// dense form (device closed loop): every row id < n_rows with AVN_CP_ROW_USED is a pair; the row's status change goes to chg[id] / has[id]
+// (id order = the order NarrowPhase::update walks the status bits) and rows that must be removed are counted in *n_remove
+template <class T> void launch_narrow_phase_dense(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t n_rows, uint32_t* chg, uint32_t* has,
+                                                  uint32_t* n_remove, hipStream_t);
 // manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
 template <class T> void launch_gather_manifolds(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
 // store_contact_impulses' write into the ContactGraph (plugin.rs:744-749): table row <- DW::mp_w
@@ -137,6 +141,69 @@ template <class T> struct ContactsStage {
 };
 template <class T> void launch_unpack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);
 void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
+
+// ---- k_graph.hip: the closed loop's integer bookkeeping ON THE DEVICE -------------------------------------------------------
+// ContactGraph edge list + IdPool (data_structures/id_pool.rs:31-40), the status-change loop of NarrowPhase::update
+// (collision/narrow_phase/system_param.rs:141-389) and the ConstraintGraph (solver/constraint_graph.rs:163-296), all in HBM, so
+// that a step of the closed loop moves only a few counters over the bus.
+#define PG_NONE 0xFFFFFFFFu
+#define AVN_CP_ROW_USED 0x40000000u   // internal row flag (never reported through the ABI): the ContactId is live
+// counters block (uint32 words of PG::ctr)
+enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
+       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
+       PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
+       PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
+struct PG {
+    uint32_t rows;          // capacity of the per-row arrays (= CT::cap)
+    int2* bodies;           // [rows] ContactPair::body1 / body2
+    uint32_t* color;        // [rows] colour of the row's constraint handle (0..23) | PG_NONE
+    uint32_t* lpos;         // [rows] ContactConstraintHandle::local_index
+    uint32_t* lists;        // [24][list_stride] GraphColor::manifold_handles (contact ids; manifold index 0: convex pairs)
+    uint32_t list_stride;
+    uint32_t* bcol;         // [n_bodies] bit c set = the body is in GraphColor c's body_set
+    uint32_t* free_ids;     // IdPool: free ids ascending, live part [ctr[FREE_HEAD], +ctr[N_FREE])
+    uint32_t* free_alt;     // merge target (ping-pong)
+    uint32_t* ctr;          // counters block
+    const uint32_t* ent2slot;  // collider Entity::index() -> slot
+    // per-step scratch
+    uint32_t* chg;          // [rows] packed status change of the row (0 = none): flags | n_manifolds << 16 | (dcount + 128) << 24
+    uint32_t* has;          // [rows] 0 | 1
+    uint32_t* off;          // [rows] exclusive scan of has = op index
+    uint32_t* op_cid;       // [ops]
+    uint32_t* op_info;      // [ops] kind (0 none, 1 push, 2 pop) | static1 << 2 | static2 << 3 | remove << 4 | colour << 8
+    int2* op_bodies;        // [ops]
+    uint32_t* ekey_a, *eval_a, *ekey_b, *eval_b;   // [2 ops] (body | n_bodies = none, 2 op + side): sorted by body, stable
+    uint32_t* epos;         // [2 ops] sorted position of entry 2 op + side
+    uint32_t* popbefore;    // [2 ops] colours freed on the entry's body by this step's earlier pops
+    uint32_t* prevpush;     // [2 ops] 1 + sorted position of the previous push entry of the same body | 0
+    uint32_t* est;          // [2 ops] dataflow state of a push entry: colours taken on the body by this step's pushes so far | DONE
+    uint32_t* tile_agg;     // [5 tiles] segmented-scan tile aggregates
+    uint32_t* ckey_a, *cval_a, *ckey_b, *cval_b;   // [ops] (colour, op): bucketed by colour, stable
+    uint32_t* rem_flag, *rem_off, *rem_ids;        // [ops]
+};
+#define PG_EST_DONE 0x80000000u
+template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, hipStream_t);
+void launch_pg_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, hipStream_t);
+uint32_t pg_scan_tiles(uint32_t n_entries);
+void launch_pg_entry_scan(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
+void launch_pg_color(const PG&, uint32_t n_ops, hipStream_t);
+void launch_pg_apply_masks(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
+void launch_pg_bucket_keys(const PG&, uint32_t n_ops, hipStream_t);
+void launch_pg_replay(const PG&, const uint32_t* order, hipStream_t);
+template <class T> void launch_pg_remove(const PG&, const CT<T>&, const BP<T>&, uint32_t n_ops, hipStream_t);
+void launch_pg_merge_free(const PG&, uint32_t head, uint32_t n_free, uint32_t n_rem, hipStream_t);
+void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t);
+template <class T> void launch_pg_rebuild_pair_set(const CT<T>&, const BP<T>&, uint32_t n_rows, hipStream_t);
+// overflow colour on the device: incidence CSR of the body-centric warm start + per-body ranks of the dataflow passes
+struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; };
+template <class T> void launch_ovf_entries(const DW<T>&, uint32_t o0, uint32_t n23, uint32_t* keys, uint32_t* vals, hipStream_t);
+template <class T> void launch_ovf_csr(const DW<T>&, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t);
+void overflow_flow_experiment_mode();
+void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles, uint32_t n_tiles, hipStream_t);
+template <class T> void launch_overflow_flow(const DW<T>&, const StepParams<T>&, int pass, const OverflowFlow&, uint32_t epoch, uint32_t grid_blocks, hipStream_t);
+// radix sort on the low `bits` bits of the keys (stable LSD, 8 bits per pass); the result is in (*keys_out, *vals_out)
+void launch_radix_sort_bits(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t bits, uint32_t* hist, uint32_t* block_sums,
+                            uint32_t** keys_out, uint32_t** vals_out, hipStream_t);
 // k_narrow.hip: device staging copies of avn_shape_pairs / avn_query_manifolds_out (host layout, nullptr = not wanted)
 template <class T> struct QueryStage {
     const uint8_t *shape1, *shape2;

@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -162,7 +163,34 @@ template <class T> struct World : WorldBase {
     PipeColor pipe_colors[AVN_GRAPH_COLOR_COUNT];
     std::vector<uint32_t> pipe_handles;        // colour-major contact ids (GraphColor::manifold_handles)
     uint32_t pipe_offsets[AVN_GRAPH_COLOR_COUNT + 1];
+    // pinned host staging (grow-only): island block arrays on their way up, narrow-phase change list on its way down
+    struct Pinned {
+        void* p = nullptr; size_t cap = 0;
+        ~Pinned() { if (p) (void)hipHostFree(p); }
+        hipError_t ensure(size_t bytes) {
+            if (bytes <= cap) return hipSuccess;
+            if (p) (void)hipHostFree(p);
+            p = nullptr; cap = 0;
+            size_t c = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
+            hipError_t e = hipHostMalloc(&p, c, hipHostMallocDefault);
+            if (e == hipSuccess) cap = c;
+            return e;
+        }
+    };
     avn_pipeline_stats pipe_stats;
+    // ---- the same closed loop with the bookkeeping ON THE DEVICE (k_graph.hip): the host keeps exact mirrors of a few counters ----
+    bool pipe_dev = false;               // avn_pipeline_enable(1): device bookkeeping (AVN_PIPELINE_HOST=1 or enable(2): the host structures above)
+    PG pg;
+    DevBuf b_pg_bodies, b_pg_color, b_pg_lpos, b_pg_lists, b_pg_bcol, b_pg_free_a, b_pg_free_b, b_pg_ctr, b_pg_ent2slot;
+    DevBuf b_pg_chg, b_pg_has, b_pg_off, b_pg_op_cid, b_pg_op_info, b_pg_op_bodies, b_pg_ekey_a, b_pg_eval_a, b_pg_ekey_b, b_pg_eval_b, b_pg_epos, b_pg_popbefore, b_pg_prevpush,
+        b_pg_est, b_pg_tile_agg, b_pg_ckey_a, b_pg_cval_a, b_pg_ckey_b, b_pg_cval_b, b_pg_rem_flag, b_pg_rem_off, b_pg_rem_ids, b_pg_hist, b_pg_sums;
+    DevBuf b_ovf_keys_a, b_ovf_vals_a, b_ovf_keys_b, b_ovf_vals_b, b_ovf_rank, b_ovf_ticket;
+    uint32_t pg_rows = 0, pg_ops_cap = 0, pg_ovf_cap = 0;
+    uint32_t pgm_head = 0, pgm_n_free = 0, pgm_next_id = 0, pgm_live = 0, pgm_tomb = 0;   // exact host mirrors of the device counters
+    uint32_t pgm_len[AVN_GRAPH_COLOR_COUNT] = {0};
+    uint32_t ovf_epoch = 0, ovf_epoch_after_substeps = 0;
+    uint64_t pg_dump_step = 0;
+    Pinned pin_ctr;
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
@@ -187,20 +215,6 @@ template <class T> struct World : WorldBase {
     IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     bool island_cache_records = true;    // AVN_ISLAND_CACHE_RECORDS=0: bodies only in LDS (A/B runs, tests)
     bool islands_dirty = false;          // the manifold set changed since the blocks were built
-    // pinned host staging (grow-only): island block arrays on their way up, narrow-phase change list on its way down
-    struct Pinned {
-        void* p = nullptr; size_t cap = 0;
-        ~Pinned() { if (p) (void)hipHostFree(p); }
-        hipError_t ensure(size_t bytes) {
-            if (bytes <= cap) return hipSuccess;
-            if (p) (void)hipHostFree(p);
-            p = nullptr; cap = 0;
-            size_t c = (bytes + bytes / 2 + 4095) & ~(size_t)4095;
-            hipError_t e = hipHostMalloc(&p, c, hipHostMallocDefault);
-            if (e == hipSuccess) cap = c;
-            return e;
-        }
-    };
     Pinned pin_islands, pin_changes;
     static constexpr uint32_t CHANGES_PREFIX = 2048;   // status changes fetched together with their count (one round trip)
     bool any_damped = false;
@@ -220,6 +234,7 @@ template <class T> struct World : WorldBase {
         std::memset(&dw, 0, sizeof dw);
         std::memset(&bp, 0, sizeof bp);
         std::memset(&ct, 0, sizeof ct);
+        std::memset(&pg, 0, sizeof pg);
         std::memset(&pipe_stats, 0, sizeof pipe_stats);
         std::memset(pipe_offsets, 0, sizeof pipe_offsets);
         std::memset(&last_timers, 0, sizeof last_timers);
@@ -518,8 +533,10 @@ template <class T> struct World : WorldBase {
     // (launch_build_incidence_slots, run after the manifolds are in place).  Host part: only the overflow colour -- its
     // per-body entry lists (CSR, list order) and its level schedule.
     bool slots_dirty = true;
+    bool ovf_csr_dirty = false;
     avn_status rebuild_incidence() {
         if (!incidence_dirty) return AVN_OK;
+        if (pipe_dev) { ovf_csr_dirty = true; return rebuild_incidence_device(); }
         uint32_t N = dw.n_bodies, M = dw.n_manifolds;
         if (M == 0) { incidence_dirty = false; island_mode = false; islands_dirty = false; return AVN_OK; }
         if (h_body_has_sb.size() != N || h_m_body1.size() != M) { error = "incidence: bodies / manifolds out of sync"; return AVN_ERR_STATE; }
@@ -1097,6 +1114,7 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipMemset((char*)ct.meta + (size_t)old * sizeof(uint4), 0, (c - old) * sizeof(uint4)));
         ct.cap = (uint32_t)c;
         h_ct_used.resize(c, 0); h_ct_c1.resize(c, 0); h_ct_c2.resize(c, 0); h_ct_b1.resize(c, -1); h_ct_b2.resize(c, -1);
+        if (pipe_dev) return pg_ensure_rows(ct.cap);
         return AVN_OK;
     }
     avn_status contact_pairs_add(const avn_contact_pairs* p) override {
@@ -1216,9 +1234,15 @@ template <class T> struct World : WorldBase {
         if (moved) graph_valid = false;
         return AVN_OK;
     }
+    uint32_t ovf_grid_blocks = 0;   // device closed loop: captured grid of the overflow colour's dataflow pass (with slack, like the colours')
     void set_color_offsets(const uint32_t* offsets) {
-        if (std::memcmp(color_offsets, offsets, sizeof color_offsets) != 0) graph_valid = false;  // (ranges captured as kernel arguments)
+        if (!use_handles && std::memcmp(color_offsets, offsets, sizeof color_offsets) != 0) graph_valid = false;  // (ranges captured as kernel arguments; handle mode reads them from the device)
         std::memcpy(color_offsets, offsets, sizeof color_offsets);
+        {
+            const uint32_t n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
+            const uint32_t need = (n23 + 63u) / 64u;
+            if (pipe_dev && (need > ovf_grid_blocks || ovf_grid_blocks > 4 * need + 64)) { ovf_grid_blocks = n23 ? (n23 + n23 / 4 + 64 + 63u) / 64u : 0u; graph_valid = false; }
+        }
         // launch grids per colour: the kernels read the live colour ranges from device memory, so a captured grid stays
         // valid while it still covers the colour; grids are captured with 25 % slack and re-captured when outgrown
         for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
@@ -1267,7 +1291,7 @@ template <class T> struct World : WorldBase {
     avn_status contacts_download(const uint32_t* ids, size_t n, const avn_contacts_out* o) override {
         if (!o || (n && !ids)) return AVN_ERR_BAD_ARG;
         for (size_t i = 0; i < n; ++i)
-            if (ids[i] >= ct.cap || !h_ct_used[ids[i]]) { error = "contacts_download: no such contact"; return AVN_ERR_STATE; }
+            if (ids[i] >= ct.cap || (!pipe_dev && !h_ct_used[ids[i]])) { error = "contacts_download: no such contact"; return AVN_ERR_STATE; }   // (device closed loop: liveness is a row flag)
         avn_status st = stage_reserve(al(4 * n) * 4 + al(n) + al(sizeof(T) * 3 * n) + al(sizeof(T) * n) * 2 + al(sizeof(T) * 12 * n) * 2 + al(sizeof(T) * 4 * n) * 4 + al(sizeof(T) * 8 * n) + al(16 * n) * 2 + 4096);
         if (st != AVN_OK) return st;
         const uint32_t* d_id;
@@ -1365,6 +1389,26 @@ template <class T> struct World : WorldBase {
     avn_status pipeline_enable(int on) override {
         if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
         if (on && pipe_on) return AVN_OK;
+        if (pipe_on && pipe_dev) {   // leaving the device closed loop: its rows and keys go with it
+            HIPCHK(hipStreamSynchronize(stream));
+            if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
+            pipe_dev = false; pipe_on = false;
+            contact_keys_live = false; h_live_keys.clear();
+            avn_status st = rebuild_pair_set(n_pair_keys);   // only the keys the host uploaded / collected outside the closed loop remain
+            if (st != AVN_OK) return st;
+            if (!on) return AVN_OK;
+        }
+        // on == 1: the bookkeeping runs on the device (k_graph.hip); on == 2 or AVN_PIPELINE_HOST=1: host structures (round-1 path, kept for A/B runs)
+        const bool want_dev = on == 1 && !getenv("AVN_PIPELINE_HOST");
+        if (want_dev) {
+            for (uint32_t id = 0; id < pipe_pairs.size(); ++id)
+                if (pipe_pairs[id].used) { uint32_t cid = id; avn_status st = contact_pairs_remove(&cid, 1); if (st != AVN_OK) return st; }
+            pipe_pairs.clear(); pipe_active.clear(); pipe_handles.clear();
+            avn_status st = pipeline_device_reset();
+            if (st != AVN_OK) return st;
+            pipe_on = true; pipe_dev = true;
+            return AVN_OK;
+        }
         pipe_on = on != 0;
         // a fresh ContactGraph / ConstraintGraph: rows, ids, colour lists and the broad phase's pair set start empty
         for (uint32_t id = 0; id < pipe_pairs.size(); ++id)
@@ -1379,6 +1423,7 @@ template <class T> struct World : WorldBase {
     }
     avn_status pipeline_stats_get(avn_pipeline_stats* o) override {
         if (!o) return AVN_ERR_BAD_ARG;
+        if (pipe_dev) { pipe_stats.active_pairs = pgm_live; pipe_stats.manifolds = dw.n_manifolds; *o = pipe_stats; return AVN_OK; }
         pipe_stats.active_pairs = (uint32_t)pipe_active.size();
         pipe_stats.manifolds = (uint32_t)pipe_handles.size();
         *o = pipe_stats;
@@ -1386,6 +1431,15 @@ template <class T> struct World : WorldBase {
     }
     avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override {
         if (!off || !ids || !n) return AVN_ERR_BAD_ARG;
+        if (pipe_dev) {   // the lists live on the device: fetched on request (tests, inspection)
+            HIPCHK(hipStreamSynchronize(stream));
+            std::memcpy(pipe_offsets, color_offsets, sizeof pipe_offsets);
+            pipe_handles.resize(dw.n_manifolds);
+            if (dw.n_manifolds) {
+                HIPCHK(hipMemcpyAsync(pipe_handles.data(), b_handles.p, (size_t)dw.n_manifolds * 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+            }
+        }
         std::memcpy(off, pipe_offsets, sizeof pipe_offsets);
         *ids = pipe_handles.data(); *n = pipe_handles.size();
         return AVN_OK;
@@ -1518,6 +1572,289 @@ template <class T> struct World : WorldBase {
         last_timers.kernel_launches = launches;
         return AVN_OK;
     }
+    // ---- closed loop, bookkeeping on the device -------------------------------------------------------------------------------
+    template <class U> avn_status pg_buf(DevBuf& b, size_t count, U** field, bool keep = false) {
+        hipError_t err;
+        b.ensure(std::max<size_t>(count, 1) * sizeof(U), err, keep, stream);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        *field = b.as<U>();
+        return AVN_OK;
+    }
+    // per-row arrays follow CT::cap (contents kept: they are persistent state); per-op scratch is sized for one op per row
+    avn_status pg_ensure_rows(uint32_t rows) {
+        if (rows <= pg_rows) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        const uint32_t old = pg_rows;
+        avn_status st;
+#define PGB(buf, cnt, field, keep) do { if ((st = pg_buf(buf, cnt, &(field), keep)) != AVN_OK) return st; } while (0)
+        PGB(b_pg_bodies, rows, pg.bodies, true); PGB(b_pg_color, rows, pg.color, true); PGB(b_pg_lpos, rows, pg.lpos, true);
+        PGB(b_pg_free_a, rows, pg.free_ids, true); PGB(b_pg_free_b, rows, pg.free_alt, true);
+        {   // colour lists: [24][stride] re-laid out for the new stride
+            uint32_t* nl = nullptr;
+            if (hipMalloc((void**)&nl, (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4) != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT && old; ++c)
+                if (pgm_len[c]) HIPCHK(hipMemcpy(nl + (size_t)c * rows, pg.lists + (size_t)c * old, (size_t)pgm_len[c] * 4, hipMemcpyDeviceToDevice));
+            if (b_pg_lists.p) (void)hipFree(b_pg_lists.p);
+            b_pg_lists.p = nl; b_pg_lists.cap = (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4;
+            pg.lists = nl; pg.list_stride = rows;
+        }
+        PGB(b_pg_chg, rows, pg.chg, false); PGB(b_pg_has, rows, pg.has, false); PGB(b_pg_off, rows + 1, pg.off, false);
+        PGB(b_pg_op_cid, rows, pg.op_cid, false); PGB(b_pg_op_info, rows, pg.op_info, false); PGB(b_pg_op_bodies, rows, pg.op_bodies, false);
+        PGB(b_pg_ekey_a, 2 * (size_t)rows, pg.ekey_a, false); PGB(b_pg_eval_a, 2 * (size_t)rows, pg.eval_a, false);
+        PGB(b_pg_ekey_b, 2 * (size_t)rows, pg.ekey_b, false); PGB(b_pg_eval_b, 2 * (size_t)rows, pg.eval_b, false);
+        PGB(b_pg_epos, 2 * (size_t)rows, pg.epos, false); PGB(b_pg_popbefore, 2 * (size_t)rows, pg.popbefore, false);
+        PGB(b_pg_prevpush, 2 * (size_t)rows, pg.prevpush, false); PGB(b_pg_est, 2 * (size_t)rows, pg.est, false);
+        PGB(b_pg_tile_agg, 5 * (size_t)pg_scan_tiles(2 * rows) + 8, pg.tile_agg, false);
+        PGB(b_pg_ckey_a, rows, pg.ckey_a, false); PGB(b_pg_cval_a, rows, pg.cval_a, false); PGB(b_pg_ckey_b, rows, pg.ckey_b, false); PGB(b_pg_cval_b, rows, pg.cval_b, false);
+        PGB(b_pg_rem_flag, rows, pg.rem_flag, false); PGB(b_pg_rem_off, rows + 1, pg.rem_off, false); PGB(b_pg_rem_ids, rows, pg.rem_ids, false);
+        uint32_t* dummy;
+        PGB(b_pg_hist, (size_t)256 * radix_blocks(2 * rows) + 256, dummy, false);
+        PGB(b_pg_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks(2 * rows)), scan_block_sums_needed(2 * rows)) + 16, dummy, false);
+#undef PGB
+        pg.rows = rows; pg_rows = rows;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    avn_status pipeline_device_reset() {
+        overflow_flow_experiment_mode();
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(stream_bp));
+        avn_status st;
+        hipError_t err;
+        b_pg_ctr.ensure(PGC_WORDS * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        pg.ctr = b_pg_ctr.as<uint32_t>();
+        HIPCHK(hipMemset(pg.ctr, 0, PGC_WORDS * 4));
+        if ((st = pg_buf(b_pg_bcol, (size_t)cap_bodies + 1, &pg.bcol)) != AVN_OK) return st;
+        HIPCHK(hipMemset(pg.bcol, 0, ((size_t)cap_bodies + 1) * 4));
+        {   // collider entity -> slot (dense: Entity::index() values are small integers)
+            uint32_t max_ent = 0;
+            for (uint32_t e : slot_entity) max_ent = std::max(max_ent, e);
+            if (max_ent > (1u << 27)) { error = "pipeline_enable: collider entity indices above 2^27 need the host bookkeeping (AVN_PIPELINE_HOST=1)"; return AVN_ERR_CAPACITY; }
+            std::vector<uint32_t> e2s((size_t)max_ent + 1, 0u);
+            for (uint32_t i = 0; i < slot_entity.size(); ++i) e2s[slot_entity[i]] = i;
+            uint32_t* d;
+            if ((st = pg_buf(b_pg_ent2slot, e2s.size(), &d)) != AVN_OK) return st;
+            HIPCHK(hipMemcpy(d, e2s.data(), e2s.size() * 4, hipMemcpyHostToDevice));
+            pg.ent2slot = d;
+        }
+        if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
+        if ((st = ensure_contact_rows(std::max<uint32_t>(ct.cap, 1024u))) != AVN_OK) return st;
+        pg_rows = 0;   // (re)allocate everything for the table's capacity
+        std::memset(pgm_len, 0, sizeof pgm_len);
+        if ((st = pg_ensure_rows(ct.cap)) != AVN_OK) return st;
+        HIPCHK(hipMemset(pg.color, 0xFF, (size_t)pg_rows * 4));
+        contact_keys_live = false; h_live_keys.clear();   // (the pair set keeps the keys the host announced: existing pairs stay existing)
+        pgm_head = pgm_n_free = pgm_next_id = pgm_live = pgm_tomb = 0;
+        std::memset(&pipe_stats, 0, sizeof pipe_stats);
+        std::memset(pipe_offsets, 0, sizeof pipe_offsets);
+        uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+        dw.n_manifolds = 0;
+        set_color_offsets(zero);
+        HIPCHK(hipMemcpy(dw.color_offsets, zero, sizeof zero, hipMemcpyHostToDevice));
+        use_handles = true; any_restitution = materials_restitution;
+        incidence_dirty = true; graph_valid = false;
+        if (pin_ctr.ensure(4096) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        return AVN_OK;
+    }
+    static uint32_t bits_for(uint32_t max_value) { uint32_t b = 1; while (b < 32 && (max_value >> b)) ++b; return b; }
+    // ContactGraph::pair_set with room for `expect` more keys: rebuilt from the live rows when it would pass half full (tombstones count)
+    avn_status pg_pair_set_reserve(uint32_t n_rows_now, uint32_t incoming) {
+        const uint64_t need_keys = (uint64_t)n_pair_keys + pgm_live + pgm_tomb + incoming + 16;
+        if (bp.pair_set_cap && 2 * need_keys <= bp.pair_set_cap) return AVN_OK;
+        uint32_t need = 1024;
+        while ((uint64_t)need < 4 * ((uint64_t)n_pair_keys + pgm_live + incoming + 16)) need <<= 1;
+        HIPCHK(hipStreamSynchronize(bs));
+        hipError_t err;
+        b_pair_set.ensure((size_t)need * 8, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        bp.pair_set = b_pair_set.as<uint64_t>();
+        bp.pair_set_cap = need;
+        HIPCHK(hipMemsetAsync(bp.pair_set, 0xFF, (size_t)need * 8, bs));
+        launch_hs_insert(bp.pair_set, need, b_pair_keys.as<uint64_t>(), n_pair_keys, bs);   // keys announced by the host (avn_existing_pairs_upload, pairs collected outside the loop)
+        launch_pg_rebuild_pair_set<T>(ct, bp, n_rows_now, bs);
+        HIPCHK(hipGetLastError());
+        pgm_tomb = 0;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    avn_status pipeline_step_device() {
+        avn_status st;
+        launches = 0;
+        double host_ms = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
+        HIPCHK(hipEventRecord(ev[0], stream));
+        if ((st = update_aabb()) != AVN_OK) return st;
+        if ((st = collect_launch()) != AVN_OK) return st;
+        lap();
+        // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
+        uint32_t total = 0;
+        if (collect_pending) {
+            collect_pending = false;
+            HIPCHK(hipEventSynchronize(ev_counters));
+            t0 = std::chrono::steady_clock::now();
+            const uint32_t dropped = h_counters[0];
+            total = h_counters[2];
+            if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+            if (total) {
+                hipError_t err;
+                b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
+                if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
+                launch_sweep<T>(bp, collect_n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), bs);
+                launches += 2;
+                const uint32_t fresh = total > pgm_n_free ? total - pgm_n_free : 0u;
+                if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return st;
+                if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return st;
+                launch_hs_insert_pairs(bp.pair_set, bp.pair_set_cap, b_pairs.as<avn_pair>(), total, bs);   // add_edge_and_key_with: the keys join the pair set
+                launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bs);
+                launches += 3;
+                HIPCHK(hipGetLastError());
+                const uint32_t used = std::min(total, pgm_n_free);
+                pgm_head += used; pgm_n_free -= used; pgm_next_id += total - used; pgm_live += total;
+                pipe_stats.pairs_added += total;
+            }
+            bp.n_intervals = collect_n - dropped;
+            last_timers.pair_count = total;
+        }
+        HIPCHK(hipEventRecord(ev[1], stream));
+        // ---- narrow phase over every live row; changes numbered in ascending ContactId ----
+        const uint32_t n_rows = pgm_next_id;
+        uint32_t n_ops = 0, n_rem = 0;
+        if (n_rows) {
+            launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            launch_exclusive_scan(pg.has, pg.off, n_rows, b_pg_sums.as<uint32_t>(), pg.ctr + PGC_N_OPS, stream);
+            launches += 1 + exclusive_scan_launches(n_rows);
+            HIPCHK(hipGetLastError());
+            uint32_t* h = (uint32_t*)pin_ctr.p;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
+            lap();
+            HIPCHK(hipStreamSynchronize(stream));
+            t0 = std::chrono::steady_clock::now();
+            n_ops = h[0]; n_rem = h[1];
+            if (h[2]) { error = "device constraint graph: a dataflow wait timed out in the previous step"; return AVN_ERR_STATE; }
+        }
+        pipe_stats.last_status_changes = n_ops;
+        ++pg_dump_step;
+        if (n_ops) {
+            // ---- the status-change loop: decisions, colours, handle lists ----
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
+            launch_pg_classify(pg, n_rows, dw.n_bodies, stream);
+            uint32_t *ek, *evv;
+            launch_radix_sort_bits(pg.ekey_a, pg.eval_a, pg.ekey_b, pg.eval_b, 2 * n_ops, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ek, &evv, stream);
+            launch_pg_entry_scan(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_color(pg, n_ops, stream);
+            launch_pg_apply_masks(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_bucket_keys(pg, n_ops, stream);
+            uint32_t *ck, *order;
+            launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
+            launch_pg_replay(pg, order, stream);
+            launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
+            if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
+                launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
+                launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
+                launch_pg_merge_free(pg, pgm_head, pgm_n_free, n_rem, stream);
+                HIPCHK(hipMemcpyAsync(pg.free_ids, pg.free_alt, ((size_t)pgm_n_free + n_rem) * 4, hipMemcpyDeviceToDevice, stream));
+                pgm_head = 0; pgm_n_free += n_rem; pgm_live -= n_rem; pgm_tomb += n_rem;
+                pipe_stats.pairs_removed += n_rem;
+                launches += 5;
+            }
+            HIPCHK(hipGetLastError());
+            uint32_t* h = (uint32_t*)pin_ctr.p + 16;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
+            lap();
+            HIPCHK(hipStreamSynchronize(stream));
+            t0 = std::chrono::steady_clock::now();
+            if (h[32]) { error = "device constraint graph: the colouring's dataflow wait timed out"; return AVN_ERR_STATE; }
+            if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
+                std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
+                std::vector<int2> bd(n_ops);
+                HIPCHK(hipMemcpy(a.data(), pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(b.data(), pg.op_info, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(bd.data(), pg.op_bodies, (size_t)n_ops * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(o.data(), order, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(cnt.data(), pg.ctr + PGC_BUCKET, 32 * 4, hipMemcpyDeviceToHost));
+                char path[512];
+                std::snprintf(path, sizeof path, "%s/step_%04llu.bin", dir, (unsigned long long)pg_dump_step);
+                if (FILE* f = std::fopen(path, "wb")) {
+                    uint32_t hdr[4] = {n_ops, n_rem, 0, 0};
+                    std::fwrite(hdr, 4, 4, f); std::fwrite(a.data(), 4, n_ops, f); std::fwrite(b.data(), 4, n_ops, f); std::fwrite(bd.data(), 8, n_ops, f);
+                    std::fwrite(o.data(), 4, n_ops, f); std::fwrite(cnt.data(), 4, 32, f);
+                    std::fclose(f);
+                }
+            }
+            pipe_stats.manifolds_pushed = h[34]; pipe_stats.manifolds_popped = h[35];
+            uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
+            uint32_t M = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[c]; offs[c] = M; M += h[c]; }
+            offs[AVN_GRAPH_COLOR_COUNT] = M;
+            if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
+            if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
+            dw.n_manifolds = M;
+            set_color_offsets(offs);
+            hipError_t err;
+            if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, stream);
+            ++launches;
+            HIPCHK(hipGetLastError());
+            incidence_dirty = true;
+        }
+        pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
+        lap();
+        pipe_stats.last_host_ms = host_ms;
+        if ((st = solver()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[4], stream));
+        ev_valid = true;
+        last_timers.kernel_launches = launches;
+        return AVN_OK;
+    }
+    // the overflow colour's CSR + ranks, and the slot table of the other colours, from the gathered manifold arrays (all on the device)
+    avn_status rebuild_incidence_device() {
+        const uint32_t N = dw.n_bodies, M = dw.n_manifolds;
+        incidence_dirty = false;
+        island_mode = false; islands_dirty = false;
+        if (M == 0) return AVN_OK;
+        hipError_t err;
+        bool moved = b_inc_slot.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * cap_bodies * sizeof(uint32_t), err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (moved || dw.inc_stride != cap_bodies) graph_valid = false;
+        dw.inc_slot = b_inc_slot.as<uint32_t>(); dw.inc_stride = cap_bodies;
+        slots_dirty = true;
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+        moved = b_inc_off.ensure(((size_t)N + 2) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (n23 > pg_ovf_cap) {
+            HIPCHK(hipStreamSynchronize(stream));
+            const size_t c = std::max<size_t>(2 * (size_t)n23 + 1024, (size_t)pg_ovf_cap * 3);
+            for (DevBuf* b : {&b_inc_ent, &b_ovf_keys_a, &b_ovf_vals_a, &b_ovf_keys_b, &b_ovf_vals_b, &b_ovf_rank}) {
+                b->ensure(c * 4, err);
+                if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            }
+            pg_ovf_cap = (uint32_t)(c / 2);
+            moved = true;
+        }
+        if (b_inc_ent.cap == 0) { b_inc_ent.ensure(1024, err); b_ovf_rank.ensure(1024, err); moved = true; }
+        if (b_ovf_ticket.ensure(((size_t)cap_bodies + 1) * 4, err)) moved = true;
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (moved || !dw.inc_off) graph_valid = false;
+        dw.inc_off = b_inc_off.as<uint32_t>(); dw.inc_ent = b_inc_ent.as<uint32_t>();
+        islands_dirty = island_candidate(M) && dw.n_joints == 0;
+        return AVN_OK;
+    }
+    // after k_gather_manifolds (the CSR reads DW::m_bodies of the overflow range)
+    void overflow_csr_device() {
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+        uint32_t *k = b_ovf_keys_a.as<uint32_t>(), *v = b_ovf_vals_a.as<uint32_t>();
+        if (n23) {
+            launch_ovf_entries<T>(dw, o0, n23, k, v, stream);
+            launch_radix_sort_bits(k, v, b_ovf_keys_b.as<uint32_t>(), b_ovf_vals_b.as<uint32_t>(), 2 * n23, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &k, &v, stream);
+            launches += 1 + ((bits_for(dw.n_bodies) + 7) / 8) * radix_pass_launches(2 * n23);
+        }
+        launch_ovf_csr<T>(dw, o0, n23, k, v, b_inc_off.as<uint32_t>(), b_inc_ent.as<uint32_t>(), b_ovf_rank.as<uint32_t>(), stream);
+        launches += 2;
+    }
     avn_status update_aabb() {
         launch_update_aabb<T>(dw, bp, params, bs);
         ++launches;
@@ -1607,6 +1944,7 @@ template <class T> struct World : WorldBase {
     void prepare_contact_constraints() {
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+        if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
         launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
     }
     void store_contact_impulses() {
@@ -1626,6 +1964,21 @@ template <class T> struct World : WorldBase {
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
     void contact_pass(int pass) {
         if (!dw.n_manifolds) return;
+        if (pipe_dev) {   // overflow colour first (one dataflow launch), then colours 0..22
+            // (launched whenever a grid is captured for it, whatever the colour's current population: the captured graph must not
+            //  depend on the step's counts; an empty colour costs one launch of idle lanes)
+            if (ovf_grid_blocks && ovf_epoch < PGC_OVF_TILES) {
+                OverflowFlow of{b_ovf_rank.as<uint32_t>(), b_ovf_ticket.as<uint32_t>(), pg.ctr + PGC_OVF_TILE, pg.ctr + PGC_ERROR};
+                launch_overflow_flow<T>(dw, params, pass, of, ovf_epoch, ovf_grid_blocks, stream);
+                ++ovf_epoch; ++launches;
+            }
+            uint32_t gb[AVN_GRAPH_COLOR_COUNT];
+            std::memcpy(gb, grid_blocks, sizeof gb);
+            gb[AVN_COLOR_OVERFLOW_INDEX] = 0;
+            OverflowSchedule none{0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+            launches += launch_contact_pass<T>(dw, params, pass, gb, nullptr, none, stream);
+            return;
+        }
         OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
                              sched_overflow.d_order.as<uint32_t>(), nullptr, nullptr, 0};
         if (sched_overflow.gorder.size() > overflow_level_threshold) {  // a big overflow colour: one device-wide launch per level instead of one workgroup per component
@@ -1682,17 +2035,33 @@ template <class T> struct World : WorldBase {
         if constexpr (sizeof(T) == 4) {
             if (islands_active()) {   // every substep of every island block in ONE launch (k_island_substeps)
                 launch_island_substeps(dw, params, islands, cfg.substeps, cfg.solver_iterations, stream); ++launches;
+                // (device closed loop: the restitution pass after the loop still runs colour by colour; its overflow pass starts a fresh epoch count)
+                if (pipe_dev && ovf_grid_blocks) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+                ovf_epoch = 0;
                 return AVN_OK;
             }
         }
         // the body-centric warm start's slot table (not needed by the island blocks); outside the capture below
         if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
-        if (!cfg.use_graph) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
+        const bool flow = pipe_dev && dw.n_manifolds && ovf_grid_blocks;
+        if (flow && (uint64_t)cfg.substeps * 2 * cfg.solver_iterations + 2 > PGC_OVF_TILES) { error = "device closed loop: too many contact passes per step for the overflow tickets"; return AVN_ERR_CAPACITY; }
+        if (!cfg.use_graph) {
+            if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+            ovf_epoch = 0;
+            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            ovf_epoch_after_substeps = ovf_epoch;
+            return AVN_OK;
+        }
         if (!graph_valid) {
+            if (getenv("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
             drop_graph();
             uint32_t before = launches;
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            // the overflow passes' tickets and tile counters restart with every step (a kernel node, replayed first)
+            if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+            ovf_epoch = 0;
             for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            ovf_epoch_after_substeps = ovf_epoch;
             HIPCHK(hipStreamEndCapture(stream, &graph));
             graph_launches = launches - before;
             launches = before;
@@ -1701,6 +2070,7 @@ template <class T> struct World : WorldBase {
         }
         HIPCHK(hipGraphLaunch(graph_exec, stream));
         launches += graph_launches;
+        ovf_epoch = ovf_epoch_after_substeps;   // (the restitution pass after the loop continues the step's epochs)
         return AVN_OK;
     }
     uint32_t graph_launches = 0;
@@ -1714,7 +2084,18 @@ template <class T> struct World : WorldBase {
         prepare_contact_constraints();
         pre_process_velocity_increments();
         // host work that only the substep loop needs, done while the prepare kernels above run
-        if (islands_dirty) { islands_dirty = false; if ((st = rebuild_island_blocks()) != AVN_OK) return st; }
+        if (islands_dirty) {
+            islands_dirty = false;
+            if (pipe_dev) {   // the island builder is host code: fetch the (small) gathered body pairs
+                const uint32_t M = dw.n_manifolds;
+                std::vector<int2> mb(M);
+                HIPCHK(hipMemcpyAsync(mb.data(), dw.m_bodies, (size_t)M * sizeof(int2), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                h_m_body1.resize(M); h_m_body2.resize(M);
+                for (uint32_t m = 0; m < M; ++m) { h_m_body1[m] = mb[m].x; h_m_body2[m] = mb[m].y; }
+            }
+            if ((st = rebuild_island_blocks()) != AVN_OK) return st;
+        }
         HIPCHK(hipEventRecord(ev[2], stream));
         if ((st = run_substeps()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[3], stream));
@@ -1806,7 +2187,7 @@ template <class T> struct World : WorldBase {
     avn_status step() override {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
-        if (pipe_on) return pipeline_step();
+        if (pipe_on) return pipe_dev ? pipeline_step_device() : pipeline_step();
         launches = 0;
         HIPCHK(hipEventRecord(ev[0], stream));
         const bool overlap = overlap_bp && have_colliders;

@@ -831,6 +831,25 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
         uint32_t* tv = vi; vi = vo; vo = tv;
     }
 }
+// the same sort on the low `bits` bits only (device ConstraintGraph: keys are body indices / colours); any n, no single-launch form
+void launch_radix_sort_bits(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t bits, uint32_t* hist, uint32_t* block_sums,
+                            uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
+    uint32_t* ki = keys_a; uint32_t* vi = vals_a; uint32_t* ko = keys_b; uint32_t* vo = vals_b;
+    const uint32_t nb = radix_blocks(n);
+    for (uint32_t shift = 0; n && shift < bits; shift += 8) {
+        if (nb <= RS_FUSED_MAX_BLOCKS) {
+            hipLaunchKernelGGL((k_radix_hist<uint32_t, true>), dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, nullptr);
+            hipLaunchKernelGGL((k_radix_scatter<uint32_t, true>), dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, nullptr);
+        } else {
+            hipLaunchKernelGGL((k_radix_hist<uint32_t, false>), dim3(nb), dim3(64), 0, s, ki, n, shift, hist, nb, nullptr);
+            launch_exclusive_scan(hist, hist, 256 * nb, block_sums, nullptr, s, nullptr);
+            hipLaunchKernelGGL((k_radix_scatter<uint32_t, false>), dim3(nb), dim3(64), 0, s, ki, vi, ko, vo, n, shift, hist, nb, nullptr);
+        }
+        uint32_t* tk = ki; ki = ko; ko = tk;
+        uint32_t* tv = vi; vi = vo; vo = tv;
+    }
+    *keys_out = ki; *vals_out = vi;
+}
 template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, const uint32_t* sorted_collider, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_gather_sorted<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bp, sorted_collider, n);
 }

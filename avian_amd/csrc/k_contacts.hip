@@ -19,6 +19,8 @@
 //                                  normal_part.rs:116-166, tangent_part.rs:155-244
 //   k_solve_restitution            plugin.rs:630-718, contact/mod.rs:358-407
 //   k_store_contact_impulses       plugin.rs:722-755
+#include <cstdlib>
+
 #include "avn_kernels.h"
 #include "avn_body_ops.h"
 
@@ -41,13 +43,40 @@ template <class T> __device__ __forceinline__ BodyView<T> global_bodies(const DW
 
 // Fetch SolverBody + SolverBodyInertia, substituting DUMMY for a missing body and a DUMMY inertia for a
 // dominant one (solver/plugin.rs:491-512).
-template <class T, bool WITH_DELTA, int STRIDE>
+// Agent-scope accesses of one record (k_overflow_flow: lanes of different workgroups hand a body's velocities to each other inside
+// ONE launch; the XCDs' L2s are not coherent with each other, so these go to the coherence point component by component).
+__device__ uint32_t g_ovf_mode = 0;   // EXPERIMENT (AVN_OVF_MODE): 0 agent-scope accesses, 1 system-scope accesses, 2 agent + acquire fence after the ticket match
+template <class T> __device__ __forceinline__ Vec4<T> ld_rec_agent(const Vec4<T>* q) {
+    const T* f = reinterpret_cast<const T*>(q);
+    Vec4<T> r;
+    if (g_ovf_mode == 1) {
+        r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return r;
+    }
+    r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return r;
+}
+template <class T> __device__ __forceinline__ void st_rec_agent(Vec4<T>* q, Vec4<T> v) {
+    T* f = reinterpret_cast<T*>(q);
+    if (g_ovf_mode == 1) {
+        __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <class T, bool WITH_DELTA, int STRIDE, bool COH = false>
 __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
     // The six records are fetched UNCONDITIONALLY (every body index is a valid row; rows of bodies without a SolverBody
     // hold DUMMY values) and the DUMMY substitution is a select afterwards: no load waits on the constraint's flag word,
     // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
     const size_t o = (size_t)idx * STRIDE;
-    Vec4<T> l = bv.lin[o], a = bv.ang[o];
+    Vec4<T> l, a;
+    if (COH) { l = ld_rec_agent<T>(&bv.lin[o]); a = ld_rec_agent<T>(&bv.ang[o]); }   // (the velocities are the only records a contact pass writes)
+    else { l = bv.lin[o]; a = bv.ang[o]; }
     Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
     if (WITH_DELTA) { dp = bv.dp[o]; dq = bv.dq[o]; }
     Vec4<T> sa = bv.sia[o], sb = bv.sib[o];
@@ -64,8 +93,9 @@ __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool n
     b.inv_mass = V3<T>{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
     b.I = Sym3<T>{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
 }
-template <class T, int STRIDE> __device__ __forceinline__ void store_body(const BodyView<T>& bv, int idx, bool no_body, const BodyRef<T>& b) {
+template <class T, int STRIDE, bool COH = false> __device__ __forceinline__ void store_body(const BodyView<T>& bv, int idx, bool no_body, const BodyRef<T>& b) {
     if (no_body) return;  // writes to a DUMMY body are discarded
+    if (COH) { st_rec_agent<T>(&bv.lin[(size_t)idx * STRIDE], make4<T>(b.v, b.lin_w)); st_rec_agent<T>(&bv.ang[(size_t)idx * STRIDE], make4<T>(b.om, b.ang_w)); return; }
     bv.lin[(size_t)idx * STRIDE] = make4<T>(b.v, b.lin_w);
     bv.ang[(size_t)idx * STRIDE] = make4<T>(b.om, b.ang_w);
 }
@@ -300,7 +330,7 @@ __device__ __forceinline__ void warm_core(const DW<T>& w, const StepParams<T>& p
     store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
 
-template <class T, bool USE_BIAS, int STRIDE>
+template <class T, bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
     // level 1: every load that only depends on m, issued up front and unconditionally (memory-level parallelism: the
     // kernel is latency-bound at one manifold per lane; the point planes hold 4 slots per manifold, so unused points
@@ -318,8 +348,8 @@ __device__ __forceinline__ void solve_core(const DW<T>& w, const StepParams<T>& 
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
-    load_body<T, true, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, true, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     if (np == 0) return;
     V3<T> normal = xyz<T>(h0);
     T friction = h0.w;
@@ -388,8 +418,8 @@ __device__ __forceinline__ void solve_core(const DW<T>& w, const StepParams<T>& 
 #pragma unroll
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
         if (k < np) w.c_pd[k * S + m] = pd[k];
-    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
-    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
 
 // ---- f32: the two bodies of a manifold as the two halves of PACKED-f32 registers -----------------------------------------
@@ -428,7 +458,7 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
     b.om = sub_lo_add_hi(b.om, smul(b.I, cross(anchors, p)));
 }
 
-template <bool USE_BIAS, int STRIDE>
+template <bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
     // memory levels exactly as solve_one: (headers + point records) | body gathers
@@ -445,8 +475,8 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
-    load_body<T, true, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, true, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, true, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     if (np == 0) return;
     BodyPair bp;
     bp.v = pair3(b1.v, b2.v); bp.om = pair3(b1.om, b2.om); bp.inv_mass = pair3(b1.inv_mass, b2.inv_mass);
@@ -522,17 +552,17 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
         if (k < np) w.c_pd[k * S + m] = pd[k];
     b1.v = lo3(bp.v); b1.om = lo3(bp.om); b2.v = hi3(bp.v); b2.om = hi3(bp.om);
-    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
-    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
-template <class T, bool USE_BIAS, int STRIDE> struct SolveDispatch {
-    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) { solve_core<T, USE_BIAS, STRIDE>(w, p, m, bv, i1, i2); }
+template <class T, bool USE_BIAS, int STRIDE, bool COH = false> struct SolveDispatch {
+    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) { solve_core<T, USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
 };
-template <bool USE_BIAS, int STRIDE> struct SolveDispatch<float, USE_BIAS, STRIDE> {
-    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) { solve_core_packed<USE_BIAS, STRIDE>(w, p, m, bv, i1, i2); }
+template <bool USE_BIAS, int STRIDE, bool COH> struct SolveDispatch<float, USE_BIAS, STRIDE, COH> {
+    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) { solve_core_packed<USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
 };
 
-template <class T, int STRIDE>
+template <class T, int STRIDE, bool COH = false>
 __device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
     Vec4<T> h1 = w.c_h1[m];
     uint32_t cm = scalar_to_bits(h1.w);
@@ -542,8 +572,8 @@ __device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParam
     if (restitution == T(0)) return;
     V3<T> normal = xyz<T>(w.m_n[m]);
     BodyRef<T> b1, b2;
-    load_body<T, false, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, false, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    load_body<T, false, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
     uint32_t S = w.m_stride;
     uint32_t iterations = np > 1 ? p.restitution_iterations : 1u;
     T threshold = p.restitution_threshold;
@@ -564,18 +594,18 @@ __device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParam
             w.c_pd[s] = pd;
             apply_impulse(b1, b2, impulse * normal, a1, a2);
         }
-    store_body<T, STRIDE>(bv, i1, cm & AVN_CM_NOBODY1, b1);
-    store_body<T, STRIDE>(bv, i2, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
+    store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
 
 enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
 // one manifold of a pass against the world's HBM body arrays
-template <class T, int PASS> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
+template <class T, int PASS, bool COH = false> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
     const int2 b = w.m_bodies[m];   // (a level-1 load like the constraint records: the body gathers depend on it)
     const BodyView<T> bv = global_bodies(w);
-    if (PASS == PASS_BIAS) SolveDispatch<T, true, 2>::run(w, p, m, bv, b.x, b.y);
-    else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2>::run(w, p, m, bv, b.x, b.y);
-    else restitution_core<T, 2>(w, p, m, bv, b.x, b.y);
+    if (PASS == PASS_BIAS) SolveDispatch<T, true, 2, COH>::run(w, p, m, bv, b.x, b.y);
+    else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2, COH>::run(w, p, m, bv, b.x, b.y);
+    else restitution_core<T, 2, COH>(w, p, m, bv, b.x, b.y);
 }
 
 // (Tried and rejected: the whole substep loop as ONE persistent launch, <= 1 workgroup per CU, with a device-wide barrier --
@@ -619,6 +649,75 @@ __global__ __launch_bounds__(OVERFLOW_THREADS) void k_overflow_pass(DW<T> w, Ste
         for (uint32_t k = k0 + threadIdx.x; k < k1; k += OVERFLOW_THREADS) pass_one<T, PASS>(w, p, order[k]);
         __syncthreads();  // same CU: the level's body writes are in its L1 / L2 before the next level gathers them
     }
+}
+
+// The overflow colour as ONE launch per pass (device closed loop): dataflow instead of levels.  Lane i owns the i-th manifold of the
+// colour's list.  For each of its bodies that has a SolverBody the manifold knows its RANK among that body's overflow manifolds in
+// list order (k_ovf_post) and the body carries a ticket counting the overflow manifolds solved on it since the step began: the lane
+// waits until ticket == epoch * (manifolds on the body) + rank on both bodies, solves with agent-scope accesses of the velocities,
+// and bumps the tickets.  Every body therefore sees its overflow manifolds in list order -- the reference's serial result -- while
+// unrelated manifolds run concurrently and a dependent one starts as soon as its predecessors are through (no level barrier, no
+// launch per level: a pile's overflow colour is hundreds of levels deep while it settles).  Tiles are handed out by an atomic
+// counter, so a lane only waits for lanes of waves that already run; spins are bounded (PGC_ERROR is raised instead of hanging).
+template <class T, int PASS>
+__global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, StepParams<T> p, OverflowFlow of, uint32_t epoch) {
+    __shared__ uint32_t s_tile;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) s_tile = atomicAdd(&of.tiles[epoch], 1u);
+    __syncthreads();
+    const uint32_t o0 = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+    const uint32_t i = s_tile * CONTACT_THREADS + lane;
+    const bool valid = i < n23;
+    const uint32_t m = o0 + (valid ? i : 0u);
+    uint32_t r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, t1 = 0, t2 = 0;
+    int2 b = make_int2(0, 0);
+    if (valid) {
+        b = w.m_bodies[m];
+        r1 = of.rank[2 * i]; r2 = of.rank[2 * i + 1];
+        if (r1 != 0xFFFFFFFFu) t1 = epoch * (w.inc_off[b.x + 1] - w.inc_off[b.x]) + r1;
+        if (r2 != 0xFFFFFFFFu) t2 = epoch * (w.inc_off[b.y + 1] - w.inc_off[b.y]) + r2;
+    }
+    bool done = !valid;
+    for (uint32_t it = 0;; ++it) {
+        if (!done) {
+            const bool ready = (r1 == 0xFFFFFFFFu || __hip_atomic_load(&of.ticket[b.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t1) &&
+                               (r2 == 0xFFFFFFFFu || __hip_atomic_load(&of.ticket[b.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t2);
+            if (ready) {
+                asm volatile("" ::: "memory");
+                if (g_ovf_mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                pass_one<T, PASS, true>(w, p, m);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the velocity stores are performed before the tickets move
+                if (r1 != 0xFFFFFFFFu) __hip_atomic_fetch_add(&of.ticket[b.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r2 != 0xFFFFFFFFu && !(r1 != 0xFFFFFFFFu && b.x == b.y)) __hip_atomic_fetch_add(&of.ticket[b.y], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                done = true;
+            }
+        }
+        if (__all(done)) break;
+        if (it > (1u << 22)) { if (lane == 0) atomicOr(of.error, 2u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+// tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
+// not reliably ordered against a synchronous (null-stream) hipMemcpy issued between replays on ROCm 7.2 (found by the closed-loop tests:
+// a whole step of wrong impulses after avn_pipeline_handles_get had copied with hipMemcpy); kernel nodes keep the chain.
+__global__ __launch_bounds__(256) void k_overflow_reset(uint32_t* __restrict__ ticket, uint32_t n_ticket, uint32_t* __restrict__ tiles, uint32_t n_tiles) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n_ticket) ticket[i] = 0u;
+    if (i < n_tiles) tiles[i] = 0u;
+}
+void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles, uint32_t n_tiles, hipStream_t s) {
+    const uint32_t n = n_ticket > n_tiles ? n_ticket : n_tiles;
+    hipLaunchKernelGGL(k_overflow_reset, dim3((n + 255) / 256), dim3(256), 0, s, ticket, n_ticket, tiles, n_tiles);
+}
+void overflow_flow_experiment_mode() {   // (not inside a stream capture)
+    if (const char* e = getenv("AVN_OVF_MODE")) { uint32_t m = (uint32_t)atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ovf_mode), &m, sizeof m); }
+}
+template <class T> void launch_overflow_flow(const DW<T>& w, const StepParams<T>& p, int pass, const OverflowFlow& of, uint32_t epoch, uint32_t grid_blocks, hipStream_t s) {
+    if (!grid_blocks) return;
+
+    if (pass == PASS_BIAS) hipLaunchKernelGGL((k_overflow_flow<T, PASS_BIAS>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
+    else if (pass == PASS_RELAX) hipLaunchKernelGGL((k_overflow_flow<T, PASS_RELAX>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
+    else hipLaunchKernelGGL((k_overflow_flow<T, PASS_RESTITUTION>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
 }
 
 template <class T>
@@ -826,7 +925,8 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
     template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t);                               \
-    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t);
+    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t); \
+    template void launch_overflow_flow<T>(const DW<T>&, const StepParams<T>&, int, const OverflowFlow&, uint32_t, uint32_t, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

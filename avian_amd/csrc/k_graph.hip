@@ -1,0 +1,526 @@
+// k_graph.hip — the closed loop's integer bookkeeping on the device: IdPool, ContactGraph rows, the status-change loop of
+// NarrowPhase::update and the ConstraintGraph (greedy colouring + per-colour handle lists), bit-identical to the reference's
+// serial loops.
+//
+// Reference (paths relative to /root/reference/src):
+//   data_structures/id_pool.rs:31-40                     IdPool::alloc_id / free_id (lowest free id first)
+//   collision/contact_types/contact_graph.rs:521-631     add_edge_and_key_with / remove_edge_by_id
+//   collision/narrow_phase/system_param.rs:141-389       the status-change loop (ascending ContactId)
+//   dynamics/solver/constraint_graph.rs:163-296          push_manifold (greedy colouring) / pop_manifold (swap_remove)
+//
+// The reference walks the changed contacts serially.  What makes the walk order-dependent is (a) the greedy colour choice of
+// a push, which depends on the colours taken by the EARLIER pushes on the same two bodies, and (b) the position of every
+// handle inside its colour's Vec (push = append, pop = swap_remove).  Both are replayed exactly:
+//
+//   1. k_narrow_phase<DENSE> leaves one packed change word per row; an exclusive scan over the rows numbers the changes in
+//      ascending ContactId = the reference's processing order ("ops").
+//   2. k_pg_classify turns a change into PUSH | POP | nothing (+ REMOVE) -- the if/else chain of system_param.rs:155-373 --
+//      and emits one (body, op) entry per non-static side; a stable radix sort by body gives every body its ops in order.
+//   3. A pop's colour is known (stored on the row), so the bits it frees in a body's colour mask are STATIC: a segmented scan
+//      over the sorted entries gives every entry the colours freed on its body by earlier pops (k_pg_scan_*).  Only pushes
+//      depend on each other: k_pg_color is a dataflow kernel, one lane per op in op order, that waits (agent-scope loads) for
+//      the previous push entry of each of its bodies, picks the reference's colour (lowest free of 0..19 for two non-static
+//      bodies, highest free of 22..1 next to a static one, else overflow) and publishes the bits.  Waves take their tile from
+//      an atomic counter, so a lane only ever waits for lanes of waves that already run: no deadlock; spins are bounded.
+//   4. The ops are bucketed by colour (stable) and k_pg_replay replays each colour's push / swap_remove sequence with one wave,
+//      64 ops at a time (tools/experiments/replay_batches.py is the CPU model of the rule that makes a batch parallel).
+//   5. Removed pairs free their ids into the sorted free list (k_pg_merge_free), rows are cleared, keys leave the pair set.
+//
+// Per-body colour masks (PG::bcol, bit c = "in GraphColor c's body_set") replace the 24 BitVecs: same information, one load.
+#include "avn_kernels.h"
+
+namespace avn {
+
+#define PG_KIND_NONE 0u
+#define PG_KIND_PUSH 1u
+#define PG_KIND_POP 2u
+#define PG_SPIN_LIMIT (1u << 22)
+
+__device__ __forceinline__ uint32_t ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// same-wave read-after-write through memory (k_pg_replay): bypass the CU's L1
+__device__ __forceinline__ uint32_t ld_wg(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+__device__ __forceinline__ int wave_incl_add(int v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { int u = __shfl_up(v, off); if ((int)lane >= off) v += u; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_min(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t u = (uint32_t)__shfl_up((int)v, off); if ((int)lane >= off) v = u < v ? u : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { uint32_t u = (uint32_t)__shfl_up((int)v, off); if ((int)lane >= off) v = u > v ? u : v; }
+    return v;
+}
+
+// ---- new pairs: IdPool::alloc_id in emission order + ContactGraph::add_edge_and_key_with --------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn_pair* __restrict__ pairs, uint32_t total) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t head = pg.ctr[PGC_FREE_HEAD], n_free = pg.ctr[PGC_N_FREE], next = pg.ctr[PGC_NEXT_ID];
+    const uint32_t id = i < n_free ? pg.free_ids[head + i] : next + (i - n_free);   // the i-th lowest free id, then fresh ids
+    const avn_pair pr = pairs[i];
+    const uint32_t f = pr.flags;
+    const uint32_t flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
+                           ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u) | AVN_CP_ROW_USED;
+    ct.meta[id] = make_uint4(pg.ent2slot[pr.collider1], pg.ent2slot[pr.collider2], flags, 0u);
+    ct.dcount[id] = 0;
+    pg.bodies[id] = make_int2(pr.body1, pr.body2);
+    pg.color[id] = PG_NONE;
+}
+__global__ void k_pg_after_add(PG pg, uint32_t total) {
+    const uint32_t n_free = pg.ctr[PGC_N_FREE];
+    const uint32_t used = total < n_free ? total : n_free;
+    pg.ctr[PGC_FREE_HEAD] += used;
+    pg.ctr[PGC_N_FREE] = n_free - used;
+    pg.ctr[PGC_NEXT_ID] += total - used;
+}
+template <class T> void launch_pg_add_pairs(const PG& pg, const CT<T>& ct, const avn_pair* pairs, uint32_t total, hipStream_t s) {
+    if (!total) return;
+    hipLaunchKernelGGL(k_pg_add_pairs<T>, dim3((total + 255) / 256), dim3(256), 0, s, pg, ct, pairs, total);
+    hipLaunchKernelGGL(k_pg_after_add, dim3(1), dim3(1), 0, s, pg, total);
+}
+
+// ---- the status-change loop, decision part (system_param.rs:155-373) ------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pg_classify(PG pg, uint32_t n_rows, uint32_t n_bodies) {
+    __shared__ uint32_t hist[AVN_GRAPH_COLOR_COUNT];
+    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c < n_rows && pg.has[c]) {
+        const uint32_t k = pg.off[c];
+        const uint32_t w = pg.chg[c];
+        const uint32_t flags = w & 0xFFFFu, n_manifolds = (w >> 16) & 0xFFu;
+        const int dcount = (int)((w >> 24) & 0xFFu) - 128;
+        const bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+        const uint32_t col = pg.color[c];
+        const bool has_handle = col != PG_NONE;   // ContactEdge::constraint_handles is non-empty (one manifold per convex pair)
+        uint32_t kind = PG_KIND_NONE, remove = 0;
+        if (flags & AVN_CP_DISJOINT_AABB) { if (generates && has_handle) kind = PG_KIND_POP; remove = 1; }
+        else if (flags & AVN_CP_STARTED_TOUCHING) { if (generates && n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
+        else if (flags & AVN_CP_STOPPED_TOUCHING) { if (generates && has_handle) kind = PG_KIND_POP; }
+        else if (touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) { if (n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
+        else if (touching && generates && dcount > 0) { if (!has_handle) kind = PG_KIND_PUSH; }
+        else if (touching && generates && dcount < 0) { if (has_handle) kind = PG_KIND_POP; }
+        const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
+        if (kind == PG_KIND_PUSH && s1 && s2) kind = PG_KIND_NONE;   // (debug_assert in the reference: never both)
+        const int2 b = pg.bodies[c];
+        const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
+        pg.op_cid[k] = c;
+        pg.op_info[k] = kind | (s1 ? 4u : 0u) | (s2 ? 8u : 0u) | (remove << 4) | (opcol << 8);
+        pg.op_bodies[k] = b;
+        pg.rem_flag[k] = remove;
+        // one entry per side whose body's colour mask the op reads or writes: non-static sides of pushes and of pops of colours 0..22
+        const bool masks = kind == PG_KIND_PUSH || (kind == PG_KIND_POP && col < (uint32_t)AVN_COLOR_OVERFLOW_INDEX);
+        pg.ekey_a[2 * k] = (masks && !s1) ? (uint32_t)b.x : n_bodies;
+        pg.ekey_a[2 * k + 1] = (masks && !s2) ? (uint32_t)b.y : n_bodies;
+        pg.eval_a[2 * k] = 2 * k; pg.eval_a[2 * k + 1] = 2 * k + 1;
+        if (kind == PG_KIND_POP) atomicAdd(&hist[col], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT && hist[threadIdx.x]) { atomicAdd(&pg.ctr[PGC_BUCKET + threadIdx.x], hist[threadIdx.x]); atomicAdd(&pg.ctr[PGC_N_POP], hist[threadIdx.x]); }
+}
+void launch_pg_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_pg_classify, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, n_rows, n_bodies);
+}
+
+// ---- segmented scan over the body-sorted entries: colours freed by earlier pops, previous push entry ----------------------------
+#define PGS_TILE 256
+__device__ __forceinline__ void pg_entry_fields(const PG& pg, uint32_t val, uint32_t& popbit, uint32_t& is_push) {
+    const uint32_t info = pg.op_info[val >> 1], kind = info & 3u, col = (info >> 8) & 0xFFu;
+    popbit = (kind == PG_KIND_POP && col < (uint32_t)AVN_COLOR_OVERFLOW_INDEX) ? (1u << col) : 0u;
+    is_push = kind == PG_KIND_PUSH;
+}
+// in-tile INCLUSIVE segmented scan (keys sorted: "same segment" == same key); pop: OR of pop bits, lp: 1 + position of the latest push entry
+__device__ __forceinline__ void pg_tile_scan(uint32_t key, uint32_t& pop, uint32_t& lp, uint32_t* s_key, uint32_t* s_pop, uint32_t* s_lp) {
+    const uint32_t t = threadIdx.x;
+    s_key[t] = key; s_pop[t] = pop; s_lp[t] = lp;
+    __syncthreads();
+    for (uint32_t off = 1; off < PGS_TILE; off <<= 1) {
+        uint32_t ap = 0, al = 0;
+        if (t >= off && s_key[t - off] == key) { ap = s_pop[t - off]; al = s_lp[t - off]; }
+        __syncthreads();
+        pop |= ap; lp = al > lp ? al : lp;
+        s_pop[t] = pop; s_lp[t] = lp;
+        __syncthreads();
+    }
+}
+// tile aggregates: [first key, last key, pop of the trailing segment, lp of the trailing segment, uniform]
+__global__ __launch_bounds__(PGS_TILE) void k_pg_scan_tiles(PG pg, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n) {
+    __shared__ uint32_t s_key[PGS_TILE], s_pop[PGS_TILE], s_lp[PGS_TILE];
+    const uint32_t t = threadIdx.x, e = blockIdx.x * PGS_TILE + t;
+    const bool valid = e < n;
+    uint32_t key = valid ? keys[e] : 0xFFFFFFFFu, pop = 0, lp = 0;
+    if (valid) { uint32_t ip; pg_entry_fields(pg, vals[e], pop, ip); lp = ip ? e + 1 : 0u; }
+    pg_tile_scan(key, pop, lp, s_key, s_pop, s_lp);
+    const uint32_t last = min(n - blockIdx.x * PGS_TILE, (uint32_t)PGS_TILE) - 1;
+    if (t == last) {
+        uint32_t* a = pg.tile_agg + 5 * (size_t)blockIdx.x;
+        a[0] = s_key[0]; a[1] = key; a[2] = pop; a[3] = lp; a[4] = s_key[0] == key;
+    }
+}
+__global__ __launch_bounds__(PGS_TILE) void k_pg_scan_apply(PG pg, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t n_bodies) {
+    __shared__ uint32_t s_key[PGS_TILE], s_pop[PGS_TILE], s_lp[PGS_TILE];
+    __shared__ uint32_t c_pop, c_lp;
+    const uint32_t t = threadIdx.x, e = blockIdx.x * PGS_TILE + t;
+    const bool valid = e < n;
+    const uint32_t key = valid ? keys[e] : 0xFFFFFFFFu;
+    const uint32_t val = valid ? vals[e] : 0u;
+    uint32_t own_pop = 0, own_push = 0;
+    if (valid) pg_entry_fields(pg, val, own_pop, own_push);
+    uint32_t pop = own_pop, lp = own_push ? e + 1 : 0u;
+    if (t == 0) {   // carry of the tile's first segment from the tiles before it (not for the "no body" key: nobody reads those)
+        uint32_t cp = 0, cl = 0;
+        if (blockIdx.x && key < n_bodies) {
+            for (uint32_t b = blockIdx.x; b-- > 0;) {
+                const uint32_t* a = pg.tile_agg + 5 * (size_t)b;
+                if (a[1] != key) break;
+                cp |= a[2]; if (!cl) cl = a[3];
+                if (!a[4]) break;
+            }
+        }
+        c_pop = cp; c_lp = cl;
+    }
+    pg_tile_scan(key, pop, lp, s_key, s_pop, s_lp);
+    if (!valid) return;
+    // inclusive -> exclusive inside the segment
+    uint32_t ex_pop = 0, ex_lp = 0;
+    if (t > 0 && s_key[t - 1] == key) { ex_pop = s_pop[t - 1]; ex_lp = s_lp[t - 1]; }
+    if (s_key[0] == key) { ex_pop |= c_pop; if (!ex_lp) ex_lp = c_lp; }   // still the tile's first segment
+    pg.epos[val] = e;
+    pg.popbefore[e] = ex_pop;
+    pg.prevpush[e] = ex_lp;
+    pg.est[e] = 0u;
+}
+uint32_t pg_scan_tiles(uint32_t n_entries) { return (n_entries + PGS_TILE - 1) / PGS_TILE; }
+void launch_pg_entry_scan(const PG& pg, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t n_bodies, hipStream_t s) {
+    if (!n) return;
+    const uint32_t nb = pg_scan_tiles(n);
+    hipLaunchKernelGGL(k_pg_scan_tiles, dim3(nb), dim3(PGS_TILE), 0, s, pg, keys, vals, n);
+    hipLaunchKernelGGL(k_pg_scan_apply, dim3(nb), dim3(PGS_TILE), 0, s, pg, keys, vals, n, n_bodies);
+}
+
+// ---- ConstraintGraph::push_manifold: the greedy colour of every push, in op order (dataflow) ----------------------------------
+__device__ __forceinline__ uint32_t pg_pick_color(bool s1, bool s2, uint32_t mask1, uint32_t mask2) {
+    if (!s1 && !s2) {   // lowest colour of 0..DYNAMIC_COLOR_COUNT-1 free on both bodies (constraint_graph.rs:181-196)
+        const uint32_t free_bits = ~(mask1 | mask2) & ((1u << AVN_DYNAMIC_COLOR_COUNT) - 1u);
+        return free_bits ? (uint32_t)__ffs((int)free_bits) - 1u : (uint32_t)AVN_COLOR_OVERFLOW_INDEX;
+    }
+    // next to a static body: highest free colour of COLOR_OVERFLOW_INDEX-1 .. 1 on the non-static body (:197-222)
+    const uint32_t m = s1 ? mask2 : mask1;
+    const uint32_t free_bits = ~m & (((1u << AVN_COLOR_OVERFLOW_INDEX) - 1u) & ~1u);
+    return free_bits ? 31u - (uint32_t)__clz((int)free_bits) : (uint32_t)AVN_COLOR_OVERFLOW_INDEX;
+}
+__global__ __launch_bounds__(64) void k_pg_color(PG pg, uint32_t n_ops) {
+    __shared__ uint32_t s_tile;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) s_tile = atomicAdd(&pg.ctr[PGC_TILE], 1u);   // tiles are taken in start order: a lane only waits for lanes of running waves
+    __syncthreads();
+    const uint32_t k = s_tile * 64u + lane;
+    uint32_t info = 0;
+    if (k < n_ops) info = pg.op_info[k];
+    const bool active = (info & 3u) == PG_KIND_PUSH;
+    const bool s1 = info & 4u, s2 = info & 8u;
+    uint32_t e[2] = {0, 0}, pp[2] = {0, 0}, base[2] = {0, 0};
+    bool side[2] = {false, false};
+    if (active) {
+        const int2 b = pg.op_bodies[k];
+        side[0] = !s1; side[1] = !s2;
+        for (int s = 0; s < 2; ++s)
+            if (side[s]) {
+                e[s] = pg.epos[2 * k + s];
+                pp[s] = pg.prevpush[e[s]];
+                base[s] = pg.bcol[s ? b.y : b.x] & ~pg.popbefore[e[s]];   // the body's mask with this step's earlier pops applied
+            }
+    }
+    bool done = !active;
+    uint32_t color = 0xFFu;
+    for (uint32_t it = 0;; ++it) {
+        if (!done) {
+            uint32_t taken[2] = {0, 0};
+            bool ready = true;
+            for (int s = 0; s < 2; ++s)
+                if (side[s] && pp[s]) {
+                    const uint32_t v = ld_agent(&pg.est[pp[s] - 1u]);
+                    if (!(v & PG_EST_DONE)) ready = false;
+                    taken[s] = v & ~PG_EST_DONE;
+                }
+            if (ready) {
+                color = pg_pick_color(s1, s2, base[0] | taken[0], base[1] | taken[1]);
+                const uint32_t bit = color < (uint32_t)AVN_COLOR_OVERFLOW_INDEX ? (1u << color) : 0u;   // the overflow colour has no body set
+                for (int s = 0; s < 2; ++s)
+                    if (side[s]) st_agent(&pg.est[e[s]], taken[s] | bit | PG_EST_DONE);
+                pg.op_info[k] = (info & 0xFFu) | (color << 8);
+                done = true;
+            }
+        }
+        if (__all(done)) break;
+        if (it > PG_SPIN_LIMIT) { if (lane == 0) atomicOr(&pg.ctr[PGC_ERROR], 1u); break; }
+        __builtin_amdgcn_s_sleep(1);
+    }
+    // this step's pushes per colour (with the pops counted by k_pg_classify: the bucket sizes of the replay)
+    for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        const unsigned long long m = __ballot(active && color == c);
+        if (m && lane == 0) { atomicAdd(&pg.ctr[PGC_BUCKET + c], (uint32_t)__popcll(m)); atomicAdd(&pg.ctr[PGC_N_PUSH], (uint32_t)__popcll(m)); }
+    }
+}
+void launch_pg_color(const PG& pg, uint32_t n_ops, hipStream_t s) {
+    (void)hipMemsetAsync(pg.ctr + PGC_TILE, 0, sizeof(uint32_t), s);
+    if (n_ops) hipLaunchKernelGGL(k_pg_color, dim3((n_ops + 63) / 64), dim3(64), 0, s, pg, n_ops);
+}
+// body masks after the step's ops: (mask & ~freed by pops) | taken by pushes -- a push only ever takes a bit that is free at its
+// time and a pop only frees a bit an OLDER manifold holds (every contact id has at most one op per step), so the order inside
+// the step does not matter for the final mask
+__global__ __launch_bounds__(256) void k_pg_apply_masks(PG pg, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n, uint32_t n_bodies) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const uint32_t key = keys[e];
+    if (key >= n_bodies) return;
+    if (e + 1 < n && keys[e + 1] == key) return;   // not the segment's last entry
+    uint32_t own_pop, own_push;
+    pg_entry_fields(pg, vals[e], own_pop, own_push);
+    const uint32_t freed = pg.popbefore[e] | own_pop;
+    const uint32_t lp = own_push ? e + 1 : pg.prevpush[e];
+    const uint32_t taken = lp ? (pg.est[lp - 1u] & ~PG_EST_DONE) : 0u;
+    pg.bcol[key] = (pg.bcol[key] & ~freed) | taken;
+}
+void launch_pg_apply_masks(const PG& pg, const uint32_t* keys, const uint32_t* vals, uint32_t n, uint32_t n_bodies, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pg_apply_masks, dim3((n + 255) / 256), dim3(256), 0, s, pg, keys, vals, n, n_bodies);
+}
+
+// ---- per-colour op sequences + exact replay of push / swap_remove ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_pg_bucket_keys(PG pg, uint32_t n_ops) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ops) return;
+    const uint32_t info = pg.op_info[k];
+    pg.ckey_a[k] = (info & 3u) == PG_KIND_NONE ? (uint32_t)AVN_GRAPH_COLOR_COUNT : ((info >> 8) & 0xFFu);
+    pg.cval_a[k] = k;
+}
+void launch_pg_bucket_keys(const PG& pg, uint32_t n_ops, hipStream_t s) {
+    if (n_ops) hipLaunchKernelGGL(k_pg_bucket_keys, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, n_ops);
+}
+// One wave per colour.  See tools/experiments/replay_batches.py for the rule: with h_t the list length before op t of a batch,
+// a push writes position h_t and a pop vacates position h_t - 1 (its content fills the hole the popped handle leaves).  While
+// every pop's handle sits BELOW the lowest position the batch's pushes / vacates touch, holes and moving tail never meet: the
+// filler of a pop is the list entry at h_t - 1 as of the batch start, or the handle of the latest earlier push of the batch at
+// that height, and all lanes apply their op at once.  The first op that breaks the rule runs alone, serially.
+__global__ __launch_bounds__(64) void k_pg_replay(PG pg, const uint32_t* __restrict__ order) {
+    __shared__ uint32_t s_cons[64];
+    const uint32_t c = blockIdx.x, lane = threadIdx.x;
+    uint32_t b0 = 0;
+    for (uint32_t i = 0; i < c; ++i) b0 += pg.ctr[PGC_BUCKET + i];
+    const uint32_t b1 = b0 + pg.ctr[PGC_BUCKET + c];
+    uint32_t* __restrict__ list = pg.lists + (size_t)c * pg.list_stride;
+    uint32_t L = pg.ctr[PGC_LEN + c];
+    uint32_t cur = b0;
+    while (cur < b1) {
+        const uint32_t n = min(64u, b1 - cur);
+        const bool valid = lane < n;
+        uint32_t x = 0; bool push = false;
+        if (valid) { const uint32_t k = order[cur + lane]; x = pg.op_cid[k]; push = (pg.op_info[k] & 3u) == PG_KIND_PUSH; }
+        const bool pop = valid && !push;
+        const int delta = valid ? (push ? 1 : -1) : 0;
+        const int incl = wave_incl_add(delta, lane);
+        const uint32_t h = (uint32_t)((int)L + incl - delta);              // list length before this lane's op
+        const uint32_t touch = valid ? (push ? h : h - 1u) : 0xFFFFFFFFu;
+        const uint32_t P = pop ? ld_wg(&pg.lpos[x]) : 0u;                  // ContactConstraintHandle::local_index
+        const uint32_t lomin = wave_incl_min(touch, lane), pmax = wave_incl_max(pop ? P + 1u : 0u, lane);
+        const unsigned long long cf = __ballot(valid && pmax > lomin);
+        const uint32_t f = cf ? (uint32_t)__ffsll((long long)cf) - 1u : n;   // ops [0, f) are conflict-free
+        if (f == 0) {   // the batch's first op alone: the serial statement of the reference
+            if (lane == 0) {
+                if (push) { list[L] = x; pg.lpos[x] = L; pg.color[x] = c; }
+                else {
+                    const uint32_t last = ld_wg(&list[L - 1u]);
+                    if (P != L - 1u) { list[P] = last; pg.lpos[last] = P; }   // swap_remove + "fix moved manifold handle"
+                    pg.color[x] = PG_NONE;
+                }
+            }
+            L = (uint32_t)((int)L + __shfl(delta, 0));
+            cur += 1;
+        } else {
+            const bool in = lane < f;
+            // stack matching: the latest earlier push of the batch that wrote the position this pop vacates
+            int match = -1;
+            for (uint32_t s = 0; s + 1 < f; ++s) {
+                const bool ps = __shfl((int)push, (int)s) != 0;
+                const uint32_t hs = (uint32_t)__shfl((int)h, (int)s);
+                if (in && pop && s < lane && ps && hs == h - 1u) match = (int)s;
+            }
+            s_cons[lane] = 0u;
+            __syncthreads();
+            if (in && pop && match >= 0) s_cons[match] = 1u;
+            __syncthreads();
+            const uint32_t ym = (uint32_t)__shfl((int)x, match >= 0 ? match : 0);
+            // every filler is read from the list AS OF THE BATCH START: all loads of all lanes are performed before any lane stores
+            // (a later push of the batch may write the very position an earlier pop vacates)
+            uint32_t y0 = 0;
+            if (in && pop && match < 0) y0 = ld_wg(&list[h - 1u]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (in && pop) {
+                const uint32_t y = match >= 0 ? ym : y0;
+                list[P] = y; pg.lpos[y] = P;
+                pg.color[x] = PG_NONE;
+            } else if (in && push) {
+                pg.color[x] = c;
+                if (!s_cons[lane]) { list[h] = x; pg.lpos[x] = h; }   // (a consumed push's handle already moved into a pop's hole)
+            }
+            L = (uint32_t)__shfl((int)h + delta, (int)(f - 1u));
+            cur += f;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the batch's stores are performed before the next batch's loads
+        __syncthreads();
+    }
+    if (lane == 0) pg.ctr[PGC_LEN + c] = L;
+}
+void launch_pg_replay(const PG& pg, const uint32_t* order, hipStream_t s) {
+    hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, order);
+}
+
+// ---- removed pairs: ContactGraph::remove_edge_by_id + IdPool::free_id --------------------------------------------------------------
+__device__ __forceinline__ uint64_t pg_hs_mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_remove(PG pg, CT<T> ct, BP<T> bp, uint32_t n_ops) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n_ops || !pg.rem_flag[k]) return;
+    const uint32_t c = pg.op_cid[k];
+    pg.rem_ids[pg.rem_off[k]] = c;   // ascending: ops are in id order
+    const uint4 meta = ct.meta[c];
+    const uint32_t a = bp.col_info[meta.x].x, b = bp.col_info[meta.y].x;   // collider entities -> PairKey
+    const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+    ct.meta[c] = make_uint4(0u, 0u, 0u, 0u);
+    ct.dcount[c] = 0;
+    pg.color[c] = PG_NONE;
+    if (bp.pair_set_cap) {
+        const uint32_t mask = bp.pair_set_cap - 1u;
+        uint32_t h = (uint32_t)pg_hs_mix(key) & mask;
+        for (;;) {
+            const uint64_t v = bp.pair_set[h];
+            if (v == key) { bp.pair_set[h] = ~0ull - 1ull; break; }   // tombstone
+            if (v == ~0ull) break;
+            h = (h + 1u) & mask;
+        }
+    }
+}
+template <class T> void launch_pg_remove(const PG& pg, const CT<T>& ct, const BP<T>& bp, uint32_t n_ops, hipStream_t s) {
+    if (n_ops) hipLaunchKernelGGL(k_pg_remove<T>, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, ct, bp, n_ops);
+}
+// free list (ascending) <- merge(live part of the free list, removed ids (ascending)); both inputs are duplicate-free and disjoint
+__global__ __launch_bounds__(256) void k_pg_merge_free(PG pg, uint32_t head, uint32_t n_free, uint32_t n_rem) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t* __restrict__ A = pg.free_ids + head;
+    const uint32_t* __restrict__ B = pg.rem_ids;
+    if (i < n_free) {
+        const uint32_t v = A[i];
+        uint32_t lo = 0, hi = n_rem;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (B[mid] < v) lo = mid + 1; else hi = mid; }
+        pg.free_alt[i + lo] = v;
+    } else if (i < n_free + n_rem) {
+        const uint32_t j = i - n_free, v = B[j];
+        uint32_t lo = 0, hi = n_free;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (A[mid] < v) lo = mid + 1; else hi = mid; }
+        pg.free_alt[j + lo] = v;
+    }
+    if (i == 0) { pg.ctr[PGC_FREE_HEAD] = 0; pg.ctr[PGC_N_FREE] = n_free + n_rem; }
+}
+void launch_pg_merge_free(const PG& pg, uint32_t head, uint32_t n_free, uint32_t n_rem, hipStream_t s) {
+    hipLaunchKernelGGL(k_pg_merge_free, dim3((n_free + n_rem + 255) / 256 + 1), dim3(256), 0, s, pg, head, n_free, n_rem);
+}
+
+// ---- GraphColor::manifold_handles of all colours, concatenated colour-major (what the solver's arrays are ordered by) ---------
+__global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __restrict__ handles, uint32_t* __restrict__ color_offsets, uint32_t total) {
+    __shared__ uint32_t off[AVN_GRAPH_COLOR_COUNT + 1];
+    if (threadIdx.x == 0) {
+        uint32_t a = 0;
+        for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { off[c] = a; a += pg.ctr[PGC_LEN + c]; }
+        off[AVN_GRAPH_COLOR_COUNT] = a;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0 && threadIdx.x <= AVN_GRAPH_COLOR_COUNT) { color_offsets[threadIdx.x] = off[threadIdx.x]; pg.ctr[PGC_OFFSETS + threadIdx.x] = off[threadIdx.x]; }
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= total || m >= off[AVN_GRAPH_COLOR_COUNT]) return;
+    uint32_t lo = 0, hi = AVN_GRAPH_COLOR_COUNT;   // colour c: off[c] <= m < off[c + 1]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= m) lo = mid; else hi = mid; }
+    handles[m] = pg.lists[(size_t)lo * pg.list_stride + (m - off[lo])];
+}
+void launch_pg_build_handles(const PG& pg, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t s) {
+    hipLaunchKernelGGL(k_pg_build_handles, dim3((total + 255) / 256 + 1), dim3(256), 0, s, pg, handles, color_offsets, total);
+}
+
+// ---- ContactGraph::pair_set rebuilt from the live rows (after growth, or when tombstones pile up) ------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_rebuild_pair_set(CT<T> ct, BP<T> bp, uint32_t n_rows) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_rows) return;
+    const uint4 meta = ct.meta[c];
+    if (!(meta.z & AVN_CP_ROW_USED)) return;
+    const uint32_t a = bp.col_info[meta.x].x, b = bp.col_info[meta.y].x;
+    const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+    const uint32_t mask = bp.pair_set_cap - 1u;
+    uint32_t h = (uint32_t)pg_hs_mix(key) & mask;
+    for (;;) {
+        const unsigned long long prev = atomicCAS((unsigned long long*)&bp.pair_set[h], ~0ull, (unsigned long long)key);
+        if (prev == ~0ull || prev == key) return;
+        h = (h + 1u) & mask;
+    }
+}
+template <class T> void launch_pg_rebuild_pair_set(const CT<T>& ct, const BP<T>& bp, uint32_t n_rows, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_pg_rebuild_pair_set<T>, dim3((n_rows + 255) / 256), dim3(256), 0, s, ct, bp, n_rows);
+}
+
+// ---- the overflow colour on the device ------------------------------------------------------------------------------------------
+// The reference solves colour 23 serially in list order (solver/plugin.rs:461-467).  Only the relative order of the manifolds
+// that share a body matters, so the device needs, per body with a SolverBody, its overflow manifolds in list order: the CSR
+// of the body-centric warm start (DW::inc_off / inc_ent), whose positions inside a body's segment are also the manifold's RANKS
+// for the dataflow passes (k_overflow_flow, k_contacts.hip).
+template <class T>
+__global__ __launch_bounds__(256) void k_ovf_entries(DW<T> w, uint32_t o0, uint32_t n23, uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n23) return;
+    const int2 b = w.m_bodies[o0 + i];
+    keys[2 * i] = meta_has_solver_body(w.bmeta[b.x]) ? (uint32_t)b.x : w.n_bodies;
+    keys[2 * i + 1] = meta_has_solver_body(w.bmeta[b.y]) ? (uint32_t)b.y : w.n_bodies;
+    vals[2 * i] = i; vals[2 * i + 1] = i | 0x80000000u;
+}
+template <class T> void launch_ovf_entries(const DW<T>& w, uint32_t o0, uint32_t n23, uint32_t* keys, uint32_t* vals, hipStream_t s) {
+    if (n23) hipLaunchKernelGGL(k_ovf_entries<T>, dim3((n23 + 255) / 256), dim3(256), 0, s, w, o0, n23, keys, vals);
+}
+__global__ __launch_bounds__(256) void k_ovf_offsets(const uint32_t* __restrict__ keys, uint32_t n_e, uint32_t n_bodies, uint32_t* __restrict__ inc_off) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b > n_bodies) return;
+    uint32_t lo = 0, hi = n_e;   // first sorted entry with key >= b
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (keys[mid] < b) lo = mid + 1; else hi = mid; }
+    inc_off[b] = lo;
+}
+__global__ __launch_bounds__(256) void k_ovf_post(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t n_e, uint32_t n_bodies, uint32_t o0,
+                                                  const uint32_t* __restrict__ inc_off, uint32_t* __restrict__ inc_ent, uint32_t* __restrict__ rank) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_e) return;
+    const uint32_t key = keys[e], val = vals[e];
+    const uint32_t i = val & 0x7FFFFFFFu, side = val >> 31;
+    if (key >= n_bodies) { rank[2 * i + side] = PG_NONE; return; }
+    inc_ent[e] = (o0 + i) | (side << 31);
+    rank[2 * i + side] = e - inc_off[key];
+}
+template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t s) {
+    hipLaunchKernelGGL(k_ovf_offsets, dim3((w.n_bodies + 256) / 256), dim3(256), 0, s, keys, 2 * n23, w.n_bodies, inc_off);
+    if (n23) hipLaunchKernelGGL(k_ovf_post, dim3((2 * n23 + 255) / 256), dim3(256), 0, s, keys, vals, 2 * n23, w.n_bodies, o0, inc_off, inc_ent, rank);
+}
+
+#define INST(T)                                                                                                         \
+    template void launch_pg_add_pairs<T>(const PG&, const CT<T>&, const avn_pair*, uint32_t, hipStream_t);              \
+    template void launch_pg_remove<T>(const PG&, const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                    \
+    template void launch_pg_rebuild_pair_set<T>(const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                     \
+    template void launch_ovf_entries<T>(const DW<T>&, uint32_t, uint32_t, uint32_t*, uint32_t*, hipStream_t);           \
+    template void launch_ovf_csr<T>(const DW<T>&, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace avn

@@ -103,13 +103,18 @@ template <class T> __device__ int np_prune_points(const NpPt<T>* pts, V3<T> norm
     return k;
 }
 
-template <class T>
+// DENSE = false: the pairs are active[0 .. n_active), changes are appended to `changes` in arbitrary order (the host sorts them).
+// DENSE = true (device closed loop, k_graph.hip): every row id < n_active with AVN_CP_ROW_USED is a pair; a row's change is left in
+// chg[id] / has[id] (`changes` / `n_changes` reinterpreted), so that a scan over the rows numbers the changes in ascending ContactId.
+template <class T, bool DENSE>
 __global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
-                                                     avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes) {
+                                                     avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
+                                                     uint32_t* __restrict__ has) {
     uint32_t a = blockIdx.x * 64 + threadIdx.x;
     if (a >= n_active) return;
-    const uint32_t c = active[a];
+    const uint32_t c = DENSE ? a : active[a];
     uint4 meta = ct.meta[c];
+    if (DENSE && !(meta.z & AVN_CP_ROW_USED)) { chg[c] = 0u; has[c] = 0u; return; }
     const uint32_t slot1 = meta.x, slot2 = meta.y;
     uint32_t flags = meta.z;
     const uint32_t old_nman = meta.w & 0xFFu, old_pc = (meta.w >> 8) & 0xFFu;
@@ -227,10 +232,14 @@ __global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct
         else if (!touching && was_touching) { flags |= AVN_CP_STOPPED_TOUCHING; status = true; }
         else if (dcount != 0) status = true;
     }
-    if (status) {
+    if (DENSE) {
+        chg[c] = status ? ((flags & 0xFFFFu) | (n_manifolds << 16) | (((uint32_t)(dcount + 128) & 0xFFu) << 24)) : 0u;
+        has[c] = status ? 1u : 0u;
+        if (flags & AVN_CP_DISJOINT_AABB) atomicAdd(n_changes, 1u);   // rows to remove (here `n_changes` is the removal counter)
+    } else if (status) {
         uint32_t slot = atomicAdd(n_changes, 1u);
         avn_contact_change ch;
-        ch.contact_id = c; ch.flags = flags; ch.manifold_count_change = dcount; ch.manifold_count = n_manifolds;
+        ch.contact_id = c; ch.flags = flags & ~(uint32_t)AVN_CP_ROW_USED; ch.manifold_count_change = dcount; ch.manifold_count = n_manifolds;
         changes[slot] = ch;
     }
     // the transient status flags are handled (and cleared) by the host's status processing, system_param.rs:141-389
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(256) void k_init_contact_rows(CT<T> ct, const uint3
     uint32_t f = pf[i];
     uint32_t flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
                      ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u);
-    ct.meta[ids[i]] = make_uint4(s1[i], s2[i], flags, 0u);
+    ct.meta[ids[i]] = make_uint4(s1[i], s2[i], flags | AVN_CP_ROW_USED, 0u);
     ct.dcount[ids[i]] = 0;
 }
 template <class T>
@@ -289,7 +298,7 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     const uint32_t c = ids[i];
     const uint4 meta = ct.meta[c];
     const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
-    if (o.flags) o.flags[i] = meta.z;
+    if (o.flags) o.flags[i] = meta.z & ~(uint32_t)AVN_CP_ROW_USED;
     if (o.point_count) o.point_count[i] = (uint8_t)np;
     Vec4<T> n4 = np ? ct.n[c] : make4<T>(0, 0, 0, 0), tv = np ? ct.tv[c] : make4<T>(0, 0, 0, 0);
     st3(o.normal, i, xyz<T>(n4));
@@ -320,7 +329,12 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
     (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
-    if (n_active) hipLaunchKernelGGL(k_narrow_phase<T>, dim3((n_active + 63) / 64), dim3(64), 0, st, w, bp, ct, p, active, n_active, changes, n_changes);
+    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + 63) / 64), dim3(64), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr);
+}
+template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
+                                                  uint32_t* n_remove, hipStream_t st) {
+    (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
+    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + 63) / 64), dim3(64), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has);
 }
 template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);
@@ -335,6 +349,7 @@ template <class T> void launch_unpack_contacts(const CT<T>& ct, const uint32_t* 
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
+    template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_manifolds<T>(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                  \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
     template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);

@@ -500,7 +500,12 @@ AVN_API avn_status AVN_FN(contacts_download)(avn_world* w, const uint32_t* conta
  * processing of NarrowPhase::update (narrow_phase/system_param.rs:141-389) and the ConstraintGraph
  * (solver/constraint_graph.rs:163-296) — and avn_step becomes the whole PhysicsSchedule pass over the path:
  *   UPDATE_AABB -> COLLECT_COLLISION_PAIRS -> (new rows) -> NARROW_PHASE -> (status changes -> push / pop -> handles) -> SOLVER.
- * An Avian integration does NOT use this: it forwards its own structures' changes through the calls above. */
+ * An Avian integration does NOT use this: it forwards its own structures' changes through the calls above.
+ * avn_pipeline_enable(w, 1): ALL of that bookkeeping runs on the device (k_graph.hip: ids in emission order, the status-change loop in
+ *   ascending ContactId, the greedy colouring and the push / swap_remove order of every colour list replayed exactly, the overflow
+ *   colour solved in list order by a dataflow pass); per step the host reads three small counter blocks.
+ * avn_pipeline_enable(w, 2) (or AVN_PIPELINE_HOST=1): the same loop with host-side structures (round-1 path, kept for A/B runs).
+ * avn_pipeline_enable(w, 0): off. */
 typedef struct avn_pipeline_stats {
     uint64_t pairs_added, pairs_removed, manifolds_pushed, manifolds_popped;  /* since avn_pipeline_enable */
     uint32_t active_pairs, manifolds;      /* now */

@@ -1944,9 +1944,21 @@ template <class S> avn_status World<S>::pipeline_step() {
         P.handles_dirty = true; ++P.stats.manifolds_popped;
     };
     std::vector<uint32_t> removed;
+    // AVO_PIPE_STATS=1 (debug aid for the device constraint graph's design): shape of this step's push / pop sequence
+    static const bool pipe_stats_on = std::getenv("AVO_PIPE_STATS") != nullptr;
+    struct OpRec { uint8_t push; uint8_t color; uint32_t b1, b2, pos, len; bool s1, s2; };
+    std::vector<OpRec> oprecs;
     for (const avn_contact_change& c : contact_changes) {
         uint32_t cid = c.contact_id, flags = c.flags;
         bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+        if (pipe_stats_on) {
+            PipelineState::Pair& p = P.pairs[cid];
+            bool is_pop = (flags & AVN_CP_DISJOINT_AABB) ? (generates && p.n_handles) : (flags & AVN_CP_STARTED_TOUCHING) ? false : (flags & AVN_CP_STOPPED_TOUCHING) ? (generates && p.n_handles)
+                          : false;
+            bool is_push = !(flags & AVN_CP_DISJOINT_AABB) && (((flags & AVN_CP_STARTED_TOUCHING) && generates) || (!(flags & AVN_CP_STARTED_TOUCHING) && !(flags & AVN_CP_STOPPED_TOUCHING) && touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)));
+            if (is_pop) { auto it = P.graph.where.find(((uint64_t)cid << 8) | (p.n_handles - 1)); oprecs.push_back({0, it->second.color, (uint32_t)p.b1, (uint32_t)p.b2, it->second.local_index, (uint32_t)P.graph.colors[it->second.color].manifold_handles.size(), (bool)(flags & AVN_CP_STATIC1), (bool)(flags & AVN_CP_STATIC2)}); }
+            else if (is_push) oprecs.push_back({1, 255, (uint32_t)p.b1, (uint32_t)p.b2, 0, 0, (bool)(flags & AVN_CP_STATIC1), (bool)(flags & AVN_CP_STATIC2)});
+        }
         if (flags & AVN_CP_DISJOINT_AABB) {
             if (generates) while (P.pairs[cid].n_handles) pop(cid);
             removed.push_back(cid);
@@ -1986,6 +1998,52 @@ template <class S> avn_status World<S>::pipeline_step() {
         P.handles_dirty = false;
     }
     P.stats.last_overflow_manifolds = P.offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - P.offsets[AVN_COLOR_OVERFLOW_INDEX];
+    if (pipe_stats_on) {
+        // dependency-round depth of the op sequence (ops sharing a non-static body are ordered), pops per colour, pops that hit
+        // the tail window of their colour's list, level depth of the overflow colour
+        std::unordered_map<uint32_t, uint32_t> depth_of_body;
+        uint32_t max_depth = 0, n_push = 0, n_pop = 0, pops_c[AVN_GRAPH_COLOR_COUNT] = {0}, win_pops = 0;
+        for (const OpRec& o : oprecs) {
+            uint32_t d = 0;
+            if (!o.s1) d = std::max(d, depth_of_body[o.b1]);
+            if (!o.s2) d = std::max(d, depth_of_body[o.b2]);
+            ++d;
+            if (!o.s1) depth_of_body[o.b1] = d;
+            if (!o.s2) depth_of_body[o.b2] = d;
+            max_depth = std::max(max_depth, d);
+            if (o.push) ++n_push; else { ++n_pop; ++pops_c[o.color]; }
+        }
+        for (const OpRec& o : oprecs) if (!o.push && o.pos + pops_c[o.color] >= o.len) ++win_pops;
+        uint32_t push_depth = 0;
+        {
+            std::unordered_map<uint32_t, uint32_t> pd;
+            for (const OpRec& o : oprecs) {
+                if (!o.push) continue;
+                uint32_t d = 0;
+                if (!o.s1) d = std::max(d, pd[o.b1]);
+                if (!o.s2) d = std::max(d, pd[o.b2]);
+                ++d;
+                if (!o.s1) pd[o.b1] = d;
+                if (!o.s2) pd[o.b2] = d;
+                push_depth = std::max(push_depth, d);
+            }
+        }
+        std::fprintf(stderr, "[avo pipe] push-only depth %u\n", push_depth);
+        uint32_t max_pops = 0; for (uint32_t x : pops_c) max_pops = std::max(max_pops, x);
+        std::unordered_map<uint32_t, uint32_t> lvl_of_body; uint32_t levels = 0;
+        for (const auto& h : P.graph.colors[AVN_COLOR_OVERFLOW_INDEX].manifold_handles) {
+            uint32_t l = 0;
+            const bool d1 = h.body1 < bodies.size() && bodies[h.body1].rb_type != AVN_RB_STATIC, d2 = h.body2 < bodies.size() && bodies[h.body2].rb_type != AVN_RB_STATIC;
+            if (d1) l = std::max(l, lvl_of_body[h.body1]);
+            if (d2) l = std::max(l, lvl_of_body[h.body2]);
+            ++l;
+            if (d1) lvl_of_body[h.body1] = l;
+            if (d2) lvl_of_body[h.body2] = l;
+            levels = std::max(levels, l);
+        }
+        std::fprintf(stderr, "[avo pipe] changes %zu push %u pop %u (overflow pops %u, max/colour %u, tail-window pops %u) op depth %u | manifolds %zu overflow %u levels %u | new pairs %zu removed %zu\n",
+                     contact_changes.size(), n_push, n_pop, pops_c[AVN_COLOR_OVERFLOW_INDEX], max_pops, win_pops, max_depth, P.handles.size(), P.stats.last_overflow_manifolds, levels, pairs.size(), removed.size());
+    }
     solver();
     return AVN_OK;
 }

@@ -1,0 +1,186 @@
+"""GPU: the closed loop with the ContactGraph / IdPool / ConstraintGraph bookkeeping ON THE DEVICE (k_graph.hip,
+avn_pipeline_enable(1)) against the oracle's serial restatement of the reference loops (IdPool data_structures/id_pool.rs:31-40,
+status-change loop collision/narrow_phase/system_param.rs:141-389, push_manifold / pop_manifold
+dynamics/solver/constraint_graph.rs:163-296): after EVERY step the colour lists (contact ids AND their order inside every colour:
+the swap_remove replay), the pipeline counters and the bodies must be identical, bit for bit."""
+import numpy as np
+import pytest
+
+from avian_amd import scenes
+from helpers import F, hip_lib, oracle_lib
+from pipeline_scenes import dropped_boxes
+from test_pipeline_cpu import make
+
+pytestmark = pytest.mark.gpu
+
+STATS = ("pairs_added", "pairs_removed", "manifolds_pushed", "manifolds_popped", "active_pairs", "manifolds", "last_status_changes", "last_overflow_manifolds")
+
+
+def first_diff(a, b):
+    n = min(len(a), len(b))
+    d = np.flatnonzero(a[:n] != b[:n])
+    return (int(d[0]) if len(d) else n), len(a), len(b)
+
+
+def compare_step(s, wo, wh, check_rows=False):
+    oo, oh = wo.pipeline_handles(), wh.pipeline_handles()
+    assert np.array_equal(oo[0], oh[0]), f"step {s}: colour offsets differ\noracle {oo[0]}\ndevice {oh[0]}"
+    if not np.array_equal(oo[1], oh[1]):
+        for c in range(24):
+            a, b = oo[1][oo[0][c]:oo[0][c + 1]], oh[1][oh[0][c]:oh[0][c + 1]]
+            if not np.array_equal(a, b):
+                same_set = np.array_equal(np.sort(a), np.sort(b))
+                raise AssertionError(f"step {s}: colour {c} list differs at {first_diff(a, b)} (same set: {same_set})")
+    so, sh = wo.pipeline_stats(), wh.pipeline_stats()
+    for f in STATS:
+        assert getattr(so, f) == getattr(sh, f), f"step {s}: stats.{f}: oracle {getattr(so, f)} device {getattr(sh, f)}"
+    bo, bh = wo.bodies_download(), wh.bodies_download()
+    for k in bo:
+        assert np.array_equal(bo[k], bh[k]), f"step {s}: bodies.{k} differs (max |d| {np.abs(bo[k] - bh[k]).max()})"
+    if check_rows and len(oh[1]):
+        ids = np.unique(oh[1])
+        ro, rh = wo.contacts_download(ids), wh.contacts_download(ids)
+        for k in ro:
+            assert np.array_equal(ro[k], rh[k]), f"step {s}: contact rows {k} differ"
+
+
+def pair(bits, bodies, colliders, substeps=4, use_graph=None):
+    out = []
+    for lib in (oracle_lib(), hip_lib()):
+        w, _ = make(lib, bits, bodies, colliders, substeps)
+        w.pipeline_enable()
+        out.append(w)
+    return out
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_dropped_pile_device_graph_matches_oracle_every_step(bits):
+    bodies, colliders = dropped_boxes(seed=21, n=80)
+    wo, wh = pair(bits, bodies, colliders)
+    for s in range(60):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh, check_rows=(s % 10 == 9))
+    sh = wh.pipeline_stats()
+    assert sh.manifolds_pushed > 80 and sh.manifolds_popped > 0
+    assert sh.last_host_ms < 5.0
+
+
+def test_pairs_removed_and_ids_reused_like_the_oracle():
+    """Bodies fly apart (pairs removed, ids freed) while others keep colliding (new pairs take the LOWEST free ids)."""
+    bodies, colliders = dropped_boxes(seed=5, n=48, balls=True)
+    bodies["linear_velocity"][1:25] = [[5.0, 1.0, 0.0]] * 24
+    bodies["linear_velocity"][25:] = [[-4.0, 0.5, 1.0]] * 24
+    wo, wh = pair(32, bodies, colliders)
+    for s in range(90):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+    st = wh.pipeline_stats()
+    assert st.pairs_removed > 10 and st.pairs_added > st.active_pairs, "the scene must free ids and allocate again afterwards"
+
+
+def test_churning_pile_replays_swap_remove_exactly():
+    """300 tumbling boxes / balls: hundreds of pushes and pops per step in every colour, lists short enough that the moving tail
+    and the holes meet (the serial path of k_pg_replay), tile-spanning body segments in the colouring's entry scan."""
+    bodies, colliders = dropped_boxes(seed=3, n=300)
+    bodies["angular_velocity"][1:] *= 4.0
+    wo, wh = pair(32, bodies, colliders)
+    changes = 0
+    for s in range(45):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+        changes += wh.pipeline_stats().last_status_changes
+    assert changes > 1500
+
+
+def test_overflow_colour_dataflow_pass_matches_the_serial_reference_loop():
+    """A dense stack pushes thousands of manifolds into colour 23; the oracle solves it serially in list order
+    (solver/plugin.rs:461-467), the device with k_overflow_flow (per-body tickets): same bits, graph replay and direct launches."""
+    sc = scenes.box_stack(9, 8, 9)
+    for use_graph in (1, 0):
+        worlds = []
+        for lib in (oracle_lib(), hip_lib()):
+            cfg = F.default_config(32, substeps=4)
+            cfg.use_graph = use_graph
+            w = F.World(lib, cfg)
+            w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+            w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+            w.pipeline_enable()
+            worlds.append(w)
+        wo, wh = worlds
+        seen = 0
+        for s in range(10):
+            wo.step(); wh.step()
+            compare_step(s, wo, wh)
+            seen = max(seen, wh.pipeline_stats().last_overflow_manifolds)
+        assert seen > 300, "the scene must actually use colour 23"
+
+
+def test_restitution_pass_continues_the_overflow_epochs():
+    sc = scenes.box_stack(7, 7, 7)
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(32, substeps=3))
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.4, restitution=0.5)
+        w.pipeline_enable()
+        worlds.append(w)
+    wo, wh = worlds
+    for s in range(8):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+
+
+def test_host_and_device_bookkeeping_agree():
+    bodies, colliders = dropped_boxes(seed=9, n=120)
+    wd, _ = make(hip_lib(), 32, bodies, colliders); wd.pipeline_enable()
+    wh, _ = make(hip_lib(), 32, bodies, colliders); wh.pipeline_enable(host_bookkeeping=True)
+    for s in range(30):
+        wd.step(); wh.step()
+        od, oh = wd.pipeline_handles(), wh.pipeline_handles()
+        assert np.array_equal(od[0], oh[0]) and np.array_equal(od[1], oh[1]), f"step {s}"
+        bd, bh = wd.bodies_download(), wh.bodies_download()
+        for k in bd:
+            assert np.array_equal(bd[k], bh[k]), f"step {s}: bodies.{k}"
+
+
+def test_medium_stack_6400_boxes_first_steps():
+    """20 x 16 x 20 boxes: the first steps push ~70 k manifolds at once (colouring depth in the hundreds), then thousands of
+    pushes and pops per step with a deep overflow colour."""
+    sc = scenes.box_stack(20, 16, 20)
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(32, substeps=4))
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable()
+        worlds.append(w)
+    wo, wh = worlds
+    for s in range(10):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+    assert wh.pipeline_stats().manifolds > 25000
+
+
+def test_cfg2_closed_loop_22_steps_bit_identical_to_the_oracle(monkeypatch):
+    """BASELINE.json config 2 (100 000 cuboids, 4 substeps) closed loop, device bookkeeping: 1.24 M pairs, ~10^6 manifolds pushed in the
+    second step, ~2 * 10^5 status changes per step afterwards, an overflow colour of 2 * 10^5 manifolds that is hundreds of levels deep:
+    colour lists (with their order), counters, contact rows of a sample and all bodies equal the oracle's after every one of 22 steps."""
+    monkeypatch.setenv("AVO_THREADS", "16")
+    sc = scenes.box_stack(50, 40, 50)
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(32, substeps=4))
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable()
+        worlds.append(w)
+    wo, wh = worlds
+    for s in range(22):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+    ids = np.unique(wh.pipeline_handles()[1])[::97]
+    ro, rh = wo.contacts_download(ids), wh.contacts_download(ids)
+    for k in ro:
+        assert np.array_equal(ro[k], rh[k]), f"contact rows {k} differ"
+    st = wh.pipeline_stats()
+    assert st.manifolds > 300000 and st.pairs_removed > 1000 and st.last_host_ms < 1.0
