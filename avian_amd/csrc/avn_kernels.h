@@ -152,7 +152,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
        PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
-       PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
+       PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
 struct PG {
     uint32_t rows;          // capacity of the per-row arrays (= CT::cap)
     int2* bodies;           // [rows] ContactPair::body1 / body2
@@ -189,7 +189,7 @@ void launch_pg_entry_scan(const PG&, const uint32_t* keys, const uint32_t* vals,
 void launch_pg_color(const PG&, uint32_t n_ops, hipStream_t);
 void launch_pg_apply_masks(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
 void launch_pg_bucket_keys(const PG&, uint32_t n_ops, hipStream_t);
-void launch_pg_replay(const PG&, const uint32_t* order, hipStream_t);
+void launch_pg_replay(const PG&, const uint32_t* order, uint32_t n_ops, hipStream_t);
 template <class T> void launch_pg_remove(const PG&, const CT<T>&, const BP<T>&, uint32_t n_ops, hipStream_t);
 void launch_pg_merge_free(const PG&, uint32_t head, uint32_t n_free, uint32_t n_rem, hipStream_t);
 void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t);
@@ -198,7 +198,6 @@ template <class T> void launch_pg_rebuild_pair_set(const CT<T>&, const BP<T>&, u
 struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; };
 template <class T> void launch_ovf_entries(const DW<T>&, uint32_t o0, uint32_t n23, uint32_t* keys, uint32_t* vals, hipStream_t);
 template <class T> void launch_ovf_csr(const DW<T>&, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t);
-void overflow_flow_experiment_mode();
 void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles, uint32_t n_tiles, hipStream_t);
 template <class T> void launch_overflow_flow(const DW<T>&, const StepParams<T>&, int pass, const OverflowFlow&, uint32_t epoch, uint32_t grid_blocks, hipStream_t);
 // radix sort on the low `bits` bits of the keys (stable LSD, 8 bits per pass); the result is in (*keys_out, *vals_out)

@@ -1616,7 +1616,6 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status pipeline_device_reset() {
-        overflow_flow_experiment_mode();
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipStreamSynchronize(stream_bp));
         avn_status st;
@@ -1748,7 +1747,7 @@ template <class T> struct World : WorldBase {
             launch_pg_bucket_keys(pg, n_ops, stream);
             uint32_t *ck, *order;
             launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
-            launch_pg_replay(pg, order, stream);
+            launch_pg_replay(pg, order, n_ops, stream);
             launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
             if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
                 launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
@@ -1767,6 +1766,13 @@ template <class T> struct World : WorldBase {
             HIPCHK(hipStreamSynchronize(stream));
             t0 = std::chrono::steady_clock::now();
             if (h[32]) { error = "device constraint graph: the colouring's dataflow wait timed out"; return AVN_ERR_STATE; }
+            if (getenv("AVN_PG_REPLAY_STATS")) {
+                uint32_t d[96];
+                HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[avn replay] colour: ops/iterations/serial/reloads:");
+                for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (d[72 + c]) std::fprintf(stderr, " %d:%u/%u/%u/%u", c, d[72 + c], d[c], d[24 + c], d[48 + c]);
+                std::fprintf(stderr, "\n");
+            }
             if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
                 std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
                 std::vector<int2> bd(n_ops);

@@ -45,28 +45,32 @@ template <class T> __device__ __forceinline__ BodyView<T> global_bodies(const DW
 // dominant one (solver/plugin.rs:491-512).
 // Agent-scope accesses of one record (k_overflow_flow: lanes of different workgroups hand a body's velocities to each other inside
 // ONE launch; the XCDs' L2s are not coherent with each other, so these go to the coherence point component by component).
-__device__ uint32_t g_ovf_mode = 0;   // EXPERIMENT (AVN_OVF_MODE): 0 agent-scope accesses, 1 system-scope accesses, 2 agent + acquire fence after the ticket match
-template <class T> __device__ __forceinline__ Vec4<T> ld_rec_agent(const Vec4<T>* q) {
-    const T* f = reinterpret_cast<const T*>(q);
-    Vec4<T> r;
-    if (g_ovf_mode == 1) {
-        r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return r;
-    }
-    r.x = __hip_atomic_load(f + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.y = __hip_atomic_load(f + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    r.z = __hip_atomic_load(f + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r.w = __hip_atomic_load(f + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return r;
+// 16-byte agent-scope (sc1: write-through / L1-bypassing) accesses of one record through a buffer descriptor -- one instruction per
+// 16 bytes instead of four dword atomics (a dword sc1 store is one fabric write each), and, unlike inline asm, visible to the compiler's
+// vmcnt bookkeeping.  `base` is wave-uniform (the world's array), `byte_off` the record's offset (< 2^31: 32 B x 2^26 bodies).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define AVN_BUF_AUX_SC1 16
+template <class V> __device__ __forceinline__ __amdgpu_buffer_rsrc_t rec_rsrc(V* base) { return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7FFFFFFF, 0x00020000); }
+__device__ __forceinline__ Vec4<float> ld_rec_agent(Vec4<float>* base, size_t idx) {
+    const u32x4 r = __builtin_amdgcn_raw_buffer_load_b128(rec_rsrc(base), (int)(idx * sizeof(Vec4<float>)), 0, AVN_BUF_AUX_SC1);
+    return make4<float>(__uint_as_float(r.x), __uint_as_float(r.y), __uint_as_float(r.z), __uint_as_float(r.w));
 }
-template <class T> __device__ __forceinline__ void st_rec_agent(Vec4<T>* q, Vec4<T> v) {
-    T* f = reinterpret_cast<T*>(q);
-    if (g_ovf_mode == 1) {
-        __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        return;
-    }
-    __hip_atomic_store(f + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(f + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(f + 3, v.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ Vec4<double> ld_rec_agent(Vec4<double>* base, size_t idx) {
+    const __amdgpu_buffer_rsrc_t rs = rec_rsrc(base);
+    const u32x4 a = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * sizeof(Vec4<double>)), 0, AVN_BUF_AUX_SC1);
+    const u32x4 b = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(idx * sizeof(Vec4<double>) + 16), 0, AVN_BUF_AUX_SC1);
+    return make4<double>(__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z), __hiloint2double((int)b.y, (int)b.x), __hiloint2double((int)b.w, (int)b.z));
+}
+__device__ __forceinline__ void st_rec_agent(Vec4<float>* base, size_t idx, Vec4<float> v) {
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)}, rec_rsrc(base), (int)(idx * sizeof(Vec4<float>)), 0,
+                                           AVN_BUF_AUX_SC1);
+}
+__device__ __forceinline__ void st_rec_agent(Vec4<double>* base, size_t idx, Vec4<double> v) {
+    const __amdgpu_buffer_rsrc_t rs = rec_rsrc(base);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)__double2loint(v.x), (uint32_t)__double2hiint(v.x), (uint32_t)__double2loint(v.y), (uint32_t)__double2hiint(v.y)}, rs,
+                                           (int)(idx * sizeof(Vec4<double>)), 0, AVN_BUF_AUX_SC1);
+    __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)__double2loint(v.z), (uint32_t)__double2hiint(v.z), (uint32_t)__double2loint(v.w), (uint32_t)__double2hiint(v.w)}, rs,
+                                           (int)(idx * sizeof(Vec4<double>) + 16), 0, AVN_BUF_AUX_SC1);
 }
 template <class T, bool WITH_DELTA, int STRIDE, bool COH = false>
 __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
@@ -75,7 +79,7 @@ __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool n
     // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
     const size_t o = (size_t)idx * STRIDE;
     Vec4<T> l, a;
-    if (COH) { l = ld_rec_agent<T>(&bv.lin[o]); a = ld_rec_agent<T>(&bv.ang[o]); }   // (the velocities are the only records a contact pass writes)
+    if (COH) { l = ld_rec_agent(bv.lin, o); a = ld_rec_agent(bv.ang, o); }   // (the velocities are the only records a contact pass writes)
     else { l = bv.lin[o]; a = bv.ang[o]; }
     Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
     if (WITH_DELTA) { dp = bv.dp[o]; dq = bv.dq[o]; }
@@ -95,7 +99,7 @@ __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool n
 }
 template <class T, int STRIDE, bool COH = false> __device__ __forceinline__ void store_body(const BodyView<T>& bv, int idx, bool no_body, const BodyRef<T>& b) {
     if (no_body) return;  // writes to a DUMMY body are discarded
-    if (COH) { st_rec_agent<T>(&bv.lin[(size_t)idx * STRIDE], make4<T>(b.v, b.lin_w)); st_rec_agent<T>(&bv.ang[(size_t)idx * STRIDE], make4<T>(b.om, b.ang_w)); return; }
+    if (COH) { st_rec_agent(bv.lin, (size_t)idx * STRIDE, make4<T>(b.v, b.lin_w)); st_rec_agent(bv.ang, (size_t)idx * STRIDE, make4<T>(b.om, b.ang_w)); return; }
     bv.lin[(size_t)idx * STRIDE] = make4<T>(b.v, b.lin_w);
     bv.ang[(size_t)idx * STRIDE] = make4<T>(b.om, b.ang_w);
 }
@@ -684,7 +688,6 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
                                (r2 == 0xFFFFFFFFu || __hip_atomic_load(&of.ticket[b.y], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == t2);
             if (ready) {
                 asm volatile("" ::: "memory");
-                if (g_ovf_mode == 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 pass_one<T, PASS, true>(w, p, m);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the velocity stores are performed before the tickets move
                 if (r1 != 0xFFFFFFFFu) __hip_atomic_fetch_add(&of.ticket[b.x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -693,8 +696,8 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
             }
         }
         if (__all(done)) break;
-        if (it > (1u << 22)) { if (lane == 0) atomicOr(of.error, 2u); break; }
-        __builtin_amdgcn_s_sleep(1);
+        if (it > (1u << 20)) { if (lane == 0) atomicOr(of.error, 2u); break; }
+        __builtin_amdgcn_s_sleep(8);   // (thousands of waves poll: a short sleep floods the fabric with sc1 loads and slows the lanes that work)
     }
 }
 // tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
@@ -708,9 +711,6 @@ __global__ __launch_bounds__(256) void k_overflow_reset(uint32_t* __restrict__ t
 void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles, uint32_t n_tiles, hipStream_t s) {
     const uint32_t n = n_ticket > n_tiles ? n_ticket : n_tiles;
     hipLaunchKernelGGL(k_overflow_reset, dim3((n + 255) / 256), dim3(256), 0, s, ticket, n_ticket, tiles, n_tiles);
-}
-void overflow_flow_experiment_mode() {   // (not inside a stream capture)
-    if (const char* e = getenv("AVN_OVF_MODE")) { uint32_t m = (uint32_t)atoi(e); (void)hipMemcpyToSymbol(HIP_SYMBOL(g_ovf_mode), &m, sizeof m); }
 }
 template <class T> void launch_overflow_flow(const DW<T>& w, const StepParams<T>& p, int pass, const OverflowFlow& of, uint32_t epoch, uint32_t grid_blocks, hipStream_t s) {
     if (!grid_blocks) return;

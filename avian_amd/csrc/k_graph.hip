@@ -41,6 +41,11 @@ __device__ __forceinline__ void st_agent(uint32_t* p, uint32_t v) { __hip_atomic
 // same-wave read-after-write through memory (k_pg_replay): bypass the CU's L1
 __device__ __forceinline__ uint32_t ld_wg(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
+// A global store the compiler's s_waitcnt insertion does not see (k_pg_replay): hipcc drains ALL outstanding memory operations
+// (vmcnt(0)) in front of the stores of a loop body that also holds rarely-taken loads, i.e. every batch would wait ~2 us for the
+// previous batch's scattered stores.  The kernel drains them itself where it matters (chunk start, window reload).
+__device__ __forceinline__ void st_async(uint32_t* p, uint32_t v) { asm volatile("global_store_dword %0, %1, off" : : "v"(p), "v"(v) : "memory"); }
+
 __device__ __forceinline__ int wave_incl_add(int v, uint32_t lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) { int u = __shfl_up(v, off); if ((int)lane >= off) v += u; }
@@ -261,7 +266,7 @@ __global__ __launch_bounds__(64) void k_pg_color(PG pg, uint32_t n_ops) {
         }
         if (__all(done)) break;
         if (it > PG_SPIN_LIMIT) { if (lane == 0) atomicOr(&pg.ctr[PGC_ERROR], 1u); break; }
-        __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_s_sleep(2);
     }
     // this step's pushes per colour (with the pops counted by k_pg_classify: the bucket sizes of the replay)
     for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
@@ -304,83 +309,173 @@ __global__ __launch_bounds__(256) void k_pg_bucket_keys(PG pg, uint32_t n_ops) {
 void launch_pg_bucket_keys(const PG& pg, uint32_t n_ops, hipStream_t s) {
     if (n_ops) hipLaunchKernelGGL(k_pg_bucket_keys, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, n_ops);
 }
+// rx[i] = contact id of the i-th op of the colour-bucketed sequence | push << 31 (one contiguous stream for k_pg_replay)
+__global__ __launch_bounds__(256) void k_pg_replay_gather(PG pg, const uint32_t* __restrict__ order, uint32_t* __restrict__ rx, uint32_t n_ops) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_ops) return;
+    const uint32_t k = order[i];
+    rx[i] = pg.op_cid[k] | ((pg.op_info[k] & 3u) == PG_KIND_PUSH ? 0x80000000u : 0u);
+}
 // One wave per colour.  See tools/experiments/replay_batches.py for the rule: with h_t the list length before op t of a batch,
 // a push writes position h_t and a pop vacates position h_t - 1 (its content fills the hole the popped handle leaves).  While
 // every pop's handle sits BELOW the lowest position the batch's pushes / vacates touch, holes and moving tail never meet: the
 // filler of a pop is the list entry at h_t - 1 as of the batch start, or the handle of the latest earlier push of the batch at
 // that height, and all lanes apply their op at once.  The first op that breaks the rule runs alone, serially.
-__global__ __launch_bounds__(64) void k_pg_replay(PG pg, const uint32_t* __restrict__ order) {
-    __shared__ uint32_t s_cons[64];
+// The batch loop touches no global memory on its critical path: the ops of a chunk (RP_CHUNK) and the current positions of its pops
+// are staged in LDS, so is a window of the list around its moving end, and a small LDS hash (pop handle -> index in the chunk)
+// patches the staged position of a handle that moves before its own pop comes up.  Global stores are fire-and-forget; they are
+// drained once per chunk / window reload, before the next staging loads.
+#define RP_CHUNK 1024u
+#define RP_HASH 2048u
+#define RP_WIN 2048u
+__global__ __launch_bounds__(64) void k_pg_replay(PG pg, const uint32_t* __restrict__ rx) {
+    __shared__ uint32_t cx[RP_CHUNK], cP[RP_CHUNK], hkey[RP_HASH], hval[RP_HASH], win[RP_WIN], s_cons[64];
+    // (the block is ONE wave: LDS operations execute in program order, so the phases below need no s_barrier -- and must not have
+    //  __syncthreads(), whose fence would drain the scattered global stores of every batch, ~2 us each, before the next phase)
     const uint32_t c = blockIdx.x, lane = threadIdx.x;
     uint32_t b0 = 0;
     for (uint32_t i = 0; i < c; ++i) b0 += pg.ctr[PGC_BUCKET + i];
     const uint32_t b1 = b0 + pg.ctr[PGC_BUCKET + c];
     uint32_t* __restrict__ list = pg.lists + (size_t)c * pg.list_stride;
     uint32_t L = pg.ctr[PGC_LEN + c];
-    uint32_t cur = b0;
-    while (cur < b1) {
-        const uint32_t n = min(64u, b1 - cur);
-        const bool valid = lane < n;
-        uint32_t x = 0; bool push = false;
-        if (valid) { const uint32_t k = order[cur + lane]; x = pg.op_cid[k]; push = (pg.op_info[k] & 3u) == PG_KIND_PUSH; }
-        const bool pop = valid && !push;
-        const int delta = valid ? (push ? 1 : -1) : 0;
-        const int incl = wave_incl_add(delta, lane);
-        const uint32_t h = (uint32_t)((int)L + incl - delta);              // list length before this lane's op
-        const uint32_t touch = valid ? (push ? h : h - 1u) : 0xFFFFFFFFu;
-        const uint32_t P = pop ? ld_wg(&pg.lpos[x]) : 0u;                  // ContactConstraintHandle::local_index
-        const uint32_t lomin = wave_incl_min(touch, lane), pmax = wave_incl_max(pop ? P + 1u : 0u, lane);
-        const unsigned long long cf = __ballot(valid && pmax > lomin);
-        const uint32_t f = cf ? (uint32_t)__ffsll((long long)cf) - 1u : n;   // ops [0, f) are conflict-free
-        if (f == 0) {   // the batch's first op alone: the serial statement of the reference
-            if (lane == 0) {
-                if (push) { list[L] = x; pg.lpos[x] = L; pg.color[x] = c; }
-                else {
-                    const uint32_t last = ld_wg(&list[L - 1u]);
-                    if (P != L - 1u) { list[P] = last; pg.lpos[last] = P; }   // swap_remove + "fix moved manifold handle"
-                    pg.color[x] = PG_NONE;
+    uint32_t dbg_iter = 0, dbg_serial = 0, dbg_reload = 0;
+    uint32_t wbase = 0; bool wvalid = false;   // the window: list[wbase .. wbase + RP_WIN) as the replay has left it so far
+    auto hash_patch = [&](uint32_t y, uint32_t newP) {   // handle y moved to newP: if it is popped later in this chunk, that pop must find it there
+        uint32_t hsl = (y * 2654435761u) >> 21;   // 11 bits
+        for (;;) {
+            const uint32_t k = hkey[hsl];
+            if (k == y) { cP[hval[hsl]] = newP; return; }
+            if (k == 0xFFFFFFFFu) return;
+            hsl = (hsl + 1u) & (RP_HASH - 1u);
+        }
+    };
+    for (uint32_t c0 = b0; c0 < b1; c0 += RP_CHUNK) {
+        const uint32_t nC = min(RP_CHUNK, b1 - c0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous chunk's stores are performed before this chunk's positions are read
+        for (uint32_t i = lane; i < RP_HASH; i += 64) hkey[i] = 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        {   // two memory levels for the whole chunk (ops, then the pops' positions), every load of a level in flight at once
+            uint32_t vv[RP_CHUNK / 64], pp[RP_CHUNK / 64];
+#pragma unroll
+            for (uint32_t j = 0; j < RP_CHUNK / 64; ++j) { const uint32_t i = j * 64 + lane; vv[j] = i < nC ? rx[c0 + i] : 0x80000000u; }
+#pragma unroll
+            for (uint32_t j = 0; j < RP_CHUNK / 64; ++j) pp[j] = (vv[j] >> 31) ? 0u : ld_agent(&pg.lpos[vv[j]]);
+#pragma unroll
+            for (uint32_t j = 0; j < RP_CHUNK / 64; ++j) {
+                const uint32_t i = j * 64 + lane, v = vv[j];
+                if (i < nC) {
+                    cx[i] = v;
+                    if (!(v >> 31)) {
+                        cP[i] = pp[j];
+                        uint32_t hsl = (v * 2654435761u) >> 21;
+                        for (;;) { const uint32_t prev = atomicCAS(&hkey[hsl], 0xFFFFFFFFu, v); if (prev == 0xFFFFFFFFu) break; hsl = (hsl + 1u) & (RP_HASH - 1u); }
+                        hval[hsl] = i;
+                    }
                 }
             }
-            L = (uint32_t)((int)L + __shfl(delta, 0));
-            cur += 1;
-        } else {
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t cur = 0; cur < nC;) {
+            const uint32_t n = min(64u, nC - cur);
+            const bool valid = lane < n;
+            const uint32_t v = valid ? cx[cur + lane] : 0u;
+            const uint32_t x = v & 0x7FFFFFFFu;
+            const bool push = valid && (v >> 31), pop = valid && !(v >> 31);
+            const int delta = valid ? (push ? 1 : -1) : 0;
+            // prefix sum of the +1 / -1 deltas from two ballots (no cross-lane scan: a ds_bpermute chain costs more than the whole batch)
+            const unsigned long long pushes_all = __ballot(push), pops_all = __ballot(pop);
+            const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+            const int incl = __popcll(pushes_all & le_mask) - __popcll(pops_all & le_mask);
+            const uint32_t h = (uint32_t)((int)L + incl - delta);              // list length before this lane's op
+            const uint32_t touch = valid ? (push ? h : h - 1u) : 0xFFFFFFFFu;
+            const uint32_t P = pop ? cP[cur + lane] : 0u;                      // ContactConstraintHandle::local_index, current
+            // conflict-free prefix.  Every position the batch touches is >= L - 64, so a batch whose pops all sit below that is
+            // conflict-free as a whole (the common case: one ballot); otherwise the exact rule with prefix min / max scans
+            uint32_t f = n;
+            if (__ballot(pop && P + 64u >= L)) {
+                const uint32_t lomin = wave_incl_min(touch, lane), pmax = wave_incl_max(pop ? P + 1u : 0u, lane);
+                const unsigned long long cf = __ballot(valid && pmax > lomin);
+                f = cf ? (uint32_t)__ffsll((long long)cf) - 1u : n;   // ops [0, f) are conflict-free
+            }
+            // the window must hold every position this iteration reads or writes at the list's end (all within 64 of L).  Invariant:
+            // win mirrors list[wbase .. current length) -- loaded below, or written since by a push / a hole fill
+            if (!wvalid || L < wbase + 64u || L + 64u >= wbase + RP_WIN) {
+                if (!wvalid || (wbase != 0u && L < wbase + 64u) || L + 64u >= wbase + RP_WIN) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // earlier iterations' list stores are performed before the reload
+                    wbase = L > RP_WIN / 2u ? L - RP_WIN / 2u : 0u;
+                    const uint32_t wend = min(L, wbase + RP_WIN);
+                    for (uint32_t i0 = 0; wbase + i0 < wend; i0 += 16 * 64) {   // 16 loads per lane in flight
+                        uint32_t t[16];
+#pragma unroll
+                        for (uint32_t j = 0; j < 16; ++j) { const uint32_t i = i0 + j * 64 + lane; t[j] = wbase + i < wend ? ld_agent(&list[wbase + i]) : 0u; }
+#pragma unroll
+                        for (uint32_t j = 0; j < 16; ++j) { const uint32_t i = i0 + j * 64 + lane; if (wbase + i < wend) win[i] = t[j]; }
+                    }
+                    wvalid = true; ++dbg_reload;
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            ++dbg_iter;
+            if (f == 0) {   // the batch's first op alone: the serial statement of the reference
+                ++dbg_serial;
+                if (lane == 0) {
+                    if (push) { st_async(&list[L], x); st_async(&pg.lpos[x], L); st_async(&pg.color[x], c); win[L - wbase] = x; }
+                    else {
+                        const uint32_t last = win[L - 1u - wbase];
+                        if (P != L - 1u) {   // swap_remove + "fix moved manifold handle"
+                            st_async(&list[P], last); st_async(&pg.lpos[last], P);
+                            if (P >= wbase) win[P - wbase] = last;
+                            hash_patch(last, P);
+                        }
+                        st_async(&pg.color[x], PG_NONE);
+                    }
+                }
+                L = (uint32_t)((int)L + __shfl(delta, 0));
+                cur += 1;
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
             const bool in = lane < f;
             // stack matching: the latest earlier push of the batch that wrote the position this pop vacates
             int match = -1;
-            for (uint32_t s = 0; s + 1 < f; ++s) {
-                const bool ps = __shfl((int)push, (int)s) != 0;
-                const uint32_t hs = (uint32_t)__shfl((int)h, (int)s);
-                if (in && pop && s < lane && ps && hs == h - 1u) match = (int)s;
+            const unsigned long long fmask = f == 64 ? ~0ull : ((1ull << f) - 1ull);
+            const unsigned long long pushes = pushes_all & fmask, pops = pops_all & fmask;
+            if (pushes && pops) {
+                const uint32_t s_lo = (uint32_t)__ffsll((long long)pushes) - 1u, s_hi = 63u - (uint32_t)__clzll((long long)pops);   // only pushes before the last pop can match
+                for (uint32_t s = s_lo; s < s_hi; ++s) {
+                    if (!((pushes >> s) & 1ull)) continue;   // (wave-uniform)
+                    const uint32_t hs = (uint32_t)__builtin_amdgcn_readlane((int)h, (int)s);
+                    if (in && pop && s < lane && hs == h - 1u) match = (int)s;
+                }
             }
             s_cons[lane] = 0u;
-            __syncthreads();
+            __builtin_amdgcn_wave_barrier();
             if (in && pop && match >= 0) s_cons[match] = 1u;
-            __syncthreads();
             const uint32_t ym = (uint32_t)__shfl((int)x, match >= 0 ? match : 0);
-            // every filler is read from the list AS OF THE BATCH START: all loads of all lanes are performed before any lane stores
-            // (a later push of the batch may write the very position an earlier pop vacates)
-            uint32_t y0 = 0;
-            if (in && pop && match < 0) y0 = ld_wg(&list[h - 1u]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
+            // every filler is read from the list AS OF THE BATCH START: all reads of all lanes before any lane writes
+            uint32_t y = ym;
+            if (in && pop && match < 0) y = win[h - 1u - wbase];
+            __builtin_amdgcn_wave_barrier();
             if (in && pop) {
-                const uint32_t y = match >= 0 ? ym : y0;
-                list[P] = y; pg.lpos[y] = P;
-                pg.color[x] = PG_NONE;
+                st_async(&list[P], y); st_async(&pg.lpos[y], P);
+                st_async(&pg.color[x], PG_NONE);
+                if (P >= wbase) win[P - wbase] = y;
+                if (match < 0) hash_patch(y, P);   // (a handle pushed in this step has no pop in it)
             } else if (in && push) {
-                pg.color[x] = c;
-                if (!s_cons[lane]) { list[h] = x; pg.lpos[x] = h; }   // (a consumed push's handle already moved into a pop's hole)
+                st_async(&pg.color[x], c);
+                if (!s_cons[lane]) { st_async(&list[h], x); st_async(&pg.lpos[x], h); win[h - wbase] = x; }   // (a consumed push's handle already moved into a pop's hole)
             }
             L = (uint32_t)__shfl((int)h + delta, (int)(f - 1u));
             cur += f;
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // the batch's stores are performed before the next batch's loads
-        __syncthreads();
     }
-    if (lane == 0) pg.ctr[PGC_LEN + c] = L;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) { pg.ctr[PGC_LEN + c] = L; pg.ctr[PGC_DBG + c] = dbg_iter; pg.ctr[PGC_DBG + 24 + c] = dbg_serial; pg.ctr[PGC_DBG + 48 + c] = dbg_reload; pg.ctr[PGC_DBG + 72 + c] = b1 - b0; }
 }
-void launch_pg_replay(const PG& pg, const uint32_t* order, hipStream_t s) {
-    hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, order);
+void launch_pg_replay(const PG& pg, const uint32_t* order, uint32_t n_ops, hipStream_t s) {
+    if (n_ops) hipLaunchKernelGGL(k_pg_replay_gather, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, order, pg.ekey_a, n_ops);   // (ekey_a: the colouring's entry buffers are free again)
+    hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, pg.ekey_a);
 }
 
 // ---- removed pairs: ContactGraph::remove_edge_by_id + IdPool::free_id --------------------------------------------------------------
