@@ -189,6 +189,7 @@ template <class T> struct World : WorldBase {
     uint32_t pgm_head = 0, pgm_n_free = 0, pgm_next_id = 0, pgm_live = 0, pgm_tomb = 0;   // exact host mirrors of the device counters
     uint32_t pgm_len[AVN_GRAPH_COLOR_COUNT] = {0};
     uint32_t ovf_epoch = 0, ovf_epoch_after_substeps = 0;
+
     uint64_t pg_dump_step = 0;
     Pinned pin_ctr;
     SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
@@ -2160,11 +2161,19 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
+    // single systems run outside avn_step: the dataflow passes' per-step state has to be fresh
+    avn_status flow_begin_standalone() {
+        if (!dw.n_manifolds || !(pipe_dev && ovf_grid_blocks)) return AVN_OK;
+        launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream);
+        ovf_epoch = 0;
+        return AVN_OK;
+    }
     avn_status run_system(avn_system sys) override {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
         if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if (sys != AVN_SYS_SOLVER && (st = flow_begin_standalone()) != AVN_OK) return st;
         if ((st = dispatch_system(sys)) != AVN_OK) return st;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
@@ -2174,6 +2183,7 @@ template <class T> struct World : WorldBase {
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
         if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if ((st = flow_begin_standalone()) != AVN_OK) return st;
         hipEvent_t a, b;
         HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
         HIPCHK(hipStreamSynchronize(stream));

@@ -700,6 +700,11 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
         __builtin_amdgcn_s_sleep(8);   // (thousands of waves poll: a short sleep floods the fabric with sc1 loads and slows the lanes that work)
     }
 }
+// (Tried and rejected, round 2: a whole pass as ONE dataflow launch over all colours -- every manifold waits for per-body tickets in
+//  "overflow list order, then colour order", its constraint records already loaded.  Bit-identical (the closed loop tracked the oracle),
+//  but 219 us per cfg2 pass against 15 x 8.4 = 126 us for the colour launches: a body's 15 manifolds are 15 dependent hops of
+//  poll + sc1 gather + ~1 500 issues + write-through + ticket, ~14 us each with ~10 000 waves polling.  The ticket pass stays where the
+//  alternative is hundreds of launches: the overflow colour, k_overflow_flow.)
 // tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
 // not reliably ordered against a synchronous (null-stream) hipMemcpy issued between replays on ROCm 7.2 (found by the closed-loop tests:
 // a whole step of wrong impulses after avn_pipeline_handles_get had copied with hipMemcpy); kernel nodes keep the chain.
