@@ -103,6 +103,7 @@ template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const Swee
 template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const SweepScratch&, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
 size_t sweep_long_item_bytes();
 uint32_t sweep_pad_records();
+uint32_t sweep_bounds_group();  // sorted records per y/z bounds group of the sweep's batch cull
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);

@@ -404,6 +404,23 @@ template <class T> struct World : WorldBase {
             cap_bodies = (uint32_t)c;
         }
         if (moved || dw.n_bodies != n) graph_valid = false;
+        if (have_bodies && n < dw.n_bodies) {
+            // fewer bodies than before: everything that may still index a body >= n is dropped (the host re-uploads it; nothing
+            // may gather or schedule out of range meanwhile) -- uploaded manifolds, joints, colliders whose body is gone
+            bool bad_m = false, bad_j = false, bad_c = false;
+            if (!use_handles) for (size_t i = 0; i < h_m_body1.size() && !bad_m; ++i) bad_m = (uint32_t)h_m_body1[i] >= n || (uint32_t)h_m_body2[i] >= n;
+            for (size_t i = 0; i < h_j_body1.size() && !bad_j; ++i) bad_j = (h_j_body1[i] >= 0 && (uint32_t)h_j_body1[i] >= n) || (h_j_body2[i] >= 0 && (uint32_t)h_j_body2[i] >= n);
+            for (size_t i = 0; i < h_col_body.size() && !bad_c; ++i) bad_c = h_col_body[i] >= 0 && (uint32_t)h_col_body[i] >= n;
+            if (bad_m || (use_handles && dw.n_manifolds)) {
+                uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+                dw.n_manifolds = 0; h_m_body1.clear(); h_m_body2.clear();
+                set_color_offsets(zero);
+                HIPCHK(hipMemcpyAsync(dw.color_offsets, zero, sizeof zero, hipMemcpyHostToDevice, stream));
+                island_mode = false; islands_dirty = false;
+            }
+            if (bad_j) { dw.n_joints = 0; h_j_body1.clear(); h_j_body2.clear(); h_j_damped.clear(); h_j_collision_disabled.clear(); h_j_type.clear(); any_damped = false; }
+            if (bad_c || pipe_on) { bp.n_colliders = 0; bp.n_intervals = 0; have_colliders = false; slot_entity.clear(); entity_slot.clear(); h_col_body.clear(); pipe_on = false; pipe_dev = false; }
+        }
         dw.n_bodies = n;
         size_t total = 0;
         total += al(sizeof(T) * 3 * n) * 7 + al(sizeof(T) * 4 * n) + al(sizeof(T) * 6 * n) + al(sizeof(T) * n) * 6 + al(n) * 4;
@@ -1009,7 +1026,7 @@ template <class T> struct World : WorldBase {
             size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
             GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
             GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
-            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_bb, cc / 8 + 2, bp.s_bb); GROW(b_s_end, cc, bp.s_end);
+            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_bb, cc / sweep_bounds_group() + 2, bp.s_bb); GROW(b_s_end, cc, bp.s_end);
             GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
             Key* dummy_k; uint32_t* dummy_u;
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
@@ -1018,6 +1035,7 @@ template <class T> struct World : WorldBase {
             GROW(b_counts, cc * sweep_count_slots() + 1, dummy_u); GROW(b_offsets, cc * sweep_count_slots() + 1, dummy_u);
             {   // long-interval chunks: every interval may need one slot, plus room for the chunks of scene-spanning ones
                 size_t lcap = cc + 65536;
+                if (const char* e = getenv("AVN_SWEEP_LONG_CAP")) lcap = std::max<size_t>(8, (size_t)strtoull(e, nullptr, 10));   // (tests: force the grow-and-retry path)
                 uint8_t* dummy_b;
                 GROW(b_long_items, lcap * sweep_long_item_bytes(), dummy_b);
                 GROW(b_long_counts, lcap, dummy_u); GROW(b_long_off, lcap, dummy_u);
@@ -1694,9 +1712,15 @@ template <class T> struct World : WorldBase {
             collect_pending = false;
             HIPCHK(hipEventSynchronize(ev_counters));
             t0 = std::chrono::steady_clock::now();
+            if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
+                if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return st;
+                if ((st = collect_launch()) != AVN_OK) return st;
+                collect_pending = false;
+                HIPCHK(hipEventSynchronize(ev_counters));
+                if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+            }
             const uint32_t dropped = h_counters[0];
             total = h_counters[2];
-            if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
             if (total) {
                 hipError_t err;
                 b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
@@ -1906,13 +1930,31 @@ template <class T> struct World : WorldBase {
         collect_pending = true;
         return AVN_OK;
     }
+    avn_status grow_long_chunks(uint32_t chunks_needed) {
+        HIPCHK(hipStreamSynchronize(bs));
+        const size_t lcap = (size_t)chunks_needed + chunks_needed / 4 + 65536;
+        bool moved = false;
+        uint8_t* dummy_b; uint32_t* dummy_u;
+        GROW(b_long_items, lcap * sweep_long_item_bytes(), dummy_b);
+        GROW(b_long_counts, lcap, dummy_u); GROW(b_long_off, lcap, dummy_u);
+        sweep_scratch.long_items = b_long_items.p; sweep_scratch.long_counts = b_long_counts.as<uint32_t>();
+        sweep_scratch.long_off = b_long_off.as<uint32_t>(); sweep_scratch.long_cap = (uint32_t)lcap;
+        return AVN_OK;
+    }
     avn_status collect_finish() {
         if (!collect_pending) return AVN_OK;
         collect_pending = false;
         uint32_t n = collect_n;
         HIPCHK(hipEventSynchronize(ev_counters));
+        if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
+            avn_status st = grow_long_chunks(h_counters[3]);
+            if (st != AVN_OK) return st;
+            if ((st = collect_launch()) != AVN_OK) return st;
+            collect_pending = false;
+            HIPCHK(hipEventSynchronize(ev_counters));
+            if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+        }
         uint32_t dropped = h_counters[0], total = h_counters[2];
-        if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
         if (total) {
             hipError_t err;
             b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
@@ -2069,10 +2111,17 @@ template <class T> struct World : WorldBase {
             ovf_epoch = 0;
             for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
             ovf_epoch_after_substeps = ovf_epoch;
-            HIPCHK(hipStreamEndCapture(stream, &graph));
+            // whatever went wrong inside the capture, the stream must leave capture mode and the partial graph must not survive
+            hipError_t ce = hipStreamEndCapture(stream, &graph);
             graph_launches = launches - before;
             launches = before;
-            HIPCHK(hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0));
+            if (ce == hipSuccess) ce = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                (void)hipGetLastError();
+                drop_graph();
+                error = std::string("substep graph capture failed: ") + hipGetErrorName(ce);
+                return AVN_ERR_HIP;
+            }
             graph_valid = true;
         }
         HIPCHK(hipGraphLaunch(graph_exec, stream));

@@ -459,20 +459,22 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
     return pr;
 }
 
+#define SW_BB_GROUP 8u   // sorted records per bounds group (k_batch_bounds, the sweep's `j / SW_BB_GROUP`, the host's s_bb sizing)
 // Batch cull of the sweep: the y/z bounds of every group of 8 consecutive sorted records.  A wave tests its 64 boxes against a
 // group's bounds before it loads the group's records; on a lattice consecutive records share a y row, so most groups of the
 // ~6 000 x-overlapping candidates of an interval are rejected with 4 compares instead of 32.  Conservative by construction
 // (a record that overlaps a lane overlaps the union of its group; a NaN anywhere in a group disables the cull for it, because the
 // reference's negated compares let NaN boxes through): the emitted pairs and their order do not change.
+uint32_t sweep_bounds_group() { return SW_BB_GROUP; }
 template <class T>
 __global__ __launch_bounds__(256) void k_batch_bounds(const Vec4<T>* __restrict__ s_yz, uint32_t n, Vec4<T>* __restrict__ s_bb) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g * 8u >= n) return;
+    if (g * SW_BB_GROUP >= n) return;
     const T inf = Limits<T>::max * T(2);
     T lo_y = inf, hi_y = -inf, lo_z = inf, hi_z = -inf;
     bool nan = false;
     for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t idx = g * 8u + k;
+        const uint32_t idx = g * SW_BB_GROUP + k;
         if (idx >= n) break;
         const Vec4<T> r = s_yz[idx];
         nan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
@@ -604,6 +606,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     };
 
     constexpr uint32_t SW_BATCH = sizeof(T) == 4 ? 8u : 4u;  // candidates per scalar-load batch (SGPR budget)
+    // the batch cull below tests a whole batch against ONE group's bounds: a batch must never straddle two groups (else true pairs of the
+    // second group could be culled), i.e. batches start on multiples of SW_BATCH (j_first) and SW_BATCH divides the group size
+    static_assert(SW_BB_GROUP % SW_BATCH == 0 && (SW_BB_GROUP & (SW_BB_GROUP - 1u)) == 0, "sweep batch cull: SW_BATCH must divide the bounds group size");
     // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je), cut at batch-aligned positions so that every
     // batch lies inside one group of k_batch_bounds (the few records before i0 + 1 this adds fail every lane's `jj > i` test)
     const uint32_t j_first = (i0 + 1u) & ~(SW_BATCH - 1u);
@@ -612,7 +617,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     const uint32_t jb = j_first + wv * qlen;
     const uint32_t jq = min(je, jb + qlen);
     for (uint32_t j = jb; j < jq; j += SW_BATCH) {
-        const Vec4<T> bb = s_bb[j >> 3];   // wave-uniform: one scalar load
+        const Vec4<T> bb = s_bb[j / SW_BB_GROUP];   // wave-uniform: one scalar load
         if (!(lane_mask_ule(me.x, bb.y) & lane_mask_uge(me.y, bb.x) & lane_mask_ule(me.z, bb.w) & lane_mask_uge(me.w, bb.z))) continue;
         Vec4<T> c[SW_BATCH];
 #pragma unroll
@@ -666,7 +671,9 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_long(const Vec4<T>* __rest
                                                             const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
     __shared__ uint32_t wave_tot[SW_WAVES];
     uint32_t t = threadIdx.x, lane = t & 63u, wv = t >> 6;
-    uint32_t nl = *n_long;
+    // (n_long[1] = k_sweep_ranges ran out of chunk slots: the reserved items were never written -- nothing here may touch them;
+    //  the host grows the chunk arrays to the requested count and runs the count pass again)
+    uint32_t nl = n_long[1] ? 0u : *n_long;
     for (uint32_t it = blockIdx.x; it < nl; it += gridDim.x) {
         LongItem item = items[it];
         uint32_t i = item.i;
@@ -704,7 +711,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_long(const Vec4<T>* __rest
 // per long interval: chunk counts -> in-interval chunk offsets, and the interval's total into counts[i]
 __global__ __launch_bounds__(256) void k_long_finish(const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long, const uint32_t* __restrict__ long_counts,
                                                       uint32_t* __restrict__ long_off, uint32_t* __restrict__ counts) {
-    uint32_t nl = *n_long;
+    uint32_t nl = n_long[1] ? 0u : *n_long;
     for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nl; k += gridDim.x * 256) {
         LongItem it = items[k];
         if (!it.n_chunks) continue;
@@ -856,7 +863,7 @@ template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, co
 template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s) {
     if (!n) return;
     (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
-    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / 8u + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb);
+    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / SW_BB_GROUP + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb);
     hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
                        sc.n_long, sc.long_cap, sc.n_long + 1);
 }

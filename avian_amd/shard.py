@@ -148,16 +148,37 @@ def slab_plan(aabb_min_x: np.ndarray, world_size: int) -> SlabPlan:
     return SlabPlan(world_size, splits, np.clip(slab, 0, world_size - 1))
 
 
-def slab_colliders(p: SlabPlan, rank: int, aabb_min_x: np.ndarray, aabb_max_x: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
-    """Returns (local: ascending global collider indices of rank's sub-world = owned + halo, owned_mask over `local`)."""
+def slab_colliders(p: SlabPlan, rank: int, aabb_min_x: np.ndarray, aabb_max_x: np.ndarray, prev_order: np.ndarray = None) -> Tuple[np.ndarray, np.ndarray]:
+    """Returns (local: global collider indices of rank's sub-world = owned + halo, owned_mask over `local`).  `local` is in the
+    single world's PERSISTENT interval order when `prev_order` is given (see slab_next_order), else ascending."""
     mn = np.asarray(aabb_min_x, np.float64); mx = np.asarray(aabb_max_x, np.float64)
     owned = p.slab_of_collider == rank
     if not owned.any():
         return np.zeros(0, np.int64), np.zeros(0, bool)
     reach = mx[owned].max()
     halo = (p.slab_of_collider > rank) & (mn <= reach)
-    local = np.flatnonzero(owned | halo)
+    member = owned | halo
+    if prev_order is None:
+        local = np.flatnonzero(member)
+    else:
+        po = np.asarray(prev_order, np.int64)
+        seen = np.zeros(len(member), bool); seen[po] = True
+        local = np.concatenate([po[member[po]], np.flatnonzero(member & ~seen)])   # (colliders new this frame: appended at the end, broad_phase.rs:296-315)
     return local, owned[local]
+
+
+def slab_next_order(prev_order: np.ndarray, aabb_min_x: np.ndarray, n_colliders: int) -> np.ndarray:
+    """The single world's AabbIntervals order AFTER this frame's sort, from the order before it: the reference's insertion sort is
+    stable (broad_phase.rs:479-487), so equal min.x keep the PREVIOUS frame's relative order -- not the upload order.  Every rank
+    evaluates this on the replicated AABB extents (-0.0 == +0.0; intervals with a non-finite key are dropped like
+    update_aabb_intervals drops them, :230-279), so the slab sub-worlds can be seeded with the order the single world would have.
+    prev_order = None: first frame (upload order)."""
+    x = np.asarray(aabb_min_x, np.float64) + 0.0
+    po = np.arange(n_colliders, dtype=np.int64) if prev_order is None else np.asarray(prev_order, np.int64)
+    seen = np.zeros(n_colliders, bool); seen[po] = True
+    po = np.concatenate([po, np.flatnonzero(~seen)])
+    po = po[np.isfinite(x[po])]
+    return po[np.argsort(x[po], kind="stable")]
 
 
 def slab_filter_pairs(pairs: np.ndarray, entity_index: np.ndarray, owned_mask: np.ndarray) -> np.ndarray:
@@ -212,12 +233,16 @@ def pair_keys(rec: np.ndarray) -> np.ndarray:
 
 
 def slab_broad_phase_step(lib: F.Library, bits: int, bodies: Dict[str, np.ndarray], colliders: Dict[str, np.ndarray], aabb_min_x: np.ndarray,
-                          aabb_max_x: np.ndarray, known_keys: np.ndarray, rank: int, world_size: int, dist=None, device=None) -> np.ndarray:
+                          aabb_max_x: np.ndarray, known_keys: np.ndarray, rank: int, world_size: int, dist=None, device=None,
+                          prev_order: np.ndarray = None) -> np.ndarray:
     """One frame of the slab-sharded broad phase on this rank: plan the slabs from the (replicated) AABB extents, sweep this
     rank's slab + halo with the single-GPU broad phase, drop halo-owned pairs, all-gather.  known_keys = PairKeys already in
-    the contact graph (globally).  Returns the step's NEW pairs of the whole world, [P, 3] uint32, in the single-world order."""
+    the contact graph (globally).  Returns the step's NEW pairs of the whole world, [P, 3] uint32, in the single-world order.
+    prev_order: the single world's interval order BEFORE this frame (slab_next_order of the previous frame; None on the first
+    frame).  The sub-world is uploaded in that order, so ties in min.x break as in the persistent single world -- with None
+    they break by upload index, which is the single world's behaviour only on its first frame."""
     pl = slab_plan(aabb_min_x, world_size)
-    local, owned = slab_colliders(pl, rank, aabb_min_x, aabb_max_x)
+    local, owned = slab_colliders(pl, rank, aabb_min_x, aabb_max_x, prev_order)
     mine = np.zeros(0, PAIR_DTYPE_LOCAL)
     if len(local):
         b, c, _ = slab_subworld(bodies, colliders, local)

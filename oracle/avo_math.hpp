@@ -178,7 +178,13 @@ template <class S> inline S clamp_s(S x, S lo, S hi) { S r = x; if (r < lo) r = 
 // glam Quat * Quat.  f32 `Quat` is SSE2-backed on x86_64 (rtm::quat_mul association):
 //   (w_l*rhs + x_l*rhs.wzyx*[+,-,+,-]) + (y_l*rhs.zwxy*[+,+,-,-] + z_l*rhs.yxwz*[-,+,+,-])
 // f64 `DQuat` is the scalar implementation (left-to-right sums).
+// use_scalar_quat_mul(): glam's scalar-math f32 `Quat` product (targets without SSE2 / with the `scalar-math` feature) sums left to right
+// like DQuat; switched on only to MEASURE how far the two associations drift apart (tests/test_oracle_tolerance.py).
+inline bool& use_scalar_quat_mul() { static bool v = false; return v; }
 inline Q4<float> qmul(Q4<float> l, Q4<float> r) {
+    if (use_scalar_quat_mul())
+        return {l.w * r.x + l.x * r.w + l.y * r.z - l.z * r.y, l.w * r.y - l.x * r.z + l.y * r.w + l.z * r.x, l.w * r.z + l.x * r.y - l.y * r.x + l.z * r.w,
+                l.w * r.w - l.x * r.x - l.y * r.y - l.z * r.z};
     return {(l.w * r.x + l.x * r.w) + (l.y * r.z + -(l.z * r.y)),
             (l.w * r.y + -(l.x * r.z)) + (l.y * r.w + l.z * r.x),
             (l.w * r.z + l.x * r.y) + (-(l.y * r.x) + l.z * r.w),

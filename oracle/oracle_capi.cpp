@@ -152,6 +152,8 @@ avn_status avo_constraint_graph_lists(const avn_constraint_graph* g, uint32_t* o
 }
 // test hook: switch the oracle's sin/cos to the host libm (to measure the deterministic kernel's deviation)
 void avo_use_libm_trig(int on) { avo::use_libm_trig() = on != 0; }
+// test hook: glam's scalar (left-to-right) f32 quaternion product instead of the SSE2 association
+void avo_use_scalar_quat(int on) { avo::use_scalar_quat_mul() = on != 0; }
 void avo_sin_cos_f32(float a, float* s, float* c) { avo::sin_cos_det(a, *s, *c); }
 void avo_sin_cos_f64(double a, double* s, double* c) { avo::sin_cos_det(a, *s, *c); }
 float avo_asin_f32(float x) { return avo::asin_det(x); }

@@ -100,11 +100,13 @@ def run_slabs(lib, rank, world, steps, out_path, device=None):
     full.bodies_upload(**sc.body_kwargs()); full.colliders_upload(**cols)
     known = np.zeros(0, np.uint64)
     per_step = []
+    order = None   # the single world's persistent interval order, replicated on every rank
     for s in range(steps):
         b = moved(sc, s)
         full.bodies_upload(**b); full.run_system("UPDATE_AABB")
         mn, mx, _ = full.aabbs_download()
-        rec = shard.slab_broad_phase_step(lib, 32, b, cols, mn[:, 0], mx[:, 0], known, rank, world, dist if world > 1 else None, device)
+        rec = shard.slab_broad_phase_step(lib, 32, b, cols, mn[:, 0], mx[:, 0], known, rank, world, dist if world > 1 else None, device, prev_order=order)
+        order = shard.slab_next_order(order, mn[:, 0], len(mn))
         known = np.concatenate([known, shard.pair_keys(rec)])
         per_step.append(rec)
     if rank == 0:

@@ -231,6 +231,54 @@ def test_broadphase_edge_cases():
     assert np.array_equal(eo, eh) and len(eo) == n - 1, "the non-finite AABB interval is dropped"
 
 
+@pytest.mark.parametrize("bits", [32, 64])
+def test_sweep_batch_cull_with_non_finite_yz_and_ragged_group_count(bits):
+    """The sweep culls whole groups of 8 sorted records against their y/z bounds (k_batch_bounds): the last group is ragged when the interval
+    count is not a multiple of 8, and intervals with a non-finite y / z (dropped by update_aabb_intervals, sorted to the end) sit in the
+    padded tail the bounds kernel reads.  1 003 colliders in a slab, six of them non-finite: same pair list and interval order as the oracle."""
+    n = 1003
+    rng = np.random.default_rng(11)
+    pos = np.stack([rng.uniform(0, 6, n), rng.uniform(0, 6, n), rng.uniform(0, 6, n)], 1)
+    pos[5, 1] = np.nan; pos[77, 2] = np.nan; pos[130, 1] = np.inf; pos[131, 2] = -np.inf; pos[999, 1] = np.nan; pos[1002, 2] = np.inf
+    bodies = dict(position=pos, rotation=np.tile([0, 0, 0, 1.0], (n, 1)), linear_velocity=np.zeros((n, 3)), angular_velocity=np.zeros((n, 3)),
+                  inv_mass=np.ones(n), inv_inertia_local=np.tile([6, 0, 0, 6, 0, 6.0], (n, 1)), rb_type=np.zeros(n, np.uint8))
+    col = dict(entity_index=np.arange(n, dtype=np.uint32), body=np.arange(n, dtype=np.int32), shape=np.zeros(n, np.uint8), half_extents=np.full((n, 3), 0.35))
+    wo, wh = make_pair(bits)
+    for w in (wo, wh):
+        w.bodies_upload(**bodies); w.colliders_upload(**col)
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+    po, ph = wo.pairs_get(), wh.pairs_get()
+    assert len(po) > 1000 and np.array_equal(po, ph)
+    touched = set(po["collider1"].tolist()) | set(po["collider2"].tolist())
+    assert not ({5, 77, 130, 131, 999, 1002} & touched), "an interval whose AABB is not finite is dropped before the sweep (broad_phase.rs:230-279)"
+    _, _, eo = wo.aabbs_download(); _, _, eh = wh.aabbs_download()
+    assert np.array_equal(eo, eh) and len(eo) == n - 6
+
+
+def test_long_interval_chunk_overflow_grows_and_retries(monkeypatch):
+    """A wall of 9 600 boxes sharing one x extent: every interval has > 8 192 sweep candidates and is cut into chunks -- more chunks
+    than the (here artificially small) chunk arrays hold.  The library must grow them and run the count pass again instead of reading the
+    unwritten items: same pair list as the oracle."""
+    monkeypatch.setenv("AVN_SWEEP_LONG_CAP", "1024")
+    ny, nz = 120, 80
+    n = ny * nz
+    yy, zz = np.meshgrid(np.arange(ny) * 3.0, np.arange(nz) * 3.0, indexing="ij")
+    rng = np.random.default_rng(7)
+    pos = np.stack([rng.uniform(-0.2, 0.2, n), yy.ravel(), zz.ravel()], 1)
+    pos[::7, 1] += 2.2   # some boxes reach their neighbours
+    bodies = dict(position=pos, rotation=np.tile([0, 0, 0, 1.0], (n, 1)), linear_velocity=np.zeros((n, 3)), angular_velocity=np.zeros((n, 3)),
+                  inv_mass=np.ones(n), inv_inertia_local=np.tile([6, 0, 0, 6, 0, 6.0], (n, 1)), rb_type=np.zeros(n, np.uint8))
+    col = dict(entity_index=np.arange(n, dtype=np.uint32), body=np.arange(n, dtype=np.int32), shape=np.zeros(n, np.uint8), half_extents=np.full((n, 3), 0.5))
+    wo, wh = make_pair(32)
+    for w in (wo, wh):
+        w.bodies_upload(**bodies); w.colliders_upload(**col)
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+    po, ph = wo.pairs_get(), wh.pairs_get()
+    assert len(po) > 500 and np.array_equal(po, ph)
+
+
 def test_bad_arguments_are_reported_not_crashed():
     wh = F.World(hip_lib(), F.default_config(32))
     with pytest.raises(F.AvnError) as e:

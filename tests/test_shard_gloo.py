@@ -146,6 +146,55 @@ def test_slab_sharded_broad_phase_equals_single_world(scene):
     assert len(loc) == 0 or own.all()
 
 
+def test_slab_sharded_broad_phase_keeps_the_persistent_tie_order_over_frames():
+    """A lattice (many equal min.x) whose columns trade places over frames: in the single persistent world equal keys keep the
+    PREVIOUS frame's relative order (stable insertion sort over the kept AabbIntervals), so collider1 / collider2 of a new pair
+    depend on history.  Slab sub-worlds seeded with that order (slab_next_order) reproduce it; seeding by upload index does not
+    (ADVICE round 1)."""
+    lib = oracle_lib()
+    sc = scenes.box_stack(6, 3, 6)
+    n = sc.n
+    rng = np.random.default_rng(5)
+    frames = []
+    pos = sc.position.copy()
+    K = 12   # boxes 1 .. 2K are taken out of the lattice: K couples (A = 1 + 2k, B = 2 + 2k) far above it, 40 apart in y
+    for f in range(5):
+        b = sc.body_kwargs()
+        if f:   # whole x-columns of the lattice jump to other lattice columns: orders change, new keys tie with columns already there
+            ux, inv = np.unique(pos[1 + 2 * K:, 0], return_inverse=True)
+            pos[1 + 2 * K:, 0] = rng.permutation(ux)[inv]
+        for k in range(K):
+            A, B = 1 + 2 * k, 2 + 2 * k
+            y0 = 100.0 + 100.0 * k
+            # frame 0: A right of B (sorted order B, A); frame 1+: the SAME min.x -- the persistent world keeps B before A, a fresh
+            # world would put A (lower upload index) first; frame 3+: they touch, and the new pair is (B, A) only with the kept order
+            xa, xb = (50.0 + k, 49.0 + k) if f == 0 else (49.5 + k, 49.5 + k)
+            pos[A] = [xa, y0, 0.0]
+            pos[B] = [xb, y0 + (40.0 if f < 3 else 0.9), 0.0]
+        b["position"] = pos.copy()
+        frames.append(b)
+    ref, _, _ = single_world_pairs(lib, sc, frames)
+    assert sum(len(r) for r in ref[1:]) > 50 and len(ref[3]) >= K, "later frames must create new pairs"
+    cols = sc.collider_kwargs()
+    full = F.World(lib, F.default_config(32, substeps=1))
+    full.bodies_upload(**frames[0]); full.colliders_upload(**cols)
+    for seeded in (True, False):
+        known = np.zeros(0, np.uint64); order = None; same = True
+        for f, b in enumerate(frames):
+            full.bodies_upload(**b); full.run_system("UPDATE_AABB")
+            mn, mx, _ = full.aabbs_download()
+            parts = [shard.slab_broad_phase_step(lib, 32, b, cols, mn[:, 0], mx[:, 0], known, r, 3, prev_order=order if seeded else None) for r in range(3)]
+            rec = np.concatenate(parts)
+            same = same and np.array_equal(rec, ref[f])
+            known = np.concatenate([known, shard.pair_keys(ref[f])])
+            order = shard.slab_next_order(order, mn[:, 0], len(mn))
+        if seeded:
+            assert same, "slabs seeded with the persistent order must equal the single world on every frame"
+        else:
+            assert not same, "the scene must actually distinguish the persistent order from the upload order"
+    full.close()
+
+
 def test_slab_sharded_broad_phase_gloo_world_size_2_over_frames(tmp_path):
     """world_size 2 on gloo, three frames of colliders in free flight (they cross the slab boundary): the all-gathered pair
     records of every frame equal the single persistent world's new pairs, bit for bit and in order."""
