@@ -180,6 +180,13 @@ class avn_timers(C.Structure):
                 ("island_blocks", C.c_uint32), ("reserved0", C.c_uint32)]
 
 
+class avn_diagnostics(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("prepare_constraints_ms", "update_velocity_increments_ms", "integrate_velocities_ms", "warm_start_ms",
+                                          "solve_constraints_ms", "integrate_positions_ms", "relax_velocities_ms", "apply_restitution_ms", "finalize_ms",
+                                          "store_impulses_ms", "swept_ccd_ms", "substeps_ms", "broad_phase_ms", "narrow_phase_ms")] + \
+               [(n, C.c_uint32) for n in ("contact_constraint_count", "contact_count", "per_system_valid", "reserved0")]
+
+
 PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),
                        ("flags", "<u4"), ("reserved", "<u4")])
 
@@ -188,7 +195,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -214,7 +221,7 @@ class Library:
         f("last_error").restype = C.c_char_p
         for name in ("config_set", "bodies_upload", "bodies_download", "solver_bodies_download", "manifolds_upload",
                      "impulses_download", "constraints_download", "distance_joints_upload", "joints_upload", "joints_download",
-                     "colliders_upload", "timers_get"):
+                     "colliders_upload", "timers_get", "diagnostics_get"):
             f(name).argtypes = [vp, vp]
         f("existing_pairs_upload").argtypes = [vp, vp, C.c_size_t]
         f("pairs_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -598,6 +605,12 @@ class World:
 
     def synchronize(self):
         self._check(self.lib.fn("synchronize")(self.handle))
+
+    def diagnostics(self) -> avn_diagnostics:
+        """SolverDiagnostics + CollisionDiagnostics of the last step (milliseconds)."""
+        d = avn_diagnostics()
+        self._check(self.lib.fn("diagnostics_get")(self.handle, C.byref(d)))
+        return d
 
     def timers(self) -> avn_timers:
         t = avn_timers()

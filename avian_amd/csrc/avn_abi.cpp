@@ -59,6 +59,7 @@ AVN_API avn_status avn_run_system(avn_world* w, avn_system s) { GUARD(run_system
 AVN_API avn_status avn_step(avn_world* w) { GUARD(step()); }
 AVN_API avn_status avn_synchronize(avn_world* w) { GUARD(synchronize()); }
 AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)); }
+AVN_API avn_status avn_diagnostics_get(avn_world* w, avn_diagnostics* d) { GUARD(diagnostics(d)); }
 AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD(profile_system(s, r, ms, l)); }
 AVN_API avn_status avn_dynamic_bounds(avn_world* w, double* mn, double* mx) { GUARD(dynamic_bounds(mn, mx)); }
 AVN_API avn_status avn_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { GUARD(contact_manifolds(p, o)); }

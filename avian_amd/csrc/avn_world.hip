@@ -123,6 +123,13 @@ template <class T> struct World : WorldBase {
     uint32_t bias_timed = 0, bias_launches = 0;  // substeps timed in the last step; launches of one pass
     uint32_t substep_index = 0;
     bool ev_valid = false;
+    // SolverDiagnostics / CollisionDiagnostics stamps (avn_diagnostics_get): events on the world's stream
+    enum { DG_BP0 = 0, DG_BP1, DG_NP1, DG_PREP1, DG_INC1, DG_SUB1, DG_REST1, DG_FIN1, DG_STORE1, DG_STEP_COUNT, DG_SUBSTEPS = 16, DG_PER = 5 };
+    hipEvent_t ev_dg[DG_STEP_COUNT] = {nullptr};
+    hipEvent_t ev_dgs[DG_SUBSTEPS * DG_PER] = {nullptr};   // per substep: start, after warm start, after solve, after positions, end
+    bool dg_stamped[DG_STEP_COUNT] = {false};
+    uint32_t dg_substeps = 0; bool dg_np = false;
+    void stamp(int id) { if (ev_dg[id]) { (void)hipEventRecord(ev_dg[id], stream); dg_stamped[id] = true; } }
     DW<T> dw;
     BP<T> bp;
     // capacities
@@ -250,6 +257,8 @@ template <class T> struct World : WorldBase {
         if (stream_bp) (void)hipStreamDestroy(stream_bp);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_bias) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_dg) if (e) (void)hipEventDestroy(e);
+        for (auto& e : ev_dgs) if (e) (void)hipEventDestroy(e);
         if (ev_counters) (void)hipEventDestroy(ev_counters);
         if (h_counters) (void)hipHostFree(h_counters);
         if (stream) (void)hipStreamDestroy(stream);
@@ -282,6 +291,8 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventCreate(&ev_bp_t0)); HIPCHK(hipEventCreate(&ev_bp_t1));
         if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
         for (auto& x : ev) HIPCHK(hipEventCreate(&x));
+        for (auto& x : ev_dg) HIPCHK(hipEventCreate(&x));
+        for (auto& x : ev_dgs) HIPCHK(hipEventCreate(&x));
         for (auto& x : ev_bias) HIPCHK(hipEventCreate(&x));
         hipError_t err;
         b_misc.ensure(4096, err);
@@ -1585,6 +1596,7 @@ template <class T> struct World : WorldBase {
         }
         pipe_stats.last_overflow_manifolds = pipe_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - pipe_offsets[AVN_COLOR_OVERFLOW_INDEX];
         pipe_stats.last_host_ms = host_ms + std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        stamp(DG_NP1); dg_np = true;
         if ((st = solver()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
@@ -1835,6 +1847,7 @@ template <class T> struct World : WorldBase {
         pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
         lap();
         pipe_stats.last_host_ms = host_ms;
+        stamp(DG_NP1); dg_np = true;
         if ((st = solver()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
@@ -2063,7 +2076,11 @@ template <class T> struct World : WorldBase {
         ++launches;
     }
     void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)
+        const bool dg = !cfg.use_graph && substep_index < DG_SUBSTEPS;   // (events captured into a hipGraph cannot be read back)
+        hipEvent_t* de = ev_dgs + (size_t)substep_index * DG_PER;
+        if (dg) (void)hipEventRecord(de[0], stream);
         warm_start(true);  // integrate_velocities + warm_start
+        if (dg) (void)hipEventRecord(de[1], stream);
         // measurement hook: the dominant kernel's launches inside the step.  Direct launches only: events recorded as nodes of a
         // captured graph cannot be read back with hipEventElapsedTime on this runtime (hipErrorInvalidHandle).
         const bool timed = substep_index < BIAS_EV && dw.n_manifolds != 0 && !cfg.use_graph;
@@ -2071,16 +2088,20 @@ template <class T> struct World : WorldBase {
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_BIAS);
         if (timed) { (void)hipEventRecord(ev_bias[2 * substep_index + 1], stream); bias_launches = launches - bias_launches; bias_timed = substep_index + 1; }
         ++substep_index;
+        if (dg) (void)hipEventRecord(de[2], stream);
         integrate_positions();
+        if (dg) (void)hipEventRecord(de[3], stream);
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_RELAX);
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
         xpbd_velocity_projection();
         joint_damping();
+        if (dg) { (void)hipEventRecord(de[4], stream); dg_substeps = substep_index; }
     }
     bool islands_active() const { return island_mode && dw.n_joints == 0 && dw.n_manifolds != 0; }
     avn_status run_substeps() {
         substep_index = 0;
         bias_timed = 0;
+        dg_substeps = 0;
         if constexpr (sizeof(T) == 4) {
             if (islands_active()) {   // every substep of every island block in ONE launch (k_island_substeps)
                 launch_island_substeps(dw, params, islands, cfg.substeps, cfg.solver_iterations, stream); ++launches;
@@ -2138,7 +2159,9 @@ template <class T> struct World : WorldBase {
         prepare_solver_bodies();
         prepare_joints();
         prepare_contact_constraints();
+        stamp(DG_PREP1);
         pre_process_velocity_increments();
+        stamp(DG_INC1);
         // host work that only the substep loop needs, done while the prepare kernels above run
         if (islands_dirty) {
             islands_dirty = false;
@@ -2155,15 +2178,19 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventRecord(ev[2], stream));
         if ((st = run_substeps()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[3], stream));
+        stamp(DG_SUB1);
         launch_clear_increments<T>(dw, stream); ++launches;
         if (any_restitution) contact_pass(PASS_RESTITUTION_);  // restitution == 0 everywhere: every manifold would early-out
+        stamp(DG_REST1);
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
     avn_status solver_back() {    // the write-back into Position / Rotation / velocities and the ContactGraph
         launch_writeback_solver_bodies<T>(dw, stream); ++launches;
         if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
+        stamp(DG_FIN1);
         store_contact_impulses();
+        stamp(DG_STORE1);
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }
@@ -2252,6 +2279,8 @@ template <class T> struct World : WorldBase {
     avn_status step() override {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
+        for (bool& b : dg_stamped) b = false;
+        dg_np = false;
         if (pipe_on) return pipe_dev ? pipeline_step_device() : pipeline_step();
         launches = 0;
         HIPCHK(hipEventRecord(ev[0], stream));
@@ -2284,6 +2313,7 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp)); return AVN_OK; }
+    avn_status diagnostics(avn_diagnostics* d) override;
     avn_status timers(avn_timers* t) override {
         if (!t) return AVN_ERR_BAD_ARG;
         HIPCHK(hipStreamSynchronize(stream));
@@ -2314,6 +2344,39 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
 };
+
+template <class T> avn_status World<T>::diagnostics(avn_diagnostics* d) {
+    if (!d) return AVN_ERR_BAD_ARG;
+    std::memset(d, 0, sizeof *d);
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipStreamSynchronize(stream_bp));
+    if (!ev_valid) return AVN_OK;
+    auto ms = [&](hipEvent_t a, hipEvent_t b) { float f = 0; return hipEventElapsedTime(&f, a, b) == hipSuccess ? (double)f : 0.0; };
+    // step-level events of timers(): ev[0] step start, ev[1] after the broad phase, ev[2] before the substep loop, ev[3] after it, ev[4] end
+    d->broad_phase_ms = bp_timed ? ms(ev_bp_t0, ev_bp_t1) : ms(ev[0], ev[1]);
+    const bool np = dg_np && dg_stamped[DG_NP1];
+    if (np) d->narrow_phase_ms = ms(ev[1], ev_dg[DG_NP1]);
+    if (dg_stamped[DG_PREP1]) d->prepare_constraints_ms = ms(np ? ev_dg[DG_NP1] : ev[1], ev_dg[DG_PREP1]);
+    if (dg_stamped[DG_INC1]) d->update_velocity_increments_ms = ms(ev_dg[DG_PREP1], ev_dg[DG_INC1]);
+    d->substeps_ms = ms(ev[2], ev[3]);
+    if (dg_stamped[DG_REST1]) d->apply_restitution_ms = ms(ev_dg[DG_SUB1], ev_dg[DG_REST1]);
+    if (dg_stamped[DG_FIN1]) d->finalize_ms = ms(ev_dg[DG_REST1], ev_dg[DG_FIN1]);
+    if (dg_stamped[DG_STORE1]) d->store_impulses_ms = ms(ev_dg[DG_FIN1], ev_dg[DG_STORE1]);
+    if (dg_substeps && !cfg.use_graph && !islands_active()) {
+        for (uint32_t s = 0; s < dg_substeps; ++s) {
+            hipEvent_t* e = ev_dgs + (size_t)s * DG_PER;
+            d->warm_start_ms += ms(e[0], e[1]); d->solve_constraints_ms += ms(e[1], e[2]);
+            d->integrate_positions_ms += ms(e[2], e[3]); d->relax_velocities_ms += ms(e[3], e[4]);
+        }
+        d->per_system_valid = 1;
+    }
+    uint32_t cc = 0;
+    HIPCHK(hipMemcpyAsync(&cc, dw.constraint_count, 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    d->contact_constraint_count = cc;
+    d->contact_count = pipe_on ? (pipe_dev ? pgm_live : (uint32_t)pipe_active.size()) : last_timers.pair_count;
+    return AVN_OK;
+}
 
 template <class T> static WorldBase* make_world(const avn_config* cfg, avn_status* st, std::string* err) {
     World<T>* w = new (std::nothrow) World<T>();

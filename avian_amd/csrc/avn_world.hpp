@@ -74,6 +74,7 @@ struct WorldBase {
     virtual avn_status step() = 0;
     virtual avn_status synchronize() = 0;
     virtual avn_status timers(avn_timers*) = 0;
+    virtual avn_status diagnostics(avn_diagnostics*) = 0;
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
     virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;

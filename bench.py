@@ -92,6 +92,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the PCIe-inclusive leg")
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (device narrow phase) leg")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc side pass that measures roofline.traffic in this run")
+    ap.add_argument("--no-iters8", action="store_true", help="skip the solver_iterations = 8 extension leg")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample (split between the 1-thread and the multi-thread run)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-thread CPU sample (default min(64, host cores))")
     args = ap.parse_args()
@@ -212,39 +214,106 @@ def main():
         in_step = {"avg_launch_us": round(t_in * 1e6, 3), "frac": round((algo_bytes_per_pass / int(tm_direct.bias_pass_launches)) / t_in / 1e9 / HBM_PEAK_GBS, 5),
                    "note": "pass time / launches inside whole steps (direct launches): includes inter-launch gaps and the contention of the broad phase "
                            "running on its own stream next to the first substep"}
+    # HBM traffic of the dominant kernel: measured IN THIS RUN by a rocprofv3 side pass (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of
+    # this script, kernel-trace only; corrections as MI355X_MICROARCH.md prescribes: tools/pmc_traffic.py).  When the side pass is skipped
+    # or fails, `traffic` is null and `traffic_from_profile` names the committed file the last measured figure came from.
     traffic = None
-    pmc = os.path.join(REPO, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(pmc):
+    traffic_src = None
+    if rank == 0 and world_size == 1 and not args.no_traffic:
+        import subprocess
+        outp = os.path.join(REPO, "gpurun_out", "bench_pmc_traffic.json")
+        os.makedirs(os.path.dirname(outp), exist_ok=True)
         try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            r = subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_traffic.py"), outp, "--steps", "2", "--warmup", "1", "--scene", args.scene],
+                               capture_output=True, text=True, timeout=240)
+            if r.returncode == 0 and os.path.exists(outp):
+                traffic = json.load(open(outp)).get("hbm_bytes_per_launch")
+                traffic_src = "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE side passes of this run (tools/pmc_traffic.py)"
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": "k_color_pass<float, SOLVE_BIAS>", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "avg_launch_us": round(avg_launch_s * 1e6, 3), "launches_per_pass": launches_per_pass,
+    if traffic is None:
+        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+            pmc = os.path.join(REPO, "profiles", name)
+            if os.path.exists(pmc):
+                traffic_src = {"traffic_from_profile": "profiles/" + name, "hbm_bytes_per_launch": json.load(open(pmc)).get("hbm_bytes_per_launch"),
+                               "note": "NOT measured in this run"}
+                break
+    # whole-step figure of SURVEY.md §8(d): (228 N + (672 + 212 P) M) bytes per substep against the whole step's wall time
+    n_dyn = sc.n - 1
+    algo_bytes_per_substep = 228 * n_dyn + 672 * meta["n_manifolds"] + 212 * pts
+    step_s = elapsed / args.steps
+    whole_step = {"algorithmic_bytes_per_step": int(algo_bytes_per_substep * substeps), "achieved": round(algo_bytes_per_substep * substeps / step_s / 1e9, 2),
+                  "frac": round(algo_bytes_per_substep * substeps / step_s / 1e9 / HBM_PEAK_GBS, 5),
+                  "substep_loop_frac": round(algo_bytes_per_substep * substeps / (tm.substeps_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5) if tm.substeps_ms > 0 else None}
+    iso = {"avg_launch_us": round(avg_launch_s * 1e6, 3), "achieved": round(achieved_gbs, 2), "frac": round(achieved_gbs / HBM_PEAK_GBS, 5),
+           "measured": "20 back-to-back biased-solve passes on the world's stream, HIP events on that stream, nothing else running"}
+    if in_step is not None:   # the PRIMARY figure: the launches as they run inside whole steps
+        t_in = in_step["avg_launch_us"] * 1e-6
+        prim_gbs = (algo_bytes_per_pass / int(tm_direct.bias_pass_launches)) / t_in / 1e9
+        prim = {"achieved": round(prim_gbs, 2), "frac": round(prim_gbs / HBM_PEAK_GBS, 5), "avg_launch_us": in_step["avg_launch_us"],
+                "measured": "HIP events around the biased-solve pass of every substep inside whole steps (direct launches, broad phase overlapped on its own stream): pass time / launches"}
+    else:
+        prim = {"achieved": iso["achieved"], "frac": iso["frac"], "avg_launch_us": iso["avg_launch_us"], "measured": iso["measured"]}
+    roofline = {"bound": "hbm", "kernel": "k_color_pass<float, SOLVE_BIAS>", "achieved": prim["achieved"], "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": prim["frac"], "traffic": traffic, "traffic_source": traffic_src,
+                "avg_launch_us": prim["avg_launch_us"], "launches_per_pass": launches_per_pass,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_pass / launches_per_pass),
-                "measured": "20 back-to-back biased-solve passes (300 launches) on the world's stream, HIP events on that stream, nothing else running",
-                "in_step": in_step}
+                "measured": prim["measured"], "isolated": iso, "whole_step": whole_step}
+
+    # ---- declared extension: solver_iterations = 8 (BASELINE.json config 2 says "4 substeps x 8 XPBD iters"; the reference has no such knob --
+    # SURVEY.md header note 2 -- so this is NOT the parity configuration and never `value`): 8 outer repeats of the biased solve, the relax pass
+    # and the joint pass per substep
+    iters8 = None
+    if rank == 0 and world_size == 1 and not args.no_iters8:
+        cfg.solver_iterations = 8
+        w.config_set(cfg)
+        for _ in range(2):
+            w.step()
+        w.synchronize()
+        n8 = max(3, min(10, args.steps))
+        c0 = time.perf_counter()
+        for _ in range(n8):
+            w.step()
+        w.synchronize()
+        ms8 = (time.perf_counter() - c0) / n8 * 1e3
+        iters8 = {"solver_iterations": 8, "ms_per_step": round(ms8, 4), "substeps_per_s": round(substeps / (ms8 / 1e3), 2),
+                  "contact_passes_per_s": round(substeps * 16 / (ms8 / 1e3), 1),
+                  "note": "declared extension of avn_config (not reference behaviour): each substep repeats biased solve, relax and the joint pass 8 times"}
+        cfg.solver_iterations = 1
+        w.config_set(cfg)
 
     # ---- PCIe-inclusive step (reported next to `value`, never as `value`): what a host-resident ECS pays when the boundary
-    # hands over host buffers every step — re-upload bodies + the colour-major manifold set, step, download bodies + impulses
+    # hands over host buffers every step — re-upload bodies + the colour-major manifold set, step, download bodies + impulses.
+    # The host arrays are PINNED (page-locked) once, as a Bevy integration would keep its staging buffers, so that the figure is the bus,
+    # not the pageable-copy path (which swung 14 -> 29 ms between boxes in round 1).
     pcie = None
     if rank == 0 and world_size == 1 and not args.no_pcie:
         from avian_amd import scenes
-        n_p = 3
+
+        def pinned(a):
+            if a is None or not hasattr(a, "nbytes") or a.nbytes == 0:
+                return a
+            t = torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+            keep.append(t)
+            return t.numpy()
+        keep = []
+        bk = {k: pinned(v) for k, v in sc.body_kwargs().items()}
+        mfp = {k: pinned(v) for k, v in meta["manifolds"].items()}
+        n_p = 5
+        w.bodies_upload(**bk); scenes.upload_manifolds(w, mfp, meta["offsets"], sc.friction, sc.restitution); w.step()
         w.synchronize()
         c0 = time.perf_counter()
         for _ in range(n_p):
-            w.bodies_upload(**sc.body_kwargs())
-            scenes.upload_manifolds(w, meta["manifolds"], meta["offsets"], sc.friction, sc.restitution)
+            w.bodies_upload(**bk)
+            scenes.upload_manifolds(w, mfp, meta["offsets"], sc.friction, sc.restitution)
             w.step()
             w.bodies_download(); w.impulses_download()
         w.synchronize()
         ms_p = (time.perf_counter() - c0) / n_p * 1e3
-        host_bytes = sum(int(np.asarray(v).nbytes) for v in sc.body_kwargs().values() if v is not None) + \
-            sum(int(np.asarray(v).nbytes) for v in meta["manifolds"].values() if hasattr(v, "nbytes"))
+        host_bytes = sum(int(np.asarray(v).nbytes) for v in bk.values() if v is not None) + \
+            sum(int(np.asarray(v).nbytes) for v in mfp.values() if hasattr(v, "nbytes"))
         pcie = {"ms_per_step": round(ms_p, 3), "substeps_per_s": round(substeps / (ms_p / 1e3), 2), "host_bytes_up_per_step": host_bytes,
-                "note": "pageable host arrays through avn_bodies_upload / avn_manifolds_upload / *_download every step (incidence CSR rebuilt on the host); "
+                "note": "pinned host arrays through avn_bodies_upload / avn_manifolds_upload / *_download every step (incidence CSR rebuilt on the host); "
                         "the device-resident path above keeps everything in HBM"}
 
     # ---- closed loop (secondary figure, never `value`): the same bodies with the DEVICE narrow phase instead of the fixed
@@ -255,23 +324,34 @@ def main():
         wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
         wc.existing_pairs_upload(np.zeros(0, np.uint64))
         wc.collider_materials_upload(friction=sc.friction, restitution=sc.restitution)
-        wc.pipeline_enable()
+        wc.pipeline_enable()    # ContactGraph / IdPool / ConstraintGraph bookkeeping on the device (k_graph.hip)
+
+        def window(n):
+            wc.synchronize()
+            c0 = time.perf_counter()
+            host = ch = byt = 0.0; ovf = 0
+            for _ in range(n):
+                wc.step()
+                ps = wc.pipeline_stats(); host += ps.last_host_ms; ch += ps.last_status_changes; ovf = max(ovf, ps.last_overflow_manifolds)
+                byt += substeps * (228 * (sc.n - 1) + 1520 * ps.manifolds)     # SURVEY.md §8(d) with P = 4 (an upper bound: piles hold 1-4 points)
+            wc.synchronize()
+            ms = (time.perf_counter() - c0) / n * 1e3
+            ps = wc.pipeline_stats()
+            return {"ms_per_step": round(ms, 3), "substeps_per_s": round(substeps / (ms / 1e3), 2), "host_bookkeeping_ms": round(host / n, 3),
+                    "status_changes_per_step": round(ch / n, 1), "manifolds_at_end": ps.manifolds, "max_overflow_manifolds": int(ovf),
+                    "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(byt / n / (ms / 1e3) / 1e9, 2),
+                                 "frac": round(byt / n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                                 "note": "whole closed-loop step: solver bytes of SURVEY.md §8(d) at P = 4 (upper bound) / wall time; the narrow phase's and the bookkeeping's own bytes are not counted"}}
         for _ in range(4):
             wc.step()
-        wc.synchronize()
-        n_c = 10
-        c0 = time.perf_counter()
-        host_ms = changes = 0.0
-        for _ in range(n_c):
-            wc.step()
-            ps = wc.pipeline_stats(); host_ms += ps.last_host_ms; changes += ps.last_status_changes
-        wc.synchronize()
-        ms_c = (time.perf_counter() - c0) / n_c * 1e3
+        transient = window(20)   # steps 4..23: the pile is still compacting (~2e5 status changes per step, an overflow colour 10^5 strong and hundreds of levels deep)
+        settled = window(20)     # steps 24..43
         ps = wc.pipeline_stats()
-        closed = {"ms_per_step": round(ms_c, 3), "substeps_per_s": round(substeps / (ms_c / 1e3), 2), "active_pairs": ps.active_pairs,
-                  "manifolds": ps.manifolds, "overflow_manifolds": ps.last_overflow_manifolds, "status_changes_per_step": round(changes / n_c, 1),
-                  "host_bookkeeping_ms": round(host_ms / n_c, 3),
-                  "note": "avn_pipeline_enable: Ball/Cuboid narrow phase on device (parry part parity-unpinned), host status processing in the library"}
+        closed = {"ms_per_step": settled["ms_per_step"], "substeps_per_s": settled["substeps_per_s"], "host_bookkeeping_ms": settled["host_bookkeeping_ms"],
+                  "window": "steps 24..43 after avn_pipeline_enable (20 steps)", "active_pairs": ps.active_pairs, "roofline": settled["roofline"],
+                  "settled": settled, "transient_steps_4_23": transient,
+                  "note": "avn_pipeline_enable(1): broad phase -> Ball/Cuboid narrow phase (parry part parity-unpinned) -> status-change loop, greedy colouring, handle lists "
+                          "and the overflow colour's order ALL on the device; per step the host reads three counter blocks"}
         del wc
 
     # ---- CPU baseline: the oracle on the same inputs, rank 0 at N=1 only, bounded sample -------------------------
@@ -304,7 +384,7 @@ def main():
             wo.close()
             return {"value": round(n_cpu * substeps / cpu_s, 4), "unit": "substeps/s", "cores": threads, "kind": "port",
                     "sample": f"{n_cpu} whole steps ({n_cpu * substeps} substeps) of the same {args.scene} inputs after 1 warm-up step, "
-                              f"C++ oracle (g++ -O2 -ffp-contract=off) with {threads} thread(s) on {os.cpu_count()} host cores"
+                              f"C++ oracle (g++ -O3 -ffp-contract=off) with {threads} thread(s) on {os.cpu_count()} host cores"
                               + ("" if threads == 1 else "; threads follow the reference's own parallel loops (par_for_each over a colour's constraints, "
                                                           "chunk = len / threads, min_len 64; par_iter_mut over bodies); the broad phase is serial as in the reference"),
                     "ms_per_step": round(cpu_s / n_cpu * 1e3, 2), "substep_loop_only_ms": round(sm, 2)}
@@ -344,6 +424,7 @@ def main():
                           "kernel_launches_per_step": tm.kernel_launches},
             "substep_loop_only_substeps_per_s": round(substeps / (tm.substeps_ms / 1e3), 2) if tm.substeps_ms > 0 else None,
             "roofline": roofline,
+            "solver_iterations_8": iters8,
             "pcie_inclusive": pcie,
             "closed_loop": closed,
             "cpu_baseline": cpu,

@@ -423,6 +423,33 @@ typedef struct avn_timers {
     uint32_t reserved0;
 } avn_timers;
 
+/* SolverDiagnostics (dynamics/solver/diagnostics.rs:13-37) and CollisionDiagnostics (collision/diagnostics.rs:13-19): the same fields in
+ * the same meaning, as milliseconds of the LAST avn_step -- what a replacement plugin writes into those two resources.  The systems of the
+ * SubstepSchedule are accumulated over the step's substeps, as the reference accumulates them (solver/plugin.rs:459,481 ...).  Device times
+ * come from events on the world's stream; per-substep systems need direct launches (events captured into a hipGraph cannot be read back):
+ * with avn_config.use_graph = 1 the five substep fields are 0, `substeps_ms` carries the loop's total and `per_system_valid` is 0.
+ * integrate_velocities is fused into the warm-start launch (k_body_warm_start): its time is part of warm_start_ms and the field is 0. */
+typedef struct avn_diagnostics {
+    double prepare_constraints_ms;         /* SolverSystems::PrepareSolverBodies .. PrepareContactConstraints (+ PrepareJoints) */
+    double update_velocity_increments_ms;  /* pre_process_velocity_increments */
+    double integrate_velocities_ms;
+    double warm_start_ms;
+    double solve_constraints_ms;           /* solve_contacts<true> */
+    double integrate_positions_ms;
+    double relax_velocities_ms;            /* solve_contacts<false> (+ the XPBD systems that follow it in the substep) */
+    double apply_restitution_ms;           /* clear_velocity_increments + solve_restitution */
+    double finalize_ms;                    /* writeback_solver_bodies + writeback_joint_forces */
+    double store_impulses_ms;
+    double swept_ccd_ms;                   /* always 0: SweptCcd is outside the path */
+    double substeps_ms;                    /* the whole substep loop (always filled) */
+    double broad_phase_ms;                 /* CollisionDiagnostics::broad_phase: update_aabb + collect_collision_pairs */
+    double narrow_phase_ms;                /* CollisionDiagnostics::narrow_phase: update_contacts + the status-change processing (closed loop only) */
+    uint32_t contact_constraint_count;
+    uint32_t contact_count;                /* contact pairs in the ContactGraph (closed loop), else broad-phase pairs of the step */
+    uint32_t per_system_valid;
+    uint32_t reserved0;
+} avn_diagnostics;
+
 /* ---- entry points --------------------------------------------------------------------------- */
 AVN_API avn_status AVN_FN(world_create)(const avn_config* cfg, avn_world** out);
 AVN_API void AVN_FN(world_destroy)(avn_world* w);
@@ -472,6 +499,7 @@ AVN_API avn_status AVN_FN(timers_get)(avn_world* w, avn_timers* out);
  * events ON THAT STREAM; returns the total elapsed milliseconds and the number of kernel launches issued.
  * (The oracle times the same calls with a host clock.)  The reference's equivalent is the per-system
  * `Instant::now()/elapsed()` accumulation into SolverDiagnostics (solver/plugin.rs:459,481). */
+AVN_API avn_status AVN_FN(diagnostics_get)(avn_world* w, avn_diagnostics* out);
 AVN_API avn_status AVN_FN(profile_system)(avn_world* w, avn_system sys, uint32_t repeats, double* total_ms,
                                            uint32_t* kernel_launches);
 

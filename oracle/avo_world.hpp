@@ -285,6 +285,7 @@ struct WorldBase {
     virtual avn_status run_system(avn_system) = 0;
     virtual avn_status step() = 0;
     virtual avn_status timers(avn_timers*) = 0;
+    virtual avn_status diagnostics(avn_diagnostics*) = 0;
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
     virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;
@@ -1735,15 +1736,24 @@ template <class S> struct World : WorldBase {
     // =============================================================================================
     //                                      SCHEDULES
     // =============================================================================================
+    // SolverDiagnostics / CollisionDiagnostics of the last step, wall clock like the reference's own Instant::now() pairs (plugin.rs:459,481)
+    avn_diagnostics diag{};
+    template <class Fn> void timed(double& acc, Fn&& f) {
+        auto t0 = std::chrono::steady_clock::now();
+        f();
+        acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     void substep() {  // SubstepSchedule order, solver/schedule.rs:59-69 + xpbd/plugin.rs:30-40
-        integrate_velocities();
-        warm_start();
-        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(true);
-        integrate_positions();
-        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(false);
-        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve_iter(it);
-        xpbd_velocity_projection();
-        joint_damping();
+        timed(diag.integrate_velocities_ms, [&] { integrate_velocities(); });
+        timed(diag.warm_start_ms, [&] { warm_start(); });
+        timed(diag.solve_constraints_ms, [&] { for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(true); });
+        timed(diag.integrate_positions_ms, [&] { integrate_positions(); });
+        timed(diag.relax_velocities_ms, [&] {
+            for (uint32_t it = 0; it < cfg.solver_iterations; ++it) solve_contacts(false);
+            for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve_iter(it);
+            xpbd_velocity_projection();
+            joint_damping();
+        });
     }
     // extension: extra joint iterations must not re-take the pre-solve snapshot
     void xpbd_solve_iter(uint32_t it) {
@@ -1754,16 +1764,16 @@ template <class S> struct World : WorldBase {
         for (size_t i = 0; i < bodies.size(); ++i) { bodies[i].pre_solve_delta_position = sp[i]; bodies[i].pre_solve_delta_rotation = sq[i]; }
     }
     void solver() {  // SolverSystems, solver/schedule.rs:32-46
-        prepare_solver_bodies();
-        prepare_joints();
-        prepare_contact_constraints();
-        pre_process_velocity_increments();
-        for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
-        clear_velocity_increments();
-        solve_restitution();
-        writeback_solver_bodies();
-        writeback_joint_forces();
-        store_contact_impulses();
+        const double bp = diag.broad_phase_ms, np_ms = diag.narrow_phase_ms;
+        diag = avn_diagnostics{};
+        diag.broad_phase_ms = bp; diag.narrow_phase_ms = np_ms; diag.per_system_valid = 1;
+        timed(diag.prepare_constraints_ms, [&] { prepare_solver_bodies(); prepare_joints(); prepare_contact_constraints(); });
+        timed(diag.update_velocity_increments_ms, [&] { pre_process_velocity_increments(); });
+        timed(diag.substeps_ms, [&] { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); });
+        timed(diag.apply_restitution_ms, [&] { clear_velocity_increments(); solve_restitution(); });
+        timed(diag.finalize_ms, [&] { writeback_solver_bodies(); writeback_joint_forces(); });
+        timed(diag.store_impulses_ms, [&] { store_contact_impulses(); });
+        diag.contact_constraint_count = last_timers.contact_constraint_count;
     }
     avn_status run_system(avn_system sys) override {
         switch (sys) {
@@ -1794,11 +1804,14 @@ template <class S> struct World : WorldBase {
     }
     avn_status step() override {
         if (pipe) return pipeline_step();
-        if (have_colliders) { update_aabb(); collect_collision_pairs(); }
+        diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
+        if (have_colliders) timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
         solver();
+        diag.contact_count = (uint32_t)pairs.size();
         return AVN_OK;
     }
     avn_status timers(avn_timers* t) override { if (!t) return AVN_ERR_BAD_ARG; *t = last_timers; return AVN_OK; }
+    avn_status diagnostics(avn_diagnostics* d) override { if (!d) return AVN_ERR_BAD_ARG; *d = diag; return AVN_OK; }
     avn_status profile_system(avn_system sys, uint32_t repeats, double* total_ms, uint32_t* launches) override {
         auto t0 = std::chrono::steady_clock::now();
         for (uint32_t r = 0; r < repeats; ++r) { avn_status st = run_system(sys); if (st != AVN_OK) return st; }
@@ -1912,8 +1925,9 @@ template <class S> avn_status World<S>::pipeline_handles_get(uint32_t* off, cons
 }
 template <class S> avn_status World<S>::pipeline_step() {
     PipelineState& P = *pipe;
-    update_aabb();
-    collect_collision_pairs();
+    diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
+    timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
+    auto np_t0 = std::chrono::steady_clock::now();
     if (!pairs.empty()) {
         std::vector<uint32_t> ids, c1, c2, fl;
         for (const avn_pair& pr : pairs) {
@@ -1998,6 +2012,7 @@ template <class S> avn_status World<S>::pipeline_step() {
         P.handles_dirty = false;
     }
     P.stats.last_overflow_manifolds = P.offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - P.offsets[AVN_COLOR_OVERFLOW_INDEX];
+    diag.narrow_phase_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - np_t0).count();
     if (pipe_stats_on) {
         // dependency-round depth of the op sequence (ops sharing a non-static body are ordered), pops per colour, pops that hit
         // the tail window of their colour's list, level depth of the overflow colour
@@ -2045,6 +2060,7 @@ template <class S> avn_status World<S>::pipeline_step() {
                      contact_changes.size(), n_push, n_pop, pops_c[AVN_COLOR_OVERFLOW_INDEX], max_pops, win_pops, max_depth, P.handles.size(), P.stats.last_overflow_manifolds, levels, pairs.size(), removed.size());
     }
     solver();
+    diag.contact_count = (uint32_t)P.active.size();
     return AVN_OK;
 }
 

@@ -45,6 +45,7 @@ avn_status avo_run_system(avn_world* w, avn_system s) { FWD(run_system(s)); }
 avn_status avo_step(avn_world* w) { FWD(step()); }
 avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
+avn_status avo_diagnostics_get(avn_world* w, avn_diagnostics* d) { FWD(diagnostics(d)); }
 avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
 avn_status avo_dynamic_bounds(avn_world* w, double* mn, double* mx) { FWD(dynamic_bounds(mn, mx)); }
 avn_status avo_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { FWD(contact_manifolds(p, o)); }

@@ -24,7 +24,7 @@ def collect(counter, tag, bench_args):
     os.makedirs(d, exist_ok=True)
     env = dict(os.environ, TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", tag, "--",
-           sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-pcie", "--no-closed-loop"] + bench_args
+           sys.executable, os.path.join(REPO, "bench.py"), "--no-cpu-baseline", "--no-pcie", "--no-closed-loop", "--no-traffic", "--no-iters8"] + bench_args
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     open(os.path.join(d, "stdout.log"), "w").write(r.stdout + "\n---\n" + r.stderr[-4000:])
     files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
