@@ -1,0 +1,27 @@
+//! MI355X plugins for Avian's 3D hot path.
+//!
+//! ```ignore
+//! app.add_plugins(
+//!     PhysicsPlugins::default()
+//!         .build()
+//!         .disable::<BroadPhasePlugin>()      // src/collision/broad_phase.rs:33-170
+//!         .disable::<NarrowPhasePlugin>()     // only with `Mi355xMode::ClosedLoop` (Ball / Cuboid colliders)
+//!         .disable::<IntegratorPlugin>()      // src/dynamics/integrator/mod.rs:45-88
+//!         .disable::<SolverPlugin>()          // src/dynamics/solver/plugin.rs:88-151
+//!         .disable::<XpbdSolverPlugin>()      // src/dynamics/solver/xpbd/plugin.rs:21-110
+//!         .add(Mi355xPhysicsPlugin::default()),
+//! );
+//! ```
+//! `SolverSchedulePlugin` stays enabled: it owns the ordering of `SolverSystems` and the substep runner
+//! (src/dynamics/solver/schedule.rs:32-49); the systems of this crate are added INTO the reference's own sets
+//! (the mechanism of crates/avian3d/examples/custom_broad_phase.rs:63-72), so everything else in Avian keeps its place.
+//!
+//! Layers: [`world::Mi355xWorld`] is the safe owner of the `avn_world*`; [`staging::Staging`] turns ECS queries into the
+//! Structure-of-Arrays the C ABI borrows for the duration of a call; [`plugins`] holds the systems.
+
+pub mod plugins;
+pub mod staging;
+pub mod world;
+
+pub use plugins::{Mi355xMode, Mi355xPhysicsPlugin};
+pub use world::{Mi355xError, Mi355xWorld};

@@ -1,0 +1,212 @@
+//! The replacement plugins.  Every system is added into the system set of the reference system it replaces, so the rest of Avian
+//! (narrow phase, sleeping, spatial queries, transform sync, user systems ordered against Avian's sets) keeps its ordering.
+
+use crate::{staging::Staging, world::{default_config, Mi355xWorld}};
+use avian3d::{
+    collision::{broad_phase::BroadPhaseSystems, narrow_phase::NarrowPhaseConfig},
+    dynamics::{
+        integrator::IntegrationSystems,
+        solver::{
+            constraint_graph::ConstraintGraph,
+            schedule::{SolverSystems, SubstepCount},
+            solver_body::SolverBody,
+            SolverConfig, SolverDiagnostics,
+        },
+    },
+    collision::CollisionDiagnostics,
+    prelude::*,
+};
+use avian_mi355x_sys as ffi;
+use bevy::prelude::*;
+use core::time::Duration;
+
+/// How much of the step stays on the device.
+#[derive(Clone, Copy, Default, PartialEq, Eq)]
+pub enum Mi355xMode {
+    /// Avian's own (parry) narrow phase keeps running on the host; its manifolds are uploaded every step (`avn_manifolds_upload`),
+    /// the substep loop runs device-resident.  Works with every collider shape; pays the manifold upload over PCIe.
+    #[default]
+    HostNarrowPhase,
+    /// Ball / Cuboid colliders only: contact rows live in HBM, `NarrowPhase::update_contacts`, the status-change loop, the
+    /// `ConstraintGraph` and the `IdPool` run on the device (`avn_pipeline_enable(1)`); per step only new pairs and body state cross
+    /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_contact_changes_get` by `gpu_closed_loop_events`.
+    ClosedLoop,
+}
+
+#[derive(Default)]
+pub struct Mi355xPhysicsPlugin {
+    pub mode: Mi355xMode,
+    pub device: i32,
+}
+
+#[derive(Resource, Default)]
+struct Mi355xStaging(Staging);
+#[derive(Resource)]
+struct Mi355xSettings { mode: Mi355xMode }
+
+impl Plugin for Mi355xPhysicsPlugin {
+    fn build(&self, app: &mut App) {
+        let mut config = default_config();
+        config.device = self.device;
+        let world = match Mi355xWorld::new(config) {
+            Ok(w) => w,
+            // no gfx950 device: there is no CPU fallback in the library -- the application keeps the stock plugins
+            Err(e) => panic!("{e}: do not disable Avian's BroadPhasePlugin / IntegratorPlugin / SolverPlugin / XpbdSolverPlugin on a host without an MI355X"),
+        };
+        app.insert_resource(world).init_resource::<Mi355xStaging>().insert_resource(Mi355xSettings { mode: self.mode });
+        app.init_resource::<SolverDiagnostics>().init_resource::<CollisionDiagnostics>();
+
+        // the same sets as the plugins being replaced: src/collision/broad_phase.rs:51-74, src/dynamics/solver/plugin.rs:103-150,
+        // src/dynamics/integrator/mod.rs:52-71
+        app.add_systems(
+            PhysicsSchedule,
+            (
+                (sync_config, gpu_upload_bodies, gpu_broad_phase).chain().in_set(BroadPhaseSystems::CollectCollisions),
+                gpu_upload_constraints.in_set(SolverSystems::PrepareContactConstraints).run_if(|s: Res<Mi355xSettings>| s.mode == Mi355xMode::HostNarrowPhase),
+                gpu_solver.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER)
+                gpu_download.in_set(SolverSystems::StoreContactImpulses),
+                gpu_diagnostics.after(SolverSystems::StoreContactImpulses),
+            ),
+        );
+        // IntegratorPlugin's own bookkeeping set stays meaningful for user systems ordered against it
+        app.configure_sets(PhysicsSchedule, IntegrationSystems::UpdateVelocityIncrements.before(SolverSystems::Substep));
+    }
+}
+
+/// `SubstepCount`, `Gravity`, `SolverConfig`, `PhysicsLengthUnit`, `NarrowPhaseConfig`, the step's delta -> `avn_config_set` when any changed.
+fn sync_config(
+    mut w: ResMut<Mi355xWorld>, substeps: Res<SubstepCount>, gravity: Res<Gravity>, solver: Res<SolverConfig>, length_unit: Res<PhysicsLengthUnit>,
+    narrow: Res<NarrowPhaseConfig>, time: Res<Time<Physics>>,
+) {
+    let mut c = w.config;
+    c.substeps = substeps.0;
+    c.dt_ns = time.delta().as_nanos() as u64;
+    c.gravity = [gravity.0.x as f64, gravity.0.y as f64, gravity.0.z as f64];
+    c.length_unit = length_unit.0 as f64;
+    c.contact_damping_ratio = solver.contact_damping_ratio as f64;
+    c.contact_frequency_factor = solver.contact_frequency_factor as f64;
+    c.max_overlap_solve_speed = solver.max_overlap_solve_speed as f64;
+    c.warm_start_coefficient = solver.warm_start_coefficient as f64;
+    c.restitution_threshold = solver.restitution_threshold as f64;
+    c.restitution_iterations = solver.restitution_iterations as u32;
+    c.match_contacts = narrow.match_contacts as u32;
+    c.default_speculative_margin = narrow.default_speculative_margin as f64;
+    c.contact_tolerance = narrow.contact_tolerance as f64;
+    if c.dt_ns != 0 && (c.substeps, c.dt_ns, c.gravity, c.length_unit) != (w.config.substeps, w.config.dt_ns, w.config.gravity, w.config.length_unit)
+        || solver.is_changed() || narrow.is_changed()
+    {
+        w.set_config(c);
+    }
+}
+
+/// ECS -> device: what `prepare_solver_bodies` (src/dynamics/solver/solver_body/plugin.rs:173-251) and `update_aabb`
+/// (src/collision/collider/backend.rs:498-624) read.
+fn gpu_upload_bodies(
+    mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
+    increments: Query<&VelocityIntegrationData>,
+    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
+) {
+    let st = &mut st.0;
+    st.fill_bodies(bodies.iter(), |e| increments.get(e).map_or((Vec3::ZERO, Vec3::ZERO), |v| (v.linear_increment(), v.angular_increment())));
+    st.fill_colliders(colliders.iter());
+    let (b, c) = (st.bodies_desc(), st.colliders_desc());
+    let raw = w.raw();
+    let s1 = unsafe { ffi::avn_bodies_upload(raw, &b) }; w.check(s1);
+    let s2 = unsafe { ffi::avn_colliders_upload(raw, &c) }; w.check(s2);
+}
+
+/// BroadPhasePlugin replacement (src/collision/broad_phase.rs:347-474): device AABB update + sweep-and-prune; the new pairs come back in
+/// the reference's emission order and become `ContactEdge`s exactly as `sweep_and_prune` creates them (:443-468).
+fn gpu_broad_phase(
+    mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, settings: Res<Mi355xSettings>, mut contact_graph: ResMut<ContactGraph>,
+    mut diagnostics: ResMut<CollisionDiagnostics>,
+) {
+    if settings.mode == Mi355xMode::ClosedLoop { return; }   // avn_step runs the broad phase itself (gpu_solver)
+    w.run_system(ffi::AVN_SYS_UPDATE_AABB);
+    w.run_system(ffi::AVN_SYS_COLLECT_COLLISION_PAIRS);
+    let entity_of = |index: u32| st.0.collider_entities[st.0.c_entity_index.iter().position(|&i| i == index).expect("collider of a device pair")];
+    let pairs: Vec<ffi::avn_pair> = w.pairs().to_vec();
+    for pair in pairs {
+        // AVN_PAIR_NEEDS_CUSTOM_FILTER: CollisionHooks::filter_pairs cannot be called from the device (src/collision/broad_phase.rs:431-439):
+        // such pairs are created unfiltered and the narrow phase's hook pass removes them, like pairs whose filter changed its mind.
+        let (c1, c2) = (entity_of(pair.collider1), entity_of(pair.collider2));
+        let (b1, b2) = (st.0.body_entities[pair.body1 as usize], st.0.body_entities[pair.body2 as usize]);
+        let mut edge = ContactEdge::new(c1, c2);
+        edge.body1 = Some(b1); edge.body2 = Some(b2);
+        contact_graph.add_edge_with(edge, |contact_pair| {
+            contact_pair.body1 = Some(b1); contact_pair.body2 = Some(b2);
+            contact_pair.flags.set(ContactPairFlags::GENERATE_CONSTRAINTS, pair.flags & ffi::AVN_PAIR_GENERATE_CONSTRAINTS != 0);
+            contact_pair.flags.set(ContactPairFlags::MODIFY_CONTACTS, pair.flags & ffi::AVN_PAIR_MODIFY_CONTACTS != 0);
+            contact_pair.flags.set(ContactPairFlags::CONTACT_EVENTS, pair.flags & ffi::AVN_PAIR_CONTACT_EVENTS != 0);
+        });
+    }
+    diagnostics.broad_phase += Duration::from_secs_f64(w.diagnostics().broad_phase_ms * 1e-3);
+}
+
+/// `prepare_contact_constraints` replacement (src/dynamics/solver/plugin.rs:363-448), host narrow phase mode: the colour-major manifold set.
+fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, constraint_graph: Res<ConstraintGraph>, contact_graph: Res<ContactGraph>) {
+    st.0.fill_manifolds(&constraint_graph, &contact_graph);
+    let m = st.0.manifolds_desc();
+    let raw = w.raw();
+    let s = unsafe { ffi::avn_manifolds_upload(raw, &m) };
+    w.check(s);
+}
+
+/// SolverSystems::PrepareSolverBodies .. Restitution in one call.  `SolverSchedulePlugin`'s own runner (src/dynamics/solver/schedule.rs:194-213)
+/// still loops over the (now nearly empty) `SubstepSchedule`; user systems added there see host `SolverBody` state only if the application
+/// opts into per-substep round trips (caveat).
+fn gpu_solver(mut w: ResMut<Mi355xWorld>, settings: Res<Mi355xSettings>) {
+    match settings.mode {
+        Mi355xMode::HostNarrowPhase => w.run_system(ffi::AVN_SYS_SOLVER),
+        Mi355xMode::ClosedLoop => w.step(),   // avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
+    }
+}
+
+/// `writeback_solver_bodies` (src/dynamics/solver/solver_body/plugin.rs:255-284) + `store_contact_impulses` (src/dynamics/solver/plugin.rs:722-755).
+fn gpu_download(
+    mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, settings: Res<Mi355xSettings>,
+    mut bodies: Query<(&mut Position, &mut Rotation, &mut LinearVelocity, &mut AngularVelocity), With<SolverBody>>, mut contact_graph: ResMut<ContactGraph>,
+) {
+    let st = &mut st.0;
+    let out = st.bodies_out_desc();
+    let raw = w.raw();
+    let s = unsafe { ffi::avn_bodies_download(raw, &out) }; w.check(s);
+    for (i, &e) in st.body_entities.iter().enumerate() {
+        let Ok((mut p, mut r, mut lv, mut av)) = bodies.get_mut(e) else { continue };   // only bodies that own a SolverBody are written back
+        p.0 = Vec3::from_slice(&st.out_position[3 * i..]); r.0 = Quat::from_slice(&st.out_rotation[4 * i..]);
+        lv.0 = Vec3::from_slice(&st.out_linear_velocity[3 * i..]); av.0 = Vec3::from_slice(&st.out_angular_velocity[3 * i..]);
+    }
+    if settings.mode == Mi355xMode::HostNarrowPhase {
+        let imp = st.impulses_out_desc();
+        let s = unsafe { ffi::avn_impulses_download(raw, &imp) }; w.check(s);
+        for (m, &(contact_id, manifold_index)) in st.m_handles.iter().enumerate() {
+            let Some(manifold) = contact_graph.get_manifold_mut(ContactManifoldHandle { contact_id, manifold_index }) else {
+                unreachable!("Contact manifold {manifold_index:?} for contact ID {contact_id:?} not found in contact graph.")
+            };
+            for (k, contact) in manifold.points.iter_mut().enumerate().take(ffi::AVN_MAX_MANIFOLD_POINTS as usize) {
+                contact.warm_start_normal_impulse = st.out_warm_n[4 * m + k];
+                contact.warm_start_tangent_impulse = Vec2::new(st.out_warm_t[2 * (4 * m + k)], st.out_warm_t[2 * (4 * m + k) + 1]);
+                contact.normal_impulse = st.out_normal_impulse[4 * m + k];
+            }
+        }
+    }
+}
+
+/// The device's event timers into the reference's own resources (src/dynamics/solver/diagnostics.rs:13-37, src/collision/diagnostics.rs:13-19).
+fn gpu_diagnostics(mut w: ResMut<Mi355xWorld>, mut solver: ResMut<SolverDiagnostics>, mut collision: ResMut<CollisionDiagnostics>) {
+    let d = w.diagnostics();
+    let ms = |x: f64| Duration::from_secs_f64(x * 1e-3);
+    solver.prepare_constraints += ms(d.prepare_constraints_ms);
+    solver.update_velocity_increments += ms(d.update_velocity_increments_ms);
+    solver.integrate_velocities += ms(d.integrate_velocities_ms);
+    solver.warm_start += ms(if d.per_system_valid != 0 { d.warm_start_ms } else { d.substeps_ms });   // graph replay: the loop's total, undivided
+    solver.solve_constraints += ms(d.solve_constraints_ms);
+    solver.integrate_positions += ms(d.integrate_positions_ms);
+    solver.relax_velocities += ms(d.relax_velocities_ms);
+    solver.apply_restitution += ms(d.apply_restitution_ms);
+    solver.finalize += ms(d.finalize_ms);
+    solver.store_impulses += ms(d.store_impulses_ms);
+    solver.contact_constraint_count = d.contact_constraint_count;
+    collision.narrow_phase += ms(d.narrow_phase_ms);
+    collision.contact_count = d.contact_count;
+}

@@ -1,0 +1,137 @@
+//! Safe ownership of the device world.  One caller thread at a time, like the single-threaded executor of `PhysicsSchedule`
+//! (src/schedule/mod.rs:90): the handle is `Send` (Bevy resources move between threads) but not `Sync`.
+
+use avian_mi355x_sys as ffi;
+use bevy::prelude::Resource;
+use std::ffi::CStr;
+
+#[derive(Debug)]
+pub struct Mi355xError {
+    pub status: ffi::avn_status,
+    pub message: String,
+}
+
+impl core::fmt::Display for Mi355xError {
+    fn fmt(&self, f: &mut core::fmt::Formatter<'_>) -> core::fmt::Result {
+        write!(f, "avian_mi355x: status {}: {}", self.status, self.message)
+    }
+}
+impl std::error::Error for Mi355xError {}
+
+/// The device-resident physics world (`avn_world*`).
+#[derive(Resource)]
+pub struct Mi355xWorld {
+    raw: *mut ffi::avn_world,
+    pub config: ffi::avn_config,
+}
+// SAFETY: the library keeps no thread-local state per world; `&mut self` on every call serialises access.
+unsafe impl Send for Mi355xWorld {}
+
+impl Mi355xWorld {
+    /// `avn_world_create`.  Fails with `AVN_ERR_NO_DEVICE` when no gfx950 device is visible: the path has no CPU fallback, the
+    /// caller keeps the stock plugins in that case.
+    pub fn new(config: ffi::avn_config) -> Result<Self, Mi355xError> {
+        let mut raw = core::ptr::null_mut();
+        // SAFETY: `config` is a valid `avn_config` with `struct_size` set by `default_config`.
+        let status = unsafe { ffi::avn_world_create(&config, &mut raw) };
+        if status != ffi::AVN_OK {
+            let message = unsafe { cstr(ffi::avn_last_error(core::ptr::null())) };
+            return Err(Mi355xError { status, message });
+        }
+        Ok(Self { raw, config })
+    }
+
+    /// The reference's convention on invariant violations is to panic (src/dynamics/solver/plugin.rs:393-395, 735-739;
+    /// src/collision/broad_phase.rs:469-471): systems call this on every status.
+    #[track_caller]
+    pub fn check(&self, status: ffi::avn_status) {
+        if status != ffi::AVN_OK {
+            let message = unsafe { cstr(ffi::avn_last_error(self.raw)) };
+            panic!("avian_mi355x: status {status}: {message}");
+        }
+    }
+
+    pub fn raw(&mut self) -> *mut ffi::avn_world {
+        self.raw
+    }
+
+    /// Resources changed (`SubstepCount`, `Gravity`, `SolverConfig`, `PhysicsLengthUnit`, `NarrowPhaseConfig`, `Time<Physics>` delta).
+    pub fn set_config(&mut self, config: ffi::avn_config) {
+        self.config = config;
+        let st = unsafe { ffi::avn_config_set(self.raw, &self.config) };
+        self.check(st);
+    }
+
+    pub fn run_system(&mut self, system: ffi::avn_system) {
+        let st = unsafe { ffi::avn_run_system(self.raw, system) };
+        self.check(st);
+    }
+
+    pub fn step(&mut self) {
+        let st = unsafe { ffi::avn_step(self.raw) };
+        self.check(st);
+    }
+
+    /// New broad-phase pairs of the last `AVN_SYS_COLLECT_COLLISION_PAIRS`, in the reference's emission order.  The slice is owned by
+    /// the library and valid until the next call on this world.
+    pub fn pairs(&mut self) -> &[ffi::avn_pair] {
+        let (mut p, mut n) = (core::ptr::null(), 0usize);
+        let st = unsafe { ffi::avn_pairs_get(self.raw, &mut p, &mut n) };
+        self.check(st);
+        if n == 0 { &[] } else { unsafe { core::slice::from_raw_parts(p, n) } }
+    }
+
+    /// Status changes of the last `AVN_SYS_NARROW_PHASE`, ascending `ContactId` (the order of the status-bit walk,
+    /// src/collision/narrow_phase/system_param.rs:141-145).
+    pub fn contact_changes(&mut self) -> &[ffi::avn_contact_change] {
+        let (mut p, mut n) = (core::ptr::null(), 0usize);
+        let st = unsafe { ffi::avn_contact_changes_get(self.raw, &mut p, &mut n) };
+        self.check(st);
+        if n == 0 { &[] } else { unsafe { core::slice::from_raw_parts(p, n) } }
+    }
+
+    /// `SolverDiagnostics` + `CollisionDiagnostics` of the last step (src/dynamics/solver/diagnostics.rs:13-37,
+    /// src/collision/diagnostics.rs:13-19), milliseconds.
+    pub fn diagnostics(&mut self) -> ffi::avn_diagnostics {
+        let mut d = unsafe { core::mem::zeroed::<ffi::avn_diagnostics>() };
+        let st = unsafe { ffi::avn_diagnostics_get(self.raw, &mut d) };
+        self.check(st);
+        d
+    }
+}
+
+impl Drop for Mi355xWorld {
+    fn drop(&mut self) {
+        unsafe { ffi::avn_world_destroy(self.raw) }
+    }
+}
+
+unsafe fn cstr(p: *const core::ffi::c_char) -> String {
+    if p.is_null() { String::new() } else { unsafe { CStr::from_ptr(p) }.to_string_lossy().into_owned() }
+}
+
+/// `avn_config` with the defaults of the reference's resources: `SubstepCount` 6 (src/dynamics/solver/schedule.rs:185-191),
+/// `Gravity` (0, -9.81, 0), `SolverConfig::default()` (src/dynamics/solver/plugin.rs:216-302), `NarrowPhaseConfig::default()`
+/// (src/collision/narrow_phase/mod.rs:203-255), `PhysicsLengthUnit` 1.
+pub fn default_config() -> ffi::avn_config {
+    ffi::avn_config {
+        struct_size: core::mem::size_of::<ffi::avn_config>() as u32,
+        scalar_bits: 32,
+        device: 0,
+        substeps: 6,
+        dt_ns: 1_000_000_000 / 64, // Time<Fixed> default 64 Hz
+        gravity: [0.0, -9.81, 0.0],
+        length_unit: 1.0,
+        contact_damping_ratio: 10.0,
+        contact_frequency_factor: 1.5,
+        max_overlap_solve_speed: 4.0,
+        warm_start_coefficient: 1.0,
+        restitution_threshold: 1.0,
+        restitution_iterations: 1,
+        match_contacts: 1,
+        default_speculative_margin: f64::MAX,
+        contact_tolerance: 0.005,
+        solver_iterations: 1,
+        use_graph: 1,
+    }
+}
