@@ -31,3 +31,13 @@ def test_contact_manifolds_empty_and_bad_arguments():
     assert out["point_count"].shape == (0,)
     with pytest.raises(F.AvnError):
         wh.contact_manifolds([7], [[1, 1, 1]], [[0, 0, 0]], [[0, 0, 0, 1]], [0], [[1, 1, 1]], [[0, 0, 0]], [[0, 0, 0, 1]], [0.0])
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_hip_manifolds_against_the_independent_second_opinion(bits):
+    """The device contact_manifolds query against tests/narrow_bruteforce.py (projected support-face intersection, 15-axis SAT optimality):
+    the same check the oracle passes on the CPU, run on the product directly."""
+    from test_narrow_second_opinion import check_projected_polygon_intersection
+    w = F.World(hip_lib(), F.default_config(bits))
+    for seed in (1, 2):
+        check_projected_polygon_intersection(w, seed)
