@@ -187,6 +187,10 @@ class avn_diagnostics(C.Structure):
                [(n, C.c_uint32) for n in ("contact_constraint_count", "contact_count", "per_system_valid", "reserved0")]
 
 
+class avn_halo_plan(C.Structure):
+    _fields_ = [("n_peers", C.c_uint32), ("peer_rank", vp), ("send_offsets", vp), ("send_bodies", vp), ("recv_offsets", vp), ("recv_bodies", vp)]
+
+
 PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),
                        ("flags", "<u4"), ("reserved", "<u4")])
 
@@ -195,7 +199,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -227,6 +231,12 @@ class Library:
         f("pairs_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         f("aabbs_download").argtypes = [vp, vp, vp, vp, C.POINTER(C.c_size_t)]
         f("run_system").argtypes = [vp, C.c_int]
+        f("halo_plan_upload").argtypes = [vp, vp]
+        f("run_color_pass").argtypes = [vp, C.c_int, C.c_uint32]
+        f("halo_pack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_size_t)]
+        f("halo_unpack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+        f("comm_unique_id").argtypes = [vp]
+        f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
         f("profile_system").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
         f("step").argtypes = [vp]
         f("synchronize").argtypes = [vp]
@@ -259,6 +269,14 @@ class Library:
 
     def pair_key(self, a: int, b: int) -> int:
         return int(self.fn("pair_key")(a, b))
+
+    def comm_unique_id(self) -> bytes:
+        """``avn_comm_unique_id``: the RCCL rendezvous token rank 0 creates and hands to the other ranks (any side channel)."""
+        buf = (C.c_uint8 * 128)()
+        st = self.fn("comm_unique_id")(buf)
+        if st != 0:
+            raise AvnError(st, (self.fn("last_error")(None) or b"comm_unique_id failed").decode())
+        return bytes(buf)
 
     def islands_partition(self, rb_type, center_x, edge_body1, edge_body2, n_ranks: int):
         """``avn_islands_partition``: returns (island_of_body, rank_of_body, n_islands)."""
@@ -605,6 +623,35 @@ class World:
 
     def synchronize(self):
         self._check(self.lib.fn("synchronize")(self.handle))
+
+    # -- level-2 sharding (one island over several worlds) -----------------------------------------------------------------
+    def halo_plan_upload(self, peers, send_offsets, send_bodies, recv_offsets, recv_bodies):
+        peers = np.ascontiguousarray(peers, np.int32)
+        so = np.ascontiguousarray(send_offsets, np.uint32); sb = np.ascontiguousarray(send_bodies, np.int32)
+        ro = np.ascontiguousarray(recv_offsets, np.uint32); rb = np.ascontiguousarray(recv_bodies, np.int32)
+        plan = avn_halo_plan(len(peers), _ptr(peers), _ptr(so), _ptr(sb), _ptr(ro), _ptr(rb))
+        self._check(self.lib.fn("halo_plan_upload")(self.handle, C.byref(plan)))
+        self._halo = (peers, so, ro)
+
+    def run_color_pass(self, system: str, color: int):
+        self._check(self.lib.fn("run_color_pass")(self.handle, SYSTEMS.index(system), int(color)))
+
+    def halo_pack(self, color: int, peer: int) -> np.ndarray:
+        peers, so, _ = self._halo
+        n = int(so[color * len(peers) + peer + 1] - so[color * len(peers) + peer])
+        out = np.zeros((n, 8), self.dtype)
+        cnt = C.c_size_t()
+        self._check(self.lib.fn("halo_pack")(self.handle, int(color), int(peer), _ptr(out), C.byref(cnt)))
+        assert cnt.value == n
+        return out
+
+    def halo_unpack(self, color: int, peer: int, rec: np.ndarray):
+        rec = np.ascontiguousarray(rec, self.dtype)
+        self._check(self.lib.fn("halo_unpack")(self.handle, int(color), int(peer), _ptr(rec), len(rec)))
+
+    def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.fn("comm_init")(self.handle, buf, int(n_ranks), int(rank)))
 
     def diagnostics(self) -> avn_diagnostics:
         """SolverDiagnostics + CollisionDiagnostics of the last step (milliseconds)."""

@@ -134,6 +134,16 @@ AVN_API avn_status avn_islands_partition(const avn_islands_in* in, int32_t* isla
     } catch (...) { return AVN_ERR_OOM; }
 }
 
+AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD(halo_plan_upload(p)); }
+AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD(run_color_pass(pass, color)); }
+AVN_API avn_status avn_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { GUARD(halo_pack(color, peer, out, count)); }
+AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD(halo_unpack(color, peer, in, count)); }
+AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
+    try { return avn::comm_unique_id(out, g_create_error); }
+    catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }
+}
+AVN_API avn_status avn_comm_init(avn_world* w, const uint8_t* unique_id, int n_ranks, int rank) { GUARD(comm_init(unique_id, n_ranks, rank)); }
+
 AVN_API uint64_t avn_pair_key(uint32_t a, uint32_t b) { return a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
 
 AVN_API avn_status avn_constraint_graph_create(uint32_t, avn_constraint_graph** out) {

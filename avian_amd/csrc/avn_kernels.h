@@ -41,7 +41,7 @@ struct SweepScratch {
     uint32_t long_cap;
 };
 
-enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3 };
+enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3, PASS_WARM_START_COLORS = 4 /* manifold-centric, one launch per colour */ };
 
 // k_bodies.hip
 template <class T> void launch_prepare_solver_bodies(const DW<T>&, hipStream_t);
@@ -221,6 +221,9 @@ template <class T> struct BodyStage {  // device staging copies of the avn_bodie
     const int8_t* dominance;
 };
 template <class T> void launch_pack_bodies(const DW<T>&, const BodyStage<T>&, hipStream_t);
+// level-2 sharding: (SolverBody linear | angular velocity records) of a list of bodies <-> a contiguous buffer of 2 records per body
+template <class T> void launch_halo_pack(const DW<T>&, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t);
+template <class T> void launch_halo_unpack(const DW<T>&, const int32_t* bodies, uint32_t n, const Vec4<T>* in, hipStream_t);
 template <class T> struct ManifoldStage {
     const int32_t *body1, *body2;
     const T *normal, *friction, *restitution, *tangent_velocity, *anchor1, *anchor2, *penetration, *normal_speed, *warm_n, *warm_t;

@@ -88,7 +88,23 @@ struct WorldBase {
     virtual avn_status pipeline_enable(int) = 0;
     virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
     virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
+    virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
+    virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
+    virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
+    virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
+    virtual avn_status comm_init(const uint8_t*, int, int) = 0;
 };
+
+// RCCL transport of the level-2 halo exchange (avn_comm.cpp; librccl is opened on first use)
+struct CommXfer { void* ptr; size_t bytes; int peer; };
+struct Comm {
+    void* handle = nullptr;   // ncclComm_t
+    int n_ranks = 0, rank = 0;
+    ~Comm();
+    avn_status init(const uint8_t* unique_id, int n_ranks, int rank, std::string& err);
+    avn_status exchange(const CommXfer* sends, size_t n_sends, const CommXfer* recvs, size_t n_recvs, hipStream_t s, std::string& err);
+};
+avn_status comm_unique_id(uint8_t* out, std::string& err);
 
 WorldBase* make_world_f32(const avn_config* cfg, avn_status* st, std::string* err);
 WorldBase* make_world_f64(const avn_config* cfg, avn_status* st, std::string* err);

@@ -607,7 +607,8 @@ enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3 };
 template <class T, int PASS, bool COH = false> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
     const int2 b = w.m_bodies[m];   // (a level-1 load like the constraint records: the body gathers depend on it)
     const BodyView<T> bv = global_bodies(w);
-    if (PASS == PASS_BIAS) SolveDispatch<T, true, 2, COH>::run(w, p, m, bv, b.x, b.y);
+    if (PASS == PASS_WARM) warm_core<T, 2>(w, p, m, bv, b.x, b.y);   // (manifold-centric warm start of one colour: level-2 sharding exchanges after every colour)
+    else if (PASS == PASS_BIAS) SolveDispatch<T, true, 2, COH>::run(w, p, m, bv, b.x, b.y);
     else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2, COH>::run(w, p, m, bv, b.x, b.y);
     else restitution_core<T, 2, COH>(w, p, m, bv, b.x, b.y);
 }
@@ -919,6 +920,7 @@ template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<
 template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
     switch (pass) {
         case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
+        case 4: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_WARM_START_COLORS: colour by colour
         case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, arg_offsets, ovf, s);
         case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, arg_offsets, ovf, s);
         default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, arg_offsets, ovf, s);

@@ -198,6 +198,32 @@ template <class T> void launch_unpack_aabbs(const BP<T>& bp, T* mn, T* mx, uint3
     if (n) hipLaunchKernelGGL(k_unpack_aabbs<T>, g256(n), dim3(256), 0, st, bp, mn, mx, ents);
 }
 
+// ---- level-2 sharding: boundary-body velocities in and out of a contiguous exchange buffer -------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_pack(DW<T> w, const int32_t* __restrict__ bodies, uint32_t n, Vec4<T>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = bodies[i];
+    out[2 * i] = w.sb_lin[b]; out[2 * i + 1] = w.sb_ang[b];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_unpack(DW<T> w, const int32_t* __restrict__ bodies, uint32_t n, const Vec4<T>* __restrict__ in) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = bodies[i];
+    w.sb_lin[b] = in[2 * i]; w.sb_ang[b] = in[2 * i + 1];
+}
+template <class T> void launch_halo_pack(const DW<T>& w, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_halo_pack<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, out);
+}
+template <class T> void launch_halo_unpack(const DW<T>& w, const int32_t* bodies, uint32_t n, const Vec4<T>* in, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_halo_unpack<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, in);
+}
+template void launch_halo_pack<float>(const DW<float>&, const int32_t*, uint32_t, Vec4<float>*, hipStream_t);
+template void launch_halo_pack<double>(const DW<double>&, const int32_t*, uint32_t, Vec4<double>*, hipStream_t);
+template void launch_halo_unpack<float>(const DW<float>&, const int32_t*, uint32_t, const Vec4<float>*, hipStream_t);
+template void launch_halo_unpack<double>(const DW<double>&, const int32_t*, uint32_t, const Vec4<double>*, hipStream_t);
+
 #define INST(T)                                                                                     \
     template void launch_pack_bodies<T>(const DW<T>&, const BodyStage<T>&, hipStream_t);            \
     template void launch_pack_manifolds<T>(const DW<T>&, const ManifoldStage<T>&, hipStream_t);     \

@@ -257,3 +257,128 @@ def slab_broad_phase_step(lib: F.Library, bits: int, bodies: Dict[str, np.ndarra
 
 
 PAIR_DTYPE_LOCAL = F.PAIR_DTYPE
+
+
+# ---- level 2: ONE island split over several worlds (x-slabs) with a global colouring (include/avian_mi355x.h, avn_halo_plan) ----------
+#
+# Ownership: a non-static body belongs to the x-slab its position falls into; a manifold belongs to the owner of body1 (body2 when body1
+# is static).  A world holds its owned manifolds, the bodies they touch, its owned bodies and all static bodies.  After colour c of a
+# contact pass the world that solved the (only) manifold of colour c on a shared body sends that body's velocities to the other holders.
+
+@dataclass
+class Level2Rank:
+    bodies: np.ndarray            # global body indices of this world, ascending (local index = position)
+    manifolds: np.ndarray         # global manifold indices (colour-major order of the global set)
+    color_offsets: np.ndarray     # [25] local colour offsets
+    peers: np.ndarray             # ranks this world exchanges with
+    send_offsets: np.ndarray      # [24 * n_peers + 1]
+    send_bodies: np.ndarray       # LOCAL body indices
+    recv_offsets: np.ndarray
+    recv_bodies: np.ndarray
+
+
+def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray, world_size: int,
+                has_solver_body: np.ndarray = None) -> List[Level2Rank]:
+    """body1 / body2: the GLOBAL colour-major manifold set; color_offsets: its [25] offsets (the reference's colouring of the whole island)."""
+    position = np.asarray(position, np.float64); rb_type = np.asarray(rb_type)
+    b1 = np.asarray(body1, np.int64); b2 = np.asarray(body2, np.int64)
+    offs = np.asarray(color_offsets, np.int64)
+    n = len(rb_type)
+    static = rb_type == F.RB_STATIC
+    moving = ~static if has_solver_body is None else np.asarray(has_solver_body, bool)
+    dyn = np.flatnonzero(~static)
+    xs = np.sort(position[dyn, 0], kind="stable")
+    cuts = [xs[min(len(xs) - 1, (len(xs) * r) // world_size)] for r in range(1, world_size)]
+    owner = np.full(n, -1, np.int64)
+    owner[dyn] = np.searchsorted(np.asarray(cuts), position[dyn, 0], side="right")
+    m_owner = np.where(static[b1], owner[b2], owner[b1])
+    color_of = np.repeat(np.arange(len(offs) - 1), np.diff(offs))
+    held = [np.zeros(n, bool) for _ in range(world_size)]
+    m_of = []
+    for r in range(world_size):
+        mine = np.flatnonzero(m_owner == r)
+        m_of.append(mine)
+        held[r][static] = True; held[r][owner == r] = True
+        held[r][b1[mine]] = True; held[r][b2[mine]] = True
+    held = np.stack(held)                                 # [R, n]
+    shared = moving & (held.sum(0) > 1)
+    # per colour: the rank that moves each shared body, and who needs it
+    sends = [[{} for _ in range(len(offs) - 1)] for _ in range(world_size)]   # sends[s][c][r] = [global body ...]
+    touches = shared[b1] | shared[b2]                     # (only manifolds on a shared body take part in the exchange)
+    for c in range(len(offs) - 1):
+        for m in (np.flatnonzero(touches[offs[c]:offs[c + 1]]) + offs[c]).tolist():
+            s = int(m_owner[m])
+            for b in (int(b1[m]), int(b2[m])):
+                if not shared[b]:
+                    continue
+                if c == len(offs) - 2:
+                    raise ValueError("level2_plan: an overflow-colour manifold touches a body shared between slabs (solved serially across worlds: not supported)")
+                for r in np.flatnonzero(held[:, b]):
+                    if r != s:
+                        sends[s][c].setdefault(int(r), []).append(b)
+    out = []
+    for r in range(world_size):
+        bodies = np.flatnonzero(held[r])
+        g2l = np.full(n, -1, np.int64); g2l[bodies] = np.arange(len(bodies))
+        peers = sorted({p for c in range(len(offs) - 1) for p in sends[r][c]} | {s for s in range(world_size) if s != r and any(r in sends[s][c] for c in range(len(offs) - 1))})
+        so, sb, ro, rb = [0], [], [0], []
+        for c in range(len(offs) - 1):
+            for p in peers:
+                lst = sorted(sends[r][c].get(p, [])); sb.extend(g2l[lst].tolist()); so.append(len(sb))
+                lst = sorted(sends[p][c].get(r, [])); rb.extend(g2l[lst].tolist()); ro.append(len(rb))
+        mine = m_of[r]
+        local_offs = np.concatenate([[0], np.cumsum(np.bincount(color_of[mine], minlength=len(offs) - 1))])
+        out.append(Level2Rank(bodies, mine, local_offs.astype(np.uint32), np.asarray(peers, np.int32), np.asarray(so if peers else [0], np.uint32), np.asarray(sb, np.int32),
+                              np.asarray(ro if peers else [0], np.uint32), np.asarray(rb, np.int32)))
+    return out
+
+
+def level2_local_manifolds(rank: Level2Rank, manifolds: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """The rank's rows of a global manifold dict (arrays whose first dimension is the manifold count), bodies re-indexed."""
+    n = len(manifolds["body1"])
+    g2l = {int(g): i for i, g in enumerate(rank.bodies)}
+    out = {}
+    for k, v in manifolds.items():
+        a = np.asarray(v) if v is not None else None
+        out[k] = a[rank.manifolds] if a is not None and a.ndim >= 1 and len(a) == n else v
+    out["body1"] = np.asarray([g2l[int(b)] for b in out["body1"]], np.int32)
+    out["body2"] = np.asarray([g2l[int(b)] for b in out["body2"]], np.int32)
+    return out
+
+
+CONTACT_PASSES = ("WARM_START", "SOLVE_CONTACTS_BIAS", "SOLVE_CONTACTS_RELAX", "SOLVE_RESTITUTION")
+
+
+def level2_pass(world, rank: Level2Rank, system: str, exchange):
+    """One contact pass, colour by colour in solve order (overflow first), with the halo exchange after every colour.
+    exchange(color, {peer_index: records to send}) -> {peer_index: records received}."""
+    for c in [F.COLOR_OVERFLOW_INDEX] + list(range(F.COLOR_OVERFLOW_INDEX)):
+        world.run_color_pass(system, c)
+        if len(rank.peers) == 0:
+            continue
+        np_ = len(rank.peers)
+        out = {p: world.halo_pack(c, p) for p in range(np_) if rank.send_offsets[c * np_ + p + 1] > rank.send_offsets[c * np_ + p]}
+        need = [p for p in range(np_) if rank.recv_offsets[c * np_ + p + 1] > rank.recv_offsets[c * np_ + p]]
+        got = exchange(c, out, need)
+        for p in need:
+            world.halo_unpack(c, p, got[p])
+
+
+def level2_solver(world, rank: Level2Rank, substeps: int, exchange, restitution: bool = True):
+    """SolverSystems in the reference's order (solver/schedule.rs:32-69) with the contact passes split by colour: what avn_step does
+    inside the library once a communicator is set; here the transport is the caller's (`exchange`)."""
+    for s in ("PREPARE_SOLVER_BODIES", "PREPARE_JOINTS", "PREPARE_CONTACT_CONSTRAINTS", "PRE_PROCESS_VELOCITY_INCREMENTS"):
+        world.run_system(s)
+    for _ in range(substeps):
+        world.run_system("INTEGRATE_VELOCITIES")
+        level2_pass(world, rank, "WARM_START", exchange)
+        level2_pass(world, rank, "SOLVE_CONTACTS_BIAS", exchange)
+        world.run_system("INTEGRATE_POSITIONS")
+        level2_pass(world, rank, "SOLVE_CONTACTS_RELAX", exchange)
+        for s in ("XPBD_SOLVE", "XPBD_VELOCITY_PROJECTION", "JOINT_DAMPING"):
+            world.run_system(s)
+    world.run_system("CLEAR_VELOCITY_INCREMENTS")
+    if restitution:
+        level2_pass(world, rank, "SOLVE_RESTITUTION", exchange)
+    world.run_system("WRITEBACK_SOLVER_BODIES")
+    world.run_system("STORE_CONTACT_IMPULSES")

@@ -94,6 +94,7 @@ def main():
     ap.add_argument("--no-closed-loop", action="store_true", help="skip the closed-loop (device narrow phase) leg")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 --pmc side pass that measures roofline.traffic in this run")
     ap.add_argument("--no-iters8", action="store_true", help="skip the solver_iterations = 8 extension leg")
+    ap.add_argument("--no-level2", action="store_true", help="N > 1: skip the one-island-over-all-GPUs leg (level-2 sharding over RCCL)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the CPU oracle sample (split between the 1-thread and the multi-thread run)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the multi-thread CPU sample (default min(64, host cores))")
     args = ap.parse_args()
@@ -398,7 +399,37 @@ def main():
             cpu = dict(cpu, single_thread={k: single[k] for k in ("value", "ms_per_step", "substep_loop_only_ms")},
                        multi_thread={k: multi[k] for k in ("value", "cores", "ms_per_step", "substep_loop_only_ms")})
 
-    if rank == 0:
+    # ---- N > 1: level-2 sharding leg -- ONE cfg2 island over all N GPUs (strong scaling), exchange issued by the library over RCCL ----------
+    # Not part of `value`.  A watchdog guards the leg: should the exchange hang on some fabric, the JSON line is still printed (with
+    # level2.status = "timeout") and the process exits 0 -- the headline measurement above must not depend on it.
+    level2 = None
+    if world_size > 1 and os.environ.get("AVN_BENCH_LEVEL2", "1") != "0" and backend == "nccl" and not args.no_level2:
+        import threading
+        from avian_amd import level2_bench
+        done = threading.Event()
+        line_holder = {}
+
+        def watchdog():
+            if not done.wait(float(os.environ.get("AVN_BENCH_LEVEL2_TIMEOUT", "150"))):
+                if rank == 0 and "make" in line_holder:
+                    print(json.dumps(line_holder["make"]({"status": "timeout"})), flush=True)
+                os._exit(0)
+        threading.Thread(target=watchdog, daemon=True).start()
+
+        def bcast(b):
+            o = [b]
+            dist.broadcast_object_list(o, src=0)
+            return o[0]
+
+        def armax(x):
+            tt = torch.tensor([x], dtype=torch.float64, device=coll_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        nx_, ny_, nz_, _ = SCENES[args.scene]
+    else:
+        done = None
+
+    def make_line(level2_obj):
         total_substeps = world_size * args.steps * substeps
         out = {
             "metric": "physics substeps/sec at N dynamic bodies (3D)",
@@ -429,7 +460,20 @@ def main():
             "closed_loop": closed,
             "cpu_baseline": cpu,
         }
-        print(json.dumps(out))
+        if level2_obj is not None:
+            out["level2"] = level2_obj
+        return out
+
+    if done is not None:
+        line_holder["make"] = make_line
+        try:
+            w.close()   # (the slab world + the unsplit island need the memory headroom of a fresh device, not this world's buffers)
+            level2 = level2_bench.run(lib, rank, world_size, local_rank, bcast, armax, dist.barrier, dims=(nx_, ny_, nz_), substeps=substeps)
+        except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for the headline figure
+            level2 = {"status": "error: " + str(e)[:300]}
+        done.set()
+    if rank == 0:
+        print(json.dumps(make_line(level2)), flush=True)
     if world_size > 1:
         dist.destroy_process_group()
 

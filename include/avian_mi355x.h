@@ -546,6 +546,36 @@ AVN_API avn_status AVN_FN(pipeline_stats_get)(avn_world* w, avn_pipeline_stats* 
 /* the colour lists the pipeline holds: offsets[25] and the contact ids (buffer owned by the world) */
 AVN_API avn_status AVN_FN(pipeline_handles_get)(avn_world* w, uint32_t* color_offsets, const uint32_t** contact_id, size_t* n_out);
 
+/* ---- level-2 sharding: ONE contact island split over several worlds (x-slabs), SURVEY.md section 8(e) ---------------------------------
+ * Every world holds the manifolds it OWNS (those whose body1 -- body2 when body1 is static -- lies in its slab), the bodies they touch and
+ * the static bodies.  A body present in several worlds ("shared") is integrated identically by each of them; what differs is who solves
+ * which manifold.  With ONE global colouring (the reference's, over the whole island: avn_manifolds.color_offsets of every world uses the
+ * global colour of each manifold) every world runs the colour launches of the single-world step on its subset, and after each colour the
+ * world whose manifold moved a shared body hands that body's (linear, angular) velocity to the other holders: the single world's state is
+ * restored before the next colour, so the split run is BIT-IDENTICAL to the unsplit one (a body is in at most one manifold per colour).
+ * Not supported in this form: overflow-colour manifolds or joints on shared bodies (rejected by the planner, avian_amd/shard.py).
+ *
+ *   avn_halo_plan_upload   per (colour, peer): local body indices to send and to receive, in the same order on both sides
+ *   avn_run_color_pass     one colour of one contact pass (AVN_SYS_WARM_START / SOLVE_CONTACTS_BIAS / SOLVE_CONTACTS_RELAX / SOLVE_RESTITUTION)
+ *   avn_halo_pack/unpack   host transport of one (colour, peer) list: 8 scalars per body (linear.xyz, w lane, angular.xyz, w lane)
+ *   avn_comm_unique_id / avn_comm_init   library transport: RCCL; avn_step then exchanges by grouped ncclSend / ncclRecv on the world's
+ *                          stream after every colour and no host code runs inside the step */
+typedef struct avn_halo_plan {
+    uint32_t n_peers;
+    const int32_t* peer_rank;      /* [n_peers] */
+    const uint32_t* send_offsets;  /* [24 * n_peers + 1]: list of (colour c, peer p) = send_bodies[send_offsets[c * n_peers + p] .. [.. + 1]) */
+    const int32_t* send_bodies;    /* local body indices */
+    const uint32_t* recv_offsets;  /* [24 * n_peers + 1] */
+    const int32_t* recv_bodies;
+} avn_halo_plan;
+AVN_API avn_status AVN_FN(halo_plan_upload)(avn_world* w, const avn_halo_plan* plan);
+AVN_API avn_status AVN_FN(run_color_pass)(avn_world* w, avn_system pass, uint32_t color);
+AVN_API avn_status AVN_FN(halo_pack)(avn_world* w, uint32_t color, uint32_t peer, void* out /* [8 * count] scalars */, size_t* count);
+AVN_API avn_status AVN_FN(halo_unpack)(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count);
+#define AVN_COMM_ID_BYTES 128
+AVN_API avn_status AVN_FN(comm_unique_id)(uint8_t* out /* [AVN_COMM_ID_BYTES] */);
+AVN_API avn_status AVN_FN(comm_init)(avn_world* w, const uint8_t* unique_id, int n_ranks, int rank);
+
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);
 

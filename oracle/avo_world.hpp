@@ -286,6 +286,10 @@ struct WorldBase {
     virtual avn_status step() = 0;
     virtual avn_status timers(avn_timers*) = 0;
     virtual avn_status diagnostics(avn_diagnostics*) = 0;
+    virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
+    virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
+    virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
+    virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
     virtual avn_status profile_system(avn_system, uint32_t, double*, uint32_t*) = 0;
     virtual avn_status dynamic_bounds(double*, double*) = 0;
     virtual avn_status contact_manifolds(const avn_shape_pairs*, const avn_query_manifolds_out*) = 0;
@@ -817,9 +821,12 @@ template <class S> struct World : WorldBase {
     // overflow colour serially FIRST, then colours 0..22 (solver/plugin.rs:461-479).
     // ... the constraints of one colour 0..22 touch disjoint bodies: par_for_each(&mut color.contact_constraints, 64, ..)
     // (plugin.rs:476,564,662)
+    int only_color = -1;   // >= 0: the pass functions below visit this colour only (avn_run_color_pass, level-2 sharding)
     template <class F> void for_each_constraint_in_solver_order(F f) {
-        for (ContactConstraint<S>& k : color_constraints[AVN_COLOR_OVERFLOW_INDEX]) f(k);
+        if (only_color < 0 || only_color == AVN_COLOR_OVERFLOW_INDEX)
+            for (ContactConstraint<S>& k : color_constraints[AVN_COLOR_OVERFLOW_INDEX]) f(k);
         for (int c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) {
+            if (only_color >= 0 && only_color != c) continue;
             std::vector<ContactConstraint<S>>& v = color_constraints[c];
             pool.par_for_each(v.size(), 64, [&](size_t b0, size_t b1) { for (size_t i = b0; i < b1; ++i) f(v[i]); });
         }
@@ -1808,6 +1815,58 @@ template <class S> struct World : WorldBase {
         if (have_colliders) timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
         solver();
         diag.contact_count = (uint32_t)pairs.size();
+        return AVN_OK;
+    }
+    // ---- level-2 sharding (header: avn_halo_plan) ----
+    struct Halo { std::vector<int32_t> peers; std::vector<uint32_t> send_off, recv_off; std::vector<int32_t> send, recv; } halo;
+    avn_status halo_plan_upload(const avn_halo_plan* p) override {
+        if (!p) return AVN_ERR_BAD_ARG;
+        const size_t n = (size_t)AVN_GRAPH_COLOR_COUNT * p->n_peers;
+        if (p->n_peers && (!p->peer_rank || !p->send_offsets || !p->recv_offsets)) { error = "halo_plan_upload: null array"; return AVN_ERR_BAD_ARG; }
+        halo.peers.assign(p->peer_rank, p->peer_rank + p->n_peers);
+        halo.send_off.assign(p->send_offsets, p->send_offsets + (p->n_peers ? n + 1 : 0)); halo.recv_off.assign(p->recv_offsets, p->recv_offsets + (p->n_peers ? n + 1 : 0));
+        const size_t ns = p->n_peers ? halo.send_off[n] : 0, nr = p->n_peers ? halo.recv_off[n] : 0;
+        halo.send.assign(p->send_bodies, p->send_bodies + ns); halo.recv.assign(p->recv_bodies, p->recv_bodies + nr);
+        for (int32_t b : halo.send) if (b < 0 || (size_t)b >= bodies.size()) { error = "halo_plan_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+        for (int32_t b : halo.recv) if (b < 0 || (size_t)b >= bodies.size()) { error = "halo_plan_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+        return AVN_OK;
+    }
+    avn_status run_color_pass(avn_system pass, uint32_t color) override {
+        if (color >= AVN_GRAPH_COLOR_COUNT) { error = "run_color_pass: colour out of range"; return AVN_ERR_BAD_ARG; }
+        only_color = (int)color;
+        avn_status st = AVN_OK;
+        switch (pass) {
+            case AVN_SYS_WARM_START: warm_start(); break;
+            case AVN_SYS_SOLVE_CONTACTS_BIAS: solve_contacts(true); break;
+            case AVN_SYS_SOLVE_CONTACTS_RELAX: solve_contacts(false); break;
+            case AVN_SYS_SOLVE_RESTITUTION: solve_restitution(); break;
+            default: error = "run_color_pass: not a contact pass"; st = AVN_ERR_BAD_ARG;
+        }
+        only_color = -1;
+        return st;
+    }
+    avn_status halo_pack(uint32_t color, uint32_t peer, void* out, size_t* count) override {
+        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size() || !count) return AVN_ERR_BAD_ARG;
+        const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.send_off[k], b1 = halo.send_off[k + 1];
+        *count = b1 - b0;
+        S* o = (S*)out;
+        for (size_t i = b0; i < b1 && o; ++i) {
+            const SolverBody<S>& sb = bodies[halo.send[i]].sb;
+            S* r = o + 8 * (i - b0);
+            r[0] = sb.linear_velocity.x; r[1] = sb.linear_velocity.y; r[2] = sb.linear_velocity.z; r[3] = S(0);
+            r[4] = sb.angular_velocity.x; r[5] = sb.angular_velocity.y; r[6] = sb.angular_velocity.z; r[7] = S(0);
+        }
+        return AVN_OK;
+    }
+    avn_status halo_unpack(uint32_t color, uint32_t peer, const void* in, size_t count) override {
+        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size()) return AVN_ERR_BAD_ARG;
+        const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.recv_off[k], b1 = halo.recv_off[k + 1];
+        if (count != b1 - b0 || (count && !in)) { error = "halo_unpack: count does not match the plan"; return AVN_ERR_BAD_ARG; }
+        const S* r = (const S*)in;
+        for (size_t i = b0; i < b1; ++i, r += 8) {
+            SolverBody<S>& sb = bodies[halo.recv[i]].sb;
+            sb.linear_velocity = V3<S>{r[0], r[1], r[2]}; sb.angular_velocity = V3<S>{r[4], r[5], r[6]};
+        }
         return AVN_OK;
     }
     avn_status timers(avn_timers* t) override { if (!t) return AVN_ERR_BAD_ARG; *t = last_timers; return AVN_OK; }

@@ -46,6 +46,13 @@ avn_status avo_step(avn_world* w) { FWD(step()); }
 avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
 avn_status avo_diagnostics_get(avn_world* w, avn_diagnostics* d) { FWD(diagnostics(d)); }
+avn_status avo_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { FWD(halo_plan_upload(p)); }
+avn_status avo_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { FWD(run_color_pass(pass, color)); }
+avn_status avo_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { FWD(halo_pack(color, peer, out, count)); }
+avn_status avo_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { FWD(halo_unpack(color, peer, in, count)); }
+// the CPU checker has no device transport: the host moves the records (avn_halo_pack / avn_halo_unpack)
+avn_status avo_comm_unique_id(uint8_t* out) { if (!out) return AVN_ERR_BAD_ARG; std::memset(out, 0, AVN_COMM_ID_BYTES); return AVN_OK; }
+avn_status avo_comm_init(avn_world*, const uint8_t*, int, int) { return AVN_ERR_STATE; }
 avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
 avn_status avo_dynamic_bounds(avn_world* w, double* mn, double* mx) { FWD(dynamic_bounds(mn, mx)); }
 avn_status avo_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { FWD(contact_manifolds(p, o)); }

@@ -113,12 +113,47 @@ def run_slabs(lib, rank, world, steps, out_path, device=None):
         np.savez(out_path, **{f"pairs_s{s}": r for s, r in enumerate(per_step)})
 
 
+def run_level2(lib, rank, world, steps, out_path):
+    """Level-2 sharding over real ranks: this rank builds ONLY its slab world, steps it with shard.level2_solver and moves the boundary
+    records with point-to-point sends (gloo here; the library's own RCCL transport replaces this loop on a multi-GPU node)."""
+    from level2_helpers import global_problem
+    sc, pm, offs, _ = global_problem(lib, 8, 4, 5, seed=7)
+    plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world)
+    me = plan[rank]
+    w = F.World(lib, F.default_config(32, substeps=3))
+    w.bodies_upload(**{k: (np.asarray(v)[me.bodies] if v is not None else None) for k, v in sc.body_kwargs().items()})
+    scenes.upload_manifolds(w, shard.level2_local_manifolds(me, pm), me.color_offsets, sc.friction, 0.3)
+    w.halo_plan_upload(me.peers, me.send_offsets, me.send_bodies, me.recv_offsets, me.recv_bodies)
+
+    def exchange(color, out, need):
+        n_p = len(me.peers)
+        reqs, bufs = [], {}
+        for p in need:
+            cnt = int(me.recv_offsets[color * n_p + p + 1] - me.recv_offsets[color * n_p + p])
+            bufs[p] = torch.empty((cnt, 8), dtype=torch.float32)
+            reqs.append(dist.irecv(bufs[p], src=int(me.peers[p]), tag=color))
+        for p, rec in out.items():
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(rec, np.float32)), dst=int(me.peers[p]), tag=color))
+        for r in reqs:
+            r.wait()
+        return {p: bufs[p].numpy() for p in need}
+    for _ in range(steps):
+        shard.level2_solver(w, me, 3, exchange, restitution=True)
+    b = w.bodies_download(); imp = w.impulses_download()
+    np.savez(out_path + f".rank{rank}.npz", bodies=me.bodies, manifolds=me.manifolds, **{"b_" + k: v for k, v in b.items()}, **{"i_" + k: v for k, v in imp.items()})
+
+
 def main():
     case, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     backend = os.environ.get("AVN_SHARD_BACKEND", "oracle")
     dist.init_process_group(backend="gloo" if backend == "oracle" else "nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = oracle_lib() if backend == "oracle" else hip_lib()
+    if case == "level2":
+        run_level2(lib, rank, world, steps, out_path)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if case == "slabs":
         run_slabs(lib, rank, world, steps, out_path, None if backend == "oracle" else f"cuda:{os.environ.get('LOCAL_RANK', '0')}")
         dist.barrier()
