@@ -113,6 +113,126 @@ def exchange_bounds(world: F.World, dist=None, device=None):
     return a[:, :3], a[:, 3:], bounds_overlap(a[:, :3], a[:, 3:])
 
 
+# ---- level 1, second half: the re-partition that `exchange_bounds` triggers ---------------------------------------------------------------
+#
+# When two ranks' dynamic bounds intersect, a body of one may be about to touch a body of the other: a pair neither rank's broad phase
+# can see.  The islands involved must be co-located BEFORE the frame's pair search.  What has to travel so that the run continues the
+# single world bit for bit:
+#   * the bodies' state (position, rotation, velocities; mass data) and their colliders;
+#   * the contact pairs already known (the pair set that keeps the sweep from re-emitting them, and -- in emission order per island --
+#     the input of the colouring);
+#   * the persistent interval order of the sweep (reference broad_phase.rs:230-279: a stable insertion sort from LAST frame's order,
+#     so ties in min.x are history): the ranks' orders are merged by the key they are sorted by (last sweep's min.x).  Ties between
+#     colliders that come from different ranks are broken by ascending entity index -- the single world's order whenever the two have
+#     never swapped; otherwise that history lived on no rank and the merged order may differ by a swap of equal keys (pair lists then
+#     differ by the order of two pairs, never by content).
+# The upload path is the existing ABI: a fresh world whose colliders are uploaded in the merged order starts from exactly that
+# interval order (avn_colliders_upload appends new intervals in upload order), `avn_existing_pairs_upload` seeds the pair set.
+
+@dataclass
+class RankState:
+    gid: np.ndarray                      # global body index of every local body, ascending (static bodies are on every rank)
+    bodies: Dict[str, np.ndarray]        # the local bodies' CURRENT upload arrays (bodies_download merged over the original kwargs)
+    colliders: Dict[str, np.ndarray]     # local collider arrays; `body` = LOCAL index, entity_index = global
+    known: np.ndarray                    # [K, 2] global body pairs found so far, in this rank's emission order
+    order: np.ndarray                    # entity index per interval: the rank's persistent sweep order
+    order_key: np.ndarray                # min.x each interval had at the rank's last sweep (what `order` is sorted by); nan = never swept
+
+
+def aabb_cross_pairs(states: List["RankState"], aabb: List[Tuple[np.ndarray, np.ndarray]], rb_static: np.ndarray) -> np.ndarray:
+    """Global body pairs (a, b) of DIFFERENT ranks whose collider AABBs intersect now: the candidate edges that merge islands."""
+    out = []
+    R = len(states)
+    for a in range(R):
+        for b in range(a + 1, R):
+            ca, cb = states[a].colliders, states[b].colliders
+            ga = states[a].gid[np.asarray(ca["body"])]; gb = states[b].gid[np.asarray(cb["body"])]
+            ka = np.flatnonzero(~rb_static[ga]); kb = np.flatnonzero(~rb_static[gb])
+            if not len(ka) or not len(kb):
+                continue
+            mna, mxa = aabb[a][0][ka], aabb[a][1][ka]; mnb, mxb = aabb[b][0][kb], aabb[b][1][kb]
+            hit = np.all(mna[:, None, :] <= mxb[None, :, :], axis=2) & np.all(mxa[:, None, :] >= mnb[None, :, :], axis=2)
+            ia, ib = np.nonzero(hit)
+            out.append(np.stack([ga[ka[ia]], gb[kb[ib]]], axis=1))
+    return np.concatenate(out).astype(np.int64) if out else np.zeros((0, 2), np.int64)
+
+
+def merge_interval_orders(states: List["RankState"]) -> np.ndarray:
+    """The global persistent interval order (entity indices) from the ranks' orders: k-way merge on (last sweep's min.x, entity index)
+    that never reorders one rank's own list; colliders present on several ranks (static bodies) are kept once."""
+    import heapq
+    def stream(r):
+        st = states[r]
+        for pos, (e, k) in enumerate(zip(st.order.tolist(), st.order_key.tolist())):
+            yield ((-np.inf if np.isnan(k) else k), e, r, pos)
+    # heapq.merge needs every input sorted by the merge key: inside one rank the key is (min.x) only, so compare on that and break cross-rank
+    # ties by entity; a rank's own equal-key run stays in its order because merge is stable per input
+    merged, seen = [], set()
+    heads = [stream(r) for r in range(len(states))]
+    cur = [next(h, None) for h in heads]
+    while any(c is not None for c in cur):
+        best = None
+        for r, c in enumerate(cur):
+            if c is None:
+                continue
+            if best is None or (c[0], c[1]) < (cur[best][0], cur[best][1]):
+                best = r
+        e = cur[best][1]
+        if e not in seen:
+            seen.add(e); merged.append(e)
+        cur[best] = next(heads[best], None)
+    return np.asarray(merged, np.int64)
+
+
+def repartition(lib: F.Library, states: List["RankState"], aabb: List[Tuple[np.ndarray, np.ndarray]], n_bodies: int, rb_type: np.ndarray,
+                world_size: int, joints_edges: np.ndarray = None):
+    """Every rank calls this with the SAME gathered inputs and gets the same answer: (plan, [RankState per rank]).  The new states hold the
+    bodies' current data; `order` is the merged global order restricted to the rank (upload the colliders in that order)."""
+    rb_type = np.asarray(rb_type)
+    static = rb_type == F.RB_STATIC
+    # global body / collider tables (a body's data comes from any rank that holds it: owners for moving bodies, anyone for static ones)
+    fields = [k for k, v in states[0].bodies.items() if v is not None]
+    glob_b = {k: None for k in fields}
+    for st in states:
+        for k in fields:
+            v = np.asarray(st.bodies[k])
+            if glob_b[k] is None:
+                glob_b[k] = np.zeros((n_bodies,) + v.shape[1:], v.dtype)
+            glob_b[k][st.gid] = v
+    cfields = [k for k, v in states[0].colliders.items() if v is not None and k != "body"]
+    n_col = 1 + max(int(np.max(st.colliders["entity_index"])) for st in states)
+    glob_c = {k: None for k in cfields}
+    col_body = np.full(n_col, -1, np.int64)
+    for st in states:
+        ent = np.asarray(st.colliders["entity_index"]).astype(np.int64)
+        col_body[ent] = st.gid[np.asarray(st.colliders["body"])]
+        for k in cfields:
+            v = np.asarray(st.colliders[k])
+            if glob_c[k] is None:
+                glob_c[k] = np.zeros((n_col,) + v.shape[1:], v.dtype)
+            glob_c[k][ent] = v
+    known = np.concatenate([st.known.reshape(-1, 2) for st in states]).astype(np.int64)
+    cross = aabb_cross_pairs(states, aabb, static)
+    edges = [known, cross] + ([np.asarray(joints_edges).reshape(-1, 2)] if joints_edges is not None else [])
+    pl = plan(lib, rb_type, glob_b["position"], np.concatenate(edges), world_size)
+    order = merge_interval_orders(states)
+    out = []
+    for r in range(world_size):
+        loc = pl.local_bodies(r)
+        g2l = np.full(n_bodies, -1, np.int64); g2l[loc] = np.arange(len(loc))
+        ents = order[g2l[col_body[order]] >= 0]                     # the rank's colliders in the merged order
+        cols = {k: glob_c[k][ents] for k in cfields}
+        cols["entity_index"] = ents.astype(np.uint32)
+        cols["body"] = g2l[col_body[ents]].astype(np.int32)
+        for k, v in states[0].colliders.items():
+            if v is None:
+                cols[k] = None
+        bodies = {k: (glob_b[k][loc] if k in glob_b else None) for k in states[0].bodies}
+        owner = np.where(static[known[:, 0]], pl.rank_of_body[known[:, 1]], pl.rank_of_body[known[:, 0]])
+        out.append(RankState(loc, bodies, cols, known[owner == r], ents, np.full(len(ents), np.nan)))
+    return pl, out, cross
+
+
 # ---- x-slab sharding of the broad phase (SURVEY.md §8e: "each GPU sorts/sweeps its slab (+halo)") -----------------------
 #
 # The sweep-and-prune emits pairs i-major over the intervals sorted by min.x: pair (i, j) belongs to the EARLIER interval i

@@ -79,6 +79,69 @@ def run_world(lib, sc_bodies, sc_colliders, joints, friction, restitution, steps
     return out, all_pairs, overlaps
 
 
+def run_world_repartition(lib, sc, rank, world, steps, substeps):
+    """The level-1 flow WITH the re-partition: like run_world, but when the per-step bounds exchange reports intersecting ranks every rank
+    gathers the ranks' states, re-plans (shard.repartition) and rebuilds its sub-world from the bodies, known pairs and merged interval
+    order it now owns.  Returns (global ids, bodies_download, per-step owned counts, steps at which the assignment changed)."""
+    edges0 = scenes.brute_force_pairs(sc)
+    pl = shard.plan(lib, sc.rb_type, sc.position, edges0, world)
+    bodies, loc, g2l = shard.split_bodies(pl, rank, sc.body_kwargs())
+    cols = shard.split_colliders(g2l, sc.collider_kwargs())
+    st = shard.RankState(loc, bodies, cols, np.zeros((0, 2), np.int64), np.asarray(cols["entity_index"]).astype(np.int64), np.full(len(cols["entity_index"]), np.nan))
+
+    def build(st):
+        w = F.World(lib, F.default_config(32, substeps=substeps))
+        w.bodies_upload(**st.bodies)
+        w.colliders_upload(**st.colliders)
+        # one collider per body with entity_index = global body index (scenes.Scene): a known body pair IS its collider pair
+        w.existing_pairs_upload(np.array([lib.pair_key(int(a), int(b)) for a, b in st.known], np.uint64))
+        return w
+
+    def current(st, w):
+        cur = w.bodies_download()
+        b = dict(st.bodies)
+        for k in ("position", "rotation", "linear_velocity", "angular_velocity"):
+            b[k] = cur[k].astype(np.float64)
+        return b
+    w = build(st)
+    owned_hist, changed = [], []
+    for s in range(steps):
+        w.run_system("UPDATE_AABB")
+        _, _, ov = shard.exchange_bounds(w, dist if world > 1 else None)
+        if ov:
+            st.bodies = current(st, w)
+            mn, mx, _ = w.aabbs_download()
+            gathered = [None] * world
+            dist.all_gather_object(gathered, (st, (mn.astype(np.float64), mx.astype(np.float64))))
+            pl2, new_states, cross = shard.repartition(lib, [g[0] for g in gathered], [g[1] for g in gathered], sc.n, sc.rb_type, world)
+            if any(not np.array_equal(g[0].gid, n.gid) for g, n in zip(gathered, new_states)):
+                w.close()
+                st = new_states[rank]
+                w = build(st)
+                w.run_system("UPDATE_AABB")
+                changed.append(s)
+        w.run_system("COLLECT_COLLISION_PAIRS")
+        p = w.pairs_get()
+        st.known = np.concatenate([st.known, np.stack([st.gid[p["body1"]], st.gid[p["body2"]]], axis=1).astype(np.int64)])
+        mn, _, ents = w.aabbs_download()
+        e2slot = {int(e): i for i, e in enumerate(np.asarray(st.colliders["entity_index"]))}
+        st.order = ents.astype(np.int64)
+        st.order_key = np.array([mn[e2slot[int(e)], 0] for e in ents], np.float64)
+        g2l = np.full(sc.n, -1, np.int64); g2l[st.gid] = np.arange(len(st.gid))
+        cur = w.bodies_download()
+        sub = sc.subset(st.gid)
+        sub.position = cur["position"].astype(np.float64); sub.linear_velocity = cur["linear_velocity"].astype(np.float64)
+        sub.angular_velocity = cur["angular_velocity"].astype(np.float64)
+        mf = scenes.axis_aligned_manifolds(sub, g2l[st.known])
+        offs, perm = scenes.color_manifolds(lib, mf, sub.rb_type)
+        scenes.upload_manifolds(w, scenes.permute_manifolds(mf, perm), offs, sc.friction, sc.restitution)
+        w.run_system("SOLVER")
+        owned_hist.append(int((sc.rb_type[st.gid] != F.RB_STATIC).sum()))
+    out = w.bodies_download()
+    w.close()
+    return st.gid, out, owned_hist, changed
+
+
 def slab_scene():
     sc = scenes.sparse_mixed(6000, side=26.0)
     sc.linear_velocity *= 6.0   # colliders cross slab boundaries within a few frames
@@ -151,6 +214,23 @@ def main():
     lib = oracle_lib() if backend == "oracle" else hip_lib()
     if case == "level2":
         run_level2(lib, rank, world, steps, out_path)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if case == "merge":   # the thrown body merges the two ranks' islands: re-partition, then continue as the single world would
+        sc, _ = build_case("approach")
+        gid, got, owned_hist, changed = run_world_repartition(lib, sc, rank, world, steps, 2)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, (gid, got, owned_hist, changed))
+        if rank == 0:
+            merged = {k: np.zeros((sc.n,) + v.shape[1:], v.dtype) for k, v in got.items()}
+            holders = np.zeros(sc.n, np.int64)
+            for g, d, _, _ in gathered:
+                dyn = sc.rb_type[g] != F.RB_STATIC
+                holders[g[dyn]] += 1
+                for k in merged:
+                    merged[k][g] = d[k]          # (static bodies: identical everywhere)
+            np.savez(out_path, holders=holders, owned_hist=np.array([g[2] for g in gathered]), changed=np.array(gathered[0][3], np.int64), **merged)
         dist.barrier()
         dist.destroy_process_group()
         return

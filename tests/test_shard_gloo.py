@@ -93,6 +93,42 @@ def test_bounds_exchange_detects_cross_rank_approach(tmp_path):
     assert 0 <= int(got["first_overlap"]) <= 5, "the thrown body reaches the other rank's stack: bounds must overlap"
 
 
+def test_thrown_body_merges_two_ranks_islands_and_the_run_stays_the_single_world(tmp_path):
+    """Level 1 completed: the bounds exchange triggers shard.repartition, the two islands land on one rank together with their known pairs
+    and the merged interval order, and from then on the run equals the single world bit for bit (bodies after 12 steps, through the impact)."""
+    out = str(tmp_path / "merge.npz")
+    steps = 12
+    launch("merge", out, steps)
+    got = np.load(out)
+    sc, _ = SW.build_case("approach")
+    ref, _, _ = SW.run_world(oracle_lib(), sc.body_kwargs(), sc.collider_kwargs(), None, sc.friction, sc.restitution, steps, 2)
+    assert np.all(got["holders"][1:] == 1), "every dynamic body lives on exactly one rank at the end"
+    assert len(got["changed"]) >= 1, "the thrown body must have forced a re-partition"
+    oh = got["owned_hist"]
+    assert oh[:, 0].tolist() == [8, 8] and sorted(oh[:, -1].tolist()) == [0, 16], "two islands of 8 became one island of 16 on one rank"
+    for k in ("position", "rotation", "linear_velocity", "angular_velocity"):
+        assert np.array_equal(got[k], ref[k]), f"{k}: the re-partitioned run differs from the single world"
+    # the impact really happened: bodies of the right stack were moved by the thrown one
+    rest, _, _ = SW.run_world(oracle_lib(), *_without_throw(sc), None, sc.friction, sc.restitution, steps, 2)
+    assert float(np.abs(ref["linear_velocity"][9:] - rest["linear_velocity"][9:]).max()) > 0.1
+
+
+def _without_throw(sc):
+    b = sc.body_kwargs()
+    b["linear_velocity"] = np.zeros_like(b["linear_velocity"])
+    return b, sc.collider_kwargs()
+
+
+def test_merge_interval_orders_and_cross_pairs():
+    """Unit level: the k-way merge keeps each rank's own order, sorts across ranks by (key, entity) and keeps replicated colliders once."""
+    mk = lambda order, key: shard.RankState(np.zeros(0, np.int64), {}, {}, np.zeros((0, 2), np.int64), np.array(order, np.int64), np.array(key, float))
+    a = mk([0, 5, 3, 7], [-9.0, 1.0, 1.0, 4.0])       # 5 before 3 although tied: history, must survive
+    b = mk([0, 4, 2, 6], [-9.0, 1.0, 2.0, 4.0])
+    assert shard.merge_interval_orders([a, b]).tolist() == [0, 4, 5, 3, 2, 6, 7]
+    fresh = mk([0, 2, 1], [np.nan] * 3)
+    assert shard.merge_interval_orders([fresh, mk([0, 3], [np.nan] * 2)]).tolist() == [0, 2, 1, 3]
+
+
 def test_bounds_overlap_predicate():
     mn = np.array([[0, 0, 0], [1, 1, 1], [5, 5, 5.0]]); mx = np.array([[1, 1, 1], [2, 2, 2], [6, 6, 6.0]])
     assert shard.bounds_overlap(mn, mx) == [(0, 1)]          # touching counts, like ColliderAabb::intersects
