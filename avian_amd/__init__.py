@@ -12,7 +12,7 @@ from __future__ import annotations
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libavian_mi355x.so")
+LIB_PATH = os.environ.get("AVN_LIB_PATH") or os.path.join(_HERE, "csrc", "libavian_mi355x.so")   # (AVN_LIB_PATH: A/B builds of the same library)
 _lib = None
 
 

@@ -41,7 +41,7 @@ struct SweepScratch {
     uint32_t long_cap;
 };
 
-enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3, PASS_WARM_START_COLORS = 4 /* manifold-centric, one launch per colour */ };
+enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3, PASS_WARM_START_COLORS = 4 /* manifold-centric, one launch per colour */, PASS_MEMORY_SKELETON = 5 /* loads + stores of the solve pass, no solve */ };
 
 // k_bodies.hip
 template <class T> void launch_prepare_solver_bodies(const DW<T>&, hipStream_t);

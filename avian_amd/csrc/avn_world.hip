@@ -2027,6 +2027,7 @@ template <class T> struct World : WorldBase {
     void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
     void contact_pass(int pass) {
         if (!dw.n_manifolds) return;
+        if (bias_skeleton && pass == PASS_SOLVE_BIAS) pass = PASS_MEMORY_SKELETON;   // AVN_BIAS_SKELETON=1: measurement aid, state unchanged
         if (pipe_dev) {   // overflow colour first (one dataflow launch), then colours 0..22
             // (launched whenever a grid is captured for it, whatever the colour's current population: the captured graph must not
             //  depend on the step's counts; an empty colour costs one launch of idle lanes)
@@ -2332,6 +2333,7 @@ template <class T> struct World : WorldBase {
     } halo;
     DevBuf b_halo_send, b_halo_recv, b_halo_out, b_halo_in;
     bool halo_on = false;
+    bool bias_skeleton = getenv("AVN_BIAS_SKELETON") != nullptr && getenv("AVN_BIAS_SKELETON")[0] == '1';
     Comm comm;
     std::vector<CommXfer> xf_send, xf_recv;
     avn_status halo_plan_upload(const avn_halo_plan* p) override {
