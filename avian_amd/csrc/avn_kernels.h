@@ -82,7 +82,7 @@ void launch_island_substeps(const DW<float>&, const StepParams<float>&, const Is
 // k_xpbd.hip
 template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);
 template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,
-                                              const uint32_t* level_offsets, const uint32_t* order, hipStream_t);
+                                              const uint32_t* level_offsets, const int4* rec, hipStream_t);
 template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepParams<T>&, hipStream_t);
 // k_broadphase.hip
 template <class T> void launch_update_aabb(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);

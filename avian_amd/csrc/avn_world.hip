@@ -929,6 +929,13 @@ template <class T> struct World : WorldBase {
             if ((st = upload_u32(s->d_comp_level_begin, s->comp_level_begin)) != AVN_OK) return st;
             if ((st = upload_u32(s->d_level_offsets, s->level_offsets)) != AVN_OK) return st;
             if ((st = upload_u32(s->d_order, s->order)) != AVN_OK) return st;
+            std::vector<uint32_t> rec(4 * s->order.size());
+            for (size_t k = 0; k < s->order.size(); ++k) {
+                const uint32_t j = s->order[k];
+                rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; rec[4 * k + 3] = 0u;
+            }
+            if ((st = upload_u32(s->d_rec, rec)) != AVN_OK) return st;
+            HIPCHK(hipStreamSynchronize(stream));   // (`rec` is a local: the copy must have left it)
         }
         HIPCHK(hipStreamSynchronize(stream));
         joint_schedule_dirty = false;
@@ -2063,7 +2070,7 @@ template <class T> struct World : WorldBase {
         if (snapshot && xpbd_body_passes_needed()) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
         if (!dw.n_joints) return;
         launch_joint_schedule<T>(dw, params, 0, (uint32_t)sched_solve.n_components, sched_solve.d_comp_level_begin.as<uint32_t>(),
-                                 sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_order.as<uint32_t>(), stream);
+                                 sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_rec.as<int4>(), stream);
         ++launches;
     }
     void xpbd_velocity_projection() { if (xpbd_body_passes_needed()) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
@@ -2074,7 +2081,7 @@ template <class T> struct World : WorldBase {
             (void)hipMemsetAsync(&dw.sb_lin[dw.n_bodies], 0, 2 * DUMMY_SLOTS * sizeof(V), stream);  // DUMMY_SLOTS bodies x (lin | ang) slot
         }
         launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp.n_components, sched_damp.d_comp_level_begin.as<uint32_t>(),
-                                 sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_order.as<uint32_t>(), stream);
+                                 sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_rec.as<int4>(), stream);
         ++launches;
     }
     void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)

@@ -78,18 +78,21 @@ __global__ __launch_bounds__(256) void k_prepare_joints(DW<T> w) {
 template <class T> struct JBody {
     V3<T> dp; Q4<T> dq; V3<T> inv_mass; Sym3<T> I; T dp_w;
 };
-template <class T> __device__ __forceinline__ void jload(const DW<T>& w, int idx, bool nobody, bool dummy_inertia, JBody<T>& b) {
+// (all four records are loaded unconditionally -- a body without a SolverBody still has valid slots -- and the DUMMY substitutions are
+//  selects on the loaded values: the loads do not wait for the flag words, one memory round trip less per schedule level)
+template <class T> __device__ __forceinline__ void jselect(Vec4<T> d, Vec4<T> q, Vec4<T> sa, Vec4<T> sb, bool nobody, bool dummy_inertia, JBody<T>& b) {
     if (nobody) { b.dp = vzero<T>(); b.dq = qidentity<T>(); b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); b.dp_w = 0; return; }
-    Vec4<T> d = w.sb_dp[idx];
-    b.dp = xyz<T>(d); b.dp_w = d.w; b.dq = quat<T>(w.sb_dq[idx]);
+    b.dp = xyz<T>(d); b.dp_w = d.w; b.dq = quat<T>(q);
     if (dummy_inertia) { b.inv_mass = vzero<T>(); b.I = sym_zero<T>(); }
     else {
-        Vec4<T> sa = w.si_a[idx], sb = w.si_b[idx];
         b.inv_mass = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
         b.I = Sym3<T>{sa.y, sa.z, sa.w, sb.x, sb.y, sb.z};
     }
 }
-
+template <class T> __device__ __forceinline__ void jload(const DW<T>& w, int idx, bool nobody, bool dummy_inertia, JBody<T>& b) {
+    Vec4<T> d = w.sb_dp[idx], q = w.sb_dq[idx], sa = w.si_a[idx], sb = w.si_b[idx];
+    jselect<T>(d, q, sa, sb, nobody, dummy_inertia, b);
+}
 // xpbd/mod.rs:393-413 compute_lagrange_update (w = [w1, w2]; `iter().sum()` starts from 0.0)
 template <class T> __device__ __forceinline__ T compute_lagrange_update(T lagrange, T c, T w1, T w2, T compliance, T dt) {
     T w_sum = T(0) + w1 + w2;
@@ -170,25 +173,29 @@ template <class T> __device__ __forceinline__ V3<T> correction_along_axis(T lim_
 
 // solve_xpbd_joint<T> (xpbd/plugin.rs:145-189) for one joint of any type: fixed.rs:74-91, revolute.rs:92-183,
 // spherical.rs:85-209, prismatic.rs:83-192, distance.rs:61-117
-template <class T> __device__ __forceinline__ void joint_solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t j) {
-    int2 b = w.j_bodies[j];
+template <class T> __device__ __forceinline__ void joint_solve_one(const DW<T>& w, const StepParams<T>& p, uint32_t j, int2 b) {
+    // one memory level: flags, both bodies' four records and the joint's own records are all addressed by (j, b) from the schedule record
     uint32_t f1 = w.sb_flags[b.x], f2 = w.sb_flags[b.y];
+    Vec4<T> d1 = w.sb_dp[b.x], q1 = w.sb_dq[b.x], sa1 = w.si_a[b.x], sb1 = w.si_b[b.x];
+    Vec4<T> d2 = w.sb_dp[b.y], q2 = w.sb_dq[b.y], sa2 = w.si_a[b.y], sb2 = w.si_b[b.y];
+    Vec4<T> a1v = w.j_a1[j], a2v = w.j_a2[j], par = w.j_par[j];
+    Vec4<T> jr1 = w.j_r1[j], jr2 = w.j_r2[j], jcd = w.j_cd[j], jlag = w.j_lag[j];
+    asm volatile("" ::: "memory");   // (keeps the loads above in one batch: see k_contacts.hip solve_core)
     bool nobody1 = f1 & AVN_SBF_NO_SOLVER_BODY, nobody2 = f2 & AVN_SBF_NO_SOLVER_BODY;
     // dominance of the (possibly DUMMY) inertias; DUMMY rows carry dominance 128
-    int dom1 = (int)(int16_t)(scalar_to_bits(w.si_b[b.x].w) >> 16), dom2 = (int)(int16_t)(scalar_to_bits(w.si_b[b.y].w) >> 16);
+    int dom1 = (int)(int16_t)(scalar_to_bits(sb1.w) >> 16), dom2 = (int)(int16_t)(scalar_to_bits(sb2.w) >> 16);
     int rel = dom1 - dom2;
     JBody<T> b1, b2;
-    jload<T>(w, b.x, nobody1, rel > 0, b1);
-    jload<T>(w, b.y, nobody2, rel < 0, b2);
-    Vec4<T> a1v = w.j_a1[j], a2v = w.j_a2[j], par = w.j_par[j];
+    jselect<T>(d1, q1, sa1, sb1, nobody1, rel > 0, b1);
+    jselect<T>(d2, q2, sa2, sb2, nobody2, rel < 0, b2);
     uint32_t meta = scalar_to_bits(par.w);
     uint32_t type = jm_type(meta), limits = jm_limits(meta);
     T limit_min = a1v.w, limit_max = a2v.w, c0 = par.x;
     T dt = p.h_adj;
     const T PI = T(3.14159265358979323846264338327950288), EPS = Limits<T>::eps;
     JData<T> d;
-    d.r1 = xyz<T>(w.j_r1[j]); d.r2 = xyz<T>(w.j_r2[j]); d.cd = xyz<T>(w.j_cd[j]);
-    d.lag = xyz<T>(w.j_lag[j]);
+    d.r1 = xyz<T>(jr1); d.r2 = xyz<T>(jr2); d.cd = xyz<T>(jcd);
+    d.lag = xyz<T>(jlag);
     d.rl0 = vzero<T>(); d.rl1 = vzero<T>();
     bool angular = type != AVN_JOINT_DISTANCE;
     T c1 = 0, c2 = 0;
@@ -290,10 +297,9 @@ template <class T> __device__ __forceinline__ void joint_solve_one(const DW<T>& 
     if (!nobody2) { w.sb_dp[b.y] = make4<T>(b2.dp, b2.dp_w); w.sb_dq[b.y] = make4<T>(b2.dq); }
 }
 
-template <class T> __device__ __forceinline__ void joint_damping_one(const DW<T>& w, const StepParams<T>& p, uint32_t j) {
+template <class T> __device__ __forceinline__ void joint_damping_one(const DW<T>& w, const StepParams<T>& p, uint32_t j, int2 b) {
     Vec4<T> par = w.j_par[j];
     if (!(scalar_to_bits(par.w) & 1u)) return;  // no JointDamping component
-    int2 b = w.j_bodies[j];
     uint32_t f1 = w.sb_flags[b.x], f2 = w.sb_flags[b.y];
     bool nobody1 = f1 & AVN_SBF_NO_SOLVER_BODY, nobody2 = f2 & AVN_SBF_NO_SOLVER_BODY;
     T delta_secs = p.h_adj;
@@ -320,23 +326,36 @@ template <class T> __device__ __forceinline__ void joint_damping_one(const DW<T>
     w.sb_lin[i2] = make4<T>(v2, l2.w); w.sb_ang[i2] = make4<T>(om2, g2.w);
 }
 
-// One workgroup per joint component; levels separated by workgroup barriers.
+// One workgroup (one wave) per joint component; levels separated by workgroup barriers.
 //   comp_level_begin[c] .. comp_level_begin[c+1]  : level slots of component c
-//   level_offsets[l] .. level_offsets[l+1]        : joints (via `order`) of level slot l
+//   level_offsets[l] .. level_offsets[l+1]        : schedule slots of level slot l
+//   rec[k] = (joint, body1, body2, 0)             : the slot's record, written by the host with the schedule
+// A chain is the worst case: 99 levels of ONE joint, every level a dependent walk through memory.  The walk used to be
+// level_offsets -> order -> j_bodies -> flags / dominance -> body records (five round trips per level); with the bodies in the slot record
+// and the record of the lane's NEXT level fetched while the current one is solved, a level costs one round trip (its body and joint
+// records, all addressed by the record) plus the solve.
 template <class T, int OP>
 __global__ __launch_bounds__(JOINT_THREADS) void k_joint_schedule(DW<T> w, StepParams<T> p, const uint32_t* __restrict__ comp_level_begin,
                                                                    const uint32_t* __restrict__ level_offsets,
-                                                                   const uint32_t* __restrict__ order) {
-    uint32_t c = blockIdx.x;
-    uint32_t l0 = comp_level_begin[c], l1 = comp_level_begin[c + 1];
+                                                                   const int4* __restrict__ rec) {
+    const uint32_t c = blockIdx.x;
+    const uint32_t l0 = comp_level_begin[c], l1 = comp_level_begin[c + 1];
+    if (l0 >= l1) return;
+    uint32_t j0 = level_offsets[l0], j1 = level_offsets[l0 + 1];
+    int4 cur = make_int4(0, 0, 0, 0);
+    if (j0 + threadIdx.x < j1) cur = rec[j0 + threadIdx.x];
     for (uint32_t l = l0; l < l1; ++l) {
-        uint32_t j0 = level_offsets[l], j1 = level_offsets[l + 1];
+        // the next level's bounds and this lane's first record there: independent of anything this level computes
+        uint32_t n0 = j1, n1 = j1;
+        int4 nxt = make_int4(0, 0, 0, 0);
+        if (l + 1 < l1) { n1 = level_offsets[l + 2]; if (n0 + threadIdx.x < n1) nxt = rec[n0 + threadIdx.x]; }
         for (uint32_t k = j0 + threadIdx.x; k < j1; k += JOINT_THREADS) {
-            uint32_t j = order[k];
-            if (OP == 0) joint_solve_one<T>(w, p, j);
-            else joint_damping_one<T>(w, p, j);
+            const int4 r = (k == j0 + threadIdx.x) ? cur : rec[k];
+            if (OP == 0) joint_solve_one<T>(w, p, (uint32_t)r.x, make_int2(r.y, r.z));
+            else joint_damping_one<T>(w, p, (uint32_t)r.x, make_int2(r.y, r.z));
         }
         __syncthreads();
+        j0 = n0; j1 = n1; cur = nxt;
     }
 }
 
@@ -354,10 +373,10 @@ template <class T> void launch_prepare_joints(const DW<T>& w, hipStream_t s) {
     if (w.n_joints) hipLaunchKernelGGL(k_prepare_joints<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w);
 }
 template <class T> void launch_joint_schedule(const DW<T>& w, const StepParams<T>& p, int op, uint32_t n_components,
-                                              const uint32_t* comp_level_begin, const uint32_t* level_offsets, const uint32_t* order, hipStream_t s) {
+                                              const uint32_t* comp_level_begin, const uint32_t* level_offsets, const int4* rec, hipStream_t s) {
     if (!w.n_joints || !n_components) return;
-    if (op == 0) hipLaunchKernelGGL((k_joint_schedule<T, 0>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, order);
-    else hipLaunchKernelGGL((k_joint_schedule<T, 1>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, order);
+    if (op == 0) hipLaunchKernelGGL((k_joint_schedule<T, 0>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, rec);
+    else hipLaunchKernelGGL((k_joint_schedule<T, 1>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, rec);
 }
 template <class T> void launch_writeback_joint_forces(const DW<T>& w, const StepParams<T>& p, hipStream_t s) {
     if (w.n_joints) hipLaunchKernelGGL(k_writeback_joint_forces<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, p);
@@ -365,7 +384,7 @@ template <class T> void launch_writeback_joint_forces(const DW<T>& w, const Step
 
 #define INST(T)                                                                                    \
     template void launch_prepare_joints<T>(const DW<T>&, hipStream_t);                    \
-    template void launch_joint_schedule<T>(const DW<T>&, const StepParams<T>&, int, uint32_t, const uint32_t*, const uint32_t*, const uint32_t*, hipStream_t); \
+    template void launch_joint_schedule<T>(const DW<T>&, const StepParams<T>&, int, uint32_t, const uint32_t*, const uint32_t*, const int4*, hipStream_t); \
     template void launch_writeback_joint_forces<T>(const DW<T>&, const StepParams<T>&, hipStream_t);
 INST(float)
 INST(double)

@@ -347,10 +347,13 @@ def main():
             wc.step()
         transient = window(20)   # steps 4..23: the pile is still compacting (~2e5 status changes per step, an overflow colour 10^5 strong and hundreds of levels deep)
         settled = window(20)     # steps 24..43
+        for _ in range(56):
+            wc.step()
+        steady = window(20)      # steps 100..119: the pile has stopped compacting (2-3e4 status changes per step, a few hundred overflow manifolds)
         ps = wc.pipeline_stats()
         closed = {"ms_per_step": settled["ms_per_step"], "substeps_per_s": settled["substeps_per_s"], "host_bookkeeping_ms": settled["host_bookkeeping_ms"],
                   "window": "steps 24..43 after avn_pipeline_enable (20 steps)", "active_pairs": ps.active_pairs, "roofline": settled["roofline"],
-                  "settled": settled, "transient_steps_4_23": transient,
+                  "settled": settled, "transient_steps_4_23": transient, "steady_steps_100_119": steady,
                   "note": "avn_pipeline_enable(1): broad phase -> Ball/Cuboid narrow phase (parry part parity-unpinned) -> status-change loop, greedy colouring, handle lists "
                           "and the overflow colour's order ALL on the device; per step the host reads three counter blocks"}
         del wc
