@@ -187,6 +187,20 @@ class avn_diagnostics(C.Structure):
                [(n, C.c_uint32) for n in ("contact_constraint_count", "contact_count", "per_system_valid", "reserved0")]
 
 
+class avn_sleep_params(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("time_to_sleep", C.c_float), ("linear_threshold", C.c_float), ("angular_threshold", C.c_float),
+                ("delta_secs", C.c_float), ("length_unit", C.c_double)]
+
+
+class avn_sleep_stats(C.Structure):
+    _fields_ = [("n_islands", C.c_uint32), ("n_island_bodies", C.c_uint32), ("n_resting_islands", C.c_uint32), ("n_resting_bodies", C.c_uint32),
+                ("n_awake_bodies", C.c_uint32), ("reserved0", C.c_uint32)]
+
+
+class avn_sleep_out(C.Structure):
+    _fields_ = [("sleep_timer", vp), ("island", vp), ("island_rests", vp)]
+
+
 class avn_halo_plan(C.Structure):
     _fields_ = [("n_peers", C.c_uint32), ("peer_rank", vp), ("send_offsets", vp), ("send_bodies", vp), ("recv_offsets", vp), ("recv_bodies", vp)]
 
@@ -199,7 +213,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -235,6 +249,10 @@ class Library:
         f("run_color_pass").argtypes = [vp, C.c_int, C.c_uint32]
         f("halo_pack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_size_t)]
         f("halo_unpack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+        f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+        f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
+        f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
+        f("sleep_reset").argtypes = [vp, vp, C.c_size_t]
         f("comm_unique_id").argtypes = [vp]
         f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
         f("profile_system").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
@@ -648,6 +666,36 @@ class World:
     def halo_unpack(self, color: int, peer: int, rec: np.ndarray):
         rec = np.ascontiguousarray(rec, self.dtype)
         self._check(self.lib.fn("halo_unpack")(self.handle, int(color), int(peer), _ptr(rec), len(rec)))
+
+    # -- islands and sleeping -----------------------------------------------------------------
+    def islands_get(self):
+        """``avn_islands_get``: (island label per body = lowest body index of its island, 0xFFFFFFFF for static bodies; island count)."""
+        lab = np.zeros(self.n_bodies, np.uint32)
+        n = C.c_uint32()
+        self._check(self.lib.fn("islands_get")(self.handle, _ptr(lab), C.byref(n)))
+        return lab, int(n.value)
+
+    def sleep_update(self, delta_secs: float = 1.0 / 60.0, time_to_sleep: float = 0.5, linear_threshold: float = 0.15, angular_threshold: float = 0.15,
+                     length_unit: float = 1.0) -> avn_sleep_stats:
+        """``avn_sleep_update``: update_sleeping_states + the decision of sleep_islands for the step just taken."""
+        p = avn_sleep_params(C.sizeof(avn_sleep_params), time_to_sleep, linear_threshold, angular_threshold, delta_secs, length_unit)
+        st = avn_sleep_stats()
+        self._check(self.lib.fn("sleep_update")(self.handle, C.byref(p), C.byref(st)))
+        return st
+
+    def sleep_get(self):
+        n = self.n_bodies
+        out = dict(sleep_timer=np.zeros(n, np.float32), island=np.zeros(n, np.uint32), island_rests=np.zeros(n, np.uint8))
+        o = avn_sleep_out(_ptr(out["sleep_timer"]), _ptr(out["island"]), _ptr(out["island_rests"]))
+        self._check(self.lib.fn("sleep_get")(self.handle, C.byref(o)))
+        return out
+
+    def sleep_reset(self, bodies=None):
+        if bodies is None or len(bodies) == 0:
+            self._check(self.lib.fn("sleep_reset")(self.handle, None, 0))
+        else:
+            b = np.ascontiguousarray(bodies, np.uint32)
+            self._check(self.lib.fn("sleep_reset")(self.handle, _ptr(b), len(b)))
 
     def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

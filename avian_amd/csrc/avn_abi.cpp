@@ -138,6 +138,10 @@ AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { 
 AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD(run_color_pass(pass, color)); }
 AVN_API avn_status avn_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { GUARD(halo_pack(color, peer, out, count)); }
 AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD(halo_unpack(color, peer, in, count)); }
+AVN_API avn_status avn_islands_get(avn_world* w, uint32_t* island_of_body, uint32_t* n_islands) { GUARD(islands_get(island_of_body, n_islands)); }
+AVN_API avn_status avn_sleep_update(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* st) { GUARD(sleep_update(p, st)); }
+AVN_API avn_status avn_sleep_get(avn_world* w, const avn_sleep_out* o) { GUARD(sleep_get(o)); }
+AVN_API avn_status avn_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(sleep_reset(bodies, n)); }
 AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
     try { return avn::comm_unique_id(out, g_create_error); }
     catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }

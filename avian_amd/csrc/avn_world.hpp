@@ -94,6 +94,10 @@ struct WorldBase {
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
     virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
     virtual avn_status comm_init(const uint8_t*, int, int) = 0;
+    virtual avn_status islands_get(uint32_t*, uint32_t*) = 0;
+    virtual avn_status sleep_update(const avn_sleep_params*, avn_sleep_stats*) = 0;
+    virtual avn_status sleep_get(const avn_sleep_out*) = 0;
+    virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
 };
 
 // RCCL transport of the level-2 halo exchange (avn_comm.cpp; librccl is opened on first use)

@@ -1,0 +1,135 @@
+// k_islands.hip — simulation islands and the sleeping decision on the device (include/avian_mi355x.h: avn_islands_get / avn_sleep_update).
+//
+// Islands: connected components of the constraint graph over non-static bodies (reference dynamics/solver/islands/mod.rs:1-10,
+// merge_islands :814-990 -- a body without a BodyIslandNode, i.e. a static one, never links two islands).  One pass of a lock-free
+// union-find over the edges (manifold body pairs + joints): find with path halving, hook the LARGER root under the SMALLER by compare-and-
+// swap, retry from the value the failed swap returned.  Parents only ever decrease, so every tree's root is its lowest body index: the
+// label is canonical without a renumbering pass.  Loads and stores of the parent array are agent-scope (the eight XCD L2s are not coherent
+// with each other; the swap is the only operation correctness rests on, a stale parent merely costs a retry).
+//
+// Sleeping: update_sleeping_states (islands/sleeping.rs:184-241) with the island's awake bit as a store of 1 by any body that is not yet
+// sleepy, and the resting islands / awake body counts by one more pass.
+#include "avn_kernels.h"
+
+namespace avn {
+
+__device__ __forceinline__ uint32_t cc_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cc_st(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t cc_find(uint32_t* L, uint32_t x) {
+    uint32_t cur = x, next = cc_ld(L + cur);
+    while (next != cur) {
+        const uint32_t nn = cc_ld(L + next);
+        if (nn != next) cc_st(L + cur, nn);   // path halving: a benign race, parents only decrease
+        cur = next; next = nn;
+    }
+    return cur;
+}
+__device__ __forceinline__ void cc_union(uint32_t* L, uint32_t a, uint32_t b) {
+    uint32_t ra = cc_find(L, a), rb = cc_find(L, b);
+    while (ra != rb) {
+        if (ra < rb) { const uint32_t t = ra; ra = rb; rb = t; }   // ra > rb: ra goes under rb
+        uint32_t expected = ra;
+        if (__hip_atomic_compare_exchange_strong(L + ra, &expected, rb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+        ra = cc_find(L, expected);   // ra had stopped being a root: `expected` is its parent now
+        rb = cc_find(L, rb);
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(256) void k_cc_init(DW<T> w, uint32_t* __restrict__ L) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b < w.n_bodies) L[b] = b;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_cc_edges(DW<T> w, const int2* __restrict__ edges, uint32_t n, uint32_t* __restrict__ L) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int2 e = edges[i];
+    if (e.x < 0 || e.y < 0 || (uint32_t)e.x >= w.n_bodies || (uint32_t)e.y >= w.n_bodies || e.x == e.y) return;
+    if (meta_rb_type(w.bmeta[e.x]) == AVN_RB_STATIC || meta_rb_type(w.bmeta[e.y]) == AVN_RB_STATIC) return;
+    cc_union(L, (uint32_t)e.x, (uint32_t)e.y);
+}
+// labels out (lowest body index of the island, PG_NONE for static bodies) + ctr[0] = islands, ctr[1] = island bodies
+template <class T>
+__global__ __launch_bounds__(256) void k_cc_finish(DW<T> w, uint32_t* __restrict__ L, uint32_t* __restrict__ label, uint32_t* __restrict__ ctr) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    bool node = false, root = false;
+    if (b < w.n_bodies) {
+        node = meta_rb_type(w.bmeta[b]) != AVN_RB_STATIC;
+        uint32_t r = 0xFFFFFFFFu;
+        if (node) { r = cc_find(L, b); root = r == b; }
+        label[b] = r;
+    }
+    const unsigned long long nb = __ballot(node), rb = __ballot(root);
+    if ((threadIdx.x & 63) == 0) {
+        if (rb) atomicAdd(ctr + 0, (uint32_t)__popcll(rb));
+        if (nb) atomicAdd(ctr + 1, (uint32_t)__popcll(nb));
+    }
+}
+
+// update_sleeping_states, the per-body half (sleeping.rs:200-229)
+template <class T>
+__global__ __launch_bounds__(256) void k_sleep_timers(DW<T> w, SleepParams<T> sp, const uint32_t* __restrict__ label, float* __restrict__ timer,
+                                                      uint32_t* __restrict__ awake) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= w.n_bodies) return;
+    const uint32_t l = label[b];
+    if (l == 0xFFFFFFFFu) { timer[b] = 0.0f; return; }
+    const V3<T> v = xyz<T>(w.sb_lin[b]), om = xyz<T>(w.sb_ang[b]);
+    const T v2 = length_squared(v), w2 = length_squared(om);
+    float t = timer[b];
+    if (v2 < sp.length_unit_squared * sp.lin_threshold_squared && w2 < sp.ang_threshold_squared) t = t + sp.delta_secs;
+    else t = 0.0f;
+    timer[b] = t;
+    if (t < sp.time_to_sleep) awake[l] = 1u;   // awake_island_bit_vec.set(island): any writer, same value
+}
+// sleep_islands' decision (sleeping.rs:256-266), per body; ctr[2] = resting islands, ctr[3] = bodies in them
+__global__ __launch_bounds__(256) void k_sleep_decide(uint32_t n, const uint32_t* __restrict__ label, const uint32_t* __restrict__ awake,
+                                                      uint8_t* __restrict__ rests, uint32_t* __restrict__ ctr) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    bool r = false, root = false;
+    if (b < n) {
+        const uint32_t l = label[b];
+        r = l != 0xFFFFFFFFu && awake[l] == 0u;
+        root = r && l == b;
+        rests[b] = r ? 1 : 0;
+    }
+    const unsigned long long rb = __ballot(r), ib = __ballot(root);
+    if ((threadIdx.x & 63) == 0) {
+        if (ib) atomicAdd(ctr + 2, (uint32_t)__popcll(ib));
+        if (rb) atomicAdd(ctr + 3, (uint32_t)__popcll(rb));
+    }
+}
+__global__ __launch_bounds__(256) void k_sleep_reset(float* __restrict__ timer, const uint32_t* __restrict__ bodies, uint32_t n, uint32_t n_bodies) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bodies ? bodies[i] : i;
+    if (b < n_bodies) timer[b] = 0.0f;
+}
+
+template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t s) {
+    if (!w.n_bodies) return;
+    const uint32_t nb = (w.n_bodies + 255) / 256;
+    hipLaunchKernelGGL(k_cc_init<T>, dim3(nb), dim3(256), 0, s, w, parent);
+    if (w.n_manifolds) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, (const int2*)w.m_bodies, w.n_manifolds, parent);
+    if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent);
+    hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr);
+}
+template <class T> void launch_sleep_update(const DW<T>& w, const SleepParams<T>& sp, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint32_t* ctr, hipStream_t s) {
+    if (!w.n_bodies) return;
+    const uint32_t nb = (w.n_bodies + 255) / 256;
+    hipLaunchKernelGGL(k_sleep_timers<T>, dim3(nb), dim3(256), 0, s, w, sp, label, timer, awake);
+    hipLaunchKernelGGL(k_sleep_decide, dim3(nb), dim3(256), 0, s, w.n_bodies, label, (const uint32_t*)awake, rests, ctr);
+}
+void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32_t n_bodies, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_sleep_reset, dim3((n + 255) / 256), dim3(256), 0, s, timer, bodies, n, n_bodies);
+}
+
+#define INST(T)                                                                                              \
+    template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t);            \
+    template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint32_t*, hipStream_t);
+INST(float)
+INST(double)
+#undef INST
+
+}  // namespace avn

@@ -43,6 +43,14 @@ def plan(lib: F.Library, rb_type, position, edges: np.ndarray, world_size: int) 
     return ShardPlan(world_size, isl, rk, n)
 
 
+def plan_from_world(lib: F.Library, world: F.World, rb_type, position, world_size: int) -> ShardPlan:
+    """The same plan from the islands the LIBRARY holds (avn_islands_get: connected components of the world's current constraint graph,
+    computed on the device): the labels travel as star edges (body -> lowest body of its island), 4 bytes per body instead of the edge list."""
+    lab, _ = world.islands_get()
+    b = np.flatnonzero(lab != 0xFFFFFFFF)
+    return plan(lib, rb_type, position, np.stack([b, lab[b].astype(np.int64)], axis=1), world_size)
+
+
 def _take(d: Dict[str, np.ndarray], idx: np.ndarray) -> Dict[str, np.ndarray]:
     return {k: (None if v is None else np.asarray(v)[idx]) for k, v in d.items()}
 

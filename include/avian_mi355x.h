@@ -618,6 +618,51 @@ typedef struct avn_islands_in {
 AVN_API avn_status AVN_FN(islands_partition)(const avn_islands_in* in, int32_t* island_of_body, int32_t* rank_of_body,
                                               uint32_t* n_islands);
 
+/* ---- islands and sleeping on the device ---------------------------------------------------------------------
+ * avn_islands_get: the simulation islands of the world's CURRENT constraint graph -- connected components over the contact manifolds the
+ * solver holds (closed loop: the touching pairs that generate constraints; otherwise the uploaded manifolds) and the joints, where only
+ * non-static bodies connect (islands/mod.rs:1-10, :814-990 merge_islands: a static body never merges islands; kinematic ones do).  Label =
+ * the LOWEST body index of the island (0xFFFFFFFF for static bodies): the partition the reference's persistent union-find holds once its
+ * pending splits are done (split_island, :995+, is deferred there: ONE island per step, and only when a body wants to sleep).
+ * Computed by a lock-free union-find on the device (k_islands.hip); feeds the island-block builder and the multi-GPU partitioner.
+ *
+ * avn_sleep_update: update_sleeping_states (islands/sleeping.rs:184-241) for one step, on the device, in the reference's arithmetic:
+ *   per non-static body   v2 = |SolverBody.linear_velocity|^2, w2 = |SolverBody.angular_velocity|^2      (Scalar)
+ *                         rests = v2 < length_unit^2 * (lin * |lin|) && w2 < ang * |ang|                 (thresholds f32, "keep signs")
+ *                         SleepTimer (f32) += delta_secs (f32) if rests else = 0
+ *   per island            kept awake if any body has SleepTimer < time_to_sleep; otherwise it RESTS: sleep_islands (:243-280) would put it
+ *                         to sleep.
+ * What the call reports is the DECISION.  Putting an island to sleep / waking it (SleepIslands / WakeIslands, :300-520: Sleeping
+ * components, the ContactGraph's sleeping set, pop / push of the constraint handles) is the host's side of the boundary and is NOT done
+ * here; neither is the one-step delay a pending split adds in the reference.  Call it after avn_step (the Sleeping set runs after the
+ * Solver set, schedule/mod.rs). */
+typedef struct avn_sleep_params {
+    uint32_t struct_size;
+    float time_to_sleep;          /* TimeToSleep, default 0.5 s */
+    float linear_threshold;       /* SleepThreshold.linear, default 0.15 */
+    float angular_threshold;      /* SleepThreshold.angular, default 0.15 */
+    float delta_secs;             /* Time::delta_secs() of the step (f32) */
+    double length_unit;           /* PhysicsLengthUnit, default 1 */
+} avn_sleep_params;
+typedef struct avn_sleep_stats {
+    uint32_t n_islands;                   /* islands of the current constraint graph */
+    uint32_t n_island_bodies;             /* non-static bodies */
+    uint32_t n_resting_islands;           /* islands no body keeps awake: sleep_islands would put them to sleep */
+    uint32_t n_resting_bodies;            /* bodies in those islands */
+    uint32_t n_awake_bodies;              /* n_island_bodies - n_resting_bodies: the solver's N once the host has acted on the decision */
+    uint32_t reserved0;
+} avn_sleep_stats;
+typedef struct avn_sleep_out {
+    float* sleep_timer;        /* [n_bodies] SleepTimer after the update (0 for static bodies); may be NULL */
+    uint32_t* island;          /* [n_bodies] island label (lowest body index), 0xFFFFFFFF for static bodies; may be NULL */
+    uint8_t* island_rests;     /* [n_bodies] 1 = the body's island rests (would be put to sleep); may be NULL */
+} avn_sleep_out;
+AVN_API avn_status AVN_FN(islands_get)(avn_world* w, uint32_t* island_of_body /* [n_bodies] */, uint32_t* n_islands);
+AVN_API avn_status AVN_FN(sleep_update)(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* stats);
+AVN_API avn_status AVN_FN(sleep_get)(avn_world* w, const avn_sleep_out* out);
+/* SleepTimer = 0 for the listed bodies (n = 0: for all): what waking an island does to its bodies (sleeping.rs:492) */
+AVN_API avn_status AVN_FN(sleep_reset)(avn_world* w, const uint32_t* bodies, size_t n);
+
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as
  * doubles: the per-rank bound exchanged between ranks to detect islands of different ranks coming into AABB contact.
  * Empty worlds return min = +inf, max = -inf. */

@@ -286,6 +286,10 @@ struct WorldBase {
     virtual avn_status step() = 0;
     virtual avn_status timers(avn_timers*) = 0;
     virtual avn_status diagnostics(avn_diagnostics*) = 0;
+    virtual avn_status islands_get(uint32_t*, uint32_t*) = 0;
+    virtual avn_status sleep_update(const avn_sleep_params*, avn_sleep_stats*) = 0;
+    virtual avn_status sleep_get(const avn_sleep_out*) = 0;
+    virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
@@ -1867,6 +1871,83 @@ template <class S> struct World : WorldBase {
             SolverBody<S>& sb = bodies[halo.recv[i]].sb;
             sb.linear_velocity = V3<S>{r[0], r[1], r[2]}; sb.angular_velocity = V3<S>{r[4], r[5], r[6]};
         }
+        return AVN_OK;
+    }
+    // ---- islands and sleeping: the checker of avn_islands_get / avn_sleep_update (header).  Deliberately NOT the product's algorithm: a
+    // breadth-first flood over adjacency lists in ascending body order (the first body reached is the island's lowest index), and the
+    // serial loops of update_sleeping_states / sleep_islands (islands/sleeping.rs:184-280) over bodies and islands.
+    std::vector<uint32_t> isl_label;
+    std::vector<float> sleep_timer;
+    std::vector<uint8_t> isl_rests;
+    uint32_t isl_count = 0, isl_nodes = 0;
+    void islands_compute() {
+        const size_t n = bodies.size();
+        std::vector<std::vector<uint32_t>> adj(n);
+        auto node = [&](int32_t b) { return b >= 0 && (size_t)b < n && bodies[b].rb_type != AVN_RB_STATIC; };
+        for (const auto& m : manifolds) if (node(m.body1) && node(m.body2) && m.body1 != m.body2) { adj[m.body1].push_back((uint32_t)m.body2); adj[m.body2].push_back((uint32_t)m.body1); }
+        for (const auto& j : joints) if (node(j.body1) && node(j.body2) && j.body1 != j.body2) { adj[j.body1].push_back((uint32_t)j.body2); adj[j.body2].push_back((uint32_t)j.body1); }
+        isl_label.assign(n, 0xFFFFFFFFu);
+        isl_count = 0; isl_nodes = 0;
+        std::vector<uint32_t> queue;
+        for (size_t s = 0; s < n; ++s) {
+            if (!node((int32_t)s)) continue;
+            ++isl_nodes;
+            if (isl_label[s] != 0xFFFFFFFFu) continue;
+            ++isl_count;
+            isl_label[s] = (uint32_t)s;
+            queue.assign(1, (uint32_t)s);
+            for (size_t q = 0; q < queue.size(); ++q)
+                for (uint32_t o : adj[queue[q]]) if (isl_label[o] == 0xFFFFFFFFu) { isl_label[o] = (uint32_t)s; queue.push_back(o); }
+        }
+    }
+    avn_status islands_get(uint32_t* island_of_body, uint32_t* n_islands) override {
+        islands_compute();
+        if (island_of_body) std::copy(isl_label.begin(), isl_label.end(), island_of_body);
+        if (n_islands) *n_islands = isl_count;
+        return AVN_OK;
+    }
+    avn_status sleep_update(const avn_sleep_params* sp, avn_sleep_stats* out) override {
+        if (!sp || sp->struct_size != sizeof(avn_sleep_params)) { error = "sleep_update: bad params"; return AVN_ERR_BAD_ARG; }
+        islands_compute();
+        const size_t n = bodies.size();
+        if (sleep_timer.size() != n) sleep_timer.assign(n, 0.0f);
+        const S length_unit_squared = (S)sp->length_unit * (S)sp->length_unit;
+        const float delta_secs = sp->delta_secs;
+        std::vector<uint8_t> awake(n, 0);   // AwakeIslandBitVec, indexed by island label
+        for (size_t b = 0; b < n; ++b) {
+            if (isl_label[b] == 0xFFFFFFFFu) { sleep_timer[b] = 0.0f; continue; }
+            const SolverBody<S>& sb = bodies[b].sb;
+            const S lin_vel_squared = length_squared(sb.linear_velocity), ang_vel_squared = length_squared(sb.angular_velocity);
+            // "Keep signs."
+            const float lin_threshold_squared = sp->linear_threshold * std::fabs(sp->linear_threshold);
+            const float ang_threshold_squared = sp->angular_threshold * std::fabs(sp->angular_threshold);
+            if (lin_vel_squared < length_unit_squared * (S)lin_threshold_squared && ang_vel_squared < (S)ang_threshold_squared) sleep_timer[b] += delta_secs;
+            else sleep_timer[b] = 0.0f;
+            if (sleep_timer[b] < sp->time_to_sleep) awake[isl_label[b]] = 1;
+        }
+        isl_rests.assign(n, 0);
+        uint32_t resting_islands = 0, resting_bodies = 0;
+        for (size_t b = 0; b < n; ++b) {
+            if (isl_label[b] == 0xFFFFFFFFu || awake[isl_label[b]]) continue;
+            isl_rests[b] = 1; ++resting_bodies;
+            if (isl_label[b] == b) ++resting_islands;
+        }
+        if (out) { out->n_islands = isl_count; out->n_island_bodies = isl_nodes; out->n_resting_islands = resting_islands; out->n_resting_bodies = resting_bodies;
+                   out->n_awake_bodies = isl_nodes - resting_bodies; out->reserved0 = 0; }
+        return AVN_OK;
+    }
+    avn_status sleep_get(const avn_sleep_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        if (sleep_timer.size() != bodies.size() || isl_rests.size() != bodies.size()) { error = "sleep_get: call avn_sleep_update first"; return AVN_ERR_STATE; }
+        if (o->sleep_timer) std::copy(sleep_timer.begin(), sleep_timer.end(), o->sleep_timer);
+        if (o->island) std::copy(isl_label.begin(), isl_label.end(), o->island);
+        if (o->island_rests) std::copy(isl_rests.begin(), isl_rests.end(), o->island_rests);
+        return AVN_OK;
+    }
+    avn_status sleep_reset(const uint32_t* ids, size_t n) override {
+        if (sleep_timer.size() != bodies.size()) sleep_timer.assign(bodies.size(), 0.0f);
+        if (!ids || n == 0) { std::fill(sleep_timer.begin(), sleep_timer.end(), 0.0f); return AVN_OK; }
+        for (size_t i = 0; i < n; ++i) if (ids[i] < sleep_timer.size()) sleep_timer[ids[i]] = 0.0f;
         return AVN_OK;
     }
     avn_status timers(avn_timers* t) override { if (!t) return AVN_ERR_BAD_ARG; *t = last_timers; return AVN_OK; }

@@ -46,6 +46,10 @@ avn_status avo_step(avn_world* w) { FWD(step()); }
 avn_status avo_synchronize(avn_world* w) { return w ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_timers_get(avn_world* w, avn_timers* t) { FWD(timers(t)); }
 avn_status avo_diagnostics_get(avn_world* w, avn_diagnostics* d) { FWD(diagnostics(d)); }
+avn_status avo_islands_get(avn_world* w, uint32_t* island_of_body, uint32_t* n_islands) { FWD(islands_get(island_of_body, n_islands)); }
+avn_status avo_sleep_update(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* st) { FWD(sleep_update(p, st)); }
+avn_status avo_sleep_get(avn_world* w, const avn_sleep_out* o) { FWD(sleep_get(o)); }
+avn_status avo_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { FWD(sleep_reset(bodies, n)); }
 avn_status avo_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { FWD(halo_plan_upload(p)); }
 avn_status avo_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { FWD(run_color_pass(pass, color)); }
 avn_status avo_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { FWD(halo_pack(color, peer, out, count)); }
