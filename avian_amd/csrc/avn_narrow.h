@@ -98,15 +98,22 @@ __device__ __forceinline__ uint32_t fid_face(uint32_t c) { return (3u << 30) | c
 template <class T> struct NpPoint { V3<T> anchor1, anchor2; T penetration; uint32_t fid1, fid2; };
 template <class T> struct NpManifold { V3<T> normal; int n; NpPoint<T> pts[AVN_NP_MAX_RAW]; };
 
-template <class T> struct NpEmit {  // conversion context of contact_query.rs:233-252
-    Q4<T> rotation1;
-    V3<T> normal, d12;  // world normal; position1 - position2
+// Where the raw points of a manifold go.  NpArraySink: the NpManifold of the batch query (per-lane array).  k_narrow.hip has an LDS sink.
+template <class T> struct NpArraySink {
     NpManifold<T>* out;
+    V3<T> d12;  // position1 - position2
+    __device__ __forceinline__ int n() const { return out->n; }
+    __device__ __forceinline__ void put(V3<T> anchor1, T penetration, uint32_t f1, uint32_t f2) { out->pts[out->n++] = NpPoint<T>{anchor1, anchor1 + d12, penetration, f1, f2}; }
+};
+template <class T, class Sink> struct NpEmit {  // conversion context of contact_query.rs:233-252
+    Q4<T> rotation1;
+    V3<T> normal;  // world normal
+    Sink* sink;
     __device__ __forceinline__ void push(V3<T> local_p1, T dist, uint32_t f1, uint32_t f2) {
-        if (out->n >= AVN_NP_MAX_RAW) return;
+        if (sink->n() >= AVN_NP_MAX_RAW) return;
         V3<T> point1 = qrot(rotation1, local_p1);
         V3<T> anchor1 = point1 + (normal * dist) * T(0.5);
-        out->pts[out->n++] = NpPoint<T>{anchor1, anchor1 + d12, -dist, f1, f2};
+        sink->put(anchor1, -dist, f1, f2);   // (anchor2 = anchor1 + (position1 - position2): the sink's business)
     }
 };
 // local_n1 -> world normal (normalise, rotate, is_normalized check); false = the manifold is dropped
@@ -221,6 +228,7 @@ template <class T> __device__ __forceinline__ bool closest_points_line2d(V2<T> e
 }
 template <class T> __device__ __forceinline__ bool np_inside(const V2<T>* poly, V2<T> p) {
     T sign = perp2(V2<T>{poly[0].x - poly[3].x, poly[0].y - poly[3].y}, V2<T>{p.x - poly[3].x, p.y - poly[3].y});
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
         T ns = perp2(V2<T>{poly[j + 1].x - poly[j].x, poly[j + 1].y - poly[j].y}, V2<T>{p.x - poly[j].x, p.y - poly[j].y});
         if (sign == T(0)) sign = ns;
@@ -228,11 +236,14 @@ template <class T> __device__ __forceinline__ bool np_inside(const V2<T>* poly, 
     }
     return true;
 }
-template <class T> __device__ void face_face_contacts(const Iso<T>& pos12, const Face<T>& face1, V3<T> sep_axis1, const Face<T>& face2, NpEmit<T>& em) {
+// (every loop has a constant trip count and is unrolled: the faces and their projections are indexed by compile-time constants only and
+//  stay in registers -- as dynamically indexed arrays they lived in scratch memory, which made this function the narrow phase's cost)
+template <class T, class Em> __device__ void face_face_contacts(const Iso<T>& pos12, const Face<T>& face1, V3<T> sep_axis1, const Face<T>& face2, Em& em) {
     V3<T> b0, b1;
     na_orthonormal_basis(sep_axis1, b0, b1);
     V2<T> p1[4], p2[4];
     V3<T> v2_1[4];
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         p1[k] = {na_dot(face1.v[k], b0), na_dot(face1.v[k], b1)};
         v2_1[k] = iso_point(pos12, face2.v[k]);
@@ -241,24 +252,30 @@ template <class T> __device__ void face_face_contacts(const Iso<T>& pos12, const
     {
         V3<T> normal2_1 = na_cross(v2_1[2] - v2_1[1], v2_1[0] - v2_1[1]);
         T denom = na_dot(normal2_1, sep_axis1);
-        if (!(fabs_t(denom) <= Limits<T>::eps))
+        if (!(fabs_t(denom) <= Limits<T>::eps)) {
+#pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (np_inside(p2, p1[i])) {
                     T dist = na_dot(v2_1[0] - face1.v[i], normal2_1) / denom;
                     em.push(face1.v[i], dist, face1.vid[i], face2.fid);
                 }
+        }
     }
     {
         V3<T> normal1 = na_cross(face1.v[2] - face1.v[1], face1.v[0] - face1.v[1]);
         T denom = -na_dot(normal1, sep_axis1);
-        if (!(fabs_t(denom) <= Limits<T>::eps))
+        if (!(fabs_t(denom) <= Limits<T>::eps)) {
+#pragma unroll
             for (int i = 0; i < 4; ++i)
                 if (np_inside(p1, p2[i])) {
                     T dist = na_dot(face1.v[0] - v2_1[i], normal1) / denom;
                     em.push(v2_1[i] - sep_axis1 * dist, dist, face1.fid, face2.vid[i]);
                 }
+        }
     }
+#pragma unroll
     for (int j = 0; j < 4; ++j)
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             T s, t;
             if (!closest_points_line2d(p1[i], p1[(i + 1) & 3], p2[j], p2[(j + 1) & 3], s, t)) continue;
@@ -271,14 +288,19 @@ template <class T> __device__ void face_face_contacts(const Iso<T>& pos12, const
 }
 
 // contact_query::contact_manifolds for one pair (he: cuboid half extents, ball radius in x); false = no manifold
-template <class T>
-__device__ bool contact_manifolds_pair(uint32_t shape1, V3<T> he1, V3<T> position1, Q4<T> rotation1, uint32_t shape2, V3<T> he2, V3<T> position2, Q4<T> rotation2,
-                                       T prediction, NpManifold<T>& out) {
-    out.n = 0;
+// `defer` (optional): the cuboid-cuboid path has a cheap half -- the three SAT sweeps, after which most AABB-overlapping pairs are known to be
+// apart -- and a heavy half (support faces, clipping in the plane, conversion of up to 16 raw points).  With defer != nullptr and
+// *defer == false on entry the function stops after the SAT of a pair that survives it, leaves the separating direction in *axis and sets
+// *defer = true (nothing of `out` is valid); called again with *defer == true it skips the SAT and continues from *axis.  A caller that
+// gathers the survivors of a workgroup into dense waves (k_narrow_phase) runs the heavy half at full lane occupancy; the result is the
+// one-call result bit for bit.
+template <class T, class Sink>
+__device__ bool contact_manifolds_pair_sink(uint32_t shape1, V3<T> he1, V3<T> position1, Q4<T> rotation1, uint32_t shape2, V3<T> he2, V3<T> position2, Q4<T> rotation2,
+                                            T prediction, Sink& sink, V3<T>& normal_out, bool* defer = nullptr, V3<T>* axis = nullptr) {
     Iso<T> isometry1 = make_isometry(position1, rotation1), isometry2 = make_isometry(position2, rotation2);
     Iso<T> pos12 = iso_inv_mul(isometry1, isometry2);
-    NpEmit<T> em;
-    em.rotation1 = rotation1; em.d12 = position1 - position2; em.out = &out;
+    NpEmit<T, Sink> em;
+    em.rotation1 = rotation1; em.sink = &sink;
     const bool ball1 = shape1 == AVN_SHAPE_BALL, ball2 = shape2 == AVN_SHAPE_BALL;
     if (ball1 && ball2) {  // contact_manifold_ball_ball
         T r1 = he1.x, r2 = he2.x;
@@ -315,16 +337,21 @@ __device__ bool contact_manifolds_pair(uint32_t shape1, V3<T> he1, V3<T> positio
         }
     } else {  // contact_manifold_cuboid_cuboid
         Iso<T> pos21 = iso_inverse(pos12);
-        V3<T> d1, d2, d3;
-        T sep1 = sat_normal_oneway(he1, he2, pos12, d1);
-        if (sep1 > prediction) return false;
-        T sep2 = sat_normal_oneway(he2, he1, pos21, d2);
-        if (sep2 > prediction) return false;
-        T sep3 = sat_edge_twoway(he1, he2, pos12, d3);
-        if (sep3 > prediction) return false;
-        V3<T> best = d1;
-        if (sep2 > sep1 && sep2 > sep3) best = iso_vec(pos12, -d2);
-        else if (sep3 > sep1) best = d3;
+        V3<T> best;
+        if (defer && *defer) best = *axis;
+        else {
+            V3<T> d1, d2, d3;
+            T sep1 = sat_normal_oneway(he1, he2, pos12, d1);
+            if (sep1 > prediction) return false;
+            T sep2 = sat_normal_oneway(he2, he1, pos21, d2);
+            if (sep2 > prediction) return false;
+            T sep3 = sat_edge_twoway(he1, he2, pos12, d3);
+            if (sep3 > prediction) return false;
+            best = d1;
+            if (sep2 > sep1 && sep2 > sep3) best = iso_vec(pos12, -d2);
+            else if (sep3 > sep1) best = d3;
+            if (defer) { *defer = true; *axis = best; return false; }
+        }
         V3<T> local_n2 = iso_vec(pos21, -best);
         if (!np_world_normal(rotation1, best, em.normal)) return false;
         Face<T> f1, f2;
@@ -332,8 +359,15 @@ __device__ bool contact_manifolds_pair(uint32_t shape1, V3<T> he1, V3<T> positio
         cuboid_support_face(he2, local_n2, f2);
         face_face_contacts(pos12, f1, best, f2, em);
     }
-    out.normal = em.normal;
-    return out.n > 0;
+    normal_out = em.normal;
+    return sink.n() > 0;
+}
+template <class T>
+__device__ bool contact_manifolds_pair(uint32_t shape1, V3<T> he1, V3<T> position1, Q4<T> rotation1, uint32_t shape2, V3<T> he2, V3<T> position2, Q4<T> rotation2,
+                                       T prediction, NpManifold<T>& out) {
+    out.n = 0;
+    NpArraySink<T> sink{&out, position1 - position2};
+    return contact_manifolds_pair_sink<T, NpArraySink<T>>(shape1, he1, position1, rotation1, shape2, he2, position2, rotation2, prediction, sink, out.normal);
 }
 
 }  // namespace avn

@@ -346,6 +346,7 @@ template <class T> struct World : WorldBase {
         params.length_unit = (T)cfg.length_unit;
         params.restitution_iterations = cfg.restitution_iterations;
         params.match_contacts = cfg.match_contacts;
+        params.np_debug = getenv("AVN_NP_DEBUG") ? (uint32_t)atoi(getenv("AVN_NP_DEBUG")) : 0u;
         // update_contact_softness, reference solver/plugin.rs:326-350
         T dt = params.dt_f64cast, h = params.h_f64cast;
         T max_hz = T(1) / (dt * T(2));

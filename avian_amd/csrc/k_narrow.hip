@@ -64,55 +64,36 @@ template <class T> __device__ __forceinline__ T np_combine(T a, uint32_t ra, T b
     return (a + b) * T(0.5);
 }
 
-// ContactManifold::prune_points: indices of the (up to four) points to keep, in the reference's output order
-template <class T> __device__ int np_prune_points(const NpPt<T>* pts, V3<T> normal, int n, int* keep) {
-    const T MIN_DISTANCE_SQUARED = T(1e-6);
-    V3<T> projected[AVN_NP_MAX_RAW];
-    T pen_sq[AVN_NP_MAX_RAW];
-    for (int i = 0; i < n; ++i) {
-        projected[i] = pts[i].anchor1 - normal * dot(pts[i].anchor1, normal);
-        pen_sq[i] = smax(pts[i].penetration * pts[i].penetration, MIN_DISTANCE_SQUARED);
+// The raw points of ONE pair in LDS: word w of point k of lane l at col[(w * AVN_NP_MAX_RAW + k) * NP_THREADS] with col = base + l -- every
+// lane has its own column, neighbouring lanes neighbouring banks.  6 words per point: anchor1 (as contact_query returns it), penetration,
+// the two feature ids; anchor2 = anchor1 + (position1 - position2) is recomputed where it is needed.
+#define NP_THREADS 128
+#define NP_POINT_WORDS 6
+template <class T> struct NpLdsSink {
+    T* col;
+    int cnt;
+    __device__ __forceinline__ int n() const { return cnt; }
+    __device__ __forceinline__ T& at(int w, int k) const { return col[(size_t)(w * AVN_NP_MAX_RAW + k) * NP_THREADS]; }
+    __device__ __forceinline__ void put(V3<T> a1, T pen, uint32_t f1, uint32_t f2) {
+        at(0, cnt) = a1.x; at(1, cnt) = a1.y; at(2, cnt) = a1.z; at(3, cnt) = pen; at(4, cnt) = bits_to_scalar(f1, T(0)); at(5, cnt) = bits_to_scalar(f2, T(0));
+        ++cnt;
     }
-    int p1 = 0;
-    T value = -Limits<T>::max;
-    for (int i = 0; i < n; ++i) {
-        T v = smax(length_squared(projected[i]), MIN_DISTANCE_SQUARED) * pen_sq[i];
-        if (v > value) { value = v; p1 = i; }
+    __device__ __forceinline__ void get(int k, V3<T>& a1, T& pen, uint32_t& f1, uint32_t& f2) const {
+        a1 = {at(0, k), at(1, k), at(2, k)}; pen = at(3, k); f1 = scalar_to_bits(at(4, k)); f2 = scalar_to_bits(at(5, k));
     }
-    int p2 = -1;
-    T max_distance = -Limits<T>::max;
-    for (int i = 0; i < n; ++i) {
-        if (i == p1) continue;
-        T v = smax(length_squared(projected[i] - projected[p1]), MIN_DISTANCE_SQUARED) * pen_sq[i];
-        if (v > max_distance) { max_distance = v; p2 = i; }
+    __device__ __forceinline__ void move(int dst, int src) const {
+#pragma unroll
+        for (int w = 0; w < NP_POINT_WORDS; ++w) at(w, dst) = at(w, src);
     }
-    int p3 = -1, p4 = -1;
-    T min_value = T(0), max_value = T(0);
-    V3<T> perp = cross(projected[p2] - projected[p1], normal);
-    for (int i = 0; i < n; ++i) {
-        if (i == p1 || i == p2) continue;
-        T v = dot(perp, projected[i] - projected[p1]);
-        if (v < min_value) { min_value = v; p3 = i; }
-        else if (v > max_value) { max_value = v; p4 = i; }
-    }
-    int k = 0;
-    keep[k++] = p1;
-    if (p3 >= 0) keep[k++] = p3;
-    keep[k++] = p2;
-    if (p4 >= 0) keep[k++] = p4;
-    return k;
-}
+};
 
-// DENSE = false: the pairs are active[0 .. n_active), changes are appended to `changes` in arbitrary order (the host sorts them).
-// DENSE = true (device closed loop, k_graph.hip): every row id < n_active with AVN_CP_ROW_USED is a pair; a row's change is left in
-// chg[id] / has[id] (`changes` / `n_changes` reinterpreted), so that a scan over the rows numbers the changes in ascending ContactId.
-template <class T, bool DENSE>
-__global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
-                                                     avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                                                     uint32_t* __restrict__ has) {
-    uint32_t a = blockIdx.x * 64 + threadIdx.x;
-    if (a >= n_active) return;
-    const uint32_t c = DENSE ? a : active[a];
+// One pair.  HEAVY = false: the whole update unless the pair is a cuboid-cuboid one that survives the SAT -- then nothing is written,
+// *deferred = true and *axis holds the separating direction.  HEAVY = true: the deferred pair again, from the top (every input is re-read:
+// nothing was written), with the SAT replaced by *axis.
+template <class T, bool DENSE, bool HEAVY>
+__device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t c,
+                               avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
+                               uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col) {
     uint4 meta = ct.meta[c];
     if (DENSE && !(meta.z & AVN_CP_ROW_USED)) { chg[c] = 0u; has[c] = 0u; return; }
     const uint32_t slot1 = meta.x, slot2 = meta.y;
@@ -163,38 +144,91 @@ __global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct
         const T effective_speculative_margin = delta_secs * length(relative_linear_velocity);
         const T max_contact_distance = smax(effective_speculative_margin, p.contact_tolerance) + collision_margin_sum;
         const bool was_touching = flags & AVN_CP_TOUCHING;
-        // old_manifolds = contacts.manifolds.clone(): only what match_contacts reads
+        // old_manifolds = contacts.manifolds.clone(): only what match_contacts reads (constant indices: registers)
         V3<T> old_a1[AVN_MAX_MANIFOLD_POINTS], old_a2[AVN_MAX_MANIFOLD_POINTS];
         T old_wn[AVN_MAX_MANIFOLD_POINTS], old_wx[AVN_MAX_MANIFOLD_POINTS], old_wy[AVN_MAX_MANIFOLD_POINTS];
         uint2 old_fid[AVN_MAX_MANIFOLD_POINTS];
         const uint32_t old_n = old_nman ? old_pc : 0u;
-        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            old_a1[k] = vzero<T>(); old_a2[k] = vzero<T>(); old_wn[k] = T(0); old_wx[k] = T(0); old_wy[k] = T(0); old_fid[k] = make_uint2(0u, 0u);
             if (k < old_n) {
                 size_t s = (size_t)k * ct.cap + c;
                 Vec4<T> oa = ct.a1[s], ob = ct.a2[s], ow = ct.w[s];
                 old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid[s];
             }
-        NpManifold<T> qm;
-        const bool has = contact_manifolds_pair<T>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, qm);
-        NpPt<T> kept[AVN_NP_MAX_RAW];
+        }
+        // the raw points of the manifold go to this lane's LDS column (NpLdsSink): the only dynamically indexed storage of the update
+        NpLdsSink<T> sink{lds_col, 0};
+        V3<T> normal = vzero<T>();
+        bool defer = HEAVY;
+        const bool has_manifold = p.np_debug == 1u ? false
+            : contact_manifolds_pair_sink<T, NpLdsSink<T>>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
+        if (!HEAVY && defer) { if (p.np_debug == 2u) defer = false; else { *deferred = true; return; } }
+        const V3<T> d12 = x1 - x2;
+        // one raw point -> the ContactPoint being built (system_param.rs:590-640), always from the same expressions
+        auto build = [&](int k, NpPt<T>& pt) {
+            V3<T> ra1; T rpen;
+            sink.get(k, ra1, rpen, pt.fid1, pt.fid2);
+            pt.anchor1 = (ra1 + collider_offset1) - world_com1;
+            pt.anchor2 = ((ra1 + d12) + collider_offset2) - world_com2;
+            pt.penetration = rpen + collision_margin_sum;
+            V3<T> relative_velocity = (relative_linear_velocity + cross(ang_vel2, pt.anchor2)) - cross(ang_vel1, pt.anchor1);
+            pt.normal_speed = dot(relative_velocity, normal);
+            pt.warm_n = T(0); pt.warm_tx = T(0); pt.warm_ty = T(0);
+        };
         int nk = 0;
-        if (has)
-            for (int k = 0; k < qm.n; ++k) {
+        if (has_manifold)
+            for (int k = 0; k < sink.cnt; ++k) {
                 NpPt<T> pt;
-                pt.anchor1 = (qm.pts[k].anchor1 + collider_offset1) - world_com1;
-                pt.anchor2 = (qm.pts[k].anchor2 + collider_offset2) - world_com2;
-                pt.penetration = qm.pts[k].penetration + collision_margin_sum;
-                V3<T> relative_velocity = (relative_linear_velocity + cross(ang_vel2, pt.anchor2)) - cross(ang_vel1, pt.anchor1);
-                pt.normal_speed = dot(relative_velocity, qm.normal);
-                pt.warm_n = T(0); pt.warm_tx = T(0); pt.warm_ty = T(0);
-                pt.fid1 = qm.pts[k].fid1; pt.fid2 = qm.pts[k].fid2;
-                bool keep = -pt.penetration < effective_speculative_margin || (pt.normal_speed * delta_secs - pt.penetration < effective_speculative_margin);
-                if (keep) kept[nk++] = pt;
+                build(k, pt);
+                const bool keep = -pt.penetration < effective_speculative_margin || (pt.normal_speed * delta_secs - pt.penetration < effective_speculative_margin);
+                if (keep) { if (nk != k) sink.move(nk, k); ++nk; }   // compaction in place: nk <= k
             }
-        int order[AVN_MAX_MANIFOLD_POINTS] = {0, 1, 2, 3};
+        int o0 = 0, o1 = 1, o2 = 2, o3 = 3;   // the (up to four) points to keep, in the reference's output order
         n_manifolds = 0; point_count = 0;
         if (nk > 0) {
-            point_count = nk > 4 ? (uint32_t)np_prune_points<T>(kept, qm.normal, nk, order) : (uint32_t)nk;
+            point_count = (uint32_t)nk;
+            if (nk > 4) {   // ContactManifold::prune_points (contact_types/mod.rs:425-520): three passes over the kept points
+                const T MIN_DISTANCE_SQUARED = T(1e-6);
+                auto projected = [&](int i, T& pen_sq) {
+                    V3<T> ra1; T rpen; uint32_t f1, f2;
+                    sink.get(i, ra1, rpen, f1, f2);
+                    const V3<T> a1 = (ra1 + collider_offset1) - world_com1;
+                    const T pen = rpen + collision_margin_sum;
+                    pen_sq = smax(pen * pen, MIN_DISTANCE_SQUARED);
+                    return a1 - normal * dot(a1, normal);
+                };
+                int p1 = 0; T value = -Limits<T>::max; V3<T> proj1 = vzero<T>();
+                for (int i = 0; i < nk; ++i) {
+                    T ps; const V3<T> pr = projected(i, ps);
+                    const T v = smax(length_squared(pr), MIN_DISTANCE_SQUARED) * ps;
+                    if (v > value) { value = v; p1 = i; proj1 = pr; }
+                }
+                int p2 = -1; T max_distance = -Limits<T>::max; V3<T> proj2 = vzero<T>();
+                for (int i = 0; i < nk; ++i) {
+                    if (i == p1) continue;
+                    T ps; const V3<T> pr = projected(i, ps);
+                    const T v = smax(length_squared(pr - proj1), MIN_DISTANCE_SQUARED) * ps;
+                    if (v > max_distance) { max_distance = v; p2 = i; proj2 = pr; }
+                }
+                int p3 = -1, p4 = -1; T min_value = T(0), max_value = T(0);
+                const V3<T> perp = cross(proj2 - proj1, normal);
+                for (int i = 0; i < nk; ++i) {
+                    if (i == p1 || i == p2) continue;
+                    T ps; const V3<T> pr = projected(i, ps);
+                    const T v = dot(perp, pr - proj1);
+                    if (v < min_value) { min_value = v; p3 = i; }
+                    else if (v > max_value) { max_value = v; p4 = i; }
+                }
+                int k = 1;          // output order: p1, [p3], p2, [p4]
+                o0 = p1;
+                if (p3 >= 0) { o1 = p3; k = 2; }
+                if (k == 1) o1 = p2; else o2 = p2;
+                ++k;
+                if (p4 >= 0) { if (k == 2) o2 = p4; else o3 = p4; ++k; }
+                point_count = (uint32_t)k;
+            }
             n_manifolds = 1;
         }
         const bool touching = n_manifolds != 0;
@@ -202,21 +236,23 @@ __global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct
         if (touching) {
             const T thr = T(0.1) * p.length_unit;
             const T thr2 = thr * thr;
-            ct.n[c] = make4<T>(qm.normal, friction);
+            ct.n[c] = make4<T>(normal, friction);
             ct.tv[c] = make4<T>(T(0), T(0), T(0), restitution);
             for (uint32_t k = 0; k < point_count; ++k) {
-                NpPt<T> pt = kept[order[k]];
+                NpPt<T> pt;
+                build(k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3)), pt);
                 if (p.match_contacts && old_n) {  // ContactManifold::match_contacts
-                    for (uint32_t j = 0; j < old_n; ++j) {
-                        if ((pt.fid1 == old_fid[j].x && pt.fid2 == old_fid[j].y) || (pt.fid2 == old_fid[j].x && pt.fid1 == old_fid[j].y)) {
-                            pt.warm_n = old_wn[j]; pt.warm_tx = old_wx[j]; pt.warm_ty = old_wy[j];
-                            break;
-                        }
-                        const bool unknown = pt.fid1 == 0u || pt.fid2 == 0u;
-                        if ((unknown && (length_squared(pt.anchor1 - old_a1[j]) < thr2 && length_squared(pt.anchor2 - old_a2[j]) < thr2)) ||
-                            (length_squared(pt.anchor1 - old_a2[j]) < thr2 && length_squared(pt.anchor2 - old_a1[j]) < thr2)) {
-                            pt.warm_n = old_wn[j]; pt.warm_tx = old_wx[j]; pt.warm_ty = old_wy[j];
-                            break;
+                    bool matched = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < AVN_MAX_MANIFOLD_POINTS; ++j) {
+                        if (j < old_n && !matched) {
+                            const bool unknown = pt.fid1 == 0u || pt.fid2 == 0u;
+                            if (((pt.fid1 == old_fid[j].x && pt.fid2 == old_fid[j].y) || (pt.fid2 == old_fid[j].x && pt.fid1 == old_fid[j].y)) ||
+                                (unknown && (length_squared(pt.anchor1 - old_a1[j]) < thr2 && length_squared(pt.anchor2 - old_a2[j]) < thr2)) ||
+                                (length_squared(pt.anchor1 - old_a2[j]) < thr2 && length_squared(pt.anchor2 - old_a1[j]) < thr2)) {
+                                pt.warm_n = old_wn[j]; pt.warm_tx = old_wx[j]; pt.warm_ty = old_wy[j];
+                                matched = true;
+                            }
                         }
                     }
                 }
@@ -246,6 +282,43 @@ __global__ __launch_bounds__(64) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct
     const uint32_t kept_flags = flags & ~(uint32_t)(AVN_CP_STARTED_TOUCHING | AVN_CP_STOPPED_TOUCHING | AVN_CP_STARTED_GENERATING_CONSTRAINTS);
     ct.meta[c] = make_uint4(slot1, slot2, kept_flags, n_manifolds | (point_count << 8));
     ct.dcount[c] = dcount;
+}
+
+// DENSE = false: the pairs are active[0 .. n_active), changes are appended to `changes` in arbitrary order (the host sorts them).
+// DENSE = true (device closed loop, k_graph.hip): every row id < n_active with AVN_CP_ROW_USED is a pair; a row's change is left in
+// chg[id] / has[id] (`changes` / `n_changes` reinterpreted), so that a scan over the rows numbers the changes in ascending ContactId.
+//
+// Two passes inside the workgroup.  Pass 1, one lane per pair: everything that is cheap -- AABB / layer tests, ball paths, and for two
+// cuboids the SAT, after which ~60 % of a settled pile's AABB-overlapping pairs are done (apart).  The survivors' (row, axis) go to an LDS
+// list; pass 2 hands them to the first lanes of the workgroup, so the heavy half (clipping, point conversion, pruning, matching; its raw points live in
+// an LDS column per lane) runs in waves that are full instead of in every wave at 40 % occupancy.
+template <class T, bool DENSE>
+__global__ __launch_bounds__(NP_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
+                                                             avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
+                                                             uint32_t* __restrict__ has) {
+    __shared__ uint32_t s_row[NP_THREADS];
+    __shared__ T s_axis[3 * NP_THREADS];
+    __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];   // f32: 48 KB, f64: 96 KB
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const uint32_t a = blockIdx.x * NP_THREADS + threadIdx.x;
+    if (a < n_active) {
+        const uint32_t c = DENSE ? a : active[a];
+        bool deferred = false;
+        V3<T> axis = vzero<T>();
+        np_update_pair<T, DENSE, false>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
+        if (deferred) {
+            const uint32_t k = atomicAdd(&s_n, 1u);
+            s_row[k] = c; s_axis[3 * k] = axis.x; s_axis[3 * k + 1] = axis.y; s_axis[3 * k + 2] = axis.z;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < s_n) {
+        V3<T> axis{s_axis[3 * threadIdx.x], s_axis[3 * threadIdx.x + 1], s_axis[3 * threadIdx.x + 2]};
+        bool deferred = false;
+        np_update_pair<T, DENSE, true>(w, bp, ct, p, s_row[threadIdx.x], changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
+    }
 }
 
 template <class T>
@@ -329,12 +402,12 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
     (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
-    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + 63) / 64), dim3(64), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr);
+    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t st) {
     (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
-    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + 63) / 64), dim3(64), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has);
+    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has);
 }
 template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);
