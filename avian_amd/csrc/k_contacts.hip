@@ -349,10 +349,6 @@ __device__ __forceinline__ void solve_core(const DW<T>& w, const StepParams<T>& 
         uint32_t s = k * S + m;
         pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
     }
-    // Compiler fence: without it the early exit below is hoisted above the point loads (a full memory round trip on `h1` alone) and the
-    // point loads are scheduled after the wait on the body indices (another one): three dependent round trips instead of the two the
-    // data flow needs.  Nothing may sink below this line, so every level-1 load is in flight before the first wait.
-    asm volatile("" ::: "memory");
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
@@ -466,32 +462,12 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
     b.om = sub_lo_add_hi(b.om, smul(b.I, cross(anchors, p)));
 }
 
-// (Measured, cfg2, 40 steps, two runs each: no fences, no prefetch 2468 substeps/s | fences only 2420 | prefetch only 2359 | both 2487.
-//  The launch stays ~8.5 us either way: its memory skeleton alone -- AVN_BIAS_SKELETON, tools/measure_floor.py -- costs 5.9 us, 0.57 of
-//  the HBM peak for a 27 MB launch, and the remaining 2.6 us are the in-lane impulse chain at less than one wave per SIMD.)
-// L2 prefetch of the NEXT colour launch's constraint records (pf = the manifold this lane's position maps to there, or PF_NONE): one dword
-// load per 16-byte record pulls the cache lines; the destination register is never read.  Issued once this lane's own loads have all
-// returned (the asm's input operand is the last gathered word), i.e. while the wave is in its arithmetic and the memory system idles.
-#define PF_NONE 0xFFFFFFFFu
-// `sink` is ONE register that every prefetch load targets and that stays allocated until the end of the kernel (the compiler does not know
-// the asm is a load still in flight: a register it reused would be overwritten when the data arrives).
-__device__ __forceinline__ void prefetch_dword(const void* p, uint32_t& sink) {
-    asm volatile("global_load_dword %0, %1, off" : "+v"(sink) : "v"(p));
-}
-__device__ __forceinline__ void prefetch_records(const DW<float>& w, uint32_t pf, uint32_t& sink) {
-    if (pf == PF_NONE) return;
-    prefetch_dword(&w.m_bodies[pf], sink);
-    prefetch_dword(&w.c_h1[pf], sink); prefetch_dword(&w.m_n[pf], sink); prefetch_dword(&w.m_tv[pf], sink);
-    const uint32_t S = w.m_stride;
-#pragma unroll
-    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        const uint32_t s = k * S + pf;
-        prefetch_dword(&w.c_pa[s], sink); prefetch_dword(&w.c_pb[s], sink); prefetch_dword(&w.c_pc[s], sink); prefetch_dword(&w.c_pd[s], sink);
-    }
-}
-
+// (Tried and rejected, round 2 -- DESIGN.md section 4.1: compiler fences that put every level-1 load in flight before the first wait, and
+//  an L2 prefetch of the NEXT colour launch's records issued during the impulse chain.  cfg2, two runs each on one box: neither 2 468
+//  substeps/s | fences only 2 420 | prefetch only 2 359 | both 2 487 -- and the PMC pass showed the prefetch as 13 MB of EXTRA fetch traffic
+//  per launch (42.3 MB against 29.2 MB): the lines do not survive in L2 until the next launch.  +0.8 % for +45 % traffic: removed.)
 template <bool USE_BIAS, int STRIDE, bool COH = false>
-__device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2, uint32_t pf = PF_NONE) {
+__device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
     // memory levels exactly as solve_one: (headers + point records) | body gathers
     Vec4<T> h1 = w.c_h1[m];
@@ -504,10 +480,6 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
         uint32_t s = k * S + m;
         pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
     }
-    // Compiler fence: without it the early exit below is hoisted above the point loads (a full memory round trip on `h1` alone) and the
-    // point loads are scheduled after the wait on the body indices (another one): three dependent round trips instead of the two the
-    // data flow needs.  Nothing may sink below this line, so every level-1 load is in flight before the first wait.
-    asm volatile("" ::: "memory");
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
@@ -518,15 +490,6 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
     bp.v = pair3(b1.v, b2.v); bp.om = pair3(b1.om, b2.om); bp.inv_mass = pair3(b1.inv_mass, b2.inv_mass);
     bp.I = Sym3<F2>{F2(b1.I.m00, b2.I.m00), F2(b1.I.m01, b2.I.m01), F2(b1.I.m02, b2.I.m02), F2(b1.I.m11, b2.I.m11), F2(b1.I.m12, b2.I.m12), F2(b1.I.m22, b2.I.m22)};
     Q4<F2> dq{F2(b1.dq.x, b2.dq.x), F2(b1.dq.y, b2.dq.y), F2(b1.dq.z, b2.dq.z), F2(b1.dq.w, b2.dq.w)};
-    uint32_t sink = 0;
-    if (STRIDE == 2 && !COH) {
-        // every load of this lane has to be back before the prefetches are issued (loads return in order and share one counter: a later
-        // wait on an own value would otherwise wait for the prefetches too): consume one word of every gather and of the last records
-        asm volatile("" :: "v"(b1.v.x), "v"(b1.om.x), "v"(b1.dp.x), "v"(b1.dq.x), "v"(b1.inv_mass.x), "v"(b1.I.m00), "v"(b1.I.m22),
-                           "v"(b2.v.x), "v"(b2.om.x), "v"(b2.dp.x), "v"(b2.dq.x), "v"(b2.inv_mass.x), "v"(b2.I.m00), "v"(b2.I.m22),
-                           "v"(pa[3].x), "v"(pb[3].x), "v"(pc[3].x), "v"(pd[3].x), "v"(h2.x), "v"(h0.x));
-        prefetch_records(w, pf, sink);
-    }
     V3<T> normal = xyz<T>(h0);
     T friction = h0.w;
     SoftCoef<T> soft = (cm & AVN_CM_SOFT_ND) ? p.soft_non_dynamic : p.soft_dynamic;
@@ -599,13 +562,12 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
     b1.v = lo3(bp.v); b1.om = lo3(bp.om); b2.v = hi3(bp.v); b2.om = hi3(bp.om);
     store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
     store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
-    if (STRIDE == 2 && !COH) asm volatile("" :: "v"(sink));   // (keeps the prefetch target register out of the allocator's hands until here)
 }
 template <class T, bool USE_BIAS, int STRIDE, bool COH = false> struct SolveDispatch {
-    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2, uint32_t = 0xFFFFFFFFu) { solve_core<T, USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
+    static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) { solve_core<T, USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
 };
 template <bool USE_BIAS, int STRIDE, bool COH> struct SolveDispatch<float, USE_BIAS, STRIDE, COH> {
-    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2, uint32_t pf = PF_NONE) { solve_core_packed<USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2, pf); }
+    static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) { solve_core_packed<USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
 };
 
 template <class T, int STRIDE, bool COH = false>
@@ -659,7 +621,6 @@ __device__ __forceinline__ void skeleton_core(const DW<T>& w, uint32_t m, const 
         uint32_t s = k * S + m;
         pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
     }
-    asm volatile("" ::: "memory");
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
@@ -683,14 +644,13 @@ __device__ __forceinline__ void skeleton_core(const DW<T>& w, uint32_t m, const 
 
 enum { PASS_WARM = 0, PASS_BIAS = 1, PASS_RELAX = 2, PASS_RESTITUTION = 3, PASS_SKELETON = 5 };
 // one manifold of a pass against the world's HBM body arrays
-template <class T, int PASS, bool COH = false> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m, uint32_t pf = 0xFFFFFFFFu) {
+template <class T, int PASS, bool COH = false> __device__ __forceinline__ void pass_one(const DW<T>& w, const StepParams<T>& p, uint32_t m) {
     const int2 b = w.m_bodies[m];   // (a level-1 load like the constraint records: the body gathers depend on it)
-    asm volatile("" ::: "memory");  // issued FIRST: loads return in order, and the gathers wait for this one only
     const BodyView<T> bv = global_bodies(w);
     if (PASS == PASS_WARM) warm_core<T, 2>(w, p, m, bv, b.x, b.y);   // (manifold-centric warm start of one colour: level-2 sharding exchanges after every colour)
     else if (PASS == PASS_SKELETON) skeleton_core<T, 2>(w, m, bv, b.x, b.y);
-    else if (PASS == PASS_BIAS) SolveDispatch<T, true, 2, COH>::run(w, p, m, bv, b.x, b.y, pf);
-    else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2, COH>::run(w, p, m, bv, b.x, b.y, pf);
+    else if (PASS == PASS_BIAS) SolveDispatch<T, true, 2, COH>::run(w, p, m, bv, b.x, b.y);
+    else if (PASS == PASS_RELAX) SolveDispatch<T, false, 2, COH>::run(w, p, m, bv, b.x, b.y);
     else restitution_core<T, 2, COH>(w, p, m, bv, b.x, b.y);
 }
 
@@ -702,7 +662,7 @@ template <class T, int PASS, bool COH = false> __device__ __forceinline__ void p
 // One colour: manifolds [offsets[c], offsets[c+1]) read from device memory so that a captured graph stays
 // valid while the colour populations drift; the grid is a multiple of 8 blocks and remapped per XCD.
 template <class T, int PASS>
-__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepParams<T> p, uint32_t color, uint32_t arg_base, uint32_t arg_end, uint32_t pf_base, uint32_t pf_end) {
+__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepParams<T> p, uint32_t color, uint32_t arg_base, uint32_t arg_end) {
     // arg_end != 0: the colour range travels in the kernel arguments (one dependent scalar load less in a latency-bound
     // launch; the host re-captures the graph when the ranges change) -- used for host-uploaded manifold sets, which are
     // static between uploads.  arg_end == 0: read the live range from device memory (handle mode: colours drift every step).
@@ -716,15 +676,7 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass(DW<T> w, StepPar
     const uint32_t blk = (blockIdx.x & 7u) * per + row;
     uint32_t m = base + blk * CONTACT_THREADS + threadIdx.x;
     if (m >= end) return;
-    // the next launch of this pass cuts its colour into eighths the same way: tile (xcd, row) of that colour is solved on this XCD, whose
-    // L2 is the one to warm
-    uint32_t pf = 0xFFFFFFFFu;
-    if (pf_end > pf_base) {
-        const uint32_t tiles2 = (pf_end - pf_base + CONTACT_THREADS - 1u) / CONTACT_THREADS, per2 = (tiles2 + 7u) >> 3;
-        const uint32_t m2 = pf_base + ((blockIdx.x & 7u) * per2 + row) * CONTACT_THREADS + threadIdx.x;
-        if (row < per2 && m2 < pf_end) pf = m2;
-    }
-    pass_one<T, PASS>(w, p, m, pf);
+    pass_one<T, PASS>(w, p, m);
 }
 // The overflow colour: the reference solves it strictly serially in manifold_handles order (solver/plugin.rs:461-467).
 // Only the relative order of manifolds that SHARE A BODY can change a result, so the host turns the list into a level
@@ -862,16 +814,11 @@ template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const S
         hipLaunchKernelGGL((k_overflow_pass<T, PASS>), dim3(ovf.n_components), dim3(OVERFLOW_THREADS), 0, s, w, p, ovf.comp_level_begin, ovf.level_offsets, ovf.order);
         ++launches;
     }
-    static const bool prefetch = getenv("AVN_COLOR_PREFETCH") == nullptr || getenv("AVN_COLOR_PREFETCH")[0] != '0';
     for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c)
         if (grid_blocks[c]) {
             uint32_t b = arg_offsets ? arg_offsets[c] : 0u, e = arg_offsets ? arg_offsets[c + 1] : 0u;
             if (arg_offsets && e == b) continue;  // (a captured range is exact: an empty colour needs no launch)
-            uint32_t pb = 0, pe = 0;              // the next non-empty colour of this pass (static ranges only)
-            if (arg_offsets && prefetch && (PASS == PASS_BIAS || PASS == PASS_RELAX))
-                for (uint32_t c2 = c + 1; c2 < AVN_COLOR_OVERFLOW_INDEX; ++c2)
-                    if (grid_blocks[c2] && arg_offsets[c2 + 1] > arg_offsets[c2]) { pb = arg_offsets[c2]; pe = arg_offsets[c2 + 1]; break; }
-            hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e, pb, pe);
+            hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e);
             ++launches;
         }
     return launches;

@@ -1,15 +1,17 @@
 #!/bin/bash
-# The round's measurement batch (run on the GPU box from the repo root): PMC traffic, the bench line, the rocprofv3 kernel
-# summaries of the bench and of the reference scenes, the reference-scene comparison, and an N = 2 smoke of the bench's
-# multi-rank path on one device.  Everything lands in gpurun_out/final/; copy what is judged into profiles/.
+# The round's measurement batch (run on the GPU box from the repo root): the bench line (with its in-run PMC traffic pass), rocprofv3
+# kernel summaries of the bench, of the closed loop, of cfg3 and cfg5 and of the reference's own scenes, the colour pass against its
+# memory skeleton, the other configurations' step times, the reference-scene comparison, and smokes of the multi-rank paths on one
+# device.  Everything lands in gpurun_out/final/; copy what is judged into profiles/ (tools/collect_profiles.sh).
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/final
-mkdir -p $O
+rm -rf $O; mkdir -p $O
 export TMPDIR=/tmp
 cd $R
-timeout 400 python tools/pmc_traffic.py $O/pmc_traffic.json > $O/pmc.log 2>&1
-cp $O/pmc_traffic.json $R/profiles/r01_pmc_traffic.json 2>/dev/null      # bench.py reads `traffic` from here
+timeout 900 python bench.py > $O/bench_cfg2.json 2> $O/bench.err
+tail -c 400 $O/bench_cfg2.json; echo
+cp $R/gpurun_out/bench_pmc_traffic.json $O/pmc_traffic.json 2>/dev/null
 for c in fetch write; do f=$(find $R/gpurun_out/pmc_$c -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python - "$f" "$O/pmc_${c}_size_per_kernel.csv" <<'PY'
 import csv, sys
 from collections import defaultdict
@@ -20,16 +22,39 @@ w = csv.writer(open(sys.argv[2], "w")); w.writerow(["kernel", "counter", "launch
 for (k, c), (s, n) in sorted(acc.items()): w.writerow([k, c, n, round(s / n, 3)])
 PY
 done
-timeout 600 python bench.py > $O/bench_cfg2.json 2> $O/bench.err
-tail -c 600 $O/bench_cfg2.json
-(cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_bench -o b -- python $R/bench.py --no-cpu-baseline --no-pcie --no-closed-loop > $O/bench_under_rocprof.json 2> $O/prof_bench.err)
-cp $(find $O/prof_bench -name "*kernel_stats.csv" | head -1) $O/kernel_stats_cfg2.csv
-for s in many large; do
-  (cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$s -o p -- python $R/tools/profile_reference_scene.py $s > $O/prof_$s.log 2>&1)
-  cp $(find $O/prof_$s -name "*kernel_stats.csv" | head -1) $O/kernel_stats_scene_$s.csv
-done
-find $O -name "*kernel_trace.csv" -delete
-timeout 300 python tools/bench_reference_scenes.py 300 4 $O/reference_scenes.json > $O/reference_scenes.log 2>&1; tail -2 $O/reference_scenes.log
-AVN_BENCH_SINGLE_DEVICE=1 AVN_BENCH_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_single_device.json 2> $O/bench_n2.err; tail -c 400 $O/bench_n2_single_device.json
-rm -rf $O/prof_bench $O/prof_many $O/prof_large
+rm -rf $R/gpurun_out/pmc_fetch $R/gpurun_out/pmc_write
+prof() {  # prof <tag> <cmd...>: rocprofv3 kernel-trace + stats, keep the stats csv only
+  tag=$1; shift
+  (cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -o p -- "$@" > $O/prof_$tag.log 2>&1)
+  cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$tag.csv 2>/dev/null
+}
+prof cfg2 python $R/bench.py --no-cpu-baseline --no-pcie --no-closed-loop --no-traffic --no-iters8
+tail -1 $O/prof_cfg2.log > $O/bench_under_rocprof.json
+prof cfg2_closed_loop python $R/tools/time_closed_loop.py 50 40 50 120
+f=$(find $O/prof_cfg2_closed_loop -name "*kernel_trace.csv" | head -1)
+python tools/closed_loop_breakdown.py $f 4 40 > $O/closed_loop_breakdown.txt 2>&1
+python - "$f" >> $O/closed_loop_breakdown.txt <<'PY'
+import collections, csv, sys
+rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
+st = [i for i, r in enumerate(rows) if "k_update_aabb" in r["Kernel_Name"]]
+for a, b in ((4, 24), (24, 44), (100, 120)):
+    agg = collections.defaultdict(lambda: [0, 0])
+    for r in rows[st[a]:st[b] if b < len(st) else len(rows)]:
+        k = r["Kernel_Name"].split("(")[0].replace("void avn::", "").replace("avn::", "")
+        agg[k][0] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"]); agg[k][1] += 1
+    n = b - a
+    print(f"\n== steps {a}..{b - 1}: kernel sum {sum(v[0] for v in agg.values()) / n / 1e6:.3f} ms/step")
+    for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])[:16]:
+        print(f"{v[0] / n / 1e3:9.1f} us/step {v[1] / n:7.1f} calls/step {v[0] / v[1] / 1e3:8.1f} us avg  {k[:100]}")
+PY
+prof cfg3 python $R/tools/profile_config.py cfg3 20
+prof cfg5 python $R/tools/profile_config.py cfg5 8
+for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
+for t in cfg2 cfg2_closed_loop cfg3 cfg5 scene_many scene_large; do rm -rf $O/prof_$t; done
+timeout 200 python tools/measure_floor.py > $O/color_pass_floor.json 2> $O/floor.err; tail -c 300 $O/color_pass_floor.json; echo
+timeout 400 python tools/time_configs.py $O/other_configs.json > $O/time_configs.log 2>&1
+timeout 400 python tools/bench_reference_scenes.py 300 4 $O/reference_scenes.json > $O/reference_scenes.log 2>&1; tail -2 $O/reference_scenes.log
+AVN_BENCH_SINGLE_DEVICE=1 AVN_BENCH_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_single_device.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_single_device.json; echo
+timeout 200 python tools/level2_multi_gpu.py --steps 10 2> $O/level2.err | grep '^{' > $O/level2_world1.json; tail -c 300 $O/level2_world1.json; echo
 ls -la $O
