@@ -555,6 +555,12 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     const bool has_candidates = valid && end_i > i + 1u;
     if (!has_candidates) { const T inf = Limits<T>::max * T(2); me = make4<T>(inf, -inf, inf, -inf); }
     const uint32_t my_flags = valid ? s_flags[i] : 0u;
+    if (EMIT) {
+        // the emit pass repeats the sweep only where the count pass found something: a wave whose 64 (interval, quarter) slots are all
+        // empty has nothing to write (a settled scene finds a few hundred new pairs among 4 x 10^5 slots)
+        const uint32_t mine = (valid && !(my_flags & AVN_IV_LONG)) ? counts[i * SW_WAVES + wv] : 0u;
+        if (!__any(mine != 0u)) return;   // wave-uniform; the kernel has no workgroup barrier
+    }
     l_info[wv][lane] = valid ? s_info[i] : make_uint4(0, 0, 0, 0);
     l_flags[wv][lane] = my_flags;
     l_cnt[wv][lane] = (EMIT && valid) ? offsets[i * SW_WAVES + wv] : 0u;
