@@ -193,12 +193,12 @@ class avn_sleep_params(C.Structure):
 
 
 class avn_sleep_stats(C.Structure):
-    _fields_ = [("n_islands", C.c_uint32), ("n_island_bodies", C.c_uint32), ("n_resting_islands", C.c_uint32), ("n_resting_bodies", C.c_uint32),
-                ("n_awake_bodies", C.c_uint32), ("reserved0", C.c_uint32)]
+    _fields_ = [("n_islands", C.c_uint32), ("n_island_bodies", C.c_uint32), ("n_sleeping_bodies", C.c_uint32), ("n_awake_bodies", C.c_uint32),
+                ("n_resting_islands", C.c_uint32), ("n_resting_bodies", C.c_uint32), ("n_waking_islands", C.c_uint32), ("n_waking_bodies", C.c_uint32)]
 
 
 class avn_sleep_out(C.Structure):
-    _fields_ = [("sleep_timer", vp), ("island", vp), ("island_rests", vp)]
+    _fields_ = [("sleep_timer", vp), ("island", vp), ("island_rests", vp), ("island_wakes", vp)]
 
 
 class avn_halo_plan(C.Structure):
@@ -685,8 +685,8 @@ class World:
 
     def sleep_get(self):
         n = self.n_bodies
-        out = dict(sleep_timer=np.zeros(n, np.float32), island=np.zeros(n, np.uint32), island_rests=np.zeros(n, np.uint8))
-        o = avn_sleep_out(_ptr(out["sleep_timer"]), _ptr(out["island"]), _ptr(out["island_rests"]))
+        out = dict(sleep_timer=np.zeros(n, np.float32), island=np.zeros(n, np.uint32), island_rests=np.zeros(n, np.uint8), island_wakes=np.zeros(n, np.uint8))
+        o = avn_sleep_out(_ptr(out["sleep_timer"]), _ptr(out["island"]), _ptr(out["island_rests"]), _ptr(out["island_wakes"]))
         self._check(self.lib.fn("sleep_get")(self.handle, C.byref(o)))
         return out
 

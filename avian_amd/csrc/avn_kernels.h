@@ -224,8 +224,8 @@ template <class T> void launch_pack_bodies(const DW<T>&, const BodyStage<T>&, hi
 // islands and sleeping (k_islands.hip)
 template <class T> struct SleepParams { T length_unit_squared, lin_threshold_squared, ang_threshold_squared; float delta_secs, time_to_sleep; };
 template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t);
-template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests,
-                                            uint32_t* ctr /* [2] resting islands, [3] resting bodies */, hipStream_t);
+template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,
+                                            uint32_t* ctr /* [2] resting islands, [3] resting bodies, [4] waking islands, [5] their sleeping bodies, [6] sleeping bodies */, hipStream_t);
 void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32_t n_bodies, hipStream_t);
 // level-2 sharding: (SolverBody linear | angular velocity records) of a list of bodies <-> a contiguous buffer of 2 records per body
 template <class T> void launch_halo_pack(const DW<T>&, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t);

@@ -2498,7 +2498,7 @@ template <class T> struct World : WorldBase {
         return AVN_OK;
     }
     // ---- islands and sleeping (include/avian_mi355x.h: avn_islands_get / avn_sleep_update; k_islands.hip) --------------------------------
-    DevBuf b_isl_parent, b_isl_label, b_isl_ctr, b_sleep_timer, b_isl_awake, b_isl_rests;
+    DevBuf b_isl_parent, b_isl_label, b_isl_ctr, b_sleep_timer, b_isl_awake, b_isl_rests, b_isl_wakes;
     uint32_t sleep_n = 0;       // body count the timers belong to (a different count restarts them)
     bool islands_fresh = false; // labels on the device describe the current constraint graph
     avn_status island_buffers() {
@@ -2506,6 +2506,7 @@ template <class T> struct World : WorldBase {
         hipError_t err;
         for (DevBuf* b : {&b_isl_parent, &b_isl_label, &b_isl_awake}) { b->ensure(n * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; } }
         b_isl_rests.ensure(n, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_isl_wakes.ensure(n, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         b_isl_ctr.ensure(64, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         const bool grown = b_sleep_timer.ensure(n * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         if (grown || sleep_n != dw.n_bodies) { HIPCHK(hipMemsetAsync(b_sleep_timer.p, 0, n * 4, stream)); sleep_n = dw.n_bodies; }
@@ -2541,15 +2542,15 @@ template <class T> struct World : WorldBase {
         k.ang_threshold_squared = (T)(sp->angular_threshold * std::fabs(sp->angular_threshold));
         k.delta_secs = sp->delta_secs; k.time_to_sleep = sp->time_to_sleep;
         HIPCHK(hipMemsetAsync(b_isl_awake.p, 0, (size_t)std::max<uint32_t>(dw.n_bodies, 1) * 4, stream));
-        launch_sleep_update<T>(dw, k, b_isl_label.as<uint32_t>(), b_sleep_timer.as<float>(), b_isl_awake.as<uint32_t>(), b_isl_rests.as<uint8_t>(), b_isl_ctr.as<uint32_t>(), stream);
+        launch_sleep_update<T>(dw, k, b_isl_label.as<uint32_t>(), b_sleep_timer.as<float>(), b_isl_awake.as<uint32_t>(), b_isl_rests.as<uint8_t>(), b_isl_wakes.as<uint8_t>(), b_isl_ctr.as<uint32_t>(), stream);
         launches += 2;
         HIPCHK(hipGetLastError());
         if (out) {
-            uint32_t ctr[4] = {0, 0, 0, 0};
-            HIPCHK(hipMemcpyAsync(ctr, b_isl_ctr.p, 16, hipMemcpyDeviceToHost, stream));
+            uint32_t ctr[8] = {0};
+            HIPCHK(hipMemcpyAsync(ctr, b_isl_ctr.p, 32, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipStreamSynchronize(stream));
-            out->n_islands = ctr[0]; out->n_island_bodies = ctr[1]; out->n_resting_islands = ctr[2]; out->n_resting_bodies = ctr[3];
-            out->n_awake_bodies = ctr[1] - ctr[3]; out->reserved0 = 0;
+            out->n_islands = ctr[0]; out->n_island_bodies = ctr[1]; out->n_sleeping_bodies = ctr[6]; out->n_awake_bodies = ctr[1] - ctr[6];
+            out->n_resting_islands = ctr[2]; out->n_resting_bodies = ctr[3]; out->n_waking_islands = ctr[4]; out->n_waking_bodies = ctr[5];
         }
         return AVN_OK;
     }
@@ -2562,6 +2563,7 @@ template <class T> struct World : WorldBase {
         if (o->sleep_timer) HIPCHK(hipMemcpyAsync(o->sleep_timer, b_sleep_timer.p, n * 4, hipMemcpyDeviceToHost, stream));
         if (o->island) HIPCHK(hipMemcpyAsync(o->island, b_isl_label.p, n * 4, hipMemcpyDeviceToHost, stream));
         if (o->island_rests) HIPCHK(hipMemcpyAsync(o->island_rests, b_isl_rests.p, n, hipMemcpyDeviceToHost, stream));
+        if (o->island_wakes) HIPCHK(hipMemcpyAsync(o->island_wakes, b_isl_wakes.p, n, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }

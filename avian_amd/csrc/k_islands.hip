@@ -35,6 +35,9 @@ __device__ __forceinline__ void cc_union(uint32_t* L, uint32_t a, uint32_t b) {
     }
 }
 
+// a body with a BodyIslandNode (islands/mod.rs:96-140): dynamic or kinematic, not disabled; sleeping bodies keep theirs
+__device__ __forceinline__ bool island_node(uint32_t bmeta) { return meta_rb_type(bmeta) != AVN_RB_STATIC && !(meta_flags(bmeta) & AVN_BODY_DISABLED); }
+
 template <class T>
 __global__ __launch_bounds__(256) void k_cc_init(DW<T> w, uint32_t* __restrict__ L) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
@@ -46,7 +49,7 @@ __global__ __launch_bounds__(256) void k_cc_edges(DW<T> w, const int2* __restric
     if (i >= n) return;
     const int2 e = edges[i];
     if (e.x < 0 || e.y < 0 || (uint32_t)e.x >= w.n_bodies || (uint32_t)e.y >= w.n_bodies || e.x == e.y) return;
-    if (meta_rb_type(w.bmeta[e.x]) == AVN_RB_STATIC || meta_rb_type(w.bmeta[e.y]) == AVN_RB_STATIC) return;
+    if (!island_node(w.bmeta[e.x]) || !island_node(w.bmeta[e.y])) return;
     cc_union(L, (uint32_t)e.x, (uint32_t)e.y);
 }
 // labels out (lowest body index of the island, PG_NONE for static bodies) + ctr[0] = islands, ctr[1] = island bodies
@@ -55,7 +58,7 @@ __global__ __launch_bounds__(256) void k_cc_finish(DW<T> w, uint32_t* __restrict
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     bool node = false, root = false;
     if (b < w.n_bodies) {
-        node = meta_rb_type(w.bmeta[b]) != AVN_RB_STATIC;
+        node = island_node(w.bmeta[b]);
         uint32_t r = 0xFFFFFFFFu;
         if (node) { r = cc_find(L, b); root = r == b; }
         label[b] = r;
@@ -75,29 +78,41 @@ __global__ __launch_bounds__(256) void k_sleep_timers(DW<T> w, SleepParams<T> sp
     if (b >= w.n_bodies) return;
     const uint32_t l = label[b];
     if (l == 0xFFFFFFFFu) { timer[b] = 0.0f; return; }
+    if (meta_flags(w.bmeta[b]) & AVN_BODY_SLEEPING) { atomicOr(&awake[l], 2u); return; }   // Without<Sleeping>: the island holds a sleeper
     const V3<T> v = xyz<T>(w.sb_lin[b]), om = xyz<T>(w.sb_ang[b]);
     const T v2 = length_squared(v), w2 = length_squared(om);
     float t = timer[b];
     if (v2 < sp.length_unit_squared * sp.lin_threshold_squared && w2 < sp.ang_threshold_squared) t = t + sp.delta_secs;
     else t = 0.0f;
     timer[b] = t;
-    if (t < sp.time_to_sleep) awake[l] = 1u;   // awake_island_bit_vec.set(island): any writer, same value
+    if (t < sp.time_to_sleep) atomicOr(&awake[l], 1u);   // awake_island_bit_vec.set(island)
 }
-// sleep_islands' decision (sleeping.rs:256-266), per body; ctr[2] = resting islands, ctr[3] = bodies in them
-__global__ __launch_bounds__(256) void k_sleep_decide(uint32_t n, const uint32_t* __restrict__ label, const uint32_t* __restrict__ awake,
-                                                      uint8_t* __restrict__ rests, uint32_t* __restrict__ ctr) {
+// sleep_islands' decision (sleeping.rs:256-266), per body.  awake[l]: bit 0 = some awake body keeps the island awake, bit 1 = it holds a sleeping
+// body.  ctr[2] resting islands, [3] bodies in them, [4] waking islands, [5] sleeping bodies in them, [6] sleeping bodies
+template <class T>
+__global__ __launch_bounds__(256) void k_sleep_decide(DW<T> w, const uint32_t* __restrict__ label, const uint32_t* __restrict__ awake,
+                                                      uint8_t* __restrict__ rests, uint8_t* __restrict__ wakes, uint32_t* __restrict__ ctr) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
-    bool r = false, root = false;
-    if (b < n) {
+    bool r = false, wk = false, root = false, sl = false;
+    if (b < w.n_bodies) {
         const uint32_t l = label[b];
-        r = l != 0xFFFFFFFFu && awake[l] == 0u;
-        root = r && l == b;
+        if (l != 0xFFFFFFFFu) {
+            const uint32_t a = awake[l];
+            sl = (meta_flags(w.bmeta[b]) & AVN_BODY_SLEEPING) != 0;
+            r = !(a & 1u) && !(a & 2u);
+            wk = (a & 1u) && (a & 2u);
+            root = l == b;
+        }
         rests[b] = r ? 1 : 0;
+        wakes[b] = wk ? 1 : 0;
     }
-    const unsigned long long rb = __ballot(r), ib = __ballot(root);
+    const unsigned long long rb = __ballot(r), rr = __ballot(r && root), wr = __ballot(wk && root), ws = __ballot(wk && sl), sb = __ballot(sl);
     if ((threadIdx.x & 63) == 0) {
-        if (ib) atomicAdd(ctr + 2, (uint32_t)__popcll(ib));
+        if (rr) atomicAdd(ctr + 2, (uint32_t)__popcll(rr));
         if (rb) atomicAdd(ctr + 3, (uint32_t)__popcll(rb));
+        if (wr) atomicAdd(ctr + 4, (uint32_t)__popcll(wr));
+        if (ws) atomicAdd(ctr + 5, (uint32_t)__popcll(ws));
+        if (sb) atomicAdd(ctr + 6, (uint32_t)__popcll(sb));
     }
 }
 __global__ __launch_bounds__(256) void k_sleep_reset(float* __restrict__ timer, const uint32_t* __restrict__ bodies, uint32_t n, uint32_t n_bodies) {
@@ -115,11 +130,11 @@ template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_
     if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent);
     hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr);
 }
-template <class T> void launch_sleep_update(const DW<T>& w, const SleepParams<T>& sp, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint32_t* ctr, hipStream_t s) {
+template <class T> void launch_sleep_update(const DW<T>& w, const SleepParams<T>& sp, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes, uint32_t* ctr, hipStream_t s) {
     if (!w.n_bodies) return;
     const uint32_t nb = (w.n_bodies + 255) / 256;
     hipLaunchKernelGGL(k_sleep_timers<T>, dim3(nb), dim3(256), 0, s, w, sp, label, timer, awake);
-    hipLaunchKernelGGL(k_sleep_decide, dim3(nb), dim3(256), 0, s, w.n_bodies, label, (const uint32_t*)awake, rests, ctr);
+    hipLaunchKernelGGL(k_sleep_decide<T>, dim3(nb), dim3(256), 0, s, w, label, (const uint32_t*)awake, rests, wakes, ctr);
 }
 void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32_t n_bodies, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_sleep_reset, dim3((n + 255) / 256), dim3(256), 0, s, timer, bodies, n, n_bodies);
@@ -127,7 +142,7 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
 
 #define INST(T)                                                                                              \
     template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t);            \
-    template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint32_t*, hipStream_t);
+    template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint8_t*, uint32_t*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

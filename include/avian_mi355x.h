@@ -627,11 +627,12 @@ AVN_API avn_status AVN_FN(islands_partition)(const avn_islands_in* in, int32_t* 
  * Computed by a lock-free union-find on the device (k_islands.hip); feeds the island-block builder and the multi-GPU partitioner.
  *
  * avn_sleep_update: update_sleeping_states (islands/sleeping.rs:184-241) for one step, on the device, in the reference's arithmetic:
- *   per non-static body   v2 = |SolverBody.linear_velocity|^2, w2 = |SolverBody.angular_velocity|^2      (Scalar)
+ *   per awake body        v2 = |SolverBody.linear_velocity|^2, w2 = |SolverBody.angular_velocity|^2      (Scalar; bodies uploaded with
+ *                         AVN_BODY_SLEEPING are skipped like the reference's `Without<Sleeping>`, their timer stays)
  *                         rests = v2 < length_unit^2 * (lin * |lin|) && w2 < ang * |ang|                 (thresholds f32, "keep signs")
  *                         SleepTimer (f32) += delta_secs (f32) if rests else = 0
- *   per island            kept awake if any body has SleepTimer < time_to_sleep; otherwise it RESTS: sleep_islands (:243-280) would put it
- *                         to sleep.
+ *   per island            kept awake if any awake body has SleepTimer < time_to_sleep; an awake island nobody keeps awake RESTS
+ *                         (sleep_islands, :243-280, would put it to sleep); an island with sleeping bodies that IS kept awake WAKES.
  * What the call reports is the DECISION.  Putting an island to sleep / waking it (SleepIslands / WakeIslands, :300-520: Sleeping
  * components, the ContactGraph's sleeping set, pop / push of the constraint handles) is the host's side of the boundary and is NOT done
  * here; neither is the one-step delay a pending split adds in the reference.  Call it after avn_step (the Sleeping set runs after the
@@ -646,16 +647,20 @@ typedef struct avn_sleep_params {
 } avn_sleep_params;
 typedef struct avn_sleep_stats {
     uint32_t n_islands;                   /* islands of the current constraint graph */
-    uint32_t n_island_bodies;             /* non-static bodies */
-    uint32_t n_resting_islands;           /* islands no body keeps awake: sleep_islands would put them to sleep */
+    uint32_t n_island_bodies;             /* bodies with a BodyIslandNode: non-static, not AVN_BODY_DISABLED */
+    uint32_t n_sleeping_bodies;           /* of those, uploaded with AVN_BODY_SLEEPING (the host has put their island to sleep) */
+    uint32_t n_awake_bodies;              /* n_island_bodies - n_sleeping_bodies: the solver's N of the step just taken */
+    uint32_t n_resting_islands;           /* awake islands no body keeps awake: sleep_islands would put them to sleep (sleeping.rs:262-266) */
     uint32_t n_resting_bodies;            /* bodies in those islands */
-    uint32_t n_awake_bodies;              /* n_island_bodies - n_resting_bodies: the solver's N once the host has acted on the decision */
-    uint32_t reserved0;
+    uint32_t n_waking_islands;            /* islands with a sleeping body AND a body that keeps them awake (a contact merged an awake island
+                                             into a sleeping one): sleep_islands would wake them (sleeping.rs:258-261) */
+    uint32_t n_waking_bodies;             /* sleeping bodies in those islands */
 } avn_sleep_stats;
 typedef struct avn_sleep_out {
-    float* sleep_timer;        /* [n_bodies] SleepTimer after the update (0 for static bodies); may be NULL */
-    uint32_t* island;          /* [n_bodies] island label (lowest body index), 0xFFFFFFFF for static bodies; may be NULL */
-    uint8_t* island_rests;     /* [n_bodies] 1 = the body's island rests (would be put to sleep); may be NULL */
+    float* sleep_timer;        /* [n_bodies] SleepTimer after the update (0 for bodies without an island node); may be NULL */
+    uint32_t* island;          /* [n_bodies] island label (lowest body index), 0xFFFFFFFF for bodies without an island node; may be NULL */
+    uint8_t* island_rests;     /* [n_bodies] 1 = the body's island is awake and rests (would be put to sleep); may be NULL */
+    uint8_t* island_wakes;     /* [n_bodies] 1 = the body's island holds sleeping bodies and is kept awake (would be woken); may be NULL */
 } avn_sleep_out;
 AVN_API avn_status AVN_FN(islands_get)(avn_world* w, uint32_t* island_of_body /* [n_bodies] */, uint32_t* n_islands);
 AVN_API avn_status AVN_FN(sleep_update)(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* stats);

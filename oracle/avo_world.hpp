@@ -1878,12 +1878,12 @@ template <class S> struct World : WorldBase {
     // serial loops of update_sleeping_states / sleep_islands (islands/sleeping.rs:184-280) over bodies and islands.
     std::vector<uint32_t> isl_label;
     std::vector<float> sleep_timer;
-    std::vector<uint8_t> isl_rests;
+    std::vector<uint8_t> isl_rests, isl_wakes;
     uint32_t isl_count = 0, isl_nodes = 0;
     void islands_compute() {
         const size_t n = bodies.size();
         std::vector<std::vector<uint32_t>> adj(n);
-        auto node = [&](int32_t b) { return b >= 0 && (size_t)b < n && bodies[b].rb_type != AVN_RB_STATIC; };
+        auto node = [&](int32_t b) { return b >= 0 && (size_t)b < n && bodies[b].rb_type != AVN_RB_STATIC && !(bodies[b].body_flags & AVN_BODY_DISABLED); };   // BodyIslandNode, islands/mod.rs:96-140
         for (const auto& m : manifolds) if (node(m.body1) && node(m.body2) && m.body1 != m.body2) { adj[m.body1].push_back((uint32_t)m.body2); adj[m.body2].push_back((uint32_t)m.body1); }
         for (const auto& j : joints) if (node(j.body1) && node(j.body2) && j.body1 != j.body2) { adj[j.body1].push_back((uint32_t)j.body2); adj[j.body2].push_back((uint32_t)j.body1); }
         isl_label.assign(n, 0xFFFFFFFFu);
@@ -1913,9 +1913,11 @@ template <class S> struct World : WorldBase {
         if (sleep_timer.size() != n) sleep_timer.assign(n, 0.0f);
         const S length_unit_squared = (S)sp->length_unit * (S)sp->length_unit;
         const float delta_secs = sp->delta_secs;
-        std::vector<uint8_t> awake(n, 0);   // AwakeIslandBitVec, indexed by island label
+        std::vector<uint8_t> awake(n, 0), is_sleeping(n, 0);   // AwakeIslandBitVec and PhysicsIsland::is_sleeping, indexed by island label
+        uint32_t sleeping_bodies = 0;
         for (size_t b = 0; b < n; ++b) {
             if (isl_label[b] == 0xFFFFFFFFu) { sleep_timer[b] = 0.0f; continue; }
+            if (bodies[b].body_flags & AVN_BODY_SLEEPING) { is_sleeping[isl_label[b]] = 1; ++sleeping_bodies; continue; }   // query filter Without<Sleeping>
             const SolverBody<S>& sb = bodies[b].sb;
             const S lin_vel_squared = length_squared(sb.linear_velocity), ang_vel_squared = length_squared(sb.angular_velocity);
             // "Keep signs."
@@ -1925,15 +1927,17 @@ template <class S> struct World : WorldBase {
             else sleep_timer[b] = 0.0f;
             if (sleep_timer[b] < sp->time_to_sleep) awake[isl_label[b]] = 1;
         }
-        isl_rests.assign(n, 0);
-        uint32_t resting_islands = 0, resting_bodies = 0;
+        // sleep_islands (sleeping.rs:256-266): awake bit and sleeping -> wake; no awake bit, not sleeping (and no pending split) -> sleep
+        isl_rests.assign(n, 0); isl_wakes.assign(n, 0);
+        uint32_t resting_islands = 0, resting_bodies = 0, waking_islands = 0, waking_bodies = 0;
         for (size_t b = 0; b < n; ++b) {
-            if (isl_label[b] == 0xFFFFFFFFu || awake[isl_label[b]]) continue;
-            isl_rests[b] = 1; ++resting_bodies;
-            if (isl_label[b] == b) ++resting_islands;
+            const uint32_t l = isl_label[b];
+            if (l == 0xFFFFFFFFu) continue;
+            if (awake[l] && is_sleeping[l]) { isl_wakes[b] = 1; if (l == b) ++waking_islands; if (bodies[b].body_flags & AVN_BODY_SLEEPING) ++waking_bodies; }
+            else if (!awake[l] && !is_sleeping[l]) { isl_rests[b] = 1; ++resting_bodies; if (l == b) ++resting_islands; }
         }
-        if (out) { out->n_islands = isl_count; out->n_island_bodies = isl_nodes; out->n_resting_islands = resting_islands; out->n_resting_bodies = resting_bodies;
-                   out->n_awake_bodies = isl_nodes - resting_bodies; out->reserved0 = 0; }
+        if (out) { out->n_islands = isl_count; out->n_island_bodies = isl_nodes; out->n_sleeping_bodies = sleeping_bodies; out->n_awake_bodies = isl_nodes - sleeping_bodies;
+                   out->n_resting_islands = resting_islands; out->n_resting_bodies = resting_bodies; out->n_waking_islands = waking_islands; out->n_waking_bodies = waking_bodies; }
         return AVN_OK;
     }
     avn_status sleep_get(const avn_sleep_out* o) override {
@@ -1942,6 +1946,7 @@ template <class S> struct World : WorldBase {
         if (o->sleep_timer) std::copy(sleep_timer.begin(), sleep_timer.end(), o->sleep_timer);
         if (o->island) std::copy(isl_label.begin(), isl_label.end(), o->island);
         if (o->island_rests) std::copy(isl_rests.begin(), isl_rests.end(), o->island_rests);
+        if (o->island_wakes) std::copy(isl_wakes.begin(), isl_wakes.end(), o->island_wakes);
         return AVN_OK;
     }
     avn_status sleep_reset(const uint32_t* ids, size_t n) override {

@@ -107,3 +107,33 @@ def test_one_big_island_and_many_small_ones():
     scenes.upload_manifolds(w2, scenes.permute_manifolds(mfs, perm2), offs2, 0.5, 0.0)
     lab2, n2 = w2.islands_get()
     assert np.array_equal(lab2, want) and n2 == m
+
+
+def test_sleeping_and_disabled_bodies_on_hip():
+    """The CPU case of tests/test_sleep_cpu.py::test_sleeping_and_disabled_bodies, HIP against the oracle (f32 and f64)."""
+    for bits in (32, 64):
+        res = []
+        for lib in (hip_lib(), oracle_lib()):
+            n = 7
+            sc = scenes.box_stacks(6, 1, 1, 1, gap=3.0)
+            b = sc.body_kwargs()
+            flags = np.zeros(n, np.uint8); flags[1] = flags[2] = F.BODY_SLEEPING; flags[5] = F.BODY_DISABLED
+            b["body_flags"] = flags
+            v = np.zeros((n, 3)); v[3] = [1.0, 0, 0]
+            b["linear_velocity"] = v; b["gravity_scale"] = np.zeros(n)
+            w = F.World(lib, F.default_config(bits, substeps=1))
+            w.bodies_upload(**b)
+            out = []
+            for jb1, jb2 in (([1, 5], [2, 6]), ([1, 2], [2, 3])):
+                J = dict(body1=np.array(jb1, np.int32), body2=np.array(jb2, np.int32), local_anchor1=np.zeros((2, 3)), local_anchor2=np.zeros((2, 3)),
+                         limit_min=np.zeros(2), limit_max=np.full(2, 100.0), compliance=np.zeros(2))
+                w.distance_joints_upload(**J)
+                w.run_system("PREPARE_SOLVER_BODIES")
+                st = w.sleep_update(delta_secs=1.0, time_to_sleep=0.5)
+                out.append(([getattr(st, f) for f, _ in st._fields_], w.sleep_get()))
+            res.append(out)
+        for (sa, ga), (sb, gb) in zip(*res):
+            assert sa == sb
+            for k in ga:
+                assert np.array_equal(ga[k], gb[k]), (bits, k)
+        assert res[0][1][0][6:] == [1, 2], "the moving body wakes the sleeping island it was linked to"

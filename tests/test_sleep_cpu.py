@@ -73,7 +73,7 @@ def test_islands_equal_scipy_and_sleeping_equals_the_restatement(bits):
         assert np.array_equal(got["island_rests"], rests), f"step {step}: resting decision"
         assert np.array_equal(got["island"], want)
         assert st.n_islands == 3 and st.n_island_bodies == sc.n - 1
-        assert st.n_resting_bodies == int(rests.sum()) and st.n_awake_bodies == sc.n - 1 - int(rests.sum())
+        assert st.n_resting_bodies == int(rests.sum()) and st.n_awake_bodies == sc.n - 1 and st.n_sleeping_bodies == 0 and st.n_waking_islands == 0
         assert st.n_resting_islands == len(set(want[rests.astype(bool)].tolist()))
         slept |= st.n_resting_islands > 0
     assert slept, "a resting stack must reach TimeToSleep within 45 steps (0.5 s = 30 steps)"
@@ -112,6 +112,45 @@ def test_joints_and_kinematic_bodies_link_islands_static_ones_do_not():
     w2.distance_joints_upload(**J)
     lab, n = w2.islands_get()
     assert n == 2 and lab.tolist() == [0, 0, 2]
+
+
+def test_sleeping_and_disabled_bodies():
+    """Bodies the host has put to sleep (AVN_BODY_SLEEPING) are skipped by update_sleeping_states (`Without<Sleeping>`) but keep their island
+    node: an island of sleepers is neither resting nor waking; once an awake, moving body is linked to it, it wakes (sleeping.rs:258-261).
+    A disabled body has no island node at all (islands/mod.rs:124-135)."""
+    lib = oracle_lib()
+    n = 7   # ground + 6 boxes in a row, each its own island until joints link them
+    sc = scenes.box_stacks(6, 1, 1, 1, gap=3.0)
+    assert sc.n == n
+    b = sc.body_kwargs()
+    flags = np.zeros(n, np.uint8)
+    flags[1] = flags[2] = F.BODY_SLEEPING      # island {1, 2}: asleep
+    flags[5] = F.BODY_DISABLED                 # no node
+    b["body_flags"] = flags
+    v = np.zeros((n, 3)); v[3] = [1.0, 0, 0]   # body 3 moves; 4 rests; 6 rests
+    b["linear_velocity"] = v
+    b["gravity_scale"] = np.zeros(n)
+    w = F.World(lib, F.default_config(32, substeps=1))
+    w.bodies_upload(**b)
+    J = dict(body1=np.array([1, 5], np.int32), body2=np.array([2, 6], np.int32), local_anchor1=np.zeros((2, 3)), local_anchor2=np.zeros((2, 3)),
+             limit_min=np.zeros(2), limit_max=np.full(2, 100.0), compliance=np.zeros(2))
+    w.distance_joints_upload(**J)
+    w.run_system("PREPARE_SOLVER_BODIES")
+    st = w.sleep_update(delta_secs=1.0, time_to_sleep=0.5)
+    g = w.sleep_get()
+    assert g["island"].tolist() == [NONE, 1, 1, 3, 4, NONE, 6], "the joint to the disabled body links nothing"
+    assert (st.n_islands, st.n_island_bodies, st.n_sleeping_bodies, st.n_awake_bodies) == (4, 5, 2, 3)
+    assert g["island_rests"].tolist() == [0, 0, 0, 0, 1, 0, 1] and g["island_wakes"].tolist() == [0] * 7
+    assert (st.n_resting_islands, st.n_resting_bodies, st.n_waking_islands, st.n_waking_bodies) == (2, 2, 0, 0)
+    assert g["sleep_timer"].tolist() == [0, 0, 0, 0, 1, 0, 1], "sleepers' timers are not advanced"
+    # a joint now links the moving body 3 to the sleeping island: it has to wake
+    J = dict(body1=np.array([1, 2], np.int32), body2=np.array([2, 3], np.int32), local_anchor1=np.zeros((2, 3)), local_anchor2=np.zeros((2, 3)),
+             limit_min=np.zeros(2), limit_max=np.full(2, 100.0), compliance=np.zeros(2))
+    w.distance_joints_upload(**J)
+    st = w.sleep_update(delta_secs=1.0, time_to_sleep=0.5)
+    g = w.sleep_get()
+    assert g["island"].tolist() == [NONE, 1, 1, 1, 4, NONE, 6]
+    assert g["island_wakes"].tolist() == [0, 1, 1, 1, 0, 0, 0] and (st.n_waking_islands, st.n_waking_bodies) == (1, 2)
 
 
 def test_threshold_signs_and_length_unit():
