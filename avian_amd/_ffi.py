@@ -187,6 +187,11 @@ class avn_diagnostics(C.Structure):
                [(n, C.c_uint32) for n in ("contact_constraint_count", "contact_count", "per_system_valid", "reserved0")]
 
 
+class avn_level2_in(C.Structure):
+    _fields_ = [("n_bodies", C.c_uint32), ("rb_type", vp), ("center_x", vp), ("n_manifolds", C.c_uint32), ("body1", vp), ("body2", vp),
+                ("color_offsets", vp), ("n_ranks", C.c_uint32)]
+
+
 class avn_sleep_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("time_to_sleep", C.c_float), ("linear_threshold", C.c_float), ("angular_threshold", C.c_float),
                 ("delta_secs", C.c_float), ("length_unit", C.c_double)]
@@ -205,6 +210,11 @@ class avn_halo_plan(C.Structure):
     _fields_ = [("n_peers", C.c_uint32), ("peer_rank", vp), ("send_offsets", vp), ("send_bodies", vp), ("recv_offsets", vp), ("recv_bodies", vp)]
 
 
+class avn_level2_rank(C.Structure):
+    _fields_ = [("n_bodies", C.c_uint32), ("bodies", C.POINTER(C.c_int32)), ("n_manifolds", C.c_uint32), ("manifolds", C.POINTER(C.c_uint32)),
+                ("color_offsets", C.POINTER(C.c_uint32)), ("halo", avn_halo_plan)]
+
+
 PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),
                        ("flags", "<u4"), ("reserved", "<u4")])
 
@@ -213,7 +223,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -249,6 +259,10 @@ class Library:
         f("run_color_pass").argtypes = [vp, C.c_int, C.c_uint32]
         f("halo_pack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_size_t)]
         f("halo_unpack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+        f("level2_plan_create").argtypes = [C.POINTER(avn_level2_in), C.POINTER(vp)]
+        f("level2_plan_destroy").argtypes = [vp]
+        f("level2_plan_destroy").restype = None
+        f("level2_plan_rank").argtypes = [vp, C.c_uint32, C.POINTER(avn_level2_rank)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
         f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
@@ -287,6 +301,34 @@ class Library:
 
     def pair_key(self, a: int, b: int) -> int:
         return int(self.fn("pair_key")(a, b))
+
+    def level2_plan(self, rb_type, center_x, body1, body2, color_offsets, n_ranks: int):
+        """``avn_level2_plan_*``: per rank a dict(bodies, manifolds, color_offsets, peers, send_offsets, send_bodies, recv_offsets, recv_bodies)."""
+        rb = np.ascontiguousarray(rb_type, np.uint8); cx = np.ascontiguousarray(center_x, np.float64)
+        b1 = np.ascontiguousarray(body1, np.int32); b2 = np.ascontiguousarray(body2, np.int32); co = np.ascontiguousarray(color_offsets, np.uint32)
+        inp = avn_level2_in(len(rb), _ptr(rb), _ptr(cx), len(b1), _ptr(b1), _ptr(b2), _ptr(co), int(n_ranks))
+        h = vp()
+        st = self.fn("level2_plan_create")(C.byref(inp), C.byref(h))
+        if st != 0:
+            raise AvnError(st, "level2_plan: refused (an overflow-colour manifold on a shared body, or bad indices)")
+        try:
+            out = []
+            for r in range(n_ranks):
+                k = avn_level2_rank()
+                st = self.fn("level2_plan_rank")(h, r, C.byref(k))
+                if st != 0:
+                    raise AvnError(st, "level2_plan_rank")
+                arr = lambda p, n, t: np.ctypeslib.as_array(p, shape=(n,)).astype(t).copy() if n else np.zeros(0, t)
+                npeers = k.halo.n_peers
+                nl = 24 * npeers + 1 if npeers else 1
+                so = arr(C.cast(k.halo.send_offsets, C.POINTER(C.c_uint32)), nl, np.uint32); ro = arr(C.cast(k.halo.recv_offsets, C.POINTER(C.c_uint32)), nl, np.uint32)
+                out.append(dict(bodies=arr(k.bodies, k.n_bodies, np.int64), manifolds=arr(k.manifolds, k.n_manifolds, np.int64), color_offsets=arr(k.color_offsets, 25, np.uint32),
+                                peers=arr(C.cast(k.halo.peer_rank, C.POINTER(C.c_int32)), npeers, np.int32), send_offsets=so,
+                                send_bodies=arr(C.cast(k.halo.send_bodies, C.POINTER(C.c_int32)), int(so[-1]), np.int32), recv_offsets=ro,
+                                recv_bodies=arr(C.cast(k.halo.recv_bodies, C.POINTER(C.c_int32)), int(ro[-1]), np.int32)))
+            return out
+        finally:
+            self.fn("level2_plan_destroy")(h)
 
     def comm_unique_id(self) -> bytes:
         """``avn_comm_unique_id``: the RCCL rendezvous token rank 0 creates and hands to the other ranks (any side channel)."""

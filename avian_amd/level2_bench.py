@@ -31,7 +31,7 @@ def run(lib, rank, world_size, device, broadcast_bytes, all_reduce_max, barrier,
     from avian_amd import _ffi as F, scenes, shard
     t_plan = time.perf_counter()
     sc, pm, offs = global_island(lib, F, scenes, *dims, device=device)
-    plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world_size)
+    plan = shard.level2_plan_lib(lib, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world_size)   # the library's planner (C ABI)
     mine = plan[rank]
     t_plan = time.perf_counter() - t_plan
 

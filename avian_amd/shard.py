@@ -405,6 +405,20 @@ class Level2Rank:
     recv_bodies: np.ndarray
 
 
+def level2_plan_lib(lib: F.Library, position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray,
+                    world_size: int) -> List[Level2Rank]:
+    """The plan from the library's own planner (avn_level2_plan_*: what a host in any language calls).  `level2_plan` below is the same
+    rule in numpy, kept as its independent check (tests/test_level2_cpu.py)."""
+    out = []
+    try:
+        ranks = lib.level2_plan(rb_type, np.asarray(position, np.float64)[:, 0], body1, body2, color_offsets, world_size)
+    except F.AvnError as e:
+        raise ValueError(str(e))
+    for k in ranks:
+        out.append(Level2Rank(k["bodies"], k["manifolds"], k["color_offsets"], k["peers"], k["send_offsets"], k["send_bodies"], k["recv_offsets"], k["recv_bodies"]))
+    return out
+
+
 def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray, world_size: int,
                 has_solver_body: np.ndarray = None) -> List[Level2Rank]:
     """body1 / body2: the GLOBAL colour-major manifold set; color_offsets: its [25] offsets (the reference's colouring of the whole island)."""

@@ -572,6 +572,31 @@ AVN_API avn_status AVN_FN(halo_plan_upload)(avn_world* w, const avn_halo_plan* p
 AVN_API avn_status AVN_FN(run_color_pass)(avn_world* w, avn_system pass, uint32_t color);
 AVN_API avn_status AVN_FN(halo_pack)(avn_world* w, uint32_t color, uint32_t peer, void* out /* [8 * count] scalars */, size_t* count);
 AVN_API avn_status AVN_FN(halo_unpack)(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count);
+/* The level-2 planner (host integer work, no device): which world owns which manifold, which bodies each world holds, and the per-colour
+ * send / receive lists -- everything avn_halo_plan_upload and the per-rank uploads need, so that a host in any language shards without
+ * re-implementing it.  Slabs are cut at the quantiles of the non-static bodies' x; a manifold belongs to the slab of its body1 (body2 when
+ * body1 is static); a body is SHARED when more than one world holds it; lists are in ascending global body index (the same order on both
+ * sides of every pair of ranks).  AVN_ERR_BAD_ARG when an overflow-colour manifold touches a shared body. */
+typedef struct avn_level2_in {
+    uint32_t n_bodies;
+    const uint8_t* rb_type;        /* [n_bodies] AVN_RB_* */
+    const double* center_x;        /* [n_bodies] */
+    uint32_t n_manifolds;
+    const int32_t* body1;          /* [n_manifolds] the GLOBAL colour-major manifold set */
+    const int32_t* body2;
+    const uint32_t* color_offsets; /* [25] of that set */
+    uint32_t n_ranks;
+} avn_level2_in;
+typedef struct avn_level2_rank {   /* pointers are owned by the plan */
+    uint32_t n_bodies;  const int32_t* bodies;            /* global index of every local body, ascending (local index = position) */
+    uint32_t n_manifolds; const uint32_t* manifolds;      /* global manifold indices, ascending (= colour-major) */
+    const uint32_t* color_offsets;                        /* [25] of the local set */
+    avn_halo_plan halo;                                   /* LOCAL body indices */
+} avn_level2_rank;
+typedef struct avn_level2_plan avn_level2_plan;
+AVN_API avn_status AVN_FN(level2_plan_create)(const avn_level2_in* in, avn_level2_plan** out);
+AVN_API void AVN_FN(level2_plan_destroy)(avn_level2_plan* plan);
+AVN_API avn_status AVN_FN(level2_plan_rank)(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out);
 #define AVN_COMM_ID_BYTES 128
 AVN_API avn_status AVN_FN(comm_unique_id)(uint8_t* out /* [AVN_COMM_ID_BYTES] */);
 AVN_API avn_status AVN_FN(comm_init)(avn_world* w, const uint8_t* unique_id, int n_ranks, int rank);

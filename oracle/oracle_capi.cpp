@@ -4,6 +4,7 @@
 #include "avo_world.hpp"
 
 #include <new>
+#include <set>
 
 struct avn_world { avo::WorldBase* impl; };
 struct avn_constraint_graph { avo::ConstraintGraph g; };
@@ -70,6 +71,92 @@ avn_status avo_contacts_download(avn_world* w, const uint32_t* ids, size_t n, co
 avn_status avo_pipeline_enable(avn_world* w, int on) { FWD(pipeline_enable(on)); }
 avn_status avo_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { FWD(pipeline_stats_get(o)); }
 avn_status avo_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { FWD(pipeline_handles_get(off, ids, n)); }
+// Checker for avn_level2_plan_* (header).  Deliberately organised the other way round from the product's planner: per colour a
+// body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
+// body in ascending index, so they come out sorted without sorting.
+struct avn_level2_plan {
+    struct Rank { std::vector<int32_t> bodies, peers, send_bodies, recv_bodies; std::vector<uint32_t> manifolds, color_offsets, send_offsets, recv_offsets; };
+    std::vector<Rank> ranks;
+};
+avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) {
+    if (!in || !out || in->n_ranks == 0 || !in->color_offsets || (in->n_bodies && (!in->rb_type || !in->center_x)) || (in->n_manifolds && (!in->body1 || !in->body2))) return AVN_ERR_BAD_ARG;
+    *out = nullptr;
+    const uint32_t N = in->n_bodies, M = in->n_manifolds, R = in->n_ranks, C = AVN_GRAPH_COLOR_COUNT;
+    if (in->color_offsets[0] != 0 || in->color_offsets[C] != M) return AVN_ERR_BAD_ARG;
+    std::vector<uint32_t> dyn;
+    for (uint32_t b = 0; b < N; ++b) if (in->rb_type[b] != AVN_RB_STATIC) dyn.push_back(b);
+    std::vector<double> xs(dyn.size());
+    for (size_t i = 0; i < dyn.size(); ++i) xs[i] = in->center_x[dyn[i]];
+    std::sort(xs.begin(), xs.end());
+    std::vector<int32_t> slab(N, -1);
+    for (uint32_t b : dyn) {   // slab = number of cuts <= x
+        int32_t k = 0;
+        for (uint32_t r = 1; r < R; ++r) if (xs[std::min<size_t>(xs.size() - 1, xs.size() * (size_t)r / R)] <= in->center_x[b]) ++k;
+        slab[b] = k;
+    }
+    std::vector<int32_t> owner_of(M);
+    std::vector<std::set<uint32_t>> holders(N);
+    for (uint32_t m = 0; m < M; ++m) {
+        const int32_t a = in->body1[m], b = in->body2[m];
+        if (a < 0 || b < 0 || (uint32_t)a >= N || (uint32_t)b >= N) return AVN_ERR_BAD_ARG;
+        owner_of[m] = in->rb_type[a] == AVN_RB_STATIC ? slab[b] : slab[a];
+        if (owner_of[m] < 0) return AVN_ERR_BAD_ARG;
+        holders[a].insert((uint32_t)owner_of[m]); holders[b].insert((uint32_t)owner_of[m]);
+    }
+    for (uint32_t b : dyn) holders[b].insert((uint32_t)slab[b]);
+    auto shared = [&](uint32_t b) { return in->rb_type[b] != AVN_RB_STATIC && holders[b].size() > 1; };
+    // mover[c][b] = the rank whose manifold of colour c touches shared body b (-1: none)
+    std::vector<std::vector<int32_t>> mover(C, std::vector<int32_t>(N, -1));
+    for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m)
+            for (int32_t b : {in->body1[m], in->body2[m]})
+                if (shared((uint32_t)b)) { if (c == AVN_COLOR_OVERFLOW_INDEX) return AVN_ERR_BAD_ARG; mover[c][b] = owner_of[m]; }
+    avn_level2_plan* pl = new avn_level2_plan;
+    pl->ranks.resize(R);
+    for (uint32_t r = 0; r < R; ++r) {
+        auto& k = pl->ranks[r];
+        std::vector<int32_t> local(N, -1);
+        for (uint32_t b = 0; b < N; ++b)
+            if (in->rb_type[b] == AVN_RB_STATIC || holders[b].count(r)) { local[b] = (int32_t)k.bodies.size(); k.bodies.push_back((int32_t)b); }
+        std::set<int32_t> peers;
+        for (uint32_t c = 0; c < C; ++c)
+            for (uint32_t b : dyn) {
+                if (mover[c][b] < 0 || !holders[b].count(r)) continue;
+                if ((uint32_t)mover[c][b] == r) { for (uint32_t h : holders[b]) if (h != r) peers.insert((int32_t)h); }
+                else peers.insert(mover[c][b]);
+            }
+        k.peers.assign(peers.begin(), peers.end());
+        k.send_offsets.push_back(0); k.recv_offsets.push_back(0);
+        if (!k.peers.empty())
+            for (uint32_t c = 0; c < C; ++c)
+                for (int32_t p : k.peers) {
+                    for (uint32_t b : dyn) {
+                        if (mover[c][b] == (int32_t)r && holders[b].count((uint32_t)p)) k.send_bodies.push_back(local[b]);
+                        if (mover[c][b] == p && holders[b].count(r)) k.recv_bodies.push_back(local[b]);
+                    }
+                    k.send_offsets.push_back((uint32_t)k.send_bodies.size()); k.recv_offsets.push_back((uint32_t)k.recv_bodies.size());
+                }
+        k.color_offsets.assign(C + 1, 0);
+        for (uint32_t c = 0; c < C; ++c) {
+            for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m) if ((uint32_t)owner_of[m] == r) k.manifolds.push_back(m);
+            k.color_offsets[c + 1] = (uint32_t)k.manifolds.size();
+        }
+    }
+    *out = pl;
+    return AVN_OK;
+}
+void avo_level2_plan_destroy(avn_level2_plan* plan) { delete plan; }
+avn_status avo_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out) {
+    if (!plan || !out || rank >= plan->ranks.size()) return AVN_ERR_BAD_ARG;
+    const auto& k = plan->ranks[rank];
+    out->n_bodies = (uint32_t)k.bodies.size(); out->bodies = k.bodies.data();
+    out->n_manifolds = (uint32_t)k.manifolds.size(); out->manifolds = k.manifolds.data(); out->color_offsets = k.color_offsets.data();
+    out->halo.n_peers = (uint32_t)k.peers.size(); out->halo.peer_rank = k.peers.data();
+    out->halo.send_offsets = k.send_offsets.data(); out->halo.send_bodies = k.send_bodies.data();
+    out->halo.recv_offsets = k.recv_offsets.data(); out->halo.recv_bodies = k.recv_bodies.data();
+    return AVN_OK;
+}
+
 // Checker for avn_islands_partition (header).  Deliberately a DIFFERENT algorithm from the product's union-find:
 // breadth-first flood fill over an adjacency list, islands discovered in ascending body index (= numbered by their
 // smallest member), then the same slab rule (reference island statistics: islands/mod.rs:213-232).

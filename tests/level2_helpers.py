@@ -27,7 +27,7 @@ def make_single(lib, bits, sc, pm, offs, restitution, substeps):
 
 
 def make_split(lib, bits, sc, pm, offs, restitution, substeps, world_size):
-    plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world_size)
+    plan = shard.level2_plan_lib(lib, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world_size)
     worlds = []
     for r in plan:
         w = F.World(lib, F.default_config(bits, substeps=substeps))

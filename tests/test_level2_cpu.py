@@ -47,6 +47,27 @@ def test_plan_properties():
         shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs_bad, 2)
 
 
+def test_library_planner_equals_the_numpy_planner():
+    """avn_level2_plan_* of the product (host C++), of the oracle (a differently organised implementation) and shard.level2_plan (numpy)
+    give the same plan: bodies, manifolds, colour offsets, peers and every send / receive list."""
+    from helpers import hip_lib
+    lib = oracle_lib()
+    for dims, R in (((9, 3, 4), 3), ((8, 4, 5), 2), ((6, 2, 2), 4), ((5, 2, 2), 1)):
+        sc, pm, offs, _ = global_problem(lib, *dims)
+        want = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, R)
+        for L in (hip_lib(), lib):
+            got = shard.level2_plan_lib(L, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, R)
+            assert len(got) == len(want) == R
+            for a, b in zip(got, want):
+                for f in ("bodies", "manifolds", "color_offsets", "peers", "send_offsets", "send_bodies", "recv_offsets", "recv_bodies"):
+                    assert np.array_equal(np.asarray(getattr(a, f)).astype(np.int64), np.asarray(getattr(b, f)).astype(np.int64)), (dims, R, L.prefix, f)
+    sc, pm, offs, _ = global_problem(lib, 9, 3, 4)
+    offs_bad = offs.copy(); offs_bad[:] = 0; offs_bad[24] = len(pm["body1"])
+    for L in (hip_lib(), lib):
+        with pytest.raises(ValueError):
+            shard.level2_plan_lib(L, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs_bad, 2)
+
+
 def test_level2_over_gloo_world_size_2(tmp_path):
     """Two real processes (torch.distributed, gloo): each builds only its slab, steps it with shard.level2_solver and exchanges the boundary
     records point to point after every colour; merged result == the single world, bit for bit."""
