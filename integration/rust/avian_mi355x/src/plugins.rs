@@ -66,6 +66,9 @@ impl Plugin for Mi355xPhysicsPlugin {
                 gpu_solver.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER)
                 gpu_download.in_set(SolverSystems::StoreContactImpulses),
                 gpu_diagnostics.after(SolverSystems::StoreContactImpulses),
+                // replaces update_sleeping_states (src/dynamics/solver/islands/sleeping.rs:71-83 chains it before sleep_islands): the timers and
+                // the per-island decision come from the device, the commands that act on it stay Avian's own
+                gpu_sleeping.in_set(PhysicsStepSystems::Sleeping).run_if(resource_exists::<PhysicsIslands>),
             ),
         );
         // IntegratorPlugin's own bookkeeping set stays meaningful for user systems ordered against it
@@ -209,4 +212,34 @@ fn gpu_diagnostics(mut w: ResMut<Mi355xWorld>, mut solver: ResMut<SolverDiagnost
     solver.contact_constraint_count = d.contact_constraint_count;
     collision.narrow_phase += ms(d.narrow_phase_ms);
     collision.contact_count = d.contact_count;
+}
+
+/// `update_sleeping_states` + the decision of `sleep_islands` on the device (`avn_sleep_update`); `SleepIslands` / `WakeIslands` -- the
+/// commands that insert `Sleeping`, move contact pairs to the ContactGraph's sleeping set and pop / push constraint handles -- are
+/// Avian's own (src/dynamics/solver/islands/sleeping.rs:300-520) and are queued here exactly where `sleep_islands` queues them.
+fn gpu_sleeping(
+    mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, time_to_sleep: Res<TimeToSleep>, length_unit: Res<PhysicsLengthUnit>, time: Res<Time>,
+    mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, mut commands: Commands,
+) {
+    let st = &st.0;
+    // world-level thresholds: per-body `SleepThreshold` overrides would travel as one more array of `avn_bodies` (not in the ABI yet)
+    let stats = w.sleep_update(time_to_sleep.0, (SleepThreshold::default().linear, SleepThreshold::default().angular), time.delta_secs(), length_unit.0 as f64);
+    if stats.n_resting_islands == 0 && stats.n_waking_islands == 0 && stats.n_awake_bodies == 0 { return; }
+    let (timer, _label, rests, wakes) = w.sleep_state(st.body_entities.len());
+    let (mut to_sleep, mut to_wake) = (Vec::new(), Vec::new());
+    for (i, &e) in st.body_entities.iter().enumerate() {
+        let Ok((mut t, node)) = timers.get_mut(e) else { continue };
+        t.0 = timer[i];
+        if rests[i] != 0 { to_sleep.push(node.island_id); }
+        if wakes[i] != 0 { to_wake.push(node.island_id); }
+    }
+    to_sleep.sort_unstable(); to_sleep.dedup(); to_wake.sort_unstable(); to_wake.dedup();
+    // (the reference additionally refuses to sleep an island with pending splits, `constraints_removed > 0`: PhysicsIslands still holds
+    //  that counter on the host, so the filter is applied here)
+    commands.queue(move |world: &mut World| {
+        let islands = world.resource::<PhysicsIslands>();
+        let ok: Vec<IslandId> = to_sleep.into_iter().filter(|id| islands.get(*id).is_some_and(|i| i.constraints_removed() == 0 && !i.is_sleeping())).collect();
+        SleepIslands(ok).apply(world);
+        WakeIslands(to_wake).apply(world);
+    });
 }

@@ -100,6 +100,49 @@ impl Mi355xWorld {
     }
 }
 
+/// Islands, the sleeping decision and multi-GPU sharding (include/avian_mi355x.h, "islands and sleeping", "level-2 sharding").
+impl Mi355xWorld {
+    /// `update_sleeping_states` + the decision of `sleep_islands` for the step just taken (src/dynamics/solver/islands/sleeping.rs:184-280).
+    /// The caller (the Sleeping set's system in `plugins.rs`) applies it: `SleepIslands` / `WakeIslands` stay host-side.
+    pub fn sleep_update(&mut self, time_to_sleep: f32, threshold: (f32, f32), delta_secs: f32, length_unit: f64) -> ffi::avn_sleep_stats {
+        let p = ffi::avn_sleep_params {
+            struct_size: core::mem::size_of::<ffi::avn_sleep_params>() as u32,
+            time_to_sleep,
+            linear_threshold: threshold.0,
+            angular_threshold: threshold.1,
+            delta_secs,
+            length_unit,
+        };
+        let mut stats = unsafe { core::mem::zeroed::<ffi::avn_sleep_stats>() };
+        let st = unsafe { ffi::avn_sleep_update(self.raw, &p, &mut stats) };
+        self.check(st);
+        stats
+    }
+
+    /// Per body: `SleepTimer`, island label (lowest body index), "island rests", "island wakes".
+    pub fn sleep_state(&mut self, n_bodies: usize) -> (Vec<f32>, Vec<u32>, Vec<u8>, Vec<u8>) {
+        let (mut t, mut l, mut r, mut k) = (vec![0f32; n_bodies], vec![0u32; n_bodies], vec![0u8; n_bodies], vec![0u8; n_bodies]);
+        let out = ffi::avn_sleep_out { sleep_timer: t.as_mut_ptr(), island: l.as_mut_ptr(), island_rests: r.as_mut_ptr(), island_wakes: k.as_mut_ptr() };
+        let st = unsafe { ffi::avn_sleep_get(self.raw, &out) };
+        self.check(st);
+        (t, l, r, k)
+    }
+
+    /// What `WakeIslands::apply` does to the timers of the bodies it wakes (sleeping.rs:492).
+    pub fn sleep_reset(&mut self, bodies: &[u32]) {
+        let st = unsafe { ffi::avn_sleep_reset(self.raw, bodies.as_ptr(), bodies.len()) };
+        self.check(st);
+    }
+
+    /// Level 2: this rank's send / receive lists (from `avn_level2_plan_rank`), then the library's own transport.
+    pub fn enable_level2(&mut self, halo: &ffi::avn_halo_plan, unique_id: &[u8; ffi::AVN_COMM_ID_BYTES as usize], n_ranks: i32, rank: i32) {
+        let st = unsafe { ffi::avn_halo_plan_upload(self.raw, halo) };
+        self.check(st);
+        let st = unsafe { ffi::avn_comm_init(self.raw, unique_id.as_ptr(), n_ranks, rank) };
+        self.check(st);
+    }
+}
+
 impl Drop for Mi355xWorld {
     fn drop(&mut self) {
         unsafe { ffi::avn_world_destroy(self.raw) }
