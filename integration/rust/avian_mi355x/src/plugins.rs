@@ -219,7 +219,7 @@ fn gpu_diagnostics(mut w: ResMut<Mi355xWorld>, mut solver: ResMut<SolverDiagnost
 /// Avian's own (src/dynamics/solver/islands/sleeping.rs:300-520) and are queued here exactly where `sleep_islands` queues them.
 fn gpu_sleeping(
     mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, time_to_sleep: Res<TimeToSleep>, length_unit: Res<PhysicsLengthUnit>, time: Res<Time>,
-    mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, mut commands: Commands,
+    mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, mut islands: ResMut<PhysicsIslands>, mut commands: Commands,
 ) {
     let st = &st.0;
     // world-level thresholds: per-body `SleepThreshold` overrides would travel as one more array of `avn_bodies` (not in the ABI yet)
@@ -227,11 +227,20 @@ fn gpu_sleeping(
     if stats.n_resting_islands == 0 && stats.n_waking_islands == 0 && stats.n_awake_bodies == 0 { return; }
     let (timer, _label, rests, wakes) = w.sleep_state(st.body_entities.len());
     let (mut to_sleep, mut to_wake) = (Vec::new(), Vec::new());
+    islands.split_candidate_sleep_timer = 0.0;
     for (i, &e) in st.body_entities.iter().enumerate() {
         let Ok((mut t, node)) = timers.get_mut(e) else { continue };
         t.0 = timer[i];
         if rests[i] != 0 { to_sleep.push(node.island_id); }
         if wakes[i] != 0 { to_wake.push(node.island_id); }
+        // the sleepiest body of an island that still has to be split picks the split candidate (sleeping.rs:231-239); the split itself is
+        // Avian's `split_island` in SolverSystems::Finalize of the next step, over the host's own contact graph
+        if timer[i] >= time_to_sleep.0 && timer[i] > islands.split_candidate_sleep_timer
+            && islands.get(node.island_id).is_some_and(|isl| isl.constraints_removed() > 0)
+        {
+            islands.split_candidate = Some(node.island_id);
+            islands.split_candidate_sleep_timer = timer[i];
+        }
     }
     to_sleep.sort_unstable(); to_sleep.dedup(); to_wake.sort_unstable(); to_wake.dedup();
     // (the reference additionally refuses to sleep an island with pending splits, `constraints_removed > 0`: PhysicsIslands still holds
