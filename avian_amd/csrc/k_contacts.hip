@@ -465,7 +465,9 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
 // (Tried and rejected, round 2 -- DESIGN.md section 4.1: compiler fences that put every level-1 load in flight before the first wait, and
 //  an L2 prefetch of the NEXT colour launch's records issued during the impulse chain.  cfg2, two runs each on one box: neither 2 468
 //  substeps/s | fences only 2 420 | prefetch only 2 359 | both 2 487 -- and the PMC pass showed the prefetch as 13 MB of EXTRA fetch traffic
-//  per launch (42.3 MB against 29.2 MB): the lines do not survive in L2 until the next launch.  +0.8 % for +45 % traffic: removed.)
+//  per launch (42.3 MB against 29.2 MB): the lines do not survive in L2 until the next launch.  +0.8 % for +45 % traffic: removed.
+//  Non-temporal (`nt`) loads / stores of the records, meant to keep the 9.6 MB of body records in L2 across launches: the PMC traffic
+//  stays at 29.3 MB per launch (the bodies are not retained either way) and the launch takes 9.26 us instead of 8.34: removed as well.)
 template <bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
