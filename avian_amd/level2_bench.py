@@ -9,10 +9,10 @@ import time
 import numpy as np
 
 
-def global_island(lib, F, scenes, nx, ny, nz, device, seed=5):
+def global_island(lib, F, scenes, nx, ny, nz, device, seed=5, bits=32):
     """The whole island, identical on every rank: bodies, the broad phase's pairs (found on this rank's GPU), face manifolds, colouring."""
     sc = scenes.box_stack(nx, ny, nz)
-    probe = F.World(lib, F.default_config(32, substeps=1, device=device))
+    probe = F.World(lib, F.default_config(bits, substeps=1, device=device))
     probe.bodies_upload(**sc.body_kwargs())
     probe.colliders_upload(**sc.collider_kwargs())
     probe.existing_pairs_upload(np.zeros(0, np.uint64))
@@ -26,17 +26,17 @@ def global_island(lib, F, scenes, nx, ny, nz, device, seed=5):
     return sc, scenes.permute_manifolds(mf, perm), offs
 
 
-def run(lib, rank, world_size, device, broadcast_bytes, all_reduce_max, barrier, dims=(50, 40, 50), substeps=4, steps=10, warmup=3, check_steps=3):
+def run(lib, rank, world_size, device, broadcast_bytes, all_reduce_max, barrier, dims=(50, 40, 50), substeps=4, steps=10, warmup=3, check_steps=3, bits=32):
     """broadcast_bytes(b: bytes | None) -> bytes (from rank 0); all_reduce_max(x: float) -> float; barrier()."""
     from avian_amd import _ffi as F, scenes, shard
     t_plan = time.perf_counter()
-    sc, pm, offs = global_island(lib, F, scenes, *dims, device=device)
+    sc, pm, offs = global_island(lib, F, scenes, *dims, device=device, bits=bits)
     plan = shard.level2_plan_lib(lib, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world_size)   # the library's planner (C ABI)
     mine = plan[rank]
     t_plan = time.perf_counter() - t_plan
 
     def make(split):
-        w = F.World(lib, F.default_config(32, substeps=substeps, device=device, use_graph=0 if split else 1))
+        w = F.World(lib, F.default_config(bits, substeps=substeps, device=device, use_graph=0 if split else 1))
         if split:
             w.bodies_upload(**{k: (np.asarray(v)[mine.bodies] if v is not None else None) for k, v in sc.body_kwargs().items()})
             scenes.upload_manifolds(w, shard.level2_local_manifolds(mine, pm), mine.color_offsets, sc.friction, sc.restitution)
@@ -84,7 +84,7 @@ def run(lib, rank, world_size, device, broadcast_bytes, all_reduce_max, barrier,
     n_send = int(len(mine.send_bodies)); n_recv = int(len(mine.recv_bodies))
     lists = int(np.count_nonzero(np.diff(mine.send_offsets.astype(np.int64)))) if len(mine.peers) else 0
     split.close(); single.close()
-    return {"status": "ok", "island": f"box stack {dims[0]}x{dims[1]}x{dims[2]} ({sc.n - 1} bodies, {len(pm['body1'])} manifolds), ONE island over {world_size} x-slabs",
+    return {"status": "ok", "scalar_bits": bits, "substeps": substeps, "island": f"box stack {dims[0]}x{dims[1]}x{dims[2]} ({sc.n - 1} bodies, {len(pm['body1'])} manifolds), ONE island over {world_size} x-slabs",
             "scaling": "strong", "bit_identical_to_unsplit_island": bool(all_ok), "checked_steps": check_steps,
             "ms_per_step_split": round(t_split / steps * 1e3, 4), "ms_per_step_unsplit_one_gpu": round(t_single / steps * 1e3, 4),
             "substeps_per_s_split": round(steps * substeps / t_split, 2),

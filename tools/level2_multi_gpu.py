@@ -19,6 +19,8 @@ def main():
     ap.add_argument("--dims", type=int, nargs=3, default=[50, 40, 50])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bits", type=int, default=32)
+    ap.add_argument("--substeps", type=int, default=4)
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -41,7 +43,7 @@ def main():
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
-    res = level2_bench.run(lib, rank, world, local, bcast, armax, dist.barrier, dims=tuple(args.dims), steps=args.steps, warmup=args.warmup)
+    res = level2_bench.run(lib, rank, world, local, bcast, armax, dist.barrier, dims=tuple(args.dims), steps=args.steps, warmup=args.warmup, bits=args.bits, substeps=args.substeps)
     if rank == 0:
         print(json.dumps(res))
     dist.destroy_process_group()
