@@ -29,16 +29,22 @@ def run_kat(lib, case, bits=32, **cfgkw):
               angular_velocity=arr("angular_velocity", None), inv_mass=arr("inv_mass", None),
               inv_inertia_local=arr("inv_inertia_local", None), rb_type=np.zeros(n, np.uint8),
               accel_linear=arr("accel_linear", [0, 0, 0]), accel_angular=arr("accel_angular", [0, 0, 0]))
-    w.bodies_upload(**kw)
-    for _ in range(case["steps"]):
-        # the reference's ForcePlugin re-applies the user's persistent force/acceleration every step and
-        # clear_velocity_increments (integrator/mod.rs:316-328) wipes it at the end of the step: re-upload like the ECS would
-        w.step()
-        if np.any(kw["accel_linear"]) or np.any(kw["accel_angular"]):
+    imp = arr("impulse_linear", [0, 0, 0])   # Forces::apply_linear_impulse in FixedUpdate: LinearVelocity += J / m BEFORE every physics step
+    impa = arr("impulse_angular", [0, 0, 0])  # apply_angular_impulse: AngularVelocity += I_world^-1 J (isotropic inertia in these tests: I^-1 = inv_inertia_local[0])
+    kick = np.any(imp) or np.any(impa)
+    reupload = kick or np.any(kw["accel_linear"]) or np.any(kw["accel_angular"])
+    for s in range(case["steps"]):
+        # the reference's ForcePlugin re-applies the user's persistent force / acceleration every step and clear_velocity_increments
+        # (integrator/mod.rs:316-328) wipes it at the end of the step: re-upload like the ECS would
+        if s > 0 and reupload:
             out = w.bodies_download()
-            kw.update(position=out["position"], rotation=out["rotation"], linear_velocity=out["linear_velocity"],
-                      angular_velocity=out["angular_velocity"])
+            kw.update(position=out["position"], rotation=out["rotation"], linear_velocity=out["linear_velocity"], angular_velocity=out["angular_velocity"])
+        if kick:
+            kw["linear_velocity"] = np.asarray(kw["linear_velocity"], np.float64) + imp * kw["inv_mass"][:, None]
+            kw["angular_velocity"] = np.asarray(kw["angular_velocity"], np.float64) + impa * kw["inv_inertia_local"][:, :1]
+        if s == 0 or reupload:
             w.bodies_upload(**kw)
+        w.step()
     w.synchronize()
     out = w.bodies_download()
     w.close()
@@ -56,6 +62,11 @@ def check_kat(out, case):
         elif field == "rotation_angle_between_z":  # glam Quat::angle_between = 2 acos(|dot|)
             a = e["value_rotation_z"]
             want = np.array([0.0, 0.0, math.sin(a / 2), math.cos(a / 2)])
+            got = out["rotation"][b].astype(np.float64)
+            diff = 2.0 * math.acos(min(1.0, abs(float(got @ want))))
+            assert diff < eps, f"{case['name']}: angle difference {diff} is not less than {eps}"
+        elif field == "rotation_angle_between":  # against an arbitrary quaternion
+            want = np.array(e["value_quat"], np.float64)
             got = out["rotation"][b].astype(np.float64)
             diff = 2.0 * math.acos(min(1.0, abs(float(got @ want))))
             assert diff < eps, f"{case['name']}: angle difference {diff} is not less than {eps}"
