@@ -432,6 +432,11 @@ template <class T> struct World : WorldBase {
                 island_mode = false; islands_dirty = false;
             }
             if (bad_j) { dw.n_joints = 0; h_j_body1.clear(); h_j_body2.clear(); h_j_damped.clear(); h_j_collision_disabled.clear(); h_j_type.clear(); any_damped = false; }
+            // a halo plan (level-2 sharding) names local body indices too: one that reaches past the new count is dropped with the rest
+            bool bad_h = false;
+            for (int32_t b : halo.send) bad_h = bad_h || (uint32_t)b >= n;
+            for (int32_t b : halo.recv) bad_h = bad_h || (uint32_t)b >= n;
+            if (bad_h) { halo = HaloPlan(); halo_on = false; }
             if (bad_c || pipe_on) { bp.n_colliders = 0; bp.n_intervals = 0; have_colliders = false; slot_entity.clear(); entity_slot.clear(); h_col_body.clear(); pipe_on = false; pipe_dev = false; }
         }
         dw.n_bodies = n;

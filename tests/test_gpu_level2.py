@@ -115,3 +115,9 @@ def test_halo_plan_without_communicator_is_refused():
         w.halo_plan_upload([1], [0] * 24 + [1], [10 ** 6], [0] * 24 + [1], [1])
     w.halo_plan_upload([], [], [], [], [])   # back to a plain world
     w.step()
+    # a plan that names a body the next, smaller upload no longer has is dropped with the manifolds that named it (no out-of-range gather)
+    last = sc.n - 1
+    w.halo_plan_upload([1], [0] * 24 + [1], [last], [0] * 24 + [1], [last])
+    small = {k: (np.asarray(v)[:last] if v is not None else None) for k, v in sc.body_kwargs().items()}
+    w.bodies_upload(**small)
+    w.step()
