@@ -194,7 +194,8 @@ class avn_level2_in(C.Structure):
 
 class avn_sleep_params(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("time_to_sleep", C.c_float), ("linear_threshold", C.c_float), ("angular_threshold", C.c_float),
-                ("delta_secs", C.c_float), ("length_unit", C.c_double)]
+                ("delta_secs", C.c_float), ("length_unit", C.c_double), ("body_linear_threshold", vp), ("body_angular_threshold", vp),
+                ("body_sleeping_disabled", vp)]
 
 
 class avn_sleep_stats(C.Structure):
@@ -718,9 +719,14 @@ class World:
         return lab, int(n.value)
 
     def sleep_update(self, delta_secs: float = 1.0 / 60.0, time_to_sleep: float = 0.5, linear_threshold: float = 0.15, angular_threshold: float = 0.15,
-                     length_unit: float = 1.0) -> avn_sleep_stats:
+                     length_unit: float = 1.0, body_linear_threshold=None, body_angular_threshold=None, body_sleeping_disabled=None) -> avn_sleep_stats:
         """``avn_sleep_update``: update_sleeping_states + the decision of sleep_islands for the step just taken."""
-        p = avn_sleep_params(C.sizeof(avn_sleep_params), time_to_sleep, linear_threshold, angular_threshold, delta_secs, length_unit)
+        bl = None if body_linear_threshold is None else np.ascontiguousarray(body_linear_threshold, np.float32)
+        ba = None if body_angular_threshold is None else np.ascontiguousarray(body_angular_threshold, np.float32)
+        bd = None if body_sleeping_disabled is None else np.ascontiguousarray(body_sleeping_disabled, np.uint8)
+        for a in (bl, ba, bd):
+            assert a is None or len(a) == self.n_bodies
+        p = avn_sleep_params(C.sizeof(avn_sleep_params), time_to_sleep, linear_threshold, angular_threshold, delta_secs, length_unit, _ptr(bl), _ptr(ba), _ptr(bd))
         st = avn_sleep_stats()
         self._check(self.lib.fn("sleep_update")(self.handle, C.byref(p), C.byref(st)))
         return st

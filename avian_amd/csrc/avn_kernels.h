@@ -222,7 +222,10 @@ template <class T> struct BodyStage {  // device staging copies of the avn_bodie
 };
 template <class T> void launch_pack_bodies(const DW<T>&, const BodyStage<T>&, hipStream_t);
 // islands and sleeping (k_islands.hip)
-template <class T> struct SleepParams { T length_unit_squared, lin_threshold_squared, ang_threshold_squared; float delta_secs, time_to_sleep; };
+template <class T> struct SleepParams {
+    T length_unit_squared, lin_threshold_squared, ang_threshold_squared; float delta_secs, time_to_sleep;
+    const float *body_lin, *body_ang; const uint8_t* body_disabled;   // optional per-body SleepThreshold / SleepingDisabled (device copies), nullptr = world level
+};
 template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t);
 template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,
                                             uint32_t* ctr /* [2] resting islands, [3] resting bodies, [4] waking islands, [5] their sleeping bodies, [6] sleeping bodies */, hipStream_t);

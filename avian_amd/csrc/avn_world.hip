@@ -2546,6 +2546,14 @@ template <class T> struct World : WorldBase {
         k.lin_threshold_squared = (T)(sp->linear_threshold * std::fabs(sp->linear_threshold));   // f32 product, "keep signs", then `as Scalar`
         k.ang_threshold_squared = (T)(sp->angular_threshold * std::fabs(sp->angular_threshold));
         k.delta_secs = sp->delta_secs; k.time_to_sleep = sp->time_to_sleep;
+        k.body_lin = nullptr; k.body_ang = nullptr; k.body_disabled = nullptr;
+        if (sp->body_linear_threshold || sp->body_angular_threshold || sp->body_sleeping_disabled) {
+            const size_t n = dw.n_bodies;
+            if ((st = stage_reserve(al(4 * n) * 2 + al(n) + 1024)) != AVN_OK) return st;
+            if ((st = stage_in<float>(sp->body_linear_threshold, n, &k.body_lin)) != AVN_OK) return st;
+            if ((st = stage_in<float>(sp->body_angular_threshold, n, &k.body_ang)) != AVN_OK) return st;
+            if ((st = stage_in<uint8_t>(sp->body_sleeping_disabled, n, &k.body_disabled)) != AVN_OK) return st;
+        }
         HIPCHK(hipMemsetAsync(b_isl_awake.p, 0, (size_t)std::max<uint32_t>(dw.n_bodies, 1) * 4, stream));
         launch_sleep_update<T>(dw, k, b_isl_label.as<uint32_t>(), b_sleep_timer.as<float>(), b_isl_awake.as<uint32_t>(), b_isl_rests.as<uint8_t>(), b_isl_wakes.as<uint8_t>(), b_isl_ctr.as<uint32_t>(), stream);
         launches += 2;

@@ -78,11 +78,19 @@ __global__ __launch_bounds__(256) void k_sleep_timers(DW<T> w, SleepParams<T> sp
     if (b >= w.n_bodies) return;
     const uint32_t l = label[b];
     if (l == 0xFFFFFFFFu) { timer[b] = 0.0f; return; }
+    if (sp.body_disabled && sp.body_disabled[b]) {   // SleepingDisabled (sleeping.rs:164-182): timer reset, island kept awake -- and woken if it sleeps
+        timer[b] = 0.0f;
+        atomicOr(&awake[l], (meta_flags(w.bmeta[b]) & AVN_BODY_SLEEPING) ? 3u : 1u);
+        return;
+    }
     if (meta_flags(w.bmeta[b]) & AVN_BODY_SLEEPING) { atomicOr(&awake[l], 2u); return; }   // Without<Sleeping>: the island holds a sleeper
     const V3<T> v = xyz<T>(w.sb_lin[b]), om = xyz<T>(w.sb_ang[b]);
     const T v2 = length_squared(v), w2 = length_squared(om);
+    T lin2 = sp.lin_threshold_squared, ang2 = sp.ang_threshold_squared;
+    if (sp.body_lin) { const float l = sp.body_lin[b]; lin2 = (T)(l * fabsf(l)); }     // "Keep signs.": f32 product, then `as Scalar`
+    if (sp.body_ang) { const float a = sp.body_ang[b]; ang2 = (T)(a * fabsf(a)); }
     float t = timer[b];
-    if (v2 < sp.length_unit_squared * sp.lin_threshold_squared && w2 < sp.ang_threshold_squared) t = t + sp.delta_secs;
+    if (v2 < sp.length_unit_squared * lin2 && w2 < ang2) t = t + sp.delta_secs;
     else t = 0.0f;
     timer[b] = t;
     if (t < sp.time_to_sleep) atomicOr(&awake[l], 1u);   // awake_island_bit_vec.set(island)

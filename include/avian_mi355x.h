@@ -669,6 +669,11 @@ typedef struct avn_sleep_params {
     float angular_threshold;      /* SleepThreshold.angular, default 0.15 */
     float delta_secs;             /* Time::delta_secs() of the step (f32) */
     double length_unit;           /* PhysicsLengthUnit, default 1 */
+    /* optional per-body components, host arrays of n_bodies entries (NULL = the world-level value above for every body) */
+    const float* body_linear_threshold;    /* SleepThreshold.linear of each body */
+    const float* body_angular_threshold;   /* SleepThreshold.angular */
+    const uint8_t* body_sleeping_disabled; /* 1 = SleepingDisabled: skipped by update_sleeping_states (`Without<SleepingDisabled>`), timer reset to 0
+                                              and its island kept awake (wake_islands_with_sleeping_disabled, sleeping.rs:164-182) */
 } avn_sleep_params;
 typedef struct avn_sleep_stats {
     uint32_t n_islands;                   /* islands of the current constraint graph */

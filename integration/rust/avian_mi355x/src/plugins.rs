@@ -219,11 +219,18 @@ fn gpu_diagnostics(mut w: ResMut<Mi355xWorld>, mut solver: ResMut<SolverDiagnost
 /// Avian's own (src/dynamics/solver/islands/sleeping.rs:300-520) and are queued here exactly where `sleep_islands` queues them.
 fn gpu_sleeping(
     mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, time_to_sleep: Res<TimeToSleep>, length_unit: Res<PhysicsLengthUnit>, time: Res<Time>,
-    mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, mut islands: ResMut<PhysicsIslands>, mut commands: Commands,
+    mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, thresholds: Query<(&SleepThreshold, Has<SleepingDisabled>)>,
+    mut islands: ResMut<PhysicsIslands>, mut commands: Commands,
 ) {
     let st = &st.0;
-    // world-level thresholds: per-body `SleepThreshold` overrides would travel as one more array of `avn_bodies` (not in the ABI yet)
-    let stats = w.sleep_update(time_to_sleep.0, (SleepThreshold::default().linear, SleepThreshold::default().angular), time.delta_secs(), length_unit.0 as f64);
+    // per-body `SleepThreshold` / `SleepingDisabled` in body order (avn_sleep_params.body_*), the world-level pair is only the fallback
+    let (mut lin, mut ang, mut off) = (Vec::with_capacity(st.body_entities.len()), Vec::with_capacity(st.body_entities.len()), Vec::with_capacity(st.body_entities.len()));
+    for &e in st.body_entities.iter() {
+        let (t, d) = thresholds.get(e).map_or((SleepThreshold::default(), false), |(t, d)| (*t, d));
+        lin.push(t.linear); ang.push(t.angular); off.push(d as u8);
+    }
+    let stats = w.sleep_update(time_to_sleep.0, (SleepThreshold::default().linear, SleepThreshold::default().angular), time.delta_secs(), length_unit.0 as f64,
+                               Some((&lin, &ang, &off)));
     if stats.n_resting_islands == 0 && stats.n_waking_islands == 0 && stats.n_awake_bodies == 0 { return; }
     let (timer, _label, rests, wakes) = w.sleep_state(st.body_entities.len());
     let (mut to_sleep, mut to_wake) = (Vec::new(), Vec::new());

@@ -104,7 +104,8 @@ impl Mi355xWorld {
 impl Mi355xWorld {
     /// `update_sleeping_states` + the decision of `sleep_islands` for the step just taken (src/dynamics/solver/islands/sleeping.rs:184-280).
     /// The caller (the Sleeping set's system in `plugins.rs`) applies it: `SleepIslands` / `WakeIslands` stay host-side.
-    pub fn sleep_update(&mut self, time_to_sleep: f32, threshold: (f32, f32), delta_secs: f32, length_unit: f64) -> ffi::avn_sleep_stats {
+    pub fn sleep_update(&mut self, time_to_sleep: f32, threshold: (f32, f32), delta_secs: f32, length_unit: f64,
+                        per_body: Option<(&[f32], &[f32], &[u8])>) -> ffi::avn_sleep_stats {
         let p = ffi::avn_sleep_params {
             struct_size: core::mem::size_of::<ffi::avn_sleep_params>() as u32,
             time_to_sleep,
@@ -112,6 +113,10 @@ impl Mi355xWorld {
             angular_threshold: threshold.1,
             delta_secs,
             length_unit,
+            // per-body `SleepThreshold` / `SleepingDisabled`: staged by the caller when any body overrides the defaults (plugins.rs)
+            body_linear_threshold: per_body.map_or(core::ptr::null(), |p| p.0.as_ptr()),
+            body_angular_threshold: per_body.map_or(core::ptr::null(), |p| p.1.as_ptr()),
+            body_sleeping_disabled: per_body.map_or(core::ptr::null(), |p| p.2.as_ptr()),
         };
         let mut stats = unsafe { core::mem::zeroed::<ffi::avn_sleep_stats>() };
         let st = unsafe { ffi::avn_sleep_update(self.raw, &p, &mut stats) };

@@ -1917,12 +1917,21 @@ template <class S> struct World : WorldBase {
         uint32_t sleeping_bodies = 0;
         for (size_t b = 0; b < n; ++b) {
             if (isl_label[b] == 0xFFFFFFFFu) { sleep_timer[b] = 0.0f; continue; }
-            if (bodies[b].body_flags & AVN_BODY_SLEEPING) { is_sleeping[isl_label[b]] = 1; ++sleeping_bodies; continue; }   // query filter Without<Sleeping>
+            if (bodies[b].body_flags & AVN_BODY_SLEEPING) ++sleeping_bodies;
+            // wake_islands_with_sleeping_disabled (sleeping.rs:164-182; the reference chains it after update_sleeping_states, whose query skips these bodies)
+            if (sp->body_sleeping_disabled && sp->body_sleeping_disabled[b]) {
+                awake[isl_label[b]] = 1; sleep_timer[b] = 0.0f;
+                if (bodies[b].body_flags & AVN_BODY_SLEEPING) is_sleeping[isl_label[b]] = 1;
+                continue;
+            }
+            if (bodies[b].body_flags & AVN_BODY_SLEEPING) { is_sleeping[isl_label[b]] = 1; continue; }   // query filter Without<Sleeping>
             const SolverBody<S>& sb = bodies[b].sb;
             const S lin_vel_squared = length_squared(sb.linear_velocity), ang_vel_squared = length_squared(sb.angular_velocity);
             // "Keep signs."
-            const float lin_threshold_squared = sp->linear_threshold * std::fabs(sp->linear_threshold);
-            const float ang_threshold_squared = sp->angular_threshold * std::fabs(sp->angular_threshold);
+            const float lt = sp->body_linear_threshold ? sp->body_linear_threshold[b] : sp->linear_threshold;
+            const float at = sp->body_angular_threshold ? sp->body_angular_threshold[b] : sp->angular_threshold;
+            const float lin_threshold_squared = lt * std::fabs(lt);
+            const float ang_threshold_squared = at * std::fabs(at);
             if (lin_vel_squared < length_unit_squared * (S)lin_threshold_squared && ang_vel_squared < (S)ang_threshold_squared) sleep_timer[b] += delta_secs;
             else sleep_timer[b] = 0.0f;
             if (sleep_timer[b] < sp->time_to_sleep) awake[isl_label[b]] = 1;

@@ -137,3 +137,33 @@ def test_sleeping_and_disabled_bodies_on_hip():
             for k in ga:
                 assert np.array_equal(ga[k], gb[k]), (bits, k)
         assert res[0][1][0][6:] == [1, 2], "the moving body wakes the sleeping island it was linked to"
+
+
+def test_per_body_thresholds_and_sleeping_disabled_on_hip():
+    rng = np.random.default_rng(3)
+    sc = scenes.box_stacks(40, 1, 2, 1, gap=3.0)     # 40 islands of two stacked boxes
+    b = sc.body_kwargs()
+    b["linear_velocity"] = rng.normal(scale=0.1, size=(sc.n, 3)); b["angular_velocity"] = rng.normal(scale=0.06, size=(sc.n, 3)); b["gravity_scale"] = np.zeros(sc.n)
+    flags = np.zeros(sc.n, np.uint8); flags[rng.random(sc.n) < 0.15] = F.BODY_SLEEPING
+    b["body_flags"] = flags
+    pairs = scenes.brute_force_pairs(sc)
+    mf = scenes.axis_aligned_manifolds(sc, pairs)
+    lin = rng.uniform(-0.05, 0.6, sc.n).astype(np.float32); ang = rng.uniform(-0.02, 0.4, sc.n).astype(np.float32); off = (rng.random(sc.n) < 0.1).astype(np.uint8)
+    for bits in (32, 64):
+        res = []
+        for lib in (hip_lib(), oracle_lib()):
+            offs, perm = scenes.color_manifolds(oracle_lib(), mf, sc.rb_type)
+            w = F.World(lib, F.default_config(bits, substeps=1))
+            w.bodies_upload(**b)
+            scenes.upload_manifolds(w, scenes.permute_manifolds(mf, perm), offs, sc.friction, 0.0)
+            w.run_system("PREPARE_SOLVER_BODIES")
+            out = []
+            for _ in range(3):
+                st = w.sleep_update(delta_secs=0.3, time_to_sleep=0.5, body_linear_threshold=lin, body_angular_threshold=ang, body_sleeping_disabled=off)
+                out.append(([getattr(st, f) for f, _ in st._fields_], w.sleep_get()))
+            res.append(out)
+        for (sa, ga), (sb, gb) in zip(*res):
+            assert sa == sb, (bits, sa, sb)
+            for k in ga:
+                assert np.array_equal(ga[k], gb[k]), (bits, k)
+        assert res[0][-1][0][4] > 0 and res[0][-1][0][6] > 0, "the scene must produce resting and waking islands"

@@ -186,3 +186,29 @@ def test_partitioner_fed_by_the_library_islands():
     b = shard.plan_from_world(lib, w, sc.rb_type, sc.position, 2)
     assert a.n_islands == b.n_islands == 5
     assert np.array_equal(a.island_of_body, b.island_of_body) and np.array_equal(a.rank_of_body, b.rank_of_body)
+
+
+def test_per_body_thresholds_and_sleeping_disabled():
+    """SleepThreshold per body and SleepingDisabled (sleeping.rs:164-241): a disabled body never accumulates time and keeps its whole island
+    awake; a body with a larger threshold rests while its equally fast neighbour does not."""
+    lib = oracle_lib()
+    sc = scenes.box_stacks(4, 1, 1, 1, gap=3.0)     # ground + 4 separate boxes
+    b = sc.body_kwargs()
+    v = np.zeros((sc.n, 3)); v[1:] = [0.2, 0, 0]
+    b["linear_velocity"] = v; b["gravity_scale"] = np.zeros(sc.n)
+    w = F.World(lib, F.default_config(32, substeps=1))
+    w.bodies_upload(**b)
+    J = dict(body1=np.array([3], np.int32), body2=np.array([4], np.int32), local_anchor1=np.zeros((1, 3)), local_anchor2=np.zeros((1, 3)),
+             limit_min=np.zeros(1), limit_max=np.full(1, 100.0), compliance=np.zeros(1))
+    w.distance_joints_upload(**J)
+    w.run_system("PREPARE_SOLVER_BODIES")
+    lin = np.array([0.15, 0.15, 0.3, 0.3, 0.3], np.float32)      # body 1 keeps the default and is too fast; 2, 3, 4 may rest at |v| = 0.2
+    off = np.array([0, 0, 0, 1, 0], np.uint8)                    # body 3 has SleepingDisabled: island {3, 4} stays awake
+    st = w.sleep_update(delta_secs=1.0, time_to_sleep=0.5, body_linear_threshold=lin, body_sleeping_disabled=off)
+    g = w.sleep_get()
+    assert g["island"].tolist() == [NONE, 1, 2, 3, 3]
+    assert g["sleep_timer"].tolist() == [0, 0, 1, 0, 1] and g["island_rests"].tolist() == [0, 0, 1, 0, 0]
+    assert (st.n_resting_islands, st.n_resting_bodies) == (1, 1)
+    ang = np.array([0.15, 0.15, -0.15, 0.15, 0.15], np.float32)   # a negative angular threshold never lets body 2 rest
+    st = w.sleep_update(delta_secs=1.0, time_to_sleep=0.5, body_linear_threshold=lin, body_angular_threshold=ang, body_sleeping_disabled=off)
+    assert w.sleep_get()["sleep_timer"].tolist() == [0, 0, 0, 0, 2] and st.n_resting_islands == 0
