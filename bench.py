@@ -415,7 +415,7 @@ def main():
         line_holder = {}
 
         def watchdog():
-            if not done.wait(float(os.environ.get("AVN_BENCH_LEVEL2_TIMEOUT", "300"))):
+            if not done.wait(float(os.environ.get("AVN_BENCH_LEVEL2_TIMEOUT", "120"))):
                 if rank == 0 and "make" in line_holder:
                     part = dict(line_holder.get("partial") or {}, status="timeout" if "partial" not in line_holder else "ok (cfg5 leg timed out)")
                     print(json.dumps(line_holder["make"](part)), flush=True)
