@@ -226,7 +226,8 @@ template <class T> struct SleepParams {
     T length_unit_squared, lin_threshold_squared, ang_threshold_squared; float delta_secs, time_to_sleep;
     const float *body_lin, *body_ang; const uint8_t* body_disabled;   // optional per-body SleepThreshold / SleepingDisabled (device copies), nullptr = world level
 };
-template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t);
+template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t,
+                                       uint32_t solver_nodes = 0u /* 1: only bodies with a SolverBody connect (island-block builder) */);
 template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,
                                             uint32_t* ctr /* [2] resting islands, [3] resting bodies, [4] waking islands, [5] their sleeping bodies, [6] sleeping bodies */, hipStream_t);
 void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32_t n_bodies, hipStream_t);

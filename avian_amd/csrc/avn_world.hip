@@ -653,9 +653,24 @@ template <class T> struct World : WorldBase {
         auto has_sb = [&](int32_t b) { return b >= 0 && (uint32_t)b < N && h_body_has_sb[(uint32_t)b]; };
         std::vector<uint32_t>& parent = isl_parent;
         parent.resize(N);
-        for (uint32_t i = 0; i < N; ++i) parent[i] = i;
+        bool labelled = false;
+        static const bool host_labels = getenv("AVN_ISLAND_LABELS_HOST") != nullptr;   // A/B: the host union-find below
+        if (pipe_dev && !host_labels) {
+            // device closed loop: the manifolds' bodies are on the device already -- label the islands there (k_islands.hip: lock-free
+            // union-find, root = lowest body index, only bodies with a SolverBody connect) and fetch 4 bytes per body; parent[] then holds
+            // roots directly
+            avn_status st = island_buffers();
+            if (st != AVN_OK) return st;
+            HIPCHK(hipMemsetAsync(b_isl_ctr.p, 0, 64, stream));
+            launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream, 1u);
+            launches += 3;
+            HIPCHK(hipMemcpyAsync(parent.data(), b_isl_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            for (uint32_t i = 0; i < N; ++i) if (parent[i] == 0xFFFFFFFFu) parent[i] = i;   // (bodies without a SolverBody: never asked)
+            labelled = true;
+        } else for (uint32_t i = 0; i < N; ++i) parent[i] = i;
         auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
-        for (uint32_t m = 0; m < M; ++m) {
+        for (uint32_t m = 0; m < M && !labelled; ++m) {
             int32_t a = h_m_body1[m], b = h_m_body2[m];
             if (has_sb(a) && has_sb(b)) { uint32_t ra = find((uint32_t)a), rb = find((uint32_t)b); if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); }
         }

@@ -36,7 +36,12 @@ __device__ __forceinline__ void cc_union(uint32_t* L, uint32_t a, uint32_t b) {
 }
 
 // a body with a BodyIslandNode (islands/mod.rs:96-140): dynamic or kinematic, not disabled; sleeping bodies keep theirs
-__device__ __forceinline__ bool island_node(uint32_t bmeta) { return meta_rb_type(bmeta) != AVN_RB_STATIC && !(meta_flags(bmeta) & AVN_BODY_DISABLED); }
+__device__ __forceinline__ bool island_node(uint32_t bmeta, uint32_t solver_nodes = 0u) {
+    // solver_nodes: the island-BLOCK builder's notion (avn_world.hip rebuild_island_blocks) -- only bodies that own a SolverBody connect, a
+    // sleeping body is as inert as a static one inside the solver
+    if (solver_nodes) return meta_has_solver_body(bmeta);
+    return meta_rb_type(bmeta) != AVN_RB_STATIC && !(meta_flags(bmeta) & AVN_BODY_DISABLED);
+}
 
 template <class T>
 __global__ __launch_bounds__(256) void k_cc_init(DW<T> w, uint32_t* __restrict__ L) {
@@ -44,21 +49,21 @@ __global__ __launch_bounds__(256) void k_cc_init(DW<T> w, uint32_t* __restrict__
     if (b < w.n_bodies) L[b] = b;
 }
 template <class T>
-__global__ __launch_bounds__(256) void k_cc_edges(DW<T> w, const int2* __restrict__ edges, uint32_t n, uint32_t* __restrict__ L) {
+__global__ __launch_bounds__(256) void k_cc_edges(DW<T> w, const int2* __restrict__ edges, uint32_t n, uint32_t* __restrict__ L, uint32_t solver_nodes) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const int2 e = edges[i];
     if (e.x < 0 || e.y < 0 || (uint32_t)e.x >= w.n_bodies || (uint32_t)e.y >= w.n_bodies || e.x == e.y) return;
-    if (!island_node(w.bmeta[e.x]) || !island_node(w.bmeta[e.y])) return;
+    if (!island_node(w.bmeta[e.x], solver_nodes) || !island_node(w.bmeta[e.y], solver_nodes)) return;
     cc_union(L, (uint32_t)e.x, (uint32_t)e.y);
 }
 // labels out (lowest body index of the island, PG_NONE for static bodies) + ctr[0] = islands, ctr[1] = island bodies
 template <class T>
-__global__ __launch_bounds__(256) void k_cc_finish(DW<T> w, uint32_t* __restrict__ L, uint32_t* __restrict__ label, uint32_t* __restrict__ ctr) {
+__global__ __launch_bounds__(256) void k_cc_finish(DW<T> w, uint32_t* __restrict__ L, uint32_t* __restrict__ label, uint32_t* __restrict__ ctr, uint32_t solver_nodes) {
     const uint32_t b = blockIdx.x * 256 + threadIdx.x;
     bool node = false, root = false;
     if (b < w.n_bodies) {
-        node = island_node(w.bmeta[b]);
+        node = island_node(w.bmeta[b], solver_nodes);
         uint32_t r = 0xFFFFFFFFu;
         if (node) { r = cc_find(L, b); root = r == b; }
         label[b] = r;
@@ -130,13 +135,13 @@ __global__ __launch_bounds__(256) void k_sleep_reset(float* __restrict__ timer, 
     if (b < n_bodies) timer[b] = 0.0f;
 }
 
-template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t s) {
+template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t s, uint32_t solver_nodes) {
     if (!w.n_bodies) return;
     const uint32_t nb = (w.n_bodies + 255) / 256;
     hipLaunchKernelGGL(k_cc_init<T>, dim3(nb), dim3(256), 0, s, w, parent);
-    if (w.n_manifolds) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, (const int2*)w.m_bodies, w.n_manifolds, parent);
-    if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent);
-    hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr);
+    if (w.n_manifolds) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, (const int2*)w.m_bodies, w.n_manifolds, parent, solver_nodes);
+    if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent, solver_nodes);
+    hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr, solver_nodes);
 }
 template <class T> void launch_sleep_update(const DW<T>& w, const SleepParams<T>& sp, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes, uint32_t* ctr, hipStream_t s) {
     if (!w.n_bodies) return;
@@ -149,7 +154,7 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
 }
 
 #define INST(T)                                                                                              \
-    template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t);            \
+    template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t, uint32_t);            \
     template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint8_t*, uint32_t*, hipStream_t);
 INST(float)
 INST(double)
