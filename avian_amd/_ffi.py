@@ -187,6 +187,11 @@ class avn_diagnostics(C.Structure):
                [(n, C.c_uint32) for n in ("contact_constraint_count", "contact_count", "per_system_valid", "reserved0")]
 
 
+class avn_slab_in(C.Structure):
+    _fields_ = [("n_colliders", C.c_uint32), ("aabb_min_x", vp), ("aabb_max_x", vp), ("prev_order", vp), ("n_prev", C.c_uint32),
+                ("n_ranks", C.c_uint32), ("rank", C.c_uint32)]
+
+
 class avn_level2_in(C.Structure):
     _fields_ = [("n_bodies", C.c_uint32), ("rb_type", vp), ("center_x", vp), ("n_manifolds", C.c_uint32), ("body1", vp), ("body2", vp),
                 ("color_offsets", vp), ("n_ranks", C.c_uint32)]
@@ -224,7 +229,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -260,6 +265,8 @@ class Library:
         f("run_color_pass").argtypes = [vp, C.c_int, C.c_uint32]
         f("halo_pack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.POINTER(C.c_size_t)]
         f("halo_unpack").argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t]
+        f("slab_select").argtypes = [C.POINTER(avn_slab_in), vp, vp, C.POINTER(C.c_uint32), vp, C.POINTER(C.c_uint32)]
+        f("interval_orders_merge").argtypes = [C.c_uint32, vp, vp, vp, vp, C.POINTER(C.c_uint32)]
         f("level2_plan_create").argtypes = [C.POINTER(avn_level2_in), C.POINTER(vp)]
         f("level2_plan_destroy").argtypes = [vp]
         f("level2_plan_destroy").restype = None
@@ -302,6 +309,32 @@ class Library:
 
     def pair_key(self, a: int, b: int) -> int:
         return int(self.fn("pair_key")(a, b))
+
+    def slab_select(self, aabb_min_x, aabb_max_x, prev_order, n_ranks: int, rank: int, want_next: bool = True):
+        """``avn_slab_select``: (local collider indices in the persistent order, owned mask, next frame's prev_order or None)."""
+        mn = np.ascontiguousarray(aabb_min_x, np.float64); mx = np.ascontiguousarray(aabb_max_x, np.float64)
+        po = None if prev_order is None else np.ascontiguousarray(prev_order, np.uint32)
+        n = len(mn)
+        inp = avn_slab_in(n, _ptr(mn), _ptr(mx), _ptr(po), 0 if po is None else len(po), int(n_ranks), int(rank))
+        local = np.zeros(max(n, 1), np.uint32); owned = np.zeros(max(n, 1), np.uint8); nxt = np.zeros(max(n, 1), np.uint32)
+        nl, nn = C.c_uint32(), C.c_uint32()
+        st = self.fn("slab_select")(C.byref(inp), _ptr(local), _ptr(owned), C.byref(nl), _ptr(nxt) if want_next else None, C.byref(nn))
+        if st != 0:
+            raise AvnError(st, "slab_select: bad arguments")
+        return local[: nl.value].astype(np.int64), owned[: nl.value].astype(bool), (nxt[: nn.value].astype(np.int64) if want_next else None)
+
+    def interval_orders_merge(self, entity_lists, key_lists):
+        """``avn_interval_orders_merge``: the merged global interval order (entity indices)."""
+        ents = [np.ascontiguousarray(e, np.uint32) for e in entity_lists]; keys = [np.ascontiguousarray(k, np.float64) for k in key_lists]
+        L = len(ents)
+        ep = (vp * L)(*[e.ctypes.data_as(vp) for e in ents]); kp = (vp * L)(*[k.ctypes.data_as(vp) for k in keys])
+        lens = np.array([len(e) for e in ents], np.uint32)
+        out = np.zeros(max(int(lens.sum()), 1), np.uint32)
+        n = C.c_uint32()
+        st = self.fn("interval_orders_merge")(L, ep, kp, _ptr(lens), _ptr(out), C.byref(n))
+        if st != 0:
+            raise AvnError(st, "interval_orders_merge: bad arguments")
+        return out[: n.value].astype(np.int64)
 
     def level2_plan(self, rb_type, center_x, body1, body2, color_offsets, n_ranks: int):
         """``avn_level2_plan_*``: per rank a dict(bodies, manifolds, color_offsets, peers, send_offsets, send_bodies, recv_offsets, recv_bodies)."""

@@ -1,8 +1,10 @@
-// avn_level2.cpp — the level-2 sharding planner behind the C ABI (include/avian_mi355x.h: avn_level2_plan_*).  Host integer work only.
+// avn_level2.cpp — the host planners of the multi-GPU modes behind the C ABI (include/avian_mi355x.h: avn_level2_plan_*, avn_slab_select,
+// avn_interval_orders_merge).  Host integer work only.
 #include <algorithm>
 #include <map>
 #include <new>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/avian_mi355x.h"
@@ -105,6 +107,84 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
 }
 
 AVN_API void avn_level2_plan_destroy(avn_level2_plan* plan) { delete plan; }
+
+AVN_API avn_status avn_slab_select(const avn_slab_in* in, uint32_t* local, uint8_t* owned, uint32_t* n_local, uint32_t* next_order, uint32_t* n_next) {
+    if (!in || !local || !owned || !n_local || in->n_ranks == 0 || in->rank >= in->n_ranks || (in->n_colliders && (!in->aabb_min_x || !in->aabb_max_x)) ||
+        (in->n_prev && !in->prev_order) || (next_order && !n_next))
+        return AVN_ERR_BAD_ARG;
+    try {
+        const uint32_t n = in->n_colliders, R = in->n_ranks;
+        for (uint32_t i = 0; i < in->n_prev; ++i) if (in->prev_order[i] >= n) return AVN_ERR_BAD_ARG;
+        // the persistent order before this frame's sort: prev_order, then the colliders it does not know yet
+        std::vector<uint32_t> po;
+        po.reserve(n);
+        std::vector<uint8_t> seen(n, 0);
+        if (in->prev_order) for (uint32_t i = 0; i < in->n_prev; ++i) { if (seen[in->prev_order[i]]) return AVN_ERR_BAD_ARG; seen[in->prev_order[i]] = 1; po.push_back(in->prev_order[i]); }
+        for (uint32_t c = 0; c < n; ++c) if (!seen[c]) po.push_back(c);
+        // slab boundaries on key values
+        std::vector<double> xs(in->aabb_min_x, in->aabb_min_x + n);
+        std::stable_sort(xs.begin(), xs.end(), [](double a, double b) { return a < b || (b != b && a == a); });   // NaN last, like a numeric sort
+        const double inf = 1.0 / 0.0;
+        std::vector<double> splits(R + 1, inf);
+        splits[0] = -inf;
+        for (uint32_t r = 1; r < R; ++r) splits[r] = n ? xs[std::min<size_t>(n - 1, (size_t)n * r / R)] : inf;
+        for (uint32_t r = 1; r <= R; ++r) splits[r] = std::max(splits[r], splits[r - 1]);
+        auto slab_of = [&](double x) {   // splits[s] <= x < splits[s + 1], clipped
+            int64_t s = (int64_t)(std::upper_bound(splits.begin(), splits.end(), x) - splits.begin()) - 1;
+            return (uint32_t)std::min<int64_t>(std::max<int64_t>(s, 0), (int64_t)R - 1);
+        };
+        double reach = -inf;
+        bool any = false;
+        for (uint32_t c = 0; c < n; ++c)
+            if (slab_of(in->aabb_min_x[c]) == in->rank) { any = true; const double m = in->aabb_max_x[c]; if (m != m || reach != reach) reach = 0.0 / 0.0; else reach = std::max(reach, m); }
+        uint32_t k = 0;
+        if (any)
+            for (uint32_t c : po) {
+                const uint32_t s = slab_of(in->aabb_min_x[c]);
+                const bool own = s == in->rank, halo = s > in->rank && in->aabb_min_x[c] <= reach;
+                if (own || halo) { local[k] = c; owned[k] = own ? 1 : 0; ++k; }
+            }
+        *n_local = k;
+        if (next_order) {
+            std::vector<std::pair<double, uint32_t>> keyed;   // (key, position in po): a stable sort on the key alone
+            std::vector<uint32_t> fin;
+            for (uint32_t c : po) { const double x = in->aabb_min_x[c] + 0.0; if (x - x == 0.0) fin.push_back(c); }   // finite keys only
+            std::stable_sort(fin.begin(), fin.end(), [&](uint32_t a, uint32_t b) { return in->aabb_min_x[a] + 0.0 < in->aabb_min_x[b] + 0.0; });
+            for (size_t i = 0; i < fin.size(); ++i) next_order[i] = fin[i];
+            *n_next = (uint32_t)fin.size();
+        }
+        return AVN_OK;
+    } catch (const std::bad_alloc&) { return AVN_ERR_OOM; } catch (...) { return AVN_ERR_STATE; }
+}
+
+AVN_API avn_status avn_interval_orders_merge(uint32_t n_lists, const uint32_t* const* entities, const double* const* keys, const uint32_t* lengths, uint32_t* out, uint32_t* n_out) {
+    if (!n_out || (n_lists && (!entities || !keys || !lengths))) return AVN_ERR_BAD_ARG;
+    try {
+        std::vector<uint32_t> head(n_lists, 0);
+        std::vector<uint32_t> merged;
+        uint32_t max_e = 0;
+        for (uint32_t l = 0; l < n_lists; ++l) for (uint32_t i = 0; i < lengths[l]; ++i) max_e = std::max(max_e, entities[l][i]);
+        std::vector<uint8_t> seen((size_t)max_e + 1, 0);
+        const double ninf = -1.0 / 0.0;
+        auto key_of = [&](uint32_t l, uint32_t i) { const double k = keys[l][i]; return k != k ? ninf : k; };
+        for (;;) {
+            int best = -1;
+            for (uint32_t l = 0; l < n_lists; ++l) {
+                if (head[l] >= lengths[l]) continue;
+                if (best < 0) { best = (int)l; continue; }
+                const double ka = key_of(l, head[l]), kb = key_of((uint32_t)best, head[best]);
+                const uint32_t ea = entities[l][head[l]], eb = entities[best][head[best]];
+                if (ka < kb || (ka == kb && ea < eb)) best = (int)l;
+            }
+            if (best < 0) break;
+            const uint32_t e = entities[best][head[best]++];
+            if (!seen[e]) { seen[e] = 1; merged.push_back(e); }
+        }
+        if (out) for (size_t i = 0; i < merged.size(); ++i) out[i] = merged[i];
+        *n_out = (uint32_t)merged.size();
+        return AVN_OK;
+    } catch (const std::bad_alloc&) { return AVN_ERR_OOM; } catch (...) { return AVN_ERR_STATE; }
+}
 
 AVN_API avn_status avn_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out) {
     if (!plan || !out || rank >= plan->ranks.size()) return AVN_ERR_BAD_ARG;

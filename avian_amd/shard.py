@@ -223,7 +223,7 @@ def repartition(lib: F.Library, states: List["RankState"], aabb: List[Tuple[np.n
     cross = aabb_cross_pairs(states, aabb, static)
     edges = [known, cross] + ([np.asarray(joints_edges).reshape(-1, 2)] if joints_edges is not None else [])
     pl = plan(lib, rb_type, glob_b["position"], np.concatenate(edges), world_size)
-    order = merge_interval_orders(states)
+    order = lib.interval_orders_merge([st.order for st in states], [st.order_key for st in states])   # (numpy twin: merge_interval_orders)
     out = []
     for r in range(world_size):
         loc = pl.local_bodies(r)
@@ -369,8 +369,9 @@ def slab_broad_phase_step(lib: F.Library, bits: int, bodies: Dict[str, np.ndarra
     prev_order: the single world's interval order BEFORE this frame (slab_next_order of the previous frame; None on the first
     frame).  The sub-world is uploaded in that order, so ties in min.x break as in the persistent single world -- with None
     they break by upload index, which is the single world's behaviour only on its first frame."""
-    pl = slab_plan(aabb_min_x, world_size)
-    local, owned = slab_colliders(pl, rank, aabb_min_x, aabb_max_x, prev_order)
+    # the planner behind the ABI (avn_slab_select, host C++); slab_plan / slab_colliders / slab_next_order above are the same rule in numpy,
+    # kept as its independent check (tests/test_planners_cpu.py)
+    local, owned, _ = lib.slab_select(aabb_min_x, aabb_max_x, prev_order, world_size, rank, want_next=False)
     mine = np.zeros(0, PAIR_DTYPE_LOCAL)
     if len(local):
         b, c, _ = slab_subworld(bodies, colliders, local)

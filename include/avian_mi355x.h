@@ -572,6 +572,28 @@ AVN_API avn_status AVN_FN(halo_plan_upload)(avn_world* w, const avn_halo_plan* p
 AVN_API avn_status AVN_FN(run_color_pass)(avn_world* w, avn_system pass, uint32_t color);
 AVN_API avn_status AVN_FN(halo_pack)(avn_world* w, uint32_t color, uint32_t peer, void* out /* [8 * count] scalars */, size_t* count);
 AVN_API avn_status AVN_FN(halo_unpack)(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count);
+/* ---- host planners of the x-slab sharded broad phase and of the re-partition (integer work, no device) -------------
+ * avn_slab_select: slabs are balanced contiguous ranges of the colliders sorted by AABB min.x, cut ON key values (colliders with equal
+ * min.x never straddle a cut); rank r's sub-world = the colliders it owns + the later ones its owned intervals can reach (min.x <= the
+ * largest max.x it owns), listed in the single world's PERSISTENT interval order (prev_order: the order before this frame's sort, NULL =
+ * upload order; colliders not in it are appended, broad_phase.rs:296-315).  next_order = that order after this frame's stable sort
+ * (-0.0 == +0.0, non-finite keys dropped, :230-279, :479-487): next frame's prev_order, identical on every rank. */
+typedef struct avn_slab_in {
+    uint32_t n_colliders;
+    const double* aabb_min_x;    /* [n] */
+    const double* aabb_max_x;    /* [n] */
+    const uint32_t* prev_order;  /* [n_prev] collider indices, or NULL */
+    uint32_t n_prev;
+    uint32_t n_ranks, rank;
+} avn_slab_in;
+AVN_API avn_status AVN_FN(slab_select)(const avn_slab_in* in, uint32_t* local /* [n] */, uint8_t* owned /* [n] */, uint32_t* n_local,
+                                       uint32_t* next_order /* [n], may be NULL */, uint32_t* n_next);
+/* avn_interval_orders_merge: the global persistent interval order out of the ranks' orders when islands migrate (shard.repartition): k-way
+ * merge on (the min.x each list is sorted by, entity index) that never reorders one list's own entries; an entity present in several lists
+ * (static bodies) is kept once; a NaN key (never swept) sorts first. */
+AVN_API avn_status AVN_FN(interval_orders_merge)(uint32_t n_lists, const uint32_t* const* entities, const double* const* keys, const uint32_t* lengths,
+                                                 uint32_t* out /* [sum of lengths] */, uint32_t* n_out);
+
 /* The level-2 planner (host integer work, no device): which world owns which manifold, which bodies each world holds, and the per-colour
  * send / receive lists -- everything avn_halo_plan_upload and the per-rank uploads need, so that a host in any language shards without
  * re-implementing it.  Slabs are cut at the quantiles of the non-static bodies' x; a manifold belongs to the slab of its body1 (body2 when

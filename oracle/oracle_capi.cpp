@@ -3,6 +3,7 @@
 #define AVN_PREFIX_ORACLE 1
 #include "avo_world.hpp"
 
+#include <cmath>
 #include <new>
 #include <set>
 
@@ -154,6 +155,74 @@ avn_status avo_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_
     out->halo.n_peers = (uint32_t)k.peers.size(); out->halo.peer_rank = k.peers.data();
     out->halo.send_offsets = k.send_offsets.data(); out->halo.send_bodies = k.send_bodies.data();
     out->halo.recv_offsets = k.recv_offsets.data(); out->halo.recv_bodies = k.recv_bodies.data();
+    return AVN_OK;
+}
+
+// Checkers for avn_slab_select / avn_interval_orders_merge (header), written the slow obvious way: slab of a collider = number of
+// boundaries at or below its key, orders by repeated selection.
+avn_status avo_slab_select(const avn_slab_in* in, uint32_t* local, uint8_t* owned, uint32_t* n_local, uint32_t* next_order, uint32_t* n_next) {
+    if (!in || !local || !owned || !n_local || in->n_ranks == 0 || in->rank >= in->n_ranks || (next_order && !n_next)) return AVN_ERR_BAD_ARG;
+    const uint32_t n = in->n_colliders, R = in->n_ranks;
+    std::vector<uint32_t> order;
+    std::vector<bool> have(n, false);
+    for (uint32_t i = 0; i < in->n_prev; ++i) { if (in->prev_order[i] >= n || have[in->prev_order[i]]) return AVN_ERR_BAD_ARG; have[in->prev_order[i]] = true; order.push_back(in->prev_order[i]); }
+    for (uint32_t c = 0; c < n; ++c) if (!have[c]) order.push_back(c);
+    std::vector<double> xs;
+    for (uint32_t c = 0; c < n; ++c) if (in->aabb_min_x[c] == in->aabb_min_x[c]) xs.push_back(in->aabb_min_x[c]);
+    std::sort(xs.begin(), xs.end());
+    for (uint32_t c = 0; c < n; ++c) if (in->aabb_min_x[c] != in->aabb_min_x[c]) xs.push_back(in->aabb_min_x[c]);   // NaNs last
+    std::vector<double> bound;   // boundaries 1 .. R - 1, made non-decreasing
+    for (uint32_t r = 1; r < R; ++r) {
+        double b = n ? xs[std::min<size_t>(n - 1, (size_t)n * r / R)] : HUGE_VAL;
+        if (!bound.empty() && !(b >= bound.back())) b = bound.back();
+        bound.push_back(b);
+    }
+    auto slab = [&](double x) { uint32_t s = 0; for (double b : bound) if (b <= x) ++s; if (x != x) s = R - 1; return std::min(s, R - 1); };
+    bool any = false, nan_reach = false;
+    double reach = -HUGE_VAL;
+    for (uint32_t c = 0; c < n; ++c) if (slab(in->aabb_min_x[c]) == in->rank) { any = true; if (in->aabb_max_x[c] != in->aabb_max_x[c]) nan_reach = true; else if (in->aabb_max_x[c] > reach) reach = in->aabb_max_x[c]; }
+    uint32_t k = 0;
+    if (any)
+        for (uint32_t c : order) {
+            const uint32_t s = slab(in->aabb_min_x[c]);
+            if (s == in->rank) { local[k] = c; owned[k++] = 1; }
+            else if (s > in->rank && !nan_reach && in->aabb_min_x[c] <= reach) { local[k] = c; owned[k++] = 0; }
+        }
+    *n_local = k;
+    if (next_order) {
+        std::vector<uint32_t> fin;
+        for (uint32_t c : order) if (std::isfinite(in->aabb_min_x[c])) fin.push_back(c);
+        // insertion sort (stable), like the reference's own (broad_phase.rs:479-487)
+        for (size_t i = 1; i < fin.size(); ++i) {
+            const uint32_t v = fin[i]; size_t j = i;
+            while (j > 0 && in->aabb_min_x[fin[j - 1]] + 0.0 > in->aabb_min_x[v] + 0.0) { fin[j] = fin[j - 1]; --j; }
+            fin[j] = v;
+        }
+        for (size_t i = 0; i < fin.size(); ++i) next_order[i] = fin[i];
+        *n_next = (uint32_t)fin.size();
+    }
+    return AVN_OK;
+}
+avn_status avo_interval_orders_merge(uint32_t n_lists, const uint32_t* const* entities, const double* const* keys, const uint32_t* lengths, uint32_t* out, uint32_t* n_out) {
+    if (!n_out || (n_lists && (!entities || !keys || !lengths))) return AVN_ERR_BAD_ARG;
+    std::vector<uint32_t> at(n_lists, 0);
+    std::set<uint32_t> done;
+    uint32_t k = 0;
+    while (true) {
+        int pick = -1;
+        for (uint32_t l = 0; l < n_lists; ++l) {
+            if (at[l] == lengths[l]) continue;
+            if (pick < 0) { pick = (int)l; continue; }
+            double a = keys[l][at[l]], b = keys[pick][at[pick]];
+            if (a != a) a = -HUGE_VAL;
+            if (b != b) b = -HUGE_VAL;
+            if (a < b || (a == b && entities[l][at[l]] < entities[pick][at[pick]])) pick = (int)l;
+        }
+        if (pick < 0) break;
+        const uint32_t e = entities[pick][at[pick]++];
+        if (done.insert(e).second) { if (out) out[k] = e; ++k; }
+    }
+    *n_out = k;
     return AVN_OK;
 }
 
