@@ -166,5 +166,71 @@ def check_pendulum_keeps_its_length(lib, bits):
     assert ymin < 3.1, "the bob swings down to the bottom of its arc"
 
 
-CHECKS = [check_free_fall, check_box_comes_to_rest, check_friction_cone, check_restitution, check_momentum_is_conserved, check_stack_stays_put,
+def _qrot(q, v):
+    q = np.asarray(q, np.float64); v = np.asarray(v, np.float64)
+    u, w = q[:3], q[3]
+    return v + 2.0 * np.cross(u, np.cross(u, v) + w * v)
+
+
+def _joint_world(lib, bits, jtype, vel=(0, 0, 0), ang=(0, 0, 0), substeps=8):
+    """A static anchor body at (0, 10, 0) and a dynamic 0.5 m box whose centre starts 1 m along +x, joined at the anchor body's centre."""
+    sc = Scene()
+    a = sc.add_ball((0, 10.0, 0), r=0.1); sc.rb[a] = F.RB_STATIC; sc.inv_m[a] = 0.0; sc.inv_i[a] = [0.0] * 6
+    b = sc.add_box((1.0, 10.0, 0), half=(0.25, 0.25, 0.25), vel=vel)
+    sc.ang[b] = list(map(float, ang))
+    w = sc.world(lib, bits, substeps=substeps)
+    w.joints_upload(joint_type=np.array([jtype], np.uint8), body1=np.array([a], np.int32), body2=np.array([b], np.int32),
+                    local_anchor1=np.zeros((1, 3)), local_anchor2=np.array([[-1.0, 0, 0]]), compliance=np.zeros((1, 3)))
+    return w, a, b
+
+
+def _anchor_gap(o, a, b):
+    pa = o["position"][a].astype(np.float64)
+    pb = o["position"][b].astype(np.float64) + _qrot(o["rotation"][b], [-1.0, 0, 0])
+    return float(np.linalg.norm(pa - pb))
+
+
+def check_fixed_joint_holds_the_pose(lib, bits):
+    """FixedJoint, compliance 0, to a static body: the box neither falls nor turns, whatever it was doing before."""
+    w, a, b = _joint_world(lib, bits, F.JOINT_FIXED, vel=(0.5, -0.5, 0.3), ang=(1.0, 2.0, -1.0))
+    outs = run(w, 120, every=1)
+    assert max(_anchor_gap(o, a, b) for o in outs[10:]) < 5e-3
+    q = outs[-1]["rotation"][b].astype(np.float64)
+    assert 2.0 * math.acos(min(1.0, abs(q[3]))) < 2e-2, "relative rotation stays the initial one (identity)"
+    assert np.abs(outs[-1]["position"][b] - np.array([1.0, 10.0, 0.0])).max() < 5e-3
+
+
+def check_revolute_joint_is_a_hinge(lib, bits):
+    """RevoluteJoint about Z: the arm swings down in the XY plane, its own Z axis never leaves the world's, the pivot stays in the anchor."""
+    w, a, b = _joint_world(lib, bits, F.JOINT_REVOLUTE, vel=(0, 0, 0.5), ang=(0.5, 0.5, 0))   # an out-of-plane kick the hinge must absorb
+    outs = run(w, 90, every=1)
+    assert max(_anchor_gap(o, a, b) for o in outs[10:]) < 5e-3
+    for o in outs[10:]:
+        z = _qrot(o["rotation"][b], [0, 0, 1.0])
+        assert abs(z[2]) > 1.0 - 1e-3, "the hinge axis of the arm stays parallel to the anchor body's"
+        assert abs(o["position"][b][2]) < 5e-3, "and the arm stays in the hinge plane"
+    assert min(o["position"][b][1] for o in outs) < 9.2, "it swings down"
+
+
+def check_spherical_joint_keeps_the_pivot(lib, bits):
+    w, a, b = _joint_world(lib, bits, F.JOINT_SPHERICAL, vel=(0, 0, 2.0), ang=(1.0, 0, 0))
+    outs = run(w, 90, every=1)
+    assert max(_anchor_gap(o, a, b) for o in outs[10:]) < 5e-3
+    assert max(abs(o["position"][b][2]) for o in outs) > 0.3, "a ball joint lets the arm leave the plane"
+    assert max(abs(np.linalg.norm(o["position"][b].astype(np.float64) - np.array([0, 10.0, 0])) - 1.0) for o in outs[10:]) < 5e-3
+
+
+def check_prismatic_joint_slides_along_its_axis(lib, bits):
+    """PrismaticJoint along X (no limits): gravity cannot pull the slider off its rail, the push along the rail is not resisted."""
+    w, a, b = _joint_world(lib, bits, F.JOINT_PRISMATIC, vel=(1.0, 0, 0))
+    out = run(w, 60)
+    p = out["position"][b].astype(np.float64)
+    assert abs(p[0] - 2.0) < 0.02, f"x = {p[0]} after 1 s at 1 m/s from x = 1"
+    assert abs(p[1] - 10.0) < 5e-3 and abs(p[2]) < 5e-3
+    q = out["rotation"][b].astype(np.float64)
+    assert 2.0 * math.acos(min(1.0, abs(q[3]))) < 1e-2
+
+
+CHECKS = [check_fixed_joint_holds_the_pose, check_revolute_joint_is_a_hinge, check_spherical_joint_keeps_the_pivot, check_prismatic_joint_slides_along_its_axis,
+          check_free_fall, check_box_comes_to_rest, check_friction_cone, check_restitution, check_momentum_is_conserved, check_stack_stays_put,
           check_pendulum_keeps_its_length]
