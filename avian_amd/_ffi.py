@@ -154,6 +154,10 @@ class avn_contacts_out(C.Structure):
                                   "warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse", "feature_id1", "feature_id2")]
 
 
+class avn_contacts_in(C.Structure):
+    _fields_ = avn_contacts_out._fields_   # the same pointers, read instead of written
+
+
 class avn_pipeline_stats(C.Structure):
     _fields_ = [("pairs_added", C.c_uint64), ("pairs_removed", C.c_uint64), ("manifolds_pushed", C.c_uint64), ("manifolds_popped", C.c_uint64),
                 ("active_pairs", C.c_uint32), ("manifolds", C.c_uint32), ("last_status_changes", C.c_uint32), ("last_overflow_manifolds", C.c_uint32),
@@ -233,7 +237,7 @@ ABI_SYMBOLS = [
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
-    "contacts_download", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
+    "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
 ]
 
 
@@ -300,6 +304,7 @@ class Library:
         f("contact_changes_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
         f("manifold_handles_upload").argtypes = [vp, vp, vp]
         f("contacts_download").argtypes = [vp, vp, C.c_size_t, vp]
+        f("contacts_upload").argtypes = [vp, vp, C.c_size_t, vp]
         f("pipeline_enable").argtypes = [vp, C.c_int]
         f("pipeline_stats_get").argtypes = [vp, vp]
         f("pipeline_handles_get").argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -655,6 +660,23 @@ class World:
                                                       "feature_id1", "feature_id2")])
         self._check(self.lib.fn("contacts_download")(self.handle, _ptr(ids), n, C.byref(o)))
         return out
+
+    _CONTACT_ROW_FIELDS = (("flags", np.uint32, ()), ("point_count", np.uint8, ()), ("normal", None, (3,)), ("friction", None, ()), ("restitution", None, ()),
+                           ("anchor1", None, (4, 3)), ("anchor2", None, (4, 3)), ("penetration", None, (4,)), ("normal_speed", None, (4,)),
+                           ("warm_start_normal_impulse", None, (4,)), ("warm_start_tangent_impulse", None, (4, 2)), ("normal_impulse", None, (4,)),
+                           ("feature_id1", np.uint32, (4,)), ("feature_id2", np.uint32, (4,)))
+
+    def contacts_upload(self, contact_id, rows):
+        """``avn_contacts_upload``: rows in the layout ``contacts_download`` returns (a dict of arrays), for contact ids that exist."""
+        ids = np.ascontiguousarray(contact_id, np.uint32)
+        n = ids.size
+        keep = []
+        for name, dt, shape in self._CONTACT_ROW_FIELDS:
+            a = np.ascontiguousarray(rows[name], dt or self.dtype)
+            assert a.shape == (n,) + shape, f"contacts_upload: {name} has shape {a.shape}, expected {(n,) + shape}"
+            keep.append(a)
+        o = avn_contacts_in(*[_ptr(a) for a in keep])
+        self._check(self.lib.fn("contacts_upload")(self.handle, _ptr(ids), n, C.byref(o)))
 
     # -- standalone closed loop (the library keeps IdPool / ContactGraph bookkeeping / ConstraintGraph itself) ------------
     def pipeline_enable(self, on: bool = True, host_bookkeeping: bool = False):

@@ -70,6 +70,7 @@ AVN_API avn_status avn_active_pairs_set(avn_world* w, const uint32_t* ids, size_
 AVN_API avn_status avn_contact_changes_get(avn_world* w, const avn_contact_change** o, size_t* n) { GUARD(contact_changes_get(o, n)); }
 AVN_API avn_status avn_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { GUARD(manifold_handles_upload(off, ids)); }
 AVN_API avn_status avn_contacts_download(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_out* o) { GUARD(contacts_download(ids, n, o)); }
+AVN_API avn_status avn_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_in* in) { GUARD(contacts_upload(ids, n, in)); }
 AVN_API avn_status avn_pipeline_enable(avn_world* w, int on) { GUARD(pipeline_enable(on)); }
 AVN_API avn_status avn_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { GUARD(pipeline_stats_get(o)); }
 AVN_API avn_status avn_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { GUARD(pipeline_handles_get(off, ids, n)); }

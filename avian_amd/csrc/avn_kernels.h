@@ -141,6 +141,7 @@ template <class T> struct ContactsStage {
     uint32_t *feature_id1, *feature_id2;
 };
 template <class T> void launch_unpack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);
+template <class T> void launch_pack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);   // stage -> rows
 void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 
 // ---- k_graph.hip: the closed loop's integer bookkeeping ON THE DEVICE -------------------------------------------------------

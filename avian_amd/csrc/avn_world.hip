@@ -1373,6 +1373,39 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
+    avn_status contacts_upload(const uint32_t* ids, size_t n, const avn_contacts_in* in) override {
+        if (!in || (n && !ids)) return AVN_ERR_BAD_ARG;
+        if (n && (!in->flags || !in->point_count || !in->normal || !in->friction || !in->restitution || !in->anchor1 || !in->anchor2 || !in->penetration || !in->normal_speed ||
+                  !in->warm_start_normal_impulse || !in->warm_start_tangent_impulse || !in->normal_impulse || !in->feature_id1 || !in->feature_id2)) {
+            error = "contacts_upload: every field of avn_contacts_in is required"; return AVN_ERR_BAD_ARG;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (ids[i] >= ct.cap || (!pipe_dev && !h_ct_used[ids[i]])) { error = "contacts_upload: no such contact (avn_contact_pairs_add first)"; return AVN_ERR_STATE; }
+            if (in->point_count[i] > AVN_MAX_MANIFOLD_POINTS) { error = "contacts_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
+        }
+        if (!n) return AVN_OK;
+        avn_status st = stage_reserve(al(4 * n) * 2 + al(n) + al(sizeof(T) * 3 * n) + al(sizeof(T) * n) * 2 + al(sizeof(T) * 12 * n) * 2 + al(sizeof(T) * 4 * n) * 4 + al(sizeof(T) * 8 * n) + al(16 * n) * 2 + 4096);
+        if (st != AVN_OK) return st;
+        const uint32_t *d_id, *d_flags, *d_f1, *d_f2; const uint8_t* d_pc;
+        const T *d_n, *d_fr, *d_re, *d_a1, *d_a2, *d_pen, *d_ns, *d_wn, *d_wt, *d_ni;
+        if ((st = stage_in<uint32_t>(ids, n, &d_id)) != AVN_OK || (st = stage_in<uint32_t>(in->flags, n, &d_flags)) != AVN_OK || (st = stage_in<uint8_t>(in->point_count, n, &d_pc)) != AVN_OK ||
+            (st = stage_in<T>((const T*)in->normal, 3 * n, &d_n)) != AVN_OK || (st = stage_in<T>((const T*)in->friction, n, &d_fr)) != AVN_OK ||
+            (st = stage_in<T>((const T*)in->restitution, n, &d_re)) != AVN_OK || (st = stage_in<T>((const T*)in->anchor1, 12 * n, &d_a1)) != AVN_OK ||
+            (st = stage_in<T>((const T*)in->anchor2, 12 * n, &d_a2)) != AVN_OK || (st = stage_in<T>((const T*)in->penetration, 4 * n, &d_pen)) != AVN_OK ||
+            (st = stage_in<T>((const T*)in->normal_speed, 4 * n, &d_ns)) != AVN_OK || (st = stage_in<T>((const T*)in->warm_start_normal_impulse, 4 * n, &d_wn)) != AVN_OK ||
+            (st = stage_in<T>((const T*)in->warm_start_tangent_impulse, 8 * n, &d_wt)) != AVN_OK || (st = stage_in<T>((const T*)in->normal_impulse, 4 * n, &d_ni)) != AVN_OK ||
+            (st = stage_in<uint32_t>(in->feature_id1, 4 * n, &d_f1)) != AVN_OK || (st = stage_in<uint32_t>(in->feature_id2, 4 * n, &d_f2)) != AVN_OK)
+            return st;
+        ContactsStage<T> s;   // read-only here; the struct is shared with the download direction
+        s.flags = const_cast<uint32_t*>(d_flags); s.point_count = const_cast<uint8_t*>(d_pc); s.normal = const_cast<T*>(d_n); s.friction = const_cast<T*>(d_fr);
+        s.restitution = const_cast<T*>(d_re); s.anchor1 = const_cast<T*>(d_a1); s.anchor2 = const_cast<T*>(d_a2); s.penetration = const_cast<T*>(d_pen);
+        s.normal_speed = const_cast<T*>(d_ns); s.warm_n = const_cast<T*>(d_wn); s.warm_t = const_cast<T*>(d_wt); s.normal_impulse = const_cast<T*>(d_ni);
+        s.feature_id1 = const_cast<uint32_t*>(d_f1); s.feature_id2 = const_cast<uint32_t*>(d_f2);
+        launch_pack_contacts<T>(ct, d_id, (uint32_t)n, s, stream);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));   // the staging buffer is reused by the next call
+        return AVN_OK;
+    }
     avn_status pairs_get(const avn_pair** out, size_t* n) override {
         if (!out || !n) return AVN_ERR_BAD_ARG;
         *out = h_pairs.data();

@@ -86,6 +86,7 @@ struct WorldBase {
     virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
     virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
     virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
+    virtual avn_status contacts_upload(const uint32_t*, size_t, const avn_contacts_in*) = 0;
     virtual avn_status pipeline_enable(int) = 0;
     virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
     virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;

@@ -393,6 +393,30 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     }
 }
 
+// avn_contacts_upload: the inverse record copy (rows that migrate between worlds); slots and manifold_count_change stay
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_contacts(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n, ContactsStage<T> in) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = ids[i];
+    uint4 meta = ct.meta[c];
+    const uint32_t np = min((uint32_t)in.point_count[i], (uint32_t)AVN_MAX_MANIFOLD_POINTS);
+    meta.z = (in.flags[i] & ~(uint32_t)AVN_CP_ROW_USED) | AVN_CP_ROW_USED;
+    meta.w = (np ? 1u : 0u) | (np << 8);
+    ct.meta[c] = meta;
+    V3<T> nn = ld3(in.normal, i);
+    ct.n[c] = make4<T>(nn.x, nn.y, nn.z, in.friction[i]);
+    ct.tv[c] = make4<T>(T(0), T(0), T(0), in.restitution[i]);
+    for (uint32_t k = 0; k < np; ++k) {
+        size_t d = (size_t)k * ct.cap + c, s = 4 * (size_t)i + k;
+        V3<T> a1 = ld3(in.anchor1, s), a2 = ld3(in.anchor2, s);
+        ct.a1[d] = make4<T>(a1.x, a1.y, a1.z, in.penetration[s]);
+        ct.a2[d] = make4<T>(a2.x, a2.y, a2.z, in.normal_speed[s]);
+        ct.w[d] = make4<T>(in.warm_n[s], in.warm_t[2 * s], in.warm_t[2 * s + 1], in.normal_impulse[s]);
+        ct.fid[d] = make_uint2(in.feature_id1[s], in.feature_id2[s]);
+    }
+}
+
 template <class T> void launch_init_contact_rows(const CT<T>& ct, const uint32_t* ids, const uint32_t* s1, const uint32_t* s2, const uint32_t* pf, uint32_t n, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_init_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, s1, s2, pf, n);
 }
@@ -418,7 +442,11 @@ template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct,
 template <class T> void launch_unpack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& o, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_unpack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, o);
 }
+template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& in, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_pack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, in);
+}
 #define INST(T)                                                                                                                                      \
+    template void launch_pack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);                              \
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \

@@ -373,6 +373,23 @@ typedef struct avn_contacts_out {
     uint32_t* feature_id1;    /* [4n] */
     uint32_t* feature_id2;    /* [4n] */
 } avn_contacts_out;
+/* the same row, host -> device (avn_contacts_upload); every field is required */
+typedef struct avn_contacts_in {
+    const uint32_t* flags;          /* [n] AVN_CP_* */
+    const uint8_t* point_count;     /* [n] 0..4 */
+    const void* normal;             /* [3n] */
+    const void* friction;           /* [n] */
+    const void* restitution;        /* [n] */
+    const void* anchor1;            /* [3*4n] */
+    const void* anchor2;            /* [3*4n] */
+    const void* penetration;        /* [4n] */
+    const void* normal_speed;       /* [4n] */
+    const void* warm_start_normal_impulse;   /* [4n] */
+    const void* warm_start_tangent_impulse;  /* [2*4n] */
+    const void* normal_impulse;     /* [4n] */
+    const uint32_t* feature_id1;    /* [4n] */
+    const uint32_t* feature_id2;    /* [4n] */
+} avn_contacts_in;
 
 /* ---- systems (one id per reference system on the path; for schedule-faithful drivers and
  *      per-kernel parity tests) ---------------------------------------------------------------- */
@@ -521,6 +538,14 @@ AVN_API avn_status AVN_FN(contact_changes_get)(avn_world* w, const avn_contact_c
  * narrow phase; n = color_offsets[24]. */
 AVN_API avn_status AVN_FN(manifold_handles_upload)(avn_world* w, const uint32_t* color_offsets, const uint32_t* contact_id);
 AVN_API avn_status AVN_FN(contacts_download)(avn_world* w, const uint32_t* contact_id, size_t n, const avn_contacts_out* out);
+/* the inverse: overwrite rows that exist (avn_contact_pairs_add) with what NarrowPhase::update reads of the previous step -- the
+ * ContactPair flags (collision/contact_types/mod.rs:56-110; whether the pair was touching decides the started / stopped events,
+ * narrow_phase/system_param.rs:560-584) and manifolds[0] with its points, whose feature ids carry the warm-start impulses over in
+ * match_contacts (contact_types/mod.rs:568-600).  For rows that move between worlds when a closed-loop world is re-partitioned or
+ * rebuilt: a world that receives bodies, colliders in interval order, avn_existing_pairs_upload, avn_contact_pairs_add and these
+ * rows continues bit-identically (tests/test_pipeline_cpu.py, tests/test_gpu_pipeline.py).  The collider slots of the row and its
+ * manifold_count_change stay as they are; points beyond point_count are not read. */
+AVN_API avn_status AVN_FN(contacts_upload)(avn_world* w, const uint32_t* contact_id, size_t n, const avn_contacts_in* in);
 
 /* ---- standalone closed loop -----------------------------------------------------------------------------------------
  * For drivers WITHOUT Avian's host structures (benches, demos, tests): the library keeps them itself — IdPool

@@ -304,6 +304,7 @@ struct WorldBase {
     virtual avn_status contact_changes_get(const avn_contact_change**, size_t*) = 0;
     virtual avn_status manifold_handles_upload(const uint32_t*, const uint32_t*) = 0;
     virtual avn_status contacts_download(const uint32_t*, size_t, const avn_contacts_out*) = 0;
+    virtual avn_status contacts_upload(const uint32_t*, size_t, const avn_contacts_in*) = 0;
     virtual avn_status pipeline_enable(int) = 0;
     virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
     virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
@@ -1428,6 +1429,41 @@ template <class S> struct World : WorldBase {
                 if (o->normal_impulse) ((S*)o->normal_impulse)[s] = live ? c.normal_impulse : S(0);
                 if (o->feature_id1) o->feature_id1[s] = live ? c.feature_id1 : 0u;
                 if (o->feature_id2) o->feature_id2[s] = live ? c.feature_id2 : 0u;
+            }
+        }
+        return AVN_OK;
+    }
+    // the inverse of contacts_download: a ContactPair that moved here with its manifold (what NarrowPhase::update reads of the
+    // previous step: flags for the started/stopped events, system_param.rs:560-584; the points for match_contacts,
+    // contact_types/mod.rs:568-600)
+    avn_status contacts_upload(const uint32_t* ids, size_t n, const avn_contacts_in* in) override {
+        if (!in || (n && !ids)) return AVN_ERR_BAD_ARG;
+        if (n && (!in->flags || !in->point_count || !in->normal || !in->friction || !in->restitution || !in->anchor1 || !in->anchor2 || !in->penetration || !in->normal_speed ||
+                  !in->warm_start_normal_impulse || !in->warm_start_tangent_impulse || !in->normal_impulse || !in->feature_id1 || !in->feature_id2)) {
+            error = "contacts_upload: every field of avn_contacts_in is required"; return AVN_ERR_BAD_ARG;
+        }
+        for (size_t i = 0; i < n; ++i) {
+            if (ids[i] >= contact_rows.size() || !contact_rows[ids[i]].used) { error = "contacts_upload: no such contact (avn_contact_pairs_add first)"; return AVN_ERR_STATE; }
+            if (in->point_count[i] > AVN_MAX_MANIFOLD_POINTS) { error = "contacts_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
+        }
+        for (size_t i = 0; i < n; ++i) {
+            CtRow& r = contact_rows[ids[i]];
+            r.flags = in->flags[i];
+            r.point_count = in->point_count[i];
+            r.n_manifolds = r.point_count ? 1u : 0u;
+            r.normal = rd3(in->normal, i);
+            r.friction = ((const S*)in->friction)[i];
+            r.restitution = ((const S*)in->restitution)[i];
+            for (int k = 0; k < r.point_count; ++k) {
+                size_t s = 4 * i + k;
+                CtPoint& c = r.pts[k];
+                c.anchor1 = rd3(in->anchor1, s); c.anchor2 = rd3(in->anchor2, s);
+                c.penetration = ((const S*)in->penetration)[s];
+                c.normal_speed = ((const S*)in->normal_speed)[s];
+                c.warm_start_normal_impulse = ((const S*)in->warm_start_normal_impulse)[s];
+                c.warm_start_tangent_impulse = {((const S*)in->warm_start_tangent_impulse)[2 * s], ((const S*)in->warm_start_tangent_impulse)[2 * s + 1]};
+                c.normal_impulse = ((const S*)in->normal_impulse)[s];
+                c.feature_id1 = in->feature_id1[s]; c.feature_id2 = in->feature_id2[s];
             }
         }
         return AVN_OK;

@@ -69,6 +69,7 @@ avn_status avo_active_pairs_set(avn_world* w, const uint32_t* ids, size_t n) { F
 avn_status avo_contact_changes_get(avn_world* w, const avn_contact_change** o, size_t* n) { FWD(contact_changes_get(o, n)); }
 avn_status avo_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { FWD(manifold_handles_upload(off, ids)); }
 avn_status avo_contacts_download(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_out* o) { FWD(contacts_download(ids, n, o)); }
+avn_status avo_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_in* in) { FWD(contacts_upload(ids, n, in)); }
 avn_status avo_pipeline_enable(avn_world* w, int on) { FWD(pipeline_enable(on)); }
 avn_status avo_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { FWD(pipeline_stats_get(o)); }
 avn_status avo_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { FWD(pipeline_handles_get(off, ids, n)); }

@@ -115,3 +115,39 @@ def test_overflow_colour_per_level_launches_match_oracle(monkeypatch):
         for k in bo:
             assert np.array_equal(bo[k], bh[k]), f"step {s}: bodies.{k}"
     assert seen_overflow > 50, "the scene must actually use colour 23"
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_contact_rows_move_to_a_fresh_world_and_it_continues_bit_identically(bits):
+    """avn_contacts_upload on the device: the pile of tests/test_pipeline_cpu.py is moved onto a fresh HIP world after 45 steps and
+    both continue under one host pipeline for 40 more — pairs, status changes, bodies, rows and interval order stay equal; the
+    migrated HIP world also equals the oracle's migrated world (same procedure there), so the upload kernel writes what the
+    restatement writes."""
+    import migration_helpers as M
+    bodies, colliders = dropped_boxes(seed=11, n=30)
+    ah, bh, plh, _ = M.run_migration(hip_lib(), bits, bodies, colliders, steps_before=45, steps_after=40)
+    assert len(plh.pairs) > 20 and plh.graph.lists()[1].size > 10
+    M.assert_same_world(ah, bh, plh)
+    ao, bo, plo, _ = M.run_migration(oracle_lib(), bits, bodies, colliders, steps_before=45, steps_after=40)
+    assert sorted(plo.pairs) == sorted(plh.pairs)
+    M.assert_same_world(bo, bh, plh)
+
+
+def test_contacts_upload_hip_round_trip_and_errors():
+    import migration_helpers as M
+    bodies, colliders = dropped_boxes(seed=2, n=12)
+    w = M.new_world(hip_lib(), 32, bodies, colliders)
+    pl = ContactPipeline(w, hip_lib())
+    for _ in range(30):
+        pl.step()
+    ids = np.array(sorted(pl.pairs), np.uint32)
+    rows = w.contacts_download(ids)
+    scrambled = {k: np.roll(v, 1, axis=0) for k, v in rows.items()}
+    w.contacts_upload(ids, scrambled)
+    got = w.contacts_download(ids)
+    live = np.arange(4)[None, :] < scrambled["point_count"][:, None]
+    assert np.array_equal(got["flags"], scrambled["flags"]) and np.array_equal(got["point_count"], scrambled["point_count"])
+    for k in ("anchor1", "anchor2", "penetration", "warm_start_normal_impulse", "warm_start_tangent_impulse", "normal_impulse", "feature_id1", "feature_id2"):
+        assert np.array_equal(got[k][live], scrambled[k][live]) and not np.any(got[k][~live]), k
+    with pytest.raises(F.AvnError):
+        w.contacts_upload(np.array([1 << 20], np.uint32), {k: v[:1] for k, v in rows.items()})

@@ -74,3 +74,55 @@ def test_library_pipeline_equals_the_python_driver():
     st = wb.pipeline_stats()
     assert st.pairs_added == pa.stats["pairs_added"] and st.manifolds_pushed == pa.stats["pushes"] and st.manifolds_popped == pa.stats["pops"]
     assert st.active_pairs == len(pa.active) and st.manifolds == len(ha)
+
+
+def test_a_world_continues_on_a_fresh_world_when_its_contact_rows_move_with_it():
+    """avn_contacts_upload (the reference holds no test of its own: its ContactGraph never leaves the process).  A pile is stepped,
+    moved onto a fresh world — bodies, colliders in interval order, pair set, contact rows, colour lists — and both are stepped
+    further under ONE host pipeline: every broad-phase pair list, every status-change list, the bodies and the rows stay
+    bit-identical.  Without the rows (negative control) the continuation differs: the warm-start impulses and the touching flags
+    are state."""
+    import migration_helpers as M
+    lib = oracle_lib()
+    for bits in (32, 64):
+        bodies, colliders = dropped_boxes(seed=11, n=30)
+        a, b, pl, _ = M.run_migration(lib, bits, bodies, colliders, steps_before=45, steps_after=40)
+        assert len(pl.pairs) > 20 and pl.graph.lists()[1].size > 10
+        M.assert_same_world(a, b, pl)
+    bodies, colliders = dropped_boxes(seed=11, n=30)
+    a, b, pl, mirror = M.run_migration(lib, 32, bodies, colliders, steps_before=45, steps_after=5, rows=False)
+    ba, bb = a.bodies_download(), b.bodies_download()
+    assert mirror.differences > 0 or not np.array_equal(ba["linear_velocity"], bb["linear_velocity"])
+
+
+def test_contacts_upload_round_trip_and_errors():
+    import pytest
+    import migration_helpers as M
+    lib = oracle_lib()
+    bodies, colliders = dropped_boxes(seed=2, n=12)
+    w = M.new_world(lib, 64, bodies, colliders)
+    pl = ContactPipeline(w, lib)
+    for _ in range(30):
+        pl.step()
+    ids = np.array(sorted(pl.pairs), np.uint32)
+    rows = w.contacts_download(ids)
+    assert rows["point_count"].max() >= 1
+    scrambled = {k: np.roll(v, 1, axis=0) for k, v in rows.items()}
+    w.contacts_upload(ids, scrambled)
+    got = w.contacts_download(ids)
+    live = np.arange(4)[None, :] < scrambled["point_count"][:, None]
+    for k, v in scrambled.items():
+        if k in ("flags", "point_count"):
+            assert np.array_equal(got[k], v), k
+        elif v.ndim == 1 or k == "normal":                  # per-manifold fields: zero when the row has no manifold
+            m = scrambled["point_count"] > 0
+            assert np.array_equal(got[k][m], v[m]), k
+        else:                                             # per-point fields: points beyond point_count read as zero
+            assert np.array_equal(got[k][live], v[live]), k
+            assert not np.any(got[k][~live]), k
+    w.contacts_upload(ids, rows)
+    with pytest.raises(F.AvnError):
+        w.contacts_upload(np.array([10_000], np.uint32), {k: v[:1] for k, v in rows.items()})
+    bad = {k: v[:1].copy() for k, v in rows.items()}; bad["point_count"][0] = 5
+    with pytest.raises(F.AvnError):
+        w.contacts_upload(ids[:1], bad)
