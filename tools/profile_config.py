@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One configuration of tools/time_configs.py under a profiler: `rocprofv3 --kernel-trace --stats -- python tools/profile_config.py cfg3|cfg5 [steps]`."""
+"""One configuration of tools/time_configs.py under a profiler: `rocprofv3 --kernel-trace --stats -- python tools/profile_config.py cfg3|cfg5|cfg5f32 [steps]`."""
 import os
 import sys
 
@@ -28,8 +28,13 @@ def main():
         w = F.World(lib, F.default_config(64, substeps=8))
         setup(w, lib, sc)
         print(time_steps(w, 8, warmup=2, steps=steps))
+    elif which == "cfg5f32":   # cfg5's scene in f32: the f32 colour kernel at launches large enough to fill the chip (312 k manifolds per colour)
+        sc = scenes.box_stack(100, 50, 100)
+        w = F.World(lib, F.default_config(32, substeps=8))
+        setup(w, lib, sc)
+        print(time_steps(w, 8, warmup=2, steps=steps))
     else:
-        raise SystemExit("cfg3 | cfg5")
+        raise SystemExit("cfg3 | cfg5 | cfg5f32")
 
 
 if __name__ == "__main__":
