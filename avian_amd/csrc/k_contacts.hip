@@ -467,7 +467,11 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
 //  substeps/s | fences only 2 420 | prefetch only 2 359 | both 2 487 -- and the PMC pass showed the prefetch as 13 MB of EXTRA fetch traffic
 //  per launch (42.3 MB against 29.2 MB): the lines do not survive in L2 until the next launch.  +0.8 % for +45 % traffic: removed.
 //  Non-temporal (`nt`) loads / stores of the records, meant to keep the 9.6 MB of body records in L2 across launches: the PMC traffic
-//  stays at 29.3 MB per launch (the bodies are not retained either way) and the launch takes 9.26 us instead of 8.34: removed as well.)
+//  stays at 29.3 MB per launch (the bodies are not retained either way) and the launch takes 9.26 us instead of 8.34: removed as well.
+//  Occupancy hints, `__launch_bounds__(64, 3)` for f32 (170 -> 168 VGPRs, 2 -> 3 waves per SIMD, 16 B of scratch per lane) and `(64, 2)`
+//  for f64 (256 + 24 AGPRs -> 256, 1 -> 2 waves, 100 B of scratch): measured where occupancy could matter, at 230-250 k manifolds per launch
+//  (cfg5 and its f32 twin, two runs each on one box): f64 23.6-24.0 -> 24.9-25.0 ms per step, f32 13.1-13.2 -> 13.3-13.4.  The spills cost
+//  more than the extra wave hides; at that size a launch already moves its bytes at ~5.8 TB/s behind the launch-to-launch floor.)
 template <bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
