@@ -471,7 +471,19 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
 //  Occupancy hints, `__launch_bounds__(64, 3)` for f32 (170 -> 168 VGPRs, 2 -> 3 waves per SIMD, 16 B of scratch per lane) and `(64, 2)`
 //  for f64 (256 + 24 AGPRs -> 256, 1 -> 2 waves, 100 B of scratch): measured where occupancy could matter, at 230-250 k manifolds per launch
 //  (cfg5 and its f32 twin, two runs each on one box): f64 23.6-24.0 -> 24.9-25.0 ms per step, f32 13.1-13.2 -> 13.3-13.4.  The spills cost
-//  more than the extra wave hides; at that size a launch already moves its bytes at ~5.8 TB/s behind the launch-to-launch floor.)
+//  more than the extra wave hides; at that size a launch already moves its bytes at ~5.8 TB/s behind the launch-to-launch floor.
+//  A whole pass as ONE persistent launch again, this time without cache maintenance (round 1's version paid ~15 us of buffer_wbl2 / buffer_inv
+//  per barrier; tools/neighbour_sync_probe.hip: with agent-scope accesses only, a device-wide hand-over costs ~3.6 us): 256 workgroups of 256
+//  lanes, one per CU (96 KB of dynamic LDS requested to keep it so: two on a CU double the chain), velocities through the COH accesses,
+//  per colour "s_waitcnt vmcnt(0) -> s_barrier -> one arrival atomic -> the last arriver stores a release word -> one lane polls it", and
+//  the NEXT colour's 600 B of records per lane requested into a second register set before the impulse chain.  Bit-identical (49 parity /
+//  closed-loop tests).  cfg2, same box: 2 170 substeps/s without the prefetch wait, 2 040 with the prefetch behind the gathers, against
+//  2 430-2 465 for the launches.  Per-workgroup timestamps of one launch: released -> gathers back 1.4 us, impulse chain + stores 6.0-6.7 us,
+//  stores performed + arrival 1.2 us, release 0.45 us = ~9.5-10 us per colour, the launches' 9.7: the kernel boundary (1.6 us) was never the
+//  expensive part, the in-lane chain is, and it does not overlap with anything when all waves of a colour run in lockstep.  Removed.
+//  Hoisting what does not depend on the velocities (rotated anchors, separation and its speculative / biased terms for all four points) in
+//  front of the chain as one branch-free block, to give the in-order VALU stream independent work: bit-identical, 8.9 us per launch instead
+//  of 8.4 (longer live ranges, nothing gained: the compiler already interleaves what the basic blocks allow).  Removed.)
 template <bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;

@@ -24,7 +24,48 @@ __global__ __launch_bounds__(64) void k_chase(const uint32_t* __restrict__ t0, c
     if (LEVELS >= 4) v = t3[v & 0xFFFFu];
     out[i] = v;
 }
+// What one wave's VALU stream costs when it has a SIMD to itself (the colour kernels run at <= 1 wave per SIMD at cfg2): a chain of N
+// dependent / independent f32 and packed-f32 multiplies, timed with the 100 MHz s_memrealtime next to the shader clock (s_memtime).
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int KIND>
+__global__ __launch_bounds__(64) void k_valu(float* out, unsigned long long* stamp, float seed) {
+    float a = seed + threadIdx.x, b = 1.0000001f, c = seed, d = seed * 2;
+    f2v pa = {a, c}, pb2 = {b, b}, pc = {c, a}, pd = {d, a};
+    unsigned long long r0 = __builtin_amdgcn_s_memrealtime(), t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int i = 0; i < 64; ++i) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (KIND == 0) { a = a * b; }                                    // dependent v_mul_f32
+            else if (KIND == 1) { a = a * b; c = c * b; d = d * b; }         // three independent chains of v_mul_f32
+            else if (KIND == 2) { pa = pa * pb2; }                           // dependent v_pk_mul_f32
+            else { pa = pa * pb2; pc = pc * pb2; pd = pd * pb2; }            // three independent chains of v_pk_mul_f32
+        }
+    }
+    unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    out[blockIdx.x * 64 + threadIdx.x] = a + c + d + pa.x + pa.y + pc.x + pc.y + pd.x + pd.y;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { stamp[0] = t1 - t0; stamp[1] = r1 - r0; }
+}
+template <int KIND> static int valu(const char* name, int per_iter, float* out, unsigned long long* stamp) {
+    unsigned long long h[2];
+    for (int rep = 0; rep < 3; ++rep) {
+        hipLaunchKernelGGL(k_valu<KIND>, dim3(1024), dim3(64), 0, 0, out, stamp, 1.0f + rep);
+        CK(hipDeviceSynchronize());
+    }
+    CK(hipMemcpy(h, stamp, 16, hipMemcpyDeviceToHost));
+    const double n = 64.0 * 16 * per_iter, us = h[1] * 0.01;
+    std::printf("%-44s %6.0f instr in %6.2f us = %5.2f ns per instr | s_memtime ticks per instr %5.2f (tick rate %.0f MHz)\n", name, n, us, us * 1e3 / n, (double)h[0] / n, h[0] / us);
+    return 0;
+}
 int main() {
+    {
+        float* vo; unsigned long long* vs;
+        CK(hipMalloc(&vo, 1024 * 64 * 4)); CK(hipMalloc(&vs, 16));
+        if (valu<0>("v_mul_f32, one dependent chain", 1, vo, vs)) return 1;
+        if (valu<1>("v_mul_f32, three independent chains", 3, vo, vs)) return 1;
+        if (valu<2>("v_pk_mul_f32, one dependent chain", 1, vo, vs)) return 1;
+        if (valu<3>("v_pk_mul_f32, three independent chains", 3, vo, vs)) return 1;
+    }
     const int N = 256, GRID = 1024, REPS = 20;
     hipStream_t st; CK(hipStreamCreate(&st));
     uint32_t* t[4]; uint32_t* out;
