@@ -139,12 +139,61 @@ impl Mi355xWorld {
         self.check(st);
     }
 
+    /// Contact-table rows of pairs that move to another world (a re-partition hands an island to another rank): `rows_out` of the world
+    /// that gives them up, `rows_in` on the one that takes them, after `avn_contact_pairs_add` created the rows there.  What travels is what
+    /// `NarrowPhase::update` reads of the previous step: the `ContactPair` flags and `manifolds[0]` with feature ids and warm-start impulses.
+    pub fn contact_rows_out(&mut self, contact_ids: &[u32]) -> ContactRows {
+        let n = contact_ids.len();
+        let mut r = ContactRows::zeroed(n);
+        let out = ffi::avn_contacts_out {
+            flags: r.flags.as_mut_ptr(), point_count: r.point_count.as_mut_ptr(), normal: r.normal.as_mut_ptr().cast(), friction: r.friction.as_mut_ptr().cast(),
+            restitution: r.restitution.as_mut_ptr().cast(), anchor1: r.anchor1.as_mut_ptr().cast(), anchor2: r.anchor2.as_mut_ptr().cast(),
+            penetration: r.penetration.as_mut_ptr().cast(), normal_speed: r.normal_speed.as_mut_ptr().cast(),
+            warm_start_normal_impulse: r.warm_start_normal_impulse.as_mut_ptr().cast(), warm_start_tangent_impulse: r.warm_start_tangent_impulse.as_mut_ptr().cast(),
+            normal_impulse: r.normal_impulse.as_mut_ptr().cast(), feature_id1: r.feature_id1.as_mut_ptr(), feature_id2: r.feature_id2.as_mut_ptr(),
+        };
+        let st = unsafe { ffi::avn_contacts_download(self.raw, contact_ids.as_ptr(), n, &out) };
+        self.check(st);
+        r
+    }
+
+    pub fn contact_rows_in(&mut self, contact_ids: &[u32], r: &ContactRows) {
+        assert_eq!(r.flags.len(), contact_ids.len());
+        let inp = ffi::avn_contacts_in {
+            flags: r.flags.as_ptr(), point_count: r.point_count.as_ptr(), normal: r.normal.as_ptr().cast(), friction: r.friction.as_ptr().cast(),
+            restitution: r.restitution.as_ptr().cast(), anchor1: r.anchor1.as_ptr().cast(), anchor2: r.anchor2.as_ptr().cast(),
+            penetration: r.penetration.as_ptr().cast(), normal_speed: r.normal_speed.as_ptr().cast(),
+            warm_start_normal_impulse: r.warm_start_normal_impulse.as_ptr().cast(), warm_start_tangent_impulse: r.warm_start_tangent_impulse.as_ptr().cast(),
+            normal_impulse: r.normal_impulse.as_ptr().cast(), feature_id1: r.feature_id1.as_ptr(), feature_id2: r.feature_id2.as_ptr(),
+        };
+        let st = unsafe { ffi::avn_contacts_upload(self.raw, contact_ids.as_ptr(), contact_ids.len(), &inp) };
+        self.check(st);
+    }
+
     /// Level 2: this rank's send / receive lists (from `avn_level2_plan_rank`), then the library's own transport.
     pub fn enable_level2(&mut self, halo: &ffi::avn_halo_plan, unique_id: &[u8; ffi::AVN_COMM_ID_BYTES as usize], n_ranks: i32, rank: i32) {
         let st = unsafe { ffi::avn_halo_plan_upload(self.raw, halo) };
         self.check(st);
         let st = unsafe { ffi::avn_comm_init(self.raw, unique_id.as_ptr(), n_ranks, rank) };
         self.check(st);
+    }
+}
+
+/// Rows of the contact table in the layout of `avn_contacts_out` / `avn_contacts_in` (f32 worlds; slot = 4 * row + point).
+pub struct ContactRows {
+    pub flags: Vec<u32>, pub point_count: Vec<u8>, pub normal: Vec<f32>, pub friction: Vec<f32>, pub restitution: Vec<f32>,
+    pub anchor1: Vec<f32>, pub anchor2: Vec<f32>, pub penetration: Vec<f32>, pub normal_speed: Vec<f32>,
+    pub warm_start_normal_impulse: Vec<f32>, pub warm_start_tangent_impulse: Vec<f32>, pub normal_impulse: Vec<f32>,
+    pub feature_id1: Vec<u32>, pub feature_id2: Vec<u32>,
+}
+impl ContactRows {
+    pub fn zeroed(n: usize) -> Self {
+        Self {
+            flags: vec![0; n], point_count: vec![0; n], normal: vec![0.0; 3 * n], friction: vec![0.0; n], restitution: vec![0.0; n],
+            anchor1: vec![0.0; 12 * n], anchor2: vec![0.0; 12 * n], penetration: vec![0.0; 4 * n], normal_speed: vec![0.0; 4 * n],
+            warm_start_normal_impulse: vec![0.0; 4 * n], warm_start_tangent_impulse: vec![0.0; 8 * n], normal_impulse: vec![0.0; 4 * n],
+            feature_id1: vec![0; 4 * n], feature_id2: vec![0; 4 * n],
+        }
     }
 }
 
