@@ -141,7 +141,8 @@ template <class T> struct ContactsStage {
     uint32_t *feature_id1, *feature_id2;
 };
 template <class T> void launch_unpack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);
-template <class T> void launch_pack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, hipStream_t);   // stage -> rows
+template <class T> void launch_remap_row_slots(const CT<T>&, const uint32_t* map, uint32_t n_old, uint32_t apply, uint32_t* n_orphans, hipStream_t);   // collider slots of live rows after a re-upload
+template <class T> void launch_pack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, uint32_t* error, hipStream_t);   // stage -> rows (ids without a live row: skipped, *error |= 4)
 void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 
 // ---- k_graph.hip: the closed loop's integer bookkeeping ON THE DEVICE -------------------------------------------------------

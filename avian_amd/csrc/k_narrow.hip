@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = ids[i];
-    const uint4 meta = ct.meta[c];
+    uint4 meta = ct.meta[c];
+    if (!(meta.z & AVN_CP_ROW_USED)) meta = make_uint4(0u, 0u, 0u, 0u);   // a free id: reads back as an empty pair (flags 0, no points), never as stale data
     const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
     if (o.flags) o.flags[i] = meta.z & ~(uint32_t)AVN_CP_ROW_USED;
     if (o.point_count) o.point_count[i] = (uint8_t)np;
@@ -393,13 +394,16 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     }
 }
 
-// avn_contacts_upload: the inverse record copy (rows that migrate between worlds); slots and manifold_count_change stay
+// avn_contacts_upload: the inverse record copy (rows that migrate between worlds); slots and manifold_count_change stay.
+// A row must exist (avn_contact_pairs_add, or the closed loop's own k_pg_add_pairs): an id whose row is not live is skipped and
+// reported through `error` (bit 2 of the closed loop's error word) -- writing it would create a pair no list knows about.
 template <class T>
-__global__ __launch_bounds__(256) void k_pack_contacts(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n, ContactsStage<T> in) {
+__global__ __launch_bounds__(256) void k_pack_contacts(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n, ContactsStage<T> in, uint32_t* error) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const uint32_t c = ids[i];
     uint4 meta = ct.meta[c];
+    if (!(meta.z & AVN_CP_ROW_USED)) { if (error) atomicOr(error, 4u); return; }
     const uint32_t np = min((uint32_t)in.point_count[i], (uint32_t)AVN_MAX_MANIFOLD_POINTS);
     meta.z = (in.flags[i] & ~(uint32_t)AVN_CP_ROW_USED) | AVN_CP_ROW_USED;
     meta.w = (np ? 1u : 0u) | (np << 8);
@@ -417,6 +421,22 @@ __global__ __launch_bounds__(256) void k_pack_contacts(CT<T> ct, const uint32_t*
     }
 }
 
+// avn_colliders_upload with a changed slot assignment while rows are live: meta.x / meta.y are collider slots.  apply = 0 counts the live
+// rows that name a slot without a successor (nothing is written), apply = 1 renumbers.
+template <class T>
+__global__ __launch_bounds__(256) void k_remap_row_slots(CT<T> ct, const uint32_t* __restrict__ map, uint32_t n_old, uint32_t apply, uint32_t* n_orphans) {
+    uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ct.cap) return;
+    uint4 meta = ct.meta[c];
+    if (!(meta.z & AVN_CP_ROW_USED)) return;
+    const uint32_t a = meta.x < n_old ? map[meta.x] : 0xFFFFFFFFu, b = meta.y < n_old ? map[meta.y] : 0xFFFFFFFFu;
+    if (!apply) { if (a == 0xFFFFFFFFu || b == 0xFFFFFFFFu) atomicAdd(n_orphans, 1u); return; }
+    meta.x = a; meta.y = b;
+    ct.meta[c] = meta;
+}
+template <class T> void launch_remap_row_slots(const CT<T>& ct, const uint32_t* map, uint32_t n_old, uint32_t apply, uint32_t* n_orphans, hipStream_t st) {
+    if (ct.cap) hipLaunchKernelGGL(k_remap_row_slots<T>, dim3((ct.cap + 255) / 256), dim3(256), 0, st, ct, map, n_old, apply, n_orphans);
+}
 template <class T> void launch_init_contact_rows(const CT<T>& ct, const uint32_t* ids, const uint32_t* s1, const uint32_t* s2, const uint32_t* pf, uint32_t n, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_init_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, s1, s2, pf, n);
 }
@@ -442,11 +462,12 @@ template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct,
 template <class T> void launch_unpack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& o, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_unpack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, o);
 }
-template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& in, hipStream_t st) {
-    if (n) hipLaunchKernelGGL(k_pack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, in);
+template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* ids, uint32_t n, const ContactsStage<T>& in, uint32_t* error, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_pack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, in, error);
 }
 #define INST(T)                                                                                                                                      \
-    template void launch_pack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);                              \
+    template void launch_remap_row_slots<T>(const CT<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);                               \
+    template void launch_pack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, uint32_t*, hipStream_t);                              \
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \

@@ -1,0 +1,156 @@
+// world/joints.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
+// XpbdSolverPlugin's joint upload, read-back and the level schedules.
+
+    // ---- joints ----------------------------------------------------------------------------------------
+    avn_status distance_joints_upload(const avn_distance_joints* j) override {
+        if (!j || (j->count && (!j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->limit_min || !j->limit_max || !j->compliance))) {
+            error = "distance_joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        // the special case joint_type = DISTANCE of joints_upload
+        std::vector<uint8_t> types(j->count, (uint8_t)AVN_JOINT_DISTANCE);
+        std::vector<T> comp(3 * (size_t)j->count, T(0));
+        for (size_t i = 0; i < j->count; ++i) comp[3 * i] = ((const T*)j->compliance)[i];
+        avn_joints g;
+        std::memset(&g, 0, sizeof g);
+        g.count = j->count; g.joint_type = types.data(); g.body1 = j->body1; g.body2 = j->body2;
+        g.local_anchor1 = j->local_anchor1; g.local_anchor2 = j->local_anchor2; g.limit_min = j->limit_min; g.limit_max = j->limit_max;
+        g.compliance = comp.data(); g.damping_linear = j->damping_linear; g.damping_angular = j->damping_angular;
+        g.collision_disabled = j->collision_disabled;
+        return joints_upload(&g);
+    }
+    avn_status joints_upload(const avn_joints* j) override {
+        if (!have_bodies) { error = "joints_upload before bodies_upload"; return AVN_ERR_STATE; }
+        if (!j || (j->count && (!j->joint_type || !j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->compliance))) {
+            error = "joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        uint32_t J = j->count;
+        for (uint32_t i = 0; i < J; ++i) {
+            if (j->joint_type[i] >= AVN_JOINT_TYPE_COUNT) { error = "joints_upload: bad joint_type"; return AVN_ERR_BAD_ARG; }
+            if (j->body1[i] < 0 || j->body2[i] < 0 || (uint32_t)j->body1[i] >= dw.n_bodies || (uint32_t)j->body2[i] >= dw.n_bodies || j->body1[i] == j->body2[i]) {
+                error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
+            }
+        }
+        bool moved = false;
+        if (J > cap_joints) {
+            HIPCHK(hipStreamSynchronize(stream));
+            size_t c = std::max<size_t>(J, cap_joints + cap_joints / 2);
+            GROW(b_j_bodies, c, dw.j_bodies); GROW(b_j_a1, c, dw.j_a1); GROW(b_j_a2, c, dw.j_a2); GROW(b_j_par, c, dw.j_par);
+            GROW(b_j_b1, c, dw.j_b1); GROW(b_j_b2, c, dw.j_b2); GROW(b_j_ax, c, dw.j_ax); GROW(b_j_l2, c, dw.j_l2);
+            GROW(b_j_r1, c, dw.j_r1); GROW(b_j_r2, c, dw.j_r2); GROW(b_j_cd, c, dw.j_cd); GROW(b_j_lag, c, dw.j_lag);
+            GROW(b_j_s0, c, dw.j_s0); GROW(b_j_s1, c, dw.j_s1); GROW(b_j_s2, c, dw.j_s2); GROW(b_j_s3, c, dw.j_s3);
+            GROW(b_j_rl0, c, dw.j_rl0); GROW(b_j_rl1, c, dw.j_rl1); GROW(b_j_force, c, dw.j_force); GROW(b_j_torque, c, dw.j_torque);
+            cap_joints = (uint32_t)c;
+        }
+        if (moved || dw.n_joints != J) graph_valid = false;
+        dw.n_joints = J;
+        avn_status st = stage_reserve(al(4 * (size_t)J) * 2 + al(J) * 2 + al(sizeof(T) * 3 * J) * 4 + al(sizeof(T) * 4 * J) * 2 + al(sizeof(T) * J) * 6 + 8192);
+        if (st != AVN_OK) return st;
+        JointStage<T> s;
+        std::memset(&s, 0, sizeof s);
+        SIN(joint_type, j->joint_type, J, uint8_t); SIN(limit_flags, j->limit_flags, J, uint8_t);
+        SIN(body1, j->body1, J, int32_t); SIN(body2, j->body2, J, int32_t);
+        SIN(local_anchor1, j->local_anchor1, 3 * (size_t)J, T); SIN(local_anchor2, j->local_anchor2, 3 * (size_t)J, T);
+        SIN(local_basis1, j->local_basis1, 4 * (size_t)J, T); SIN(local_basis2, j->local_basis2, 4 * (size_t)J, T);
+        SIN(axis, j->axis, 3 * (size_t)J, T);
+        SIN(limit_min, j->limit_min, J, T); SIN(limit_max, j->limit_max, J, T); SIN(limit2_min, j->limit2_min, J, T); SIN(limit2_max, j->limit2_max, J, T);
+        SIN(compliance, j->compliance, 3 * (size_t)J, T);
+        SIN(damping_linear, j->damping_linear, J, T); SIN(damping_angular, j->damping_angular, J, T);
+        launch_pack_joints<T>(dw, s, stream);
+        HIPCHK(hipGetLastError());
+        h_j_body1.assign(j->body1, j->body1 + J);
+        h_j_body2.assign(j->body2, j->body2 + J);
+        h_j_type.assign(j->joint_type, j->joint_type + J);
+        bool damp = j->damping_linear && j->damping_angular;
+        h_j_damped.assign(J, damp ? 1 : 0);
+        any_damped = damp && J > 0;
+        // body pairs whose joints disable collision (reference broad_phase.rs:423-428)
+        std::vector<uint64_t> disabled;
+        for (uint32_t i = 0; i < J; ++i)
+            if (j->collision_disabled && j->collision_disabled[i]) {
+                uint32_t a = (uint32_t)j->body1[i], b = (uint32_t)j->body2[i];
+                disabled.push_back(a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a);
+            }
+        st = build_hash_set(b_disabled_set, bp.disabled_set, bp.disabled_cap, disabled.data(), (uint32_t)disabled.size());
+        if (st != AVN_OK) return st;
+        joint_schedule_dirty = true;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status joints_download(const avn_joints_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        size_t J = dw.n_joints;
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * J) * 7 + 1024);
+        if (st != AVN_OK) return st;
+        T* a = o->world_r1 ? stage_alloc<T>(3 * J) : nullptr;
+        T* b = o->world_r2 ? stage_alloc<T>(3 * J) : nullptr;
+        T* c = o->center_difference ? stage_alloc<T>(3 * J) : nullptr;
+        T* d = o->total_lagrange ? stage_alloc<T>(3 * J) : nullptr;
+        T* e = o->force ? stage_alloc<T>(3 * J) : nullptr;
+        T* f = o->total_rotation_lagrange ? stage_alloc<T>(3 * J) : nullptr;
+        T* g = o->torque ? stage_alloc<T>(3 * J) : nullptr;
+        launch_unpack_joints<T>(dw, a, b, c, d, e, f, g, stream);
+        HIPCHK(hipGetLastError());
+        SOUT(o->world_r1, a, 3 * J, T); SOUT(o->world_r2, b, 3 * J, T); SOUT(o->center_difference, c, 3 * J, T);
+        SOUT(o->total_lagrange, d, 3 * J, T); SOUT(o->force, e, 3 * J, T);
+        SOUT(o->total_rotation_lagrange, f, 3 * J, T); SOUT(o->torque, g, 3 * J, T);
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status upload_u32(DevBuf& b, const std::vector<uint32_t>& v) {
+        hipError_t err;
+        b.ensure(std::max<size_t>(v.size(), 1) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (!v.empty()) HIPCHK(hipMemcpyAsync(b.p, v.data(), v.size() * 4, hipMemcpyHostToDevice, stream));
+        return AVN_OK;
+    }
+    avn_status rebuild_joint_schedules() {
+        if (!joint_schedule_dirty) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t J = dw.n_joints, N = dw.n_bodies;
+        // the reference's serial order: one system per joint type in the order of xpbd/plugin.rs:77-82 (= the AVN_JOINT_* ids),
+        // each iterating its joints in array (= spawn) order
+        std::vector<uint32_t> all(J);
+        std::iota(all.begin(), all.end(), 0u);
+        std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return h_j_type[a] < h_j_type[b]; });
+        std::vector<int32_t> k1(J), k2(J);
+        for (uint32_t k = 0; k < J; ++k) {
+            uint32_t i = all[k];
+            // bodies without a SolverBody are DUMMY in solve_xpbd_joint: never modified => they do not serialise joints
+            k1[k] = h_body_has_sb[h_j_body1[i]] ? h_j_body1[i] : -1;
+            k2[k] = h_body_has_sb[h_j_body2[i]] ? h_j_body2[i] : -1;
+        }
+        sched_solve.build(all, k1, k2, N);
+        std::vector<uint32_t> damped;
+        std::vector<int32_t> d1, d2;
+        sched_damp.touches_dummy = false;
+        for (uint32_t k = 0; k < J; ++k) {
+            uint32_t i = all[k];
+            if (h_j_damped[i]) {
+                damped.push_back(i);
+                // joint_damping's DUMMY bodies are shared by the joints of ONE type and mutable: virtual bodies N + 2t, N + 2t + 1
+                bool m1 = !h_body_has_sb[h_j_body1[i]], m2 = !h_body_has_sb[h_j_body2[i]];
+                d1.push_back(m1 ? (int32_t)(N + 2u * h_j_type[i]) : h_j_body1[i]);
+                d2.push_back(m2 ? (int32_t)(N + 2u * h_j_type[i] + 1u) : h_j_body2[i]);
+                if (m1 || m2) sched_damp.touches_dummy = true;
+            }
+        }
+        sched_damp.build(damped, d1, d2, N + DUMMY_SLOTS);
+        avn_status st;
+        for (JointSchedule* s : {&sched_solve, &sched_damp}) {
+            if ((st = upload_u32(s->d_comp_level_begin, s->comp_level_begin)) != AVN_OK) return st;
+            if ((st = upload_u32(s->d_level_offsets, s->level_offsets)) != AVN_OK) return st;
+            if ((st = upload_u32(s->d_order, s->order)) != AVN_OK) return st;
+            std::vector<uint32_t> rec(4 * s->order.size());
+            for (size_t k = 0; k < s->order.size(); ++k) {
+                const uint32_t j = s->order[k];
+                rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; rec[4 * k + 3] = 0u;
+            }
+            if ((st = upload_u32(s->d_rec, rec)) != AVN_OK) return st;
+            HIPCHK(hipStreamSynchronize(stream));   // (`rec` is a local: the copy must have left it)
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        joint_schedule_dirty = false;
+        graph_valid = false;
+        return AVN_OK;
+    }
+

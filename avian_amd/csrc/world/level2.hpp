@@ -1,0 +1,169 @@
+// world/level2.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
+// level-2 sharding: halo plan, per-colour passes, exchange.
+
+    // ---- level-2 sharding (include/avian_mi355x.h: avn_halo_plan) ------------------------------------------------------------------------
+    // One contact island over several worlds: global colouring, and after every colour launch the (linear, angular) velocity records of the
+    // shared bodies this world's manifolds moved go to the other holders.  Exchange records of one colour are contiguous over the peers
+    // (list k = colour * n_peers + peer), so a colour costs one pack launch, one grouped RCCL send/recv and one unpack launch.
+    struct HaloPlan {
+        std::vector<int32_t> peers, send, recv;
+        std::vector<uint32_t> send_off, recv_off;   // [24 * n_peers + 1]
+    } halo;
+    DevBuf b_halo_send, b_halo_recv, b_halo_out, b_halo_in;
+    bool halo_on = false;
+    bool bias_skeleton = getenv("AVN_BIAS_SKELETON") != nullptr && getenv("AVN_BIAS_SKELETON")[0] == '1';
+    Comm comm;
+    std::vector<CommXfer> xf_send, xf_recv;
+    avn_status halo_plan_upload(const avn_halo_plan* p) override {
+        if (!p) { error = "halo_plan_upload: null plan"; return AVN_ERR_BAD_ARG; }
+        const size_t n = (size_t)AVN_GRAPH_COLOR_COUNT * p->n_peers;
+        if (p->n_peers && (!p->peer_rank || !p->send_offsets || !p->recv_offsets)) { error = "halo_plan_upload: null array"; return AVN_ERR_BAD_ARG; }
+        HaloPlan h;
+        if (p->n_peers) {
+            h.peers.assign(p->peer_rank, p->peer_rank + p->n_peers);
+            h.send_off.assign(p->send_offsets, p->send_offsets + n + 1); h.recv_off.assign(p->recv_offsets, p->recv_offsets + n + 1);
+            for (size_t k = 0; k < n; ++k)
+                if (h.send_off[k] > h.send_off[k + 1] || h.recv_off[k] > h.recv_off[k + 1]) { error = "halo_plan_upload: offsets must ascend"; return AVN_ERR_BAD_ARG; }
+            if (h.send_off[0] || h.recv_off[0]) { error = "halo_plan_upload: offsets must start at 0"; return AVN_ERR_BAD_ARG; }
+            if ((h.send_off[n] && !p->send_bodies) || (h.recv_off[n] && !p->recv_bodies)) { error = "halo_plan_upload: null body list"; return AVN_ERR_BAD_ARG; }
+            h.send.assign(p->send_bodies, p->send_bodies + h.send_off[n]); h.recv.assign(p->recv_bodies, p->recv_bodies + h.recv_off[n]);
+            const int64_t nb = have_bodies ? (int64_t)dw.n_bodies : INT32_MAX;
+            for (int32_t b : h.send) if (b < 0 || b >= nb) { error = "halo_plan_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+            for (int32_t b : h.recv) if (b < 0 || b >= nb) { error = "halo_plan_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        halo = std::move(h);
+        halo_on = !halo.peers.empty();
+        drop_graph();
+        if (!halo_on) return AVN_OK;
+        hipError_t err;
+        b_halo_send.ensure(std::max<size_t>(halo.send.size(), 1) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_halo_recv.ensure(std::max<size_t>(halo.recv.size(), 1) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_halo_out.ensure(std::max<size_t>(halo.send.size(), 1) * 2 * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_halo_in.ensure(std::max<size_t>(halo.recv.size(), 1) * 2 * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (!halo.send.empty()) HIPCHK(hipMemcpyAsync(b_halo_send.p, halo.send.data(), halo.send.size() * 4, hipMemcpyHostToDevice, stream));
+        if (!halo.recv.empty()) HIPCHK(hipMemcpyAsync(b_halo_recv.p, halo.recv.data(), halo.recv.size() * 4, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    // one colour of one contact pass, in the single-world launch shape (overflow colour: the host schedule's launches)
+    avn_status color_pass_enqueue(int pass, uint32_t color) {
+        if (!dw.n_manifolds || !grid_blocks[color]) return AVN_OK;
+        if (pipe_dev) { error = "level-2 colour passes need host-uploaded manifolds (not the device closed loop)"; return AVN_ERR_STATE; }
+        uint32_t gb[AVN_GRAPH_COLOR_COUNT] = {0};
+        gb[color] = grid_blocks[color];
+        OverflowSchedule ovf{0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+        if (color == AVN_COLOR_OVERFLOW_INDEX) {
+            ovf = OverflowSchedule{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
+                                   sched_overflow.d_order.as<uint32_t>(), nullptr, nullptr, 0};
+            if (sched_overflow.gorder.size() > overflow_level_threshold) {
+                ovf.gorder = sched_overflow.d_gorder.as<uint32_t>();
+                ovf.glevel_offsets = sched_overflow.glevel_offsets.data();
+                ovf.n_glevels = (uint32_t)sched_overflow.glevel_offsets.size() - 1;
+            }
+        }
+        launches += launch_contact_pass<T>(dw, params, pass, gb, use_handles ? nullptr : color_offsets, ovf, stream);
+        return AVN_OK;
+    }
+    static int color_pass_of(avn_system sys) {
+        switch (sys) {
+            case AVN_SYS_WARM_START: return PASS_WARM_START_COLORS;
+            case AVN_SYS_SOLVE_CONTACTS_BIAS: return PASS_SOLVE_BIAS;
+            case AVN_SYS_SOLVE_CONTACTS_RELAX: return PASS_SOLVE_RELAX;
+            case AVN_SYS_SOLVE_RESTITUTION: return PASS_RESTITUTION_;
+            default: return -1;
+        }
+    }
+    avn_status run_color_pass(avn_system sys, uint32_t color) override {
+        if (color >= AVN_GRAPH_COLOR_COUNT) { error = "run_color_pass: colour out of range"; return AVN_ERR_BAD_ARG; }
+        const int pass = color_pass_of(sys);
+        if (pass < 0) { error = "run_color_pass: not a contact pass"; return AVN_ERR_BAD_ARG; }
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if (pass == PASS_RESTITUTION_ && !any_restitution) return AVN_OK;
+        if ((st = color_pass_enqueue(pass, color)) != AVN_OK) return st;
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status halo_list(uint32_t color, uint32_t peer, const std::vector<uint32_t>& off, size_t* b0, size_t* b1) {
+        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size()) { error = "halo: colour or peer out of range"; return AVN_ERR_BAD_ARG; }
+        const size_t k = (size_t)color * halo.peers.size() + peer;
+        *b0 = off[k]; *b1 = off[k + 1];
+        return AVN_OK;
+    }
+    avn_status halo_pack(uint32_t color, uint32_t peer, void* out, size_t* count) override {
+        if (!count) { error = "halo_pack: null count"; return AVN_ERR_BAD_ARG; }
+        size_t b0, b1;
+        avn_status st = halo_list(color, peer, halo.send_off, &b0, &b1);
+        if (st != AVN_OK) return st;
+        *count = b1 - b0;
+        if (b1 == b0) return AVN_OK;
+        if (!out) { error = "halo_pack: null output"; return AVN_ERR_BAD_ARG; }
+        if ((st = need_bodies()) != AVN_OK) return st;
+        launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + b0, (uint32_t)(b1 - b0), b_halo_out.as<V>() + 2 * b0, stream); ++launches;
+        HIPCHK(hipMemcpyAsync(out, b_halo_out.as<V>() + 2 * b0, (b1 - b0) * 2 * sizeof(V), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status halo_unpack(uint32_t color, uint32_t peer, const void* in, size_t count) override {
+        size_t b0, b1;
+        avn_status st = halo_list(color, peer, halo.recv_off, &b0, &b1);
+        if (st != AVN_OK) return st;
+        if (count != b1 - b0 || (count && !in)) { error = "halo_unpack: count does not match the plan"; return AVN_ERR_BAD_ARG; }
+        if (!count) return AVN_OK;
+        if ((st = need_bodies()) != AVN_OK) return st;
+        HIPCHK(hipMemcpyAsync(b_halo_in.as<V>() + 2 * b0, in, count * 2 * sizeof(V), hipMemcpyHostToDevice, stream));
+        launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + b0, (uint32_t)count, b_halo_in.as<V>() + 2 * b0, stream); ++launches;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status comm_init(const uint8_t* unique_id, int n_ranks, int rank) override {
+        HIPCHK(hipStreamSynchronize(stream));
+        return comm.init(unique_id, n_ranks, rank, error);
+    }
+    // the exchange after colour c inside avn_step: everything is enqueued on the world's stream, no host code waits
+    avn_status halo_exchange(uint32_t c) {
+        const size_t np = halo.peers.size(), k0 = (size_t)c * np;
+        const size_t s0 = halo.send_off[k0], s1 = halo.send_off[k0 + np], r0 = halo.recv_off[k0], r1 = halo.recv_off[k0 + np];
+        if (s1 == s0 && r1 == r0) return AVN_OK;
+        if (s1 > s0) { launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + s0, (uint32_t)(s1 - s0), b_halo_out.as<V>() + 2 * s0, stream); ++launches; }
+        xf_send.clear(); xf_recv.clear();
+        for (size_t p = 0; p < np; ++p) {
+            const size_t a = halo.send_off[k0 + p], b = halo.send_off[k0 + p + 1], ra = halo.recv_off[k0 + p], rb = halo.recv_off[k0 + p + 1];
+            if (b > a) xf_send.push_back(CommXfer{b_halo_out.as<V>() + 2 * a, (b - a) * 2 * sizeof(V), halo.peers[p]});
+            if (rb > ra) xf_recv.push_back(CommXfer{b_halo_in.as<V>() + 2 * ra, (rb - ra) * 2 * sizeof(V), halo.peers[p]});
+        }
+        avn_status st = comm.exchange(xf_send.data(), xf_send.size(), xf_recv.data(), xf_recv.size(), stream, error);
+        if (st != AVN_OK) return st;
+        ++halo_exchanges;
+        if (r1 > r0) { launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + r0, (uint32_t)(r1 - r0), b_halo_in.as<V>() + 2 * r0, stream); ++launches; }
+        return AVN_OK;
+    }
+    uint32_t halo_exchanges = 0;
+    // one contact pass in level-2 form: colours in solve order (overflow first), exchange after each
+    avn_status level2_pass(int pass) {
+        static const auto order = [] { std::array<uint32_t, AVN_GRAPH_COLOR_COUNT> o; o[0] = AVN_COLOR_OVERFLOW_INDEX; for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) o[c + 1] = c; return o; }();
+        for (uint32_t c : order) {
+            avn_status st = color_pass_enqueue(pass, c);
+            if (st == AVN_OK) st = halo_exchange(c);
+            if (st != AVN_OK) return st;
+        }
+        return AVN_OK;
+    }
+    avn_status level2_substeps() {   // SubstepSchedule with the contact passes split by colour (avian_amd/shard.py: level2_solver)
+        for (uint32_t s = 0; s < cfg.substeps; ++s) {
+            integrate_velocities();
+            avn_status st = level2_pass(PASS_WARM_START_COLORS);
+            for (uint32_t it = 0; it < cfg.solver_iterations && st == AVN_OK; ++it) st = level2_pass(PASS_SOLVE_BIAS);
+            if (st != AVN_OK) return st;
+            integrate_positions();
+            for (uint32_t it = 0; it < cfg.solver_iterations && st == AVN_OK; ++it) st = level2_pass(PASS_SOLVE_RELAX);
+            if (st != AVN_OK) return st;
+            for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
+            xpbd_velocity_projection();
+            joint_damping();
+        }
+        return AVN_OK;
+    }

@@ -1,0 +1,350 @@
+// world/pipeline_device.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
+// closed loop with the bookkeeping on the device (k_graph.hip).
+
+    // ---- closed loop, bookkeeping on the device -------------------------------------------------------------------------------
+    template <class U> avn_status pg_buf(DevBuf& b, size_t count, U** field, bool keep = false) {
+        hipError_t err;
+        b.ensure(std::max<size_t>(count, 1) * sizeof(U), err, keep, stream);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        *field = b.as<U>();
+        return AVN_OK;
+    }
+    // per-row arrays follow CT::cap (contents kept: they are persistent state); per-op scratch is sized for one op per row
+    avn_status pg_ensure_rows(uint32_t rows) {
+        if (rows <= pg_rows) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        const uint32_t old = pg_rows;
+        avn_status st;
+#define PGB(buf, cnt, field, keep) do { if ((st = pg_buf(buf, cnt, &(field), keep)) != AVN_OK) return st; } while (0)
+        PGB(b_pg_bodies, rows, pg.bodies, true); PGB(b_pg_color, rows, pg.color, true); PGB(b_pg_lpos, rows, pg.lpos, true);
+        PGB(b_pg_free_a, rows, pg.free_ids, true); PGB(b_pg_free_b, rows, pg.free_alt, true);
+        {   // colour lists: [24][stride] re-laid out for the new stride
+            uint32_t* nl = nullptr;
+            if (hipMalloc((void**)&nl, (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4) != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT && old; ++c)
+                if (pgm_len[c]) HIPCHK(hipMemcpy(nl + (size_t)c * rows, pg.lists + (size_t)c * old, (size_t)pgm_len[c] * 4, hipMemcpyDeviceToDevice));
+            if (b_pg_lists.p) (void)hipFree(b_pg_lists.p);
+            b_pg_lists.p = nl; b_pg_lists.cap = (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4;
+            pg.lists = nl; pg.list_stride = rows;
+        }
+        PGB(b_pg_chg, rows, pg.chg, false); PGB(b_pg_has, rows, pg.has, false); PGB(b_pg_off, rows + 1, pg.off, false);
+        PGB(b_pg_op_cid, rows, pg.op_cid, false); PGB(b_pg_op_info, rows, pg.op_info, false); PGB(b_pg_op_bodies, rows, pg.op_bodies, false);
+        PGB(b_pg_ekey_a, 2 * (size_t)rows, pg.ekey_a, false); PGB(b_pg_eval_a, 2 * (size_t)rows, pg.eval_a, false);
+        PGB(b_pg_ekey_b, 2 * (size_t)rows, pg.ekey_b, false); PGB(b_pg_eval_b, 2 * (size_t)rows, pg.eval_b, false);
+        PGB(b_pg_epos, 2 * (size_t)rows, pg.epos, false); PGB(b_pg_popbefore, 2 * (size_t)rows, pg.popbefore, false);
+        PGB(b_pg_prevpush, 2 * (size_t)rows, pg.prevpush, false); PGB(b_pg_est, 2 * (size_t)rows, pg.est, false);
+        PGB(b_pg_tile_agg, 5 * (size_t)pg_scan_tiles(2 * rows) + 8, pg.tile_agg, false);
+        PGB(b_pg_ckey_a, rows, pg.ckey_a, false); PGB(b_pg_cval_a, rows, pg.cval_a, false); PGB(b_pg_ckey_b, rows, pg.ckey_b, false); PGB(b_pg_cval_b, rows, pg.cval_b, false);
+        PGB(b_pg_rem_flag, rows, pg.rem_flag, false); PGB(b_pg_rem_off, rows + 1, pg.rem_off, false); PGB(b_pg_rem_ids, rows, pg.rem_ids, false);
+        uint32_t* dummy;
+        PGB(b_pg_hist, (size_t)256 * radix_blocks(2 * rows) + 256, dummy, false);
+        PGB(b_pg_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks(2 * rows)), scan_block_sums_needed(2 * rows)) + 16, dummy, false);
+#undef PGB
+        pg.rows = rows; pg_rows = rows;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    // per-body colour masks (one 24-bit word per body): follow cap_bodies, contents kept, the new tail zeroed
+    uint32_t pg_bcol_words = 0;
+    avn_status pg_bcol_grow() {
+        const uint32_t want = cap_bodies + 1;
+        if (want <= pg_bcol_words) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        avn_status st = pg_buf(b_pg_bcol, want, &pg.bcol, true);
+        if (st != AVN_OK) return st;
+        HIPCHK(hipMemsetAsync(pg.bcol + pg_bcol_words, 0, (size_t)(want - pg_bcol_words) * 4, stream));
+        pg_bcol_words = want;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    // collider entity -> slot (dense: Entity::index() values are small integers); rebuilt by every colliders_upload that changes the slots
+    avn_status pg_upload_ent2slot() {
+        uint32_t max_ent = 0;
+        for (uint32_t e : slot_entity) max_ent = std::max(max_ent, e);
+        if (max_ent > (1u << 27)) { error = "pipeline_enable: collider entity indices above 2^27 need the host bookkeeping (AVN_PIPELINE_HOST=1)"; return AVN_ERR_CAPACITY; }
+        std::vector<uint32_t> e2s((size_t)max_ent + 1, 0u);
+        for (uint32_t i = 0; i < slot_entity.size(); ++i) e2s[slot_entity[i]] = i;
+        HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
+        uint32_t* d;
+        avn_status st = pg_buf(b_pg_ent2slot, e2s.size(), &d);
+        if (st != AVN_OK) return st;
+        HIPCHK(hipMemcpy(d, e2s.data(), e2s.size() * 4, hipMemcpyHostToDevice));
+        pg.ent2slot = d;
+        return AVN_OK;
+    }
+    avn_status pipeline_device_reset() {
+        HIPCHK(hipStreamSynchronize(stream));
+        HIPCHK(hipStreamSynchronize(stream_bp));
+        avn_status st;
+        hipError_t err;
+        b_pg_ctr.ensure(PGC_WORDS * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        pg.ctr = b_pg_ctr.as<uint32_t>();
+        HIPCHK(hipMemset(pg.ctr, 0, PGC_WORDS * 4));
+        pg_bcol_words = 0;
+        if ((st = pg_bcol_grow()) != AVN_OK) return st;
+        HIPCHK(hipMemset(pg.bcol, 0, (size_t)pg_bcol_words * 4));
+        if ((st = pg_upload_ent2slot()) != AVN_OK) return st;
+        if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
+        if ((st = ensure_contact_rows(std::max<uint32_t>(ct.cap, 1024u))) != AVN_OK) return st;
+        pg_rows = 0;   // (re)allocate everything for the table's capacity
+        std::memset(pgm_len, 0, sizeof pgm_len);
+        if ((st = pg_ensure_rows(ct.cap)) != AVN_OK) return st;
+        HIPCHK(hipMemset(pg.color, 0xFF, (size_t)pg_rows * 4));
+        contact_keys_live = false; h_live_keys.clear();   // (the pair set keeps the keys the host announced: existing pairs stay existing)
+        pgm_head = pgm_n_free = pgm_next_id = pgm_live = pgm_tomb = 0;
+        std::memset(&pipe_stats, 0, sizeof pipe_stats);
+        std::memset(pipe_offsets, 0, sizeof pipe_offsets);
+        uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+        dw.n_manifolds = 0;
+        set_color_offsets(zero);
+        HIPCHK(hipMemcpy(dw.color_offsets, zero, sizeof zero, hipMemcpyHostToDevice));
+        use_handles = true; any_restitution = materials_restitution;
+        incidence_dirty = true; graph_valid = false;
+        if (pin_ctr.ensure(4096) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        return AVN_OK;
+    }
+    static uint32_t bits_for(uint32_t max_value) { uint32_t b = 1; while (b < 32 && (max_value >> b)) ++b; return b; }
+    // ContactGraph::pair_set with room for `expect` more keys: rebuilt from the live rows when it would pass half full (tombstones count)
+    avn_status pg_pair_set_reserve(uint32_t n_rows_now, uint32_t incoming) {
+        const uint64_t need_keys = (uint64_t)n_pair_keys + pgm_live + pgm_tomb + incoming + 16;
+        if (bp.pair_set_cap && 2 * need_keys <= bp.pair_set_cap) return AVN_OK;
+        uint32_t need = 1024;
+        while ((uint64_t)need < 4 * ((uint64_t)n_pair_keys + pgm_live + incoming + 16)) need <<= 1;
+        HIPCHK(hipStreamSynchronize(bs));
+        hipError_t err;
+        b_pair_set.ensure((size_t)need * 8, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        bp.pair_set = b_pair_set.as<uint64_t>();
+        bp.pair_set_cap = need;
+        HIPCHK(hipMemsetAsync(bp.pair_set, 0xFF, (size_t)need * 8, bs));
+        launch_hs_insert(bp.pair_set, need, b_pair_keys.as<uint64_t>(), n_pair_keys, bs);   // keys announced by the host (avn_existing_pairs_upload, pairs collected outside the loop)
+        launch_pg_rebuild_pair_set<T>(ct, bp, n_rows_now, bs);
+        HIPCHK(hipGetLastError());
+        pgm_tomb = 0;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    // PGC_ERROR: bit 0 = k_pg_color's dataflow wait ran out (colouring), bit 1 = k_overflow_flow's ticket wait ran out (overflow colour's
+    // solve), bit 2 = k_pack_contacts was asked to write a row that is not live.  The word is read back at the end of every step into pinned
+    // memory (no extra synchronisation: the copy rides the stream); whoever synchronises next -- avn_synchronize, the next avn_step -- reports
+    // it under the name of the kernel that raised it and clears it.
+    uint32_t* h_pg_error = nullptr;   // pinned
+    bool pg_error_pending = false;
+    avn_status pg_error_fetch() {     // enqueue the read-back behind everything the step launched
+        if (!pipe_dev || !pg.ctr) return AVN_OK;
+        if (!h_pg_error) { HIPCHK(hipHostMalloc((void**)&h_pg_error, 64, hipHostMallocDefault)); *h_pg_error = 0; }
+        HIPCHK(hipMemcpyAsync(h_pg_error, pg.ctr + PGC_ERROR, 4, hipMemcpyDeviceToHost, stream));
+        pg_error_pending = true;
+        return AVN_OK;
+    }
+    avn_status pg_error_report(uint32_t word) {   // the stream is idle here
+        if (!word) return AVN_OK;
+        error = "device closed loop:";
+        if (word & 1u) error += " k_pg_color: the colouring's dataflow wait timed out (colour lists of this step are not the reference's);";
+        if (word & 2u) error += " k_overflow_flow: a ticket wait of the overflow colour's solve timed out (the step's velocities are not the reference's);";
+        if (word & 4u) error += " k_pack_contacts: avn_contacts_upload named a contact id whose row is not live (skipped);";
+        if (word & ~7u) error += " unknown bits in the error word;";
+        error += " the error word has been cleared";
+        HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (h_pg_error) *h_pg_error = 0;
+        return AVN_ERR_STATE;
+    }
+    avn_status pg_error_check() {     // after a synchronisation of `stream`
+        if (!pg_error_pending) return AVN_OK;
+        pg_error_pending = false;
+        return pg_error_report(*h_pg_error);
+    }
+    avn_status pipeline_step_device() {
+        avn_status st;
+        launches = 0;
+        double host_ms = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
+        HIPCHK(hipEventRecord(ev[0], stream));
+        if ((st = update_aabb()) != AVN_OK) return st;
+        if ((st = collect_launch()) != AVN_OK) return st;
+        lap();
+        // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
+        uint32_t total = 0;
+        if (collect_pending) {
+            collect_pending = false;
+            HIPCHK(hipEventSynchronize(ev_counters));
+            t0 = std::chrono::steady_clock::now();
+            if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
+                if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return st;
+                if ((st = collect_launch()) != AVN_OK) return st;
+                collect_pending = false;
+                HIPCHK(hipEventSynchronize(ev_counters));
+                if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+            }
+            const uint32_t dropped = h_counters[0];
+            total = h_counters[2];
+            if (total) {
+                hipError_t err;
+                b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
+                if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
+                launch_sweep<T>(bp, collect_n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), bs);
+                launches += 2;
+                const uint32_t fresh = total > pgm_n_free ? total - pgm_n_free : 0u;
+                if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return st;
+                if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return st;
+                launch_hs_insert_pairs(bp.pair_set, bp.pair_set_cap, b_pairs.as<avn_pair>(), total, bs);   // add_edge_and_key_with: the keys join the pair set
+                launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bs);
+                launches += 3;
+                HIPCHK(hipGetLastError());
+                const uint32_t used = std::min(total, pgm_n_free);
+                pgm_head += used; pgm_n_free -= used; pgm_next_id += total - used; pgm_live += total;
+                pipe_stats.pairs_added += total;
+            }
+            bp.n_intervals = collect_n - dropped;
+            last_timers.pair_count = total;
+        }
+        HIPCHK(hipEventRecord(ev[1], stream));
+        // ---- narrow phase over every live row; changes numbered in ascending ContactId ----
+        const uint32_t n_rows = pgm_next_id;
+        uint32_t n_ops = 0, n_rem = 0;
+        if (n_rows) {
+            launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            launch_exclusive_scan(pg.has, pg.off, n_rows, b_pg_sums.as<uint32_t>(), pg.ctr + PGC_N_OPS, stream);
+            launches += 1 + exclusive_scan_launches(n_rows);
+            HIPCHK(hipGetLastError());
+            uint32_t* h = (uint32_t*)pin_ctr.p;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
+            lap();
+            HIPCHK(hipStreamSynchronize(stream));
+            t0 = std::chrono::steady_clock::now();
+            n_ops = h[0]; n_rem = h[1];
+            pg_error_pending = false;
+            if (h[2]) return pg_error_report(h[2]);   // raised by the previous step's solver passes (normally already reported by avn_synchronize)
+        }
+        pipe_stats.last_status_changes = n_ops;
+        ++pg_dump_step;
+        if (n_ops) {
+            // ---- the status-change loop: decisions, colours, handle lists ----
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
+            launch_pg_classify(pg, n_rows, dw.n_bodies, stream);
+            uint32_t *ek, *evv;
+            launch_radix_sort_bits(pg.ekey_a, pg.eval_a, pg.ekey_b, pg.eval_b, 2 * n_ops, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ek, &evv, stream);
+            launch_pg_entry_scan(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_color(pg, n_ops, stream);
+            launch_pg_apply_masks(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_bucket_keys(pg, n_ops, stream);
+            uint32_t *ck, *order;
+            launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
+            launch_pg_replay(pg, order, n_ops, stream);
+            launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
+            if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
+                launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
+                launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
+                launch_pg_merge_free(pg, pgm_head, pgm_n_free, n_rem, stream);
+                HIPCHK(hipMemcpyAsync(pg.free_ids, pg.free_alt, ((size_t)pgm_n_free + n_rem) * 4, hipMemcpyDeviceToDevice, stream));
+                pgm_head = 0; pgm_n_free += n_rem; pgm_live -= n_rem; pgm_tomb += n_rem;
+                pipe_stats.pairs_removed += n_rem;
+                launches += 5;
+            }
+            HIPCHK(hipGetLastError());
+            uint32_t* h = (uint32_t*)pin_ctr.p + 16;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
+            lap();
+            HIPCHK(hipStreamSynchronize(stream));
+            t0 = std::chrono::steady_clock::now();
+            if (h[32]) return pg_error_report(h[32]);
+            if (getenv("AVN_PG_REPLAY_STATS")) {
+                uint32_t d[96];
+                HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[avn replay] colour: ops/iterations/serial/reloads:");
+                for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (d[72 + c]) std::fprintf(stderr, " %d:%u/%u/%u/%u", c, d[72 + c], d[c], d[24 + c], d[48 + c]);
+                std::fprintf(stderr, "\n");
+            }
+            if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
+                std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
+                std::vector<int2> bd(n_ops);
+                HIPCHK(hipMemcpy(a.data(), pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(b.data(), pg.op_info, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(bd.data(), pg.op_bodies, (size_t)n_ops * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(o.data(), order, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(cnt.data(), pg.ctr + PGC_BUCKET, 32 * 4, hipMemcpyDeviceToHost));
+                char path[512];
+                std::snprintf(path, sizeof path, "%s/step_%04llu.bin", dir, (unsigned long long)pg_dump_step);
+                if (FILE* f = std::fopen(path, "wb")) {
+                    uint32_t hdr[4] = {n_ops, n_rem, 0, 0};
+                    std::fwrite(hdr, 4, 4, f); std::fwrite(a.data(), 4, n_ops, f); std::fwrite(b.data(), 4, n_ops, f); std::fwrite(bd.data(), 8, n_ops, f);
+                    std::fwrite(o.data(), 4, n_ops, f); std::fwrite(cnt.data(), 4, 32, f);
+                    std::fclose(f);
+                }
+            }
+            pipe_stats.manifolds_pushed = h[34]; pipe_stats.manifolds_popped = h[35];
+            uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
+            uint32_t M = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[c]; offs[c] = M; M += h[c]; }
+            offs[AVN_GRAPH_COLOR_COUNT] = M;
+            if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
+            if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
+            dw.n_manifolds = M;
+            set_color_offsets(offs);
+            hipError_t err;
+            if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, stream);
+            ++launches;
+            HIPCHK(hipGetLastError());
+            incidence_dirty = true;
+        }
+        pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
+        lap();
+        pipe_stats.last_host_ms = host_ms;
+        stamp(DG_NP1); dg_np = true;
+        if ((st = solver()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[4], stream));
+        ev_valid = true;
+        last_timers.kernel_launches = launches;
+        return pg_error_fetch();
+    }
+    // the overflow colour's CSR + ranks, and the slot table of the other colours, from the gathered manifold arrays (all on the device)
+    avn_status rebuild_incidence_device() {
+        const uint32_t N = dw.n_bodies, M = dw.n_manifolds;
+        incidence_dirty = false;
+        island_mode = false; islands_dirty = false;
+        if (M == 0) return AVN_OK;
+        hipError_t err;
+        bool moved = b_inc_slot.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * cap_bodies * sizeof(uint32_t), err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (moved || dw.inc_stride != cap_bodies) graph_valid = false;
+        dw.inc_slot = b_inc_slot.as<uint32_t>(); dw.inc_stride = cap_bodies;
+        slots_dirty = true;
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+        moved = b_inc_off.ensure(((size_t)N + 2) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (n23 > pg_ovf_cap) {
+            HIPCHK(hipStreamSynchronize(stream));
+            const size_t c = std::max<size_t>(2 * (size_t)n23 + 1024, (size_t)pg_ovf_cap * 3);
+            for (DevBuf* b : {&b_inc_ent, &b_ovf_keys_a, &b_ovf_vals_a, &b_ovf_keys_b, &b_ovf_vals_b, &b_ovf_rank}) {
+                b->ensure(c * 4, err);
+                if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            }
+            pg_ovf_cap = (uint32_t)(c / 2);
+            moved = true;
+        }
+        if (b_inc_ent.cap == 0) { b_inc_ent.ensure(1024, err); b_ovf_rank.ensure(1024, err); moved = true; }
+        if (b_ovf_ticket.ensure(((size_t)cap_bodies + 1) * 4, err)) moved = true;
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (moved || !dw.inc_off) graph_valid = false;
+        dw.inc_off = b_inc_off.as<uint32_t>(); dw.inc_ent = b_inc_ent.as<uint32_t>();
+        islands_dirty = island_candidate(M) && dw.n_joints == 0;
+        return AVN_OK;
+    }
+    // after k_gather_manifolds (the CSR reads DW::m_bodies of the overflow range)
+    void overflow_csr_device() {
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+        uint32_t *k = b_ovf_keys_a.as<uint32_t>(), *v = b_ovf_vals_a.as<uint32_t>();
+        if (n23) {
+            launch_ovf_entries<T>(dw, o0, n23, k, v, stream);
+            launch_radix_sort_bits(k, v, b_ovf_keys_b.as<uint32_t>(), b_ovf_vals_b.as<uint32_t>(), 2 * n23, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &k, &v, stream);
+            launches += 1 + ((bits_for(dw.n_bodies) + 7) / 8) * radix_pass_launches(2 * n23);
+        }
+        launch_ovf_csr<T>(dw, o0, n23, k, v, b_inc_off.as<uint32_t>(), b_inc_ent.as<uint32_t>(), b_ovf_rank.as<uint32_t>(), stream);
+        launches += 2;
+    }

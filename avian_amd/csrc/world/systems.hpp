@@ -1,0 +1,326 @@
+// world/systems.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
+// the systems of the schedule, the substep loop (hipGraph), avn_run_system / avn_step.
+
+    // ---- systems -------------------------------------------------------------------------------------------
+    avn_status need_bodies() { if (!have_bodies) { error = "no bodies uploaded"; return AVN_ERR_STATE; } return AVN_OK; }
+    void prepare_solver_bodies() { launch_prepare_solver_bodies<T>(dw, stream); ++launches; }
+    void prepare_joints() { if (dw.n_joints) { launch_prepare_joints<T>(dw, stream); ++launches; } }
+    void prepare_contact_constraints() {
+        // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
+        if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+        if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
+        launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
+    }
+    void store_contact_impulses() {
+        launch_store_contact_impulses<T>(dw, stream); ++launches;
+        if (use_handles && dw.n_manifolds) { launch_scatter_impulses<T>(dw, ct, b_handles.as<uint32_t>(), stream); ++launches; }
+    }
+    void pre_process_velocity_increments() { launch_pre_process_increments<T>(dw, params, stream); ++launches; }
+    void integrate_velocities() { launch_integrate_velocities<T>(dw, params, stream); ++launches; }
+    // warm start of ALL colours in one body-centric launch; `fused` also runs integrate_velocities for the body first
+    void warm_start(bool fused) {
+        if (dw.n_manifolds) {
+            if (slots_dirty && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }  // (normally done by prepare)
+            launch_body_warm_start<T>(dw, params, fused, stream); ++launches;
+        }
+        else if (fused) integrate_velocities();
+    }
+    void integrate_positions() { launch_integrate_positions<T>(dw, params, stream); ++launches; }
+    void contact_pass(int pass) {
+        if (!dw.n_manifolds) return;
+        if (bias_skeleton && pass == PASS_SOLVE_BIAS) pass = PASS_MEMORY_SKELETON;   // AVN_BIAS_SKELETON=1: measurement aid, state unchanged
+        if (pipe_dev) {   // overflow colour first (one dataflow launch), then colours 0..22
+            // (launched whenever a grid is captured for it, whatever the colour's current population: the captured graph must not
+            //  depend on the step's counts; an empty colour costs one launch of idle lanes)
+            if (ovf_grid_blocks && ovf_epoch < PGC_OVF_TILES) {
+                OverflowFlow of{b_ovf_rank.as<uint32_t>(), b_ovf_ticket.as<uint32_t>(), pg.ctr + PGC_OVF_TILE, pg.ctr + PGC_ERROR};
+                launch_overflow_flow<T>(dw, params, pass, of, ovf_epoch, ovf_grid_blocks, stream);
+                ++ovf_epoch; ++launches;
+            }
+            uint32_t gb[AVN_GRAPH_COLOR_COUNT];
+            std::memcpy(gb, grid_blocks, sizeof gb);
+            gb[AVN_COLOR_OVERFLOW_INDEX] = 0;
+            OverflowSchedule none{0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
+            launches += launch_contact_pass<T>(dw, params, pass, gb, nullptr, none, stream);
+            return;
+        }
+        OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
+                             sched_overflow.d_order.as<uint32_t>(), nullptr, nullptr, 0};
+        if (sched_overflow.gorder.size() > overflow_level_threshold) {  // a big overflow colour: one device-wide launch per level instead of one workgroup per component
+            ovf.gorder = sched_overflow.d_gorder.as<uint32_t>();
+            ovf.glevel_offsets = sched_overflow.glevel_offsets.data();
+            ovf.n_glevels = (uint32_t)sched_overflow.glevel_offsets.size() - 1;
+        }
+        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, use_handles ? nullptr : color_offsets, ovf, stream);
+    }
+    // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
+    // installed (xpbd/plugin.rs:61-76,192-240).  With no joints the projection adds 2 * (dq * conj(dq)).xyz / h:
+    //  - f32 (glam's SIMD `Quat`, pairwise sums): every xyz component cancels exactly, e.g. y = (-wy + xz) + (yw - zx) is
+    //    a + (-a) = 0, so the two systems are exact no-ops (up to the sign of a zero) and are skipped;
+    //  - f64 (scalar `DQuat`, left-to-right sums): y = ((-wy + xz) + yw) - zx leaves a rounding residual of order
+    //    ulp(wy), so the reference really perturbs omega every substep — replicate, don't "fix" (found by the cfg5 test).
+    bool xpbd_body_passes_needed() const { return dw.n_joints != 0 || sizeof(T) == 8; }
+    void xpbd_solve(bool snapshot) {
+        if (snapshot && xpbd_body_passes_needed()) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
+        if (!dw.n_joints) return;
+        launch_joint_schedule<T>(dw, params, 0, (uint32_t)sched_solve.n_components, sched_solve.d_comp_level_begin.as<uint32_t>(),
+                                 sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_rec.as<int4>(), stream);
+        ++launches;
+    }
+    void xpbd_velocity_projection() { if (xpbd_body_passes_needed()) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
+    void joint_damping() {
+        if (!any_damped || !sched_damp.n_components) return;
+        if (sched_damp.touches_dummy) {
+            // reset the two virtual SolverBody::DUMMY slots (all-zero bit pattern = zero velocities)
+            (void)hipMemsetAsync(&dw.sb_lin[dw.n_bodies], 0, 2 * DUMMY_SLOTS * sizeof(V), stream);  // DUMMY_SLOTS bodies x (lin | ang) slot
+        }
+        launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp.n_components, sched_damp.d_comp_level_begin.as<uint32_t>(),
+                                 sched_damp.d_level_offsets.as<uint32_t>(), sched_damp.d_rec.as<int4>(), stream);
+        ++launches;
+    }
+    void substep() {  // SubstepSchedule order (reference solver/schedule.rs:59-69, xpbd/plugin.rs:30-40)
+        const bool dg = !cfg.use_graph && substep_index < DG_SUBSTEPS;   // (events captured into a hipGraph cannot be read back)
+        hipEvent_t* de = ev_dgs + (size_t)substep_index * DG_PER;
+        if (dg) (void)hipEventRecord(de[0], stream);
+        warm_start(true);  // integrate_velocities + warm_start
+        if (dg) (void)hipEventRecord(de[1], stream);
+        // measurement hook: the dominant kernel's launches inside the step.  Direct launches only: events recorded as nodes of a
+        // captured graph cannot be read back with hipEventElapsedTime on this runtime (hipErrorInvalidHandle).
+        const bool timed = substep_index < BIAS_EV && dw.n_manifolds != 0 && !cfg.use_graph;
+        if (timed) { (void)hipEventRecord(ev_bias[2 * substep_index], stream); bias_launches = launches; }
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_BIAS);
+        if (timed) { (void)hipEventRecord(ev_bias[2 * substep_index + 1], stream); bias_launches = launches - bias_launches; bias_timed = substep_index + 1; }
+        ++substep_index;
+        if (dg) (void)hipEventRecord(de[2], stream);
+        integrate_positions();
+        if (dg) (void)hipEventRecord(de[3], stream);
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) contact_pass(PASS_SOLVE_RELAX);
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
+        xpbd_velocity_projection();
+        joint_damping();
+        if (dg) { (void)hipEventRecord(de[4], stream); dg_substeps = substep_index; }
+    }
+    bool islands_active() const { return island_mode && dw.n_joints == 0 && dw.n_manifolds != 0 && !halo_on; }
+    avn_status run_substeps() {
+        substep_index = 0;
+        bias_timed = 0;
+        dg_substeps = 0;
+        if (halo_on) {   // level-2 sharding: direct launches, the exchanges are RCCL calls on the same stream
+            if (!comm.handle) { error = "a halo plan is set but no communicator: call avn_comm_init, or drive the colours through avn_run_color_pass"; return AVN_ERR_STATE; }
+            return level2_substeps();
+        }
+        if constexpr (sizeof(T) == 4) {
+            if (islands_active()) {   // every substep of every island block in ONE launch (k_island_substeps)
+                launch_island_substeps(dw, params, islands, cfg.substeps, cfg.solver_iterations, stream); ++launches;
+                // (device closed loop: the restitution pass after the loop still runs colour by colour; its overflow pass starts a fresh epoch count)
+                if (pipe_dev && ovf_grid_blocks) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+                ovf_epoch = 0;
+                return AVN_OK;
+            }
+        }
+        // the body-centric warm start's slot table (not needed by the island blocks); outside the capture below
+        if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
+        const bool flow = pipe_dev && dw.n_manifolds && ovf_grid_blocks;
+        if (flow && (uint64_t)cfg.substeps * 2 * cfg.solver_iterations + 2 > PGC_OVF_TILES) { error = "device closed loop: too many contact passes per step for the overflow tickets"; return AVN_ERR_CAPACITY; }
+        if (!cfg.use_graph) {
+            if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+            ovf_epoch = 0;
+            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            ovf_epoch_after_substeps = ovf_epoch;
+            return AVN_OK;
+        }
+        if (!graph_valid) {
+            if (getenv("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
+            drop_graph();
+            uint32_t before = launches;
+            HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            // the overflow passes' tickets and tile counters restart with every step (a kernel node, replayed first)
+            if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+            ovf_epoch = 0;
+            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            ovf_epoch_after_substeps = ovf_epoch;
+            // whatever went wrong inside the capture, the stream must leave capture mode and the partial graph must not survive
+            hipError_t ce = hipStreamEndCapture(stream, &graph);
+            graph_launches = launches - before;
+            launches = before;
+            if (ce == hipSuccess) ce = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
+            if (ce != hipSuccess) {
+                (void)hipGetLastError();
+                drop_graph();
+                error = std::string("substep graph capture failed: ") + hipGetErrorName(ce);
+                return AVN_ERR_HIP;
+            }
+            graph_valid = true;
+        }
+        HIPCHK(hipGraphLaunch(graph_exec, stream));
+        launches += graph_launches;
+        ovf_epoch = ovf_epoch_after_substeps;   // (the restitution pass after the loop continues the step's epochs)
+        return AVN_OK;
+    }
+    uint32_t graph_launches = 0;
+    avn_status solver_front() {   // everything that only READS the rigid-body components
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
+        prepare_solver_bodies();
+        prepare_joints();
+        prepare_contact_constraints();
+        stamp(DG_PREP1);
+        pre_process_velocity_increments();
+        stamp(DG_INC1);
+        // host work that only the substep loop needs, done while the prepare kernels above run
+        if (islands_dirty) {
+            islands_dirty = false;
+            if (pipe_dev) {   // the island builder is host code: fetch the (small) gathered body pairs
+                const uint32_t M = dw.n_manifolds;
+                std::vector<int2> mb(M);
+                HIPCHK(hipMemcpyAsync(mb.data(), dw.m_bodies, (size_t)M * sizeof(int2), hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                h_m_body1.resize(M); h_m_body2.resize(M);
+                for (uint32_t m = 0; m < M; ++m) { h_m_body1[m] = mb[m].x; h_m_body2[m] = mb[m].y; }
+            }
+            if ((st = rebuild_island_blocks()) != AVN_OK) return st;
+        }
+        HIPCHK(hipEventRecord(ev[2], stream));
+        if ((st = run_substeps()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[3], stream));
+        stamp(DG_SUB1);
+        launch_clear_increments<T>(dw, stream); ++launches;
+        // restitution == 0 everywhere: every manifold would early-out.  (Level 2: the exchanges are collective and `any_restitution` is a
+        // per-rank fact, so the pass always runs there; a rank without restitution launches kernels whose lanes all early-out.)
+        if (halo_on) { if ((st = level2_pass(PASS_RESTITUTION_)) != AVN_OK) return st; }
+        else if (any_restitution) contact_pass(PASS_RESTITUTION_);
+        stamp(DG_REST1);
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status solver_back() {    // the write-back into Position / Rotation / velocities and the ContactGraph
+        launch_writeback_solver_bodies<T>(dw, stream); ++launches;
+        if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
+        stamp(DG_FIN1);
+        store_contact_impulses();
+        stamp(DG_STORE1);
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    avn_status solver() {
+        avn_status st = solver_front();
+        if (st != AVN_OK) return st;
+        return solver_back();
+    }
+    avn_status dispatch_system(avn_system sys) {
+        avn_status st = AVN_OK;
+        switch (sys) {
+            case AVN_SYS_UPDATE_AABB: if ((st = update_aabb()) != AVN_OK) return st; break;
+            case AVN_SYS_COLLECT_COLLISION_PAIRS: if ((st = collect_collision_pairs()) != AVN_OK) return st; break;
+            case AVN_SYS_PREPARE_SOLVER_BODIES: prepare_solver_bodies(); break;
+            case AVN_SYS_PREPARE_JOINTS: prepare_joints(); break;
+            case AVN_SYS_PREPARE_CONTACT_CONSTRAINTS: prepare_contact_constraints(); break;
+            case AVN_SYS_PRE_PROCESS_VELOCITY_INCREMENTS: pre_process_velocity_increments(); break;
+            case AVN_SYS_INTEGRATE_VELOCITIES: integrate_velocities(); break;
+            case AVN_SYS_WARM_START: warm_start(false); break;
+            case AVN_SYS_SOLVE_CONTACTS_BIAS: contact_pass(PASS_SOLVE_BIAS); break;
+            case AVN_SYS_INTEGRATE_POSITIONS: integrate_positions(); break;
+            case AVN_SYS_SOLVE_CONTACTS_RELAX: contact_pass(PASS_SOLVE_RELAX); break;
+            case AVN_SYS_XPBD_SOLVE: xpbd_solve(true); break;
+            case AVN_SYS_XPBD_VELOCITY_PROJECTION: xpbd_velocity_projection(); break;
+            case AVN_SYS_JOINT_DAMPING: joint_damping(); break;
+            case AVN_SYS_CLEAR_VELOCITY_INCREMENTS: launch_clear_increments<T>(dw, stream); ++launches; break;
+            case AVN_SYS_SOLVE_RESTITUTION: if (any_restitution) contact_pass(PASS_RESTITUTION_); break;
+            case AVN_SYS_WRITEBACK_SOLVER_BODIES:
+                launch_writeback_solver_bodies<T>(dw, stream); ++launches;
+                if (dw.n_joints) { launch_writeback_joint_forces<T>(dw, params, stream); ++launches; }
+                break;
+            case AVN_SYS_STORE_CONTACT_IMPULSES: store_contact_impulses(); break;
+            case AVN_SYS_NARROW_PHASE: if ((st = narrow_phase()) != AVN_OK) return st; break;
+            case AVN_SYS_SUBSTEP: substep(); break;
+            case AVN_SYS_SOLVER: {
+                HIPCHK(hipEventRecord(ev[0], stream)); HIPCHK(hipEventRecord(ev[1], stream));
+                if ((st = solver()) != AVN_OK) return st;
+                HIPCHK(hipEventRecord(ev[4], stream));
+                ev_valid = true;
+                break;
+            }
+            default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
+        }
+        HIPCHK(hipGetLastError());
+        return AVN_OK;
+    }
+    // single systems run outside avn_step: the dataflow passes' per-step state has to be fresh
+    avn_status flow_begin_standalone() {
+        if (!dw.n_manifolds || !(pipe_dev && ovf_grid_blocks)) return AVN_OK;
+        launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream);
+        ovf_epoch = 0;
+        return AVN_OK;
+    }
+    avn_status run_system(avn_system sys) override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if (sys != AVN_SYS_SOLVER && (st = flow_begin_standalone()) != AVN_OK) return st;
+        if ((st = dispatch_system(sys)) != AVN_OK) return st;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status profile_system(avn_system sys, uint32_t repeats, double* total_ms, uint32_t* n_launches) override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
+        if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if ((st = flow_begin_standalone()) != AVN_OK) return st;
+        hipEvent_t a, b;
+        HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t before = launches;
+        HIPCHK(hipEventRecord(a, stream));  // events on the stream the kernels are launched on
+        for (uint32_t r = 0; r < repeats; ++r)
+            if ((st = dispatch_system(sys)) != AVN_OK) break;
+        HIPCHK(hipEventRecord(b, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, a, b));
+        (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        if (total_ms) *total_ms = ms;
+        if (n_launches) *n_launches = launches - before;
+        return st;
+    }
+    avn_status step() override {
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        for (bool& b : dg_stamped) b = false;
+        dg_np = false;
+        if (pipe_on) return pipe_dev ? pipeline_step_device() : pipeline_step();
+        launches = 0;
+        HIPCHK(hipEventRecord(ev[0], stream));
+        const bool overlap = overlap_bp && have_colliders;
+        bp_timed = false;
+        if (have_colliders) {
+            if (overlap) {
+                HIPCHK(hipStreamWaitEvent(stream_bp, ev[0], 0));  // after the previous step's write-back
+                bs = stream_bp;
+                HIPCHK(hipEventRecord(ev_bp_t0, stream_bp));
+            }
+            st = update_aabb();
+            if (st == AVN_OK) st = collect_launch();
+            if (overlap) { (void)hipEventRecord(ev_bp_t1, stream_bp); bp_timed = true; }
+            if (st != AVN_OK) { bs = stream; return st; }
+        }
+        HIPCHK(hipEventRecord(ev[1], stream));
+        st = solver_front();                              // enqueued while the broad phase runs / its pair counters travel back
+        if (st == AVN_OK) st = collect_finish();          // (emit pass only when the step found new pairs)
+        if (overlap) {
+            (void)hipEventRecord(ev_bp_done, stream_bp);
+            (void)hipStreamWaitEvent(stream, ev_bp_done, 0);  // the write-back must not overtake k_update_aabb's reads
+            bs = stream;
+        }
+        if (st != AVN_OK) return st;
+        if ((st = solver_back()) != AVN_OK) return st;
+        HIPCHK(hipEventRecord(ev[4], stream));
+        ev_valid = true;
+        last_timers.kernel_launches = launches;
+        return AVN_OK;
+    }
+    avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp)); return pg_error_check(); }
+

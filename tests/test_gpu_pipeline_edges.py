@@ -121,3 +121,93 @@ def test_f64_box_stack_closed_loop_matches_oracle():
         wo.step(); wh.step()
         same_bodies(wo, wh, f"f64 step {s}")
     assert wh.pipeline_stats().manifolds > 100
+
+
+def _respawn(w, bodies, colliders, new_pos, new_he, entity, collider_first):
+    """Append one dynamic cuboid to a running closed-loop world: every body is re-uploaded with its CURRENT state (what an ECS host does
+    each step), the collider list gains one entry — at the end, or at the front so that every existing collider changes its slot."""
+    cur = w.bodies_download()
+    n = len(bodies["inv_mass"])
+    vol = 8.0 * float(np.prod(new_he))
+    d = [vol / 3 * (new_he[1] ** 2 + new_he[2] ** 2), vol / 3 * (new_he[0] ** 2 + new_he[2] ** 2), vol / 3 * (new_he[0] ** 2 + new_he[1] ** 2)]
+    nb = dict(position=np.vstack([cur["position"], [new_pos]]), rotation=np.vstack([cur["rotation"], [[0.0, 0, 0, 1]]]),
+              linear_velocity=np.vstack([cur["linear_velocity"], [[0.0, -1.0, 0.0]]]), angular_velocity=np.vstack([cur["angular_velocity"], [[0.3, 0.0, 0.2]]]),
+              inv_mass=np.append(bodies["inv_mass"], 1.0 / vol), inv_inertia_local=np.vstack([bodies["inv_inertia_local"], [[1 / d[0], 0, 0, 1 / d[1], 0, 1 / d[2]]]]),
+              rb_type=np.append(bodies["rb_type"], F.RB_DYNAMIC).astype(np.uint8))
+    ent = np.append(colliders["entity_index"], entity).astype(np.uint32); body = np.append(colliders["body"], n).astype(np.int32)
+    shape = np.append(colliders["shape"], F.SHAPE_CUBOID).astype(np.uint8); he = np.vstack([colliders["half_extents"], [new_he]])
+    if collider_first:
+        ent, body, shape, he = np.roll(ent, 1), np.roll(body, 1), np.roll(shape, 1), np.roll(he, 1, axis=0)
+    nc = dict(entity_index=ent, body=body, shape=shape, half_extents=he)
+    w.bodies_upload(**nb); w.colliders_upload(**nc); w.collider_materials_upload(friction=0.6, restitution=0.0)
+    return nb, nc
+
+
+def test_bodies_and_colliders_spawned_inside_the_device_closed_loop():
+    """`pg.bcol` and `ent2slot` were sized once at avn_pipeline_enable.  Two spawns while contacts are live — one appended, one whose
+    collider is uploaded FIRST (every live row's collider slots are renumbered) — and the run stays equal to the oracle's, step by step."""
+    from test_gpu_graph import compare_step
+    bodies, colliders = dropped_boxes(seed=11, n=40)
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(32, substeps=4))
+        upload(w, bodies, colliders); w.collider_materials_upload(friction=0.6, restitution=0.0); w.pipeline_enable()
+        worlds.append(w)
+    wo, wh = worlds
+    s = 0
+    for _ in range(25):
+        wo.step(); wh.step(); compare_step(s, wo, wh); s += 1
+    assert wh.pipeline_stats().manifolds > 20
+    state = [(bodies, colliders), (bodies, colliders)]
+    for k, (pos, first) in enumerate((([1.5, 6.0, 1.5], False), ([2.5, 7.0, 2.0], True))):
+        state = [_respawn(w, st[0], st[1], pos, [0.4, 0.3, 0.5], 5000 + k, first) for w, st in zip((wo, wh), state)]
+        for _ in range(30):
+            wo.step(); wh.step(); compare_step(s, wo, wh, check_rows=(s % 10 == 0)); s += 1
+    # the spawned boxes have landed on the pile: they are part of the contact graph
+    ids = wh.pipeline_handles()[1]
+    assert len(ids) and wh.bodies_download()["position"][-1, 1] < 5.0
+
+
+def test_despawn_inside_the_closed_loop_is_refused_not_ignored():
+    """Fewer bodies, or a collider with live contact rows missing from the upload: AVN_ERR_STATE and an unchanged world (the
+    library used to switch the closed loop off silently)."""
+    bodies, colliders = dropped_boxes(seed=12, n=20)
+    w = F.World(hip_lib(), F.default_config(32, substeps=4))
+    upload(w, bodies, colliders); w.pipeline_enable()
+    for _ in range(20):
+        w.step()
+    before, st = w.bodies_download(), w.pipeline_stats()
+    assert st.manifolds > 5
+    with pytest.raises(F.AvnError):
+        w.bodies_upload(**{k: np.asarray(v)[:-1] for k, v in bodies.items()})
+    # the ground carries contact rows: dropping its collider orphans them
+    with pytest.raises(F.AvnError):
+        w.colliders_upload(**{k: np.asarray(v)[1:] for k, v in colliders.items()})
+    w.step(); w.synchronize()
+    assert w.pipeline_stats().manifolds > 5 and np.isfinite(w.bodies_download()["position"]).all()
+    # the documented way out: leave the loop, upload, enter again
+    w.pipeline_enable(False)
+    w.bodies_upload(**{k: np.asarray(v)[:-1] for k, v in bodies.items()})
+    w.colliders_upload(**{k: np.asarray(v)[:-1] for k, v in colliders.items()})
+    w.existing_pairs_upload(np.zeros(0, np.uint64)); w.pipeline_enable()
+    for _ in range(5):
+        w.step()
+    assert w.pipeline_stats().manifolds > 0
+
+
+def test_contacts_upload_to_a_dead_row_is_skipped_and_reported():
+    """in the device closed loop liveness is a row flag; an upload to a free ContactId must not create a phantom pair."""
+    bodies, colliders = dropped_boxes(seed=13, n=12)
+    w = F.World(hip_lib(), F.default_config(32, substeps=4))
+    upload(w, bodies, colliders); w.pipeline_enable()
+    for _ in range(15):
+        w.step()
+    ids = np.unique(w.pipeline_handles()[1]).astype(np.uint32)
+    rows = w.contacts_download(ids[:1])
+    dead = np.array([w.pipeline_stats().pairs_added + 7], np.uint32)   # beyond every id handed out so far, inside the table's capacity
+    with pytest.raises(F.AvnError, match="k_pack_contacts"):
+        w.contacts_upload(dead, rows)
+    z = w.contacts_download(dead)
+    assert int(z["flags"][0]) == 0 and int(z["point_count"][0]) == 0
+    w.contacts_upload(ids[:1], rows)          # a live row is fine, and the error word was cleared
+    w.step(); w.synchronize()
