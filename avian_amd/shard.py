@@ -507,17 +507,24 @@ def level2_pass(world, rank: Level2Rank, system: str, exchange):
             world.halo_unpack(c, p, got[p])
 
 
-def level2_solver(world, rank: Level2Rank, substeps: int, exchange, restitution: bool = True):
+def level2_solver(world, rank: Level2Rank, substeps: int, exchange, restitution: bool = True, solver_iterations: int = 1, has_joints: bool = False):
     """SolverSystems in the reference's order (solver/schedule.rs:32-69) with the contact passes split by colour: what avn_step does
-    inside the library once a communicator is set; here the transport is the caller's (`exchange`)."""
+    inside the library once a communicator is set; here the transport is the caller's (`exchange`).  `solver_iterations` is the
+    declared extension of avn_config: like the library's level2_substeps the biased solve and the relax pass run that many times per
+    substep.  The library also repeats the joint pass WITHOUT re-taking the XPBD snapshot, which avn_run_system cannot express: with
+    joints and more than one iteration only the library-issued transport (avn_comm_init) is valid."""
+    assert solver_iterations >= 1
+    assert solver_iterations == 1 or not has_joints, "joints with solver_iterations > 1: use the library transport (avn_comm_init)"
     for s in ("PREPARE_SOLVER_BODIES", "PREPARE_JOINTS", "PREPARE_CONTACT_CONSTRAINTS", "PRE_PROCESS_VELOCITY_INCREMENTS"):
         world.run_system(s)
     for _ in range(substeps):
         world.run_system("INTEGRATE_VELOCITIES")
         level2_pass(world, rank, "WARM_START", exchange)
-        level2_pass(world, rank, "SOLVE_CONTACTS_BIAS", exchange)
+        for _it in range(solver_iterations):
+            level2_pass(world, rank, "SOLVE_CONTACTS_BIAS", exchange)
         world.run_system("INTEGRATE_POSITIONS")
-        level2_pass(world, rank, "SOLVE_CONTACTS_RELAX", exchange)
+        for _it in range(solver_iterations):
+            level2_pass(world, rank, "SOLVE_CONTACTS_RELAX", exchange)
         for s in ("XPBD_SOLVE", "XPBD_VELOCITY_PROJECTION", "JOINT_DAMPING"):
             world.run_system(s)
     world.run_system("CLEAR_VELOCITY_INCREMENTS")
