@@ -329,11 +329,16 @@ def sparse_mixed(n: int = 1_000_000, side: float = 1000.0, seed: int = 0x9E3779B
     return Scene(pos, q, vel, np.zeros((n, 3)), inv_mass, inv_i, np.zeros(n, np.uint8), he, shape)
 
 
-def stack_with_chains(nx: int = 50, ny: int = 20, nz: int = 50, n_chains: int = 100, links: int = 100):
+def stack_with_chains(nx: int = 50, ny: int = 20, nz: int = 50, n_chains: int = 100, links: int = 100, swing: bool = False):
     """cfg3 of SURVEY.md §8d: an nx*ny*nz box stack (as cfg2) plus `n_chains` chains of `links` unit-density balls
     (r = 0.06, mass properties as examples/chain_3d.rs:59) hanging beside the stack, spacing 0.132, joined by
     DistanceJoints with_limits(0.132, 0.132), compliance 1e-5, anchors at the body centres, first link kinematic.
-    Returns (scene, joints dict).  Chain bodies carry no collider interaction with the stack (they hang clear of it)."""
+    Returns (scene, joints dict).  Chain bodies carry no collider interaction with the stack (they hang clear of it).
+
+    ``swing=True`` (the closed-loop parity scene): the same bodies and joints, placed so that chains and stack INTERACT within a
+    few steps -- the first half of the chains hangs 0.25..1.45 m off the stack's +x face with a pendulum-like velocity towards it
+    (the lower links hit the face first), the second half hangs above the stack, lowest link 0.2 m over the top layer, and is
+    lowered onto it by its kinematic first link at 3 m/s."""
     base = box_stack(nx, ny, nz)
     r = 0.06
     spacing = 0.132
@@ -356,6 +361,22 @@ def stack_with_chains(nx: int = 50, ny: int = 20, nz: int = 50, n_chains: int = 
                np.concatenate([base.rb_type, np.zeros(nb, np.uint8)]), np.concatenate([base.half_extents, np.full((nb, 3), r)]),
                np.concatenate([base.shape, np.ones(nb, np.uint8)]))
     first = n0 + np.arange(n_chains) * links
+    if swing:
+        k = np.arange(links)
+        stack_top = 0.99 * ny
+        for c in range(n_chains):
+            rows = slice(n0 + c * links, n0 + (c + 1) * links)
+            if c < n_chains // 2:      # beside the +x face, swinging in
+                sc.position[rows, 0] = nx * 0.5 + 0.25 + (c // 10) * 0.3
+                sc.position[rows, 1] = 1.0 + (links - 1 - k) * spacing
+                sc.position[rows, 2] = ((c % 10) - 4.5) * 1.0 + 0.37
+                sc.linear_velocity[rows, 0] = -4.0 * k / links
+            else:                      # above the top layer, lowered onto it
+                d = c - n_chains // 2
+                sc.position[rows, 0] = ((d // 10) - 2.0) * 3.0 + 0.21
+                sc.position[rows, 1] = stack_top + 0.2 + r + (links - 1 - k) * spacing
+                sc.position[rows, 2] = ((d % 10) - 4.5) * 3.0 + 0.13
+                sc.linear_velocity[rows, 1] = -3.0
     sc.rb_type[first] = F.RB_KINEMATIC
     b1 = (n0 + np.arange(nb)).reshape(n_chains, links)[:, :-1].ravel()
     J = len(b1)

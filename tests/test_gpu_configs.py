@@ -1,9 +1,11 @@
-"""BASELINE.json's configurations at (or near) full size on the GPU, through the C ABI.
+"""BASELINE.json's configurations at full size on the GPU, through the C ABI.
 
-cfg2/cfg3/cfg4 are compared with the CPU oracle bit for bit at full size where the oracle finishes in seconds; cfg5
-(500k f64) and the multi-step runs are checked through size-independent properties (run-to-run bit identity, sorted /
-duplicate-free pair lists, idempotence of the broad phase, brute-force spot checks) plus an oracle comparison at a
-reduced size.  TOL = 0 everywhere (see tests/test_gpu_parity.py)."""
+cfg2/cfg3/cfg4/cfg5 are compared with the CPU oracle bit for bit at FULL size (cfg5: 500 k bodies, f64, 8 substeps, one whole step
+with the threaded oracle: pair sequence, bodies, impulses); the multi-step runs are additionally checked through size-independent
+properties (run-to-run bit identity, sorted / duplicate-free pair lists, idempotence of the broad phase, brute-force spot checks).
+TOL = 0 everywhere (see tests/test_gpu_parity.py).  The closed-loop runs of cfg1/cfg2/cfg3: tests/test_gpu_closed_loop_configs.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -121,3 +123,37 @@ def test_cfg5_f64_eight_substeps(size):
     assert float(np.abs(a["linear_velocity"]).max()) < 5.0 and float(np.abs(a["position"][1:] - sc.position[1:]).max()) < 0.1
     tm = wh.timers()
     assert tm.contact_constraint_count > 3_000_000 and tm.kernel_launches > 100
+
+
+def test_cfg5_full_size_one_whole_step_matches_the_threaded_oracle(monkeypatch):
+    """cfg5 at FULL size against the oracle: 100 x 50 x 100 = 500 000 cuboids, f64, 8 substeps.  The pair SEQUENCE of
+    the broad phase (6.3 M pairs), then one whole avn_step -- broad phase again, prepare, 8 substeps over 3.43 M manifolds, write-back,
+    impulse store -- bodies and impulses bit for bit.  The oracle runs its colour / body loops on min(64, cores) threads (bit-identical to
+    its serial form, tests/test_oracle_threads.py); its sweep is serial like the reference's (~10 s at this size)."""
+    monkeypatch.setenv("AVO_THREADS", str(max(1, min(64, os.cpu_count() or 1))))
+    sc = scenes.box_stack(100, 50, 100)
+    assert sc.n == 500_001
+    cfg = lambda: F.default_config(64, substeps=8)
+    wo, wh = F.World(oracle_lib(), cfg()), F.World(hip_lib(), cfg())
+    pairs = []
+    for w in (wo, wh):
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        w.existing_pairs_upload(np.zeros(0, np.uint64))
+        w.run_system("UPDATE_AABB"); w.run_system("COLLECT_COLLISION_PAIRS")
+        pairs.append(w.pairs_get().copy())
+    po, ph = pairs
+    assert len(ph) == len(po) > 6_000_000 and np.array_equal(po, ph), "cfg5: pair SEQUENCE differs from the reference order"
+    # the synthetic face manifolds are solver INPUT (scenes.py): built once from the common pair list, coloured once
+    mf = scenes.axis_aligned_manifolds(sc, np.stack([ph["body1"], ph["body2"]], axis=1))
+    offs, perm = scenes.color_manifolds(hip_lib(), mf, sc.rb_type)
+    offs_o, perm_o = scenes.color_manifolds(oracle_lib(), mf, sc.rb_type)
+    assert np.array_equal(offs, offs_o) and np.array_equal(perm, perm_o), "host ConstraintGraph: colours differ between the two libraries"
+    pm = scenes.permute_manifolds(mf, perm)
+    for w in (wo, wh):
+        scenes.upload_manifolds(w, pm, offs, sc.friction, sc.restitution)
+        w.step()
+    compare_dicts(wo.bodies_download(), wh.bodies_download(), "cfg5 full size: bodies")
+    compare_dicts(wo.impulses_download(), wh.impulses_download(), "cfg5 full size: impulses")
+    assert wh.timers().contact_constraint_count == wo.timers().contact_constraint_count > 3_400_000
+    imp = wh.impulses_download()
+    assert float(np.abs(imp["normal_impulse"]).max()) > 0.0

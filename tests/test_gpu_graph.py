@@ -161,26 +161,5 @@ def test_medium_stack_6400_boxes_first_steps():
     assert wh.pipeline_stats().manifolds > 25000
 
 
-def test_cfg2_closed_loop_22_steps_bit_identical_to_the_oracle(monkeypatch):
-    """BASELINE.json config 2 (100 000 cuboids, 4 substeps) closed loop, device bookkeeping: 1.24 M pairs, ~10^6 manifolds pushed in the
-    second step, ~2 * 10^5 status changes per step afterwards, an overflow colour of 2 * 10^5 manifolds that is hundreds of levels deep:
-    colour lists (with their order), counters, contact rows of a sample and all bodies equal the oracle's after every one of 22 steps."""
-    monkeypatch.setenv("AVO_THREADS", "16")
-    sc = scenes.box_stack(50, 40, 50)
-    worlds = []
-    for lib in (oracle_lib(), hip_lib()):
-        w = F.World(lib, F.default_config(32, substeps=4))
-        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
-        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
-        w.pipeline_enable()
-        worlds.append(w)
-    wo, wh = worlds
-    for s in range(22):
-        wo.step(); wh.step()
-        compare_step(s, wo, wh)
-    ids = np.unique(wh.pipeline_handles()[1])[::97]
-    ro, rh = wo.contacts_download(ids), wh.contacts_download(ids)
-    for k in ro:
-        assert np.array_equal(ro[k], rh[k]), f"contact rows {k} differ"
-    st = wh.pipeline_stats()
-    assert st.manifolds > 300000 and st.pairs_removed > 1000 and st.last_host_ms < 5.0   # (the oracle's 16 threads share the host here; alone: ~0.25 ms)
+# cfg2 / cfg3 / cfg1 in the closed loop at full size: tests/test_gpu_closed_loop_configs.py (cfg2 runs 120 steps there, the first 22 of
+# which are what this file checked in round 2).
