@@ -28,6 +28,7 @@ template <class T> struct BP {
     uint64_t* disabled_set;  // body pairs whose joints disable collision
     uint32_t disabled_cap;
     Vec4<T>* s_bb;         // per group of 8 consecutive sorted records: (min of min.y, max of max.y, min of min.z, max of max.z) -- the sweep's batch cull
+    Vec4<T>* s_bb2;        // the same bounds per 64 consecutive sorted records (second level of the cull)
 };
 #define AVN_IV_DROPPED 0x80000000u
 #define AVN_IV_LONG 0x40000000u   // > SW_CAP sweep candidates: swept by k_sweep_long in chunks
@@ -104,6 +105,8 @@ template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const 
 size_t sweep_long_item_bytes();
 uint32_t sweep_pad_records();
 uint32_t sweep_bounds_group();  // sorted records per y/z bounds group of the sweep's batch cull
+uint32_t sweep_bounds_words(uint32_t n_records);          // Vec4 records of BP::s_bb for both cull levels
+uint32_t sweep_bounds_level2_offset(uint32_t n_records);  // BP::s_bb2 = BP::s_bb + this
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
@@ -131,6 +134,8 @@ template <class T> void launch_narrow_phase(const DW<T>&, const BP<T>&, const CT
 // (id order = the order NarrowPhase::update walks the status bits) and rows that must be removed are counted in *n_remove
 template <class T> void launch_narrow_phase_dense(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t);
+template <class T> void launch_narrow_phase_rows(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* list, uint32_t n_list, uint32_t range_base, uint32_t n_range,
+                                                 uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t);   // rows added this step (counter not reset)
 // manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
 template <class T> void launch_gather_manifolds(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
 // store_contact_impulses' write into the ContactGraph (plugin.rs:744-749): table row <- DW::mp_w

@@ -263,6 +263,7 @@ template <class T> struct World : WorldBase {
         if (ev_counters) (void)hipEventDestroy(ev_counters);
         if (h_counters) (void)hipHostFree(h_counters);
         if (h_pg_error) (void)hipHostFree(h_pg_error);
+        for (hipEvent_t e : {ev_np_fork, ev_np_old}) if (e) (void)hipEventDestroy(e);
         if (stream) (void)hipStreamDestroy(stream);
     }
     void bind() override { (void)hipSetDevice(cfg.device); }

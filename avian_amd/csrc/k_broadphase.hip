@@ -423,7 +423,7 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 #define SW_WAVES 4
 #define SW_THREADS (64 * SW_WAVES)
 #define SW_Q 1024   // ring slots per wave: < 64 carried + 8 x 64 appended per batch
-#define SW_CAP 8192u
+#define SW_CAP 65536u   // absolute long-interval rule; the two-level batch cull below keeps lattice layers of ~10^4 x-overlapping candidates on the k_sweep path
 #define SW_LONG_MIN 256u   // relative long-interval rule (k_sweep_ranges): never below this many candidates
 #define SW_LCHUNK 4096u
 
@@ -466,22 +466,39 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
 // (a record that overlaps a lane overlaps the union of its group; a NaN anywhere in a group disables the cull for it, because the
 // reference's negated compares let NaN boxes through): the emitted pairs and their order do not change.
 uint32_t sweep_bounds_group() { return SW_BB_GROUP; }
+// Second level: the bounds of every 64 consecutive sorted records (8 groups).  cfg5's lattice layers hold 5 000 boxes with equal min.x, so an
+// interval has ~10^4 x-overlapping candidates of which the ~5 rows that overlap it in y are ~500: a wave that tests 64 records with four
+// compares skips whole rows (records of one layer are consecutive in (y, z) upload order) and only descends into the few groups of its
+// own and the neighbouring rows.  Same conservativeness rules as level one (NaN anywhere in the 64: never culled).
+#define SW_BB2_GROUP 64u
+uint32_t sweep_bounds_words(uint32_t n_records) { return n_records / SW_BB_GROUP + 2u + n_records / SW_BB2_GROUP + 2u; }   // Vec4 records of both levels
+uint32_t sweep_bounds_level2_offset(uint32_t n_records) { return n_records / SW_BB_GROUP + 2u; }
 template <class T>
-__global__ __launch_bounds__(256) void k_batch_bounds(const Vec4<T>* __restrict__ s_yz, uint32_t n, Vec4<T>* __restrict__ s_bb) {
+__global__ __launch_bounds__(256) void k_batch_bounds(const Vec4<T>* __restrict__ s_yz, uint32_t n, Vec4<T>* __restrict__ s_bb, Vec4<T>* __restrict__ s_bb2) {
     const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    if (g * SW_BB_GROUP >= n) return;
+    const bool live = (size_t)g * SW_BB_GROUP < n;
     const T inf = Limits<T>::max * T(2);
     T lo_y = inf, hi_y = -inf, lo_z = inf, hi_z = -inf;
     bool nan = false;
-    for (uint32_t k = 0; k < 8u; ++k) {
-        const uint32_t idx = g * SW_BB_GROUP + k;
-        if (idx >= n) break;
-        const Vec4<T> r = s_yz[idx];
-        nan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
-        lo_y = r.x < lo_y ? r.x : lo_y; hi_y = r.y > hi_y ? r.y : hi_y;
-        lo_z = r.z < lo_z ? r.z : lo_z; hi_z = r.w > hi_z ? r.w : hi_z;
+    if (live)
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t idx = g * SW_BB_GROUP + k;
+            if (idx >= n) break;
+            const Vec4<T> r = s_yz[idx];
+            nan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
+            lo_y = r.x < lo_y ? r.x : lo_y; hi_y = r.y > hi_y ? r.y : hi_y;
+            lo_z = r.z < lo_z ? r.z : lo_z; hi_z = r.w > hi_z ? r.w : hi_z;
+        }
+    if (live) s_bb[g] = nan ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
+    // level two: the eight groups of lanes 8 k .. 8 k + 7 (a workgroup starts on a multiple of 256 groups: the octets are aligned)
+    uint32_t nn = nan ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const T a = __shfl_xor(lo_y, off), b = __shfl_xor(hi_y, off), c = __shfl_xor(lo_z, off), d = __shfl_xor(hi_z, off);
+        nn |= (uint32_t)__shfl_xor((int)nn, off);
+        lo_y = a < lo_y ? a : lo_y; hi_y = b > hi_y ? b : hi_y; lo_z = c < lo_z ? c : lo_z; hi_z = d > hi_z ? d : hi_z;
     }
-    s_bb[g] = nan ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
+    if (live && (g & 7u) == 0u) s_bb2[g >> 3] = nn ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
 }
 
 // end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems.
@@ -530,7 +547,7 @@ __global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __res
 }
 
 template <class T, bool EMIT>
-__global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const Vec4<T>* __restrict__ s_bb, const uint32_t* __restrict__ s_end,
+__global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const Vec4<T>* __restrict__ s_bb, const Vec4<T>* __restrict__ s_bb2, const uint32_t* __restrict__ s_end,
                                                        const uint4* __restrict__ s_info, const uint32_t* __restrict__ s_flags, PairSets hs,
                                                        uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
     __shared__ uint32_t l_q[SW_WAVES][SW_Q];
@@ -615,14 +632,20 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     // the batch cull below tests a whole batch against ONE group's bounds: a batch must never straddle two groups (else true pairs of the
     // second group could be culled), i.e. batches start on multiples of SW_BATCH (j_first) and SW_BATCH divides the group size
     static_assert(SW_BB_GROUP % SW_BATCH == 0 && (SW_BB_GROUP & (SW_BB_GROUP - 1u)) == 0, "sweep batch cull: SW_BATCH must divide the bounds group size");
-    // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je), cut at batch-aligned positions so that every
-    // batch lies inside one group of k_batch_bounds (the few records before i0 + 1 this adds fail every lane's `jj > i` test)
-    const uint32_t j_first = (i0 + 1u) & ~(SW_BATCH - 1u);
+    // this wave's quarter [jb, jq) of the workgroup's candidate range [i0 + 1, je), cut at positions aligned to the LEVEL-TWO groups (64
+    // records) so that every batch lies inside one group of each level of k_batch_bounds (i0 is a multiple of 64: the range starts at the
+    // workgroup's own records, which fail every lane's `jj > i` test or are the lane's genuine later neighbours)
+    static_assert(SW_BB2_GROUP % SW_BB_GROUP == 0, "sweep batch cull: level two must be made of whole level-one groups");
+    const uint32_t j_first = i0;
     uint32_t qlen = (je - j_first + SW_WAVES - 1u) / SW_WAVES;
-    qlen = (qlen + SW_BATCH - 1u) / SW_BATCH * SW_BATCH;
+    qlen = (qlen + SW_BB2_GROUP - 1u) / SW_BB2_GROUP * SW_BB2_GROUP;
     const uint32_t jb = j_first + wv * qlen;
     const uint32_t jq = min(je, jb + qlen);
-    for (uint32_t j = jb; j < jq; j += SW_BATCH) {
+    for (uint32_t j2 = jb; j2 < jq; j2 += SW_BB2_GROUP) {
+      const Vec4<T> b2 = s_bb2[j2 / SW_BB2_GROUP];   // wave-uniform: one scalar load per 64 candidates
+      if (!(lane_mask_ule(me.x, b2.y) & lane_mask_uge(me.y, b2.x) & lane_mask_ule(me.z, b2.w) & lane_mask_uge(me.w, b2.z))) continue;
+      const uint32_t j2e = min(jq, j2 + SW_BB2_GROUP);
+      for (uint32_t j = j2; j < j2e; j += SW_BATCH) {
         const Vec4<T> bb = s_bb[j / SW_BB_GROUP];   // wave-uniform: one scalar load
         if (!(lane_mask_ule(me.x, bb.y) & lane_mask_uge(me.y, bb.x) & lane_mask_ule(me.z, bb.w) & lane_mask_uge(me.w, bb.z))) continue;
         Vec4<T> c[SW_BATCH];
@@ -660,6 +683,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
             __builtin_amdgcn_wave_barrier();
             while (qn >= 64u) { drain(64u); head = (head + 64u) & (SW_Q - 1u); qn -= 64u; }
         }
+      }
     }
     if (qn) drain(qn);
     __builtin_amdgcn_wave_barrier();
@@ -848,6 +872,9 @@ template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b
 void launch_radix_sort_bits(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t bits, uint32_t* hist, uint32_t* block_sums,
                             uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
     uint32_t* ki = keys_a; uint32_t* vi = vals_a; uint32_t* ko = keys_b; uint32_t* vo = vals_b;
+    // a settled pile's overflow colour (a few hundred manifolds -> < 1 000 entries) and small scenes: the one-workgroup sort, 1 launch instead
+    // of 2 per 8 bits (it sorts all 32 bits: the same permutation, the keys have no bits above `bits`)
+    if (n && n <= SS_MAX && bits > 8) { hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, (const uint32_t*)nullptr); *keys_out = keys_a; *vals_out = vals_a; return; }
     const uint32_t nb = radix_blocks(n);
     for (uint32_t shift = 0; n && shift < bits; shift += 8) {
         if (nb <= RS_FUSED_MAX_BLOCKS) {
@@ -869,7 +896,7 @@ template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, co
 template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s) {
     if (!n) return;
     (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
-    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / SW_BB_GROUP + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb);
+    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / SW_BB_GROUP + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb, bp.s_bb2);
     hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
                        sc.n_long, sc.long_cap, sc.n_long + 1);
 }
@@ -881,11 +908,11 @@ template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, con
     LongItem* li = (LongItem*)sc.long_items;
     PairSets hs{bp.pair_set, bp.pair_set_cap, bp.disabled_set, bp.disabled_cap};
     if (emit) {
-        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
         hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
     } else {
-        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
         hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
         hipLaunchKernelGGL(k_long_finish, dim3(64), dim3(256), 0, s, li, sc.n_long, sc.long_counts, sc.long_off, counts);

@@ -295,7 +295,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
 template <class T, bool DENSE>
 __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
                                                              avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                                                             uint32_t* __restrict__ has) {
+                                                             uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base) {
     __shared__ uint32_t s_row[NP_THREADS];
     __shared__ T s_axis[3 * NP_THREADS];
     __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];   // f32: 48 KB, f64: 96 KB
@@ -304,7 +304,9 @@ __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, 
     __syncthreads();
     const uint32_t a = blockIdx.x * NP_THREADS + threadIdx.x;
     if (a < n_active) {
-        const uint32_t c = DENSE ? a : active[a];
+        // DENSE with a row list (the rows a step ADDED, narrow phase overlapped with the broad phase): ids list[0 .. n_list), then the
+        // contiguous fresh ids range_base ..; DENSE without one: every row id; sparse: the active list
+        const uint32_t c = !DENSE ? active[a] : (active || n_list || range_base) ? (a < n_list ? active[a] : range_base + (a - n_list)) : a;
         bool deferred = false;
         V3<T> axis = vzero<T>();
         np_update_pair<T, DENSE, false>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
@@ -446,12 +448,22 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
     (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
-    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr);
+    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t st) {
     (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
-    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has);
+    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
+}
+// the rows list[0 .. n_list) followed by range_base .. range_base + n_range: same per-row work and outputs as the dense form; the
+// removal counter is NOT reset (it continues the count of the launch over the older rows)
+template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* list, uint32_t n_list, uint32_t range_base,
+                                                 uint32_t n_range, uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t st) {
+    const uint32_t n = n_list + n_range;
+    if (!n) return;
+    // (range_base = 0 with an empty list would read as the plain dense form: a world's first pairs take the dense launch instead)
+    if (!n_list && !range_base) { hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u); return; }
+    hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
 }
 template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);
@@ -472,6 +484,7 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
     template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
+    template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_manifolds<T>(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                  \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
     template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);

@@ -136,7 +136,7 @@
             size_t cc = std::max<size_t>(C, cap_colliders + cap_colliders / 2);
             GROW(b_col_info, cc, bp.col_info); GROW(b_col_he, cc, bp.col_he); GROW(b_col_spec, cc, bp.col_spec); GROW(b_col_layers, cc, bp.col_layers);
             GROW(b_aabb_min, cc, bp.aabb_min); GROW(b_aabb_max, cc, bp.aabb_max); GROW(b_iv, cc, bp.iv_collider);
-            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_bb, cc / sweep_bounds_group() + 2, bp.s_bb); GROW(b_s_end, cc, bp.s_end);
+            GROW(b_s_minx, cc, bp.s_minx); GROW(b_s_maxx, cc, bp.s_maxx); GROW(b_s_yz, cc + sweep_pad_records(), bp.s_yz); GROW(b_s_bb, sweep_bounds_words((uint32_t)cc), bp.s_bb); bp.s_bb2 = bp.s_bb + sweep_bounds_level2_offset((uint32_t)cc); GROW(b_s_end, cc, bp.s_end);
             GROW(b_s_info, cc, bp.s_info); GROW(b_s_flags, cc, bp.s_flags);
             Key* dummy_k; uint32_t* dummy_u;
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);

@@ -27,7 +27,8 @@
             b_pg_lists.p = nl; b_pg_lists.cap = (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4;
             pg.lists = nl; pg.list_stride = rows;
         }
-        PGB(b_pg_chg, rows, pg.chg, false); PGB(b_pg_has, rows, pg.has, false); PGB(b_pg_off, rows + 1, pg.off, false);
+        PGB(b_pg_chg, rows, pg.chg, true); PGB(b_pg_has, rows, pg.has, true);   // (kept: the overlapped narrow phase has written the old rows' changes when a step's new pairs grow the table)
+        PGB(b_pg_off, rows + 1, pg.off, false);
         PGB(b_pg_op_cid, rows, pg.op_cid, false); PGB(b_pg_op_info, rows, pg.op_info, false); PGB(b_pg_op_bodies, rows, pg.op_bodies, false);
         PGB(b_pg_ekey_a, 2 * (size_t)rows, pg.ekey_a, false); PGB(b_pg_eval_a, 2 * (size_t)rows, pg.eval_a, false);
         PGB(b_pg_ekey_b, 2 * (size_t)rows, pg.ekey_b, false); PGB(b_pg_eval_b, 2 * (size_t)rows, pg.eval_b, false);
@@ -129,6 +130,8 @@
     // solve), bit 2 = k_pack_contacts was asked to write a row that is not live.  The word is read back at the end of every step into pinned
     // memory (no extra synchronisation: the copy rides the stream); whoever synchronises next -- avn_synchronize, the next avn_step -- reports
     // it under the name of the kernel that raised it and clears it.
+    hipEvent_t ev_np_fork = nullptr, ev_np_old = nullptr;
+    bool np_overlap_enabled = getenv("AVN_NO_NP_OVERLAP") == nullptr;
     uint32_t* h_pg_error = nullptr;   // pinned
     bool pg_error_pending = false;
     avn_status pg_error_fetch() {     // enqueue the read-back behind everything the step launched
@@ -164,51 +167,82 @@
         auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
         HIPCHK(hipEventRecord(ev[0], stream));
         if ((st = update_aabb()) != AVN_OK) return st;
-        if ((st = collect_launch()) != AVN_OK) return st;
+        // The narrow phase of the rows that exist at the START of the step needs the new AABBs and nothing else of the broad phase: it runs
+        // on the world's stream while sort + sweep + emit run on the broad-phase stream (both are VALU-bound kernels that leave half the
+        // chip idle on their own).  The rows a step ADDS are created only after that launch has finished (they may reuse freed ids: a row
+        // must not come alive under a running launch) and get their own small launch.  Same per-row work, same outputs: chg / has per row,
+        // so the scan still numbers the changes in ascending ContactId.  AVN_NO_NP_OVERLAP=1: the serial order (A/B runs).
+        const uint32_t n_rows_old = pgm_next_id, head_old = pgm_head;
+        const bool np_overlap = np_overlap_enabled && n_rows_old != 0 && bp.n_intervals != 0;
+        if (np_overlap) {
+            if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming)); }
+            HIPCHK(hipEventRecord(ev_np_fork, stream));
+            HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_fork, 0));
+            bs = stream_bp;
+        }
+        st = collect_launch();
+        if (st != AVN_OK) { bs = stream; return st; }
+        if (np_overlap) {
+            launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            ++launches;
+            HIPCHK(hipEventRecord(ev_np_old, stream));
+        }
         lap();
         // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
-        uint32_t total = 0;
+        uint32_t total = 0, used_ids = 0;
+        auto fail = [&](avn_status e) { bs = stream; return e; };
         if (collect_pending) {
             collect_pending = false;
             HIPCHK(hipEventSynchronize(ev_counters));
             t0 = std::chrono::steady_clock::now();
             if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
-                if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return st;
-                if ((st = collect_launch()) != AVN_OK) return st;
+                if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return fail(st);
+                if ((st = collect_launch()) != AVN_OK) return fail(st);
                 collect_pending = false;
                 HIPCHK(hipEventSynchronize(ev_counters));
-                if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return AVN_ERR_CAPACITY; }
+                if (h_counters[4]) { error = "collect_collision_pairs: long-interval chunk capacity exceeded"; return fail(AVN_ERR_CAPACITY); }
             }
             const uint32_t dropped = h_counters[0];
             total = h_counters[2];
             if (total) {
                 hipError_t err;
                 b_pairs.ensure((size_t)total * sizeof(avn_pair), err);
-                if (err != hipSuccess) { error = "pair buffer allocation failed"; return AVN_ERR_OOM; }
+                if (err != hipSuccess) { error = "pair buffer allocation failed"; return fail(AVN_ERR_OOM); }
                 launch_sweep<T>(bp, collect_n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), bs);
                 launches += 2;
                 const uint32_t fresh = total > pgm_n_free ? total - pgm_n_free : 0u;
-                if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return st;
-                if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return st;
+                if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return fail(st);   // (growing synchronises the world's stream first: the launch over the old rows is done)
+                if (np_overlap) HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_old, 0));               // nothing below may touch a row while that launch runs
+                if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return fail(st);
                 launch_hs_insert_pairs(bp.pair_set, bp.pair_set_cap, b_pairs.as<avn_pair>(), total, bs);   // add_edge_and_key_with: the keys join the pair set
                 launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bs);
                 launches += 3;
                 HIPCHK(hipGetLastError());
                 const uint32_t used = std::min(total, pgm_n_free);
+                used_ids = used;
                 pgm_head += used; pgm_n_free -= used; pgm_next_id += total - used; pgm_live += total;
                 pipe_stats.pairs_added += total;
             }
             bp.n_intervals = collect_n - dropped;
             last_timers.pair_count = total;
         }
+        if (np_overlap) {
+            HIPCHK(hipEventRecord(ev_bp_done, stream_bp));
+            HIPCHK(hipStreamWaitEvent(stream, ev_bp_done, 0));
+            bs = stream;
+        }
         HIPCHK(hipEventRecord(ev[1], stream));
         // ---- narrow phase over every live row; changes numbered in ascending ContactId ----
         const uint32_t n_rows = pgm_next_id;
         uint32_t n_ops = 0, n_rem = 0;
         if (n_rows) {
-            launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream); ++launches; }
+            else if (total) {   // the rows this step added: the lowest free ids first (k_pg_add_pairs), then the fresh ones
+                launch_narrow_phase_rows<T>(dw, bp, ct, params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+                ++launches;
+            }
             launch_exclusive_scan(pg.has, pg.off, n_rows, b_pg_sums.as<uint32_t>(), pg.ctr + PGC_N_OPS, stream);
-            launches += 1 + exclusive_scan_launches(n_rows);
+            launches += exclusive_scan_launches(n_rows);
             HIPCHK(hipGetLastError());
             uint32_t* h = (uint32_t*)pin_ctr.p;
             HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
