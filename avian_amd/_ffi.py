@@ -181,7 +181,7 @@ class avn_timers(C.Structure):
     _fields_ = [("broad_phase_ms", C.c_double), ("prepare_ms", C.c_double), ("substeps_ms", C.c_double),
                 ("finalize_ms", C.c_double), ("step_ms", C.c_double), ("contact_constraint_count", C.c_uint32),
                 ("pair_count", C.c_uint32), ("kernel_launches", C.c_uint32), ("bias_pass_launches", C.c_uint32), ("bias_pass_ms", C.c_double),
-                ("island_blocks", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("island_blocks", C.c_uint32), ("side_island_bodies", C.c_uint32)]
 
 
 class avn_diagnostics(C.Structure):

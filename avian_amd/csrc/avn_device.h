@@ -89,6 +89,13 @@ template <class T> struct DW {
     V* pre_dp;     // PreSolveDeltaPosition
     V* pre_dq;     // PreSolveDeltaRotation
     uint32_t* sb_flags;
+    // Island-level concurrency inside the substep loop: bodies of islands that hold joints but NO contact manifold ("side" islands: hanging
+    // chains, mechanisms clear of everything) run their whole substep loop on a second stream next to the contact passes of the other
+    // islands -- islands exchange nothing inside the solver (islands/mod.rs:1-10), so every body sees exactly its own operation sequence.
+    // side_group[body] = 1 for bodies of side islands; body_group selects what a per-body kernel of the substep loop processes:
+    // 0 = every body (no split), 1 = the main group only, 2 = the side group only.
+    const uint8_t* side_group;
+    uint32_t body_group;
     // ---- contact manifolds (the ContactGraph side; colour-major) ----
     uint32_t n_manifolds, m_stride;   // m_stride: element stride between point slots ([p][m] layout)
     int2* m_bodies;
@@ -139,6 +146,12 @@ template <class T> struct DW {
     V* j_force;    // (force.xyz, 0)
     V* j_torque;   // (torque.xyz, 0)
 };
+#ifdef __HIPCC__
+template <class T> __device__ __forceinline__ bool body_in_group(const DW<T>& w, uint32_t body) {
+    return w.body_group == 0u || (uint32_t)w.side_group[body] == w.body_group - 1u;
+}
+#endif
+
 
 // Block index remap so that each XCD (block b runs on XCD b % 8) walks one contiguous eighth of the
 // work: neighbouring work items share bodies / sweep ranges, and each XCD has a private 4 MiB L2.

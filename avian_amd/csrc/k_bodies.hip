@@ -98,6 +98,7 @@ template <class T>
 __global__ __launch_bounds__(BODY_THREADS) void k_integrate_velocities(DW<T> w, StepParams<T> p) {
     uint32_t i = blockIdx.x * BODY_THREADS + threadIdx.x;
     if (i >= w.n_bodies) return;
+    if (!body_in_group(w, i)) return;
     uint32_t sbf = w.sb_flags[i];
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
     Vec4<T> l4 = w.sb_lin[i], a4 = w.sb_ang[i];
@@ -112,6 +113,7 @@ template <class T>
 __global__ __launch_bounds__(BODY_THREADS) void k_integrate_positions(DW<T> w, StepParams<T> p) {
     uint32_t i = blockIdx.x * BODY_THREADS + threadIdx.x;
     if (i >= w.n_bodies) return;
+    if (!body_in_group(w, i)) return;
     uint32_t sbf = w.sb_flags[i];
     if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
     V3<T> v = xyz<T>(w.sb_lin[i]), om = xyz<T>(w.sb_ang[i]);
@@ -143,6 +145,7 @@ template <class T>
 __global__ __launch_bounds__(BODY_THREADS) void k_xpbd_snapshot(DW<T> w) {
     uint32_t i = blockIdx.x * BODY_THREADS + threadIdx.x;
     if (i >= w.n_bodies) return;
+    if (!body_in_group(w, i)) return;
     if (w.sb_flags[i] & AVN_SBF_NO_SOLVER_BODY) return;
     w.pre_dp[i] = w.sb_dp[i];
     w.pre_dq[i] = w.sb_dq[i];
@@ -152,6 +155,7 @@ template <class T>
 __global__ __launch_bounds__(BODY_THREADS) void k_xpbd_velocity_projection(DW<T> w, StepParams<T> p) {
     uint32_t i = blockIdx.x * BODY_THREADS + threadIdx.x;
     if (i >= w.n_bodies) return;
+    if (!body_in_group(w, i)) return;
     if (w.sb_flags[i] & AVN_SBF_NO_SOLVER_BODY) return;
     T delta_secs = p.h_adj;
     Vec4<T> l4 = w.sb_lin[i], a4 = w.sb_ang[i];

@@ -299,6 +299,7 @@ template <class T, bool FUSE_INTEGRATE>
 __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepParams<T> p) {
     const uint32_t body = xcd_block(blockIdx.x, gridDim.x) * WS_THREADS + threadIdx.x;
     if (body >= w.n_bodies) return;
+    if (!body_in_group(w, body)) return;
     body_warm_start_one<T, FUSE_INTEGRATE>(w, p, body);
 }
 

@@ -150,6 +150,95 @@
         }
         HIPCHK(hipStreamSynchronize(stream));
         joint_schedule_dirty = false;
+        groups_dirty = true;
+        graph_valid = false;
+        return AVN_OK;
+    }
+    // ---- island-level concurrency: joint-only islands on their own stream (DW::side_group) -------------------------------------------
+    // Islands = connected components of the bodies that own a SolverBody under "share a joint or a manifold" (islands/mod.rs:1-10).  An
+    // island with joints and without any manifold is a SIDE island: nothing in the contact passes touches its bodies, nothing in its joint
+    // pass touches anybody else, so its substep loop (integrate_velocities, integrate_positions, the XPBD solve in the serial joint order of
+    // xpbd/plugin.rs:77-82,145-189, velocity projection, joint damping) runs on `stream_side` next to the other islands' colour launches.
+    // Per body and per joint the operation sequence is the single stream's: results are bit-identical.  Host-uploaded manifolds only (the
+    // bodies of the manifolds are on the host then); joint damping against a body without a SolverBody couples the joints of one type
+    // through the shared DUMMY (joint_damping::<T>): no split then.
+    bool groups_dirty = true, groups_active = false, groups_enabled = getenv("AVN_NO_ISLAND_STREAMS") == nullptr;
+    JointSchedule sched_solve_main, sched_damp_main, sched_solve_side, sched_damp_side;
+    DevBuf b_side_group;
+    hipStream_t stream_side = nullptr;
+    hipEvent_t ev_side_fork = nullptr, ev_side_done = nullptr;
+    uint32_t side_bodies = 0, side_joints = 0;
+    avn_status upload_schedule(JointSchedule& sc) {
+        avn_status st;
+        if ((st = upload_u32(sc.d_comp_level_begin, sc.comp_level_begin)) != AVN_OK) return st;
+        if ((st = upload_u32(sc.d_level_offsets, sc.level_offsets)) != AVN_OK) return st;
+        std::vector<uint32_t> rec(4 * sc.order.size());
+        for (size_t k = 0; k < sc.order.size(); ++k) {
+            const uint32_t j = sc.order[k];
+            rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; rec[4 * k + 3] = 0u;
+        }
+        if ((st = upload_u32(sc.d_rec, rec)) != AVN_OK) return st;
+        HIPCHK(hipStreamSynchronize(stream));
+        return AVN_OK;
+    }
+    avn_status rebuild_body_groups() {
+        if (!groups_dirty) return AVN_OK;
+        groups_dirty = false;
+        const bool was = groups_active;
+        groups_active = false;
+        const uint32_t J = dw.n_joints, N = dw.n_bodies, M = dw.n_manifolds;
+        dw.side_group = nullptr; dw.body_group = 0;
+        if (was) graph_valid = false;
+        if (!groups_enabled || pipe_on || use_handles || halo_on || !J || !M || sched_damp.touches_dummy || h_m_body1.size() != M || h_body_has_sb.size() != N) return AVN_OK;
+        auto has_sb = [&](int32_t b) { return b >= 0 && (uint32_t)b < N && h_body_has_sb[(uint32_t)b]; };
+        std::vector<uint32_t> parent(N);
+        std::iota(parent.begin(), parent.end(), 0u);
+        auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+        auto unite = [&](uint32_t a, uint32_t b) { a = find(a); b = find(b); if (a != b) parent[std::max(a, b)] = std::min(a, b); };
+        for (uint32_t j = 0; j < J; ++j) if (has_sb(h_j_body1[j]) && has_sb(h_j_body2[j])) unite((uint32_t)h_j_body1[j], (uint32_t)h_j_body2[j]);
+        for (uint32_t m = 0; m < M; ++m) if (has_sb(h_m_body1[m]) && has_sb(h_m_body2[m])) unite((uint32_t)h_m_body1[m], (uint32_t)h_m_body2[m]);
+        std::vector<uint8_t> has_manifold(N, 0), has_joint(N, 0);
+        for (uint32_t m = 0; m < M; ++m) { if (has_sb(h_m_body1[m])) has_manifold[find((uint32_t)h_m_body1[m])] = 1; if (has_sb(h_m_body2[m])) has_manifold[find((uint32_t)h_m_body2[m])] = 1; }
+        for (uint32_t j = 0; j < J; ++j) { if (has_sb(h_j_body1[j])) has_joint[find((uint32_t)h_j_body1[j])] = 1; if (has_sb(h_j_body2[j])) has_joint[find((uint32_t)h_j_body2[j])] = 1; }
+        std::vector<uint8_t> side(N, 0);
+        side_bodies = 0;
+        for (uint32_t b = 0; b < N; ++b) if (h_body_has_sb[b]) { const uint32_t r = find(b); if (has_joint[r] && !has_manifold[r]) { side[b] = 1; ++side_bodies; } }
+        if (!side_bodies) return AVN_OK;
+        // the two halves of the joint schedules (a joint of a side island has both SolverBody-owning bodies in it; one without any goes with the main group)
+        auto joint_side = [&](uint32_t j) { return (has_sb(h_j_body1[j]) && side[(uint32_t)h_j_body1[j]]) || (has_sb(h_j_body2[j]) && side[(uint32_t)h_j_body2[j]]); };
+        std::vector<uint32_t> all(J);
+        std::iota(all.begin(), all.end(), 0u);
+        std::stable_sort(all.begin(), all.end(), [&](uint32_t a, uint32_t b) { return h_j_type[a] < h_j_type[b]; });
+        side_joints = 0;
+        for (int g = 0; g < 2; ++g) {
+            std::vector<uint32_t> js, damped;
+            std::vector<int32_t> k1, k2, d1, d2;
+            for (uint32_t i : all) {
+                if ((joint_side(i) ? 1 : 0) != g) continue;
+                js.push_back(i);
+                k1.push_back(has_sb(h_j_body1[i]) ? h_j_body1[i] : -1); k2.push_back(has_sb(h_j_body2[i]) ? h_j_body2[i] : -1);
+                if (h_j_damped[i]) { damped.push_back(i); d1.push_back(h_j_body1[i]); d2.push_back(h_j_body2[i]); }   // (no DUMMY-touching damping here: checked above)
+            }
+            if (g) side_joints = (uint32_t)js.size();
+            JointSchedule& so = g ? sched_solve_side : sched_solve_main; JointSchedule& da = g ? sched_damp_side : sched_damp_main;
+            so.build(js, k1, k2, N);
+            da.touches_dummy = false;
+            da.build(damped, d1, d2, N + DUMMY_SLOTS);
+            avn_status st;
+            if ((st = upload_schedule(so)) != AVN_OK || (st = upload_schedule(da)) != AVN_OK) return st;
+        }
+        hipError_t err;
+        b_side_group.ensure(std::max<size_t>(N, 1), err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemcpyAsync(b_side_group.p, side.data(), N, hipMemcpyHostToDevice, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        if (!stream_side) {
+            HIPCHK(hipStreamCreateWithFlags(&stream_side, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming));
+        }
+        dw.side_group = b_side_group.as<uint8_t>();
+        groups_active = true;
         graph_valid = false;
         return AVN_OK;
     }

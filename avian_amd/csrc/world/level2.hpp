@@ -34,6 +34,7 @@
         HIPCHK(hipStreamSynchronize(stream));
         halo = std::move(h);
         halo_on = !halo.peers.empty();
+        groups_dirty = true;
         drop_graph();
         if (!halo_on) return AVN_OK;
         hipError_t err;

@@ -54,6 +54,7 @@
     bool ovf_csr_dirty = false;
     avn_status rebuild_incidence() {
         if (!incidence_dirty) return AVN_OK;
+        groups_dirty = true;   // bodies, manifolds or their mode changed: the island streams' grouping follows
         if (pipe_dev) { ovf_csr_dirty = true; return rebuild_incidence_device(); }
         uint32_t N = dw.n_bodies, M = dw.n_manifolds;
         if (M == 0) { incidence_dirty = false; island_mode = false; islands_dirty = false; return AVN_OK; }

@@ -63,12 +63,20 @@
     void xpbd_solve(bool snapshot) {
         if (snapshot && xpbd_body_passes_needed()) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
         if (!dw.n_joints) return;
-        launch_joint_schedule<T>(dw, params, 0, (uint32_t)sched_solve.n_components, sched_solve.d_comp_level_begin.as<uint32_t>(),
-                                 sched_solve.d_level_offsets.as<uint32_t>(), sched_solve.d_rec.as<int4>(), stream);
+        JointSchedule& sc = dw.body_group == 1u ? sched_solve_main : sched_solve;   // (island streams: the side islands' joints run in substep_side)
+        if (!sc.n_components) return;
+        launch_joint_schedule<T>(dw, params, 0, (uint32_t)sc.n_components, sc.d_comp_level_begin.as<uint32_t>(), sc.d_level_offsets.as<uint32_t>(), sc.d_rec.as<int4>(), stream);
         ++launches;
     }
     void xpbd_velocity_projection() { if (xpbd_body_passes_needed()) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
     void joint_damping() {
+        if (dw.body_group == 1u) {
+            if (!any_damped || !sched_damp_main.n_components) return;
+            launch_joint_schedule<T>(dw, params, 1, (uint32_t)sched_damp_main.n_components, sched_damp_main.d_comp_level_begin.as<uint32_t>(),
+                                     sched_damp_main.d_level_offsets.as<uint32_t>(), sched_damp_main.d_rec.as<int4>(), stream);
+            ++launches;
+            return;
+        }
         if (!any_damped || !sched_damp.n_components) return;
         if (sched_damp.touches_dummy) {
             // reset the two virtual SolverBody::DUMMY slots (all-zero bit pattern = zero velocities)
@@ -100,6 +108,40 @@
         joint_damping();
         if (dg) { (void)hipEventRecord(de[4], stream); dg_substeps = substep_index; }
     }
+    // the substep of the side islands (joints, no manifolds) on stream_side: the same systems in the same order, minus the contact passes
+    void substep_side() {
+        DW<T> ds = dw;
+        ds.body_group = 2u;
+        launch_integrate_velocities<T>(ds, params, stream_side); ++launches;
+        launch_integrate_positions<T>(ds, params, stream_side); ++launches;
+        for (uint32_t it = 0; it < cfg.solver_iterations; ++it) {
+            if (it == 0) { launch_xpbd_snapshot<T>(ds, stream_side); ++launches; }
+            if (sched_solve_side.n_components) {
+                launch_joint_schedule<T>(ds, params, 0, (uint32_t)sched_solve_side.n_components, sched_solve_side.d_comp_level_begin.as<uint32_t>(),
+                                         sched_solve_side.d_level_offsets.as<uint32_t>(), sched_solve_side.d_rec.as<int4>(), stream_side);
+                ++launches;
+            }
+        }
+        launch_xpbd_velocity_projection<T>(ds, params, stream_side); ++launches;
+        if (any_damped && sched_damp_side.n_components) {
+            launch_joint_schedule<T>(ds, params, 1, (uint32_t)sched_damp_side.n_components, sched_damp_side.d_comp_level_begin.as<uint32_t>(),
+                                     sched_damp_side.d_level_offsets.as<uint32_t>(), sched_damp_side.d_rec.as<int4>(), stream_side);
+            ++launches;
+        }
+    }
+    // all substeps of a step: one stream, or the main islands on `stream` and the side islands on `stream_side` between a fork and a join
+    avn_status substep_loop() {
+        if (!groups_active) { for (uint32_t s = 0; s < cfg.substeps; ++s) substep(); return AVN_OK; }
+        HIPCHK(hipEventRecord(ev_side_fork, stream));
+        HIPCHK(hipStreamWaitEvent(stream_side, ev_side_fork, 0));
+        dw.body_group = 1u;
+        for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+        dw.body_group = 0u;
+        for (uint32_t s = 0; s < cfg.substeps; ++s) substep_side();
+        HIPCHK(hipEventRecord(ev_side_done, stream_side));
+        HIPCHK(hipStreamWaitEvent(stream, ev_side_done, 0));
+        return AVN_OK;
+    }
     bool islands_active() const { return island_mode && dw.n_joints == 0 && dw.n_manifolds != 0 && !halo_on; }
     avn_status run_substeps() {
         substep_index = 0;
@@ -125,9 +167,9 @@
         if (!cfg.use_graph) {
             if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
             ovf_epoch = 0;
-            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            avn_status sl = substep_loop();
             ovf_epoch_after_substeps = ovf_epoch;
-            return AVN_OK;
+            return sl;
         }
         if (!graph_valid) {
             if (getenv("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
@@ -137,10 +179,12 @@
             // the overflow passes' tickets and tile counters restart with every step (a kernel node, replayed first)
             if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
             ovf_epoch = 0;
-            for (uint32_t s = 0; s < cfg.substeps; ++s) substep();
+            const avn_status sl = substep_loop();   // (the side islands' stream joins the capture through the fork event and leaves it at the join)
+            dw.body_group = 0u;
             ovf_epoch_after_substeps = ovf_epoch;
             // whatever went wrong inside the capture, the stream must leave capture mode and the partial graph must not survive
             hipError_t ce = hipStreamEndCapture(stream, &graph);
+            if (ce == hipSuccess && sl != AVN_OK) ce = hipErrorUnknown;
             graph_launches = launches - before;
             launches = before;
             if (ce == hipSuccess) ce = hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0);
@@ -163,6 +207,7 @@
         if (st != AVN_OK) return st;
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
         if ((st = rebuild_incidence()) != AVN_OK) return st;
+        if ((st = rebuild_body_groups()) != AVN_OK) return st;
         prepare_solver_bodies();
         prepare_joints();
         prepare_contact_constraints();

@@ -18,7 +18,7 @@
             last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;
             last_timers.step_ms = e;
             last_timers.bias_pass_ms = 0; last_timers.bias_pass_launches = 0;
-            last_timers.island_blocks = islands_active() ? islands.n_blocks : 0u; last_timers.reserved0 = 0;
+            last_timers.island_blocks = islands_active() ? islands.n_blocks : 0u; last_timers.side_island_bodies = groups_active ? side_bodies : 0u;
             if (bias_timed) {   // mean over the step's substeps
                 double sum = 0;
                 for (uint32_t k = 0; k < bias_timed; ++k) { float f = 0; HIPCHK(hipEventElapsedTime(&f, ev_bias[2 * k], ev_bias[2 * k + 1])); sum += f; }

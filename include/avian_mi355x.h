@@ -437,7 +437,8 @@ typedef struct avn_timers {
                                  (0 otherwise: events captured into a hipGraph cannot be read back) */
     uint32_t island_blocks;   /* workgroups of the island-block substep kernel in the last step; 0 = the substeps ran as
                                  device-wide colour launches (big islands, joints, f64, or AVN_ISLAND_BLOCKS=0) */
-    uint32_t reserved0;
+    uint32_t side_island_bodies; /* bodies of islands that hold joints and no contact manifold: their substep loop ran on a second stream
+                                    next to the other islands' contact passes (island-level concurrency; 0 = one stream) */
 } avn_timers;
 
 /* SolverDiagnostics (dynamics/solver/diagnostics.rs:13-37) and CollisionDiagnostics (collision/diagnostics.rs:13-19): the same fields in

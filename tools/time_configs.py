@@ -42,7 +42,7 @@ def time_steps(w, substeps, warmup=3, steps=20):
     dt = (time.perf_counter() - t0) / steps
     tm = w.timers()
     return {"ms_per_step": round(dt * 1e3, 4), "substeps_per_s": round(substeps / dt, 1), "kernel_launches_per_step": int(tm.kernel_launches),
-            "island_blocks": int(tm.island_blocks),
+            "island_blocks": int(tm.island_blocks), "side_island_bodies": int(tm.side_island_bodies),
             "last_step_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4), "substeps": round(tm.substeps_ms, 4), "finalize": round(tm.finalize_ms, 4)}}
 
 
