@@ -187,5 +187,6 @@
             materials_restitution = false;
         }
         have_colliders = true;
+        if (pipe_dev && !same) { avn_status se = pg_upload_ent2slot(); if (se != AVN_OK) return se; }   // k_pg_add_pairs turns the pairs' collider entities into slots
         return AVN_OK;
     }
