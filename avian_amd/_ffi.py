@@ -312,6 +312,20 @@ class Library:
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
 
+    def _declare_islands(self):
+        if getattr(self, "_islands_declared", False):
+            return
+        f = self.fn
+        f("islands_create").restype = vp; f("islands_create").argtypes = []
+        f("islands_destroy").restype = None; f("islands_destroy").argtypes = [vp]
+        for name, args in (("islands_body_add", [vp, C.c_uint32]), ("islands_collider_add", [vp, C.c_uint32, C.c_uint32]),
+                           ("islands_joint_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_pair_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
+                           ("islands_status_change", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_flush_wake", [vp]), ("islands_split_candidate", [vp]),
+                           ("islands_sleeping_systems", [vp, vp, vp, C.c_uint32, C.c_float]), ("islands_wake_body", [vp, C.c_uint32]), ("islands_sleep_body", [vp, C.c_uint32]),
+                           ("islands_last_result", [vp, vp]), ("islands_stats_get", [vp, vp]), ("islands_state", [vp, C.c_uint32, vp, vp, vp, vp])):
+            f(name).restype = C.c_int; f(name).argtypes = args
+        self._islands_declared = True
+
     def pair_key(self, a: int, b: int) -> int:
         return int(self.fn("pair_key")(a, b))
 
@@ -848,6 +862,75 @@ class ConstraintGraph:
     def close(self):
         if getattr(self, "handle", None):
             self.lib.fn("constraint_graph_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class avn_islands_result(C.Structure):
+    _fields_ = [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
+
+
+class avn_islands_stats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_islands", "n_sleeping_islands", "n_bodies", "n_sleeping_bodies", "merges", "splits", "split_candidate", "sleeping_pairs")]
+
+
+class IslandManager:
+    """``avn_island_manager`` (persistent islands + sleeping bookkeeping, islands/mod.rs, islands/sleeping.rs) behind the ABI: a host structure."""
+    NONE = 0xFFFFFFFF
+
+    def __init__(self, lib: Library):
+        lib._declare_islands()
+        self.lib = lib
+        self.handle = lib.fn("islands_create")()
+        if not self.handle:
+            raise AvnError(4, "islands_create")
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise AvnError(st, what)
+
+    def body_add(self, body): self._chk(self.lib.fn("islands_body_add")(self.handle, body), "islands_body_add")
+    def collider_add(self, collider, body): self._chk(self.lib.fn("islands_collider_add")(self.handle, collider, self.NONE if body is None else body), "islands_collider_add")
+    def joint_add(self, joint, b1, b2): self._chk(self.lib.fn("islands_joint_add")(self.handle, joint, b1, b2), "islands_joint_add")
+    def pair_add(self, cid, c1, c2): self._chk(self.lib.fn("islands_pair_add")(self.handle, cid, c1, c2), "islands_pair_add")
+    def status_change(self, cid, flags, manifold_count=1): self._chk(self.lib.fn("islands_status_change")(self.handle, cid, flags, manifold_count), "islands_status_change")
+    def flush_wake(self): self._chk(self.lib.fn("islands_flush_wake")(self.handle), "islands_flush_wake"); return self.last_result()
+    def split_candidate(self): self._chk(self.lib.fn("islands_split_candidate")(self.handle), "islands_split_candidate")
+    def wake_body(self, body): self._chk(self.lib.fn("islands_wake_body")(self.handle, body), "islands_wake_body"); return self.last_result()
+    def sleep_body(self, body): self._chk(self.lib.fn("islands_sleep_body")(self.handle, body), "islands_sleep_body"); return self.last_result()
+
+    def sleeping_systems(self, sleep_timer, flags, time_to_sleep=0.5):
+        t = np.ascontiguousarray(sleep_timer, np.float32); f = np.ascontiguousarray(flags, np.uint8)
+        self._chk(self.lib.fn("islands_sleeping_systems")(self.handle, _ptr(t), _ptr(f), len(t), C.c_float(time_to_sleep)), "islands_sleeping_systems")
+        return self.last_result()
+
+    def last_result(self):
+        r = avn_islands_result()
+        self._chk(self.lib.fn("islands_last_result")(self.handle, C.byref(r)), "islands_last_result")
+        out = {}
+        for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken"):
+            n = getattr(r, "n_" + name)
+            out[name] = np.ctypeslib.as_array(C.cast(getattr(r, name), C.POINTER(C.c_uint32)), (n,)).copy() if n else np.zeros(0, np.uint32)
+        return out
+
+    def stats(self):
+        s = avn_islands_stats()
+        self._chk(self.lib.fn("islands_stats_get")(self.handle, C.byref(s)), "islands_stats_get")
+        return s
+
+    def state(self, n_bodies):
+        a = np.zeros(n_bodies, np.uint32); b = np.zeros(n_bodies, np.uint32); c = np.zeros(n_bodies, np.uint8); d = np.zeros(n_bodies, np.uint32)
+        self._chk(self.lib.fn("islands_state")(self.handle, n_bodies, _ptr(a), _ptr(b), _ptr(c), _ptr(d)), "islands_state")
+        return dict(island=a, next=b, sleeping=c, removed=d)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fn("islands_destroy")(self.handle)
             self.handle = None
 
     def __del__(self):

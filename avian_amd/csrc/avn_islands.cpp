@@ -1,0 +1,363 @@
+// avn_islands.cpp -- see avn_islands.hpp.  Host C++ (no device code): the island manager of the closed loop and the avn_islands_* C ABI.
+#include "avn_islands.hpp"
+
+#include <algorithm>
+#include <new>
+
+namespace avn {
+
+void IslandManager::clear_results() { popped_.clear(); pushed_.clear(); pairs_slept_.clear(); pairs_woken_.clear(); bodies_slept_.clear(); bodies_woken_.clear(); }
+
+// slab::Slab::insert / remove: the vacant keys form a stack (remove pushes, insert pops; a fresh key only when the stack is empty)
+uint32_t IslandManager::island_insert(Island&& isl) {
+    uint32_t key;
+    if (vacant_.empty()) { key = (uint32_t)islands_.size(); islands_.emplace_back(); }
+    else { key = vacant_.back(); vacant_.pop_back(); }
+    isl.used = true;
+    islands_[key] = std::move(isl);
+    ++n_islands_;
+    return key;
+}
+void IslandManager::island_remove(uint32_t id) {   // PhysicsIslands::remove_island, islands/mod.rs:441-449
+    if (candidate_ == id) candidate_ = NONE;
+    islands_[id] = Island();
+    vacant_.push_back(id);
+    --n_islands_;
+}
+
+avn_status IslandManager::body_add(uint32_t body) {   // BodyIslandNode::on_add, :1330-1345
+    if (node_.size() <= body) { node_.resize((size_t)body + 1, 0); asleep_.resize((size_t)body + 1, 0); isl_of_.resize((size_t)body + 1, NONE); colliders_of_.resize((size_t)body + 1); joint_edges_.resize((size_t)body + 1); }
+    if (node_[body]) { error = "islands_body_add: the body already has a node"; return AVN_ERR_STATE; }
+    Island isl;
+    isl.bodies.push_back(body);
+    isl_of_[body] = island_insert(std::move(isl));
+    node_[body] = 1;
+    return AVN_OK;
+}
+avn_status IslandManager::collider_add(uint32_t collider, uint32_t body) {
+    collider_body_[collider] = body;
+    if (body != NONE) {
+        if (colliders_of_.size() <= body) { colliders_of_.resize((size_t)body + 1); }
+        colliders_of_[body].push_back(collider);
+    }
+    return AVN_OK;
+}
+uint32_t IslandManager::node_of(uint32_t collider) {
+    auto it = collider_node_.find(collider);
+    if (it != collider_node_.end()) return it->second;
+    const uint32_t n = (uint32_t)contact_edges_.size();
+    contact_edges_.emplace_back();
+    collider_node_.emplace(collider, n);
+    return n;
+}
+avn_status IslandManager::pair_add(uint32_t id, uint32_t c1, uint32_t c2) {   // ContactGraph::add_edge_and_key_with, contact_graph.rs:521-566
+    if (contacts_.size() <= id) contacts_.resize((size_t)id + 1);
+    if (contacts_[id].live) { error = "islands_pair_add: contact id in use"; return AVN_ERR_STATE; }
+    auto f1 = collider_body_.find(c1), f2 = collider_body_.find(c2);
+    if (f1 == collider_body_.end() || f2 == collider_body_.end()) { error = "islands_pair_add: unknown collider"; return AVN_ERR_BAD_ARG; }
+    Contact c;
+    c.live = true;
+    c.c1 = node_of(c1); c.c2 = node_of(c2);
+    c.rb1 = f1->second; c.rb2 = f2->second;
+    c.b1 = body_has_node(c.rb1) ? c.rb1 : NONE; c.b2 = body_has_node(c.rb2) ? c.rb2 : NONE;
+    contacts_[id] = c;
+    contact_edges_[c.c1].out.push_back(id);   // (the reference links at the HEAD of both lists: the walks below run backwards)
+    contact_edges_[c.c2].in.push_back(id);
+    return AVN_OK;
+}
+
+// merge_islands, :814-990: the island with fewer bodies is appended to the other (ties: body1's island stays)
+uint32_t IslandManager::merge(uint32_t body1, uint32_t body2) {
+    if (!body_has_node(body1)) return isl_of_[body2];
+    if (!body_has_node(body2)) return isl_of_[body1];
+    uint32_t big = isl_of_[body1], small = isl_of_[body2];
+    if (big == small) return big;
+    if (islands_[big].bodies.size() < islands_[small].bodies.size()) std::swap(big, small);
+    Island& B = islands_[big]; Island& S = islands_[small];
+    for (uint32_t b : S.bodies) isl_of_[b] = big;
+    B.bodies.insert(B.bodies.end(), S.bodies.begin(), S.bodies.end());
+    B.removed += S.removed;
+    if (S.sleeping) { B.sleeping = true; B.timer = std::max(S.timer, B.timer); }
+    island_remove(small);
+    ++merges_;
+    return big;
+}
+uint32_t IslandManager::link_contact(uint32_t id) {   // add_contact, :513-582
+    Contact& c = contacts_[id];
+    if (c.b1 == NONE && c.b2 == NONE) return NONE;
+    const uint32_t isl = merge(c.b1 != NONE ? c.b1 : c.b2, c.b2 != NONE ? c.b2 : c.b1);
+    c.linked = true;
+    return isl;
+}
+uint32_t IslandManager::unlink_contact(uint32_t id) {   // remove_contact, :594-660
+    Contact& c = contacts_[id];
+    c.linked = false;
+    const uint32_t isl = contact_island(c);
+    islands_[isl].removed += 1;
+    return isl;
+}
+avn_status IslandManager::joint_add(uint32_t jid, uint32_t body1, uint32_t body2) {   // joint_graph/mod.rs:238-270 + islands/mod.rs:668-735
+    if (joints_.size() <= jid) joints_.resize((size_t)jid + 1);
+    joints_[jid] = Joint{body1, body2};
+    const uint32_t hi = std::max(body1, body2);
+    if (joint_edges_.size() <= hi) joint_edges_.resize((size_t)hi + 1);
+    joint_edges_[body1].out.push_back(jid);
+    joint_edges_[body2].in.push_back(jid);
+    if (body_has_node(body1) || body_has_node(body2)) merge(body_has_node(body1) ? body1 : body2, body_has_node(body2) ? body2 : body1);
+    return AVN_OK;
+}
+
+// one iteration of the status loop of NarrowPhase::update, system_param.rs:155-373 (the ConstraintGraph half is the caller's)
+avn_status IslandManager::status_change(uint32_t id, uint32_t flags, uint32_t manifold_count) {
+    if (id >= contacts_.size() || !contacts_[id].live) { error = "islands_status_change: no such contact"; return AVN_ERR_STATE; }
+    Contact& c = contacts_[id];
+    const bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS;
+    if (flags & AVN_CP_DISJOINT_AABB) {
+        if (generates) { c.handles = 0; if (c.linked) unlink_contact(id); }
+        if (c.sleeping) --sleeping_pairs_;
+        // ContactGraph::remove_edge_by_id: out of both edge lists
+        auto drop = [&](std::vector<uint32_t>& v) { auto it = std::find(v.rbegin(), v.rend(), id); if (it != v.rend()) v.erase(std::next(it).base()); };
+        drop(contact_edges_[c.c1].out); drop(contact_edges_[c.c2].in);
+        contacts_[id] = Contact();
+    } else if (flags & AVN_CP_STARTED_TOUCHING) {
+        c.touching = true; c.generates = generates;
+        if (generates) {
+            c.handles = manifold_count;
+            const uint32_t isl = link_contact(id);
+            if (isl != NONE && islands_[isl].sleeping) to_wake_.push_back(isl);
+        }
+    } else if (flags & AVN_CP_STOPPED_TOUCHING) {
+        c.touching = false; c.generates = generates;
+        if (generates && c.handles) {
+            c.handles = 0;
+            const uint32_t isl = unlink_contact(id);
+            if (islands_[isl].sleeping) to_wake_.push_back(isl);
+        }
+    } else if ((flags & AVN_CP_TOUCHING) && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) {
+        c.generates = true;
+        c.handles = manifold_count;
+        const uint32_t isl = link_contact(id);
+        if (isl != NONE && islands_[isl].sleeping) to_wake_.push_back(isl);
+    }
+    return AVN_OK;
+}
+avn_status IslandManager::flush_wake() {   // system_param.rs:391-398
+    clear_results();
+    if (to_wake_.empty()) return AVN_OK;
+    std::sort(to_wake_.begin(), to_wake_.end());
+    to_wake_.erase(std::unique(to_wake_.begin(), to_wake_.end()), to_wake_.end());
+    wake_islands(to_wake_);
+    to_wake_.clear();
+    return AVN_OK;
+}
+
+// EdgeWeights::next: the outgoing list (newest edge first), then the incoming list (newest first)
+template <class F> void IslandManager::edges_in_reference_order(const EdgeLists& l, uint32_t, bool, F f) const {
+    for (size_t k = l.out.size(); k-- > 0;) f(l.out[k]);
+    for (size_t k = l.in.size(); k-- > 0;) f(l.in[k]);
+}
+// SleepIslands::apply (sleeping.rs:355-420) over ContactGraph::sleep_entity_with (contact_graph.rs:768-838)
+void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
+    std::vector<uint32_t> batch;
+    for (uint32_t id : ids) {
+        if (id >= islands_.size() || !islands_[id].used) continue;
+        Island& isl = islands_[id];
+        if (isl.sleeping) return;   // (the reference `return`s out of the whole command here)
+        isl.sleeping = true;
+        for (uint32_t b : isl.bodies) {
+            for (uint32_t col : colliders_of_[b]) {
+                auto it = collider_node_.find(col);
+                if (it == collider_node_.end()) continue;
+                batch.clear();
+                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { if (!contacts_[e].sleeping) batch.push_back(e); });
+                for (uint32_t e : batch) {
+                    Contact& c = contacts_[e];
+                    if (!c.touching) continue;
+                    c.sleeping = true; ++sleeping_pairs_;
+                    pairs_slept_.push_back(e);
+                    if (c.generates) { for (uint32_t k = 0; k < c.handles; ++k) popped_.push_back(e); c.handles = 0; }
+                }
+            }
+            bodies_slept_.push_back(b);
+            asleep_[b] = 1;
+        }
+    }
+}
+// WakeIslands::apply (:470-540) over wake_entity_with (:705-766)
+void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
+    std::vector<uint32_t> batch;
+    for (uint32_t id : ids) {
+        if (id >= islands_.size() || !islands_[id].used || !islands_[id].sleeping) continue;
+        Island& isl = islands_[id];
+        isl.sleeping = false;
+        for (uint32_t b : isl.bodies) {
+            for (uint32_t col : colliders_of_[b]) {
+                auto it = collider_node_.find(col);
+                if (it == collider_node_.end()) continue;
+                batch.clear();
+                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { if (contacts_[e].sleeping) batch.push_back(e); });
+                for (uint32_t e : batch) {
+                    Contact& c = contacts_[e];
+                    if (!c.touching) continue;
+                    c.sleeping = false; --sleeping_pairs_;
+                    pairs_woken_.push_back(e);
+                    if (c.generates) { pushed_.push_back(e); c.handles = 1; }   // one manifold per convex pair
+                }
+            }
+            bodies_woken_.push_back(b);
+            asleep_[b] = 0;
+        }
+    }
+}
+
+// split_island, :995-1280: depth-first from the old list's bodies in list order; a body's contacts are collected (collider by collider, edge
+// list order, only linked ones with constraint handles not yet claimed) before any of them is claimed, then its joints the same way
+void IslandManager::split(uint32_t island) {
+    if (island >= islands_.size() || !islands_[island].used) return;
+    if (islands_[island].sleeping || islands_[island].removed == 0) return;
+    std::vector<uint32_t> seeds = std::move(islands_[island].bodies);
+    island_remove(island);
+    ++splits_;
+    ++mark_gen_;
+    if (mark_body_.size() < node_.size()) mark_body_.resize(node_.size(), 0);
+    if (mark_contact_.size() < contacts_.size()) mark_contact_.resize(contacts_.size(), 0);
+    if (mark_joint_.size() < joints_.size()) mark_joint_.resize(joints_.size(), 0);
+    std::vector<uint32_t> stack;
+    std::vector<std::pair<uint32_t, uint32_t>> found;
+    for (uint32_t seed : seeds) {
+        if (mark_body_[seed] == mark_gen_) continue;
+        mark_body_[seed] = mark_gen_;
+        Island isl;
+        const uint32_t new_id = next_key();
+        stack.assign(1, seed);
+        while (!stack.empty()) {
+            const uint32_t body = stack.back(); stack.pop_back();
+            isl_of_[body] = new_id;
+            isl.bodies.push_back(body);
+            found.clear();
+            for (uint32_t col : colliders_of_[body]) {
+                auto it = collider_node_.find(col);
+                if (it == collider_node_.end()) continue;
+                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) {
+                    const Contact& c = contacts_[e];
+                    if (c.linked && mark_contact_[e] == mark_gen_) return;
+                    if (!c.handles) return;
+                    found.push_back({e, c.rb1 == body ? c.rb2 : c.rb1});
+                });
+            }
+            for (auto& pr : found) {
+                if (body_has_node(pr.second) && mark_body_[pr.second] != mark_gen_) { stack.push_back(pr.second); mark_body_[pr.second] = mark_gen_; }
+                mark_contact_[pr.first] = mark_gen_;
+            }
+            found.clear();
+            if (body < joint_edges_.size())
+                edges_in_reference_order(joint_edges_[body], body, false, [&](uint32_t j) {
+                    if (mark_joint_[j] == mark_gen_) return;
+                    found.push_back({j, joints_[j].b1 == body ? joints_[j].b2 : joints_[j].b1});
+                });
+            for (auto& pr : found) {
+                if (body_has_node(pr.second) && mark_body_[pr.second] != mark_gen_) { stack.push_back(pr.second); mark_body_[pr.second] = mark_gen_; }
+                mark_joint_[pr.first] = mark_gen_;
+            }
+        }
+        island_insert(std::move(isl));
+    }
+}
+avn_status IslandManager::split_candidate_now() { if (candidate_ != NONE) split(candidate_); return AVN_OK; }
+
+avn_status IslandManager::sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep) {
+    clear_results();
+    if (n_bodies && (!sleep_timer || !flags)) { error = "islands_sleeping_systems: null array"; return AVN_ERR_BAD_ARG; }
+    awake_.assign(islands_.size(), 0);
+    candidate_timer_ = 0.0f;
+    const uint32_t n = std::min<uint32_t>(n_bodies, (uint32_t)node_.size());
+    // update_sleeping_states, island side (sleeping.rs:224-239), in body order (the ABI's stand-in for the query's iteration order)
+    for (uint32_t b = 0; b < n; ++b) {
+        if (!node_[b] || !(flags[b] & 1u)) continue;
+        const uint32_t isl = isl_of_[b];
+        if (sleep_timer[b] < time_to_sleep) awake_[isl] = 1;
+        else if (islands_[isl].removed > 0 && sleep_timer[b] > candidate_timer_) { candidate_ = isl; candidate_timer_ = sleep_timer[b]; }
+    }
+    // wake_islands_with_sleeping_disabled, :164-182
+    for (uint32_t b = 0; b < n; ++b) if (node_[b] && (flags[b] & 2u)) awake_[isl_of_[b]] = 1;
+    // sleep_islands, :243-280, in slab key order
+    std::vector<uint32_t> to_sleep, to_wake;
+    for (uint32_t k = 0; k < islands_.size(); ++k) {
+        const Island& isl = islands_[k];
+        if (!isl.used) continue;
+        if (awake_[k]) { if (isl.sleeping) to_wake.push_back(k); }
+        else if (!isl.sleeping && isl.removed == 0) to_sleep.push_back(k);
+    }
+    sleep_islands(to_sleep);
+    wake_islands(to_wake);
+    last_slept_ = (uint32_t)to_sleep.size(); last_woken_ = (uint32_t)to_wake.size();
+    return AVN_OK;
+}
+avn_status IslandManager::wake_body(uint32_t body) {   // WakeBody, sleeping.rs:438-452
+    clear_results();
+    if (!body_has_node(body)) { error = "islands_wake_body: the body has no island node"; return AVN_ERR_BAD_ARG; }
+    wake_islands({isl_of_[body]});
+    return AVN_OK;
+}
+avn_status IslandManager::sleep_body(uint32_t body) {   // SleepBody, :296-352
+    clear_results();
+    if (!body_has_node(body)) { error = "islands_sleep_body: the body has no island node"; return AVN_ERR_BAD_ARG; }
+    if (islands_[isl_of_[body]].removed > 0) split(isl_of_[body]);
+    sleep_islands({isl_of_[body]});
+    return AVN_OK;
+}
+avn_status IslandManager::last_result(avn_islands_result* o) const {
+    if (!o) return AVN_ERR_BAD_ARG;
+    o->popped = popped_.data(); o->n_popped = popped_.size(); o->pushed = pushed_.data(); o->n_pushed = pushed_.size();
+    o->pairs_slept = pairs_slept_.data(); o->n_pairs_slept = pairs_slept_.size(); o->pairs_woken = pairs_woken_.data(); o->n_pairs_woken = pairs_woken_.size();
+    o->bodies_slept = bodies_slept_.data(); o->n_bodies_slept = bodies_slept_.size(); o->bodies_woken = bodies_woken_.data(); o->n_bodies_woken = bodies_woken_.size();
+    return AVN_OK;
+}
+avn_status IslandManager::stats(avn_islands_stats* o) const {
+    if (!o) return AVN_ERR_BAD_ARG;
+    uint32_t ns = 0, nb = 0, nsb = 0;
+    for (const Island& i : islands_) if (i.used && i.sleeping) ++ns;
+    for (size_t b = 0; b < node_.size(); ++b) if (node_[b]) { ++nb; if (asleep_[b]) ++nsb; }
+    o->n_islands = n_islands_; o->n_sleeping_islands = ns; o->n_bodies = nb; o->n_sleeping_bodies = nsb;
+    o->merges = merges_; o->splits = splits_; o->split_candidate = candidate_; o->sleeping_pairs = sleeping_pairs_;
+    return AVN_OK;
+}
+avn_status IslandManager::state(uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) const {
+    if (next_in_island) {
+        for (uint32_t b = 0; b < n_bodies; ++b) next_in_island[b] = NONE;
+        for (const Island& i : islands_)
+            if (i.used) for (size_t k = 0; k + 1 < i.bodies.size(); ++k) if (i.bodies[k] < n_bodies) next_in_island[i.bodies[k]] = i.bodies[k + 1];
+    }
+    for (uint32_t b = 0; b < n_bodies; ++b) {
+        const bool n = body_has_node(b);
+        if (island_of_body) island_of_body[b] = n ? isl_of_[b] : NONE;
+        if (island_sleeping) island_sleeping[b] = n && islands_[isl_of_[b]].sleeping;
+        if (removed) removed[b] = n ? islands_[isl_of_[b]].removed : 0u;
+    }
+    return AVN_OK;
+}
+
+}  // namespace avn
+
+// ---- C ABI (include/avian_mi355x.h: avn_islands_*) ----------------------------------------------------------------------------------
+struct avn_island_manager { avn::IslandManager m; };
+extern "C" {
+AVN_API avn_island_manager* avn_islands_create(void) { return new (std::nothrow) avn_island_manager(); }
+AVN_API void avn_islands_destroy(avn_island_manager* m) { delete m; }
+#define AVN_ISL(call) do { if (!m) return AVN_ERR_BAD_ARG; try { return m->m.call; } catch (...) { m->m.error = "out of host memory"; return AVN_ERR_OOM; } } while (0)
+AVN_API avn_status avn_islands_body_add(avn_island_manager* m, uint32_t body) { AVN_ISL(body_add(body)); }
+AVN_API avn_status avn_islands_collider_add(avn_island_manager* m, uint32_t collider, uint32_t body) { AVN_ISL(collider_add(collider, body)); }
+AVN_API avn_status avn_islands_joint_add(avn_island_manager* m, uint32_t joint, uint32_t b1, uint32_t b2) { AVN_ISL(joint_add(joint, b1, b2)); }
+AVN_API avn_status avn_islands_pair_add(avn_island_manager* m, uint32_t id, uint32_t c1, uint32_t c2) { AVN_ISL(pair_add(id, c1, c2)); }
+AVN_API avn_status avn_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t manifold_count) { AVN_ISL(status_change(id, flags, manifold_count)); }
+AVN_API avn_status avn_islands_flush_wake(avn_island_manager* m) { AVN_ISL(flush_wake()); }
+AVN_API avn_status avn_islands_split_candidate(avn_island_manager* m) { AVN_ISL(split_candidate_now()); }
+AVN_API avn_status avn_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { AVN_ISL(sleeping_systems(t, f, n, tts)); }
+AVN_API avn_status avn_islands_wake_body(avn_island_manager* m, uint32_t body) { AVN_ISL(wake_body(body)); }
+AVN_API avn_status avn_islands_sleep_body(avn_island_manager* m, uint32_t body) { AVN_ISL(sleep_body(body)); }
+AVN_API avn_status avn_islands_last_result(avn_island_manager* m, avn_islands_result* out) { AVN_ISL(last_result(out)); }
+AVN_API avn_status avn_islands_stats_get(avn_island_manager* m, avn_islands_stats* out) { AVN_ISL(stats(out)); }
+AVN_API avn_status avn_islands_state(avn_island_manager* m, uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) {
+    AVN_ISL(state(n_bodies, island_of_body, next_in_island, island_sleeping, removed));
+}
+}

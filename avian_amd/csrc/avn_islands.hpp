@@ -1,0 +1,110 @@
+// avn_islands.hpp -- persistent simulation islands + the bookkeeping of sleeping, host side (include/avian_mi355x.h: avn_island_manager).
+//
+// What it replaces (paths relative to /root/reference/src): PhysicsIslands (dynamics/solver/islands/mod.rs:404-1280: create / remove,
+// add_contact, remove_contact, add_joint, merge_islands, split_island), the island side of the Sleeping set
+// (dynamics/solver/islands/sleeping.rs:164-280: awake bits, split candidate, sleep_islands), the SleepIslands / WakeIslands commands
+// (:355-540) with ContactGraph::sleep_entity_with / wake_entity_with (collision/contact_types/contact_graph.rs:705-838), and the part of
+// the ContactGraph / JointGraph those walk: a collider's / body's edge list in petgraph order (data_structures/stable_graph.rs:640-675).
+//
+// The reference keeps all of this in intrusive linked lists threaded through ECS components.  Here the SAME ORDERS come out of flat
+// arrays: an island owns a vector of its bodies (a merge appends the smaller island's vector, a split writes the depth-first visit
+// order), a collider owns two vectors of edge ids in insertion order (the reference's lists are "newest first": walked backwards), the
+// slab's vacant keys are a stack.  A contact does not store its island: both of its bodies are in one island from the moment it is
+// linked (add_contact merges them; a split keeps bodies joined by a linked contact together), so `island of a contact` is the island of
+// whichever of its bodies owns a node.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/avian_mi355x.h"
+
+namespace avn {
+
+class IslandManager {
+public:
+    static constexpr uint32_t NONE = 0xFFFFFFFFu;
+    std::string error;
+
+    avn_status body_add(uint32_t body);
+    avn_status collider_add(uint32_t collider, uint32_t body);
+    avn_status joint_add(uint32_t joint, uint32_t body1, uint32_t body2);
+    avn_status pair_add(uint32_t contact_id, uint32_t collider1, uint32_t collider2);
+    avn_status status_change(uint32_t contact_id, uint32_t flags, uint32_t manifold_count);
+    avn_status flush_wake();
+    avn_status split_candidate_now();
+    avn_status sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep);
+    avn_status wake_body(uint32_t body);
+    avn_status sleep_body(uint32_t body);
+    avn_status last_result(avn_islands_result* out) const;
+    avn_status stats(avn_islands_stats* out) const;
+    avn_status state(uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) const;
+
+    // what the world reads directly
+    bool body_has_node(uint32_t b) const { return b < node_.size() && node_[b]; }
+    bool body_sleeps(uint32_t b) const { return b < asleep_.size() && asleep_[b]; }
+    uint32_t island_of(uint32_t b) const { return isl_of_[b]; }
+    uint32_t last_slept() const { return last_slept_; }
+    uint32_t last_woken() const { return last_woken_; }
+    const std::vector<uint32_t>& popped() const { return popped_; }
+    const std::vector<uint32_t>& pushed() const { return pushed_; }
+    const std::vector<uint32_t>& pairs_slept() const { return pairs_slept_; }
+    const std::vector<uint32_t>& pairs_woken() const { return pairs_woken_; }
+    const std::vector<uint32_t>& bodies_slept() const { return bodies_slept_; }
+    const std::vector<uint32_t>& bodies_woken() const { return bodies_woken_; }
+
+private:
+    struct Island {
+        bool used = false, sleeping = false;
+        uint32_t removed = 0;          // constraints_removed
+        float timer = 0.0f;            // PhysicsIsland::sleep_timer (only ever combined by merges)
+        std::vector<uint32_t> bodies;  // the body list, head first
+    };
+    struct Contact {
+        bool live = false, touching = false, sleeping = false, generates = false, linked = false;
+        uint32_t handles = 0;
+        uint32_t c1 = NONE, c2 = NONE;       // nodes of the edge lists
+        uint32_t b1 = NONE, b2 = NONE;       // bodies of the colliders (NONE: no island node)
+        uint32_t rb1 = NONE, rb2 = NONE;     // the colliders' bodies whether they own a node or not (the DFS names the "other" body by entity)
+    };
+    struct Joint { uint32_t b1 = NONE, b2 = NONE; };
+    struct EdgeLists { std::vector<uint32_t> out, in; };   // insertion order; the reference iterates newest first
+
+    std::vector<uint8_t> node_, asleep_;
+    std::vector<uint32_t> isl_of_;
+    std::vector<std::vector<uint32_t>> colliders_of_;
+    std::unordered_map<uint32_t, uint32_t> collider_node_, collider_body_;
+    std::vector<EdgeLists> contact_edges_;   // per collider node
+    std::vector<EdgeLists> joint_edges_;     // per body
+    std::vector<Contact> contacts_;
+    std::vector<Joint> joints_;
+    std::vector<Island> islands_;
+    std::vector<uint32_t> vacant_;           // slab: last freed key on top
+    uint32_t n_islands_ = 0;
+    uint32_t candidate_ = NONE;
+    float candidate_timer_ = 0.0f;
+    std::vector<uint8_t> awake_;
+    std::vector<uint32_t> to_wake_;
+    uint32_t merges_ = 0, splits_ = 0, sleeping_pairs_ = 0, last_slept_ = 0, last_woken_ = 0;
+    std::vector<uint32_t> popped_, pushed_, pairs_slept_, pairs_woken_, bodies_slept_, bodies_woken_;
+    // split scratch
+    std::vector<uint32_t> mark_contact_, mark_joint_, mark_body_;
+    uint32_t mark_gen_ = 0;
+
+    void clear_results();
+    uint32_t next_key() const { return vacant_.empty() ? (uint32_t)islands_.size() : vacant_.back(); }
+    uint32_t island_insert(Island&& isl);
+    void island_remove(uint32_t id);
+    uint32_t merge(uint32_t body1, uint32_t body2);
+    uint32_t link_contact(uint32_t id);
+    uint32_t unlink_contact(uint32_t id);
+    uint32_t contact_island(const Contact& c) const { return isl_of_[c.b1 != NONE ? c.b1 : c.b2]; }
+    template <class F> void edges_in_reference_order(const EdgeLists& l, uint32_t self_out_node, bool contact_graph, F f) const;
+    void sleep_islands(const std::vector<uint32_t>& ids);
+    void wake_islands(const std::vector<uint32_t>& ids);
+    void split(uint32_t island);
+    uint32_t node_of(uint32_t collider);
+};
+
+}  // namespace avn

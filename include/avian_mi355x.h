@@ -746,6 +746,103 @@ AVN_API avn_status AVN_FN(sleep_get)(avn_world* w, const avn_sleep_out* out);
 /* SleepTimer = 0 for the listed bodies (n = 0: for all): what waking an island does to its bodies (sleeping.rs:492) */
 AVN_API avn_status AVN_FN(sleep_reset)(avn_world* w, const uint32_t* bodies, size_t n);
 
+
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * Persistent simulation islands and the ACTUATION of sleeping (second half).
+ *
+ * Reference: dynamics/solver/islands/mod.rs (PhysicsIslands: create / remove, add_contact :513-582, remove_contact :594-660, add_joint,
+ * merge_islands :814-990, split_island :995-1280, BodyIslandNode hooks :1330-1414) and islands/sleeping.rs (update_sleeping_states
+ * :184-241, sleep_islands :243-280, SleepIslands :355-420, WakeIslands :470-540), on top of collision/contact_types/contact_graph.rs
+ * (edge lists of a collider in petgraph order: outgoing edges newest first, then incoming edges newest first; sleep_entity_with /
+ * wake_entity_with :705-838) and data_structures/stable_graph.rs.
+ *
+ * Two layers:
+ *  (1) avn_island_manager -- the reference's PhysicsIslands plus the island-relevant part of ContactGraph / JointGraph as a HOST structure
+ *      (it is host state of the ECS in the reference too).  Everything whose ORDER the reference defines through linked lists is kept in
+ *      that order: an island's body list (merges append the smaller island; a split rebuilds it in depth-first visit order), the slab ids
+ *      of islands (vacant keys are reused last-freed-first), a collider's edge list.  A Bevy integration can keep Avian's own resources
+ *      instead and only use layer (2); the standalone closed loop owns one manager per world.
+ *  (2) avn_sleeping_enable -- the closed loop (avn_pipeline_enable) drives its manager itself: island bookkeeping inside the status loop,
+ *      WakeIslands after the narrow phase, split_island in Finalize, the Sleeping set at the end of avn_step, and the actuation on the
+ *      device: a sleeping island's touching constraint-generating pairs leave the colour lists (pop_manifold in body-list x edge-list
+ *      order -- that order decides where swap_remove moves the other handles), its pairs stop being updated by the narrow phase, its
+ *      bodies lose their SolverBody and their intervals turn inactive; waking pushes the manifolds back in the same order (which decides
+ *      their colours) and resets the bodies' SleepTimers. */
+typedef struct avn_island_manager avn_island_manager;
+AVN_API avn_island_manager* AVN_FN(islands_create)(void);
+AVN_API void AVN_FN(islands_destroy)(avn_island_manager* m);
+/* BodyIslandNode::on_add: a new island holding `body` (bodies with a SolverBody: dynamic / kinematic, enabled); call in spawn order */
+AVN_API avn_status AVN_FN(islands_body_add)(avn_island_manager* m, uint32_t body);
+/* RigidBodyColliders of `body` gains `collider` (Entity::index() of the collider); colliders of bodies WITHOUT a node (static) are announced
+ * with body = 0xFFFFFFFF */
+AVN_API avn_status AVN_FN(islands_collider_add)(avn_island_manager* m, uint32_t collider, uint32_t body);
+/* JointGraph::add_joint + PhysicsIslands::add_joint: merges the two bodies' islands; call in joint spawn order */
+AVN_API avn_status AVN_FN(islands_joint_add)(avn_island_manager* m, uint32_t joint, uint32_t body1, uint32_t body2);
+/* ContactGraph::add_edge_and_key_with: the pair enters both colliders' edge lists at their heads */
+AVN_API avn_status AVN_FN(islands_pair_add)(avn_island_manager* m, uint32_t contact_id, uint32_t collider1, uint32_t collider2);
+/* one iteration of the status loop of NarrowPhase::update (system_param.rs:141-389) for `contact_id`: `flags` are the pair's AVN_CP_* bits
+ * as avn_contact_change reports them (DISJOINT_AABB removes the pair; STARTED_TOUCHING / STOPPED_TOUCHING / STARTED_GENERATING_CONSTRAINTS
+ * link / unlink the contact and queue its island for waking when it sleeps).  Call in ascending ContactId like the reference. */
+AVN_API avn_status AVN_FN(islands_status_change)(avn_island_manager* m, uint32_t contact_id, uint32_t flags, uint32_t manifold_count);
+/* WakeIslands(sorted, deduplicated islands queued by the status loop), then returns how many manifolds it pushed back: their contact ids in
+ * push order and the bodies whose Sleeping component it removed, readable until the next call through avn_islands_last_*.  */
+AVN_API avn_status AVN_FN(islands_flush_wake)(avn_island_manager* m);
+/* split_island(split_candidate) -- SolverSystems::Finalize */
+AVN_API avn_status AVN_FN(islands_split_candidate)(avn_island_manager* m);
+/* The Sleeping set after the solver.  `sleep_timer` [n_bodies]: the SleepTimers AFTER update_sleeping_states' increment / reset (the caller
+ * owns that arithmetic: it reads SolverBody velocities); `flags` [n_bodies]: bit 0 = the body took part in update_sleeping_states (has a
+ * SolverBody, not Sleeping, not SleepingDisabled), bit 1 = SleepingDisabled (wake_islands_with_sleeping_disabled).  Runs the island side of
+ * update_sleeping_states (awake bits, split candidate), wake_islands_with_sleeping_disabled, sleep_islands, then SleepIslands and
+ * WakeIslands; results through avn_islands_last_*. */
+AVN_API avn_status AVN_FN(islands_sleeping_systems)(avn_island_manager* m, const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep);
+/* WakeBody / SleepBody commands (user-driven; sleeping.rs:283-352, 438-452) */
+AVN_API avn_status AVN_FN(islands_wake_body)(avn_island_manager* m, uint32_t body);
+AVN_API avn_status AVN_FN(islands_sleep_body)(avn_island_manager* m, uint32_t body);
+/* what the last flush_wake / sleeping_systems / wake_body / sleep_body did, in the reference's order: contact ids whose manifolds were
+ * popped (SleepIslands) and pushed (WakeIslands), contact ids moved to the sleeping / the active pair set, bodies put to sleep / woken.
+ * Pointers stay valid until the next call on the manager. */
+typedef struct avn_islands_result {
+    const uint32_t* popped;  size_t n_popped;
+    const uint32_t* pushed;  size_t n_pushed;
+    const uint32_t* pairs_slept; size_t n_pairs_slept;    /* ContactEdgeFlags::SLEEPING set (every touching pair, constraint-generating or not) */
+    const uint32_t* pairs_woken; size_t n_pairs_woken;
+    const uint32_t* bodies_slept; size_t n_bodies_slept;
+    const uint32_t* bodies_woken; size_t n_bodies_woken;  /* their SleepTimer is reset to 0 */
+} avn_islands_result;
+AVN_API avn_status AVN_FN(islands_last_result)(avn_island_manager* m, avn_islands_result* out);
+typedef struct avn_islands_stats {
+    uint32_t n_islands, n_sleeping_islands, n_bodies, n_sleeping_bodies;
+    uint32_t merges, splits;           /* totals since creation */
+    uint32_t split_candidate;          /* IslandId or 0xFFFFFFFF */
+    uint32_t sleeping_pairs;           /* edges with ContactEdgeFlags::SLEEPING */
+} avn_islands_stats;
+AVN_API avn_status AVN_FN(islands_stats_get)(avn_island_manager* m, avn_islands_stats* out);
+/* per body [n_bodies]: IslandId (slab key; 0xFFFFFFFF = no node), the NEXT body of the island's list (0xFFFFFFFF = tail), 1 = the body's
+ * island sleeps, constraints_removed of the body's island.  Any pointer may be NULL. */
+AVN_API avn_status AVN_FN(islands_state)(avn_island_manager* m, uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping,
+                                         uint32_t* constraints_removed_of_body_island);
+
+/* (2) the closed loop with persistent islands and sleeping.  `p` as for avn_sleep_update (thresholds, time_to_sleep, delta_secs, optional
+ * per-body arrays -- copied); p = NULL switches it off (every island is woken first).  Needs avn_pipeline_enable; islands start as one per
+ * body that owns a SolverBody, merged by the uploaded joints in upload order.  From then on avn_step keeps N = the awake bodies. */
+AVN_API avn_status AVN_FN(sleeping_enable)(avn_world* w, const avn_sleep_params* p);
+typedef struct avn_sleeping_stats {
+    avn_islands_stats islands;
+    uint32_t n_awake_bodies;           /* bodies that owned a SolverBody in the step just taken */
+    uint32_t last_islands_slept, last_islands_woken, last_manifolds_popped, last_manifolds_pushed;
+    double last_host_ms;               /* host time of the island bookkeeping of the last step */
+} avn_sleeping_stats;
+AVN_API avn_status AVN_FN(sleeping_stats_get)(avn_world* w, avn_sleeping_stats* out);
+typedef struct avn_sleeping_out {
+    uint32_t* island;          /* [n_bodies] IslandId, 0xFFFFFFFF = no node */
+    uint32_t* next_in_island;  /* [n_bodies] */
+    uint8_t* sleeping;         /* [n_bodies] 1 = the body has the Sleeping component */
+    float* sleep_timer;        /* [n_bodies] */
+} avn_sleeping_out;
+AVN_API avn_status AVN_FN(sleeping_state_get)(avn_world* w, const avn_sleeping_out* out);
+/* WakeBody for the listed bodies (a host that moved or kicked a sleeping body: wake_on_changed, sleeping.rs:556-604) */
+AVN_API avn_status AVN_FN(wake_bodies)(avn_world* w, const uint32_t* bodies, size_t n);
+
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as
  * doubles: the per-rank bound exchanged between ranks to detect islands of different ranks coming into AABB contact.
  * Empty worlds return min = +inf, max = -inf. */

@@ -2,6 +2,7 @@
 // (include/avian_mi355x.h) under the `avo_` prefix so tests drive both with identical calls.
 #define AVN_PREFIX_ORACLE 1
 #include "avo_world.hpp"
+#include "avo_islands.hpp"
 
 #include <cmath>
 #include <new>
@@ -9,6 +10,7 @@
 
 struct avn_world { avo::WorldBase* impl; };
 struct avn_constraint_graph { avo::ConstraintGraph g; };
+struct avn_island_manager { avo::IslandManager m; };
 static thread_local std::string g_create_error;
 
 extern "C" {
@@ -282,6 +284,32 @@ avn_status avo_islands_partition(const avn_islands_in* in, int32_t* island_of_bo
     return AVN_OK;
 }
 uint64_t avo_pair_key(uint32_t a, uint32_t b) { return avo::pair_key(a, b); }
+
+// ---- avn_islands_* (header): the linked-list restatement of avo_islands.hpp ----
+avn_island_manager* avo_islands_create(void) { return new (std::nothrow) avn_island_manager(); }
+void avo_islands_destroy(avn_island_manager* m) { delete m; }
+avn_status avo_islands_body_add(avn_island_manager* m, uint32_t body) { return m ? m->m.body_add(body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_collider_add(avn_island_manager* m, uint32_t collider, uint32_t body) { return m ? m->m.collider_add(collider, body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_joint_add(avn_island_manager* m, uint32_t joint, uint32_t b1, uint32_t b2) { return m ? m->m.joint_add(joint, b1, b2) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_pair_add(avn_island_manager* m, uint32_t id, uint32_t c1, uint32_t c2) { return m ? m->m.pair_add(id, c1, c2) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t mc) { return m ? m->m.status_change(id, flags, mc) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_flush_wake(avn_island_manager* m) { return m ? m->m.flush_wake() : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_split_candidate(avn_island_manager* m) { return m ? m->m.split_candidate_now() : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { return m ? m->m.sleeping_systems(t, f, n, tts) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_wake_body(avn_island_manager* m, uint32_t body) { return m ? m->m.wake_body(body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_sleep_body(avn_island_manager* m, uint32_t body) { return m ? m->m.sleep_body(body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_last_result(avn_island_manager* m, avn_islands_result* o) {
+    if (!m || !o) return AVN_ERR_BAD_ARG;
+    avo::IslandManager& g = m->m;
+    o->popped = g.popped.data(); o->n_popped = g.popped.size(); o->pushed = g.pushed.data(); o->n_pushed = g.pushed.size();
+    o->pairs_slept = g.pairs_slept.data(); o->n_pairs_slept = g.pairs_slept.size(); o->pairs_woken = g.pairs_woken.data(); o->n_pairs_woken = g.pairs_woken.size();
+    o->bodies_slept = g.bodies_slept.data(); o->n_bodies_slept = g.bodies_slept.size(); o->bodies_woken = g.bodies_woken.data(); o->n_bodies_woken = g.bodies_woken.size();
+    return AVN_OK;
+}
+avn_status avo_islands_stats_get(avn_island_manager* m, avn_islands_stats* o) { return m ? m->m.stats(o) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_state(avn_island_manager* m, uint32_t n, uint32_t* a, uint32_t* b, uint8_t* c, uint32_t* d) { return m ? m->m.state(n, a, b, c, d) : AVN_ERR_BAD_ARG; }
+// debug aid of the oracle only (not in the header): PhysicsIsland::validate over every island; 1 = consistent
+int avo_islands_validate(avn_island_manager* m) { std::string why; return m && m->m.validate(why) ? 1 : 0; }
 
 avn_status avo_constraint_graph_create(uint32_t, avn_constraint_graph** out) {
     if (!out) return AVN_ERR_BAD_ARG;

@@ -23,7 +23,7 @@ def oracle_lib() -> F.Library:
     """The CPU oracle (test infrastructure).  Built on demand with its own Makefile (g++, seconds)."""
     global _oracle
     if _oracle is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "avo_world.hpp", "avo_math.hpp", "avo_narrow.hpp", "avo_parallel.hpp")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle_capi.cpp", "avo_world.hpp", "avo_islands.hpp", "avo_math.hpp", "avo_narrow.hpp", "avo_parallel.hpp")]
         stale = not os.path.exists(ORACLE_SO) or any(os.path.getmtime(s) > os.path.getmtime(ORACLE_SO) for s in srcs)
         if stale:
             subprocess.run(["make", "-C", ORACLE_DIR], check=True, capture_output=True)

@@ -1,0 +1,169 @@
+"""CPU: the persistent-island manager behind the ABI (avn_islands_*: host C++ in the product library, avian_amd/csrc/avn_islands.cpp --
+flat vectors) against the oracle's restatement with the reference's own structures (oracle/avo_islands.hpp -- intrusive linked lists, a
+slab, petgraph edge lists; islands/mod.rs:404-1280, islands/sleeping.rs:164-540, contact_graph.rs:705-838).  Both are driven by the SAME
+random streams of pair / status / sleeping events; after every command island ids (slab keys), the order of every island's body list,
+sleeping flags, constraints_removed, the split candidate and the pop / push / sleep / wake sequences must be equal."""
+import numpy as np
+import pytest
+
+from helpers import F, hip_lib, oracle_lib
+
+NONE = 0xFFFFFFFF
+
+
+def managers():
+    return F.IslandManager(oracle_lib()), F.IslandManager(hip_lib())
+
+
+def same(mo, mh, n_bodies, what):
+    so, sh = mo.state(n_bodies), mh.state(n_bodies)
+    for k in so:
+        assert np.array_equal(so[k], sh[k]), f"{what}: {k} differs\noracle {so[k]}\nproduct {sh[k]}"
+    to, th = mo.stats(), mh.stats()
+    for f, _ in to._fields_:
+        assert getattr(to, f) == getattr(th, f), f"{what}: stats.{f}: oracle {getattr(to, f)} product {getattr(th, f)}"
+    v = mo.lib.fn("islands_validate"); v.argtypes = [F.vp]; v.restype = F.C.c_int   # (oracle only: PhysicsIsland::validate, islands/mod.rs:255-400)
+    assert v(mo.handle) == 1, f"{what}: the oracle's linked lists are inconsistent"
+
+
+def same_result(ro, rh, what):
+    for k in ro:
+        assert np.array_equal(ro[k], rh[k]), f"{what}: {k} differs\noracle {ro[k]}\nproduct {rh[k]}"
+
+
+def build(n_bodies, n_static, rng, colliders_per_body=1):
+    ms = managers()
+    for m in ms:
+        ent = 100
+        for b in range(n_bodies):
+            static = b < n_static
+            if not static:
+                m.body_add(b)
+            for _ in range(colliders_per_body if not static else 1):
+                m.collider_add(ent, None if static else b); ent += 1
+    col_body = {}
+    ent = 100
+    for b in range(n_bodies):
+        for _ in range(colliders_per_body if b >= n_static else 1):
+            col_body[ent] = b; ent += 1
+    return ms, col_body
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_event_streams_keep_both_managers_identical(seed):
+    rng = np.random.default_rng(seed)
+    n_bodies, n_static = 40, 3
+    (mo, mh), col_body = build(n_bodies, n_static, rng, colliders_per_body=1 + seed % 2)
+    cols = sorted(col_body)
+    # a few joints first (spawn order)
+    for j in range(5):
+        a, b = rng.choice(np.arange(n_static, n_bodies), 2, replace=False)
+        for m in (mo, mh):
+            m.joint_add(j, int(a), int(b))
+    same(mo, mh, n_bodies, "after joints")
+    live = {}      # cid -> dict(c1, c2, touching, generates)
+    free = []
+    next_id = 0
+    timers = np.zeros(n_bodies, np.float32)
+    for step in range(120):
+        # --- broad phase: new pairs (lowest free id first) ---
+        for _ in range(rng.integers(0, 6)):
+            c1, c2 = rng.choice(cols, 2, replace=False)
+            b1, b2 = col_body[c1], col_body[c2]
+            if b1 == b2 or (b1 < n_static and b2 < n_static) or any({p["c1"], p["c2"]} == {c1, c2} for p in live.values()):
+                continue
+            if free:
+                free.sort(); cid = free.pop(0)
+            else:
+                cid = next_id; next_id += 1
+            live[cid] = dict(c1=int(c1), c2=int(c2), touching=False, sleeping_body=False)
+            for m in (mo, mh):
+                m.pair_add(cid, int(c1), int(c2))
+        # --- narrow phase status loop, ascending id; sleeping pairs are not updated ---
+        asleep = mo.state(n_bodies)
+        body_sleeps = lambda b: b >= n_static and bool(asleep["sleeping"][b])   # (island sleeping == its bodies have Sleeping here)
+        for cid in sorted(live):
+            p = live[cid]
+            b1, b2 = col_body[p["c1"]], col_body[p["c2"]]
+            if p.get("pair_sleeping"):
+                continue
+            r = rng.random()
+            gen = F.CP_GENERATE_CONSTRAINTS
+            if not p["touching"] and r < 0.30:
+                p["touching"] = True
+                for m in (mo, mh): m.status_change(cid, F.CP_STARTED_TOUCHING | F.CP_TOUCHING | gen, 1)
+            elif p["touching"] and r < 0.12:
+                p["touching"] = False
+                for m in (mo, mh): m.status_change(cid, F.CP_STOPPED_TOUCHING | gen, 0)
+            elif not p["touching"] and r > 0.93:
+                for m in (mo, mh): m.status_change(cid, F.CP_DISJOINT_AABB | gen, 0)
+                del live[cid]; free.append(cid)
+        ro, rh = mo.flush_wake(), mh.flush_wake()
+        same_result(ro, rh, f"step {step}: WakeIslands after the status loop")
+        for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
+        same(mo, mh, n_bodies, f"step {step}: after the status loop")
+        # --- Finalize: split_island(candidate) ---
+        for m in (mo, mh): m.split_candidate()
+        same(mo, mh, n_bodies, f"step {step}: after split_island")
+        # --- Sleeping set ---
+        st = mo.state(n_bodies)
+        flags = np.zeros(n_bodies, np.uint8)
+        for b in range(n_static, n_bodies):
+            if st["sleeping"][b]:
+                continue   # Sleeping bodies are outside the query
+            flags[b] = 1
+            if rng.random() < 0.25: timers[b] = 0.0
+            else: timers[b] += np.float32(1 / 60)
+        if step % 17 == 5: flags[n_static + 1] = 2       # a SleepingDisabled body for one step
+        ro, rh = mo.sleeping_systems(timers, flags, 0.2), mh.sleeping_systems(timers, flags, 0.2)
+        same_result(ro, rh, f"step {step}: SleepIslands / WakeIslands")
+        for c in ro["pairs_slept"]: live[int(c)]["pair_sleeping"] = True
+        for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
+        for b in ro["bodies_woken"]: timers[int(b)] = 0.0
+        same(mo, mh, n_bodies, f"step {step}: after the sleeping systems")
+        if step % 29 == 11:
+            b = int(rng.integers(n_static, n_bodies))
+            ro, rh = mo.wake_body(b), mh.wake_body(b)
+            same_result(ro, rh, f"step {step}: WakeBody")
+            for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
+            for x in ro["bodies_woken"]: timers[int(x)] = 0.0
+        if step % 31 == 7:
+            b = int(rng.integers(n_static, n_bodies))
+            if not mo.state(n_bodies)["sleeping"][b]:
+                ro, rh = mo.sleep_body(b), mh.sleep_body(b)
+                same_result(ro, rh, f"step {step}: SleepBody")
+                for c in ro["pairs_slept"]: live[int(c)]["pair_sleeping"] = True
+            same(mo, mh, n_bodies, f"step {step}: after SleepBody")
+    s = mh.stats()
+    assert s.merges > 5 and s.splits > 0, "the stream must exercise merges and splits"
+
+
+def test_merge_appends_the_smaller_island_and_reuses_the_last_freed_key():
+    """merge_islands (islands/mod.rs:814-990): ties keep body1's island; the smaller island's bodies go to the END of the bigger one's list;
+    its slab key is the next one handed out (split_island creates new islands from it)."""
+    for lib in (oracle_lib(), hip_lib()):
+        m = F.IslandManager(lib)
+        for b in range(6):
+            m.body_add(b); m.collider_add(10 + b, b)
+        m.pair_add(0, 10, 11); m.pair_add(1, 12, 13); m.pair_add(2, 11, 12); m.pair_add(3, 14, 15)
+        T = F.CP_STARTED_TOUCHING | F.CP_TOUCHING | F.CP_GENERATE_CONSTRAINTS
+        m.status_change(0, T)     # islands 0,1 -> 0 (tie: body 0's island stays), list 0,1
+        m.status_change(1, T)     # 2,3 -> 2, list 2,3
+        m.status_change(2, T)     # body1 = 1 (island 0, 2 bodies), body2 = 2 (island 2, 2 bodies): tie -> island 0 stays: 0,1,2,3
+        st = m.state(6)
+        assert st["island"].tolist() == [0, 0, 0, 0, 4, 5] and st["next"][:4].tolist() == [1, 2, 3, NONE]
+        # stop touching 2: constraints_removed = 1; every body wants to sleep -> candidate = island 0; split -> {0,1} keeps key 0 (freed last),
+        # {2,3} takes key 2 (freed before: merges freed 1, 3, 2 in that order -> stack [1, 3, 2], then 0 on top)
+        m.status_change(2, F.CP_STOPPED_TOUCHING | F.CP_GENERATE_CONSTRAINTS, 0)
+        timers = np.full(6, 1.0, np.float32); flags = np.ones(6, np.uint8)
+        r = m.sleeping_systems(timers, flags, 0.5)
+        assert len(r["bodies_slept"]) == 2, "islands 4 and 5 (one body each, nothing removed) fall asleep at once; island 0 has a pending split"
+        assert m.stats().split_candidate == 0
+        m.split_candidate()
+        st = m.state(6)
+        assert st["island"].tolist() == [0, 0, 2, 2, 4, 5], st["island"]
+        r = m.sleeping_systems(timers, flags, 0.5)
+        assert sorted(r["bodies_slept"].tolist()) == [0, 1, 2, 3] and r["popped"].tolist() == [0, 1]
+        # waking pushes back in body-list x edge-list order
+        r = m.wake_body(3)
+        assert r["pushed"].tolist() == [1] and r["bodies_woken"].tolist() == [2, 3]
