@@ -212,6 +212,18 @@ class avn_sleep_stats(C.Structure):
                 ("n_resting_islands", C.c_uint32), ("n_resting_bodies", C.c_uint32), ("n_waking_islands", C.c_uint32), ("n_waking_bodies", C.c_uint32)]
 
 
+class avn_islands_stats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_islands", "n_sleeping_islands", "n_bodies", "n_sleeping_bodies", "merges", "splits", "split_candidate", "sleeping_pairs")]
+
+
+class avn_sleeping_stats(C.Structure):
+    _fields_ = [("islands", avn_islands_stats)] + [(n, C.c_uint32) for n in ("n_awake_bodies", "last_islands_slept", "last_islands_woken", "last_manifolds_popped", "last_manifolds_pushed")] + [("last_host_ms", C.c_double)]
+
+
+class avn_sleeping_out(C.Structure):
+    _fields_ = [("island", vp), ("next_in_island", vp), ("sleeping", vp), ("sleep_timer", vp)]
+
+
 class avn_sleep_out(C.Structure):
     _fields_ = [("sleep_timer", vp), ("island", vp), ("island_rests", vp), ("island_wakes", vp)]
 
@@ -238,6 +250,9 @@ ABI_SYMBOLS = [
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
     "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
+    "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
+    "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
+    "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies",
 ]
 
 
@@ -279,6 +294,10 @@ class Library:
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
         f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
         f("sleep_reset").argtypes = [vp, vp, C.c_size_t]
+        f("sleeping_enable").argtypes = [vp, C.POINTER(avn_sleep_params)]
+        f("sleeping_stats_get").argtypes = [vp, C.POINTER(avn_sleeping_stats)]
+        f("sleeping_state_get").argtypes = [vp, C.POINTER(avn_sleeping_out)]
+        f("wake_bodies").argtypes = [vp, vp, C.c_size_t]
         f("comm_unique_id").argtypes = [vp]
         f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
         f("profile_system").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
@@ -814,6 +833,36 @@ class World:
             b = np.ascontiguousarray(bodies, np.uint32)
             self._check(self.lib.fn("sleep_reset")(self.handle, _ptr(b), len(b)))
 
+    # -- persistent islands + sleeping ACTUATION in the closed loop (islands/mod.rs, islands/sleeping.rs) --------------------------------
+    def sleeping_enable(self, on: bool = True, delta_secs: float = 1.0 / 60.0, time_to_sleep: float = 0.5, linear_threshold: float = 0.15, angular_threshold: float = 0.15,
+                        length_unit: float = 1.0, body_linear_threshold=None, body_angular_threshold=None, body_sleeping_disabled=None):
+        """``avn_sleeping_enable``: avn_step keeps persistent islands, puts resting ones to sleep and wakes them (needs pipeline_enable)."""
+        if not on:
+            self._check(self.lib.fn("sleeping_enable")(self.handle, None)); return
+        bl = None if body_linear_threshold is None else np.ascontiguousarray(body_linear_threshold, np.float32)
+        ba = None if body_angular_threshold is None else np.ascontiguousarray(body_angular_threshold, np.float32)
+        bd = None if body_sleeping_disabled is None else np.ascontiguousarray(body_sleeping_disabled, np.uint8)
+        for a in (bl, ba, bd):
+            assert a is None or len(a) == self.n_bodies
+        p = avn_sleep_params(C.sizeof(avn_sleep_params), time_to_sleep, linear_threshold, angular_threshold, delta_secs, length_unit, _ptr(bl), _ptr(ba), _ptr(bd))
+        self._check(self.lib.fn("sleeping_enable")(self.handle, C.byref(p)))
+
+    def sleeping_stats(self) -> "avn_sleeping_stats":
+        st = avn_sleeping_stats()
+        self._check(self.lib.fn("sleeping_stats_get")(self.handle, C.byref(st)))
+        return st
+
+    def sleeping_state(self):
+        n = self.n_bodies
+        out = dict(island=np.zeros(n, np.uint32), next_in_island=np.zeros(n, np.uint32), sleeping=np.zeros(n, np.uint8), sleep_timer=np.zeros(n, np.float32))
+        o = avn_sleeping_out(_ptr(out["island"]), _ptr(out["next_in_island"]), _ptr(out["sleeping"]), _ptr(out["sleep_timer"]))
+        self._check(self.lib.fn("sleeping_state_get")(self.handle, C.byref(o)))
+        return out
+
+    def wake_bodies(self, bodies):
+        b = np.ascontiguousarray(bodies, np.uint32)
+        self._check(self.lib.fn("wake_bodies")(self.handle, _ptr(b), len(b)))
+
     def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.fn("comm_init")(self.handle, buf, int(n_ranks), int(rank)))
@@ -873,10 +922,6 @@ class ConstraintGraph:
 
 class avn_islands_result(C.Structure):
     _fields_ = [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
-
-
-class avn_islands_stats(C.Structure):
-    _fields_ = [(n, C.c_uint32) for n in ("n_islands", "n_sleeping_islands", "n_bodies", "n_sleeping_bodies", "merges", "splits", "split_candidate", "sleeping_pairs")]
 
 
 class IslandManager:

@@ -143,6 +143,10 @@ AVN_API avn_status avn_islands_get(avn_world* w, uint32_t* island_of_body, uint3
 AVN_API avn_status avn_sleep_update(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* st) { GUARD(sleep_update(p, st)); }
 AVN_API avn_status avn_sleep_get(avn_world* w, const avn_sleep_out* o) { GUARD(sleep_get(o)); }
 AVN_API avn_status avn_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(sleep_reset(bodies, n)); }
+AVN_API avn_status avn_sleeping_enable(avn_world* w, const avn_sleep_params* p) { GUARD(sleeping_enable(p)); }
+AVN_API avn_status avn_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { GUARD(sleeping_stats_get(o)); }
+AVN_API avn_status avn_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { GUARD(sleeping_state_get(o)); }
+AVN_API avn_status avn_wake_bodies(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(wake_bodies(bodies, n)); }
 AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
     try { return avn::comm_unique_id(out, g_create_error); }
     catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }

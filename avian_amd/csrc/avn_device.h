@@ -19,6 +19,7 @@ AVN_HD uint32_t meta_rb_type(uint32_t m) { return m & 3u; }
 AVN_HD uint32_t meta_locked(uint32_t m) { return (m >> 8) & 0x3Fu; }
 AVN_HD uint32_t meta_flags(uint32_t m) { return (m >> 16) & 0xFFu; }
 AVN_HD int meta_dominance(uint32_t m) { return (int)(int8_t)(m >> 24); }
+AVN_HD uint32_t meta_with_flags(uint32_t m, uint32_t flags) { return (m & ~(0xFFu << 16)) | ((flags & 0xFFu) << 16); }
 AVN_HD bool meta_active(uint32_t m) { return (meta_flags(m) & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED)) == 0; }
 AVN_HD bool meta_has_solver_body(uint32_t m) { return meta_rb_type(m) != AVN_RB_STATIC && meta_active(m); }
 

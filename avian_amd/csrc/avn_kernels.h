@@ -156,6 +156,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 // that a step of the closed loop moves only a few counters over the bus.
 #define PG_NONE 0xFFFFFFFFu
 #define AVN_CP_ROW_USED 0x40000000u   // internal row flag (never reported through the ABI): the ContactId is live
+#define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
        PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
@@ -188,10 +189,18 @@ struct PG {
     uint32_t* tile_agg;     // [5 tiles] segmented-scan tile aggregates
     uint32_t* ckey_a, *cval_a, *ckey_b, *cval_b;   // [ops] (colour, op): bucketed by colour, stable
     uint32_t* rem_flag, *rem_off, *rem_ids;        // [ops]
+    uint32_t* op_chg;       // [ops] the row's packed status change (PG::chg) next to op_cid: what the host-side island manager reads (sleeping enabled)
+    uint32_t* new_ids;      // [new pairs of the step] the ContactId k_pg_add_pairs gave the i-th new pair (NULL: not recorded)
 };
 #define PG_EST_DONE 0x80000000u
 template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, hipStream_t);
 void launch_pg_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, hipStream_t);
+// an op batch from a LIST instead of from the rows' status changes (SleepIslands / WakeIslands: pops and pushes in the island manager's order):
+// fills the same op arrays as k_pg_classify for ops (cids[k], kinds[k] = 1 push | 2 pop); the rest of the pipeline is the status loop's
+template <class T> void launch_pg_ops_from_list(const PG&, const CT<T>&, const uint32_t* cids, const uint32_t* kinds, uint32_t n, uint32_t n_bodies, hipStream_t);
+// SLEEPING bit of contact rows, Sleeping flag of bodies (+ SleepTimer = 0 for woken bodies)
+template <class T> void launch_rows_set_sleeping(const CT<T>&, const uint32_t* cids, uint32_t n, uint32_t sleeping, hipStream_t);
+template <class T> void launch_bodies_set_sleeping(const DW<T>&, const uint32_t* bodies, uint32_t n, uint32_t sleeping, float* timer, hipStream_t);
 uint32_t pg_scan_tiles(uint32_t n_entries);
 void launch_pg_entry_scan(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
 void launch_pg_color(const PG&, uint32_t n_ops, hipStream_t);
@@ -237,6 +246,8 @@ template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t*
                                        uint32_t solver_nodes = 0u /* 1: only bodies with a SolverBody connect (island-block builder) */);
 template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,
                                             uint32_t* ctr /* [2] resting islands, [3] resting bodies, [4] waking islands, [5] their sleeping bodies, [6] sleeping bodies */, hipStream_t);
+// update_sleeping_states, body half, for the closed loop with persistent islands: timer[b] updated, flags[b] = 1 took part | 2 SleepingDisabled | 4 owns a SolverBody
+template <class T> void launch_sleep_timers_flags(const DW<T>&, const SleepParams<T>&, float* timer, uint8_t* flags, hipStream_t);
 void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32_t n_bodies, hipStream_t);
 // level-2 sharding: (SolverBody linear | angular velocity records) of a list of bodies <-> a contiguous buffer of 2 records per body
 template <class T> void launch_halo_pack(const DW<T>&, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t);

@@ -1,5 +1,6 @@
 // avn_world.hip — host orchestration of the MI355X physics step (see avn_world.hpp).
 #include "avn_world.hpp"
+#include "avn_islands.hpp"
 
 #include <algorithm>
 #include <array>
@@ -192,6 +193,7 @@ template <class T> struct World : WorldBase {
     DevBuf b_pg_bodies, b_pg_color, b_pg_lpos, b_pg_lists, b_pg_bcol, b_pg_free_a, b_pg_free_b, b_pg_ctr, b_pg_ent2slot;
     DevBuf b_pg_chg, b_pg_has, b_pg_off, b_pg_op_cid, b_pg_op_info, b_pg_op_bodies, b_pg_ekey_a, b_pg_eval_a, b_pg_ekey_b, b_pg_eval_b, b_pg_epos, b_pg_popbefore, b_pg_prevpush,
         b_pg_est, b_pg_tile_agg, b_pg_ckey_a, b_pg_cval_a, b_pg_ckey_b, b_pg_cval_b, b_pg_rem_flag, b_pg_rem_off, b_pg_rem_ids, b_pg_hist, b_pg_sums;
+    DevBuf b_pg_op_chg, b_pg_new_ids;
     DevBuf b_ovf_keys_a, b_ovf_vals_a, b_ovf_keys_b, b_ovf_vals_b, b_ovf_rank, b_ovf_ticket;
     uint32_t pg_rows = 0, pg_ops_cap = 0, pg_ovf_cap = 0;
     uint32_t pgm_head = 0, pgm_n_free = 0, pgm_next_id = 0, pgm_live = 0, pgm_tomb = 0;   // exact host mirrors of the device counters
@@ -411,6 +413,7 @@ template <class T> struct World : WorldBase {
 #include "world/systems.hpp"
 #include "world/level2.hpp"
 #include "world/islands.hpp"
+#include "world/sleeping.hpp"
 #include "world/timers.hpp"
 };
 

@@ -99,6 +99,10 @@ struct WorldBase {
     virtual avn_status sleep_update(const avn_sleep_params*, avn_sleep_stats*) = 0;
     virtual avn_status sleep_get(const avn_sleep_out*) = 0;
     virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
+    virtual avn_status sleeping_enable(const avn_sleep_params*) = 0;
+    virtual avn_status sleeping_stats_get(avn_sleeping_stats*) = 0;
+    virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
+    virtual avn_status wake_bodies(const uint32_t*, size_t) = 0;
 };
 
 // RCCL transport of the level-2 halo exchange (avn_comm.cpp; librccl is opened on first use)

@@ -77,6 +77,7 @@ __global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn
     ct.dcount[id] = 0;
     pg.bodies[id] = make_int2(pr.body1, pr.body2);
     pg.color[id] = PG_NONE;
+    if (pg.new_ids) pg.new_ids[i] = id;
 }
 __global__ void k_pg_after_add(PG pg, uint32_t total) {
     const uint32_t n_free = pg.ctr[PGC_N_FREE];
@@ -117,6 +118,7 @@ __global__ __launch_bounds__(256) void k_pg_classify(PG pg, uint32_t n_rows, uin
         const int2 b = pg.bodies[c];
         const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
         pg.op_cid[k] = c;
+        pg.op_chg[k] = w;
         pg.op_info[k] = kind | (s1 ? 4u : 0u) | (s2 ? 8u : 0u) | (remove << 4) | (opcol << 8);
         pg.op_bodies[k] = b;
         pg.rem_flag[k] = remove;
@@ -133,6 +135,47 @@ __global__ __launch_bounds__(256) void k_pg_classify(PG pg, uint32_t n_rows, uin
 void launch_pg_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, hipStream_t s) {
     if (n_rows) hipLaunchKernelGGL(k_pg_classify, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, n_rows, n_bodies);
 }
+
+// An op batch from a list (SleepIslands / WakeIslands of the island manager): the arrays k_pg_classify fills, for ops given as
+// (contact id, kind).  A pop of a row without a handle and a push of a row that has one are no-ops, like pop_manifold / push_manifold
+// on the host structures.
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_ops_from_list(PG pg, CT<T> ct, const uint32_t* __restrict__ cids, const uint32_t* __restrict__ kinds, uint32_t n, uint32_t n_bodies) {
+    __shared__ uint32_t hist[AVN_GRAPH_COLOR_COUNT];
+    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k < n) {
+        const uint32_t c = cids[k];
+        const uint32_t flags = ct.meta[c].z;
+        const uint32_t col = pg.color[c];
+        const bool has_handle = col != PG_NONE;
+        uint32_t kind = kinds[k];
+        if (kind == PG_KIND_POP && !has_handle) kind = PG_KIND_NONE;
+        if (kind == PG_KIND_PUSH && has_handle) kind = PG_KIND_NONE;
+        const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
+        if (kind == PG_KIND_PUSH && s1 && s2) kind = PG_KIND_NONE;
+        const int2 b = pg.bodies[c];
+        const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
+        pg.op_cid[k] = c;
+        pg.op_chg[k] = 0u;
+        pg.op_info[k] = kind | (s1 ? 4u : 0u) | (s2 ? 8u : 0u) | (opcol << 8);
+        pg.op_bodies[k] = b;
+        pg.rem_flag[k] = 0u;
+        const bool masks = kind == PG_KIND_PUSH || (kind == PG_KIND_POP && col < (uint32_t)AVN_COLOR_OVERFLOW_INDEX);
+        pg.ekey_a[2 * k] = (masks && !s1) ? (uint32_t)b.x : n_bodies;
+        pg.ekey_a[2 * k + 1] = (masks && !s2) ? (uint32_t)b.y : n_bodies;
+        pg.eval_a[2 * k] = 2 * k; pg.eval_a[2 * k + 1] = 2 * k + 1;
+        if (kind == PG_KIND_POP) atomicAdd(&hist[col], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT && hist[threadIdx.x]) { atomicAdd(&pg.ctr[PGC_BUCKET + threadIdx.x], hist[threadIdx.x]); atomicAdd(&pg.ctr[PGC_N_POP], hist[threadIdx.x]); }
+}
+template <class T> void launch_pg_ops_from_list(const PG& pg, const CT<T>& ct, const uint32_t* cids, const uint32_t* kinds, uint32_t n, uint32_t n_bodies, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pg_ops_from_list<T>, dim3((n + 255) / 256), dim3(256), 0, s, pg, ct, cids, kinds, n, n_bodies);
+}
+template void launch_pg_ops_from_list<float>(const PG&, const CT<float>&, const uint32_t*, const uint32_t*, uint32_t, uint32_t, hipStream_t);
+template void launch_pg_ops_from_list<double>(const PG&, const CT<double>&, const uint32_t*, const uint32_t*, uint32_t, uint32_t, hipStream_t);
 
 // ---- segmented scan over the body-sorted entries: colours freed by earlier pops, previous push entry ----------------------------
 #define PGS_TILE 256

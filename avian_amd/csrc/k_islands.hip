@@ -128,6 +128,43 @@ __global__ __launch_bounds__(256) void k_sleep_decide(DW<T> w, const uint32_t* _
         if (sb) atomicAdd(ctr + 6, (uint32_t)__popcll(sb));
     }
 }
+// The closed loop with persistent islands (world/sleeping.hpp): the body half of update_sleeping_states (sleeping.rs:200-223) plus the timer
+// reset of wake_islands_with_sleeping_disabled (:164-182); the island half runs in the host's island manager, which reads `flags`.
+template <class T>
+__global__ __launch_bounds__(256) void k_sleep_timers_flags(DW<T> w, SleepParams<T> sp, float* __restrict__ timer, uint8_t* __restrict__ flags) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= w.n_bodies) return;
+    const uint32_t bm = w.bmeta[b];
+    if (!island_node(bm, 0u)) { flags[b] = 0; return; }
+    const bool has_sb = !(meta_flags(bm) & AVN_BODY_SLEEPING);   // a body with a node owns a SolverBody unless it sleeps
+    if (sp.body_disabled && sp.body_disabled[b]) { flags[b] = (uint8_t)(2u | (has_sb ? 4u : 0u)); timer[b] = 0.0f; return; }
+    if (!has_sb) { flags[b] = 0; return; }
+    const V3<T> v = xyz<T>(w.sb_lin[b]), om = xyz<T>(w.sb_ang[b]);
+    const T v2 = length_squared(v), w2 = length_squared(om);
+    T lin2 = sp.lin_threshold_squared, ang2 = sp.ang_threshold_squared;
+    if (sp.body_lin) { const float l = sp.body_lin[b]; lin2 = (T)(l * fabsf(l)); }
+    if (sp.body_ang) { const float a = sp.body_ang[b]; ang2 = (T)(a * fabsf(a)); }
+    float t = timer[b];
+    if (v2 < sp.length_unit_squared * lin2 && w2 < ang2) t = t + sp.delta_secs;
+    else t = 0.0f;
+    timer[b] = t;
+    flags[b] = 5;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_bodies_set_sleeping(DW<T> w, const uint32_t* __restrict__ bodies, uint32_t n, uint32_t sleeping, float* __restrict__ timer) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bodies[i];
+    if (b >= w.n_bodies) return;
+    w.bmeta[b] = meta_with_flags(w.bmeta[b], sleeping ? (meta_flags(w.bmeta[b]) | AVN_BODY_SLEEPING) : (meta_flags(w.bmeta[b]) & ~(uint32_t)AVN_BODY_SLEEPING));
+    if (!sleeping && timer) timer[b] = 0.0f;   // WakeIslands: sleep_timer.0 = 0.0 (sleeping.rs:492)
+}
+template <class T> void launch_sleep_timers_flags(const DW<T>& w, const SleepParams<T>& sp, float* timer, uint8_t* flags, hipStream_t s) {
+    if (w.n_bodies) hipLaunchKernelGGL(k_sleep_timers_flags<T>, dim3((w.n_bodies + 255) / 256), dim3(256), 0, s, w, sp, timer, flags);
+}
+template <class T> void launch_bodies_set_sleeping(const DW<T>& w, const uint32_t* bodies, uint32_t n, uint32_t sleeping, float* timer, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_bodies_set_sleeping<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, sleeping, timer);
+}
 __global__ __launch_bounds__(256) void k_sleep_reset(float* __restrict__ timer, const uint32_t* __restrict__ bodies, uint32_t n, uint32_t n_bodies) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -154,6 +191,8 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
 }
 
 #define INST(T)                                                                                              \
+    template void launch_sleep_timers_flags<T>(const DW<T>&, const SleepParams<T>&, float*, uint8_t*, hipStream_t);   \
+    template void launch_bodies_set_sleeping<T>(const DW<T>&, const uint32_t*, uint32_t, uint32_t, float*, hipStream_t); \
     template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t, uint32_t);            \
     template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint8_t*, uint32_t*, hipStream_t);
 INST(float)

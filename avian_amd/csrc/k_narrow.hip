@@ -95,7 +95,8 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
                                avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
                                uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col) {
     uint4 meta = ct.meta[c];
-    if (DENSE && !(meta.z & AVN_CP_ROW_USED)) { chg[c] = 0u; has[c] = 0u; return; }
+    // (a free id; or a pair of ContactGraph::sleeping_pairs: update_contacts walks the ACTIVE pairs only, system_param.rs:437-475)
+    if (DENSE && (!(meta.z & AVN_CP_ROW_USED) || (meta.z & AVN_CP_ROW_SLEEPING))) { chg[c] = 0u; has[c] = 0u; return; }
     const uint32_t slot1 = meta.x, slot2 = meta.y;
     uint32_t flags = meta.z;
     const uint32_t old_nman = meta.w & 0xFFu, old_pc = (meta.w >> 8) & 0xFFu;
@@ -374,7 +375,7 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     uint4 meta = ct.meta[c];
     if (!(meta.z & AVN_CP_ROW_USED)) meta = make_uint4(0u, 0u, 0u, 0u);   // a free id: reads back as an empty pair (flags 0, no points), never as stale data
     const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
-    if (o.flags) o.flags[i] = meta.z & ~(uint32_t)AVN_CP_ROW_USED;
+    if (o.flags) o.flags[i] = meta.z & ~(uint32_t)(AVN_CP_ROW_USED | AVN_CP_ROW_SLEEPING);
     if (o.point_count) o.point_count[i] = (uint8_t)np;
     Vec4<T> n4 = np ? ct.n[c] : make4<T>(0, 0, 0, 0), tv = np ? ct.tv[c] : make4<T>(0, 0, 0, 0);
     st3(o.normal, i, xyz<T>(n4));
@@ -439,6 +440,17 @@ __global__ __launch_bounds__(256) void k_remap_row_slots(CT<T> ct, const uint32_
 template <class T> void launch_remap_row_slots(const CT<T>& ct, const uint32_t* map, uint32_t n_old, uint32_t apply, uint32_t* n_orphans, hipStream_t st) {
     if (ct.cap) hipLaunchKernelGGL(k_remap_row_slots<T>, dim3((ct.cap + 255) / 256), dim3(256), 0, st, ct, map, n_old, apply, n_orphans);
 }
+template <class T>
+__global__ __launch_bounds__(256) void k_rows_set_sleeping(CT<T> ct, const uint32_t* __restrict__ cids, uint32_t n, uint32_t sleeping) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    uint4 meta = ct.meta[cids[i]];
+    meta.z = sleeping ? (meta.z | AVN_CP_ROW_SLEEPING) : (meta.z & ~(uint32_t)AVN_CP_ROW_SLEEPING);
+    ct.meta[cids[i]] = meta;
+}
+template <class T> void launch_rows_set_sleeping(const CT<T>& ct, const uint32_t* cids, uint32_t n, uint32_t sleeping, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_rows_set_sleeping<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, cids, n, sleeping);
+}
 template <class T> void launch_init_contact_rows(const CT<T>& ct, const uint32_t* ids, const uint32_t* s1, const uint32_t* s2, const uint32_t* pf, uint32_t n, hipStream_t st) {
     if (n) hipLaunchKernelGGL(k_init_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, s1, s2, pf, n);
 }
@@ -478,6 +490,7 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     if (n) hipLaunchKernelGGL(k_pack_contacts<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n, in, error);
 }
 #define INST(T)                                                                                                                                      \
+    template void launch_rows_set_sleeping<T>(const CT<T>&, const uint32_t*, uint32_t, uint32_t, hipStream_t);                                          \
     template void launch_remap_row_slots<T>(const CT<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t*, hipStream_t);                               \
     template void launch_pack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, uint32_t*, hipStream_t);                              \
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \

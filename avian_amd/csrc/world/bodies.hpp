@@ -71,10 +71,30 @@
         launch_pack_bodies<T>(dw, s, stream);
         HIPCHK(hipGetLastError());
         // host copy of "has SolverBody" for the joint schedules
-        h_body_has_sb.resize(n);
+        h_body_has_sb.resize(n); h_rb_type.resize(n); h_body_flags.resize(n);
+        std::vector<uint32_t> asleep;
         for (uint32_t i = 0; i < n; ++i) {
             uint8_t fl = b->body_flags ? b->body_flags[i] : 0;
+            h_rb_type[i] = b->rb_type[i];
+            if (slp_on) {   // the Sleeping component is the island manager's (SleepIslands / WakeIslands), not the uploader's
+                if (b->rb_type[i] != AVN_RB_STATIC && !(fl & AVN_BODY_DISABLED) && !isl.body_has_node(i)) { avn_status si = isl.body_add(i); if (si != AVN_OK) { error = isl.error; return si; } }
+                if (isl.body_has_node(i) && isl.body_sleeps(i)) { fl |= AVN_BODY_SLEEPING; asleep.push_back(i); } else fl &= (uint8_t)~AVN_BODY_SLEEPING;
+            }
+            h_body_flags[i] = fl;
             h_body_has_sb[i] = b->rb_type[i] != AVN_RB_STATIC && !(fl & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED));
+        }
+        if (slp_on) {
+            // (the packed flags are the uploader's: put the manager's Sleeping flags back, clear the others)
+            std::vector<uint32_t> awake_list;
+            for (uint32_t i = 0; i < n; ++i) if (!(h_body_flags[i] & AVN_BODY_SLEEPING) && b->body_flags && (b->body_flags[i] & AVN_BODY_SLEEPING)) awake_list.push_back(i);
+            HIPCHK(hipStreamSynchronize(stream));
+            avn_status s2 = stage_reserve((asleep.size() + awake_list.size()) * 4 + 1024);
+            if (s2 != AVN_OK) return s2;
+            const uint32_t *d1 = nullptr, *d2 = nullptr;
+            if ((s2 = stage_in<uint32_t>(asleep.data(), asleep.size(), &d1)) != AVN_OK || (s2 = stage_in<uint32_t>(awake_list.data(), awake_list.size(), &d2)) != AVN_OK) return s2;
+            launch_bodies_set_sleeping<T>(dw, d1, (uint32_t)asleep.size(), 1u, nullptr, stream);
+            launch_bodies_set_sleeping<T>(dw, d2, (uint32_t)awake_list.size(), 0u, nullptr, stream);
+            if (b_slp_timer.cap < (size_t)n * 4) { hipError_t e3; b_slp_timer.ensure((size_t)n * 4 + 256, e3, true, stream); b_slp_flags.ensure((size_t)n + 64, e3); if (e3 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; } }
         }
         joint_schedule_dirty = true;
         incidence_dirty = true;

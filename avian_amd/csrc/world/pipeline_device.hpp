@@ -29,7 +29,7 @@
         }
         PGB(b_pg_chg, rows, pg.chg, true); PGB(b_pg_has, rows, pg.has, true);   // (kept: the overlapped narrow phase has written the old rows' changes when a step's new pairs grow the table)
         PGB(b_pg_off, rows + 1, pg.off, false);
-        PGB(b_pg_op_cid, rows, pg.op_cid, false); PGB(b_pg_op_info, rows, pg.op_info, false); PGB(b_pg_op_bodies, rows, pg.op_bodies, false);
+        PGB(b_pg_op_cid, rows, pg.op_cid, false); PGB(b_pg_op_chg, rows, pg.op_chg, false); PGB(b_pg_op_info, rows, pg.op_info, false); PGB(b_pg_op_bodies, rows, pg.op_bodies, false);
         PGB(b_pg_ekey_a, 2 * (size_t)rows, pg.ekey_a, false); PGB(b_pg_eval_a, 2 * (size_t)rows, pg.eval_a, false);
         PGB(b_pg_ekey_b, 2 * (size_t)rows, pg.ekey_b, false); PGB(b_pg_eval_b, 2 * (size_t)rows, pg.eval_b, false);
         PGB(b_pg_epos, 2 * (size_t)rows, pg.epos, false); PGB(b_pg_popbefore, 2 * (size_t)rows, pg.popbefore, false);
@@ -94,6 +94,7 @@
         HIPCHK(hipMemset(pg.color, 0xFF, (size_t)pg_rows * 4));
         contact_keys_live = false; h_live_keys.clear();   // (the pair set keeps the keys the host announced: existing pairs stay existing)
         pgm_head = pgm_n_free = pgm_next_id = pgm_live = pgm_tomb = 0;
+        slp_on = false; isl = IslandManager();   // (avn_sleeping_enable follows avn_pipeline_enable)
         std::memset(&pipe_stats, 0, sizeof pipe_stats);
         std::memset(pipe_offsets, 0, sizeof pipe_offsets);
         uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
@@ -159,6 +160,90 @@
         pg_error_pending = false;
         return pg_error_report(*h_pg_error);
     }
+    // One batch of ConstraintGraph ops through the device pipeline: ops from the rows' status changes (the status loop; list_cids == NULL) or
+    // from a list (SleepIslands / WakeIslands, world/sleeping.hpp) -> body-sorted entries -> greedy colours as dataflow -> masks -> colour
+    // buckets -> exact swap_remove replay -> (pair removals) -> the colours' lengths back to the host -> the concatenated handle list.
+    avn_status pg_apply_ops(uint32_t n_ops, uint32_t n_rem, uint32_t n_rows, const uint32_t* list_cids, const uint32_t* list_kinds, double& host_ms) {
+        avn_status st;
+        {
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
+            if (list_cids) launch_pg_ops_from_list<T>(pg, ct, list_cids, list_kinds, n_ops, dw.n_bodies, stream);
+            else launch_pg_classify(pg, n_rows, dw.n_bodies, stream);
+            if (slp_on && !list_cids) {   // the island manager reads the loop's changes: (contact id, packed change) per op, in ascending id
+                if (pin_slp_ops.ensure((size_t)n_ops * 8 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+                HIPCHK(hipMemcpyAsync(pin_slp_ops.p, pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync((uint32_t*)pin_slp_ops.p + n_ops, pg.op_chg, (size_t)n_ops * 4, hipMemcpyDeviceToHost, stream));
+            }
+            uint32_t *ek, *evv;
+            launch_radix_sort_bits(pg.ekey_a, pg.eval_a, pg.ekey_b, pg.eval_b, 2 * n_ops, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ek, &evv, stream);
+            launch_pg_entry_scan(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_color(pg, n_ops, stream);
+            launch_pg_apply_masks(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
+            launch_pg_bucket_keys(pg, n_ops, stream);
+            uint32_t *ck, *order;
+            launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
+            launch_pg_replay(pg, order, n_ops, stream);
+            launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
+            if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
+                launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
+                launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
+                launch_pg_merge_free(pg, pgm_head, pgm_n_free, n_rem, stream);
+                HIPCHK(hipMemcpyAsync(pg.free_ids, pg.free_alt, ((size_t)pgm_n_free + n_rem) * 4, hipMemcpyDeviceToDevice, stream));
+                pgm_head = 0; pgm_n_free += n_rem; pgm_live -= n_rem; pgm_tomb += n_rem;
+                pipe_stats.pairs_removed += n_rem;
+                launches += 5;
+            }
+            HIPCHK(hipGetLastError());
+            uint32_t* h = (uint32_t*)pin_ctr.p + 16;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
+            HIPCHK(hipStreamSynchronize(stream));
+            auto t0 = std::chrono::steady_clock::now();
+            if (h[32]) return pg_error_report(h[32]);
+            if (getenv("AVN_PG_REPLAY_STATS")) {
+                uint32_t d[96];
+                HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
+                std::fprintf(stderr, "[avn replay] colour: ops/iterations/serial/reloads:");
+                for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (d[72 + c]) std::fprintf(stderr, " %d:%u/%u/%u/%u", c, d[72 + c], d[c], d[24 + c], d[48 + c]);
+                std::fprintf(stderr, "\n");
+            }
+            if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
+                std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
+                std::vector<int2> bd(n_ops);
+                HIPCHK(hipMemcpy(a.data(), pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(b.data(), pg.op_info, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(bd.data(), pg.op_bodies, (size_t)n_ops * 8, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(o.data(), order, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(cnt.data(), pg.ctr + PGC_BUCKET, 32 * 4, hipMemcpyDeviceToHost));
+                char path[512];
+                std::snprintf(path, sizeof path, "%s/step_%04llu.bin", dir, (unsigned long long)pg_dump_step);
+                if (FILE* f = std::fopen(path, "wb")) {
+                    uint32_t hdr[4] = {n_ops, n_rem, 0, 0};
+                    std::fwrite(hdr, 4, 4, f); std::fwrite(a.data(), 4, n_ops, f); std::fwrite(b.data(), 4, n_ops, f); std::fwrite(bd.data(), 8, n_ops, f);
+                    std::fwrite(o.data(), 4, n_ops, f); std::fwrite(cnt.data(), 4, 32, f);
+                    std::fclose(f);
+                }
+            }
+            pipe_stats.manifolds_pushed = h[34]; pipe_stats.manifolds_popped = h[35];
+            uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
+            uint32_t M = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[c]; offs[c] = M; M += h[c]; }
+            offs[AVN_GRAPH_COLOR_COUNT] = M;
+            if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
+            if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
+            dw.n_manifolds = M;
+            set_color_offsets(offs);
+            hipError_t err;
+            if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, stream);
+            ++launches;
+            HIPCHK(hipGetLastError());
+            incidence_dirty = true;
+            host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        }
+        return AVN_OK;
+    }
     avn_status pipeline_step_device() {
         avn_status st;
         launches = 0;
@@ -215,7 +300,19 @@
                 if (np_overlap) HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_old, 0));               // nothing below may touch a row while that launch runs
                 if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return fail(st);
                 launch_hs_insert_pairs(bp.pair_set, bp.pair_set_cap, b_pairs.as<avn_pair>(), total, bs);   // add_edge_and_key_with: the keys join the pair set
+                pg.new_ids = nullptr;
+                if (slp_on) {   // the island manager's edge lists: (ContactId, collider1, collider2) of every new pair, in emission order
+                    hipError_t e2;
+                    b_pg_new_ids.ensure((size_t)total * 4, e2);
+                    if (e2 != hipSuccess) { error = "hipMalloc failed"; return fail(AVN_ERR_OOM); }
+                    pg.new_ids = b_pg_new_ids.as<uint32_t>();
+                }
                 launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bs);
+                if (slp_on) {
+                    if (pin_slp_pairs.ensure((size_t)total * (sizeof(avn_pair) + 4) + 64) != hipSuccess) { error = "hipHostMalloc failed"; return fail(AVN_ERR_OOM); }
+                    HIPCHK(hipMemcpyAsync(pin_slp_pairs.p, b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, bs));
+                    HIPCHK(hipMemcpyAsync((char*)pin_slp_pairs.p + (size_t)total * sizeof(avn_pair), pg.new_ids, (size_t)total * 4, hipMemcpyDeviceToHost, bs));
+                }
                 launches += 3;
                 HIPCHK(hipGetLastError());
                 const uint32_t used = std::min(total, pgm_n_free);
@@ -255,83 +352,18 @@
         }
         pipe_stats.last_status_changes = n_ops;
         ++pg_dump_step;
-        if (n_ops) {
-            // ---- the status-change loop: decisions, colours, handle lists ----
-            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
-            launch_pg_classify(pg, n_rows, dw.n_bodies, stream);
-            uint32_t *ek, *evv;
-            launch_radix_sort_bits(pg.ekey_a, pg.eval_a, pg.ekey_b, pg.eval_b, 2 * n_ops, bits_for(dw.n_bodies), b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ek, &evv, stream);
-            launch_pg_entry_scan(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
-            launch_pg_color(pg, n_ops, stream);
-            launch_pg_apply_masks(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
-            launch_pg_bucket_keys(pg, n_ops, stream);
-            uint32_t *ck, *order;
-            launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
-            launch_pg_replay(pg, order, n_ops, stream);
-            launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
-            if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
-                launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
-                launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
-                launch_pg_merge_free(pg, pgm_head, pgm_n_free, n_rem, stream);
-                HIPCHK(hipMemcpyAsync(pg.free_ids, pg.free_alt, ((size_t)pgm_n_free + n_rem) * 4, hipMemcpyDeviceToDevice, stream));
-                pgm_head = 0; pgm_n_free += n_rem; pgm_live -= n_rem; pgm_tomb += n_rem;
-                pipe_stats.pairs_removed += n_rem;
-                launches += 5;
-            }
-            HIPCHK(hipGetLastError());
-            uint32_t* h = (uint32_t*)pin_ctr.p + 16;
-            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
+        if (n_ops) {   // ---- the status-change loop: decisions, colours, handle lists ----
             lap();
-            HIPCHK(hipStreamSynchronize(stream));
+            if ((st = pg_apply_ops(n_ops, n_rem, n_rows, nullptr, nullptr, host_ms)) != AVN_OK) return st;
             t0 = std::chrono::steady_clock::now();
-            if (h[32]) return pg_error_report(h[32]);
-            if (getenv("AVN_PG_REPLAY_STATS")) {
-                uint32_t d[96];
-                HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
-                std::fprintf(stderr, "[avn replay] colour: ops/iterations/serial/reloads:");
-                for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (d[72 + c]) std::fprintf(stderr, " %d:%u/%u/%u/%u", c, d[72 + c], d[c], d[24 + c], d[48 + c]);
-                std::fprintf(stderr, "\n");
-            }
-            if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
-                std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
-                std::vector<int2> bd(n_ops);
-                HIPCHK(hipMemcpy(a.data(), pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(b.data(), pg.op_info, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(bd.data(), pg.op_bodies, (size_t)n_ops * 8, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(o.data(), order, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(cnt.data(), pg.ctr + PGC_BUCKET, 32 * 4, hipMemcpyDeviceToHost));
-                char path[512];
-                std::snprintf(path, sizeof path, "%s/step_%04llu.bin", dir, (unsigned long long)pg_dump_step);
-                if (FILE* f = std::fopen(path, "wb")) {
-                    uint32_t hdr[4] = {n_ops, n_rem, 0, 0};
-                    std::fwrite(hdr, 4, 4, f); std::fwrite(a.data(), 4, n_ops, f); std::fwrite(b.data(), 4, n_ops, f); std::fwrite(bd.data(), 8, n_ops, f);
-                    std::fwrite(o.data(), 4, n_ops, f); std::fwrite(cnt.data(), 4, 32, f);
-                    std::fclose(f);
-                }
-            }
-            pipe_stats.manifolds_pushed = h[34]; pipe_stats.manifolds_popped = h[35];
-            uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
-            uint32_t M = 0;
-            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[c]; offs[c] = M; M += h[c]; }
-            offs[AVN_GRAPH_COLOR_COUNT] = M;
-            if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
-            if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
-            dw.n_manifolds = M;
-            set_color_offsets(offs);
-            hipError_t err;
-            if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
-            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, stream);
-            ++launches;
-            HIPCHK(hipGetLastError());
-            incidence_dirty = true;
         }
+        if (slp_on && (st = sleeping_after_status_loop(total, n_ops, host_ms)) != AVN_OK) return st;   // islands: new pairs, the loop's link / unlink, WakeIslands
         pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
         lap();
         pipe_stats.last_host_ms = host_ms;
         stamp(DG_NP1); dg_np = true;
         if ((st = solver()) != AVN_OK) return st;
+        if (slp_on && (st = sleeping_after_solver()) != AVN_OK) return st;   // split_island + the Sleeping set (synchronises: the host reads the timers)
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
         last_timers.kernel_launches = launches;

@@ -1,0 +1,186 @@
+// world/sleeping.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
+// persistent simulation islands and the ACTUATION of sleeping in the device closed loop (include/avian_mi355x.h: avn_sleeping_enable).
+//
+// Who does what (reference: dynamics/solver/islands/mod.rs, islands/sleeping.rs, collision/narrow_phase/system_param.rs:141-398):
+//   * the island manager (avn_islands.hpp, host C++) keeps what the reference keeps in linked lists threaded through ECS components -- island
+//     membership and body-list order, slab ids, the colliders' edge lists, which pairs touch / sleep -- and decides: merges inside the status
+//     loop, the deferred split, which islands sleep and wake, and in WHICH ORDER their manifolds leave / re-enter the ConstraintGraph;
+//   * the device does the arithmetic and the bulk state: SleepTimers from the SolverBody velocities (k_sleep_timers_flags), the narrow phase
+//     that skips the pairs of ContactGraph::sleeping_pairs (AVN_CP_ROW_SLEEPING), the Sleeping flag of bodies (no SolverBody, inactive
+//     interval), and the pops / pushes themselves: the manager's ordered list goes through the same op pipeline as the status loop's ops
+//     (pg_apply_ops: dataflow greedy colouring, exact swap_remove replay), so colours and list orders are the reference's.
+// Per step the host reads the loop's changes (8 bytes per change), the new pairs (28 bytes each) and the timers (5 bytes per body); with a
+// sleeping pile all three are empty or tiny.  avn_step synchronises at its end in this mode (the Sleeping set needs the timers).
+    bool slp_on = false;
+    IslandManager isl;
+    SleepParams<T> slp_k;
+    float slp_time_to_sleep = 0.5f;
+    DevBuf b_slp_lin, b_slp_ang, b_slp_dis, b_slp_timer, b_slp_flags;
+    Pinned pin_slp_ops, pin_slp_pairs, pin_slp_timers;
+    std::vector<uint8_t> h_rb_type, h_body_flags;      // host copies of the uploaded RigidBody type / body flags (island nodes, Sleeping)
+    uint32_t slp_n_awake = 0, slp_last_slept = 0, slp_last_woken = 0, slp_last_popped = 0, slp_last_pushed = 0;
+    double slp_host_ms = 0;
+    std::vector<uint32_t> slp_list;                    // scratch: cids | kinds of an op list
+
+    bool slp_node(uint32_t b) const { return h_rb_type[b] != AVN_RB_STATIC && !(h_body_flags[b] & AVN_BODY_DISABLED); }   // BodyIslandNode, islands/mod.rs:96-140
+    avn_status slp_fail(avn_status st) { error = isl.error; return st; }
+
+    avn_status sleeping_enable(const avn_sleep_params* p) override {
+        if (!p) {
+            if (!slp_on) return AVN_OK;
+            double ms = 0;
+            for (uint32_t b = 0; b < dw.n_bodies; ++b)
+                if (isl.body_has_node(b) && isl.body_sleeps(b)) { avn_status st = isl.wake_body(b); if (st != AVN_OK) return slp_fail(st); if ((st = sleeping_apply_result(false, ms)) != AVN_OK) return st; }
+            slp_on = false;
+            isl = IslandManager();
+            return AVN_OK;
+        }
+        if (p->struct_size != sizeof(avn_sleep_params)) { error = "sleeping_enable: bad params"; return AVN_ERR_BAD_ARG; }
+        if (!pipe_on || !pipe_dev) { error = "sleeping_enable: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
+        if (pgm_next_id) { error = "sleeping_enable: enable it before the first step of the closed loop"; return AVN_ERR_STATE; }
+        const uint32_t n = dw.n_bodies;
+        if (h_rb_type.size() != n) { error = "sleeping_enable: upload bodies first"; return AVN_ERR_STATE; }
+        avn_status st;
+        isl = IslandManager();
+        for (uint32_t b = 0; b < n; ++b) if (slp_node(b) && (st = isl.body_add(b)) != AVN_OK) return slp_fail(st);
+        for (uint32_t s = 0; s < slot_entity.size(); ++s) {
+            const uint32_t b = (uint32_t)h_col_body[s];
+            if ((st = isl.collider_add(slot_entity[s], slp_node(b) ? b : IslandManager::NONE)) != AVN_OK) return slp_fail(st);
+        }
+        for (uint32_t j = 0; j < h_j_body1.size(); ++j) if ((st = isl.joint_add(j, (uint32_t)h_j_body1[j], (uint32_t)h_j_body2[j])) != AVN_OK) return slp_fail(st);
+        for (uint32_t b = 0; b < n; ++b) if (slp_node(b) && (h_body_flags[b] & AVN_BODY_SLEEPING) && (st = isl.sleep_body(b)) != AVN_OK) return slp_fail(st);   // bodies uploaded asleep
+        // the timer kernel's parameters and per-body components
+        slp_k.length_unit_squared = (T)p->length_unit * (T)p->length_unit;
+        slp_k.lin_threshold_squared = (T)(p->linear_threshold * std::fabs(p->linear_threshold));
+        slp_k.ang_threshold_squared = (T)(p->angular_threshold * std::fabs(p->angular_threshold));
+        slp_k.delta_secs = p->delta_secs; slp_k.time_to_sleep = p->time_to_sleep;
+        slp_k.body_lin = nullptr; slp_k.body_ang = nullptr; slp_k.body_disabled = nullptr;
+        slp_time_to_sleep = p->time_to_sleep;
+        HIPCHK(hipStreamSynchronize(stream));
+        hipError_t err;
+        auto up = [&](DevBuf& b, const void* src, size_t bytes) -> const void* {
+            if (!src) return nullptr;
+            b.ensure(std::max<size_t>(bytes, 1), err);
+            if (err != hipSuccess) return nullptr;
+            if (hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice) != hipSuccess) { err = hipErrorUnknown; return nullptr; }
+            return b.p;
+        };
+        err = hipSuccess;
+        slp_k.body_lin = (const float*)up(b_slp_lin, p->body_linear_threshold, (size_t)n * 4);
+        slp_k.body_ang = (const float*)up(b_slp_ang, p->body_angular_threshold, (size_t)n * 4);
+        slp_k.body_disabled = (const uint8_t*)up(b_slp_dis, p->body_sleeping_disabled, n);
+        if (err != hipSuccess) { error = "sleeping_enable: device allocation / copy failed"; return AVN_ERR_OOM; }
+        b_slp_timer.ensure(std::max<size_t>(n, 1) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_slp_flags.ensure(std::max<size_t>(n, 1), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemset(b_slp_timer.p, 0, std::max<size_t>(n, 1) * 4));
+        slp_n_awake = slp_last_slept = slp_last_woken = slp_last_popped = slp_last_pushed = 0;
+        slp_on = true;
+        return AVN_OK;
+    }
+    // The device side of a batch of the manager's commands (SleepIslands / WakeIslands): SLEEPING bits of the pairs, Sleeping flags of the
+    // bodies (+ SleepTimer = 0 for woken ones), and the pops / pushes IN THE MANAGER'S ORDER through the op pipeline.
+    avn_status sleeping_apply_result(bool count, double& host_ms) {
+        const std::vector<uint32_t>&popped = isl.popped(), &pushed = isl.pushed(), &ps = isl.pairs_slept(), &pw = isl.pairs_woken(), &bsl = isl.bodies_slept(), &bw = isl.bodies_woken();
+        if (count) { slp_last_popped = (uint32_t)popped.size(); slp_last_pushed = (uint32_t)pushed.size(); }
+        const size_t n_ops = popped.size() + pushed.size();
+        const size_t words = 2 * n_ops + ps.size() + pw.size() + bsl.size() + bw.size();
+        if (!words) return AVN_OK;
+        slp_list.clear();
+        slp_list.insert(slp_list.end(), popped.begin(), popped.end()); slp_list.insert(slp_list.end(), pushed.begin(), pushed.end());
+        slp_list.insert(slp_list.end(), popped.size(), 2u /* PG_KIND_POP */); slp_list.insert(slp_list.end(), pushed.size(), 1u /* PG_KIND_PUSH */);
+        const size_t o_ps = slp_list.size(); slp_list.insert(slp_list.end(), ps.begin(), ps.end());
+        const size_t o_pw = slp_list.size(); slp_list.insert(slp_list.end(), pw.begin(), pw.end());
+        const size_t o_bs = slp_list.size(); slp_list.insert(slp_list.end(), bsl.begin(), bsl.end());
+        const size_t o_bw = slp_list.size(); slp_list.insert(slp_list.end(), bw.begin(), bw.end());
+        avn_status st = stage_reserve(slp_list.size() * 4 + 1024);
+        if (st != AVN_OK) return st;
+        const uint32_t* d;
+        if ((st = stage_in<uint32_t>(slp_list.data(), slp_list.size(), &d)) != AVN_OK) return st;
+        launch_rows_set_sleeping<T>(ct, d + o_ps, (uint32_t)ps.size(), 1u, stream);
+        launch_rows_set_sleeping<T>(ct, d + o_pw, (uint32_t)pw.size(), 0u, stream);
+        launch_bodies_set_sleeping<T>(dw, d + o_bs, (uint32_t)bsl.size(), 1u, nullptr, stream);
+        launch_bodies_set_sleeping<T>(dw, d + o_bw, (uint32_t)bw.size(), 0u, b_slp_timer.as<float>(), stream);
+        launches += 4;
+        HIPCHK(hipGetLastError());
+        for (uint32_t b : bsl) { h_body_flags[b] |= AVN_BODY_SLEEPING; h_body_has_sb[b] = 0; }
+        for (uint32_t b : bw) { h_body_flags[b] &= (uint8_t)~AVN_BODY_SLEEPING; h_body_has_sb[b] = h_rb_type[b] != AVN_RB_STATIC && !(h_body_flags[b] & AVN_BODY_DISABLED); }
+        if (!bsl.empty() || !bw.empty()) { joint_schedule_dirty = true; groups_dirty = true; incidence_dirty = true; }
+        if (n_ops) { if ((st = pg_apply_ops((uint32_t)n_ops, 0u, 0u, d, d + n_ops, host_ms)) != AVN_OK) return st; }
+        else HIPCHK(hipStreamSynchronize(stream));   // (the staging arena is reused by the next call)
+        return AVN_OK;
+    }
+    // after the status loop of the step (its ops are already in the colour lists): the manager sees the new pairs and the loop's link / unlink
+    // events in the reference's order, then the deferred WakeIslands (system_param.rs:391-398) runs before the solver
+    avn_status sleeping_after_status_loop(uint32_t n_new_pairs, uint32_t n_ops, double& host_ms) {
+        auto t0 = std::chrono::steady_clock::now();
+        avn_status st;
+        if (n_new_pairs) {
+            const avn_pair* pr = (const avn_pair*)pin_slp_pairs.p;
+            const uint32_t* ids = (const uint32_t*)((const char*)pin_slp_pairs.p + (size_t)n_new_pairs * sizeof(avn_pair));
+            for (uint32_t i = 0; i < n_new_pairs; ++i) if ((st = isl.pair_add(ids[i], pr[i].collider1, pr[i].collider2)) != AVN_OK) return slp_fail(st);
+        }
+        if (n_ops) {
+            const uint32_t* cid = (const uint32_t*)pin_slp_ops.p; const uint32_t* chg = cid + n_ops;
+            for (uint32_t k = 0; k < n_ops; ++k) if ((st = isl.status_change(cid[k], chg[k] & 0xFFFFu, (chg[k] >> 16) & 0xFFu)) != AVN_OK) return slp_fail(st);
+        }
+        if ((st = isl.flush_wake()) != AVN_OK) return slp_fail(st);
+        host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return sleeping_apply_result(false, host_ms);
+    }
+    // split_island (SolverSystems::Finalize) and the Sleeping set (update_sleeping_states, wake_islands_with_sleeping_disabled, sleep_islands,
+    // then SleepIslands / WakeIslands)
+    avn_status sleeping_after_solver() {
+        const uint32_t n = dw.n_bodies;
+        double host_ms = 0;
+        auto t0 = std::chrono::steady_clock::now();
+        avn_status st;
+        launch_sleep_timers_flags<T>(dw, slp_k, b_slp_timer.as<float>(), b_slp_flags.as<uint8_t>(), stream); ++launches;   // behind the write-back: SolverBody velocities of this step
+        HIPCHK(hipGetLastError());
+        if (pin_slp_timers.ensure((size_t)n * 5 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        float* h_timer = (float*)pin_slp_timers.p; uint8_t* h_flags = (uint8_t*)(h_timer + n);
+        HIPCHK(hipMemcpyAsync(h_timer, b_slp_timer.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_flags, b_slp_flags.p, n, hipMemcpyDeviceToHost, stream));
+        if ((st = isl.split_candidate_now()) != AVN_OK) return slp_fail(st);   // (host work while the solver's kernels run)
+        host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        HIPCHK(hipStreamSynchronize(stream));
+        t0 = std::chrono::steady_clock::now();
+        uint32_t awake = 0;
+        for (uint32_t b = 0; b < n; ++b) awake += (h_flags[b] >> 2) & 1u;
+        slp_n_awake = awake;
+        if ((st = isl.sleeping_systems(h_timer, h_flags, n, slp_time_to_sleep)) != AVN_OK) return slp_fail(st);
+        slp_last_slept = isl.last_slept(); slp_last_woken = isl.last_woken();
+        host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        st = sleeping_apply_result(true, host_ms);
+        slp_host_ms = host_ms;
+        return st;
+    }
+    avn_status sleeping_stats_get(avn_sleeping_stats* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        std::memset(o, 0, sizeof *o);
+        if (!slp_on) return AVN_OK;
+        isl.stats(&o->islands);
+        o->n_awake_bodies = slp_n_awake; o->last_islands_slept = slp_last_slept; o->last_islands_woken = slp_last_woken;
+        o->last_manifolds_popped = slp_last_popped; o->last_manifolds_pushed = slp_last_pushed; o->last_host_ms = slp_host_ms;
+        return AVN_OK;
+    }
+    avn_status sleeping_state_get(const avn_sleeping_out* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        if (!slp_on) { error = "sleeping_state_get: sleeping is not enabled"; return AVN_ERR_STATE; }
+        const uint32_t n = dw.n_bodies;
+        avn_status st = isl.state(n, o->island, o->next_in_island, nullptr, nullptr);
+        if (st != AVN_OK) return slp_fail(st);
+        if (o->sleeping) for (uint32_t b = 0; b < n; ++b) o->sleeping[b] = (h_body_flags[b] & AVN_BODY_SLEEPING) ? 1 : 0;
+        if (o->sleep_timer) { HIPCHK(hipMemcpyAsync(o->sleep_timer, b_slp_timer.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream)); HIPCHK(hipStreamSynchronize(stream)); }
+        return AVN_OK;
+    }
+    avn_status wake_bodies(const uint32_t* ids, size_t n) override {   // WakeBody (sleeping.rs:438-452)
+        if (!slp_on) { error = "wake_bodies: sleeping is not enabled"; return AVN_ERR_STATE; }
+        if (n && !ids) return AVN_ERR_BAD_ARG;
+        double ms = 0;
+        for (size_t i = 0; i < n; ++i) {
+            avn_status st = isl.wake_body(ids[i]);
+            if (st != AVN_OK) return slp_fail(st);
+            if ((st = sleeping_apply_result(false, ms)) != AVN_OK) return st;
+        }
+        return AVN_OK;
+    }

@@ -27,6 +27,7 @@
 
 #include "../include/avian_mi355x.h"
 #include "avo_parallel.hpp"
+#include "avo_islands.hpp"
 #include "avo_math.hpp"
 #include "avo_narrow.hpp"
 
@@ -308,6 +309,10 @@ struct WorldBase {
     virtual avn_status pipeline_enable(int) = 0;
     virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
     virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
+    virtual avn_status sleeping_enable(const avn_sleep_params*) = 0;
+    virtual avn_status sleeping_stats_get(avn_sleeping_stats*) = 0;
+    virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
+    virtual avn_status wake_bodies(const uint32_t*, size_t) = 0;
 };
 
 struct ConstraintGraph;  // defined below (solver/constraint_graph.rs restatement)
@@ -366,11 +371,28 @@ template <class S> struct World : WorldBase {
 
     PipelineState* pipe = nullptr;
     World() { std::memset(&last_timers, 0, sizeof last_timers); std::memset(color_offsets, 0, sizeof color_offsets); }
-    ~World() override { pipeline_delete(pipe); }
+    ~World() override { pipeline_delete(pipe); delete slp; }
     avn_status pipeline_enable(int on) override;
     avn_status pipeline_stats_get(avn_pipeline_stats* o) override;
     avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override;
     avn_status pipeline_step();
+    // ---- persistent islands + sleeping in the closed loop (header: avn_sleeping_enable; avo_islands.hpp) ----
+    struct Sleeping {
+        avn_sleep_params p;
+        std::vector<float> lin, ang;          // per-body SleepThreshold (empty: the world-level value)
+        std::vector<uint8_t> disabled;        // SleepingDisabled
+        IslandManager isl;
+        std::vector<float> timer;             // SleepTimer
+        uint32_t n_awake = 0, last_slept = 0, last_woken = 0, last_popped = 0, last_pushed = 0;
+        double host_ms = 0;
+    };
+    Sleeping* slp = nullptr;
+    avn_status sleeping_enable(const avn_sleep_params* p) override;
+    avn_status sleeping_stats_get(avn_sleeping_stats* o) override;
+    avn_status sleeping_state_get(const avn_sleeping_out* o) override;
+    avn_status wake_bodies(const uint32_t* ids, size_t n) override;
+    void sleeping_apply(bool count);          // the ConstraintGraph / Sleeping-component side of the manager's last result
+    void sleeping_systems();                  // split_island + the Sleeping set, after the solver
 
     // -- time: Duration arithmetic of run_physics_schedule / run_substep_schedule (schedule/mod.rs:240-284,
     //    solver/schedule.rs:194-200).  sub_delta = delta.div_f64(substeps) = from_secs_f64(secs/substeps)
@@ -444,6 +466,13 @@ template <class S> struct World : WorldBase {
             o.pre_solve_delta_rotation = qidentity<S>();
             accel_linear[i] = rd3(b->accel_linear, i);
             accel_angular[i] = rd3(b->accel_angular, i);
+            if (slp) {   // the Sleeping component is the island manager's (SleepIslands / WakeIslands), not the uploader's
+                if (o.rb_type != AVN_RB_STATIC && !(o.body_flags & AVN_BODY_DISABLED) && !slp->isl.has_node((uint32_t)i)) slp->isl.body_add((uint32_t)i);
+                const bool asleep = slp->isl.has_node((uint32_t)i) && slp->isl.body_sleeping[i];
+                o.body_flags = asleep ? (o.body_flags | AVN_BODY_SLEEPING) : (o.body_flags & (uint8_t)~AVN_BODY_SLEEPING);
+                o.has_solver_body = o.rb_type != AVN_RB_STATIC && o.active();
+                if (slp->timer.size() < n) slp->timer.resize(n, 0.0f);
+            }
         }
         return AVN_OK;
     }
@@ -2131,6 +2160,7 @@ template <class S> avn_status World<S>::pipeline_step() {
         avn_status st = contact_pairs_add(&cp);
         if (st != AVN_OK) return st;
         P.stats.pairs_added += ids.size();
+        if (slp) for (size_t i = 0; i < ids.size(); ++i) { st = slp->isl.pair_add(ids[i], c1[i], c2[i]); if (st != AVN_OK) { error = slp->isl.error; return st; } }
     }
     avn_status st = active_pairs_set(P.active.data(), P.active.size());
     if (st != AVN_OK) return st;
@@ -2155,6 +2185,7 @@ template <class S> avn_status World<S>::pipeline_step() {
     for (const avn_contact_change& c : contact_changes) {
         uint32_t cid = c.contact_id, flags = c.flags;
         bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+        if (slp) { avn_status si = slp->isl.status_change(cid, flags, c.manifold_count); if (si != AVN_OK) { error = slp->isl.error; return si; } }
         if (pipe_stats_on) {
             PipelineState::Pair& p = P.pairs[cid];
             bool is_pop = (flags & AVN_CP_DISJOINT_AABB) ? (generates && p.n_handles) : (flags & AVN_CP_STARTED_TOUCHING) ? false : (flags & AVN_CP_STOPPED_TOUCHING) ? (generates && p.n_handles)
@@ -2188,6 +2219,10 @@ template <class S> avn_status World<S>::pipeline_step() {
         P.active.swap(keep);
         for (uint32_t cid : removed) { P.pairs.erase(cid); P.free_ids.insert(cid); }
         P.stats.pairs_removed += removed.size();
+    }
+    if (slp) {   // the deferred WakeIslands of the status loop (system_param.rs:391-398), applied before the solver
+        slp->isl.flush_wake();
+        sleeping_apply(false);
     }
     if (P.handles_dirty) {
         size_t n = 0;
@@ -2251,6 +2286,126 @@ template <class S> avn_status World<S>::pipeline_step() {
     }
     solver();
     diag.contact_count = (uint32_t)P.active.size();
+    if (slp) sleeping_systems();
+    return AVN_OK;
+}
+
+// ---- persistent islands + sleeping in the closed loop ------------------------------------------------------------------------------
+template <class S> avn_status World<S>::sleeping_enable(const avn_sleep_params* p) {
+    if (!p) {   // off: every island awake again
+        if (slp) {
+            for (size_t b = 0; b < bodies.size(); ++b) if (slp->isl.has_node((uint32_t)b) && slp->isl.body_sleeping[b]) { slp->isl.wake_body((uint32_t)b); sleeping_apply(false); }
+            delete slp; slp = nullptr;
+        }
+        return AVN_OK;
+    }
+    if (p->struct_size != sizeof(avn_sleep_params)) { error = "sleeping_enable: bad params"; return AVN_ERR_BAD_ARG; }
+    if (!pipe) { error = "sleeping_enable: needs the closed loop (avn_pipeline_enable)"; return AVN_ERR_STATE; }
+    if (!pipe->pairs.empty()) { error = "sleeping_enable: enable it before the first step of the closed loop"; return AVN_ERR_STATE; }
+    delete slp;
+    slp = new Sleeping();
+    slp->p = *p;
+    const size_t n = bodies.size();
+    if (p->body_linear_threshold) slp->lin.assign(p->body_linear_threshold, p->body_linear_threshold + n);
+    if (p->body_angular_threshold) slp->ang.assign(p->body_angular_threshold, p->body_angular_threshold + n);
+    if (p->body_sleeping_disabled) slp->disabled.assign(p->body_sleeping_disabled, p->body_sleeping_disabled + n);
+    slp->p.body_linear_threshold = nullptr; slp->p.body_angular_threshold = nullptr; slp->p.body_sleeping_disabled = nullptr;
+    slp->timer.assign(n, 0.0f);
+    auto node = [&](size_t b) { return bodies[b].rb_type != AVN_RB_STATIC && !(bodies[b].body_flags & AVN_BODY_DISABLED); };   // BodyIslandNode, islands/mod.rs:96-140
+    for (size_t b = 0; b < n; ++b) if (node(b)) slp->isl.body_add((uint32_t)b);
+    for (const Collider<S>& c : colliders) slp->isl.collider_add(c.entity, node((size_t)c.body) ? (uint32_t)c.body : IslandManager::NONE);
+    for (size_t j = 0; j < joints.size(); ++j) slp->isl.joint_add((uint32_t)j, (uint32_t)joints[j].body1, (uint32_t)joints[j].body2);
+    for (size_t b = 0; b < n; ++b) if (node(b) && (bodies[b].body_flags & AVN_BODY_SLEEPING)) { slp->isl.sleep_body((uint32_t)b); slp->isl.clear_results(); }   // bodies uploaded asleep
+    return AVN_OK;
+}
+// pops / pushes of SleepIslands / WakeIslands into the ConstraintGraph, pairs into / out of the active set, Sleeping on / off the bodies
+template <class S> void World<S>::sleeping_apply(bool count) {
+    PipelineState& P = *pipe;
+    IslandManager& M = slp->isl;
+    for (uint32_t cid : M.popped) {
+        PipelineState::Pair& pr = P.pairs[cid];
+        if (!pr.n_handles) continue;
+        --pr.n_handles;
+        P.graph.pop_manifold(((uint64_t)cid << 8) | pr.n_handles);
+        P.handles_dirty = true; ++P.stats.manifolds_popped;
+    }
+    for (uint32_t cid : M.pushed) {
+        PipelineState::Pair& pr = P.pairs[cid];
+        const uint32_t flags = contact_rows[cid].flags;
+        P.graph.push_manifold(((uint64_t)cid << 8) | pr.n_handles, (uint32_t)pr.b1, (uint32_t)pr.b2, flags & AVN_CP_STATIC1, flags & AVN_CP_STATIC2);
+        ++pr.n_handles; P.handles_dirty = true; ++P.stats.manifolds_pushed;
+    }
+    if (!M.pairs_slept.empty()) {   // ContactGraph::sleeping_pairs: out of the narrow phase's iteration
+        std::set<uint32_t> gone(M.pairs_slept.begin(), M.pairs_slept.end());
+        std::vector<uint32_t> keep;
+        for (uint32_t a : P.active) if (!gone.count(a)) keep.push_back(a);
+        P.active.swap(keep);
+    }
+    for (uint32_t cid : M.pairs_woken) P.active.push_back(cid);
+    for (uint32_t b : M.bodies_slept) { bodies[b].body_flags |= AVN_BODY_SLEEPING; bodies[b].has_solver_body = false; }
+    for (uint32_t b : M.bodies_woken) {
+        bodies[b].body_flags &= (uint8_t)~AVN_BODY_SLEEPING;
+        bodies[b].has_solver_body = bodies[b].rb_type != AVN_RB_STATIC && bodies[b].active();
+        slp->timer[b] = 0.0f;   // sleep_timer.0 = 0.0 (sleeping.rs:492)
+    }
+    if (count) { slp->last_popped = (uint32_t)M.popped.size(); slp->last_pushed = (uint32_t)M.pushed.size(); }
+}
+template <class S> void World<S>::sleeping_systems() {
+    auto t0 = std::chrono::steady_clock::now();
+    Sleeping& Z = *slp;
+    const size_t n = bodies.size();
+    Z.isl.split_candidate_now();   // split_island, SolverSystems::Finalize (islands/mod.rs:160-178)
+    // update_sleeping_states, body side (sleeping.rs:203-223): bodies with a SolverBody, not Sleeping, not SleepingDisabled
+    const S length_unit_squared = (S)Z.p.length_unit * (S)Z.p.length_unit;
+    std::vector<uint8_t> flags(n, 0);
+    Z.n_awake = 0;
+    for (size_t b = 0; b < n; ++b) {
+        if (!Z.isl.has_node((uint32_t)b)) continue;
+        const bool disabled = !Z.disabled.empty() && Z.disabled[b];
+        if (disabled) { flags[b] = 2; Z.timer[b] = 0.0f; if (bodies[b].has_solver_body) ++Z.n_awake; continue; }   // wake_islands_with_sleeping_disabled resets the timer
+        if (!bodies[b].has_solver_body) continue;   // Sleeping
+        ++Z.n_awake;
+        flags[b] = 1;
+        const SolverBody<S>& sb = bodies[b].sb;
+        const S lin_vel_squared = length_squared(sb.linear_velocity), ang_vel_squared = length_squared(sb.angular_velocity);
+        const float lt = Z.lin.empty() ? Z.p.linear_threshold : Z.lin[b], at = Z.ang.empty() ? Z.p.angular_threshold : Z.ang[b];
+        const float lin_threshold_squared = lt * std::fabs(lt), ang_threshold_squared = at * std::fabs(at);   // "Keep signs."
+        if (lin_vel_squared < length_unit_squared * (S)lin_threshold_squared && ang_vel_squared < (S)ang_threshold_squared) Z.timer[b] += Z.p.delta_secs;
+        else Z.timer[b] = 0.0f;
+    }
+    Z.isl.sleeping_systems(Z.timer.data(), flags.data(), (uint32_t)n, Z.p.time_to_sleep);
+    Z.last_slept = Z.isl.last_slept; Z.last_woken = Z.isl.last_woken;
+    sleeping_apply(true);
+    Z.host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+}
+template <class S> avn_status World<S>::sleeping_stats_get(avn_sleeping_stats* o) {
+    if (!o) return AVN_ERR_BAD_ARG;
+    std::memset(o, 0, sizeof *o);
+    if (!slp) return AVN_OK;
+    slp->isl.stats(&o->islands);
+    o->n_awake_bodies = slp->n_awake; o->last_islands_slept = slp->last_slept; o->last_islands_woken = slp->last_woken;
+    o->last_manifolds_popped = slp->last_popped; o->last_manifolds_pushed = slp->last_pushed; o->last_host_ms = slp->host_ms;
+    return AVN_OK;
+}
+template <class S> avn_status World<S>::sleeping_state_get(const avn_sleeping_out* o) {
+    if (!o) return AVN_ERR_BAD_ARG;
+    if (!slp) { error = "sleeping_state_get: sleeping is not enabled"; return AVN_ERR_STATE; }
+    const uint32_t n = (uint32_t)bodies.size();
+    slp->isl.state(n, o->island, o->next_in_island, nullptr, nullptr);
+    for (uint32_t b = 0; b < n; ++b) {
+        if (o->sleeping) o->sleeping[b] = (bodies[b].body_flags & AVN_BODY_SLEEPING) ? 1 : 0;
+        if (o->sleep_timer) o->sleep_timer[b] = slp->timer[b];
+    }
+    return AVN_OK;
+}
+template <class S> avn_status World<S>::wake_bodies(const uint32_t* ids, size_t n) {
+    if (!slp) { error = "wake_bodies: sleeping is not enabled"; return AVN_ERR_STATE; }
+    if (n && !ids) return AVN_ERR_BAD_ARG;
+    for (size_t i = 0; i < n; ++i) {
+        if (!slp->isl.has_node(ids[i])) { error = "wake_bodies: the body has no island node"; return AVN_ERR_BAD_ARG; }
+        slp->isl.wake_body(ids[i]);
+        sleeping_apply(false);
+    }
     return AVN_OK;
 }
 

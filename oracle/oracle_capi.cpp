@@ -2,7 +2,6 @@
 // (include/avian_mi355x.h) under the `avo_` prefix so tests drive both with identical calls.
 #define AVN_PREFIX_ORACLE 1
 #include "avo_world.hpp"
-#include "avo_islands.hpp"
 
 #include <cmath>
 #include <new>
@@ -75,6 +74,10 @@ avn_status avo_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, cons
 avn_status avo_pipeline_enable(avn_world* w, int on) { FWD(pipeline_enable(on)); }
 avn_status avo_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { FWD(pipeline_stats_get(o)); }
 avn_status avo_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { FWD(pipeline_handles_get(off, ids, n)); }
+avn_status avo_sleeping_enable(avn_world* w, const avn_sleep_params* p) { FWD(sleeping_enable(p)); }
+avn_status avo_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { FWD(sleeping_stats_get(o)); }
+avn_status avo_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { FWD(sleeping_state_get(o)); }
+avn_status avo_wake_bodies(avn_world* w, const uint32_t* ids, size_t n) { FWD(wake_bodies(ids, n)); }
 // Checker for avn_level2_plan_* (header).  Deliberately organised the other way round from the product's planner: per colour a
 // body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
 // body in ascending index, so they come out sorted without sorting.

@@ -50,3 +50,12 @@ def dropped_boxes(seed=0, n=60, balls=True):
     bodies = dict(position=pos, rotation=rot, linear_velocity=lv, angular_velocity=av, inv_mass=inv_mass, inv_inertia_local=ii, rb_type=rb)
     colliders = dict(entity_index=np.arange(m, dtype=np.uint32) + 100, body=np.arange(m, dtype=np.int32), shape=shape, half_extents=he)
     return bodies, colliders
+
+
+def stack_and_projectile(nx=3, ny=3, nz=3, height=32.0, offset=(0.3, 0.0, 0.2)):
+    """A small box stack (settles and falls asleep within a second or two) and one more box high above it that lands on it later:
+    bodies = [ground, the stack ..., the projectile]."""
+    base = scenes.box_stack(nx, ny, nz)
+    centers = np.vstack([base.position[1:], [[offset[0], height, offset[2]]]])
+    sc = scenes._assemble(centers, (0.5, 0.5, 0.5), base.position[0], base.half_extents[0])
+    return sc
