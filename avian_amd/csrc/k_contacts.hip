@@ -446,7 +446,14 @@ __device__ __forceinline__ F2 operator-(F2 a, F2 b) { return F2(a.v - b.v); }
 __device__ __forceinline__ F2 operator*(F2 a, F2 b) { return F2(a.v * b.v); }
 __device__ __forceinline__ F2 operator-(F2 a) { return F2(-a.v); }
 // body1 (lo): a - b; body2 (hi): a + b   (apply_impulse's  v1 -= ..., v2 += ...)
-__device__ __forceinline__ F2 sub_lo_add_hi(F2 a, F2 b) { return F2(a.v + f2raw{-b.v.x, b.v.y}); }  // a - b == a + (-b) bit for bit: one v_pk_add_f32 with neg_lo
+// a - b == a + (-b) bit for bit: ONE v_pk_add_f32 with neg_lo on the second operand.  Written as inline asm: from `a.v + f2raw{-b.v.x, b.v.y}`
+// hipcc builds the half-negated vector first (v_pk_add_f32 t, b, 0 neg_lo neg_hi; v_mov_b32 t.hi, b.hi) -- three instructions per component,
+// 2 x 6 components x 8 impulse applications = 96 of the ~1 500 VALU issues of a lane's solve (round 3: the "v_mov pack / unpack" of the ISA).
+__device__ __forceinline__ F2 sub_lo_add_hi(F2 a, F2 b) {
+    f2raw r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    return F2(r);
+}
 __device__ __forceinline__ V3<F2> sub_lo_add_hi(V3<F2> a, V3<F2> b) { return {sub_lo_add_hi(a.x, b.x), sub_lo_add_hi(a.y, b.y), sub_lo_add_hi(a.z, b.z)}; }
 __device__ __forceinline__ V3<F2> pair3(V3<float> lo, V3<float> hi) { return {F2(lo.x, hi.x), F2(lo.y, hi.y), F2(lo.z, hi.z)}; }
 __device__ __forceinline__ V3<F2> splat3(V3<float> a) { return {F2(a.x), F2(a.y), F2(a.z)}; }

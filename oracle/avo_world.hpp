@@ -376,6 +376,7 @@ template <class S> struct World : WorldBase {
     avn_status pipeline_stats_get(avn_pipeline_stats* o) override;
     avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override;
     avn_status pipeline_step();
+    avn_status pipeline_refresh_handles();
     // ---- persistent islands + sleeping in the closed loop (header: avn_sleeping_enable; avo_islands.hpp) ----
     struct Sleeping {
         avn_sleep_params p;
@@ -2142,6 +2143,22 @@ template <class S> avn_status World<S>::pipeline_handles_get(uint32_t* off, cons
     *ids = pipe->handles.data(); *n = pipe->handles.size();
     return AVN_OK;
 }
+// GraphColor::manifold_handles of all colours, concatenated colour-major -> the solver's handle list (when the lists changed)
+template <class S> avn_status World<S>::pipeline_refresh_handles() {
+    PipelineState& P = *pipe;
+    if (!P.handles_dirty) return AVN_OK;
+    size_t n = 0;
+    P.handles.clear();
+    for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+        P.offsets[c] = (uint32_t)n;
+        for (const auto& h : P.graph.colors[c].manifold_handles) { P.handles.push_back((uint32_t)(h.handle >> 8)); ++n; }
+    }
+    P.offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+    avn_status st = manifold_handles_upload(P.offsets, P.handles.data());
+    if (st != AVN_OK) return st;
+    P.handles_dirty = false;
+    return AVN_OK;
+}
 template <class S> avn_status World<S>::pipeline_step() {
     PipelineState& P = *pipe;
     diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
@@ -2224,18 +2241,8 @@ template <class S> avn_status World<S>::pipeline_step() {
         slp->isl.flush_wake();
         sleeping_apply(false);
     }
-    if (P.handles_dirty) {
-        size_t n = 0;
-        P.handles.clear();
-        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
-            P.offsets[c] = (uint32_t)n;
-            for (const auto& h : P.graph.colors[c].manifold_handles) { P.handles.push_back((uint32_t)(h.handle >> 8)); ++n; }
-        }
-        P.offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
-        st = manifold_handles_upload(P.offsets, P.handles.data());
-        if (st != AVN_OK) return st;
-        P.handles_dirty = false;
-    }
+    st = pipeline_refresh_handles();
+    if (st != AVN_OK) return st;
     P.stats.last_overflow_manifolds = P.offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - P.offsets[AVN_COLOR_OVERFLOW_INDEX];
     diag.narrow_phase_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - np_t0).count();
     if (pipe_stats_on) {
@@ -2286,7 +2293,7 @@ template <class S> avn_status World<S>::pipeline_step() {
     }
     solver();
     diag.contact_count = (uint32_t)P.active.size();
-    if (slp) sleeping_systems();
+    if (slp) { sleeping_systems(); return pipeline_refresh_handles(); }   // (SleepIslands / WakeIslands changed the colour lists: what avn_pipeline_handles_get shows is the state after the step)
     return AVN_OK;
 }
 
@@ -2406,7 +2413,7 @@ template <class S> avn_status World<S>::wake_bodies(const uint32_t* ids, size_t 
         slp->isl.wake_body(ids[i]);
         sleeping_apply(false);
     }
-    return AVN_OK;
+    return pipeline_refresh_handles();
 }
 
 }  // namespace avo
