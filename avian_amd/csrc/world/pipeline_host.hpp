@@ -39,7 +39,12 @@
     }
     avn_status pipeline_stats_get(avn_pipeline_stats* o) override {
         if (!o) return AVN_ERR_BAD_ARG;
-        if (pipe_dev) { pipe_stats.active_pairs = pgm_live; pipe_stats.manifolds = dw.n_manifolds; *o = pipe_stats; return AVN_OK; }
+        if (pipe_dev) {
+            avn_islands_stats is; std::memset(&is, 0, sizeof is);
+            if (slp_on) isl.stats(&is);
+            pipe_stats.active_pairs = pgm_live - is.sleeping_pairs;   // ContactGraph::active_pairs: the pairs of sleeping_pairs are not among them
+            pipe_stats.manifolds = dw.n_manifolds; *o = pipe_stats; return AVN_OK;
+        }
         pipe_stats.active_pairs = (uint32_t)pipe_active.size();
         pipe_stats.manifolds = (uint32_t)pipe_handles.size();
         *o = pipe_stats;
