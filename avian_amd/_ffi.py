@@ -527,10 +527,12 @@ class World:
         self._check(self.lib.fn("bodies_upload")(self.handle, C.byref(b)))
         self.n_bodies = n
 
-    def bodies_download(self):
+    def bodies_download(self, out=None):
+        """``out``: a dict of preallocated arrays of the world's scalar type (e.g. page-locked staging) to download into."""
         n, dt = self.n_bodies, self.dtype
-        out = {"position": np.empty((n, 3), dt), "rotation": np.empty((n, 4), dt),
-               "linear_velocity": np.empty((n, 3), dt), "angular_velocity": np.empty((n, 3), dt)}
+        if out is None:
+            out = {"position": np.empty((n, 3), dt), "rotation": np.empty((n, 4), dt),
+                   "linear_velocity": np.empty((n, 3), dt), "angular_velocity": np.empty((n, 3), dt)}
         o = avn_bodies_out(*[_ptr(out[k]) for k in ("position", "rotation", "linear_velocity", "angular_velocity")])
         self._check(self.lib.fn("bodies_download")(self.handle, C.byref(o)))
         return out
@@ -562,10 +564,11 @@ class World:
         self._check(self.lib.fn("manifolds_upload")(self.handle, C.byref(s)))
         self.n_manifolds = m
 
-    def impulses_download(self):
+    def impulses_download(self, out=None):
         m, dt = self.n_manifolds, self.dtype
-        out = {"warm_start_normal_impulse": np.zeros((m, 4), dt), "warm_start_tangent_impulse": np.zeros((m, 4, 2), dt),
-               "normal_impulse": np.zeros((m, 4), dt)}
+        if out is None:
+            out = {"warm_start_normal_impulse": np.zeros((m, 4), dt), "warm_start_tangent_impulse": np.zeros((m, 4, 2), dt),
+                   "normal_impulse": np.zeros((m, 4), dt)}
         o = avn_impulses_out(*[_ptr(out[k]) for k, _ in avn_impulses_out._fields_])
         self._check(self.lib.fn("impulses_download")(self.handle, C.byref(o)))
         return out

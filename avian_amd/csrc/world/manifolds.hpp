@@ -12,12 +12,6 @@
         if (m->color_offsets[0] != 0 || m->color_offsets[AVN_GRAPH_COLOR_COUNT] != M) { error = "manifolds_upload: bad color_offsets"; return AVN_ERR_BAD_ARG; }
         for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c)
             if (m->color_offsets[c] > m->color_offsets[c + 1]) { error = "manifolds_upload: color_offsets not monotone"; return AVN_ERR_BAD_ARG; }
-        for (uint32_t i = 0; i < M; ++i) {
-            if (m->body1[i] < 0 || m->body2[i] < 0 || (uint32_t)m->body1[i] >= dw.n_bodies || (uint32_t)m->body2[i] >= dw.n_bodies) { error = "manifolds_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
-            if (m->point_count[i] > AVN_MAX_MANIFOLD_POINTS) { error = "manifolds_upload: point_count > 4"; return AVN_ERR_BAD_ARG; }
-        }
-        any_restitution = false;
-        for (uint32_t i = 0; i < M && !any_restitution; ++i) any_restitution = !(((const T*)m->restitution)[i] == T(0));
         if (use_handles) graph_valid = false;
         use_handles = false;  // the manifolds come from the host again
         avn_status st0 = ensure_manifold_capacity(M);
@@ -39,8 +33,32 @@
         SIN(warm_n, m->warm_start_normal_impulse, 4 * (size_t)M, T); SIN(warm_t, m->warm_start_tangent_impulse, 8 * (size_t)M, T);
         launch_pack_manifolds<T>(dw, s, stream);
         HIPCHK(hipGetLastError());
-        h_m_body1.assign(m->body1, m->body1 + M);
-        h_m_body2.assign(m->body2, m->body2 + M);
+        // (while the copies run) one pass over the host arrays: range checks, "any restitution", and the host copy of the ContactPair bodies (incidence CSR source)
+        {
+            const uint32_t nb = dw.n_bodies;
+            const T* rest = (const T*)m->restitution;
+            h_m_body1.resize(M); h_m_body2.resize(M);
+            bool bad_body = false, bad_pc = false, any_r = false;
+            for (uint32_t i = 0; i < M; ++i) {
+                const int32_t a = m->body1[i], b = m->body2[i];
+                bad_body |= (uint32_t)a >= nb || (uint32_t)b >= nb;   // (negative indices wrap above nb)
+                bad_pc |= m->point_count[i] > AVN_MAX_MANIFOLD_POINTS;
+                any_r |= !(rest[i] == T(0));
+                h_m_body1[i] = a; h_m_body2[i] = b;
+            }
+            any_restitution = any_r;
+            if (bad_body || bad_pc) {   // nothing of a rejected upload may be solved: the world is left without manifolds
+                HIPCHK(hipStreamSynchronize(stream));
+                uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+                dw.n_manifolds = 0; h_m_body1.clear(); h_m_body2.clear();
+                set_color_offsets(zero);
+                HIPCHK(hipMemcpyAsync(dw.color_offsets, zero, sizeof zero, hipMemcpyHostToDevice, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                graph_valid = false; incidence_dirty = true;
+                error = bad_body ? "manifolds_upload: body index out of range" : "manifolds_upload: point_count > 4";
+                return AVN_ERR_BAD_ARG;
+            }
+        }
         incidence_dirty = true;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;

@@ -232,8 +232,9 @@ def permute_manifolds(mf: Dict[str, np.ndarray], perm: np.ndarray) -> Dict[str, 
 def upload_manifolds(world: F.World, mf: Dict[str, np.ndarray], color_offsets: np.ndarray, friction, restitution,
                      warm_n: Optional[np.ndarray] = None, warm_t: Optional[np.ndarray] = None):
     m = len(mf["body1"])
-    fr = np.broadcast_to(np.asarray(friction, dtype=np.float64), (m,))
-    re = np.broadcast_to(np.asarray(restitution, dtype=np.float64), (m,))
+    # (arrays already in the world's scalar type pass through untouched: a host that keeps page-locked staging buffers hands them over as they are)
+    fr = friction if isinstance(friction, np.ndarray) and friction.shape == (m,) else np.broadcast_to(np.asarray(friction, dtype=np.float64), (m,))
+    re = restitution if isinstance(restitution, np.ndarray) and restitution.shape == (m,) else np.broadcast_to(np.asarray(restitution, dtype=np.float64), (m,))
     world.manifolds_upload(color_offsets=color_offsets, body1=mf["body1"], body2=mf["body2"], normal=mf["normal"],
                            friction=fr, restitution=re, point_count=mf["point_count"], anchor1=mf["anchor1"],
                            anchor2=mf["anchor2"], penetration=mf["penetration"], normal_speed=mf["normal_speed"],
