@@ -30,6 +30,9 @@ pub enum Mi355xMode {
     /// Ball / Cuboid colliders only: contact rows live in HBM, `NarrowPhase::update_contacts`, the status-change loop, the
     /// `ConstraintGraph` and the `IdPool` run on the device (`avn_pipeline_enable(1)`); per step only new pairs and body state cross
     /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_contact_changes_get` by `gpu_closed_loop_events`.
+    /// `CollisionHooks` (src/collision/hooks.rs:147-186) cannot run on the device: while any uploaded collider carries
+    /// `ActiveCollisionHooks` the plugin runs the step in `HostNarrowPhase` mode instead (`effective_mode`), where Avian's own narrow phase
+    /// calls `filter_pairs` / `modify_contacts` as always.
     ClosedLoop,
 }
 
@@ -42,7 +45,19 @@ pub struct Mi355xPhysicsPlugin {
 #[derive(Resource, Default)]
 struct Mi355xStaging(Staging);
 #[derive(Resource)]
-struct Mi355xSettings { mode: Mi355xMode }
+struct Mi355xSettings { mode: Mi355xMode, warned_hooks: bool }
+impl Mi355xSettings {
+    /// ClosedLoop only while no collider needs a host hook (hooks.rs:162-186: MODIFY_CONTACTS pairs must pass through `modify_contacts`,
+    /// FILTER_PAIRS pairs through `filter_pairs`); the switch is per step -- leaving / entering the device loop is avn_pipeline_enable(0 / 1),
+    /// which drops / rebuilds the device contact rows (one step without warm starting, like any ContactGraph rebuild).
+    fn effective_mode(&mut self, st: &Staging) -> Mi355xMode {
+        if self.mode == Mi355xMode::ClosedLoop && st.colliders_with_hooks != 0 {
+            if !self.warned_hooks { bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks: running in HostNarrowPhase mode", st.colliders_with_hooks); self.warned_hooks = true; }
+            return Mi355xMode::HostNarrowPhase;
+        }
+        self.mode
+    }
+}
 
 impl Plugin for Mi355xPhysicsPlugin {
     fn build(&self, app: &mut App) {
@@ -53,7 +68,7 @@ impl Plugin for Mi355xPhysicsPlugin {
             // no gfx950 device: there is no CPU fallback in the library -- the application keeps the stock plugins
             Err(e) => panic!("{e}: do not disable Avian's BroadPhasePlugin / IntegratorPlugin / SolverPlugin / XpbdSolverPlugin on a host without an MI355X"),
         };
-        app.insert_resource(world).init_resource::<Mi355xStaging>().insert_resource(Mi355xSettings { mode: self.mode });
+        app.insert_resource(world).init_resource::<Mi355xStaging>().insert_resource(Mi355xSettings { mode: self.mode, warned_hooks: false });
         app.init_resource::<SolverDiagnostics>().init_resource::<CollisionDiagnostics>();
 
         // the same sets as the plugins being replaced: src/collision/broad_phase.rs:51-74, src/dynamics/solver/plugin.rs:103-150,
@@ -62,7 +77,7 @@ impl Plugin for Mi355xPhysicsPlugin {
             PhysicsSchedule,
             (
                 (sync_config, gpu_upload_bodies, gpu_broad_phase).chain().in_set(BroadPhaseSystems::CollectCollisions),
-                gpu_upload_constraints.in_set(SolverSystems::PrepareContactConstraints).run_if(|s: Res<Mi355xSettings>| s.mode == Mi355xMode::HostNarrowPhase),
+                gpu_upload_constraints.in_set(SolverSystems::PrepareContactConstraints),   // (HostNarrowPhase steps only: checked inside)
                 gpu_solver.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER)
                 gpu_download.in_set(SolverSystems::StoreContactImpulses),
                 gpu_diagnostics.after(SolverSystems::StoreContactImpulses),
@@ -121,13 +136,16 @@ fn gpu_upload_bodies(
 /// BroadPhasePlugin replacement (src/collision/broad_phase.rs:347-474): device AABB update + sweep-and-prune; the new pairs come back in
 /// the reference's emission order and become `ContactEdge`s exactly as `sweep_and_prune` creates them (:443-468).
 fn gpu_broad_phase(
-    mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, settings: Res<Mi355xSettings>, mut contact_graph: ResMut<ContactGraph>,
+    mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>, mut contact_graph: ResMut<ContactGraph>,
     mut diagnostics: ResMut<CollisionDiagnostics>,
 ) {
-    if settings.mode == Mi355xMode::ClosedLoop { return; }   // avn_step runs the broad phase itself (gpu_solver)
+    let mode = settings.effective_mode(&st.0);
+    w.set_closed_loop(mode == Mi355xMode::ClosedLoop);      // avn_pipeline_enable(1 / 0) when the effective mode changed
+    if mode == Mi355xMode::ClosedLoop { return; }   // avn_step runs the broad phase itself (gpu_solver)
     w.run_system(ffi::AVN_SYS_UPDATE_AABB);
     w.run_system(ffi::AVN_SYS_COLLECT_COLLISION_PAIRS);
-    let entity_of = |index: u32| st.0.collider_entities[st.0.c_entity_index.iter().position(|&i| i == index).expect("collider of a device pair")];
+    // (an index map built with the upload: a linear `position()` per returned pair was O(n^2) at cfg2's 1.2 M first-frame pairs)
+    let entity_of = |index: u32| st.0.collider_entities[*st.0.collider_slot.get(&index).expect("collider of a device pair")];
     let pairs: Vec<ffi::avn_pair> = w.pairs().to_vec();
     for pair in pairs {
         // AVN_PAIR_NEEDS_CUSTOM_FILTER: CollisionHooks::filter_pairs cannot be called from the device (src/collision/broad_phase.rs:431-439):
@@ -147,7 +165,8 @@ fn gpu_broad_phase(
 }
 
 /// `prepare_contact_constraints` replacement (src/dynamics/solver/plugin.rs:363-448), host narrow phase mode: the colour-major manifold set.
-fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, constraint_graph: Res<ConstraintGraph>, contact_graph: Res<ContactGraph>) {
+fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>, constraint_graph: Res<ConstraintGraph>, contact_graph: Res<ContactGraph>) {
+    if settings.effective_mode(&st.0) != Mi355xMode::HostNarrowPhase { return; }
     st.0.fill_manifolds(&constraint_graph, &contact_graph);
     let m = st.0.manifolds_desc();
     let raw = w.raw();
@@ -158,8 +177,8 @@ fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStagi
 /// SolverSystems::PrepareSolverBodies .. Restitution in one call.  `SolverSchedulePlugin`'s own runner (src/dynamics/solver/schedule.rs:194-213)
 /// still loops over the (now nearly empty) `SubstepSchedule`; user systems added there see host `SolverBody` state only if the application
 /// opts into per-substep round trips (caveat).
-fn gpu_solver(mut w: ResMut<Mi355xWorld>, settings: Res<Mi355xSettings>) {
-    match settings.mode {
+fn gpu_solver(mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>) {
+    match settings.effective_mode(&st.0) {
         Mi355xMode::HostNarrowPhase => w.run_system(ffi::AVN_SYS_SOLVER),
         Mi355xMode::ClosedLoop => w.step(),   // avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
     }
@@ -167,7 +186,7 @@ fn gpu_solver(mut w: ResMut<Mi355xWorld>, settings: Res<Mi355xSettings>) {
 
 /// `writeback_solver_bodies` (src/dynamics/solver/solver_body/plugin.rs:255-284) + `store_contact_impulses` (src/dynamics/solver/plugin.rs:722-755).
 fn gpu_download(
-    mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, settings: Res<Mi355xSettings>,
+    mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>,
     mut bodies: Query<(&mut Position, &mut Rotation, &mut LinearVelocity, &mut AngularVelocity), With<SolverBody>>, mut contact_graph: ResMut<ContactGraph>,
 ) {
     let st = &mut st.0;
@@ -179,7 +198,7 @@ fn gpu_download(
         p.0 = Vec3::from_slice(&st.out_position[3 * i..]); r.0 = Quat::from_slice(&st.out_rotation[4 * i..]);
         lv.0 = Vec3::from_slice(&st.out_linear_velocity[3 * i..]); av.0 = Vec3::from_slice(&st.out_angular_velocity[3 * i..]);
     }
-    if settings.mode == Mi355xMode::HostNarrowPhase {
+    if settings.effective_mode(st) == Mi355xMode::HostNarrowPhase {
         let imp = st.impulses_out_desc();
         let s = unsafe { ffi::avn_impulses_download(raw, &imp) }; w.check(s);
         for (m, &(contact_id, manifold_index)) in st.m_handles.iter().enumerate() {

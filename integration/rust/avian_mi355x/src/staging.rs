@@ -20,6 +20,10 @@ pub struct Staging {
     pub rb_type: Vec<u8>, pub locked_axes: Vec<u8>, pub dominance: Vec<i8>, pub body_flags: Vec<u8>,
     // avn_colliders
     pub collider_entities: Vec<Entity>,
+    /// `Entity::index()` of a collider -> its slot of the last upload (what a device pair's collider index resolves through)
+    pub collider_slot: bevy::platform::collections::HashMap<u32, usize>,
+    /// colliders of the last upload that carry `ActiveCollisionHooks` (filter_pairs / modify_contacts need the host narrow phase)
+    pub colliders_with_hooks: usize,
     pub c_entity_index: Vec<u32>, pub c_body: Vec<i32>, pub c_shape: Vec<u8>, pub c_half_extents: Vec<f32>,
     pub c_memberships: Vec<u32>, pub c_filters: Vec<u32>, pub c_flags: Vec<u8>, pub c_margin: Vec<f32>, pub c_speculative: Vec<f32>,
     // avn_manifolds (colour-major: the order of GraphColor::manifold_handles, src/dynamics/solver/constraint_graph.rs:66-80)
@@ -95,13 +99,16 @@ impl Staging {
         colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
     ) {
         macro_rules! clear { ($($f:ident),*) => { $( self.$f.clear(); )* } }
-        clear!(collider_entities, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative);
+        clear!(collider_entities, collider_slot, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative);
+        self.colliders_with_hooks = 0;
         for (e, collider, of, layers, margin, spec, sensor, events, hooks) in colliders {
             let shape = collider.shape_scaled();
             let (kind, he) = if let Some(b) = shape.as_ball() { (ffi::AVN_SHAPE_BALL, Vec3::new(b.radius, 0.0, 0.0)) }
                              else if let Some(c) = shape.as_cuboid() { (ffi::AVN_SHAPE_CUBOID, Vec3::new(c.half_extents.x, c.half_extents.y, c.half_extents.z)) }
                              else { continue };
             let Some(&body) = self.body_index.get(&of.body) else { continue };
+            self.collider_slot.insert(e.index(), self.collider_entities.len());
+            if hooks { self.colliders_with_hooks += 1; }
             self.collider_entities.push(e);
             self.c_entity_index.push(e.index()); self.c_body.push(body); self.c_shape.push(kind as u8); push3(&mut self.c_half_extents, he);
             self.c_memberships.push(layers.memberships.0); self.c_filters.push(layers.filters.0);

@@ -23,6 +23,7 @@ impl std::error::Error for Mi355xError {}
 pub struct Mi355xWorld {
     raw: *mut ffi::avn_world,
     pub config: ffi::avn_config,
+    closed_loop: bool,
 }
 // SAFETY: the library keeps no thread-local state per world; `&mut self` on every call serialises access.
 unsafe impl Send for Mi355xWorld {}
@@ -38,7 +39,7 @@ impl Mi355xWorld {
             let message = unsafe { cstr(ffi::avn_last_error(core::ptr::null())) };
             return Err(Mi355xError { status, message });
         }
-        Ok(Self { raw, config })
+        Ok(Self { raw, config, closed_loop: false })
     }
 
     /// The reference's convention on invariant violations is to panic (src/dynamics/solver/plugin.rs:393-395, 735-739;
@@ -70,6 +71,36 @@ impl Mi355xWorld {
     pub fn step(&mut self) {
         let st = unsafe { ffi::avn_step(self.raw) };
         self.check(st);
+    }
+
+    /// `avn_pipeline_enable(1 / 0)` when the wanted state differs from the current one (the plugin's effective mode can change from one
+    /// step to the next: a collider gained or lost `ActiveCollisionHooks`).  Leaving the loop drops the device contact rows; entering it
+    /// starts from an empty ContactGraph on the device (include/avian_mi355x.h: avn_pipeline_enable).
+    pub fn set_closed_loop(&mut self, on: bool) {
+        if on == self.closed_loop { return; }
+        let st = unsafe { ffi::avn_pipeline_enable(self.raw, if on { 1 } else { 0 }) };
+        self.check(st);
+        self.closed_loop = on;
+    }
+
+    /// Persistent islands + sleeping inside the closed loop (`avn_sleeping_enable`): the library keeps its own island manager and actuates
+    /// sleeping on the device; `None` switches it off again.
+    pub fn set_sleeping(&mut self, params: Option<ffi::avn_sleep_params>) {
+        let st = unsafe { ffi::avn_sleeping_enable(self.raw, params.as_ref().map_or(core::ptr::null(), |p| p as *const _)) };
+        self.check(st);
+    }
+
+    /// `WakeBody` for bodies the application moved or kicked (src/dynamics/solver/islands/sleeping.rs:556-604 wake_on_changed).
+    pub fn wake_bodies(&mut self, bodies: &[u32]) {
+        let st = unsafe { ffi::avn_wake_bodies(self.raw, bodies.as_ptr(), bodies.len()) };
+        self.check(st);
+    }
+
+    pub fn sleeping_stats(&mut self) -> ffi::avn_sleeping_stats {
+        let mut s = unsafe { core::mem::zeroed::<ffi::avn_sleeping_stats>() };
+        let st = unsafe { ffi::avn_sleeping_stats_get(self.raw, &mut s) };
+        self.check(st);
+        s
     }
 
     /// New broad-phase pairs of the last `AVN_SYS_COLLECT_COLLISION_PAIRS`, in the reference's emission order.  The slice is owned by
