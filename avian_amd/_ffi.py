@@ -252,7 +252,7 @@ ABI_SYMBOLS = [
     "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
     "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
-    "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies",
+    "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange",
 ]
 
 
@@ -298,6 +298,7 @@ class Library:
         f("sleeping_stats_get").argtypes = [vp, C.POINTER(avn_sleeping_stats)]
         f("sleeping_state_get").argtypes = [vp, C.POINTER(avn_sleeping_out)]
         f("wake_bodies").argtypes = [vp, vp, C.c_size_t]
+        f("bounds_exchange").argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32), vp, C.c_uint32, C.POINTER(C.c_uint32)]
         f("comm_unique_id").argtypes = [vp]
         f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
         f("profile_system").argtypes = [vp, C.c_int, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
@@ -865,6 +866,14 @@ class World:
     def wake_bodies(self, bodies):
         b = np.ascontiguousarray(bodies, np.uint32)
         self._check(self.lib.fn("wake_bodies")(self.handle, _ptr(b), len(b)))
+
+    def bounds_exchange(self, max_ranks: int = 64):
+        """``avn_bounds_exchange``: (bounds [n_ranks, 6], overlapping rank pairs [k, 2]) -- the library reduces this world's dynamic bounds on the
+        device and all-gathers them over the communicator of comm_init (a world without one is its own only rank)."""
+        b = np.zeros((max_ranks, 6), np.float64); ov = np.zeros((max_ranks * max_ranks, 2), np.uint32)
+        n, k = C.c_uint32(), C.c_uint32()
+        self._check(self.lib.fn("bounds_exchange")(self.handle, _ptr(b), max_ranks, C.byref(n), _ptr(ov), len(ov), C.byref(k)))
+        return b[: n.value].copy(), ov[: min(k.value, len(ov))].astype(np.int64)
 
     def comm_init(self, unique_id: bytes, n_ranks: int, rank: int):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)

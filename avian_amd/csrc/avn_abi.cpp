@@ -143,6 +143,7 @@ AVN_API avn_status avn_islands_get(avn_world* w, uint32_t* island_of_body, uint3
 AVN_API avn_status avn_sleep_update(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* st) { GUARD(sleep_update(p, st)); }
 AVN_API avn_status avn_sleep_get(avn_world* w, const avn_sleep_out* o) { GUARD(sleep_get(o)); }
 AVN_API avn_status avn_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(sleep_reset(bodies, n)); }
+AVN_API avn_status avn_bounds_exchange(avn_world* w, double* bounds, uint32_t cap_ranks, uint32_t* n_ranks, uint32_t* overlaps, uint32_t cap_overlaps, uint32_t* n_overlaps) { GUARD(bounds_exchange(bounds, cap_ranks, n_ranks, overlaps, cap_overlaps, n_overlaps)); }
 AVN_API avn_status avn_sleeping_enable(avn_world* w, const avn_sleep_params* p) { GUARD(sleeping_enable(p)); }
 AVN_API avn_status avn_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { GUARD(sleeping_stats_get(o)); }
 AVN_API avn_status avn_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { GUARD(sleeping_state_get(o)); }

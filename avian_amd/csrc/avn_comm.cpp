@@ -21,6 +21,7 @@ struct Rccl {
     ncclResult_t (*GroupEnd)() = nullptr;
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
 };
@@ -37,7 +38,7 @@ void load_once() {
     for (const char* n : names) { g_rccl.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL); if (g_rccl.lib) break; }
     if (!g_rccl.lib) { g_rccl.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "dlopen failed"); return; }
     bool ok = sym(g_rccl.GetUniqueId, "ncclGetUniqueId") && sym(g_rccl.CommInitRank, "ncclCommInitRank") && sym(g_rccl.CommDestroy, "ncclCommDestroy") &&
-              sym(g_rccl.GroupStart, "ncclGroupStart") && sym(g_rccl.GroupEnd, "ncclGroupEnd") && sym(g_rccl.Send, "ncclSend") && sym(g_rccl.Recv, "ncclRecv") &&
+              sym(g_rccl.GroupStart, "ncclGroupStart") && sym(g_rccl.GroupEnd, "ncclGroupEnd") && sym(g_rccl.Send, "ncclSend") && sym(g_rccl.Recv, "ncclRecv") && sym(g_rccl.AllGather, "ncclAllGather") &&
               sym(g_rccl.GetErrorString, "ncclGetErrorString");
     if (!ok) { dlclose(g_rccl.lib); g_rccl.lib = nullptr; }
 }
@@ -91,6 +92,14 @@ avn_status Comm::exchange(const CommXfer* sends, size_t n_sends, const CommXfer*
     ncclResult_t e = g_rccl.GroupEnd();
     if (r != ncclSuccess) return fail(err, "ncclSend/ncclRecv", r);
     if (e != ncclSuccess) return fail(err, "ncclGroupEnd", e);
+    return AVN_OK;
+}
+
+// Level-1 sharding's only per-step exchange: every rank's dynamic bounds (48 bytes) to every rank.
+avn_status Comm::all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s, std::string& err) {
+    if (!handle) { err = "all-gather without a communicator (avn_comm_init)"; return AVN_ERR_STATE; }
+    ncclResult_t r = g_rccl.AllGather(send, recv, bytes_per_rank, ncclUint8, (ncclComm_t)handle, s);
+    if (r != ncclSuccess) return fail(err, "ncclAllGather", r);
     return AVN_OK;
 }
 

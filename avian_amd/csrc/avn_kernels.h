@@ -103,6 +103,7 @@ template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const u
 template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const SweepScratch&, hipStream_t);
 template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const SweepScratch&, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
 size_t sweep_long_item_bytes();
+template <class T> void launch_bounds_reduce(const T* partial, uint32_t n_partials, double* out6, hipStream_t);   // k_dynamic_bounds' partials -> one (min, max)
 uint32_t sweep_pad_records();
 uint32_t sweep_bounds_group();  // sorted records per y/z bounds group of the sweep's batch cull
 uint32_t sweep_bounds_words(uint32_t n_records);          // Vec4 records of BP::s_bb for both cull levels

@@ -95,6 +95,7 @@ struct WorldBase {
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
     virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
     virtual avn_status comm_init(const uint8_t*, int, int) = 0;
+    virtual avn_status bounds_exchange(double*, uint32_t, uint32_t*, uint32_t*, uint32_t, uint32_t*) = 0;
     virtual avn_status islands_get(uint32_t*, uint32_t*) = 0;
     virtual avn_status sleep_update(const avn_sleep_params*, avn_sleep_stats*) = 0;
     virtual avn_status sleep_get(const avn_sleep_out*) = 0;
@@ -113,6 +114,7 @@ struct Comm {
     ~Comm();
     avn_status init(const uint8_t* unique_id, int n_ranks, int rank, std::string& err);
     avn_status exchange(const CommXfer* sends, size_t n_sends, const CommXfer* recvs, size_t n_recvs, hipStream_t s, std::string& err);
+    avn_status all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t s, std::string& err);
 };
 avn_status comm_unique_id(uint8_t* out, std::string& err);
 

@@ -110,6 +110,24 @@ template <class T> uint32_t launch_dynamic_bounds(const DW<T>& w, const BP<T>& b
     return nb;
 }
 
+// the per-workgroup partials of k_dynamic_bounds -> (min.xyz, max.xyz) as doubles: what a rank sends into the bounds all-gather
+template <class T>
+__global__ __launch_bounds__(64) void k_bounds_reduce(const T* __restrict__ partial, uint32_t nb, double* __restrict__ out) {
+    const uint32_t t = threadIdx.x;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double v[6] = {inf, inf, inf, -inf, -inf, -inf};
+    for (uint32_t b = t; b < nb; b += 64)
+        for (int k = 0; k < 6; ++k) { const double x = (double)partial[b * 6 + k]; v[k] = k < 3 ? (x < v[k] ? x : v[k]) : (x > v[k] ? x : v[k]); }
+    for (int off = 32; off > 0; off >>= 1)
+        for (int k = 0; k < 6; ++k) { const double o = __shfl_xor(v[k], off); v[k] = k < 3 ? (o < v[k] ? o : v[k]) : (o > v[k] ? o : v[k]); }
+    if (t < 6) out[t] = v[t];
+}
+template <class T> void launch_bounds_reduce(const T* partial, uint32_t nb, double* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_bounds_reduce<T>, dim3(1), dim3(64), 0, s, partial, nb, out);
+}
+template void launch_bounds_reduce<float>(const float*, uint32_t, double*, hipStream_t);
+template void launch_bounds_reduce<double>(const double*, uint32_t, double*, hipStream_t);
+
 // ---------------------------------------------------------------------------------------------------------
 // keys
 __device__ __forceinline__ uint32_t order_key(float x) {

@@ -124,6 +124,39 @@
         HIPCHK(hipStreamSynchronize(stream));
         return comm.init(unique_id, n_ranks, rank, error);
     }
+    // ---- level-1 sharding: the bounds all-gather behind the ABI (avn_bounds_exchange) ---------------------------------------------------------
+    DevBuf b_bounds_send, b_bounds_recv;
+    avn_status bounds_exchange(double* bounds, uint32_t cap_ranks, uint32_t* n_ranks_out, uint32_t* overlaps, uint32_t cap_overlaps, uint32_t* n_overlaps) override {
+        const uint32_t nr = comm.handle ? (uint32_t)comm.n_ranks : 1u;
+        if (n_ranks_out) *n_ranks_out = nr;
+        if (!bounds || cap_ranks < nr) { error = "bounds_exchange: the bounds array must hold n_ranks x 6 doubles"; return AVN_ERR_BAD_ARG; }
+        avn_status st = need_bodies();
+        if (st != AVN_OK) return st;
+        hipError_t err;
+        b_bounds_send.ensure(6 * sizeof(double), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_bounds_recv.ensure((size_t)nr * 6 * sizeof(double), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        const uint32_t nb = (bp.n_colliders + 255) / 256;
+        if ((st = stage_reserve((size_t)std::max(nb, 1u) * 6 * sizeof(T) + 1024)) != AVN_OK) return st;
+        T* part = stage_alloc<T>((size_t)std::max(nb, 1u) * 6);
+        launch_dynamic_bounds<T>(dw, bp, part, stream);
+        launch_bounds_reduce<T>(part, nb, b_bounds_send.as<double>(), stream);
+        launches += 2;
+        HIPCHK(hipGetLastError());
+        if (comm.handle) { if ((st = comm.all_gather(b_bounds_send.p, b_bounds_recv.p, 6 * sizeof(double), stream, error)) != AVN_OK) return st; }
+        else HIPCHK(hipMemcpyAsync(b_bounds_recv.p, b_bounds_send.p, 6 * sizeof(double), hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemcpyAsync(bounds, b_bounds_recv.p, (size_t)nr * 6 * sizeof(double), hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipStreamSynchronize(stream));
+        uint32_t found = 0;
+        for (uint32_t i = 0; i < nr; ++i)
+            for (uint32_t j = i + 1; j < nr; ++j) {
+                const double *a = bounds + 6 * i, *b = bounds + 6 * j;
+                bool hit = true;
+                for (int k = 0; k < 3; ++k) hit = hit && a[k] <= b[3 + k] && a[3 + k] >= b[k];   // ColliderAabb::intersects (closed intervals); empty bounds (+inf, -inf) never hit
+                if (hit) { if (overlaps && found < cap_overlaps) { overlaps[2 * found] = i; overlaps[2 * found + 1] = j; } ++found; }
+            }
+        if (n_overlaps) *n_overlaps = found;
+        return AVN_OK;
+    }
     // the exchange after colour c inside avn_step: everything is enqueued on the world's stream, no host code waits
     avn_status halo_exchange(uint32_t c) {
         const size_t np = halo.peers.size(), k0 = (size_t)c * np;

@@ -648,6 +648,13 @@ AVN_API avn_status AVN_FN(level2_plan_rank)(const avn_level2_plan* plan, uint32_
 #define AVN_COMM_ID_BYTES 128
 AVN_API avn_status AVN_FN(comm_unique_id)(uint8_t* out /* [AVN_COMM_ID_BYTES] */);
 AVN_API avn_status AVN_FN(comm_init)(avn_world* w, const uint8_t* unique_id, int n_ranks, int rank);
+/* Level-1 sharding's per-step exchange, issued BY THE LIBRARY: this world's dynamic bounds (avn_dynamic_bounds: union of the ColliderAabbs of the
+ * colliders on non-static bodies, after AVN_SYS_UPDATE_AABB / avn_step) are reduced on the device and all-gathered over the communicator of
+ * avn_comm_init (ncclAllGather of 48 bytes per rank on the world's stream; without a communicator the world is its own only rank).
+ * bounds [n_ranks][6] = (min.xyz, max.xyz) per rank; overlaps [cap][2]: the rank pairs (i < j) whose bounds intersect -- islands of different
+ * ranks coming into AABB contact, the trigger of the re-partition (avian_amd/shard.py: repartition; broad_phase.rs:373-474 decides pairs on
+ * the same closed-interval test).  *n_overlaps = how many exist (may exceed cap). */
+AVN_API avn_status AVN_FN(bounds_exchange)(avn_world* w, double* bounds, uint32_t cap_ranks, uint32_t* n_ranks, uint32_t* overlaps, uint32_t cap_overlaps, uint32_t* n_overlaps);
 
 /* PairKey::new (data_structures/pair_key.rs:14-21) — exported so hosts build identical keys */
 AVN_API uint64_t AVN_FN(pair_key)(uint32_t id1, uint32_t id2);

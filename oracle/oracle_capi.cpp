@@ -60,6 +60,13 @@ avn_status avo_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const vo
 // the CPU checker has no device transport: the host moves the records (avn_halo_pack / avn_halo_unpack)
 avn_status avo_comm_unique_id(uint8_t* out) { if (!out) return AVN_ERR_BAD_ARG; std::memset(out, 0, AVN_COMM_ID_BYTES); return AVN_OK; }
 avn_status avo_comm_init(avn_world*, const uint8_t*, int, int) { return AVN_ERR_STATE; }
+// (no transport in the checker: a world is its own only rank)
+avn_status avo_bounds_exchange(avn_world* w, double* bounds, uint32_t cap_ranks, uint32_t* n_ranks, uint32_t*, uint32_t, uint32_t* n_overlaps) {
+    if (!w || !bounds || cap_ranks < 1) return AVN_ERR_BAD_ARG;
+    if (n_ranks) *n_ranks = 1;
+    if (n_overlaps) *n_overlaps = 0;
+    return w->impl->dynamic_bounds(bounds, bounds + 3);
+}
 avn_status avo_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { FWD(profile_system(s, r, ms, l)); }
 avn_status avo_dynamic_bounds(avn_world* w, double* mn, double* mx) { FWD(dynamic_bounds(mn, mx)); }
 avn_status avo_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { FWD(contact_manifolds(p, o)); }

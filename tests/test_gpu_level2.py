@@ -93,6 +93,12 @@ for bits in (32, 64):
     for k in ia:
         assert np.array_equal(ia[k], ib[k]), (bits, k)
     assert float(np.abs(a["linear_velocity"]).max()) > 0.05
+    # level 1's exchange through the same communicator: ncclAllGather of the device-reduced bounds == avn_dynamic_bounds, no overlaps with itself
+    bounds, ov = looped.bounds_exchange()
+    mn, mx = looped.dynamic_bounds()
+    assert bounds.shape == (1, 6) and np.array_equal(bounds[0], np.concatenate([mn, mx])) and len(ov) == 0, (bounds, mn, mx)
+    b0, ov0 = plain.bounds_exchange()     # no communicator: a world is its own only rank
+    assert np.array_equal(b0[0], np.concatenate(plain.dynamic_bounds())) and len(ov0) == 0
 print("SELF_EXCHANGE_OK")
 """
 

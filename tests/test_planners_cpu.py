@@ -71,3 +71,15 @@ def test_interval_orders_merge_equals_numpy(name, getlib):
         want = shard.merge_interval_orders(states)
         got = lib.interval_orders_merge(ents, keys)
         assert np.array_equal(got, want), (name, trial)
+
+
+def test_bounds_exchange_of_a_single_rank_is_its_own_bounds():
+    """avn_bounds_exchange on the oracle (no transport: one rank): the row equals avn_dynamic_bounds."""
+    from avian_amd import scenes
+    sc = scenes.box_stack(3, 3, 3)
+    w = F.World(oracle_lib(), F.default_config(32))
+    w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+    w.run_system("UPDATE_AABB")
+    b, ov = w.bounds_exchange()
+    mn, mx = w.dynamic_bounds()
+    assert b.shape == (1, 6) and np.array_equal(b[0], np.concatenate([mn, mx])) and len(ov) == 0
