@@ -370,13 +370,19 @@ def main():
                   "note": "avn_pipeline_enable(1): broad phase -> Ball/Cuboid narrow phase (parry part parity-unpinned) -> status-change loop, greedy colouring, handle lists "
                           "and the overflow colour's order ALL on the device; per step the host reads three counter blocks"}
         del wc
-        # ---- the same loop with persistent islands + sleeping (avn_sleeping_enable): N is not constant any more -- every
-        # window reports the awake body count next to its time.  A 12.5 k-box stack plus one box dropped on it from 40 m (lands at ~2.8 s):
-        # the lattice settles, is split and put to sleep, wakes itself when a still-active pair starts touching, is woken by the impact.
+        # ---- the closed loop with persistent islands + sleeping (avn_sleeping_enable): N is not constant any more -- every
+        # window reports the awake body count next to its time.  Scene: the reference's own "Many Pyramids 3D" bench (10 x 10 pyramids of base 10:
+        # 5 500 boxes in 100 islands, benches/src/dim3/many_pyramids.rs:15-64) plus one box dropped from 35 m onto one pyramid (lands at ~2.7 s):
+        # the islands settle and fall asleep one by one, the impact wakes exactly one of them.  (cfg2's 100 k lattice never rests long enough:
+        # it is split and put to sleep, and woken again by a still-active pair that starts touching in the next narrow phase.)
         try:
             from avian_amd import scenes as _sc
-            base = _sc.box_stack(25, 20, 25)
-            scs = _sc._assemble(np.vstack([base.position[1:], [[0.3, 60.0, 0.2]]]), (0.5, 0.5, 0.5), base.position[0], base.half_extents[0])
+            base = _sc.many_pyramids(10, 10, 10)
+            top = base.position[10:][np.argmax(base.position[10:, 1])]
+            extra = np.array([[top[0] + 0.2, top[1] + 35.0, top[2] + 0.1]])
+            scs = _sc.Scene(np.vstack([base.position, extra]), np.vstack([base.rotation, [[0, 0, 0, 1.0]]]), np.vstack([base.linear_velocity, [[0, 0, 0.0]]]),
+                            np.vstack([base.angular_velocity, [[0, 0, 0.0]]]), np.append(base.inv_mass, base.inv_mass[-1]), np.vstack([base.inv_inertia_local, base.inv_inertia_local[-1:]]),
+                            np.append(base.rb_type, 0).astype(np.uint8), np.vstack([base.half_extents, [[0.5, 0.5, 0.5]]]), np.append(base.shape, 0).astype(np.uint8))
             ws = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
             ws.bodies_upload(**scs.body_kwargs()); ws.colliders_upload(**scs.collider_kwargs())
             ws.existing_pairs_upload(np.zeros(0, np.uint64)); ws.collider_materials_upload(friction=scs.friction, restitution=scs.restitution)
@@ -385,7 +391,7 @@ def main():
             budget_t0 = time.perf_counter()
             for wi in range(5):
                 c0 = time.perf_counter(); awake = host = 0.0; slept = woken = 0
-                n_w = 60
+                n_w = 50
                 for _ in range(n_w):
                     ws.step()
                     st = ws.sleeping_stats(); awake += st.n_awake_bodies; host += st.last_host_ms; slept += st.last_islands_slept; woken += st.last_islands_woken
@@ -397,8 +403,9 @@ def main():
                              "sleeping_islands_at_end": int(st.islands.n_sleeping_islands), "splits_total": int(st.islands.splits), "manifolds_at_end": int(ws.pipeline_stats().manifolds)})
                 if time.perf_counter() - budget_t0 > 60:
                     break
-            closed["sleeping"] = {"scene": "12 500-box stack + one box dropped from 60 m, f32, 4 substeps, avn_sleeping_enable (thresholds 0.15 / 0.15, time_to_sleep 0.5 s)",
-                                  "dynamic_bodies": int(scs.n - 1), "windows": wins,
+            closed["sleeping"] = {"scene": "Many Pyramids 3D (5 500 boxes, 100 islands, 10 static grounds) + one box dropped from 35 m, f32, 4 substeps, avn_sleeping_enable "
+                                           "(thresholds 0.15 / 0.15, time_to_sleep 0.5 s)",
+                                  "dynamic_bodies": int((scs.rb_type == 0).sum()), "windows": wins,
                                   "note": "persistent islands, deferred split, SleepIslands / WakeIslands with the reference's pop / push order (host island manager + device op pipeline); "
                                           "avn_step synchronises at its end in this mode"}
             del ws
