@@ -132,7 +132,7 @@
     // memory (no extra synchronisation: the copy rides the stream); whoever synchronises next -- avn_synchronize, the next avn_step -- reports
     // it under the name of the kernel that raised it and clears it.
     hipEvent_t ev_np_fork = nullptr, ev_np_old = nullptr;
-    bool np_overlap_enabled = getenv("AVN_NO_NP_OVERLAP") == nullptr;
+    bool np_overlap_enabled = !(getenv("AVN_NO_NP_OVERLAP") && getenv("AVN_NO_NP_OVERLAP")[0] && getenv("AVN_NO_NP_OVERLAP")[0] != '0');
     uint32_t* h_pg_error = nullptr;   // pinned
     bool pg_error_pending = false;
     avn_status pg_error_fetch() {     // enqueue the read-back behind everything the step launched
