@@ -52,7 +52,7 @@ template <class T> struct StepParams {
     SoftCoef<T> soft_dynamic, soft_non_dynamic;
     uint32_t restitution_iterations;
     uint32_t match_contacts;
-    uint32_t np_debug;   // measurement aid (AVN_NP_DEBUG): 1 = the narrow phase stops after its input loads, 2 = after the SAT (results are wrong: timing only)
+    uint32_t np_debug;   // measurement aid (AVN_NP_DEBUG): 1 = the narrow phase stops after its input loads, 2 = after the SAT; 3 / 4 / 5 = the heavy kernel stops after its loads / after the clipping / after the pruning (results are wrong: timing only; AVN_NP_DEBUG_STEP = the one closed-loop step it applies to)
 };
 
 // Two Vec4 records of a body that are always touched together (linear|angular velocity, delta position|rotation, the

@@ -40,7 +40,9 @@ struct SweepScratch {
     uint32_t* long_off;     // [long_cap] chunk offset inside its interval's output range
     uint32_t* n_long;       // [2] device counters: chunks used, overflow flag
     uint32_t long_cap;
+    uint32_t* hits;         // [sweep_hit_words(n)] per wave of k_sweep: (pairs found by the count pass, the first few as (lane, j) records)
 };
+size_t sweep_hit_words(uint32_t n_intervals);
 
 enum { PASS_WARM_START = 0, PASS_SOLVE_BIAS = 1, PASS_SOLVE_RELAX = 2, PASS_RESTITUTION_ = 3, PASS_WARM_START_COLORS = 4 /* manifold-centric, one launch per colour */, PASS_MEMORY_SKELETON = 5 /* loads + stores of the solve pass, no solve */ };
 
@@ -125,7 +127,13 @@ template <class T> struct CT {
     Vec4<T>* w;        // [p][row] (warm_start_normal, warm_start_tangent.x, .y, normal_impulse)
     uint2* fid;        // [p][row] (feature_id1, feature_id2)
     Vec4<T>* col_mat;  // per collider slot: (friction, restitution, bits(friction_combine | restitution_combine << 8), 0)
+    // the narrow phase's hand-over between its two kernels: the cuboid pairs that survive the SAT (k_narrow.hip)
+    uint32_t* np_row;  // [cap + slack] row ids: 64 lists, arbitrary order inside a list
+    T* np_axis;        // [3 (cap + slack)] the separating direction the SAT found for np_row[k]
+    uint32_t* np_ctr;  // per list, a cache line apart: (entries, workgroups of the second kernel that are done); zero between launches
 };
+size_t np_survivor_list_slack();     // entries np_row / np_axis need beyond `cap`
+size_t np_survivor_counter_bytes();  // size of np_ctr
 template <class T> void launch_init_contact_rows(const CT<T>&, const uint32_t* ids, const uint32_t* slot1, const uint32_t* slot2, const uint32_t* pair_flags, uint32_t n, hipStream_t);
 template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* ids, uint32_t n, hipStream_t);
 // NarrowPhase::update_contacts over the active pairs; changes[0..*n_changes) in arbitrary order (the host sorts by id)

@@ -294,7 +294,7 @@ template <class T, class Em> __device__ void face_face_contacts(const Iso<T>& po
 // *defer = true (nothing of `out` is valid); called again with *defer == true it skips the SAT and continues from *axis.  A caller that
 // gathers the survivors of a workgroup into dense waves (k_narrow_phase) runs the heavy half at full lane occupancy; the result is the
 // one-call result bit for bit.
-template <class T, class Sink>
+template <class T, class Sink, int MODE = 0>   // MODE 1: `defer` given and false on entry (stop after the SAT), 2: given and true (continue from *axis), 0: decided at run time
 __device__ bool contact_manifolds_pair_sink(uint32_t shape1, V3<T> he1, V3<T> position1, Q4<T> rotation1, uint32_t shape2, V3<T> he2, V3<T> position2, Q4<T> rotation2,
                                             T prediction, Sink& sink, V3<T>& normal_out, bool* defer = nullptr, V3<T>* axis = nullptr) {
     Iso<T> isometry1 = make_isometry(position1, rotation1), isometry2 = make_isometry(position2, rotation2);
@@ -338,7 +338,7 @@ __device__ bool contact_manifolds_pair_sink(uint32_t shape1, V3<T> he1, V3<T> po
     } else {  // contact_manifold_cuboid_cuboid
         Iso<T> pos21 = iso_inverse(pos12);
         V3<T> best;
-        if (defer && *defer) best = *axis;
+        if (MODE == 2 || (MODE == 0 && defer && *defer)) best = *axis;
         else {
             V3<T> d1, d2, d3;
             T sep1 = sat_normal_oneway(he1, he2, pos12, d1);
@@ -350,7 +350,7 @@ __device__ bool contact_manifolds_pair_sink(uint32_t shape1, V3<T> he1, V3<T> po
             best = d1;
             if (sep2 > sep1 && sep2 > sep3) best = iso_vec(pos12, -d2);
             else if (sep3 > sep1) best = d3;
-            if (defer) { *defer = true; *axis = best; return false; }
+            if (MODE == 1 || (MODE == 0 && defer)) { *defer = true; *axis = best; return false; }
         }
         V3<T> local_n2 = iso_vec(pos21, -best);
         if (!np_world_normal(rotation1, best, em.normal)) return false;

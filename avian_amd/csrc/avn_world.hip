@@ -143,13 +143,13 @@ template <class T> struct World : WorldBase {
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_b1, b_j_b2, b_j_ax, b_j_l2, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_s0, b_j_s1, b_j_s2, b_j_s3, b_j_rl0, b_j_rl1, b_j_force,
         b_j_torque;
     DevBuf b_col_info, b_col_he, b_col_spec, b_col_layers, b_aabb_min, b_aabb_max, b_iv, b_s_minx, b_s_maxx, b_s_yz, b_s_bb, b_s_end, b_s_info, b_s_flags;
-    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off;
+    DevBuf b_keys_a, b_keys_b, b_vals_a, b_vals_b, b_hist, b_block_sums, b_counts, b_offsets, b_pairs, b_pair_set, b_disabled_set, b_pair_keys, b_long_items, b_long_counts, b_long_off, b_sweep_hits;
     DevBuf b_inc_off, b_inc_ent, b_inc_slot;
     bool overflow_csr_nonzero = true;  // the device CSR offsets may be non-zero (first build uploads them)
     uint32_t overflow_csr_bodies = 0;
     // ---- narrow phase: the ContactGraph side on device (CT) + host mirrors of what the host structures of the reference hold ----
     CT<T> ct;
-    DevBuf b_ct_meta, b_ct_dcount, b_ct_n, b_ct_tv, b_ct_a1, b_ct_a2, b_ct_w, b_ct_fid, b_col_mat, b_active, b_changes, b_handles;
+    DevBuf b_ct_meta, b_ct_dcount, b_ct_n, b_ct_tv, b_ct_a1, b_ct_a2, b_ct_w, b_ct_fid, b_col_mat, b_active, b_changes, b_handles, b_np_row, b_np_axis, b_np_ctr;
     std::unordered_map<uint32_t, uint32_t> entity_slot;   // collider Entity::index() -> slot (last colliders_upload)
     std::vector<int32_t> h_col_body;                       // body of each collider slot
     std::vector<uint8_t> h_ct_used;
@@ -202,7 +202,7 @@ template <class T> struct World : WorldBase {
 
     uint64_t pg_dump_step = 0;
     Pinned pin_ctr;
-    SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0};
+    SweepScratch sweep_scratch{nullptr, nullptr, nullptr, nullptr, 0, nullptr};
     DevBuf stage;  // staging arena for uploads/downloads
     size_t stage_off = 0;
     // host state

@@ -441,6 +441,8 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 #define SW_WAVES 4
 #define SW_THREADS (64 * SW_WAVES)
 #define SW_Q 1024   // ring slots per wave: < 64 carried + 8 x 64 appended per batch
+#define SW_HIT_WORDS 16u     // per wave of k_sweep, one 64-byte line: [0] pairs the count pass found, [1 ..] the first SW_HIT_RECORDS of them
+#define SW_HIT_RECORDS 15u
 #define SW_CAP 65536u   // absolute long-interval rule; the two-level batch cull below keeps lattice layers of ~10^4 x-overlapping candidates on the k_sweep path
 #define SW_LONG_MIN 256u   // relative long-interval rule (k_sweep_ranges): never below this many candidates
 #define SW_LCHUNK 4096u
@@ -567,8 +569,9 @@ __global__ __launch_bounds__(256) void k_sweep_ranges(uint32_t n, const T* __res
 template <class T, bool EMIT>
 __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>* __restrict__ s_yz, const Vec4<T>* __restrict__ s_bb, const Vec4<T>* __restrict__ s_bb2, const uint32_t* __restrict__ s_end,
                                                        const uint4* __restrict__ s_info, const uint32_t* __restrict__ s_flags, PairSets hs,
-                                                       uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out) {
+                                                       uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, avn_pair* __restrict__ out, uint32_t* __restrict__ hits) {
     __shared__ uint32_t l_q[SW_WAVES][SW_Q];
+    __shared__ uint32_t l_hits[SW_WAVES];
     __shared__ uint4 l_info[SW_WAVES][64];
     __shared__ uint32_t l_flags[SW_WAVES][64];
     __shared__ uint32_t l_cnt[SW_WAVES][64];  // count pass: pairs found; emit pass: running output position
@@ -595,6 +598,27 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
         // empty has nothing to write (a settled scene finds a few hundred new pairs among 4 x 10^5 slots)
         const uint32_t mine = (valid && !(my_flags & AVN_IV_LONG)) ? counts[i * SW_WAVES + wv] : 0u;
         if (!__any(mine != 0u)) return;   // wave-uniform; the kernel has no workgroup barrier
+        // ... and where it found only a few, it left them as (lane, j) records: no second sweep, the pairs are written from the records
+        // (a settled pile's few thousand new pairs per step are spread over a third of the waves, one or two each).  A lane's pairs go
+        // out in ascending j: the position of a record is its rank among the records of its lane.
+        const uint32_t* __restrict__ rec = hits + (size_t)((i0 >> 6) * SW_WAVES + wv) * SW_HIT_WORDS;
+        const uint32_t nh = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec[0]);
+        if (nh <= SW_HIT_RECORDS) {
+            const uint32_t e = lane < nh ? rec[1u + lane] : 0xFFFFFFFFu;
+            uint32_t rank = 0;
+            for (uint32_t k = 0; k < nh; ++k) {
+                const uint32_t ek = (uint32_t)__shfl((int)e, (int)k);
+                rank += ((ek >> 26) == (e >> 26) && ek < e) ? 1u : 0u;
+            }
+            if (lane < nh) {
+                const uint32_t src = e >> 26, jj = i0 + (e & 0x3FFFFFFu);
+                out[offsets[(i0 + src) * SW_WAVES + wv] + rank] = make_pair(s_info[i0 + src], s_flags[i0 + src], s_info[jj], s_flags[jj]);
+            }
+            return;
+        }
+    } else {
+        if (lane == 0) l_hits[wv] = 0u;
+        __builtin_amdgcn_wave_barrier();
     }
     l_info[wv][lane] = valid ? s_info[i] : make_uint4(0, 0, 0, 0);
     l_flags[wv][lane] = my_flags;
@@ -625,7 +649,11 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
             pass = pair_filters(hs, in1, f1, in2, f2);
         }
         if (!EMIT) {
-            if (pass) atomicAdd(&l_cnt[wv][src], 1u);
+            if (pass) {
+                atomicAdd(&l_cnt[wv][src], 1u);
+                const uint32_t h = atomicAdd(&l_hits[wv], 1u);
+                if (h < SW_HIT_RECORDS) hits[(size_t)((i0 >> 6) * SW_WAVES + wv) * SW_HIT_WORDS + 1u + h] = e;
+            }
         } else {
             // deterministic in-order positions: entries of one source lane are in ascending j (= ascending queue slot)
             unsigned long long rem = __ballot(pass);
@@ -705,6 +733,7 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep(uint32_t n, const Vec4<T>*
     }
     if (qn) drain(qn);
     __builtin_amdgcn_wave_barrier();
+    if (!EMIT && lane == 0) hits[(size_t)((i0 >> 6) * SW_WAVES + wv) * SW_HIT_WORDS] = l_hits[wv];
     if (!EMIT && valid) {
         if (!(my_flags & AVN_IV_LONG)) counts[i * SW_WAVES + wv] = l_cnt[wv][lane];
         else if (wv != 0) counts[i * SW_WAVES + wv] = 0u;  // slot 0 of a long interval is written by k_long_finish
@@ -926,17 +955,18 @@ template <class T> void launch_sweep(const BP<T>& bp, uint32_t n, bool emit, con
     LongItem* li = (LongItem*)sc.long_items;
     PairSets hs{bp.pair_set, bp.pair_set_cap, bp.disabled_set, bp.disabled_cap};
     if (emit) {
-        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out, sc.hits);
         hipLaunchKernelGGL((k_sweep_long<T, true>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
     } else {
-        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out);
+        hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(SW_THREADS), 0, s, n, bp.s_yz, bp.s_bb, bp.s_bb2, bp.s_end, bp.s_info, bp.s_flags, hs, counts, offsets, out, sc.hits);
         hipLaunchKernelGGL((k_sweep_long<T, false>), dim3(2048), dim3(SW_THREADS), 0, s, bp.s_yz, bp.s_info, bp.s_flags, hs, li, sc.n_long, sc.long_counts,
                            sc.long_off, offsets, out);
         hipLaunchKernelGGL(k_long_finish, dim3(64), dim3(256), 0, s, li, sc.n_long, sc.long_counts, sc.long_off, counts);
     }
 }
 size_t sweep_long_item_bytes() { return sizeof(LongItem); }
+size_t sweep_hit_words(uint32_t n) { return ((size_t)(n + 63u) / 64u + 8u) * SW_WAVES * SW_HIT_WORDS; }
 uint32_t sweep_count_slots() { return SW_WAVES; }
 uint32_t sweep_pad_records() { return 8u; }  // k_sweep reads whole candidate batches: s_yz needs this many records past n
 

@@ -67,11 +67,13 @@ template <class T> __device__ __forceinline__ T np_combine(T a, uint32_t ra, T b
 // The raw points of ONE pair in LDS: word w of point k of lane l at col[(w * AVN_NP_MAX_RAW + k) * NP_THREADS] with col = base + l -- every
 // lane has its own column, neighbouring lanes neighbouring banks.  6 words per point: anchor1 (as contact_query returns it), penetration,
 // the two feature ids; anchor2 = anchor1 + (position1 - position2) is recomputed where it is needed.
-#define NP_THREADS 128
+#define NP_THREADS 64          // the heavy kernel's workgroup (one wave): 24 KB (f32) / 48 KB (f64) of LDS
+#define NP_LIGHT_THREADS 256   // the light kernel's workgroup: no LDS
 #define NP_POINT_WORDS 6
 template <class T> struct NpLdsSink {
     T* col;
     int cnt;
+    static __device__ __forceinline__ NpLdsSink make(T* c) { return NpLdsSink{c, 0}; }
     __device__ __forceinline__ int n() const { return cnt; }
     __device__ __forceinline__ T& at(int w, int k) const { return col[(size_t)(w * AVN_NP_MAX_RAW + k) * NP_THREADS]; }
     __device__ __forceinline__ void put(V3<T> a1, T pen, uint32_t f1, uint32_t f2) {
@@ -86,6 +88,20 @@ template <class T> struct NpLdsSink {
         for (int w = 0; w < NP_POINT_WORDS; ++w) at(w, dst) = at(w, src);
     }
 };
+// The light kernel's sink: the paths it finishes itself (a ball against a ball or a cuboid) produce at most ONE raw point: registers.
+template <class T> struct NpOneSink {
+    V3<T> a1_;
+    T pen_;
+    uint32_t f1_, f2_;
+    int cnt;
+    static __device__ __forceinline__ NpOneSink make(T*) { return NpOneSink{vzero<T>(), T(0), 0u, 0u, 0}; }
+    __device__ __forceinline__ int n() const { return cnt; }
+    __device__ __forceinline__ void put(V3<T> a1, T pen, uint32_t f1, uint32_t f2) { a1_ = a1; pen_ = pen; f1_ = f1; f2_ = f2; ++cnt; }
+    __device__ __forceinline__ void get(int, V3<T>& a1, T& pen, uint32_t& f1, uint32_t& f2) const { a1 = a1_; pen = pen_; f1 = f1_; f2 = f2_; }
+    __device__ __forceinline__ void move(int, int) const {}
+};
+template <class T, bool HEAVY> struct NpSinkOf { typedef NpOneSink<T> type; };
+template <class T> struct NpSinkOf<T, true> { typedef NpLdsSink<T> type; };
 
 // One pair.  HEAVY = false: the whole update unless the pair is a cuboid-cuboid one that survives the SAT -- then nothing is written,
 // *deferred = true and *axis holds the separating direction.  HEAVY = true: the deferred pair again, from the top (every input is re-read:
@@ -150,22 +166,39 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         T old_wn[AVN_MAX_MANIFOLD_POINTS], old_wx[AVN_MAX_MANIFOLD_POINTS], old_wy[AVN_MAX_MANIFOLD_POINTS];
         uint2 old_fid[AVN_MAX_MANIFOLD_POINTS];
         const uint32_t old_n = old_nman ? old_pc : 0u;
+        // (the heavy kernel issues these loads before the clipping that hides them; the light one only for a pair that turns out to touch --
+        //  a ball pair: most of its pairs are cuboids, apart or deferred, and must not carry 44 registers of old points through the SAT)
+        auto load_old_points = [&]() {
 #pragma unroll
-        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-            old_a1[k] = vzero<T>(); old_a2[k] = vzero<T>(); old_wn[k] = T(0); old_wx[k] = T(0); old_wy[k] = T(0); old_fid[k] = make_uint2(0u, 0u);
-            if (k < old_n) {
-                size_t s = (size_t)k * ct.cap + c;
-                Vec4<T> oa = ct.a1[s], ob = ct.a2[s], ow = ct.w[s];
-                old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid[s];
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                old_a1[k] = vzero<T>(); old_a2[k] = vzero<T>(); old_wn[k] = T(0); old_wx[k] = T(0); old_wy[k] = T(0); old_fid[k] = make_uint2(0u, 0u);
+                if (k < old_n) {
+                    size_t s = (size_t)k * ct.cap + c;
+                    Vec4<T> oa = ct.a1[s], ob = ct.a2[s], ow = ct.w[s];
+                    old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid[s];
+                }
             }
+        };
+        if (HEAVY) load_old_points();
+        if (HEAVY && p.np_debug == 3u) {   // timing cut-off: every input loaded, nothing computed or written
+            T acc = ((x1.x + x2.y) + (q1.w + q2.x)) + ((world_com1.x + world_com2.y) + (lin_vel1.z + lin_vel2.x)) + ((ang_vel1.x + ang_vel2.y) + (friction + restitution)) + (sp1 + sp2);
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) acc += (old_a1[k].x + old_a2[k].y) + (old_wn[k] + bits_to_scalar(old_fid[k].x ^ old_fid[k].y, T(0)));
+            if (acc == T(123456.75)) chg[c] = 7u;
+            return;
         }
         // the raw points of the manifold go to this lane's LDS column (NpLdsSink): the only dynamically indexed storage of the update
-        NpLdsSink<T> sink{lds_col, 0};
+        typedef typename NpSinkOf<T, HEAVY>::type Sink;
+        Sink sink = Sink::make(lds_col);
         V3<T> normal = vzero<T>();
         bool defer = HEAVY;
         const bool has_manifold = p.np_debug == 1u ? false
-            : contact_manifolds_pair_sink<T, NpLdsSink<T>>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
+            : contact_manifolds_pair_sink<T, Sink, HEAVY ? 2 : 1>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
         if (!HEAVY && defer) { if (p.np_debug == 2u) defer = false; else { *deferred = true; return; } }
+        if (HEAVY && p.np_debug == 4u) {   // timing cut-off: the manifold's raw points are in LDS, nothing converted or written
+            if (has_manifold && normal.x + T(sink.cnt) == T(123456.75)) chg[c] = 7u;
+            return;
+        }
         const V3<T> d12 = x1 - x2;
         // one raw point -> the ContactPoint being built (system_param.rs:590-640), always from the same expressions
         auto build = [&](int k, NpPt<T>& pt) {
@@ -190,7 +223,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         n_manifolds = 0; point_count = 0;
         if (nk > 0) {
             point_count = (uint32_t)nk;
-            if (nk > 4) {   // ContactManifold::prune_points (contact_types/mod.rs:425-520): three passes over the kept points
+            if (HEAVY && nk > 4) {   // ContactManifold::prune_points (contact_types/mod.rs:425-520): three passes over the kept points
                 const T MIN_DISTANCE_SQUARED = T(1e-6);
                 auto projected = [&](int i, T& pen_sq) {
                     V3<T> ra1; T rpen; uint32_t f1, f2;
@@ -232,9 +265,14 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             }
             n_manifolds = 1;
         }
+        if (HEAVY && p.np_debug == 5u) {   // timing cut-off: points kept / pruned, nothing matched or written
+            if (T(o0 + o1 + o2 + o3) + T(point_count) == T(123456.75)) chg[c] = 7u;
+            return;
+        }
         const bool touching = n_manifolds != 0;
         flags = touching ? (flags | AVN_CP_TOUCHING) : (flags & ~(uint32_t)AVN_CP_TOUCHING);
         if (touching) {
+            if (!HEAVY) load_old_points();
             const T thr = T(0.1) * p.length_unit;
             const T thr2 = thr * thr;
             ct.n[c] = make4<T>(normal, friction);
@@ -289,39 +327,80 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
 // DENSE = true (device closed loop, k_graph.hip): every row id < n_active with AVN_CP_ROW_USED is a pair; a row's change is left in
 // chg[id] / has[id] (`changes` / `n_changes` reinterpreted), so that a scan over the rows numbers the changes in ascending ContactId.
 //
-// Two passes inside the workgroup.  Pass 1, one lane per pair: everything that is cheap -- AABB / layer tests, ball paths, and for two
-// cuboids the SAT, after which ~60 % of a settled pile's AABB-overlapping pairs are done (apart).  The survivors' (row, axis) go to an LDS
-// list; pass 2 hands them to the first lanes of the workgroup, so the heavy half (clipping, point conversion, pruning, matching; its raw points live in
-// an LDS column per lane) runs in waves that are full instead of in every wave at 40 % occupancy.
+// Two kernels.  k_narrow_phase, one lane per pair: everything that is cheap -- AABB / layer tests, ball paths, and for two cuboids the SAT,
+// after which ~60 % of a settled pile's AABB-overlapping pairs are done (apart).  It holds no LDS and half the registers of the whole
+// update, so it runs four waves deep and leaves a CU's LDS to whatever shares the chip (the sweep, when the narrow phase overlaps the broad
+// phase).  The survivors' (row, separating axis) go to a list in HBM (wave-aggregated append: order arbitrary, the outputs are per row).
+// k_narrow_phase_heavy, one lane per SURVIVOR: support faces, clipping, point conversion, pruning, matching, with its raw points in an LDS
+// column per lane -- every wave full (round 2 ran this half inside the first kernel's workgroups: 60 % of the lanes of a wave that existed
+// per 128 pairs, one such wave per workgroup while 48 KB of LDS per workgroup capped the CU at three of them).  Its grid is sized for the
+// worst case (every pair survives) and the workgroups beyond the list leave at once; the last workgroup to finish clears the list's counter
+// for the next launch, which saves a memset launch per narrow phase.
+// The survivor list is NP_LISTS lists: a workgroup of the first kernel appends to list (blockIdx mod NP_LISTS), whose counter has a cache line
+// of its own -- one list would mean one atomic per wave on ONE address: measured 6.4 ns each, 125 us for cfg2's 19 k waves, the largest single
+// item of the kernel.  List k owns np_row[k * seg .. (k + 1) * seg) with seg = NP_LIGHT_THREADS * ceil(workgroups / NP_LISTS): it cannot overflow.
+#define NP_LISTS 64u
+#define NP_CTR_STRIDE 16u   // words between the counters of two lists: (entries, workgroups of the second kernel that are done, -, ...)
+__host__ __device__ __forceinline__ uint32_t np_list_segment(uint32_t n_pairs) {
+    const uint32_t wgs = (n_pairs + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS;
+    return NP_LIGHT_THREADS * ((wgs + NP_LISTS - 1) / NP_LISTS);
+}
 template <class T, bool DENSE>
-__global__ __launch_bounds__(NP_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
-                                                             avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                                                             uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base) {
-    __shared__ uint32_t s_row[NP_THREADS];
-    __shared__ T s_axis[3 * NP_THREADS];
-    __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];   // f32: 48 KB, f64: 96 KB
-    __shared__ uint32_t s_n;
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    const uint32_t a = blockIdx.x * NP_THREADS + threadIdx.x;
+__global__ __launch_bounds__(NP_LIGHT_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
+                                                                   avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
+                                                                   uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base) {
+    const uint32_t a = blockIdx.x * NP_LIGHT_THREADS + threadIdx.x;
+    bool deferred = false;
+    V3<T> axis = vzero<T>();
+    uint32_t c = 0;
     if (a < n_active) {
         // DENSE with a row list (the rows a step ADDED, narrow phase overlapped with the broad phase): ids list[0 .. n_list), then the
         // contiguous fresh ids range_base ..; DENSE without one: every row id; sparse: the active list
-        const uint32_t c = !DENSE ? active[a] : (active || n_list || range_base) ? (a < n_list ? active[a] : range_base + (a - n_list)) : a;
-        bool deferred = false;
-        V3<T> axis = vzero<T>();
-        np_update_pair<T, DENSE, false>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
+        c = !DENSE ? active[a] : (active || n_list || range_base) ? (a < n_list ? active[a] : range_base + (a - n_list)) : a;
+        np_update_pair<T, DENSE, false>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, nullptr);
+    }
+    const uint64_t m = __ballot(deferred);
+    if (m) {
+        const uint32_t list = blockIdx.x % NP_LISTS;
+        const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(ct.np_ctr + list * NP_CTR_STRIDE, (uint32_t)__popcll(m));
+        base = __shfl(base, (int)leader);
         if (deferred) {
-            const uint32_t k = atomicAdd(&s_n, 1u);
-            s_row[k] = c; s_axis[3 * k] = axis.x; s_axis[3 * k + 1] = axis.y; s_axis[3 * k + 2] = axis.z;
+            const size_t k = (size_t)list * np_list_segment(n_active) + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            ct.np_row[k] = c;
+            ct.np_axis[3 * k] = axis.x; ct.np_axis[3 * k + 1] = axis.y; ct.np_axis[3 * k + 2] = axis.z;
         }
     }
-    __syncthreads();
-    if (threadIdx.x < s_n) {
-        V3<T> axis{s_axis[3 * threadIdx.x], s_axis[3 * threadIdx.x + 1], s_axis[3 * threadIdx.x + 2]};
+}
+// workgroup (chunk, list) = (blockIdx / NP_LISTS, blockIdx mod NP_LISTS): the populated chunks come first in the grid.  The last workgroup of
+// a list to finish clears the list's counters for the next launch (every workgroup that takes part has read the count before it reports);
+// the workgroups beyond a list's end leave without touching anything.
+template <class T, bool DENSE>
+__global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_heavy(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, avn_contact_change* __restrict__ changes,
+                                                                   uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg, uint32_t* __restrict__ has, uint32_t n_pairs) {
+    __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];   // f32: 24 KB, f64: 48 KB
+    const uint32_t list = blockIdx.x % NP_LISTS, chunk = blockIdx.x / NP_LISTS;
+    uint32_t* ctr = ct.np_ctr + list * NP_CTR_STRIDE;
+    const uint32_t n = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (chunk * NP_THREADS >= n) return;
+    const uint32_t i = chunk * NP_THREADS + threadIdx.x;
+    if (i < n) {
+        const size_t k = (size_t)list * np_list_segment(n_pairs) + i;
+        V3<T> axis{ct.np_axis[3 * k], ct.np_axis[3 * k + 1], ct.np_axis[3 * k + 2]};
         bool deferred = false;
-        np_update_pair<T, DENSE, true>(w, bp, ct, p, s_row[threadIdx.x], changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
+        np_update_pair<T, DENSE, true>(w, bp, ct, p, ct.np_row[k], changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
     }
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(ctr + 1, 1u) == (n + NP_THREADS - 1) / NP_THREADS - 1u) { atomicExch(ctr, 0u); atomicExch(ctr + 1, 0u); }
+}
+size_t np_survivor_list_slack() { return (size_t)NP_LISTS * NP_LIGHT_THREADS; }
+size_t np_survivor_counter_bytes() { return (size_t)NP_LISTS * NP_CTR_STRIDE * sizeof(uint32_t); }
+template <class T, bool DENSE>
+static void launch_np_heavy(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg, uint32_t* has,
+                            uint32_t n_pairs, hipStream_t st) {
+    const uint32_t chunks = np_list_segment(n_pairs) / NP_THREADS;
+    hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs);
 }
 
 template <class T>
@@ -460,12 +539,16 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
     (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
-    if (n_active) hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
+    if (!n_active) return;
+    hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
+    launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t st) {
     (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
-    if (n_rows) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
+    if (!n_rows) return;
+    hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st);
 }
 // the rows list[0 .. n_list) followed by range_base .. range_base + n_range: same per-row work and outputs as the dense form; the
 // removal counter is NOT reset (it continues the count of the launch over the older rows)
@@ -474,8 +557,9 @@ template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp
     const uint32_t n = n_list + n_range;
     if (!n) return;
     // (range_base = 0 with an empty list would read as the plain dense form: a world's first pairs take the dense launch instead)
-    if (!n_list && !range_base) { hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u); return; }
-    hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
+    if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u);
+    else hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st);
 }
 template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);

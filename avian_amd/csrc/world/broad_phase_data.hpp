@@ -143,6 +143,7 @@
             GROW(b_hist, (size_t)256 * radix_blocks((uint32_t)cc) + 256, dummy_u);
             GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc * sweep_count_slots())) + 16, dummy_u);
             GROW(b_counts, cc * sweep_count_slots() + 1, dummy_u); GROW(b_offsets, cc * sweep_count_slots() + 1, dummy_u);
+            GROW(b_sweep_hits, sweep_hit_words((uint32_t)cc), sweep_scratch.hits);
             {   // long-interval chunks: every interval may need one slot, plus room for the chunks of scene-spanning ones
                 size_t lcap = cc + 65536;
                 if (const char* e = getenv("AVN_SWEEP_LONG_CAP")) lcap = std::max<size_t>(8, (size_t)strtoull(e, nullptr, 10));   // (tests: force the grow-and-retry path)

@@ -53,6 +53,16 @@
         if ((st = grow_planes(b_ct_w, sizeof(V), (void**)&ct.w)) != AVN_OK) return st;
         if ((st = grow_planes(b_ct_fid, sizeof(uint2), (void**)&ct.fid)) != AVN_OK) return st;
         HIPCHK(hipMemset((char*)ct.meta + (size_t)old * sizeof(uint4), 0, (c - old) * sizeof(uint4)));
+        // the narrow phase's survivor list (scratch of one launch pair: nothing to keep) and its counters
+        {
+            hipError_t err;
+            const size_t slots = c + np_survivor_list_slack();   // 64 lists, each rounded up to whole workgroups of the first kernel (k_narrow.hip)
+            b_np_row.ensure(slots * sizeof(uint32_t), err);
+            if (err == hipSuccess) b_np_axis.ensure(3 * slots * sizeof(T), err);
+            if (err == hipSuccess && !b_np_ctr.p) { b_np_ctr.ensure(np_survivor_counter_bytes(), err); if (err == hipSuccess) HIPCHK(hipMemset(b_np_ctr.p, 0, np_survivor_counter_bytes())); }
+            if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+            ct.np_row = b_np_row.as<uint32_t>(); ct.np_axis = b_np_axis.as<T>(); ct.np_ctr = b_np_ctr.as<uint32_t>();
+        }
         ct.cap = (uint32_t)c;
         h_ct_used.resize(c, 0); h_ct_c1.resize(c, 0); h_ct_c2.resize(c, 0); h_ct_b1.resize(c, -1); h_ct_b2.resize(c, -1);
         if (pipe_dev) return pg_ensure_rows(ct.cap);

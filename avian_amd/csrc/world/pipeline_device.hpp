@@ -132,6 +132,8 @@
     // memory (no extra synchronisation: the copy rides the stream); whoever synchronises next -- avn_synchronize, the next avn_step -- reports
     // it under the name of the kernel that raised it and clears it.
     hipEvent_t ev_np_fork = nullptr, ev_np_old = nullptr;
+    uint32_t pipe_step_no = 0;   // closed-loop steps taken by this world (measurement aids only)
+    int np_debug_step = getenv("AVN_NP_DEBUG_STEP") ? atoi(getenv("AVN_NP_DEBUG_STEP")) : -1;
     bool np_overlap_enabled = !(getenv("AVN_NO_NP_OVERLAP") && getenv("AVN_NO_NP_OVERLAP")[0] && getenv("AVN_NO_NP_OVERLAP")[0] != '0');
     uint32_t* h_pg_error = nullptr;   // pinned
     bool pg_error_pending = false;
@@ -258,6 +260,9 @@
         // must not come alive under a running launch) and get their own small launch.  Same per-row work, same outputs: chg / has per row,
         // so the scan still numbers the changes in ascending ContactId.  AVN_NO_NP_OVERLAP=1: the serial order (A/B runs).
         const uint32_t n_rows_old = pgm_next_id, head_old = pgm_head;
+        StepParams<T> np_params = params;   // (AVN_NP_DEBUG_STEP: the measurement cut-offs of the narrow phase in ONE step of a run, so that the launch sees a real state)
+        if (np_debug_step >= 0 && (uint32_t)np_debug_step != pipe_step_no) np_params.np_debug = 0u;
+        ++pipe_step_no;
         const bool np_overlap = np_overlap_enabled && n_rows_old != 0 && bp.n_intervals != 0;
         if (np_overlap) {
             if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming)); }
@@ -268,7 +273,7 @@
         st = collect_launch();
         if (st != AVN_OK) { bs = stream; return st; }
         if (np_overlap) {
-            launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
             ++launches;
             HIPCHK(hipEventRecord(ev_np_old, stream));
         }
@@ -333,9 +338,9 @@
         const uint32_t n_rows = pgm_next_id;
         uint32_t n_ops = 0, n_rem = 0;
         if (n_rows) {
-            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream); ++launches; }
+            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream); ++launches; }
             else if (total) {   // the rows this step added: the lowest free ids first (k_pg_add_pairs), then the fresh ones
-                launch_narrow_phase_rows<T>(dw, bp, ct, params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+                launch_narrow_phase_rows<T>(dw, bp, ct, np_params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
                 ++launches;
             }
             launch_exclusive_scan(pg.has, pg.off, n_rows, b_pg_sums.as<uint32_t>(), pg.ctr + PGC_N_OPS, stream);

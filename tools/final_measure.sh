@@ -53,7 +53,7 @@ f5=$(find $O/prof_cfg5 -name "*kernel_trace.csv" | head -1)
 [ -n "$f5" ] && python tools/trace_percentiles.py $f5 > $O/cfg5_percentiles.txt 2>&1
 # cfg3 with and without the island streams (A/B on this box), the PCIe-inclusive step call by call
 for e in 0 1; do AVN_NO_ISLAND_STREAMS=$e python $R/tools/profile_config.py cfg3 30 2>/dev/null | tail -1 | sed "s/^/island_streams_off=$e /"; done > $O/cfg3_island_streams_ab.txt
-timeout 120 python tools/time_pcie.py 8 > $O/pcie_calls.json 2> $O/pcie.err
+timeout 120 python tools/time_pcie.py 20 > $O/pcie_calls.json 2> $O/pcie.err
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
 for t in cfg2 cfg2_closed_loop cfg3 cfg5 scene_many scene_large; do rm -rf $O/prof_$t; done
