@@ -256,7 +256,7 @@ template <class T> struct World : WorldBase {
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_bp) (void)hipStreamSynchronize(stream_bp);
         drop_graph();
-        for (hipEvent_t e : {ev_bp_done, ev_bp_t0, ev_bp_t1}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_bp_done, ev_bp_t0, ev_bp_t1, ev_spin}) if (e) (void)hipEventDestroy(e);
         if (stream_bp) (void)hipStreamDestroy(stream_bp);
         for (auto& e : ev) if (e) (void)hipEventDestroy(e);
         for (auto& e : ev_bias) if (e) (void)hipEventDestroy(e);

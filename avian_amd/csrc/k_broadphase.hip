@@ -445,7 +445,7 @@ void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, 
 #define SW_HIT_RECORDS 15u
 #define SW_CAP 65536u   // absolute long-interval rule; the two-level batch cull below keeps lattice layers of ~10^4 x-overlapping candidates on the k_sweep path
 #define SW_LONG_MIN 256u   // relative long-interval rule (k_sweep_ranges): never below this many candidates
-#define SW_LCHUNK 4096u
+#define SW_LCHUNK 512u    // candidates per LongItem: two iterations of a workgroup (4096 made the ground of cfg2 25 workgroups x 16 dependent iterations: 29 us)
 
 // wave-wide compare masks (LLVM fcmp predicates: UGE = 11, ULE = 13); inactive lanes read 0
 __device__ __forceinline__ unsigned long long lane_mask_ule(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 13); }

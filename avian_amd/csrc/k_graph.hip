@@ -516,9 +516,181 @@ __global__ __launch_bounds__(64) void k_pg_replay(PG pg, const uint32_t* __restr
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) { pg.ctr[PGC_LEN + c] = L; pg.ctr[PGC_DBG + c] = dbg_iter; pg.ctr[PGC_DBG + 24 + c] = dbg_serial; pg.ctr[PGC_DBG + 48 + c] = dbg_reload; pg.ctr[PGC_DBG + 72 + c] = b1 - b0; }
 }
+// The same replay RW_B ops at a time by a whole workgroup (round 3; tools/experiments/replay_wide.py is its CPU model, checked against the
+// serial semantics).  The wave version above spends ~4 us per 64 ops -- its stack matching walks the pushes of the batch one readlane at a
+// time -- and a settled pile's largest colour has 4 600 ops per step (15 000 while the pile collapses): 0.3 - 1.6 ms with 23 of 24 waves
+// long finished.  Per batch, with H_t the list length after op t and L the length at the batch start:
+//   * a pop at t vacates level q = H_t; what sits there is the handle of the push s = 1 + (largest u < t with H_u <= q) -- lengths move by
+//     +-1, so that op is the push that last went up through q --, or of op 0 if there is no such u and L <= q, else the list entry at q
+//     as of the batch start.  One descent in a min-tree over H per pop instead of a walk over the pushes.
+//   * at 1024 ops a filler taken from the list is popped LATER IN THE SAME BATCH a dozen times per batch (the wave version cut the batch
+//     there): that pop finds it in the hole it was moved to -- pred[j] = the pop whose filler op j pops, P_j = P_pred through pointer
+//     jumping --, and the placement of a filler that is popped later in the batch is never written.
+//   * exact while every pop's resolved position is below the lowest level touched up to that op (checked with block-wide prefix min / max
+//     when a quick whole-batch test fails); the first op that breaks it runs alone and the batch restarts behind it.
+// Between batches the stores are drained and everything is re-read from memory (agent-scope loads): no staged window, no patching.
+#define RW_B 1024u
+#define RW_HASH 2048u
+__global__ __launch_bounds__(RW_B) void k_pg_replay_wide(PG pg, const uint32_t* __restrict__ rx) {
+    __shared__ int T[2 * RW_B];   // min-tree over H: leaves at [RW_B, 2 RW_B)
+    __shared__ uint32_t s_x[RW_B], s_P[RW_B], s_flag[RW_B], hkey[RW_HASH], hval[RW_HASH];
+    __shared__ int s_pred[RW_B];
+    __shared__ int s_wsum[RW_B / 64];
+    __shared__ uint32_t s_wmin[RW_B / 64], s_wmax[RW_B / 64];
+    __shared__ uint32_t s_f, s_L;
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t b0 = 0;
+    for (uint32_t i = 0; i < c; ++i) b0 += pg.ctr[PGC_BUCKET + i];
+    const uint32_t b1 = b0 + pg.ctr[PGC_BUCKET + c];
+    uint32_t* __restrict__ list = pg.lists + (size_t)c * pg.list_stride;
+    uint32_t L = pg.ctr[PGC_LEN + c];
+    uint32_t dbg_iter = 0, dbg_serial = 0, dbg_cut = 0;
+    uint32_t nlim = 0;
+    for (uint32_t cur = b0; cur < b1;) {
+        uint32_t n = min(RW_B, b1 - cur);
+        if (nlim) { n = nlim; nlim = 0; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the previous batch's stores are performed ...
+        __syncthreads();                                    // ... by every wave, before anything is read back
+        const bool valid = tid < n;
+        const uint32_t v = valid ? rx[cur + tid] : 0u;
+        const uint32_t x = v & 0x7FFFFFFFu;
+        const bool push = valid && (v >> 31), pop = valid && !(v >> 31);
+        const uint32_t P0 = pop ? ld_agent(&pg.lpos[x]) : 0u;
+        // lengths: prefix sum of +1 / -1 (ballots inside a wave, wave totals through LDS)
+        const unsigned long long pushes_w = __ballot(push), pops_w = __ballot(pop);
+        const unsigned long long le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1ull);
+        int incl = __popcll(pushes_w & le_mask) - __popcll(pops_w & le_mask);
+        if (lane == 0) s_wsum[wv] = __popcll(pushes_w) - __popcll(pops_w);
+        s_x[tid] = x; s_P[tid] = P0; s_flag[tid] = 0u; s_pred[tid] = -1;
+        hkey[tid] = 0xFFFFFFFFu; hkey[tid + RW_B] = 0xFFFFFFFFu; hval[tid] = 0xFFFFFFFFu; hval[tid + RW_B] = 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t k = 0; k < wv; ++k) incl += s_wsum[k];
+        const int delta = valid ? (push ? 1 : -1) : 0;
+        const int H = (int)L + incl;                       // length after this op
+        const uint32_t h = (uint32_t)(H - delta);          // ... and before it
+        T[RW_B + tid] = valid ? H : 0x7FFFFFFF;
+        // the tree: every wave builds the six levels above its 64 leaves (LDS operations of a wave execute in order), one wave the top four
+        for (uint32_t size = RW_B / 2; size >= RW_B / 64; size >>= 1) {
+            const uint32_t per = size / (RW_B / 64);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < per) { const uint32_t node = size + wv * per + lane; T[node] = min(T[2 * node], T[2 * node + 1]); }
+        }
+        __syncthreads();
+        if (wv == 0)
+            for (uint32_t size = RW_B / 128; size >= 1; size >>= 1) {
+                __builtin_amdgcn_wave_barrier();
+                if (lane < size) { const uint32_t node = size + lane; T[node] = min(T[2 * node], T[2 * node + 1]); }
+            }
+        __syncthreads();
+        // fillers
+        int match = -1;
+        uint32_t y = 0;
+        if (pop) {
+            const int q = H;
+            uint32_t node = RW_B + tid;
+            int u = -1;
+            while (node > 1u) {
+                if ((node & 1u) && T[node - 1u] <= q) {   // the left sibling's range ends right in front of ours and holds a length <= q: its last one
+                    node -= 1u;
+                    while (node < RW_B) node = T[2u * node + 1u] <= q ? 2u * node + 1u : 2u * node;
+                    u = (int)(node - RW_B);
+                    break;
+                }
+                node >>= 1;
+            }
+            if (u >= 0) match = u + 1;
+            else if ((int)L <= q) match = 0;
+            if (match >= 0) { y = s_x[match]; atomicOr(&s_flag[match], 1u); }   // that push's handle goes straight into this pop's hole
+            else {
+                y = ld_agent(&list[q]);
+                uint32_t hsl = (y * 2654435761u) >> 21;   // 11 bits
+                for (;;) {
+                    const uint32_t prev = atomicCAS(&hkey[hsl], 0xFFFFFFFFu, y);
+                    if (prev == 0xFFFFFFFFu || prev == y) { atomicMin(&hval[hsl], tid); break; }   // (the FIRST pop that moves a handle: lanes behind a cut may hold stale duplicates)
+                    hsl = (hsl + 1u) & (RW_HASH - 1u);
+                }
+            }
+        }
+        __syncthreads();
+        // a pop of a handle that an earlier pop of this batch moved
+        int pred0 = -1;
+        if (pop) {
+            uint32_t hsl = (x * 2654435761u) >> 21;
+            for (;;) {
+                const uint32_t k = hkey[hsl];
+                if (k == x) { const uint32_t i = hval[hsl]; if (i < tid) pred0 = (int)i; break; }
+                if (k == 0xFFFFFFFFu) break;
+                hsl = (hsl + 1u) & (RW_HASH - 1u);
+            }
+            s_pred[tid] = pred0;
+        }
+        __syncthreads();
+        if (pred0 >= 0) atomicOr(&s_flag[pred0], 2u);   // its placement is dead: this pop's filler takes the slot
+        int root = pred0;
+        for (;;) {   // pointer jumping to the pop whose position was read from memory
+            int nxt = -1;
+            if (root >= 0) nxt = s_pred[root];
+            const int more = __syncthreads_or(nxt >= 0);
+            if (!more) break;
+            if (nxt >= 0) { root = nxt; s_pred[tid] = root; }
+            __syncthreads();
+        }
+        const uint32_t P = root >= 0 ? s_P[root] : P0;
+        // conflict-free prefix
+        const uint32_t touch = valid ? (push ? h : h - 1u) : 0xFFFFFFFFu;
+        const uint32_t pend = pop ? P + 1u : 0u;
+        uint32_t tmin = touch, pmx = pend;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { tmin = min(tmin, (uint32_t)__shfl_xor((int)tmin, off)); pmx = max(pmx, (uint32_t)__shfl_xor((int)pmx, off)); }
+        if (lane == 0) { s_wmin[wv] = tmin; s_wmax[wv] = pmx; }
+        if (tid == 0) s_f = n;
+        __syncthreads();
+        uint32_t all_min = 0xFFFFFFFFu, all_max = 0u;
+        for (uint32_t k = 0; k < RW_B / 64; ++k) { all_min = min(all_min, s_wmin[k]); all_max = max(all_max, s_wmax[k]); }
+        if (all_max > all_min) {   // (block-uniform) rare: the exact rule, prefix min of the touched levels against prefix max of the pops' positions
+            uint32_t lomin = wave_incl_min(touch, lane), pmax = wave_incl_max(pend, lane);
+            for (uint32_t k = 0; k < wv; ++k) { lomin = min(lomin, s_wmin[k]); pmax = max(pmax, s_wmax[k]); }
+            if (valid && pmax > lomin) atomicMin(&s_f, tid);
+            __syncthreads();
+        }
+        const uint32_t f = s_f;
+        ++dbg_iter;
+        if (f == 0u) {   // the batch's first op alone: the serial statement of the reference
+            ++dbg_serial;
+            if (tid == 0) {
+                if (push) { st_async(&list[L], x); st_async(&pg.lpos[x], L); st_async(&pg.color[x], c); s_L = L + 1u; }
+                else {
+                    if (P0 != L - 1u) { const uint32_t last = ld_agent(&list[L - 1u]); st_async(&list[P0], last); st_async(&pg.lpos[last], P0); }   // swap_remove + "fix moved manifold handle"
+                    st_async(&pg.color[x], PG_NONE);
+                    s_L = L - 1u;
+                }
+            }
+            __syncthreads();
+            L = s_L;
+            cur += 1;
+            continue;
+        }
+        if (f < n) { ++dbg_cut; nlim = f; continue; }   // the same ops again without the tail behind the cut (its lanes marked pushes consumed, fillers dead)
+        if (pop) {
+            if (!(s_flag[tid] & 2u)) { st_async(&list[P], y); st_async(&pg.lpos[y], P); }
+            st_async(&pg.color[x], PG_NONE);
+        } else if (push) {
+            st_async(&pg.color[x], c);
+            if (!(s_flag[tid] & 1u)) { st_async(&list[h], x); st_async(&pg.lpos[x], h); }
+        }
+        if (tid == n - 1u) s_L = (uint32_t)H;
+        __syncthreads();
+        L = s_L;
+        cur += n;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) { pg.ctr[PGC_LEN + c] = L; pg.ctr[PGC_DBG + c] = dbg_iter; pg.ctr[PGC_DBG + 24 + c] = dbg_serial; pg.ctr[PGC_DBG + 48 + c] = dbg_cut; pg.ctr[PGC_DBG + 72 + c] = b1 - b0; }
+}
 void launch_pg_replay(const PG& pg, const uint32_t* order, uint32_t n_ops, hipStream_t s) {
     if (n_ops) hipLaunchKernelGGL(k_pg_replay_gather, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, order, pg.ekey_a, n_ops);   // (ekey_a: the colouring's entry buffers are free again)
-    hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, pg.ekey_a);
+    static const bool wave_version = getenv("AVN_PG_REPLAY_WAVE") && getenv("AVN_PG_REPLAY_WAVE")[0] && getenv("AVN_PG_REPLAY_WAVE")[0] != '0';   // (A/B runs)
+    if (wave_version) hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, pg.ekey_a);
+    else hipLaunchKernelGGL(k_pg_replay_wide, dim3(AVN_GRAPH_COLOR_COUNT), dim3(RW_B), 0, s, pg, pg.ekey_a);
 }
 
 // ---- removed pairs: ContactGraph::remove_edge_by_id + IdPool::free_id --------------------------------------------------------------

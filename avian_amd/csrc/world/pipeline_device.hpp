@@ -132,6 +132,24 @@
     // memory (no extra synchronisation: the copy rides the stream); whoever synchronises next -- avn_synchronize, the next avn_step -- reports
     // it under the name of the kernel that raised it and clears it.
     hipEvent_t ev_np_fork = nullptr, ev_np_old = nullptr;
+    // The closed loop reads three counter blocks per step, and the device idles while the host finds out that they arrived: a blocking
+    // hipStreamSynchronize costs 20-35 us of that per read (interrupt + wake-up), polling the event 2-3.  AVN_NO_SPIN_SYNC=1: blocking waits.
+    hipEvent_t ev_spin = nullptr;
+    bool spin_enabled = !(getenv("AVN_NO_SPIN_SYNC") && getenv("AVN_NO_SPIN_SYNC")[0] && getenv("AVN_NO_SPIN_SYNC")[0] != '0');
+    hipError_t spin_event(hipEvent_t e) {
+        if (!spin_enabled) return hipEventSynchronize(e);
+        for (;;) {
+            const hipError_t r = hipEventQuery(e);
+            if (r != hipErrorNotReady) return r;
+            __builtin_ia32_pause();
+        }
+    }
+    hipError_t spin_sync(hipStream_t s) {
+        if (!spin_enabled) return hipStreamSynchronize(s);
+        if (!ev_spin) { const hipError_t r = hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming); if (r != hipSuccess) return r; }
+        const hipError_t r = hipEventRecord(ev_spin, s);
+        return r != hipSuccess ? r : spin_event(ev_spin);
+    }
     uint32_t pipe_step_no = 0;   // closed-loop steps taken by this world (measurement aids only)
     int np_debug_step = getenv("AVN_NP_DEBUG_STEP") ? atoi(getenv("AVN_NP_DEBUG_STEP")) : -1;
     bool np_overlap_enabled = !(getenv("AVN_NO_NP_OVERLAP") && getenv("AVN_NO_NP_OVERLAP")[0] && getenv("AVN_NO_NP_OVERLAP")[0] != '0');
@@ -199,7 +217,7 @@
             uint32_t* h = (uint32_t*)pin_ctr.p + 16;
             HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
             HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(spin_sync(stream));
             auto t0 = std::chrono::steady_clock::now();
             if (h[32]) return pg_error_report(h[32]);
             if (getenv("AVN_PG_REPLAY_STATS")) {
@@ -268,22 +286,21 @@
             if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming)); }
             HIPCHK(hipEventRecord(ev_np_fork, stream));
             HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_fork, 0));
+            // (issued BEFORE the broad phase's ~20 launches: the host needs ~150 us to enqueue those, and the narrow phase would start that late)
+            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            ++launches;
+            HIPCHK(hipEventRecord(ev_np_old, stream));
             bs = stream_bp;
         }
         st = collect_launch();
         if (st != AVN_OK) { bs = stream; return st; }
-        if (np_overlap) {
-            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
-            ++launches;
-            HIPCHK(hipEventRecord(ev_np_old, stream));
-        }
         lap();
         // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
         uint32_t total = 0, used_ids = 0;
         auto fail = [&](avn_status e) { bs = stream; return e; };
         if (collect_pending) {
             collect_pending = false;
-            HIPCHK(hipEventSynchronize(ev_counters));
+            HIPCHK(spin_event(ev_counters));
             t0 = std::chrono::steady_clock::now();
             if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
                 if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return fail(st);
@@ -349,7 +366,7 @@
             uint32_t* h = (uint32_t*)pin_ctr.p;
             HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
             lap();
-            HIPCHK(hipStreamSynchronize(stream));
+            HIPCHK(spin_sync(stream));
             t0 = std::chrono::steady_clock::now();
             n_ops = h[0]; n_rem = h[1];
             pg_error_pending = false;
