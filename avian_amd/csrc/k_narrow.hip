@@ -137,18 +137,25 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         const Q4<T> q1 = quat<T>(rot1), q2 = quat<T>(rot2);
         // the collider sits on the body entity: collider.position - body.position
         const V3<T> collider_offset1 = have1 ? x1 - x1 : vzero<T>(), collider_offset2 = have2 ? x2 - x2 : vzero<T>();
-        const V3<T> world_com1 = have1 ? qrot(q1, xyz<T>(w.com[body1])) : vzero<T>(), world_com2 = have2 ? qrot(q2, xyz<T>(w.com[body2])) : vzero<T>();
+        // what only a pair WITH a manifold needs (centres of mass, angular velocities, materials): the heavy kernel loads it up front, the light
+        // one -- whose cuboid pairs end apart or deferred -- only for a ball pair that touches (6 of its ~26 scattered 16-byte gathers per pair)
+        V3<T> world_com1 = vzero<T>(), world_com2 = vzero<T>(), ang_vel1 = vzero<T>(), ang_vel2 = vzero<T>();
+        T friction = T(0), restitution = T(0);
+        auto load_manifold_inputs = [&]() {
+            world_com1 = have1 ? qrot(q1, xyz<T>(w.com[body1])) : vzero<T>(); world_com2 = have2 ? qrot(q2, xyz<T>(w.com[body2])) : vzero<T>();
+            ang_vel1 = have1 ? xyz<T>(w.avel[body1]) : vzero<T>(); ang_vel2 = have2 ? xyz<T>(w.avel[body2]) : vzero<T>();
+            const Vec4<T> m1 = ct.col_mat[slot1], m2 = ct.col_mat[slot2];
+            const uint32_t r1 = scalar_to_bits(m1.z), r2 = scalar_to_bits(m2.z);
+            friction = np_combine<T>(m1.x, r1 & 0xFFu, m2.x, r2 & 0xFFu);
+            restitution = np_combine<T>(m1.y, (r1 >> 8) & 0xFFu, m2.y, (r2 >> 8) & 0xFFu);
+        };
+        if (HEAVY) load_manifold_inputs();
         V3<T> lin_vel1 = have1 ? xyz<T>(w.lvel[body1]) : vzero<T>(), lin_vel2 = have2 ? xyz<T>(w.lvel[body2]) : vzero<T>();
-        const V3<T> ang_vel1 = have1 ? xyz<T>(w.avel[body1]) : vzero<T>(), ang_vel2 = have2 ? xyz<T>(w.avel[body2]) : vzero<T>();
         flags = (flags & ~(uint32_t)(AVN_CP_STATIC1 | AVN_CP_STATIC2)) | (is_static1 ? (uint32_t)AVN_CP_STATIC1 : 0u) | (is_static2 ? (uint32_t)AVN_CP_STATIC2 : 0u);
         const uint32_t cf1 = (ci1.z >> 8) & 0xFFu, cf2 = (ci2.z >> 8) & 0xFFu;
         const bool is_disabled = !have1 || !have2 || (cf1 & AVN_COLLIDER_SENSOR) || (cf2 & AVN_COLLIDER_SENSOR);
         if (!is_disabled && !(flags & AVN_CP_GENERATE_CONSTRAINTS)) { flags |= AVN_CP_STARTED_GENERATING_CONSTRAINTS; status = true; }
         flags = is_disabled ? (flags & ~(uint32_t)AVN_CP_GENERATE_CONSTRAINTS) : (flags | AVN_CP_GENERATE_CONSTRAINTS);
-        const Vec4<T> m1 = ct.col_mat[slot1], m2 = ct.col_mat[slot2];
-        const uint32_t r1 = scalar_to_bits(m1.z), r2 = scalar_to_bits(m2.z);
-        const T friction = np_combine<T>(m1.x, r1 & 0xFFu, m2.x, r2 & 0xFFu);
-        const T restitution = np_combine<T>(m1.y, (r1 >> 8) & 0xFFu, m2.y, (r2 >> 8) & 0xFFu);
         const Vec4<T> he1 = bp.col_he[slot1], he2 = bp.col_he[slot2];  // (half_extents, collision_margin)
         const T collision_margin_sum = he1.w + he2.w;
         const T sp1 = bp.col_spec[slot1], sp2 = bp.col_spec[slot2];
@@ -195,6 +202,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         const bool has_manifold = p.np_debug == 1u ? false
             : contact_manifolds_pair_sink<T, Sink, HEAVY ? 2 : 1>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
         if (!HEAVY && defer) { if (p.np_debug == 2u) defer = false; else { *deferred = true; return; } }
+        if (!HEAVY && has_manifold) load_manifold_inputs();
         if (HEAVY && p.np_debug == 4u) {   // timing cut-off: the manifold's raw points are in LDS, nothing converted or written
             if (has_manifold && normal.x + T(sink.cnt) == T(123456.75)) chg[c] = 7u;
             return;
