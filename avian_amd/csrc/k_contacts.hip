@@ -491,7 +491,11 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
 //  expensive part, the in-lane chain is, and it does not overlap with anything when all waves of a colour run in lockstep.  Removed.
 //  Hoisting what does not depend on the velocities (rotated anchors, separation and its speculative / biased terms for all four points) in
 //  front of the chain as one branch-free block, to give the in-order VALU stream independent work: bit-identical, 8.9 us per launch instead
-//  of 8.4 (longer live ranges, nothing gained: the compiler already interleaves what the basic blocks allow).  Removed.)
+//  of 8.4 (longer live ranges, nothing gained: the compiler already interleaves what the basic blocks allow).  Removed.
+//  Round 3, the anchors delivered as (body1, body2) pairs by the loads -- records laid out (a1.x, a2.x, a1.y, a2.y) (a1.z, a2.z, ..) instead of
+//  one record per side -- timed with the existing records reinterpreted that way (wrong values, same instruction stream): 120 -> 84 v_mov,
+//  1 386 -> 1 353 VALU instructions, 8.006 -> 7.926 us per isolated launch (A/B on one box, twice).  1 % for a second copy of the anchors
+//  (the body-centric warm start reads ONE side per entry and would otherwise fetch both): not built.)
 template <bool USE_BIAS, int STRIDE, bool COH = false>
 __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
     typedef float T;
