@@ -311,20 +311,28 @@ def main():
         n_b, n_m = sc.n, meta["n_manifolds"]
         bout = {k: pinned(np.zeros(sh, w.dtype)) for k, sh in (("position", (n_b, 3)), ("rotation", (n_b, 4)), ("linear_velocity", (n_b, 3)), ("angular_velocity", (n_b, 3)))}
         iout = {k: pinned(np.zeros(sh, w.dtype)) for k, sh in (("warm_start_normal_impulse", (n_m, 4)), ("warm_start_tangent_impulse", (n_m, 4, 2)), ("normal_impulse", (n_m, 4)))}
-        n_p = 8
-        w.bodies_upload(**bk); scenes.upload_manifolds(w, mfp, meta["offsets"], fr, re_); w.step()
-        w.synchronize()
-        c0 = time.perf_counter()
-        for _ in range(n_p):
+        n_p = 20
+
+        def pcie_step():
             w.bodies_upload(**bk)
             scenes.upload_manifolds(w, mfp, meta["offsets"], fr, re_)
             w.step()
             w.bodies_download(out=bout); w.impulses_download(out=iout)
-        w.synchronize()
-        ms_p = (time.perf_counter() - c0) / n_p * 1e3
+            w.synchronize()
+        for _ in range(3):   # (the first transfers out of freshly page-locked buffers map them into the device's address space: 10-40 ms each)
+            pcie_step()
+        per_step = []
+        for _ in range(n_p):
+            c0 = time.perf_counter()
+            pcie_step()
+            per_step.append((time.perf_counter() - c0) * 1e3)
+        # the MEDIAN step: on some boxes of the pool single transfers stall for 10-40 ms (one step in ten); the mean and the worst step are reported next to it
+        ms_p = float(np.median(per_step))
         up_bytes = sum(int(np.asarray(v).nbytes) for v in bk.values() if v is not None) + sum(int(np.asarray(v).nbytes) for v in mfp.values() if hasattr(v, "nbytes")) + 2 * fr.nbytes
         down_bytes = sum(int(v.nbytes) for v in bout.values()) + sum(int(v.nbytes) for v in iout.values())
-        pcie = {"ms_per_step": round(ms_p, 3), "substeps_per_s": round(substeps / (ms_p / 1e3), 2), "host_bytes_up_per_step": up_bytes, "host_bytes_down_per_step": down_bytes,
+        pcie = {"ms_per_step": round(ms_p, 3), "substeps_per_s": round(substeps / (ms_p / 1e3), 2), "steps": n_p, "statistic": "median over the steps",
+                "mean_ms_per_step": round(float(np.mean(per_step)), 3), "max_ms_per_step": round(float(np.max(per_step)), 3),
+                "host_bytes_up_per_step": up_bytes, "host_bytes_down_per_step": down_bytes,
                 "note": "page-locked host arrays in the ABI's own types through avn_bodies_upload / avn_manifolds_upload / avn_bodies_download / avn_impulses_download every step "
                         "(everything re-sent, changed or not); the device-resident path above keeps everything in HBM"}
 

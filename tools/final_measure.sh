@@ -29,7 +29,7 @@ prof() {  # prof <tag> <cmd...>: rocprofv3 kernel-trace + stats, keep the stats 
   cp $(find $O/prof_$tag -name "*kernel_stats.csv" | head -1) $O/kernel_stats_$tag.csv 2>/dev/null
 }
 prof cfg2 python $R/bench.py --no-cpu-baseline --no-pcie --no-closed-loop --no-traffic --no-iters8
-tail -1 $O/prof_cfg2.log > $O/bench_under_rocprof.json
+grep "^{" $O/prof_cfg2.log | tail -1 > $O/bench_under_rocprof.json
 prof cfg2_closed_loop python $R/tools/time_closed_loop.py 50 40 50 120
 f=$(find $O/prof_cfg2_closed_loop -name "*kernel_trace.csv" | head -1)
 python tools/closed_loop_breakdown.py $f 4 40 > $O/closed_loop_breakdown.txt 2>&1
@@ -54,6 +54,11 @@ f5=$(find $O/prof_cfg5 -name "*kernel_trace.csv" | head -1)
 # cfg3 with and without the island streams (A/B on this box), the PCIe-inclusive step call by call
 for e in 0 1; do AVN_NO_ISLAND_STREAMS=$e python $R/tools/profile_config.py cfg3 30 2>/dev/null | tail -1 | sed "s/^/island_streams_off=$e /"; done > $O/cfg3_island_streams_ab.txt
 timeout 120 python tools/time_pcie.py 20 > $O/pcie_calls.json 2> $O/pcie.err
+# the closed loop: one steady step's kernel timeline, the narrow phase's cut-off timings, A/B of the round's switches on this box
+bash tools/step_timeline.sh 110 > /dev/null 2>&1; cp $R/gpurun_out/timeline/timeline.txt $O/closed_loop_step110_timeline.txt 2>/dev/null
+AVN_NO_NP_OVERLAP=1 bash tools/np_phases.sh 60 > $O/narrow_phase_cutoffs.txt 2>&1
+for e in "" AVN_PG_REPLAY_WAVE=1 AVN_NO_NP_OVERLAP=1 AVN_NO_SPIN_SYNC=1; do echo "== ${e:-default}"; env $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | tail -1; done > $O/closed_loop_switches_ab.txt
+python tools/pmc_any.py $O/pmc_narrow_phase.json 30 narrow "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY" > $O/pmc_narrow_phase.txt 2>&1
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
 for t in cfg2 cfg2_closed_loop cfg3 cfg5 scene_many scene_large; do rm -rf $O/prof_$t; done
