@@ -5,7 +5,9 @@
 //!     PhysicsPlugins::default()
 //!         .build()
 //!         .disable::<BroadPhasePlugin>()      // src/collision/broad_phase.rs:33-170
-//!         .disable::<NarrowPhasePlugin>()     // only with `Mi355xMode::ClosedLoop` (Ball / Cuboid colliders)
+//!         // NarrowPhasePlugin stays: with the default `Mi355xMode::Auto` the step runs closed-loop on the device whenever every collider is a
+//!         // Ball / Cuboid without hooks (Avian's narrow phase then walks an empty pair list) and falls back to Avian's own narrow phase
+//!         // otherwise; disable it only with an explicit `Mi355xMode::ClosedLoop`
 //!         .disable::<IntegratorPlugin>()      // src/dynamics/integrator/mod.rs:45-88
 //!         .disable::<SolverPlugin>()          // src/dynamics/solver/plugin.rs:88-151
 //!         .disable::<XpbdSolverPlugin>()      // src/dynamics/solver/xpbd/plugin.rs:21-110

@@ -23,9 +23,14 @@ use core::time::Duration;
 /// How much of the step stays on the device.
 #[derive(Clone, Copy, Default, PartialEq, Eq)]
 pub enum Mi355xMode {
+    /// The default: `ClosedLoop` whenever the scene allows it -- every collider a Ball or a Cuboid on a rigid body the staging knows, no
+    /// `ActiveCollisionHooks` -- and `HostNarrowPhase` otherwise, decided per step (`Mi355xSettings::effective_mode`).  The host-manifold
+    /// flow moves ~160 MB over PCIe per cfg2 step (5 ms) where the closed loop moves three counter blocks: it must not be what a user
+    /// gets without asking.
+    #[default]
+    Auto,
     /// Avian's own (parry) narrow phase keeps running on the host; its manifolds are uploaded every step (`avn_manifolds_upload`),
     /// the substep loop runs device-resident.  Works with every collider shape; pays the manifold upload over PCIe.
-    #[default]
     HostNarrowPhase,
     /// Ball / Cuboid colliders only: contact rows live in HBM, `NarrowPhase::update_contacts`, the status-change loop, the
     /// `ConstraintGraph` and the `IdPool` run on the device (`avn_pipeline_enable(1)`); per step only new pairs and body state cross
@@ -51,11 +56,16 @@ impl Mi355xSettings {
     /// FILTER_PAIRS pairs through `filter_pairs`); the switch is per step -- leaving / entering the device loop is avn_pipeline_enable(0 / 1),
     /// which drops / rebuilds the device contact rows (one step without warm starting, like any ContactGraph rebuild).
     fn effective_mode(&mut self, st: &Staging) -> Mi355xMode {
-        if self.mode == Mi355xMode::ClosedLoop && st.colliders_with_hooks != 0 {
-            if !self.warned_hooks { bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks: running in HostNarrowPhase mode", st.colliders_with_hooks); self.warned_hooks = true; }
+        if self.mode == Mi355xMode::HostNarrowPhase { return Mi355xMode::HostNarrowPhase; }
+        if st.colliders_with_hooks != 0 || st.colliders_unsupported != 0 {
+            if !self.warned_hooks && self.mode == Mi355xMode::ClosedLoop {
+                bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks, {} are not Ball / Cuboid colliders on a known body: running in HostNarrowPhase mode",
+                                 st.colliders_with_hooks, st.colliders_unsupported);
+                self.warned_hooks = true;
+            }
             return Mi355xMode::HostNarrowPhase;
         }
-        self.mode
+        Mi355xMode::ClosedLoop
     }
 }
 
@@ -180,7 +190,7 @@ fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStagi
 fn gpu_solver(mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>) {
     match settings.effective_mode(&st.0) {
         Mi355xMode::HostNarrowPhase => w.run_system(ffi::AVN_SYS_SOLVER),
-        Mi355xMode::ClosedLoop => w.step(),   // avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
+        Mi355xMode::ClosedLoop | Mi355xMode::Auto => w.step(),   // (effective_mode never returns Auto) avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
     }
 }
 

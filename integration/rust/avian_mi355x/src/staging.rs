@@ -24,6 +24,9 @@ pub struct Staging {
     pub collider_slot: bevy::platform::collections::HashMap<u32, usize>,
     /// colliders of the last upload that carry `ActiveCollisionHooks` (filter_pairs / modify_contacts need the host narrow phase)
     pub colliders_with_hooks: usize,
+    /// colliders the device narrow phase cannot take (neither Ball nor Cuboid, or not on a body the staging knows): with any of them the
+    /// step must keep Avian's own narrow phase (`Mi355xSettings::effective_mode`)
+    pub colliders_unsupported: usize,
     pub c_entity_index: Vec<u32>, pub c_body: Vec<i32>, pub c_shape: Vec<u8>, pub c_half_extents: Vec<f32>,
     pub c_memberships: Vec<u32>, pub c_filters: Vec<u32>, pub c_flags: Vec<u8>, pub c_margin: Vec<f32>, pub c_speculative: Vec<f32>,
     // avn_manifolds (colour-major: the order of GraphColor::manifold_handles, src/dynamics/solver/constraint_graph.rs:66-80)
@@ -101,12 +104,13 @@ impl Staging {
         macro_rules! clear { ($($f:ident),*) => { $( self.$f.clear(); )* } }
         clear!(collider_entities, collider_slot, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative);
         self.colliders_with_hooks = 0;
+        self.colliders_unsupported = 0;
         for (e, collider, of, layers, margin, spec, sensor, events, hooks) in colliders {
             let shape = collider.shape_scaled();
             let (kind, he) = if let Some(b) = shape.as_ball() { (ffi::AVN_SHAPE_BALL, Vec3::new(b.radius, 0.0, 0.0)) }
                              else if let Some(c) = shape.as_cuboid() { (ffi::AVN_SHAPE_CUBOID, Vec3::new(c.half_extents.x, c.half_extents.y, c.half_extents.z)) }
-                             else { continue };
-            let Some(&body) = self.body_index.get(&of.body) else { continue };
+                             else { self.colliders_unsupported += 1; continue };
+            let Some(&body) = self.body_index.get(&of.body) else { self.colliders_unsupported += 1; continue };
             self.collider_slot.insert(e.index(), self.collider_entities.len());
             if hooks { self.colliders_with_hooks += 1; }
             self.collider_entities.push(e);
