@@ -776,7 +776,10 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
 //  "overflow list order, then colour order", its constraint records already loaded.  Bit-identical (the closed loop tracked the oracle),
 //  but 219 us per cfg2 pass against 15 x 8.4 = 126 us for the colour launches: a body's 15 manifolds are 15 dependent hops of
 //  poll + sc1 gather + ~1 500 issues + write-through + ticket, ~14 us each with ~10 000 waves polling.  The ticket pass stays where the
-//  alternative is hundreds of launches: the overflow colour, k_overflow_flow.)
+//  alternative is hundreds of launches: the overflow colour, k_overflow_flow.
+//  Round 3: fewer manifolds per wave (32 / 16 / 8 instead of 64), against the solves of lanes that become ready in different polling rounds
+//  running one after the other: cfg2's collapse window 7.00 -> 7.10 / 7.29 / 7.71 ms per step, the settled step 2.98 -> 2.95 (A/B on one box):
+//  more waves polling cost more than the serialisation.  Not kept.)
 // tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
 // not reliably ordered against a synchronous (null-stream) hipMemcpy issued between replays on ROCm 7.2 (found by the closed-loop tests:
 // a whole step of wrong impulses after avn_pipeline_handles_get had copied with hipMemcpy); kernel nodes keep the chain.
