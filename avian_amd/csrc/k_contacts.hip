@@ -779,7 +779,8 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
 //  alternative is hundreds of launches: the overflow colour, k_overflow_flow.
 //  Round 3: fewer manifolds per wave (32 / 16 / 8 instead of 64), against the solves of lanes that become ready in different polling rounds
 //  running one after the other: cfg2's collapse window 7.00 -> 7.10 / 7.29 / 7.71 ms per step, the settled step 2.98 -> 2.95 (A/B on one box):
-//  more waves polling cost more than the serialisation.  Not kept.)
+//  more waves polling cost more than the serialisation.  Not kept.  Neither was touching a manifold's constraint records BEFORE its ticket
+//  wait (so that a hop would find them in L2): 7.22 -> 7.27 ms, nothing gained -- the hop is the sc1 gather and the in-lane chain.)
 // tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
 // not reliably ordered against a synchronous (null-stream) hipMemcpy issued between replays on ROCm 7.2 (found by the closed-loop tests:
 // a whole step of wrong impulses after avn_pipeline_handles_get had copied with hipMemcpy); kernel nodes keep the chain.
