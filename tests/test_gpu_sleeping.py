@@ -97,3 +97,21 @@ def test_wake_bodies_and_switching_sleeping_off():
         w.sleeping_enable(False)
         w.step()
     compare_step(151, wo, wh)
+
+
+def test_large_stack_sleeps_and_wakes_in_thousands_of_ops():
+    """2 197 boxes (13 x 13 x 13) with a SHORT time_to_sleep and generous thresholds: the lattice flip-flops -- the whole island
+    falls asleep every few steps (5 000 - 8 500 manifolds popped at once, in body-list x edge-list order) and the status loop wakes it in the
+    next step (as many pushed back): batches of the workgroup replay (k_pg_replay_wide) full of pops whose fillers are popped later in the same
+    batch, whole colour lists emptied and refilled, cuts.  Every step against the oracle: colour lists with order, counters, bodies, island
+    state."""
+    sc = stack_and_projectile(13, 13, 13, height=12.0)
+    wo, wh = pair_of_worlds(sc.body_kwargs(), sc.collider_kwargs(), bits=32, time_to_sleep=0.05, linear_threshold=3.0, angular_threshold=3.0)
+    popped = events = 0
+    for s in range(70):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh, check_rows=(s % 35 == 34))
+        compare_sleeping(s, wo, wh)
+        st = wh.sleeping_stats()
+        popped += st.last_manifolds_popped; events += 1 if st.last_manifolds_popped else 0
+    assert popped > 40000 and events >= 8, (popped, events)
