@@ -131,6 +131,7 @@ template <class T> struct World : WorldBase {
     hipEvent_t ev_dgs[DG_SUBSTEPS * DG_PER] = {nullptr};   // per substep: start, after warm start, after solve, after positions, end
     bool dg_stamped[DG_STEP_COUNT] = {false};
     uint32_t dg_substeps = 0; bool dg_np = false;
+    const unsigned EV_FLAGS = getenv("AVN_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence;   // (A/B: the default, fencing events)
     void stamp(int id) { if (ev_dg[id]) { (void)hipEventRecord(ev_dg[id], stream); dg_stamped[id] = true; } }
     DW<T> dw;
     BP<T> bp;
@@ -294,13 +295,17 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIPCHK(hipStreamCreateWithFlags(&stream_bp, hipStreamNonBlocking));
         bs = stream;
-        HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming));
-        HIPCHK(hipEventCreate(&ev_bp_t0)); HIPCHK(hipEventCreate(&ev_bp_t1));
+        // Events that order streams of THIS device or only measure time carry hipEventDisableSystemFence: a default event makes the device write
+        // back and invalidate its caches when it is recorded (system-scope release), and the kernels behind it start cold -- a dozen records
+        // per step cost cfg2 ~0.1 ms of 1.6.  Kernel boundaries already release at agent scope, which is all a second stream needs.  (Events
+        // behind which the HOST reads pinned memory -- ev_counters, ev_spin -- keep the default.)
+        HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming | EV_FLAGS));
+        HIPCHK(hipEventCreateWithFlags(&ev_bp_t0, EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_bp_t1, EV_FLAGS));
         if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
-        for (auto& x : ev) HIPCHK(hipEventCreate(&x));
-        for (auto& x : ev_dg) HIPCHK(hipEventCreate(&x));
-        for (auto& x : ev_dgs) HIPCHK(hipEventCreate(&x));
-        for (auto& x : ev_bias) HIPCHK(hipEventCreate(&x));
+        for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
+        for (auto& x : ev_dg) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
+        for (auto& x : ev_dgs) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
+        for (auto& x : ev_bias) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
         hipError_t err;
         b_misc.ensure(4096, err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }

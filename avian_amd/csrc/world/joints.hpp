@@ -234,8 +234,8 @@
         HIPCHK(hipStreamSynchronize(stream));
         if (!stream_side) {
             HIPCHK(hipStreamCreateWithFlags(&stream_side, hipStreamNonBlocking));
-            HIPCHK(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming));
-            HIPCHK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&ev_side_fork, hipEventDisableTiming | EV_FLAGS));
+            HIPCHK(hipEventCreateWithFlags(&ev_side_done, hipEventDisableTiming | EV_FLAGS));
         }
         dw.side_group = b_side_group.as<uint8_t>();
         groups_active = true;

@@ -283,7 +283,7 @@
         ++pipe_step_no;
         const bool np_overlap = np_overlap_enabled && n_rows_old != 0 && bp.n_intervals != 0;
         if (np_overlap) {
-            if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming)); }
+            if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming | EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming | EV_FLAGS)); }
             HIPCHK(hipEventRecord(ev_np_fork, stream));
             HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_fork, 0));
             // (issued BEFORE the broad phase's ~20 launches: the host needs ~150 us to enqueue those, and the narrow phase would start that late)

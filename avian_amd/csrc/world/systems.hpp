@@ -316,7 +316,7 @@
         if ((st = rebuild_incidence()) != AVN_OK) return st;
         if ((st = flow_begin_standalone()) != AVN_OK) return st;
         hipEvent_t a, b;
-        HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventCreateWithFlags(&a, EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&b, EV_FLAGS));
         HIPCHK(hipStreamSynchronize(stream));
         uint32_t before = launches;
         HIPCHK(hipEventRecord(a, stream));  // events on the stream the kernels are launched on
@@ -338,9 +338,27 @@
         dg_np = false;
         if (pipe_on) return pipe_dev ? pipeline_step_device() : pipeline_step();
         launches = 0;
+        static const bool host_trace = getenv("AVN_HOST_TRACE") != nullptr;   // debugging aid: where the HOST spends a step (us since the call)
+        const auto ht0 = std::chrono::steady_clock::now();
+        auto hus = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count(); };
+        double h_bp = 0, h_front = 0, h_wait = 0;
         HIPCHK(hipEventRecord(ev[0], stream));
+        if (host_trace) {   // (debugging aid) a ring of (start, end) events per step, read back by avn_synchronize: spans and the gaps BETWEEN steps
+            if (trace_ev.empty()) { trace_ev.resize(2 * TRACE_STEPS); for (auto& e : trace_ev) HIPCHK(hipEventCreateWithFlags(&e, EV_FLAGS)); }
+            HIPCHK(hipEventRecord(trace_ev[2 * (trace_n % TRACE_STEPS)], stream));
+        }
         const bool overlap = overlap_bp && have_colliders;
         bp_timed = false;
+        static const bool bp_first = getenv("AVN_BP_ENQUEUE_FIRST") != nullptr;   // (A/B: round 2's order)
+        const bool front_first = overlap && !bp_first;
+        if (front_first) {
+            // the solver's front only READS the rigid-body components, as the broad phase does: with the broad phase on its own stream the
+            // order in which the HOST enqueues the two is free, and the world's stream is the one that must never wait for the host -- the
+            // broad phase's ~20 launches take the host 70 us, and it has a millisecond of slack
+            HIPCHK(hipEventRecord(ev[1], stream));
+            if ((st = solver_front()) != AVN_OK) return st;
+            h_front = hus();
+        }
         if (have_colliders) {
             if (overlap) {
                 HIPCHK(hipStreamWaitEvent(stream_bp, ev[0], 0));  // after the previous step's write-back
@@ -352,9 +370,14 @@
             if (overlap) { (void)hipEventRecord(ev_bp_t1, stream_bp); bp_timed = true; }
             if (st != AVN_OK) { bs = stream; return st; }
         }
-        HIPCHK(hipEventRecord(ev[1], stream));
-        st = solver_front();                              // enqueued while the broad phase runs / its pair counters travel back
+        h_bp = hus();
+        if (!front_first) {
+            HIPCHK(hipEventRecord(ev[1], stream));
+            st = solver_front();                              // enqueued while the broad phase runs / its pair counters travel back
+            h_front = hus();
+        }
         if (st == AVN_OK) st = collect_finish();          // (emit pass only when the step found new pairs)
+        h_wait = hus();
         if (overlap) {
             (void)hipEventRecord(ev_bp_done, stream_bp);
             (void)hipStreamWaitEvent(stream, ev_bp_done, 0);  // the write-back must not overtake k_update_aabb's reads
@@ -363,9 +386,28 @@
         if (st != AVN_OK) return st;
         if ((st = solver_back()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[4], stream));
+        if (host_trace) { HIPCHK(hipEventRecord(trace_ev[2 * (trace_n % TRACE_STEPS) + 1], stream)); ++trace_n; }
         ev_valid = true;
         last_timers.kernel_launches = launches;
+        if (host_trace && getenv("AVN_HOST_TRACE")[0] == '2') std::fprintf(stderr, "[avn host] broad phase enqueued %.0f us, solver front %.0f, counters back %.0f, step enqueued %.0f\n", h_bp, h_front, h_wait, hus());
         return AVN_OK;
     }
-    avn_status synchronize() override { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp)); return pg_error_check(); }
+    static constexpr uint32_t TRACE_STEPS = 64;
+    std::vector<hipEvent_t> trace_ev;
+    uint32_t trace_n = 0;
+    avn_status synchronize() override {
+        HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
+        if (trace_n >= 8 && trace_n <= TRACE_STEPS) {
+            double span = 0, gap = 0;
+            for (uint32_t i = 4; i + 1 < trace_n; ++i) {
+                float a = 0, b = 0;
+                HIPCHK(hipEventElapsedTime(&a, trace_ev[2 * i], trace_ev[2 * i + 1]));
+                HIPCHK(hipEventElapsedTime(&b, trace_ev[2 * i + 1], trace_ev[2 * i + 2]));
+                span += a; gap += b;
+            }
+            std::fprintf(stderr, "[avn trace] %u steps: mean span %.4f ms, mean gap to the next step's start %.4f ms\n", trace_n - 5, span / (trace_n - 5), gap / (trace_n - 5));
+        }
+        trace_n = 0;
+        return pg_error_check();
+    }
 
