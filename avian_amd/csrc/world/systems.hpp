@@ -405,6 +405,7 @@
                 HIPCHK(hipEventElapsedTime(&b, trace_ev[2 * i + 1], trace_ev[2 * i + 2]));
                 span += a; gap += b;
             }
+            if (getenv("AVN_HOST_TRACE")[0] == '3') { std::fprintf(stderr, "[avn trace] spans (ms):"); for (uint32_t i = 0; i < trace_n; ++i) { float a = 0; HIPCHK(hipEventElapsedTime(&a, trace_ev[2 * i], trace_ev[2 * i + 1])); std::fprintf(stderr, " %.3f", a); } std::fprintf(stderr, "\n"); }
             std::fprintf(stderr, "[avn trace] %u steps: mean span %.4f ms, mean gap to the next step's start %.4f ms\n", trace_n - 5, span / (trace_n - 5), gap / (trace_n - 5));
         }
         trace_n = 0;
