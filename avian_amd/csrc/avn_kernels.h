@@ -251,6 +251,7 @@ template <class T> struct SleepParams {
     T length_unit_squared, lin_threshold_squared, ang_threshold_squared; float delta_secs, time_to_sleep;
     const float *body_lin, *body_ang; const uint8_t* body_disabled;   // optional per-body SleepThreshold / SleepingDisabled (device copies), nullptr = world level
 };
+template <class T> void launch_islands_validate(const DW<T>&, const uint32_t* label, uint32_t* invalid, hipStream_t, uint32_t solver_nodes);   // last step's labels against this step's edges
 template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t,
                                        uint32_t solver_nodes = 0u /* 1: only bodies with a SolverBody connect (island-block builder) */);
 template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,

@@ -222,7 +222,8 @@ template <class T> struct World : WorldBase {
     bool island_enabled = true, island_mode = false;
     size_t island_max_manifolds = 65536;  // above this the colour launches are throughput- not latency-bound (1 wave per SIMD = 65k manifolds): keep the device-wide path
     uint32_t island_pack_bodies = 256;    // islands are packed into one block up to this many bodies (a single island may reach ISLAND_MAX_BODIES)
-    std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent, isl_mcount;
+    std::vector<uint32_t> isl_parent, isl_island_of, isl_count, isl_block_of_island, isl_slot, isl_body_off, isl_bodies, isl_col_off, isl_cursor, isl_ent, isl_mcount, isl_root_island, isl_roots;
+    bool isl_labels_step_valid = false;   // b_isl_label / isl_roots hold the labels of an earlier closed-loop step (reused while they still group the manifolds)
     DevBuf b_isl_bodies;   // [body_off | bodies | col_off | ent], 256-byte aligned parts
     IslandBlocks islands{nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
     bool island_cache_records = true;    // AVN_ISLAND_CACHE_RECORDS=0: bodies only in LDS (A/B runs, tests)

@@ -172,6 +172,22 @@ __global__ __launch_bounds__(256) void k_sleep_reset(float* __restrict__ timer, 
     if (b < n_bodies) timer[b] = 0.0f;
 }
 
+// Are last step's labels still a valid GROUPING for this step's manifolds?  Yes while no manifold joins two island nodes of different labels
+// (and none touches a node that was not labelled): components that have split since are merely coarser than necessary, which the island
+// blocks do not mind -- all they need is that no manifold crosses a block.  *invalid |= 1 otherwise.
+template <class T>
+__global__ __launch_bounds__(256) void k_cc_validate(DW<T> w, const int2* __restrict__ pairs, uint32_t n, const uint32_t* __restrict__ label, uint32_t* __restrict__ invalid, uint32_t solver_nodes) {
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const int2 p = pairs[e];
+    const bool na = p.x >= 0 && (uint32_t)p.x < w.n_bodies && island_node(w.bmeta[p.x], solver_nodes), nb = p.y >= 0 && (uint32_t)p.y < w.n_bodies && island_node(w.bmeta[p.y], solver_nodes);
+    const uint32_t la = na ? label[p.x] : 0u, lb = nb ? label[p.y] : 0u;
+    if ((na && la == 0xFFFFFFFFu) || (nb && lb == 0xFFFFFFFFu) || (na && nb && la != lb)) atomicOr(invalid, 1u);
+}
+template <class T> void launch_islands_validate(const DW<T>& w, const uint32_t* label, uint32_t* invalid, hipStream_t s, uint32_t solver_nodes) {
+    if (w.n_manifolds) hipLaunchKernelGGL(k_cc_validate<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, (const int2*)w.m_bodies, w.n_manifolds, label, invalid, solver_nodes);
+    if (w.n_joints) hipLaunchKernelGGL(k_cc_validate<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, label, invalid, solver_nodes);
+}
 template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t s, uint32_t solver_nodes) {
     if (!w.n_bodies) return;
     const uint32_t nb = (w.n_bodies + 255) / 256;
@@ -194,6 +210,7 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
     template void launch_sleep_timers_flags<T>(const DW<T>&, const SleepParams<T>&, float*, uint8_t*, hipStream_t);   \
     template void launch_bodies_set_sleeping<T>(const DW<T>&, const uint32_t*, uint32_t, uint32_t, float*, hipStream_t); \
     template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t, uint32_t);            \
+    template void launch_islands_validate<T>(const DW<T>&, const uint32_t*, uint32_t*, hipStream_t, uint32_t);       \
     template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint8_t*, uint32_t*, hipStream_t);
 INST(float)
 INST(double)

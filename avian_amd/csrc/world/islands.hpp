@@ -21,6 +21,7 @@
         if (st != AVN_OK) return st;
         if ((st = island_buffers()) != AVN_OK) return st;
         HIPCHK(hipMemsetAsync(b_isl_ctr.p, 0, 64, stream));
+        isl_labels_step_valid = false;   // (the island blocks' reusable labels live in the same buffer, with the solver-node rule)
         launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream);
         launches += 2 + (dw.n_manifolds ? 1 : 0) + (dw.n_joints ? 1 : 0);
         HIPCHK(hipGetLastError());

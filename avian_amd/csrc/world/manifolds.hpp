@@ -163,11 +163,27 @@
             avn_status st = island_buffers();
             if (st != AVN_OK) return st;
             HIPCHK(hipMemsetAsync(b_isl_ctr.p, 0, 64, stream));
-            launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream, 1u);
-            launches += 3;
-            HIPCHK(hipMemcpyAsync(parent.data(), b_isl_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipStreamSynchronize(stream));
-            for (uint32_t i = 0; i < N; ++i) if (parent[i] == 0xFFFFFFFFu) parent[i] = i;   // (bodies without a SolverBody: never asked)
+            bool reuse = false;
+            if (isl_labels_step_valid && isl_roots.size() == N) {
+                // last step's labels, checked against this step's manifolds on the device: one small kernel and a 4-byte read-back instead of
+                // the union-find (100 us at 13 k manifolds: deep trees under "root = lowest index") and the read-back of every label
+                launch_islands_validate<T>(dw, b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>() + 8, stream, 1u);
+                ++launches;
+                uint32_t invalid = 1;
+                HIPCHK(hipMemcpyAsync(&invalid, b_isl_ctr.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                reuse = invalid == 0;
+            }
+            if (reuse) parent = isl_roots;
+            else {
+                launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream, 1u);
+                launches += 3;
+                HIPCHK(hipMemcpyAsync(parent.data(), b_isl_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipStreamSynchronize(stream));
+                isl_roots = parent;   // (as the device holds them: 0xFFFFFFFF for a body that was no island node)
+                isl_labels_step_valid = true;
+            }
+            for (uint32_t i = 0; i < N; ++i) if (parent[i] == 0xFFFFFFFFu || !h_body_has_sb[i]) parent[i] = i;   // (bodies without a SolverBody: never asked)
             labelled = true;
         } else for (uint32_t i = 0; i < N; ++i) parent[i] = i;
         auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
@@ -178,12 +194,16 @@
         // islands numbered by their lowest body (the root: unions keep the smaller index on top), bodies inside in index order
         std::vector<uint32_t>& island_of = isl_island_of; std::vector<uint32_t>& count = isl_count;
         island_of.assign(N, 0xFFFFFFFFu);
+        std::vector<uint32_t>& root_island = isl_root_island;
+        root_island.assign(N, 0xFFFFFFFFu);
         count.clear();
         for (uint32_t i = 0; i < N; ++i) {
             if (!h_body_has_sb[i]) continue;
             uint32_t r = find(i);
-            if (r == i) { island_of[i] = (uint32_t)count.size(); count.push_back(0u); }
-            island_of[i] = island_of[r];   // r <= i: already numbered
+            // (with REUSED labels the root -- the lowest index of the component when it was labelled -- may have lost its SolverBody since: it
+            //  then only lends its index to the group, so the root's island is kept apart from island_of, which lists MEMBERS)
+            if (root_island[r] == 0xFFFFFFFFu) { root_island[r] = (uint32_t)count.size(); count.push_back(0u); }
+            island_of[i] = root_island[r];   // islands are numbered by their first member with a SolverBody, bodies inside in index order
             if (++count[island_of[i]] > ISLAND_MAX_BODIES) return AVN_OK;   // an island too big for one workgroup's LDS: device-wide path
         }
         const uint32_t n_islands = (uint32_t)count.size();

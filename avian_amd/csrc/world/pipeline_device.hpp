@@ -74,6 +74,7 @@
         return AVN_OK;
     }
     avn_status pipeline_device_reset() {
+        island_backoff = 0; isl_labels_step_valid = false;
         HIPCHK(hipStreamSynchronize(stream));
         HIPCHK(hipStreamSynchronize(stream_bp));
         avn_status st;
