@@ -818,28 +818,32 @@ uint32_t radix_pass_launches(uint32_t n) { uint32_t nb = radix_blocks(n); return
 #define SS_MAX 8192u
 #define SS_WAVES 8
 #define SS_THREADS (64 * SS_WAVES)
-__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted) {
+__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted, uint32_t bits) {
     if (unsorted && *unsorted == 0u) return;   // the persistent order is still sorted
     __shared__ uint32_t cnt[SS_WAVES][256];    // per-wave digit counts, then the wave's running output offsets
     __shared__ uint32_t tot[256];
     const uint32_t t = threadIdx.x, lane = t & 63u;
     const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
     const unsigned long long lt_mask = (1ull << lane) - 1ull;
-    const uint32_t base = wv * RS_TILE;
+    // the keys are dealt to ALL eight waves in equal tiles of `rounds` x 64 (a settled pile's overflow colour sorts ~600 entries: with fixed
+    // 1 024-key tiles one wave walked ten rounds while seven watched), and only the passes the key width needs are made
+    const uint32_t rounds = max(1u, (n + SS_THREADS - 1u) / SS_THREADS);   // <= RS_ROUNDS for n <= SS_MAX
+    const uint32_t base = wv * rounds * 64u;
     uint32_t* ki = keys_a; uint32_t* vi = vals_a; uint32_t* ko = keys_b; uint32_t* vo = vals_b;
-    for (uint32_t shift = 0; shift < 32u; shift += 8u) {
+    for (uint32_t shift = 0; shift < bits; shift += 8u) {
         uint32_t key[RS_ROUNDS], val[RS_ROUNDS];
 #pragma unroll
         for (uint32_t r = 0; r < RS_ROUNDS; ++r) {   // the wave's tile, all loads in flight at once
             const uint32_t idx = base + r * 64u + lane;
-            key[r] = idx < n ? ki[idx] : 0u;
-            val[r] = idx < n ? vi[idx] : 0u;
+            const bool in = r < rounds && idx < n;   // (r < rounds is wave-uniform)
+            key[r] = in ? ki[idx] : 0u;
+            val[r] = in ? vi[idx] : 0u;
         }
         for (uint32_t d = lane; d < 256u; d += 64u) cnt[wv][d] = 0u;
         __syncthreads();
 #pragma unroll
         for (uint32_t r = 0; r < RS_ROUNDS; ++r)
-            if (base + r * 64u + lane < n) atomicAdd(&cnt[wv][(key[r] >> shift) & 255u], 1u);
+            if (r < rounds && base + r * 64u + lane < n) atomicAdd(&cnt[wv][(key[r] >> shift) & 255u], 1u);
         __syncthreads();
         // thread d < 256: digit total, and the exclusive prefix over the waves (the tiles before this one)
         if (t < 256u) {
@@ -863,6 +867,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uin
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (uint32_t r = 0; r < RS_ROUNDS; ++r) {
+            if (r < rounds) {   // (wave-uniform)
             const bool valid = base + r * 64u + lane < n;
             const uint32_t digit = (key[r] >> shift) & 255u;
             unsigned long long peers = __ballot(valid);   // match-any over the 8 digit bits
@@ -879,6 +884,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uin
             if (valid && rank == 0) cnt[wv][digit] += (uint32_t)__popcll(peers);
             __builtin_amdgcn_wave_barrier();
             if (valid) { ko[pos] = key[r]; vo[pos] = val[r]; }
+            }
         }
         __syncthreads();   // (workgroup-scope release/acquire: the next pass reads what other waves wrote)
         uint32_t* tk = ki; ki = ko; ko = tk;
@@ -888,7 +894,7 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uin
 template <class K> static bool sort_small(K*, uint32_t*, K*, uint32_t*, uint32_t, const uint32_t*, hipStream_t) { return false; }
 template <> bool sort_small<uint32_t>(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* unsorted, hipStream_t s) {
     if (n > SS_MAX) return false;
-    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted);   // four passes: ends in (keys_a, vals_a)
+    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted, 32u);   // four passes: ends in (keys_a, vals_a)
     return true;
 }
 uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes) { return key_bytes == 4 && n <= SS_MAX ? 1u : key_bytes * radix_pass_launches(n); }
@@ -921,7 +927,12 @@ void launch_radix_sort_bits(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b
     uint32_t* ki = keys_a; uint32_t* vi = vals_a; uint32_t* ko = keys_b; uint32_t* vo = vals_b;
     // a settled pile's overflow colour (a few hundred manifolds -> < 1 000 entries) and small scenes: the one-workgroup sort, 1 launch instead
     // of 2 per 8 bits (it sorts all 32 bits: the same permutation, the keys have no bits above `bits`)
-    if (n && n <= SS_MAX && bits > 8) { hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, (const uint32_t*)nullptr); *keys_out = keys_a; *vals_out = vals_a; return; }
+    if (n && n <= SS_MAX && bits > 8) {
+        const uint32_t passes = (bits + 7u) / 8u;   // an odd number of passes ends in the second pair of buffers
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, (const uint32_t*)nullptr, 8u * passes);
+        *keys_out = (passes & 1u) ? keys_b : keys_a; *vals_out = (passes & 1u) ? vals_b : vals_a;
+        return;
+    }
     const uint32_t nb = radix_blocks(n);
     for (uint32_t shift = 0; n && shift < bits; shift += 8) {
         if (nb <= RS_FUSED_MAX_BLOCKS) {
