@@ -130,8 +130,10 @@ avn_status IslandManager::status_change(uint32_t id, uint32_t flags, uint32_t ma
         c.touching = false; c.generates = generates;
         if (generates && c.handles) {
             c.handles = 0;
-            const uint32_t isl = unlink_contact(id);
-            if (islands_[isl].sleeping) to_wake_.push_back(isl);
+            if (c.linked) {   // (a pair whose colliders sit on bodies without island nodes was never linked: link_contact returned NONE)
+                const uint32_t isl = unlink_contact(id);
+                if (islands_[isl].sleeping) to_wake_.push_back(isl);
+            }
         }
     } else if ((flags & AVN_CP_TOUCHING) && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) {
         c.generates = true;

@@ -44,6 +44,7 @@ public:
     // what the world reads directly
     bool body_has_node(uint32_t b) const { return b < node_.size() && node_[b]; }
     bool body_sleeps(uint32_t b) const { return b < asleep_.size() && asleep_[b]; }
+    bool has_collider(uint32_t collider) const { return collider_body_.count(collider) != 0; }
     uint32_t island_of(uint32_t b) const { return isl_of_[b]; }
     uint32_t last_slept() const { return last_slept_; }
     uint32_t last_woken() const { return last_woken_; }

@@ -358,7 +358,11 @@ template <class T> struct World : WorldBase {
         params.length_unit = (T)cfg.length_unit;
         params.restitution_iterations = cfg.restitution_iterations;
         params.match_contacts = cfg.match_contacts;
+#ifdef AVN_MEASURE   // measurement build only (make measure): cut-offs of the narrow phase's kernels (tools/np_phases.sh)
         params.np_debug = getenv("AVN_NP_DEBUG") ? (uint32_t)atoi(getenv("AVN_NP_DEBUG")) : 0u;
+#else
+        params.np_debug = 0u;
+#endif
         // update_contact_softness, reference solver/plugin.rs:326-350
         T dt = params.dt_f64cast, h = params.h_f64cast;
         T max_hz = T(1) / (dt * T(2));

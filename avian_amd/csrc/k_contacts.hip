@@ -996,7 +996,9 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     switch (pass) {
         case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
         case 4: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_WARM_START_COLORS: colour by colour
-        case 5: return launch_pass<T, PASS_SKELETON>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_MEMORY_SKELETON (measurement aid)
+#ifdef AVN_MEASURE
+        case 5: return launch_pass<T, PASS_SKELETON>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_MEMORY_SKELETON (measurement aid, `make measure` only)
+#endif
         case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, arg_offsets, ovf, s);
         case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, arg_offsets, ovf, s);
         default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, arg_offsets, ovf, s);

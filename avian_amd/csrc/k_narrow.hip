@@ -5,6 +5,13 @@
 #include "avn_kernels.h"
 #include "avn_narrow.h"
 
+// measurement cut-offs (AVN_NP_DEBUG, tools/np_phases.sh): compiled in only by `make measure`; the default library has no switch that changes results
+#ifdef AVN_MEASURE
+#define NP_DEBUG(p) ((p).np_debug)
+#else
+#define NP_DEBUG(p) 0u
+#endif
+
 namespace avn {
 
 template <class T> __device__ __forceinline__ V3<T> ld3(const T* p, size_t i) { return {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; }
@@ -187,7 +194,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             }
         };
         if (HEAVY) load_old_points();
-        if (HEAVY && p.np_debug == 3u) {   // timing cut-off: every input loaded, nothing computed or written
+        if (HEAVY && NP_DEBUG(p) == 3u) {   // timing cut-off: every input loaded, nothing computed or written
             T acc = ((x1.x + x2.y) + (q1.w + q2.x)) + ((world_com1.x + world_com2.y) + (lin_vel1.z + lin_vel2.x)) + ((ang_vel1.x + ang_vel2.y) + (friction + restitution)) + (sp1 + sp2);
 #pragma unroll
             for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) acc += (old_a1[k].x + old_a2[k].y) + (old_wn[k] + bits_to_scalar(old_fid[k].x ^ old_fid[k].y, T(0)));
@@ -199,11 +206,11 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         Sink sink = Sink::make(lds_col);
         V3<T> normal = vzero<T>();
         bool defer = HEAVY;
-        const bool has_manifold = p.np_debug == 1u ? false
+        const bool has_manifold = NP_DEBUG(p) == 1u ? false
             : contact_manifolds_pair_sink<T, Sink, HEAVY ? 2 : 1>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
-        if (!HEAVY && defer) { if (p.np_debug == 2u) defer = false; else { *deferred = true; return; } }
+        if (!HEAVY && defer) { if (NP_DEBUG(p) == 2u) defer = false; else { *deferred = true; return; } }
         if (!HEAVY && has_manifold) load_manifold_inputs();
-        if (HEAVY && p.np_debug == 4u) {   // timing cut-off: the manifold's raw points are in LDS, nothing converted or written
+        if (HEAVY && NP_DEBUG(p) == 4u) {   // timing cut-off: the manifold's raw points are in LDS, nothing converted or written
             if (has_manifold && normal.x + T(sink.cnt) == T(123456.75)) chg[c] = 7u;
             return;
         }
@@ -273,7 +280,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             }
             n_manifolds = 1;
         }
-        if (HEAVY && p.np_debug == 5u) {   // timing cut-off: points kept / pruned, nothing matched or written
+        if (HEAVY && NP_DEBUG(p) == 5u) {   // timing cut-off: points kept / pruned, nothing matched or written
             if (T(o0 + o1 + o2 + o3) + T(point_count) == T(123456.75)) chg[c] = 7u;
             return;
         }

@@ -94,7 +94,7 @@
             if ((s2 = stage_in<uint32_t>(asleep.data(), asleep.size(), &d1)) != AVN_OK || (s2 = stage_in<uint32_t>(awake_list.data(), awake_list.size(), &d2)) != AVN_OK) return s2;
             launch_bodies_set_sleeping<T>(dw, d1, (uint32_t)asleep.size(), 1u, nullptr, stream);
             launch_bodies_set_sleeping<T>(dw, d2, (uint32_t)awake_list.size(), 0u, nullptr, stream);
-            if (b_slp_timer.cap < (size_t)n * 4) { hipError_t e3; b_slp_timer.ensure((size_t)n * 4 + 256, e3, true, stream); b_slp_flags.ensure((size_t)n + 64, e3); if (e3 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; } }
+            if ((s2 = slp_grow_bodies(n)) != AVN_OK) return s2;   // spawned bodies: SleepTimer 0, the world's thresholds
         }
         joint_schedule_dirty = true;
         incidence_dirty = true;

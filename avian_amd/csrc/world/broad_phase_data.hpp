@@ -188,6 +188,14 @@
             materials_restitution = false;
         }
         have_colliders = true;
+        if (slp_on) {   // colliders spawned inside the loop join the island manager's RigidBodyColliders lists (upload order = Add order)
+            for (uint32_t i = 0; i < C; ++i) {
+                if (isl.has_collider(c->entity_index[i])) continue;
+                const uint32_t b = (uint32_t)c->body[i];
+                const avn_status si = isl.collider_add(c->entity_index[i], (b < h_rb_type.size() && slp_node(b)) ? b : IslandManager::NONE);
+                if (si != AVN_OK) return slp_fail(si);
+            }
+        }
         if (pipe_dev && !same) { avn_status se = pg_upload_ent2slot(); if (se != AVN_OK) return se; }   // k_pg_add_pairs turns the pairs' collider entities into slots
         return AVN_OK;
     }

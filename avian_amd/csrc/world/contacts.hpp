@@ -304,6 +304,12 @@
     }
     avn_status pairs_get(const avn_pair** out, size_t* n) override {
         if (!out || !n) return AVN_ERR_BAD_ARG;
+        if (pipe_dev && h_pairs.empty() && last_timers.pair_count) {
+            // device closed loop: the step's new pairs (emission order) never left the device -- fetched on request (tests, inspection)
+            HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
+            h_pairs.resize(last_timers.pair_count);
+            HIPCHK(hipMemcpy(h_pairs.data(), b_pairs.p, (size_t)last_timers.pair_count * sizeof(avn_pair), hipMemcpyDeviceToHost));
+        }
         *out = h_pairs.data();
         *n = h_pairs.size();
         return AVN_OK;

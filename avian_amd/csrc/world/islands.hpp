@@ -3,12 +3,13 @@
 
     // ---- islands and sleeping (include/avian_mi355x.h: avn_islands_get / avn_sleep_update; k_islands.hip) --------------------------------
     DevBuf b_isl_parent, b_isl_label, b_isl_ctr, b_sleep_timer, b_isl_awake, b_isl_rests, b_isl_wakes;
+    DevBuf b_isl_blk_label;     // the island-BLOCK builder's labels (solver-node rule, reused across closed-loop steps): never what avn_sleep_get reports
     uint32_t sleep_n = 0;       // body count the timers belong to (a different count restarts them)
     bool islands_fresh = false; // labels on the device describe the current constraint graph
     avn_status island_buffers() {
         const size_t n = std::max<uint32_t>(dw.n_bodies, 1);
         hipError_t err;
-        for (DevBuf* b : {&b_isl_parent, &b_isl_label, &b_isl_awake}) { b->ensure(n * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; } }
+        for (DevBuf* b : {&b_isl_parent, &b_isl_label, &b_isl_awake, &b_isl_blk_label}) { b->ensure(n * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; } }
         b_isl_rests.ensure(n, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         b_isl_wakes.ensure(n, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         b_isl_ctr.ensure(64, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
@@ -21,7 +22,6 @@
         if (st != AVN_OK) return st;
         if ((st = island_buffers()) != AVN_OK) return st;
         HIPCHK(hipMemsetAsync(b_isl_ctr.p, 0, 64, stream));
-        isl_labels_step_valid = false;   // (the island blocks' reusable labels live in the same buffer, with the solver-node rule)
         launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream);
         launches += 2 + (dw.n_manifolds ? 1 : 0) + (dw.n_joints ? 1 : 0);
         HIPCHK(hipGetLastError());

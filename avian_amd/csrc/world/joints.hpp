@@ -30,6 +30,14 @@
                 error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
             }
         }
+        if (slp_on) {
+            // the island manager links joints when they are added (PhysicsIslands::add_joint, islands/mod.rs:668-735) and has no way to take one
+            // back without the bodies' JointGraph history: with sleeping on, an upload may only APPEND joints to the set it already knows
+            if (J < h_j_body1.size()) { error = "joints_upload: with avn_sleeping_enable on, joints can only be appended (avn_sleeping_enable(NULL) first to change the set)"; return AVN_ERR_STATE; }
+            for (size_t i = 0; i < h_j_body1.size(); ++i)
+                if (h_j_body1[i] != j->body1[i] || h_j_body2[i] != j->body2[i]) { error = "joints_upload: with avn_sleeping_enable on, the bodies of an existing joint cannot change"; return AVN_ERR_STATE; }
+            for (uint32_t i = (uint32_t)h_j_body1.size(); i < J; ++i) { const avn_status si = isl.joint_add(i, (uint32_t)j->body1[i], (uint32_t)j->body2[i]); if (si != AVN_OK) return slp_fail(si); }
+        }
         bool moved = false;
         if (J > cap_joints) {
             HIPCHK(hipStreamSynchronize(stream));

@@ -167,7 +167,7 @@
             if (isl_labels_step_valid && isl_roots.size() == N) {
                 // last step's labels, checked against this step's manifolds on the device: one small kernel and a 4-byte read-back instead of
                 // the union-find (100 us at 13 k manifolds: deep trees under "root = lowest index") and the read-back of every label
-                launch_islands_validate<T>(dw, b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>() + 8, stream, 1u);
+                launch_islands_validate<T>(dw, b_isl_blk_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>() + 8, stream, 1u);
                 ++launches;
                 uint32_t invalid = 1;
                 HIPCHK(hipMemcpyAsync(&invalid, b_isl_ctr.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, stream));
@@ -176,9 +176,9 @@
             }
             if (reuse) parent = isl_roots;
             else {
-                launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream, 1u);
+                launch_islands<T>(dw, b_isl_parent.as<uint32_t>(), b_isl_blk_label.as<uint32_t>(), b_isl_ctr.as<uint32_t>(), stream, 1u);
                 launches += 3;
-                HIPCHK(hipMemcpyAsync(parent.data(), b_isl_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
+                HIPCHK(hipMemcpyAsync(parent.data(), b_isl_blk_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream));
                 HIPCHK(hipStreamSynchronize(stream));
                 isl_roots = parent;   // (as the device holds them: 0xFFFFFFFF for a body that was no island node)
                 isl_labels_step_valid = true;

@@ -152,7 +152,11 @@
         return r != hipSuccess ? r : spin_event(ev_spin);
     }
     uint32_t pipe_step_no = 0;   // closed-loop steps taken by this world (measurement aids only)
+#ifdef AVN_MEASURE
     int np_debug_step = getenv("AVN_NP_DEBUG_STEP") ? atoi(getenv("AVN_NP_DEBUG_STEP")) : -1;
+#else
+    static constexpr int np_debug_step = -1;
+#endif
     bool np_overlap_enabled = !(getenv("AVN_NO_NP_OVERLAP") && getenv("AVN_NO_NP_OVERLAP")[0] && getenv("AVN_NO_NP_OVERLAP")[0] != '0');
     uint32_t* h_pg_error = nullptr;   // pinned
     bool pg_error_pending = false;

@@ -6,6 +6,7 @@
         if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
         if (on && pipe_on) return AVN_OK;
         if (pipe_on && pipe_dev) {   // leaving the device closed loop: its rows and keys go with it
+            if (slp_on) { avn_status sw = sleeping_enable(nullptr); if (sw != AVN_OK) return sw; }   // the island manager goes too: no body may stay flagged Sleeping without it
             HIPCHK(hipStreamSynchronize(stream));
             if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
             pipe_dev = false; pipe_on = false;

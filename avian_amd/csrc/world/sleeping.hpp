@@ -22,6 +22,40 @@
     double slp_host_ms = 0;
     std::vector<uint32_t> slp_list;                    // scratch: cids | kinds of an op list
 
+    float slp_lin_default = 0.0f, slp_ang_default = 0.0f;   // the world-level SleepThreshold: what a body spawned after avn_sleeping_enable gets in the per-body arrays
+    uint32_t slp_bodies = 0;                                 // bodies the per-body arrays (timer, flags, thresholds, SleepingDisabled) cover
+    // bodies spawned inside the loop: SleepTimer 0 (the component's default, sleeping.rs:96-110), the world's thresholds, not SleepingDisabled
+    avn_status slp_grow_bodies(uint32_t n) {
+        if (n <= slp_bodies) return AVN_OK;
+        HIPCHK(hipStreamSynchronize(stream));
+        const uint32_t old = slp_bodies;
+        hipError_t e;
+        b_slp_timer.ensure((size_t)n * 4, e, true, stream);
+        if (e != hipSuccess) { error = "hipMalloc failed (sleep timers)"; return AVN_ERR_OOM; }
+        b_slp_flags.ensure((size_t)n, e);
+        if (e != hipSuccess) { error = "hipMalloc failed (sleep flags)"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemsetAsync((float*)b_slp_timer.p + old, 0, (size_t)(n - old) * 4, stream));
+        auto grow_f = [&](DevBuf& b, const float*& field, float fill) -> avn_status {
+            if (!field) return AVN_OK;
+            b.ensure((size_t)n * 4, e, true, stream);
+            if (e != hipSuccess) { error = "hipMalloc failed (per-body sleep thresholds)"; return AVN_ERR_OOM; }
+            std::vector<float> tail(n - old, fill);
+            HIPCHK(hipMemcpy((float*)b.p + old, tail.data(), tail.size() * 4, hipMemcpyHostToDevice));
+            field = (const float*)b.p;
+            return AVN_OK;
+        };
+        avn_status st;
+        if ((st = grow_f(b_slp_lin, slp_k.body_lin, slp_lin_default)) != AVN_OK || (st = grow_f(b_slp_ang, slp_k.body_ang, slp_ang_default)) != AVN_OK) return st;
+        if (slp_k.body_disabled) {
+            b_slp_dis.ensure((size_t)n, e, true, stream);
+            if (e != hipSuccess) { error = "hipMalloc failed (SleepingDisabled flags)"; return AVN_ERR_OOM; }
+            HIPCHK(hipMemsetAsync((uint8_t*)b_slp_dis.p + old, 0, n - old, stream));
+            slp_k.body_disabled = (const uint8_t*)b_slp_dis.p;
+        }
+        HIPCHK(hipStreamSynchronize(stream));
+        slp_bodies = n;
+        return AVN_OK;
+    }
     bool slp_node(uint32_t b) const { return h_rb_type[b] != AVN_RB_STATIC && !(h_body_flags[b] & AVN_BODY_DISABLED); }   // BodyIslandNode, islands/mod.rs:96-140
     avn_status slp_fail(avn_status st) { error = isl.error; return st; }
 
@@ -56,6 +90,7 @@
         slp_k.delta_secs = p->delta_secs; slp_k.time_to_sleep = p->time_to_sleep;
         slp_k.body_lin = nullptr; slp_k.body_ang = nullptr; slp_k.body_disabled = nullptr;
         slp_time_to_sleep = p->time_to_sleep;
+        slp_lin_default = p->linear_threshold; slp_ang_default = p->angular_threshold; slp_bodies = n;
         HIPCHK(hipStreamSynchronize(stream));
         hipError_t err;
         auto up = [&](DevBuf& b, const void* src, size_t bytes) -> const void* {

@@ -137,6 +137,7 @@ struct IslandManager {
         return n;
     }
     bool has_node(uint32_t body) const { return body != NONE && body < body_has_node.size() && body_has_node[body]; }
+    bool has_collider(uint32_t collider) const { return collider_body.count(collider) != 0; }
 
     // BodyIslandNode::on_add, islands/mod.rs:1330-1345
     avn_status body_add(uint32_t body) {
@@ -293,8 +294,10 @@ struct IslandManager {
             e.touching = false; e.generates = generates;
             if (generates && e.handles) {
                 e.handles = 0;
-                const uint32_t isl = remove_contact(id);
-                if (islands.get(isl)->is_sleeping) islands_to_wake.push_back(isl);
+                if (e.has_island) {   // (both bodies without an island node: add_contact returned None, nothing to unlink)
+                    const uint32_t isl = remove_contact(id);
+                    if (islands.get(isl)->is_sleeping) islands_to_wake.push_back(isl);
+                }
             }
         } else if ((flags & AVN_CP_TOUCHING) && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) {
             e.generates = true;

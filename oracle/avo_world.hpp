@@ -472,7 +472,10 @@ template <class S> struct World : WorldBase {
                 const bool asleep = slp->isl.has_node((uint32_t)i) && slp->isl.body_sleeping[i];
                 o.body_flags = asleep ? (o.body_flags | AVN_BODY_SLEEPING) : (o.body_flags & (uint8_t)~AVN_BODY_SLEEPING);
                 o.has_solver_body = o.rb_type != AVN_RB_STATIC && o.active();
-                if (slp->timer.size() < n) slp->timer.resize(n, 0.0f);
+                if (slp->timer.size() < n) slp->timer.resize(n, 0.0f);   // spawned inside the loop: SleepTimer 0, the world's thresholds, not SleepingDisabled
+                if (!slp->lin.empty() && slp->lin.size() < n) slp->lin.resize(n, slp->p.linear_threshold);
+                if (!slp->ang.empty() && slp->ang.size() < n) slp->ang.resize(n, slp->p.angular_threshold);
+                if (!slp->disabled.empty() && slp->disabled.size() < n) slp->disabled.resize(n, 0);
             }
         }
         return AVN_OK;
@@ -601,6 +604,15 @@ template <class S> struct World : WorldBase {
     avn_status joints_upload(const avn_joints* j) override {
         if (!j || (j->count && (!j->joint_type || !j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->compliance))) {
             error = "joints_upload: null array"; return AVN_ERR_BAD_ARG;
+        }
+        if (slp) {   // PhysicsIslands::add_joint links when a joint is added (islands/mod.rs:668-735): with sleeping on an upload may only APPEND joints
+            if (j->count < joints.size()) { error = "joints_upload: with avn_sleeping_enable on, joints can only be appended (avn_sleeping_enable(NULL) first to change the set)"; return AVN_ERR_STATE; }
+            for (size_t i = 0; i < joints.size(); ++i)
+                if (joints[i].body1 != j->body1[i] || joints[i].body2 != j->body2[i]) { error = "joints_upload: with avn_sleeping_enable on, the bodies of an existing joint cannot change"; return AVN_ERR_STATE; }
+            for (size_t i = joints.size(); i < j->count; ++i) {
+                if (j->body1[i] < 0 || j->body2[i] < 0 || (size_t)j->body1[i] >= bodies.size() || (size_t)j->body2[i] >= bodies.size() || j->body1[i] == j->body2[i]) { error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG; }
+                slp->isl.joint_add((uint32_t)i, (uint32_t)j->body1[i], (uint32_t)j->body2[i]);
+            }
         }
         joints.resize(j->count);
         collision_disabled_bodies.clear();
@@ -1313,6 +1325,13 @@ template <class S> struct World : WorldBase {
         collider_slot.swap(next_slot);
         intervals.swap(kept);
         have_colliders = true;
+        if (slp)   // colliders spawned inside the loop join their body's RigidBodyColliders (upload order = Add order)
+            for (const Collider<S>& o : colliders) {
+                if (slp->isl.has_collider(o.entity)) continue;
+                const Body<S>& b = bodies[(size_t)o.body];
+                const bool node = b.rb_type != AVN_RB_STATIC && !(b.body_flags & AVN_BODY_DISABLED);
+                slp->isl.collider_add(o.entity, node ? (uint32_t)o.body : IslandManager::NONE);
+            }
         return AVN_OK;
     }
     avn_status existing_pairs_upload(const uint64_t* keys, size_t n) override {
@@ -2120,6 +2139,7 @@ template <class S> avn_status World<S>::pipeline_enable(int on) {
     if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
     if (on && pipe) return AVN_OK;
     if (pipe) {
+        if (slp) sleeping_enable(nullptr);   // the island manager goes with the loop: every island awake again first
         for (auto& kv : pipe->pairs) { uint32_t id = kv.first; contact_pairs_remove(&id, 1); }
         pipeline_delete(pipe); pipe = nullptr;
     }

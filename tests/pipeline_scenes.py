@@ -59,3 +59,38 @@ def stack_and_projectile(nx=3, ny=3, nz=3, height=32.0, offset=(0.3, 0.0, 0.2)):
     centers = np.vstack([base.position[1:], [[offset[0], height, offset[2]]]])
     sc = scenes._assemble(centers, (0.5, 0.5, 0.5), base.position[0], base.half_extents[0])
     return sc
+
+
+def stack_chain_and_projectile(nx=3, ny=3, nz=3, links=8, height=30.0, link_r=0.2, spacing=0.5):
+    """Sleeping WITH joints: a small box stack, a chain of `links` balls joined by DistanceJoints whose first link is kinematic (at rest) and
+    whose lower links lie on the stack's top layer -- joints and contacts in ONE island (PhysicsIslands::add_joint, islands/mod.rs:668-735) --,
+    and a box high above that lands on the stack later and wakes the whole island.  bodies = [ground, stack ..., chain links ..., projectile];
+    returns (scene, joints dict)."""
+    base = scenes.box_stack(nx, ny, nz)
+    top = 0.99 * ny
+    n0 = base.n
+    # the chain hangs over the stack's centre column; the last three links already rest on the top layer, side by side along x
+    k = np.arange(links)
+    hang = links - 3
+    pos = np.zeros((links, 3))
+    pos[:hang, 0] = 0.0; pos[:hang, 1] = top + link_r + (hang - k[:hang]) * spacing; pos[:hang, 2] = 0.1
+    pos[hang:, 0] = (k[hang:] - hang + 1) * spacing * 0.9; pos[hang:, 1] = top + link_r; pos[hang:, 2] = 0.1
+    m = 4.0 / 3.0 * np.pi * link_r ** 3
+    inertia = 0.4 * m * link_r * link_r
+    proj = np.array([[0.3 - 1.0, height, -0.8]])
+    n = n0 + links + 1
+    mc, (ixx, iyy, izz) = scenes.cuboid_mass_properties(0.5, 0.5, 0.5)
+    sc = scenes.Scene(np.concatenate([base.position, pos, proj]), np.concatenate([base.rotation, np.tile([0, 0, 0, 1.0], (links + 1, 1))]),
+                      np.zeros((n, 3)), np.zeros((n, 3)),
+                      np.concatenate([base.inv_mass, np.full(links, 1.0 / m), [1.0 / mc]]),
+                      np.concatenate([base.inv_inertia_local, np.tile([1.0 / inertia, 0, 0, 1.0 / inertia, 0, 1.0 / inertia], (links, 1)), [[1.0 / ixx, 0, 0, 1.0 / iyy, 0, 1.0 / izz]]]),
+                      np.concatenate([base.rb_type, np.zeros(links + 1, np.uint8)]),
+                      np.concatenate([base.half_extents, np.full((links, 3), link_r), [[0.5, 0.5, 0.5]]]),
+                      np.concatenate([base.shape, np.full(links, F.SHAPE_BALL, np.uint8), [0]]).astype(np.uint8))
+    sc.rb_type[n0] = F.RB_KINEMATIC
+    b1 = n0 + np.arange(links - 1)
+    d = np.linalg.norm(sc.position[b1 + 1] - sc.position[b1], axis=1)
+    J = links - 1
+    joints = dict(body1=b1.astype(np.int32), body2=(b1 + 1).astype(np.int32), local_anchor1=np.zeros((J, 3)), local_anchor2=np.zeros((J, 3)),
+                  limit_min=d.copy(), limit_max=d.copy(), compliance=np.full(J, 1e-5), collision_disabled=np.ones(J, np.uint8))
+    return sc, joints

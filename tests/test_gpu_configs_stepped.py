@@ -1,0 +1,184 @@
+"""GPU: the configurations of BASELINE.json that round 3 only compared on a first frame or timed on frozen inputs, STEPPED in the closed
+loop (device broad phase -> narrow phase -> ContactGraph / ConstraintGraph bookkeeping -> solver) against the oracle, tolerance 0
+(VERDICT r3 "next round" item 1):
+
+* cfg4 as a simulated scene: 1 000 000 mixed ball / cuboid bodies, 20 steps -- the step's new pairs in EMISSION ORDER every frame (intervals
+  re-sorted as bodies move: broad_phase.rs:214-315,373-474), the persistent interval order, manifolds, colour lists, bodies;
+* cfg5 in the closed loop: 500 000 cuboids, f64, 8 substeps, 10 steps with the threaded oracle;
+* sleeping WITH joints (islands/mod.rs:668-735 add_joint): a chain draped over a stack -- joints and contacts in one island -- falls
+  asleep, flip-flops, is woken by a dropped box, sleeps again; 260 steps, joints compared too;
+* sleeping at cfg2 scale (100 000 bodies): 40 steps, island ids, body-list order, timers every step;
+* the declared iters = 8 extension at cfg2 full size, one step;
+* bodies / colliders / joints SPAWNED after avn_sleeping_enable (the island manager must learn them).
+"""
+import os
+
+import numpy as np
+import pytest
+
+from avian_amd import scenes
+from helpers import F, compare_dicts, hip_lib, oracle_lib
+from pipeline_scenes import stack_and_projectile, stack_chain_and_projectile
+from test_gpu_closed_loop_configs import closed_loop_pair, threads
+from test_gpu_configs import setup
+from test_gpu_graph import compare_step
+from test_gpu_sleeping import compare_sleeping
+
+pytestmark = pytest.mark.gpu
+
+
+def compare_new_pairs(s, wo, wh):
+    po, ph = wo.pairs_get(), wh.pairs_get()
+    assert len(po) == len(ph) and np.array_equal(po, ph), f"step {s}: the step's new pairs differ (count {len(po)} vs {len(ph)}, or their emission order)"
+    return len(ph)
+
+
+def test_cfg4_one_million_mixed_bodies_stepped_20_frames(monkeypatch):
+    """BASELINE.json config 4 as a SIMULATED scene: every body moves (|v| <= sqrt 3 m/s + gravity), so the interval order, the swept AABBs
+    and the pair set evolve; ball-ball, ball-cuboid and cuboid-cuboid manifolds form and break among a million bodies."""
+    monkeypatch.setenv("AVO_THREADS", threads())
+    sc = scenes.sparse_mixed(1_000_000)
+    wo, wh = closed_loop_pair(sc)
+    pairs_total = 0
+    for s in range(20):
+        wo.step(); wh.step()
+        pairs_total += compare_new_pairs(s, wo, wh)
+        compare_step(s, wo, wh, check_rows=(s % 5 == 4))
+        if s % 5 == 4:
+            mo, xo, eo = wo.aabbs_download(); mh, xh, eh = wh.aabbs_download()
+            assert np.array_equal(eo, eh), f"step {s}: persistent interval order differs"
+            assert np.array_equal(mo, mh) and np.array_equal(xo, xh), f"step {s}: ColliderAabbs differ"
+    st = wh.pipeline_stats()
+    assert pairs_total > 3000 and st.pairs_added == pairs_total
+    assert st.pairs_added > st.active_pairs or st.pairs_removed == 0
+    assert st.manifolds_pushed > 100, "some of the million bodies must touch"
+    assert st.last_host_ms < 20.0
+    b = wh.bodies_download()
+    assert np.isfinite(b["position"]).all()
+
+
+def test_cfg5_half_a_million_f64_closed_loop_10_steps(monkeypatch):
+    """BASELINE.json config 5 (500 000 cuboids, Scalar = f64, 8 substeps) in the closed loop: the lattice starts to collapse (status changes
+    by the hundred thousand, a deep overflow colour), every step against the threaded oracle."""
+    monkeypatch.setenv("AVO_THREADS", threads())
+    sc = scenes.box_stack(100, 50, 100)
+    assert sc.n == 500_001
+    wo, wh = closed_loop_pair(sc, bits=64, substeps=8)
+    for s in range(10):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+        if s in (0, 9):
+            compare_new_pairs(s, wo, wh)
+            ids = np.unique(wh.pipeline_handles()[1])[::211]
+            ro, rh = wo.contacts_download(ids), wh.contacts_download(ids)
+            for k in ro:
+                assert np.array_equal(ro[k], rh[k]), f"step {s}: contact rows {k} differ"
+    st = wh.pipeline_stats()
+    assert st.pairs_added > 6_000_000 and st.manifolds > 1_000_000 and st.last_status_changes > 10_000
+    assert wh.bodies_download()["position"].dtype == np.float64
+
+
+def sleeping_pair(sc, joints=None, bits=32, substeps=4, **sleep_kw):
+    out = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(bits, substeps=substeps))
+        w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+        if joints is not None:
+            w.distance_joints_upload(**joints)
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable(); w.sleeping_enable(**sleep_kw)
+        out.append(w)
+    return out
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_sleeping_with_joints_chain_and_stack_sleep_and_are_woken(bits):
+    """A stack with a chain draped over it: the chain's DistanceJoints and the contacts are ONE island (add_joint merges, the deferred split
+    keeps jointed bodies together).  It falls asleep and wakes itself a few times (non-touching pairs that start touching),
+    stays asleep, a box dropped from 30 m lands on it (step ~135): merge, WakeIslands, the joint schedule is rebuilt for the woken bodies;
+    it settles and sleeps again.  Every step: colour lists with order, counters, bodies, joints, island ids, body-list order, timers."""
+    sc, joints = stack_chain_and_projectile()
+    wo, wh = sleeping_pair(sc, joints, bits=bits, time_to_sleep=0.3, linear_threshold=0.3, angular_threshold=0.6)
+    slept = asleep_before_impact = woken_by_impact = 0
+    for s in range(260):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh, check_rows=(s % 50 == 49))
+        compare_sleeping(s, wo, wh)
+        compare_dicts(wo.joints_download(), wh.joints_download(), f"step {s}: joints")
+        st = wh.sleeping_stats()
+        slept += st.last_islands_slept
+        if 115 < s < 130 and st.n_awake_bodies == 1:
+            asleep_before_impact = 1
+        if s > 130 and st.n_awake_bodies == sc.n - 1:
+            woken_by_impact = 1
+    st = wh.sleeping_stats()
+    assert slept >= 4 and asleep_before_impact and woken_by_impact, (slept, asleep_before_impact, woken_by_impact)
+    assert st.islands.n_islands == 1 and st.islands.n_sleeping_islands == 1, "chain, stack and the landed box end up asleep in one island"
+    assert float(np.abs(wh.joints_download()["total_lagrange"]).max()) > 0.0
+
+
+def test_sleeping_at_cfg2_scale_40_steps(monkeypatch):
+    """cfg2's 100 000 bodies with avn_sleeping_enable: one island of 100 000 (merges by the hundred thousand in the first step), the split
+    candidate, 5 bytes per body and 8 bytes per status change read by the host every step."""
+    monkeypatch.setenv("AVO_THREADS", threads())
+    sc = scenes.box_stack(50, 40, 50)
+    wo, wh = sleeping_pair(sc)
+    for s in range(40):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh)
+        compare_sleeping(s, wo, wh)
+    st = wh.sleeping_stats()
+    assert st.islands.merges >= 99_999 and st.islands.n_bodies == 100_000
+    assert st.last_host_ms < 200.0
+
+
+def test_cfg2_full_size_eight_solver_iterations_one_step(monkeypatch):
+    """The declared `solver_iterations = 8` extension (BASELINE.json's "8 XPBD iters" has no reference knob: SURVEY.md header note 2) at the
+    size the bench reports it: 100 000 bodies, 678 200 manifolds, one whole step."""
+    monkeypatch.setenv("AVO_THREADS", threads())
+    sc = scenes.box_stack(50, 40, 50)
+    wo = F.World(oracle_lib(), F.default_config(32, substeps=4, solver_iterations=8))
+    wh = F.World(hip_lib(), F.default_config(32, substeps=4, solver_iterations=8))
+    po = setup(wo, oracle_lib(), sc); ph = setup(wh, hip_lib(), sc)
+    assert np.array_equal(po, ph) and len(po) == 1_244_836
+    wo.step(); wh.step()
+    compare_dicts(wo.bodies_download(), wh.bodies_download(), "cfg2 iters = 8: bodies")
+    compare_dicts(wo.impulses_download(), wh.impulses_download(), "cfg2 iters = 8: impulses")
+
+
+def test_spawn_bodies_colliders_and_joints_while_sleeping_is_on():
+    """Bodies, colliders and a joint uploaded AFTER avn_sleeping_enable: the island manager learns the new colliders (RigidBodyColliders)
+    and the joint (add_joint merges its bodies' islands), the new bodies' SleepTimers start at 0 and take the world's thresholds."""
+    base = stack_and_projectile(3, 3, 3, height=60.0)
+    n0 = base.n
+    lin = np.full(n0, 0.15, np.float32); ang = np.full(n0, 0.15, np.float32); dis = np.zeros(n0, np.uint8)
+    wo, wh = sleeping_pair(base, body_linear_threshold=lin, body_angular_threshold=ang, body_sleeping_disabled=dis)
+    for s in range(30):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh); compare_sleeping(s, wo, wh)
+    # spawn two boxes 1.2 m over the stack, joined to each other by a DistanceJoint
+    for w in (wo, wh):
+        b = w.bodies_download()
+        extra = np.array([[0.2, 5.5, 0.1], [0.2, 6.9, 0.1]])
+        kw = base.body_kwargs()
+        kw = {k: (np.concatenate([v, v[-2:]]) if isinstance(v, np.ndarray) else v) for k, v in kw.items()}
+        kw["position"] = np.concatenate([b["position"].astype(np.float64), extra]); kw["rotation"] = np.concatenate([b["rotation"].astype(np.float64), [[0, 0, 0, 1.0]] * 2])
+        kw["linear_velocity"] = np.concatenate([b["linear_velocity"].astype(np.float64), np.zeros((2, 3))]); kw["angular_velocity"] = np.concatenate([b["angular_velocity"].astype(np.float64), np.zeros((2, 3))])
+        w.bodies_upload(**kw)
+        ck = base.collider_kwargs()
+        w.colliders_upload(entity_index=np.concatenate([ck["entity_index"], [n0 + 500, n0 + 501]]).astype(np.uint32), body=np.arange(n0 + 2, dtype=np.int32),
+                           shape=np.concatenate([ck["shape"], [0, 0]]).astype(np.uint8), half_extents=np.concatenate([ck["half_extents"], [[0.5, 0.5, 0.5]] * 2]))
+        w.collider_materials_upload(friction=0.5)
+        w.distance_joints_upload(body1=np.array([n0], np.int32), body2=np.array([n0 + 1], np.int32), local_anchor1=np.zeros((1, 3)), local_anchor2=np.zeros((1, 3)),
+                                 limit_min=np.array([1.4]), limit_max=np.array([1.4]), compliance=np.array([1e-5]))
+    compare_sleeping(30, wo, wh)
+    so = wh.sleeping_state()
+    assert so["island"][n0] == so["island"][n0 + 1] != 0xFFFFFFFF, "the joint must merge the two spawned bodies' islands"
+    assert (so["sleep_timer"][n0:] == 0).all()
+    for s in range(31, 150):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh); compare_sleeping(s, wo, wh)
+        compare_dicts(wo.joints_download(), wh.joints_download(), f"step {s}: joints")
+    st = wh.sleeping_stats()
+    assert st.islands.n_bodies == n0 - 1 + 2
+    assert wh.sleeping_state()["island"][n0] == wh.sleeping_state()["island"][1], "the spawned boxes landed on the stack: one island"

@@ -62,7 +62,7 @@ def main():
                         "island_blocks": int(tm.island_blocks), "kernel_launches_per_step": int(tm.kernel_launches),
                         "last_step_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4), "substeps": round(tm.substeps_ms, 4),
                                          "finalize": round(tm.finalize_ms, 4), "step": round(tm.step_ms, 4)},
-                        "path": "closed loop: device broad phase + device narrow phase (Ball/Cuboid) + library host bookkeeping + solver (avn_pipeline_enable)"})
+                        "path": "closed loop: device broad phase + device narrow phase (Ball/Cuboid) + ContactGraph / ConstraintGraph bookkeeping on the device (k_graph.hip) + solver (avn_pipeline_enable(1))"})
         print(f"{name}: {n_dyn} boxes, {substeps} substeps, {steps} steps | MI355X {th * 1e3:.3f} ms/step ({substeps / th:.0f} substeps/s) | "
               f"CPU oracle 1 thread {to * 1e3:.2f} ms/step ({substeps / to:.1f} substeps/s), {threads} threads {tm_ * 1e3:.2f} ms/step | x{min(to, tm_) / th:.0f} | bodies bit-identical after {steps + 1} steps: {same} | "
               f"manifolds {st.manifolds}, active pairs {st.active_pairs}, status changes last step {st.last_status_changes}, max |v| {float(np.abs(bh['linear_velocity']).max()):.3f} | "

@@ -43,6 +43,11 @@ def main():
     if "--reps" in a:
         reps = int(a[a.index("--reps") + 1])
     out = {}
+    # AVN_BIAS_SKELETON only exists in the measurement build of the library (make -C avian_amd/csrc measure: -DAVN_MEASURE)
+    mlib = os.path.join(REPO, "avian_amd", "csrc", "measure", "libavian_mi355x.so")
+    if not os.path.exists(mlib):
+        subprocess.run(["make", "-C", os.path.join(REPO, "avian_amd", "csrc"), "-j8", "measure"], check=True)
+    os.environ["AVN_LIB_PATH"] = mlib
     for name, env in (("solve", {}), ("memory_skeleton", {"AVN_BIAS_SKELETON": "1"})):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--child", scene, str(reps)], env=dict(os.environ, **env), capture_output=True, text=True, cwd=REPO)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
