@@ -56,12 +56,12 @@ template <class T> void launch_writeback_solver_bodies(const DW<T>&, hipStream_t
 template <class T> void launch_xpbd_snapshot(const DW<T>&, hipStream_t);
 template <class T> void launch_xpbd_velocity_projection(const DW<T>&, const StepParams<T>&, hipStream_t);
 // k_contacts.hip
-template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t);
+template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t, bool count_clean = false /* *DW::constraint_count is known to be zero */);
 template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
 // body-centric warm start over the incidence CSR (DW::inc_off / inc_ent), optionally preceded by integrate_velocities
 template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);
 // (re)build DW::inc_slot from DW::m_bodies / color_offsets (memset + one kernel)
-template <class T> void launch_build_incidence_slots(const DW<T>&, hipStream_t);
+template <class T> void launch_build_incidence_slots(const DW<T>&, hipStream_t, bool cleared = false /* the table has been set to EMPTY already */);
 uint32_t color_grid_blocks(uint32_t count);
 // level schedule of the overflow colour (device arrays; see k_overflow_pass): manifold indices in `order`
 struct OverflowSchedule {
@@ -88,8 +88,10 @@ template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&
                                               const uint32_t* level_offsets, const int4* rec, hipStream_t);
 template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepParams<T>&, hipStream_t);
 // k_broadphase.hip
-template <class T> void launch_update_aabb(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);
-template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t);
+// zero_words[0 .. n_zero) (n_zero <= 256) are cleared by the kernel: the step-scoped counters of what follows; returns whether a kernel ran
+template <class T> bool launch_update_aabb(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t, uint32_t* zero_words = nullptr, uint32_t n_zero = 0);
+// counters_clean: n_dropped[0..2) is known to be zero (no memset launch)
+template <class T> void launch_interval_keys(const DW<T>&, const BP<T>&, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t, bool counters_clean = false);
 // partial: 6 * ceil(C / 256) scalars; returns the number of partial records written
 template <class T> uint32_t launch_dynamic_bounds(const DW<T>&, const BP<T>&, T* partial, hipStream_t);
 uint32_t radix_blocks(uint32_t n);
@@ -99,10 +101,10 @@ uint32_t scan_block_sums_needed(uint32_t n);
 uint32_t exclusive_scan_launches(uint32_t n);  // kernels launch_exclusive_scan issues for n items
 // `enabled` (device flag, may be null): when it reads 0 every kernel of the call returns immediately
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
-                                          const uint32_t* enabled, hipStream_t);
+                                          const uint32_t* enabled, K** keys_out, uint32_t** vals_out /* where the result is: one of the two buffer pairs */, hipStream_t);
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t, const uint32_t* enabled = nullptr);
 template <class T> void launch_gather_sorted(const DW<T>&, const BP<T>&, const uint32_t* sorted_collider, uint32_t n, hipStream_t);
-template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const SweepScratch&, hipStream_t);
+template <class T> void launch_sweep_ranges(const BP<T>&, uint32_t n, const SweepScratch&, hipStream_t, bool counters_clean = false /* SweepScratch::n_long[0..2) is known to be zero */);
 template <class T> void launch_sweep(const BP<T>&, uint32_t n, bool emit, const SweepScratch&, uint32_t* counts, const uint32_t* offsets, avn_pair* out, hipStream_t);
 size_t sweep_long_item_bytes();
 template <class T> void launch_bounds_reduce(const T* partial, uint32_t n_partials, double* out6, hipStream_t);   // k_dynamic_bounds' partials -> one (min, max)
@@ -142,7 +144,7 @@ template <class T> void launch_narrow_phase(const DW<T>&, const BP<T>&, const CT
 // dense form (device closed loop): every row id < n_rows with AVN_CP_ROW_USED is a pair; the row's status change goes to chg[id] / has[id]
 // (id order = the order NarrowPhase::update walks the status bits) and rows that must be removed are counted in *n_remove
 template <class T> void launch_narrow_phase_dense(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t n_rows, uint32_t* chg, uint32_t* has,
-                                                  uint32_t* n_remove, hipStream_t);
+                                                  uint32_t* n_remove, hipStream_t, bool reset_counter = true /* false: *n_remove is known to be zero (no memset launch) */);
 template <class T> void launch_narrow_phase_rows(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* list, uint32_t n_list, uint32_t range_base, uint32_t n_range,
                                                  uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t);   // rows added this step (counter not reset)
 // manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
@@ -168,7 +170,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 #define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
-       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
+       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
        PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
 struct PG {
@@ -202,8 +204,11 @@ struct PG {
     uint32_t* new_ids;      // [new pairs of the step] the ContactId k_pg_add_pairs gave the i-th new pair (NULL: not recorded)
 };
 #define PG_EST_DONE 0x80000000u
-template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, hipStream_t);
-void launch_pg_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, hipStream_t);
+// ids + rows + PairKeys of the step's new pairs and the IdPool counters, one launch (pair_set must have room: pg_pair_set_reserve)
+template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, uint64_t* pair_set, uint32_t pair_set_cap, hipStream_t);
+// exclusive scan of PG::has (= op index per changed row) + the classification of the changed rows, one launch; ctr[PGC_N_OPS] <- changes.
+// PGC_BUCKET must be zero when it starts (k_pg_build_handles leaves it so).
+void launch_pg_scan_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t);
 // an op batch from a LIST instead of from the rows' status changes (SleepIslands / WakeIslands: pops and pushes in the island manager's order):
 // fills the same op arrays as k_pg_classify for ops (cids[k], kinds[k] = 1 push | 2 pop); the rest of the pipeline is the status loop's
 template <class T> void launch_pg_ops_from_list(const PG&, const CT<T>&, const uint32_t* cids, const uint32_t* kinds, uint32_t n, uint32_t n_bodies, hipStream_t);

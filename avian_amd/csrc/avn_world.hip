@@ -267,7 +267,7 @@ template <class T> struct World : WorldBase {
         if (ev_counters) (void)hipEventDestroy(ev_counters);
         if (h_counters) (void)hipHostFree(h_counters);
         if (h_pg_error) (void)hipHostFree(h_pg_error);
-        for (hipEvent_t e : {ev_np_fork, ev_np_old}) if (e) (void)hipEventDestroy(e);
+        for (hipEvent_t e : {ev_np_fork, ev_np_old, ev_slot_clear}) if (e) (void)hipEventDestroy(e);
         for (hipEvent_t e : {ev_side_fork, ev_side_done}) if (e) (void)hipEventDestroy(e);
         if (stream_side) { (void)hipStreamSynchronize(stream_side); (void)hipStreamDestroy(stream_side); }
         if (stream) (void)hipStreamDestroy(stream);

@@ -20,6 +20,7 @@
 // Integer/compare work only; VALU-bound in the sweep for dense scenes (O(k) tests per interval), HBM/L2 traffic is the
 // sorted records once per 64 intervals.
 #include "avn_kernels.h"
+#include "avn_scan.h"
 
 namespace avn {
 
@@ -43,8 +44,11 @@ template <class T> __device__ __forceinline__ void shape_aabb(uint32_t shape, V3
 }
 
 template <class T>
-__global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepParams<T> p) {
+__global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepParams<T> p, uint32_t* __restrict__ zero_words, uint32_t n_zero) {
     uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    // the first kernel of a step also clears the step-scoped counters of the kernels behind it (constraint count, dropped / unsorted,
+    // long-interval chunks): one memset launch less per counter on the step's serial chain
+    if (c < n_zero) zero_words[c] = 0u;
     if (c >= bp.n_colliders) return;
     uint4 ci = bp.col_info[c];  // entity, body, shape | cflags << 8, -
     Vec4<T> he4 = bp.col_he[c];  // (half_extents.xyz, collision_margin)
@@ -254,73 +258,31 @@ __global__ __launch_bounds__(64) void k_radix_scatter(const K* __restrict__ keys
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// exclusive scan (uint32), three kernels; tile = 2048
-#define SC_TILE 2048
-__global__ __launch_bounds__(256) void k_scan_sums(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ sums, const uint32_t* __restrict__ enabled) {
-    __shared__ uint32_t red[256];
+// exclusive scan (uint32) in ONE launch: avn_scan.h (chained scan, decoupled look-back, self-cleaning state)
+__global__ __launch_bounds__(256) void k_scan_chained(const uint32_t* in, uint32_t* out /* may alias `in` */, uint32_t n, uint32_t* __restrict__ st, uint32_t* __restrict__ total,
+                                                      const uint32_t* __restrict__ enabled) {
     if (enabled && *enabled == 0u) return;
-    uint32_t base = blockIdx.x * SC_TILE, t = threadIdx.x, s = 0;
-    for (uint32_t k = 0; k < SC_TILE / 256; ++k) { uint32_t i = base + t * (SC_TILE / 256) + k; if (i < n) s += in[i]; }
-    red[t] = s;
-    __syncthreads();
-    for (uint32_t st = 128; st > 0; st >>= 1) { if (t < st) red[t] += red[t + st]; __syncthreads(); }
-    if (t == 0) sums[blockIdx.x] = red[0];
-}
-__global__ __launch_bounds__(256) void k_scan_top(uint32_t* sums, uint32_t nb, uint32_t* total, const uint32_t* __restrict__ enabled) {
-    // single block: sequential over chunks of 256 with a running carry
-    __shared__ uint32_t buf[256];
-    __shared__ uint32_t carry;
-    if (enabled && *enabled == 0u) return;
-    uint32_t t = threadIdx.x;
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t c0 = 0; c0 < nb; c0 += 256) {
-        uint32_t i = c0 + t;
-        uint32_t v = i < nb ? sums[i] : 0u;
-        buf[t] = v;
-        __syncthreads();
-        for (uint32_t off = 1; off < 256; off <<= 1) {
-            uint32_t add = t >= off ? buf[t - off] : 0u;
-            __syncthreads();
-            buf[t] += add;
-            __syncthreads();
-        }
-        uint32_t incl = buf[t];
-        if (i < nb) sums[i] = carry + incl - v;
-        __syncthreads();
-        if (t == 255) carry += incl;
-        __syncthreads();
-    }
-    if (t == 0 && total) *total = carry;
-}
-__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* in, uint32_t* out, uint32_t n, const uint32_t* __restrict__ sums, const uint32_t* __restrict__ enabled) {
-    __shared__ uint32_t buf[256];
-    if (enabled && *enabled == 0u) return;
-    uint32_t base = blockIdx.x * SC_TILE, t = threadIdx.x;
-    const uint32_t per = SC_TILE / 256;
-    uint32_t v[per];
-    uint32_t s = 0;
-    for (uint32_t k = 0; k < per; ++k) { uint32_t i = base + t * per + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
-    buf[t] = s;
-    __syncthreads();
-    for (uint32_t off = 1; off < 256; off <<= 1) {
-        uint32_t add = t >= off ? buf[t - off] : 0u;
-        __syncthreads();
-        buf[t] += add;
-        __syncthreads();
-    }
-    uint32_t excl = buf[t] - s + sums[blockIdx.x];
-    for (uint32_t k = 0; k < per; ++k) { uint32_t i = base + t * per + k; if (i < n) out[i] = excl; excl += v[k]; }
+    const uint32_t nb = gridDim.x, t = threadIdx.x;
+    const uint32_t tile = sc_take_tile(st);
+    const uint32_t base = tile * SC_TILE;
+    constexpr uint32_t per = SC_TILE / 256;
+    uint32_t v[per], s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t i = base + t * per + k; v[k] = i < n ? in[i] : 0u; s += v[k]; }
+    uint32_t tile_sum;
+    uint32_t excl = sc_block_excl(s, &tile_sum);
+    excl += sc_lookback(st, tile, nb, tile_sum);
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) { const uint32_t i = base + t * per + k; if (i < n) out[i] = excl; excl += v[k]; }
+    if (total && tile == nb - 1u && t == 255u) *total = excl;   // (thread 255 of the last tile ends on the grand total)
 }
 void launch_exclusive_scan(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* block_sums, uint32_t* total, hipStream_t s, const uint32_t* enabled) {
     if (n == 0) { if (total) (void)hipMemsetAsync(total, 0, sizeof(uint32_t), s); return; }
     uint32_t nb = (n + SC_TILE - 1) / SC_TILE;
-    hipLaunchKernelGGL(k_scan_sums, dim3(nb), dim3(256), 0, s, in, n, block_sums, enabled);
-    hipLaunchKernelGGL(k_scan_top, dim3(1), dim3(256), 0, s, block_sums, nb, total, enabled);
-    hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, out, n, block_sums, enabled);
+    hipLaunchKernelGGL(k_scan_chained, dim3(nb), dim3(256), 0, s, in, out, n, block_sums, total, enabled);
 }
-uint32_t exclusive_scan_launches(uint32_t n) { return n == 0 ? 0u : 3u; }
-uint32_t scan_block_sums_needed(uint32_t n) { return (n + SC_TILE - 1) / SC_TILE + 1; }
+uint32_t exclusive_scan_launches(uint32_t n) { return n == 0 ? 0u : 1u; }
+uint32_t scan_block_sums_needed(uint32_t n) { return 2u * ((n + SC_TILE - 1) / SC_TILE) + 8u; }   // uint32 words of scan state: ticket, done, 64-bit status per tile (zeroed at allocation, self-cleaning after)
 
 // ---------------------------------------------------------------------------------------------------------
 // gather the sorted interval records
@@ -800,11 +762,12 @@ __global__ __launch_bounds__(256) void k_long_finish(const LongItem* __restrict_
 
 // ---------------------------------------------------------------------------------------------------------
 // launchers
-template <class T> void launch_update_aabb(const DW<T>& w, const BP<T>& bp, const StepParams<T>& p, hipStream_t s) {
-    if (bp.n_colliders) hipLaunchKernelGGL(k_update_aabb<T>, dim3((bp.n_colliders + 255) / 256), dim3(256), 0, s, w, bp, p);
+template <class T> bool launch_update_aabb(const DW<T>& w, const BP<T>& bp, const StepParams<T>& p, hipStream_t s, uint32_t* zero_words, uint32_t n_zero) {
+    if (bp.n_colliders) hipLaunchKernelGGL(k_update_aabb<T>, dim3((bp.n_colliders + 255) / 256), dim3(256), 0, s, w, bp, p, zero_words, n_zero < 256u ? n_zero : 256u);
+    return bp.n_colliders != 0;   // false: nothing was launched, nothing was cleared
 }
-template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t s) {
-    (void)hipMemsetAsync(n_dropped, 0, 2 * sizeof(uint32_t), s);  // [n_dropped, unsorted]
+template <class T> void launch_interval_keys(const DW<T>& w, const BP<T>& bp, typename BP<T>::Key* keys, uint32_t* vals, uint32_t* n_dropped, hipStream_t s, bool counters_clean) {
+    if (!counters_clean) (void)hipMemsetAsync(n_dropped, 0, 2 * sizeof(uint32_t), s);  // [n_dropped, unsorted]
     if (bp.n_intervals) hipLaunchKernelGGL(k_interval_keys<T>, dim3((bp.n_intervals + 255) / 256), dim3(256), 0, s, w, bp, keys, vals, n_dropped);
 }
 uint32_t radix_blocks(uint32_t n) { return (n + RS_TILE - 1) / RS_TILE; }
@@ -818,8 +781,8 @@ uint32_t radix_pass_launches(uint32_t n) { uint32_t nb = radix_blocks(n); return
 #define SS_MAX 8192u
 #define SS_WAVES 8
 #define SS_THREADS (64 * SS_WAVES)
-__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted, uint32_t bits) {
-    if (unsorted && *unsorted == 0u) return;   // the persistent order is still sorted
+// the sort of one tile of <= SS_MAX (key, value) pairs by ONE workgroup: `bits` / 8 passes, ping-pong between (keys_a, vals_a) and (keys_b, vals_b)
+__device__ __forceinline__ void sort_small_body(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, uint32_t bits) {
     __shared__ uint32_t cnt[SS_WAVES][256];    // per-wave digit counts, then the wave's running output offsets
     __shared__ uint32_t tot[256];
     const uint32_t t = threadIdx.x, lane = t & 63u;
@@ -891,20 +854,89 @@ __global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uin
         uint32_t* tv = vi; vi = vo; vo = tv;
     }
 }
-template <class K> static bool sort_small(K*, uint32_t*, K*, uint32_t*, uint32_t, const uint32_t*, hipStream_t) { return false; }
-template <> bool sort_small<uint32_t>(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* unsorted, hipStream_t s) {
-    if (n > SS_MAX) return false;
-    hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted, 32u);   // four passes: ends in (keys_a, vals_a)
-    return true;
+__global__ __launch_bounds__(SS_THREADS) void k_sort_small(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted, uint32_t bits) {
+    if (unsorted && *unsorted == 0u) return;   // the persistent order is still sorted
+    sort_small_body(keys_a, vals_a, keys_b, vals_b, n, bits);
 }
-uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes) { return key_bytes == 4 && n <= SS_MAX ? 1u : key_bytes * radix_pass_launches(n); }
+// Medium sorts (SS_MAX < n <= SM_TILE x SM_MAX_TILES keys; round 4: cfg2's 100 k intervals took four radix passes of two launches each,
+// 155 us on the closed loop's critical path): TWO launches.  k_sort_tiles: every workgroup sorts one tile of SM_TILE pairs as k_sort_small
+// does (tile-local ping-pong inside the two buffers).  k_merge_tiles: an element's final position is its position in its own tile plus,
+// for every EARLIER tile, the number of keys <= its key and, for every LATER tile, the number of keys < its key -- exactly the stable
+// order (equal keys keep their input order: earlier tile first, tile order inside a tile).  The tiles' first / last keys sit in LDS and
+// decide most (element, tile) pairs without a search: the broad phase sorts LAST frame's order by this frame's keys, so a tile's key range
+// overlaps its neighbours' at most; only there an element binary-searches.  Worst case (unrelated order: a scene's first frame) every
+// element searches every tile: T x log2(SM_TILE) dependent loads from L2 -- slower than the radix passes, once.
+#define SM_TILE 2048u
+#define SM_MAX_TILES 128u
+__global__ __launch_bounds__(SS_THREADS) void k_sort_tiles(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* __restrict__ unsorted, uint32_t bits) {
+    if (unsorted && *unsorted == 0u) return;
+    const uint32_t t0 = blockIdx.x * SM_TILE;
+    sort_small_body(keys_a + t0, vals_a + t0, keys_b + t0, vals_b + t0, min(SM_TILE, n - t0), bits);
+}
+__global__ __launch_bounds__(256) void k_merge_tiles(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin, uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, uint32_t n,
+                                                     const uint32_t* __restrict__ unsorted) {
+    __shared__ uint32_t s_first[SM_MAX_TILES], s_last[SM_MAX_TILES];
+    const uint32_t e = blockIdx.x * 256 + threadIdx.x;
+    if (unsorted && *unsorted == 0u) {   // (uniform) nothing was sorted: the result is the input, in the output buffers
+        if (e < n) { kout[e] = kin[e]; vout[e] = vin[e]; }
+        return;
+    }
+    const uint32_t T = (n + SM_TILE - 1u) / SM_TILE;
+    if (threadIdx.x < T) {
+        const uint32_t t0 = threadIdx.x * SM_TILE, nt = min(SM_TILE, n - t0);
+        s_first[threadIdx.x] = kin[t0]; s_last[threadIdx.x] = kin[t0 + nt - 1u];
+    }
+    __syncthreads();
+    if (e >= n) return;
+    const uint32_t key = kin[e], val = vin[e];
+    const uint32_t t = e / SM_TILE;
+    uint32_t pos = e - t * SM_TILE;
+    for (uint32_t u = 0; u < T; ++u) {
+        if (u == t) continue;
+        const uint32_t t0 = u * SM_TILE, nt = min(SM_TILE, n - t0);
+        const uint32_t first = s_first[u], last = s_last[u];
+        if (u < t) {   // keys <= key of an earlier tile
+            if (key >= last) pos += nt;
+            else if (key >= first) {
+                uint32_t lo = 0, hi = nt;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kin[t0 + mid] <= key) lo = mid + 1u; else hi = mid; }
+                pos += lo;
+            }
+        } else {       // keys < key of a later tile
+            if (key > last) pos += nt;
+            else if (key > first) {
+                uint32_t lo = 0, hi = nt;
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (kin[t0 + mid] < key) lo = mid + 1u; else hi = mid; }
+                pos += lo;
+            }
+        }
+    }
+    kout[pos] = key; vout[pos] = val;
+}
+template <class K> static bool sort_small(K*, uint32_t*, K*, uint32_t*, uint32_t, const uint32_t*, K**, uint32_t**, hipStream_t) { return false; }
+template <> bool sort_small<uint32_t>(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b, uint32_t* vals_b, uint32_t n, const uint32_t* unsorted, uint32_t** keys_out, uint32_t** vals_out, hipStream_t s) {
+    if (n <= SS_MAX) {
+        hipLaunchKernelGGL(k_sort_small, dim3(1), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted, 32u);   // four passes: ends in (keys_a, vals_a)
+        *keys_out = keys_a; *vals_out = vals_a;
+        return true;
+    }
+    if (n <= SM_TILE * SM_MAX_TILES) {   // tiles (four passes: sorted tiles in (keys_a, vals_a)), then the merge into (keys_b, vals_b)
+        hipLaunchKernelGGL(k_sort_tiles, dim3((n + SM_TILE - 1u) / SM_TILE), dim3(SS_THREADS), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted, 32u);
+        hipLaunchKernelGGL(k_merge_tiles, dim3((n + 255u) / 256u), dim3(256), 0, s, keys_a, vals_a, keys_b, vals_b, n, unsorted);
+        *keys_out = keys_b; *vals_out = vals_b;
+        return true;
+    }
+    return false;
+}
+uint32_t radix_sort_launches(uint32_t n, uint32_t key_bytes) { return key_bytes == 4 && n <= SS_MAX ? 1u : key_bytes == 4 && n <= SM_TILE * SM_MAX_TILES ? 2u : key_bytes * radix_pass_launches(n); }
 template <class K> void launch_radix_sort(K* keys_a, uint32_t* vals_a, K* keys_b, uint32_t* vals_b, uint32_t n, uint32_t* hist, uint32_t* block_sums,
-                                          const uint32_t* unsorted, hipStream_t s) {
-    // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even.  Every kernel
-    // returns at once when *unsorted == 0 (the persistent interval order is still sorted: the reference's insertion sort
-    // is O(n) then, ours is O(launch)).
+                                          const uint32_t* unsorted, K** keys_out, uint32_t** vals_out, hipStream_t s) {
+    // Every kernel returns at once (or copies through) when *unsorted == 0 (the persistent interval order is still sorted: the reference's
+    // insertion sort is O(n) then, ours is O(launch)); the result is in (*keys_out, *vals_out) either way.
+    *keys_out = keys_a; *vals_out = vals_a;
     if (n == 0) return;
-    if (sort_small<K>(keys_a, vals_a, keys_b, vals_b, n, unsorted, s)) return;   // one workgroup, one launch
+    if (sort_small<K>(keys_a, vals_a, keys_b, vals_b, n, unsorted, keys_out, vals_out, s)) return;   // one workgroup / tiles + merge: one or two launches
+    // sizeof(K) passes of 8 bits: the result ends in (keys_a, vals_a) because the pass count is even
     uint32_t nb = radix_blocks(n);
     K* ki = keys_a; uint32_t* vi = vals_a; K* ko = keys_b; uint32_t* vo = vals_b;
     for (uint32_t pass = 0; pass < sizeof(K); ++pass) {
@@ -951,9 +983,9 @@ void launch_radix_sort_bits(uint32_t* keys_a, uint32_t* vals_a, uint32_t* keys_b
 template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, const uint32_t* sorted_collider, uint32_t n, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_gather_sorted<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bp, sorted_collider, n);
 }
-template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s) {
+template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s, bool counters_clean) {
     if (!n) return;
-    (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
+    if (!counters_clean) (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
     hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / SW_BB_GROUP + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb, bp.s_bb2);
     hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
                        sc.n_long, sc.long_cap, sc.n_long + 1);
@@ -982,16 +1014,16 @@ uint32_t sweep_count_slots() { return SW_WAVES; }
 uint32_t sweep_pad_records() { return 8u; }  // k_sweep reads whole candidate batches: s_yz needs this many records past n
 
 #define INST(T)                                                                                          \
-    template void launch_update_aabb<T>(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t);  \
-    template void launch_interval_keys<T>(const DW<T>&, const BP<T>&, typename BP<T>::Key*, uint32_t*, uint32_t*, hipStream_t); \
+    template bool launch_update_aabb<T>(const DW<T>&, const BP<T>&, const StepParams<T>&, hipStream_t, uint32_t*, uint32_t);  \
+    template void launch_interval_keys<T>(const DW<T>&, const BP<T>&, typename BP<T>::Key*, uint32_t*, uint32_t*, hipStream_t, bool); \
     template void launch_gather_sorted<T>(const DW<T>&, const BP<T>&, const uint32_t*, uint32_t, hipStream_t); \
-    template void launch_sweep_ranges<T>(const BP<T>&, uint32_t, const SweepScratch&, hipStream_t);     \
+    template void launch_sweep_ranges<T>(const BP<T>&, uint32_t, const SweepScratch&, hipStream_t, bool);     \
     template uint32_t launch_dynamic_bounds<T>(const DW<T>&, const BP<T>&, T*, hipStream_t);            \
     template void launch_sweep<T>(const BP<T>&, uint32_t, bool, const SweepScratch&, uint32_t*, const uint32_t*, avn_pair*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST
-template void launch_radix_sort<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
-template void launch_radix_sort<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, hipStream_t);
+template void launch_radix_sort<uint32_t>(uint32_t*, uint32_t*, uint32_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, uint32_t**, uint32_t**, hipStream_t);
+template void launch_radix_sort<uint64_t>(uint64_t*, uint32_t*, uint64_t*, uint32_t*, uint32_t, uint32_t*, uint32_t*, const uint32_t*, uint64_t**, uint32_t**, hipStream_t);
 
 }  // namespace avn

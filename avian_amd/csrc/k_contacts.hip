@@ -817,8 +817,8 @@ __global__ __launch_bounds__(256) void k_store_contact_impulses(DW<T> w) {
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-template <class T> void launch_prepare_contact_constraints(const DW<T>& w, const StepParams<T>& p, hipStream_t s) {
-    (void)hipMemsetAsync(w.constraint_count, 0, sizeof(uint32_t), s);
+template <class T> void launch_prepare_contact_constraints(const DW<T>& w, const StepParams<T>& p, hipStream_t s, bool count_clean) {
+    if (!count_clean) (void)hipMemsetAsync(w.constraint_count, 0, sizeof(uint32_t), s);
     if (w.n_manifolds) hipLaunchKernelGGL(k_prepare_contact_constraints<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, p);
 }
 template <class T> void launch_store_contact_impulses(const DW<T>& w, hipStream_t s) {
@@ -870,8 +870,8 @@ __global__ __launch_bounds__(256) void k_build_incidence_slots(DW<T> w) {
     w.inc_slot[(size_t)lo * w.inc_stride + (uint32_t)b.x] = m;
     w.inc_slot[(size_t)lo * w.inc_stride + (uint32_t)b.y] = m | 0x80000000u;
 }
-template <class T> void launch_build_incidence_slots(const DW<T>& w, hipStream_t s) {
-    (void)hipMemsetAsync(w.inc_slot, 0xFF, (size_t)AVN_COLOR_OVERFLOW_INDEX * w.inc_stride * sizeof(uint32_t), s);
+template <class T> void launch_build_incidence_slots(const DW<T>& w, hipStream_t s, bool cleared) {
+    if (!cleared) (void)hipMemsetAsync(w.inc_slot, 0xFF, (size_t)AVN_COLOR_OVERFLOW_INDEX * w.inc_stride * sizeof(uint32_t), s);
     if (w.n_manifolds) hipLaunchKernelGGL(k_build_incidence_slots<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w);
 }
 // ------------------------------------------------------------------------------------------------------
@@ -1006,10 +1006,10 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
 }
 
 #define INST(T)                                                                                             \
-    template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t);   \
+    template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t, bool);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
-    template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t);                               \
+    template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t, bool);                               \
     template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t); \
     template void launch_overflow_flow<T>(const DW<T>&, const StepParams<T>&, int, const OverflowFlow&, uint32_t, uint32_t, hipStream_t);
 INST(float)

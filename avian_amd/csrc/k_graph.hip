@@ -28,6 +28,7 @@
 //
 // Per-body colour masks (PG::bcol, bit c = "in GraphColor c's body_set") replace the 24 BitVecs: same information, one load.
 #include "avn_kernels.h"
+#include "avn_scan.h"
 
 namespace avn {
 
@@ -63,77 +64,111 @@ __device__ __forceinline__ uint32_t wave_incl_max(uint32_t v, uint32_t lane) {
 }
 
 // ---- new pairs: IdPool::alloc_id in emission order + ContactGraph::add_edge_and_key_with --------------------------------------
+// One launch (round 4; was k_hs_insert_pairs + k_pg_add_pairs + k_pg_after_add): every pair takes its id, initialises its row and puts its
+// PairKey into ContactGraph::pair_set; the LAST workgroup to finish (ticket in ctr[PGC_ADD_DONE]) moves the IdPool's counters -- every
+// workgroup has read them by then.
+__device__ __forceinline__ uint64_t pg_hs_mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
 template <class T>
-__global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn_pair* __restrict__ pairs, uint32_t total) {
+__global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn_pair* __restrict__ pairs, uint32_t total, uint64_t* __restrict__ pair_set, uint32_t pair_set_mask) {
+    __shared__ uint32_t s_last;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= total) return;
     const uint32_t head = pg.ctr[PGC_FREE_HEAD], n_free = pg.ctr[PGC_N_FREE], next = pg.ctr[PGC_NEXT_ID];
-    const uint32_t id = i < n_free ? pg.free_ids[head + i] : next + (i - n_free);   // the i-th lowest free id, then fresh ids
-    const avn_pair pr = pairs[i];
-    const uint32_t f = pr.flags;
-    const uint32_t flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
-                           ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u) | AVN_CP_ROW_USED;
-    ct.meta[id] = make_uint4(pg.ent2slot[pr.collider1], pg.ent2slot[pr.collider2], flags, 0u);
-    ct.dcount[id] = 0;
-    pg.bodies[id] = make_int2(pr.body1, pr.body2);
-    pg.color[id] = PG_NONE;
-    if (pg.new_ids) pg.new_ids[i] = id;
+    if (i < total) {
+        const uint32_t id = i < n_free ? pg.free_ids[head + i] : next + (i - n_free);   // the i-th lowest free id, then fresh ids
+        const avn_pair pr = pairs[i];
+        const uint32_t f = pr.flags;
+        const uint32_t flags = ((f & AVN_PAIR_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_CP_GENERATE_CONSTRAINTS : 0u) | ((f & AVN_PAIR_MODIFY_CONTACTS) ? (uint32_t)AVN_CP_MODIFY_CONTACTS : 0u) |
+                               ((f & AVN_PAIR_CONTACT_EVENTS) ? (uint32_t)AVN_CP_CONTACT_EVENTS : 0u) | AVN_CP_ROW_USED;
+        ct.meta[id] = make_uint4(pg.ent2slot[pr.collider1], pg.ent2slot[pr.collider2], flags, 0u);
+        ct.dcount[id] = 0;
+        pg.bodies[id] = make_int2(pr.body1, pr.body2);
+        pg.color[id] = PG_NONE;
+        if (pg.new_ids) pg.new_ids[i] = id;
+        // add_edge_and_key_with (contact_graph.rs:521-566): the key joins the pair set
+        const uint32_t a = pr.collider1, b = pr.collider2;
+        const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+        uint32_t h = (uint32_t)pg_hs_mix(key) & pair_set_mask;
+        for (;;) {
+            const unsigned long long prev = atomicCAS((unsigned long long*)&pair_set[h], ~0ull, (unsigned long long)key);
+            if (prev == ~0ull || prev == key) break;
+            h = (h + 1u) & pair_set_mask;
+        }
+    }
+    __syncthreads();   // every thread of the workgroup has read the counters
+    if (threadIdx.x == 0) { __threadfence(); s_last = atomicAdd(&pg.ctr[PGC_ADD_DONE], 1u) == gridDim.x - 1u ? 1u : 0u; }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        const uint32_t used = total < n_free ? total : n_free;
+        pg.ctr[PGC_FREE_HEAD] = head + used;
+        pg.ctr[PGC_N_FREE] = n_free - used;
+        pg.ctr[PGC_NEXT_ID] = next + (total - used);
+        pg.ctr[PGC_ADD_DONE] = 0u;
+    }
 }
-__global__ void k_pg_after_add(PG pg, uint32_t total) {
-    const uint32_t n_free = pg.ctr[PGC_N_FREE];
-    const uint32_t used = total < n_free ? total : n_free;
-    pg.ctr[PGC_FREE_HEAD] += used;
-    pg.ctr[PGC_N_FREE] = n_free - used;
-    pg.ctr[PGC_NEXT_ID] += total - used;
-}
-template <class T> void launch_pg_add_pairs(const PG& pg, const CT<T>& ct, const avn_pair* pairs, uint32_t total, hipStream_t s) {
+template <class T> void launch_pg_add_pairs(const PG& pg, const CT<T>& ct, const avn_pair* pairs, uint32_t total, uint64_t* pair_set, uint32_t pair_set_cap, hipStream_t s) {
     if (!total) return;
-    hipLaunchKernelGGL(k_pg_add_pairs<T>, dim3((total + 255) / 256), dim3(256), 0, s, pg, ct, pairs, total);
-    hipLaunchKernelGGL(k_pg_after_add, dim3(1), dim3(1), 0, s, pg, total);
+    hipLaunchKernelGGL(k_pg_add_pairs<T>, dim3((total + 255) / 256), dim3(256), 0, s, pg, ct, pairs, total, pair_set, pair_set_cap - 1u);
 }
 
 // ---- the status-change loop, decision part (system_param.rs:155-373) ------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pg_classify(PG pg, uint32_t n_rows, uint32_t n_bodies) {
-    __shared__ uint32_t hist[AVN_GRAPH_COLOR_COUNT];
-    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT) hist[threadIdx.x] = 0;
-    __syncthreads();
-    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
-    if (c < n_rows && pg.has[c]) {
-        const uint32_t k = pg.off[c];
-        const uint32_t w = pg.chg[c];
-        const uint32_t flags = w & 0xFFFFu, n_manifolds = (w >> 16) & 0xFFu;
-        const int dcount = (int)((w >> 24) & 0xFFu) - 128;
-        const bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
-        const uint32_t col = pg.color[c];
-        const bool has_handle = col != PG_NONE;   // ContactEdge::constraint_handles is non-empty (one manifold per convex pair)
-        uint32_t kind = PG_KIND_NONE, remove = 0;
-        if (flags & AVN_CP_DISJOINT_AABB) { if (generates && has_handle) kind = PG_KIND_POP; remove = 1; }
-        else if (flags & AVN_CP_STARTED_TOUCHING) { if (generates && n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
-        else if (flags & AVN_CP_STOPPED_TOUCHING) { if (generates && has_handle) kind = PG_KIND_POP; }
-        else if (touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) { if (n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
-        else if (touching && generates && dcount > 0) { if (!has_handle) kind = PG_KIND_PUSH; }
-        else if (touching && generates && dcount < 0) { if (has_handle) kind = PG_KIND_POP; }
-        const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
-        if (kind == PG_KIND_PUSH && s1 && s2) kind = PG_KIND_NONE;   // (debug_assert in the reference: never both)
-        const int2 b = pg.bodies[c];
-        const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
-        pg.op_cid[k] = c;
-        pg.op_chg[k] = w;
-        pg.op_info[k] = kind | (s1 ? 4u : 0u) | (s2 ? 8u : 0u) | (remove << 4) | (opcol << 8);
-        pg.op_bodies[k] = b;
-        pg.rem_flag[k] = remove;
-        // one entry per side whose body's colour mask the op reads or writes: non-static sides of pushes and of pops of colours 0..22
-        const bool masks = kind == PG_KIND_PUSH || (kind == PG_KIND_POP && col < (uint32_t)AVN_COLOR_OVERFLOW_INDEX);
-        pg.ekey_a[2 * k] = (masks && !s1) ? (uint32_t)b.x : n_bodies;
-        pg.ekey_a[2 * k + 1] = (masks && !s2) ? (uint32_t)b.y : n_bodies;
-        pg.eval_a[2 * k] = 2 * k; pg.eval_a[2 * k + 1] = 2 * k + 1;
-        if (kind == PG_KIND_POP) atomicAdd(&hist[col], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x < AVN_GRAPH_COLOR_COUNT && hist[threadIdx.x]) { atomicAdd(&pg.ctr[PGC_BUCKET + threadIdx.x], hist[threadIdx.x]); atomicAdd(&pg.ctr[PGC_N_POP], hist[threadIdx.x]); }
+// one changed row -> op k (k = the number of changed rows with a lower ContactId: the reference's processing order)
+__device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32_t k, uint32_t n_bodies, uint32_t* hist) {
+    const uint32_t w = pg.chg[c];
+    const uint32_t flags = w & 0xFFFFu, n_manifolds = (w >> 16) & 0xFFu;
+    const int dcount = (int)((w >> 24) & 0xFFu) - 128;
+    const bool generates = flags & AVN_CP_GENERATE_CONSTRAINTS, touching = flags & AVN_CP_TOUCHING;
+    const uint32_t col = pg.color[c];
+    const bool has_handle = col != PG_NONE;   // ContactEdge::constraint_handles is non-empty (one manifold per convex pair)
+    uint32_t kind = PG_KIND_NONE, remove = 0;
+    if (flags & AVN_CP_DISJOINT_AABB) { if (generates && has_handle) kind = PG_KIND_POP; remove = 1; }
+    else if (flags & AVN_CP_STARTED_TOUCHING) { if (generates && n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
+    else if (flags & AVN_CP_STOPPED_TOUCHING) { if (generates && has_handle) kind = PG_KIND_POP; }
+    else if (touching && (flags & AVN_CP_STARTED_GENERATING_CONSTRAINTS)) { if (n_manifolds && !has_handle) kind = PG_KIND_PUSH; }
+    else if (touching && generates && dcount > 0) { if (!has_handle) kind = PG_KIND_PUSH; }
+    else if (touching && generates && dcount < 0) { if (has_handle) kind = PG_KIND_POP; }
+    const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
+    if (kind == PG_KIND_PUSH && s1 && s2) kind = PG_KIND_NONE;   // (debug_assert in the reference: never both)
+    const int2 b = pg.bodies[c];
+    const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
+    pg.op_cid[k] = c;
+    pg.op_chg[k] = w;
+    pg.op_info[k] = kind | (s1 ? 4u : 0u) | (s2 ? 8u : 0u) | (remove << 4) | (opcol << 8);
+    pg.op_bodies[k] = b;
+    pg.rem_flag[k] = remove;
+    // one entry per side whose body's colour mask the op reads or writes: non-static sides of pushes and of pops of colours 0..22
+    const bool masks = kind == PG_KIND_PUSH || (kind == PG_KIND_POP && col < (uint32_t)AVN_COLOR_OVERFLOW_INDEX);
+    pg.ekey_a[2 * k] = (masks && !s1) ? (uint32_t)b.x : n_bodies;
+    pg.ekey_a[2 * k + 1] = (masks && !s2) ? (uint32_t)b.y : n_bodies;
+    pg.eval_a[2 * k] = 2 * k; pg.eval_a[2 * k + 1] = 2 * k + 1;
+    if (kind == PG_KIND_POP) atomicAdd(&hist[col], 1u);
 }
-void launch_pg_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, hipStream_t s) {
-    if (n_rows) hipLaunchKernelGGL(k_pg_classify, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, n_rows, n_bodies);
+// The exclusive scan over the rows' "has a change" flags (= the op index of every changed row, ascending ContactId) and the
+// classification of the changed rows in ONE launch (round 4: was k_scan_sums -> k_scan_top -> k_scan_apply -> k_pg_classify, the last of
+// them a 1.2 M-row gather for ~30 k changes): the chained scan of avn_scan.h with k_pg_classify's body as its apply stage.  Thread t of a
+// tile owns rows base + 8 t .. + 7.  ctr[PGC_N_OPS] <- the number of changes.
+__global__ __launch_bounds__(256) void k_pg_scan_classify(PG pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* __restrict__ st) {
+    __shared__ uint32_t hist[AVN_GRAPH_COLOR_COUNT];
+    const uint32_t nb = gridDim.x, t = threadIdx.x;
+    if (t < AVN_GRAPH_COLOR_COUNT) hist[t] = 0;
+    const uint32_t tile = sc_take_tile(st);   // (barrier: hist is cleared)
+    constexpr uint32_t per = SC_TILE / 256;
+    const uint32_t c0 = tile * SC_TILE + t * per;
+    uint32_t h[per], s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) { h[k] = (c0 + k < n_rows && pg.has[c0 + k]) ? 1u : 0u; s += h[k]; }
+    uint32_t tile_sum;
+    uint32_t excl = sc_block_excl(s, &tile_sum);
+    excl += sc_lookback(st, tile, nb, tile_sum);
+    if (s) {
+#pragma unroll
+        for (uint32_t k = 0; k < per; ++k) if (h[k]) { pg_classify_row(pg, c0 + k, excl, n_bodies, hist); ++excl; }
+    }
+    if (tile == nb - 1u && t == 255u) pg.ctr[PGC_N_OPS] = excl;
+    __syncthreads();
+    if (t < AVN_GRAPH_COLOR_COUNT && hist[t]) { atomicAdd(&pg.ctr[PGC_BUCKET + t], hist[t]); atomicAdd(&pg.ctr[PGC_N_POP], hist[t]); }
+}
+void launch_pg_scan_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_pg_scan_classify, dim3((n_rows + SC_TILE - 1) / SC_TILE), dim3(256), 0, s, pg, n_rows, n_bodies, scan_state);
 }
 
 // An op batch from a list (SleepIslands / WakeIslands of the island manager): the arrays k_pg_classify fills, for ops given as
@@ -318,7 +353,7 @@ __global__ __launch_bounds__(64) void k_pg_color(PG pg, uint32_t n_ops) {
     }
 }
 void launch_pg_color(const PG& pg, uint32_t n_ops, hipStream_t s) {
-    (void)hipMemsetAsync(pg.ctr + PGC_TILE, 0, sizeof(uint32_t), s);
+    // (ctr[PGC_TILE] is zero here: k_pg_build_handles, the last kernel of every op batch, leaves it so)
     if (n_ops) hipLaunchKernelGGL(k_pg_color, dim3((n_ops + 63) / 64), dim3(64), 0, s, pg, n_ops);
 }
 // body masks after the step's ops: (mask & ~freed by pops) | taken by pushes -- a push only ever takes a bit that is free at its
@@ -694,7 +729,6 @@ void launch_pg_replay(const PG& pg, const uint32_t* order, uint32_t n_ops, hipSt
 }
 
 // ---- removed pairs: ContactGraph::remove_edge_by_id + IdPool::free_id --------------------------------------------------------------
-__device__ __forceinline__ uint64_t pg_hs_mix(uint64_t k) { k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33; return k; }
 template <class T>
 __global__ __launch_bounds__(256) void k_pg_remove(PG pg, CT<T> ct, BP<T> bp, uint32_t n_ops) {
     const uint32_t k = blockIdx.x * 256 + threadIdx.x;
@@ -753,6 +787,10 @@ __global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __res
     }
     __syncthreads();
     if (blockIdx.x == 0 && threadIdx.x <= AVN_GRAPH_COLOR_COUNT) { color_offsets[threadIdx.x] = off[threadIdx.x]; pg.ctr[PGC_OFFSETS + threadIdx.x] = off[threadIdx.x]; }
+    // the op batch is over: its scoped counters start the next batch at zero without a memset launch (buckets of the replay, the dataflow
+    // colouring's tile tickets, the narrow phase's removal count -- the host has read them)
+    if (blockIdx.x == 0 && threadIdx.x < 32u) pg.ctr[PGC_BUCKET + threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 32u) { pg.ctr[PGC_TILE] = 0u; pg.ctr[PGC_N_REM] = 0u; }
     const uint32_t m = blockIdx.x * 256 + threadIdx.x;
     if (m >= total || m >= off[AVN_GRAPH_COLOR_COUNT]) return;
     uint32_t lo = 0, hi = AVN_GRAPH_COLOR_COUNT;   // colour c: off[c] <= m < off[c + 1]
@@ -824,7 +862,7 @@ template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23
 }
 
 #define INST(T)                                                                                                         \
-    template void launch_pg_add_pairs<T>(const PG&, const CT<T>&, const avn_pair*, uint32_t, hipStream_t);              \
+    template void launch_pg_add_pairs<T>(const PG&, const CT<T>&, const avn_pair*, uint32_t, uint64_t*, uint32_t, hipStream_t);              \
     template void launch_pg_remove<T>(const PG&, const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                    \
     template void launch_pg_rebuild_pair_set<T>(const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                     \
     template void launch_ovf_entries<T>(const DW<T>&, uint32_t, uint32_t, uint32_t*, uint32_t*, hipStream_t);           \

@@ -559,8 +559,8 @@ template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, con
     launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
-                                                  uint32_t* n_remove, hipStream_t st) {
-    (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
+                                                  uint32_t* n_remove, hipStream_t st, bool reset_counter) {
+    if (reset_counter) (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
     if (!n_rows) return;
     hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
     launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st);
@@ -595,7 +595,7 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
-    template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
+    template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, bool); \
     template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
     template void launch_gather_manifolds<T>(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                  \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \

@@ -1,8 +1,15 @@
 // world/broad_phase.hpp -- fragment of the body of `template <class T> struct World` (avn_world.hip includes it inside the class):
 // BroadPhasePlugin's systems: update_aabb, collect_collision_pairs (launch / finish halves).
 
-    avn_status update_aabb() {
-        launch_update_aabb<T>(dw, bp, params, bs);
+    // step_counters: inside a step the kernel also clears the counters of what follows it on the step's chain -- misc[32] the constraint
+    // count, [33..34] dropped / unsorted, [35] pair total, [36..37] long-interval chunks / overflow -- instead of one memset launch each
+    bool bp_counters_clean = false, constraint_count_clean = false;
+    // (mode 1: the broad phase's counters only -- a frozen-manifold step prepares its constraints on the OTHER stream meanwhile; mode 2, the
+    //  closed loop, where everything of the step is behind this kernel: the constraint count too)
+    avn_status update_aabb(int step_counters = 0) {
+        const bool ran = launch_update_aabb<T>(dw, bp, params, bs, step_counters ? b_misc.as<uint32_t>() + (step_counters == 2 ? 32 : 33) : nullptr, step_counters == 2 ? 6u : step_counters ? 5u : 0u);
+        bp_counters_clean = step_counters && ran;
+        constraint_count_clean = step_counters == 2 && ran;
         ++launches;
         HIPCHK(hipGetLastError());
         return AVN_OK;
@@ -32,10 +39,13 @@
         sweep_scratch.n_long = misc + 36;  // [36] chunks, [37] overflow
         Key* keys_a = b_keys_a.as<Key>(); Key* keys_b = b_keys_b.as<Key>();
         uint32_t* vals_a = b_vals_a.as<uint32_t>(); uint32_t* vals_b = b_vals_b.as<uint32_t>();
-        launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, bs);
-        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), d_dropped + 1, bs);
-        launch_gather_sorted<T>(dw, bp, vals_a, n, bs);
-        launch_sweep_ranges<T>(bp, n, sweep_scratch, bs);
+        const bool clean = bp_counters_clean;   // (k_update_aabb of this step cleared them; a second count pass of one step clears them itself)
+        bp_counters_clean = false;
+        launch_interval_keys<T>(dw, bp, keys_a, vals_a, d_dropped, bs, clean);
+        Key* keys_sorted; uint32_t* vals_sorted;
+        launch_radix_sort<Key>(keys_a, vals_a, keys_b, vals_b, n, b_hist.as<uint32_t>(), b_block_sums.as<uint32_t>(), d_dropped + 1, &keys_sorted, &vals_sorted, bs);
+        launch_gather_sorted<T>(dw, bp, vals_sorted, n, bs);
+        launch_sweep_ranges<T>(bp, n, sweep_scratch, bs, clean);
         launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, bs);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, bs);
         launches += 3 + radix_sort_launches(n, (uint32_t)sizeof(Key)) + 4 + exclusive_scan_launches(n * sweep_count_slots());

@@ -142,6 +142,7 @@
             GROW(b_keys_a, cc, dummy_k); GROW(b_keys_b, cc, dummy_k); GROW(b_vals_a, cc, dummy_u); GROW(b_vals_b, cc, dummy_u);
             GROW(b_hist, (size_t)256 * radix_blocks((uint32_t)cc) + 256, dummy_u);
             GROW(b_block_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)cc)), scan_block_sums_needed((uint32_t)cc * sweep_count_slots())) + 16, dummy_u);
+            HIPCHK(hipMemset(b_block_sums.p, 0, b_block_sums.cap));   // the one-launch scan's state: zero once, self-cleaning afterwards (avn_scan.h)
             GROW(b_counts, cc * sweep_count_slots() + 1, dummy_u); GROW(b_offsets, cc * sweep_count_slots() + 1, dummy_u);
             GROW(b_sweep_hits, sweep_hit_words((uint32_t)cc), sweep_scratch.hits);
             {   // long-interval chunks: every interval may need one slot, plus room for the chunks of scene-spanning ones

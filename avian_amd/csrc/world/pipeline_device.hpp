@@ -41,6 +41,7 @@
         PGB(b_pg_hist, (size_t)256 * radix_blocks(2 * rows) + 256, dummy, false);
         PGB(b_pg_sums, std::max<size_t>(scan_block_sums_needed(256 * radix_blocks(2 * rows)), scan_block_sums_needed(2 * rows)) + 16, dummy, false);
 #undef PGB
+        HIPCHK(hipMemset(b_pg_sums.p, 0, b_pg_sums.cap));   // the one-launch scan's state: zero once, self-cleaning afterwards (avn_scan.h)
         pg.rows = rows; pg_rows = rows;
         graph_valid = false;
         return AVN_OK;
@@ -176,6 +177,8 @@
         if (word & ~7u) error += " unknown bits in the error word;";
         error += " the error word has been cleared";
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
+        HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));   // (an aborted batch never reached k_pg_build_handles, which cleans these)
+        HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (h_pg_error) *h_pg_error = 0;
         return AVN_ERR_STATE;
@@ -191,9 +194,9 @@
     avn_status pg_apply_ops(uint32_t n_ops, uint32_t n_rem, uint32_t n_rows, const uint32_t* list_cids, const uint32_t* list_kinds, double& host_ms) {
         avn_status st;
         {
-            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
+            // (ctr[PGC_BUCKET ..] and ctr[PGC_TILE] are zero here: k_pg_build_handles, the last kernel of every batch, leaves them so; the status
+            //  loop's ops were classified by k_pg_scan_classify, the scan that counted them)
             if (list_cids) launch_pg_ops_from_list<T>(pg, ct, list_cids, list_kinds, n_ops, dw.n_bodies, stream);
-            else launch_pg_classify(pg, n_rows, dw.n_bodies, stream);
             if (slp_on && !list_cids) {   // the island manager reads the loop's changes: (contact id, packed change) per op, in ascending id
                 if (pin_slp_ops.ensure((size_t)n_ops * 8 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
                 HIPCHK(hipMemcpyAsync(pin_slp_ops.p, pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost, stream));
@@ -208,23 +211,24 @@
             uint32_t *ck, *order;
             launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
             launch_pg_replay(pg, order, n_ops, stream);
-            launches += 8 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
+            launches += 7 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
             if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
                 launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
                 launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
                 launch_pg_merge_free(pg, pgm_head, pgm_n_free, n_rem, stream);
-                HIPCHK(hipMemcpyAsync(pg.free_ids, pg.free_alt, ((size_t)pgm_n_free + n_rem) * 4, hipMemcpyDeviceToDevice, stream));
+                // the merged list IS the free list from here on: the two buffers change roles (no copy back)
+                std::swap(b_pg_free_a.p, b_pg_free_b.p); std::swap(b_pg_free_a.cap, b_pg_free_b.cap);
+                std::swap(pg.free_ids, pg.free_alt);
                 pgm_head = 0; pgm_n_free += n_rem; pgm_live -= n_rem; pgm_tomb += n_rem;
                 pipe_stats.pairs_removed += n_rem;
-                launches += 5;
+                launches += 3;
             }
             HIPCHK(hipGetLastError());
-            uint32_t* h = (uint32_t*)pin_ctr.p + 16;
-            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_LEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
-            HIPCHK(hipMemcpyAsync(h + 32, pg.ctr + PGC_ERROR, 4 * 4, hipMemcpyDeviceToHost, stream));   // ERROR, TILE, N_PUSH, N_POP
+            uint32_t* h = (uint32_t*)pin_ctr.p + 64;
+            HIPCHK(hipMemcpyAsync(h, pg.ctr, 64 * 4, hipMemcpyDeviceToHost, stream));   // the counters block up to the colours' lengths, in one copy
             HIPCHK(spin_sync(stream));
             auto t0 = std::chrono::steady_clock::now();
-            if (h[32]) return pg_error_report(h[32]);
+            if (h[PGC_ERROR]) return pg_error_report(h[PGC_ERROR]);
             if (getenv("AVN_PG_REPLAY_STATS")) {
                 uint32_t d[96];
                 HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
@@ -249,10 +253,10 @@
                     std::fclose(f);
                 }
             }
-            pipe_stats.manifolds_pushed = h[34]; pipe_stats.manifolds_popped = h[35];
+            pipe_stats.manifolds_pushed = h[PGC_N_PUSH]; pipe_stats.manifolds_popped = h[PGC_N_POP];
             uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
             uint32_t M = 0;
-            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[c]; offs[c] = M; M += h[c]; }
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[PGC_LEN + c]; offs[c] = M; M += h[PGC_LEN + c]; }
             offs[AVN_GRAPH_COLOR_COUNT] = M;
             if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
             if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
@@ -276,7 +280,7 @@
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
         HIPCHK(hipEventRecord(ev[0], stream));
-        if ((st = update_aabb()) != AVN_OK) return st;
+        if ((st = update_aabb(2)) != AVN_OK) return st;
         // The narrow phase of the rows that exist at the START of the step needs the new AABBs and nothing else of the broad phase: it runs
         // on the world's stream while sort + sweep + emit run on the broad-phase stream (both are VALU-bound kernels that leave half the
         // chip idle on their own).  The rows a step ADDS are created only after that launch has finished (they may reuse freed ids: a row
@@ -292,13 +296,17 @@
             HIPCHK(hipEventRecord(ev_np_fork, stream));
             HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_fork, 0));
             // (issued BEFORE the broad phase's ~20 launches: the host needs ~150 us to enqueue those, and the narrow phase would start that late)
-            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false);
             ++launches;
             HIPCHK(hipEventRecord(ev_np_old, stream));
             bs = stream_bp;
         }
+        // prepare_solver_bodies and pre_process_velocity_increments only read the rigid-body components: enqueued here, on the world's stream, they
+        // run next to the broad phase instead of on the serial chain in front of the solver.  (Not with sleeping on: WakeIslands changes which bodies
+        // own a SolverBody between the status loop and the solver.)
+        if (!slp_on) { prepare_solver_bodies(); pre_process_velocity_increments(); bodies_prepared_early = true; }
         st = collect_launch();
-        if (st != AVN_OK) { bs = stream; return st; }
+        if (st != AVN_OK) { bs = stream; bodies_prepared_early = false; return st; }
         lap();
         // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
         uint32_t total = 0, used_ids = 0;
@@ -326,7 +334,6 @@
                 if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return fail(st);   // (growing synchronises the world's stream first: the launch over the old rows is done)
                 if (np_overlap) HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_old, 0));               // nothing below may touch a row while that launch runs
                 if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return fail(st);
-                launch_hs_insert_pairs(bp.pair_set, bp.pair_set_cap, b_pairs.as<avn_pair>(), total, bs);   // add_edge_and_key_with: the keys join the pair set
                 pg.new_ids = nullptr;
                 if (slp_on) {   // the island manager's edge lists: (ContactId, collider1, collider2) of every new pair, in emission order
                     hipError_t e2;
@@ -334,13 +341,13 @@
                     if (e2 != hipSuccess) { error = "hipMalloc failed"; return fail(AVN_ERR_OOM); }
                     pg.new_ids = b_pg_new_ids.as<uint32_t>();
                 }
-                launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bs);
+                launch_pg_add_pairs<T>(pg, ct, b_pairs.as<avn_pair>(), total, bp.pair_set, bp.pair_set_cap, bs);   // ids, rows, PairKeys (add_edge_and_key_with), IdPool counters
                 if (slp_on) {
                     if (pin_slp_pairs.ensure((size_t)total * (sizeof(avn_pair) + 4) + 64) != hipSuccess) { error = "hipHostMalloc failed"; return fail(AVN_ERR_OOM); }
                     HIPCHK(hipMemcpyAsync(pin_slp_pairs.p, b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, bs));
                     HIPCHK(hipMemcpyAsync((char*)pin_slp_pairs.p + (size_t)total * sizeof(avn_pair), pg.new_ids, (size_t)total * 4, hipMemcpyDeviceToHost, bs));
                 }
-                launches += 3;
+                launches += 1;
                 HIPCHK(hipGetLastError());
                 const uint32_t used = std::min(total, pgm_n_free);
                 used_ids = used;
@@ -360,13 +367,13 @@
         const uint32_t n_rows = pgm_next_id;
         uint32_t n_ops = 0, n_rem = 0;
         if (n_rows) {
-            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream); ++launches; }
+            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false); ++launches; }
             else if (total) {   // the rows this step added: the lowest free ids first (k_pg_add_pairs), then the fresh ones
                 launch_narrow_phase_rows<T>(dw, bp, ct, np_params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
                 ++launches;
             }
-            launch_exclusive_scan(pg.has, pg.off, n_rows, b_pg_sums.as<uint32_t>(), pg.ctr + PGC_N_OPS, stream);
-            launches += exclusive_scan_launches(n_rows);
+            launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream);   // ops numbered in ascending ContactId AND classified
+            ++launches;
             HIPCHK(hipGetLastError());
             uint32_t* h = (uint32_t*)pin_ctr.p;
             HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
@@ -381,6 +388,14 @@
         ++pg_dump_step;
         if (n_ops) {   // ---- the status-change loop: decisions, colours, handle lists ----
             lap();
+            // the warm start's slot table will be rebuilt for the new lists: its 22 x cap_bodies words are set to EMPTY on the (idle) broad-phase
+            // stream while the op pipeline runs, instead of by a memset in front of the solver
+            if (dw.inc_slot && dw.inc_stride == cap_bodies && b_inc_slot.cap >= (size_t)AVN_COLOR_OVERFLOW_INDEX * cap_bodies * sizeof(uint32_t)) {
+                if (!ev_slot_clear) HIPCHK(hipEventCreateWithFlags(&ev_slot_clear, hipEventDisableTiming | EV_FLAGS));
+                HIPCHK(hipMemsetAsync(dw.inc_slot, 0xFF, (size_t)AVN_COLOR_OVERFLOW_INDEX * dw.inc_stride * sizeof(uint32_t), stream_bp));
+                HIPCHK(hipEventRecord(ev_slot_clear, stream_bp));
+                slot_clear_pending = true;
+            }
             if ((st = pg_apply_ops(n_ops, n_rem, n_rows, nullptr, nullptr, host_ms)) != AVN_OK) return st;
             t0 = std::chrono::steady_clock::now();
         }
@@ -405,7 +420,7 @@
         hipError_t err;
         bool moved = b_inc_slot.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * cap_bodies * sizeof(uint32_t), err);
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-        if (moved || dw.inc_stride != cap_bodies) graph_valid = false;
+        if (moved || dw.inc_stride != cap_bodies) { graph_valid = false; slot_clear_pending = false; }   // (a new table: the early clear hit the old one)
         dw.inc_slot = b_inc_slot.as<uint32_t>(); dw.inc_stride = cap_bodies;
         slots_dirty = true;
         const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;

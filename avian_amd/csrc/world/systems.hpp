@@ -9,7 +9,8 @@
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
         if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
-        launch_prepare_contact_constraints<T>(dw, params, stream); ++launches;
+        launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean); ++launches;
+        constraint_count_clean = false;
     }
     void store_contact_impulses() {
         launch_store_contact_impulses<T>(dw, stream); ++launches;
@@ -154,6 +155,7 @@
         if constexpr (sizeof(T) == 4) {
             if (islands_active()) {   // every substep of every island block in ONE launch (k_island_substeps)
                 launch_island_substeps(dw, params, islands, cfg.substeps, cfg.solver_iterations, stream); ++launches;
+                slot_clear_pending = false;   // (the island blocks do not use the slot table: a later colour-launch step clears it itself)
                 // (device closed loop: the restitution pass after the loop still runs colour by colour; its overflow pass starts a fresh epoch count)
                 if (pipe_dev && ovf_grid_blocks) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
                 ovf_epoch = 0;
@@ -161,7 +163,11 @@
             }
         }
         // the body-centric warm start's slot table (not needed by the island blocks); outside the capture below
-        if (slots_dirty && dw.n_manifolds && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }
+        if (slots_dirty && dw.n_manifolds && dw.inc_slot) {
+            if (slot_clear_pending) { HIPCHK(hipStreamWaitEvent(stream, ev_slot_clear, 0)); }   // (the table was set to EMPTY on the broad-phase stream while the op pipeline ran)
+            launch_build_incidence_slots<T>(dw, stream, slot_clear_pending); launches += 2; slots_dirty = false;
+        }
+        slot_clear_pending = false;
         const bool flow = pipe_dev && dw.n_manifolds && ovf_grid_blocks;
         if (flow && (uint64_t)cfg.substeps * 2 * cfg.solver_iterations + 2 > PGC_OVF_TILES) { error = "device closed loop: too many contact passes per step for the overflow tickets"; return AVN_ERR_CAPACITY; }
         if (!cfg.use_graph) {
@@ -202,6 +208,9 @@
         return AVN_OK;
     }
     uint32_t graph_launches = 0;
+    bool bodies_prepared_early = false;    // prepare_solver_bodies + pre_process_velocity_increments of this step are already on the stream
+    bool slot_clear_pending = false;       // DW::inc_slot is being set to EMPTY on stream_bp (ev_slot_clear): build_incidence_slots skips its own memset
+    hipEvent_t ev_slot_clear = nullptr;
     uint32_t island_backoff = 0;   // closed-loop steps for which the island blocks are not attempted again
     avn_status solver_front() {   // everything that only READS the rigid-body components
         avn_status st = need_bodies();
@@ -209,11 +218,12 @@
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
         if ((st = rebuild_incidence()) != AVN_OK) return st;
         if ((st = rebuild_body_groups()) != AVN_OK) return st;
-        prepare_solver_bodies();
+        if (!bodies_prepared_early) prepare_solver_bodies();   // (device closed loop: enqueued at the step's start, next to the broad phase)
         prepare_joints();
         prepare_contact_constraints();
         stamp(DG_PREP1);
-        pre_process_velocity_increments();
+        if (!bodies_prepared_early) pre_process_velocity_increments();
+        bodies_prepared_early = false;
         stamp(DG_INC1);
         // host work that only the substep loop needs, done while the prepare kernels above run
         // (device closed loop: a scene whose islands did not fit a workgroup -- one big pile -- is not asked again for a while: the attempt
@@ -370,7 +380,7 @@
                 bs = stream_bp;
                 HIPCHK(hipEventRecord(ev_bp_t0, stream_bp));
             }
-            st = update_aabb();
+            st = update_aabb(1);
             if (st == AVN_OK) st = collect_launch();
             if (overlap) { (void)hipEventRecord(ev_bp_t1, stream_bp); bp_timed = true; }
             if (st != AVN_OK) { bs = stream; return st; }
