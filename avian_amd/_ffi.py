@@ -216,6 +216,10 @@ class avn_islands_stats(C.Structure):
     _fields_ = [(n, C.c_uint32) for n in ("n_islands", "n_sleeping_islands", "n_bodies", "n_sleeping_bodies", "merges", "splits", "split_candidate", "sleeping_pairs")]
 
 
+class avn_despawn_list(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("n_colliders", C.c_uint32), ("collider_entities", vp), ("n_bodies", C.c_uint32), ("bodies", vp)]
+
+
 class avn_sleeping_stats(C.Structure):
     _fields_ = [("islands", avn_islands_stats)] + [(n, C.c_uint32) for n in ("n_awake_bodies", "last_islands_slept", "last_islands_woken", "last_manifolds_popped", "last_manifolds_pushed")] + [("last_host_ms", C.c_double)]
 
@@ -252,7 +256,8 @@ ABI_SYMBOLS = [
     "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
     "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
-    "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange",
+    "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies",
+    "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange", "despawn",
 ]
 
 
@@ -298,6 +303,7 @@ class Library:
         f("sleeping_stats_get").argtypes = [vp, C.POINTER(avn_sleeping_stats)]
         f("sleeping_state_get").argtypes = [vp, C.POINTER(avn_sleeping_out)]
         f("wake_bodies").argtypes = [vp, vp, C.c_size_t]
+        f("despawn").argtypes = [vp, C.POINTER(avn_despawn_list)]
         f("bounds_exchange").argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32), vp, C.c_uint32, C.POINTER(C.c_uint32)]
         f("comm_unique_id").argtypes = [vp]
         f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
@@ -342,7 +348,8 @@ class Library:
                            ("islands_joint_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_pair_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
                            ("islands_status_change", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_flush_wake", [vp]), ("islands_split_candidate", [vp]),
                            ("islands_sleeping_systems", [vp, vp, vp, C.c_uint32, C.c_float]), ("islands_wake_body", [vp, C.c_uint32]), ("islands_sleep_body", [vp, C.c_uint32]),
-                           ("islands_last_result", [vp, vp]), ("islands_stats_get", [vp, vp]), ("islands_state", [vp, C.c_uint32, vp, vp, vp, vp])):
+                           ("islands_last_result", [vp, vp]), ("islands_stats_get", [vp, vp]), ("islands_state", [vp, C.c_uint32, vp, vp, vp, vp]),
+                           ("islands_collider_remove", [vp, C.c_uint32]), ("islands_body_remove", [vp, C.c_uint32]), ("islands_renumber_bodies", [vp, vp, C.c_uint32])):
             f(name).restype = C.c_int; f(name).argtypes = args
         self._islands_declared = True
 
@@ -867,6 +874,14 @@ class World:
         b = np.ascontiguousarray(bodies, np.uint32)
         self._check(self.lib.fn("wake_bodies")(self.handle, _ptr(b), len(b)))
 
+    def despawn(self, bodies=(), collider_entities=()):
+        """``avn_despawn``: remove bodies (with their colliders) and / or single colliders inside the closed loop -- ContactGraph edges in
+        edge-list order, ConstraintGraph pops, IdPool, islands, renumbering.  Follow it with bodies_upload + colliders_upload of what remains."""
+        b = np.ascontiguousarray(bodies, np.uint32); c = np.ascontiguousarray(collider_entities, np.uint32)
+        d = avn_despawn_list(C.sizeof(avn_despawn_list), len(c), _ptr(c) if len(c) else None, len(b), _ptr(b) if len(b) else None)
+        self._check(self.lib.fn("despawn")(self.handle, C.byref(d)))
+        self.n_bodies -= len(b)
+
     def bounds_exchange(self, max_ranks: int = 64):
         """``avn_bounds_exchange``: (bounds [n_ranks, 6], overlapping rank pairs [k, 2]) -- the library reduces this world's dynamic bounds on the
         device and all-gathers them over the communicator of comm_init (a world without one is its own only rank)."""
@@ -933,7 +948,7 @@ class ConstraintGraph:
 
 
 class avn_islands_result(C.Structure):
-    _fields_ = [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
+    _fields_ = [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken", "pairs_removed") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
 
 
 class IslandManager:
@@ -960,6 +975,12 @@ class IslandManager:
     def split_candidate(self): self._chk(self.lib.fn("islands_split_candidate")(self.handle), "islands_split_candidate")
     def wake_body(self, body): self._chk(self.lib.fn("islands_wake_body")(self.handle, body), "islands_wake_body"); return self.last_result()
     def sleep_body(self, body): self._chk(self.lib.fn("islands_sleep_body")(self.handle, body), "islands_sleep_body"); return self.last_result()
+    def collider_remove(self, collider): self._chk(self.lib.fn("islands_collider_remove")(self.handle, collider), "islands_collider_remove"); return self.last_result()
+    def body_remove(self, body): self._chk(self.lib.fn("islands_body_remove")(self.handle, body), "islands_body_remove"); return self.last_result()
+
+    def renumber_bodies(self, new_index):
+        m = np.ascontiguousarray(new_index, np.uint32)
+        self._chk(self.lib.fn("islands_renumber_bodies")(self.handle, _ptr(m), len(m)), "islands_renumber_bodies")
 
     def sleeping_systems(self, sleep_timer, flags, time_to_sleep=0.5):
         t = np.ascontiguousarray(sleep_timer, np.float32); f = np.ascontiguousarray(flags, np.uint8)
@@ -970,7 +991,7 @@ class IslandManager:
         r = avn_islands_result()
         self._chk(self.lib.fn("islands_last_result")(self.handle, C.byref(r)), "islands_last_result")
         out = {}
-        for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken"):
+        for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken", "pairs_removed"):
             n = getattr(r, "n_" + name)
             out[name] = np.ctypeslib.as_array(C.cast(getattr(r, name), C.POINTER(C.c_uint32)), (n,)).copy() if n else np.zeros(0, np.uint32)
         return out

@@ -148,6 +148,7 @@ AVN_API avn_status avn_sleeping_enable(avn_world* w, const avn_sleep_params* p) 
 AVN_API avn_status avn_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { GUARD(sleeping_stats_get(o)); }
 AVN_API avn_status avn_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { GUARD(sleeping_state_get(o)); }
 AVN_API avn_status avn_wake_bodies(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(wake_bodies(bodies, n)); }
+AVN_API avn_status avn_despawn(avn_world* w, const avn_despawn_list* d) { GUARD(despawn(d)); }
 AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
     try { return avn::comm_unique_id(out, g_create_error); }
     catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }

@@ -6,7 +6,7 @@
 
 namespace avn {
 
-void IslandManager::clear_results() { popped_.clear(); pushed_.clear(); pairs_slept_.clear(); pairs_woken_.clear(); bodies_slept_.clear(); bodies_woken_.clear(); }
+void IslandManager::clear_results() { popped_.clear(); pushed_.clear(); pairs_slept_.clear(); pairs_woken_.clear(); bodies_slept_.clear(); bodies_woken_.clear(); pairs_removed_.clear(); }
 
 // slab::Slab::insert / remove: the vacant keys form a stack (remove pushes, insert pops; a fresh key only when the stack is empty)
 uint32_t IslandManager::island_insert(Island&& isl) {
@@ -308,11 +308,94 @@ avn_status IslandManager::sleep_body(uint32_t body) {   // SleepBody, :296-352
     sleep_islands({isl_of_[body]});
     return AVN_OK;
 }
+// ---- despawn ----------------------------------------------------------------------------------------------------------------------------
+std::vector<uint32_t> IslandManager::collider_edges_in_order(uint32_t collider) const {
+    std::vector<uint32_t> out;
+    auto it = collider_node_.find(collider);
+    if (it == collider_node_.end()) return out;
+    edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { out.push_back(e); });
+    return out;
+}
+// one edge of remove_collider (narrow_phase/mod.rs:411-455 + contact_graph.rs:669-690): a TOUCHING pair that is linked is unlinked, then the edge
+// leaves both edge lists
+avn_status IslandManager::remove_collider_edge(uint32_t id) {
+    if (id >= contacts_.size() || !contacts_[id].live) return AVN_OK;
+    Contact& c = contacts_[id];
+    if (c.touching && c.linked) unlink_contact(id);
+    if (c.sleeping) --sleeping_pairs_;
+    auto drop = [&](std::vector<uint32_t>& v) { auto it = std::find(v.rbegin(), v.rend(), id); if (it != v.rend()) v.erase(std::next(it).base()); };
+    drop(contact_edges_[c.c1].out); drop(contact_edges_[c.c2].in);
+    contacts_[id] = Contact();
+    return AVN_OK;
+}
+avn_status IslandManager::collider_forget(uint32_t collider) {
+    auto it = collider_body_.find(collider);
+    if (it == collider_body_.end()) return AVN_OK;
+    const uint32_t b = it->second;
+    if (b != NONE && b < colliders_of_.size()) { auto& v = colliders_of_[b]; v.erase(std::remove(v.begin(), v.end(), collider), v.end()); }
+    collider_body_.erase(it);
+    collider_node_.erase(collider);   // (its node stays behind, empty; a re-added collider gets a fresh one)
+    return AVN_OK;
+}
+avn_status IslandManager::collider_remove(uint32_t collider) {
+    clear_results();
+    if (!collider_body_.count(collider)) { error = "islands_collider_remove: unknown collider"; return AVN_ERR_BAD_ARG; }
+    for (uint32_t id : collider_edges_in_order(collider)) {
+        const Contact& c = contacts_[id];
+        if (c.touching) for (uint32_t k = 0; k < c.handles; ++k) popped_.push_back(id);
+        pairs_removed_.push_back(id);
+        remove_collider_edge(id);
+    }
+    return collider_forget(collider);
+}
+avn_status IslandManager::wake_island(uint32_t island) {
+    clear_results();
+    if (island != NONE) wake_islands({island});
+    return AVN_OK;
+}
+// BodyIslandNode::on_remove, islands/mod.rs:1336-1400: the body leaves its island's list; an island left empty is removed
+avn_status IslandManager::body_remove(uint32_t body, bool wake) {
+    clear_results();
+    if (!body_has_node(body)) return AVN_OK;
+    const uint32_t island = isl_of_[body];
+    Island& I = islands_[island];
+    I.bodies.erase(std::remove(I.bodies.begin(), I.bodies.end(), body), I.bodies.end());
+    if (I.bodies.empty()) island_remove(island);
+    node_[body] = 0; asleep_[body] = 0; isl_of_[body] = NONE;
+    if (wake && island < islands_.size() && islands_[island].used) wake_islands({island});
+    return AVN_OK;
+}
+avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_old) {
+    if (n_old && !new_index) { error = "islands_renumber_bodies: null map"; return AVN_ERR_BAD_ARG; }
+    uint32_t n_new = 0;
+    for (uint32_t b = 0; b < n_old; ++b) if (new_index[b] != NONE) n_new = std::max(n_new, new_index[b] + 1u);
+    auto m = [&](uint32_t b) { return b != NONE && b < n_old ? new_index[b] : NONE; };
+    for (uint32_t b = 0; b < n_old && b < node_.size(); ++b) if (new_index[b] == NONE && node_[b]) { error = "islands_renumber_bodies: a removed body still owns an island node (avn_islands_body_remove first)"; return AVN_ERR_STATE; }
+    std::vector<uint8_t> node(n_new, 0), asleep(n_new, 0);
+    std::vector<uint32_t> isl_of(n_new, NONE);
+    std::vector<std::vector<uint32_t>> cols(n_new);
+    std::vector<EdgeLists> jedges(n_new);
+    for (uint32_t b = 0; b < n_old && b < node_.size(); ++b) {
+        const uint32_t nb = new_index[b];
+        if (nb == NONE) continue;
+        node[nb] = node_[b]; asleep[nb] = asleep_[b]; isl_of[nb] = isl_of_[b];
+        if (b < colliders_of_.size()) cols[nb] = std::move(colliders_of_[b]);
+        if (b < joint_edges_.size()) jedges[nb] = std::move(joint_edges_[b]);
+    }
+    node_.swap(node); asleep_.swap(asleep); isl_of_.swap(isl_of); colliders_of_.swap(cols); joint_edges_.swap(jedges);
+    for (auto& kv : collider_body_) kv.second = m(kv.second);
+    for (Contact& c : contacts_) if (c.live) { c.b1 = m(c.b1); c.b2 = m(c.b2); c.rb1 = m(c.rb1); c.rb2 = m(c.rb2); }
+    for (Joint& j : joints_) { j.b1 = m(j.b1); j.b2 = m(j.b2); }
+    for (Island& I : islands_) if (I.used) for (uint32_t& b : I.bodies) b = m(b);
+    mark_body_.clear();
+    return AVN_OK;
+}
 avn_status IslandManager::last_result(avn_islands_result* o) const {
     if (!o) return AVN_ERR_BAD_ARG;
     o->popped = popped_.data(); o->n_popped = popped_.size(); o->pushed = pushed_.data(); o->n_pushed = pushed_.size();
     o->pairs_slept = pairs_slept_.data(); o->n_pairs_slept = pairs_slept_.size(); o->pairs_woken = pairs_woken_.data(); o->n_pairs_woken = pairs_woken_.size();
     o->bodies_slept = bodies_slept_.data(); o->n_bodies_slept = bodies_slept_.size(); o->bodies_woken = bodies_woken_.data(); o->n_bodies_woken = bodies_woken_.size();
+    o->pairs_removed = pairs_removed_.data(); o->n_pairs_removed = pairs_removed_.size();
     return AVN_OK;
 }
 avn_status IslandManager::stats(avn_islands_stats* o) const {
@@ -357,6 +440,9 @@ AVN_API avn_status avn_islands_split_candidate(avn_island_manager* m) { AVN_ISL(
 AVN_API avn_status avn_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { AVN_ISL(sleeping_systems(t, f, n, tts)); }
 AVN_API avn_status avn_islands_wake_body(avn_island_manager* m, uint32_t body) { AVN_ISL(wake_body(body)); }
 AVN_API avn_status avn_islands_sleep_body(avn_island_manager* m, uint32_t body) { AVN_ISL(sleep_body(body)); }
+AVN_API avn_status avn_islands_collider_remove(avn_island_manager* m, uint32_t collider) { AVN_ISL(collider_remove(collider)); }
+AVN_API avn_status avn_islands_body_remove(avn_island_manager* m, uint32_t body) { AVN_ISL(body_remove(body, true)); }
+AVN_API avn_status avn_islands_renumber_bodies(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old) { AVN_ISL(renumber_bodies(new_index, n_old)); }
 AVN_API avn_status avn_islands_last_result(avn_island_manager* m, avn_islands_result* out) { AVN_ISL(last_result(out)); }
 AVN_API avn_status avn_islands_stats_get(avn_island_manager* m, avn_islands_stats* out) { AVN_ISL(stats(out)); }
 AVN_API avn_status avn_islands_state(avn_island_manager* m, uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) {

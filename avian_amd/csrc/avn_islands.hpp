@@ -37,6 +37,15 @@ public:
     avn_status sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep);
     avn_status wake_body(uint32_t body);
     avn_status sleep_body(uint32_t body);
+    // despawn (avn_despawn / avn_islands_collider_remove ...): see the header
+    avn_status collider_remove(uint32_t collider);          // the whole of remove_collider, edge order from the manager's own lists
+    avn_status remove_collider_edge(uint32_t contact_id);   // one edge of it (the world drives the order from the device's insertion stamps)
+    avn_status collider_forget(uint32_t collider);          // ... and the collider's exit from RigidBodyColliders / the node map
+    avn_status body_remove(uint32_t body, bool wake);       // BodyIslandNode::on_remove (+ WakeIslands([its island]) when `wake`)
+    avn_status wake_island(uint32_t island);
+    avn_status renumber_bodies(const uint32_t* new_index, uint32_t n_old);
+    const std::vector<uint32_t>& pairs_removed() const { return pairs_removed_; }
+    std::vector<uint32_t> collider_edges_in_order(uint32_t collider) const;   // outgoing newest first, then incoming newest first
     avn_status last_result(avn_islands_result* out) const;
     avn_status stats(avn_islands_stats* out) const;
     avn_status state(uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) const;
@@ -46,6 +55,7 @@ public:
     bool body_sleeps(uint32_t b) const { return b < asleep_.size() && asleep_[b]; }
     bool has_collider(uint32_t collider) const { return collider_body_.count(collider) != 0; }
     uint32_t island_of(uint32_t b) const { return isl_of_[b]; }
+    uint32_t island_key_bound() const { return (uint32_t)islands_.size(); }   // slab keys are below this
     uint32_t last_slept() const { return last_slept_; }
     uint32_t last_woken() const { return last_woken_; }
     const std::vector<uint32_t>& popped() const { return popped_; }
@@ -88,7 +98,7 @@ private:
     std::vector<uint8_t> awake_;
     std::vector<uint32_t> to_wake_;
     uint32_t merges_ = 0, splits_ = 0, sleeping_pairs_ = 0, last_slept_ = 0, last_woken_ = 0;
-    std::vector<uint32_t> popped_, pushed_, pairs_slept_, pairs_woken_, bodies_slept_, bodies_woken_;
+    std::vector<uint32_t> popped_, pushed_, pairs_slept_, pairs_woken_, bodies_slept_, bodies_woken_, pairs_removed_;
     // split scratch
     std::vector<uint32_t> mark_contact_, mark_joint_, mark_body_;
     uint32_t mark_gen_ = 0;

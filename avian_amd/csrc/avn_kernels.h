@@ -170,7 +170,8 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 #define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
-       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
+       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
+       PGC_COLLECT = 14 /* k_pg_collect_edges: records written */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
        PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
 struct PG {
@@ -202,7 +203,18 @@ struct PG {
     uint32_t* rem_flag, *rem_off, *rem_ids;        // [ops]
     uint32_t* op_chg;       // [ops] the row's packed status change (PG::chg) next to op_cid: what the host-side island manager reads (sleeping enabled)
     uint32_t* new_ids;      // [new pairs of the step] the ContactId k_pg_add_pairs gave the i-th new pair (NULL: not recorded)
+    unsigned long long* seq; // [rows] insertion stamp of the row's ContactEdge (the n-th pair ever added): a collider's edge list is its live edges by DESCENDING stamp
 };
+// avn_despawn: the edges of the removed colliders (rm_rank[slot] != PG_NONE); one record of 8 words per edge, any order
+struct PGEdgeRec { uint32_t cid, slot1, slot2, flags, color, seq_lo, seq_hi, pad; };
+template <class T> void launch_pg_collect_edges(const PG&, const CT<T>&, uint32_t n_rows, const uint32_t* rm_rank, PGEdgeRec* out, uint32_t cap, hipStream_t);
+// rows `ids` (ascending) leave the table: cleared, PairKeys tombstoned, PG::rem_ids <- ids (for launch_pg_merge_free)
+template <class T> void launch_pg_remove_list(const PG&, const CT<T>&, const BP<T>&, const uint32_t* ids, uint32_t n, hipStream_t);
+// body renumbering after a despawn: PG::bodies of the live rows, joint bodies, and compaction of per-body arrays (dst[new_index[i]] = src[i])
+template <class T> void launch_pg_renumber_rows(const PG&, const CT<T>&, uint32_t n_rows, const uint32_t* new_index, hipStream_t);
+void launch_renumber_int2(int2* v, uint32_t n, const uint32_t* new_index, hipStream_t);
+void launch_compact_u32(const uint32_t* src, uint32_t* dst, const uint32_t* new_index, uint32_t n_old, hipStream_t);
+void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_index, uint32_t n_old, hipStream_t);
 #define PG_EST_DONE 0x80000000u
 // ids + rows + PairKeys of the step's new pairs and the IdPool counters, one launch (pair_set must have room: pg_pair_set_reserve)
 template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, uint64_t* pair_set, uint32_t pair_set_cap, hipStream_t);

@@ -194,7 +194,7 @@ template <class T> struct World : WorldBase {
     DevBuf b_pg_bodies, b_pg_color, b_pg_lpos, b_pg_lists, b_pg_bcol, b_pg_free_a, b_pg_free_b, b_pg_ctr, b_pg_ent2slot;
     DevBuf b_pg_chg, b_pg_has, b_pg_off, b_pg_op_cid, b_pg_op_info, b_pg_op_bodies, b_pg_ekey_a, b_pg_eval_a, b_pg_ekey_b, b_pg_eval_b, b_pg_epos, b_pg_popbefore, b_pg_prevpush,
         b_pg_est, b_pg_tile_agg, b_pg_ckey_a, b_pg_cval_a, b_pg_ckey_b, b_pg_cval_b, b_pg_rem_flag, b_pg_rem_off, b_pg_rem_ids, b_pg_hist, b_pg_sums;
-    DevBuf b_pg_op_chg, b_pg_new_ids;
+    DevBuf b_pg_op_chg, b_pg_new_ids, b_pg_seq;
     DevBuf b_ovf_keys_a, b_ovf_vals_a, b_ovf_keys_b, b_ovf_vals_b, b_ovf_rank, b_ovf_ticket;
     uint32_t pg_rows = 0, pg_ops_cap = 0, pg_ovf_cap = 0;
     uint32_t pgm_head = 0, pgm_n_free = 0, pgm_next_id = 0, pgm_live = 0, pgm_tomb = 0;   // exact host mirrors of the device counters
@@ -290,6 +290,7 @@ template <class T> struct World : WorldBase {
         if (const char* e = getenv("AVN_ISLAND_BLOCKS")) island_enabled = atoi(e) != 0;                                  // 0: always the device-wide colour launches
         if (const char* e = getenv("AVN_ISLAND_CACHE_RECORDS")) island_cache_records = atoi(e) != 0;
         if (const char* e = getenv("AVN_ISLAND_MAX_MANIFOLDS")) island_max_manifolds = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = getenv("AVN_ISLAND_MAX_BODIES_TOTAL")) island_max_bodies_total = (size_t)strtoull(e, nullptr, 10);
         if (const char* e = getenv("AVN_ISLAND_PACK_BODIES")) island_pack_bodies = std::min<uint32_t>(ISLAND_MAX_BODIES, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));
         // (CU masks -- 64 CUs for the broad phase, 192 for the solver -- were tried for the overlap below and lost: a colour launch
         //  on 192 CUs is 12 % slower than on 256, more than the contention it avoids; tools/cumask_probe.hip)
@@ -338,6 +339,7 @@ template <class T> struct World : WorldBase {
         if (c->substeps == 0 || c->dt_ns == 0) { error = "config: substeps and dt_ns must be > 0"; return AVN_ERR_BAD_ARG; }
         if (c->scalar_bits != sizeof(T) * 8) { error = "config: scalar_bits cannot change after world creation"; return AVN_ERR_BAD_ARG; }
         cfg = *c;
+        slp_world_asleep = slp_world_idle = false;
         if (cfg.solver_iterations == 0) cfg.solver_iterations = 1;
         // Duration arithmetic of run_physics_schedule / run_substep_schedule (reference schedule/mod.rs:240-284,
         // solver/schedule.rs:194-200): sub_delta = delta.div_f64(substeps), rounded to the nearest nanosecond.
@@ -424,6 +426,7 @@ template <class T> struct World : WorldBase {
 #include "world/level2.hpp"
 #include "world/islands.hpp"
 #include "world/sleeping.hpp"
+#include "world/despawn.hpp"
 #include "world/timers.hpp"
 };
 

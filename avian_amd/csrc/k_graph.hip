@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn
     __shared__ uint32_t s_last;
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const uint32_t head = pg.ctr[PGC_FREE_HEAD], n_free = pg.ctr[PGC_N_FREE], next = pg.ctr[PGC_NEXT_ID];
+    const unsigned long long seq0 = ((unsigned long long)pg.ctr[PGC_SEQ + 1] << 32) | pg.ctr[PGC_SEQ];
     if (i < total) {
         const uint32_t id = i < n_free ? pg.free_ids[head + i] : next + (i - n_free);   // the i-th lowest free id, then fresh ids
         const avn_pair pr = pairs[i];
@@ -84,6 +85,7 @@ __global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn
         pg.bodies[id] = make_int2(pr.body1, pr.body2);
         pg.color[id] = PG_NONE;
         if (pg.new_ids) pg.new_ids[i] = id;
+        pg.seq[id] = seq0 + i;   // the edge's place in its colliders' edge lists (newest first = descending stamp)
         // add_edge_and_key_with (contact_graph.rs:521-566): the key joins the pair set
         const uint32_t a = pr.collider1, b = pr.collider2;
         const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(256) void k_pg_add_pairs(PG pg, CT<T> ct, const avn
         pg.ctr[PGC_FREE_HEAD] = head + used;
         pg.ctr[PGC_N_FREE] = n_free - used;
         pg.ctr[PGC_NEXT_ID] = next + (total - used);
+        const unsigned long long seq1 = seq0 + total;
+        pg.ctr[PGC_SEQ] = (uint32_t)seq1; pg.ctr[PGC_SEQ + 1] = (uint32_t)(seq1 >> 32);
         pg.ctr[PGC_ADD_DONE] = 0u;
     }
 }
@@ -777,6 +781,75 @@ void launch_pg_merge_free(const PG& pg, uint32_t head, uint32_t n_free, uint32_t
     hipLaunchKernelGGL(k_pg_merge_free, dim3((n_free + n_rem + 255) / 256 + 1), dim3(256), 0, s, pg, head, n_free, n_rem);
 }
 
+// ---- avn_despawn: the device half (world/despawn.hpp) -------------------------------------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_collect_edges(PG pg, CT<T> ct, uint32_t n_rows, const uint32_t* __restrict__ rm_rank, PGEdgeRec* __restrict__ out, uint32_t cap) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_rows) return;
+    const uint4 meta = ct.meta[c];
+    if (!(meta.z & AVN_CP_ROW_USED)) return;
+    if (rm_rank[meta.x] == PG_NONE && rm_rank[meta.y] == PG_NONE) return;
+    const uint32_t k = atomicAdd(&pg.ctr[PGC_COLLECT], 1u);
+    if (k >= cap) return;   // (the host sees the count and retries with room)
+    const unsigned long long sq = pg.seq[c];
+    out[k] = PGEdgeRec{c, meta.x, meta.y, meta.z, pg.color[c], (uint32_t)sq, (uint32_t)(sq >> 32), 0u};
+}
+template <class T> void launch_pg_collect_edges(const PG& pg, const CT<T>& ct, uint32_t n_rows, const uint32_t* rm_rank, PGEdgeRec* out, uint32_t cap, hipStream_t s) {
+    (void)hipMemsetAsync(pg.ctr + PGC_COLLECT, 0, 4, s);
+    if (n_rows) hipLaunchKernelGGL(k_pg_collect_edges<T>, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, ct, n_rows, rm_rank, out, cap);
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_remove_list(PG pg, CT<T> ct, BP<T> bp, const uint32_t* __restrict__ ids, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = ids[i];
+    pg.rem_ids[i] = c;
+    const uint4 meta = ct.meta[c];
+    const uint32_t a = bp.col_info[meta.x].x, b = bp.col_info[meta.y].x;   // collider entities -> PairKey
+    const uint64_t key = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a;
+    ct.meta[c] = make_uint4(0u, 0u, 0u, 0u);
+    ct.dcount[c] = 0;
+    pg.color[c] = PG_NONE;
+    if (bp.pair_set_cap) {
+        const uint32_t mask = bp.pair_set_cap - 1u;
+        uint32_t h = (uint32_t)pg_hs_mix(key) & mask;
+        for (;;) {
+            const uint64_t v = bp.pair_set[h];
+            if (v == key) { bp.pair_set[h] = ~0ull - 1ull; break; }   // tombstone
+            if (v == ~0ull) break;
+            h = (h + 1u) & mask;
+        }
+    }
+}
+template <class T> void launch_pg_remove_list(const PG& pg, const CT<T>& ct, const BP<T>& bp, const uint32_t* ids, uint32_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_pg_remove_list<T>, dim3((n + 255) / 256), dim3(256), 0, s, pg, ct, bp, ids, n);
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_pg_renumber_rows(PG pg, CT<T> ct, uint32_t n_rows, const uint32_t* __restrict__ new_index) {
+    const uint32_t c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= n_rows || !(ct.meta[c].z & AVN_CP_ROW_USED)) return;
+    const int2 b = pg.bodies[c];
+    pg.bodies[c] = make_int2((int)new_index[b.x], (int)new_index[b.y]);
+}
+template <class T> void launch_pg_renumber_rows(const PG& pg, const CT<T>& ct, uint32_t n_rows, const uint32_t* new_index, hipStream_t s) {
+    if (n_rows) hipLaunchKernelGGL(k_pg_renumber_rows<T>, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, ct, n_rows, new_index);
+}
+__global__ __launch_bounds__(256) void k_renumber_int2(int2* __restrict__ v, uint32_t n, const uint32_t* __restrict__ new_index) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int2 b = v[i];
+    v[i] = make_int2((int)new_index[b.x], (int)new_index[b.y]);
+}
+void launch_renumber_int2(int2* v, uint32_t n, const uint32_t* new_index, hipStream_t s) { if (n) hipLaunchKernelGGL(k_renumber_int2, dim3((n + 255) / 256), dim3(256), 0, s, v, n, new_index); }
+template <class U> __global__ __launch_bounds__(256) void k_compact(const U* __restrict__ src, U* __restrict__ dst, const uint32_t* __restrict__ new_index, uint32_t n_old) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_old) return;
+    const uint32_t j = new_index[i];
+    if (j != PG_NONE) dst[j] = src[i];
+}
+void launch_compact_u32(const uint32_t* src, uint32_t* dst, const uint32_t* new_index, uint32_t n_old, hipStream_t s) { if (n_old) hipLaunchKernelGGL(k_compact<uint32_t>, dim3((n_old + 255) / 256), dim3(256), 0, s, src, dst, new_index, n_old); }
+void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_index, uint32_t n_old, hipStream_t s) { if (n_old) hipLaunchKernelGGL(k_compact<uint8_t>, dim3((n_old + 255) / 256), dim3(256), 0, s, src, dst, new_index, n_old); }
+
 // ---- GraphColor::manifold_handles of all colours, concatenated colour-major (what the solver's arrays are ordered by) ---------
 __global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __restrict__ handles, uint32_t* __restrict__ color_offsets, uint32_t total) {
     __shared__ uint32_t off[AVN_GRAPH_COLOR_COUNT + 1];
@@ -864,6 +937,9 @@ template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23
 #define INST(T)                                                                                                         \
     template void launch_pg_add_pairs<T>(const PG&, const CT<T>&, const avn_pair*, uint32_t, uint64_t*, uint32_t, hipStream_t);              \
     template void launch_pg_remove<T>(const PG&, const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                    \
+    template void launch_pg_collect_edges<T>(const PG&, const CT<T>&, uint32_t, const uint32_t*, PGEdgeRec*, uint32_t, hipStream_t); \
+    template void launch_pg_remove_list<T>(const PG&, const CT<T>&, const BP<T>&, const uint32_t*, uint32_t, hipStream_t); \
+    template void launch_pg_renumber_rows<T>(const PG&, const CT<T>&, uint32_t, const uint32_t*, hipStream_t);           \
     template void launch_pg_rebuild_pair_set<T>(const CT<T>&, const BP<T>&, uint32_t, hipStream_t);                     \
     template void launch_ovf_entries<T>(const DW<T>&, uint32_t, uint32_t, uint32_t*, uint32_t*, hipStream_t);           \
     template void launch_ovf_csr<T>(const DW<T>&, uint32_t, uint32_t, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t*, hipStream_t);

@@ -4,15 +4,18 @@
     // ---- bodies ------------------------------------------------------------------------------------------
     static constexpr uint32_t DUMMY_SLOTS = 2 * AVN_JOINT_TYPE_COUNT;  // joint_damping::<T>: two fresh DUMMY SolverBodies per joint type
     avn_status bodies_upload(const avn_bodies* b) override {
+        slp_world_asleep = slp_world_idle = false;
         if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass || !b->inv_inertia_local || !b->rb_type))) {
             error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG;
         }
         uint32_t n = b->count;
         bool moved = false;
-        if (pipe_on && have_bodies && n < dw.n_bodies) {
+        if (despawn_needs_bodies && n != despawn_expected_bodies) { error = "bodies_upload: after avn_despawn exactly the remaining bodies must be uploaded"; return AVN_ERR_STATE; }
+        const bool after_despawn = despawn_needs_bodies;   // (the library has renumbered everything it holds for exactly this upload)
+        if (pipe_on && have_bodies && n < dw.n_bodies && !after_despawn) {
             // a despawn renumbers bodies: every contact row, colour mask and handle list of the closed loop names body indices.  Nothing is
             // touched; the host ends the loop (avn_pipeline_enable(0)), uploads the new bodies and colliders and starts it again.
-            error = "bodies_upload: fewer bodies than before while the closed loop is on (avn_pipeline_enable(0) first, then upload bodies and colliders and enable again)";
+            error = "bodies_upload: fewer bodies than before while the closed loop is on: call avn_despawn for the bodies that leave (or avn_pipeline_enable(0), upload, enable again)";
             return AVN_ERR_STATE;
         }
         if (n + DUMMY_SLOTS > cap_bodies || !have_bodies) {
@@ -29,7 +32,7 @@
             if (pipe_dev) { avn_status sg = pg_bcol_grow(); if (sg != AVN_OK) return sg; }   // bodies spawned inside the closed loop: their colour masks start empty
         }
         if (moved || dw.n_bodies != n) graph_valid = false;
-        if (have_bodies && n < dw.n_bodies) {
+        if (have_bodies && n < dw.n_bodies && !after_despawn) {
             // fewer bodies than before: everything that may still index a body >= n is dropped (the host re-uploads it; nothing
             // may gather or schedule out of range meanwhile) -- uploaded manifolds, joints, colliders whose body is gone
             bool bad_m = false, bad_j = false, bad_c = false;
@@ -99,6 +102,7 @@
         joint_schedule_dirty = true;
         incidence_dirty = true;
         have_bodies = true;
+        despawn_needs_bodies = false;
         HIPCHK(hipStreamSynchronize(stream));  // host arrays are only borrowed for the call
         return AVN_OK;
     }

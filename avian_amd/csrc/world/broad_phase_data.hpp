@@ -22,6 +22,7 @@
         return AVN_OK;
     }
     avn_status existing_pairs_upload(const uint64_t* keys, size_t n) override {
+        slp_world_asleep = slp_world_idle = false;
         if (n && !keys) return AVN_ERR_BAD_ARG;
         hipError_t err;
         b_pair_keys.ensure(std::max<size_t>(n, 1) * 8, err);
@@ -57,8 +58,10 @@
         return AVN_OK;
     }
     avn_status colliders_upload(const avn_colliders* c) override {
+        slp_world_asleep = slp_world_idle = false;
         if (!have_bodies) { error = "colliders_upload before bodies_upload"; return AVN_ERR_STATE; }
         if (!c || (c->count && (!c->entity_index || !c->body || !c->shape || !c->half_extents))) { error = "colliders_upload: null array"; return AVN_ERR_BAD_ARG; }
+        if (despawn_needs_bodies) { error = "colliders_upload: after avn_despawn the remaining bodies are uploaded first"; return AVN_ERR_STATE; }
         uint32_t C = c->count;
         for (uint32_t i = 0; i < C; ++i)
             if (c->body[i] < 0 || (uint32_t)c->body[i] >= dw.n_bodies) { error = "colliders_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
@@ -189,6 +192,7 @@
             materials_restitution = false;
         }
         have_colliders = true;
+        despawn_needs_colliders = false;
         if (slp_on) {   // colliders spawned inside the loop join the island manager's RigidBodyColliders lists (upload order = Add order)
             for (uint32_t i = 0; i < C; ++i) {
                 if (isl.has_collider(c->entity_index[i])) continue;

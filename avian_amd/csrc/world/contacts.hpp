@@ -3,6 +3,7 @@
 
     // ---- narrow phase, part 2 ------------------------------------------------------------------------------------------
     avn_status collider_materials_upload(const avn_collider_materials* m) override {
+        slp_world_asleep = slp_world_idle = false;
         if (!m || m->count != bp.n_colliders) { error = "collider_materials_upload: count must equal the collider count"; return AVN_ERR_BAD_ARG; }
         uint32_t C = m->count;
         std::vector<V> mats(C);

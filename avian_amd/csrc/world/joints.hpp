@@ -19,6 +19,7 @@
         return joints_upload(&g);
     }
     avn_status joints_upload(const avn_joints* j) override {
+        slp_world_asleep = slp_world_idle = false;
         if (!have_bodies) { error = "joints_upload before bodies_upload"; return AVN_ERR_STATE; }
         if (!j || (j->count && (!j->joint_type || !j->body1 || !j->body2 || !j->local_anchor1 || !j->local_anchor2 || !j->compliance))) {
             error = "joints_upload: null array"; return AVN_ERR_BAD_ARG;
@@ -73,8 +74,10 @@
         any_damped = damp && J > 0;
         // body pairs whose joints disable collision (reference broad_phase.rs:423-428)
         std::vector<uint64_t> disabled;
+        h_j_collision_disabled.assign(J, 0);
         for (uint32_t i = 0; i < J; ++i)
             if (j->collision_disabled && j->collision_disabled[i]) {
+                h_j_collision_disabled[i] = 1;
                 uint32_t a = (uint32_t)j->body1[i], b = (uint32_t)j->body2[i];
                 disabled.push_back(a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a);
             }

@@ -146,7 +146,10 @@
     // manifold" (a body without one -- static, sleeping, disabled -- is never written by the solver and joins nothing;
     // kinematic bodies DO have a SolverBody that the solver reads and re-writes, so they merge like dynamic ones).  Eligible
     // when f32, no joints, few enough manifolds for the colour launches to be latency-bound and every island fits a block.
-    bool island_candidate(size_t M) const { return sizeof(T) == 4 && island_enabled && M != 0 && M <= island_max_manifolds; }
+    // (... and few enough BODIES: the block builder is host code that touches every body with a SolverBody, and the one launch stages all of
+    //  them in LDS -- at cfg4's 10^6 free bodies around 2 k manifolds the attempt cost 5 ms of host time per step, found by the stepped cfg4 timing)
+    size_t island_max_bodies_total = 65536;
+    bool island_candidate(size_t M) const { return sizeof(T) == 4 && island_enabled && M != 0 && M <= island_max_manifolds && dw.n_bodies <= island_max_bodies_total; }
     avn_status rebuild_island_blocks() {
         island_mode = false;
         const uint32_t N = dw.n_bodies, M = dw.n_manifolds;
@@ -156,7 +159,21 @@
         parent.resize(N);
         bool labelled = false;
         static const bool host_labels = getenv("AVN_ISLAND_LABELS_HOST") != nullptr;   // A/B: the host union-find below
-        if (pipe_dev && !host_labels) {
+        if (pipe_dev && slp_on && !host_labels) {
+            // sleeping on: the persistent islands ARE a grouping of the awake bodies no manifold crosses (an island pending its split is merely
+            // coarser than necessary) -- taken straight from the manager: no labelling kernel, no read-back, no synchronisation
+            std::vector<uint32_t>& rep = isl_roots;
+            rep.assign((size_t)isl.island_key_bound(), 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < N; ++i) {
+                parent[i] = i;
+                if (!h_body_has_sb[i] || !isl.body_has_node(i)) continue;
+                const uint32_t k = isl.island_of(i);
+                if (rep[k] == 0xFFFFFFFFu) rep[k] = i;
+                parent[i] = rep[k];
+            }
+            isl_labels_step_valid = false;
+            labelled = true;
+        } else if (pipe_dev && !host_labels) {
             // device closed loop: the manifolds' bodies are on the device already -- label the islands there (k_islands.hip: lock-free
             // union-find, root = lowest body index, only bodies with a SolverBody connect) and fetch 4 bytes per body; parent[] then holds
             // roots directly

@@ -18,6 +18,7 @@
 #define PGB(buf, cnt, field, keep) do { if ((st = pg_buf(buf, cnt, &(field), keep)) != AVN_OK) return st; } while (0)
         PGB(b_pg_bodies, rows, pg.bodies, true); PGB(b_pg_color, rows, pg.color, true); PGB(b_pg_lpos, rows, pg.lpos, true);
         PGB(b_pg_free_a, rows, pg.free_ids, true); PGB(b_pg_free_b, rows, pg.free_alt, true);
+        PGB(b_pg_seq, rows, pg.seq, true);
         {   // colour lists: [24][stride] re-laid out for the new stride
             uint32_t* nl = nullptr;
             if (hipMalloc((void**)&nl, (size_t)AVN_GRAPH_COLOR_COUNT * rows * 4) != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
@@ -275,7 +276,18 @@
     }
     avn_status pipeline_step_device() {
         avn_status st;
+        if (despawn_needs_bodies || despawn_needs_colliders) { error = "avn_step: avn_despawn must be followed by avn_bodies_upload and avn_colliders_upload of what remains"; return AVN_ERR_STATE; }
         launches = 0;
+        if (slp_on && slp_world_idle) {   // nothing is awake and the last step proved the state stationary: the step is the identity (world/sleeping.hpp)
+            for (hipEvent_t e : ev) HIPCHK(hipEventRecord(e, stream));
+            ev_valid = true;
+            pipe_stats.last_status_changes = 0; pipe_stats.last_host_ms = 0; last_timers.pair_count = 0; last_timers.kernel_launches = 0;
+            h_pairs.clear();
+            slp_n_awake = slp_last_slept = slp_last_woken = slp_last_popped = slp_last_pushed = 0; slp_host_ms = 0;
+            ++pipe_step_no; ++pg_dump_step;
+            return AVN_OK;
+        }
+        slp_step_started_asleep = slp_on && slp_world_asleep; slp_step_changed = false;
         double host_ms = 0;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
@@ -385,6 +397,7 @@
             if (h[2]) return pg_error_report(h[2]);   // raised by the previous step's solver passes (normally already reported by avn_synchronize)
         }
         pipe_stats.last_status_changes = n_ops;
+        if (n_ops || total) slp_step_changed = true;
         ++pg_dump_step;
         if (n_ops) {   // ---- the status-change loop: decisions, colours, handle lists ----
             lap();

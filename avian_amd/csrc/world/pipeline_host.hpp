@@ -3,6 +3,7 @@
 
     // ---- standalone closed loop ------------------------------------------------------------------------------------------
     avn_status pipeline_enable(int on) override {
+        slp_world_asleep = slp_world_idle = false;
         if (on && !have_colliders) { error = "pipeline_enable: upload bodies and colliders first"; return AVN_ERR_STATE; }
         if (on && pipe_on) return AVN_OK;
         if (pipe_on && pipe_dev) {   // leaving the device closed loop: its rows and keys go with it

@@ -12,6 +12,14 @@
 // Per step the host reads the loop's changes (8 bytes per change), the new pairs (28 bytes each) and the timers (5 bytes per body); with a
 // sleeping pile all three are empty or tiny.  avn_step synchronises at its end in this mode (the Sleeping set needs the timers).
     bool slp_on = false;
+    // Every body that could own a SolverBody sleeps (checked after the Sleeping set of a step; any upload, WakeBody, despawn or configuration
+    // change clears it): nothing can move, no AABB changes, no pair starts or stops touching, no timer advances -- avn_step is the identity and
+    // returns without a launch ("a sleeping pile costs nothing", islands/sleeping.rs:243-280).
+    bool slp_world_asleep = false;
+    // ... but only from the SECOND such step on: the step in which the last island fell asleep still moved its bodies, so the next step's AABBs and
+    // contacts are new (a non-touching pair may start touching and wake the island again: DESIGN.md 4.8's flip-flop).  A step that STARTED with
+    // everything asleep and changed nothing (no new pair, no status change, nothing woken) proves the state stationary.
+    bool slp_world_idle = false, slp_step_started_asleep = false, slp_step_changed = false;
     IslandManager isl;
     SleepParams<T> slp_k;
     float slp_time_to_sleep = 0.5f;
@@ -60,6 +68,7 @@
     avn_status slp_fail(avn_status st) { error = isl.error; return st; }
 
     avn_status sleeping_enable(const avn_sleep_params* p) override {
+        slp_world_asleep = slp_world_idle = false;
         if (!p) {
             if (!slp_on) return AVN_OK;
             double ms = 0;
@@ -187,6 +196,8 @@
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         st = sleeping_apply_result(true, host_ms);
         slp_host_ms = host_ms;
+        slp_world_asleep = st == AVN_OK && std::none_of(h_body_has_sb.begin(), h_body_has_sb.end(), [](uint8_t x) { return x != 0; });
+        slp_world_idle = slp_world_asleep && slp_step_started_asleep && !slp_step_changed && isl.last_slept() == 0 && isl.last_woken() == 0;
         return st;
     }
     avn_status sleeping_stats_get(avn_sleeping_stats* o) override {
@@ -209,6 +220,7 @@
         return AVN_OK;
     }
     avn_status wake_bodies(const uint32_t* ids, size_t n) override {   // WakeBody (sleeping.rs:438-452)
+        slp_world_asleep = slp_world_idle = false;
         if (!slp_on) { error = "wake_bodies: sleeping is not enabled"; return AVN_ERR_STATE; }
         if (n && !ids) return AVN_ERR_BAD_ARG;
         double ms = 0;

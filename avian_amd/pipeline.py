@@ -36,6 +36,10 @@ class ContactPipeline:
         self.edge_touching: Dict[int, bool] = {}
         self.n_handles: Dict[int, int] = {}    # ContactEdge::constraint_handles.len()
         self.active: List[int] = []            # ContactGraph::active_pairs
+        # the ContactGraph's adjacency (StableUnGraph): per collider its outgoing (collider1) / incoming (collider2) edges in INSERTION
+        # order -- the reference links a new edge at the head of both lists, so its walks are these lists backwards
+        self.out_edges: Dict[int, List[int]] = {}
+        self.in_edges: Dict[int, List[int]] = {}
         self.handles_dirty = True
         self.stats = dict(pairs_added=0, pairs_removed=0, pushes=0, pops=0)
 
@@ -55,6 +59,8 @@ class ContactPipeline:
             self.pairs[i] = (int(p["collider1"]), int(p["collider2"]), int(p["body1"]), int(p["body2"]))
             self.edge_touching[i] = False
             self.n_handles[i] = 0
+            self.out_edges.setdefault(int(p["collider1"]), []).append(i)
+            self.in_edges.setdefault(int(p["collider2"]), []).append(i)
         self.active.extend(ids.tolist())
         self.w.active_pairs_set(np.asarray(self.active, np.uint32))
         self.stats["pairs_added"] += len(ids)
@@ -110,6 +116,8 @@ class ContactPipeline:
             self.active = [a for a in self.active if a not in gone]
             self.w.active_pairs_set(np.asarray(self.active, np.uint32))
             for cid in removed:
+                c1, c2, _, _ = self.pairs[cid]
+                self.out_edges[c1].remove(cid); self.in_edges[c2].remove(cid)
                 del self.pairs[cid], self.edge_touching[cid], self.n_handles[cid]
                 heapq.heappush(self.free_ids, cid)
             self.stats["pairs_removed"] += len(removed)
@@ -118,6 +126,30 @@ class ContactPipeline:
             self.w.manifold_handles_upload(offsets, handles.astype(np.uint32))
             self.handles_dirty = False
         return len(ch)
+
+    def remove_collider(self, entity: int):
+        """``remove_collider`` of the reference (collision/narrow_phase/mod.rs:399-457 over ContactGraph::remove_collider_with,
+        contact_types/contact_graph.rs:641-700, and StableUnGraph::remove_node_with, data_structures/stable_graph.rs:251-283): every edge
+        of the collider -- outgoing edges newest first, then incoming edges newest first --; a touching pair's constraint handles are
+        popped, then the edge leaves the graph, the pair set and the active pairs, and its id returns to the pool.  The caller uploads the
+        remaining colliders afterwards (the interval is dropped in place)."""
+        ids = list(reversed(self.out_edges.get(entity, []))) + list(reversed(self.in_edges.get(entity, [])))
+        for cid in ids:
+            if self.edge_touching[cid]:
+                self._pop_all(cid)
+            c1, c2, _, _ = self.pairs[cid]
+            self.out_edges[c1].remove(cid); self.in_edges[c2].remove(cid)
+            self.w.contact_pairs_remove(np.asarray([cid], np.uint32))
+            self.active.remove(cid)
+            del self.pairs[cid], self.edge_touching[cid], self.n_handles[cid]
+            heapq.heappush(self.free_ids, cid)
+            self.stats["pairs_removed"] += 1
+        self.out_edges.pop(entity, None); self.in_edges.pop(entity, None)
+        self.w.active_pairs_set(np.asarray(self.active, np.uint32))
+        if self.handles_dirty:
+            offsets, handles = self.graph.lists()
+            self.w.manifold_handles_upload(offsets, handles.astype(np.uint32))
+            self.handles_dirty = False
 
     def step(self):
         w = self.w

@@ -815,8 +815,20 @@ typedef struct avn_islands_result {
     const uint32_t* pairs_woken; size_t n_pairs_woken;
     const uint32_t* bodies_slept; size_t n_bodies_slept;
     const uint32_t* bodies_woken; size_t n_bodies_woken;  /* their SleepTimer is reset to 0 */
+    const uint32_t* pairs_removed; size_t n_pairs_removed; /* avn_islands_collider_remove: the collider's edges in removal order (they left the ContactGraph) */
 } avn_islands_result;
 AVN_API avn_status AVN_FN(islands_last_result)(avn_island_manager* m, avn_islands_result* out);
+/* Despawn (round 4; what avn_despawn drives inside the closed loop, for a host that keeps its own loop):
+ *  collider_remove: remove_collider (collision/narrow_phase/mod.rs:399-457) -- the collider's edges in the ContactGraph's edge-list order (outgoing
+ *    newest first, then incoming newest first): result.popped = the contact ids whose constraint handles the host must pop (one entry per handle, in
+ *    order; TOUCHING pairs only), result.pairs_removed = every edge, in order; touching pairs linked into an island are unlinked
+ *    (constraints_removed += 1); the collider leaves its body's RigidBodyColliders.
+ *  body_remove: BodyIslandNode::on_remove (islands/mod.rs:1336-1400) followed by the queued WakeIslands([the island the body was in]) -- result as for
+ *    avn_islands_wake_body.  Remove the body's colliders first.
+ *  renumber_bodies: new_index[old] = new body index | 0xFFFFFFFF (removed): the host compacted its body arrays. */
+AVN_API avn_status AVN_FN(islands_collider_remove)(avn_island_manager* m, uint32_t collider);
+AVN_API avn_status AVN_FN(islands_body_remove)(avn_island_manager* m, uint32_t body);
+AVN_API avn_status AVN_FN(islands_renumber_bodies)(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old);
 typedef struct avn_islands_stats {
     uint32_t n_islands, n_sleeping_islands, n_bodies, n_sleeping_bodies;
     uint32_t merges, splits;           /* totals since creation */
@@ -849,6 +861,35 @@ typedef struct avn_sleeping_out {
 AVN_API avn_status AVN_FN(sleeping_state_get)(avn_world* w, const avn_sleeping_out* out);
 /* WakeBody for the listed bodies (a host that moved or kicked a sleeping body: wake_on_changed, sleeping.rs:556-604) */
 AVN_API avn_status AVN_FN(wake_bodies)(avn_world* w, const uint32_t* bodies, size_t n);
+
+/* Despawn INSIDE the closed loop (avn_pipeline_enable; round 4 -- rounds 1-3 refused it and the host had to restart the loop, losing warm starts
+ * and the ContactId history).  What the reference does when entities with a RigidBody / Collider are despawned between two steps
+ * (collision/narrow_phase/mod.rs:399-457 remove_collider, :459-560 remove_body_on / remove_collider_on; contact_types/contact_graph.rs:641-700
+ * ContactGraph::remove_collider_with; data_structures/stable_graph.rs:251-315 remove_node_with / remove_edge; dynamics/solver/islands/mod.rs:
+ * 1336-1400 BodyIslandNode::on_remove), in the order given:
+ *   1. every collider of `collider_entities` (a collider despawned on its own), then every body of `bodies` with all of its colliders (upload
+ *      order = RigidBodyColliders order): the collider's contact edges are walked in the ContactGraph's edge-list order -- outgoing edges
+ *      (the collider is collider1) newest first, then incoming edges newest first --, a TOUCHING pair's constraint handles are popped from the
+ *      ConstraintGraph in that order (swap_remove: the order decides where the other handles of the colour lists end up) and its contact is
+ *      unlinked from its island (constraints_removed += 1); every edge leaves ContactGraph::pair_set and its ContactId returns to the IdPool
+ *      (lowest free id first at the next allocation);
+ *   2. with avn_sleeping_enable on: the body leaves its island's body list (an island left empty is removed), then the queued
+ *      WakeIslands([the island the body was in]) runs;
+ *   3. the remaining bodies are RENUMBERED by stable compaction (body i becomes i - #removed below i) in everything the library holds: contact
+ *      rows, colour masks, joints, the island manager, sleep timers.  A joint that names a removed body is refused (AVN_ERR_STATE: upload the
+ *      joints without it first).
+ * The rigid-body and collider COMPONENTS are the host's: after avn_despawn it must call avn_bodies_upload (the remaining bodies, new numbering)
+ * and avn_colliders_upload (the remaining colliders in their previous relative order; `body` in the new numbering) before the next avn_step --
+ * the interval of a removed collider is dropped in place (update_aabb_intervals' retain_mut, collision/broad_phase.rs:230-279), the others keep
+ * their order.  Until both have happened avn_step returns AVN_ERR_STATE. */
+typedef struct avn_despawn_list {
+    uint32_t struct_size;
+    uint32_t n_colliders;
+    const uint32_t* collider_entities;   /* Entity::index() of colliders despawned WITHOUT their body, in despawn order */
+    uint32_t n_bodies;
+    const uint32_t* bodies;              /* body indices (current numbering) despawned WITH all their colliders, in despawn order; no duplicates */
+} avn_despawn_list;
+AVN_API avn_status AVN_FN(despawn)(avn_world* w, const avn_despawn_list* d);
 
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as
  * doubles: the per-rank bound exchanged between ranks to detect islands of different ranks coming into AABB contact.

@@ -125,17 +125,18 @@ struct IslandManager {
     std::vector<uint32_t> islands_to_wake;
     uint32_t merges = 0, splits = 0, sleeping_pairs = 0;
     // results of the last command batch
-    std::vector<uint32_t> popped, pushed, pairs_slept, pairs_woken, bodies_slept, bodies_woken;
+    std::vector<uint32_t> popped, pushed, pairs_slept, pairs_woken, bodies_slept, bodies_woken, pairs_removed;
     std::string error;
 
-    void clear_results() { popped.clear(); pushed.clear(); pairs_slept.clear(); pairs_woken.clear(); bodies_slept.clear(); bodies_woken.clear(); }
+    void clear_results() { popped.clear(); pushed.clear(); pairs_slept.clear(); pairs_woken.clear(); bodies_slept.clear(); bodies_woken.clear(); pairs_removed.clear(); }
     uint32_t node_of(uint32_t collider) {
         auto it = collider_index.find(collider);
         if (it != collider_index.end()) return it->second;
-        uint32_t n = (uint32_t)collider_index.size();
+        uint32_t n = next_node++;   // (never reused: a despawned collider's node stays behind, empty)
         collider_index.emplace(collider, n);
         return n;
     }
+    uint32_t next_node = 0;
     bool has_node(uint32_t body) const { return body != NONE && body < body_has_node.size() && body_has_node[body]; }
     bool has_collider(uint32_t collider) const { return collider_body.count(collider) != 0; }
 
@@ -172,6 +173,91 @@ struct IslandManager {
         contacts[id] = e;
         contact_lists.add_edge(id, node_of(c1), node_of(c2));
         return AVN_OK;
+    }
+
+    // ---- despawn (round 4) -------------------------------------------------------------------------------------------------------------
+    // the island half of remove_collider's callback for ONE edge (collision/narrow_phase/mod.rs:411-455) followed by the edge's removal
+    // (contact_graph.rs:669-690): a TOUCHING pair that is linked into an island is unlinked (constraints_removed += 1)
+    void remove_collider_edge(uint32_t id) {
+        if (id >= contacts.size() || !contacts[id].live) return;
+        ContactEdge& e = contacts[id];
+        if (e.touching && e.has_island) remove_contact(id);
+        if (e.sleeping) --sleeping_pairs;
+        contact_lists.remove_edge(id);
+        contacts[id] = ContactEdge();
+    }
+    // avn_islands_collider_remove: the whole of remove_collider for a host that keeps its own loop -- StableUnGraph::remove_node_with's order (the
+    // node's outgoing list from its head, then its incoming list from its head), the handles the host must pop, every edge removed
+    avn_status collider_remove_full(uint32_t collider) {
+        clear_results();
+        if (!collider_body.count(collider)) { error = "islands_collider_remove: unknown collider"; return AVN_ERR_BAD_ARG; }
+        auto it = collider_index.find(collider);
+        if (it != collider_index.end())
+            for (uint32_t id : contact_lists.edges_of(it->second)) {
+                const ContactEdge& e = contacts[id];
+                if (e.touching) for (uint32_t k = 0; k < e.handles; ++k) popped.push_back(id);
+                pairs_removed.push_back(id);
+                remove_collider_edge(id);
+            }
+        collider_remove(collider);
+        return AVN_OK;
+    }
+    avn_status body_remove_and_wake(uint32_t body) {
+        clear_results();
+        const uint32_t isl = body_remove(body);
+        if (isl != NONE) wake_islands({isl});
+        return AVN_OK;
+    }
+    // the collider leaves RigidBodyColliders and the ContactGraph's node map (its edges are gone already)
+    void collider_remove(uint32_t collider) {
+        auto it = collider_body.find(collider);
+        if (it == collider_body.end()) return;
+        const uint32_t b = it->second;
+        if (b != NONE && b < body_colliders.size()) { auto& v = body_colliders[b]; v.erase(std::remove(v.begin(), v.end(), collider), v.end()); }
+        collider_body.erase(it);
+        collider_index.erase(collider);   // (node indices are not reused: a new collider gets a fresh node)
+    }
+    // BodyIslandNode::on_remove, islands/mod.rs:1336-1400; returns the island the body was in (NONE: it had no node)
+    uint32_t body_remove(uint32_t body) {
+        if (!has_node(body)) return NONE;
+        const IslandNode bn = body_node[body];
+        if (bn.prev != NONE) body_node[bn.prev].next = bn.next;
+        if (bn.next != NONE) body_node[bn.next].prev = bn.prev;
+        PhysicsIsland* island = islands.get(bn.island_id);
+        island->body_count -= 1;
+        if (island->head_body == body) {
+            island->head_body = bn.next;
+            if (island->head_body == NONE) remove_island(bn.island_id);   // the island is empty
+        } else if (island->tail_body == body) island->tail_body = bn.prev;
+        body_node[body] = IslandNode();
+        body_has_node[body] = 0; body_sleeping[body] = 0;
+        return bn.island_id;
+    }
+    // stable compaction of the body indices after a despawn: new_index[old] = new | NONE (removed)
+    void renumber_bodies(const std::vector<uint32_t>& new_index, uint32_t n_new) {
+        auto m = [&](uint32_t b) { return b != NONE && b < new_index.size() ? new_index[b] : NONE; };
+        std::vector<IslandNode> bn(n_new); std::vector<uint8_t> hn(n_new, 0), sl(n_new, 0); std::vector<std::vector<uint32_t>> bc(n_new);
+        for (uint32_t b = 0; b < body_node.size() && b < new_index.size(); ++b) {
+            const uint32_t nb = new_index[b];
+            if (nb == NONE) continue;
+            IslandNode x = body_node[b]; x.prev = m(x.prev); x.next = m(x.next);
+            bn[nb] = x; hn[nb] = body_has_node[b]; sl[nb] = body_sleeping[b];
+            if (b < body_colliders.size()) bc[nb] = body_colliders[b];
+        }
+        body_node.swap(bn); body_has_node.swap(hn); body_sleeping.swap(sl); body_colliders.swap(bc);
+        for (auto& kv : collider_body) kv.second = m(kv.second);
+        for (ContactEdge& e : contacts) if (e.live) { e.body1 = m(e.body1); e.body2 = m(e.body2); }
+        for (auto& en : islands.entries) if (en.occupied) { en.v.head_body = m(en.v.head_body); en.v.tail_body = m(en.v.tail_body); }
+        // the JointGraph's nodes are bodies: its per-node list heads move with them (a despawned body carries no joint: the caller checked)
+        for (JointEdge& j : joints) if (j.live) { j.body1 = m(j.body1); j.body2 = m(j.body2); }
+        Lists jl;
+        for (int d = 0; d < 2; ++d) {
+            jl.node_next[d].assign(n_new, NONE);
+            for (uint32_t b = 0; b < joint_lists.node_next[d].size() && b < new_index.size(); ++b) if (new_index[b] != NONE) jl.node_next[d][new_index[b]] = joint_lists.node_next[d][b];
+        }
+        jl.edges = joint_lists.edges;
+        for (EdgeLinks& e : jl.edges) if (e.live) { e.node[0] = m(e.node[0]); e.node[1] = m(e.node[1]); }
+        joint_lists = jl;
     }
 
     // merge_islands, islands/mod.rs:814-990

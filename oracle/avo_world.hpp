@@ -313,6 +313,7 @@ struct WorldBase {
     virtual avn_status sleeping_stats_get(avn_sleeping_stats*) = 0;
     virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
     virtual avn_status wake_bodies(const uint32_t*, size_t) = 0;
+    virtual avn_status despawn(const avn_despawn_list*) = 0;
 };
 
 struct ConstraintGraph;  // defined below (solver/constraint_graph.rs restatement)
@@ -392,6 +393,8 @@ template <class S> struct World : WorldBase {
     avn_status sleeping_stats_get(avn_sleeping_stats* o) override;
     avn_status sleeping_state_get(const avn_sleeping_out* o) override;
     avn_status wake_bodies(const uint32_t* ids, size_t n) override;
+    avn_status despawn(const avn_despawn_list* d) override;
+    bool despawn_needs_bodies = false, despawn_needs_colliders = false;   // avn_despawn happened: the host owes the remaining bodies / colliders
     void sleeping_apply(bool count);          // the ConstraintGraph / Sleeping-component side of the manager's last result
     void sleeping_systems();                  // split_island + the Sleeping set, after the solver
 
@@ -436,6 +439,8 @@ template <class S> struct World : WorldBase {
         if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass ||
                                 !b->inv_inertia_local || !b->rb_type))) { error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG; }
         size_t n = b->count;
+        if (despawn_needs_bodies && n != bodies.size()) { error = "bodies_upload: after avn_despawn exactly the remaining bodies must be uploaded"; return AVN_ERR_STATE; }
+        despawn_needs_bodies = false;
         bodies.resize(n);
         accel_linear.resize(n);
         accel_angular.resize(n);
@@ -1325,6 +1330,7 @@ template <class S> struct World : WorldBase {
         collider_slot.swap(next_slot);
         intervals.swap(kept);
         have_colliders = true;
+        despawn_needs_colliders = false;
         if (slp)   // colliders spawned inside the loop join their body's RigidBodyColliders (upload order = Add order)
             for (const Collider<S>& o : colliders) {
                 if (slp->isl.has_collider(o.entity)) continue;
@@ -2126,6 +2132,11 @@ struct PipelineState {
     std::map<uint32_t, Pair> pairs;
     std::vector<uint32_t> active;
     ConstraintGraph graph;
+    // the ContactGraph's adjacency (StableUnGraph: a node per collider, per-node edge lists linked at the head): what remove_collider walks
+    IslandManager::Lists lists;
+    std::unordered_map<uint32_t, uint32_t> node_of_collider;
+    uint32_t node(uint32_t collider) { auto it = node_of_collider.find(collider); if (it != node_of_collider.end()) return it->second; const uint32_t n = (uint32_t)node_of_collider.size() + nodes_dropped; node_of_collider.emplace(collider, n); return n; }
+    uint32_t nodes_dropped = 0;   // (node indices are never reused: a removed collider's node stays behind, empty)
     std::vector<uint32_t> handles;
     uint32_t offsets[AVN_GRAPH_COLOR_COUNT + 1] = {0};
     avn_pipeline_stats stats;
@@ -2181,6 +2192,7 @@ template <class S> avn_status World<S>::pipeline_refresh_handles() {
 }
 template <class S> avn_status World<S>::pipeline_step() {
     PipelineState& P = *pipe;
+    if (despawn_needs_bodies || despawn_needs_colliders) { error = "avn_step: avn_despawn must be followed by avn_bodies_upload and avn_colliders_upload of what remains"; return AVN_ERR_STATE; }
     diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
     timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
     auto np_t0 = std::chrono::steady_clock::now();
@@ -2190,6 +2202,7 @@ template <class S> avn_status World<S>::pipeline_step() {
             uint32_t id;
             if (!P.free_ids.empty()) { id = *P.free_ids.begin(); P.free_ids.erase(P.free_ids.begin()); } else id = P.next_id++;
             P.pairs[id] = {pr.collider1, pr.collider2, pr.body1, pr.body2, 0u};
+            P.lists.add_edge(id, P.node(pr.collider1), P.node(pr.collider2));
             P.active.push_back(id);
             ids.push_back(id); c1.push_back(pr.collider1); c2.push_back(pr.collider2); fl.push_back(pr.flags);
         }
@@ -2254,7 +2267,7 @@ template <class S> avn_status World<S>::pipeline_step() {
         std::vector<uint32_t> keep;
         for (uint32_t a : P.active) if (!gone.count(a)) keep.push_back(a);
         P.active.swap(keep);
-        for (uint32_t cid : removed) { P.pairs.erase(cid); P.free_ids.insert(cid); }
+        for (uint32_t cid : removed) { P.pairs.erase(cid); P.free_ids.insert(cid); P.lists.remove_edge(cid); }
         P.stats.pairs_removed += removed.size();
     }
     if (slp) {   // the deferred WakeIslands of the status loop (system_param.rs:391-398), applied before the solver
@@ -2424,6 +2437,119 @@ template <class S> avn_status World<S>::sleeping_state_get(const avn_sleeping_ou
         if (o->sleep_timer) o->sleep_timer[b] = slp->timer[b];
     }
     return AVN_OK;
+}
+// ---- despawn inside the closed loop (header: avn_despawn) ------------------------------------------------------------------------------
+// collision/narrow_phase/mod.rs:399-457 remove_collider (the callback: pops + islands.remove_contact for TOUCHING pairs), :459-560 the observers
+// (WakeIslands([the body's island]) queued, then remove_collider per collider); contact_types/contact_graph.rs:641-700 remove_collider_with (every
+// edge of the node, callback first, then out of the active / sleeping pairs and the pair set); data_structures/stable_graph.rs:251-283
+// remove_node_with (the node's OUTGOING list from its head, then its INCOMING list from its head: newest edge first; the edge id is freed,
+// :286-315); dynamics/solver/islands/mod.rs:1336-1400 BodyIslandNode::on_remove.
+template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
+    if (!d || d->struct_size != sizeof(avn_despawn_list) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
+    if (!pipe) { error = "despawn: needs the closed loop (avn_pipeline_enable)"; return AVN_ERR_STATE; }
+    if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
+    PipelineState& P = *pipe;
+    const size_t n_old = bodies.size();
+    std::vector<uint8_t> gone_body(n_old, 0);
+    for (uint32_t i = 0; i < d->n_bodies; ++i) {
+        const uint32_t b = d->bodies[i];
+        if (b >= n_old || gone_body[b]) { error = "despawn: body index out of range or listed twice"; return AVN_ERR_BAD_ARG; }
+        gone_body[b] = 1;
+    }
+    for (uint32_t i = 0; i < d->n_colliders; ++i) if (!collider_slot.count(d->collider_entities[i])) { error = "despawn: unknown collider"; return AVN_ERR_BAD_ARG; }
+    for (const Joint<S>& j : joints) if (gone_body[(size_t)j.body1] || gone_body[(size_t)j.body2]) { error = "despawn: a joint names a despawned body (upload the joints without it first)"; return AVN_ERR_STATE; }
+    std::unordered_set<uint32_t> gone_collider;
+    auto remove_collider = [&](uint32_t entity) {
+        if (gone_collider.count(entity)) return;   // (ContactGraph::remove_collider_with: the entity has no node any more)
+        gone_collider.insert(entity);
+        auto nd = P.node_of_collider.find(entity);
+        if (nd != P.node_of_collider.end()) {
+            for (uint32_t id : P.lists.edges_of(nd->second)) {   // outgoing newest first, then incoming newest first
+                PipelineState::Pair& pr = P.pairs[id];
+                const bool touching = contact_rows[id].flags & AVN_CP_TOUCHING;
+                if (touching) {
+                    while (pr.n_handles) { --pr.n_handles; P.graph.pop_manifold(((uint64_t)id << 8) | pr.n_handles); P.handles_dirty = true; ++P.stats.manifolds_popped; }
+                }
+                if (slp) slp->isl.remove_collider_edge(id);   // (unlinks a touching, linked pair from its island first)
+                // out of the active pairs, the pair set, the graph; the id returns to the pool
+                contact_pairs_remove(&id, 1);
+                P.active.erase(std::remove(P.active.begin(), P.active.end(), id), P.active.end());
+                P.lists.remove_edge(id);
+                P.pairs.erase(id); P.free_ids.insert(id);
+                ++P.stats.pairs_removed;
+            }
+            P.node_of_collider.erase(nd); ++P.nodes_dropped;
+        }
+        if (slp) slp->isl.collider_remove(entity);
+    };
+    auto island_of = [&](int32_t body) -> uint32_t { return slp && body >= 0 && slp->isl.has_node((uint32_t)body) ? slp->isl.body_node[(size_t)body].island_id : IslandManager::NONE; };
+    auto wake = [&](uint32_t island) {
+        if (!slp || island == IslandManager::NONE) return;
+        slp->isl.clear_results();
+        slp->isl.wake_islands({island});
+        sleeping_apply(false);
+    };
+    // 1. colliders despawned on their own (remove_collider_on::<Remove, ColliderMarker>)
+    for (uint32_t i = 0; i < d->n_colliders; ++i) {
+        const uint32_t ent = d->collider_entities[i];
+        const uint32_t isl = island_of(colliders[collider_slot[ent]].body);
+        remove_collider(ent);
+        wake(isl);
+    }
+    // 2. bodies with their colliders (remove_body_on::<Remove, RigidBody>, the colliders' own observers find nothing left), then
+    //    BodyIslandNode::on_remove, then the queued WakeIslands
+    for (uint32_t i = 0; i < d->n_bodies; ++i) {
+        const uint32_t b = d->bodies[i];
+        const uint32_t isl = island_of((int32_t)b);
+        for (const Collider<S>& c : colliders) if ((uint32_t)c.body == b) remove_collider(c.entity);   // RigidBodyColliders: upload order
+        if (slp) slp->isl.body_remove(b);
+        wake(isl);
+    }
+    // 3. stable compaction of the bodies and of everything that names one
+    std::vector<uint32_t> new_index(n_old, IslandManager::NONE);
+    uint32_t n_new = 0;
+    for (size_t b = 0; b < n_old; ++b) if (!gone_body[b]) new_index[b] = n_new++;
+    {
+        std::vector<Body<S>> nb; std::vector<V3<S>> al, aa;
+        nb.reserve(n_new); al.reserve(n_new); aa.reserve(n_new);
+        for (size_t b = 0; b < n_old; ++b) if (!gone_body[b]) { nb.push_back(bodies[b]); al.push_back(accel_linear[b]); aa.push_back(accel_angular[b]); }
+        bodies.swap(nb); accel_linear.swap(al); accel_angular.swap(aa);
+    }
+    // colliders: the despawned ones leave; the others keep their relative slot order, intervals are retained in place (broad_phase.rs:230-279)
+    {
+        std::vector<uint32_t> new_slot(colliders.size(), IslandManager::NONE);
+        std::vector<Collider<S>> nc; std::vector<Material> nm;
+        for (size_t s_ = 0; s_ < colliders.size(); ++s_) {
+            const Collider<S>& c = colliders[s_];
+            if (gone_collider.count(c.entity) || gone_body[(size_t)c.body]) continue;
+            new_slot[s_] = (uint32_t)nc.size();
+            nc.push_back(c); nc.back().body = (int32_t)new_index[(size_t)c.body];
+            if (s_ < materials.size()) nm.push_back(materials[s_]);
+        }
+        std::vector<AabbInterval> kept;
+        for (const AabbInterval& iv : intervals) if (new_slot[iv.collider] != IslandManager::NONE) kept.push_back({new_slot[iv.collider], iv.flags});
+        colliders.swap(nc); intervals.swap(kept);
+        if (!materials.empty()) materials.swap(nm);
+        collider_slot.clear();
+        for (uint32_t s_ = 0; s_ < colliders.size(); ++s_) collider_slot.emplace(colliders[s_].entity, s_);
+    }
+    for (Joint<S>& j : joints) { j.body1 = (int32_t)new_index[(size_t)j.body1]; j.body2 = (int32_t)new_index[(size_t)j.body2]; }
+    collision_disabled_bodies.clear();
+    for (const Joint<S>& j : joints) if (j.collision_disabled) collision_disabled_bodies.insert(pair_key((uint32_t)j.body1, (uint32_t)j.body2));
+    for (auto& kv : P.pairs) { kv.second.b1 = (int32_t)new_index[(size_t)kv.second.b1]; kv.second.b2 = (int32_t)new_index[(size_t)kv.second.b2]; }
+    for (auto& col : P.graph.colors) {   // GraphColor::body_set is indexed by the body: the bits move with the bodies (a despawned body's bits went with its pops)
+        std::vector<bool> ns(n_new, false);
+        for (size_t b = 0; b < col.body_set.size() && b < n_old; ++b) if (col.body_set[b] && !gone_body[b]) ns[new_index[b]] = true;
+        col.body_set.swap(ns);
+        for (auto& h : col.manifold_handles) { h.body1 = new_index[h.body1]; h.body2 = new_index[h.body2]; }
+    }
+    if (slp) {
+        slp->isl.renumber_bodies(new_index, n_new);
+        auto compact = [&](auto& v) { if (v.empty()) return; std::remove_reference_t<decltype(v)> o; for (size_t b = 0; b < n_old && b < v.size(); ++b) if (!gone_body[b]) o.push_back(v[b]); v.swap(o); };
+        compact(slp->timer); compact(slp->lin); compact(slp->ang); compact(slp->disabled);
+    }
+    despawn_needs_bodies = d->n_bodies != 0; despawn_needs_colliders = d->n_bodies != 0 || d->n_colliders != 0;
+    return pipeline_refresh_handles();
 }
 template <class S> avn_status World<S>::wake_bodies(const uint32_t* ids, size_t n) {
     if (!slp) { error = "wake_bodies: sleeping is not enabled"; return AVN_ERR_STATE; }

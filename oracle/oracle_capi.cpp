@@ -85,6 +85,7 @@ avn_status avo_sleeping_enable(avn_world* w, const avn_sleep_params* p) { FWD(sl
 avn_status avo_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { FWD(sleeping_stats_get(o)); }
 avn_status avo_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { FWD(sleeping_state_get(o)); }
 avn_status avo_wake_bodies(avn_world* w, const uint32_t* ids, size_t n) { FWD(wake_bodies(ids, n)); }
+avn_status avo_despawn(avn_world* w, const avn_despawn_list* d) { FWD(despawn(d)); }
 // Checker for avn_level2_plan_* (header).  Deliberately organised the other way round from the product's planner: per colour a
 // body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
 // body in ascending index, so they come out sorted without sorting.
@@ -314,6 +315,17 @@ avn_status avo_islands_last_result(avn_island_manager* m, avn_islands_result* o)
     o->popped = g.popped.data(); o->n_popped = g.popped.size(); o->pushed = g.pushed.data(); o->n_pushed = g.pushed.size();
     o->pairs_slept = g.pairs_slept.data(); o->n_pairs_slept = g.pairs_slept.size(); o->pairs_woken = g.pairs_woken.data(); o->n_pairs_woken = g.pairs_woken.size();
     o->bodies_slept = g.bodies_slept.data(); o->n_bodies_slept = g.bodies_slept.size(); o->bodies_woken = g.bodies_woken.data(); o->n_bodies_woken = g.bodies_woken.size();
+    o->pairs_removed = g.pairs_removed.data(); o->n_pairs_removed = g.pairs_removed.size();
+    return AVN_OK;
+}
+avn_status avo_islands_collider_remove(avn_island_manager* m, uint32_t collider) { return m ? m->m.collider_remove_full(collider) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_body_remove(avn_island_manager* m, uint32_t body) { return m ? m->m.body_remove_and_wake(body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_renumber_bodies(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old) {
+    if (!m || (n_old && !new_index)) return AVN_ERR_BAD_ARG;
+    std::vector<uint32_t> map(new_index, new_index + n_old);
+    uint32_t n_new = 0;
+    for (uint32_t v : map) if (v != avo::IslandManager::NONE) n_new = std::max(n_new, v + 1u);
+    m->m.renumber_bodies(map, n_new);
     return AVN_OK;
 }
 avn_status avo_islands_stats_get(avn_island_manager* m, avn_islands_stats* o) { return m ? m->m.stats(o) : AVN_ERR_BAD_ARG; }

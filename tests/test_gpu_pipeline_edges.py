@@ -168,15 +168,15 @@ def test_bodies_and_colliders_spawned_inside_the_device_closed_loop():
     assert len(ids) and wh.bodies_download()["position"][-1, 1] < 6.5
 
 
-def test_despawn_inside_the_closed_loop_is_refused_not_ignored():
-    """Fewer bodies, or a collider with live contact rows missing from the upload: AVN_ERR_STATE and an unchanged world (the
-    library used to switch the closed loop off silently)."""
+def test_shrinking_uploads_without_avn_despawn_are_refused_not_ignored():
+    """Fewer bodies, or a collider with live contact rows missing from the upload, WITHOUT avn_despawn: AVN_ERR_STATE and an unchanged world
+    (the library used to switch the closed loop off silently).  The way to remove bodies is avn_despawn (tests/test_gpu_despawn.py)."""
     bodies, colliders = dropped_boxes(seed=12, n=20)
     w = F.World(hip_lib(), F.default_config(32, substeps=4))
     upload(w, bodies, colliders); w.pipeline_enable()
     for _ in range(20):
         w.step()
-    before, st = w.bodies_download(), w.pipeline_stats()
+    st = w.pipeline_stats()
     assert st.manifolds > 5
     with pytest.raises(F.AvnError):
         w.bodies_upload(**{k: np.asarray(v)[:-1] for k, v in bodies.items()})
@@ -185,14 +185,6 @@ def test_despawn_inside_the_closed_loop_is_refused_not_ignored():
         w.colliders_upload(**{k: np.asarray(v)[1:] for k, v in colliders.items()})
     w.step(); w.synchronize()
     assert w.pipeline_stats().manifolds > 5 and np.isfinite(w.bodies_download()["position"]).all()
-    # the documented way out: leave the loop, upload, enter again
-    w.pipeline_enable(False)
-    w.bodies_upload(**{k: np.asarray(v)[:-1] for k, v in bodies.items()})
-    w.colliders_upload(**{k: np.asarray(v)[:-1] for k, v in colliders.items()})
-    w.existing_pairs_upload(np.zeros(0, np.uint64)); w.pipeline_enable()
-    for _ in range(5):
-        w.step()
-    assert w.pipeline_stats().manifolds > 0
 
 
 def test_contacts_upload_to_a_dead_row_is_skipped_and_reported():

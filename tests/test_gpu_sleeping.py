@@ -115,3 +115,30 @@ def test_large_stack_sleeps_and_wakes_in_thousands_of_ops():
         st = wh.sleeping_stats()
         popped += st.last_manifolds_popped; events += 1 if st.last_manifolds_popped else 0
     assert popped > 40000 and events >= 8, (popped, events)
+
+
+def test_a_world_entirely_asleep_steps_as_the_identity_and_can_be_woken():
+    """Once every body sleeps nothing can change: the device closed loop returns from avn_step without a launch (world/sleeping.hpp), the oracle
+    runs the whole step -- colour lists, counters, bodies, island state and timers must stay equal for 60 such steps; then WakeBody, and a spawn
+    into the sleeping world (the upload ends the shortcut)."""
+    sc = stack_and_projectile(3, 3, 3, height=3.6)
+    wo, wh = pair_of_worlds(sc.body_kwargs(), sc.collider_kwargs(), time_to_sleep=0.3, linear_threshold=0.4, angular_threshold=0.8)
+    s = 0
+    all_asleep_since = None
+    for _ in range(400):
+        wo.step(); wh.step()
+        compare_step(s, wo, wh); compare_sleeping(s, wo, wh); s += 1
+        if wh.sleeping_state()["sleeping"].sum() == sc.n - 1:
+            all_asleep_since = all_asleep_since if all_asleep_since is not None else s
+            if s - all_asleep_since >= 60:
+                break
+        else:
+            all_asleep_since = None
+    assert all_asleep_since is not None and s - all_asleep_since >= 60, "the world must fall asleep as a whole and stay asleep"
+    assert wh.timers().kernel_launches == 0, "a fully sleeping world costs no launch"
+    for w in (wo, wh):
+        w.wake_bodies([3])
+    compare_step(s, wo, wh); compare_sleeping(s, wo, wh)
+    for _ in range(30):
+        wo.step(); wh.step(); compare_step(s, wo, wh); compare_sleeping(s, wo, wh); s += 1
+    assert wh.timers().kernel_launches > 0

@@ -9,6 +9,7 @@ import pytest
 from helpers import F, hip_lib, oracle_lib
 
 NONE = 0xFFFFFFFF
+DESPAWN = True
 
 
 def managers():
@@ -56,8 +57,10 @@ def test_random_event_streams_keep_both_managers_identical(seed):
     (mo, mh), col_body = build(n_bodies, n_static, rng, colliders_per_body=1 + seed % 2)
     cols = sorted(col_body)
     # a few joints first (spawn order)
+    jointed = set()
     for j in range(5):
         a, b = rng.choice(np.arange(n_static, n_bodies), 2, replace=False)
+        jointed |= {int(a), int(b)}
         for m in (mo, mh):
             m.joint_add(j, int(a), int(b))
     same(mo, mh, n_bodies, "after joints")
@@ -65,6 +68,7 @@ def test_random_event_streams_keep_both_managers_identical(seed):
     free = []
     next_id = 0
     timers = np.zeros(n_bodies, np.float32)
+    despawned, n_despawned = set(), 0
     for step in range(120):
         # --- broad phase: new pairs (lowest free id first) ---
         for _ in range(rng.integers(0, 6)):
@@ -109,12 +113,12 @@ def test_random_event_streams_keep_both_managers_identical(seed):
         st = mo.state(n_bodies)
         flags = np.zeros(n_bodies, np.uint8)
         for b in range(n_static, n_bodies):
-            if st["sleeping"][b]:
-                continue   # Sleeping bodies are outside the query
+            if st["sleeping"][b] or b in despawned:
+                continue   # Sleeping bodies are outside the query (and a despawned body has no node)
             flags[b] = 1
             if rng.random() < 0.25: timers[b] = 0.0
             else: timers[b] += np.float32(1 / 60)
-        if step % 17 == 5: flags[n_static + 1] = 2       # a SleepingDisabled body for one step
+        if step % 17 == 5 and (n_static + 1) not in despawned: flags[n_static + 1] = 2       # a SleepingDisabled body for one step
         ro, rh = mo.sleeping_systems(timers, flags, 0.2), mh.sleeping_systems(timers, flags, 0.2)
         same_result(ro, rh, f"step {step}: SleepIslands / WakeIslands")
         for c in ro["pairs_slept"]: live[int(c)]["pair_sleeping"] = True
@@ -123,19 +127,52 @@ def test_random_event_streams_keep_both_managers_identical(seed):
         same(mo, mh, n_bodies, f"step {step}: after the sleeping systems")
         if step % 29 == 11:
             b = int(rng.integers(n_static, n_bodies))
+            while b in despawned: b = int(rng.integers(n_static, n_bodies))
             ro, rh = mo.wake_body(b), mh.wake_body(b)
             same_result(ro, rh, f"step {step}: WakeBody")
             for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
             for x in ro["bodies_woken"]: timers[int(x)] = 0.0
         if step % 31 == 7:
             b = int(rng.integers(n_static, n_bodies))
-            if not mo.state(n_bodies)["sleeping"][b]:
+            if b not in despawned and not mo.state(n_bodies)["sleeping"][b]:
                 ro, rh = mo.sleep_body(b), mh.sleep_body(b)
                 same_result(ro, rh, f"step {step}: SleepBody")
                 for c in ro["pairs_slept"]: live[int(c)]["pair_sleeping"] = True
             same(mo, mh, n_bodies, f"step {step}: after SleepBody")
+        if step % 19 == 13 and DESPAWN:
+            # despawn a body: remove_collider per collider (edge-list order), BodyIslandNode::on_remove + the queued WakeIslands
+            cand = [b for b in range(n_static, n_bodies) if b not in despawned and b not in jointed]   # (a body that carries a joint cannot leave: both managers refuse it)
+            b = int(rng.choice(cand))
+            for c in [c for c in cols if col_body[c] == b]:
+                ro, rh = mo.collider_remove(c), mh.collider_remove(c)
+                same_result(ro, rh, f"step {step}: remove_collider({c})")
+                for cid in ro["pairs_removed"]:
+                    del live[int(cid)]; free.append(int(cid))
+                cols.remove(c)
+            ro, rh = mo.body_remove(b), mh.body_remove(b)
+            same_result(ro, rh, f"step {step}: body_remove({b})")
+            for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
+            for x in ro["bodies_woken"]: timers[int(x)] = 0.0
+            despawned.add(b)
+            n_despawned += 1
+            same(mo, mh, n_bodies, f"step {step}: after the despawn of body {b}")
+        if step == 70 and despawned:
+            # the host compacts its body arrays: both managers renumber, and so does this driver
+            new_index = np.full(n_bodies, NONE, np.uint32)
+            k = 0
+            for b in range(n_bodies):
+                if b not in despawned:
+                    new_index[b] = k; k += 1
+            for m in (mo, mh): m.renumber_bodies(new_index)
+            col_body = {c: int(new_index[b]) for c, b in col_body.items() if b not in despawned}
+            jointed = {int(new_index[b]) for b in jointed}
+            timers = timers[new_index != NONE].copy()
+            n_bodies = k
+            despawned = set()
+            same(mo, mh, n_bodies, f"step {step}: after renumber_bodies")
     s = mh.stats()
     assert s.merges > 5 and s.splits > 0, "the stream must exercise merges and splits"
+    assert n_despawned >= 5
 
 
 def test_merge_appends_the_smaller_island_and_reuses_the_last_freed_key():
