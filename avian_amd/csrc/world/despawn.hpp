@@ -88,6 +88,7 @@
         for (auto& v : in_of) std::sort(v.begin(), v.end(), newest_first);
         // ---- walk the units in order; pops accumulate into one op batch until a WakeIslands with an effect has to run in between ----
         std::vector<uint8_t> edge_done(recs.size(), 0);
+        std::unordered_map<uint32_t, uint32_t> rec_of;   // contact id -> record (built when a wake makes it necessary)
         std::vector<uint32_t> pops, removed;
         double host_ms = 0;
         auto flush_pops = [&]() -> avn_status {
@@ -123,6 +124,10 @@
                 if ((st = isl.wake_island(island)) != AVN_OK) return slp_fail(st);   // the queued WakeIslands([island]): a no-op unless it sleeps
                 if (!isl.pushed().empty() || !isl.bodies_woken().empty() || !isl.pairs_woken().empty()) {
                     if ((st = flush_pops()) != AVN_OK) return st;
+                    // (the woken island's pairs are back in the ConstraintGraph: an edge record collected before the wake that belongs to a LATER
+                    //  unit of this despawn has a handle now -- its pop reads the colour on the device, the record only says "pop me")
+                    if (rec_of.empty()) for (uint32_t k = 0; k < recs.size(); ++k) rec_of.emplace(recs[k].cid, k);
+                    for (uint32_t cid : isl.pushed()) { auto it = rec_of.find(cid); if (it != rec_of.end()) recs[it->second].color = 0u; }
                     if ((st = sleeping_apply_result(false, host_ms)) != AVN_OK) return st;
                 }
             }

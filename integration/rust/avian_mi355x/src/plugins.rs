@@ -133,8 +133,19 @@ fn gpu_upload_bodies(
     mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
     increments: Query<&VelocityIntegrationData>,
     colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
+    mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
 ) {
     let st = &mut st.0;
+    // Despawns since the last step, in the order Bevy reports the removals (= the order Avian's own observers ran in).  The staging still holds
+    // LAST frame's numbering here: body index = position in `body_entities` (sorted by Entity, so dropping entries is the stable compaction
+    // avn_despawn renumbers by), collider = Entity::index().  In the device closed loop the library removes them from its ContactGraph /
+    // ConstraintGraph / islands without restarting the loop (round 4; it used to be avn_pipeline_enable(0 / 1): a step without warm starting).
+    let gone_bodies: Vec<u32> = removed_bodies.read().filter_map(|e| st.body_index.get(&e).map(|&i| i as u32)).collect();
+    let gone_of_bodies: std::collections::HashSet<u32> = gone_bodies.iter().copied().collect();
+    let gone_colliders: Vec<u32> = removed_colliders.read()
+        .filter(|e| st.collider_slot.get(&e.index()).is_some_and(|&s| !gone_of_bodies.contains(&(st.c_body[s] as u32))))   // (a body's own colliders leave with it)
+        .map(|e| e.index()).collect();
+    w.despawn(&gone_bodies, &gone_colliders);
     st.fill_bodies(bodies.iter(), |e| increments.get(e).map_or((Vec3::ZERO, Vec3::ZERO), |v| (v.linear_increment(), v.angular_increment())));
     st.fill_colliders(colliders.iter());
     let (b, c) = (st.bodies_desc(), st.colliders_desc());

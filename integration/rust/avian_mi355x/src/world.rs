@@ -83,6 +83,22 @@ impl Mi355xWorld {
         self.closed_loop = on;
     }
 
+    /// Entities that left the world since the last step, inside the closed loop (`avn_despawn`): what Avian's `remove_body_on` /
+    /// `remove_collider_on` observers do to its own ContactGraph / ConstraintGraph / PhysicsIslands (src/collision/narrow_phase/mod.rs:399-560)
+    /// happens to the device's -- pops in edge-list order, ContactIds back into the IdPool, the bodies' island nodes unlinked -- and the library
+    /// renumbers the remaining bodies by stable compaction.  The caller uploads the remaining bodies and colliders next (same call order as
+    /// every frame: `avn_bodies_upload`, `avn_colliders_upload`).  A no-op outside the closed loop (the graphs are Avian's own there).
+    pub fn despawn(&mut self, bodies: &[u32], collider_entities: &[u32]) {
+        if !self.closed_loop || (bodies.is_empty() && collider_entities.is_empty()) { return; }
+        let d = ffi::avn_despawn_list {
+            struct_size: core::mem::size_of::<ffi::avn_despawn_list>() as u32,
+            n_colliders: collider_entities.len() as u32, collider_entities: if collider_entities.is_empty() { core::ptr::null() } else { collider_entities.as_ptr() },
+            n_bodies: bodies.len() as u32, bodies: if bodies.is_empty() { core::ptr::null() } else { bodies.as_ptr() },
+        };
+        let st = unsafe { ffi::avn_despawn(self.raw, &d) };
+        self.check(st);
+    }
+
     /// Persistent islands + sleeping inside the closed loop (`avn_sleeping_enable`): the library keeps its own island manager and actuates
     /// sleeping on the device; `None` switches it off again.
     pub fn set_sleeping(&mut self, params: Option<ffi::avn_sleep_params>) {

@@ -139,6 +139,7 @@ def test_a_world_entirely_asleep_steps_as_the_identity_and_can_be_woken():
     for w in (wo, wh):
         w.wake_bodies([3])
     compare_step(s, wo, wh); compare_sleeping(s, wo, wh)
-    for _ in range(30):
+    for k in range(30):
         wo.step(); wh.step(); compare_step(s, wo, wh); compare_sleeping(s, wo, wh); s += 1
-    assert wh.timers().kernel_launches > 0
+        if k == 0:
+            assert wh.timers().kernel_launches > 0, "WakeBody ends the shortcut"
