@@ -231,8 +231,7 @@ uint32_t pg_scan_tiles(uint32_t n_entries);
 void launch_pg_entry_scan(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
 void launch_pg_color(const PG&, uint32_t n_ops, hipStream_t);
 void launch_pg_apply_masks(const PG&, const uint32_t* keys, const uint32_t* vals, uint32_t n_entries, uint32_t n_bodies, hipStream_t);
-void launch_pg_bucket_keys(const PG&, uint32_t n_ops, hipStream_t);
-void launch_pg_replay(const PG&, const uint32_t* order, uint32_t n_ops, hipStream_t);
+void launch_pg_replay(const PG&, uint32_t n_ops, hipStream_t);   // stable partition of the ops by colour + the exact push / swap_remove replay of every colour
 template <class T> void launch_pg_remove(const PG&, const CT<T>&, const BP<T>&, uint32_t n_ops, hipStream_t);
 void launch_pg_merge_free(const PG&, uint32_t head, uint32_t n_free, uint32_t n_rem, hipStream_t);
 void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t);

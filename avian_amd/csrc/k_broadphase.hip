@@ -289,8 +289,12 @@ uint32_t scan_block_sums_needed(uint32_t n) { return 2u * ((n + SC_TILE - 1) / S
 template <class T>
 __global__ __launch_bounds__(256) void k_gather_sorted(DW<T> w, BP<T> bp, const uint32_t* __restrict__ sorted_collider, uint32_t n) {
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    uint32_t c = sorted_collider[i];
+    const bool live = i < n;
+    // (no early return: every lane takes part in the shuffles of the batch-cull bounds at the end; lanes past n contribute neutral boxes)
+    uint32_t c = live ? sorted_collider[i] : 0u;
+    T by_lo = Limits<T>::max * T(2), by_hi = -(Limits<T>::max * T(2)), bz_lo = by_lo, bz_hi = by_hi;
+    bool bnan = false;
+    if (live) {
     bp.iv_collider[i] = c;  // the persistent interval order for the next frame
     uint4 ci = bp.col_info[c];
     uint2 layers = bp.col_layers[c];
@@ -319,6 +323,28 @@ __global__ __launch_bounds__(256) void k_gather_sorted(DW<T> w, BP<T> bp, const 
     bp.s_yz[i] = make4<T>(mn.y, mx.y, mn.z, mx.z);
     bp.s_info[i] = make_uint4(ci.x, ci.y, layers.x, layers.y);
     bp.s_flags[i] = f;
+    by_lo = mn.y; by_hi = mx.y; bz_lo = mn.z; bz_hi = mx.z;
+    bnan = (mn.y != mn.y) | (mx.y != mx.y) | (mn.z != mn.z) | (mx.z != mx.z);
+    }
+    // the sweep's batch cull (see "Batch cull" below; round 4: was its own kernel, k_batch_bounds, reading s_yz back): the y / z bounds of every 8
+    // and of every 64 consecutive sorted records, reduced across the lanes that just wrote them.  A workgroup starts on a multiple of 256
+    // records, so octets and waves are aligned with the groups.  Conservative as before: a NaN anywhere in a group disables the cull for it.
+    const T inf = Limits<T>::max * T(2);
+    uint32_t nn = bnan ? 1u : 0u;
+#pragma unroll
+    for (int off = 1; off < 8; off <<= 1) {
+        const T a = __shfl_xor(by_lo, off), b = __shfl_xor(by_hi, off), cc = __shfl_xor(bz_lo, off), d = __shfl_xor(bz_hi, off);
+        nn |= (uint32_t)__shfl_xor((int)nn, off);
+        by_lo = a < by_lo ? a : by_lo; by_hi = b > by_hi ? b : by_hi; bz_lo = cc < bz_lo ? cc : bz_lo; bz_hi = d > bz_hi ? d : bz_hi;
+    }
+    if (live && (i & 7u) == 0u) bp.s_bb[i >> 3] = nn ? make4<T>(-inf, inf, -inf, inf) : make4<T>(by_lo, by_hi, bz_lo, bz_hi);
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+        const T a = __shfl_xor(by_lo, off), b = __shfl_xor(by_hi, off), cc = __shfl_xor(bz_lo, off), d = __shfl_xor(bz_hi, off);
+        nn |= (uint32_t)__shfl_xor((int)nn, off);
+        by_lo = a < by_lo ? a : by_lo; by_hi = b > by_hi ? b : by_hi; bz_lo = cc < bz_lo ? cc : bz_lo; bz_hi = d > bz_hi ? d : bz_hi;
+    }
+    if (live && (i & 63u) == 0u) bp.s_bb2[i >> 6] = nn ? make4<T>(-inf, inf, -inf, inf) : make4<T>(by_lo, by_hi, bz_lo, bz_hi);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -441,7 +467,7 @@ __device__ __forceinline__ avn_pair make_pair(uint4 in1, uint32_t f1, uint4 in2,
     return pr;
 }
 
-#define SW_BB_GROUP 8u   // sorted records per bounds group (k_batch_bounds, the sweep's `j / SW_BB_GROUP`, the host's s_bb sizing)
+#define SW_BB_GROUP 8u   // sorted records per bounds group (written by k_gather_sorted; the sweep's `j / SW_BB_GROUP`, the host's s_bb sizing)
 // Batch cull of the sweep: the y/z bounds of every group of 8 consecutive sorted records.  A wave tests its 64 boxes against a
 // group's bounds before it loads the group's records; on a lattice consecutive records share a y row, so most groups of the
 // ~6 000 x-overlapping candidates of an interval are rejected with 4 compares instead of 32.  Conservative by construction
@@ -455,33 +481,7 @@ uint32_t sweep_bounds_group() { return SW_BB_GROUP; }
 #define SW_BB2_GROUP 64u
 uint32_t sweep_bounds_words(uint32_t n_records) { return n_records / SW_BB_GROUP + 2u + n_records / SW_BB2_GROUP + 2u; }   // Vec4 records of both levels
 uint32_t sweep_bounds_level2_offset(uint32_t n_records) { return n_records / SW_BB_GROUP + 2u; }
-template <class T>
-__global__ __launch_bounds__(256) void k_batch_bounds(const Vec4<T>* __restrict__ s_yz, uint32_t n, Vec4<T>* __restrict__ s_bb, Vec4<T>* __restrict__ s_bb2) {
-    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
-    const bool live = (size_t)g * SW_BB_GROUP < n;
-    const T inf = Limits<T>::max * T(2);
-    T lo_y = inf, hi_y = -inf, lo_z = inf, hi_z = -inf;
-    bool nan = false;
-    if (live)
-        for (uint32_t k = 0; k < 8u; ++k) {
-            const uint32_t idx = g * SW_BB_GROUP + k;
-            if (idx >= n) break;
-            const Vec4<T> r = s_yz[idx];
-            nan |= (r.x != r.x) | (r.y != r.y) | (r.z != r.z) | (r.w != r.w);
-            lo_y = r.x < lo_y ? r.x : lo_y; hi_y = r.y > hi_y ? r.y : hi_y;
-            lo_z = r.z < lo_z ? r.z : lo_z; hi_z = r.w > hi_z ? r.w : hi_z;
-        }
-    if (live) s_bb[g] = nan ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
-    // level two: the eight groups of lanes 8 k .. 8 k + 7 (a workgroup starts on a multiple of 256 groups: the octets are aligned)
-    uint32_t nn = nan ? 1u : 0u;
-#pragma unroll
-    for (int off = 1; off < 8; off <<= 1) {
-        const T a = __shfl_xor(lo_y, off), b = __shfl_xor(hi_y, off), c = __shfl_xor(lo_z, off), d = __shfl_xor(hi_z, off);
-        nn |= (uint32_t)__shfl_xor((int)nn, off);
-        lo_y = a < lo_y ? a : lo_y; hi_y = b > hi_y ? b : hi_y; lo_z = c < lo_z ? c : lo_z; hi_z = d > hi_z ? d : hi_z;
-    }
-    if (live && (g & 7u) == 0u) s_bb2[g >> 3] = nn ? make4<T>(-inf, inf, -inf, inf) : make4<T>(lo_y, hi_y, lo_z, hi_z);
-}
+static_assert(SW_BB_GROUP == 8u && SW_BB2_GROUP == 64u, "k_gather_sorted reduces the cull bounds over octets and whole waves");
 
 // end(i) = first j > i with min_x[j] > max_x[i]; long intervals are cut into LongItems.
 // "Long" is absolute (more than SW_CAP candidates) or RELATIVE: a wave of k_sweep walks the union of its 64 lanes' candidate
@@ -747,16 +747,27 @@ __global__ __launch_bounds__(SW_THREADS) void k_sweep_long(const Vec4<T>* __rest
     }
 }
 
-// per long interval: chunk counts -> in-interval chunk offsets, and the interval's total into counts[i]
+// per long interval: chunk counts -> in-interval chunk offsets, and the interval's total into counts[i].  One WAVE per interval (round 4: one
+// lane walked cfg2's ground -- 196 chunks of 512 candidates -- load by dependent load, 30 us on the broad phase's chain): 64 chunks per
+// round, a wave scan, the running total carried in a register.
 __global__ __launch_bounds__(256) void k_long_finish(const LongItem* __restrict__ items, const uint32_t* __restrict__ n_long, const uint32_t* __restrict__ long_counts,
                                                       uint32_t* __restrict__ long_off, uint32_t* __restrict__ counts) {
-    uint32_t nl = n_long[1] ? 0u : *n_long;
-    for (uint32_t k = blockIdx.x * 256 + threadIdx.x; k < nl; k += gridDim.x * 256) {
-        LongItem it = items[k];
+    const uint32_t nl = n_long[1] ? 0u : *n_long;
+    const uint32_t lane = threadIdx.x & 63u, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+    for (uint32_t k = wave; k < nl; k += n_waves) {   // (wave-uniform)
+        const LongItem it = items[k];
         if (!it.n_chunks) continue;
         uint32_t run = 0;
-        for (uint32_t c = 0; c < it.n_chunks; ++c) { long_off[k + c] = run; run += long_counts[k + c]; }
-        counts[it.i * SW_WAVES] = run;
+        for (uint32_t c0 = 0; c0 < it.n_chunks; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            const uint32_t v = c < it.n_chunks ? long_counts[k + c] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) { const uint32_t u = (uint32_t)__shfl_up((int)incl, off); if ((int)lane >= off) incl += u; }
+            if (c < it.n_chunks) long_off[k + c] = run + incl - v;
+            run += (uint32_t)__shfl((int)incl, 63);
+        }
+        if (lane == 0) counts[it.i * SW_WAVES] = run;
     }
 }
 
@@ -986,7 +997,6 @@ template <class T> void launch_gather_sorted(const DW<T>& w, const BP<T>& bp, co
 template <class T> void launch_sweep_ranges(const BP<T>& bp, uint32_t n, const SweepScratch& sc, hipStream_t s, bool counters_clean) {
     if (!n) return;
     if (!counters_clean) (void)hipMemsetAsync(sc.n_long, 0, 2 * sizeof(uint32_t), s);  // [n_long, overflow]
-    hipLaunchKernelGGL(k_batch_bounds<T>, dim3((n / SW_BB_GROUP + 256u) / 256u), dim3(256), 0, s, bp.s_yz, n, bp.s_bb, bp.s_bb2);
     hipLaunchKernelGGL(k_sweep_ranges<T>, dim3((n + 255) / 256), dim3(256), 0, s, n, bp.s_minx, bp.s_maxx, bp.s_end, bp.s_flags, (LongItem*)sc.long_items,
                        sc.n_long, sc.long_cap, sc.n_long + 1);
 }

@@ -381,23 +381,6 @@ void launch_pg_apply_masks(const PG& pg, const uint32_t* keys, const uint32_t* v
 }
 
 // ---- per-colour op sequences + exact replay of push / swap_remove ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_pg_bucket_keys(PG pg, uint32_t n_ops) {
-    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= n_ops) return;
-    const uint32_t info = pg.op_info[k];
-    pg.ckey_a[k] = (info & 3u) == PG_KIND_NONE ? (uint32_t)AVN_GRAPH_COLOR_COUNT : ((info >> 8) & 0xFFu);
-    pg.cval_a[k] = k;
-}
-void launch_pg_bucket_keys(const PG& pg, uint32_t n_ops, hipStream_t s) {
-    if (n_ops) hipLaunchKernelGGL(k_pg_bucket_keys, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, n_ops);
-}
-// rx[i] = contact id of the i-th op of the colour-bucketed sequence | push << 31 (one contiguous stream for k_pg_replay)
-__global__ __launch_bounds__(256) void k_pg_replay_gather(PG pg, const uint32_t* __restrict__ order, uint32_t* __restrict__ rx, uint32_t n_ops) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n_ops) return;
-    const uint32_t k = order[i];
-    rx[i] = pg.op_cid[k] | ((pg.op_info[k] & 3u) == PG_KIND_PUSH ? 0x80000000u : 0u);
-}
 // One wave per colour.  See tools/experiments/replay_batches.py for the rule: with h_t the list length before op t of a batch,
 // a push writes position h_t and a pop vacates position h_t - 1 (its content fills the hole the popped handle leaves).  While
 // every pop's handle sits BELOW the lowest position the batch's pushes / vacates touch, holes and moving tail never meet: the
@@ -725,8 +708,33 @@ __global__ __launch_bounds__(RW_B) void k_pg_replay_wide(PG pg, const uint32_t* 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (tid == 0) { pg.ctr[PGC_LEN + c] = L; pg.ctr[PGC_DBG + c] = dbg_iter; pg.ctr[PGC_DBG + 24 + c] = dbg_serial; pg.ctr[PGC_DBG + 48 + c] = dbg_cut; pg.ctr[PGC_DBG + 72 + c] = b1 - b0; }
 }
-void launch_pg_replay(const PG& pg, const uint32_t* order, uint32_t n_ops, hipStream_t s) {
-    if (n_ops) hipLaunchKernelGGL(k_pg_replay_gather, dim3((n_ops + 255) / 256), dim3(256), 0, s, pg, order, pg.ekey_a, n_ops);   // (ekey_a: the colouring's entry buffers are free again)
+// The ops of every colour, in op order, as one contiguous stream per colour (rx[b0 .. b1) with b0 = the bucket counts before the colour): a stable
+// partition by colour in ONE launch (round 4: was k_pg_bucket_keys + a radix pass (histogram, scatter) + k_pg_replay_gather).  One workgroup
+// per colour walks the ops 1 024 at a time and keeps its own: ballot ranks inside a wave, wave totals through LDS, a running count.
+__global__ __launch_bounds__(1024) void k_pg_partition_colors(PG pg, uint32_t* __restrict__ rx, uint32_t n_ops) {
+    __shared__ uint32_t s_w[16];
+    const uint32_t c = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < c; ++i) run += pg.ctr[PGC_BUCKET + i];
+    for (uint32_t k0 = 0; k0 < n_ops; k0 += 1024u) {
+        const uint32_t k = k0 + tid;
+        uint32_t info = 0;
+        if (k < n_ops) info = pg.op_info[k];
+        const uint32_t kind = info & 3u;
+        const bool mine = kind != PG_KIND_NONE && ((info >> 8) & 0xFFu) == c;
+        const unsigned long long m = __ballot(mine);
+        if (lane == 0) s_w[wv] = (uint32_t)__popcll(m);
+        __syncthreads();
+        uint32_t before = 0, all = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < 16u; ++w) { const uint32_t v = s_w[w]; if (w < wv) before += v; all += v; }
+        if (mine) rx[run + before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pg.op_cid[k] | (kind == PG_KIND_PUSH ? 0x80000000u : 0u);
+        run += all;
+        __syncthreads();
+    }
+}
+void launch_pg_replay(const PG& pg, uint32_t n_ops, hipStream_t s) {
+    if (n_ops) hipLaunchKernelGGL(k_pg_partition_colors, dim3(AVN_GRAPH_COLOR_COUNT), dim3(1024), 0, s, pg, pg.ekey_a, n_ops);   // (ekey_a: the colouring's entry buffers are free again)
     static const bool wave_version = getenv("AVN_PG_REPLAY_WAVE") && getenv("AVN_PG_REPLAY_WAVE")[0] && getenv("AVN_PG_REPLAY_WAVE")[0] != '0';   // (A/B runs)
     if (wave_version) hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, pg.ekey_a);
     else hipLaunchKernelGGL(k_pg_replay_wide, dim3(AVN_GRAPH_COLOR_COUNT), dim3(RW_B), 0, s, pg, pg.ekey_a);

@@ -48,7 +48,7 @@
         launch_sweep_ranges<T>(bp, n, sweep_scratch, bs, clean);
         launch_sweep<T>(bp, n, false, sweep_scratch, b_counts.as<uint32_t>(), nullptr, nullptr, bs);
         launch_exclusive_scan(b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), n * sweep_count_slots(), b_block_sums.as<uint32_t>(), d_total, bs);
-        launches += 3 + radix_sort_launches(n, (uint32_t)sizeof(Key)) + 4 + exclusive_scan_launches(n * sweep_count_slots());
+        launches += 3 + radix_sort_launches(n, (uint32_t)sizeof(Key)) + 3 + exclusive_scan_launches(n * sweep_count_slots());
         HIPCHK(hipGetLastError());
         HIPCHK(hipMemcpyAsync(h_counters, d_dropped, 5 * sizeof(uint32_t), hipMemcpyDeviceToHost, bs));
         HIPCHK(hipEventRecord(ev_counters, bs));

@@ -208,11 +208,8 @@
             launch_pg_entry_scan(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
             launch_pg_color(pg, n_ops, stream);
             launch_pg_apply_masks(pg, ek, evv, 2 * n_ops, dw.n_bodies, stream);
-            launch_pg_bucket_keys(pg, n_ops, stream);
-            uint32_t *ck, *order;
-            launch_radix_sort_bits(pg.ckey_a, pg.cval_a, pg.ckey_b, pg.cval_b, n_ops, 5, b_pg_hist.as<uint32_t>(), b_pg_sums.as<uint32_t>(), &ck, &order, stream);
-            launch_pg_replay(pg, order, n_ops, stream);
-            launches += 7 + ((bits_for(dw.n_bodies) + 7) / 8 + 1) * radix_pass_launches(2 * n_ops);
+            launch_pg_replay(pg, n_ops, stream);
+            launches += 6 + ((bits_for(dw.n_bodies) + 7) / 8) * radix_pass_launches(2 * n_ops);
             if (n_rem) {   // ContactGraph::remove_edge_by_id + IdPool::free_id
                 launch_exclusive_scan(pg.rem_flag, pg.rem_off, n_ops, b_pg_sums.as<uint32_t>(), nullptr, stream);
                 launch_pg_remove<T>(pg, ct, bp, n_ops, stream);
@@ -239,6 +236,7 @@
             }
             if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
                 std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
+                const uint32_t* order = pg.ekey_a;   // (the colour-partitioned op stream of the replay: contact id | push << 31)
                 std::vector<int2> bd(n_ops);
                 HIPCHK(hipMemcpy(a.data(), pg.op_cid, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
                 HIPCHK(hipMemcpy(b.data(), pg.op_info, (size_t)n_ops * 4, hipMemcpyDeviceToHost));
