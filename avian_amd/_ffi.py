@@ -8,6 +8,7 @@ any other implementation lives.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional
 
 import numpy as np
@@ -269,9 +270,12 @@ class Library:
         self.prefix = prefix
         self.dll = C.CDLL(path)
         missing = [s for s in ABI_SYMBOLS if not hasattr(self.dll, prefix + s)]
-        if missing:
+        if missing and not os.environ.get("AVN_AB_OLDER_LIBRARY"):
             raise ImportError(f"{path}: missing ABI symbols {missing}")
-        f = self.fn
+        # (AVN_AB_OLDER_LIBRARY=1 with AVN_LIB_PATH: an A/B run against an OLDER build of the library, whose ABI lacks the newest entry points)
+        class _Absent:
+            argtypes = None; restype = None
+        f = (lambda name: self.fn(name) if hasattr(self.dll, prefix + name) else _Absent()) if missing else self.fn
         f("world_create").argtypes = [C.POINTER(avn_config), C.POINTER(vp)]
         f("world_destroy").argtypes = [vp]
         f("world_destroy").restype = None

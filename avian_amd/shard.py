@@ -13,6 +13,7 @@ what makes the stable SAP sort, the pair emission order and the persistent colou
 """
 from __future__ import annotations
 
+import heapq
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -532,3 +533,172 @@ def level2_solver(world, rank: Level2Rank, substeps: int, exchange, restitution:
         level2_pass(world, rank, "SOLVE_RESTITUTION", exchange)
     world.run_system("WRITEBACK_SOLVER_BODIES")
     world.run_system("STORE_CONTACT_IMPULSES")
+
+
+# ---- the closed loop sharded by islands: replicated integer bookkeeping, sharded physics (round 4) -------------------------------------
+class ShardedClosedLoop:
+    """One rank of a closed loop whose ISLANDS are spread over ranks and whose results equal the single world's bit for bit.
+
+    Why the integer bookkeeping cannot be per rank: ``IdPool`` hands out the LOWEST free ContactId
+    (data_structures/id_pool.rs:31-40) in the broad phase's global emission order, the status loop walks changes in ascending id
+    (collision/narrow_phase/system_param.rs:141-145), and ``pop_manifold``'s ``swap_remove`` moves the LAST handle of a colour's list into the
+    hole (dynamics/solver/constraint_graph.rs:245-296) -- an island's colours and the order of its overflow manifolds depend on what OTHER
+    islands freed and popped.  So every rank replays EVERYTHING that is integer -- the global interval order (a stable sort of all colliders'
+    min.x keys), the ContactIds, the ConstraintGraph with all colour lists -- from three small all-gathers per step (4 bytes per collider,
+    20 bytes per new pair, 16 bytes per status change), and runs only its own islands' physics: broad phase, narrow phase and solver of its
+    sub-world through the low-level ABI.  Its handle lists are the global colour lists restricted to its own pairs (a restriction keeps the
+    relative order, which is all the overflow colour's serial solve needs).
+
+    A step is three phases with an exchange after the first two: ``phase1() -> payload``, ``phase2(all payloads) -> payload``,
+    ``phase3(all payloads)``; ``step(all_gather)`` runs them over a communicator (``all_gather(obj) -> list of every rank's obj``).
+    Bodies of different ranks must not come into AABB contact (the level-1 re-partition handles that: ``exchange_bounds`` / ``repartition``).
+    """
+
+    def __init__(self, lib: F.Library, world: F.World, p: ShardPlan, rank: int, colliders: Dict[str, np.ndarray], rb_type: np.ndarray):
+        self.lib, self.w, self.plan, self.rank = lib, world, p, rank
+        self.loc = p.local_bodies(rank)                    # local body -> global body
+        ent = np.asarray(colliders["entity_index"], np.uint32)
+        body = np.asarray(colliders["body"])
+        self.n_colliders = len(ent)
+        self.global_of_entity = {int(e): i for i, e in enumerate(ent)}    # global collider slot (upload order) of an entity
+        # every collider's min.x key is contributed by ONE rank: its body's owner, static bodies by rank 0
+        owner = p.rank_of_body[body]
+        self.my_colliders = np.flatnonzero((owner == rank) | ((owner < 0) & (rank == 0)))
+        loc_ent = ent[np.flatnonzero((owner == rank) | (owner < 0))]      # the sub-world's colliders, in its upload order
+        self.local_slot_of_entity = {int(e): i for i, e in enumerate(loc_ent)}
+        self.entity = ent
+        self.order = np.arange(self.n_colliders)           # the global AabbIntervals order (broad_phase.rs:177-185), replicated
+        self.graph = F.ConstraintGraph(lib, len(rb_type))  # the global ConstraintGraph, replicated
+        self.free_ids: List[int] = []
+        self.next_id = 0
+        self.pairs: Dict[int, tuple] = {}                  # every rank's pairs: id -> (collider1, collider2, global body1, global body2, owner rank)
+        self.n_handles: Dict[int, int] = {}
+        self.active: List[int] = []                        # this rank's active pairs
+        self.stats = dict(pairs_added=0, pairs_removed=0, pushes=0, pops=0)
+
+    # -- phase 1: local AABBs + local broad phase ---------------------------------------------------------------------------------------
+    def phase1(self):
+        w = self.w
+        w.run_system("UPDATE_AABB")
+        w.run_system("COLLECT_COLLISION_PAIRS")
+        mn, _, _ = w.aabbs_download()
+        mine = self.my_colliders
+        keys = np.array([mn[self.local_slot_of_entity[int(self.entity[g])], 0] for g in mine], np.float64)
+        pr = w.pairs_get()
+        new = np.zeros(len(pr), [("c1", "<u4"), ("c2", "<u4"), ("b1", "<i8"), ("b2", "<i8"), ("flags", "<u4")])
+        new["c1"], new["c2"], new["flags"] = pr["collider1"], pr["collider2"], pr["flags"]
+        new["b1"], new["b2"] = self.loc[pr["body1"]], self.loc[pr["body2"]]
+        return dict(rank=self.rank, colliders=mine, keys=keys, pairs=new)
+
+    # -- phase 2: the global interval order, ids in the global emission order, the local narrow phase -------------------------------------
+    def phase2(self, payloads):
+        minx = np.zeros(self.n_colliders)
+        for pl in payloads:
+            minx[pl["colliders"]] = pl["keys"]
+        # sweep_and_prune's insertion sort (broad_phase.rs:373-387, 479-487) is a STABLE sort of last frame's order by this frame's min.x
+        self.order = self.order[np.argsort(minx[self.order], kind="stable")]
+        gpos = np.empty(self.n_colliders, np.int64)
+        gpos[self.order] = np.arange(self.n_colliders)
+        recs = []
+        for pl in payloads:
+            for q in pl["pairs"]:
+                recs.append((int(gpos[self.global_of_entity[int(q["c1"])]]), int(gpos[self.global_of_entity[int(q["c2"])]]), int(q["c1"]), int(q["c2"]), int(q["b1"]), int(q["b2"]),
+                             int(q["flags"]), pl["rank"]))
+        recs.sort(key=lambda r: (r[0], r[1]))   # pairs are emitted i-major over the sorted intervals, j ascending (broad_phase.rs:387-388)
+        ids, c1, c2, fl = [], [], [], []
+        for (p1, p2, a, b, gb1, gb2, flags, owner) in recs:
+            assert p1 < p2, "collider1 is the earlier interval"
+            cid = heapq.heappop(self.free_ids) if self.free_ids else self._fresh()
+            self.pairs[cid] = (a, b, gb1, gb2, owner)
+            self.n_handles[cid] = 0
+            if owner == self.rank:
+                ids.append(cid); c1.append(a); c2.append(b); fl.append(flags)
+        self.stats["pairs_added"] += len(recs)
+        if ids:
+            self.w.contact_pairs_add(np.asarray(ids, np.uint32), np.asarray(c1, np.uint32), np.asarray(c2, np.uint32), np.asarray(fl, np.uint32))
+            self.active.extend(ids)
+        self.w.active_pairs_set(np.asarray(self.active, np.uint32))
+        self.w.run_system("NARROW_PHASE")
+        return dict(rank=self.rank, changes=self.w.contact_changes_get().copy())
+
+    def _fresh(self):
+        i = self.next_id
+        self.next_id += 1
+        return i
+
+    # -- phase 3: every rank's status changes in ascending id on the replicated graph; the local handle lists; the local solver ------------
+    def phase3(self, payloads):
+        ch = np.concatenate([pl["changes"] for pl in payloads]) if payloads else np.zeros(0, F.CHANGE_DTYPE)
+        ch = ch[np.argsort(ch["contact_id"], kind="stable")]
+        removed, removed_local = [], []
+        for c in ch:
+            cid, flags, dcount, count = int(c["contact_id"]), int(c["flags"]), int(c["manifold_count_change"]), int(c["manifold_count"])
+            generates, touching = bool(flags & F.CP_GENERATE_CONSTRAINTS), bool(flags & F.CP_TOUCHING)
+            _, _, gb1, gb2, owner = self.pairs[cid]
+            def push(n):
+                for _ in range(n):
+                    col = self.graph.push(cid, gb1, gb2, bool(flags & F.CP_STATIC1), bool(flags & F.CP_STATIC2))
+                    assert col >= 0
+                    self.n_handles[cid] += 1; self.stats["pushes"] += 1
+            def pop(n):
+                for _ in range(n):
+                    self.graph.pop(cid); self.n_handles[cid] -= 1; self.stats["pops"] += 1
+            if flags & F.CP_DISJOINT_AABB:
+                if generates:
+                    pop(self.n_handles[cid])
+                removed.append(cid)
+                if owner == self.rank:
+                    removed_local.append(cid)
+            elif flags & F.CP_STARTED_TOUCHING:
+                if generates:
+                    push(count)
+            elif flags & F.CP_STOPPED_TOUCHING:
+                if generates and self.n_handles[cid]:
+                    pop(self.n_handles[cid])
+            elif touching and (flags & F.CP_STARTED_GENERATING_CONSTRAINTS):
+                push(count)
+            elif touching and generates and dcount > 0:
+                push(dcount)
+            elif touching and generates and dcount < 0:
+                pop(-dcount)
+        if removed_local:
+            self.w.contact_pairs_remove(np.asarray(removed_local, np.uint32))
+            gone = set(removed_local)
+            self.active = [a for a in self.active if a not in gone]
+            self.w.active_pairs_set(np.asarray(self.active, np.uint32))
+        for cid in removed:
+            del self.pairs[cid], self.n_handles[cid]
+            heapq.heappush(self.free_ids, cid)
+        self.stats["pairs_removed"] += len(removed)
+        # GraphColor::manifold_handles restricted to this rank's pairs, order kept
+        offsets, handles = self.graph.lists()
+        mine = np.fromiter((self.pairs[int(h)][4] == self.rank for h in handles), bool, len(handles))
+        loc_off = np.zeros(F.GRAPH_COLOR_COUNT + 1, np.uint32)
+        loc_off[1:] = np.cumsum([int(mine[offsets[c]:offsets[c + 1]].sum()) for c in range(F.GRAPH_COLOR_COUNT)])
+        self.w.manifold_handles_upload(loc_off, handles[mine].astype(np.uint32))
+        self.global_lists = (offsets, handles.astype(np.uint32))
+        self.w.run_system("SOLVER")
+        return len(ch)
+
+    def step(self, all_gather):
+        return self.phase3(all_gather(self.phase2(all_gather(self.phase1()))))
+
+
+def sharded_closed_loop_worlds(lib: F.Library, bits: int, bodies: Dict[str, np.ndarray], colliders: Dict[str, np.ndarray], p: ShardPlan, substeps: int = 4,
+                               friction: float = 0.5):
+    """The sub-worlds of every rank of ``p`` in ONE process (tests: two worlds on one device), each with its ShardedClosedLoop."""
+    out = []
+    for r in range(p.world_size):
+        b, loc, g2l = split_bodies(p, r, bodies)
+        c = split_colliders(g2l, colliders)
+        w = F.World(lib, F.default_config(bits, substeps=substeps))
+        w.bodies_upload(**b); w.colliders_upload(**c); w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=friction)
+        out.append((w, ShardedClosedLoop(lib, w, p, r, colliders, np.asarray(bodies["rb_type"])), loc))
+    return out
+
+
+def step_in_process(loops: List["ShardedClosedLoop"]):
+    """One step of every rank, the exchanges done by handing the payload lists around (no communicator: all ranks live in this process)."""
+    p1 = [l.phase1() for l in loops]
+    p2 = [l.phase2(p1) for l in loops]
+    return [l.phase3(p2) for l in loops]
