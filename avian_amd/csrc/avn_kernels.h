@@ -56,7 +56,12 @@ template <class T> void launch_writeback_solver_bodies(const DW<T>&, hipStream_t
 template <class T> void launch_xpbd_snapshot(const DW<T>&, hipStream_t);
 template <class T> void launch_xpbd_velocity_projection(const DW<T>&, const StepParams<T>&, hipStream_t);
 // k_contacts.hip
-template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t, bool count_clean = false /* *DW::constraint_count is known to be zero */);
+// the contact table as k_prepare_contact_constraints reads it in handle mode (manifold m <- row handles[m]); CT / BP are declared further down
+template <class T> struct RowsView {
+    const uint32_t* handles; const uint4* meta; const uint4* col_info; const Vec4<T>* n; const Vec4<T>* tv; const Vec4<T>* a1; const Vec4<T>* a2; const Vec4<T>* w; uint32_t cap;
+};
+template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t, bool count_clean = false /* *DW::constraint_count is known to be zero */,
+                                                           const RowsView<T>* rows = nullptr /* handle mode: read the ContactGraph side from the table (no k_gather_manifolds) */);
 template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
 // body-centric warm start over the incidence CSR (DW::inc_off / inc_ent), optionally preceded by integrate_velocities
 template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);

@@ -112,11 +112,25 @@ template <class T> __device__ __forceinline__ void apply_impulse(BodyRef<T>& b1,
 template <class T> __device__ __forceinline__ V3<T> velocity_at_point(const BodyRef<T>& b, V3<T> p) { return b.v + cross(b.om, p); }
 
 // ------------------------------------------------------------------------------------------------------
-template <class T>
-__global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, StepParams<T> p) {
+// ROWS (handle mode, round 4): the manifold's ContactGraph side is read straight from the contact table through GraphColor::manifold_handles
+// (plugin.rs:389-398) -- what k_gather_manifolds used to copy into the colour-major arrays first (64 us + 26 MB written and read back per
+// settled cfg2 step).  The headers the solve passes read every substep (m_bodies, m_n, m_tv, m_meta) are still laid out colour-major here;
+// the anchors / penetrations / warm-start impulses are only ever read by this kernel and are no longer copied.
+template <class T, bool ROWS>
+__global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, StepParams<T> p, RowsView<T> rv) {
     uint32_t m = blockIdx.x * 256 + threadIdx.x;
     bool generated = false;
     if (m < w.n_manifolds) {
+        uint32_t row = 0;
+        if (ROWS) {
+            row = rv.handles[m];
+            const uint4 meta = rv.meta[row];
+            const uint32_t npr = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
+            w.m_bodies[m] = make_int2((int)rv.col_info[meta.x].y, (int)rv.col_info[meta.y].y);
+            w.m_n[m] = rv.n[row];
+            w.m_tv[m] = rv.tv[row];
+            w.m_meta[m] = npr | (((meta.z & AVN_CP_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0u) << 8);
+        }
         uint32_t mm = w.m_meta[m];
         uint32_t np = mm & 7u, mflags = mm >> 8;
         int2 b = w.m_bodies[m];
@@ -157,7 +171,10 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
             // whole manifold instead of one per point iteration
             Vec4<T> pa1[AVN_MAX_MANIFOLD_POINTS], pa2[AVN_MAX_MANIFOLD_POINTS], pww[AVN_MAX_MANIFOLD_POINTS];
 #pragma unroll
-            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { uint32_t s = k * S + m; pa1[k] = w.mp_a1[s]; pa2[k] = w.mp_a2[s]; pww[k] = w.mp_w[s]; }
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                if (ROWS) { const size_t s = (size_t)k * rv.cap + row; pa1[k] = rv.a1[s]; pa2[k] = rv.a2[s]; pww[k] = rv.w[s]; }
+                else { uint32_t s = k * S + m; pa1[k] = w.mp_a1[s]; pa2[k] = w.mp_a2[s]; pww[k] = w.mp_w[s]; }
+            }
 #pragma unroll
             for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
                 if (k >= np) break;
@@ -817,9 +834,11 @@ __global__ __launch_bounds__(256) void k_store_contact_impulses(DW<T> w) {
 }
 
 // ---- launchers ------------------------------------------------------------------------------------------
-template <class T> void launch_prepare_contact_constraints(const DW<T>& w, const StepParams<T>& p, hipStream_t s, bool count_clean) {
+template <class T> void launch_prepare_contact_constraints(const DW<T>& w, const StepParams<T>& p, hipStream_t s, bool count_clean, const RowsView<T>* rows) {
     if (!count_clean) (void)hipMemsetAsync(w.constraint_count, 0, sizeof(uint32_t), s);
-    if (w.n_manifolds) hipLaunchKernelGGL(k_prepare_contact_constraints<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, p);
+    if (!w.n_manifolds) return;
+    if (rows) hipLaunchKernelGGL((k_prepare_contact_constraints<T, true>), dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, p, *rows);
+    else hipLaunchKernelGGL((k_prepare_contact_constraints<T, false>), dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w, p, RowsView<T>{});
 }
 template <class T> void launch_store_contact_impulses(const DW<T>& w, hipStream_t s) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_store_contact_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, s, w);
@@ -1006,7 +1025,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
 }
 
 #define INST(T)                                                                                             \
-    template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t, bool);   \
+    template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t, bool, const RowsView<T>*);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
     template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t, bool);                               \

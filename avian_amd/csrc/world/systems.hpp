@@ -7,10 +7,12 @@
     void prepare_joints() { if (dw.n_joints) { launch_prepare_joints<T>(dw, stream); ++launches; } }
     void prepare_contact_constraints() {
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
-        if (use_handles && dw.n_manifolds) { launch_gather_manifolds<T>(dw, bp, ct, b_handles.as<uint32_t>(), stream); ++launches; }
-        if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
-        launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean); ++launches;
+        // handle mode: the constraints are generated straight from the table rows the handles name (the kernel also lays out the headers the solve
+        // passes read); the overflow colour's CSR reads DW::m_bodies, so it follows
+        RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.n, ct.tv, ct.a1, ct.a2, ct.w, ct.cap};
+        launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean, use_handles ? &rv : nullptr); ++launches;
         constraint_count_clean = false;
+        if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
     }
     void store_contact_impulses() {
         launch_store_contact_impulses<T>(dw, stream); ++launches;

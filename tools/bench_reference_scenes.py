@@ -57,7 +57,9 @@ def main():
         results.append({"scene": name, "dynamic_bodies": n_dyn, "substeps": substeps, "steps": steps, "mi355x_ms_per_step": round(th * 1e3, 4),
                         "mi355x_substeps_per_s": round(substeps / th, 1), "cpu_oracle_1_thread_ms_per_step": round(to * 1e3, 3),
                         "cpu_oracle_substeps_per_s": round(substeps / to, 2),
-                        "cpu_oracle_threads": threads, "cpu_oracle_threaded_ms_per_step": round(tm_ * 1e3, 3), "cpu_oracle_threaded_substeps_per_s": round(substeps / tm_, 2), "bodies_bit_identical": bool(same), "manifolds": int(st.manifolds),
+                        "cpu_oracle_threads": threads, "cpu_oracle_threaded_ms_per_step": round(tm_ * 1e3, 3), "cpu_oracle_threaded_substeps_per_s": round(substeps / tm_, 2),
+                        "cpu_oracle_best_ms_per_step": round(min(to, tm_) * 1e3, 3), "cpu_oracle_best_is": "1 thread" if to <= tm_ else f"{threads} threads",
+                        "mi355x_over_cpu_best": round(min(to, tm_) / th, 1), "bodies_bit_identical": bool(same), "manifolds": int(st.manifolds),
                         "active_pairs": int(st.active_pairs), "host_cores": os.cpu_count(),
                         "island_blocks": int(tm.island_blocks), "kernel_launches_per_step": int(tm.kernel_launches),
                         "last_step_ms": {"broad_phase": round(tm.broad_phase_ms, 4), "prepare": round(tm.prepare_ms, 4), "substeps": round(tm.substeps_ms, 4),

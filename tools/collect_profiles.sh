@@ -17,6 +17,8 @@ cpf pmc_write_size_per_kernel.csv pmc_write_size_per_kernel.csv
 cpf closed_loop_breakdown.txt closed_loop_breakdown.txt
 cpf closed_loop_step110_timeline.txt closed_loop_step110_timeline.txt
 cpf closed_loop_switches_ab.txt closed_loop_switches_ab.txt
+cpf closed_loop_r3_vs_r4_same_box.txt closed_loop_r3_vs_r4_same_box.txt
+cpf sleeping_step230_timeline.txt sleeping_step230_timeline.txt
 cpf narrow_phase_cutoffs.txt narrow_phase_cutoffs.txt
 cpf pmc_narrow_phase.json pmc_narrow_phase.json
 cpf cfg5_percentiles.txt cfg5_percentiles.txt
