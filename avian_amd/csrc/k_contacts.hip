@@ -234,6 +234,11 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
 // whose j-th incident manifolds are neighbours in the colour-major arrays, so the record gathers of a wave coalesce; the
 // next entry's ten records are in flight while the current one is applied.  The lane first runs integrate_velocities
 // (the system that precedes warm start in the SubstepSchedule) on its body.
+// (Round 4, tried: a ring of 2 / 3 / 4 / 6 record sets in flight (all slots loaded up front, loads made unconditional so that the vmcnt
+//  bookkeeping stays exact -- checked in the ISA).  cfg2: 2 481 / 2 458 / 2 492 / 2 434 substeps/s against 2 494 for this form on the same box;
+//  the closed loop's launch stayed at 64-67 us.  So the launch is not a chain of round trips: frozen cfg2 fetches 86 MiB (its ~96 MB of
+//  records, nothing amplified) through one 16-byte record per lane and line -- the L1's tag rate -- and the closed loop, whose handle lists
+//  are in history order, pulls a whole line per 16-byte record of the colour-major SoA arrays (~8x its 67 MB).  Not kept.)
 #define WS_THREADS 64
 template <class T> struct WarmRecords { Vec4<T> h1, h0, pr[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS]; };
 template <class T> __device__ __forceinline__ void warm_fetch(const DW<T>& w, uint32_t ent, WarmRecords<T>& r) {
@@ -797,7 +802,10 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
 //  Round 3: fewer manifolds per wave (32 / 16 / 8 instead of 64), against the solves of lanes that become ready in different polling rounds
 //  running one after the other: cfg2's collapse window 7.00 -> 7.10 / 7.29 / 7.71 ms per step, the settled step 2.98 -> 2.95 (A/B on one box):
 //  more waves polling cost more than the serialisation.  Not kept.  Neither was touching a manifold's constraint records BEFORE its ticket
-//  wait (so that a hop would find them in L2): 7.22 -> 7.27 ms, nothing gained -- the hop is the sc1 gather and the in-lane chain.)
+//  wait (so that a hop would find them in L2): 7.22 -> 7.27 ms, nothing gained -- the hop is the sc1 gather and the in-lane chain.
+//  Round 4: the settled pile's ~350 overflow manifolds (40 us per pass) in ONE 512-lane workgroup with workgroup-scope fences and L2-served
+//  tickets instead of agent-scope accesses across XCDs: 40-49 us per pass, the same (A/B on one box, 3.049 vs 3.054 ms per step).  The pass is
+//  (chain depth) x (one manifold's solve latency: records + gathers + ~1 500 dependent issues + stores), not the hand-over distance.  Not kept.)
 // tickets and tile counters restart with every step.  A KERNEL, not hipMemsetAsync: inside the captured substep graph a memset node is
 // not reliably ordered against a synchronous (null-stream) hipMemcpy issued between replays on ROCm 7.2 (found by the closed-loop tests:
 // a whole step of wrong impulses after avn_pipeline_handles_get had copied with hipMemcpy); kernel nodes keep the chain.

@@ -9,6 +9,11 @@
         // GraphColor::manifold_handles indirection (plugin.rs:389-398): the colours' manifolds are fetched from the contact table
         // handle mode: the constraints are generated straight from the table rows the handles name (the kernel also lays out the headers the solve
         // passes read); the overflow colour's CSR reads DW::m_bodies, so it follows
+        // (Round 4, tried: m_bodies written by k_pg_build_handles so that the CSR chain and the slot table run on the broad-phase stream NEXT to
+        //  the constraint generation: the chain does overlap (timeline), but its one-workgroup kernels wait for CUs behind the 818 workgroups of
+        //  the generation (k_ovf_entries 4.8 -> 64 us) and the join costs another event: 2.841 / 2.852 ms per step against 2.823 / 2.846 without
+        //  (same box).  Hoisting the point-record loads above the body gathers and 3 waves per SIMD for the generation: 0.1828 / 0.1816 ms
+        //  against 0.1873 / 0.1772.  Neither kept.)
         RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.n, ct.tv, ct.a1, ct.a2, ct.w, ct.cap};
         launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean, use_handles ? &rv : nullptr); ++launches;
         constraint_count_clean = false;

@@ -20,7 +20,8 @@ for r in sel:
         else: run[1] = b; run[2] += 1
         last_end = max(last_end, b); continue
     if run: print(f"{(run[0]-t0)/1e3:9.1f} us  +{(run[1]-run[0])/1e3:8.1f} us           [{run[2]} colour / overflow launches]"); run = None
-    print(f"{(a-t0)/1e3:9.1f} us  +{(b-a)/1e3:8.1f} us  gap {(a-last_end)/1e3:7.1f}  q{q} {k}")
+    g = r.get("Grid_Size_X") or r.get("Grid_Size") or "?"
+    print(f"{(a-t0)/1e3:9.1f} us  +{(b-a)/1e3:8.1f} us  gap {(a-last_end)/1e3:7.1f}  q{q} {k}  [{g} threads]")
     last_end = max(last_end, b)
 if run: print(f"{(run[0]-t0)/1e3:9.1f} us  +{(run[1]-run[0])/1e3:8.1f} us           [{run[2]} colour / overflow launches]")
 print(f"step span {(last_end-t0)/1e3:.1f} us")

@@ -32,7 +32,7 @@ def main():
         st = w.pipeline_stats(); tm = w.timers()
         rows.append(dict(step=s, wall_ms=round(dt, 3), changes=st.last_status_changes, manifolds=st.manifolds, overflow=st.last_overflow_manifolds,
                          host_ms=round(st.last_host_ms, 3), broad_ms=round(tm.broad_phase_ms, 3), prepare_ms=round(tm.prepare_ms, 3), substeps_ms=round(tm.substeps_ms, 3),
-                         finalize_ms=round(tm.finalize_ms, 3), step_ms=round(tm.step_ms, 3), launches=tm.kernel_launches, active_pairs=st.active_pairs))
+                         finalize_ms=round(tm.finalize_ms, 3), step_ms=round(tm.step_ms, 3), launches=tm.kernel_launches, active_pairs=st.active_pairs, new_pairs=tm.pair_count))
         print(rows[-1], flush=True)
     tail = rows[4:]
     if tail:
