@@ -340,6 +340,13 @@ def main():
     # manifold set — broad phase -> narrow phase -> status changes -> ConstraintGraph -> solver, all behind avn_step
     closed = None
     if rank == 0 and world_size == 1 and not args.no_closed_loop:
+        # the frozen-manifold world (and the PCIe leg's page-locked staging buffers) are not needed any more: a second live world of this size in the
+        # process costs the closed loop 2-6 % (measured: tools/time_closed_loop.py with AVN_TOOL_EXTRA_WORLD=1; bench vs the stand-alone tool on one box)
+        w.close()
+        try:
+            keep.clear()
+        except NameError:
+            pass
         wc = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
         wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
         wc.existing_pairs_upload(np.zeros(0, np.uint64))
@@ -352,6 +359,7 @@ def main():
             host = ch = byt = 0.0; ovf = 0
             for _ in range(n):
                 wc.step()
+                wc.synchronize()   # (a frame: the host reads the step's results before it starts the next one; back-to-back avn_step calls measure 2 % slower)
                 ps = wc.pipeline_stats(); host += ps.last_host_ms; ch += ps.last_status_changes; ovf = max(ovf, ps.last_overflow_manifolds)
                 byt += substeps * (228 * (sc.n - 1) + 1520 * ps.manifolds)     # SURVEY.md §8(d) with P = 4 (an upper bound: piles hold 1-4 points)
             wc.synchronize()
