@@ -153,7 +153,6 @@ template <class T> void launch_narrow_phase_dense(const DW<T>&, const BP<T>&, co
 template <class T> void launch_narrow_phase_rows(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* list, uint32_t n_list, uint32_t range_base, uint32_t n_range,
                                                  uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t);   // rows added this step (counter not reset)
 // manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
-template <class T> void launch_gather_manifolds(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
 // store_contact_impulses' write into the ContactGraph (plugin.rs:744-749): table row <- DW::mp_w
 template <class T> void launch_scatter_impulses(const DW<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);
 template <class T> struct ContactsStage {

@@ -436,23 +436,7 @@ __global__ __launch_bounds__(256) void k_clear_contact_rows(CT<T> ct, const uint
     ct.meta[ids[i]] = make_uint4(0u, 0u, 0u, 0u);
     ct.dcount[ids[i]] = 0;
 }
-template <class T>
-__global__ __launch_bounds__(256) void k_gather_manifolds(DW<T> w, BP<T> bp, CT<T> ct, const uint32_t* __restrict__ handles) {
-    uint32_t m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= w.n_manifolds) return;
-    const uint32_t c = handles[m];
-    const uint4 meta = ct.meta[c];
-    const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
-    w.m_bodies[m] = make_int2((int)bp.col_info[meta.x].y, (int)bp.col_info[meta.y].y);
-    w.m_n[m] = ct.n[c];
-    w.m_tv[m] = ct.tv[c];
-    w.m_meta[m] = np | (((meta.z & AVN_CP_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0u) << 8);
-#pragma unroll
-    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        size_t s = (size_t)k * ct.cap + c, d = (size_t)k * w.m_stride + m;
-        w.mp_a1[d] = ct.a1[s]; w.mp_a2[d] = ct.a2[s]; w.mp_w[d] = ct.w[s];
-    }
-}
+// (k_gather_manifolds -- rows -> colour-major arrays through the handle lists -- is gone since round 4: k_prepare_contact_constraints<T, ROWS> reads the rows itself)
 template <class T>
 __global__ __launch_bounds__(256) void k_scatter_impulses(DW<T> w, CT<T> ct, const uint32_t* __restrict__ handles) {
     uint32_t m = blockIdx.x * 256 + threadIdx.x;
@@ -576,9 +560,6 @@ template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp
     else hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
     launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st);
 }
-template <class T> void launch_gather_manifolds(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
-    if (w.n_manifolds) hipLaunchKernelGGL(k_gather_manifolds<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, bp, ct, handles);
-}
 template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_scatter_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, ct, handles);
 }
@@ -597,7 +578,6 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
     template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, bool); \
     template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
-    template void launch_gather_manifolds<T>(const DW<T>&, const BP<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                  \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
     template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);
 INST(float)

@@ -455,7 +455,7 @@
         islands_dirty = island_candidate(M) && dw.n_joints == 0;
         return AVN_OK;
     }
-    // after k_gather_manifolds (the CSR reads DW::m_bodies of the overflow range)
+    // after k_prepare_contact_constraints (the CSR reads DW::m_bodies of the overflow range, which that kernel lays out)
     void overflow_csr_device() {
         const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
         uint32_t *k = b_ovf_keys_a.as<uint32_t>(), *v = b_ovf_vals_a.as<uint32_t>();
