@@ -58,7 +58,7 @@ template <class T> void launch_xpbd_velocity_projection(const DW<T>&, const Step
 // k_contacts.hip
 // the contact table as k_prepare_contact_constraints reads it in handle mode (manifold m <- row handles[m]); CT / BP are declared further down
 template <class T> struct RowsView {
-    const uint32_t* handles; const uint4* meta; const uint4* col_info; const Vec4<T>* n; const Vec4<T>* tv; const Vec4<T>* a1; const Vec4<T>* a2; const Vec4<T>* w; uint32_t cap;
+    const uint32_t* handles; const uint4* meta; const uint4* col_info; const Vec4<T>* rows;   // CT<T>::rows: 16 records per row (n | tv | a1[4] | a2[4] | w[4] | fid)
 };
 template <class T> void launch_prepare_contact_constraints(const DW<T>&, const StepParams<T>&, hipStream_t, bool count_clean = false /* *DW::constraint_count is known to be zero */,
                                                            const RowsView<T>* rows = nullptr /* handle mode: read the ContactGraph side from the table (no k_gather_manifolds) */);
@@ -120,19 +120,24 @@ uint32_t sweep_bounds_level2_offset(uint32_t n_records);  // BP::s_bb2 = BP::s_b
 uint32_t sweep_count_slots();  // counts / offsets entries per interval (the sweep keeps one per candidate-range quarter)
 void launch_hs_insert(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
 void launch_hs_insert_pairs(uint64_t* tab, uint32_t cap, const avn_pair* pairs, uint32_t n, hipStream_t);
-// The ContactGraph side of the narrow phase in HBM: rows indexed by ContactId, one manifold per (convex) pair; the point
-// planes use the same record formats as the solver-side manifold arrays (DW::mp_a1 / mp_a2 / mp_w), so gathering a colour's
-// manifolds by handle is a record copy.
+// The ContactGraph side of the narrow phase in HBM: rows indexed by ContactId, one manifold per (convex) pair.  Round 4: the manifold's records are
+// ONE BLOCK PER ROW (16 Vec4<T>: 256 B in f32, 512 B in f64) instead of [p][row] planes: only the ~17 % of the rows that hold a manifold are ever
+// read or written, and their consumers -- the narrow phase's match_contacts, the constraint generation through the handle lists, the impulse
+// write-back -- name rows in no particular order, so a plane layout cost a whole 128-byte line per 16-byte record (PMC, settled cfg2:
+// k_prepare_contact_constraints fetched 461 MB for 92 MB of records).  `meta` and `dcount`, which every launch sweeps densely, stay flat arrays.
+#define AVN_CT_ROW_V4 16u
 template <class T> struct CT {
-    uint32_t cap;      // rows allocated = element stride between point planes ([p][row])
+    uint32_t cap;      // rows allocated
     uint4* meta;       // (collider slot 1, collider slot 2, AVN_CP_* flags, n_manifolds | point_count << 8)
     int32_t* dcount;   // ContactPair::manifold_count_change
-    Vec4<T>* n;        // (normal.xyz, friction)
-    Vec4<T>* tv;       // (tangent_velocity.xyz, restitution)
-    Vec4<T>* a1;       // [p][row] (anchor1.xyz, penetration)
-    Vec4<T>* a2;       // [p][row] (anchor2.xyz, normal_speed)
-    Vec4<T>* w;        // [p][row] (warm_start_normal, warm_start_tangent.x, .y, normal_impulse)
-    uint2* fid;        // [p][row] (feature_id1, feature_id2)
+    Vec4<T>* rows;     // [cap][16]: n | tv | a1[4] | a2[4] | w[4] | fid[4] (uint2, in the last two records)
+    __host__ __device__ __forceinline__ Vec4<T>* row(uint32_t c) const { return rows + (size_t)c * AVN_CT_ROW_V4; }
+    __host__ __device__ __forceinline__ Vec4<T>& n(uint32_t c) const { return row(c)[0]; }                 // (normal.xyz, friction)
+    __host__ __device__ __forceinline__ Vec4<T>& tv(uint32_t c) const { return row(c)[1]; }                // (tangent_velocity.xyz, restitution)
+    __host__ __device__ __forceinline__ Vec4<T>& a1(uint32_t c, uint32_t k) const { return row(c)[2 + k]; }    // (anchor1.xyz, penetration)
+    __host__ __device__ __forceinline__ Vec4<T>& a2(uint32_t c, uint32_t k) const { return row(c)[6 + k]; }    // (anchor2.xyz, normal_speed)
+    __host__ __device__ __forceinline__ Vec4<T>& w(uint32_t c, uint32_t k) const { return row(c)[10 + k]; }    // (warm_start_normal, warm_start_tangent.x, .y, normal_impulse)
+    __host__ __device__ __forceinline__ uint2& fid(uint32_t c, uint32_t k) const { return reinterpret_cast<uint2*>(row(c) + 14)[k]; }   // (feature_id1, feature_id2)
     Vec4<T>* col_mat;  // per collider slot: (friction, restitution, bits(friction_combine | restitution_combine << 8), 0)
     // the narrow phase's hand-over between its two kernels: the cuboid pairs that survive the SAT (k_narrow.hip)
     uint32_t* np_row;  // [cap + slack] row ids: 64 lists, arbitrary order inside a list

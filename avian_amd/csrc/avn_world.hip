@@ -150,7 +150,7 @@ template <class T> struct World : WorldBase {
     uint32_t overflow_csr_bodies = 0;
     // ---- narrow phase: the ContactGraph side on device (CT) + host mirrors of what the host structures of the reference hold ----
     CT<T> ct;
-    DevBuf b_ct_meta, b_ct_dcount, b_ct_n, b_ct_tv, b_ct_a1, b_ct_a2, b_ct_w, b_ct_fid, b_col_mat, b_active, b_changes, b_handles, b_np_row, b_np_axis, b_np_ctr;
+    DevBuf b_ct_meta, b_ct_dcount, b_ct_rows, b_col_mat, b_active, b_changes, b_handles, b_np_row, b_np_axis, b_np_ctr;
     std::unordered_map<uint32_t, uint32_t> entity_slot;   // collider Entity::index() -> slot (last colliders_upload)
     std::vector<int32_t> h_col_body;                       // body of each collider slot
     std::vector<uint8_t> h_ct_used;

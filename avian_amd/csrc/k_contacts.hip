@@ -127,8 +127,8 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
             const uint4 meta = rv.meta[row];
             const uint32_t npr = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
             w.m_bodies[m] = make_int2((int)rv.col_info[meta.x].y, (int)rv.col_info[meta.y].y);
-            w.m_n[m] = rv.n[row];
-            w.m_tv[m] = rv.tv[row];
+            w.m_n[m] = rv.rows[(size_t)row * AVN_CT_ROW_V4];
+            w.m_tv[m] = rv.rows[(size_t)row * AVN_CT_ROW_V4 + 1];
             w.m_meta[m] = npr | (((meta.z & AVN_CP_GENERATE_CONSTRAINTS) ? (uint32_t)AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0u) << 8);
         }
         uint32_t mm = w.m_meta[m];
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
             Vec4<T> pa1[AVN_MAX_MANIFOLD_POINTS], pa2[AVN_MAX_MANIFOLD_POINTS], pww[AVN_MAX_MANIFOLD_POINTS];
 #pragma unroll
             for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-                if (ROWS) { const size_t s = (size_t)k * rv.cap + row; pa1[k] = rv.a1[s]; pa2[k] = rv.a2[s]; pww[k] = rv.w[s]; }
+                if (ROWS) { const Vec4<T>* __restrict__ r = rv.rows + (size_t)row * AVN_CT_ROW_V4; pa1[k] = r[2 + k]; pa2[k] = r[6 + k]; pww[k] = r[10 + k]; }
                 else { uint32_t s = k * S + m; pa1[k] = w.mp_a1[s]; pa2[k] = w.mp_a2[s]; pww[k] = w.mp_w[s]; }
             }
 #pragma unroll

@@ -187,9 +187,8 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
                 old_a1[k] = vzero<T>(); old_a2[k] = vzero<T>(); old_wn[k] = T(0); old_wx[k] = T(0); old_wy[k] = T(0); old_fid[k] = make_uint2(0u, 0u);
                 if (k < old_n) {
-                    size_t s = (size_t)k * ct.cap + c;
-                    Vec4<T> oa = ct.a1[s], ob = ct.a2[s], ow = ct.w[s];
-                    old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid[s];
+                    Vec4<T> oa = ct.a1(c, k), ob = ct.a2(c, k), ow = ct.w(c, k);
+                    old_a1[k] = xyz<T>(oa); old_a2[k] = xyz<T>(ob); old_wn[k] = ow.x; old_wx[k] = ow.y; old_wy[k] = ow.z; old_fid[k] = ct.fid(c, k);
                 }
             }
         };
@@ -290,8 +289,8 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             if (!HEAVY) load_old_points();
             const T thr = T(0.1) * p.length_unit;
             const T thr2 = thr * thr;
-            ct.n[c] = make4<T>(normal, friction);
-            ct.tv[c] = make4<T>(T(0), T(0), T(0), restitution);
+            ct.n(c) = make4<T>(normal, friction);
+            ct.tv(c) = make4<T>(T(0), T(0), T(0), restitution);
             for (uint32_t k = 0; k < point_count; ++k) {
                 NpPt<T> pt;
                 build(k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3)), pt);
@@ -310,11 +309,10 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
                         }
                     }
                 }
-                size_t s = (size_t)k * ct.cap + c;
-                ct.a1[s] = make4<T>(pt.anchor1, pt.penetration);
-                ct.a2[s] = make4<T>(pt.anchor2, pt.normal_speed);
-                ct.w[s] = make4<T>(pt.warm_n, pt.warm_tx, pt.warm_ty, T(0));  // ContactPoint::new: normal_impulse = 0
-                ct.fid[s] = make_uint2(pt.fid1, pt.fid2);
+                ct.a1(c, k) = make4<T>(pt.anchor1, pt.penetration);
+                ct.a2(c, k) = make4<T>(pt.anchor2, pt.normal_speed);
+                ct.w(c, k) = make4<T>(pt.warm_n, pt.warm_tx, pt.warm_ty, T(0));  // ContactPoint::new: normal_impulse = 0
+                ct.fid(c, k) = make_uint2(pt.fid1, pt.fid2);
             }
         }
         dcount = (int32_t)n_manifolds - (int32_t)old_nman;
@@ -443,7 +441,7 @@ __global__ __launch_bounds__(256) void k_scatter_impulses(DW<T> w, CT<T> ct, con
     if (m >= w.n_manifolds) return;
     const uint32_t c = handles[m];
     const uint32_t np = scalar_to_bits(w.c_h1[m].w) & 7u;  // points the constraint has (0 = constraint absent: nothing stored)
-    for (uint32_t k = 0; k < np; ++k) ct.w[(size_t)k * ct.cap + c] = w.mp_w[(size_t)k * w.m_stride + m];
+    for (uint32_t k = 0; k < np; ++k) ct.w(c, k) = w.mp_w[(size_t)k * w.m_stride + m];
 }
 template <class T>
 __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_t* __restrict__ ids, uint32_t n, ContactsStage<T> o) {
@@ -455,15 +453,15 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
     if (o.flags) o.flags[i] = meta.z & ~(uint32_t)(AVN_CP_ROW_USED | AVN_CP_ROW_SLEEPING);
     if (o.point_count) o.point_count[i] = (uint8_t)np;
-    Vec4<T> n4 = np ? ct.n[c] : make4<T>(0, 0, 0, 0), tv = np ? ct.tv[c] : make4<T>(0, 0, 0, 0);
+    Vec4<T> n4 = np ? ct.n(c) : make4<T>(0, 0, 0, 0), tv = np ? ct.tv(c) : make4<T>(0, 0, 0, 0);
     st3(o.normal, i, xyz<T>(n4));
     if (o.friction) o.friction[i] = n4.w;
     if (o.restitution) o.restitution[i] = tv.w;
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        size_t s = (size_t)k * ct.cap + c, d = 4 * (size_t)i + k;
+        const size_t d = 4 * (size_t)i + k;
         const bool live = k < np;
-        Vec4<T> a1 = live ? ct.a1[s] : make4<T>(0, 0, 0, 0), a2 = live ? ct.a2[s] : make4<T>(0, 0, 0, 0), ww = live ? ct.w[s] : make4<T>(0, 0, 0, 0);
-        uint2 f = live ? ct.fid[s] : make_uint2(0u, 0u);
+        Vec4<T> a1 = live ? ct.a1(c, k) : make4<T>(0, 0, 0, 0), a2 = live ? ct.a2(c, k) : make4<T>(0, 0, 0, 0), ww = live ? ct.w(c, k) : make4<T>(0, 0, 0, 0);
+        uint2 f = live ? ct.fid(c, k) : make_uint2(0u, 0u);
         st3(o.anchor1, d, xyz<T>(a1)); st3(o.anchor2, d, xyz<T>(a2));
         if (o.penetration) o.penetration[d] = a1.w;
         if (o.normal_speed) o.normal_speed[d] = a2.w;
@@ -490,15 +488,15 @@ __global__ __launch_bounds__(256) void k_pack_contacts(CT<T> ct, const uint32_t*
     meta.w = (np ? 1u : 0u) | (np << 8);
     ct.meta[c] = meta;
     V3<T> nn = ld3(in.normal, i);
-    ct.n[c] = make4<T>(nn.x, nn.y, nn.z, in.friction[i]);
-    ct.tv[c] = make4<T>(T(0), T(0), T(0), in.restitution[i]);
+    ct.n(c) = make4<T>(nn.x, nn.y, nn.z, in.friction[i]);
+    ct.tv(c) = make4<T>(T(0), T(0), T(0), in.restitution[i]);
     for (uint32_t k = 0; k < np; ++k) {
-        size_t d = (size_t)k * ct.cap + c, s = 4 * (size_t)i + k;
+        const size_t s = 4 * (size_t)i + k;
         V3<T> a1 = ld3(in.anchor1, s), a2 = ld3(in.anchor2, s);
-        ct.a1[d] = make4<T>(a1.x, a1.y, a1.z, in.penetration[s]);
-        ct.a2[d] = make4<T>(a2.x, a2.y, a2.z, in.normal_speed[s]);
-        ct.w[d] = make4<T>(in.warm_n[s], in.warm_t[2 * s], in.warm_t[2 * s + 1], in.normal_impulse[s]);
-        ct.fid[d] = make_uint2(in.feature_id1[s], in.feature_id2[s]);
+        ct.a1(c, k) = make4<T>(a1.x, a1.y, a1.z, in.penetration[s]);
+        ct.a2(c, k) = make4<T>(a2.x, a2.y, a2.z, in.normal_speed[s]);
+        ct.w(c, k) = make4<T>(in.warm_n[s], in.warm_t[2 * s], in.warm_t[2 * s + 1], in.normal_impulse[s]);
+        ct.fid(c, k) = make_uint2(in.feature_id1[s], in.feature_id2[s]);
     }
 }
 

@@ -26,7 +26,7 @@
         uint32_t old = ct.cap;
         size_t c = std::max<size_t>(rows, (size_t)old + old / 2);
         c = (c + 63) & ~(size_t)63;
-        // grow with contents: the rows are persistent state.  The point planes are [p][row]: re-lay them out for the new stride.
+        // grow with contents: the rows are persistent state
         auto grow_flat = [&](DevBuf& b, size_t elem, void** field) -> avn_status {
             hipError_t err;
             b.ensure(c * elem, err, true, stream);
@@ -34,25 +34,10 @@
             *field = b.p;
             return AVN_OK;
         };
-        auto grow_planes = [&](DevBuf& b, size_t elem, void** field) -> avn_status {
-            void* np = nullptr;
-            if (hipMalloc(&np, 4 * c * elem) != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-            for (int k = 0; k < 4 && old; ++k)
-                if (hipMemcpy((char*)np + (size_t)k * c * elem, (char*)b.p + (size_t)k * old * elem, (size_t)old * elem, hipMemcpyDeviceToDevice) != hipSuccess) { error = "hipMemcpy failed"; return AVN_ERR_HIP; }
-            if (b.p) (void)hipFree(b.p);
-            b.p = np; b.cap = 4 * c * elem;
-            *field = np;
-            return AVN_OK;
-        };
         avn_status st;
         if ((st = grow_flat(b_ct_meta, sizeof(uint4), (void**)&ct.meta)) != AVN_OK) return st;
         if ((st = grow_flat(b_ct_dcount, sizeof(int32_t), (void**)&ct.dcount)) != AVN_OK) return st;
-        if ((st = grow_flat(b_ct_n, sizeof(V), (void**)&ct.n)) != AVN_OK) return st;
-        if ((st = grow_flat(b_ct_tv, sizeof(V), (void**)&ct.tv)) != AVN_OK) return st;
-        if ((st = grow_planes(b_ct_a1, sizeof(V), (void**)&ct.a1)) != AVN_OK) return st;
-        if ((st = grow_planes(b_ct_a2, sizeof(V), (void**)&ct.a2)) != AVN_OK) return st;
-        if ((st = grow_planes(b_ct_w, sizeof(V), (void**)&ct.w)) != AVN_OK) return st;
-        if ((st = grow_planes(b_ct_fid, sizeof(uint2), (void**)&ct.fid)) != AVN_OK) return st;
+        if ((st = grow_flat(b_ct_rows, AVN_CT_ROW_V4 * sizeof(V), (void**)&ct.rows)) != AVN_OK) return st;   // one block of 16 records per row: grows like a flat array
         HIPCHK(hipMemset((char*)ct.meta + (size_t)old * sizeof(uint4), 0, (c - old) * sizeof(uint4)));
         // the narrow phase's survivor list (scratch of one launch pair: nothing to keep) and its counters
         {

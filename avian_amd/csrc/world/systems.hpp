@@ -14,7 +14,7 @@
         //  the generation (k_ovf_entries 4.8 -> 64 us) and the join costs another event: 2.841 / 2.852 ms per step against 2.823 / 2.846 without
         //  (same box).  Hoisting the point-record loads above the body gathers and 3 waves per SIMD for the generation: 0.1828 / 0.1816 ms
         //  against 0.1873 / 0.1772.  Neither kept.)
-        RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.n, ct.tv, ct.a1, ct.a2, ct.w, ct.cap};
+        RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.rows};
         launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean, use_handles ? &rv : nullptr); ++launches;
         constraint_count_clean = false;
         if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
