@@ -64,7 +64,7 @@ template <class T> void launch_prepare_contact_constraints(const DW<T>&, const S
                                                            const RowsView<T>* rows = nullptr /* handle mode: read the ContactGraph side from the table (no k_gather_manifolds) */);
 template <class T> void launch_store_contact_impulses(const DW<T>&, hipStream_t);
 // body-centric warm start over the incidence CSR (DW::inc_off / inc_ent), optionally preceded by integrate_velocities
-template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, hipStream_t);
+template <class T> void launch_body_warm_start(const DW<T>&, const StepParams<T>&, bool fuse_integrate_velocities, bool quads /* four lanes per body: the device closed loop */, hipStream_t);
 // (re)build DW::inc_slot from DW::m_bodies / color_offsets (memset + one kernel)
 template <class T> void launch_build_incidence_slots(const DW<T>&, hipStream_t, bool cleared = false /* the table has been set to EMPTY already */);
 uint32_t color_grid_blocks(uint32_t count);

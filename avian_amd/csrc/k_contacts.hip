@@ -325,6 +325,114 @@ __global__ __launch_bounds__(WS_THREADS) void k_body_warm_start(DW<T> w, StepPar
     body_warm_start_one<T, FUSE_INTEGRATE>(w, p, body);
 }
 
+// The same launch with FOUR LANES PER BODY (round 4).  PMC on the lane-per-body form (settled cfg2 closed loop): 5 500 VALU instructions per wave -- a wave
+// walks all 21 populated colours and runs the whole `apply` for every one of them, for whichever of its 64 bodies has a manifold there -- on 1 568 waves,
+// 1.5 per SIMD, which spend 37 % of their cycles in s_waitcnt and 35 % in issue stalls; neither fewer bytes (a block layout: 191 -> 78 MB fetched, 61 -> 58 us)
+// nor more loads in flight (a ring of record sets) moved it.  Here lane q of a body's quad owns the colours c = q (mod 4): it fetches the records and computes the
+// point contributions (-p w1 | +p w2, -I1 (r1 x p) | +I2 (r2 x p): they do not depend on the velocities) of ITS colours, six iterations instead of 23; then the four
+// lanes add the contributions of colours 4i, 4i+1, 4i+2, 4i+3 to their (identical) copies of v and omega IN THAT ORDER, points in order, through quad broadcasts.
+// x - y is x + (-y) bit for bit, and an absent point contributes -0.0 (x + -0.0 == x for every x, -0.0 and NaN included), so the additions on a body are the
+// lane-per-body form's sequence: same bits.  Four times the waves, each a quarter as long: the stalls of one hide behind the others.
+template <int J> __device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), J * 0x55, 0xF, 0xF, false));   // quad_perm:[J,J,J,J]
+}
+template <int J> __device__ __forceinline__ double quad_bcast(double x) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), J * 0x55, 0xF, 0xF, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), J * 0x55, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+template <class T> struct QuadDelta { T d[AVN_MAX_MANIFOLD_POINTS][6]; };   // per point: the additions to (v.xyz, om.xyz)
+template <int J, class T> __device__ __forceinline__ void quad_accumulate(const QuadDelta<T>& q, V3<T>& v, V3<T>& om) {
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        v.x = v.x + quad_bcast<J>(q.d[k][0]); v.y = v.y + quad_bcast<J>(q.d[k][1]); v.z = v.z + quad_bcast<J>(q.d[k][2]);
+        om.x = om.x + quad_bcast<J>(q.d[k][3]); om.y = om.y + quad_bcast<J>(q.d[k][4]); om.z = om.z + quad_bcast<J>(q.d[k][5]);
+    }
+}
+#define WSQ_THREADS 256
+template <class T, bool FUSE_INTEGRATE>
+__global__ __launch_bounds__(WSQ_THREADS) void k_body_warm_start_quad(DW<T> w, StepParams<T> p) {
+    const uint32_t gid = xcd_block(blockIdx.x, gridDim.x) * WSQ_THREADS + threadIdx.x;
+    const uint32_t body = gid >> 2, q = gid & 3u;
+    // (every exit below depends on the body only: the four lanes of a quad leave together, so the quad broadcasts always see all four)
+    if (body >= w.n_bodies) return;
+    if (!body_in_group(w, body)) return;
+    const uint32_t sbf = w.sb_flags[body];
+    if (sbf & AVN_SBF_NO_SOLVER_BODY) return;
+    constexpr uint32_t NONE = 0xFFFFFFFFu, NC = AVN_COLOR_OVERFLOW_INDEX;
+    // which colours hold a manifold of this body: lane q looks at the slots of c = q (mod 4), the quad ORs the four partial masks
+    uint32_t mask = 0u;
+#pragma unroll
+    for (uint32_t i = 0; i < (NC + 3u) / 4u; ++i) {
+        const uint32_t c = 4u * i + q;
+        if (c < NC && w.inc_slot[(size_t)c * w.inc_stride + body] != NONE) mask |= 1u << c;
+    }
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0xB1, 0xF, 0xF, false);   // quad_perm:[1,0,3,2]
+    mask |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)mask, 0x4E, 0xF, 0xF, false);   // quad_perm:[2,3,0,1]
+    uint32_t e = w.inc_off[body];
+    const uint32_t end = w.inc_off[body + 1];
+    Vec4<T> l4 = w.sb_lin[body], a4 = w.sb_ang[body];
+    const Vec4<T> sa = w.si_a[body], sb = w.si_b[body];
+    V3<T> v = xyz<T>(l4), om = xyz<T>(a4);
+    if (FUSE_INTEGRATE) (void)integrate_velocities_one<T>(w, p, body, sbf, v, om, &w.sb_dq[body]);   // (the same arithmetic on all four lanes)
+    const V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
+    const T coeff = p.warm_start_coefficient;
+    const T z = T(0), nz = -T(0);
+    // the contributions of one entry: what the lane-per-body form adds, as signed additions; absent points are -0.0
+    auto contributions = [&](const WarmRecords<T>& r, uint32_t ent, bool present, QuadDelta<T>& out) {
+        const uint32_t side = ent >> 31;
+        const uint32_t cm = scalar_to_bits(r.h1.w);
+        uint32_t np = present ? (cm & 7u) : 0u;
+        if (cm & (side ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1)) np = 0;  // (stale incidence: the body lost its SolverBody)
+        const bool ni = cm & (side ? AVN_CM_DOM2 : AVN_CM_DOM1);
+        const V3<T> inv_mass{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
+        const Sym3<T> I{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
+        const V3<T> normal = xyz<T>(r.h0);
+        const V3<T> t0 = xyz<T>(r.h1), t1 = cross(t0, normal);
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            const V3<T> rr = xyz<T>(r.pr[k]);
+            const Vec4<T> d = r.pd[k];
+            const T tx = (cm & AVN_CM_TANGENT) ? d.z : T(0), ty = (cm & AVN_CM_TANGENT) ? d.w : T(0);
+            const V3<T> imp = coeff * ((d.x * normal + tx * t0) + ty * t1);
+            const V3<T> dv = cmul(imp, inv_mass);
+            const V3<T> dw = smul(I, cross(rr, imp));
+            const bool on = k < np;
+            out.d[k][0] = on ? (side ? dv.x : -dv.x) : nz; out.d[k][1] = on ? (side ? dv.y : -dv.y) : nz; out.d[k][2] = on ? (side ? dv.z : -dv.z) : nz;
+            out.d[k][3] = on ? (side ? dw.x : -dw.x) : nz; out.d[k][4] = on ? (side ? dw.y : -dw.y) : nz; out.d[k][5] = on ? (side ? dw.z : -dw.z) : nz;
+        }
+    };
+    // (1) the overflow colour's entries, in list order (solved FIRST); usually none.  Every lane of the quad walks the same list: same additions.
+    for (; e < end; ++e) {
+        WarmRecords<T> r; QuadDelta<T> dl;
+        const uint32_t ent = w.inc_ent[e];
+        warm_fetch<T>(w, ent, r);
+        contributions(r, ent, true, dl);
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { v.x = v.x + dl.d[k][0]; v.y = v.y + dl.d[k][1]; v.z = v.z + dl.d[k][2]; om.x = om.x + dl.d[k][3]; om.y = om.y + dl.d[k][4]; om.z = om.z + dl.d[k][5]; }
+    }
+    // (2) colours 0..22 in order: the body's j-th manifold (j-th set bit of the mask) belongs to lane j mod 4 in round j / 4 -- a body of a settled pile has four
+    // or five, so a quad makes one or two rounds where a lane of the lane-per-body form walks 23 colours
+    const uint32_t n_ent = (uint32_t)__popc(mask);
+    uint32_t rest = mask;
+    for (uint32_t j0 = 0; j0 < n_ent; j0 += 4u) {   // (trip count per quad: the four lanes of a quad stay together)
+        // this lane's colour of the round: skip q set bits of `rest`; then all four lanes drop the round's four bits
+        uint32_t mine = rest;
+        for (uint32_t t = 0; t < q; ++t) mine &= mine - 1u;
+        const bool present = mine != 0u;
+        const uint32_t c = present ? (uint32_t)__ffs((int)mine) - 1u : 0u;
+        rest &= rest - 1u; rest &= rest - 1u; rest &= rest - 1u; rest &= rest - 1u;
+        const uint32_t sc = present ? w.inc_slot[(size_t)c * w.inc_stride + body] : 0u;   // (read again: it is in the L1 the mask pass left it in)
+        WarmRecords<T> r; QuadDelta<T> dl;
+        warm_fetch<T>(w, sc, r);   // (an absent entry fetches manifold 0's records and contributes -0.0: no branch around the loads)
+        contributions(r, sc, present, dl);
+        quad_accumulate<0, T>(dl, v, om); quad_accumulate<1, T>(dl, v, om); quad_accumulate<2, T>(dl, v, om); quad_accumulate<3, T>(dl, v, om);
+    }
+    if (q == 0u) {
+        w.sb_lin[body] = make4<T>(v, l4.w);
+        w.sb_ang[body] = make4<T>(om, a4.w);
+    }
+}
+
 // Warm start of ONE manifold against a BodyView (the manifold-centric form of the same arithmetic: applied colour by colour in
 // solve order every body sees the additions of k_body_warm_start in the same sequence).  Used by the island blocks, whose
 // bodies live in LDS where a colour sweep costs a workgroup barrier instead of a launch.
@@ -1012,10 +1120,21 @@ void launch_island_substeps(const DW<float>& w, const StepParams<float>& p, cons
     if (ib.cache_records) hipLaunchKernelGGL((k_island_substeps<float, true>), dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
     else hipLaunchKernelGGL((k_island_substeps<float, false>), dim3(ib.n_blocks), dim3(ISLAND_THREADS), 0, s, w, p, ib, substeps, iterations);
 }
-template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, hipStream_t s) {
+template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<T>& p, bool fuse_integrate_velocities, bool quads, hipStream_t s) {
     if (!w.n_bodies) return;
     uint32_t nb = (w.n_bodies + WS_THREADS - 1) / WS_THREADS;
     nb = ((nb + 7u) / 8u) * 8u;
+    // quads: four lanes per body (k_body_warm_start_quad) -- the device closed loop, whose handle lists are in history order (2.78 -> 2.72 ms per settled cfg2
+    // step).  With host-uploaded manifolds neighbouring bodies' manifolds are neighbours in the colour-major arrays and the lane-per-body form's gathers
+    // coalesce: there the quads LOSE (cfg2 frozen 2 497 -> 2 382 substeps/s, same box), so the caller chooses.
+    static const bool lane_per_body = getenv("AVN_WS_LANE_PER_BODY") && getenv("AVN_WS_LANE_PER_BODY")[0] == '1';   // (A/B: round 3's form everywhere; the results do not depend on it)
+    if (quads && !lane_per_body && w.inc_slot) {
+        uint32_t nq = (uint32_t)(((uint64_t)w.n_bodies * 4u + WSQ_THREADS - 1) / WSQ_THREADS);
+        nq = ((nq + 7u) / 8u) * 8u;
+        if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start_quad<T, true>), dim3(nq), dim3(WSQ_THREADS), 0, s, w, p);
+        else hipLaunchKernelGGL((k_body_warm_start_quad<T, false>), dim3(nq), dim3(WSQ_THREADS), 0, s, w, p);
+        return;
+    }
     if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
     else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
 }
@@ -1035,7 +1154,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
 #define INST(T)                                                                                             \
     template void launch_prepare_contact_constraints<T>(const DW<T>&, const StepParams<T>&, hipStream_t, bool, const RowsView<T>*);   \
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
-    template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, hipStream_t);         \
+    template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, bool, hipStream_t);   \
     template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t, bool);                               \
     template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t); \
     template void launch_overflow_flow<T>(const DW<T>&, const StepParams<T>&, int, const OverflowFlow&, uint32_t, uint32_t, hipStream_t);

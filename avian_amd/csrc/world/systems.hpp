@@ -29,7 +29,7 @@
     void warm_start(bool fused) {
         if (dw.n_manifolds) {
             if (slots_dirty && dw.inc_slot) { launch_build_incidence_slots<T>(dw, stream); launches += 2; slots_dirty = false; }  // (normally done by prepare)
-            launch_body_warm_start<T>(dw, params, fused, stream); ++launches;
+            launch_body_warm_start<T>(dw, params, fused, pipe_dev, stream); ++launches;
         }
         else if (fused) integrate_velocities();
     }
