@@ -234,11 +234,13 @@ __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, St
 // whose j-th incident manifolds are neighbours in the colour-major arrays, so the record gathers of a wave coalesce; the
 // next entry's ten records are in flight while the current one is applied.  The lane first runs integrate_velocities
 // (the system that precedes warm start in the SubstepSchedule) on its body.
-// (Round 4, tried: a ring of 2 / 3 / 4 / 6 record sets in flight (all slots loaded up front, loads made unconditional so that the vmcnt
-//  bookkeeping stays exact -- checked in the ISA).  cfg2: 2 481 / 2 458 / 2 492 / 2 434 substeps/s against 2 494 for this form on the same box;
-//  the closed loop's launch stayed at 64-67 us.  So the launch is not a chain of round trips: frozen cfg2 fetches 86 MiB (its ~96 MB of
-//  records, nothing amplified) through one 16-byte record per lane and line -- the L1's tag rate -- and the closed loop, whose handle lists
-//  are in history order, pulls a whole line per 16-byte record of the colour-major SoA arrays (~8x its 67 MB).  Not kept.)
+// (Round 4, tried on this form: a ring of 2 / 3 / 4 / 6 record sets in flight (all slots loaded up front, loads made unconditional so that the
+//  vmcnt bookkeeping stays exact -- checked in the ISA): cfg2 2 481 / 2 458 / 2 492 / 2 434 substeps/s against 2 494 on the same box, the closed
+//  loop's launch unchanged at 61-67 us.  A per-manifold block of exactly the records this kernel reads (closed loop: 191 -> 78 MB fetched per
+//  launch, PMC): 61 -> 58 us, paid back by the extra writes of the constraint generation.  So it is neither round trips nor bytes: frozen cfg2
+//  moves its 217 MB at 6 TB/s already, and in the closed loop a wave issues 5 500 VALU instructions -- the whole `apply` for each of the 21
+//  populated colours, for whichever of its 64 bodies has a manifold there -- at 1.5 waves per SIMD.  What helped there is the four-lanes-per-body
+//  form below; neither of the two was kept.)
 #define WS_THREADS 64
 template <class T> struct WarmRecords { Vec4<T> h1, h0, pr[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS]; };
 template <class T> __device__ __forceinline__ void warm_fetch(const DW<T>& w, uint32_t ent, WarmRecords<T>& r) {

@@ -21,6 +21,7 @@ cpf closed_loop_r3_vs_r4_same_box.txt closed_loop_r3_vs_r4_same_box.txt
 cpf sleeping_step230_timeline.txt sleeping_step230_timeline.txt
 cpf narrow_phase_cutoffs.txt narrow_phase_cutoffs.txt
 cpf pmc_narrow_phase.json pmc_narrow_phase.json
+cpf pmc_closed_loop_settled.json pmc_closed_loop_settled.json
 cpf cfg5_percentiles.txt cfg5_percentiles.txt
 cpf cfg3_island_streams_ab.txt cfg3_island_streams_ab.txt
 cpf color_pass_floor.json color_pass_floor.json

@@ -67,6 +67,8 @@ if [ -f $R/avian_amd/csrc/ab/libavian_r3.so ]; then
   done > $O/closed_loop_r3_vs_r4_same_box.txt 2>&1
 fi
 timeout 200 bash tools/sleeping_timeline.sh 230 > $O/sleeping_step230_timeline.txt 2>&1
+timeout 300 python tools/pmc_closed_loop_tail.py $O/pmc_closed_loop_settled.json 120 20 > $O/pmc_closed_loop_settled.txt 2>&1
+echo "== AVN_WS_LANE_PER_BODY=1 (round 3's warm start in the closed loop)" >> $O/closed_loop_switches_ab.txt; AVN_WS_LANE_PER_BODY=1 python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py >> $O/closed_loop_switches_ab.txt
 python tools/pmc_any.py $O/pmc_narrow_phase.json 30 narrow "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY" > $O/pmc_narrow_phase.txt 2>&1
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
