@@ -1,7 +1,8 @@
 """GPU: the A/B switches of the closed loop and of avn_step keep their (older) code paths correct.  Each runs a slice of the parity suite in a
 subprocess with the switch set: round 2's one-wave replay of the colour lists (AVN_PG_REPLAY_WAVE), the narrow phase behind the broad phase
 (AVN_NO_NP_OVERLAP), blocking waits (AVN_NO_SPIN_SYNC), fencing events and the broad phase enqueued first (AVN_EVENT_SYSTEM_FENCE,
-AVN_BP_ENQUEUE_FIRST), joint islands on the main stream (AVN_NO_ISLAND_STREAMS), the broad phase on the solver's stream (AVN_NO_BP_OVERLAP)."""
+AVN_BP_ENQUEUE_FIRST), joint islands on the main stream (AVN_NO_ISLAND_STREAMS), the broad phase on the solver's stream (AVN_NO_BP_OVERLAP), the
+one-lane-per-body warm start in the closed loop (AVN_WS_LANE_PER_BODY; round 4's default there is four lanes per body)."""
 import os
 import subprocess
 import sys
@@ -21,7 +22,8 @@ FROZEN = ["tests/test_gpu_parity.py", "tests/test_gpu_island_streams.py"]
     ({"AVN_NO_NP_OVERLAP": "1", "AVN_NO_SPIN_SYNC": "1"}, CLOSED_LOOP),
     ({"AVN_EVENT_SYSTEM_FENCE": "1", "AVN_BP_ENQUEUE_FIRST": "1"}, FROZEN + CLOSED_LOOP[:1]),
     ({"AVN_NO_ISLAND_STREAMS": "1", "AVN_NO_BP_OVERLAP": "1"}, ["tests/test_gpu_parity.py", "tests/test_gpu_configs.py::test_cfg3_stack_with_distance_joint_chains_matches_oracle"]),
-], ids=["wave-replay", "serial-narrow-phase-blocking-waits", "fencing-events-bp-first", "single-stream"])
+    ({"AVN_WS_LANE_PER_BODY": "1"}, CLOSED_LOOP),
+], ids=["wave-replay", "serial-narrow-phase-blocking-waits", "fencing-events-bp-first", "single-stream", "lane-per-body-warm-start"])
 def test_parity_slice_with_the_switch_set(env, targets):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *targets], capture_output=True, text=True, timeout=600, cwd=REPO,
                        env=dict(os.environ, **env))
