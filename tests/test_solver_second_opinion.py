@@ -1,0 +1,187 @@
+"""CPU: the oracle's contact solver and XPBD distance joint (SURVEY.md §8 rows a10-a23 -- the rows where the FLOPs are) against a THIRD
+restatement written from the reference's text alone (tests/solver_second_opinion.py: numpy scalars, one rounding per operation, the
+order of the Rust source).  System by system through the C ABI: the oracle's state before a system is handed to the restatement, and what the
+restatement makes of it must equal the oracle's state after the system, bit for bit, f32 and f64, on `helpers.random_world` -- random,
+physically inconsistent manifolds that reach every branch (speculative points, clamped friction, non-finite tangent masses, locked axes,
+dominance, sleeping / disabled / static / kinematic bodies, an overflow colour).  The reference holds no vectors for these rows
+(SURVEY.md §8c); two programs by one author agreeing is what the parity suite shows, a third written without looking at either is what can be
+added here."""
+import numpy as np
+import pytest
+
+import solver_second_opinion as S
+from avian_amd import _ffi as F
+from helpers import color_and_upload, oracle_lib, random_world
+
+
+def build(bits, seed, **kw):
+    lib = oracle_lib()
+    wd = random_world(seed=seed, **kw)
+    w = F.World(lib, F.default_config(bits, substeps=4))
+    offsets, perm = color_and_upload(w, lib, wd)
+    return w, wd, offsets, perm
+
+
+def same(a, b, what):
+    a = np.asarray(a); b = np.asarray(b)
+    bad = ~((a == b) | (np.isnan(a) & np.isnan(b)))
+    assert not bad.any(), f"{what}: {int(bad.sum())} of {bad.size} values differ, first at {tuple(np.argwhere(bad)[0])}: {a[tuple(np.argwhere(bad)[0])]!r} vs {b[tuple(np.argwhere(bad)[0])]!r}"
+
+
+def constraints_to_arrays(A, cons, M):
+    """The layout of avn_constraints_download for the restatement's constraints (absent constraints / points: zeros)."""
+    T = A.T
+    out = {"point_count": np.zeros(M, np.uint8), "relative_dominance": np.zeros(M, np.int16), "tangent1": np.zeros((M, 3), T), "anchor1": np.zeros((M, 4, 3), T),
+           "initial_separation": np.zeros((M, 4), T), "normal_impulse": np.zeros((M, 4), T), "total_impulse": np.zeros((M, 4), T), "normal_effective_mass": np.zeros((M, 4), T),
+           "tangent_impulse": np.zeros((M, 4, 2), T), "tangent_effective_inverse_mass": np.zeros((M, 4, 3), T), "softness_non_dynamic": np.zeros(M, np.uint8)}
+    for m, c in enumerate(cons):
+        if c is None: continue
+        out["point_count"][m] = len(c["points"]); out["relative_dominance"][m] = c["relative_dominance"]; out["tangent1"][m] = c["tangent1"]
+        out["softness_non_dynamic"][m] = c["non_dynamic_softness"]
+        for k, p in enumerate(c["points"]):
+            out["anchor1"][m, k] = p["anchor1"]; out["initial_separation"][m, k] = p["initial_separation"]; out["normal_impulse"][m, k] = p["impulse"]
+            out["total_impulse"][m, k] = p["total_impulse"]; out["normal_effective_mass"][m, k] = p["effective_mass"]
+            if p["tangent"]: out["tangent_impulse"][m, k] = p["tangent"]["impulse"]; out["tangent_effective_inverse_mass"][m, k] = p["tangent"]["k"]
+    return out
+
+
+def compare_constraints(A, cons, w, what, keys=None):
+    got = constraints_to_arrays(A, cons, w.n_manifolds)
+    ref = w.constraints_download()
+    live = ref["point_count"] > 0
+    for k in (keys or got):
+        a, b = got[k], ref[k]
+        if k != "point_count":   # rows without a constraint hold whatever the implementation leaves there
+            a, b = a[live], b[live]
+        same(a, b, f"{what}: constraints.{k}")
+
+
+def compare_bodies(bodies, w, what):
+    sb = w.solver_bodies_download()
+    has = (sb["flags"] & S.NO_SOLVER_BODY) == 0
+    same(np.array(bodies.lin)[has], sb["linear_velocity"][has], f"{what}: linear_velocity")
+    same(np.array(bodies.ang)[has], sb["angular_velocity"][has], f"{what}: angular_velocity")
+    same(np.array(bodies.dp)[has], sb["delta_position"][has], f"{what}: delta_position")
+    same(np.array(bodies.dq)[has], sb["delta_rotation"][has], f"{what}: delta_rotation")
+
+
+def generate_all(A, w, wd, perm, cfg):
+    mf = {k: np.asarray(v)[perm] for k, v in wd["manifolds"].items()}
+    T = A.T
+    for k in ("normal", "anchor1", "anchor2", "penetration", "normal_speed", "tangent_velocity"):
+        mf[k] = mf[k].astype(T)   # what the ABI hands to the library: the world's scalar type
+    bodies = S.Bodies(A, w.solver_bodies_download())
+    b = wd["bodies"]
+    lin = np.asarray(b["linear_velocity"]).astype(T)
+    flags = np.asarray(b.get("body_flags", np.zeros(len(lin), np.uint8)))
+    fr, re = wd["friction"][perm].astype(T), wd["restitution"][perm].astype(T)
+    wn, wt = wd["warm_n"][perm].astype(T), wd["warm_t"][perm].astype(T)
+    cons = [S.generate(A, bodies, lin, mf, m, fr[m], re[m], wn, wt, bool(cfg.match_contacts), np.asarray(b["rb_type"]), flags) for m in range(len(perm))]
+    return bodies, cons
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+@pytest.mark.parametrize("seed", [3, 11])
+def test_contact_constraints_system_by_system(bits, seed):
+    A = S.Arith(bits)
+    w, wd, offsets, perm = build(bits, seed, n_bodies=90, n_manifolds=260, hub_degree=26)
+    cfg = w.cfg
+    ts = S.time_scalars(A, cfg.dt_ns, cfg.substeps)
+    soft = S.contact_softness(A, cfg, ts)
+    order = S.in_solve_order(offsets)
+    assert offsets[24] - offsets[23] > 0, "the scene must reach the overflow colour"
+    w.run_system("PREPARE_SOLVER_BODIES")
+    w.run_system("PREPARE_CONTACT_CONSTRAINTS")
+    bodies, cons = generate_all(A, w, wd, perm, cfg)
+    assert sum(c is not None for c in cons) > 150 and any(c is None for c in cons)
+    compare_constraints(A, cons, w, "generate")
+    w.run_system("PRE_PROCESS_VELOCITY_INCREMENTS")
+    for sub in range(2):   # two substeps: the second starts from accumulated impulses and non-trivial delta rotations
+        w.run_system("INTEGRATE_VELOCITIES")
+        bodies = S.Bodies(A, w.solver_bodies_download())
+        w.run_system("WARM_START")
+        for m in order:
+            if cons[m] is not None: S.warm_start(A, bodies, cons[m], A.T(cfg.warm_start_coefficient))
+        compare_bodies(bodies, w, f"substep {sub}: warm start")
+        w.run_system("SOLVE_CONTACTS_BIAS")
+        for m in order:
+            if cons[m] is not None: S.solve(A, bodies, cons[m], ts["h_adj"], True, A.T(cfg.max_overlap_solve_speed) * A.T(cfg.length_unit), soft)
+        compare_bodies(bodies, w, f"substep {sub}: biased solve")
+        compare_constraints(A, cons, w, f"substep {sub}: biased solve", ("normal_impulse", "total_impulse", "tangent_impulse"))
+        w.run_system("INTEGRATE_POSITIONS")
+        bodies = S.Bodies(A, w.solver_bodies_download())
+        w.run_system("SOLVE_CONTACTS_RELAX")
+        for m in order:
+            if cons[m] is not None: S.solve(A, bodies, cons[m], ts["h_adj"], False, A.T(cfg.max_overlap_solve_speed) * A.T(cfg.length_unit), soft)
+        compare_bodies(bodies, w, f"substep {sub}: relax")
+        compare_constraints(A, cons, w, f"substep {sub}: relax", ("normal_impulse", "total_impulse", "tangent_impulse"))
+    w.run_system("SOLVE_RESTITUTION")
+    for m in order:
+        if cons[m] is not None: S.restitution(A, bodies, cons[m], A.T(cfg.restitution_threshold) * A.T(cfg.length_unit), int(cfg.restitution_iterations))
+    compare_bodies(bodies, w, "restitution")
+    compare_constraints(A, cons, w, "restitution", ("normal_impulse", "total_impulse"))
+    # store_contact_impulses (plugin.rs:722-755): impulse -> warm_start_normal_impulse, tangent impulse -> warm_start_tangent_impulse, total -> normal_impulse
+    w.run_system("STORE_CONTACT_IMPULSES")
+    imp = w.impulses_download()
+    got = constraints_to_arrays(A, cons, w.n_manifolds)
+    pts = np.arange(4)[None, :] < got["point_count"][:, None]   # the zip stops at the constraint's points: the manifold's other slots keep what they held
+    same(got["normal_impulse"][pts], imp["warm_start_normal_impulse"][pts], "store: warm_start_normal_impulse")
+    same(got["tangent_impulse"][pts], imp["warm_start_tangent_impulse"][pts], "store: warm_start_tangent_impulse")
+    same(got["total_impulse"][pts], imp["normal_impulse"][pts], "store: normal_impulse")
+    assert pts.sum() > 400
+
+
+def test_softness_coefficients_against_the_reference_defaults():
+    """ContactSoftnessCoefficients::default (plugin.rs:317-324) documents SoftnessParameters::new(10, 30) / (10, 60) at 1/60 s; and the step's own
+    coefficients for dt = 1/60, 6 substeps follow hz = 1.5 * min(1 / (2 dt), 0.25 / h)."""
+    A = S.Arith(64)
+    d = S.softness_coefficients(A, 10.0, A.T(30.0), A.T(1.0 / 60.0))
+    omega = 2 * np.pi * 30.0; h = 1.0 / 60.0
+    a1 = 20.0 + omega * h; a2 = omega * h * a1
+    assert abs(d["bias"] - omega / a1) < 1e-12 and abs(d["impulse_scale"] - 1 / (1 + a2)) < 1e-15 and abs(d["mass_scale"] - a2 / (1 + a2)) < 1e-15
+    cfg = F.default_config(64, substeps=6)
+    ts = S.time_scalars(A, cfg.dt_ns, cfg.substeps)
+    s = S.contact_softness(A, cfg, ts)
+    hz = 1.5 * min(1 / (2 * float(ts["dt"])), 0.25 / float(ts["h"]))
+    assert abs(float(ts["h"]) * 6 - float(ts["dt"])) < 2e-9 and abs(hz - 45.0) < 1e-5
+    assert s["non_dynamic"]["bias"] > s["dynamic"]["bias"] > 0
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_distance_joints_against_the_restatement(bits):
+    """XPBD_SOLVE over random DistanceJoints (serial, in joint order; dominance and missing bodies -> DUMMY) for two substeps, with the oracle's
+    sin / cos switched to the platform libm (the restatement calls the same libm through ctypes; the default build's polynomial is the
+    oracle's own and is covered by tests/test_oracle_tolerance.py)."""
+    A = S.Arith(bits)
+    lib = oracle_lib()
+    lib.dll.avo_use_libm_trig(1)
+    try:
+        w, wd, offsets, perm = build(bits, 5, n_bodies=60, n_manifolds=40, n_joints=80)
+        cfg = w.cfg
+        ts = S.time_scalars(A, cfg.dt_ns, cfg.substeps)
+        T = A.T
+        b = wd["bodies"]; J = wd["joints"]
+        pos = [A.v(x) for x in np.asarray(b["position"]).astype(T)]
+        rot = [tuple(T(c) for c in q) for q in np.asarray(b["rotation"]).astype(T)]
+        com = [A.v(x) for x in np.asarray(b["center_of_mass"]).astype(T)]
+        w.run_system("PREPARE_SOLVER_BODIES"); w.run_system("PREPARE_JOINTS"); w.run_system("PRE_PROCESS_VELOCITY_INCREMENTS")
+        joints = [dict(body1=int(J["body1"][j]), body2=int(J["body2"][j]), local_anchor1=A.v(np.asarray(J["local_anchor1"][j]).astype(T)),
+                       local_anchor2=A.v(np.asarray(J["local_anchor2"][j]).astype(T)), limit_min=T(J["limit_min"][j]), limit_max=T(J["limit_max"][j]),
+                       compliance=T(J["compliance"][j])) for j in range(len(J["body1"]))]
+        data = [S.distance_joint_prepare(A, pos, rot, com, j) for j in joints]
+        flags = np.asarray(b["body_flags"])
+        moved = 0
+        for sub in range(2):
+            w.run_system("INTEGRATE_VELOCITIES"); w.run_system("INTEGRATE_POSITIONS")
+            bodies = S.Bodies(A, w.solver_bodies_download())
+            before = np.array(bodies.dp)
+            w.run_system("XPBD_SOLVE")
+            for j, d in zip(joints, data):
+                if (flags[j["body1"]] | flags[j["body2"]]) & 2: continue   # a disabled body: get_many / the body query fails, the joint is left alone
+                S.distance_joint_solve(A, bodies, j, d, ts["h_adj"])
+            compare_bodies(bodies, w, f"substep {sub}: distance joints")
+            moved += int((np.array(bodies.dp) != before).any(axis=1).sum())
+            w.run_system("XPBD_VELOCITY_PROJECTION"); w.run_system("JOINT_DAMPING")
+        assert moved > 40
+    finally:
+        lib.dll.avo_use_libm_trig(0)
