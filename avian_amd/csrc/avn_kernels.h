@@ -182,7 +182,8 @@ enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_
        PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
        PGC_COLLECT = 14 /* k_pg_collect_edges: records written */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
-       PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512, PGC_WORDS = 1024 };
+       PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512,
+       PGC_SORT_DUP = 768 /* [24] k_pg_build_handles: manifolds of a colour whose key body was already taken (never, while the colouring's invariant holds) */, PGC_WORDS = 1024 };
 struct PG {
     uint32_t rows;          // capacity of the per-row arrays (= CT::cap)
     int2* bodies;           // [rows] ContactPair::body1 / body2
@@ -243,7 +244,10 @@ void launch_pg_apply_masks(const PG&, const uint32_t* keys, const uint32_t* vals
 void launch_pg_replay(const PG&, uint32_t n_ops, hipStream_t);   // stable partition of the ops by colour + the exact push / swap_remove replay of every colour
 template <class T> void launch_pg_remove(const PG&, const CT<T>&, const BP<T>&, uint32_t n_ops, hipStream_t);
 void launch_pg_merge_free(const PG&, uint32_t head, uint32_t n_free, uint32_t n_rem, hipStream_t);
-void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t);
+// handles <- the colours' lists, concatenated.  sort_tab != NULL: colours 0..22 in KEY-BODY order instead of list order (the solver's second order, k_graph.hip;
+// sort_tab: [23][pg_sort_stride(n_bodies)] words, all PG_NONE on entry and on exit; sort_cnt: [23][stride / 2048] words of scratch; 3 launches instead of 1)
+uint32_t pg_sort_stride(uint32_t n_bodies);
+void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t);
 template <class T> void launch_pg_rebuild_pair_set(const CT<T>&, const BP<T>&, uint32_t n_rows, hipStream_t);
 // overflow colour on the device: incidence CSR of the body-centric warm start + per-body ranks of the dataflow passes
 struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; };

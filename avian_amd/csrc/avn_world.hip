@@ -304,6 +304,9 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming | EV_FLAGS));
         HIPCHK(hipEventCreateWithFlags(&ev_bp_t0, EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_bp_t1, EV_FLAGS));
         if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
+#ifdef AVN_MEASURE
+        if (getenv("AVN_NO_HANDLE_SORT")) handle_sort = false;   // (A/B: the solver's arrays in the bookkeeping's list order, as before round 5)
+#endif
         for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
         for (auto& x : ev_dg) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
         for (auto& x : ev_dgs) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));

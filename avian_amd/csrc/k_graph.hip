@@ -859,7 +859,20 @@ void launch_compact_u32(const uint32_t* src, uint32_t* dst, const uint32_t* new_
 void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_index, uint32_t n_old, hipStream_t s) { if (n_old) hipLaunchKernelGGL(k_compact<uint8_t>, dim3((n_old + 255) / 256), dim3(256), 0, s, src, dst, new_index, n_old); }
 
 // ---- GraphColor::manifold_handles of all colours, concatenated colour-major (what the solver's arrays are ordered by) ---------
-__global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __restrict__ handles, uint32_t* __restrict__ color_offsets, uint32_t total) {
+// Round 5: the SOLVER's order inside colours 0..22 is a second, body-sorted one.  Inside such a colour no two manifolds share a non-static
+// body (constraint_graph.rs:36-48), so every order gives the same bits; only the bookkeeping (PG::lists, swap_remove) needs the reference's
+// history order, and it keeps it.  The handle lists of a pile that has been through 10^5 pops and pushes name rows in no order at all: every
+// 16-byte record the warm start gathered cost a line (248.6 MB fetched per launch against 65.3 MB of records, r04_pmc_closed_loop_settled.json),
+// the colour passes' body gathers and the constraint generation's likewise.  Sorted by KEY BODY (body1, or body2 next to a static body1) the
+// neighbours of a manifold in its colour belong to neighbouring bodies, as in a freshly uploaded manifold set.
+// No sort is needed: a colour holds at most one manifold per non-static body, so `tab[colour][key body] = ContactId` is a collision-free
+// scatter and the sorted list is the table's non-empty entries in order -- k_pg_build_handles scatters (the overflow colour keeps its list
+// order and is written directly), k_pg_sort_count counts the entries of every 2 048-body chunk of every colour, k_pg_sort_emit turns the
+// counts in front of its chunk into its base and compacts (and leaves the table EMPTY again: no memset per step).  Should two manifolds of a
+// colour ever name the same key body (the colouring's invariant broken, e.g. by a body that changed its type under a live contact), the
+// loser of the compare-and-swap goes to the END of the colour's range (ctr[PGC_SORT_DUP + colour]): nothing is lost.
+__global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __restrict__ handles, uint32_t* __restrict__ color_offsets, uint32_t total,
+                                                          const uint4* __restrict__ ct_meta, uint32_t* __restrict__ tab, uint32_t tab_stride) {
     __shared__ uint32_t off[AVN_GRAPH_COLOR_COUNT + 1];
     if (threadIdx.x == 0) {
         uint32_t a = 0;
@@ -876,10 +889,65 @@ __global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __res
     if (m >= total || m >= off[AVN_GRAPH_COLOR_COUNT]) return;
     uint32_t lo = 0, hi = AVN_GRAPH_COLOR_COUNT;   // colour c: off[c] <= m < off[c + 1]
     while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (off[mid] <= m) lo = mid; else hi = mid; }
-    handles[m] = pg.lists[(size_t)lo * pg.list_stride + (m - off[lo])];
+    const uint32_t cid = pg.lists[(size_t)lo * pg.list_stride + (m - off[lo])];
+    if (!tab || lo == (uint32_t)AVN_COLOR_OVERFLOW_INDEX) { handles[m] = cid; return; }   // list order: the overflow colour is solved serially in it
+    const int2 b = pg.bodies[cid];
+    const uint32_t kb = (ct_meta[cid].z & AVN_CP_STATIC1) ? (uint32_t)b.y : (uint32_t)b.x;
+    if (kb >= tab_stride || atomicCAS(&tab[(size_t)lo * tab_stride + kb], PG_NONE, cid) != PG_NONE) {
+        const uint32_t k = atomicAdd(&pg.ctr[PGC_SORT_DUP + lo], 1u);
+        handles[off[lo + 1] - 1u - k] = cid;
+    }
 }
-void launch_pg_build_handles(const PG& pg, uint32_t* handles, uint32_t* color_offsets, uint32_t total, hipStream_t s) {
-    hipLaunchKernelGGL(k_pg_build_handles, dim3((total + 255) / 256 + 1), dim3(256), 0, s, pg, handles, color_offsets, total);
+#define PG_SORT_CHUNK 2048u
+__global__ __launch_bounds__(256) void k_pg_sort_count(PG pg, const uint32_t* __restrict__ tab, uint32_t tab_stride, uint32_t n_chunks, uint32_t* __restrict__ cnt) {
+    __shared__ uint32_t ws[4];
+    const uint32_t chunk = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+    const uint4* p = reinterpret_cast<const uint4*>(tab + (size_t)c * tab_stride + (size_t)chunk * PG_SORT_CHUNK) + 2u * t;
+    const uint4 a = p[0], b = p[1];
+    uint32_t s = (a.x != PG_NONE) + (a.y != PG_NONE) + (a.z != PG_NONE) + (a.w != PG_NONE) + (b.x != PG_NONE) + (b.y != PG_NONE) + (b.z != PG_NONE) + (b.w != PG_NONE);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += (uint32_t)__shfl_xor((int)s, o);
+    if ((t & 63u) == 0u) ws[t >> 6] = s;
+    __syncthreads();
+    if (t == 0u) {
+        cnt[c * n_chunks + chunk] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        if (chunk == 0u) pg.ctr[PGC_SORT_DUP + c] = 0u;   // (k_pg_build_handles of this batch is done with it; the next batch starts at zero)
+    }
+}
+__global__ __launch_bounds__(256) void k_pg_sort_emit(PG pg, uint32_t* __restrict__ tab, uint32_t tab_stride, uint32_t n_chunks, const uint32_t* __restrict__ cnt, uint32_t* __restrict__ handles) {
+    __shared__ uint32_t ws[4];
+    __shared__ uint32_t s_base;
+    const uint32_t chunk = blockIdx.x, c = blockIdx.y, t = threadIdx.x;
+    if (cnt[c * n_chunks + chunk] == 0u) return;   // (block-uniform: an empty chunk has nothing to write and nothing to clean)
+    uint32_t before = 0u;
+    for (uint32_t j = t; j < chunk; j += 256u) before += cnt[c * n_chunks + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) before += (uint32_t)__shfl_xor((int)before, o);
+    if ((t & 63u) == 0u) ws[t >> 6] = before;
+    __syncthreads();
+    if (t == 0u) s_base = pg.ctr[PGC_OFFSETS + c] + ((ws[0] + ws[1]) + (ws[2] + ws[3]));
+    __syncthreads();   // (ws is reused by sc_block_excl, which starts with its own writes after this barrier)
+    uint4* p = reinterpret_cast<uint4*>(tab + (size_t)c * tab_stride + (size_t)chunk * PG_SORT_CHUNK) + 2u * t;
+    const uint4 a = p[0], b = p[1];
+    const uint32_t v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    uint32_t s = 0u;
+#pragma unroll
+    for (uint32_t k = 0; k < 8u; ++k) s += v[k] != PG_NONE;
+    uint32_t tile_sum;
+    uint32_t pos = s_base + sc_block_excl(s, &tile_sum);
+    if (s) {
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) if (v[k] != PG_NONE) handles[pos++] = v[k];
+        p[0] = make_uint4(PG_NONE, PG_NONE, PG_NONE, PG_NONE); p[1] = make_uint4(PG_NONE, PG_NONE, PG_NONE, PG_NONE);
+    }
+}
+uint32_t pg_sort_stride(uint32_t n_bodies) { return ((n_bodies + PG_SORT_CHUNK - 1u) / PG_SORT_CHUNK) * PG_SORT_CHUNK; }
+void launch_pg_build_handles(const PG& pg, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t s) {
+    const uint32_t stride = pg_sort_stride(n_bodies), n_chunks = stride / PG_SORT_CHUNK;
+    hipLaunchKernelGGL(k_pg_build_handles, dim3((total + 255) / 256 + 1), dim3(256), 0, s, pg, handles, color_offsets, total, ct_meta, sort_tab, stride);
+    if (!sort_tab || !n_chunks) return;
+    hipLaunchKernelGGL(k_pg_sort_count, dim3(n_chunks, AVN_COLOR_OVERFLOW_INDEX), dim3(256), 0, s, pg, sort_tab, stride, n_chunks, sort_cnt);
+    hipLaunchKernelGGL(k_pg_sort_emit, dim3(n_chunks, AVN_COLOR_OVERFLOW_INDEX), dim3(256), 0, s, pg, sort_tab, stride, n_chunks, sort_cnt, handles);
 }
 
 // ---- ContactGraph::pair_set rebuilt from the live rows (after growth, or when tombstones pile up) ------------------------------

@@ -86,6 +86,8 @@
         pg.ctr = b_pg_ctr.as<uint32_t>();
         HIPCHK(hipMemset(pg.ctr, 0, PGC_WORDS * 4));
         pg_bcol_words = 0;
+        pg_batch_open = false;
+        if (b_pg_sort_tab.p) HIPCHK(hipMemset(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap));
         if ((st = pg_bcol_grow()) != AVN_OK) return st;
         HIPCHK(hipMemset(pg.bcol, 0, (size_t)pg_bcol_words * 4));
         if ((st = pg_upload_ent2slot()) != AVN_OK) return st;
@@ -180,6 +182,9 @@
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));   // (an aborted batch never reached k_pg_build_handles, which cleans these)
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream));
+        HIPCHK(hipMemsetAsync(pg.ctr + PGC_SORT_DUP, 0, AVN_GRAPH_COLOR_COUNT * 4, stream));
+        if (b_pg_sort_tab.p) HIPCHK(hipMemsetAsync(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap, stream));
+        pg_batch_open = false;
         HIPCHK(hipStreamSynchronize(stream));
         if (h_pg_error) *h_pg_error = 0;
         return AVN_ERR_STATE;
@@ -192,8 +197,36 @@
     // One batch of ConstraintGraph ops through the device pipeline: ops from the rows' status changes (the status loop; list_cids == NULL) or
     // from a list (SleepIslands / WakeIslands, world/sleeping.hpp) -> body-sorted entries -> greedy colours as dataflow -> masks -> colour
     // buckets -> exact swap_remove replay -> (pair removals) -> the colours' lengths back to the host -> the concatenated handle list.
+    // The scoped counters of an op batch (replay buckets, the colouring's tile ticket, the removal count, the sort table) are left clean by the batch's own
+    // last kernels.  A batch that ended early -- an allocation failure, a device error word, a failed wait -- never reached them: the next one starts
+    // with stale bucket counts and tile tickets, i.e. wrong colour lists with no error raised.  `pg_batch_open` is set when a batch's first kernel
+    // (k_pg_scan_classify / k_pg_ops_from_list) is about to be launched and cleared behind k_pg_build_handles; still set at the next begin = clean up here.
+    bool pg_batch_open = false;
+    bool handle_sort = true;          // the solver's body-sorted order inside colours 0..22 (AVN_NO_HANDLE_SORT=1 in `make measure` builds: A/B)
+    DevBuf b_pg_sort_tab, b_pg_sort_cnt;
+    avn_status pg_batch_begin() {
+        if (pg_batch_open) {
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream));
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_SORT_DUP, 0, AVN_GRAPH_COLOR_COUNT * 4, stream));
+            if (b_pg_sort_tab.p) HIPCHK(hipMemsetAsync(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap, stream));
+        }
+        pg_batch_open = true;
+        return AVN_OK;
+    }
+    avn_status pg_sort_ensure() {   // [23][stride] words, all EMPTY between batches (k_pg_sort_emit cleans what k_pg_build_handles wrote)
+        const size_t stride = pg_sort_stride(dw.n_bodies);
+        hipError_t err;
+        const bool fresh = b_pg_sort_tab.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * stride * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (fresh) HIPCHK(hipMemsetAsync(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap, stream));
+        b_pg_sort_cnt.ensure((size_t)AVN_COLOR_OVERFLOW_INDEX * (stride / 2048u) * 4 + 64, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        return AVN_OK;
+    }
     avn_status pg_apply_ops(uint32_t n_ops, uint32_t n_rem, uint32_t n_rows, const uint32_t* list_cids, const uint32_t* list_kinds, double& host_ms) {
         avn_status st;
+        if (list_cids && (st = pg_batch_begin()) != AVN_OK) return st;   // (the status loop's batch was opened in front of k_pg_scan_classify)
         {
             // (ctr[PGC_BUCKET ..] and ctr[PGC_TILE] are zero here: k_pg_build_handles, the last kernel of every batch, leaves them so; the status
             //  loop's ops were classified by k_pg_scan_classify, the scan that counted them)
@@ -264,9 +297,14 @@
             hipError_t err;
             if (b_handles.ensure(std::max<size_t>(M, 1) * 4, err)) graph_valid = false;
             if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, stream);
-            ++launches;
+            // the solver's order inside colours 0..22: by key body (k_graph.hip, round 5) when the manifolds are dense enough in the bodies for the
+            // 23 x n_bodies table walk to be cheaper than what the locality saves (a sparse scene's colour launches are tiny either way)
+            const bool sorted = handle_sort && M >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M;
+            if (sorted && (st = pg_sort_ensure()) != AVN_OK) return st;
+            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, ct.meta, sorted ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
+            launches += sorted ? 3 : 1;
             HIPCHK(hipGetLastError());
+            pg_batch_open = false;
             incidence_dirty = true;
             host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         }
@@ -382,6 +420,7 @@
                 launch_narrow_phase_rows<T>(dw, bp, ct, np_params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
                 ++launches;
             }
+            if ((st = pg_batch_begin()) != AVN_OK) return fail(st);
             launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream);   // ops numbered in ascending ContactId AND classified
             ++launches;
             HIPCHK(hipGetLastError());
@@ -395,6 +434,7 @@
             if (h[2]) return pg_error_report(h[2]);   // raised by the previous step's solver passes (normally already reported by avn_synchronize)
         }
         pipe_stats.last_status_changes = n_ops;
+        if (!n_ops) pg_batch_open = false;   // (no change: k_pg_scan_classify touched none of the batch's counters)
         if (n_ops || total) slp_step_changed = true;
         ++pg_dump_step;
         if (n_ops) {   // ---- the status-change loop: decisions, colours, handle lists ----

@@ -58,10 +58,13 @@
             HIPCHK(hipStreamSynchronize(stream));
             std::memcpy(pipe_offsets, color_offsets, sizeof pipe_offsets);
             pipe_handles.resize(dw.n_manifolds);
-            if (dw.n_manifolds) {
-                HIPCHK(hipMemcpyAsync(pipe_handles.data(), b_handles.p, (size_t)dw.n_manifolds * 4, hipMemcpyDeviceToHost, stream));
-                HIPCHK(hipStreamSynchronize(stream));
+            // GraphColor::manifold_handles, i.e. the bookkeeping's lists in the reference's order (PG::lists) -- not the solver's arrays, whose order
+            // inside colours 0..22 is by key body since round 5 (b_handles; the overflow colour is in list order there too)
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
+                const uint32_t len = color_offsets[c + 1] - color_offsets[c];
+                if (len) HIPCHK(hipMemcpyAsync(pipe_handles.data() + color_offsets[c], pg.lists + (size_t)c * pg.list_stride, (size_t)len * 4, hipMemcpyDeviceToHost, stream));
             }
+            HIPCHK(hipStreamSynchronize(stream));
         }
         std::memcpy(off, pipe_offsets, sizeof pipe_offsets);
         *ids = pipe_handles.data(); *n = pipe_handles.size();
