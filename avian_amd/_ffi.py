@@ -952,7 +952,7 @@ class ConstraintGraph:
 
 
 class avn_islands_result(C.Structure):
-    _fields_ = [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken", "pairs_removed") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
+    _fields_ = [("struct_size", C.c_size_t)] + [(n, t) for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken", "pairs_removed") for n, t in ((name, vp), ("n_" + name, C.c_size_t))]
 
 
 class IslandManager:
@@ -993,6 +993,7 @@ class IslandManager:
 
     def last_result(self):
         r = avn_islands_result()
+        r.struct_size = C.sizeof(avn_islands_result)
         self._chk(self.lib.fn("islands_last_result")(self.handle, C.byref(r)), "islands_last_result")
         out = {}
         for name in ("popped", "pushed", "pairs_slept", "pairs_woken", "bodies_slept", "bodies_woken", "pairs_removed"):

@@ -21,6 +21,15 @@ static thread_local std::string g_create_error;
         catch (...) { w->impl->error = "unexpected C++ exception"; return AVN_ERR_STATE; }           \
     } while (0)
 
+// entry points that can change the state a step starts from (everything but avn_step, avn_synchronize and the *_get / *_download calls)
+#define GUARD_MUT(expr)                                                 \
+    do {                                                                \
+        if (!w || !w->impl) return AVN_ERR_BAD_ARG;                     \
+        try { w->impl->bind(); w->impl->touched(); return w->impl->expr; }               \
+        catch (const std::bad_alloc&) { w->impl->error = "out of host memory"; return AVN_ERR_OOM; } \
+        catch (...) { w->impl->error = "unexpected C++ exception"; return AVN_ERR_STATE; }           \
+    } while (0)
+
 extern "C" {
 
 AVN_API avn_status avn_world_create(const avn_config* cfg, avn_world** out) {
@@ -41,37 +50,37 @@ AVN_API avn_status avn_world_create(const avn_config* cfg, avn_world** out) {
 }
 AVN_API void avn_world_destroy(avn_world* w) { if (w) { if (w->impl) w->impl->bind(); delete w->impl; delete w; } }
 AVN_API const char* avn_last_error(const avn_world* w) { return (w && w->impl) ? w->impl->error.c_str() : g_create_error.c_str(); }
-AVN_API avn_status avn_config_set(avn_world* w, const avn_config* c) { GUARD(config_set(c)); }
-AVN_API avn_status avn_bodies_upload(avn_world* w, const avn_bodies* b) { GUARD(bodies_upload(b)); }
+AVN_API avn_status avn_config_set(avn_world* w, const avn_config* c) { GUARD_MUT(config_set(c)); }
+AVN_API avn_status avn_bodies_upload(avn_world* w, const avn_bodies* b) { GUARD_MUT(bodies_upload(b)); }
 AVN_API avn_status avn_bodies_download(avn_world* w, const avn_bodies_out* o) { GUARD(bodies_download(o)); }
 AVN_API avn_status avn_solver_bodies_download(avn_world* w, const avn_solver_bodies_out* o) { GUARD(solver_bodies_download(o)); }
-AVN_API avn_status avn_manifolds_upload(avn_world* w, const avn_manifolds* m) { GUARD(manifolds_upload(m)); }
+AVN_API avn_status avn_manifolds_upload(avn_world* w, const avn_manifolds* m) { GUARD_MUT(manifolds_upload(m)); }
 AVN_API avn_status avn_impulses_download(avn_world* w, const avn_impulses_out* o) { GUARD(impulses_download(o)); }
 AVN_API avn_status avn_constraints_download(avn_world* w, const avn_constraints_out* o) { GUARD(constraints_download(o)); }
-AVN_API avn_status avn_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { GUARD(distance_joints_upload(j)); }
-AVN_API avn_status avn_joints_upload(avn_world* w, const avn_joints* j) { GUARD(joints_upload(j)); }
+AVN_API avn_status avn_distance_joints_upload(avn_world* w, const avn_distance_joints* j) { GUARD_MUT(distance_joints_upload(j)); }
+AVN_API avn_status avn_joints_upload(avn_world* w, const avn_joints* j) { GUARD_MUT(joints_upload(j)); }
 AVN_API avn_status avn_joints_download(avn_world* w, const avn_joints_out* o) { GUARD(joints_download(o)); }
-AVN_API avn_status avn_colliders_upload(avn_world* w, const avn_colliders* c) { GUARD(colliders_upload(c)); }
-AVN_API avn_status avn_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { GUARD(existing_pairs_upload(k, n)); }
+AVN_API avn_status avn_colliders_upload(avn_world* w, const avn_colliders* c) { GUARD_MUT(colliders_upload(c)); }
+AVN_API avn_status avn_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { GUARD_MUT(existing_pairs_upload(k, n)); }
 AVN_API avn_status avn_pairs_get(avn_world* w, const avn_pair** o, size_t* n) { GUARD(pairs_get(o, n)); }
 AVN_API avn_status avn_aabbs_download(avn_world* w, void* mn, void* mx, uint32_t* e, size_t* n) { GUARD(aabbs_download(mn, mx, e, n)); }
-AVN_API avn_status avn_run_system(avn_world* w, avn_system s) { GUARD(run_system(s)); }
+AVN_API avn_status avn_run_system(avn_world* w, avn_system s) { GUARD_MUT(run_system(s)); }
 AVN_API avn_status avn_step(avn_world* w) { GUARD(step()); }
 AVN_API avn_status avn_synchronize(avn_world* w) { GUARD(synchronize()); }
 AVN_API avn_status avn_timers_get(avn_world* w, avn_timers* t) { GUARD(timers(t)); }
 AVN_API avn_status avn_diagnostics_get(avn_world* w, avn_diagnostics* d) { GUARD(diagnostics(d)); }
-AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD(profile_system(s, r, ms, l)); }
+AVN_API avn_status avn_profile_system(avn_world* w, avn_system s, uint32_t r, double* ms, uint32_t* l) { GUARD_MUT(profile_system(s, r, ms, l)); }
 AVN_API avn_status avn_dynamic_bounds(avn_world* w, double* mn, double* mx) { GUARD(dynamic_bounds(mn, mx)); }
 AVN_API avn_status avn_contact_manifolds(avn_world* w, const avn_shape_pairs* p, const avn_query_manifolds_out* o) { GUARD(contact_manifolds(p, o)); }
-AVN_API avn_status avn_collider_materials_upload(avn_world* w, const avn_collider_materials* m) { GUARD(collider_materials_upload(m)); }
-AVN_API avn_status avn_contact_pairs_add(avn_world* w, const avn_contact_pairs* p) { GUARD(contact_pairs_add(p)); }
-AVN_API avn_status avn_contact_pairs_remove(avn_world* w, const uint32_t* ids, size_t n) { GUARD(contact_pairs_remove(ids, n)); }
-AVN_API avn_status avn_active_pairs_set(avn_world* w, const uint32_t* ids, size_t n) { GUARD(active_pairs_set(ids, n)); }
+AVN_API avn_status avn_collider_materials_upload(avn_world* w, const avn_collider_materials* m) { GUARD_MUT(collider_materials_upload(m)); }
+AVN_API avn_status avn_contact_pairs_add(avn_world* w, const avn_contact_pairs* p) { GUARD_MUT(contact_pairs_add(p)); }
+AVN_API avn_status avn_contact_pairs_remove(avn_world* w, const uint32_t* ids, size_t n) { GUARD_MUT(contact_pairs_remove(ids, n)); }
+AVN_API avn_status avn_active_pairs_set(avn_world* w, const uint32_t* ids, size_t n) { GUARD_MUT(active_pairs_set(ids, n)); }
 AVN_API avn_status avn_contact_changes_get(avn_world* w, const avn_contact_change** o, size_t* n) { GUARD(contact_changes_get(o, n)); }
-AVN_API avn_status avn_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { GUARD(manifold_handles_upload(off, ids)); }
+AVN_API avn_status avn_manifold_handles_upload(avn_world* w, const uint32_t* off, const uint32_t* ids) { GUARD_MUT(manifold_handles_upload(off, ids)); }
 AVN_API avn_status avn_contacts_download(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_out* o) { GUARD(contacts_download(ids, n, o)); }
-AVN_API avn_status avn_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_in* in) { GUARD(contacts_upload(ids, n, in)); }
-AVN_API avn_status avn_pipeline_enable(avn_world* w, int on) { GUARD(pipeline_enable(on)); }
+AVN_API avn_status avn_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, const avn_contacts_in* in) { GUARD_MUT(contacts_upload(ids, n, in)); }
+AVN_API avn_status avn_pipeline_enable(avn_world* w, int on) { GUARD_MUT(pipeline_enable(on)); }
 AVN_API avn_status avn_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { GUARD(pipeline_stats_get(o)); }
 AVN_API avn_status avn_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { GUARD(pipeline_handles_get(off, ids, n)); }
 
@@ -135,20 +144,20 @@ AVN_API avn_status avn_islands_partition(const avn_islands_in* in, int32_t* isla
     } catch (...) { return AVN_ERR_OOM; }
 }
 
-AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD(halo_plan_upload(p)); }
-AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD(run_color_pass(pass, color)); }
+AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD_MUT(halo_plan_upload(p)); }
+AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD_MUT(run_color_pass(pass, color)); }
 AVN_API avn_status avn_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { GUARD(halo_pack(color, peer, out, count)); }
-AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD(halo_unpack(color, peer, in, count)); }
+AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD_MUT(halo_unpack(color, peer, in, count)); }
 AVN_API avn_status avn_islands_get(avn_world* w, uint32_t* island_of_body, uint32_t* n_islands) { GUARD(islands_get(island_of_body, n_islands)); }
 AVN_API avn_status avn_sleep_update(avn_world* w, const avn_sleep_params* p, avn_sleep_stats* st) { GUARD(sleep_update(p, st)); }
 AVN_API avn_status avn_sleep_get(avn_world* w, const avn_sleep_out* o) { GUARD(sleep_get(o)); }
-AVN_API avn_status avn_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(sleep_reset(bodies, n)); }
+AVN_API avn_status avn_sleep_reset(avn_world* w, const uint32_t* bodies, size_t n) { GUARD_MUT(sleep_reset(bodies, n)); }
 AVN_API avn_status avn_bounds_exchange(avn_world* w, double* bounds, uint32_t cap_ranks, uint32_t* n_ranks, uint32_t* overlaps, uint32_t cap_overlaps, uint32_t* n_overlaps) { GUARD(bounds_exchange(bounds, cap_ranks, n_ranks, overlaps, cap_overlaps, n_overlaps)); }
-AVN_API avn_status avn_sleeping_enable(avn_world* w, const avn_sleep_params* p) { GUARD(sleeping_enable(p)); }
+AVN_API avn_status avn_sleeping_enable(avn_world* w, const avn_sleep_params* p) { GUARD_MUT(sleeping_enable(p)); }
 AVN_API avn_status avn_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { GUARD(sleeping_stats_get(o)); }
 AVN_API avn_status avn_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { GUARD(sleeping_state_get(o)); }
-AVN_API avn_status avn_wake_bodies(avn_world* w, const uint32_t* bodies, size_t n) { GUARD(wake_bodies(bodies, n)); }
-AVN_API avn_status avn_despawn(avn_world* w, const avn_despawn_list* d) { GUARD(despawn(d)); }
+AVN_API avn_status avn_wake_bodies(avn_world* w, const uint32_t* bodies, size_t n) { GUARD_MUT(wake_bodies(bodies, n)); }
+AVN_API avn_status avn_despawn(avn_world* w, const avn_despawn_list* d) { GUARD_MUT(despawn(d)); }
 AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
     try { return avn::comm_unique_id(out, g_create_error); }
     catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }

@@ -1,4 +1,5 @@
 // avn_islands.cpp -- see avn_islands.hpp.  Host C++ (no device code): the island manager of the closed loop and the avn_islands_* C ABI.
+#include <cstring>
 #include "avn_islands.hpp"
 
 #include <algorithm>
@@ -391,11 +392,14 @@ avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_
     return AVN_OK;
 }
 avn_status IslandManager::last_result(avn_islands_result* o) const {
-    if (!o) return AVN_ERR_BAD_ARG;
-    o->popped = popped_.data(); o->n_popped = popped_.size(); o->pushed = pushed_.data(); o->n_pushed = pushed_.size();
-    o->pairs_slept = pairs_slept_.data(); o->n_pairs_slept = pairs_slept_.size(); o->pairs_woken = pairs_woken_.data(); o->n_pairs_woken = pairs_woken_.size();
-    o->bodies_slept = bodies_slept_.data(); o->n_bodies_slept = bodies_slept_.size(); o->bodies_woken = bodies_woken_.data(); o->n_bodies_woken = bodies_woken_.size();
-    o->pairs_removed = pairs_removed_.data(); o->n_pairs_removed = pairs_removed_.size();
+    if (!o || o->struct_size < 2 * sizeof(size_t) || o->struct_size > 4096) return AVN_ERR_BAD_ARG;
+    avn_islands_result r;
+    r.struct_size = o->struct_size;
+    r.popped = popped_.data(); r.n_popped = popped_.size(); r.pushed = pushed_.data(); r.n_pushed = pushed_.size();
+    r.pairs_slept = pairs_slept_.data(); r.n_pairs_slept = pairs_slept_.size(); r.pairs_woken = pairs_woken_.data(); r.n_pairs_woken = pairs_woken_.size();
+    r.bodies_slept = bodies_slept_.data(); r.n_bodies_slept = bodies_slept_.size(); r.bodies_woken = bodies_woken_.data(); r.n_bodies_woken = bodies_woken_.size();
+    r.pairs_removed = pairs_removed_.data(); r.n_pairs_removed = pairs_removed_.size();
+    std::memcpy(o, &r, std::min(o->struct_size, sizeof r));   // (only what the caller's version of the struct holds)
     return AVN_OK;
 }
 avn_status IslandManager::stats(avn_islands_stats* o) const {

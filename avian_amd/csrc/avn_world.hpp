@@ -57,6 +57,7 @@ struct WorldBase {
     std::string error;
     virtual ~WorldBase() {}
     virtual void bind() = 0;  // make the world's device current on the calling thread
+    virtual void touched() {}  // called by every entry point that can change the world's state other than avn_step (ends the sleeping world's identity steps)
     virtual avn_status config_set(const avn_config*) = 0;
     virtual avn_status bodies_upload(const avn_bodies*) = 0;
     virtual avn_status bodies_download(const avn_bodies_out*) = 0;

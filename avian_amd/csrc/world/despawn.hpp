@@ -11,6 +11,7 @@
 // status loop's (pg_apply_ops: exact swap_remove replay).  Then the rows are cleared, their PairKeys tombstoned, their ids merged into the
 // sorted free list, and every body index the library holds is renumbered for the host's compacted arrays.
     bool despawn_needs_bodies = false, despawn_needs_colliders = false;
+    bool despawn_broken = false;   // an avn_despawn failed after its first mutation: ContactGraph / islands are half-updated, only a restart of the closed loop clears it
     uint32_t despawn_expected_bodies = 0;
     DevBuf b_dsp_a, b_dsp_b;
 
@@ -19,6 +20,14 @@
         if (!d || d->struct_size != sizeof(avn_despawn_list) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
         if (!pipe_on || !pipe_dev) { error = "despawn: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
+        if (despawn_broken) { error = "despawn: an earlier avn_despawn failed half-way; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
+        const avn_status ds = despawn_body(d);
+        if (ds != AVN_OK && despawn_mutating) despawn_broken = true;
+        despawn_mutating = false;
+        return ds;
+    }
+    bool despawn_mutating = false;
+    avn_status despawn_body(const avn_despawn_list* d) {
         const uint32_t n_old = dw.n_bodies, C = bp.n_colliders;
         std::vector<uint8_t> gone_body(n_old, 0);
         for (uint32_t i = 0; i < d->n_bodies; ++i) {
@@ -86,6 +95,8 @@
         auto newest_first = [&](uint32_t a, uint32_t b) { return stamp_of(a) > stamp_of(b); };
         for (auto& v : out_of) std::sort(v.begin(), v.end(), newest_first);
         for (auto& v : in_of) std::sort(v.begin(), v.end(), newest_first);
+        // (everything above only reads; from here on a failure leaves the bookkeeping half-updated: despawn() marks the loop as broken)
+        despawn_mutating = true;
         // ---- walk the units in order; pops accumulate into one op batch until a WakeIslands with an effect has to run in between ----
         std::vector<uint8_t> edge_done(recs.size(), 0);
         std::unordered_map<uint32_t, uint32_t> rec_of;   // contact id -> record (built when a wake makes it necessary)

@@ -87,6 +87,7 @@
         HIPCHK(hipMemset(pg.ctr, 0, PGC_WORDS * 4));
         pg_bcol_words = 0;
         pg_batch_open = false;
+        despawn_needs_bodies = despawn_needs_colliders = despawn_broken = false; despawn_expected_bodies = 0;   // a fresh loop owes no upload
         if (b_pg_sort_tab.p) HIPCHK(hipMemset(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap));
         if ((st = pg_bcol_grow()) != AVN_OK) return st;
         HIPCHK(hipMemset(pg.bcol, 0, (size_t)pg_bcol_words * 4));
@@ -313,6 +314,9 @@
     avn_status pipeline_step_device() {
         avn_status st;
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "avn_step: avn_despawn must be followed by avn_bodies_upload and avn_colliders_upload of what remains"; return AVN_ERR_STATE; }
+        if (despawn_broken) { error = "avn_step: an avn_despawn failed half-way and left the contact bookkeeping inconsistent; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
+        // whatever ends this step early must not leave the next one believing that prepare_solver_bodies already ran or that the slot table is being cleared
+        struct StepGuard { World* w; bool ok = false; ~StepGuard() { if (!ok) { w->bodies_prepared_early = false; w->slot_clear_pending = false; w->bs = w->stream; } } } step_guard{this};
         launches = 0;
         if (slp_on && slp_world_idle) {   // nothing is awake and the last step proved the state stationary: the step is the identity (world/sleeping.hpp)
             for (hipEvent_t e : ev) HIPCHK(hipEventRecord(e, stream));
@@ -460,6 +464,7 @@
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
         last_timers.kernel_launches = launches;
+        step_guard.ok = true;
         return pg_error_fetch();
     }
     // the overflow colour's CSR + ranks, and the slot table of the other colours, from the gathered manifold arrays (all on the device)

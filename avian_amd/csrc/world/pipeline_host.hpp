@@ -11,6 +11,7 @@
             HIPCHK(hipStreamSynchronize(stream));
             if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
             pipe_dev = false; pipe_on = false;
+            despawn_needs_bodies = despawn_needs_colliders = despawn_broken = false; despawn_expected_bodies = 0;   // (the restart path after avn_despawn: any upload is welcome again)
             contact_keys_live = false; h_live_keys.clear();
             avn_status st = rebuild_pair_set(n_pair_keys);   // only the keys the host uploaded / collected outside the closed loop remain
             if (st != AVN_OK) return st;

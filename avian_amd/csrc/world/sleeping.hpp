@@ -20,6 +20,7 @@
     // contacts are new (a non-touching pair may start touching and wake the island again: DESIGN.md 4.8's flip-flop).  A step that STARTED with
     // everything asleep and changed nothing (no new pair, no status change, nothing woken) proves the state stationary.
     bool slp_world_idle = false, slp_step_started_asleep = false, slp_step_changed = false;
+    void touched() override { slp_world_asleep = slp_world_idle = false; }   // (avn_abi.cpp: every state-changing entry point other than avn_step)
     IslandManager isl;
     SleepParams<T> slp_k;
     float slp_time_to_sleep = 0.5f;

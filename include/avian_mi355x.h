@@ -809,6 +809,8 @@ AVN_API avn_status AVN_FN(islands_sleep_body)(avn_island_manager* m, uint32_t bo
  * popped (SleepIslands) and pushed (WakeIslands), contact ids moved to the sleeping / the active pair set, bodies put to sleep / woken.
  * Pointers stay valid until the next call on the manager. */
 typedef struct avn_islands_result {
+    size_t struct_size;      /* in: sizeof(avn_islands_result) as the CALLER's header declares it; the library writes no byte beyond it (the struct grew in
+                                round 4 -- pairs_removed -- and may grow again: a host built against an older header keeps working) */
     const uint32_t* popped;  size_t n_popped;
     const uint32_t* pushed;  size_t n_pushed;
     const uint32_t* pairs_slept; size_t n_pairs_slept;    /* ContactEdgeFlags::SLEEPING set (every touching pair, constraint-generating or not) */
