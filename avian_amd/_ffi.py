@@ -254,7 +254,7 @@ ABI_SYMBOLS = [
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
-    "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get",
+    "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get", "pipeline_new_pair_ids_get",
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
     "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
     "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies",
@@ -338,6 +338,7 @@ class Library:
         f("pipeline_enable").argtypes = [vp, C.c_int]
         f("pipeline_stats_get").argtypes = [vp, vp]
         f("pipeline_handles_get").argtypes = [vp, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("pipeline_new_pair_ids_get").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
 
     def fn(self, name: str):
         return getattr(self.dll, self.prefix + name)
@@ -736,6 +737,12 @@ class World:
         st = avn_pipeline_stats()
         self._check(self.lib.fn("pipeline_stats_get")(self.handle, C.byref(st)))
         return st
+
+    def pipeline_new_pair_ids(self) -> np.ndarray:
+        """ContactIds of the last closed-loop step's new pairs, entry i for pair i of ``pairs_get`` (``avn_pipeline_new_pair_ids_get``)."""
+        p, n = vp(), C.c_size_t()
+        self._check(self.lib.fn("pipeline_new_pair_ids_get")(self.handle, C.byref(p), C.byref(n)))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), (n.value,)).copy() if n.value else np.zeros(0, np.uint32)
 
     def pipeline_handles(self):
         off = np.zeros(GRAPH_COLOR_COUNT + 1, np.uint32)

@@ -83,6 +83,7 @@ AVN_API avn_status avn_contacts_upload(avn_world* w, const uint32_t* ids, size_t
 AVN_API avn_status avn_pipeline_enable(avn_world* w, int on) { GUARD_MUT(pipeline_enable(on)); }
 AVN_API avn_status avn_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { GUARD(pipeline_stats_get(o)); }
 AVN_API avn_status avn_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { GUARD(pipeline_handles_get(off, ids, n)); }
+AVN_API avn_status avn_pipeline_new_pair_ids_get(avn_world* w, const uint32_t** ids, size_t* n) { GUARD(pipeline_new_pair_ids_get(ids, n)); }
 
 // Interaction islands + x-slab assignment (host integer work; see the header).  Union-find with path halving; islands
 // are numbered by their smallest body index; slabs cut the islands, ordered by mean x then id, at equal cumulative weight.

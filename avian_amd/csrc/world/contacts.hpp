@@ -152,6 +152,7 @@
     }
     avn_status contact_changes_get(const avn_contact_change** out, size_t* n) override {
         if (!out || !n) return AVN_ERR_BAD_ARG;
+        if (pipe_on && pipe_dev) { const avn_status st = pipeline_device_changes_fetch(); if (st != AVN_OK) return st; }
         *out = h_changes.data(); *n = h_changes.size();
         return AVN_OK;
     }

@@ -386,8 +386,7 @@
                 if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return fail(st);   // (growing synchronises the world's stream first: the launch over the old rows is done)
                 if (np_overlap) HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_old, 0));               // nothing below may touch a row while that launch runs
                 if ((st = pg_pair_set_reserve(pgm_next_id, total)) != AVN_OK) return fail(st);
-                pg.new_ids = nullptr;
-                if (slp_on) {   // the island manager's edge lists: (ContactId, collider1, collider2) of every new pair, in emission order
+                {   // the ids of the new pairs in emission order: the island manager's edge lists (sleeping on), avn_pipeline_new_pair_ids_get (a host's events)
                     hipError_t e2;
                     b_pg_new_ids.ensure((size_t)total * 4, e2);
                     if (e2 != hipSuccess) { error = "hipMalloc failed"; return fail(AVN_ERR_OOM); }

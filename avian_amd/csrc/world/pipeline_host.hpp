@@ -71,6 +71,41 @@
         *ids = pipe_handles.data(); *n = pipe_handles.size();
         return AVN_OK;
     }
+    // The ids of the last step's new pairs, in the order of avn_pairs_get (host pipeline: recorded as they are handed out; device: PG::new_ids)
+    std::vector<uint32_t> h_new_pair_ids;
+    avn_status pipeline_new_pair_ids_get(const uint32_t** ids, size_t* n) override {
+        if (!ids || !n) return AVN_ERR_BAD_ARG;
+        if (!pipe_on) { error = "pipeline_new_pair_ids_get: needs avn_pipeline_enable"; return AVN_ERR_STATE; }
+        if (pipe_dev) {
+            HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
+            h_new_pair_ids.resize(last_timers.pair_count);
+            if (last_timers.pair_count) HIPCHK(hipMemcpy(h_new_pair_ids.data(), pg.new_ids, (size_t)last_timers.pair_count * 4, hipMemcpyDeviceToHost));
+        }
+        *ids = h_new_pair_ids.data(); *n = h_new_pair_ids.size();
+        return AVN_OK;
+    }
+    // NarrowPhase::update's status changes of the last closed-loop step as avn_contact_change records (device loop: the op arrays the status scan
+    // left, or their pinned copy when the island manager read them; decoded from the packed change word)
+    avn_status pipeline_device_changes_fetch() {
+        const uint32_t n = pipe_stats.last_status_changes;
+        h_changes.resize(n);
+        if (!n) return AVN_OK;
+        std::vector<uint32_t> buf;
+        const uint32_t *cid, *chg;
+        if (slp_on && pin_slp_ops.p) { cid = (const uint32_t*)pin_slp_ops.p; chg = cid + n; HIPCHK(hipStreamSynchronize(stream)); }
+        else {
+            HIPCHK(hipStreamSynchronize(stream));
+            buf.resize(2 * (size_t)n);
+            HIPCHK(hipMemcpy(buf.data(), pg.op_cid, (size_t)n * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(buf.data() + n, pg.op_chg, (size_t)n * 4, hipMemcpyDeviceToHost));
+            cid = buf.data(); chg = cid + n;
+        }
+        for (uint32_t k = 0; k < n; ++k) {
+            const uint32_t w = chg[k];
+            h_changes[k] = avn_contact_change{cid[k], w & 0xFFFFu, (int32_t)((w >> 24) & 0xFFu) - 128, (w >> 16) & 0xFFu};
+        }
+        return AVN_OK;
+    }
     static bool pbit_get(const std::vector<uint64_t>& s, uint32_t i) { return (i >> 6) < s.size() && ((s[i >> 6] >> (i & 63)) & 1ull); }
     static void pbit_set(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) >= s.size()) s.resize((i >> 6) + 1, 0ull); s[i >> 6] |= 1ull << (i & 63); }
     static void pbit_unset(std::vector<uint64_t>& s, uint32_t i) { if ((i >> 6) < s.size()) s[i >> 6] &= ~(1ull << (i & 63)); }
@@ -121,6 +156,7 @@
         HIPCHK(hipEventRecord(ev[1], stream));
         auto t0 = std::chrono::steady_clock::now();
         // ContactGraph::add_edge_and_key_with + IdPool::alloc_id for every new pair, in emission order
+        h_new_pair_ids.clear();
         if (!h_pairs.empty()) {
             size_t n = h_pairs.size();
             std::vector<uint32_t> ids(n), c1(n), c2(n), fl(n);
@@ -137,6 +173,7 @@
             }
             avn_contact_pairs cp{(uint32_t)n, ids.data(), c1.data(), c2.data(), fl.data()};
             if ((st = contact_pairs_add(&cp)) != AVN_OK) return st;
+            h_new_pair_ids = ids;
             pipe_stats.pairs_added += n;
             pipe_active_dirty = true;
         }

@@ -571,6 +571,11 @@ AVN_API avn_status AVN_FN(pipeline_enable)(avn_world* w, int on);
 AVN_API avn_status AVN_FN(pipeline_stats_get)(avn_world* w, avn_pipeline_stats* out);
 /* the colour lists the pipeline holds: offsets[25] and the contact ids (buffer owned by the world) */
 AVN_API avn_status AVN_FN(pipeline_handles_get)(avn_world* w, uint32_t* color_offsets, const uint32_t** contact_id, size_t* n_out);
+/* The ContactIds the loop gave the LAST step's new pairs (IdPool::alloc_id in emission order), entry i for pair i of avn_pairs_get: what a host that mirrors
+ * the ContactGraph keys its own edge list by (Avian's CollisionStart / CollisionEnd / CollidingEntities are rebuilt from these and avn_contact_changes_get:
+ * collision/narrow_phase/system_param.rs:141-389).  In the closed loop avn_contact_changes_get returns the status changes of the last step's narrow phase,
+ * ascending ContactId; both buffers are owned by the world and valid until the next call on it (call them right after avn_step, before avn_despawn). */
+AVN_API avn_status AVN_FN(pipeline_new_pair_ids_get)(avn_world* w, const uint32_t** contact_ids, size_t* n);
 
 /* ---- level-2 sharding: ONE contact island split over several worlds (x-slabs), SURVEY.md section 8(e) ---------------------------------
  * Every world holds the manifolds it OWNS (those whose body1 -- body2 when body1 is static -- lies in its slab), the bodies they touch and

@@ -10,7 +10,8 @@
 //!         // otherwise; disable it only with an explicit `Mi355xMode::ClosedLoop`
 //!         .disable::<IntegratorPlugin>()      // src/dynamics/integrator/mod.rs:45-88
 //!         .disable::<SolverPlugin>()          // src/dynamics/solver/plugin.rs:88-151
-//!         .disable::<XpbdSolverPlugin>()      // src/dynamics/solver/xpbd/plugin.rs:21-110
+//!         .disable::<XpbdSolverPlugin>()      // src/dynamics/solver/xpbd/plugin.rs:21-110: joints.rs uploads all five joint types with JointDamping /
+//!                                             // JointCollisionDisabled and writes JointForces back
 //!         .add(Mi355xPhysicsPlugin::default()),
 //! );
 //! ```
@@ -19,8 +20,22 @@
 //! (the mechanism of crates/avian3d/examples/custom_broad_phase.rs:63-72), so everything else in Avian keeps its place.
 //!
 //! Layers: [`world::Mi355xWorld`] is the safe owner of the `avn_world*`; [`staging::Staging`] turns ECS queries into the
-//! Structure-of-Arrays the C ABI borrows for the duration of a call; [`plugins`] holds the systems.
+//! Structure-of-Arrays the C ABI borrows for the duration of a call; [`plugins`] holds the systems of the rigid-body path, [`joints`] the
+//! XpbdSolverPlugin replacement, [`closed_loop`] what the device closed loop owes the ECS (collision events, `CollidingEntities`, `Sleeping`).
+//!
+//! Every component the recipe above takes away from Avian has a system here:
+//!
+//! | disabled plugin | what it did | here |
+//! |---|---|---|
+//! | BroadPhasePlugin | `AabbIntervals`, sweep-and-prune, new `ContactEdge`s (honouring `JointCollisionDisabled`) | `plugins::gpu_upload_bodies`, `gpu_broad_phase`; the joint-disabled pairs travel with `joints::gpu_upload_joints` |
+//! | IntegratorPlugin | velocity increments, integrate velocities / positions, speed clamps | inside `avn_step` / `AVN_SYS_SOLVER` (`plugins::gpu_solver`) |
+//! | SolverPlugin | constraint generation, warm start, solve / relax, restitution, impulse store, `joint_damping` | `plugins::gpu_upload_constraints`, `gpu_solver`, `gpu_download` |
+//! | XpbdSolverPlugin | prepare / solve of Fixed, Revolute, Spherical, Prismatic, Distance joints, velocity projection, `JointForces` | `joints::gpu_upload_joints`, `gpu_solver`, `joints::gpu_download_joints` |
+//! | (closed loop only) NarrowPhase's status loop | `CollisionStart` / `CollisionEnd`, `CollidingEntities` | `closed_loop::gpu_closed_loop_events` |
+//! | (closed loop only) island sleeping | `Sleeping`, `SleepTimer`, wake on change | `closed_loop::gpu_closed_loop_sleeping`, `gpu_closed_loop_wake_on_changed` (the library's island manager decides: `avn_sleeping_enable`) |
 
+pub mod closed_loop;
+pub mod joints;
 pub mod plugins;
 pub mod staging;
 pub mod world;

@@ -34,7 +34,9 @@ pub enum Mi355xMode {
     HostNarrowPhase,
     /// Ball / Cuboid colliders only: contact rows live in HBM, `NarrowPhase::update_contacts`, the status-change loop, the
     /// `ConstraintGraph` and the `IdPool` run on the device (`avn_pipeline_enable(1)`); per step only new pairs and body state cross
-    /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_contact_changes_get` by `gpu_closed_loop_events`.
+    /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_pipeline_new_pair_ids_get` + `avn_contact_changes_get` by
+    /// `closed_loop::gpu_closed_loop_events`; sleeping is the library's own island manager (`avn_sleeping_enable`), mirrored into `Sleeping` /
+    /// `SleepTimer` by `closed_loop::gpu_closed_loop_sleeping`.
     /// `CollisionHooks` (src/collision/hooks.rs:147-186) cannot run on the device: while any uploaded collider carries
     /// `ActiveCollisionHooks` the plugin runs the step in `HostNarrowPhase` mode instead (`effective_mode`), where Avian's own narrow phase
     /// calls `filter_pairs` / `modify_contacts` as always.
@@ -48,7 +50,7 @@ pub struct Mi355xPhysicsPlugin {
 }
 
 #[derive(Resource, Default)]
-struct Mi355xStaging(Staging);
+pub struct Mi355xStaging(pub Staging);
 #[derive(Resource)]
 struct Mi355xSettings { mode: Mi355xMode, warned_hooks: bool }
 impl Mi355xSettings {
@@ -79,6 +81,7 @@ impl Plugin for Mi355xPhysicsPlugin {
             Err(e) => panic!("{e}: do not disable Avian's BroadPhasePlugin / IntegratorPlugin / SolverPlugin / XpbdSolverPlugin on a host without an MI355X"),
         };
         app.insert_resource(world).init_resource::<Mi355xStaging>().insert_resource(Mi355xSettings { mode: self.mode, warned_hooks: false });
+        app.init_resource::<crate::joints::JointStaging>().init_resource::<crate::closed_loop::ContactMirror>().init_resource::<crate::closed_loop::ClosedLoopSleeping>();
         app.init_resource::<SolverDiagnostics>().init_resource::<CollisionDiagnostics>();
 
         // the same sets as the plugins being replaced: src/collision/broad_phase.rs:51-74, src/dynamics/solver/plugin.rs:103-150,
@@ -87,12 +90,20 @@ impl Plugin for Mi355xPhysicsPlugin {
             PhysicsSchedule,
             (
                 (sync_config, gpu_upload_bodies, gpu_broad_phase).chain().in_set(BroadPhaseSystems::CollectCollisions),
+                // XpbdSolverPlugin's PrepareJoints: the step's joint set of all five types, with JointDamping and JointCollisionDisabled
+                crate::joints::gpu_upload_joints.in_set(SolverSystems::PrepareJoints),
                 gpu_upload_constraints.in_set(SolverSystems::PrepareContactConstraints),   // (HostNarrowPhase steps only: checked inside)
                 gpu_solver.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER)
                 gpu_download.in_set(SolverSystems::StoreContactImpulses),
+                crate::joints::gpu_download_joints.in_set(SolverSystems::Writeback),   // writeback_joint_forces::<T> of all five types (xpbd/plugin.rs:242-260)
+                // closed loop only (each returns at once otherwise): the status loop's events, then the library's sleeping verdict into the ECS
+                (crate::closed_loop::gpu_closed_loop_events, crate::closed_loop::gpu_closed_loop_sleeping).chain().after(SolverSystems::StoreContactImpulses),
+                crate::closed_loop::gpu_closed_loop_wake_on_changed.before(BroadPhaseSystems::CollectCollisions),
                 gpu_diagnostics.after(SolverSystems::StoreContactImpulses),
                 // replaces update_sleeping_states (src/dynamics/solver/islands/sleeping.rs:71-83 chains it before sleep_islands): the timers and
                 // the per-island decision come from the device, the commands that act on it stay Avian's own
+                // (HostNarrowPhase steps only: in the closed loop Avian's PhysicsIslands sees no contact -- its narrow phase walks an empty pair list -- and
+                //  the library's own island manager decides, see closed_loop.rs)
                 gpu_sleeping.in_set(PhysicsStepSystems::Sleeping).run_if(resource_exists::<PhysicsIslands>),
             ),
         );
@@ -262,6 +273,7 @@ fn gpu_sleeping(
     mut timers: Query<(&mut SleepTimer, &BodyIslandNode)>, thresholds: Query<(&SleepThreshold, Has<SleepingDisabled>)>,
     mut islands: ResMut<PhysicsIslands>, mut commands: Commands,
 ) {
+    if w.is_closed_loop() { return; }   // the closed loop's sleeping is closed_loop::gpu_closed_loop_sleeping
     let st = &st.0;
     // per-body `SleepThreshold` / `SleepingDisabled` in body order (avn_sleep_params.body_*), the world-level pair is only the fallback
     let (mut lin, mut ang, mut off) = (Vec::with_capacity(st.body_entities.len()), Vec::with_capacity(st.body_entities.len()), Vec::with_capacity(st.body_entities.len()));

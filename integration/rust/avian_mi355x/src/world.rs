@@ -128,6 +128,16 @@ impl Mi355xWorld {
         if n == 0 { &[] } else { unsafe { core::slice::from_raw_parts(p, n) } }
     }
 
+    pub fn is_closed_loop(&self) -> bool { self.closed_loop }
+
+    /// ContactIds the closed loop gave the last step's new pairs, entry i for pair i of [`Self::pairs`] (`avn_pipeline_new_pair_ids_get`).
+    pub fn new_pair_ids(&mut self) -> &[u32] {
+        let (mut p, mut n) = (core::ptr::null(), 0usize);
+        let st = unsafe { ffi::avn_pipeline_new_pair_ids_get(self.raw, &mut p, &mut n) };
+        self.check(st);
+        if n == 0 { &[] } else { unsafe { core::slice::from_raw_parts(p, n) } }
+    }
+
     /// Status changes of the last `AVN_SYS_NARROW_PHASE`, ascending `ContactId` (the order of the status-bit walk,
     /// src/collision/narrow_phase/system_param.rs:141-145).
     pub fn contact_changes(&mut self) -> &[ffi::avn_contact_change] {

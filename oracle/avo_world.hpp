@@ -309,6 +309,7 @@ struct WorldBase {
     virtual avn_status pipeline_enable(int) = 0;
     virtual avn_status pipeline_stats_get(avn_pipeline_stats*) = 0;
     virtual avn_status pipeline_handles_get(uint32_t*, const uint32_t**, size_t*) = 0;
+    virtual avn_status pipeline_new_pair_ids_get(const uint32_t**, size_t*) = 0;
     virtual avn_status sleeping_enable(const avn_sleep_params*) = 0;
     virtual avn_status sleeping_stats_get(avn_sleeping_stats*) = 0;
     virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
@@ -376,6 +377,13 @@ template <class S> struct World : WorldBase {
     avn_status pipeline_enable(int on) override;
     avn_status pipeline_stats_get(avn_pipeline_stats* o) override;
     avn_status pipeline_handles_get(uint32_t* off, const uint32_t** ids, size_t* n) override;
+    std::vector<uint32_t> new_pair_ids;   // IdPool::alloc_id results of the last closed-loop step, in emission order (avn_pipeline_new_pair_ids_get)
+    avn_status pipeline_new_pair_ids_get(const uint32_t** ids, size_t* n) override {
+        if (!ids || !n) return AVN_ERR_BAD_ARG;
+        if (!pipe) { error = "pipeline_new_pair_ids_get: needs avn_pipeline_enable"; return AVN_ERR_STATE; }
+        *ids = new_pair_ids.data(); *n = new_pair_ids.size();
+        return AVN_OK;
+    }
     avn_status pipeline_step();
     avn_status pipeline_refresh_handles();
     // ---- persistent islands + sleeping in the closed loop (header: avn_sleeping_enable; avo_islands.hpp) ----
@@ -2196,6 +2204,7 @@ template <class S> avn_status World<S>::pipeline_step() {
     diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
     timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
     auto np_t0 = std::chrono::steady_clock::now();
+    new_pair_ids.clear();
     if (!pairs.empty()) {
         std::vector<uint32_t> ids, c1, c2, fl;
         for (const avn_pair& pr : pairs) {
@@ -2209,6 +2218,7 @@ template <class S> avn_status World<S>::pipeline_step() {
         avn_contact_pairs cp{(uint32_t)ids.size(), ids.data(), c1.data(), c2.data(), fl.data()};
         avn_status st = contact_pairs_add(&cp);
         if (st != AVN_OK) return st;
+        new_pair_ids = ids;
         P.stats.pairs_added += ids.size();
         if (slp) for (size_t i = 0; i < ids.size(); ++i) { st = slp->isl.pair_add(ids[i], c1[i], c2[i]); if (st != AVN_OK) { error = slp->isl.error; return st; } }
     }

@@ -81,6 +81,7 @@ avn_status avo_contacts_upload(avn_world* w, const uint32_t* ids, size_t n, cons
 avn_status avo_pipeline_enable(avn_world* w, int on) { FWD(pipeline_enable(on)); }
 avn_status avo_pipeline_stats_get(avn_world* w, avn_pipeline_stats* o) { FWD(pipeline_stats_get(o)); }
 avn_status avo_pipeline_handles_get(avn_world* w, uint32_t* off, const uint32_t** ids, size_t* n) { FWD(pipeline_handles_get(off, ids, n)); }
+avn_status avo_pipeline_new_pair_ids_get(avn_world* w, const uint32_t** ids, size_t* n) { FWD(pipeline_new_pair_ids_get(ids, n)); }
 avn_status avo_sleeping_enable(avn_world* w, const avn_sleep_params* p) { FWD(sleeping_enable(p)); }
 avn_status avo_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { FWD(sleeping_stats_get(o)); }
 avn_status avo_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { FWD(sleeping_state_get(o)); }

@@ -31,6 +31,10 @@ def compare_step(s, wo, wh, check_rows=False):
             if not np.array_equal(a, b):
                 same_set = np.array_equal(np.sort(a), np.sort(b))
                 raise AssertionError(f"step {s}: colour {c} list differs at {first_diff(a, b)} (same set: {same_set})")
+    # what a host mirrors the loop's ContactGraph from (the Rust layer's collision events): the new pairs' ids and the narrow phase's status changes
+    assert np.array_equal(wo.pipeline_new_pair_ids(), wh.pipeline_new_pair_ids()), f"step {s}: ids of the new pairs differ"
+    co, ch = wo.contact_changes_get(), wh.contact_changes_get()
+    assert len(co) == len(ch) and all(np.array_equal(co[k], ch[k]) for k in co.dtype.names), f"step {s}: status changes differ"
     so, sh = wo.pipeline_stats(), wh.pipeline_stats()
     for f in STATS:
         assert getattr(so, f) == getattr(sh, f), f"step {s}: stats.{f}: oracle {getattr(so, f)} device {getattr(sh, f)}"

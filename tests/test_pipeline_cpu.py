@@ -126,3 +126,30 @@ def test_contacts_upload_round_trip_and_errors():
     bad = {k: v[:1].copy() for k, v in rows.items()}; bad["point_count"][0] = 5
     with pytest.raises(F.AvnError):
         w.contacts_upload(ids[:1], bad)
+
+
+def test_new_pair_ids_and_status_changes_describe_the_contact_graph():
+    """avn_pipeline_new_pair_ids_get + avn_contact_changes_get are enough to mirror the loop's ContactGraph on a host (what the Rust layer builds
+    CollisionStart / CollisionEnd / CollidingEntities from): replaying them reproduces the set of touching pairs the colour lists hold."""
+    bodies, colliders = dropped_boxes(seed=5, n=60)
+    w, _ = make(oracle_lib(), 32, bodies, colliders, 4)
+    w.pipeline_enable()
+    pair_of, touching = {}, set()
+    for s in range(70):
+        w.step()
+        ids, pairs = w.pipeline_new_pair_ids(), w.pairs_get()
+        assert len(ids) == len(pairs)
+        for cid, pr in zip(ids, pairs):
+            assert int(cid) not in pair_of, "an id handed out while still live"
+            pair_of[int(cid)] = (int(pr["collider1"]), int(pr["collider2"]))
+        ch = w.contact_changes_get()
+        assert np.all(np.diff(ch["contact_id"].astype(np.int64)) > 0), "ascending ContactId"
+        for c in ch:
+            cid, fl = int(c["contact_id"]), int(c["flags"])
+            assert cid in pair_of
+            if fl & F.CP_STARTED_TOUCHING: touching.add(cid)
+            if fl & F.CP_STOPPED_TOUCHING: touching.discard(cid)
+            if fl & F.CP_DISJOINT_AABB: touching.discard(cid); del pair_of[cid]
+        _, handles = w.pipeline_handles()
+        assert set(int(h) for h in handles) <= touching, f"step {s}: a constraint handle of a pair the events do not show as touching"
+    assert len(touching) > 50

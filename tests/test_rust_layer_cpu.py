@@ -1,0 +1,85 @@
+"""CPU: the hand-written Rust layer (integration/rust/avian_mi355x, uncompiled here: no Rust toolchain in the image) only names things that exist.
+Every `ffi::avn_*` function, `ffi::avn_*` struct and `ffi::AVN_*` constant it uses must be declared by the generated bindings (avian_mi355x-sys, which
+tests/test_abi_cpu.py checks against include/avian_mi355x.h), every struct literal must name exactly the fields of the C struct, and every system the
+crate's documentation promises for a plugin the recipe disables must exist and be registered by `Mi355xPhysicsPlugin::build`."""
+import os
+import re
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(REPO, "integration", "rust", "avian_mi355x", "src")
+SYS = os.path.join(REPO, "integration", "rust", "avian_mi355x-sys", "src", "lib.rs")
+
+
+def read(name):
+    return open(os.path.join(SRC, name)).read()
+
+
+def sources():
+    return {n: read(n) for n in sorted(os.listdir(SRC)) if n.endswith(".rs")}
+
+
+def test_every_ffi_name_the_layer_uses_is_in_the_generated_bindings():
+    sys_src = open(SYS).read()
+    fns = set(re.findall(r"pub fn (avn_\w+)\(", sys_src))
+    structs = set(re.findall(r"pub struct (avn_\w+)", sys_src)) | set(re.findall(r"pub type (avn_\w+)", sys_src))
+    consts = set(re.findall(r"pub const (AVN_\w+)", sys_src))
+    assert len(fns) > 80 and len(structs) > 20 and len(consts) > 60
+    used = set()
+    for name, src in sources().items():
+        for ident in re.findall(r"(?<![\w:])ffi::(\w+)", src):
+            used.add(ident)
+            assert ident in fns or ident in structs or ident in consts, f"{name}: ffi::{ident} is not declared by avian_mi355x-sys"
+    for must in ("avn_joints_upload", "avn_joints_download", "avn_pipeline_new_pair_ids_get", "avn_contact_changes_get", "avn_sleeping_enable", "avn_sleeping_state_get",
+                 "avn_wake_bodies", "avn_despawn", "avn_step", "avn_bodies_upload", "avn_colliders_upload", "avn_manifolds_upload", "avn_pipeline_enable"):
+        assert must in used, f"the Rust layer never calls {must}"
+
+
+def test_struct_literals_name_the_fields_of_the_c_structs():
+    sys_src = open(SYS).read()
+    fields = {}
+    for m in re.finditer(r"pub struct (avn_\w+) \{(.*?)\n\}", sys_src, re.S):
+        fields[m.group(1)] = set(re.findall(r"pub (\w+):", m.group(2)))
+    checked = 0
+    for name, src in sources().items():
+        for m in re.finditer(r"(?<![\w:])ffi::(avn_\w+) \{", src):
+            struct = m.group(1)
+            if src[:m.start()].rstrip().endswith("->"): continue   # a return type in front of a function body, not a literal
+            depth, i = 1, m.end()
+            while depth and i < len(src):   # the literal's body, nested braces included
+                depth += {"{": 1, "}": -1}.get(src[i], 0); i += 1
+            body = re.sub(r"//[^\n]*", "", src[m.end():i - 1])
+            flat, d = "", 0
+            for ch in body:   # only the literal's own `field:` keys (depth 0)
+                if ch in "({[": d += 1
+                elif ch in ")}]": d -= 1
+                flat += ch if d == 0 else " "
+            keys = set(re.findall(r"(?:^|,)\s*(\w+)\s*(?=:|,|$)", flat))   # `field: value` and the `field,` shorthand
+            if not keys:
+                continue
+            assert struct in fields, f"{name}: ffi::{struct} is not a struct of the bindings"
+            assert keys == fields[struct], f"{name}: ffi::{struct} literal names {sorted(keys ^ fields[struct])} differently from the C struct"
+            checked += 1
+    assert checked >= 8
+
+
+def test_every_promised_system_exists_and_is_registered():
+    src = sources()
+    everything = "\n".join(src.values())
+    lib = src["lib.rs"]
+    promised = set(re.findall(r"`(?:\w+::)?(gpu_\w+)`", lib))
+    assert {"gpu_upload_joints", "gpu_download_joints", "gpu_closed_loop_events", "gpu_closed_loop_sleeping", "gpu_solver", "gpu_broad_phase"} <= promised
+    build = src["plugins.rs"][src["plugins.rs"].index("fn build"):src["plugins.rs"].index("fn sync_config")]
+    for system in promised:
+        assert re.search(rf"fn {system}\(", everything), f"lib.rs promises `{system}`: no such function in the crate"
+        assert system in build, f"`{system}` exists but Mi355xPhysicsPlugin::build never adds it to the schedule"
+    # the recipe disables XpbdSolverPlugin: all five joint types, their damping, their collision switch and their forces must be staged
+    joints = src["joints.rs"]
+    for needed in ("FixedJoint", "RevoluteJoint", "SphericalJoint", "PrismaticJoint", "DistanceJoint", "JointDamping", "JointCollisionDisabled", "JointForces", "JointDisabled"):
+        assert needed in joints, f"joints.rs never mentions {needed}"
+    events = src["closed_loop.rs"]
+    for needed in ("CollisionStart", "CollisionEnd", "CollidingEntities", "Sleeping", "SleepTimer", "SleepingDisabled"):
+        assert needed in events, f"closed_loop.rs never mentions {needed}"
+    # nothing in the crate may name a function that does not exist (round 4: plugins.rs promised a gpu_closed_loop_events that was never written)
+    for name, s in src.items():
+        for mentioned in set(re.findall(r"`(?:\w+::)*(gpu_\w+)`", s)):
+            assert re.search(rf"fn {mentioned}\(", everything), f"{name} mentions `{mentioned}`, which does not exist"
