@@ -5,6 +5,7 @@
 //  - gather kernels (contacts, joints) fetch a body's state in 6 aligned vector loads that are served
 //    by L2 / Infinity Cache (100k bodies x 96 B = 9.6 MB).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -12,6 +13,16 @@
 #include "avn_math.h"
 
 namespace avn {
+
+// Environment switches -- A/B runs of older code paths, debugging aids, test hooks that force rarely taken paths -- exist only in the `make measure`
+// build (-DAVN_MEASURE, csrc/measure/libavian_mi355x.so: what tools/ and the switch tests load through AVN_LIB_PATH).  The release library reads NO
+// environment variable: a stray AVN_* in a user's environment cannot change which code runs.
+#ifdef AVN_MEASURE
+inline const char* avn_env(const char* name) { return std::getenv(name); }
+#else
+inline const char* avn_env(const char*) { return nullptr; }
+#endif
+
 
 // body meta word
 //   bits 0-1  rb_type (AVN_RB_*)      bits 8-13 locked axes     bits 16-23 body_flags   bits 24-31 dominance (i8)

@@ -131,7 +131,7 @@ template <class T> struct World : WorldBase {
     hipEvent_t ev_dgs[DG_SUBSTEPS * DG_PER] = {nullptr};   // per substep: start, after warm start, after solve, after positions, end
     bool dg_stamped[DG_STEP_COUNT] = {false};
     uint32_t dg_substeps = 0; bool dg_np = false;
-    const unsigned EV_FLAGS = getenv("AVN_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence;   // (A/B: the default, fencing events)
+    const unsigned EV_FLAGS = avn_env("AVN_EVENT_SYSTEM_FENCE") ? 0u : (unsigned)hipEventDisableSystemFence;   // (A/B: the default, fencing events)
     void stamp(int id) { if (ev_dg[id]) { (void)hipEventRecord(ev_dg[id], stream); dg_stamped[id] = true; } }
     DW<T> dw;
     BP<T> bp;
@@ -286,12 +286,12 @@ template <class T> struct World : WorldBase {
         if (c->device < 0 || c->device >= ndev) { error = "config.device out of range"; return AVN_ERR_BAD_ARG; }
         HIPCHK(hipSetDevice(c->device));
         cfg.device = c->device;
-        if (const char* e = getenv("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
-        if (const char* e = getenv("AVN_ISLAND_BLOCKS")) island_enabled = atoi(e) != 0;                                  // 0: always the device-wide colour launches
-        if (const char* e = getenv("AVN_ISLAND_CACHE_RECORDS")) island_cache_records = atoi(e) != 0;
-        if (const char* e = getenv("AVN_ISLAND_MAX_MANIFOLDS")) island_max_manifolds = (size_t)strtoull(e, nullptr, 10);
-        if (const char* e = getenv("AVN_ISLAND_MAX_BODIES_TOTAL")) island_max_bodies_total = (size_t)strtoull(e, nullptr, 10);
-        if (const char* e = getenv("AVN_ISLAND_PACK_BODIES")) island_pack_bodies = std::min<uint32_t>(ISLAND_MAX_BODIES, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));
+        if (const char* e = avn_env("AVN_OVERFLOW_LEVEL_THRESHOLD")) overflow_level_threshold = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = avn_env("AVN_ISLAND_BLOCKS")) island_enabled = atoi(e) != 0;                                  // 0: always the device-wide colour launches
+        if (const char* e = avn_env("AVN_ISLAND_CACHE_RECORDS")) island_cache_records = atoi(e) != 0;
+        if (const char* e = avn_env("AVN_ISLAND_MAX_MANIFOLDS")) island_max_manifolds = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = avn_env("AVN_ISLAND_MAX_BODIES_TOTAL")) island_max_bodies_total = (size_t)strtoull(e, nullptr, 10);
+        if (const char* e = avn_env("AVN_ISLAND_PACK_BODIES")) island_pack_bodies = std::min<uint32_t>(ISLAND_MAX_BODIES, std::max<uint32_t>(1u, (uint32_t)strtoul(e, nullptr, 10)));
         // (CU masks -- 64 CUs for the broad phase, 192 for the solver -- were tried for the overlap below and lost: a colour launch
         //  on 192 CUs is 12 % slower than on 256, more than the contention it avoids; tools/cumask_probe.hip)
         HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
@@ -303,9 +303,9 @@ template <class T> struct World : WorldBase {
         // behind which the HOST reads pinned memory -- ev_counters, ev_spin -- keep the default.)
         HIPCHK(hipEventCreateWithFlags(&ev_bp_done, hipEventDisableTiming | EV_FLAGS));
         HIPCHK(hipEventCreateWithFlags(&ev_bp_t0, EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_bp_t1, EV_FLAGS));
-        if (getenv("AVN_NO_BP_OVERLAP")) overlap_bp = false;
+        if (avn_env("AVN_NO_BP_OVERLAP")) overlap_bp = false;
 #ifdef AVN_MEASURE
-        if (getenv("AVN_NO_HANDLE_SORT")) handle_sort = false;   // (A/B: the solver's arrays in the bookkeeping's list order, as before round 5)
+        if (avn_env("AVN_NO_HANDLE_SORT")) handle_sort = false;   // (A/B: the solver's arrays in the bookkeeping's list order, as before round 5)
 #endif
         for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
         for (auto& x : ev_dg) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));
@@ -364,7 +364,7 @@ template <class T> struct World : WorldBase {
         params.restitution_iterations = cfg.restitution_iterations;
         params.match_contacts = cfg.match_contacts;
 #ifdef AVN_MEASURE   // measurement build only (make measure): cut-offs of the narrow phase's kernels (tools/np_phases.sh)
-        params.np_debug = getenv("AVN_NP_DEBUG") ? (uint32_t)atoi(getenv("AVN_NP_DEBUG")) : 0u;
+        params.np_debug = avn_env("AVN_NP_DEBUG") ? (uint32_t)atoi(avn_env("AVN_NP_DEBUG")) : 0u;
 #else
         params.np_debug = 0u;
 #endif

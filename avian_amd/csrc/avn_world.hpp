@@ -14,6 +14,7 @@
 // Everything runs on one HIP stream owned by the world; the substep loop can be replayed from a hipGraph.
 // There is NO CPU fallback: without a gfx950 device world creation fails with AVN_ERR_NO_DEVICE.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <string>

@@ -1129,7 +1129,7 @@ template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<
     // quads: four lanes per body (k_body_warm_start_quad) -- the device closed loop, whose handle lists are in history order (2.78 -> 2.72 ms per settled cfg2
     // step).  With host-uploaded manifolds neighbouring bodies' manifolds are neighbours in the colour-major arrays and the lane-per-body form's gathers
     // coalesce: there the quads LOSE (cfg2 frozen 2 497 -> 2 382 substeps/s, same box), so the caller chooses.
-    static const bool lane_per_body = getenv("AVN_WS_LANE_PER_BODY") && getenv("AVN_WS_LANE_PER_BODY")[0] == '1';   // (A/B: round 3's form everywhere; the results do not depend on it)
+    static const bool lane_per_body = avn_env("AVN_WS_LANE_PER_BODY") && avn_env("AVN_WS_LANE_PER_BODY")[0] == '1';   // (A/B: round 3's form everywhere; the results do not depend on it)
     if (quads && !lane_per_body && w.inc_slot) {
         uint32_t nq = (uint32_t)(((uint64_t)w.n_bodies * 4u + WSQ_THREADS - 1) / WSQ_THREADS);
         nq = ((nq + 7u) / 8u) * 8u;

@@ -735,7 +735,7 @@ __global__ __launch_bounds__(1024) void k_pg_partition_colors(PG pg, uint32_t* _
 }
 void launch_pg_replay(const PG& pg, uint32_t n_ops, hipStream_t s) {
     if (n_ops) hipLaunchKernelGGL(k_pg_partition_colors, dim3(AVN_GRAPH_COLOR_COUNT), dim3(1024), 0, s, pg, pg.ekey_a, n_ops);   // (ekey_a: the colouring's entry buffers are free again)
-    static const bool wave_version = getenv("AVN_PG_REPLAY_WAVE") && getenv("AVN_PG_REPLAY_WAVE")[0] && getenv("AVN_PG_REPLAY_WAVE")[0] != '0';   // (A/B runs)
+    static const bool wave_version = avn_env("AVN_PG_REPLAY_WAVE") && avn_env("AVN_PG_REPLAY_WAVE")[0] && avn_env("AVN_PG_REPLAY_WAVE")[0] != '0';   // (A/B runs)
     if (wave_version) hipLaunchKernelGGL(k_pg_replay, dim3(AVN_GRAPH_COLOR_COUNT), dim3(64), 0, s, pg, pg.ekey_a);
     else hipLaunchKernelGGL(k_pg_replay_wide, dim3(AVN_GRAPH_COLOR_COUNT), dim3(RW_B), 0, s, pg, pg.ekey_a);
 }

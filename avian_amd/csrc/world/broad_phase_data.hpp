@@ -150,7 +150,7 @@
             GROW(b_sweep_hits, sweep_hit_words((uint32_t)cc), sweep_scratch.hits);
             {   // long-interval chunks: every interval may need one slot, plus room for the chunks of scene-spanning ones
                 size_t lcap = cc + 65536;
-                if (const char* e = getenv("AVN_SWEEP_LONG_CAP")) lcap = std::max<size_t>(8, (size_t)strtoull(e, nullptr, 10));   // (tests: force the grow-and-retry path)
+                if (const char* e = avn_env("AVN_SWEEP_LONG_CAP")) lcap = std::max<size_t>(8, (size_t)strtoull(e, nullptr, 10));   // (tests: force the grow-and-retry path)
                 uint8_t* dummy_b;
                 GROW(b_long_items, lcap * sweep_long_item_bytes(), dummy_b);
                 GROW(b_long_counts, lcap, dummy_u); GROW(b_long_off, lcap, dummy_u);

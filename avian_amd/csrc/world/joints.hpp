@@ -173,7 +173,7 @@
     // Per body and per joint the operation sequence is the single stream's: results are bit-identical.  Host-uploaded manifolds only (the
     // bodies of the manifolds are on the host then); joint damping against a body without a SolverBody couples the joints of one type
     // through the shared DUMMY (joint_damping::<T>): no split then.
-    bool groups_dirty = true, groups_active = false, groups_enabled = !(getenv("AVN_NO_ISLAND_STREAMS") && getenv("AVN_NO_ISLAND_STREAMS")[0] && getenv("AVN_NO_ISLAND_STREAMS")[0] != '0');
+    bool groups_dirty = true, groups_active = false, groups_enabled = !(avn_env("AVN_NO_ISLAND_STREAMS") && avn_env("AVN_NO_ISLAND_STREAMS")[0] && avn_env("AVN_NO_ISLAND_STREAMS")[0] != '0');
     JointSchedule sched_solve_main, sched_damp_main, sched_solve_side, sched_damp_side;
     DevBuf b_side_group;
     hipStream_t stream_side = nullptr;

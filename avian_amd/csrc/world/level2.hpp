@@ -12,7 +12,7 @@
     DevBuf b_halo_send, b_halo_recv, b_halo_out, b_halo_in;
     bool halo_on = false;
 #ifdef AVN_MEASURE   // measurement build only (make measure): the default library has no switch that changes results
-    bool bias_skeleton = getenv("AVN_BIAS_SKELETON") != nullptr && getenv("AVN_BIAS_SKELETON")[0] == '1';
+    bool bias_skeleton = avn_env("AVN_BIAS_SKELETON") != nullptr && avn_env("AVN_BIAS_SKELETON")[0] == '1';
 #else
     static constexpr bool bias_skeleton = false;
 #endif

@@ -158,7 +158,7 @@
         std::vector<uint32_t>& parent = isl_parent;
         parent.resize(N);
         bool labelled = false;
-        static const bool host_labels = getenv("AVN_ISLAND_LABELS_HOST") != nullptr;   // A/B: the host union-find below
+        static const bool host_labels = avn_env("AVN_ISLAND_LABELS_HOST") != nullptr;   // A/B: the host union-find below
         if (pipe_dev && slp_on && !host_labels) {
             // sleeping on: the persistent islands ARE a grouping of the awake bodies no manifold crosses (an island pending its split is merely
             // coarser than necessary) -- taken straight from the manager: no labelling kernel, no read-back, no synchronisation

@@ -141,7 +141,7 @@
     // The closed loop reads three counter blocks per step, and the device idles while the host finds out that they arrived: a blocking
     // hipStreamSynchronize costs 20-35 us of that per read (interrupt + wake-up), polling the event 2-3.  AVN_NO_SPIN_SYNC=1: blocking waits.
     hipEvent_t ev_spin = nullptr;
-    bool spin_enabled = !(getenv("AVN_NO_SPIN_SYNC") && getenv("AVN_NO_SPIN_SYNC")[0] && getenv("AVN_NO_SPIN_SYNC")[0] != '0');
+    bool spin_enabled = !(avn_env("AVN_NO_SPIN_SYNC") && avn_env("AVN_NO_SPIN_SYNC")[0] && avn_env("AVN_NO_SPIN_SYNC")[0] != '0');
     hipError_t spin_event(hipEvent_t e) {
         if (!spin_enabled) return hipEventSynchronize(e);
         for (;;) {
@@ -158,11 +158,11 @@
     }
     uint32_t pipe_step_no = 0;   // closed-loop steps taken by this world (measurement aids only)
 #ifdef AVN_MEASURE
-    int np_debug_step = getenv("AVN_NP_DEBUG_STEP") ? atoi(getenv("AVN_NP_DEBUG_STEP")) : -1;
+    int np_debug_step = avn_env("AVN_NP_DEBUG_STEP") ? atoi(avn_env("AVN_NP_DEBUG_STEP")) : -1;
 #else
     static constexpr int np_debug_step = -1;
 #endif
-    bool np_overlap_enabled = !(getenv("AVN_NO_NP_OVERLAP") && getenv("AVN_NO_NP_OVERLAP")[0] && getenv("AVN_NO_NP_OVERLAP")[0] != '0');
+    bool np_overlap_enabled = !(avn_env("AVN_NO_NP_OVERLAP") && avn_env("AVN_NO_NP_OVERLAP")[0] && avn_env("AVN_NO_NP_OVERLAP")[0] != '0');
     uint32_t* h_pg_error = nullptr;   // pinned
     bool pg_error_pending = false;
     avn_status pg_error_fetch() {     // enqueue the read-back behind everything the step launched
@@ -261,14 +261,14 @@
             HIPCHK(spin_sync(stream));
             auto t0 = std::chrono::steady_clock::now();
             if (h[PGC_ERROR]) return pg_error_report(h[PGC_ERROR]);
-            if (getenv("AVN_PG_REPLAY_STATS")) {
+            if (avn_env("AVN_PG_REPLAY_STATS")) {
                 uint32_t d[96];
                 HIPCHK(hipMemcpy(d, pg.ctr + PGC_DBG, sizeof d, hipMemcpyDeviceToHost));
                 std::fprintf(stderr, "[avn replay] colour: ops/iterations/serial/reloads:");
                 for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) if (d[72 + c]) std::fprintf(stderr, " %d:%u/%u/%u/%u", c, d[72 + c], d[c], d[24 + c], d[48 + c]);
                 std::fprintf(stderr, "\n");
             }
-            if (const char* dir = getenv("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
+            if (const char* dir = avn_env("AVN_PG_DUMP")) {   // debugging aid (tools/debug_pg.py): this step's ops as the device saw them
                 std::vector<uint32_t> a(n_ops), b(n_ops), o(n_ops), cnt(32);
                 const uint32_t* order = pg.ekey_a;   // (the colour-partitioned op stream of the replay: contact id | push << 31)
                 std::vector<int2> bd(n_ops);

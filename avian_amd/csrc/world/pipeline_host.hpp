@@ -18,7 +18,7 @@
             if (!on) return AVN_OK;
         }
         // on == 1: the bookkeeping runs on the device (k_graph.hip); on == 2 or AVN_PIPELINE_HOST=1: host structures (round-1 path, kept for A/B runs)
-        const bool want_dev = on == 1 && !getenv("AVN_PIPELINE_HOST");
+        const bool want_dev = on == 1 && !avn_env("AVN_PIPELINE_HOST");
         if (want_dev) {
             for (uint32_t id = 0; id < pipe_pairs.size(); ++id)
                 if (pipe_pairs[id].used) { uint32_t cid = id; avn_status st = contact_pairs_remove(&cid, 1); if (st != AVN_OK) return st; }

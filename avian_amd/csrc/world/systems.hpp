@@ -185,7 +185,7 @@
             return sl;
         }
         if (!graph_valid) {
-            if (getenv("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
+            if (avn_env("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
             drop_graph();
             uint32_t before = launches;
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -360,7 +360,7 @@
         dg_np = false;
         if (pipe_on) return pipe_dev ? pipeline_step_device() : pipeline_step();
         launches = 0;
-        static const bool host_trace = getenv("AVN_HOST_TRACE") != nullptr;   // debugging aid: where the HOST spends a step (us since the call)
+        static const bool host_trace = avn_env("AVN_HOST_TRACE") != nullptr;   // debugging aid: where the HOST spends a step (us since the call)
         const auto ht0 = std::chrono::steady_clock::now();
         auto hus = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count(); };
         double h_bp = 0, h_front = 0, h_wait = 0;
@@ -371,7 +371,7 @@
         }
         const bool overlap = overlap_bp && have_colliders;
         bp_timed = false;
-        static const bool bp_first = getenv("AVN_BP_ENQUEUE_FIRST") != nullptr;   // (A/B: round 2's order)
+        static const bool bp_first = avn_env("AVN_BP_ENQUEUE_FIRST") != nullptr;   // (A/B: round 2's order)
         const bool front_first = overlap && !bp_first;
         if (front_first) {
             // the solver's front only READS the rigid-body components, as the broad phase does: with the broad phase on its own stream the
@@ -411,7 +411,7 @@
         if (host_trace) { HIPCHK(hipEventRecord(trace_ev[2 * (trace_n % TRACE_STEPS) + 1], stream)); ++trace_n; }
         ev_valid = true;
         last_timers.kernel_launches = launches;
-        if (host_trace && getenv("AVN_HOST_TRACE")[0] == '2') std::fprintf(stderr, "[avn host] broad phase enqueued %.0f us, solver front %.0f, counters back %.0f, step enqueued %.0f\n", h_bp, h_front, h_wait, hus());
+        if (host_trace && avn_env("AVN_HOST_TRACE")[0] == '2') std::fprintf(stderr, "[avn host] broad phase enqueued %.0f us, solver front %.0f, counters back %.0f, step enqueued %.0f\n", h_bp, h_front, h_wait, hus());
         return AVN_OK;
     }
     static constexpr uint32_t TRACE_STEPS = 64;
@@ -427,7 +427,7 @@
                 HIPCHK(hipEventElapsedTime(&b, trace_ev[2 * i + 1], trace_ev[2 * i + 2]));
                 span += a; gap += b;
             }
-            if (getenv("AVN_HOST_TRACE")[0] == '3') { std::fprintf(stderr, "[avn trace] spans (ms):"); for (uint32_t i = 0; i < trace_n; ++i) { float a = 0; HIPCHK(hipEventElapsedTime(&a, trace_ev[2 * i], trace_ev[2 * i + 1])); std::fprintf(stderr, " %.3f", a); } std::fprintf(stderr, "\n"); }
+            if (avn_env("AVN_HOST_TRACE")[0] == '3') { std::fprintf(stderr, "[avn trace] spans (ms):"); for (uint32_t i = 0; i < trace_n; ++i) { float a = 0; HIPCHK(hipEventElapsedTime(&a, trace_ev[2 * i], trace_ev[2 * i + 1])); std::fprintf(stderr, " %.3f", a); } std::fprintf(stderr, "\n"); }
             std::fprintf(stderr, "[avn trace] %u steps: mean span %.4f ms, mean gap to the next step's start %.4f ms\n", trace_n - 5, span / (trace_n - 5), gap / (trace_n - 5));
         }
         trace_n = 0;

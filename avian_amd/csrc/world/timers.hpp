@@ -13,7 +13,7 @@
             HIPCHK(hipEventElapsedTime(&c, ev[2], ev[3]));
             HIPCHK(hipEventElapsedTime(&d, ev[3], ev[4]));
             HIPCHK(hipEventElapsedTime(&e, ev[0], ev[4]));
-            if (getenv("AVN_HOST_TRACE")) std::fprintf(stderr, "[avn events] step start -> solver start %.4f ms, prepare %.4f, substeps %.4f, finalize %.4f, whole %.4f\n", a, b, c, d, e);
+            if (avn_env("AVN_HOST_TRACE")) std::fprintf(stderr, "[avn events] step start -> solver start %.4f ms, prepare %.4f, substeps %.4f, finalize %.4f, whole %.4f\n", a, b, c, d, e);
             // overlapped broad phase: its own duration on its own stream (it is NOT a term of step_ms then)
             if (bp_timed) HIPCHK(hipEventElapsedTime(&a, ev_bp_t0, ev_bp_t1));
             last_timers.broad_phase_ms = a; last_timers.prepare_ms = b; last_timers.substeps_ms = c; last_timers.finalize_ms = d;

@@ -386,6 +386,24 @@ def main():
                   "note": "avn_pipeline_enable(1): broad phase -> Ball/Cuboid narrow phase (parry part parity-unpinned) -> status-change loop, greedy colouring, handle lists "
                           "and the overflow colour's order ALL on the device; per step the host reads three counter blocks"}
         del wc
+        # measured HBM-side traffic of the settled closed-loop step next to the algorithmic bytes: two rocprofv3 --pmc passes of
+        # tools/time_closed_loop.py (FETCH_SIZE, WRITE_SIZE separately, kernel-trace only), per-kernel means over the last 10 of 120 steps
+        if not args.no_traffic:
+            try:
+                import subprocess
+                outp = os.path.join(REPO, "gpurun_out", "bench_pmc_closed_loop.json")
+                os.makedirs(os.path.dirname(outp), exist_ok=True)
+                subprocess.run([sys.executable, os.path.join(REPO, "tools", "pmc_closed_loop_tail.py"), outp, "120", "10"], capture_output=True, text=True, timeout=420, stdin=subprocess.DEVNULL)
+                pm = json.load(open(outp))
+                tot = sum((k["fetch_MB_per_launch"] + k["write_MB_per_launch"]) * k["launches_per_step"] for k in pm["kernels"].values())
+                solver = sum((k["fetch_MB_per_launch"] + k["write_MB_per_launch"]) * k["launches_per_step"] for n, k in pm["kernels"].items()
+                             if any(t in n for t in ("k_color_pass", "k_overflow_flow", "k_body_warm_start", "k_integrate_positions")))
+                alg = substeps * (228 * (sc.n - 1) + 1520 * closed["steady_steps_100_119"]["manifolds_at_end"]) / 1e6
+                closed["roofline"]["traffic"] = {"unit": "MB per step", "all_kernels": round(tot, 1), "substep_loop_kernels": round(solver, 1), "algorithmic_substep_loop": round(alg, 1),
+                                                 "substep_loop_over_algorithmic": round(solver / alg, 3), "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in this run (FETCH x 2 on gfx950), steps 110..119"}
+            except Exception as e:  # noqa: BLE001 -- a secondary measurement must not take the line down
+                closed["roofline"]["traffic"] = None
+                closed["roofline"]["traffic_source"] = "profiles/r05_pmc_closed_loop_settled.json (the in-run pass failed: " + str(e)[:120] + ")"
         # ---- the closed loop with persistent islands + sleeping (avn_sleeping_enable): N is not constant any more -- every
         # window reports the awake body count next to its time.  Scene: the reference's own "Many Pyramids 3D" bench (10 x 10 pyramids of base 10:
         # 5 500 boxes in 100 islands, benches/src/dim3/many_pyramids.rs:15-64) plus one box dropped from 35 m onto one pyramid (lands at ~2.7 s):
@@ -530,6 +548,9 @@ def main():
                           "kernel_launches_per_step": tm.kernel_launches},
             "substep_loop_only_substeps_per_s": round(substeps / (tm.substeps_ms / 1e3), 2) if tm.substeps_ms > 0 else None,
             "roofline": roofline,
+            # the same bodies in the device closed loop (real contacts: broad phase -> narrow phase -> bookkeeping -> solver), settled window; `value` above stays the
+            # metric BASELINE.json defines (fixed manifold set), this is the number a user of the closed loop gets
+            "value_closed_loop": (closed or {}).get("substeps_per_s"),
             "solver_iterations_8": iters8,
             "pcie_inclusive": pcie,
             "closed_loop": closed,

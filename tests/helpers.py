@@ -36,6 +36,25 @@ def hip_lib() -> F.Library:
     return avian_amd.load_library()
 
 
+_measure = None
+
+
+def hip_measure_lib() -> F.Library:
+    """The `make measure` build of the product (-DAVN_MEASURE, avian_amd/csrc/measure/): the ONLY build that reads AVN_* environment switches -- the
+    release library ignores the environment (avn_device.h: avn_env).  Tests that force an older or a rarely taken code path through a switch create THAT
+    world on this library; everything else runs on the release build."""
+    global _measure
+    if _measure is None:
+        path = os.path.join(REPO, "avian_amd", "csrc", "measure", "libavian_mi355x.so")
+        assert os.path.exists(path), f"{path} is missing: `make -C avian_amd/csrc measure` (build() does it)"
+        import torch  # noqa: F401  (one HIP runtime per process, as in avian_amd.load_library)
+        _measure = F.Library(path, "avn_")
+    return _measure
+
+
+MEASURE_LIB_PATH = os.path.join(REPO, "avian_amd", "csrc", "measure", "libavian_mi355x.so")
+
+
 def random_unit_quats(rng, n):
     q = rng.normal(size=(n, 4))
     return q / np.linalg.norm(q, axis=1, keepdims=True)

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from avian_amd import scenes
-from helpers import F, compare_dicts, hip_lib, oracle_lib, random_joints
+from helpers import F, compare_dicts, hip_lib, hip_measure_lib, oracle_lib, random_joints
 from test_gpu_configs import setup
 
 pytestmark = pytest.mark.gpu
@@ -38,7 +38,7 @@ def mixed_scene(seed=7):
 def test_side_islands_on_their_own_stream_match_oracle_and_single_stream(bits, use_graph, monkeypatch):
     sc, g = mixed_scene()
     worlds = []
-    for lib, env in ((oracle_lib(), None), (hip_lib(), None), (hip_lib(), "1")):
+    for lib, env in ((oracle_lib(), None), (hip_lib(), None), (hip_measure_lib(), "1")):   # (the switch exists in the `make measure` build only)
         if env:
             monkeypatch.setenv("AVN_NO_ISLAND_STREAMS", env)
         cfg = F.default_config(bits, substeps=4)

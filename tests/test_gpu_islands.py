@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from avian_amd import scenes
-from helpers import F, color_and_upload, compare_dicts, hip_lib, oracle_lib, random_world
+from helpers import F, color_and_upload, compare_dicts, hip_lib, hip_measure_lib, oracle_lib, random_world
 
 pytestmark = pytest.mark.gpu
 TOL = 0.0  # bit-exact
@@ -52,9 +52,10 @@ def test_island_blocks_match_oracle_and_device_wide_path(case, monkeypatch):
         if case == "clusters_small_blocks":
             monkeypatch.setenv("AVN_ISLAND_PACK_BODIES", "40")
     wo = F.World(oracle_lib(), F.default_config(32, **kw))
-    wi = F.World(hip_lib(), F.default_config(32, **kw))
+    # (environment switches exist in the `make measure` build only: the worlds that need one are created on it, the plain island-block world on the release build)
+    wi = F.World(hip_measure_lib() if case == "clusters_small_blocks" else hip_lib(), F.default_config(32, **kw))
     monkeypatch.setenv("AVN_ISLAND_BLOCKS", "0")
-    wd_ = F.World(hip_lib(), F.default_config(32, **kw))
+    wd_ = F.World(hip_measure_lib(), F.default_config(32, **kw))
     monkeypatch.delenv("AVN_ISLAND_BLOCKS")
     for w in (wo, wi, wd_):
         color_and_upload(w, oracle_lib(), wd)

@@ -270,7 +270,8 @@ def test_long_interval_chunk_overflow_grows_and_retries(monkeypatch):
     bodies = dict(position=pos, rotation=np.tile([0, 0, 0, 1.0], (n, 1)), linear_velocity=np.zeros((n, 3)), angular_velocity=np.zeros((n, 3)),
                   inv_mass=np.ones(n), inv_inertia_local=np.tile([6, 0, 0, 6, 0, 6.0], (n, 1)), rb_type=np.zeros(n, np.uint8))
     col = dict(entity_index=np.arange(n, dtype=np.uint32), body=np.arange(n, dtype=np.int32), shape=np.zeros(n, np.uint8), half_extents=np.full((n, 3), 0.5))
-    wo, wh = make_pair(32)
+    from helpers import hip_measure_lib   # (AVN_SWEEP_LONG_CAP is a test hook of the `make measure` build)
+    wo, wh = F.World(oracle_lib(), F.default_config(32)), F.World(hip_measure_lib(), F.default_config(32))
     for w in (wo, wh):
         w.bodies_upload(**bodies); w.colliders_upload(**col)
         w.existing_pairs_upload(np.zeros(0, np.uint64))

@@ -100,7 +100,8 @@ def test_overflow_colour_per_level_launches_match_oracle(monkeypatch):
     monkeypatch.setenv("AVN_OVERFLOW_LEVEL_THRESHOLD", "0")
     sc = scenes.box_stack(7, 7, 7)
     worlds = []
-    for lib in (oracle_lib(), hip_lib()):
+    from helpers import hip_measure_lib   # (AVN_OVERFLOW_LEVEL_THRESHOLD is a test hook of the `make measure` build)
+    for lib in (oracle_lib(), hip_measure_lib()):
         w = F.World(lib, F.default_config(32, substeps=4))
         w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
         w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)

@@ -26,6 +26,6 @@ FROZEN = ["tests/test_gpu_parity.py", "tests/test_gpu_island_streams.py"]
 ], ids=["wave-replay", "serial-narrow-phase-blocking-waits", "fencing-events-bp-first", "single-stream", "lane-per-body-warm-start"])
 def test_parity_slice_with_the_switch_set(env, targets):
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "-p", "no:cacheprovider", *targets], capture_output=True, text=True, timeout=600, cwd=REPO,
-                       env=dict(os.environ, **env))
+                       env=dict(os.environ, AVN_LIB_PATH=os.path.join(REPO, "avian_amd", "csrc", "measure", "libavian_mi355x.so"), **env))   # (only the `make measure` build reads the environment)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout
