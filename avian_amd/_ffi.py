@@ -218,7 +218,8 @@ class avn_islands_stats(C.Structure):
 
 
 class avn_despawn_list(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("n_colliders", C.c_uint32), ("collider_entities", vp), ("n_bodies", C.c_uint32), ("bodies", vp)]
+    _fields_ = [("struct_size", C.c_uint32), ("n_colliders", C.c_uint32), ("collider_entities", vp), ("n_bodies", C.c_uint32), ("bodies", vp),
+                ("n_joints", C.c_uint32), ("joints", vp)]
 
 
 class avn_sleeping_stats(C.Structure):
@@ -257,7 +258,7 @@ ABI_SYMBOLS = [
     "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get", "pipeline_new_pair_ids_get",
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
     "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
-    "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies",
+    "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies", "islands_joint_remove", "islands_renumber_joints",
     "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange", "despawn",
 ]
 
@@ -354,7 +355,8 @@ class Library:
                            ("islands_status_change", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_flush_wake", [vp]), ("islands_split_candidate", [vp]),
                            ("islands_sleeping_systems", [vp, vp, vp, C.c_uint32, C.c_float]), ("islands_wake_body", [vp, C.c_uint32]), ("islands_sleep_body", [vp, C.c_uint32]),
                            ("islands_last_result", [vp, vp]), ("islands_stats_get", [vp, vp]), ("islands_state", [vp, C.c_uint32, vp, vp, vp, vp]),
-                           ("islands_collider_remove", [vp, C.c_uint32]), ("islands_body_remove", [vp, C.c_uint32]), ("islands_renumber_bodies", [vp, vp, C.c_uint32])):
+                           ("islands_collider_remove", [vp, C.c_uint32]), ("islands_body_remove", [vp, C.c_uint32]), ("islands_renumber_bodies", [vp, vp, C.c_uint32]),
+                           ("islands_joint_remove", [vp, C.c_uint32]), ("islands_renumber_joints", [vp, vp, C.c_uint32])):
             f(name).restype = C.c_int; f(name).argtypes = args
         self._islands_declared = True
 
@@ -885,13 +887,14 @@ class World:
         b = np.ascontiguousarray(bodies, np.uint32)
         self._check(self.lib.fn("wake_bodies")(self.handle, _ptr(b), len(b)))
 
-    def despawn(self, bodies=(), collider_entities=()):
-        """``avn_despawn``: remove bodies (with their colliders) and / or single colliders inside the closed loop -- ContactGraph edges in
-        edge-list order, ConstraintGraph pops, IdPool, islands, renumbering.  Follow it with bodies_upload + colliders_upload of what remains."""
-        b = np.ascontiguousarray(bodies, np.uint32); c = np.ascontiguousarray(collider_entities, np.uint32)
-        d = avn_despawn_list(C.sizeof(avn_despawn_list), len(c), _ptr(c) if len(c) else None, len(b), _ptr(b) if len(b) else None)
+    def despawn(self, bodies=(), collider_entities=(), joints=()):
+        """``avn_despawn``: remove joints, bodies (with their colliders) and / or single colliders inside the closed loop -- ContactGraph edges in
+        edge-list order, ConstraintGraph pops, IdPool, islands, renumbering.  Follow it with bodies_upload + colliders_upload (+ joints_upload) of what remains."""
+        b = np.ascontiguousarray(bodies, np.uint32); c = np.ascontiguousarray(collider_entities, np.uint32); j = np.ascontiguousarray(joints, np.uint32)
+        d = avn_despawn_list(C.sizeof(avn_despawn_list), len(c), _ptr(c) if len(c) else None, len(b), _ptr(b) if len(b) else None, len(j), _ptr(j) if len(j) else None)
         self._check(self.lib.fn("despawn")(self.handle, C.byref(d)))
         self.n_bodies -= len(b)
+        self.n_joints = getattr(self, "n_joints", 0) - len(j)
 
     def bounds_exchange(self, max_ranks: int = 64):
         """``avn_bounds_exchange``: (bounds [n_ranks, 6], overlapping rank pairs [k, 2]) -- the library reduces this world's dynamic bounds on the
@@ -988,6 +991,12 @@ class IslandManager:
     def sleep_body(self, body): self._chk(self.lib.fn("islands_sleep_body")(self.handle, body), "islands_sleep_body"); return self.last_result()
     def collider_remove(self, collider): self._chk(self.lib.fn("islands_collider_remove")(self.handle, collider), "islands_collider_remove"); return self.last_result()
     def body_remove(self, body): self._chk(self.lib.fn("islands_body_remove")(self.handle, body), "islands_body_remove"); return self.last_result()
+
+    def joint_remove(self, joint): self._chk(self.lib.fn("islands_joint_remove")(self.handle, joint), "islands_joint_remove"); return self.last_result()
+
+    def renumber_joints(self, new_index):
+        m = np.ascontiguousarray(new_index, np.uint32)
+        self._chk(self.lib.fn("islands_renumber_joints")(self.handle, _ptr(m), len(m)), "islands_renumber_joints")
 
     def renumber_bodies(self, new_index):
         m = np.ascontiguousarray(new_index, np.uint32)

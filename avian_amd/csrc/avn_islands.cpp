@@ -108,6 +108,36 @@ avn_status IslandManager::joint_add(uint32_t jid, uint32_t body1, uint32_t body2
     return AVN_OK;
 }
 
+avn_status IslandManager::joint_remove(uint32_t jid) {
+    clear_results();
+    if (jid >= joints_.size() || (joints_[jid].b1 == NONE && joints_[jid].b2 == NONE)) { error = "islands_joint_remove: no such joint"; return AVN_ERR_STATE; }
+    const Joint j = joints_[jid];
+    // the joint's island is its bodies' island (both are in one island from the moment the joint was added; a split keeps joined bodies together)
+    uint32_t isl = NONE;
+    if (body_has_node(j.b1)) isl = isl_of_[j.b1]; else if (body_has_node(j.b2)) isl = isl_of_[j.b2];
+    if (isl != NONE) islands_[isl].removed += 1;
+    auto drop = [&](std::vector<uint32_t>& v) { auto it = std::find(v.rbegin(), v.rend(), jid); if (it != v.rend()) v.erase(std::next(it).base()); };
+    if (j.b1 < joint_edges_.size()) drop(joint_edges_[j.b1].out);
+    if (j.b2 < joint_edges_.size()) drop(joint_edges_[j.b2].in);
+    joints_[jid] = Joint();
+    if (isl != NONE && islands_[isl].sleeping) wake_islands({isl});
+    return AVN_OK;
+}
+avn_status IslandManager::renumber_joints(const uint32_t* new_index, uint32_t n_old) {
+    if (n_old && !new_index) return AVN_ERR_BAD_ARG;
+    auto m = [&](uint32_t j) { return j < n_old ? new_index[j] : NONE; };
+    std::vector<Joint> nj;
+    for (uint32_t j = 0; j < joints_.size() && j < n_old; ++j) {
+        if (new_index[j] == NONE) continue;
+        if (nj.size() <= new_index[j]) nj.resize((size_t)new_index[j] + 1);
+        nj[new_index[j]] = joints_[j];
+    }
+    joints_.swap(nj);
+    for (EdgeLists& l : joint_edges_) { for (uint32_t& e : l.out) e = m(e); for (uint32_t& e : l.in) e = m(e); }
+    mark_joint_.clear();
+    return AVN_OK;
+}
+
 // one iteration of the status loop of NarrowPhase::update, system_param.rs:155-373 (the ConstraintGraph half is the caller's)
 avn_status IslandManager::status_change(uint32_t id, uint32_t flags, uint32_t manifold_count) {
     if (id >= contacts_.size() || !contacts_[id].live) { error = "islands_status_change: no such contact"; return AVN_ERR_STATE; }
@@ -437,6 +467,8 @@ AVN_API void avn_islands_destroy(avn_island_manager* m) { delete m; }
 AVN_API avn_status avn_islands_body_add(avn_island_manager* m, uint32_t body) { AVN_ISL(body_add(body)); }
 AVN_API avn_status avn_islands_collider_add(avn_island_manager* m, uint32_t collider, uint32_t body) { AVN_ISL(collider_add(collider, body)); }
 AVN_API avn_status avn_islands_joint_add(avn_island_manager* m, uint32_t joint, uint32_t b1, uint32_t b2) { AVN_ISL(joint_add(joint, b1, b2)); }
+AVN_API avn_status avn_islands_joint_remove(avn_island_manager* m, uint32_t joint) { AVN_ISL(joint_remove(joint)); }
+AVN_API avn_status avn_islands_renumber_joints(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old) { AVN_ISL(renumber_joints(new_index, n_old)); }
 AVN_API avn_status avn_islands_pair_add(avn_island_manager* m, uint32_t id, uint32_t c1, uint32_t c2) { AVN_ISL(pair_add(id, c1, c2)); }
 AVN_API avn_status avn_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t manifold_count) { AVN_ISL(status_change(id, flags, manifold_count)); }
 AVN_API avn_status avn_islands_flush_wake(avn_island_manager* m) { AVN_ISL(flush_wake()); }

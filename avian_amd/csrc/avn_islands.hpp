@@ -30,6 +30,11 @@ public:
     avn_status body_add(uint32_t body);
     avn_status collider_add(uint32_t collider, uint32_t body);
     avn_status joint_add(uint32_t joint, uint32_t body1, uint32_t body2);
+    // remove_joint_from_graph (joint_graph/plugin.rs:163-194): PhysicsIslands::remove_joint (islands/mod.rs:749-812: constraints_removed += 1), the joint out of
+    // both bodies' edge lists, and the WakeIslands([island]) it queues for a sleeping island; results as for wake_body
+    avn_status joint_remove(uint32_t joint);
+    // the host compacted its joint array: joint j -> new_index[j] (NONE: removed, already gone)
+    avn_status renumber_joints(const uint32_t* new_index, uint32_t n_old);
     avn_status pair_add(uint32_t contact_id, uint32_t collider1, uint32_t collider2);
     avn_status status_change(uint32_t contact_id, uint32_t flags, uint32_t manifold_count);
     avn_status flush_wake();

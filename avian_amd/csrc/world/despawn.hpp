@@ -11,13 +11,16 @@
 // status loop's (pg_apply_ops: exact swap_remove replay).  Then the rows are cleared, their PairKeys tombstoned, their ids merged into the
 // sorted free list, and every body index the library holds is renumbered for the host's compacted arrays.
     bool despawn_needs_bodies = false, despawn_needs_colliders = false;
+    bool despawn_needs_joints = false;   // joints left with the last avn_despawn: the device arrays still hold the old set until avn_joints_upload brings the remaining one
+    uint32_t despawn_expected_joints = 0;
     bool despawn_broken = false;   // an avn_despawn failed after its first mutation: ContactGraph / islands are half-updated, only a restart of the closed loop clears it
     uint32_t despawn_expected_bodies = 0;
     DevBuf b_dsp_a, b_dsp_b;
 
     avn_status despawn(const avn_despawn_list* d) override {
         slp_world_asleep = slp_world_idle = false;
-        if (!d || d->struct_size != sizeof(avn_despawn_list) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
+        if (!d || (d->struct_size != sizeof(avn_despawn_list) && d->struct_size != AVN_DESPAWN_LIST_SIZE_R4) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
+        if (d->struct_size == sizeof(avn_despawn_list) && d->n_joints && !d->joints) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
         if (!pipe_on || !pipe_dev) { error = "despawn: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
         if (despawn_broken) { error = "despawn: an earlier avn_despawn failed half-way; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
@@ -36,8 +39,15 @@
             gone_body[b] = 1;
         }
         for (uint32_t i = 0; i < d->n_colliders; ++i) if (!entity_slot.count(d->collider_entities[i])) { error = "despawn: unknown collider"; return AVN_ERR_BAD_ARG; }
+        const uint32_t n_gone_joints = d->struct_size == sizeof(avn_despawn_list) ? d->n_joints : 0u;
+        std::vector<uint8_t> gone_joint(h_j_body1.size(), 0);
+        for (uint32_t i = 0; i < n_gone_joints; ++i) {
+            const uint32_t j = d->joints[i];
+            if (j >= gone_joint.size() || gone_joint[j]) { error = "despawn: joint index out of range or listed twice"; return AVN_ERR_BAD_ARG; }
+            gone_joint[j] = 1;
+        }
         for (size_t j = 0; j < h_j_body1.size(); ++j)
-            if (gone_body[(uint32_t)h_j_body1[j]] || gone_body[(uint32_t)h_j_body2[j]]) { error = "despawn: a joint names a despawned body (upload the joints without it first)"; return AVN_ERR_STATE; }
+            if (!gone_joint[j] && (gone_body[(uint32_t)h_j_body1[j]] || gone_body[(uint32_t)h_j_body2[j]])) { error = "despawn: a joint names a despawned body: list it in avn_despawn_list::joints"; return AVN_ERR_STATE; }
         HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
         avn_status st = pg_error_check();
         if (st != AVN_OK) return st;
@@ -113,6 +123,26 @@
             pops.clear();
             return s2;
         };
+        // ---- joints leave first: remove_joint_from_graph per joint (joint_graph/plugin.rs:163-194), a sleeping island is woken (its manifolds are pushed back) ----
+        if (n_gone_joints) {
+            if (slp_on)
+                for (uint32_t i = 0; i < n_gone_joints; ++i) {
+                    if ((st = isl.joint_remove(d->joints[i])) != AVN_OK) return slp_fail(st);
+                    if (!isl.pushed().empty() || !isl.bodies_woken().empty() || !isl.pairs_woken().empty()) {
+                        if ((st = sleeping_apply_result(false, host_ms)) != AVN_OK) return st;
+                    }
+                }
+            // the joint set shrinks; the device arrays are rewritten by the upload the host owes (avn_joints_upload packs every array, prepare_joints the rest)
+            std::vector<uint32_t> jmap(gone_joint.size(), IslandManager::NONE);
+            uint32_t nj = 0;
+            for (size_t j = 0; j < gone_joint.size(); ++j) if (!gone_joint[j]) jmap[j] = nj++;
+            auto keep = [&](auto& v) { if (v.size() != gone_joint.size()) return; size_t k = 0; for (size_t j = 0; j < gone_joint.size(); ++j) if (!gone_joint[j]) v[k++] = v[j]; v.resize(k); };
+            keep(h_j_body1); keep(h_j_body2); keep(h_j_type); keep(h_j_damped); keep(h_j_collision_disabled);
+            if (slp_on && (st = isl.renumber_joints(jmap.data(), (uint32_t)jmap.size())) != AVN_OK) return slp_fail(st);
+            dw.n_joints = nj;
+            joint_schedule_dirty = true; groups_dirty = true; graph_valid = false;
+            despawn_needs_joints = true; despawn_expected_joints = nj;
+        }
         for (const Unit& u : units) {
             uint32_t island = IslandManager::NONE;
             const uint32_t owner = u.body != IslandManager::NONE ? u.body : (u.slots.empty() ? IslandManager::NONE : (uint32_t)h_col_body[u.slots[0]]);

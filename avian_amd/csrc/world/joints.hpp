@@ -31,6 +31,11 @@
                 error = "joints_upload: bad body index"; return AVN_ERR_BAD_ARG;
             }
         }
+        if (despawn_needs_joints) {   // (avn_despawn took joints out: exactly the remaining set comes back, bodies in the new numbering)
+            if (J != despawn_expected_joints) { error = "joints_upload: after avn_despawn exactly the remaining joints must be uploaded"; return AVN_ERR_STATE; }
+            if (despawn_needs_bodies) { error = "joints_upload: after avn_despawn the remaining bodies are uploaded first"; return AVN_ERR_STATE; }
+            despawn_needs_joints = false;
+        }
         if (slp_on) {
             // the island manager links joints when they are added (PhysicsIslands::add_joint, islands/mod.rs:668-735) and has no way to take one
             // back without the bodies' JointGraph history: with sleeping on, an upload may only APPEND joints to the set it already knows

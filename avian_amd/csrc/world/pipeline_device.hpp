@@ -87,7 +87,7 @@
         HIPCHK(hipMemset(pg.ctr, 0, PGC_WORDS * 4));
         pg_bcol_words = 0;
         pg_batch_open = false;
-        despawn_needs_bodies = despawn_needs_colliders = despawn_broken = false; despawn_expected_bodies = 0;   // a fresh loop owes no upload
+        despawn_needs_bodies = despawn_needs_colliders = despawn_needs_joints = despawn_broken = false; despawn_expected_bodies = 0;   // a fresh loop owes no upload
         if (b_pg_sort_tab.p) HIPCHK(hipMemset(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap));
         if ((st = pg_bcol_grow()) != AVN_OK) return st;
         HIPCHK(hipMemset(pg.bcol, 0, (size_t)pg_bcol_words * 4));
@@ -227,6 +227,9 @@
     }
     avn_status pg_apply_ops(uint32_t n_ops, uint32_t n_rem, uint32_t n_rows, const uint32_t* list_cids, const uint32_t* list_kinds, double& host_ms) {
         avn_status st;
+        // a list batch (SleepIslands / WakeIslands, avn_despawn) reuses the op arrays the status loop left its changes in: what avn_contact_changes_get
+        // reports is fetched first (with sleeping on the pinned copy the island manager read is the source and stays valid)
+        if (list_cids && !slp_on && (st = pipeline_device_changes_fetch()) != AVN_OK) return st;
         if (list_cids && (st = pg_batch_begin()) != AVN_OK) return st;   // (the status loop's batch was opened in front of k_pg_scan_classify)
         {
             // (ctr[PGC_BUCKET ..] and ctr[PGC_TILE] are zero here: k_pg_build_handles, the last kernel of every batch, leaves them so; the status
@@ -314,6 +317,7 @@
     avn_status pipeline_step_device() {
         avn_status st;
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "avn_step: avn_despawn must be followed by avn_bodies_upload and avn_colliders_upload of what remains"; return AVN_ERR_STATE; }
+        if (despawn_needs_joints) { error = "avn_step: avn_despawn removed joints: upload the remaining joints (avn_joints_upload) first"; return AVN_ERR_STATE; }
         if (despawn_broken) { error = "avn_step: an avn_despawn failed half-way and left the contact bookkeeping inconsistent; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         // whatever ends this step early must not leave the next one believing that prepare_solver_bodies already ran or that the slot table is being cleared
         struct StepGuard { World* w; bool ok = false; ~StepGuard() { if (!ok) { w->bodies_prepared_early = false; w->slot_clear_pending = false; w->bs = w->stream; } } } step_guard{this};
@@ -437,6 +441,7 @@
             if (h[2]) return pg_error_report(h[2]);   // raised by the previous step's solver passes (normally already reported by avn_synchronize)
         }
         pipe_stats.last_status_changes = n_ops;
+        pg_changes_cached = false;   // (avn_contact_changes_get: this step's changes are in the op arrays now)
         if (!n_ops) pg_batch_open = false;   // (no change: k_pg_scan_classify touched none of the batch's counters)
         if (n_ops || total) slp_step_changed = true;
         ++pg_dump_step;

@@ -11,7 +11,7 @@
             HIPCHK(hipStreamSynchronize(stream));
             if (ct.cap) HIPCHK(hipMemset(ct.meta, 0, (size_t)ct.cap * sizeof(uint4)));
             pipe_dev = false; pipe_on = false;
-            despawn_needs_bodies = despawn_needs_colliders = despawn_broken = false; despawn_expected_bodies = 0;   // (the restart path after avn_despawn: any upload is welcome again)
+            despawn_needs_bodies = despawn_needs_colliders = despawn_needs_joints = despawn_broken = false; despawn_expected_bodies = 0;   // (the restart path after avn_despawn: any upload is welcome again)
             contact_keys_live = false; h_live_keys.clear();
             avn_status st = rebuild_pair_set(n_pair_keys);   // only the keys the host uploaded / collected outside the closed loop remain
             if (st != AVN_OK) return st;
@@ -86,9 +86,12 @@
     }
     // NarrowPhase::update's status changes of the last closed-loop step as avn_contact_change records (device loop: the op arrays the status scan
     // left, or their pinned copy when the island manager read them; decoded from the packed change word)
+    bool pg_changes_cached = false;   // h_changes already holds the last step's changes (fetched before a later op batch reused the op arrays)
     avn_status pipeline_device_changes_fetch() {
+        if (pg_changes_cached) return AVN_OK;
         const uint32_t n = pipe_stats.last_status_changes;
         h_changes.resize(n);
+        pg_changes_cached = true;
         if (!n) return AVN_OK;
         std::vector<uint32_t> buf;
         const uint32_t *cid, *chg;

@@ -836,6 +836,12 @@ AVN_API avn_status AVN_FN(islands_last_result)(avn_island_manager* m, avn_island
 AVN_API avn_status AVN_FN(islands_collider_remove)(avn_island_manager* m, uint32_t collider);
 AVN_API avn_status AVN_FN(islands_body_remove)(avn_island_manager* m, uint32_t body);
 AVN_API avn_status AVN_FN(islands_renumber_bodies)(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old);
+/* A joint leaves (round 5): what `remove_joint_from_graph` does when a joint entity loses its joint component (dynamics/solver/joint_graph/plugin.rs:163-194) --
+ * PhysicsIslands::remove_joint (islands/mod.rs:749-812: unlinked from its island, constraints_removed += 1), JointGraph::remove_joint, and the WakeIslands([island])
+ * it queues when that island sleeps; result as for avn_islands_wake_body.  renumber_joints: new_index[old] = new joint index | 0xFFFFFFFF (removed): joint ids are
+ * the host's array indices, and the host compacted its joint array. */
+AVN_API avn_status AVN_FN(islands_joint_remove)(avn_island_manager* m, uint32_t joint);
+AVN_API avn_status AVN_FN(islands_renumber_joints)(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old);
 typedef struct avn_islands_stats {
     uint32_t n_islands, n_sleeping_islands, n_bodies, n_sleeping_bodies;
     uint32_t merges, splits;           /* totals since creation */
@@ -895,7 +901,16 @@ typedef struct avn_despawn_list {
     const uint32_t* collider_entities;   /* Entity::index() of colliders despawned WITHOUT their body, in despawn order */
     uint32_t n_bodies;
     const uint32_t* bodies;              /* body indices (current numbering) despawned WITH all their colliders, in despawn order; no duplicates */
+    /* round 5 (a caller built against the round-4 header passes the smaller struct_size and no joints): joints that leave, as indices into the LAST
+     * avn_joints_upload, in despawn order.  They leave FIRST: remove_joint_from_graph for each (dynamics/solver/joint_graph/plugin.rs:163-194:
+     * PhysicsIslands::remove_joint -> constraints_removed += 1, JointGraph::remove_joint, WakeIslands for a sleeping island).  Every joint that names a
+     * despawned body must be listed (the reference would keep such a joint, dangling, and skip it in every system; the library holds no dangling joint).
+     * The library's joint set shrinks to the remaining joints in their previous order; the host uploads exactly that set (avn_joints_upload) before the
+     * next avn_step, bodies in the new numbering. */
+    uint32_t n_joints;
+    const uint32_t* joints;
 } avn_despawn_list;
+#define AVN_DESPAWN_LIST_SIZE_R4 (offsetof(avn_despawn_list, n_joints))
 AVN_API avn_status AVN_FN(despawn)(avn_world* w, const avn_despawn_list* d);
 
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as

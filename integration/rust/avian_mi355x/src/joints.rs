@@ -7,8 +7,8 @@
 //! (`avn_joints_upload`; the library runs `prepare`, the per-type serial order and the damping itself, bit-identical to the serial loops) in
 //! `SolverSystems::PrepareJoints`, one download of forces and torques (`avn_joints_download`) in `SolverSystems::Writeback`.
 //!
-//! Joint order: the library solves type by type and, inside a type, in ARRAY order; the reference iterates each type's query.  The staging
-//! sorts every type's joints by `Entity`, which is the order Bevy's dense table iteration yields for joints spawned in sequence.
+//! Joint order: the library solves type by type and, inside a type, in ARRAY order; the reference iterates each type's query.  The staging keeps
+//! uploaded joints in place and appends new ones by `Entity`, which is the order Bevy's dense table iteration yields for joints spawned in sequence.
 
 use crate::{staging::Staging, world::Mi355xWorld};
 use avian3d::prelude::*;
@@ -80,7 +80,6 @@ impl JointStaging {
         spherical: impl Iterator<Item = (Entity, &'a SphericalJoint, JointExtras<'a>)>, prismatic: impl Iterator<Item = (Entity, &'a PrismaticJoint, JointExtras<'a>)>,
         distance: impl Iterator<Item = (Entity, &'a DistanceJoint, JointExtras<'a>)>,
     ) {
-        self.clear();
         let damp = |d: Option<&JointDamping>| d.map(|d| (d.linear, d.angular));
         let mut rows: Vec<Row> = Vec::new();
         rows.extend(fixed.map(|(e, j, (d, cd))| Row {
@@ -102,7 +101,13 @@ impl JointStaging {
             entity: e, kind: ffi::AVN_JOINT_DISTANCE, body1: j.body1, body2: j.body2, anchor1: j.anchor1, anchor2: j.anchor2, basis1: JointBasis::IDENTITY,
             basis2: JointBasis::IDENTITY, axis: Vec3::X, limit: Some((j.limits.min, j.limits.max)), limit2: None, compliance: [j.compliance, 0.0, 0.0],
             damping: damp(d), collision_disabled: cd }));
-        rows.sort_by_key(|r| (r.kind, r.entity));
+        // Array order: joints already uploaded keep their relative order, new ones are appended by `Entity` (spawn order).  The library solves type by
+        // type whatever the array order is (a stable sort by type, xpbd/plugin.rs:77-82) and, inside a type, in array order = spawn order, like the
+        // reference's per-type queries; and with closed-loop sleeping on it links joints into islands in the order it first sees them
+        // (`PhysicsIslands::add_joint`, islands/mod.rs:668-735) and accepts only APPENDED joints between despawns.
+        let previous: bevy::platform::collections::HashMap<Entity, usize> = self.entities.iter().enumerate().map(|(i, &e)| (e, i)).collect();
+        rows.sort_by_key(|r| (previous.get(&r.entity).copied().unwrap_or(usize::MAX), r.entity));
+        self.clear();
         for r in rows { self.push(st, r); }
     }
 

@@ -145,6 +145,8 @@ fn gpu_upload_bodies(
     increments: Query<&VelocityIntegrationData>,
     colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
+    js: Res<crate::joints::JointStaging>,
+    live_joints: Query<(), (Or<(With<FixedJoint>, With<RevoluteJoint>, With<SphericalJoint>, With<PrismaticJoint>, With<DistanceJoint>)>, Without<JointDisabled>)>,
 ) {
     let st = &mut st.0;
     // Despawns since the last step, in the order Bevy reports the removals (= the order Avian's own observers ran in).  The staging still holds
@@ -156,7 +158,11 @@ fn gpu_upload_bodies(
     let gone_colliders: Vec<u32> = removed_colliders.read()
         .filter(|e| st.collider_slot.get(&e.index()).is_some_and(|&s| !gone_of_bodies.contains(&(st.c_body[s] as u32))))   // (a body's own colliders leave with it)
         .map(|e| e.index()).collect();
-    w.despawn(&gone_bodies, &gone_colliders);
+    // joints of the last upload that are gone: their entity lost its joint component (or gained JointDisabled), or one of their bodies was despawned
+    let gone_joints: Vec<u32> = js.entities.iter().enumerate()
+        .filter(|(i, e)| !live_joints.contains(**e) || gone_of_bodies.contains(&(js.body1[*i] as u32)) || gone_of_bodies.contains(&(js.body2[*i] as u32)))
+        .map(|(i, _)| i as u32).collect();
+    w.despawn(&gone_bodies, &gone_colliders, &gone_joints);
     st.fill_bodies(bodies.iter(), |e| increments.get(e).map_or((Vec3::ZERO, Vec3::ZERO), |v| (v.linear_increment(), v.angular_increment())));
     st.fill_colliders(colliders.iter());
     let (b, c) = (st.bodies_desc(), st.colliders_desc());

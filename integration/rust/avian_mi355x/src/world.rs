@@ -88,12 +88,16 @@ impl Mi355xWorld {
     /// happens to the device's -- pops in edge-list order, ContactIds back into the IdPool, the bodies' island nodes unlinked -- and the library
     /// renumbers the remaining bodies by stable compaction.  The caller uploads the remaining bodies and colliders next (same call order as
     /// every frame: `avn_bodies_upload`, `avn_colliders_upload`).  A no-op outside the closed loop (the graphs are Avian's own there).
-    pub fn despawn(&mut self, bodies: &[u32], collider_entities: &[u32]) {
-        if !self.closed_loop || (bodies.is_empty() && collider_entities.is_empty()) { return; }
+    /// `joints`: indices into the last `avn_joints_upload` of the joints that leave -- the joint entities that were despawned and every joint that names a
+    /// despawned body (Avian keeps such a joint, dangling, and skips it in every system; the library holds none).  They leave first:
+    /// `remove_joint_from_graph` (src/dynamics/solver/joint_graph/plugin.rs:163-194).
+    pub fn despawn(&mut self, bodies: &[u32], collider_entities: &[u32], joints: &[u32]) {
+        if !self.closed_loop || (bodies.is_empty() && collider_entities.is_empty() && joints.is_empty()) { return; }
         let d = ffi::avn_despawn_list {
             struct_size: core::mem::size_of::<ffi::avn_despawn_list>() as u32,
             n_colliders: collider_entities.len() as u32, collider_entities: if collider_entities.is_empty() { core::ptr::null() } else { collider_entities.as_ptr() },
             n_bodies: bodies.len() as u32, bodies: if bodies.is_empty() { core::ptr::null() } else { bodies.as_ptr() },
+            n_joints: joints.len() as u32, joints: if joints.is_empty() { core::ptr::null() } else { joints.as_ptr() },
         };
         let st = unsafe { ffi::avn_despawn(self.raw, &d) };
         self.check(st);

@@ -208,6 +208,56 @@ struct IslandManager {
         if (isl != NONE) wake_islands({isl});
         return AVN_OK;
     }
+    // PhysicsIslands::remove_joint (islands/mod.rs:749-812) + JointGraph::remove_joint (joint_graph/mod.rs:274-285), as remove_joint_from_graph calls them
+    // when a joint entity loses its joint component (joint_graph/plugin.rs:163-194): unlink from the island's joint list, constraints_removed += 1,
+    // out of both bodies' edge lists; returns the island (NONE: the joint was linked to no island).
+    uint32_t joint_remove(uint32_t jid) {
+        if (jid >= joints.size() || !joints[jid].live) return NONE;
+        const IslandNode ji = joints[jid].island;
+        uint32_t island_id = NONE;
+        if (ji.island_id != NONE) {
+            if (ji.prev != NONE) joints[ji.prev].island.next = ji.next;
+            if (ji.next != NONE) joints[ji.next].island.prev = ji.prev;
+            if (PhysicsIsland* island = islands.get(ji.island_id)) {
+                if (island->head_joint == jid) island->head_joint = ji.next;
+                if (island->tail_joint == jid) island->tail_joint = ji.prev;
+                island->joint_count -= 1;
+                island->constraints_removed += 1;
+                island_id = island->id;
+            }
+        }
+        joint_lists.remove_edge(jid);
+        joints[jid] = JointEdge();
+        return island_id;
+    }
+    // ... followed by the WakeIslands([island]) the observer queues when that island sleeps (joint_graph/plugin.rs:186-189)
+    avn_status joint_remove_and_wake(uint32_t jid) {
+        clear_results();
+        if (jid >= joints.size() || !joints[jid].live) { error = "islands_joint_remove: no such joint"; return AVN_ERR_STATE; }
+        const uint32_t isl = joint_remove(jid);
+        if (isl != NONE) wake_islands({isl});
+        return AVN_OK;
+    }
+    // the host compacted its joint array: joint j becomes new_index[j] (NONE = removed, must be gone already); ids are array indices
+    void renumber_joints(const std::vector<uint32_t>& new_index) {
+        std::vector<JointEdge> nj;
+        Lists nl;
+        nl.node_next[0] = joint_lists.node_next[0]; nl.node_next[1] = joint_lists.node_next[1];
+        auto m = [&](uint32_t j) { return j == NONE ? NONE : new_index[j]; };
+        for (int d = 0; d < 2; ++d) for (uint32_t& h : nl.node_next[d]) h = m(h);
+        for (uint32_t j = 0; j < joints.size() && j < new_index.size(); ++j) {
+            if (new_index[j] == NONE) continue;
+            const uint32_t k = new_index[j];
+            if (nj.size() <= k) { nj.resize((size_t)k + 1); nl.edges.resize((size_t)k + 1); }
+            nj[k] = joints[j];
+            nj[k].island.prev = m(nj[k].island.prev); nj[k].island.next = m(nj[k].island.next);
+            nl.edges[k] = joint_lists.edges[j];
+            nl.edges[k].next[0] = m(nl.edges[k].next[0]); nl.edges[k].next[1] = m(nl.edges[k].next[1]);
+        }
+        for (uint32_t key = 0; key < islands.entries.size(); ++key)
+            if (islands.entries[key].occupied) { PhysicsIsland& i = islands.entries[key].v; i.head_joint = m(i.head_joint); i.tail_joint = m(i.tail_joint); }
+        joints.swap(nj); joint_lists = nl;
+    }
     // the collider leaves RigidBodyColliders and the ContactGraph's node map (its edges are gone already)
     void collider_remove(uint32_t collider) {
         auto it = collider_body.find(collider);

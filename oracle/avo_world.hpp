@@ -2455,7 +2455,8 @@ template <class S> avn_status World<S>::sleeping_state_get(const avn_sleeping_ou
 // remove_node_with (the node's OUTGOING list from its head, then its INCOMING list from its head: newest edge first; the edge id is freed,
 // :286-315); dynamics/solver/islands/mod.rs:1336-1400 BodyIslandNode::on_remove.
 template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
-    if (!d || d->struct_size != sizeof(avn_despawn_list) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
+    if (!d || (d->struct_size != sizeof(avn_despawn_list) && d->struct_size != AVN_DESPAWN_LIST_SIZE_R4) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
+    if (d->struct_size == sizeof(avn_despawn_list) && d->n_joints && !d->joints) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
     if (!pipe) { error = "despawn: needs the closed loop (avn_pipeline_enable)"; return AVN_ERR_STATE; }
     if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
     PipelineState& P = *pipe;
@@ -2467,7 +2468,15 @@ template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
         gone_body[b] = 1;
     }
     for (uint32_t i = 0; i < d->n_colliders; ++i) if (!collider_slot.count(d->collider_entities[i])) { error = "despawn: unknown collider"; return AVN_ERR_BAD_ARG; }
-    for (const Joint<S>& j : joints) if (gone_body[(size_t)j.body1] || gone_body[(size_t)j.body2]) { error = "despawn: a joint names a despawned body (upload the joints without it first)"; return AVN_ERR_STATE; }
+    const uint32_t n_gone_joints = d->struct_size == sizeof(avn_despawn_list) ? d->n_joints : 0u;
+    std::vector<uint8_t> gone_joint(joints.size(), 0);
+    for (uint32_t i = 0; i < n_gone_joints; ++i) {
+        const uint32_t j = d->joints[i];
+        if (j >= gone_joint.size() || gone_joint[j]) { error = "despawn: joint index out of range or listed twice"; return AVN_ERR_BAD_ARG; }
+        gone_joint[j] = 1;
+    }
+    for (size_t j = 0; j < joints.size(); ++j)
+        if (!gone_joint[j] && (gone_body[(size_t)joints[j].body1] || gone_body[(size_t)joints[j].body2])) { error = "despawn: a joint names a despawned body: list it in avn_despawn_list::joints"; return AVN_ERR_STATE; }
     std::unordered_set<uint32_t> gone_collider;
     auto remove_collider = [&](uint32_t entity) {
         if (gone_collider.count(entity)) return;   // (ContactGraph::remove_collider_with: the entity has no node any more)
@@ -2499,6 +2508,24 @@ template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
         slp->isl.wake_islands({island});
         sleeping_apply(false);
     };
+    // 0. joints (round 5): remove_joint_from_graph::<Remove, T> per joint, in the order given (joint_graph/plugin.rs:163-194) -- out of its island
+    //    (constraints_removed += 1), out of the JointGraph, WakeIslands([island]) when it sleeps; then the joint array closes up
+    if (n_gone_joints) {
+        for (uint32_t i = 0; i < n_gone_joints; ++i)
+            if (slp) {
+                slp->isl.clear_results();
+                const uint32_t isl = slp->isl.joint_remove(d->joints[i]);
+                if (isl != IslandManager::NONE) { slp->isl.wake_islands({isl}); sleeping_apply(false); }
+            }
+        std::vector<uint32_t> jmap(joints.size(), IslandManager::NONE);
+        std::vector<Joint<S>> kept;
+        for (size_t j = 0; j < joints.size(); ++j) if (!gone_joint[j]) { jmap[j] = (uint32_t)kept.size(); kept.push_back(joints[j]); }
+        joints.swap(kept);
+        joint_order.resize(joints.size());
+        for (uint32_t i = 0; i < joints.size(); ++i) joint_order[i] = i;
+        std::stable_sort(joint_order.begin(), joint_order.end(), [&](uint32_t a, uint32_t b) { return joints[a].type < joints[b].type; });
+        if (slp) slp->isl.renumber_joints(jmap);
+    }
     // 1. colliders despawned on their own (remove_collider_on::<Remove, ColliderMarker>)
     for (uint32_t i = 0; i < d->n_colliders; ++i) {
         const uint32_t ent = d->collider_entities[i];

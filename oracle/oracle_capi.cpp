@@ -324,6 +324,12 @@ avn_status avo_islands_last_result(avn_island_manager* m, avn_islands_result* o)
 }
 avn_status avo_islands_collider_remove(avn_island_manager* m, uint32_t collider) { return m ? m->m.collider_remove_full(collider) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_body_remove(avn_island_manager* m, uint32_t body) { return m ? m->m.body_remove_and_wake(body) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_joint_remove(avn_island_manager* m, uint32_t joint) { return m ? m->m.joint_remove_and_wake(joint) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_renumber_joints(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old) {
+    if (!m || (n_old && !new_index)) return AVN_ERR_BAD_ARG;
+    m->m.renumber_joints(std::vector<uint32_t>(new_index, new_index + n_old));
+    return AVN_OK;
+}
 avn_status avo_islands_renumber_bodies(avn_island_manager* m, const uint32_t* new_index, uint32_t n_old) {
     if (!m || (n_old && !new_index)) return AVN_ERR_BAD_ARG;
     std::vector<uint32_t> map(new_index, new_index + n_old);

@@ -9,7 +9,7 @@ import pytest
 
 from avian_amd import scenes
 from helpers import F, hip_lib, oracle_lib
-from pipeline_scenes import dropped_boxes, stack_and_projectile
+from pipeline_scenes import dropped_boxes, stack_and_projectile, stack_chain_and_projectile
 from test_despawn_cpu import subset
 from test_gpu_graph import compare_step
 from test_gpu_sleeping import compare_sleeping
@@ -141,3 +141,67 @@ def test_despawn_with_sleeping_on(bits):
         wo.step(); wh.step(); compare_step(s, wo, wh); compare_sleeping(s, wo, wh); s += 1
     st = wh.sleeping_stats()
     assert st.islands.n_bodies == sc.n - 1 - 2
+
+
+def despawn_link(worlds, sc_bodies, sc_colliders, joints, link):
+    """Despawn body `link` of a chain together with the (one or two) joints that name it: avn_despawn(joints + body), then the three uploads."""
+    gone_j = np.flatnonzero((joints["body1"] == link) | (joints["body2"] == link)).astype(np.uint32)
+    n = len(sc_bodies["inv_mass"])
+    mask = np.ones(n, bool); mask[link] = False
+    new_index = np.cumsum(mask) - 1
+    cmask = mask[np.asarray(sc_colliders["body"])]
+    nb = subset(sc_bodies, mask)
+    nc = {k: (np.asarray(v)[cmask] if isinstance(v, np.ndarray) and len(v) == len(cmask) else v) for k, v in sc_colliders.items()}
+    nc["body"] = new_index[np.asarray(sc_colliders["body"])[cmask]].astype(np.int32)
+    keep = np.ones(len(joints["body1"]), bool); keep[gone_j] = False
+    nj = {k: (np.asarray(v)[keep] if isinstance(v, np.ndarray) and len(v) == len(keep) else v) for k, v in joints.items()}
+    nj["body1"] = new_index[joints["body1"][keep]].astype(np.int32); nj["body2"] = new_index[joints["body2"][keep]].astype(np.int32)
+    for w in worlds:
+        state = w.bodies_download()
+        w.despawn(bodies=[link], joints=gone_j)
+        kw = dict(nb)
+        for k in ("position", "rotation", "linear_velocity", "angular_velocity"):
+            kw[k] = state[k][mask].astype(np.float64)
+        w.bodies_upload(**kw); w.colliders_upload(**nc); w.collider_materials_upload(friction=0.5)
+        w.distance_joints_upload(**nj)
+    return nb, nc, nj, len(gone_j)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_despawn_a_jointed_body_with_sleeping_on(bits):
+    """Round 5 (missing 6: avn_despawn refused a body that a joint names).  A chain of DistanceJoints draped over a stack, ONE island through
+    add_joint; it falls asleep; a link in the middle of the chain is despawned with its two joints: remove_joint_from_graph per joint (constraints_removed,
+    the sleeping island woken and its manifolds pushed back in the reference's order), then the body; the chain is two pieces from then on and the island
+    splits when it next rests.  Every step against the oracle: colour lists with order, bodies, joints' solver data, island ids, body-list order, timers."""
+    from helpers import compare_dicts
+    sc, joints = stack_chain_and_projectile(height=400.0)   # (the projectile stays out of the way for the length of the test)
+    bodies, colliders = sc.body_kwargs(), sc.collider_kwargs()
+    worlds = []
+    for lib in (oracle_lib(), hip_lib()):
+        w = F.World(lib, F.default_config(bits, substeps=4))
+        w.bodies_upload(**bodies); w.colliders_upload(**colliders); w.distance_joints_upload(**joints)
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable(); w.sleeping_enable(time_to_sleep=0.3, linear_threshold=0.3, angular_threshold=0.6)
+        worlds.append(w)
+    wo, wh = worlds
+    s = 0
+    slept = False
+    for _ in range(160):
+        wo.step(); wh.step(); compare_step(s, wo, wh); compare_sleeping(s, wo, wh); s += 1
+        st = wh.sleeping_stats()
+        if s > 30 and st.islands.n_sleeping_islands >= 1 and st.n_awake_bodies <= 1:
+            slept = True
+            break
+    assert slept, "stack and chain must be asleep before the despawn"
+    n_links = len(joints["body1"]) + 1
+    link = int(joints["body1"][0]) + n_links // 2          # a link in the middle of the chain
+    removed_before = wh.sleeping_stats().islands.n_sleeping_islands
+    bodies, colliders, joints, n_gone = despawn_link((wo, wh), bodies, colliders, joints, link)
+    assert n_gone == 2
+    compare_step("after the despawn", wo, wh, check_rows=True); compare_sleeping("after the despawn", wo, wh)
+    assert removed_before >= 1 and wh.sleeping_stats().islands.n_sleeping_islands == 0, "the island that lost two joints and a body wakes"
+    for _ in range(120):
+        wo.step(); wh.step(); compare_step(s, wo, wh); compare_sleeping(s, wo, wh)
+        compare_dicts(wo.joints_download(), wh.joints_download(), f"step {s}: joints"); s += 1
+    st = wh.sleeping_stats()
+    assert st.islands.n_bodies == sc.n - 1 - 1 and st.islands.splits >= 1

@@ -58,9 +58,12 @@ def test_random_event_streams_keep_both_managers_identical(seed):
     cols = sorted(col_body)
     # a few joints first (spawn order)
     jointed = set()
-    for j in range(5):
+    joints = {}   # live joints: id -> (body1, body2)
+    n_joints_removed = 0
+    for j in range(7):
         a, b = rng.choice(np.arange(n_static, n_bodies), 2, replace=False)
         jointed |= {int(a), int(b)}
+        joints[j] = (int(a), int(b))
         for m in (mo, mh):
             m.joint_add(j, int(a), int(b))
     same(mo, mh, n_bodies, "after joints")
@@ -139,6 +142,17 @@ def test_random_event_streams_keep_both_managers_identical(seed):
                 same_result(ro, rh, f"step {step}: SleepBody")
                 for c in ro["pairs_slept"]: live[int(c)]["pair_sleeping"] = True
             same(mo, mh, n_bodies, f"step {step}: after SleepBody")
+        if step % 23 == 9 and joints:
+            # a joint entity is despawned: remove_joint_from_graph (joint_graph/plugin.rs:163-194) -- unlinked from its island (constraints_removed += 1),
+            # out of the JointGraph, its island woken when it sleeps
+            j = int(rng.choice(sorted(joints)))
+            ro, rh = mo.joint_remove(j), mh.joint_remove(j)
+            same_result(ro, rh, f"step {step}: joint_remove({j})")
+            for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
+            for x in ro["bodies_woken"]: timers[int(x)] = 0.0
+            del joints[j]; n_joints_removed += 1
+            jointed = {b for ab in joints.values() for b in ab}
+            same(mo, mh, n_bodies, f"step {step}: after joint_remove({j})")
         if step % 19 == 13 and DESPAWN:
             # despawn a body: remove_collider per collider (edge-list order), BodyIslandNode::on_remove + the queued WakeIslands
             cand = [b for b in range(n_static, n_bodies) if b not in despawned and b not in jointed]   # (a body that carries a joint cannot leave: both managers refuse it)
@@ -165,14 +179,19 @@ def test_random_event_streams_keep_both_managers_identical(seed):
                     new_index[b] = k; k += 1
             for m in (mo, mh): m.renumber_bodies(new_index)
             col_body = {c: int(new_index[b]) for c, b in col_body.items() if b not in despawned}
-            jointed = {int(new_index[b]) for b in jointed}
+            # ... and its joint array (ids are array indices): the removed joints' slots close up
+            jmap = np.full(7, NONE, np.uint32)
+            for k2, j in enumerate(sorted(joints)): jmap[j] = k2
+            for m in (mo, mh): m.renumber_joints(jmap)
+            joints = {int(jmap[j]): (int(new_index[a]), int(new_index[b])) for j, (a, b) in joints.items()}
+            jointed = {b for ab in joints.values() for b in ab}
             timers = timers[new_index != NONE].copy()
             n_bodies = k
             despawned = set()
             same(mo, mh, n_bodies, f"step {step}: after renumber_bodies")
     s = mh.stats()
     assert s.merges > 5 and s.splits > 0, "the stream must exercise merges and splits"
-    assert n_despawned >= 5
+    assert n_despawned >= 5 and n_joints_removed >= 3
 
 
 def test_merge_appends_the_smaller_island_and_reuses_the_last_freed_key():
