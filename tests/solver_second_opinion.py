@@ -415,3 +415,73 @@ def distance_joint_solve(A, bodies, j, data, dt):
     b2["dq"] = A.qmul(A.from_scaled_axis(A.sym_mul(b2["I"], A.cross(world_r2, A.neg(impulse)))), b2["dq"])
     for b in bs:
         if b["has"]: bodies.dp[b["i"]] = b["dp"]; bodies.dq[b["i"]] = b["dq"]
+
+
+# ---- FixedJoint = FixedAngleConstraintShared, then PointConstraintShared (xpbd/joints/fixed.rs:36-91, shared/fixed_angle_constraint.rs:36-97,
+#      shared/point_constraint.rs:36-110, angular_constraint.rs:144-190, 233-280) ------------------------------------------------------------------
+def qconj(q): return (-q[0], -q[1], -q[2], q[3])   # Quat::inverse of a unit quaternion
+
+
+def fixed_joint_prepare(A, pos, rot, com, j):
+    d = distance_joint_prepare(A, pos, rot, com, j)   # PointConstraintShared::prepare is DistanceJoint::prepare's arithmetic
+    b1, b2 = j["body1"], j["body2"]
+    d["rotation_difference"] = A.qmul(A.qmul(rot[b1], j["local_basis1"]), qconj(A.qmul(rot[b2], j["local_basis2"])))
+    d["total_rotation_lagrange"] = (A.zero,) * 3
+    return d
+
+
+def _joint_bodies(A, bodies, j):
+    i1, i2 = j["body1"], j["body2"]
+    rel_dom = bodies.dominance_of(i1) - bodies.dominance_of(i2)
+    bs = []
+    for i, dummy in ((i1, rel_dom > 0), (i2, rel_dom < 0)):
+        has = bodies.has_solver_body(i)
+        im, I = bodies.inertia(i, dummy)
+        bs.append(dict(i=i, has=has, dp=bodies.dp[i] if has else (A.zero,) * 3, dq=bodies.dq[i] if has else (A.zero, A.zero, A.zero, A.one), im=im, I=I))
+    return bs
+
+
+def fixed_joint_solve(A, bodies, j, data, dt):
+    b1, b2 = bs = _joint_bodies(A, bodies, j)
+    # -- the angular constraint
+    q = A.qmul(A.qmul(data["rotation_difference"], b1["dq"]), qconj(b2["dq"]))
+    m2 = A.T(-2.0)
+    difference = (m2 * q[0], m2 * q[1], m2 * q[2])
+    angle = np.sqrt(A.dot(difference, difference))
+    if not angle <= A.eps:
+        axis = vdiv(difference, angle)
+        w = [A.dot(axis, A.sym_mul(b1["I"], axis)), A.dot(axis, A.sym_mul(b2["I"], axis))]
+        dl = compute_lagrange_update(A, A.zero, angle, w, j["compliance"][1], dt)
+        if not abs(dl) <= A.eps:
+            impulse = A.scale(axis, -dl)
+            b1["dq"] = A.qmul(A.from_scaled_axis(A.sym_mul(b1["I"], impulse)), b1["dq"])
+            b2["dq"] = A.qmul(A.from_scaled_axis(A.sym_mul(b2["I"], A.neg(impulse))), b2["dq"])
+        data["total_rotation_lagrange"] = A.add(data["total_rotation_lagrange"], A.scale(axis, dl))
+    # -- the point constraint
+    world_r1 = A.qrot(b1["dq"], data["world_r1"]); world_r2 = A.qrot(b2["dq"], data["world_r2"])
+    separation = A.add(A.add(A.sub(b2["dp"], b1["dp"]), A.sub(world_r2, world_r1)), data["center_difference"])
+    magnitude_squared = A.dot(separation, separation)
+    if magnitude_squared != 0:
+        magnitude = np.sqrt(magnitude_squared)
+        direction = vdiv(A.neg(separation), magnitude)
+        def gen_inv_mass(im, I, r):
+            rn = A.cross(r, direction)
+            return max(im[0], max(im[1], im[2])) + A.dot(rn, A.sym_mul(I, rn))
+        w = [gen_inv_mass(b1["im"], b1["I"], world_r1), gen_inv_mass(b2["im"], b2["I"], world_r2)]
+        dl = compute_lagrange_update(A, A.zero, magnitude, w, j["compliance"][0], dt)
+        impulse = A.scale(direction, dl)
+        data["total_lagrange"] = A.add(data["total_lagrange"], impulse)
+        b1["dp"] = A.add(b1["dp"], A.cmul(impulse, b1["im"]))
+        b1["dq"] = A.qmul(A.from_scaled_axis(A.sym_mul(b1["I"], A.cross(world_r1, impulse))), b1["dq"])
+        b2["dp"] = A.sub(b2["dp"], A.cmul(impulse, b2["im"]))
+        b2["dq"] = A.qmul(A.from_scaled_axis(A.sym_mul(b2["I"], A.cross(world_r2, A.neg(impulse)))), b2["dq"])
+    for b in bs:
+        if b["has"]: bodies.dp[b["i"]] = b["dp"]; bodies.dq[b["i"]] = b["dq"]
+
+
+def unprepared(A):
+    """Solver data of a joint whose `prepare` never ran: prepare_xpbd_joint only prepares joints whose two bodies pass `Without<RigidBodyDisabled>`
+    (xpbd/plugin.rs:128, :138-140); solve_xpbd_joint still solves them, the disabled body as SolverBody::default() with the DUMMY inertia (:160-176),
+    on the components' Default: zero vectors, the identity rotation difference."""
+    z = (A.zero,) * 3
+    return dict(world_r1=z, world_r2=z, center_difference=z, total_lagrange=z, total_rotation_lagrange=z, rotation_difference=(A.zero, A.zero, A.zero, A.one))

@@ -11,7 +11,7 @@ import pytest
 
 import solver_second_opinion as S
 from avian_amd import _ffi as F
-from helpers import color_and_upload, oracle_lib, random_world
+from helpers import color_and_upload, oracle_lib, random_joints, random_world
 
 
 def build(bits, seed, **kw):
@@ -168,20 +168,71 @@ def test_distance_joints_against_the_restatement(bits):
         joints = [dict(body1=int(J["body1"][j]), body2=int(J["body2"][j]), local_anchor1=A.v(np.asarray(J["local_anchor1"][j]).astype(T)),
                        local_anchor2=A.v(np.asarray(J["local_anchor2"][j]).astype(T)), limit_min=T(J["limit_min"][j]), limit_max=T(J["limit_max"][j]),
                        compliance=T(J["compliance"][j])) for j in range(len(J["body1"]))]
-        data = [S.distance_joint_prepare(A, pos, rot, com, j) for j in joints]
         flags = np.asarray(b["body_flags"])
+        disabled = lambda j: bool((flags[j["body1"]] | flags[j["body2"]]) & 2)
+        data = [S.unprepared(A) if disabled(j) else S.distance_joint_prepare(A, pos, rot, com, j) for j in joints]
         moved = 0
         for sub in range(2):
             w.run_system("INTEGRATE_VELOCITIES"); w.run_system("INTEGRATE_POSITIONS")
             bodies = S.Bodies(A, w.solver_bodies_download())
             before = np.array(bodies.dp)
             w.run_system("XPBD_SOLVE")
-            for j, d in zip(joints, data):
-                if (flags[j["body1"]] | flags[j["body2"]]) & 2: continue   # a disabled body: get_many / the body query fails, the joint is left alone
+            for j, d in zip(joints, data):   # (a joint with a disabled body is never prepared but IS solved, against a DUMMY: S.unprepared)
                 S.distance_joint_solve(A, bodies, j, d, ts["h_adj"])
             compare_bodies(bodies, w, f"substep {sub}: distance joints")
             moved += int((np.array(bodies.dp) != before).any(axis=1).sum())
             w.run_system("XPBD_VELOCITY_PROJECTION"); w.run_system("JOINT_DAMPING")
         assert moved > 40
+    finally:
+        lib.dll.avo_use_libm_trig(0)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fixed_joints_against_the_restatement(bits):
+    """The angular side of XPBD: FixedJoint = FixedAngleConstraintShared (rotation difference through three quaternion products, align_orientation,
+    apply_angular_impulse) followed by PointConstraintShared, on random frames; serial in joint order, two substeps, libm sin / cos on both sides."""
+    A = S.Arith(bits)
+    lib = oracle_lib()
+    lib.dll.avo_use_libm_trig(1)
+    try:
+        rng = np.random.default_rng(17)
+        wd = random_world(seed=9, n_bodies=50, n_manifolds=30, n_joints=0)
+        J = random_joints(rng, 50, 60)
+        J["joint_type"][:] = F.JOINT_FIXED
+        wd["joints_generic"] = J
+        w = F.World(lib, F.default_config(bits, substeps=4))
+        color_and_upload(w, lib, wd)
+        cfg = w.cfg
+        ts = S.time_scalars(A, cfg.dt_ns, cfg.substeps)
+        T = A.T
+        b = wd["bodies"]
+        pos = [A.v(x) for x in np.asarray(b["position"]).astype(T)]
+        rot = [tuple(T(c) for c in q) for q in np.asarray(b["rotation"]).astype(T)]
+        com = [A.v(x) for x in np.asarray(b["center_of_mass"]).astype(T)]
+        w.run_system("PREPARE_SOLVER_BODIES"); w.run_system("PREPARE_JOINTS"); w.run_system("PRE_PROCESS_VELOCITY_INCREMENTS")
+        q4 = lambda a: tuple(T(c) for c in np.asarray(a).astype(T))
+        joints = [dict(body1=int(J["body1"][j]), body2=int(J["body2"][j]), local_anchor1=A.v(np.asarray(J["local_anchor1"][j]).astype(T)),
+                       local_anchor2=A.v(np.asarray(J["local_anchor2"][j]).astype(T)), local_basis1=q4(J["local_basis1"][j]), local_basis2=q4(J["local_basis2"][j]),
+                       compliance=tuple(T(c) for c in np.asarray(J["compliance"][j]).astype(T))) for j in range(len(J["body1"]))]
+        flags = np.asarray(b["body_flags"])
+        disabled = lambda j: bool((flags[j["body1"]] | flags[j["body2"]]) & 2)
+        data = [S.unprepared(A) if disabled(j) else S.fixed_joint_prepare(A, pos, rot, com, j) for j in joints]
+        assert any(disabled(j) for j in joints), "the scene must hold a joint whose prepare is skipped"
+
+        turned = 0
+        for sub in range(2):
+            w.run_system("INTEGRATE_VELOCITIES"); w.run_system("INTEGRATE_POSITIONS")
+            bodies = S.Bodies(A, w.solver_bodies_download())
+            before = np.array(bodies.dq)
+            w.run_system("XPBD_SOLVE")
+            for j, d in zip(joints, data):
+                S.fixed_joint_solve(A, bodies, j, d, ts["h_adj"])
+            compare_bodies(bodies, w, f"substep {sub}: fixed joints")
+            turned += int((np.array(bodies.dq) != before).any(axis=1).sum())
+            w.run_system("XPBD_VELOCITY_PROJECTION"); w.run_system("JOINT_DAMPING")
+        jd = w.joints_download()
+        same(np.array([d["total_lagrange"] for d in data]), jd["total_lagrange"], "total_position_lagrange")
+        same(np.array([d["total_rotation_lagrange"] for d in data]), jd["total_rotation_lagrange"], "total_rotation_lagrange")
+        assert turned > 40
     finally:
         lib.dll.avo_use_libm_trig(0)
