@@ -259,6 +259,7 @@ ABI_SYMBOLS = [
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
     "islands_flush_wake", "islands_split_candidate", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
     "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies", "islands_joint_remove", "islands_renumber_joints",
+    "shard_create", "shard_destroy", "shard_last_error", "shard_phase2", "shard_new_local_pairs", "shard_active", "shard_phase3", "shard_removed_local", "shard_handles", "shard_stats_get",
     "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange", "despawn",
 ]
 
@@ -918,6 +919,86 @@ class World:
         t = avn_timers()
         self._check(self.lib.fn("timers_get")(self.handle, C.byref(t)))
         return t
+
+
+SHARD_PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"), ("flags", "<u4"), ("owner", "<u4")])
+
+
+class avn_shard_stats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("pairs_added", "pairs_removed", "pushes", "pops", "next_id", "n_free", "last_status_changes", "reserved")]
+
+
+class Shard:
+    """``avn_shard``: the replicated integer bookkeeping of a closed loop sharded by islands (host C++ behind the ABI; needs no device)."""
+
+    def __init__(self, lib: Library, collider_entities, rank: int):
+        self.lib = lib
+        f = lib.fn
+        f("shard_create").argtypes = [C.c_uint32, vp, C.c_uint32, C.POINTER(vp)]
+        f("shard_destroy").restype = None; f("shard_destroy").argtypes = [vp]
+        f("shard_last_error").restype = C.c_char_p; f("shard_last_error").argtypes = [vp]
+        f("shard_phase2").argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_size_t]
+        f("shard_new_local_pairs").argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("shard_active").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("shard_phase3").argtypes = [vp, vp, C.c_size_t]
+        f("shard_removed_local").argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("shard_handles").argtypes = [vp, C.c_int, vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+        f("shard_stats_get").argtypes = [vp, vp]
+        ent = np.ascontiguousarray(collider_entities, np.uint32)
+        h = vp()
+        st = f("shard_create")(len(ent), _ptr(ent), rank, C.byref(h))
+        if st != 0:
+            raise AvnError(st, "shard_create")
+        self.handle = h
+
+    def _chk(self, st, what):
+        if st != 0:
+            raise AvnError(st, what + ": " + (self.lib.fn("shard_last_error")(self.handle) or b"").decode())
+
+    @staticmethod
+    def _u32(p, n):
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), (n,)).copy() if n else np.zeros(0, np.uint32)
+
+    def phase2(self, key_collider, key_min_x, pairs):
+        kc = np.ascontiguousarray(key_collider, np.uint32); kx = np.ascontiguousarray(key_min_x, np.float64); pr = np.ascontiguousarray(pairs, SHARD_PAIR_DTYPE)
+        self._chk(self.lib.fn("shard_phase2")(self.handle, _ptr(kc), _ptr(kx), len(kc), _ptr(pr) if len(pr) else None, len(pr)), "shard_phase2")
+        a, b, c, d, n = vp(), vp(), vp(), vp(), C.c_size_t()
+        self._chk(self.lib.fn("shard_new_local_pairs")(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d), C.byref(n)), "shard_new_local_pairs")
+        return tuple(self._u32(x, n.value) for x in (a, b, c, d))
+
+    def active(self):
+        a, n = vp(), C.c_size_t()
+        self._chk(self.lib.fn("shard_active")(self.handle, C.byref(a), C.byref(n)), "shard_active")
+        return self._u32(a, n.value)
+
+    def phase3(self, changes):
+        ch = np.ascontiguousarray(changes, CHANGE_DTYPE)
+        self._chk(self.lib.fn("shard_phase3")(self.handle, _ptr(ch) if len(ch) else None, len(ch)), "shard_phase3")
+        a, n = vp(), C.c_size_t()
+        self._chk(self.lib.fn("shard_removed_local")(self.handle, C.byref(a), C.byref(n)), "shard_removed_local")
+        return self._u32(a, n.value)
+
+    def handles(self, global_lists: bool = False):
+        off = np.zeros(GRAPH_COLOR_COUNT + 1, np.uint32)
+        a, n = vp(), C.c_size_t()
+        self._chk(self.lib.fn("shard_handles")(self.handle, int(global_lists), _ptr(off), C.byref(a), C.byref(n)), "shard_handles")
+        return off, self._u32(a, n.value)
+
+    def stats(self):
+        s = avn_shard_stats()
+        self._chk(self.lib.fn("shard_stats_get")(self.handle, C.byref(s)), "shard_stats_get")
+        return s
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.fn("shard_destroy")(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class ConstraintGraph:

@@ -75,7 +75,8 @@ struct OverflowSchedule {
 };
 // grid_blocks[c] = captured grid of colour c (0 = colour skipped); arg_offsets: the 25 colour offsets to pass in the kernel
 // arguments, or nullptr = the kernels read the live ranges from DW::color_offsets; returns the number of launches issued
-template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule&, hipStream_t);
+// oct_mask: bit c = colour c runs the eight-lanes-per-manifold kernel (f32 biased solve / relax only; bit-identical: a scheduling choice)
+template <class T> uint32_t launch_contact_pass(const DW<T>&, const StepParams<T>&, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule&, hipStream_t, uint32_t oct_mask = 0u);
 // Island blocks (k_island_substeps): block b owns bodies[body_off[b] .. body_off[b+1]) (world body indices; LDS slot = position in
 // the range) and, per colour slot (0 = the overflow colour, 1 + c = colour c: solve order), the entries
 // ent[col_off[24 b + slot] .. col_off[24 b + slot + 1]) = (manifold index, LDS slot of body1 | LDS slot of body2 << 16); a side

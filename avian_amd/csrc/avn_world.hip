@@ -305,6 +305,7 @@ template <class T> struct World : WorldBase {
         HIPCHK(hipEventCreateWithFlags(&ev_bp_t0, EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_bp_t1, EV_FLAGS));
         if (avn_env("AVN_NO_BP_OVERLAP")) overlap_bp = false;
 #ifdef AVN_MEASURE
+        if (avn_env("AVN_NO_OCT")) oct_enabled = false;           // (A/B: every colour on the lane-per-manifold kernel)
         if (avn_env("AVN_NO_HANDLE_SORT")) handle_sort = false;   // (A/B: the solver's arrays in the bookkeeping's list order, as before round 5)
 #endif
         for (auto& x : ev) HIPCHK(hipEventCreateWithFlags(&x, EV_FLAGS));

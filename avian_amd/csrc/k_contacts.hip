@@ -732,6 +732,178 @@ template <bool USE_BIAS, int STRIDE, bool COH> struct SolveDispatch<float, USE_B
     static __device__ __forceinline__ void run(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) { solve_core_packed<USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
 };
 
+// ---- f32, EIGHT LANES PER MANIFOLD (round 5) ---------------------------------------------------------------------------------
+// The lane-per-manifold solve above is bound by its own instruction stream: 1 398 VALU issues on one wave per SIMD = 2.6-2.8 us of a launch whose
+// fixed cost is ~4 us, and a settled closed-loop colour holds a few thousand manifolds -- under 150 waves for 1 024 SIMDs
+// (profiles/r05_color_pass_issue_model.txt).  Here a manifold is EIGHT lanes: quad 0 = body1, quad 1 = body2, lanes 0..2 of a quad = the x / y / z
+// components of every vector of that body (lane 3 idles).  What was one v_pk_* per component for both bodies becomes ONE plain instruction for both
+// bodies and all three components: cross products read the two other components through quad_perm operands, a dot is the lane's product summed as
+// (x + y) + z through quad broadcasts, the two bodies meet through row_shl:4 / row_shr:4.  Every lane evaluates, for its own component, exactly the
+// expression of solve_core<float> in its order (subtraction from body1 as addition of the exactly negated term: x - y == x + (-y) for every x, y), and the
+// scalar impulse arithmetic is replicated in all eight lanes from bit-identical inputs: the result is the lane-per-manifold form's, bit for bit
+// (the closed-loop parity suites run on this kernel).  Eight times the waves, each ~0.6 of the instruction stream: it pays while a colour's waves
+// still find idle SIMDs (below ~16 k manifolds: launch_pass chooses per colour at capture time).
+namespace oct {
+template <int CTRL> __device__ __forceinline__ float dpp(float x) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true)); }
+__device__ __forceinline__ float rot1(float x) { return dpp<0xC9>(x); }   // quad_perm:[1,2,0,3]: lane j reads component j + 1 (mod 3)
+__device__ __forceinline__ float rot2(float x) { return dpp<0xD2>(x); }   // quad_perm:[2,0,1,3]: component j + 2
+__device__ __forceinline__ float bx(float x) { return dpp<0x00>(x); }     // quad broadcasts of the x / y / z lane
+__device__ __forceinline__ float by(float x) { return dpp<0x55>(x); }
+__device__ __forceinline__ float bz(float x) { return dpp<0xAA>(x); }
+// the other body's lane of the same component: quads 0 and 2 of a row read four lanes up, quads 1 and 3 four lanes down
+__device__ __forceinline__ float partner(float x) {
+    int t = __builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+    t = __builtin_amdgcn_update_dpp(t, __float_as_int(x), 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+    return __int_as_float(t);
+}
+// dot(a, b) = (a.x b.x + a.y b.y) + a.z b.z, the same value in all four lanes of the quad
+__device__ __forceinline__ float dot3(float a, float b) { const float p = a * b; return (bx(p) + by(p)) + bz(p); }
+}  // namespace oct
+
+#define OCT_MANIFOLDS_PER_WAVE 8
+template <bool USE_BIAS>
+__device__ __forceinline__ void solve_core_oct(const DW<float>& w, const StepParams<float>& p, uint32_t m, uint32_t lane8) {
+    using namespace oct;
+    const uint32_t j = lane8 & 3u;
+    const bool q = (lane8 & 4u) != 0u;   // this lane's body: false = body1, true = body2
+    auto sel = [&](float x, float y, float z) { return j == 0u ? x : (j == 1u ? y : z); };
+    // level 1: headers, the four points' records, the body indices
+    const Vec4<float> h1 = w.c_h1[m], h0 = w.m_n[m], h2 = w.m_tv[m];
+    const uint32_t S = w.m_stride;
+    Vec4<float> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        const uint32_t s = k * S + m;
+        pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
+    }
+    const int2 bi = w.m_bodies[m];
+    const uint32_t cm = scalar_to_bits(h1.w);
+    const uint32_t np = cm & 7u;
+    // level 2: this quad's body (paired slots: record i at base[2 i]); DUMMY by selects, as load_body
+    const size_t o = (size_t)(q ? bi.y : bi.x) * 2;
+    const Vec4<float> l4 = w.sb_lin[o], a4 = w.sb_ang[o], dp4 = w.sb_dp[o], dq4 = w.sb_dq[o], sa = w.si_a[o], sb = w.si_b[o];
+    if (np == 0) return;
+    const bool no_body = cm & (q ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1);
+    const bool ni = no_body || (cm & (q ? AVN_CM_DOM2 : AVN_CM_DOM1));
+    float v0 = no_body ? 0.0f : sel(l4.x, l4.y, l4.z);
+    float om0 = no_body ? 0.0f : sel(a4.x, a4.y, a4.z);
+    const float dpj = no_body ? 0.0f : sel(dp4.x, dp4.y, dp4.z);
+    const float b0 = no_body ? 0.0f : sel(dq4.x, dq4.y, dq4.z);
+    const float qw = no_body ? 1.0f : dq4.w;
+    const V3<float> em = effective_inv_mass<float>(sa.x, scalar_to_bits(sb.w));
+    const float im = ni ? 0.0f : sel(em.x, em.y, em.z);
+    // row j of the symmetric tensor {m00 m01 m02 m11 m12 m22} = {sa.y sa.z sa.w sb.x sb.y sb.z}
+    const float I0 = ni ? 0.0f : sel(sa.y, sa.z, sa.w), I1 = ni ? 0.0f : sel(sa.z, sb.x, sb.y), I2 = ni ? 0.0f : sel(sa.w, sb.y, sb.z);
+    const uint32_t neg = q ? 0u : 0x80000000u;   // body1's updates are subtractions
+    auto signed_for_body = [&](float x) { return __uint_as_float(__float_as_uint(x) ^ neg); };
+    // body2's value minus body1's, the same bits in both quads
+    auto d21 = [&](float x) { const float other = partner(x); const float x1 = q ? other : x, x2 = q ? x : other; return x2 - x1; };
+    // apply_impulse: v -/+= imp * inv_mass, om -/+= I (r x imp); `a1, a2` = components j + 1, j + 2 of this body's anchor
+    auto apply = [&](float imp0, float a1, float a2) {
+        v0 = v0 + signed_for_body(imp0 * im);
+        const float cx = a1 * rot2(imp0) - rot1(imp0) * a2;                 // cross(r, imp)_j = r[j+1] imp[j+2] - imp[j+1] r[j+2]
+        const float dw_ = (I0 * bx(cx) + I1 * by(cx)) + I2 * bz(cx);       // smul(I, c)_j = (c0[j] c.x + c1[j] c.y) + c2[j] c.z
+        om0 = om0 + signed_for_body(dw_);
+    };
+    const float n0 = sel(h0.x, h0.y, h0.z);
+    const float friction = h0.w;
+    const SoftCoef<float> soft = (cm & AVN_CM_SOFT_ND) ? p.soft_non_dynamic : p.soft_dynamic;
+    const float delta_secs = p.h_adj;
+    const float dtr = d21(dpj);                              // delta_translation = b2.dp - b1.dp
+    // qrot(dq, v) = (v (w w - b.b) + b ((v.b) 2)) + (b x v) (w 2)
+    const float qb1 = rot1(b0), qb2 = rot2(b0);
+    const float kA = qw * qw - dot3(b0, b0), kC = qw * 2.0f;
+    float ax0[AVN_MAX_MANIFOLD_POINTS], ax1[AVN_MAX_MANIFOLD_POINTS], ax2[AVN_MAX_MANIFOLD_POINTS];   // this body's anchor: components j, j + 1, j + 2
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        const Vec4<float> an = q ? pb[k] : pa[k];
+        ax0[k] = sel(an.x, an.y, an.z); ax1[k] = rot1(ax0[k]); ax2[k] = rot2(ax0[k]);
+    }
+    // normal impulses
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+        if (k < np) {
+            const float a0 = ax0[k], a1 = ax1[k], a2 = ax2[k];
+            const float vb = dot3(a0, b0);
+            const float rw = (a0 * kA + b0 * (vb * 2.0f)) + (qb1 * a2 - a1 * qb2) * kC;
+            const float dsep = dtr + d21(rw);                              // delta_translation + (r2w - r1w)
+            const float separation = dot3(dsep, n0) + pa[k].w;
+            const float vap = v0 + (rot1(om0) * a2 - a1 * rot2(om0));      // velocity_at_point: v + om x anchor
+            const float rel = d21(vap);
+            const float normal_speed = dot3(rel, n0);
+            const float eff_mass = pb[k].w, acc = pd[k].x;
+            float impulse;
+            if (separation > 0.0f) {
+                impulse = -eff_mass * (normal_speed + separation / delta_secs);
+            } else if (USE_BIAS) {
+                const float bias = smax(soft.bias * separation, -p.max_overlap_solve_speed);
+                const float scaled_mass = soft.mass_scale * eff_mass;
+                const float scaled_impulse = soft.impulse_scale * acc;
+                impulse = -scaled_mass * (normal_speed + bias) - scaled_impulse;
+            } else {
+                impulse = -eff_mass * normal_speed;
+            }
+            const float new_impulse = smax(acc + impulse, 0.0f);
+            impulse = new_impulse - acc;
+            pd[k].x = new_impulse;
+            pd[k].y = pd[k].y + new_impulse;
+            apply(impulse * n0, a1, a2);
+        }
+    }
+    // friction
+    if (cm & AVN_CM_TANGENT) {
+        const float t0 = sel(h1.x, h1.y, h1.z);
+        const float t1 = rot1(t0) * rot2(n0) - rot1(n0) * rot2(t0);       // cross(t0, normal)_j
+        const float tv0 = sel(h2.x, h2.y, h2.z);
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            if (k < np) {
+                const float a1 = ax1[k], a2 = ax2[k];
+                const float vap = v0 + (rot1(om0) * a2 - a1 * rot2(om0));
+                const float rel = d21(vap);
+                const float impulse_limit = friction * pd[k].x;
+                const float rv = rel + tv0;
+                const float ts1 = dot3(rv, t0), ts2 = dot3(rv, t1);
+                const float t11 = ts1 * ts1, t22 = ts2 * ts2, t12 = ts1 * ts2;
+                const float inv = t11 * pc[k].x + t22 * pc[k].y + t12 * pc[k].z;
+                const float effective_mass = (t11 + t22) * (1.0f / inv);
+                float out0 = 0.0f;                                        // a non-finite effective mass: Vector::ZERO, still applied
+                if (finite_t(effective_mass)) {
+                    const V2<float> delta{effective_mass * ts1, effective_mass * ts2};
+                    const V2<float> nw = clamp_length_max(V2<float>{pd[k].z - delta.x, pd[k].w - delta.y}, impulse_limit);
+                    const V2<float> di{nw.x - pd[k].z, nw.y - pd[k].w};
+                    pd[k].z = nw.x; pd[k].w = nw.y;
+                    out0 = di.x * t0 + di.y * t1;
+                }
+                apply(out0, a1, a2);
+            }
+        }
+    }
+    if (lane8 == 0u) {
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
+            if (k < np) w.c_pd[k * S + m] = pd[k];
+    }
+    // the x lane of each quad collects its body's components and writes the two velocity records
+    const float vy = rot1(v0), vz = rot2(v0), oy = rot1(om0), oz = rot2(om0);
+    if (j == 0u && !no_body) {
+        w.sb_lin[o] = make4<float>(v0, vy, vz, l4.w);
+        w.sb_ang[o] = make4<float>(om0, oy, oz, a4.w);
+    }
+}
+template <int PASS>
+__global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass_oct(DW<float> w, StepParams<float> p, uint32_t color, uint32_t arg_base, uint32_t arg_end) {
+    uint32_t base = arg_base, end = arg_end;
+    if (arg_end == 0u) { base = w.color_offsets[color]; end = w.color_offsets[color + 1]; }
+    // as k_color_pass: block b on XCD b % 8, every XCD a contiguous eighth of the colour's REAL tiles (here 8 manifolds per tile)
+    const uint32_t tiles = (end - base + OCT_MANIFOLDS_PER_WAVE - 1u) / OCT_MANIFOLDS_PER_WAVE, per = (tiles + 7u) >> 3, row = blockIdx.x >> 3;
+    if (row >= per) return;
+    const uint32_t blk = (blockIdx.x & 7u) * per + row;
+    const uint32_t m = base + blk * OCT_MANIFOLDS_PER_WAVE + (threadIdx.x >> 3);
+    if (m >= end) return;   // (whole manifolds leave: the eight lanes of a group stay together)
+    solve_core_oct<PASS == 1 /* PASS_BIAS */>(w, p, m, threadIdx.x & 7u);
+}
+
 template <class T, int STRIDE, bool COH = false>
 __device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
     Vec4<T> h1 = w.c_h1[m];
@@ -972,7 +1144,18 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_level(DW<T> w, Ste
     if (i >= count) return;
     pass_one<T, PASS>(w, p, order[first + i]);
 }
-template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
+// eight lanes per manifold for the colours of `oct_mask` (f32 biased solve / relax only): eight times the workgroups of the lane form's grid
+template <class T, int PASS> struct OctLaunch { static bool run(const DW<T>&, const StepParams<T>&, uint32_t, uint32_t, uint32_t, uint32_t, hipStream_t) { return false; } };
+template <int PASS> struct OctLaunch<float, PASS> {
+    static bool run(const DW<float>& w, const StepParams<float>& p, uint32_t c, uint32_t blocks, uint32_t b, uint32_t e, hipStream_t s) {
+        if constexpr (PASS == PASS_BIAS || PASS == PASS_RELAX) {
+            hipLaunchKernelGGL((k_color_pass_oct<PASS>), dim3(blocks * (CONTACT_THREADS / OCT_MANIFOLDS_PER_WAVE)), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e);
+            return true;
+        }
+        return false;
+    }
+};
+template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const StepParams<T>& p, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s, uint32_t oct_mask) {
     uint32_t launches = 0;
     if (grid_blocks[AVN_COLOR_OVERFLOW_INDEX] && ovf.n_glevels) {
         for (uint32_t l = 0; l < ovf.n_glevels; ++l) {
@@ -989,7 +1172,8 @@ template <class T, int PASS> static uint32_t launch_pass(const DW<T>& w, const S
         if (grid_blocks[c]) {
             uint32_t b = arg_offsets ? arg_offsets[c] : 0u, e = arg_offsets ? arg_offsets[c + 1] : 0u;
             if (arg_offsets && e == b) continue;  // (a captured range is exact: an empty colour needs no launch)
-            hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e);
+            if (!((oct_mask >> c) & 1u) || !OctLaunch<T, PASS>::run(w, p, c, grid_blocks[c], b, e, s))
+                hipLaunchKernelGGL((k_color_pass<T, PASS>), dim3(grid_blocks[c]), dim3(CONTACT_THREADS), 0, s, w, p, c, b, e);
             ++launches;
         }
     return launches;
@@ -1140,16 +1324,16 @@ template <class T> void launch_body_warm_start(const DW<T>& w, const StepParams<
     if (fuse_integrate_velocities) hipLaunchKernelGGL((k_body_warm_start<T, true>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
     else hipLaunchKernelGGL((k_body_warm_start<T, false>), dim3(nb), dim3(WS_THREADS), 0, s, w, p);
 }
-template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s) {
+template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams<T>& p, int pass, const uint32_t* grid_blocks, const uint32_t* arg_offsets, const OverflowSchedule& ovf, hipStream_t s, uint32_t oct_mask) {
     switch (pass) {
         case PASS_WARM: return 0;  // warm start is body-centric: launch_body_warm_start
-        case 4: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_WARM_START_COLORS: colour by colour
+        case 4: return launch_pass<T, PASS_WARM>(w, p, grid_blocks, arg_offsets, ovf, s, 0u);   // PASS_WARM_START_COLORS: colour by colour
 #ifdef AVN_MEASURE
-        case 5: return launch_pass<T, PASS_SKELETON>(w, p, grid_blocks, arg_offsets, ovf, s);   // PASS_MEMORY_SKELETON (measurement aid, `make measure` only)
+        case 5: return launch_pass<T, PASS_SKELETON>(w, p, grid_blocks, arg_offsets, ovf, s, 0u);   // PASS_MEMORY_SKELETON (measurement aid, `make measure` only)
 #endif
-        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, arg_offsets, ovf, s);
-        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, arg_offsets, ovf, s);
-        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, arg_offsets, ovf, s);
+        case PASS_BIAS: return launch_pass<T, PASS_BIAS>(w, p, grid_blocks, arg_offsets, ovf, s, oct_mask);
+        case PASS_RELAX: return launch_pass<T, PASS_RELAX>(w, p, grid_blocks, arg_offsets, ovf, s, oct_mask);
+        default: return launch_pass<T, PASS_RESTITUTION>(w, p, grid_blocks, arg_offsets, ovf, s, 0u);
     }
 }
 
@@ -1158,7 +1342,7 @@ template <class T> uint32_t launch_contact_pass(const DW<T>& w, const StepParams
     template void launch_store_contact_impulses<T>(const DW<T>&, hipStream_t);                              \
     template void launch_body_warm_start<T>(const DW<T>&, const StepParams<T>&, bool, bool, hipStream_t);   \
     template void launch_build_incidence_slots<T>(const DW<T>&, hipStream_t, bool);                               \
-    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t); \
+    template uint32_t launch_contact_pass<T>(const DW<T>&, const StepParams<T>&, int, const uint32_t*, const uint32_t*, const OverflowSchedule&, hipStream_t, uint32_t); \
     template void launch_overflow_flow<T>(const DW<T>&, const StepParams<T>&, int, const OverflowFlow&, uint32_t, uint32_t, hipStream_t);
 INST(float)
 INST(double)

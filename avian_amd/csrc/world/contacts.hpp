@@ -173,6 +173,11 @@
         return AVN_OK;
     }
     uint32_t ovf_grid_blocks = 0;   // device closed loop: captured grid of the overflow colour's dataflow pass (with slack, like the colours')
+    // Colours small enough to leave most SIMDs idle run the eight-lanes-per-manifold solve (k_color_pass_oct, f32): chosen per colour with hysteresis, and only
+    // ever changed together with a re-capture of the substep graph.  Bit-identical either way.  (AVN_NO_OCT=1 in `make measure` builds: A/B.)
+    uint32_t oct_mask = 0;
+    bool oct_enabled = sizeof(T) == 4;
+    static constexpr uint32_t OCT_ON = 12288, OCT_OFF = 20480;
     void set_color_offsets(const uint32_t* offsets) {
         if (!use_handles && std::memcmp(color_offsets, offsets, sizeof color_offsets) != 0) graph_valid = false;  // (ranges captured as kernel arguments; handle mode reads them from the device)
         std::memcpy(color_offsets, offsets, sizeof color_offsets);
@@ -194,6 +199,9 @@
                 grid_blocks[c] = cnt ? color_grid_blocks(cnt + cnt / 4 + 64) : 0u;
                 graph_valid = false;
             }
+            const bool was = (oct_mask >> c) & 1u;
+            const bool now = oct_enabled && !halo_on && cnt != 0 && (was ? cnt <= OCT_OFF : cnt <= OCT_ON);
+            if (now != was) { oct_mask ^= 1u << c; graph_valid = false; }
         }
     }
     avn_status manifold_handles_upload(const uint32_t* offsets, const uint32_t* ids) override {

@@ -49,7 +49,7 @@
             std::memcpy(gb, grid_blocks, sizeof gb);
             gb[AVN_COLOR_OVERFLOW_INDEX] = 0;
             OverflowSchedule none{0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
-            launches += launch_contact_pass<T>(dw, params, pass, gb, nullptr, none, stream);
+            launches += launch_contact_pass<T>(dw, params, pass, gb, nullptr, none, stream, oct_mask);
             return;
         }
         OverflowSchedule ovf{sched_overflow.n_components, sched_overflow.d_comp_level_begin.as<uint32_t>(), sched_overflow.d_level_offsets.as<uint32_t>(),
@@ -59,7 +59,7 @@
             ovf.glevel_offsets = sched_overflow.glevel_offsets.data();
             ovf.n_glevels = (uint32_t)sched_overflow.glevel_offsets.size() - 1;
         }
-        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, use_handles ? nullptr : color_offsets, ovf, stream);
+        launches += launch_contact_pass<T>(dw, params, pass, grid_blocks, use_handles ? nullptr : color_offsets, ovf, stream, oct_mask);
     }
     // The reference runs the snapshot and the velocity projection over ALL active bodies whenever XpbdSolverPlugin is
     // installed (xpbd/plugin.rs:61-76,192-240).  With no joints the projection adds 2 * (dq * conj(dq)).xyz / h:

@@ -684,8 +684,100 @@ class ShardedClosedLoop:
         return self.phase3(all_gather(self.phase2(all_gather(self.phase1()))))
 
 
+class ShardedClosedLoopNative:
+    """One rank of the closed loop sharded by islands with the replicated bookkeeping in the LIBRARY (``avn_shard_*``, host C++: round 5) -- the same
+    three phases as :class:`ShardedClosedLoop` (kept as the readable model and second opinion), but the payloads are FLAT arrays (no pickled objects)
+    and no per-pair Python loop runs: ``phase1() -> (key_collider u32[], key_min_x f64[], pairs SHARD_PAIR_DTYPE[])``,
+    ``phase2(gathered) -> changes CHANGE_DTYPE[]``, ``phase3(gathered)``.  ``step(gather)`` runs them over ``gather(array) -> every rank's
+    arrays concatenated`` (a tensor all-gather with a count exchange in the multi-process drivers, plain concatenation in one process)."""
+
+    def __init__(self, lib: F.Library, world: F.World, p: ShardPlan, rank: int, colliders: Dict[str, np.ndarray]):
+        self.lib, self.w, self.plan, self.rank = lib, world, p, rank
+        self.loc = p.local_bodies(rank)                    # local body -> global body
+        ent = np.asarray(colliders["entity_index"], np.uint32)
+        owner = p.rank_of_body[np.asarray(colliders["body"])]
+        # every collider's min.x key is contributed by ONE rank: its body's owner, static bodies by rank 0
+        self.my_colliders = np.flatnonzero((owner == rank) | ((owner < 0) & (rank == 0))).astype(np.uint32)
+        loc_ent = ent[np.flatnonzero((owner == rank) | (owner < 0))]      # the sub-world's colliders, in its upload order
+        slot = {int(e): i for i, e in enumerate(loc_ent)}
+        self.my_local_slots = np.array([slot[int(ent[g])] for g in self.my_colliders], np.int64)
+        self.shard = F.Shard(lib, ent, rank)
+
+    def phase1(self):
+        w = self.w
+        w.run_system("UPDATE_AABB")
+        w.run_system("COLLECT_COLLISION_PAIRS")
+        mn, _, _ = w.aabbs_download()
+        keys = np.asarray(mn[self.my_local_slots, 0], np.float64)
+        pr = w.pairs_get()
+        new = np.zeros(len(pr), F.SHARD_PAIR_DTYPE)
+        new["collider1"], new["collider2"], new["flags"] = pr["collider1"], pr["collider2"], pr["flags"]
+        new["body1"], new["body2"] = self.loc[pr["body1"]], self.loc[pr["body2"]]
+        new["owner"] = self.rank
+        return self.my_colliders, keys, new
+
+    def phase2(self, key_collider, key_min_x, pairs):
+        ids, c1, c2, fl = self.shard.phase2(key_collider, key_min_x, pairs)
+        if len(ids):
+            self.w.contact_pairs_add(ids, c1, c2, fl)
+        self.w.active_pairs_set(self.shard.active())
+        self.w.run_system("NARROW_PHASE")
+        return self.w.contact_changes_get().copy()
+
+    def phase3(self, changes):
+        removed_local = self.shard.phase3(changes)
+        if len(removed_local):
+            self.w.contact_pairs_remove(removed_local)
+            self.w.active_pairs_set(self.shard.active())
+        off, handles = self.shard.handles()
+        self.w.manifold_handles_upload(off, handles)
+        self.w.run_system("SOLVER")
+        return len(changes)
+
+    @property
+    def global_lists(self):
+        return self.shard.handles(global_lists=True)
+
+    def step(self, gather):
+        kc, kx, pr = self.phase1()
+        ch = self.phase2(gather(kc), gather(kx), gather(pr))
+        return self.phase3(gather(ch))
+
+
+def tensor_gather(dist, torch):
+    """``gather(array) -> every rank's arrays concatenated in rank order`` over torch.distributed with FLAT tensors: one all_gather of the byte
+    counts, one of the payloads padded to the largest (no pickled objects).  Works on gloo (CPU tensors) and on nccl = RCCL (device tensors)."""
+    world = dist.get_world_size()
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+    def gather(a):
+        a = np.ascontiguousarray(a)
+        raw = a.view(np.uint8).reshape(-1)
+        n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+        counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(counts, n)
+        counts = [int(c.item()) for c in counts]
+        cap = max(max(counts), 1)
+        buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+        if raw.size: buf[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
+        parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        out = np.concatenate([parts[r][:counts[r]].cpu().numpy() for r in range(world)]) if sum(counts) else np.zeros(0, np.uint8)
+        return out.view(a.dtype)
+
+    return gather
+
+
+def step_in_process_native(loops: List["ShardedClosedLoopNative"]):
+    """One step of every rank in ONE process: the gathers are concatenations in rank order."""
+    p1 = [l.phase1() for l in loops]
+    kc, kx, pr = (np.concatenate([x[i] for x in p1]) for i in range(3))
+    ch = np.concatenate([l.phase2(kc, kx, pr) for l in loops])
+    return [l.phase3(ch) for l in loops]
+
+
 def sharded_closed_loop_worlds(lib: F.Library, bits: int, bodies: Dict[str, np.ndarray], colliders: Dict[str, np.ndarray], p: ShardPlan, substeps: int = 4,
-                               friction: float = 0.5):
+                               friction: float = 0.5, native: bool = False):
     """The sub-worlds of every rank of ``p`` in ONE process (tests: two worlds on one device), each with its ShardedClosedLoop."""
     out = []
     for r in range(p.world_size):
@@ -693,7 +785,8 @@ def sharded_closed_loop_worlds(lib: F.Library, bits: int, bodies: Dict[str, np.n
         c = split_colliders(g2l, colliders)
         w = F.World(lib, F.default_config(bits, substeps=substeps))
         w.bodies_upload(**b); w.colliders_upload(**c); w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=friction)
-        out.append((w, ShardedClosedLoop(lib, w, p, r, colliders, np.asarray(bodies["rb_type"])), loc))
+        loop = ShardedClosedLoopNative(lib, w, p, r, colliders) if native else ShardedClosedLoop(lib, w, p, r, colliders, np.asarray(bodies["rb_type"]))
+        out.append((w, loop, loc))
     return out
 
 

@@ -913,6 +913,38 @@ typedef struct avn_despawn_list {
 #define AVN_DESPAWN_LIST_SIZE_R4 (offsetof(avn_despawn_list, n_joints))
 AVN_API avn_status AVN_FN(despawn)(avn_world* w, const avn_despawn_list* d);
 
+/* ---- the closed loop sharded by ISLANDS: replicated integer bookkeeping (round 5; host C++, no device needed) ---------------------------------------------
+ * Islands spread over ranks, results equal to the single world's bit for bit.  The reference's IdPool hands out the LOWEST free ContactId in the broad
+ * phase's GLOBAL emission order (data_structures/id_pool.rs:31-40, collision/broad_phase.rs:387-388), NarrowPhase::update walks status changes in
+ * ascending id (collision/narrow_phase/system_param.rs:141-145) and pop_manifold's swap_remove moves a colour's LAST handle into the hole
+ * (dynamics/solver/constraint_graph.rs:245-296): one island's ids, colours and list positions depend on what other islands did.  So every rank
+ * REPLAYS everything that is integer from flat arrays the ranks all-gather, and runs only its own islands' physics through the low-level calls above:
+ *
+ *   per step, rank r:   avn_run_system(UPDATE_AABB), (COLLECT_COLLISION_PAIRS); avn_aabbs_download, avn_pairs_get
+ *     all-gather        (global collider slot, min.x) of the colliders whose body r owns [12 B each], avn_shard_pair of r's new pairs [24 B each]
+ *     avn_shard_phase2  -> the global interval order (a stable sort of last frame's order: broad_phase.rs:373-387), ids in the global emission order
+ *                       -> avn_shard_new_local_pairs -> avn_contact_pairs_add; avn_shard_active -> avn_active_pairs_set; avn_run_system(NARROW_PHASE)
+ *     all-gather        avn_contact_changes_get [16 B per change]
+ *     avn_shard_phase3  -> every rank's changes on the replicated ConstraintGraph in ascending id; avn_shard_removed_local -> avn_contact_pairs_remove;
+ *                          avn_shard_handles(local) -> avn_manifold_handles_upload (the global colour lists restricted to r's pairs: relative order
+ *                          kept, which is all the overflow colour's serial solve needs); avn_run_system(SOLVER)
+ *
+ * Bodies of different ranks must not come into AABB contact (avn_bounds_exchange detects it, the level-1 re-partition handles it).  Body indices in
+ * avn_shard_pair are GLOBAL (the single world's); collider entities are global by nature. */
+typedef struct avn_shard avn_shard;
+typedef struct avn_shard_pair { uint32_t collider1, collider2; int32_t body1, body2; uint32_t flags; uint32_t owner; } avn_shard_pair;   /* owner = the rank that emitted it */
+typedef struct avn_shard_stats { uint32_t pairs_added, pairs_removed, pushes, pops, next_id, n_free, last_status_changes, reserved; } avn_shard_stats;
+AVN_API avn_status AVN_FN(shard_create)(uint32_t n_colliders, const uint32_t* collider_entities /* every collider of the single world, upload order */, uint32_t rank, avn_shard** out);
+AVN_API void AVN_FN(shard_destroy)(avn_shard* s);
+AVN_API const char* AVN_FN(shard_last_error)(const avn_shard* s);
+AVN_API avn_status AVN_FN(shard_phase2)(avn_shard* s, const uint32_t* key_collider /* global slots */, const double* key_min_x, size_t n_keys, const avn_shard_pair* pairs, size_t n_pairs);
+AVN_API avn_status AVN_FN(shard_new_local_pairs)(avn_shard* s, const uint32_t** contact_id, const uint32_t** collider1, const uint32_t** collider2, const uint32_t** flags, size_t* n);
+AVN_API avn_status AVN_FN(shard_active)(avn_shard* s, const uint32_t** contact_id, size_t* n);
+AVN_API avn_status AVN_FN(shard_phase3)(avn_shard* s, const avn_contact_change* changes /* all ranks', any order */, size_t n);
+AVN_API avn_status AVN_FN(shard_removed_local)(avn_shard* s, const uint32_t** contact_id, size_t* n);
+AVN_API avn_status AVN_FN(shard_handles)(avn_shard* s, int global /* 0: this rank's restriction, 1: the single world's lists */, uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1], const uint32_t** contact_id, size_t* n);
+AVN_API avn_status AVN_FN(shard_stats_get)(avn_shard* s, avn_shard_stats* out);
+
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as
  * doubles: the per-rank bound exchanged between ranks to detect islands of different ranks coming into AABB contact.
  * Empty worlds return min = +inf, max = -inf. */

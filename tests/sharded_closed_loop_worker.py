@@ -28,15 +28,22 @@ def main():
     c = shard.split_colliders(g2l, colliders)
     w = F.World(lib, F.default_config(32, substeps=4))
     w.bodies_upload(**b); w.colliders_upload(**c); w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
-    loop = shard.ShardedClosedLoop(lib, w, p, rank, colliders, np.asarray(bodies["rb_type"]))
+    native = len(sys.argv) > 3 and sys.argv[3] == "native"
 
     def all_gather(obj):
         box = [None] * world
         dist.all_gather_object(box, obj)
         return box
 
-    for _ in range(steps):
-        loop.step(all_gather)
+    if native:   # the bookkeeping in the library (avn_shard_*), the three exchanges as flat tensors
+        loop = shard.ShardedClosedLoopNative(lib, w, p, rank, colliders)
+        gather = shard.tensor_gather(dist, torch)
+        for _ in range(steps):
+            loop.step(gather)
+    else:
+        loop = shard.ShardedClosedLoop(lib, w, p, rank, colliders, np.asarray(bodies["rb_type"]))
+        for _ in range(steps):
+            loop.step(all_gather)
     mine = p.rank_of_body[loc] == rank
     got = all_gather((loc[mine], {k: v[mine] for k, v in w.bodies_download().items()}))
     if rank == 0:
