@@ -502,7 +502,7 @@ def main():
         line_holder = {}
 
         def watchdog():
-            if not done.wait(float(os.environ.get("AVN_BENCH_LEVEL2_TIMEOUT", "120"))):
+            if not done.wait(float(os.environ.get("AVN_BENCH_LEVEL2_TIMEOUT", "180"))):
                 if rank == 0 and "make" in line_holder:
                     part = dict(line_holder.get("partial") or {}, status="timeout" if "partial" not in line_holder else "ok (cfg5 leg timed out)")
                     print(json.dumps(line_holder["make"](part)), flush=True)
@@ -521,6 +521,49 @@ def main():
         nx_, ny_, nz_, _ = SCENES[args.scene]
     else:
         done = None
+
+    # ---- N > 1: the closed loop SHARDED BY ISLANDS (round 5): the reference's Many Pyramids scene (5 500 boxes, 100 islands), whole pyramids per rank, the
+    # integer bookkeeping replicated in the library (avn_shard_*), three flat-tensor all-gathers per step.  Every rank checks that its replicated colour lists
+    # hash to rank 0's.  Not part of `value`; measured for the first time on the driver's node (development boxes have one GPU: tests/test_gpu_sharded_closed_loop.py
+    # runs the same code as four worlds on one device).
+    sharded_holder = {}
+
+    def run_sharded_leg():
+        import zlib
+        from avian_amd import scenes as _sc
+        base, rows, cols = 10, 10, 10
+        scs = _sc.many_pyramids(base, rows, cols)
+        bodies_s, colliders_s = scs.body_kwargs(), scs.collider_kwargs()
+        per = base * (base + 1) // 2
+        pyr = (np.arange(scs.n) - rows) // per
+        rk = np.where(np.arange(scs.n) < rows, -1, pyr * world_size // (rows * cols)).astype(np.int32)
+        pl = shard.ShardPlan(world_size, rk.copy(), rk, rows * cols)
+        b_, loc_, g2l_ = shard.split_bodies(pl, rank, bodies_s)
+        c_ = shard.split_colliders(g2l_, colliders_s)
+        ws = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
+        ws.bodies_upload(**b_); ws.colliders_upload(**c_); ws.existing_pairs_upload(np.zeros(0, np.uint64)); ws.collider_materials_upload(friction=0.5)
+        loop = shard.ShardedClosedLoopNative(lib, ws, pl, rank, colliders_s)
+        gather = shard.tensor_gather(dist, torch)
+        for _ in range(10):
+            loop.step(gather)
+        barrier(); c0 = time.perf_counter()
+        n_st = 30
+        changes = 0
+        for _ in range(n_st):
+            changes += loop.step(gather)
+        ws.synchronize(); barrier()
+        dt_local = time.perf_counter() - c0
+        tt = torch.tensor([dt_local], dtype=torch.float64, device=coll_device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        off, handles = loop.global_lists
+        h = zlib.crc32(handles.tobytes(), zlib.crc32(off.tobytes()))
+        hs = gather(np.array([h], np.uint32))
+        st = loop.shard.stats()
+        return {"status": "ok", "scene": "Many Pyramids 3D (5 500 boxes, 100 islands), whole pyramids per rank", "n_ranks": world_size, "steps": n_st,
+                "ms_per_step": round(float(tt.item()) / n_st * 1e3, 3), "substeps_per_s": round(n_st * substeps / float(tt.item()), 2),
+                "status_changes_per_step": round(changes / n_st, 1), "contact_ids_handed_out": int(st.next_id), "pairs_removed": int(st.pairs_removed),
+                "replicated_colour_lists_equal_on_all_ranks": bool((hs == hs[0]).all()),
+                "bookkeeping": "avn_shard_* (host C++), payloads as flat tensors over torch.distributed (" + backend + "); physics through the low-level ABI (host pipeline mode)"}
 
     def make_line(level2_obj):
         total_substeps = world_size * args.steps * substeps
@@ -556,6 +599,8 @@ def main():
             "closed_loop": closed,
             "cpu_baseline": cpu,
         }
+        if sharded_holder:
+            out["closed_loop_sharded"] = sharded_holder.get("result")
         if level2_obj is not None:
             out["level2"] = level2_obj
             # The STRONG-scaling figure of an N > 1 run, at the top level (`value` / `scaling` above stay the contract's weak-scaling figure:
@@ -574,6 +619,13 @@ def main():
                                      "note": "level-2 sharding (DESIGN.md section 6): measured for the first time on the driver's multi-GPU node; no curve exists from development (one GPU per box)"}
         return out
 
+    if world_size > 1 and os.environ.get("AVN_BENCH_SHARDED", "1") != "0":
+        if done is not None:
+            line_holder["make"] = make_line   # (under the level-2 watchdog from here on: a hang prints the line without this leg)
+        try:
+            sharded_holder["result"] = run_sharded_leg()
+        except Exception as e:  # noqa: BLE001 -- never fatal for the headline figure
+            sharded_holder["result"] = {"status": "error: " + str(e)[:300]}
     if done is not None:
         line_holder["make"] = make_line
         try:
