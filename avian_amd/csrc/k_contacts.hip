@@ -779,8 +779,8 @@ __device__ __forceinline__ void solve_core_oct(const DW<float>& w, const StepPar
     const int2 bi = w.m_bodies[m];
     const uint32_t cm = scalar_to_bits(h1.w);
     const uint32_t np = cm & 7u;
-    // level 2: this quad's body (paired slots: record i at base[2 i]); DUMMY by selects, as load_body
-    const size_t o = (size_t)(q ? bi.y : bi.x) * 2;
+    // level 2: this quad's body (Pair2::operator[] addresses the paired slots: record i at base[2 i]); DUMMY by selects, as load_body
+    const size_t o = (size_t)(q ? bi.y : bi.x);
     const Vec4<float> l4 = w.sb_lin[o], a4 = w.sb_ang[o], dp4 = w.sb_dp[o], dq4 = w.sb_dq[o], sa = w.si_a[o], sb = w.si_b[o];
     if (np == 0) return;
     const bool no_body = cm & (q ? AVN_CM_NOBODY2 : AVN_CM_NOBODY1);

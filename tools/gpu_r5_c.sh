@@ -17,5 +17,3 @@ bash tools/closed_loop_quick.sh r5c_oct > /dev/null 2>&1; cp $R/gpurun_out/quick
 for e in 0 1; do echo "== reference scenes, AVN_NO_OCT=$e"; if [ $e = 1 ]; then export AVN_NO_OCT=1; else unset AVN_NO_OCT; fi; AVN_LIB_PATH=$M timeout 300 python tools/bench_reference_scenes.py 200 2 $O/ref_scenes_nooct$e.json 2>&1 | tail -3; done > $O/ref_scenes.txt 2>&1
 unset AVN_NO_OCT
 cat $O/ref_scenes.txt
-timeout 900 python -m pytest -x -q -m gpu -p no:cacheprovider tests/test_gpu_sleeping.py tests/test_gpu_sleep.py tests/test_gpu_switches.py tests/test_gpu_islands.py tests/test_gpu_island_streams.py tests/test_gpu_joints.py tests/test_gpu_level2.py tests/test_gpu_narrow.py tests/test_gpu_physics_sanity.py tests/test_gpu_pipeline_edges.py tests/test_gpu_sharded_closed_loop.py tests/test_gpu_slabs.py tests/test_gpu_golden.py tests/test_gpu_diagnostics.py > $O/tests_rest.txt 2>&1
-tail -4 $O/tests_rest.txt
