@@ -796,8 +796,13 @@ __device__ __forceinline__ void solve_core_oct(const DW<float>& w, const StepPar
     const float I0 = ni ? 0.0f : sel(sa.y, sa.z, sa.w), I1 = ni ? 0.0f : sel(sa.z, sb.x, sb.y), I2 = ni ? 0.0f : sel(sa.w, sb.y, sb.z);
     const uint32_t neg = q ? 0u : 0x80000000u;   // body1's updates are subtractions
     auto signed_for_body = [&](float x) { return __uint_as_float(__float_as_uint(x) ^ neg); };
-    // body2's value minus body1's, the same bits in both quads
-    auto d21 = [&](float x) { const float other = partner(x); const float x1 = q ? other : x, x2 = q ? x : other; return x2 - x1; };
+    // body2's value minus body1's, the same bits in both quads: body1's lanes (quads 0 and 2 of a row) compute partner - own, body2's own - partner, as
+    // two DPP subtractions (s_nop: a VALU result read through DPP needs two wait states, and the assembler sees no hazards inside inline asm)
+    auto d21 = [&](float x) {
+        float r;
+        asm("s_nop 1\n\tv_sub_f32_dpp %0, %1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\tv_subrev_f32_dpp %0, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(r) : "v"(x));
+        return r;
+    };
     // apply_impulse: v -/+= imp * inv_mass, om -/+= I (r x imp); `a1, a2` = components j + 1, j + 2 of this body's anchor
     auto apply = [&](float imp0, float a1, float a2) {
         v0 = v0 + signed_for_body(imp0 * im);

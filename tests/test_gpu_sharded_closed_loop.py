@@ -35,7 +35,7 @@ def test_two_sharded_worlds_on_one_device_equal_the_single_world(bits):
 def test_native_sharded_closed_loop_many_pyramids_on_one_device_and_its_bookkeeping_cost():
     """Round 5: the bookkeeping in the library (avn_shard_*), flat payloads.  The reference's Many Pyramids scene (5 500 boxes, 100 islands) as 4 sub-worlds
     on ONE device against the single HIP world every step for 60 steps; and what a step of the replicated bookkeeping costs the host next to the step
-    itself (printed; tools/time_sharded.py reports it for the bench)."""
+    itself (printed)."""
     import time
     from avian_amd import scenes
     base, rows, cols = 10, 10, 10
