@@ -72,18 +72,8 @@ __device__ __forceinline__ void st_rec_agent(Vec4<double>* base, size_t idx, Vec
     __builtin_amdgcn_raw_buffer_store_b128(u32x4{(uint32_t)__double2loint(v.z), (uint32_t)__double2hiint(v.z), (uint32_t)__double2loint(v.w), (uint32_t)__double2hiint(v.w)}, rs,
                                            (int)(idx * sizeof(Vec4<double>) + 16), 0, AVN_BUF_AUX_SC1);
 }
-template <class T, bool WITH_DELTA, int STRIDE, bool COH = false>
-__device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
-    // The six records are fetched UNCONDITIONALLY (every body index is a valid row; rows of bodies without a SolverBody
-    // hold DUMMY values) and the DUMMY substitution is a select afterwards: no load waits on the constraint's flag word,
-    // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
-    const size_t o = (size_t)idx * STRIDE;
-    Vec4<T> l, a;
-    if (COH) { l = ld_rec_agent(bv.lin, o); a = ld_rec_agent(bv.ang, o); }   // (the velocities are the only records a contact pass writes)
-    else { l = bv.lin[o]; a = bv.ang[o]; }
-    Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
-    if (WITH_DELTA) { dp = bv.dp[o]; dq = bv.dq[o]; }
-    Vec4<T> sa = bv.sia[o], sb = bv.sib[o];
+// the DUMMY substitutions on the six records of a body as they lie in memory (by value: plain registers for the compiler)
+template <class T, bool WITH_DELTA> __device__ __forceinline__ void body_from_recs(Vec4<T> l, Vec4<T> a, Vec4<T> dp, Vec4<T> dq, Vec4<T> sa, Vec4<T> sb, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
     // branch-free selects (v_cndmask): nothing for the compiler to sink the loads into
     const T z = T(0);
     b.v = V3<T>{no_body ? z : l.x, no_body ? z : l.y, no_body ? z : l.z};
@@ -96,6 +86,20 @@ __device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool n
     V3<T> em = effective_inv_mass<T>(sa.x, scalar_to_bits(sb.w));
     b.inv_mass = V3<T>{ni ? z : em.x, ni ? z : em.y, ni ? z : em.z};
     b.I = Sym3<T>{ni ? z : sa.y, ni ? z : sa.z, ni ? z : sa.w, ni ? z : sb.x, ni ? z : sb.y, ni ? z : sb.z};
+}
+template <class T, bool WITH_DELTA, int STRIDE, bool COH = false>
+__device__ __forceinline__ void load_body(const BodyView<T>& bv, int idx, bool no_body, bool dummy_inertia, BodyRef<T>& b) {
+    // The six records are fetched UNCONDITIONALLY (every body index is a valid row; rows of bodies without a SolverBody
+    // hold DUMMY values) and the DUMMY substitution is a select afterwards: no load waits on the constraint's flag word,
+    // so the kernel has two dependent memory levels (headers + point records | body gathers) instead of three.
+    const size_t o = (size_t)idx * STRIDE;
+    Vec4<T> l, a;
+    if (COH) { l = ld_rec_agent(bv.lin, o); a = ld_rec_agent(bv.ang, o); }   // (the velocities are the only records a contact pass writes)
+    else { l = bv.lin[o]; a = bv.ang[o]; }
+    Vec4<T> dp = make4<T>(0, 0, 0, 0), dq = make4<T>(0, 0, 0, 1);
+    if (WITH_DELTA) { dp = bv.dp[o]; dq = bv.dq[o]; }
+    Vec4<T> sa = bv.sia[o], sb = bv.sib[o];
+    body_from_recs<T, WITH_DELTA>(l, a, dp, dq, sa, sb, no_body, dummy_inertia, b);
 }
 template <class T, int STRIDE, bool COH = false> __device__ __forceinline__ void store_body(const BodyView<T>& bv, int idx, bool no_body, const BodyRef<T>& b) {
     if (no_body) return;  // writes to a DUMMY body are discarded
@@ -628,26 +632,56 @@ __device__ __forceinline__ void apply_impulse(BodyPair& b, V3<float> imp, V3<F2>
 //  one record per side -- timed with the existing records reinterpreted that way (wrong values, same instruction stream): 120 -> 84 v_mov,
 //  1 386 -> 1 353 VALU instructions, 8.006 -> 7.926 us per isolated launch (A/B on one box, twice).  1 % for a second copy of the anchors
 //  (the body-centric warm start reads ONE side per entry and would otherwise fetch both): not built.)
-template <bool USE_BIAS, int STRIDE, bool COH = false>
-__device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2) {
+// What k_overflow_flow_tag hands to solve_core_packed: the records of the manifold and of its two bodies already in registers (loaded before
+// / by the tag wait) and the tags the velocity records leave with.  NoPre: the pass fetches everything itself (every other caller).
+struct NoPre { static constexpr bool on = false; };
+struct FlowPre {
+    static constexpr bool on = true;
+    Vec4<float> h0, h1, h2, pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+    Vec4<float> l1, a1, dp1, dq1, sa1, sb1, l2, a2, dp2, dq2, sa2, sb2;
+    bool no1, no2;          // no SolverBody on that side (rank PG_NONE)
+    uint32_t tag1, tag2;    // next tags
+};
+template <bool USE_BIAS, int STRIDE, bool COH = false, class PRE = NoPre>
+__device__ __forceinline__ void solve_core_packed(const DW<float>& w, const StepParams<float>& p, uint32_t m, const BodyView<float>& bv, int i1, int i2, const PRE& pre = PRE()) {
     typedef float T;
     // memory levels exactly as solve_one: (headers + point records) | body gathers
-    Vec4<T> h1 = w.c_h1[m];
-    Vec4<T> h0 = w.m_n[m];
-    Vec4<T> h2 = w.m_tv[m];
+    Vec4<T> h1, h0, h2;
     uint32_t S = w.m_stride;
     Vec4<T> pa[AVN_MAX_MANIFOLD_POINTS], pb[AVN_MAX_MANIFOLD_POINTS], pc[AVN_MAX_MANIFOLD_POINTS], pd[AVN_MAX_MANIFOLD_POINTS];
+    if constexpr (PRE::on) {
+        h1 = pre.h1; h0 = pre.h0; h2 = pre.h2;
 #pragma unroll
-    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
-        uint32_t s = k * S + m;
-        pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) { pa[k] = pre.pa[k]; pb[k] = pre.pb[k]; pc[k] = pre.pc[k]; pd[k] = pre.pd[k]; }
+    } else {
+        h1 = w.c_h1[m];
+        h0 = w.m_n[m];
+        h2 = w.m_tv[m];
+#pragma unroll
+        for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+            uint32_t s = k * S + m;
+            pa[k] = w.c_pa[s]; pb[k] = w.c_pb[s]; pc[k] = w.c_pc[s]; pd[k] = w.c_pd[s];
+        }
     }
     uint32_t cm = scalar_to_bits(h1.w);
     uint32_t np = cm & 7u;
     BodyRef<T> b1, b2;
-    load_body<T, true, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, true, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
-    if (np == 0) return;
+    bool no1 = cm & AVN_CM_NOBODY1, no2 = cm & AVN_CM_NOBODY2;
+    if constexpr (PRE::on) {
+        no1 = pre.no1; no2 = pre.no2;
+        body_from_recs<T, true>(pre.l1, pre.a1, pre.dp1, pre.dq1, pre.sa1, pre.sb1, no1, cm & AVN_CM_DOM1, b1);
+        body_from_recs<T, true>(pre.l2, pre.a2, pre.dp2, pre.dq2, pre.sa2, pre.sb2, no2, cm & AVN_CM_DOM2, b2);
+        b1.lin_w = b1.ang_w = __uint_as_float(pre.tag1); b2.lin_w = b2.ang_w = __uint_as_float(pre.tag2);
+        if (np == 0) {   // (nothing to solve; the tags still move: they are the hand-over)
+            store_body<T, STRIDE, COH>(bv, i1, no1, b1);
+            store_body<T, STRIDE, COH>(bv, i2, no2, b2);
+            return;
+        }
+    } else {
+        load_body<T, true, STRIDE, COH>(bv, i1, no1, cm & AVN_CM_DOM1, b1);
+        load_body<T, true, STRIDE, COH>(bv, i2, no2, cm & AVN_CM_DOM2, b2);
+        if (np == 0) return;
+    }
     BodyPair bp;
     bp.v = pair3(b1.v, b2.v); bp.om = pair3(b1.om, b2.om); bp.inv_mass = pair3(b1.inv_mass, b2.inv_mass);
     bp.I = Sym3<F2>{F2(b1.I.m00, b2.I.m00), F2(b1.I.m01, b2.I.m01), F2(b1.I.m02, b2.I.m02), F2(b1.I.m11, b2.I.m11), F2(b1.I.m12, b2.I.m12), F2(b1.I.m22, b2.I.m22)};
@@ -722,8 +756,8 @@ __device__ __forceinline__ void solve_core_packed(const DW<float>& w, const Step
     for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k)
         if (k < np) w.c_pd[k * S + m] = pd[k];
     b1.v = lo3(bp.v); b1.om = lo3(bp.om); b2.v = hi3(bp.v); b2.om = hi3(bp.om);
-    store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
-    store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
+    store_body<T, STRIDE, COH>(bv, i1, no1, b1);
+    store_body<T, STRIDE, COH>(bv, i2, no2, b2);
 }
 template <class T, bool USE_BIAS, int STRIDE, bool COH = false> struct SolveDispatch {
     static __device__ __forceinline__ void run(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) { solve_core<T, USE_BIAS, STRIDE, COH>(w, p, m, bv, i1, i2); }
@@ -909,18 +943,9 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_color_pass_oct(DW<float> w,
     solve_core_oct<PASS == 1 /* PASS_BIAS */>(w, p, m, threadIdx.x & 7u);
 }
 
-template <class T, int STRIDE, bool COH = false>
-__device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
-    Vec4<T> h1 = w.c_h1[m];
-    uint32_t cm = scalar_to_bits(h1.w);
-    uint32_t np = cm & 7u;
-    if (np == 0) return;
-    T restitution = w.m_tv[m].w;
-    if (restitution == T(0)) return;
-    V3<T> normal = xyz<T>(w.m_n[m]);
-    BodyRef<T> b1, b2;
-    load_body<T, false, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
-    load_body<T, false, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+// the restitution impulses of one manifold with np > 0 points and restitution != 0 on (b1, b2)
+template <class T>
+__device__ __forceinline__ void restitution_chain(const DW<T>& w, const StepParams<T>& p, uint32_t m, uint32_t np, T restitution, V3<T> normal, BodyRef<T>& b1, BodyRef<T>& b2) {
     uint32_t S = w.m_stride;
     uint32_t iterations = np > 1 ? p.restitution_iterations : 1u;
     T threshold = p.restitution_threshold;
@@ -941,6 +966,20 @@ __device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParam
             w.c_pd[s] = pd;
             apply_impulse(b1, b2, impulse * normal, a1, a2);
         }
+}
+template <class T, int STRIDE, bool COH = false>
+__device__ __forceinline__ void restitution_core(const DW<T>& w, const StepParams<T>& p, uint32_t m, const BodyView<T>& bv, int i1, int i2) {
+    Vec4<T> h1 = w.c_h1[m];
+    uint32_t cm = scalar_to_bits(h1.w);
+    uint32_t np = cm & 7u;
+    if (np == 0) return;
+    T restitution = w.m_tv[m].w;
+    if (restitution == T(0)) return;
+    V3<T> normal = xyz<T>(w.m_n[m]);
+    BodyRef<T> b1, b2;
+    load_body<T, false, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, cm & AVN_CM_DOM1, b1);
+    load_body<T, false, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, cm & AVN_CM_DOM2, b2);
+    restitution_chain<T>(w, p, m, np, restitution, normal, b1, b2);
     store_body<T, STRIDE, COH>(bv, i1, cm & AVN_CM_NOBODY1, b1);
     store_body<T, STRIDE, COH>(bv, i2, cm & AVN_CM_NOBODY2, b2);
 }
@@ -1081,6 +1120,97 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
         __builtin_amdgcn_s_sleep(8);   // (thousands of waves poll: a short sleep floods the fabric with sc1 loads and slows the lanes that work)
     }
 }
+// Round 5, f32: the hand-over without tickets.  The w lane of a body's two velocity records (zero after k_prepare_solver_bodies, passed
+// through by every kernel of the substep loop) carries a TAG = (epoch + 1) << 20 | (overflow manifolds of this launch already solved on
+// the body).  A record is one aligned 16-byte access, so it validates itself: a lane polls the four velocity records of its two bodies
+// (agent scope) until each carries the tag its rank expects -- and then HAS the velocities; it stores them back with the next tag and is
+// done.  Against the ticket form a hop loses the writer's "stores performed -> ticket atomic" (two fabric round trips in sequence) and the
+// reader's gather after the poll (a third); and everything a manifold reads that no predecessor writes (constraint records, delta
+// position / rotation, inertia) is in registers BEFORE the wait instead of being fetched on the dependency chain.  Rank 0 on a body waits
+// for nothing (its predecessor is the previous launch); tags of other launches never match (epochs are unique inside a step, the w lanes
+// restart at zero with every step).  Same order per body as the tickets give: the reference's serial loop (solver/plugin.rs:461-467).
+#define OVF_TAG_SHIFT 20
+template <int PASS>
+__global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow_tag(DW<float> w, StepParams<float> p, OverflowFlow of, uint32_t epoch) {
+    typedef float T;
+    __shared__ uint32_t s_tile;
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) s_tile = atomicAdd(&of.tiles[epoch], 1u);
+    __syncthreads();
+    const uint32_t o0 = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = w.color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+    const uint32_t i = s_tile * CONTACT_THREADS + lane;
+    const bool valid = i < n23;
+    const uint32_t m = o0 + (valid ? i : 0u);
+    const uint32_t tag0 = (epoch + 1u) << OVF_TAG_SHIFT;
+    uint32_t r1 = 0xFFFFFFFFu, r2 = 0xFFFFFFFFu, cm = 0u;
+    int2 b = make_int2(0, 0);
+    FlowPre pre;
+    T restitution = T(0);
+    const BodyView<T> bv = global_bodies(w);
+    const Vec4<T> zero = make4<T>(0, 0, 0, 0), ident = make4<T>(0, 0, 0, 1);
+    pre.h0 = pre.h1 = pre.h2 = zero;
+    pre.dp1 = pre.dp2 = zero; pre.dq1 = pre.dq2 = ident; pre.sa1 = pre.sb1 = pre.sa2 = pre.sb2 = zero;
+#pragma unroll
+    for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) pre.pa[k] = pre.pb[k] = pre.pc[k] = pre.pd[k] = zero;
+    if (valid) {
+        b = w.m_bodies[m];
+        r1 = of.rank[2 * i]; r2 = of.rank[2 * i + 1];
+        pre.h1 = w.c_h1[m]; pre.h0 = w.m_n[m];
+        if (PASS == PASS_RESTITUTION) restitution = w.m_tv[m].w;
+        else {
+            pre.h2 = w.m_tv[m];
+            const uint32_t S = w.m_stride;
+#pragma unroll
+            for (uint32_t k = 0; k < AVN_MAX_MANIFOLD_POINTS; ++k) {
+                const uint32_t s = k * S + m;
+                pre.pa[k] = w.c_pa[s]; pre.pb[k] = w.c_pb[s]; pre.pc[k] = w.c_pc[s]; pre.pd[k] = w.c_pd[s];
+            }
+        }
+        cm = scalar_to_bits(pre.h1.w);
+        const size_t o1 = (size_t)b.x * 2, o2 = (size_t)b.y * 2;
+        if (PASS != PASS_RESTITUTION) { pre.dp1 = bv.dp[o1]; pre.dq1 = bv.dq[o1]; pre.dp2 = bv.dp[o2]; pre.dq2 = bv.dq[o2]; }
+        pre.sa1 = bv.sia[o1]; pre.sb1 = bv.sib[o1]; pre.sa2 = bv.sia[o2]; pre.sb2 = bv.sib[o2];
+    }
+    const bool has1 = r1 != 0xFFFFFFFFu, has2 = r2 != 0xFFFFFFFFu;
+    pre.no1 = !has1; pre.no2 = !has2; pre.tag1 = tag0 | (r1 + 1u); pre.tag2 = tag0 | (r2 + 1u);
+    // (the ranks come from the bodies' meta words, the constraint's flags from the SolverBody flags prepare wrote: one criterion, checked)
+    if (valid && (has1 == ((cm & AVN_CM_NOBODY1) != 0u) || has2 == ((cm & AVN_CM_NOBODY2) != 0u))) atomicOr(of.error, 8u);
+    bool done = !valid;
+    for (uint32_t it = 0;; ++it) {
+        asm volatile("" ::: "memory");
+        if (!done) {
+            bool ready = true;
+            pre.l1 = pre.a1 = pre.l2 = pre.a2 = zero;
+            if (has1) {
+                pre.l1 = ld_rec_agent(bv.lin, (size_t)b.x * 2); pre.a1 = ld_rec_agent(bv.ang, (size_t)b.x * 2);
+                if (r1 != 0u) ready = __float_as_uint(pre.l1.w) == (tag0 | r1) && __float_as_uint(pre.a1.w) == (tag0 | r1);
+            }
+            if (has2) {
+                pre.l2 = ld_rec_agent(bv.lin, (size_t)b.y * 2); pre.a2 = ld_rec_agent(bv.ang, (size_t)b.y * 2);
+                if (r2 != 0u) ready = ready && __float_as_uint(pre.l2.w) == (tag0 | r2) && __float_as_uint(pre.a2.w) == (tag0 | r2);
+            }
+            if (ready) {
+                if (PASS == PASS_RESTITUTION) {
+                    BodyRef<T> b1, b2;
+                    body_from_recs<T, false>(pre.l1, pre.a1, pre.dp1, pre.dq1, pre.sa1, pre.sb1, !has1, cm & AVN_CM_DOM1, b1);
+                    body_from_recs<T, false>(pre.l2, pre.a2, pre.dp2, pre.dq2, pre.sa2, pre.sb2, !has2, cm & AVN_CM_DOM2, b2);
+                    const uint32_t np = cm & 7u;
+                    if (np != 0u && restitution != T(0)) restitution_chain<T>(w, p, m, np, restitution, xyz<T>(pre.h0), b1, b2);
+                    // (always stored, also where nothing changed: the tag is the hand-over)
+                    b1.lin_w = b1.ang_w = __uint_as_float(pre.tag1); b2.lin_w = b2.ang_w = __uint_as_float(pre.tag2);
+                    store_body<T, 2, true>(bv, b.x, !has1, b1);
+                    store_body<T, 2, true>(bv, b.y, !has2, b2);
+                } else {
+                    solve_core_packed<PASS == PASS_BIAS, 2, true, FlowPre>(w, p, m, bv, b.x, b.y, pre);
+                }
+                done = true;
+            }
+        }
+        if (__all(done)) break;
+        if (it > (1u << 20)) { if (lane == 0) atomicOr(of.error, 2u); break; }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
 // (Tried and rejected, round 2: a whole pass as ONE dataflow launch over all colours -- every manifold waits for per-body tickets in
 //  "overflow list order, then colour order", its constraint records already loaded.  Bit-identical (the closed loop tracked the oracle),
 //  but 219 us per cfg2 pass against 15 x 8.4 = 126 us for the colour launches: a body's 15 manifolds are 15 dependent hops of
@@ -1105,9 +1235,22 @@ void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles,
     const uint32_t n = n_ticket > n_tiles ? n_ticket : n_tiles;
     hipLaunchKernelGGL(k_overflow_reset, dim3((n + 255) / 256), dim3(256), 0, s, ticket, n_ticket, tiles, n_tiles);
 }
+template <class T> struct OverflowFlowLaunch {
+    static bool run(const DW<T>&, const StepParams<T>&, int, const OverflowFlow&, uint32_t, uint32_t, hipStream_t) { return false; }
+};
+template <> struct OverflowFlowLaunch<float> {
+    static bool run(const DW<float>& w, const StepParams<float>& p, int pass, const OverflowFlow& of, uint32_t epoch, uint32_t grid_blocks, hipStream_t s) {
+        static const bool tickets = avn_env("AVN_OVF_TICKETS") != nullptr;   // (measure build: the round-2 ticket form, for A/B runs)
+        if (tickets) return false;
+        if (pass == PASS_BIAS) hipLaunchKernelGGL((k_overflow_flow_tag<PASS_BIAS>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
+        else if (pass == PASS_RELAX) hipLaunchKernelGGL((k_overflow_flow_tag<PASS_RELAX>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
+        else hipLaunchKernelGGL((k_overflow_flow_tag<PASS_RESTITUTION>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
+        return true;
+    }
+};
 template <class T> void launch_overflow_flow(const DW<T>& w, const StepParams<T>& p, int pass, const OverflowFlow& of, uint32_t epoch, uint32_t grid_blocks, hipStream_t s) {
     if (!grid_blocks) return;
-
+    if (OverflowFlowLaunch<T>::run(w, p, pass, of, epoch, grid_blocks, s)) return;   // f32: tags in the velocity records; f64 (two accesses per record): tickets
     if (pass == PASS_BIAS) hipLaunchKernelGGL((k_overflow_flow<T, PASS_BIAS>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
     else if (pass == PASS_RELAX) hipLaunchKernelGGL((k_overflow_flow<T, PASS_RELAX>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);
     else hipLaunchKernelGGL((k_overflow_flow<T, PASS_RESTITUTION>), dim3(grid_blocks), dim3(CONTACT_THREADS), 0, s, w, p, of, epoch);

@@ -178,7 +178,8 @@
         if (word & 1u) error += " k_pg_color: the colouring's dataflow wait timed out (colour lists of this step are not the reference's);";
         if (word & 2u) error += " k_overflow_flow: a ticket wait of the overflow colour's solve timed out (the step's velocities are not the reference's);";
         if (word & 4u) error += " k_pack_contacts: avn_contacts_upload named a contact id whose row is not live (skipped);";
-        if (word & ~7u) error += " unknown bits in the error word;";
+        if (word & 8u) error += " k_overflow_flow: a manifold's overflow rank and its constraint flags disagree about which body has a SolverBody;";
+        if (word & ~15u) error += " unknown bits in the error word;";
         error += " the error word has been cleared";
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));   // (an aborted batch never reached k_pg_build_handles, which cleans these)
