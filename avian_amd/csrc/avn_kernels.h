@@ -251,7 +251,7 @@ uint32_t pg_sort_stride(uint32_t n_bodies);
 void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t);
 template <class T> void launch_pg_rebuild_pair_set(const CT<T>&, const BP<T>&, uint32_t n_rows, hipStream_t);
 // overflow colour on the device: incidence CSR of the body-centric warm start + per-body ranks of the dataflow passes
-struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; };
+struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; uint32_t poll_sleep = 8; /* x 64 clocks between polling rounds */ };
 template <class T> void launch_ovf_entries(const DW<T>&, uint32_t o0, uint32_t n23, uint32_t* keys, uint32_t* vals, hipStream_t);
 template <class T> void launch_ovf_csr(const DW<T>&, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t);
 void launch_overflow_reset(uint32_t* ticket, uint32_t n_ticket, uint32_t* tiles, uint32_t n_tiles, hipStream_t);

@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow_tag(DW<float>
         }
         if (__all(done)) break;
         if (it > (1u << 20)) { if (lane == 0) atomicOr(of.error, 2u); break; }
-        __builtin_amdgcn_s_sleep(8);
+        for (uint32_t j = 0; j < of.poll_sleep; ++j) __builtin_amdgcn_s_sleep(1);
     }
 }
 // (Tried and rejected, round 2: a whole pass as ONE dataflow launch over all colours -- every manifold waits for per-body tickets in

@@ -42,6 +42,7 @@
             //  depend on the step's counts; an empty colour costs one launch of idle lanes)
             if (ovf_grid_blocks && ovf_epoch < PGC_OVF_TILES) {
                 OverflowFlow of{b_ovf_rank.as<uint32_t>(), b_ovf_ticket.as<uint32_t>(), pg.ctr + PGC_OVF_TILE, pg.ctr + PGC_ERROR};
+                if (const char* e = avn_env("AVN_OVF_POLL_SLEEP")) of.poll_sleep = (uint32_t)std::atoi(e);
                 launch_overflow_flow<T>(dw, params, pass, of, ovf_epoch, ovf_grid_blocks, stream);
                 ++ovf_epoch; ++launches;
             }

@@ -96,6 +96,12 @@ def main():
     w = closed_loop(lib, sc, bits=64, substeps=8)
     out["cfg5_500k_f64_closed_loop"] = dict(bodies=sc.n, **time_closed(w, 8, 3, 10))
     w.close()
+    sc, joints = scenes.stack_with_chains(50, 20, 50, 100, 100)
+    joints = dict(joints, collision_disabled=np.ones(len(joints["body1"]), np.uint8))
+    w = closed_loop(lib, sc, joints=joints)
+    out["cfg3_closed_loop_steps_60_79"] = dict(bodies=sc.n, joints=len(joints["body1"]), note="50 k cuboids + 100 chains of 100 links (9 900 distance joints) in the device closed loop: the stack collapses, the chains swing",
+                                               **time_closed(w, 4, 60, 20))
+    w.close()
     sc = scenes.box_stack(50, 40, 50)
     for name, slp in (("cfg2_closed_loop_steps_20_39", False), ("cfg2_closed_loop_steps_20_39_sleeping_enabled", True)):
         w = closed_loop(lib, sc, sleeping=slp)
