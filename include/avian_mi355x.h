@@ -942,7 +942,7 @@ AVN_API avn_status AVN_FN(shard_new_local_pairs)(avn_shard* s, const uint32_t** 
 AVN_API avn_status AVN_FN(shard_active)(avn_shard* s, const uint32_t** contact_id, size_t* n);
 AVN_API avn_status AVN_FN(shard_phase3)(avn_shard* s, const avn_contact_change* changes /* all ranks', any order */, size_t n);
 AVN_API avn_status AVN_FN(shard_removed_local)(avn_shard* s, const uint32_t** contact_id, size_t* n);
-AVN_API avn_status AVN_FN(shard_handles)(avn_shard* s, int global /* 0: this rank's restriction, 1: the single world's lists */, uint32_t color_offsets[AVN_GRAPH_COLOR_COUNT + 1], const uint32_t** contact_id, size_t* n);
+AVN_API avn_status AVN_FN(shard_handles)(avn_shard* s, int global /* 0: this rank's restriction, 1: the single world's lists */, uint32_t* color_offsets /* [AVN_GRAPH_COLOR_COUNT + 1] */, const uint32_t** contact_id, size_t* n);
 AVN_API avn_status AVN_FN(shard_stats_get)(avn_shard* s, avn_shard_stats* out);
 
 /* Union of the ColliderAabbs (after AVN_SYS_UPDATE_AABB) of all colliders on NON-static bodies of this world, as

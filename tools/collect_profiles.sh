@@ -17,7 +17,7 @@ cpf pmc_write_size_per_kernel.csv pmc_write_size_per_kernel.csv
 cpf closed_loop_breakdown.txt closed_loop_breakdown.txt
 cpf closed_loop_step110_timeline.txt closed_loop_step110_timeline.txt
 cpf closed_loop_switches_ab.txt closed_loop_switches_ab.txt
-cpf closed_loop_r3_vs_r4_same_box.txt closed_loop_r3_vs_r4_same_box.txt
+cpf closed_loop_r4_vs_r5_same_box.txt closed_loop_r4_vs_r5_same_box.txt
 cpf sleeping_step230_timeline.txt sleeping_step230_timeline.txt
 cpf narrow_phase_cutoffs.txt narrow_phase_cutoffs.txt
 cpf pmc_narrow_phase.json pmc_narrow_phase.json

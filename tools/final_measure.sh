@@ -59,13 +59,13 @@ timeout 120 python tools/time_pcie.py 20 > $O/pcie_calls.json 2> $O/pcie.err
 # the closed loop: one steady step's kernel timeline, the narrow phase's cut-off timings, A/B of the round's switches on this box
 bash tools/step_timeline.sh 110 > /dev/null 2>&1; cp $R/gpurun_out/timeline/timeline.txt $O/closed_loop_step110_timeline.txt 2>/dev/null
 AVN_LIB_PATH=$M AVN_NO_NP_OVERLAP=1 bash tools/np_phases.sh 60 > $O/narrow_phase_cutoffs.txt 2>&1
-for e in "" AVN_PG_REPLAY_WAVE=1 AVN_NO_NP_OVERLAP=1 AVN_NO_SPIN_SYNC=1 AVN_NO_HANDLE_SORT=1; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py; done > $O/closed_loop_switches_ab.txt
-# round 4 against round 3's library ON THIS BOX (boxes of the pool differ by 10-15 %): avian_amd/csrc/ab/libavian_r3.so is the round-3 tree built next to this one
-if [ -f $R/avian_amd/csrc/ab/libavian_r3.so ]; then
+for e in "" AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_PG_REPLAY_WAVE=1 AVN_NO_NP_OVERLAP=1 AVN_NO_SPIN_SYNC=1; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py; done > $O/closed_loop_switches_ab.txt
+# this tree against round 4's library ON THIS BOX (boxes of the pool differ by 10-15 %): avian_amd/csrc/ab/libavian_r4.so is the round-4 tree built next to this one
+if [ -f $R/avian_amd/csrc/ab/libavian_r4.so ]; then
   for k in 1 2; do
-    echo "== round 4 (this tree), run $k"; python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
-    echo "== round 3 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r3.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
-  done > $O/closed_loop_r3_vs_r4_same_box.txt 2>&1
+    echo "== round 5 (this tree), run $k"; python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
+    echo "== round 4 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r4.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
+  done > $O/closed_loop_r4_vs_r5_same_box.txt 2>&1
 fi
 timeout 200 bash tools/sleeping_timeline.sh 230 > $O/sleeping_step230_timeline.txt 2>&1
 timeout 300 python tools/pmc_closed_loop_tail.py $O/pmc_closed_loop_settled.json 120 20 > $O/pmc_closed_loop_settled.txt 2>&1
