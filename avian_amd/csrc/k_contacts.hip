@@ -124,7 +124,11 @@ template <class T, bool ROWS>
 __global__ __launch_bounds__(256) void k_prepare_contact_constraints(DW<T> w, StepParams<T> p, RowsView<T> rv) {
     uint32_t m = blockIdx.x * 256 + threadIdx.x;
     bool generated = false;
-    if (m < w.n_manifolds) {
+    // handle mode: the live manifold count is the device's (the colour offsets k_pg_build_handles / the upload left); DW::n_manifolds may be the
+    // host's UPPER BOUND of it -- the device closed loop launches this kernel before it has read the step's counts back
+    uint32_t n_live = w.n_manifolds;
+    if (ROWS) n_live = min(n_live, w.color_offsets[AVN_GRAPH_COLOR_COUNT]);
+    if (m < n_live) {
         uint32_t row = 0;
         if (ROWS) {
             row = rv.handles[m];

@@ -5,7 +5,7 @@
     static constexpr uint32_t DUMMY_SLOTS = 2 * AVN_JOINT_TYPE_COUNT;  // joint_damping::<T>: two fresh DUMMY SolverBodies per joint type
     avn_status bodies_upload(const avn_bodies* b) override {
         slp_world_asleep = slp_world_idle = false;
-        bodies_prepared_early = false; slot_clear_pending = false;   // (whatever an aborted step left behind: the new bodies are prepared by the next solver front)
+        bodies_prepared_early = false; constraints_prepared_early = false; slot_clear_pending = false;   // (whatever an aborted step left behind: the new bodies are prepared by the next solver front)
         if (!b || (b->count && (!b->position || !b->rotation || !b->linear_velocity || !b->angular_velocity || !b->inv_mass || !b->inv_inertia_local || !b->rb_type))) {
             error = "bodies_upload: null array"; return AVN_ERR_BAD_ARG;
         }

@@ -204,6 +204,7 @@
     // with stale bucket counts and tile tickets, i.e. wrong colour lists with no error raised.  `pg_batch_open` is set when a batch's first kernel
     // (k_pg_scan_classify / k_pg_ops_from_list) is about to be launched and cleared behind k_pg_build_handles; still set at the next begin = clean up here.
     bool pg_batch_open = false;
+    bool early_prepare_enabled = !avn_env("AVN_NO_EARLY_PREPARE");   // handle lists + constraint generation enqueued in front of the counters' read-back (A/B in `make measure` builds)
     bool handle_sort = true;          // the solver's body-sorted order inside colours 0..22 (AVN_NO_HANDLE_SORT=1 in `make measure` builds: A/B)
     DevBuf b_pg_sort_tab, b_pg_sort_cnt;
     avn_status pg_batch_begin() {
@@ -262,7 +263,33 @@
             HIPCHK(hipGetLastError());
             uint32_t* h = (uint32_t*)pin_ctr.p + 64;
             HIPCHK(hipMemcpyAsync(h, pg.ctr, 64 * 4, hipMemcpyDeviceToHost, stream));   // the counters block up to the colours' lengths, in one copy
-            HIPCHK(spin_sync(stream));
+            if (!ev_spin) HIPCHK(hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming));
+            HIPCHK(hipEventRecord(ev_spin, stream));   // (the host waits for THIS point, not for what it enqueues below)
+            // Round 5: what follows the replay on the device -- handle lists, the body-sorted order, constraint generation: 90 us of a settled cfg2
+            // step -- is enqueued BEFORE the host waits for the counters, bounded by M_ub = manifolds before the batch + ops (an op pushes at most
+            // one) with the exact counts read on the device, so the device works while the host synchronises, decides about the substep graph and
+            // launches it (the step-110 timeline had the device idle for 18 + 11 + 42 us there).  Not for list batches and not with sleeping on:
+            // further batches may follow before the solver.
+            bool early = !list_cids && !slp_on && early_prepare_enabled && use_handles;
+            uint32_t M_ub = 0;
+            if (early) {
+                M_ub = dw.n_manifolds + n_ops;
+                if ((st = ensure_manifold_capacity(M_ub)) != AVN_OK) return st;
+                hipError_t e2;
+                if (b_handles.ensure(std::max<size_t>(M_ub, 1) * 4, e2)) graph_valid = false;
+                if (e2 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+                const bool sorted_ub = handle_sort && M_ub >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M_ub;
+                if (sorted_ub && (st = pg_sort_ensure()) != AVN_OK) return st;
+                launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M_ub, ct.meta, sorted_ub ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
+                launches += sorted_ub ? 3 : 1;
+                DW<T> dwp = dw; dwp.n_manifolds = M_ub;
+                RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.rows};
+                launch_prepare_contact_constraints<T>(dwp, params, stream, constraint_count_clean, &rv); ++launches;
+                constraint_count_clean = false;
+                constraints_prepared_early = true;
+                HIPCHK(hipGetLastError());
+            }
+            HIPCHK(spin_event(ev_spin));
             auto t0 = std::chrono::steady_clock::now();
             if (h[PGC_ERROR]) return pg_error_report(h[PGC_ERROR]);
             if (avn_env("AVN_PG_REPLAY_STATS")) {
@@ -304,11 +331,13 @@
             if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
             // the solver's order inside colours 0..22: by key body (k_graph.hip, round 5) when the manifolds are dense enough in the bodies for the
             // 23 x n_bodies table walk to be cheaper than what the locality saves (a sparse scene's colour launches are tiny either way)
-            const bool sorted = handle_sort && M >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M;
-            if (sorted && (st = pg_sort_ensure()) != AVN_OK) return st;
-            launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, ct.meta, sorted ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
-            launches += sorted ? 3 : 1;
-            HIPCHK(hipGetLastError());
+            if (!early) {
+                const bool sorted = handle_sort && M >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M;
+                if (sorted && (st = pg_sort_ensure()) != AVN_OK) return st;
+                launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, ct.meta, sorted ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
+                launches += sorted ? 3 : 1;
+                HIPCHK(hipGetLastError());
+            } else if (M > M_ub) { error = "device closed loop: more manifolds after an op batch than manifolds before + ops"; return AVN_ERR_STATE; }
             pg_batch_open = false;
             incidence_dirty = true;
             host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -321,7 +350,7 @@
         if (despawn_needs_joints) { error = "avn_step: avn_despawn removed joints: upload the remaining joints (avn_joints_upload) first"; return AVN_ERR_STATE; }
         if (despawn_broken) { error = "avn_step: an avn_despawn failed half-way and left the contact bookkeeping inconsistent; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         // whatever ends this step early must not leave the next one believing that prepare_solver_bodies already ran or that the slot table is being cleared
-        struct StepGuard { World* w; bool ok = false; ~StepGuard() { if (!ok) { w->bodies_prepared_early = false; w->slot_clear_pending = false; w->bs = w->stream; } } } step_guard{this};
+        struct StepGuard { World* w; bool ok = false; ~StepGuard() { if (!ok) { w->bodies_prepared_early = false; w->constraints_prepared_early = false; w->slot_clear_pending = false; w->bs = w->stream; } } } step_guard{this};
         launches = 0;
         if (slp_on && slp_world_idle) {   // nothing is awake and the last step proved the state stationary: the step is the identity (world/sleeping.hpp)
             for (hipEvent_t e : ev) HIPCHK(hipEventRecord(e, stream));

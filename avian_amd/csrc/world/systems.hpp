@@ -14,9 +14,12 @@
         //  the generation (k_ovf_entries 4.8 -> 64 us) and the join costs another event: 2.841 / 2.852 ms per step against 2.823 / 2.846 without
         //  (same box).  Hoisting the point-record loads above the body gathers and 3 waves per SIMD for the generation: 0.1828 / 0.1816 ms
         //  against 0.1873 / 0.1772.  Neither kept.)
-        RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.rows};
-        launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean, use_handles ? &rv : nullptr); ++launches;
-        constraint_count_clean = false;
+        if (!constraints_prepared_early) {   // (device closed loop: normally enqueued by pg_apply_ops, in front of its read-back)
+            RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.rows};
+            launch_prepare_contact_constraints<T>(dw, params, stream, constraint_count_clean, use_handles ? &rv : nullptr); ++launches;
+            constraint_count_clean = false;
+        }
+        constraints_prepared_early = false;
         if (pipe_dev && ovf_csr_dirty && dw.n_manifolds) { overflow_csr_device(); ovf_csr_dirty = false; }
     }
     void store_contact_impulses() {
@@ -217,6 +220,7 @@
     }
     uint32_t graph_launches = 0;
     bool bodies_prepared_early = false;    // prepare_solver_bodies + pre_process_velocity_increments of this step are already on the stream
+    bool constraints_prepared_early = false;   // k_prepare_contact_constraints of this step is already on the stream (pg_apply_ops)
     bool slot_clear_pending = false;       // DW::inc_slot is being set to EMPTY on stream_bp (ev_slot_clear): build_incidence_slots skips its own memset
     hipEvent_t ev_slot_clear = nullptr;
     uint32_t island_backoff = 0;   // closed-loop steps for which the island blocks are not attempted again
