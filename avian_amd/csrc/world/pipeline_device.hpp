@@ -157,6 +157,21 @@
         return r != hipSuccess ? r : spin_event(ev_spin);
     }
     uint32_t pipe_step_no = 0;   // closed-loop steps taken by this world (measurement aids only)
+    // measurement aid (`make measure` build, AVN_PIPE_HOST_TRACE=<step>): where the HOST is, in microseconds since the step's call, at the marked points of ONE closed-loop step
+    int host_trace_step = avn_env("AVN_PIPE_HOST_TRACE") ? atoi(avn_env("AVN_PIPE_HOST_TRACE")) : -1;
+    bool host_trace_on = false;
+    std::chrono::steady_clock::time_point host_trace_t0;
+    std::vector<std::pair<const char*, double>> host_trace_marks;
+    void ht(const char* what) { if (host_trace_on) host_trace_marks.emplace_back(what, std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - host_trace_t0).count()); }
+    void ht_begin() { host_trace_on = host_trace_step >= 0 && (uint32_t)host_trace_step == pipe_step_no; host_trace_marks.clear(); host_trace_t0 = std::chrono::steady_clock::now(); }
+    void ht_end() {
+        if (!host_trace_on) return;
+        ht("step call returns");
+        std::fprintf(stderr, "[avn host trace] closed-loop step %d:", host_trace_step);
+        for (auto& m : host_trace_marks) std::fprintf(stderr, "\n  %9.1f us  %s", m.second, m.first);
+        std::fprintf(stderr, "\n");
+        host_trace_on = false;
+    }
 #ifdef AVN_MEASURE
     int np_debug_step = avn_env("AVN_NP_DEBUG_STEP") ? atoi(avn_env("AVN_NP_DEBUG_STEP")) : -1;
 #else
@@ -289,7 +304,9 @@
                 constraints_prepared_early = true;
                 HIPCHK(hipGetLastError());
             }
+            ht("op pipeline + early handles / constraints enqueued");
             HIPCHK(spin_event(ev_spin));
+            ht("read 2 (counters) arrived");
             auto t0 = std::chrono::steady_clock::now();
             if (h[PGC_ERROR]) return pg_error_report(h[PGC_ERROR]);
             if (avn_env("AVN_PG_REPLAY_STATS")) {
@@ -365,6 +382,7 @@
         double host_ms = 0;
         auto t0 = std::chrono::steady_clock::now();
         auto lap = [&]() { auto t1 = std::chrono::steady_clock::now(); host_ms += std::chrono::duration<double, std::milli>(t1 - t0).count(); };
+        ht_begin();
         HIPCHK(hipEventRecord(ev[0], stream));
         if ((st = update_aabb(2)) != AVN_OK) return st;
         // The narrow phase of the rows that exist at the START of the step needs the new AABBs and nothing else of the broad phase: it runs
@@ -391,15 +409,18 @@
         // run next to the broad phase instead of on the serial chain in front of the solver.  (Not with sleeping on: WakeIslands changes which bodies
         // own a SolverBody between the status loop and the solver.)
         if (!slp_on) { prepare_solver_bodies(); pre_process_velocity_increments(); bodies_prepared_early = true; }
+        ht("narrow phase (old rows) + solver-body kernels enqueued");
         st = collect_launch();
         if (st != AVN_OK) { bs = stream; bodies_prepared_early = false; return st; }
         lap();
+        ht("broad phase enqueued");
         // ---- new pairs (emission order) -> ids, rows, pair keys: all on the device; the host reads the pair COUNT ----
         uint32_t total = 0, used_ids = 0;
         auto fail = [&](avn_status e) { bs = stream; return e; };
         if (collect_pending) {
             collect_pending = false;
             HIPCHK(spin_event(ev_counters));
+            ht("read 0 (pair count) arrived");
             t0 = std::chrono::steady_clock::now();
             if (h_counters[4]) {   // more long-interval chunks than slots: grow to the requested count and run the count pass again
                 if ((st = grow_long_chunks(h_counters[3])) != AVN_OK) return fail(st);
@@ -464,7 +485,9 @@
             uint32_t* h = (uint32_t*)pin_ctr.p;
             HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
             lap();
+            ht("new pairs + scan_classify enqueued");
             HIPCHK(spin_sync(stream));
+            ht("read 1 (op count) arrived");
             t0 = std::chrono::steady_clock::now();
             n_ops = h[0]; n_rem = h[1];
             pg_error_pending = false;
@@ -493,13 +516,17 @@
         lap();
         pipe_stats.last_host_ms = host_ms;
         stamp(DG_NP1); dg_np = true;
+        ht("bookkeeping done, solver() called");
         if ((st = solver()) != AVN_OK) return st;
+        ht("solver() returned");
         if (slp_on && (st = sleeping_after_solver()) != AVN_OK) return st;   // split_island + the Sleeping set (synchronises: the host reads the timers)
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
         last_timers.kernel_launches = launches;
         step_guard.ok = true;
-        return pg_error_fetch();
+        st = pg_error_fetch();
+        ht_end();
+        return st;
     }
     // the overflow colour's CSR + ranks, and the slot table of the other colours, from the gathered manifold arrays (all on the device)
     avn_status rebuild_incidence_device() {

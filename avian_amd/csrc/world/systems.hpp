@@ -213,7 +213,12 @@
             }
             graph_valid = true;
         }
+        ht("substep graph: hipGraphLaunch called");
+        // (Round 5, measured and removed: the replay on a stream of its own behind an event, so that its packets would already sit in a queue when the
+        //  front finishes -- the device idles 43 us between k_build_incidence_slots and the graph's first kernel although hipGraphLaunch has returned
+        //  40 us earlier (AVN_PIPE_HOST_TRACE).  Settled step 2.42 -> 2.62 / 2.64 ms on one box: the start gap grows to 52 us and the join costs more.)
         HIPCHK(hipGraphLaunch(graph_exec, stream));
+        ht("hipGraphLaunch returned");
         launches += graph_launches;
         ovf_epoch = ovf_epoch_after_substeps;   // (the restitution pass after the loop continues the step's epochs)
         return AVN_OK;
@@ -254,6 +259,7 @@
             if ((st = rebuild_island_blocks()) != AVN_OK) return st;
             if (pipe_dev && !island_mode) island_backoff = 31;
         }
+        ht("constraints / overflow CSR enqueued");
         HIPCHK(hipEventRecord(ev[2], stream));
         if ((st = run_substeps()) != AVN_OK) return st;
         HIPCHK(hipEventRecord(ev[3], stream));

@@ -50,16 +50,12 @@ for a, b in ((4, 24), (24, 44), (100, 120)):
         print(f"{v[0] / n / 1e3:9.1f} us/step {v[1] / n:7.1f} calls/step {v[0] / v[1] / 1e3:8.1f} us avg  {k[:100]}")
 PY
 prof cfg3 python $R/tools/profile_config.py cfg3 20
-prof cfg5 python $R/tools/profile_config.py cfg5 8
-f5=$(find $O/prof_cfg5 -name "*kernel_trace.csv" | head -1)
-[ -n "$f5" ] && python tools/trace_percentiles.py $f5 > $O/cfg5_percentiles.txt 2>&1
 # cfg3 with and without the island streams (A/B on this box), the PCIe-inclusive step call by call
 for e in 0 1; do AVN_LIB_PATH=$M AVN_NO_ISLAND_STREAMS=$e python $R/tools/profile_config.py cfg3 30 2>/dev/null | tail -1 | sed "s/^/island_streams_off=$e /"; done > $O/cfg3_island_streams_ab.txt
 timeout 120 python tools/time_pcie.py 20 > $O/pcie_calls.json 2> $O/pcie.err
 # the closed loop: one steady step's kernel timeline, the narrow phase's cut-off timings, A/B of the round's switches on this box
 bash tools/step_timeline.sh 110 > /dev/null 2>&1; cp $R/gpurun_out/timeline/timeline.txt $O/closed_loop_step110_timeline.txt 2>/dev/null
-AVN_LIB_PATH=$M AVN_NO_NP_OVERLAP=1 bash tools/np_phases.sh 60 > $O/narrow_phase_cutoffs.txt 2>&1
-for e in "" AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_PG_REPLAY_WAVE=1 AVN_NO_NP_OVERLAP=1 AVN_NO_SPIN_SYNC=1; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py; done > $O/closed_loop_switches_ab.txt
+for e in "" AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_NO_EARLY_PREPARE=1 "AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_NO_EARLY_PREPARE=1"; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py; done > $O/closed_loop_switches_ab.txt
 # this tree against round 4's library ON THIS BOX (boxes of the pool differ by 10-15 %): avian_amd/csrc/ab/libavian_r4.so is the round-4 tree built next to this one
 if [ -f $R/avian_amd/csrc/ab/libavian_r4.so ]; then
   for k in 1 2; do
@@ -67,13 +63,10 @@ if [ -f $R/avian_amd/csrc/ab/libavian_r4.so ]; then
     echo "== round 4 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r4.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
   done > $O/closed_loop_r4_vs_r5_same_box.txt 2>&1
 fi
-timeout 200 bash tools/sleeping_timeline.sh 230 > $O/sleeping_step230_timeline.txt 2>&1
 timeout 300 python tools/pmc_closed_loop_tail.py $O/pmc_closed_loop_settled.json 120 20 > $O/pmc_closed_loop_settled.txt 2>&1
-echo "== AVN_WS_LANE_PER_BODY=1 (round 3's warm start in the closed loop)" >> $O/closed_loop_switches_ab.txt; AVN_LIB_PATH=$M AVN_WS_LANE_PER_BODY=1 python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py >> $O/closed_loop_switches_ab.txt
-python tools/pmc_any.py $O/pmc_narrow_phase.json 30 narrow "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TCP_TCC_WRITE_REQ TCP_TCC_WRITE_REQ_LATENCY" > $O/pmc_narrow_phase.txt 2>&1
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
-for t in cfg2 cfg2_closed_loop cfg3 cfg5 scene_many scene_large; do rm -rf $O/prof_$t; done
+for t in cfg2 cfg2_closed_loop cfg3 scene_many scene_large; do rm -rf $O/prof_$t; done
 timeout 200 python tools/measure_floor.py > $O/color_pass_floor.json 2> $O/floor.err; tail -c 300 $O/color_pass_floor.json; echo
 timeout 400 python tools/time_configs.py $O/other_configs.json > $O/time_configs.log 2>&1
 timeout 400 python tools/bench_reference_scenes.py 300 4 $O/reference_scenes.json > $O/reference_scenes.log 2>&1; tail -2 $O/reference_scenes.log
