@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""How deep are the dependency chains INSIDE a suffix of colours?  cfg2's closed loop is stepped, the ContactId -> bodies map is kept from the steps' new pairs,
+and for every c0 the manifolds of colours c0..22 are levelled (level = 1 + the highest level of an earlier manifold of the suffix on one of its bodies).
+usage: python tools/tail_depth.py [steps]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import avian_amd
+from avian_amd import _ffi as F, scenes
+
+
+def main():
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 110
+    lib = avian_amd.load_library()
+    sc = scenes.box_stack(50, 40, 50)
+    w = F.World(lib, F.default_config(32, substeps=4))
+    w.bodies_upload(**sc.body_kwargs()); w.colliders_upload(**sc.collider_kwargs())
+    w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+    w.pipeline_enable()
+    cap = 4_000_000
+    b1 = np.full(cap, -1, np.int64); b2 = np.full(cap, -1, np.int64)
+    for s in range(steps):
+        w.step(); w.synchronize()
+        p = w.pairs_get()
+        ids = w.pipeline_new_pair_ids()
+        if len(ids):
+            b1[ids] = p["body1"][:len(ids)]; b2[ids] = p["body2"][:len(ids)]
+    off, h = w.pipeline_handles()
+    static = np.asarray(sc.rb_type) == F.RB_STATIC
+    print("colour sizes:", [int(off[c + 1] - off[c]) for c in range(24)])
+    # the overflow colour (index 23) is solved serially in list order: its dataflow depth
+    last = np.zeros(sc.n, np.int32); hist = {}
+    for cid in h[off[23]:off[24]]:
+        x, y = int(b1[cid]), int(b2[cid])
+        lev = 1 + max(0 if static[x] else last[x], 0 if static[y] else last[y])
+        if not static[x]: last[x] = lev
+        if not static[y]: last[y] = lev
+        hist[lev] = hist.get(lev, 0) + 1
+    print("overflow colour:", int(off[24] - off[23]), "manifolds, levels", dict(sorted(hist.items())))
+    for c0 in (4, 5, 6, 7, 8, 9, 10, 12, 14):
+        last = np.zeros(sc.n, np.int32)
+        hist = {}
+        total = 0
+        for c in range(c0, 23):
+            ids = h[off[c]:off[c + 1]]
+            x, y = b1[ids], b2[ids]
+            assert (x >= 0).all() and (y >= 0).all()
+            lx = np.where(static[x], 0, last[x]); ly = np.where(static[y], 0, last[y])
+            lev = 1 + np.maximum(lx, ly)
+            last[x[~static[x]]] = lev[~static[x]]; last[y[~static[y]]] = lev[~static[y]]
+            for v, n in zip(*np.unique(lev, return_counts=True)): hist[int(v)] = hist.get(int(v), 0) + int(n)
+            total += len(ids)
+        print(f"c0 = {c0:2d}: {total:6d} manifolds in {23 - c0} colours, levels {dict(sorted(hist.items()))}")
+
+
+if __name__ == "__main__":
+    main()
