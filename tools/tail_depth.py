@@ -40,6 +40,23 @@ def main():
         if not static[y]: last[y] = lev
         hist[lev] = hist.get(lev, 0) + 1
     print("overflow colour:", int(off[24] - off[23]), "manifolds, levels", dict(sorted(hist.items())))
+    # how much of the overflow colour's dependency structure stays inside a wave of the dataflow pass (64 consecutive list entries)?
+    prev = {}; n_pred = n_same = 0
+    cost_now = np.zeros(int(off[24] - off[23])); cost_fwd = np.zeros_like(cost_now)   # critical path: every hop 1.0 | a hop inside a wave 0.5 (no memory round trip)
+    for i, cid in enumerate(h[off[23]:off[24]]):
+        a = b = 0.0; has = same = False
+        for body in (int(b1[cid]), int(b2[cid])):
+            if static[body]: continue
+            j = prev.get(body)
+            if j is not None:
+                has = True; intra = (j // 64) == (i // 64); same |= intra
+                a = max(a, cost_now[j]); b = max(b, cost_fwd[j] - (0.5 if intra else 0.0))
+            prev[body] = i
+        cost_now[i] = a + 1.0; cost_fwd[i] = b + 1.0
+        n_pred += has; n_same += same
+    if len(cost_now):
+        print(f"overflow colour: {n_pred} of {len(cost_now)} manifolds have a predecessor, {n_same} of them inside their own wave; critical path {cost_now.max():.1f} hops, "
+              f"{cost_fwd.max():.1f} if a hop inside a wave costs half")
     for c0 in (4, 5, 6, 7, 8, 9, 10, 12, 14):
         last = np.zeros(sc.n, np.int32)
         hist = {}
