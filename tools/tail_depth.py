@@ -13,7 +13,7 @@ from avian_amd import _ffi as F, scenes
 
 
 def main():
-    steps = int(sys.argv[1]) if len(sys.argv) > 1 else 110
+    steps = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 110
     lib = avian_amd.load_library()
     sc = scenes.box_stack(50, 40, 50)
     w = F.World(lib, F.default_config(32, substeps=4))
@@ -22,14 +22,27 @@ def main():
     w.pipeline_enable()
     cap = 4_000_000
     b1 = np.full(cap, -1, np.int64); b2 = np.full(cap, -1, np.int64)
+    static = np.asarray(sc.rb_type) == F.RB_STATIC
+    per_step = "per-step" in sys.argv   # the overflow colour's dataflow depth after EVERY step (to set against the per-launch durations of a kernel trace)
     for s in range(steps):
         w.step(); w.synchronize()
         p = w.pairs_get()
         ids = w.pipeline_new_pair_ids()
         if len(ids):
             b1[ids] = p["body1"][:len(ids)]; b2[ids] = p["body2"][:len(ids)]
+        if per_step:
+            off, h = w.pipeline_handles()
+            last = np.zeros(sc.n, np.int32); depth = 0
+            for cid in h[off[23]:off[24]]:
+                x, y = int(b1[cid]), int(b2[cid])
+                lev = 1 + max(0 if static[x] else last[x], 0 if static[y] else last[y])
+                if not static[x]: last[x] = lev
+                if not static[y]: last[y] = lev
+                depth = max(depth, lev)
+            print(f"after step {s}: overflow colour {int(off[24] - off[23])} manifolds, depth {depth}", flush=True)
+    if per_step:
+        return
     off, h = w.pipeline_handles()
-    static = np.asarray(sc.rb_type) == F.RB_STATIC
     print("colour sizes:", [int(off[c + 1] - off[c]) for c in range(24)])
     # the overflow colour (index 23) is solved serially in list order: its dataflow depth
     last = np.zeros(sc.n, np.int32); hist = {}
