@@ -36,30 +36,29 @@ avn_status IslandManager::body_add(uint32_t body) {   // BodyIslandNode::on_add,
     return AVN_OK;
 }
 avn_status IslandManager::collider_add(uint32_t collider, uint32_t body) {
-    collider_body_[collider] = body;
+    ColRec& r = col_get(collider);
+    r.body = body; r.known = true;
+    ++col_epoch_;
     if (body != NONE) {
         if (colliders_of_.size() <= body) { colliders_of_.resize((size_t)body + 1); }
         colliders_of_[body].push_back(collider);
     }
     return AVN_OK;
 }
-uint32_t IslandManager::node_of(uint32_t collider) {
-    auto it = collider_node_.find(collider);
-    if (it != collider_node_.end()) return it->second;
-    const uint32_t n = (uint32_t)contact_edges_.size();
+uint32_t IslandManager::node_of(ColRec& r) {
+    if (r.node != NONE) return r.node;
+    r.node = (uint32_t)contact_edges_.size();
     contact_edges_.emplace_back();
-    collider_node_.emplace(collider, n);
-    return n;
+    return r.node;
 }
 avn_status IslandManager::pair_add(uint32_t id, uint32_t c1, uint32_t c2) {   // ContactGraph::add_edge_and_key_with, contact_graph.rs:521-566
     if (contacts_.size() <= id) contacts_.resize((size_t)id + 1);
     if (contacts_[id].live) { error = "islands_pair_add: contact id in use"; return AVN_ERR_STATE; }
-    auto f1 = collider_body_.find(c1), f2 = collider_body_.find(c2);
-    if (f1 == collider_body_.end() || f2 == collider_body_.end()) { error = "islands_pair_add: unknown collider"; return AVN_ERR_BAD_ARG; }
+    if (!has_collider(c1) || !has_collider(c2)) { error = "islands_pair_add: unknown collider"; return AVN_ERR_BAD_ARG; }
     Contact c;
     c.live = true;
-    c.c1 = node_of(c1); c.c2 = node_of(c2);
-    c.rb1 = f1->second; c.rb2 = f2->second;
+    { ColRec& r1 = col_get(c1); c.c1 = node_of(r1); c.rb1 = r1.body; }
+    { ColRec& r2 = col_get(c2); c.c2 = node_of(r2); c.rb2 = r2.body; }
     c.b1 = body_has_node(c.rb1) ? c.rb1 : NONE; c.b2 = body_has_node(c.rb2) ? c.rb2 : NONE;
     contacts_[id] = c;
     contact_edges_[c.c1].out.push_back(id);   // (the reference links at the HEAD of both lists: the walks below run backwards)
@@ -199,10 +198,10 @@ void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
         isl.sleeping = true;
         for (uint32_t b : isl.bodies) {
             for (uint32_t col : colliders_of_[b]) {
-                auto it = collider_node_.find(col);
-                if (it == collider_node_.end()) continue;
+                const uint32_t nd = col_node(col);
+                if (nd == NONE) continue;
                 batch.clear();
-                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { if (!contacts_[e].sleeping) batch.push_back(e); });
+                edges_in_reference_order(contact_edges_[nd], nd, true, [&](uint32_t e) { if (!contacts_[e].sleeping) batch.push_back(e); });
                 for (uint32_t e : batch) {
                     Contact& c = contacts_[e];
                     if (!c.touching) continue;
@@ -225,10 +224,10 @@ void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
         isl.sleeping = false;
         for (uint32_t b : isl.bodies) {
             for (uint32_t col : colliders_of_[b]) {
-                auto it = collider_node_.find(col);
-                if (it == collider_node_.end()) continue;
+                const uint32_t nd = col_node(col);
+                if (nd == NONE) continue;
                 batch.clear();
-                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { if (contacts_[e].sleeping) batch.push_back(e); });
+                edges_in_reference_order(contact_edges_[nd], nd, true, [&](uint32_t e) { if (contacts_[e].sleeping) batch.push_back(e); });
                 for (uint32_t e : batch) {
                     Contact& c = contacts_[e];
                     if (!c.touching) continue;
@@ -245,7 +244,7 @@ void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
 
 // split_island, :995-1280: depth-first from the old list's bodies in list order; a body's contacts are collected (collider by collider, edge
 // list order, only linked ones with constraint handles not yet claimed) before any of them is claimed, then its joints the same way
-void IslandManager::split(uint32_t island) {
+void IslandManager::split(uint32_t island, const uint32_t* adj_off, const uint32_t* adj, uint32_t adj_bodies) {
     if (island >= islands_.size() || !islands_[island].used) return;
     if (islands_[island].sleeping || islands_[island].removed == 0) return;
     std::vector<uint32_t> seeds = std::move(islands_[island].bodies);
@@ -253,13 +252,16 @@ void IslandManager::split(uint32_t island) {
     ++splits_;
     ++mark_gen_;
     if (mark_body_.size() < node_.size()) mark_body_.resize(node_.size(), 0);
-    if (mark_contact_.size() < contacts_.size()) mark_contact_.resize(contacts_.size(), 0);
+    if (!adj_off && mark_contact_.size() < contacts_.size()) mark_contact_.resize(contacts_.size(), 0);
     if (mark_joint_.size() < joints_.size()) mark_joint_.resize(joints_.size(), 0);
-    std::vector<uint32_t> stack;
-    std::vector<std::pair<uint32_t, uint32_t>> found;
+    std::vector<uint32_t>& stack = split_stack_;
+    std::vector<std::pair<uint32_t, uint32_t>>& found = split_found_;
+    const uint32_t gen = mark_gen_;
+    uint32_t* const mark_body = mark_body_.data();
+    const uint32_t n_mark = (uint32_t)mark_body_.size();
     for (uint32_t seed : seeds) {
-        if (mark_body_[seed] == mark_gen_) continue;
-        mark_body_[seed] = mark_gen_;
+        if (mark_body[seed] == gen) continue;
+        mark_body[seed] = gen;
         Island isl;
         const uint32_t new_id = next_key();
         stack.assign(1, seed);
@@ -267,36 +269,111 @@ void IslandManager::split(uint32_t island) {
             const uint32_t body = stack.back(); stack.pop_back();
             isl_of_[body] = new_id;
             isl.bodies.push_back(body);
-            found.clear();
-            for (uint32_t col : colliders_of_[body]) {
-                auto it = collider_node_.find(col);
-                if (it == collider_node_.end()) continue;
-                edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) {
-                    const Contact& c = contacts_[e];
-                    if (c.linked && mark_contact_[e] == mark_gen_) return;
-                    if (!c.handles) return;
-                    found.push_back({e, c.rb1 == body ? c.rb2 : c.rb1});
-                });
+            if (adj_off) {
+                // the caller's CSR names, in the walk's order, the other bodies of the edges the walk would collect (handles held, other body owns a node).  The
+                // walk's per-contact marks only ever skip an edge whose other body is marked already (the body that claimed the edge), so they are not needed here.
+                if (body < adj_bodies) {
+                    const uint32_t e1 = adj_off[body + 1];
+                    for (uint32_t e = adj_off[body]; e < e1; ++e) {
+                        const uint32_t o = adj[e];
+                        if (o < n_mark && mark_body[o] != gen) { mark_body[o] = gen; stack.push_back(o); __builtin_prefetch(adj_off + o); }
+                    }
+                }
+            } else {
+                found.clear();
+                for (uint32_t col : colliders_of_[body]) {
+                    const uint32_t nd = col_node(col);
+                    if (nd == NONE) continue;
+                    edges_in_reference_order(contact_edges_[nd], nd, true, [&](uint32_t e) {
+                        const Contact& c = contacts_[e];
+                        if (c.linked && mark_contact_[e] == gen) return;
+                        if (!c.handles) return;
+                        found.push_back({e, c.rb1 == body ? c.rb2 : c.rb1});
+                    });
+                }
+                for (auto& pr : found) {
+                    if (body_has_node(pr.second) && mark_body[pr.second] != gen) { stack.push_back(pr.second); mark_body[pr.second] = gen; }
+                    mark_contact_[pr.first] = gen;
+                }
             }
-            for (auto& pr : found) {
-                if (body_has_node(pr.second) && mark_body_[pr.second] != mark_gen_) { stack.push_back(pr.second); mark_body_[pr.second] = mark_gen_; }
-                mark_contact_[pr.first] = mark_gen_;
-            }
-            found.clear();
-            if (body < joint_edges_.size())
+            if (body < joint_edges_.size() && (!joint_edges_[body].out.empty() || !joint_edges_[body].in.empty())) {
+                found.clear();
                 edges_in_reference_order(joint_edges_[body], body, false, [&](uint32_t j) {
-                    if (mark_joint_[j] == mark_gen_) return;
+                    if (mark_joint_[j] == gen) return;
                     found.push_back({j, joints_[j].b1 == body ? joints_[j].b2 : joints_[j].b1});
                 });
-            for (auto& pr : found) {
-                if (body_has_node(pr.second) && mark_body_[pr.second] != mark_gen_) { stack.push_back(pr.second); mark_body_[pr.second] = mark_gen_; }
-                mark_joint_[pr.first] = mark_gen_;
+                for (auto& pr : found) {
+                    if (body_has_node(pr.second) && mark_body[pr.second] != gen) { stack.push_back(pr.second); mark_body[pr.second] = gen; }
+                    mark_joint_[pr.first] = gen;
+                }
             }
         }
         island_insert(std::move(isl));
     }
 }
+void IslandManager::collider_ranks(const uint32_t* slot_entity, uint32_t n_slots, uint32_t* rank_by_slot) {
+    for (ColRec& r : col_dense_) r.rank = NONE;
+    for (auto& kv : col_sparse_) kv.second.rank = NONE;
+    uint32_t next = 0;
+    for (size_t b = 0; b < colliders_of_.size(); ++b)
+        for (uint32_t col : colliders_of_[b]) { const ColRec* r = col_find(col); if (r && r->known) col_get(col).rank = next++; }
+    for (uint32_t s = 0; s < n_slots; ++s) {
+        const ColRec* r = col_find(slot_entity[s]);
+        rank_by_slot[s] = (r && r->known && r->rank != NONE) ? r->rank : next++;
+    }
+}
 avn_status IslandManager::split_candidate_now() { if (candidate_ != NONE) split(candidate_); return AVN_OK; }
+avn_status IslandManager::split_candidate_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) {
+    if (!off || (!adj && n_bodies && off[n_bodies])) { error = "islands_split_candidate_adjacency: null array"; return AVN_ERR_BAD_ARG; }
+    if (candidate_ != NONE) split(candidate_, off, adj, n_bodies);
+    return AVN_OK;
+}
+// the closed loop's batches: pair_add / status_change over arrays, in array order; the records a call will touch are requested a few calls ahead (a settled
+// 100 k-body pile hands over 3*10^4 changes per step scattered over a 45 MB contact table: the loop was one cache miss per change)
+avn_status IslandManager::pairs_add(const uint32_t* ids, const avn_pair* pr, uint32_t n) {
+    uint32_t hi = 0;
+    for (uint32_t i = 0; i < n; ++i) hi = std::max(hi, ids[i]);
+    if (n && contacts_.size() <= hi) contacts_.resize((size_t)hi + 1);
+    avn_status st;
+    // three dependent lines per pair (the contact's record; each collider's list header; the end of each list), requested 12 / 8 / 4 calls ahead
+    for (uint32_t i = 0; i < n; ++i) {
+        if (i + 12 < n) __builtin_prefetch(&contacts_[ids[i + 12]], 1);
+        if (i + 8 < n) {
+            const uint32_t n1 = col_node(pr[i + 8].collider1), n2 = col_node(pr[i + 8].collider2);
+            if (n1 != NONE) __builtin_prefetch(&contact_edges_[n1], 1);
+            if (n2 != NONE) __builtin_prefetch(&contact_edges_[n2], 1);
+        }
+        if (i + 4 < n) {
+            const uint32_t n1 = col_node(pr[i + 4].collider1), n2 = col_node(pr[i + 4].collider2);
+            if (n1 != NONE) { const auto& v = contact_edges_[n1].out; if (!v.empty()) __builtin_prefetch(&v.back() + 1, 1); }
+            if (n2 != NONE) { const auto& v = contact_edges_[n2].in; if (!v.empty()) __builtin_prefetch(&v.back() + 1, 1); }
+        }
+        if ((st = pair_add(ids[i], pr[i].collider1, pr[i].collider2)) != AVN_OK) return st;
+    }
+    return AVN_OK;
+}
+avn_status IslandManager::status_changes(const uint32_t* cid, const uint32_t* chg, uint32_t n) {
+    avn_status st;
+    const size_t nc = contacts_.size();
+    for (uint32_t k = 0; k < n; ++k) {
+        if (k + 12 < n && cid[k + 12] < nc) __builtin_prefetch(&contacts_[cid[k + 12]], 1);
+        // a pair that leaves (DISJOINT_AABB) is searched in two edge lists: header 8 calls ahead (the contact's record has arrived by then), data 4 ahead
+        if (k + 8 < n && (chg[k + 8] & AVN_CP_DISJOINT_AABB) && cid[k + 8] < nc) {
+            const Contact& c = contacts_[cid[k + 8]];
+            if (c.live) { __builtin_prefetch(&contact_edges_[c.c1], 1); __builtin_prefetch(&contact_edges_[c.c2], 1); }
+        }
+        if (k + 4 < n && (chg[k + 4] & AVN_CP_DISJOINT_AABB) && cid[k + 4] < nc) {
+            const Contact& c = contacts_[cid[k + 4]];
+            if (c.live) {
+                const auto& o = contact_edges_[c.c1].out; const auto& i = contact_edges_[c.c2].in;
+                if (!o.empty()) __builtin_prefetch(&o.back(), 1);
+                if (!i.empty()) __builtin_prefetch(&i.back(), 1);
+            }
+        }
+        if ((st = status_change(cid[k], chg[k] & 0xFFFFu, (chg[k] >> 16) & 0xFFu)) != AVN_OK) return st;
+    }
+    return AVN_OK;
+}
 
 avn_status IslandManager::sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep) {
     clear_results();
@@ -342,9 +419,9 @@ avn_status IslandManager::sleep_body(uint32_t body) {   // SleepBody, :296-352
 // ---- despawn ----------------------------------------------------------------------------------------------------------------------------
 std::vector<uint32_t> IslandManager::collider_edges_in_order(uint32_t collider) const {
     std::vector<uint32_t> out;
-    auto it = collider_node_.find(collider);
-    if (it == collider_node_.end()) return out;
-    edges_in_reference_order(contact_edges_[it->second], it->second, true, [&](uint32_t e) { out.push_back(e); });
+    const uint32_t nd = col_node(collider);
+    if (nd == NONE) return out;
+    edges_in_reference_order(contact_edges_[nd], nd, true, [&](uint32_t e) { out.push_back(e); });
     return out;
 }
 // one edge of remove_collider (narrow_phase/mod.rs:411-455 + contact_graph.rs:669-690): a TOUCHING pair that is linked is unlinked, then the edge
@@ -360,17 +437,18 @@ avn_status IslandManager::remove_collider_edge(uint32_t id) {
     return AVN_OK;
 }
 avn_status IslandManager::collider_forget(uint32_t collider) {
-    auto it = collider_body_.find(collider);
-    if (it == collider_body_.end()) return AVN_OK;
-    const uint32_t b = it->second;
+    if (!has_collider(collider)) return AVN_OK;
+    ColRec& r = col_get(collider);
+    const uint32_t b = r.body;
     if (b != NONE && b < colliders_of_.size()) { auto& v = colliders_of_[b]; v.erase(std::remove(v.begin(), v.end(), collider), v.end()); }
-    collider_body_.erase(it);
-    collider_node_.erase(collider);   // (its node stays behind, empty; a re-added collider gets a fresh one)
+    ++col_epoch_;
+    r = ColRec();   // (its node stays behind, empty; a re-added collider gets a fresh one)
+    if (collider >= COL_DENSE) col_sparse_.erase(collider);
     return AVN_OK;
 }
 avn_status IslandManager::collider_remove(uint32_t collider) {
     clear_results();
-    if (!collider_body_.count(collider)) { error = "islands_collider_remove: unknown collider"; return AVN_ERR_BAD_ARG; }
+    if (!has_collider(collider)) { error = "islands_collider_remove: unknown collider"; return AVN_ERR_BAD_ARG; }
     for (uint32_t id : collider_edges_in_order(collider)) {
         const Contact& c = contacts_[id];
         if (c.touching) for (uint32_t k = 0; k < c.handles; ++k) popped_.push_back(id);
@@ -414,7 +492,9 @@ avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_
         if (b < joint_edges_.size()) jedges[nb] = std::move(joint_edges_[b]);
     }
     node_.swap(node); asleep_.swap(asleep); isl_of_.swap(isl_of); colliders_of_.swap(cols); joint_edges_.swap(jedges);
-    for (auto& kv : collider_body_) kv.second = m(kv.second);
+    ++col_epoch_;
+    for (ColRec& r : col_dense_) if (r.known) r.body = m(r.body);
+    for (auto& kv : col_sparse_) if (kv.second.known) kv.second.body = m(kv.second.body);
     for (Contact& c : contacts_) if (c.live) { c.b1 = m(c.b1); c.b2 = m(c.b2); c.rb1 = m(c.rb1); c.rb2 = m(c.rb2); }
     for (Joint& j : joints_) { j.b1 = m(j.b1); j.b2 = m(j.b2); }
     for (Island& I : islands_) if (I.used) for (uint32_t& b : I.bodies) b = m(b);
@@ -422,14 +502,12 @@ avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_
     return AVN_OK;
 }
 avn_status IslandManager::last_result(avn_islands_result* o) const {
-    if (!o || o->struct_size < 2 * sizeof(size_t) || o->struct_size > 4096) return AVN_ERR_BAD_ARG;
-    avn_islands_result r;
-    r.struct_size = o->struct_size;
+    if (!o) return AVN_ERR_BAD_ARG;
+    avn_islands_result& r = *o;
     r.popped = popped_.data(); r.n_popped = popped_.size(); r.pushed = pushed_.data(); r.n_pushed = pushed_.size();
     r.pairs_slept = pairs_slept_.data(); r.n_pairs_slept = pairs_slept_.size(); r.pairs_woken = pairs_woken_.data(); r.n_pairs_woken = pairs_woken_.size();
     r.bodies_slept = bodies_slept_.data(); r.n_bodies_slept = bodies_slept_.size(); r.bodies_woken = bodies_woken_.data(); r.n_bodies_woken = bodies_woken_.size();
     r.pairs_removed = pairs_removed_.data(); r.n_pairs_removed = pairs_removed_.size();
-    std::memcpy(o, &r, std::min(o->struct_size, sizeof r));   // (only what the caller's version of the struct holds)
     return AVN_OK;
 }
 avn_status IslandManager::stats(avn_islands_stats* o) const {
@@ -473,6 +551,7 @@ AVN_API avn_status avn_islands_pair_add(avn_island_manager* m, uint32_t id, uint
 AVN_API avn_status avn_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t manifold_count) { AVN_ISL(status_change(id, flags, manifold_count)); }
 AVN_API avn_status avn_islands_flush_wake(avn_island_manager* m) { AVN_ISL(flush_wake()); }
 AVN_API avn_status avn_islands_split_candidate(avn_island_manager* m) { AVN_ISL(split_candidate_now()); }
+AVN_API avn_status avn_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n) { AVN_ISL(split_candidate_adjacency(off, adj, n)); }
 AVN_API avn_status avn_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { AVN_ISL(sleeping_systems(t, f, n, tts)); }
 AVN_API avn_status avn_islands_wake_body(avn_island_manager* m, uint32_t body) { AVN_ISL(wake_body(body)); }
 AVN_API avn_status avn_islands_sleep_body(avn_island_manager* m, uint32_t body) { AVN_ISL(sleep_body(body)); }

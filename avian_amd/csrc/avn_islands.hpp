@@ -13,6 +13,7 @@
 // linked (add_contact merges them; a split keeps bodies joined by a linked contact together), so `island of a contact` is the island of
 // whichever of its bodies owns a node.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <string>
 #include <unordered_map>
@@ -37,6 +38,20 @@ public:
     avn_status renumber_joints(const uint32_t* new_index, uint32_t n_old);
     avn_status pair_add(uint32_t contact_id, uint32_t collider1, uint32_t collider2);
     avn_status status_change(uint32_t contact_id, uint32_t flags, uint32_t manifold_count);
+    // the closed loop's batches (world/sleeping.hpp): the same calls in the same order, with the next records' cache lines requested ahead
+    avn_status pairs_add(const uint32_t* contact_ids, const avn_pair* pairs, uint32_t n);
+    avn_status status_changes(const uint32_t* contact_ids, const uint32_t* packed /* flags | manifold count << 16 */, uint32_t n);
+    // split_island(candidate) with the contact neighbours handed in as a CSR (round 6): adj[off[b] .. off[b + 1]) = the OTHER body of every contact edge of
+    // body b that holds constraint handles and whose other body owns an island node, in the order split_island's walk meets them (the body's colliders in
+    // RigidBodyColliders order; per collider outgoing edges newest first, then incoming newest first).  Same result as split_candidate_now(), which derives
+    // that order from the manager's own edge lists; here the caller holds it (the closed loop builds it on the device from the rows' insertion stamps).
+    avn_status split_candidate_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies);
+    bool split_pending() const { return candidate_ != NONE && candidate_ < islands_.size() && islands_[candidate_].used && !islands_[candidate_].sleeping && islands_[candidate_].removed != 0; }
+    bool has_candidate() const { return candidate_ != NONE; }
+    // what the device-built adjacency is keyed by: the rank of every collider in the body-major concatenation of RigidBodyColliders (bodies ascending, a body's
+    // colliders in the order they were added); colliders of bodies without a node come after.  collider_epoch() changes whenever the ranks may have.
+    uint64_t collider_epoch() const { return col_epoch_; }
+    void collider_ranks(const uint32_t* slot_entity, uint32_t n_slots, uint32_t* rank_by_slot);
     avn_status flush_wake();
     avn_status split_candidate_now();
     avn_status sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep);
@@ -58,7 +73,7 @@ public:
     // what the world reads directly
     bool body_has_node(uint32_t b) const { return b < node_.size() && node_[b]; }
     bool body_sleeps(uint32_t b) const { return b < asleep_.size() && asleep_[b]; }
-    bool has_collider(uint32_t collider) const { return collider_body_.count(collider) != 0; }
+    bool has_collider(uint32_t collider) const { const ColRec* r = col_find(collider); return r && r->known; }
     uint32_t island_of(uint32_t b) const { return isl_of_[b]; }
     uint32_t island_key_bound() const { return (uint32_t)islands_.size(); }   // slab keys are below this
     uint32_t last_slept() const { return last_slept_; }
@@ -90,7 +105,20 @@ private:
     std::vector<uint8_t> node_, asleep_;
     std::vector<uint32_t> isl_of_;
     std::vector<std::vector<uint32_t>> colliders_of_;
-    std::unordered_map<uint32_t, uint32_t> collider_node_, collider_body_;
+    // colliders by Entity::index(): a dense table for the indices an ECS hands out (small integers), a map behind it for anything above
+    struct ColRec { uint32_t body = NONE, node = NONE, rank = NONE; bool known = false; };
+    static constexpr uint32_t COL_DENSE = 1u << 24;
+    std::vector<ColRec> col_dense_;
+    std::unordered_map<uint32_t, ColRec> col_sparse_;
+    const ColRec* col_find(uint32_t c) const {
+        if (c < COL_DENSE) return c < col_dense_.size() ? &col_dense_[c] : nullptr;
+        auto it = col_sparse_.find(c); return it == col_sparse_.end() ? nullptr : &it->second;
+    }
+    ColRec& col_get(uint32_t c) {
+        if (c < COL_DENSE) { if (col_dense_.size() <= c) col_dense_.resize(std::max<size_t>((size_t)c + 1, col_dense_.size() * 2)); return col_dense_[c]; }
+        return col_sparse_[c];
+    }
+    uint32_t col_node(uint32_t c) const { const ColRec* r = col_find(c); return r && r->known ? r->node : NONE; }   // NONE: no edge list yet
     std::vector<EdgeLists> contact_edges_;   // per collider node
     std::vector<EdgeLists> joint_edges_;     // per body
     std::vector<Contact> contacts_;
@@ -107,6 +135,9 @@ private:
     // split scratch
     std::vector<uint32_t> mark_contact_, mark_joint_, mark_body_;
     uint32_t mark_gen_ = 0;
+    uint64_t col_epoch_ = 1;
+    std::vector<uint32_t> split_stack_;
+    std::vector<std::pair<uint32_t, uint32_t>> split_found_;
 
     void clear_results();
     uint32_t next_key() const { return vacant_.empty() ? (uint32_t)islands_.size() : vacant_.back(); }
@@ -119,8 +150,8 @@ private:
     template <class F> void edges_in_reference_order(const EdgeLists& l, uint32_t self_out_node, bool contact_graph, F f) const;
     void sleep_islands(const std::vector<uint32_t>& ids);
     void wake_islands(const std::vector<uint32_t>& ids);
-    void split(uint32_t island);
-    uint32_t node_of(uint32_t collider);
+    void split(uint32_t island, const uint32_t* adj_off = nullptr, const uint32_t* adj = nullptr, uint32_t adj_bodies = 0);
+    uint32_t node_of(ColRec& r);
 };
 
 }  // namespace avn

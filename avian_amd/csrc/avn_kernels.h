@@ -180,7 +180,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 #define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
-       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
+       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_N_SLEEP_OPS = 11 /* status changes of this step that name a Sleeping body (sleeping on) */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
        PGC_COLLECT = 14 /* k_pg_collect_edges: records written */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
        PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512,
@@ -231,7 +231,11 @@ void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_ind
 template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, uint64_t* pair_set, uint32_t pair_set_cap, hipStream_t);
 // exclusive scan of PG::has (= op index per changed row) + the classification of the changed rows, one launch; ctr[PGC_N_OPS] <- changes.
 // PGC_BUCKET must be zero when it starts (k_pg_build_handles leaves it so).
-void launch_pg_scan_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t);
+void launch_pg_scan_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t, const uint32_t* bmeta_if_sleeping = nullptr);
+// split_island's neighbour lists as a CSR over bodies, from the rows (k_graph.hip, round 6): off[n_bodies + 2] (off[n_bodies + 1] = entries found), adj[n]
+struct IslAdj { uint32_t* count; uint32_t cap; uint32_t *e_key2, *e_other, *e_body, *k_a, *v_a, *k_b, *v_b; /* [cap] each */ };
+void launch_isl_adjacency(const PG&, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, uint32_t n_rows, uint32_t n_bodies, uint32_t n, uint32_t seq_bits, uint32_t rank_bits,
+                          uint32_t pad_key2, const IslAdj&, uint32_t* hist, uint32_t* block_sums, uint32_t* off, uint32_t* adj, hipStream_t);
 // an op batch from a LIST instead of from the rows' status changes (SleepIslands / WakeIslands: pops and pushes in the island manager's order):
 // fills the same op arrays as k_pg_classify for ops (cids[k], kinds[k] = 1 push | 2 pop); the rest of the pipeline is the status loop's
 template <class T> void launch_pg_ops_from_list(const PG&, const CT<T>&, const uint32_t* cids, const uint32_t* kinds, uint32_t n, uint32_t n_bodies, hipStream_t);

@@ -116,7 +116,7 @@ template <class T> void launch_pg_add_pairs(const PG& pg, const CT<T>& ct, const
 
 // ---- the status-change loop, decision part (system_param.rs:155-373) ------------------------------------------------------------
 // one changed row -> op k (k = the number of changed rows with a lower ContactId: the reference's processing order)
-__device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32_t k, uint32_t n_bodies, uint32_t* hist) {
+__device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32_t k, uint32_t n_bodies, uint32_t* hist, const uint32_t* __restrict__ bmeta) {
     const uint32_t w = pg.chg[c];
     const uint32_t flags = w & 0xFFFFu, n_manifolds = (w >> 16) & 0xFFu;
     const int dcount = (int)((w >> 24) & 0xFFu) - 128;
@@ -133,6 +133,10 @@ __device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32
     const bool s1 = flags & AVN_CP_STATIC1, s2 = flags & AVN_CP_STATIC2;
     if (kind == PG_KIND_PUSH && s1 && s2) kind = PG_KIND_NONE;   // (debug_assert in the reference: never both)
     const int2 b = pg.bodies[c];
+    // sleeping on: a status change on a body that sleeps may link into / unlink from a sleeping island, i.e. queue a WakeIslands (system_param.rs:391-398);
+    // a step without such a change cannot wake anything, and the host enqueues the solver BEFORE its island manager digests the changes
+    if (bmeta && ((b.x >= 0 && (uint32_t)b.x < n_bodies && (meta_flags(bmeta[b.x]) & AVN_BODY_SLEEPING)) || (b.y >= 0 && (uint32_t)b.y < n_bodies && (meta_flags(bmeta[b.y]) & AVN_BODY_SLEEPING))))
+        atomicAdd(&pg.ctr[PGC_N_SLEEP_OPS], 1u);
     const uint32_t opcol = kind == PG_KIND_POP ? col : 0xFFu;
     pg.op_cid[k] = c;
     pg.op_chg[k] = w;
@@ -150,7 +154,7 @@ __device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32
 // classification of the changed rows in ONE launch (round 4: was k_scan_sums -> k_scan_top -> k_scan_apply -> k_pg_classify, the last of
 // them a 1.2 M-row gather for ~30 k changes): the chained scan of avn_scan.h with k_pg_classify's body as its apply stage.  Thread t of a
 // tile owns rows base + 8 t .. + 7.  ctr[PGC_N_OPS] <- the number of changes.
-__global__ __launch_bounds__(256) void k_pg_scan_classify(PG pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* __restrict__ st) {
+__global__ __launch_bounds__(256) void k_pg_scan_classify(PG pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* __restrict__ st, const uint32_t* __restrict__ bmeta) {
     __shared__ uint32_t hist[AVN_GRAPH_COLOR_COUNT];
     const uint32_t nb = gridDim.x, t = threadIdx.x;
     if (t < AVN_GRAPH_COLOR_COUNT) hist[t] = 0;
@@ -165,14 +169,14 @@ __global__ __launch_bounds__(256) void k_pg_scan_classify(PG pg, uint32_t n_rows
     excl += sc_lookback(st, tile, nb, tile_sum);
     if (s) {
 #pragma unroll
-        for (uint32_t k = 0; k < per; ++k) if (h[k]) { pg_classify_row(pg, c0 + k, excl, n_bodies, hist); ++excl; }
+        for (uint32_t k = 0; k < per; ++k) if (h[k]) { pg_classify_row(pg, c0 + k, excl, n_bodies, hist, bmeta); ++excl; }
     }
     if (tile == nb - 1u && t == 255u) pg.ctr[PGC_N_OPS] = excl;
     __syncthreads();
     if (t < AVN_GRAPH_COLOR_COUNT && hist[t]) { atomicAdd(&pg.ctr[PGC_BUCKET + t], hist[t]); atomicAdd(&pg.ctr[PGC_N_POP], hist[t]); }
 }
-void launch_pg_scan_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t s) {
-    if (n_rows) hipLaunchKernelGGL(k_pg_scan_classify, dim3((n_rows + SC_TILE - 1) / SC_TILE), dim3(256), 0, s, pg, n_rows, n_bodies, scan_state);
+void launch_pg_scan_classify(const PG& pg, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t s, const uint32_t* bmeta_if_sleeping) {
+    if (n_rows) hipLaunchKernelGGL(k_pg_scan_classify, dim3((n_rows + SC_TILE - 1) / SC_TILE), dim3(256), 0, s, pg, n_rows, n_bodies, scan_state, bmeta_if_sleeping);
 }
 
 // An op batch from a list (SleepIslands / WakeIslands of the island manager): the arrays k_pg_classify fills, for ops given as
@@ -884,7 +888,7 @@ __global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __res
     // the op batch is over: its scoped counters start the next batch at zero without a memset launch (buckets of the replay, the dataflow
     // colouring's tile tickets, the narrow phase's removal count -- the host has read them)
     if (blockIdx.x == 0 && threadIdx.x < 32u) pg.ctr[PGC_BUCKET + threadIdx.x] = 0u;
-    if (blockIdx.x == 0 && threadIdx.x == 32u) { pg.ctr[PGC_TILE] = 0u; pg.ctr[PGC_N_REM] = 0u; }
+    if (blockIdx.x == 0 && threadIdx.x == 32u) { pg.ctr[PGC_TILE] = 0u; pg.ctr[PGC_N_REM] = 0u; pg.ctr[PGC_N_SLEEP_OPS] = 0u; }
     const uint32_t m = blockIdx.x * 256 + threadIdx.x;
     if (m >= total || m >= off[AVN_GRAPH_COLOR_COUNT]) return;
     uint32_t lo = 0, hi = AVN_GRAPH_COLOR_COUNT;   // colour c: off[c] <= m < off[c + 1]
@@ -1008,6 +1012,83 @@ __global__ __launch_bounds__(256) void k_ovf_post(const uint32_t* __restrict__ k
 template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t s) {
     hipLaunchKernelGGL(k_ovf_offsets, dim3((w.n_bodies + 256) / 256), dim3(256), 0, s, keys, 2 * n23, w.n_bodies, inc_off);
     if (n23) hipLaunchKernelGGL(k_ovf_post, dim3((2 * n23 + 255) / 256), dim3(256), 0, s, keys, vals, 2 * n23, w.n_bodies, o0, inc_off, inc_ent, rank);
+}
+
+// ---- the contact graph's adjacency for split_island (world/sleeping.hpp, round 6) -------------------------------------------------------
+// split_island (islands/mod.rs:995-1280) walks, for every body it visits, the body's colliders in RigidBodyColliders order and per collider the
+// ContactGraph's edge list -- outgoing edges newest first, then incoming edges newest first (stable_graph.rs:640-675) -- and follows the edges that hold
+// constraint handles.  The host manager did that over its own edge lists: ~25 edges per body of a pile, one cache miss each into a 45 MB contact table,
+// 50-70 ms for cfg2's one island every other settled step.  The rows know everything the walk reads: a row holds handles iff it has a colour
+// (PG::color), its insertion stamp (PG::seq) is its place in both edge lists (newest first = descending stamp), its collider slots name the lists.
+// So the device writes the walk's neighbour lists as a CSR over bodies: entries (side of a row) keyed by (rank of the collider in the body-major
+// concatenation of RigidBodyColliders, direction, descending stamp) -- two stable radix sorts -- and the host's walk reads 4 bytes per edge it follows.
+// Entries whose other body owns no island node (static ground) are dropped: the walk only tests them and moves on.
+__device__ __forceinline__ bool pg_island_node(uint32_t bmeta) { return meta_rb_type(bmeta) != AVN_RB_STATIC && !(meta_flags(bmeta) & AVN_BODY_DISABLED); }
+__global__ __launch_bounds__(256) void k_adj_entries(PG pg, const uint4* __restrict__ ct_meta, const uint32_t* __restrict__ bmeta, const uint32_t* __restrict__ slot_rank,
+                                                     uint32_t n_rows, uint32_t n_bodies, uint32_t seq_mask, IslAdj a) {
+    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+    bool take = false;
+    int2 b = make_int2(-1, -1);
+    uint4 m = make_uint4(0, 0, 0, 0);
+    if (r < n_rows && pg.color[r] != PG_NONE) {
+        m = ct_meta[r];
+        b = pg.bodies[r];
+        take = (m.z & AVN_CP_ROW_USED) && b.x >= 0 && b.y >= 0 && (uint32_t)b.x < n_bodies && (uint32_t)b.y < n_bodies && pg_island_node(bmeta[b.x]) && pg_island_node(bmeta[b.y]);
+    }
+    const unsigned long long mask = __ballot(take);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(a.count, 2u * (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1);
+    if (!take) return;
+    const uint32_t e = base + 2u * (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (e + 1u >= a.cap) return;   // (the host sized the arrays for 2 entries per handle: cannot happen; a.count tells)
+    const uint32_t k1 = (~(uint32_t)pg.seq[r]) & seq_mask;   // descending stamp
+    a.k_a[e] = k1; a.v_a[e] = e; a.e_key2[e] = 2u * slot_rank[m.x]; a.e_other[e] = (uint32_t)b.y; a.e_body[e] = (uint32_t)b.x;                     // outgoing edge of collider1
+    a.k_a[e + 1u] = k1; a.v_a[e + 1u] = e + 1u; a.e_key2[e + 1u] = 2u * slot_rank[m.y] + 1u; a.e_other[e + 1u] = (uint32_t)b.x; a.e_body[e + 1u] = (uint32_t)b.y;   // incoming edge of collider2
+}
+__global__ __launch_bounds__(256) void k_adj_pad(IslAdj a, uint32_t n, uint32_t seq_mask, uint32_t pad_key2) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || i < *a.count) return;
+    a.k_a[i] = seq_mask; a.v_a[i] = i; a.e_key2[i] = pad_key2; a.e_other[i] = PG_NONE; a.e_body[i] = PG_NONE;
+}
+__global__ __launch_bounds__(256) void k_adj_key2(const uint32_t* __restrict__ v_sorted, const uint32_t* __restrict__ e_key2, uint32_t* __restrict__ k_out, uint32_t n) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) k_out[i] = e_key2[v_sorted[i]];
+}
+// adj[i] = the other body of the i-th entry in walk order; off[b] = the first entry of a body >= b (entries are body-major: the ranks are)
+__global__ __launch_bounds__(256) void k_adj_finish(IslAdj a, const uint32_t* __restrict__ v_sorted, uint32_t n, uint32_t n_bodies, uint32_t* __restrict__ off, uint32_t* __restrict__ adj) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t count = min(*a.count, n);
+    if (i < count) adj[i] = a.e_other[v_sorted[i]];
+    if (i <= n_bodies) {
+        uint32_t lo = 0, hi = count;
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.e_body[v_sorted[mid]] < i) lo = mid + 1u; else hi = mid; }
+        off[i] = lo;
+    }
+    if (i == 0) off[n_bodies + 1u] = *a.count;   // (the host checks it against the capacity)
+}
+// n = 2 x the number of constraint handles (the host knows it: DW::n_manifolds), an upper bound of the entries; `scratch` arrays of IslAdj hold n words each
+void launch_isl_adjacency(const PG& pg, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, uint32_t n_rows, uint32_t n_bodies, uint32_t n, uint32_t seq_bits, uint32_t rank_bits,
+                          uint32_t pad_key2, const IslAdj& a, uint32_t* hist, uint32_t* block_sums, uint32_t* off, uint32_t* adj, hipStream_t s) {
+    (void)hipMemsetAsync(a.count, 0, 4, s);
+    const uint32_t seq_mask = seq_bits >= 32u ? 0xFFFFFFFFu : ((1u << seq_bits) - 1u);
+    if (n_rows && n) hipLaunchKernelGGL(k_adj_entries, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, ct_meta, bmeta, slot_rank, n_rows, n_bodies, seq_mask, a);
+    uint32_t* v = a.v_a;
+    if (n) {
+        hipLaunchKernelGGL(k_adj_pad, dim3((n + 255) / 256), dim3(256), 0, s, a, n, seq_mask, pad_key2);
+        uint32_t *k1, *v1;
+        launch_radix_sort_bits(a.k_a, a.v_a, a.k_b, a.v_b, n, seq_bits, hist, block_sums, &k1, &v1, s);
+        uint32_t* k2 = k1 == a.k_a ? a.k_b : a.k_a;          // the free key buffer takes the second key
+        uint32_t* v2 = v1 == a.v_a ? a.v_b : a.v_a;
+        hipLaunchKernelGGL(k_adj_key2, dim3((n + 255) / 256), dim3(256), 0, s, (const uint32_t*)v1, (const uint32_t*)a.e_key2, k2, n);
+        uint32_t *k3, *v3;
+        launch_radix_sort_bits(k2, v1, k1, v2, n, rank_bits, hist, block_sums, &k3, &v3, s);
+        v = v3;
+    }
+    const uint32_t threads = (n > n_bodies + 1u ? n : n_bodies + 1u);
+    hipLaunchKernelGGL(k_adj_finish, dim3((threads + 255) / 256), dim3(256), 0, s, a, (const uint32_t*)v, n, n_bodies, off, adj);
 }
 
 #define INST(T)                                                                                                         \

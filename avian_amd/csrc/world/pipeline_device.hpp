@@ -198,7 +198,7 @@
         error += " the error word has been cleared";
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));   // (an aborted batch never reached k_pg_build_handles, which cleans these)
-        HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream));
+        HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_SLEEP_OPS, 0, 4, stream));
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_SORT_DUP, 0, AVN_GRAPH_COLOR_COUNT * 4, stream));
         if (b_pg_sort_tab.p) HIPCHK(hipMemsetAsync(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap, stream));
         pg_batch_open = false;
@@ -225,7 +225,7 @@
     avn_status pg_batch_begin() {
         if (pg_batch_open) {
             HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));
-            HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream));
+            HIPCHK(hipMemsetAsync(pg.ctr + PGC_TILE, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_REM, 0, 4, stream)); HIPCHK(hipMemsetAsync(pg.ctr + PGC_N_SLEEP_OPS, 0, 4, stream));
             HIPCHK(hipMemsetAsync(pg.ctr + PGC_SORT_DUP, 0, AVN_GRAPH_COLOR_COUNT * 4, stream));
             if (b_pg_sort_tab.p) HIPCHK(hipMemsetAsync(b_pg_sort_tab.p, 0xFF, b_pg_sort_tab.cap, stream));
         }
@@ -283,9 +283,9 @@
             // Round 5: what follows the replay on the device -- handle lists, the body-sorted order, constraint generation: 90 us of a settled cfg2
             // step -- is enqueued BEFORE the host waits for the counters, bounded by M_ub = manifolds before the batch + ops (an op pushes at most
             // one) with the exact counts read on the device, so the device works while the host synchronises, decides about the substep graph and
-            // launches it (the step-110 timeline had the device idle for 18 + 11 + 42 us there).  Not for list batches and not with sleeping on:
-            // further batches may follow before the solver.
-            bool early = !list_cids && !slp_on && early_prepare_enabled && use_handles;
+            // launches it (the step-110 timeline had the device idle for 18 + 11 + 42 us there).  Not for list batches, and with sleeping on only in a step
+            // that cannot wake anything (slp_fast_step): further batches may follow before the solver otherwise.
+            bool early = !list_cids && (!slp_on || slp_fast_step) && early_prepare_enabled && use_handles;
             uint32_t M_ub = 0;
             if (early) {
                 M_ub = dw.n_manifolds + n_ops;
@@ -406,9 +406,10 @@
             bs = stream_bp;
         }
         // prepare_solver_bodies and pre_process_velocity_increments only read the rigid-body components: enqueued here, on the world's stream, they
-        // run next to the broad phase instead of on the serial chain in front of the solver.  (Not with sleeping on: WakeIslands changes which bodies
-        // own a SolverBody between the status loop and the solver.)
-        if (!slp_on) { prepare_solver_bodies(); pre_process_velocity_increments(); bodies_prepared_early = true; }
+        // run next to the broad phase instead of on the serial chain in front of the solver.
+        // (Sleeping on: WakeIslands changes which bodies own a SolverBody between the status loop and the solver -- sleeping_apply_result then drops the flag and the
+        //  solver's front runs both kernels again; they only read the components and rewrite the whole SolverBody.)
+        prepare_solver_bodies(); pre_process_velocity_increments(); bodies_prepared_early = true;
         ht("narrow phase (old rows) + solver-body kernels enqueued");
         st = collect_launch();
         if (st != AVN_OK) { bs = stream; bodies_prepared_early = false; return st; }
@@ -471,7 +472,7 @@
         HIPCHK(hipEventRecord(ev[1], stream));
         // ---- narrow phase over every live row; changes numbered in ascending ContactId ----
         const uint32_t n_rows = pgm_next_id;
-        uint32_t n_ops = 0, n_rem = 0;
+        uint32_t n_ops = 0, n_rem = 0, n_sleep_ops = 0;
         if (n_rows) {
             if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false); ++launches; }
             else if (total) {   // the rows this step added: the lowest free ids first (k_pg_add_pairs), then the fresh ones
@@ -479,23 +480,25 @@
                 ++launches;
             }
             if ((st = pg_batch_begin()) != AVN_OK) return fail(st);
-            launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream);   // ops numbered in ascending ContactId AND classified
+            launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream, slp_on ? dw.bmeta : nullptr);   // ops numbered in ascending ContactId AND classified
             ++launches;
             HIPCHK(hipGetLastError());
             uint32_t* h = (uint32_t*)pin_ctr.p;
-            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, 3 * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR
+            HIPCHK(hipMemcpyAsync(h, pg.ctr + PGC_N_OPS, (PGC_N_SLEEP_OPS - PGC_N_OPS + 1) * 4, hipMemcpyDeviceToHost, stream));   // N_OPS, N_REM, ERROR ... N_SLEEP_OPS
             lap();
             ht("new pairs + scan_classify enqueued");
             HIPCHK(spin_sync(stream));
             ht("read 1 (op count) arrived");
             t0 = std::chrono::steady_clock::now();
             n_ops = h[0]; n_rem = h[1];
+            n_sleep_ops = h[PGC_N_SLEEP_OPS - PGC_N_OPS];
             pg_error_pending = false;
             if (h[2]) return pg_error_report(h[2]);   // raised by the previous step's solver passes (normally already reported by avn_synchronize)
         }
         pipe_stats.last_status_changes = n_ops;
         pg_changes_cached = false;   // (avn_contact_changes_get: this step's changes are in the op arrays now)
         if (!n_ops) pg_batch_open = false;   // (no change: k_pg_scan_classify touched none of the batch's counters)
+        slp_fast_step = slp_on && slp_fast_enabled && n_sleep_ops == 0;   // no status change names a Sleeping body: nothing can wake before the solver (world/sleeping.hpp)
         if (n_ops || total) slp_step_changed = true;
         ++pg_dump_step;
         if (n_ops) {   // ---- the status-change loop: decisions, colours, handle lists ----
@@ -511,7 +514,12 @@
             if ((st = pg_apply_ops(n_ops, n_rem, n_rows, nullptr, nullptr, host_ms)) != AVN_OK) return st;
             t0 = std::chrono::steady_clock::now();
         }
-        if (slp_on && (st = sleeping_after_status_loop(total, n_ops, host_ms)) != AVN_OK) return st;   // islands: new pairs, the loop's link / unlink, WakeIslands
+        // (the island-BLOCK builder takes its grouping from the manager: where the blocks are a candidate -- small scenes, where the digest is cheap -- the manager
+        //  must have seen this step's links before the solver's front)
+        const bool slp_defer = slp_on && slp_fast_step && !(island_candidate(dw.n_manifolds) && dw.n_joints == 0);
+        if (slp_on && !slp_fast_step && (st = sleeping_after_status_loop(total, n_ops, host_ms)) != AVN_OK) return st;   // islands: new pairs, the loop's link / unlink, WakeIslands
+        if (slp_on && slp_fast_step && !slp_defer && (st = sleeping_digest_deferred(total, n_ops, host_ms)) != AVN_OK) return st;
+        if (slp_on && isl.has_candidate() && (st = sleeping_adjacency_launch()) != AVN_OK) return st;                   // split_island's neighbour lists, next to the solver
         pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
         lap();
         pipe_stats.last_host_ms = host_ms;
@@ -519,6 +527,11 @@
         ht("bookkeeping done, solver() called");
         if ((st = solver()) != AVN_OK) return st;
         ht("solver() returned");
+        if (slp_defer) {   // the manager's digest of this step, under the solver's kernels
+            double slp_ms = 0;
+            if ((st = sleeping_digest_deferred(total, n_ops, slp_ms)) != AVN_OK) return st;
+            pipe_stats.last_host_ms += slp_ms;
+        }
         if (slp_on && (st = sleeping_after_solver()) != AVN_OK) return st;   // split_island + the Sleeping set (synchronises: the host reads the timers)
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;

@@ -29,7 +29,84 @@
     std::vector<uint8_t> h_rb_type, h_body_flags;      // host copies of the uploaded RigidBody type / body flags (island nodes, Sleeping)
     uint32_t slp_n_awake = 0, slp_last_slept = 0, slp_last_woken = 0, slp_last_popped = 0, slp_last_pushed = 0;
     double slp_host_ms = 0;
+    // measurement aid (`make measure` build, AVN_SLP_TRACE=1): host milliseconds of the island bookkeeping's phases, one line per step on stderr
+    bool slp_trace = avn_env("AVN_SLP_TRACE") != nullptr;
+    double slp_tr[10] = {0};
+    static double slp_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     std::vector<uint32_t> slp_list;                    // scratch: cids | kinds of an op list
+    // Round 6.  (a) A step whose status changes name no Sleeping body cannot queue a WakeIslands (k_pg_scan_classify counts them): the solver is enqueued FIRST and the
+    // island manager digests the step's pairs and changes while the device solves (slp_fast_step).  (b) split_island's neighbour lists come from the device
+    // (launch_isl_adjacency, k_graph.hip) when a split candidate exists at the step's start: the host's walk then reads a 4-byte CSR instead of its edge lists.
+    bool slp_fast_step = false;
+    bool slp_adj_enabled = !avn_env("AVN_SLP_HOST_SPLIT"), slp_fast_enabled = !avn_env("AVN_SLP_NO_FAST");   // (A/B switches of `make measure` builds)
+    DevBuf b_adj_cnt, b_adj_key2, b_adj_other, b_adj_body, b_adj_ka, b_adj_va, b_adj_kb, b_adj_vb, b_adj_off, b_adj_out, b_adj_rank, b_adj_hist, b_adj_sums;
+    Pinned pin_adj;
+    hipEvent_t ev_adj = nullptr, ev_adj_go = nullptr;
+    uint64_t adj_rank_epoch = 0;
+    uint32_t adj_rank_slots = 0, adj_n = 0, adj_bodies = 0;
+    bool adj_pending = false;
+    std::vector<uint32_t> adj_rank_host, adj_host;
+    avn_status sleeping_adjacency_launch() {
+        adj_pending = false;
+        const uint32_t N = dw.n_bodies, n_rows = pgm_next_id, n_slots = (uint32_t)slot_entity.size(), n = 2u * dw.n_manifolds;
+        if (!slp_adj_enabled || !N || pipe_stats.pairs_added >= (1ull << 32) || n_slots >= (1u << 30) || dw.n_manifolds >= (1u << 30)) return AVN_OK;   // (the manager's own edge lists serve)
+        hipError_t err = hipSuccess;
+        if (adj_rank_epoch != isl.collider_epoch() || adj_rank_slots != n_slots) {
+            adj_rank_host.resize(std::max<size_t>(n_slots, 1));
+            isl.collider_ranks(slot_entity.data(), n_slots, adj_rank_host.data());
+            HIPCHK(hipStreamSynchronize(stream_bp));
+            b_adj_rank.ensure(adj_rank_host.size() * 4, err);
+            if (err != hipSuccess) { error = "hipMalloc failed (collider ranks)"; return AVN_ERR_OOM; }
+            HIPCHK(hipMemcpy(b_adj_rank.p, adj_rank_host.data(), (size_t)n_slots * 4, hipMemcpyHostToDevice));
+            adj_rank_epoch = isl.collider_epoch(); adj_rank_slots = n_slots;
+        }
+        const size_t cap = std::max<size_t>(n, 64);
+        if (b_adj_ka.cap < cap * 4) {
+            HIPCHK(hipStreamSynchronize(stream_bp));
+            const size_t c = cap + cap / 2;
+            for (DevBuf* b : {&b_adj_key2, &b_adj_other, &b_adj_body, &b_adj_ka, &b_adj_va, &b_adj_kb, &b_adj_vb, &b_adj_out}) { b->ensure(c * 4, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; } }
+            b_adj_hist.ensure(((size_t)256 * radix_blocks((uint32_t)c) + 256) * 4, err);
+            if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+            b_adj_sums.ensure((std::max<size_t>(scan_block_sums_needed(256 * radix_blocks((uint32_t)c)), scan_block_sums_needed((uint32_t)c)) + 16) * 4, err);
+            if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+            HIPCHK(hipMemset(b_adj_sums.p, 0, b_adj_sums.cap));   // (the one-launch scan's state: zero once, self-cleaning afterwards)
+        }
+        b_adj_cnt.ensure(64, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+        b_adj_off.ensure(((size_t)N + 2) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+        if (pin_adj.ensure(((size_t)N + 2 + n) * 4 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        if (!ev_adj) { HIPCHK(hipEventCreateWithFlags(&ev_adj, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_adj_go, hipEventDisableTiming | EV_FLAGS)); }
+        // behind every op batch of this step (the rows' colours are the constraint handles the walk follows), next to the solver
+        HIPCHK(hipEventRecord(ev_adj_go, stream));
+        HIPCHK(hipStreamWaitEvent(stream_bp, ev_adj_go, 0));
+        IslAdj a{b_adj_cnt.as<uint32_t>(), (uint32_t)(b_adj_ka.cap / 4), b_adj_key2.as<uint32_t>(), b_adj_other.as<uint32_t>(), b_adj_body.as<uint32_t>(),
+                 b_adj_ka.as<uint32_t>(), b_adj_va.as<uint32_t>(), b_adj_kb.as<uint32_t>(), b_adj_vb.as<uint32_t>()};
+        const uint32_t pad = 2u * n_slots;
+        launch_isl_adjacency(pg, ct.meta, dw.bmeta, b_adj_rank.as<uint32_t>(), n_rows, N, n, std::max(1u, bits_for((uint32_t)pipe_stats.pairs_added)), bits_for(pad), pad, a,
+                             b_adj_hist.as<uint32_t>(), b_adj_sums.as<uint32_t>(), b_adj_off.as<uint32_t>(), b_adj_out.as<uint32_t>(), stream_bp);
+        HIPCHK(hipGetLastError());
+        uint32_t* h = (uint32_t*)pin_adj.p;
+        HIPCHK(hipMemcpyAsync(h, b_adj_off.p, ((size_t)N + 2) * 4, hipMemcpyDeviceToHost, stream_bp));
+        if (n) HIPCHK(hipMemcpyAsync(h + N + 2, b_adj_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream_bp));
+        HIPCHK(hipEventRecord(ev_adj, stream_bp));
+        launches += 6;
+        adj_pending = true; adj_n = n; adj_bodies = N;
+        return AVN_OK;
+    }
+    // split_island(candidate), SolverSystems::Finalize
+    avn_status sleeping_split() {
+        if (!adj_pending) { const avn_status st = isl.split_candidate_now(); return st == AVN_OK ? st : slp_fail(st); }
+        adj_pending = false;
+        if (!isl.split_pending()) return AVN_OK;   // (the candidate merged away or has nothing to split: the CSR stays unread)
+        HIPCHK(spin_event(ev_adj));
+        const uint32_t* h = (const uint32_t*)pin_adj.p;
+        if (h[adj_bodies + 1] > adj_n) { error = "island adjacency: more entries than 2 x constraint handles"; return AVN_ERR_STATE; }
+        // (out of the DMA target into ordinary memory in one streaming pass: the walk reads it in graph order, a miss per body otherwise)
+        const size_t words = (size_t)adj_bodies + 2 + h[adj_bodies + 1];
+        adj_host.resize(words);
+        std::memcpy(adj_host.data(), h, words * 4);
+        const avn_status st = isl.split_candidate_adjacency(adj_host.data(), adj_host.data() + adj_bodies + 2, adj_bodies);
+        return st == AVN_OK ? st : slp_fail(st);
+    }
 
     float slp_lin_default = 0.0f, slp_ang_default = 0.0f;   // the world-level SleepThreshold: what a body spawned after avn_sleeping_enable gets in the per-body arrays
     uint32_t slp_bodies = 0;                                 // bodies the per-body arrays (timer, flags, thresholds, SleepingDisabled) cover
@@ -149,28 +226,54 @@
         HIPCHK(hipGetLastError());
         for (uint32_t b : bsl) { h_body_flags[b] |= AVN_BODY_SLEEPING; h_body_has_sb[b] = 0; }
         for (uint32_t b : bw) { h_body_flags[b] &= (uint8_t)~AVN_BODY_SLEEPING; h_body_has_sb[b] = h_rb_type[b] != AVN_RB_STATIC && !(h_body_flags[b] & AVN_BODY_DISABLED); }
-        if (!bsl.empty() || !bw.empty()) { joint_schedule_dirty = true; groups_dirty = true; incidence_dirty = true; }
+        if (!bsl.empty() || !bw.empty()) { joint_schedule_dirty = true; groups_dirty = true; incidence_dirty = true; bodies_prepared_early = false; }   // (which bodies own a SolverBody changed: prepare_solver_bodies again)
         if (n_ops) { if ((st = pg_apply_ops((uint32_t)n_ops, 0u, 0u, d, d + n_ops, host_ms)) != AVN_OK) return st; }
         else HIPCHK(hipStreamSynchronize(stream));   // (the staging arena is reused by the next call)
         return AVN_OK;
     }
     // after the status loop of the step (its ops are already in the colour lists): the manager sees the new pairs and the loop's link / unlink
     // events in the reference's order, then the deferred WakeIslands (system_param.rs:391-398) runs before the solver
-    avn_status sleeping_after_status_loop(uint32_t n_new_pairs, uint32_t n_ops, double& host_ms) {
+    // the manager's half of the status loop: the step's new pairs (emission order) and status changes (ascending ContactId), then the deferred WakeIslands' decision
+    avn_status sleeping_manager_digest(uint32_t n_new_pairs, uint32_t n_ops, double& host_ms) {
         auto t0 = std::chrono::steady_clock::now();
         avn_status st;
+        const double m0 = slp_now();
         if (n_new_pairs) {
             const avn_pair* pr = (const avn_pair*)pin_slp_pairs.p;
             const uint32_t* ids = (const uint32_t*)((const char*)pin_slp_pairs.p + (size_t)n_new_pairs * sizeof(avn_pair));
-            for (uint32_t i = 0; i < n_new_pairs; ++i) if ((st = isl.pair_add(ids[i], pr[i].collider1, pr[i].collider2)) != AVN_OK) return slp_fail(st);
+            if ((st = isl.pairs_add(ids, pr, n_new_pairs)) != AVN_OK) return slp_fail(st);
         }
+        const double m1 = slp_now();
         if (n_ops) {
-            const uint32_t* cid = (const uint32_t*)pin_slp_ops.p; const uint32_t* chg = cid + n_ops;
-            for (uint32_t k = 0; k < n_ops; ++k) if ((st = isl.status_change(cid[k], chg[k] & 0xFFFFu, (chg[k] >> 16) & 0xFFu)) != AVN_OK) return slp_fail(st);
+            const uint32_t* cid = (const uint32_t*)pin_slp_ops.p;
+            if ((st = isl.status_changes(cid, cid + n_ops, n_ops)) != AVN_OK) return slp_fail(st);
         }
+        const double m2 = slp_now();
         if ((st = isl.flush_wake()) != AVN_OK) return slp_fail(st);
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return sleeping_apply_result(false, host_ms);
+        slp_tr[0] = m1 - m0; slp_tr[1] = m2 - m1; slp_tr[2] = slp_now() - m2;
+        return AVN_OK;
+    }
+    // after the status loop of the step (its ops are already in the colour lists): the manager sees the new pairs and the loop's link / unlink
+    // events in the reference's order, then the deferred WakeIslands (system_param.rs:391-398) runs before the solver
+    avn_status sleeping_after_status_loop(uint32_t n_new_pairs, uint32_t n_ops, double& host_ms) {
+        avn_status st = sleeping_manager_digest(n_new_pairs, n_ops, host_ms);
+        if (st != AVN_OK) return st;
+        const double m3 = slp_now();
+        st = sleeping_apply_result(false, host_ms);
+        slp_tr[3] = slp_now() - m3;
+        return st;
+    }
+    // the same digest AFTER the solver was enqueued (slp_fast_step: no change of the step names a Sleeping body, so nothing can wake): host work under the device's
+    avn_status sleeping_digest_deferred(uint32_t n_new_pairs, uint32_t n_ops, double& host_ms) {
+        avn_status st = sleeping_manager_digest(n_new_pairs, n_ops, host_ms);
+        if (st != AVN_OK) return st;
+        slp_tr[3] = 0;
+        if (!isl.pushed().empty() || !isl.bodies_woken().empty() || !isl.pairs_woken().empty()) {
+            error = "sleeping: the island manager woke an island in a step whose status changes named no Sleeping body (device flags and manager disagree)";
+            return AVN_ERR_STATE;
+        }
+        return AVN_OK;
     }
     // split_island (SolverSystems::Finalize) and the Sleeping set (update_sleeping_states, wake_islands_with_sleeping_disabled, sleep_islands,
     // then SleepIslands / WakeIslands)
@@ -179,15 +282,18 @@
         double host_ms = 0;
         auto t0 = std::chrono::steady_clock::now();
         avn_status st;
+        double m0 = slp_now();
         launch_sleep_timers_flags<T>(dw, slp_k, b_slp_timer.as<float>(), b_slp_flags.as<uint8_t>(), stream); ++launches;   // behind the write-back: SolverBody velocities of this step
         HIPCHK(hipGetLastError());
         if (pin_slp_timers.ensure((size_t)n * 5 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
         float* h_timer = (float*)pin_slp_timers.p; uint8_t* h_flags = (uint8_t*)(h_timer + n);
         HIPCHK(hipMemcpyAsync(h_timer, b_slp_timer.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
         HIPCHK(hipMemcpyAsync(h_flags, b_slp_flags.p, n, hipMemcpyDeviceToHost, stream));
-        if ((st = isl.split_candidate_now()) != AVN_OK) return slp_fail(st);   // (host work while the solver's kernels run)
+        if ((st = sleeping_split()) != AVN_OK) return st;   // (host work while the solver's kernels run)
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        double m1 = slp_now();
         HIPCHK(hipStreamSynchronize(stream));
+        double m2 = slp_now();
         t0 = std::chrono::steady_clock::now();
         uint32_t awake = 0;
         for (uint32_t b = 0; b < n; ++b) awake += (h_flags[b] >> 2) & 1u;
@@ -195,10 +301,16 @@
         if ((st = isl.sleeping_systems(h_timer, h_flags, n, slp_time_to_sleep)) != AVN_OK) return slp_fail(st);
         slp_last_slept = isl.last_slept(); slp_last_woken = isl.last_woken();
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        double m3 = slp_now();
         st = sleeping_apply_result(true, host_ms);
         slp_host_ms = host_ms;
         slp_world_asleep = st == AVN_OK && std::none_of(h_body_has_sb.begin(), h_body_has_sb.end(), [](uint8_t x) { return x != 0; });
         slp_world_idle = slp_world_asleep && slp_step_started_asleep && !slp_step_changed && isl.last_slept() == 0 && isl.last_woken() == 0;
+        if (slp_trace) {
+            const double m4 = slp_now();
+            std::fprintf(stderr, "[avn slp] step %u (%s): pair_add %.3f status %.3f flush %.3f apply1 %.3f | split %.3f wait %.3f systems %.3f apply2 %.3f ms; awake %u slept %u woken %u popped %u pushed %u\n",
+                         pipe_step_no, slp_fast_step ? "fast" : "slow", slp_tr[0], slp_tr[1], slp_tr[2], slp_tr[3], m1 - m0, m2 - m1, m3 - m2, m4 - m3, slp_n_awake, slp_last_slept, slp_last_woken, slp_last_popped, slp_last_pushed);
+        }
         return st;
     }
     avn_status sleeping_stats_get(avn_sleeping_stats* o) override {

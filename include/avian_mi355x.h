@@ -801,6 +801,14 @@ AVN_API avn_status AVN_FN(islands_status_change)(avn_island_manager* m, uint32_t
 AVN_API avn_status AVN_FN(islands_flush_wake)(avn_island_manager* m);
 /* split_island(split_candidate) -- SolverSystems::Finalize */
 AVN_API avn_status AVN_FN(islands_split_candidate)(avn_island_manager* m);
+/* The same split with the contact neighbours handed in by the caller (round 6) -- for a host that holds the contact graph's adjacency elsewhere; the closed
+ * loop builds it on the device.  CSR over bodies: adj[off[b] .. off[b + 1]) = the OTHER body of every contact edge of body b that (a) holds constraint
+ * handles and (b) whose other body owns an island node, in the order split_island's depth-first walk meets them (islands/mod.rs:1112-1148): the body's
+ * colliders in RigidBodyColliders order; per collider the outgoing edges newest first, then the incoming edges newest first
+ * (data_structures/stable_graph.rs:640-675).  off has n_bodies + 1 entries.  Joints are walked from the manager's own JointGraph.  The result equals
+ * avn_islands_split_candidate's; the oracle's implementation checks the CSR rows of the candidate's bodies against its own edge lists first and returns
+ * AVN_ERR_STATE when they disagree. */
+AVN_API avn_status AVN_FN(islands_split_candidate_adjacency)(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n_bodies);
 /* The Sleeping set after the solver.  `sleep_timer` [n_bodies]: the SleepTimers AFTER update_sleeping_states' increment / reset (the caller
  * owns that arithmetic: it reads SolverBody velocities); `flags` [n_bodies]: bit 0 = the body took part in update_sleeping_states (has a
  * SolverBody, not Sleeping, not SleepingDisabled), bit 1 = SleepingDisabled (wake_islands_with_sleeping_disabled).  Runs the island side of
@@ -813,9 +821,9 @@ AVN_API avn_status AVN_FN(islands_sleep_body)(avn_island_manager* m, uint32_t bo
 /* what the last flush_wake / sleeping_systems / wake_body / sleep_body did, in the reference's order: contact ids whose manifolds were
  * popped (SleepIslands) and pushed (WakeIslands), contact ids moved to the sleeping / the active pair set, bodies put to sleep / woken.
  * Pointers stay valid until the next call on the manager. */
-typedef struct avn_islands_result {
-    size_t struct_size;      /* in: sizeof(avn_islands_result) as the CALLER's header declares it; the library writes no byte beyond it (the struct grew in
-                                round 4 -- pairs_removed -- and may grow again: a host built against an older header keeps working) */
+typedef struct avn_islands_result {   /* FIXED layout (round 4's: seven pointer / count pairs).  Round 5 had put a `struct_size` member in FRONT of them, which moved
+                                         every field of a round-4 host by 8 bytes: taken out again in round 6.  If this result ever has to grow, it grows
+                                         through a new entry point, not through this struct. */
     const uint32_t* popped;  size_t n_popped;
     const uint32_t* pushed;  size_t n_pushed;
     const uint32_t* pairs_slept; size_t n_pairs_slept;    /* ContactEdgeFlags::SLEEPING set (every touching pair, constraint-generating or not) */

@@ -588,6 +588,35 @@ struct IslandManager {
         }
     }
     avn_status split_candidate_now() { if (split_candidate != NONE) split_island(split_candidate); return AVN_OK; }   // split_island system, :160-178
+    // avn_islands_split_candidate_adjacency on the oracle: the caller's CSR is CHECKED -- for every body of the candidate island the row must name, in order, the other
+    // bodies of the edges split_island's walk would collect from the petgraph lists (:1112-1148) that own a node -- and then the walk above runs on the oracle's own lists
+    avn_status split_candidate_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) {
+        if (!off) return AVN_ERR_BAD_ARG;
+        if (split_candidate == NONE) return AVN_OK;
+        PhysicsIsland* island = islands.get(split_candidate);
+        if (island && !island->is_sleeping && island->constraints_removed != 0) {
+            for (uint32_t body = island->head_body; body != NONE; body = body_node[body].next) {
+                std::vector<uint32_t> want;
+                for (uint32_t collider : body_colliders[body]) {
+                    auto it = collider_index.find(collider);
+                    if (it == collider_index.end()) continue;
+                    contact_lists.for_each_edge(it->second, [&](uint32_t e) {
+                        const ContactEdge& ce = contacts[e];
+                        if (ce.handles == 0) return;
+                        const uint32_t b1 = collider_body[ce.collider1], b2 = collider_body[ce.collider2];
+                        const uint32_t other = b1 == body ? b2 : b1;
+                        if (has_node(other)) want.push_back(other);
+                    });
+                }
+                const uint32_t lo = body < n_bodies ? off[body] : 0u, hi = body < n_bodies ? off[body + 1] : 0u;
+                bool same = hi - lo == want.size();
+                for (uint32_t k = 0; same && k < want.size(); ++k) same = adj[lo + k] == want[k];
+                if (!same) { error = "islands_split_candidate_adjacency: the adjacency row of body " + std::to_string(body) + " is not the walk's edge order"; return AVN_ERR_STATE; }
+            }
+        }
+        split_island(split_candidate);
+        return AVN_OK;
+    }
 
     // the Sleeping set: island side of update_sleeping_states (sleeping.rs:224-239), wake_islands_with_sleeping_disabled (:164-182),
     // sleep_islands (:243-280), then the two queued commands

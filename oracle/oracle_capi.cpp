@@ -308,19 +308,18 @@ avn_status avo_islands_pair_add(avn_island_manager* m, uint32_t id, uint32_t c1,
 avn_status avo_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t mc) { return m ? m->m.status_change(id, flags, mc) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_flush_wake(avn_island_manager* m) { return m ? m->m.flush_wake() : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_split_candidate(avn_island_manager* m) { return m ? m->m.split_candidate_now() : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n) { return m ? m->m.split_candidate_adjacency(off, adj, n) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { return m ? m->m.sleeping_systems(t, f, n, tts) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_wake_body(avn_island_manager* m, uint32_t body) { return m ? m->m.wake_body(body) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_sleep_body(avn_island_manager* m, uint32_t body) { return m ? m->m.sleep_body(body) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_last_result(avn_island_manager* m, avn_islands_result* o) {
-    if (!m || !o || o->struct_size < 2 * sizeof(size_t) || o->struct_size > 4096) return AVN_ERR_BAD_ARG;
+    if (!m || !o) return AVN_ERR_BAD_ARG;
     avo::IslandManager& g = m->m;
-    avn_islands_result r;
-    r.struct_size = o->struct_size;
+    avn_islands_result& r = *o;
     r.popped = g.popped.data(); r.n_popped = g.popped.size(); r.pushed = g.pushed.data(); r.n_pushed = g.pushed.size();
     r.pairs_slept = g.pairs_slept.data(); r.n_pairs_slept = g.pairs_slept.size(); r.pairs_woken = g.pairs_woken.data(); r.n_pairs_woken = g.pairs_woken.size();
     r.bodies_slept = g.bodies_slept.data(); r.n_bodies_slept = g.bodies_slept.size(); r.bodies_woken = g.bodies_woken.data(); r.n_bodies_woken = g.bodies_woken.size();
     r.pairs_removed = g.pairs_removed.data(); r.n_pairs_removed = g.pairs_removed.size();
-    std::memcpy(o, &r, std::min(o->struct_size, sizeof r));
     return AVN_OK;
 }
 avn_status avo_islands_collider_remove(avn_island_manager* m, uint32_t collider) { return m ? m->m.collider_remove_full(collider) : AVN_ERR_BAD_ARG; }

@@ -50,11 +50,42 @@ def build(n_bodies, n_static, rng, colliders_per_body=1):
     return ms, col_body
 
 
+def walk_adjacency(live, col_body, n_bodies, has_node):
+    """split_island's neighbour lists as the CSR avn_islands_split_candidate_adjacency takes, written from the driver's own record of the pairs (an independent
+    statement of the edge order: a body's colliders in the order they were added = ascending entity here; per collider the outgoing edges -- the collider is
+    collider1 -- newest first, then the incoming ones newest first; only edges that hold constraint handles and whose other body owns a node)."""
+    rows = [[] for _ in range(n_bodies)]
+    by_col = {}
+    for cid, p in live.items():
+        if not p["touching"] or p.get("pair_sleeping"):
+            continue   # no constraint handles: not touching, or popped by SleepIslands
+        by_col.setdefault(p["c1"], ([], []))[0].append((p["stamp"], p["c2"]))
+        by_col.setdefault(p["c2"], ([], []))[1].append((p["stamp"], p["c1"]))
+    for c in sorted(by_col):
+        b = col_body.get(c)
+        if b is None or not has_node(b):
+            continue
+        out, inc = by_col[c]
+        for lst in (out, inc):
+            for _, other_col in sorted(lst, reverse=True):
+                ob = col_body[other_col]
+                if has_node(ob):
+                    rows[b].append(ob)
+    off = np.zeros(n_bodies + 1, np.uint32)
+    off[1:] = np.cumsum([len(r) for r in rows])
+    adj = np.array([x for r in rows for x in r], np.uint32)
+    return off, adj
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_event_streams_keep_both_managers_identical(seed):
     rng = np.random.default_rng(seed)
     n_bodies, n_static = 40, 3
     (mo, mh), col_body = build(n_bodies, n_static, rng, colliders_per_body=1 + seed % 2)
+    # round 6: the same streams with split_island driven through avn_islands_split_candidate_adjacency -- the ORACLE checks the CSR against its own petgraph lists
+    # before it walks, the product walks the CSR itself (what the closed loop does with the device-built lists); odd seeds use it, even seeds the plain call
+    use_adj = seed % 2 == 1
+    stamp = 0
     cols = sorted(col_body)
     # a few joints first (spawn order)
     jointed = set()
@@ -83,7 +114,7 @@ def test_random_event_streams_keep_both_managers_identical(seed):
                 free.sort(); cid = free.pop(0)
             else:
                 cid = next_id; next_id += 1
-            live[cid] = dict(c1=int(c1), c2=int(c2), touching=False, sleeping_body=False)
+            live[cid] = dict(c1=int(c1), c2=int(c2), touching=False, sleeping_body=False, stamp=stamp); stamp += 1
             for m in (mo, mh):
                 m.pair_add(cid, int(c1), int(c2))
         # --- narrow phase status loop, ascending id; sleeping pairs are not updated ---
@@ -110,7 +141,11 @@ def test_random_event_streams_keep_both_managers_identical(seed):
         for c in ro["pairs_woken"]: live[int(c)]["pair_sleeping"] = False
         same(mo, mh, n_bodies, f"step {step}: after the status loop")
         # --- Finalize: split_island(candidate) ---
-        for m in (mo, mh): m.split_candidate()
+        if use_adj:
+            off, adj = walk_adjacency(live, col_body, n_bodies, lambda b: b >= n_static and b not in despawned)
+            for m in (mo, mh): m.split_candidate_adjacency(off, adj)
+        else:
+            for m in (mo, mh): m.split_candidate()
         same(mo, mh, n_bodies, f"step {step}: after split_island")
         # --- Sleeping set ---
         st = mo.state(n_bodies)
