@@ -257,7 +257,7 @@ ABI_SYMBOLS = [
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
     "contacts_download", "contacts_upload", "pipeline_enable", "pipeline_stats_get", "pipeline_handles_get", "pipeline_new_pair_ids_get",
     "islands_create", "islands_destroy", "islands_body_add", "islands_collider_add", "islands_joint_add", "islands_pair_add", "islands_status_change",
-    "islands_flush_wake", "islands_split_candidate", "islands_split_candidate_adjacency", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
+    "islands_flush_wake", "islands_split_candidate", "islands_split_candidate_adjacency", "islands_split_join", "islands_sleeping_systems", "islands_wake_body", "islands_sleep_body", "islands_last_result",
     "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies", "islands_joint_remove", "islands_renumber_joints",
     "shard_create", "shard_destroy", "shard_last_error", "shard_phase2", "shard_new_local_pairs", "shard_active", "shard_phase3", "shard_removed_local", "shard_handles", "shard_stats_get",
     "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange", "despawn",
@@ -353,7 +353,7 @@ class Library:
         f("islands_destroy").restype = None; f("islands_destroy").argtypes = [vp]
         for name, args in (("islands_body_add", [vp, C.c_uint32]), ("islands_collider_add", [vp, C.c_uint32, C.c_uint32]),
                            ("islands_joint_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_pair_add", [vp, C.c_uint32, C.c_uint32, C.c_uint32]),
-                           ("islands_status_change", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_flush_wake", [vp]), ("islands_split_candidate", [vp]), ("islands_split_candidate_adjacency", [vp, vp, vp, C.c_uint32]),
+                           ("islands_status_change", [vp, C.c_uint32, C.c_uint32, C.c_uint32]), ("islands_flush_wake", [vp]), ("islands_split_candidate", [vp]), ("islands_split_candidate_adjacency", [vp, vp, vp, C.c_uint32, vp]), ("islands_split_join", [vp]),
                            ("islands_sleeping_systems", [vp, vp, vp, C.c_uint32, C.c_float]), ("islands_wake_body", [vp, C.c_uint32]), ("islands_sleep_body", [vp, C.c_uint32]),
                            ("islands_last_result", [vp, vp]), ("islands_stats_get", [vp, vp]), ("islands_state", [vp, C.c_uint32, vp, vp, vp, vp]),
                            ("islands_collider_remove", [vp, C.c_uint32]), ("islands_body_remove", [vp, C.c_uint32]), ("islands_renumber_bodies", [vp, vp, C.c_uint32]),
@@ -1069,11 +1069,17 @@ class IslandManager:
     def flush_wake(self): self._chk(self.lib.fn("islands_flush_wake")(self.handle), "islands_flush_wake"); return self.last_result()
     def split_candidate(self): self._chk(self.lib.fn("islands_split_candidate")(self.handle), "islands_split_candidate")
 
-    def split_candidate_adjacency(self, off, adj):
-        """split_island(candidate) with the contact neighbours as a CSR over bodies (the walk's edge order; see the header)."""
+    def split_candidate_adjacency(self, off, adj, labels=None):
+        """split_island(candidate) with the contact neighbours as a CSR over bodies (the walk's edge order; see the header).  With `labels` the walk of an
+        island that is still one piece runs on a worker thread: the arrays are kept alive here until split_join()."""
         o = np.ascontiguousarray(off, np.uint32); a = np.ascontiguousarray(adj, np.uint32)
         if len(a) == 0: a = np.zeros(1, np.uint32)
-        self._chk(self.lib.fn("islands_split_candidate_adjacency")(self.handle, _ptr(o), _ptr(a), len(o) - 1), "islands_split_candidate_adjacency")
+        l = None if labels is None else np.ascontiguousarray(labels, np.uint32)
+        self._adj_keep = (o, a, l)
+        self._chk(self.lib.fn("islands_split_candidate_adjacency")(self.handle, _ptr(o), _ptr(a), len(o) - 1, _ptr(l)), "islands_split_candidate_adjacency")
+
+    def split_join(self): self._chk(self.lib.fn("islands_split_join")(self.handle), "islands_split_join")
+
     def wake_body(self, body): self._chk(self.lib.fn("islands_wake_body")(self.handle, body), "islands_wake_body"); return self.last_result()
     def sleep_body(self, body): self._chk(self.lib.fn("islands_sleep_body")(self.handle, body), "islands_sleep_body"); return self.last_result()
     def collider_remove(self, collider): self._chk(self.lib.fn("islands_collider_remove")(self.handle, collider), "islands_collider_remove"); return self.last_result()

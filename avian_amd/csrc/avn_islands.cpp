@@ -26,7 +26,8 @@ void IslandManager::island_remove(uint32_t id) {   // PhysicsIslands::remove_isl
     --n_islands_;
 }
 
-avn_status IslandManager::body_add(uint32_t body) {   // BodyIslandNode::on_add, :1330-1345
+avn_status IslandManager::body_add(uint32_t body) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }   // BodyIslandNode::on_add, :1330-1345
     if (node_.size() <= body) { node_.resize((size_t)body + 1, 0); asleep_.resize((size_t)body + 1, 0); isl_of_.resize((size_t)body + 1, NONE); colliders_of_.resize((size_t)body + 1); joint_edges_.resize((size_t)body + 1); }
     if (node_[body]) { error = "islands_body_add: the body already has a node"; return AVN_ERR_STATE; }
     Island isl;
@@ -73,6 +74,7 @@ uint32_t IslandManager::merge(uint32_t body1, uint32_t body2) {
     uint32_t big = isl_of_[body1], small = isl_of_[body2];
     if (big == small) return big;
     if (islands_[big].bodies.size() < islands_[small].bodies.size()) std::swap(big, small);
+    if (async_.active && async_.holds(small)) (void)split_join();   // (its list is appended in list order: the walk's order must be in)
     Island& B = islands_[big]; Island& S = islands_[small];
     for (uint32_t b : S.bodies) isl_of_[b] = big;
     B.bodies.insert(B.bodies.end(), S.bodies.begin(), S.bodies.end());
@@ -96,18 +98,22 @@ uint32_t IslandManager::unlink_contact(uint32_t id) {   // remove_contact, :594-
     islands_[isl].removed += 1;
     return isl;
 }
-avn_status IslandManager::joint_add(uint32_t jid, uint32_t body1, uint32_t body2) {   // joint_graph/mod.rs:238-270 + islands/mod.rs:668-735
+avn_status IslandManager::joint_add(uint32_t jid, uint32_t body1, uint32_t body2) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }   // joint_graph/mod.rs:238-270 + islands/mod.rs:668-735
     if (joints_.size() <= jid) joints_.resize((size_t)jid + 1);
     joints_[jid] = Joint{body1, body2};
     const uint32_t hi = std::max(body1, body2);
     if (joint_edges_.size() <= hi) joint_edges_.resize((size_t)hi + 1);
     joint_edges_[body1].out.push_back(jid);
     joint_edges_[body2].in.push_back(jid);
+    if (body_has_joint_.size() <= hi) body_has_joint_.resize((size_t)hi + 1, 0);
+    body_has_joint_[body1] = body_has_joint_[body2] = 1;   // (never cleared by joint_remove: "may have joint edges" -- the walk then looks and finds none)
     if (body_has_node(body1) || body_has_node(body2)) merge(body_has_node(body1) ? body1 : body2, body_has_node(body2) ? body2 : body1);
     return AVN_OK;
 }
 
 avn_status IslandManager::joint_remove(uint32_t jid) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     clear_results();
     if (jid >= joints_.size() || (joints_[jid].b1 == NONE && joints_[jid].b2 == NONE)) { error = "islands_joint_remove: no such joint"; return AVN_ERR_STATE; }
     const Joint j = joints_[jid];
@@ -123,6 +129,7 @@ avn_status IslandManager::joint_remove(uint32_t jid) {
     return AVN_OK;
 }
 avn_status IslandManager::renumber_joints(const uint32_t* new_index, uint32_t n_old) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     if (n_old && !new_index) return AVN_ERR_BAD_ARG;
     auto m = [&](uint32_t j) { return j < n_old ? new_index[j] : NONE; };
     std::vector<Joint> nj;
@@ -190,6 +197,7 @@ template <class F> void IslandManager::edges_in_reference_order(const EdgeLists&
 }
 // SleepIslands::apply (sleeping.rs:355-420) over ContactGraph::sleep_entity_with (contact_graph.rs:768-838)
 void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
+    if (async_needs(ids)) (void)split_join();
     std::vector<uint32_t> batch;
     for (uint32_t id : ids) {
         if (id >= islands_.size() || !islands_[id].used) continue;
@@ -217,6 +225,7 @@ void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
 }
 // WakeIslands::apply (:470-540) over wake_entity_with (:705-766)
 void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
+    if (async_needs(ids)) (void)split_join();
     std::vector<uint32_t> batch;
     for (uint32_t id : ids) {
         if (id >= islands_.size() || !islands_[id].used || !islands_[id].sleeping) continue;
@@ -259,6 +268,8 @@ void IslandManager::split(uint32_t island, const uint32_t* adj_off, const uint32
     const uint32_t gen = mark_gen_;
     uint32_t* const mark_body = mark_body_.data();
     const uint32_t n_mark = (uint32_t)mark_body_.size();
+    const uint8_t* const has_joint = body_has_joint_.data();
+    const uint32_t n_has_joint = (uint32_t)std::min(body_has_joint_.size(), joint_edges_.size());
     for (uint32_t seed : seeds) {
         if (mark_body[seed] == gen) continue;
         mark_body[seed] = gen;
@@ -296,7 +307,7 @@ void IslandManager::split(uint32_t island, const uint32_t* adj_off, const uint32
                     mark_contact_[pr.first] = gen;
                 }
             }
-            if (body < joint_edges_.size() && (!joint_edges_[body].out.empty() || !joint_edges_[body].in.empty())) {
+            if (body < n_has_joint && has_joint[body]) {   // (one byte per body: joint_edges_ is 48 bytes per body, a cache miss per visited body of a jointless pile)
                 found.clear();
                 edges_in_reference_order(joint_edges_[body], body, false, [&](uint32_t j) {
                     if (mark_joint_[j] == gen) return;
@@ -322,12 +333,163 @@ void IslandManager::collider_ranks(const uint32_t* slot_entity, uint32_t n_slots
         rank_by_slot[s] = (r && r->known && r->rank != NONE) ? r->rank : next++;
     }
 }
-avn_status IslandManager::split_candidate_now() { if (candidate_ != NONE) split(candidate_); return AVN_OK; }
+avn_status IslandManager::split_candidate_now() {
+    if (candidate_ == NONE) return AVN_OK;   // (nothing to split: a walk still in flight is left alone)
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
+    split(candidate_);
+    return AVN_OK;
+}
 avn_status IslandManager::split_candidate_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     if (!off || (!adj && n_bodies && off[n_bodies])) { error = "islands_split_candidate_adjacency: null array"; return AVN_ERR_BAD_ARG; }
     if (candidate_ != NONE) split(candidate_, off, adj, n_bodies);
     return AVN_OK;
 }
+// ---- the split of an island whose pieces are known (labels): bookkeeping now, the order inside the pieces' body lists from a worker thread -----------------
+void IslandManager::async_walk(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) {
+    // the walk of split() over the CSR, marks and stack private to the worker; reads seeds, the CSR, the joint lists and the node flags, writes async_.order
+    AsyncSplit& a = async_;
+    const uint32_t gen = a.gen;
+    uint32_t* const mark = a.mark.data();
+    const uint32_t n_mark = (uint32_t)a.mark.size();
+    const uint8_t* const has_joint = body_has_joint_.data();
+    const uint32_t n_has_joint = (uint32_t)std::min(body_has_joint_.size(), joint_edges_.size());
+    std::vector<std::pair<uint32_t, uint32_t>> found;
+    a.order.clear(); a.order.reserve(a.seeds.size());
+    size_t piece = 0;
+    bool ok = true;
+    for (uint32_t seed : a.seeds) {
+        if (seed >= n_mark || mark[seed] == gen) continue;
+        mark[seed] = gen;
+        if (piece >= a.pieces.size() || a.pieces[piece].first != seed) { ok = false; break; }   // (the labels said otherwise)
+        const size_t begin = a.order.size();
+        a.stack.assign(1, seed);
+        while (!a.stack.empty()) {
+            const uint32_t body = a.stack.back(); a.stack.pop_back();
+            a.order.push_back(body);
+            if (body < n_bodies) {
+                const uint32_t e1 = off[body + 1];
+                for (uint32_t e = off[body]; e < e1; ++e) {
+                    const uint32_t o = adj[e];
+                    if (o < n_mark && mark[o] != gen) { mark[o] = gen; a.stack.push_back(o); if (o < n_bodies) __builtin_prefetch(adj + off[o]); }
+                }
+            }
+            if (body < n_has_joint && has_joint[body]) {
+                found.clear();
+                edges_in_reference_order(joint_edges_[body], body, false, [&](uint32_t j) {
+                    if (a.jmark[j] == gen) return;
+                    found.push_back({j, joints_[j].b1 == body ? joints_[j].b2 : joints_[j].b1});
+                });
+                for (auto& pr : found) {
+                    if (body_has_node(pr.second) && pr.second < n_mark && mark[pr.second] != gen) { a.stack.push_back(pr.second); mark[pr.second] = gen; }
+                    a.jmark[pr.first] = gen;
+                }
+            }
+        }
+        if (a.order.size() - begin != a.pieces[piece].count) { ok = false; break; }
+        ++piece;
+    }
+    a.failed = !ok || piece != a.pieces.size() || a.order.size() != a.seeds.size();
+}
+avn_status IslandManager::split_candidate_labelled_async(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies, const uint32_t* label) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
+    if (!off || !label || (!adj && n_bodies && off[n_bodies])) { error = "islands_split_candidate_adjacency: null array"; return AVN_ERR_BAD_ARG; }
+    if (!split_pending()) return AVN_OK;
+    const uint32_t island = candidate_;
+    AsyncSplit& a = async_;
+    if (++a.gen == 0) { std::fill(a.mark.begin(), a.mark.end(), 0u); std::fill(a.jmark.begin(), a.jmark.end(), 0u); std::fill(a.lab_gen.begin(), a.lab_gen.end(), 0u); a.gen = 1; }
+    if (a.mark.size() < node_.size()) a.mark.resize(node_.size(), 0);
+    if (a.jmark.size() < joints_.size()) a.jmark.resize(joints_.size(), 0);
+    if (a.lab_gen.size() < n_bodies) { a.lab_gen.resize(n_bodies, 0); a.lab_piece.resize(n_bodies, 0); }
+    // the pieces, in the order the walk would start them -- the order in which the old list first names a body of the piece -- and their sizes.  First the common
+    // case, in one STREAMING pass over the bodies: every member carries the first member's label = still one piece (a settled pile, every other step)
+    a.pieces.clear();
+    {
+        const std::vector<uint32_t>& bs = islands_[island].bodies;
+        const uint32_t first = bs.empty() ? NONE : bs[0];
+        const uint32_t l0 = first < n_bodies ? label[first] : NONE;
+        bool one = l0 < n_bodies, covered = true;
+        if (one) {
+            size_t members = 0;
+            const uint32_t n = std::min<uint32_t>(n_bodies, (uint32_t)node_.size());
+            for (uint32_t b = 0; b < n; ++b) members += (size_t)((int)(isl_of_[b] == island) & (int)(node_[b] != 0) & (int)(label[b] == l0));
+            one = members == bs.size();
+        }
+        if (one) a.pieces.push_back({NONE, (uint32_t)bs.size(), first});
+        else {
+            for (uint32_t b : bs) {   // list order: random reads of the labels
+                const uint32_t l = b < n_bodies ? label[b] : NONE;
+                if (l >= n_bodies) { covered = false; break; }
+                if (a.lab_gen[l] != a.gen) { a.lab_gen[l] = a.gen; a.lab_piece[l] = (uint32_t)a.pieces.size(); a.pieces.push_back({NONE, 0u, b}); }
+                ++a.pieces[a.lab_piece[l]].count;
+            }
+        }
+        if (!covered) { a.pieces.clear(); return split_candidate_adjacency(off, adj, n_bodies); }   // (labels do not cover the island: walk now)
+    }
+    a.seeds = std::move(islands_[island].bodies);
+    // split_island's bookkeeping: remove_island (the candidate is cleared, its key goes onto the vacant stack), then one insert per piece
+    island_remove(island);
+    ++splits_;
+    for (AsyncSplit::Piece& p : a.pieces) { Island isl; p.island = island_insert(std::move(isl)); }
+    if (a.pieces.size() == 1) {
+        // still one piece (a settled pile, every other step): the key comes straight back, nobody changes island -- the list is a copy until the walk's order arrives
+        islands_[a.pieces[0].island].bodies = a.seeds;
+        if (a.pieces[0].island != island) for (uint32_t b : a.seeds) isl_of_[b] = a.pieces[0].island;
+    } else {
+        for (AsyncSplit::Piece& p : a.pieces) islands_[p.island].bodies.reserve(p.count);
+        for (uint32_t b : a.seeds) {   // until the join: the old list's order inside every piece
+            const uint32_t id = a.pieces[a.lab_piece[label[b]]].island;
+            islands_[id].bodies.push_back(b);
+            isl_of_[b] = id;
+        }
+    }
+    a.active = true; a.failed = false;
+    a.th = std::thread([this, off, adj, n_bodies] { async_walk(off, adj, n_bodies); });
+    return AVN_OK;
+}
+std::string IslandManager::check_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) const {
+    if (candidate_ == NONE || candidate_ >= islands_.size() || !islands_[candidate_].used) return "";
+    std::vector<uint32_t> want;
+    for (uint32_t body : islands_[candidate_].bodies) {
+        want.clear();
+        for (uint32_t col : colliders_of_[body]) {
+            const uint32_t nd = col_node(col);
+            if (nd == NONE) continue;
+            edges_in_reference_order(contact_edges_[nd], nd, true, [&](uint32_t e) {
+                const Contact& c = contacts_[e];
+                if (!c.handles) return;
+                const uint32_t o = c.rb1 == body ? c.rb2 : c.rb1;
+                if (body_has_node(o)) want.push_back(o);
+            });
+        }
+        const uint32_t lo = body < n_bodies ? off[body] : 0u, hi = body < n_bodies ? off[body + 1] : 0u;
+        bool same = hi - lo == want.size();
+        for (uint32_t k = 0; same && k < want.size(); ++k) same = adj[lo + k] == want[k];
+        if (!same) {
+            std::string w = "body " + std::to_string(body) + ": manager [";
+            for (uint32_t x : want) w += std::to_string(x) + " ";
+            w += "] device [";
+            for (uint32_t k = lo; k < hi && k < lo + 16; ++k) w += std::to_string(adj[k]) + " ";
+            return w + "] off " + std::to_string(lo) + ".." + std::to_string(hi);
+        }
+    }
+    return "";
+}
+avn_status IslandManager::split_join() {
+    if (!async_.active) return AVN_OK;
+    if (async_.th.joinable()) async_.th.join();
+    async_.active = false;
+    if (async_.failed) { error = "islands: the labels handed to the split are not the components the walk found (body lists are not the reference's from here on)"; return AVN_ERR_STATE; }
+    size_t at = 0;
+    for (const AsyncSplit::Piece& p : async_.pieces) {
+        if (p.count > 1 && p.island < islands_.size() && islands_[p.island].used && islands_[p.island].bodies.size() >= p.count)
+            std::copy(async_.order.begin() + at, async_.order.begin() + at + p.count, islands_[p.island].bodies.begin());
+        at += p.count;
+    }
+    async_.pieces.clear();
+    return AVN_OK;
+}
+
 // the closed loop's batches: pair_add / status_change over arrays, in array order; the records a call will touch are requested a few calls ahead (a settled
 // 100 k-body pile hands over 3*10^4 changes per step scattered over a 45 MB contact table: the loop was one cache miss per change)
 avn_status IslandManager::pairs_add(const uint32_t* ids, const avn_pair* pr, uint32_t n) {
@@ -403,13 +565,15 @@ avn_status IslandManager::sleeping_systems(const float* sleep_timer, const uint8
     last_slept_ = (uint32_t)to_sleep.size(); last_woken_ = (uint32_t)to_wake.size();
     return AVN_OK;
 }
-avn_status IslandManager::wake_body(uint32_t body) {   // WakeBody, sleeping.rs:438-452
+avn_status IslandManager::wake_body(uint32_t body) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }   // WakeBody, sleeping.rs:438-452
     clear_results();
     if (!body_has_node(body)) { error = "islands_wake_body: the body has no island node"; return AVN_ERR_BAD_ARG; }
     wake_islands({isl_of_[body]});
     return AVN_OK;
 }
-avn_status IslandManager::sleep_body(uint32_t body) {   // SleepBody, :296-352
+avn_status IslandManager::sleep_body(uint32_t body) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }   // SleepBody, :296-352
     clear_results();
     if (!body_has_node(body)) { error = "islands_sleep_body: the body has no island node"; return AVN_ERR_BAD_ARG; }
     if (islands_[isl_of_[body]].removed > 0) split(isl_of_[body]);
@@ -447,6 +611,7 @@ avn_status IslandManager::collider_forget(uint32_t collider) {
     return AVN_OK;
 }
 avn_status IslandManager::collider_remove(uint32_t collider) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     clear_results();
     if (!has_collider(collider)) { error = "islands_collider_remove: unknown collider"; return AVN_ERR_BAD_ARG; }
     for (uint32_t id : collider_edges_in_order(collider)) {
@@ -458,12 +623,14 @@ avn_status IslandManager::collider_remove(uint32_t collider) {
     return collider_forget(collider);
 }
 avn_status IslandManager::wake_island(uint32_t island) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     clear_results();
     if (island != NONE) wake_islands({island});
     return AVN_OK;
 }
 // BodyIslandNode::on_remove, islands/mod.rs:1336-1400: the body leaves its island's list; an island left empty is removed
 avn_status IslandManager::body_remove(uint32_t body, bool wake) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     clear_results();
     if (!body_has_node(body)) return AVN_OK;
     const uint32_t island = isl_of_[body];
@@ -475,6 +642,7 @@ avn_status IslandManager::body_remove(uint32_t body, bool wake) {
     return AVN_OK;
 }
 avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_old) {
+    { const avn_status js = split_join(); if (js != AVN_OK) return js; }
     if (n_old && !new_index) { error = "islands_renumber_bodies: null map"; return AVN_ERR_BAD_ARG; }
     uint32_t n_new = 0;
     for (uint32_t b = 0; b < n_old; ++b) if (new_index[b] != NONE) n_new = std::max(n_new, new_index[b] + 1u);
@@ -484,14 +652,16 @@ avn_status IslandManager::renumber_bodies(const uint32_t* new_index, uint32_t n_
     std::vector<uint32_t> isl_of(n_new, NONE);
     std::vector<std::vector<uint32_t>> cols(n_new);
     std::vector<EdgeLists> jedges(n_new);
+    std::vector<uint8_t> hasj(n_new, 0);
     for (uint32_t b = 0; b < n_old && b < node_.size(); ++b) {
         const uint32_t nb = new_index[b];
         if (nb == NONE) continue;
         node[nb] = node_[b]; asleep[nb] = asleep_[b]; isl_of[nb] = isl_of_[b];
         if (b < colliders_of_.size()) cols[nb] = std::move(colliders_of_[b]);
         if (b < joint_edges_.size()) jedges[nb] = std::move(joint_edges_[b]);
+        if (b < body_has_joint_.size()) hasj[nb] = body_has_joint_[b];
     }
-    node_.swap(node); asleep_.swap(asleep); isl_of_.swap(isl_of); colliders_of_.swap(cols); joint_edges_.swap(jedges);
+    node_.swap(node); asleep_.swap(asleep); isl_of_.swap(isl_of); colliders_of_.swap(cols); joint_edges_.swap(jedges); body_has_joint_.swap(hasj);
     ++col_epoch_;
     for (ColRec& r : col_dense_) if (r.known) r.body = m(r.body);
     for (auto& kv : col_sparse_) if (kv.second.known) kv.second.body = m(kv.second.body);
@@ -520,6 +690,7 @@ avn_status IslandManager::stats(avn_islands_stats* o) const {
     return AVN_OK;
 }
 avn_status IslandManager::state(uint32_t n_bodies, uint32_t* island_of_body, uint32_t* next_in_island, uint8_t* island_sleeping, uint32_t* removed) const {
+    { const avn_status js = const_cast<IslandManager*>(this)->split_join(); if (js != AVN_OK) return js; }
     if (next_in_island) {
         for (uint32_t b = 0; b < n_bodies; ++b) next_in_island[b] = NONE;
         for (const Island& i : islands_)
@@ -551,7 +722,16 @@ AVN_API avn_status avn_islands_pair_add(avn_island_manager* m, uint32_t id, uint
 AVN_API avn_status avn_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t manifold_count) { AVN_ISL(status_change(id, flags, manifold_count)); }
 AVN_API avn_status avn_islands_flush_wake(avn_island_manager* m) { AVN_ISL(flush_wake()); }
 AVN_API avn_status avn_islands_split_candidate(avn_island_manager* m) { AVN_ISL(split_candidate_now()); }
-AVN_API avn_status avn_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n) { AVN_ISL(split_candidate_adjacency(off, adj, n)); }
+AVN_API avn_status avn_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n, const uint32_t* labels) {
+    if (!m) return AVN_ERR_BAD_ARG;
+    try {
+        avn_status st = m->m.split_join();
+        if (st != AVN_OK) return st;
+        if (labels && off) return m->m.split_candidate_labelled_async(off, adj, n, labels);
+        return m->m.split_candidate_adjacency(off, adj, n);
+    } catch (...) { m->m.error = "out of host memory"; return AVN_ERR_OOM; }
+}
+AVN_API avn_status avn_islands_split_join(avn_island_manager* m) { AVN_ISL(split_join()); }
 AVN_API avn_status avn_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { AVN_ISL(sleeping_systems(t, f, n, tts)); }
 AVN_API avn_status avn_islands_wake_body(avn_island_manager* m, uint32_t body) { AVN_ISL(wake_body(body)); }
 AVN_API avn_status avn_islands_sleep_body(avn_island_manager* m, uint32_t body) { AVN_ISL(sleep_body(body)); }

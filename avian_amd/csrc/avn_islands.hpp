@@ -15,7 +15,9 @@
 #pragma once
 #include <algorithm>
 #include <cstdint>
+#include <new>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -46,8 +48,26 @@ public:
     // RigidBodyColliders order; per collider outgoing edges newest first, then incoming newest first).  Same result as split_candidate_now(), which derives
     // that order from the manager's own edge lists; here the caller holds it (the closed loop builds it on the device from the rows' insertion stamps).
     avn_status split_candidate_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies);
+    // ... and when the caller also hands in the COMPONENTS of those edges (+ joints) as a label per body (the closed loop labels them on the device): the split's
+    // bookkeeping is then known without the walk -- the pieces are the labels, a piece's key is handed out when the old list first names one of its bodies (the walk
+    // starts its pieces in that order: island_remove pushes the old key, every island_insert pops the next), sizes are counts, constraints_removed and the timers
+    // start again at 0 -- and only the ORDER inside every piece's body list (the walk's visit order) is outstanding.  The walk runs on a worker thread over the
+    // caller's CSR, which must stay untouched until split_join(); until then a piece's list holds its bodies in the OLD list's order.  Every member that reads or
+    // reorders the list of a piece of more than one body (SleepIslands / WakeIslands, a merge INTO another island, the next split, despawn, renumbering,
+    // avn_islands_state) and every mutation of what the walk reads (joints, island nodes) joins first.  Appending merges do not wait: the walk orders the first n
+    // bodies of a list, the newcomers follow them either way.
+    avn_status split_candidate_labelled_async(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies, const uint32_t* label);
+    // measurement / debugging aid: the CSR rows of the candidate island's bodies against the manager's own edge lists; empty string = equal
+    std::string check_adjacency(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies) const;
+    avn_status split_join();
+    bool split_in_flight() const { return async_.active; }
+    ~IslandManager() { if (async_.th.joinable()) async_.th.join(); }
+    IslandManager() = default;
+    IslandManager(const IslandManager&) = delete;
+    void reset() { if (async_.th.joinable()) async_.th.join(); this->~IslandManager(); new (this) IslandManager(); }   // (a fresh manager in place: the worker thread member is not assignable while it runs)
     bool split_pending() const { return candidate_ != NONE && candidate_ < islands_.size() && islands_[candidate_].used && !islands_[candidate_].sleeping && islands_[candidate_].removed != 0; }
     bool has_candidate() const { return candidate_ != NONE; }
+    size_t candidate_bodies() const { return candidate_ != NONE && candidate_ < islands_.size() ? islands_[candidate_].bodies.size() : 0; }
     // what the device-built adjacency is keyed by: the rank of every collider in the body-major concatenation of RigidBodyColliders (bodies ascending, a body's
     // colliders in the order they were added); colliders of bodies without a node come after.  collider_epoch() changes whenever the ranks may have.
     uint64_t collider_epoch() const { return col_epoch_; }
@@ -121,6 +141,7 @@ private:
     uint32_t col_node(uint32_t c) const { const ColRec* r = col_find(c); return r && r->known ? r->node : NONE; }   // NONE: no edge list yet
     std::vector<EdgeLists> contact_edges_;   // per collider node
     std::vector<EdgeLists> joint_edges_;     // per body
+    std::vector<uint8_t> body_has_joint_;    // per body: joint_edges_[b] may be non-empty
     std::vector<Contact> contacts_;
     std::vector<Joint> joints_;
     std::vector<Island> islands_;
@@ -137,6 +158,17 @@ private:
     uint32_t mark_gen_ = 0;
     uint64_t col_epoch_ = 1;
     std::vector<uint32_t> split_stack_;
+    struct AsyncSplit {
+        bool active = false, failed = false;
+        struct Piece { uint32_t island, count, first; };
+        std::vector<Piece> pieces;                     // in the order the walk starts them
+        std::vector<uint32_t> seeds, order, mark, jmark, stack, lab_gen, lab_piece;
+        uint32_t gen = 0;
+        std::thread th;
+        bool holds(uint32_t island) const { for (const Piece& p : pieces) if (p.island == island && p.count > 1) return true; return false; }
+    } async_;
+    bool async_needs(const std::vector<uint32_t>& ids) const { if (async_.active) for (uint32_t id : ids) if (async_.holds(id)) return true; return false; }
+    void async_walk(const uint32_t* off, const uint32_t* adj, uint32_t n_bodies);
     std::vector<std::pair<uint32_t, uint32_t>> split_found_;
 
     void clear_results();

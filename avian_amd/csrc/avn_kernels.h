@@ -233,8 +233,8 @@ template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_p
 // PGC_BUCKET must be zero when it starts (k_pg_build_handles leaves it so).
 void launch_pg_scan_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t, const uint32_t* bmeta_if_sleeping = nullptr);
 // split_island's neighbour lists as a CSR over bodies, from the rows (k_graph.hip, round 6): off[n_bodies + 2] (off[n_bodies + 1] = entries found), adj[n]
-struct IslAdj { uint32_t* count; uint32_t cap; uint32_t *e_key2, *e_other, *e_body, *k_a, *v_a, *k_b, *v_b; /* [cap] each */ };
-void launch_isl_adjacency(const PG&, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, uint32_t n_rows, uint32_t n_bodies, uint32_t n, uint32_t seq_bits, uint32_t rank_bits,
+struct IslAdj { uint32_t cap; uint32_t *e_key2, *e_other, *e_body, *k_a, *v_a, *k_b, *v_b; /* [cap] each */ };
+void launch_isl_adjacency(const PG&, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, const uint32_t* handles, uint32_t n_handles, uint32_t n_bodies, uint32_t seq_bits, uint32_t rank_bits,
                           uint32_t pad_key2, const IslAdj&, uint32_t* hist, uint32_t* block_sums, uint32_t* off, uint32_t* adj, hipStream_t);
 // an op batch from a LIST instead of from the rows' status changes (SleepIslands / WakeIslands: pops and pushes in the island manager's order):
 // fills the same op arrays as k_pg_classify for ops (cids[k], kinds[k] = 1 push | 2 pop); the rest of the pipeline is the status loop's
@@ -288,6 +288,8 @@ template <class T> struct SleepParams {
 template <class T> void launch_islands_validate(const DW<T>&, const uint32_t* label, uint32_t* invalid, hipStream_t, uint32_t solver_nodes);   // last step's labels against this step's edges
 template <class T> void launch_islands(const DW<T>&, uint32_t* parent, uint32_t* label, uint32_t* ctr /* [0] islands, [1] island bodies */, hipStream_t,
                                        uint32_t solver_nodes = 0u /* 1: only bodies with a SolverBody connect (island-block builder) */);
+// components over the contact-table rows that hold constraint handles (+ joints): labels as launch_islands writes them
+template <class T> void launch_islands_rows(const DW<T>&, const int2* row_bodies, const uint32_t* row_color, const uint32_t* handles, uint32_t n_handles, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t);
 template <class T> void launch_sleep_update(const DW<T>&, const SleepParams<T>&, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes,
                                             uint32_t* ctr /* [2] resting islands, [3] resting bodies, [4] waking islands, [5] their sleeping bodies, [6] sleeping bodies */, hipStream_t);
 // update_sleeping_states, body half, for the closed loop with persistent islands: timer[b] updated, flags[b] = 1 took part | 2 SleepingDisabled | 4 owns a SolverBody

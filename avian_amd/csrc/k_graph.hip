@@ -1024,60 +1024,55 @@ template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23
 // concatenation of RigidBodyColliders, direction, descending stamp) -- two stable radix sorts -- and the host's walk reads 4 bytes per edge it follows.
 // Entries whose other body owns no island node (static ground) are dropped: the walk only tests them and moves on.
 __device__ __forceinline__ bool pg_island_node(uint32_t bmeta) { return meta_rb_type(bmeta) != AVN_RB_STATIC && !(meta_flags(bmeta) & AVN_BODY_DISABLED); }
+// one lane per constraint handle (the concatenated handle list the solver gathers through: exactly the rows that hold a colour): entries 2 m and 2 m + 1, no
+// compaction -- a side whose other body owns no node gets the padding key and sorts behind every real entry.  (A first version scanned the 1.2 M rows and appended
+// through one wave-aggregated counter: 226 us of same-address atomics next to the solver.)
 __global__ __launch_bounds__(256) void k_adj_entries(PG pg, const uint4* __restrict__ ct_meta, const uint32_t* __restrict__ bmeta, const uint32_t* __restrict__ slot_rank,
-                                                     uint32_t n_rows, uint32_t n_bodies, uint32_t seq_mask, IslAdj a) {
-    const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+                                                     const uint32_t* __restrict__ handles, uint32_t n_handles, uint32_t n_bodies, uint32_t seq_mask, uint32_t pad_key2, IslAdj a) {
+    const uint32_t m = blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_handles) return;
+    const uint32_t r = handles[m], e = 2u * m;
     bool take = false;
     int2 b = make_int2(-1, -1);
-    uint4 m = make_uint4(0, 0, 0, 0);
-    if (r < n_rows && pg.color[r] != PG_NONE) {
-        m = ct_meta[r];
+    uint4 mt = make_uint4(0, 0, 0, 0);
+    if (r < pg.rows && pg.color[r] != PG_NONE) {
+        mt = ct_meta[r];
         b = pg.bodies[r];
-        take = (m.z & AVN_CP_ROW_USED) && b.x >= 0 && b.y >= 0 && (uint32_t)b.x < n_bodies && (uint32_t)b.y < n_bodies && pg_island_node(bmeta[b.x]) && pg_island_node(bmeta[b.y]);
+        take = (mt.z & AVN_CP_ROW_USED) && b.x >= 0 && b.y >= 0 && (uint32_t)b.x < n_bodies && (uint32_t)b.y < n_bodies && pg_island_node(bmeta[b.x]) && pg_island_node(bmeta[b.y]);
     }
-    const unsigned long long mask = __ballot(take);
-    if (!mask) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t base = 0;
-    if (lane == (uint32_t)__ffsll((long long)mask) - 1u) base = atomicAdd(a.count, 2u * (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, __ffsll((long long)mask) - 1);
-    if (!take) return;
-    const uint32_t e = base + 2u * (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (e + 1u >= a.cap) return;   // (the host sized the arrays for 2 entries per handle: cannot happen; a.count tells)
-    const uint32_t k1 = (~(uint32_t)pg.seq[r]) & seq_mask;   // descending stamp
-    a.k_a[e] = k1; a.v_a[e] = e; a.e_key2[e] = 2u * slot_rank[m.x]; a.e_other[e] = (uint32_t)b.y; a.e_body[e] = (uint32_t)b.x;                     // outgoing edge of collider1
-    a.k_a[e + 1u] = k1; a.v_a[e + 1u] = e + 1u; a.e_key2[e + 1u] = 2u * slot_rank[m.y] + 1u; a.e_other[e + 1u] = (uint32_t)b.x; a.e_body[e + 1u] = (uint32_t)b.y;   // incoming edge of collider2
-}
-__global__ __launch_bounds__(256) void k_adj_pad(IslAdj a, uint32_t n, uint32_t seq_mask, uint32_t pad_key2) {
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || i < *a.count) return;
-    a.k_a[i] = seq_mask; a.v_a[i] = i; a.e_key2[i] = pad_key2; a.e_other[i] = PG_NONE; a.e_body[i] = PG_NONE;
+    uint32_t k1 = seq_mask, key_out = pad_key2, key_in = pad_key2, body_out = PG_NONE, body_in = PG_NONE;
+    if (take) {
+        k1 = (~(uint32_t)pg.seq[r]) & seq_mask;   // descending stamp
+        key_out = 2u * slot_rank[mt.x]; key_in = 2u * slot_rank[mt.y] + 1u;
+        body_out = (uint32_t)b.x; body_in = (uint32_t)b.y;
+    }
+    a.k_a[e] = k1; a.v_a[e] = e; a.e_key2[e] = key_out; a.e_other[e] = body_in; a.e_body[e] = body_out;                         // outgoing edge of collider1
+    a.k_a[e + 1u] = k1; a.v_a[e + 1u] = e + 1u; a.e_key2[e + 1u] = key_in; a.e_other[e + 1u] = body_out; a.e_body[e + 1u] = body_in;   // incoming edge of collider2
 }
 __global__ __launch_bounds__(256) void k_adj_key2(const uint32_t* __restrict__ v_sorted, const uint32_t* __restrict__ e_key2, uint32_t* __restrict__ k_out, uint32_t n) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) k_out[i] = e_key2[v_sorted[i]];
 }
-// adj[i] = the other body of the i-th entry in walk order; off[b] = the first entry of a body >= b (entries are body-major: the ranks are)
+// adj[i] = the other body of the i-th entry in walk order; off[b] = the first entry of a body >= b (entries are body-major: the ranks are; padding entries carry
+// body 0xFFFFFFFF and sort last, so off[n_bodies] = the number of real entries)
 __global__ __launch_bounds__(256) void k_adj_finish(IslAdj a, const uint32_t* __restrict__ v_sorted, uint32_t n, uint32_t n_bodies, uint32_t* __restrict__ off, uint32_t* __restrict__ adj) {
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    const uint32_t count = min(*a.count, n);
-    if (i < count) adj[i] = a.e_other[v_sorted[i]];
+    if (i < n) adj[i] = a.e_other[v_sorted[i]];
     if (i <= n_bodies) {
-        uint32_t lo = 0, hi = count;
+        uint32_t lo = 0, hi = n;
         while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a.e_body[v_sorted[mid]] < i) lo = mid + 1u; else hi = mid; }
         off[i] = lo;
+        if (i == n_bodies) off[n_bodies + 1u] = lo;   // (the entry count, where the host looks for it)
     }
-    if (i == 0) off[n_bodies + 1u] = *a.count;   // (the host checks it against the capacity)
 }
-// n = 2 x the number of constraint handles (the host knows it: DW::n_manifolds), an upper bound of the entries; `scratch` arrays of IslAdj hold n words each
-void launch_isl_adjacency(const PG& pg, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, uint32_t n_rows, uint32_t n_bodies, uint32_t n, uint32_t seq_bits, uint32_t rank_bits,
+// n = 2 x the number of constraint handles (DW::n_manifolds; `handles` = the solver's concatenated handle list); the arrays of IslAdj hold n words each
+void launch_isl_adjacency(const PG& pg, const uint4* ct_meta, const uint32_t* bmeta, const uint32_t* slot_rank, const uint32_t* handles, uint32_t n_handles, uint32_t n_bodies, uint32_t seq_bits, uint32_t rank_bits,
                           uint32_t pad_key2, const IslAdj& a, uint32_t* hist, uint32_t* block_sums, uint32_t* off, uint32_t* adj, hipStream_t s) {
-    (void)hipMemsetAsync(a.count, 0, 4, s);
+    const uint32_t n = 2u * n_handles;
     const uint32_t seq_mask = seq_bits >= 32u ? 0xFFFFFFFFu : ((1u << seq_bits) - 1u);
-    if (n_rows && n) hipLaunchKernelGGL(k_adj_entries, dim3((n_rows + 255) / 256), dim3(256), 0, s, pg, ct_meta, bmeta, slot_rank, n_rows, n_bodies, seq_mask, a);
     uint32_t* v = a.v_a;
     if (n) {
-        hipLaunchKernelGGL(k_adj_pad, dim3((n + 255) / 256), dim3(256), 0, s, a, n, seq_mask, pad_key2);
+        hipLaunchKernelGGL(k_adj_entries, dim3((n_handles + 255) / 256), dim3(256), 0, s, pg, ct_meta, bmeta, slot_rank, handles, n_handles, n_bodies, seq_mask, pad_key2, a);
         uint32_t *k1, *v1;
         launch_radix_sort_bits(a.k_a, a.v_a, a.k_b, a.v_b, n, seq_bits, hist, block_sums, &k1, &v1, s);
         uint32_t* k2 = k1 == a.k_a ? a.k_b : a.k_a;          // the free key buffer takes the second key

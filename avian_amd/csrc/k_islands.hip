@@ -9,6 +9,7 @@
 //
 // Sleeping: update_sleeping_states (islands/sleeping.rs:184-241) with the island's awake bit as a store of 1 by any body that is not yet
 // sleepy, and the resting islands / awake body counts by one more pass.
+#include <algorithm>
 #include "avn_kernels.h"
 
 namespace avn {
@@ -56,6 +57,20 @@ __global__ __launch_bounds__(256) void k_cc_edges(DW<T> w, const int2* __restric
     if (e.x < 0 || e.y < 0 || (uint32_t)e.x >= w.n_bodies || (uint32_t)e.y >= w.n_bodies || e.x == e.y) return;
     if (!island_node(w.bmeta[e.x], solver_nodes) || !island_node(w.bmeta[e.y], solver_nodes)) return;
     cc_union(L, (uint32_t)e.x, (uint32_t)e.y);
+}
+// the same union over the contact table's rows that hold constraint handles (PG::color): the edges split_island's walk follows (world/sleeping.hpp, round 6)
+// A FEW workgroups walk the handle list with a grid stride: the launch runs on a side stream next to the solver's latency-bound colour launches and has a
+// millisecond of slack; 4 800 workgroups of compare-and-swaps slowed those launches six-fold while they ran (timeline of round 6).
+template <class T>
+__global__ __launch_bounds__(256) void k_cc_rows(DW<T> w, const int2* __restrict__ row_bodies, const uint32_t* __restrict__ row_color, const uint32_t* __restrict__ handles, uint32_t n_handles, uint32_t* __restrict__ L) {
+    for (uint32_t m = blockIdx.x * 256 + threadIdx.x; m < n_handles; m += gridDim.x * 256) {
+        const uint32_t r = handles[m];
+        if (row_color[r] == 0xFFFFFFFFu) continue;
+        const int2 e = row_bodies[r];
+        if (e.x < 0 || e.y < 0 || (uint32_t)e.x >= w.n_bodies || (uint32_t)e.y >= w.n_bodies || e.x == e.y) continue;
+        if (!island_node(w.bmeta[e.x], 0u) || !island_node(w.bmeta[e.y], 0u)) continue;
+        cc_union(L, (uint32_t)e.x, (uint32_t)e.y);
+    }
 }
 // labels out (lowest body index of the island, PG_NONE for static bodies) + ctr[0] = islands, ctr[1] = island bodies
 template <class T>
@@ -196,6 +211,14 @@ template <class T> void launch_islands(const DW<T>& w, uint32_t* parent, uint32_
     if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent, solver_nodes);
     hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr, solver_nodes);
 }
+template <class T> void launch_islands_rows(const DW<T>& w, const int2* row_bodies, const uint32_t* row_color, const uint32_t* handles, uint32_t n_handles, uint32_t* parent, uint32_t* label, uint32_t* ctr, hipStream_t s) {
+    if (!w.n_bodies) return;
+    const uint32_t nb = (w.n_bodies + 255) / 256;
+    hipLaunchKernelGGL(k_cc_init<T>, dim3(nb), dim3(256), 0, s, w, parent);
+    if (n_handles) hipLaunchKernelGGL(k_cc_rows<T>, dim3(std::min<uint32_t>((n_handles + 255) / 256, 96u)), dim3(256), 0, s, w, row_bodies, row_color, handles, n_handles, parent);
+    if (w.n_joints) hipLaunchKernelGGL(k_cc_edges<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, (const int2*)w.j_bodies, w.n_joints, parent, 0u);
+    hipLaunchKernelGGL(k_cc_finish<T>, dim3(nb), dim3(256), 0, s, w, parent, label, ctr, 0u);
+}
 template <class T> void launch_sleep_update(const DW<T>& w, const SleepParams<T>& sp, const uint32_t* label, float* timer, uint32_t* awake, uint8_t* rests, uint8_t* wakes, uint32_t* ctr, hipStream_t s) {
     if (!w.n_bodies) return;
     const uint32_t nb = (w.n_bodies + 255) / 256;
@@ -210,6 +233,7 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
     template void launch_sleep_timers_flags<T>(const DW<T>&, const SleepParams<T>&, float*, uint8_t*, hipStream_t);   \
     template void launch_bodies_set_sleeping<T>(const DW<T>&, const uint32_t*, uint32_t, uint32_t, float*, hipStream_t); \
     template void launch_islands<T>(const DW<T>&, uint32_t*, uint32_t*, uint32_t*, hipStream_t, uint32_t);            \
+    template void launch_islands_rows<T>(const DW<T>&, const int2*, const uint32_t*, const uint32_t*, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t);   \
     template void launch_islands_validate<T>(const DW<T>&, const uint32_t*, uint32_t*, hipStream_t, uint32_t);       \
     template void launch_sleep_update<T>(const DW<T>&, const SleepParams<T>&, const uint32_t*, float*, uint32_t*, uint8_t*, uint8_t*, uint32_t*, hipStream_t);
 INST(float)

@@ -100,7 +100,7 @@
         HIPCHK(hipMemset(pg.color, 0xFF, (size_t)pg_rows * 4));
         contact_keys_live = false; h_live_keys.clear();   // (the pair set keeps the keys the host announced: existing pairs stay existing)
         pgm_head = pgm_n_free = pgm_next_id = pgm_live = pgm_tomb = 0;
-        slp_on = false; isl = IslandManager();   // (avn_sleeping_enable follows avn_pipeline_enable)
+        slp_on = false; isl.reset();   // (avn_sleeping_enable follows avn_pipeline_enable)
         std::memset(&pipe_stats, 0, sizeof pipe_stats);
         std::memset(pipe_offsets, 0, sizeof pipe_offsets);
         uint32_t zero[AVN_GRAPH_COLOR_COUNT + 1] = {0};
@@ -519,7 +519,8 @@
         const bool slp_defer = slp_on && slp_fast_step && !(island_candidate(dw.n_manifolds) && dw.n_joints == 0);
         if (slp_on && !slp_fast_step && (st = sleeping_after_status_loop(total, n_ops, host_ms)) != AVN_OK) return st;   // islands: new pairs, the loop's link / unlink, WakeIslands
         if (slp_on && slp_fast_step && !slp_defer && (st = sleeping_digest_deferred(total, n_ops, host_ms)) != AVN_OK) return st;
-        if (slp_on && isl.has_candidate() && (st = sleeping_adjacency_launch()) != AVN_OK) return st;                   // split_island's neighbour lists, next to the solver
+        // (a small candidate is walked over the manager's own edge lists in microseconds; the device lists cost ~20 launches and a hand-over)
+        if (slp_on && isl.candidate_bodies() >= slp_adj_min_bodies && (st = sleeping_adjacency_launch()) != AVN_OK) return st;   // split_island's neighbour lists, next to the solver
         pipe_stats.last_overflow_manifolds = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - color_offsets[AVN_COLOR_OVERFLOW_INDEX];
         lap();
         pipe_stats.last_host_ms = host_ms;

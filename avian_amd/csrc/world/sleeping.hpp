@@ -39,16 +39,20 @@
     // (launch_isl_adjacency, k_graph.hip) when a split candidate exists at the step's start: the host's walk then reads a 4-byte CSR instead of its edge lists.
     bool slp_fast_step = false;
     bool slp_adj_enabled = !avn_env("AVN_SLP_HOST_SPLIT"), slp_fast_enabled = !avn_env("AVN_SLP_NO_FAST");   // (A/B switches of `make measure` builds)
-    DevBuf b_adj_cnt, b_adj_key2, b_adj_other, b_adj_body, b_adj_ka, b_adj_va, b_adj_kb, b_adj_vb, b_adj_off, b_adj_out, b_adj_rank, b_adj_hist, b_adj_sums;
-    Pinned pin_adj;
+    DevBuf b_adj_parent, b_adj_label, b_adj_ccctr;
+    bool slp_async_enabled = !avn_env("AVN_SLP_SYNC_SPLIT");
+    size_t slp_adj_min_bodies = avn_env("AVN_SLP_ADJ_MIN") ? (size_t)std::atol(avn_env("AVN_SLP_ADJ_MIN")) : 2048;   // candidate islands below this are split from the manager's own lists
+    DevBuf b_adj_key2, b_adj_other, b_adj_body, b_adj_ka, b_adj_va, b_adj_kb, b_adj_vb, b_adj_off, b_adj_out, b_adj_rank, b_adj_hist, b_adj_sums;
+    Pinned pin_adj2[2];   // double-buffered: a worker thread may still walk the previous build's lists
+    uint32_t adj_flip = 0, adj_used = 0;
     hipEvent_t ev_adj = nullptr, ev_adj_go = nullptr;
     uint64_t adj_rank_epoch = 0;
     uint32_t adj_rank_slots = 0, adj_n = 0, adj_bodies = 0;
     bool adj_pending = false;
-    std::vector<uint32_t> adj_rank_host, adj_host;
+    std::vector<uint32_t> adj_rank_host;
     avn_status sleeping_adjacency_launch() {
         adj_pending = false;
-        const uint32_t N = dw.n_bodies, n_rows = pgm_next_id, n_slots = (uint32_t)slot_entity.size(), n = 2u * dw.n_manifolds;
+        const uint32_t N = dw.n_bodies, n_slots = (uint32_t)slot_entity.size(), n = 2u * dw.n_manifolds;
         if (!slp_adj_enabled || !N || pipe_stats.pairs_added >= (1ull << 32) || n_slots >= (1u << 30) || dw.n_manifolds >= (1u << 30)) return AVN_OK;   // (the manager's own edge lists serve)
         hipError_t err = hipSuccess;
         if (adj_rank_epoch != isl.collider_epoch() || adj_rank_slots != n_slots) {
@@ -71,24 +75,37 @@
             if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
             HIPCHK(hipMemset(b_adj_sums.p, 0, b_adj_sums.cap));   // (the one-launch scan's state: zero once, self-cleaning afterwards)
         }
-        b_adj_cnt.ensure(64, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
         b_adj_off.ensure(((size_t)N + 2) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
-        if (pin_adj.ensure(((size_t)N + 2 + n) * 4 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        b_adj_parent.ensure((size_t)N * 4, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+        b_adj_label.ensure((size_t)N * 4, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+        b_adj_ccctr.ensure(64, err); if (err != hipSuccess) { error = "hipMalloc failed (island adjacency)"; return AVN_ERR_OOM; }
+        if (pin_adj2[adj_flip].cap < ((size_t)2 * N + 2 + n) * 4 + 64) {
+            avn_status js = isl.split_join();   // (growing frees the old block)
+            if (js != AVN_OK) return slp_fail(js);
+            if (pin_adj2[adj_flip].ensure(((size_t)2 * N + 2 + n) * 4 + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        }
+        adj_used = adj_flip;
         if (!ev_adj) { HIPCHK(hipEventCreateWithFlags(&ev_adj, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ev_adj_go, hipEventDisableTiming | EV_FLAGS)); }
         // behind every op batch of this step (the rows' colours are the constraint handles the walk follows), next to the solver
         HIPCHK(hipEventRecord(ev_adj_go, stream));
         HIPCHK(hipStreamWaitEvent(stream_bp, ev_adj_go, 0));
-        IslAdj a{b_adj_cnt.as<uint32_t>(), (uint32_t)(b_adj_ka.cap / 4), b_adj_key2.as<uint32_t>(), b_adj_other.as<uint32_t>(), b_adj_body.as<uint32_t>(),
+        IslAdj a{(uint32_t)(b_adj_ka.cap / 4), b_adj_key2.as<uint32_t>(), b_adj_other.as<uint32_t>(), b_adj_body.as<uint32_t>(),
                  b_adj_ka.as<uint32_t>(), b_adj_va.as<uint32_t>(), b_adj_kb.as<uint32_t>(), b_adj_vb.as<uint32_t>()};
         const uint32_t pad = 2u * n_slots;
-        launch_isl_adjacency(pg, ct.meta, dw.bmeta, b_adj_rank.as<uint32_t>(), n_rows, N, n, std::max(1u, bits_for((uint32_t)pipe_stats.pairs_added)), bits_for(pad), pad, a,
+        launch_isl_adjacency(pg, ct.meta, dw.bmeta, b_adj_rank.as<uint32_t>(), b_handles.as<uint32_t>(), dw.n_manifolds, N, std::max(1u, bits_for((uint32_t)pipe_stats.pairs_added)), bits_for(pad), pad, a,
                              b_adj_hist.as<uint32_t>(), b_adj_sums.as<uint32_t>(), b_adj_off.as<uint32_t>(), b_adj_out.as<uint32_t>(), stream_bp);
         HIPCHK(hipGetLastError());
-        uint32_t* h = (uint32_t*)pin_adj.p;
+        uint32_t* h = (uint32_t*)pin_adj2[adj_used].p;
         HIPCHK(hipMemcpyAsync(h, b_adj_off.p, ((size_t)N + 2) * 4, hipMemcpyDeviceToHost, stream_bp));
         if (n) HIPCHK(hipMemcpyAsync(h + N + 2, b_adj_out.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream_bp));
+        // the components of the same edges (+ joints), 4 bytes per body: with them the split's bookkeeping (pieces, keys, sizes) needs no walk, and the walk -- the order
+        // inside the pieces' body lists -- leaves the step's critical path for a worker thread (IslandManager::split_candidate_labelled_async)
+        HIPCHK(hipMemsetAsync(b_adj_ccctr.p, 0, 64, stream_bp));
+        launch_islands_rows<T>(dw, pg.bodies, pg.color, b_handles.as<uint32_t>(), dw.n_manifolds, b_adj_parent.as<uint32_t>(), b_adj_label.as<uint32_t>(), b_adj_ccctr.as<uint32_t>(), stream_bp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h + N + 2 + n, b_adj_label.p, (size_t)N * 4, hipMemcpyDeviceToHost, stream_bp));
         HIPCHK(hipEventRecord(ev_adj, stream_bp));
-        launches += 6;
+        launches += 10;
         adj_pending = true; adj_n = n; adj_bodies = N;
         return AVN_OK;
     }
@@ -98,16 +115,48 @@
         adj_pending = false;
         if (!isl.split_pending()) return AVN_OK;   // (the candidate merged away or has nothing to split: the CSR stays unread)
         HIPCHK(spin_event(ev_adj));
-        const uint32_t* h = (const uint32_t*)pin_adj.p;
+        const uint32_t* h = (const uint32_t*)pin_adj2[adj_used].p;
         if (h[adj_bodies + 1] > adj_n) { error = "island adjacency: more entries than 2 x constraint handles"; return AVN_ERR_STATE; }
-        // (out of the DMA target into ordinary memory in one streaming pass: the walk reads it in graph order, a miss per body otherwise)
-        const size_t words = (size_t)adj_bodies + 2 + h[adj_bodies + 1];
-        adj_host.resize(words);
-        std::memcpy(adj_host.data(), h, words * 4);
-        const avn_status st = isl.split_candidate_adjacency(adj_host.data(), adj_host.data() + adj_bodies + 2, adj_bodies);
+        avn_status st = isl.split_join();   // (the previous walk, if it still runs, reads the other staging buffer)
+        if (st != AVN_OK) return slp_fail(st);
+        const uint32_t* lab = h + adj_bodies + 2 + adj_n;
+        if (avn_env("AVN_SLP_CHECK_ADJ")) {   // (`make measure` builds: the device's lists against the manager's own)
+            const std::string w = isl.check_adjacency(h, h + adj_bodies + 2, adj_bodies);
+            if (!w.empty()) {
+                std::fprintf(stderr, "[avn slp] step %u: adjacency mismatch (entries %u of %u): %s\n", pipe_step_no, h[adj_bodies + 1], adj_n, w.c_str());
+                HIPCHK(hipDeviceSynchronize());
+                const uint32_t M = adj_n / 2, R = pgm_next_id;
+                std::vector<uint32_t> hd(M), col(R), eb(adj_n), vs(adj_n), k2(adj_n);
+                HIPCHK(hipMemcpy(hd.data(), b_handles.p, (size_t)M * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(col.data(), pg.color, (size_t)R * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(eb.data(), b_adj_body.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(k2.data(), b_adj_key2.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
+                uint32_t coloured = 0, bad = 0, dup = 0; std::vector<uint8_t> seen(R, 0);
+                for (uint32_t r = 0; r < R; ++r) coloured += col[r] != 0xFFFFFFFFu;
+                for (uint32_t m = 0; m < M; ++m) { if (hd[m] >= R || col[hd[m]] == 0xFFFFFFFFu) ++bad; else if (seen[hd[m]]++) ++dup; }
+                uint32_t b2 = 0; for (uint32_t e = 0; e < adj_n; ++e) b2 += eb[e] == 2u;
+                std::fprintf(stderr, "[avn slp]   handles %u, rows with a colour %u, handles naming an uncoloured row %u, duplicates %u; entries with body 2: %u; dw.n_manifolds now %u\n", M, coloured, bad, dup, b2, dw.n_manifolds);
+                for (uint32_t e = 0; e < adj_n && e < 2000000; ++e) if (eb[e] == 2u) std::fprintf(stderr, " e%u key2 %u;", e, k2[e]);
+                std::fprintf(stderr, "\n off[0..6]: %u %u %u %u %u %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
+                { uint32_t np = 0; for (uint32_t e = 0; e < adj_n; ++e) if (eb[e] == 0xFFFFFFFFu) { if (np < 8) std::fprintf(stderr, " pad e%u key2 %u;", e, k2[e]); ++np; } std::fprintf(stderr, " pads %u\n", np); }
+                {
+                    const uint32_t sb = std::max(1u, bits_for((uint32_t)pipe_stats.pairs_added)), rb = bits_for(2u * (uint32_t)slot_entity.size());
+                    const uint32_t p1 = (sb + 7) / 8, p2 = (rb + 7) / 8;
+                    std::vector<uint32_t> va(adj_n), vb(adj_n);
+                    HIPCHK(hipMemcpy(va.data(), b_adj_va.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(vb.data(), b_adj_vb.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
+                    const bool v1_is_b = p1 & 1u; const bool v3_is_v1 = !(p2 & 1u);
+                    const std::vector<uint32_t>& v3 = (v1_is_b == v3_is_v1) ? vb : va;
+                    std::fprintf(stderr, " seq bits %u (%u passes), rank bits %u (%u passes); first entries in final order (key2:body):", sb, p1, rb, p2);
+                    for (uint32_t i = 0; i < 24 && i < adj_n; ++i) std::fprintf(stderr, " %u:%u", v3[i] < adj_n ? k2[v3[i]] : 99999999u, v3[i] < adj_n ? eb[v3[i]] : 99999999u);
+                    std::fprintf(stderr, "\n");
+                }
+            }
+        }
+        if (slp_async_enabled) { st = isl.split_candidate_labelled_async(h, h + adj_bodies + 2, adj_bodies, lab); adj_flip ^= 1u; }   // (the walk reads this staging buffer: the next build fills the other)
+        else st = isl.split_candidate_adjacency(h, h + adj_bodies + 2, adj_bodies);
         return st == AVN_OK ? st : slp_fail(st);
     }
-
     float slp_lin_default = 0.0f, slp_ang_default = 0.0f;   // the world-level SleepThreshold: what a body spawned after avn_sleeping_enable gets in the per-body arrays
     uint32_t slp_bodies = 0;                                 // bodies the per-body arrays (timer, flags, thresholds, SleepingDisabled) cover
     // bodies spawned inside the loop: SleepTimer 0 (the component's default, sleeping.rs:96-110), the world's thresholds, not SleepingDisabled
@@ -153,7 +202,7 @@
             for (uint32_t b = 0; b < dw.n_bodies; ++b)
                 if (isl.body_has_node(b) && isl.body_sleeps(b)) { avn_status st = isl.wake_body(b); if (st != AVN_OK) return slp_fail(st); if ((st = sleeping_apply_result(false, ms)) != AVN_OK) return st; }
             slp_on = false;
-            isl = IslandManager();
+            isl.reset();
             return AVN_OK;
         }
         if (p->struct_size != sizeof(avn_sleep_params)) { error = "sleeping_enable: bad params"; return AVN_ERR_BAD_ARG; }
@@ -162,7 +211,7 @@
         const uint32_t n = dw.n_bodies;
         if (h_rb_type.size() != n) { error = "sleeping_enable: upload bodies first"; return AVN_ERR_STATE; }
         avn_status st;
-        isl = IslandManager();
+        isl.reset();
         for (uint32_t b = 0; b < n; ++b) if (slp_node(b) && (st = isl.body_add(b)) != AVN_OK) return slp_fail(st);
         for (uint32_t s = 0; s < slot_entity.size(); ++s) {
             const uint32_t b = (uint32_t)h_col_body[s];

@@ -347,37 +347,49 @@ def main():
             keep.clear()
         except NameError:
             pass
-        wc = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
-        wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
-        wc.existing_pairs_upload(np.zeros(0, np.uint64))
-        wc.collider_materials_upload(friction=sc.friction, restitution=sc.restitution)
-        wc.pipeline_enable()    # ContactGraph / IdPool / ConstraintGraph bookkeeping on the device (k_graph.hip)
+        def closed_windows(sleeping):
+            wc = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
+            wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
+            wc.existing_pairs_upload(np.zeros(0, np.uint64))
+            wc.collider_materials_upload(friction=sc.friction, restitution=sc.restitution)
+            wc.pipeline_enable()    # ContactGraph / IdPool / ConstraintGraph bookkeeping on the device (k_graph.hip)
+            if sleeping:
+                wc.sleeping_enable()   # Avian's default: IslandPlugin + IslandSleepingPlugin are in SolverPlugins (dynamics/solver/mod.rs:61-84)
 
-        def window(n):
-            wc.synchronize()
-            c0 = time.perf_counter()
-            host = ch = byt = 0.0; ovf = 0
-            for _ in range(n):
+            def window(n):
+                wc.synchronize()
+                c0 = time.perf_counter()
+                host = ch = byt = 0.0; ovf = 0; isl_host = awake = 0.0
+                for _ in range(n):
+                    wc.step()
+                    wc.synchronize()   # (a frame: the host reads the step's results before it starts the next one; back-to-back avn_step calls measure 2 % slower)
+                    ps = wc.pipeline_stats(); host += ps.last_host_ms; ch += ps.last_status_changes; ovf = max(ovf, ps.last_overflow_manifolds)
+                    byt += substeps * (228 * (sc.n - 1) + 1520 * ps.manifolds)     # SURVEY.md §8(d) with P = 4 (an upper bound: piles hold 1-4 points)
+                    if sleeping:
+                        st = wc.sleeping_stats(); isl_host += st.last_host_ms; awake += st.n_awake_bodies
+                wc.synchronize()
+                ms = (time.perf_counter() - c0) / n * 1e3
+                ps = wc.pipeline_stats()
+                out = {"ms_per_step": round(ms, 3), "substeps_per_s": round(substeps / (ms / 1e3), 2), "host_bookkeeping_ms": round(host / n, 3),
+                       "status_changes_per_step": round(ch / n, 1), "manifolds_at_end": ps.manifolds, "max_overflow_manifolds": int(ovf),
+                       "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(byt / n / (ms / 1e3) / 1e9, 2),
+                                    "frac": round(byt / n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                                    "note": "whole closed-loop step: solver bytes of SURVEY.md §8(d) at P = 4 (upper bound) / wall time; the narrow phase's and the bookkeeping's own bytes are not counted"}}
+                if sleeping:
+                    st = wc.sleeping_stats()
+                    out.update(island_manager_host_ms=round(isl_host / n, 3), mean_awake_bodies=round(awake / n, 1), islands_at_end=int(st.islands.n_islands), splits_total=int(st.islands.splits))
+                return out
+            for _ in range(4):
                 wc.step()
-                wc.synchronize()   # (a frame: the host reads the step's results before it starts the next one; back-to-back avn_step calls measure 2 % slower)
-                ps = wc.pipeline_stats(); host += ps.last_host_ms; ch += ps.last_status_changes; ovf = max(ovf, ps.last_overflow_manifolds)
-                byt += substeps * (228 * (sc.n - 1) + 1520 * ps.manifolds)     # SURVEY.md §8(d) with P = 4 (an upper bound: piles hold 1-4 points)
-            wc.synchronize()
-            ms = (time.perf_counter() - c0) / n * 1e3
+            transient = window(20)   # steps 4..23: the pile is still compacting (~2e5 status changes per step, an overflow colour 10^5 strong and hundreds of levels deep)
+            settled = window(20)     # steps 24..43
+            for _ in range(56):
+                wc.step()
+            steady = window(20)      # steps 100..119: the pile has stopped compacting (2-3e4 status changes per step, a few hundred overflow manifolds)
             ps = wc.pipeline_stats()
-            return {"ms_per_step": round(ms, 3), "substeps_per_s": round(substeps / (ms / 1e3), 2), "host_bookkeeping_ms": round(host / n, 3),
-                    "status_changes_per_step": round(ch / n, 1), "manifolds_at_end": ps.manifolds, "max_overflow_manifolds": int(ovf),
-                    "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "achieved": round(byt / n / (ms / 1e3) / 1e9, 2),
-                                 "frac": round(byt / n / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
-                                 "note": "whole closed-loop step: solver bytes of SURVEY.md §8(d) at P = 4 (upper bound) / wall time; the narrow phase's and the bookkeeping's own bytes are not counted"}}
-        for _ in range(4):
-            wc.step()
-        transient = window(20)   # steps 4..23: the pile is still compacting (~2e5 status changes per step, an overflow colour 10^5 strong and hundreds of levels deep)
-        settled = window(20)     # steps 24..43
-        for _ in range(56):
-            wc.step()
-        steady = window(20)      # steps 100..119: the pile has stopped compacting (2-3e4 status changes per step, a few hundred overflow manifolds)
-        ps = wc.pipeline_stats()
+            wc.close()
+            return transient, settled, steady, ps
+        transient, settled, steady, ps = closed_windows(False)
         # headline of the leg = the steady window (the sustained rate); the two earlier windows are the transient of the initial condition
         # (a perfect lattice of 100 000 touching boxes that collapses into a pile) and are reported next to it
         closed = {"ms_per_step": steady["ms_per_step"], "substeps_per_s": steady["substeps_per_s"], "host_bookkeeping_ms": steady["host_bookkeeping_ms"],
@@ -385,7 +397,16 @@ def main():
                   "steady_steps_100_119": steady, "steps_24_43": settled, "transient_steps_4_23": transient,
                   "note": "avn_pipeline_enable(1): broad phase -> Ball/Cuboid narrow phase (parry part parity-unpinned) -> status-change loop, greedy colouring, handle lists "
                           "and the overflow colour's order ALL on the device; per step the host reads three counter blocks"}
-        del wc
+        # the same three windows with avn_sleeping_enable (round 6): persistent islands, the deferred split every other settled step, the Sleeping set at the end of
+        # every step.  Nothing of cfg2's pile falls asleep inside these windows -- the figure is what sleeping COSTS a pile that is still awake.
+        try:
+            t2, s2, st2, _ = closed_windows(True)
+            closed["sleeping_enabled"] = {"steady_steps_100_119": st2, "steps_24_43": s2, "transient_steps_4_23": t2,
+                                          "settled_ratio_to_sleeping_off": round(st2["ms_per_step"] / steady["ms_per_step"], 3),
+                                          "note": "avn_sleeping_enable on the same bodies: the island manager (host C++) digests the step's pairs and status changes UNDER the solver's kernels when no "
+                                                  "change names a Sleeping body; split_island's walk reads a device-built CSR and, for an island that is still one piece, runs on a worker thread"}
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the line down
+            closed["sleeping_enabled"] = {"status": "error: " + str(e)[:300]}
         # measured HBM-side traffic of the settled closed-loop step next to the algorithmic bytes: two rocprofv3 --pmc passes of
         # tools/time_closed_loop.py (FETCH_SIZE, WRITE_SIZE separately, kernel-trace only), per-kernel means over the last 10 of 120 steps
         if not args.no_traffic:

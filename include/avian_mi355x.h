@@ -807,8 +807,15 @@ AVN_API avn_status AVN_FN(islands_split_candidate)(avn_island_manager* m);
  * colliders in RigidBodyColliders order; per collider the outgoing edges newest first, then the incoming edges newest first
  * (data_structures/stable_graph.rs:640-675).  off has n_bodies + 1 entries.  Joints are walked from the manager's own JointGraph.  The result equals
  * avn_islands_split_candidate's; the oracle's implementation checks the CSR rows of the candidate's bodies against its own edge lists first and returns
- * AVN_ERR_STATE when they disagree. */
-AVN_API avn_status AVN_FN(islands_split_candidate_adjacency)(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n_bodies);
+ * AVN_ERR_STATE when they disagree.
+ * `labels` (may be NULL) [n_bodies]: a component id per body (a body index of the component) over exactly those edges plus the joints, 0xFFFFFFFF for a body
+ * without a node (the closed loop labels them on the device).  With labels the split's bookkeeping is known without the walk -- the pieces are the labels, a piece
+ * takes its slab key when the old body list first names one of its bodies (the walk starts its pieces in that order), sizes are counts, constraints_removed and the
+ * timers restart at 0 -- and only the ORDER inside the pieces' body lists is outstanding: the walk then runs on a worker thread, `off` / `adj` must stay valid and
+ * unchanged until avn_islands_split_join (or the next call that needs such an order: the Sleeping set putting one of the pieces to sleep, a merge of a piece INTO
+ * another island, the next split, despawn, avn_islands_state -- they join themselves), and the call returns at once.  The result is the same either way. */
+AVN_API avn_status AVN_FN(islands_split_candidate_adjacency)(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n_bodies, const uint32_t* labels);
+AVN_API avn_status AVN_FN(islands_split_join)(avn_island_manager* m);
 /* The Sleeping set after the solver.  `sleep_timer` [n_bodies]: the SleepTimers AFTER update_sleeping_states' increment / reset (the caller
  * owns that arithmetic: it reads SolverBody velocities); `flags` [n_bodies]: bit 0 = the body took part in update_sleeping_states (has a
  * SolverBody, not Sleeping, not SleepingDisabled), bit 1 = SleepingDisabled (wake_islands_with_sleeping_disabled).  Runs the island side of

@@ -308,7 +308,9 @@ avn_status avo_islands_pair_add(avn_island_manager* m, uint32_t id, uint32_t c1,
 avn_status avo_islands_status_change(avn_island_manager* m, uint32_t id, uint32_t flags, uint32_t mc) { return m ? m->m.status_change(id, flags, mc) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_flush_wake(avn_island_manager* m) { return m ? m->m.flush_wake() : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_split_candidate(avn_island_manager* m) { return m ? m->m.split_candidate_now() : AVN_ERR_BAD_ARG; }
-avn_status avo_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n) { return m ? m->m.split_candidate_adjacency(off, adj, n) : AVN_ERR_BAD_ARG; }
+// (the oracle has no worker thread: `labels` only ever allow a shortcut, the checked serial walk is always right)
+avn_status avo_islands_split_candidate_adjacency(avn_island_manager* m, const uint32_t* off, const uint32_t* adj, uint32_t n, const uint32_t*) { return m ? m->m.split_candidate_adjacency(off, adj, n) : AVN_ERR_BAD_ARG; }
+avn_status avo_islands_split_join(avn_island_manager* m) { return m ? AVN_OK : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_sleeping_systems(avn_island_manager* m, const float* t, const uint8_t* f, uint32_t n, float tts) { return m ? m->m.sleeping_systems(t, f, n, tts) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_wake_body(avn_island_manager* m, uint32_t body) { return m ? m->m.wake_body(body) : AVN_ERR_BAD_ARG; }
 avn_status avo_islands_sleep_body(avn_island_manager* m, uint32_t body) { return m ? m->m.sleep_body(body) : AVN_ERR_BAD_ARG; }

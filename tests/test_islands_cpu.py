@@ -77,6 +77,24 @@ def walk_adjacency(live, col_body, n_bodies, has_node):
     return off, adj
 
 
+def component_labels(off, adj, joints, n_bodies, has_node):
+    """a component id per body (the lowest body index of its component) over the CSR's edges and the joints; NONE for bodies without a node"""
+    parent = list(range(n_bodies))
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]; x = parent[x]
+        return x
+    for b in range(n_bodies):
+        for o in adj[off[b]:off[b + 1]]:
+            ra, rb = find(b), find(int(o))
+            if ra != rb: parent[max(ra, rb)] = min(ra, rb)
+    for a, b in joints.values():
+        if has_node(a) and has_node(b):
+            ra, rb = find(a), find(b)
+            if ra != rb: parent[max(ra, rb)] = min(ra, rb)
+    return np.array([find(b) if has_node(b) else NONE for b in range(n_bodies)], np.uint32)
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_random_event_streams_keep_both_managers_identical(seed):
     rng = np.random.default_rng(seed)
@@ -86,6 +104,7 @@ def test_random_event_streams_keep_both_managers_identical(seed):
     # before it walks, the product walks the CSR itself (what the closed loop does with the device-built lists); odd seeds use it, even seeds the plain call
     use_adj = seed % 2 == 1
     stamp = 0
+    one_piece_splits = 0
     cols = sorted(col_body)
     # a few joints first (spawn order)
     jointed = set()
@@ -142,8 +161,16 @@ def test_random_event_streams_keep_both_managers_identical(seed):
         same(mo, mh, n_bodies, f"step {step}: after the status loop")
         # --- Finalize: split_island(candidate) ---
         if use_adj:
-            off, adj = walk_adjacency(live, col_body, n_bodies, lambda b: b >= n_static and b not in despawned)
-            for m in (mo, mh): m.split_candidate_adjacency(off, adj)
+            node = lambda b: b >= n_static and b not in despawned
+            off, adj = walk_adjacency(live, col_body, n_bodies, node)
+            # seeds 3, 5: with component labels -- an island that is still one piece gets its new body order from the product's worker thread
+            labels = component_labels(off, adj, joints, n_bodies, node) if seed >= 3 else None
+            cand = mh.stats().split_candidate
+            if labels is not None and cand != NONE:
+                members = labels[mo.state(n_bodies)["island"] == cand]
+                one_piece_splits += int(len(members) > 1 and len(set(members.tolist())) == 1 and mo.state(n_bodies)["removed"][mo.state(n_bodies)["island"] == cand][0] > 0)
+            for m in (mo, mh): m.split_candidate_adjacency(off, adj, labels)
+            if step % 3 == 0: mh.split_join()   # (otherwise whoever needs the order next joins: state(), SleepIslands, a merge, the next split)
         else:
             for m in (mo, mh): m.split_candidate()
         same(mo, mh, n_bodies, f"step {step}: after split_island")
@@ -227,6 +254,7 @@ def test_random_event_streams_keep_both_managers_identical(seed):
     s = mh.stats()
     assert s.merges > 5 and s.splits > 0, "the stream must exercise merges and splits"
     assert n_despawned >= 5 and n_joints_removed >= 3
+    assert seed < 3 or not use_adj or one_piece_splits >= 3, "the worker-thread walk (an island split while it is still one piece) must be exercised"
 
 
 def test_merge_appends_the_smaller_island_and_reuses_the_last_freed_key():

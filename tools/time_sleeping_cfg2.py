@@ -44,7 +44,8 @@ def main():
         for a in range(0, steps, 20):
             b = min(a + 20, steps)
             extra = f", island manager host {host[a:b].mean():.3f} ms, awake {awake[a:b].mean():.0f}" if slp else ""
-            print(f"sleeping={int(slp)} steps {a}..{b - 1}: {ms[a:b].mean():.3f} ms/step (min {ms[a:b].min():.3f}), changes/step {chg[a:b].mean():.0f}{extra}", flush=True)
+            print(f"sleeping={int(slp)} steps {a}..{b - 1}: {ms[a:b].mean():.3f} ms/step (median {np.median(ms[a:b]):.3f}, min {ms[a:b].min():.3f}), changes/step {chg[a:b].mean():.0f}{extra}", flush=True)
+        print(f"sleeping={int(slp)} per step, last 40: " + " ".join(f"{x:.2f}" for x in ms[-40:]), flush=True)
     for a in range(0, steps, 20):
         b = min(a + 20, steps)
         print(f"ratio steps {a}..{b - 1}: {res[True][a:b].mean() / res[False][a:b].mean():.3f}")
