@@ -67,24 +67,30 @@ AVN_API const char* avn_shard_last_error(const avn_shard* s) { return s ? s->err
 AVN_API avn_status avn_shard_phase2(avn_shard* s, const uint32_t* key_collider, const double* key_min_x, size_t n_keys, const avn_shard_pair* pairs, size_t n_pairs) {
     SH_TRY {
         if ((n_keys && (!key_collider || !key_min_x)) || (n_pairs && !pairs)) { s->error = "shard_phase2: null array"; return AVN_ERR_BAD_ARG; }
-        for (size_t i = 0; i < n_keys; ++i) {
+        // Everything is validated on COPIES first; the replicated state (interval order, IdPool, pair table, active list) is only touched once the whole call is
+        // known to go through -- a rank that fails here must not be left half a step ahead of the others.
+        for (size_t i = 0; i < n_keys; ++i)
             if (key_collider[i] >= s->n_colliders) { s->error = "shard_phase2: collider slot out of range"; return AVN_ERR_BAD_ARG; }
-            s->minx[key_collider[i]] = key_min_x[i];
-        }
+        for (size_t i = 0; i < n_pairs; ++i)
+            if (!s->slot_of_entity.count(pairs[i].collider1) || !s->slot_of_entity.count(pairs[i].collider2)) { s->error = "shard_phase2: a pair names an unknown collider"; return AVN_ERR_BAD_ARG; }
+        std::vector<double> minx = s->minx;
+        for (size_t i = 0; i < n_keys; ++i) minx[key_collider[i]] = key_min_x[i];
         // sweep_and_prune's insertion sort (broad_phase.rs:373-387, 479-487) is a STABLE sort of last frame's order by this frame's min.x
-        std::stable_sort(s->order.begin(), s->order.end(), [&](uint32_t a, uint32_t b) { return s->minx[a] < s->minx[b]; });
-        for (uint32_t i = 0; i < s->n_colliders; ++i) s->gpos[s->order[i]] = i;
+        std::vector<uint32_t> order = s->order, gpos(s->n_colliders);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return minx[a] < minx[b]; });
+        for (uint32_t i = 0; i < s->n_colliders; ++i) gpos[order[i]] = i;
         s->recs.clear(); s->recs.reserve(n_pairs);
         for (size_t i = 0; i < n_pairs; ++i) {
-            auto a = s->slot_of_entity.find(pairs[i].collider1), b = s->slot_of_entity.find(pairs[i].collider2);
-            if (a == s->slot_of_entity.end() || b == s->slot_of_entity.end()) { s->error = "shard_phase2: a pair names an unknown collider"; return AVN_ERR_BAD_ARG; }
-            s->recs.push_back({s->gpos[a->second], s->gpos[b->second], pairs[i]});
+            const uint32_t p1 = gpos[s->slot_of_entity.find(pairs[i].collider1)->second], p2 = gpos[s->slot_of_entity.find(pairs[i].collider2)->second];
+            if (p1 >= p2) { s->error = "shard_phase2: collider1 must be the earlier interval of a pair"; return AVN_ERR_STATE; }
+            s->recs.push_back({p1, p2, pairs[i]});
         }
         // pairs are emitted i-major over the sorted intervals, j ascending (broad_phase.rs:387-388)
         std::sort(s->recs.begin(), s->recs.end(), [](const avn_shard::Rec& x, const avn_shard::Rec& y) { return x.p1 != y.p1 ? x.p1 < y.p1 : x.p2 < y.p2; });
+        // ---- commit ----
+        s->minx.swap(minx); s->order.swap(order); s->gpos.swap(gpos);
         s->new_ids.clear(); s->new_c1.clear(); s->new_c2.clear(); s->new_flags.clear();
         for (const avn_shard::Rec& r : s->recs) {
-            if (r.p1 >= r.p2) { s->error = "shard_phase2: collider1 must be the earlier interval of a pair"; return AVN_ERR_STATE; }
             uint32_t cid;
             if (!s->free_ids.empty()) { cid = s->free_ids.top(); s->free_ids.pop(); } else cid = s->next_id++;
             if (s->pairs.size() <= cid) s->pairs.resize(std::max<size_t>((size_t)cid + 1, s->pairs.size() + s->pairs.size() / 2));
@@ -95,7 +101,7 @@ AVN_API avn_status avn_shard_phase2(avn_shard* s, const uint32_t* key_collider, 
                 s->active.push_back(cid);
             }
         }
-        s->stats.pairs_added += (uint32_t)n_pairs;
+        s->stats.pairs_added += (uint32_t)std::min<size_t>(n_pairs, 0xFFFFFFFFu);
         s->stats.next_id = s->next_id; s->stats.n_free = (uint32_t)s->free_ids.size();
         return AVN_OK;
     } SH_CATCH

@@ -1133,6 +1133,13 @@ __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow(DW<T> w, Step
 // position / rotation, inertia) is in registers BEFORE the wait instead of being fetched on the dependency chain.  Rank 0 on a body waits
 // for nothing (its predecessor is the previous launch); tags of other launches never match (epochs are unique inside a step, the w lanes
 // restart at zero with every step).  Same order per body as the tickets give: the reference's serial loop (solver/plugin.rs:461-467).
+// WHAT THIS RELIES ON: (1) an aligned 16-byte buffer_store_dwordx4 / buffer_load_dwordx4 with the sc1 bit is SINGLE-COPY ATOMIC at agent scope across
+// the XCDs -- a reader never sees the new tag in .w next to old .x / .y / .z.  The CDNA ISA performs a naturally aligned dwordx4 access as one 16-byte request to
+// one 128-byte line (it is never split across channels), and that is the whole of the guarantee used; nothing orders two DIFFERENT records, which is why every
+// record carries its own tag.  There is no time-out that would catch a torn read: the check is empirical -- tests/test_gpu_overflow_stress.py runs the tag form
+// against the ticket form (which does not depend on it: data stores are drained before the ticket moves) and against the oracle, bit for bit, over repeated
+// collapses with 10^4..10^5 overflow manifolds; tools/stress_ovf.py is the same at cfg2's size.  (2) every kernel of the substep loop passes the w lanes of the
+// velocity records through untouched (k_prepare_solver_bodies zeroes them once per step): the same test fails on the first step if one does not.
 #define OVF_TAG_SHIFT 20
 template <int PASS>
 __global__ __launch_bounds__(CONTACT_THREADS) void k_overflow_flow_tag(DW<float> w, StepParams<float> p, OverflowFlow of, uint32_t epoch) {

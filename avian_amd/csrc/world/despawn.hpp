@@ -24,6 +24,7 @@
         if (!pipe_on || !pipe_dev) { error = "despawn: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
         if (despawn_broken) { error = "despawn: an earlier avn_despawn failed half-way; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
+        pg_new_ids_count = 0; last_timers.pair_count = 0;   // (the last step's new-pair ids may name rows that leave now: avn_pipeline_new_pair_ids_get reports an empty list until the next step)
         const avn_status ds = despawn_body(d);
         if (ds != AVN_OK && despawn_mutating) despawn_broken = true;
         despawn_mutating = false;

@@ -34,7 +34,7 @@
         if (despawn_needs_joints) {   // (avn_despawn took joints out: exactly the remaining set comes back, bodies in the new numbering)
             if (J != despawn_expected_joints) { error = "joints_upload: after avn_despawn exactly the remaining joints must be uploaded"; return AVN_ERR_STATE; }
             if (despawn_needs_bodies) { error = "joints_upload: after avn_despawn the remaining bodies are uploaded first"; return AVN_ERR_STATE; }
-            despawn_needs_joints = false;
+            // (the debt is cleared at the successful END of this call: a validation, allocation or copy that fails below must leave avn_step blocked -- ADVICE r5)
         }
         if (slp_on) {
             // the island manager links joints when they are added (PhysicsIslands::add_joint, islands/mod.rs:668-735) and has no way to take one
@@ -90,10 +90,12 @@
         if (st != AVN_OK) return st;
         joint_schedule_dirty = true;
         HIPCHK(hipStreamSynchronize(stream));
+        despawn_needs_joints = false;
         return AVN_OK;
     }
     avn_status joints_download(const avn_joints_out* o) override {
         if (!o) return AVN_ERR_BAD_ARG;
+        if (despawn_needs_joints) { error = "joints_download: avn_despawn removed joints: upload the remaining joints (avn_joints_upload) first"; return AVN_ERR_STATE; }
         size_t J = dw.n_joints;
         avn_status st = stage_reserve(al(sizeof(T) * 3 * J) * 7 + 1024);
         if (st != AVN_OK) return st;

@@ -100,6 +100,7 @@
         HIPCHK(hipMemset(pg.color, 0xFF, (size_t)pg_rows * 4));
         contact_keys_live = false; h_live_keys.clear();   // (the pair set keeps the keys the host announced: existing pairs stay existing)
         pgm_head = pgm_n_free = pgm_next_id = pgm_live = pgm_tomb = 0;
+        pg_new_ids_count = 0; last_timers.pair_count = 0;
         slp_on = false; isl.reset();   // (avn_sleeping_enable follows avn_pipeline_enable)
         std::memset(&pipe_stats, 0, sizeof pipe_stats);
         std::memset(pipe_offsets, 0, sizeof pipe_offsets);
@@ -372,7 +373,7 @@
         if (slp_on && slp_world_idle) {   // nothing is awake and the last step proved the state stationary: the step is the identity (world/sleeping.hpp)
             for (hipEvent_t e : ev) HIPCHK(hipEventRecord(e, stream));
             ev_valid = true;
-            pipe_stats.last_status_changes = 0; pipe_stats.last_host_ms = 0; last_timers.pair_count = 0; last_timers.kernel_launches = 0;
+            pipe_stats.last_status_changes = 0; pipe_stats.last_host_ms = 0; last_timers.pair_count = 0; last_timers.kernel_launches = 0; pg_new_ids_count = 0;
             h_pairs.clear();
             slp_n_awake = slp_last_slept = slp_last_woken = slp_last_popped = slp_last_pushed = 0; slp_host_ms = 0;
             ++pipe_step_no; ++pg_dump_step;
@@ -463,6 +464,7 @@
             }
             bp.n_intervals = collect_n - dropped;
             last_timers.pair_count = total;
+            pg_new_ids_count = total;
         }
         if (np_overlap) {
             HIPCHK(hipEventRecord(ev_bp_done, stream_bp));

@@ -73,13 +73,17 @@
     }
     // The ids of the last step's new pairs, in the order of avn_pairs_get (host pipeline: recorded as they are handed out; device: PG::new_ids)
     std::vector<uint32_t> h_new_pair_ids;
+    // (device loop) how many entries of PG::new_ids the LAST COMPLETED closed-loop step wrote: 0 after avn_pipeline_enable, after avn_despawn and after a step that
+    // found no pair -- last_timers.pair_count alone outlives those and named a stale or missing buffer
+    uint32_t pg_new_ids_count = 0;
     avn_status pipeline_new_pair_ids_get(const uint32_t** ids, size_t* n) override {
         if (!ids || !n) return AVN_ERR_BAD_ARG;
         if (!pipe_on) { error = "pipeline_new_pair_ids_get: needs avn_pipeline_enable"; return AVN_ERR_STATE; }
         if (pipe_dev) {
             HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
-            h_new_pair_ids.resize(last_timers.pair_count);
-            if (last_timers.pair_count) HIPCHK(hipMemcpy(h_new_pair_ids.data(), pg.new_ids, (size_t)last_timers.pair_count * 4, hipMemcpyDeviceToHost));
+            const uint32_t cnt = pg.new_ids ? pg_new_ids_count : 0u;
+            h_new_pair_ids.resize(cnt);
+            if (cnt) HIPCHK(hipMemcpy(h_new_pair_ids.data(), pg.new_ids, (size_t)cnt * 4, hipMemcpyDeviceToHost));
         }
         *ids = h_new_pair_ids.data(); *n = h_new_pair_ids.size();
         return AVN_OK;

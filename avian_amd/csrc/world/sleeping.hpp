@@ -123,34 +123,8 @@
         if (avn_env("AVN_SLP_CHECK_ADJ")) {   // (`make measure` builds: the device's lists against the manager's own)
             const std::string w = isl.check_adjacency(h, h + adj_bodies + 2, adj_bodies);
             if (!w.empty()) {
-                std::fprintf(stderr, "[avn slp] step %u: adjacency mismatch (entries %u of %u): %s\n", pipe_step_no, h[adj_bodies + 1], adj_n, w.c_str());
-                HIPCHK(hipDeviceSynchronize());
-                const uint32_t M = adj_n / 2, R = pgm_next_id;
-                std::vector<uint32_t> hd(M), col(R), eb(adj_n), vs(adj_n), k2(adj_n);
-                HIPCHK(hipMemcpy(hd.data(), b_handles.p, (size_t)M * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(col.data(), pg.color, (size_t)R * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(eb.data(), b_adj_body.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
-                HIPCHK(hipMemcpy(k2.data(), b_adj_key2.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
-                uint32_t coloured = 0, bad = 0, dup = 0; std::vector<uint8_t> seen(R, 0);
-                for (uint32_t r = 0; r < R; ++r) coloured += col[r] != 0xFFFFFFFFu;
-                for (uint32_t m = 0; m < M; ++m) { if (hd[m] >= R || col[hd[m]] == 0xFFFFFFFFu) ++bad; else if (seen[hd[m]]++) ++dup; }
-                uint32_t b2 = 0; for (uint32_t e = 0; e < adj_n; ++e) b2 += eb[e] == 2u;
-                std::fprintf(stderr, "[avn slp]   handles %u, rows with a colour %u, handles naming an uncoloured row %u, duplicates %u; entries with body 2: %u; dw.n_manifolds now %u\n", M, coloured, bad, dup, b2, dw.n_manifolds);
-                for (uint32_t e = 0; e < adj_n && e < 2000000; ++e) if (eb[e] == 2u) std::fprintf(stderr, " e%u key2 %u;", e, k2[e]);
-                std::fprintf(stderr, "\n off[0..6]: %u %u %u %u %u %u\n", h[0], h[1], h[2], h[3], h[4], h[5]);
-                { uint32_t np = 0; for (uint32_t e = 0; e < adj_n; ++e) if (eb[e] == 0xFFFFFFFFu) { if (np < 8) std::fprintf(stderr, " pad e%u key2 %u;", e, k2[e]); ++np; } std::fprintf(stderr, " pads %u\n", np); }
-                {
-                    const uint32_t sb = std::max(1u, bits_for((uint32_t)pipe_stats.pairs_added)), rb = bits_for(2u * (uint32_t)slot_entity.size());
-                    const uint32_t p1 = (sb + 7) / 8, p2 = (rb + 7) / 8;
-                    std::vector<uint32_t> va(adj_n), vb(adj_n);
-                    HIPCHK(hipMemcpy(va.data(), b_adj_va.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
-                    HIPCHK(hipMemcpy(vb.data(), b_adj_vb.p, (size_t)adj_n * 4, hipMemcpyDeviceToHost));
-                    const bool v1_is_b = p1 & 1u; const bool v3_is_v1 = !(p2 & 1u);
-                    const std::vector<uint32_t>& v3 = (v1_is_b == v3_is_v1) ? vb : va;
-                    std::fprintf(stderr, " seq bits %u (%u passes), rank bits %u (%u passes); first entries in final order (key2:body):", sb, p1, rb, p2);
-                    for (uint32_t i = 0; i < 24 && i < adj_n; ++i) std::fprintf(stderr, " %u:%u", v3[i] < adj_n ? k2[v3[i]] : 99999999u, v3[i] < adj_n ? eb[v3[i]] : 99999999u);
-                    std::fprintf(stderr, "\n");
-                }
+                error = "sleeping (AVN_SLP_CHECK_ADJ): the device-built adjacency differs from the island manager's edge lists: " + w;
+                return AVN_ERR_STATE;
             }
         }
         if (slp_async_enabled) { st = isl.split_candidate_labelled_async(h, h + adj_bodies + 2, adj_bodies, lab); adj_flip ^= 1u; }   // (the walk reads this staging buffer: the next build fills the other)

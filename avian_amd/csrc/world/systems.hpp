@@ -335,6 +335,8 @@
     avn_status run_system(avn_system sys) override {
         avn_status st = need_bodies();
         if (st != AVN_OK) return st;
+        if (despawn_needs_joints) { error = "run_system: avn_despawn removed joints: upload the remaining joints (avn_joints_upload) first"; return AVN_ERR_STATE; }
+        if (despawn_broken) { error = "run_system: an avn_despawn failed half-way; restart the closed loop"; return AVN_ERR_STATE; }
         if ((st = rebuild_joint_schedules()) != AVN_OK) return st;
         if ((st = rebuild_incidence()) != AVN_OK) return st;
         if (sys != AVN_SYS_SOLVER && (st = flow_begin_standalone()) != AVN_OK) return st;
