@@ -21,6 +21,7 @@ uint32_t IslandManager::island_insert(Island&& isl) {
 }
 void IslandManager::island_remove(uint32_t id) {   // PhysicsIslands::remove_island, islands/mod.rs:441-449
     if (candidate_ == id) candidate_ = NONE;
+    if (islands_[id].used && islands_[id].sleeping) --n_sleeping_islands_;
     islands_[id] = Island();
     vacant_.push_back(id);
     --n_islands_;
@@ -34,6 +35,7 @@ avn_status IslandManager::body_add(uint32_t body) {
     isl.bodies.push_back(body);
     isl_of_[body] = island_insert(std::move(isl));
     node_[body] = 1;
+    ++n_nodes_;
     return AVN_OK;
 }
 avn_status IslandManager::collider_add(uint32_t collider, uint32_t body) {
@@ -79,7 +81,7 @@ uint32_t IslandManager::merge(uint32_t body1, uint32_t body2) {
     for (uint32_t b : S.bodies) isl_of_[b] = big;
     B.bodies.insert(B.bodies.end(), S.bodies.begin(), S.bodies.end());
     B.removed += S.removed;
-    if (S.sleeping) { B.sleeping = true; B.timer = std::max(S.timer, B.timer); }
+    if (S.sleeping) { if (!B.sleeping) ++n_sleeping_islands_; B.sleeping = true; B.timer = std::max(S.timer, B.timer); }
     island_remove(small);
     ++merges_;
     return big;
@@ -203,7 +205,7 @@ void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
         if (id >= islands_.size() || !islands_[id].used) continue;
         Island& isl = islands_[id];
         if (isl.sleeping) return;   // (the reference `return`s out of the whole command here)
-        isl.sleeping = true;
+        isl.sleeping = true; ++n_sleeping_islands_;
         for (uint32_t b : isl.bodies) {
             for (uint32_t col : colliders_of_[b]) {
                 const uint32_t nd = col_node(col);
@@ -219,6 +221,7 @@ void IslandManager::sleep_islands(const std::vector<uint32_t>& ids) {
                 }
             }
             bodies_slept_.push_back(b);
+            if (!asleep_[b]) ++n_sleeping_bodies_;
             asleep_[b] = 1;
         }
     }
@@ -230,7 +233,7 @@ void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
     for (uint32_t id : ids) {
         if (id >= islands_.size() || !islands_[id].used || !islands_[id].sleeping) continue;
         Island& isl = islands_[id];
-        isl.sleeping = false;
+        isl.sleeping = false; --n_sleeping_islands_;
         for (uint32_t b : isl.bodies) {
             for (uint32_t col : colliders_of_[b]) {
                 const uint32_t nd = col_node(col);
@@ -246,6 +249,7 @@ void IslandManager::wake_islands(const std::vector<uint32_t>& ids) {
                 }
             }
             bodies_woken_.push_back(b);
+            if (asleep_[b]) --n_sleeping_bodies_;
             asleep_[b] = 0;
         }
     }
@@ -637,6 +641,7 @@ avn_status IslandManager::body_remove(uint32_t body, bool wake) {
     Island& I = islands_[island];
     I.bodies.erase(std::remove(I.bodies.begin(), I.bodies.end(), body), I.bodies.end());
     if (I.bodies.empty()) island_remove(island);
+    --n_nodes_; if (asleep_[body]) --n_sleeping_bodies_;
     node_[body] = 0; asleep_[body] = 0; isl_of_[body] = NONE;
     if (wake && island < islands_.size() && islands_[island].used) wake_islands({island});
     return AVN_OK;
@@ -682,10 +687,7 @@ avn_status IslandManager::last_result(avn_islands_result* o) const {
 }
 avn_status IslandManager::stats(avn_islands_stats* o) const {
     if (!o) return AVN_ERR_BAD_ARG;
-    uint32_t ns = 0, nb = 0, nsb = 0;
-    for (const Island& i : islands_) if (i.used && i.sleeping) ++ns;
-    for (size_t b = 0; b < node_.size(); ++b) if (node_[b]) { ++nb; if (asleep_[b]) ++nsb; }
-    o->n_islands = n_islands_; o->n_sleeping_islands = ns; o->n_bodies = nb; o->n_sleeping_bodies = nsb;
+    o->n_islands = n_islands_; o->n_sleeping_islands = n_sleeping_islands_; o->n_bodies = n_nodes_; o->n_sleeping_bodies = n_sleeping_bodies_;
     o->merges = merges_; o->splits = splits_; o->split_candidate = candidate_; o->sleeping_pairs = sleeping_pairs_;
     return AVN_OK;
 }

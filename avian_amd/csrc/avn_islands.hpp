@@ -147,6 +147,7 @@ private:
     std::vector<Island> islands_;
     std::vector<uint32_t> vacant_;           // slab: last freed key on top
     uint32_t n_islands_ = 0;
+    uint32_t n_sleeping_islands_ = 0, n_nodes_ = 0, n_sleeping_bodies_ = 0;   // kept as they change: avn_sleeping_stats_get is called every frame and used to walk 10^5 bodies
     uint32_t candidate_ = NONE;
     float candidate_timer_ = 0.0f;
     std::vector<uint8_t> awake_;

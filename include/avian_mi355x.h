@@ -574,7 +574,8 @@ AVN_API avn_status AVN_FN(pipeline_handles_get)(avn_world* w, uint32_t* color_of
 /* The ContactIds the loop gave the LAST step's new pairs (IdPool::alloc_id in emission order), entry i for pair i of avn_pairs_get: what a host that mirrors
  * the ContactGraph keys its own edge list by (Avian's CollisionStart / CollisionEnd / CollidingEntities are rebuilt from these and avn_contact_changes_get:
  * collision/narrow_phase/system_param.rs:141-389).  In the closed loop avn_contact_changes_get returns the status changes of the last step's narrow phase,
- * ascending ContactId; both buffers are owned by the world and valid until the next call on it (call them right after avn_step, before avn_despawn). */
+ * ascending ContactId; both buffers are owned by the world and valid until the next call on it (call them right after avn_step, before avn_despawn).  The id list is
+ * EMPTY after avn_pipeline_enable, after avn_despawn (it may name rows that just left) and after a step that found no new pair: it only ever describes a completed step. */
 AVN_API avn_status AVN_FN(pipeline_new_pair_ids_get)(avn_world* w, const uint32_t** contact_ids, size_t* n);
 
 /* ---- level-2 sharding: ONE contact island split over several worlds (x-slabs), SURVEY.md section 8(e) ---------------------------------

@@ -2460,6 +2460,7 @@ template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
     if (!pipe) { error = "despawn: needs the closed loop (avn_pipeline_enable)"; return AVN_ERR_STATE; }
     if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
     PipelineState& P = *pipe;
+    new_pair_ids.clear();   // (the ABI: after avn_despawn the last step's new-pair ids may name rows that left -- an empty list until the next step; header, avn_pipeline_new_pair_ids_get)
     const size_t n_old = bodies.size();
     std::vector<uint8_t> gone_body(n_old, 0);
     for (uint32_t i = 0; i < d->n_bodies; ++i) {
