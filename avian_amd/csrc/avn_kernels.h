@@ -90,6 +90,10 @@ struct IslandBlocks { const uint32_t *body_off, *bodies, *col_off; const uint2* 
 void launch_island_substeps(const DW<float>&, const StepParams<float>&, const IslandBlocks&, uint32_t substeps, uint32_t iterations, hipStream_t);
 // k_xpbd.hip
 template <class T> void launch_prepare_joints(const DW<T>&, hipStream_t);
+// the same walk with a component's bodies and joints staged in LDS (k_xpbd.hip, round 6): rec.w = local slot of body1 | body2 << 16, comp_bodies[c] = bodies of component c
+// (0xFFFFFFFF: too large, global walk), lds_bytes = the largest staged component
+template <class T> void launch_joint_schedule_lds(const DW<T>&, const StepParams<T>&, uint32_t n_components, const uint32_t* comp_level_begin, const uint32_t* level_offsets, const int4* rec,
+                                                  const uint32_t* comp_bodies, uint32_t lds_bytes, hipStream_t);
 template <class T> void launch_joint_schedule(const DW<T>&, const StepParams<T>&, int op, uint32_t n_components, const uint32_t* comp_level_begin,
                                               const uint32_t* level_offsets, const int4* rec, hipStream_t);
 template <class T> void launch_writeback_joint_forces(const DW<T>&, const StepParams<T>&, hipStream_t);

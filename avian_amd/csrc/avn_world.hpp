@@ -48,7 +48,11 @@ struct JointSchedule {
     uint32_t n_components = 0;
     bool touches_dummy = false;
     DevBuf d_comp_level_begin, d_level_offsets, d_order;
-    DevBuf d_rec;   // joints only: (joint, body1, body2, 0) per schedule slot, so a level needs no index walk through memory (k_xpbd.hip)
+    DevBuf d_rec;   // joints only: (joint, body1, body2, local slots) per schedule slot, so a level needs no index walk through memory (k_xpbd.hip)
+    // the LDS form of the walk (k_joint_schedule_lds): bodies per component (0xFFFFFFFF = global walk), the dynamic LDS the largest staged component needs (0: none staged)
+    std::vector<uint32_t> comp_bodies;
+    DevBuf d_comp_bodies;
+    uint32_t lds_bytes = 0;
     // bodies: per joint the two scheduling keys (body index, or -1 = does not serialise), in joint order
     // levels_only: fill glevel_offsets / gorder only (no components: n_components stays 0)
     void build(const std::vector<uint32_t>& joints, const std::vector<int32_t>& key1, const std::vector<int32_t>& key2, uint32_t n_keys, bool levels_only = false);

@@ -359,6 +359,67 @@ __global__ __launch_bounds__(JOINT_THREADS) void k_joint_schedule(DW<T> w, StepP
     }
 }
 
+// Round 6: the same level walk with the component's records in LDS.  A level of the global form is a dependent trip through memory -- the bodies a level writes are
+// the bodies the next level reads, and on gfx9 a pending store turns every later load wait into vmcnt(0): ~2.2 us per level for ~1 us of arithmetic, 220 us for the
+// 99 levels of cfg3's chains.  Here the workgroup stages everything joint_solve_one touches -- per body SolverBody delta position / rotation, SolverBodyInertia and flags,
+// per joint its fifteen records -- once, walks the levels on LDS with workgroup barriers (the same functions through a DW whose pointers name the LDS copies and whose
+// indices are the component's local ones: rec.w = local slot of body1 | body2 << 16, the joint's local index = its schedule slot), and writes back what the solve changes
+// (delta position / rotation, the three lagrange accumulators) at the end.  Every body and every joint sees the global form's operation sequence: same bits.
+// Components the host found too large for the workgroup's LDS (rec.w = 0xFFFFFFFF) walk the global form.
+#define JL_BODY_RECS 4u     // dp dq si_a si_b (+ one flags word)
+#define JL_JOINT_RECS 15u   // a1 a2 par r1 r2 cd lag rl0 rl1 ax l2 s0 s1 s2 s3
+template <class T>
+__global__ __launch_bounds__(JOINT_THREADS) void k_joint_schedule_lds(DW<T> w, StepParams<T> p, const uint32_t* __restrict__ comp_level_begin, const uint32_t* __restrict__ level_offsets,
+                                                                        const int4* __restrict__ rec, const uint32_t* __restrict__ comp_bodies) {
+    extern __shared__ __align__(16) unsigned char jl_smem[];
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const uint32_t l0 = comp_level_begin[c], l1 = comp_level_begin[c + 1];
+    if (l0 >= l1) return;
+    const uint32_t s0 = level_offsets[l0], s1 = level_offsets[l1];   // the component's schedule slots
+    const uint32_t nj = s1 - s0, nb = comp_bodies[c];
+    if (nb == 0xFFFFFFFFu) {   // too large for LDS: the global walk
+        uint32_t j0 = s0, j1 = level_offsets[l0 + 1];
+        for (uint32_t l = l0; l < l1; ++l) {
+            for (uint32_t k = j0 + t; k < j1; k += JOINT_THREADS) { const int4 r = rec[k]; joint_solve_one<T>(w, p, (uint32_t)r.x, make_int2(r.y, r.z)); }
+            __syncthreads();
+            j0 = j1; if (l + 1 < l1) j1 = level_offsets[l + 2];
+        }
+        return;
+    }
+    Vec4<T>* const lb = reinterpret_cast<Vec4<T>*>(jl_smem);                    // [nb] (dp | dq) pairs, then [nb] (si_a | si_b) pairs
+    Vec4<T>* const lj = lb + (size_t)JL_BODY_RECS * nb;                         // [15][nj]
+    uint32_t* const lf = reinterpret_cast<uint32_t*>(lj + (size_t)JL_JOINT_RECS * nj);   // [nb]
+    DW<T> lw = w;
+    lw.sb_dp.p = lb; lw.sb_dq.p = lb + 1; lw.si_a.p = lb + 2u * nb; lw.si_b.p = lb + 2u * nb + 1; lw.sb_flags = lf;   // (Pair2: field[i] is p[2 i] -- the two records of a pair interleave, as in HBM)
+    lw.j_a1 = lj; lw.j_a2 = lj + nj; lw.j_par = lj + 2u * nj; lw.j_r1 = lj + 3u * nj; lw.j_r2 = lj + 4u * nj; lw.j_cd = lj + 5u * nj; lw.j_lag = lj + 6u * nj;
+    lw.j_rl0 = lj + 7u * nj; lw.j_rl1 = lj + 8u * nj; lw.j_ax = lj + 9u * nj; lw.j_l2 = lj + 10u * nj; lw.j_s0 = lj + 11u * nj; lw.j_s1 = lj + 12u * nj; lw.j_s2 = lj + 13u * nj; lw.j_s3 = lj + 14u * nj;
+    for (uint32_t k = t; k < nj; k += JOINT_THREADS) {   // stage: one round trip for the whole component (a body named by several joints is written several times with the same bits)
+        const int4 r = rec[s0 + k];
+        const uint32_t j = (uint32_t)r.x, a = (uint32_t)r.w & 0xFFFFu, b = (uint32_t)r.w >> 16;
+        lw.j_a1[k] = w.j_a1[j]; lw.j_a2[k] = w.j_a2[j]; lw.j_par[k] = w.j_par[j]; lw.j_r1[k] = w.j_r1[j]; lw.j_r2[k] = w.j_r2[j]; lw.j_cd[k] = w.j_cd[j]; lw.j_lag[k] = w.j_lag[j];
+        lw.j_rl0[k] = w.j_rl0[j]; lw.j_rl1[k] = w.j_rl1[j]; lw.j_ax[k] = w.j_ax[j]; lw.j_l2[k] = w.j_l2[j]; lw.j_s0[k] = w.j_s0[j]; lw.j_s1[k] = w.j_s1[j]; lw.j_s2[k] = w.j_s2[j]; lw.j_s3[k] = w.j_s3[j];
+        lw.sb_dp[a] = w.sb_dp[r.y]; lw.sb_dq[a] = w.sb_dq[r.y]; lw.si_a[a] = w.si_a[r.y]; lw.si_b[a] = w.si_b[r.y]; lf[a] = w.sb_flags[r.y];
+        lw.sb_dp[b] = w.sb_dp[r.z]; lw.sb_dq[b] = w.sb_dq[r.z]; lw.si_a[b] = w.si_a[r.z]; lw.si_b[b] = w.si_b[r.z]; lf[b] = w.sb_flags[r.z];
+    }
+    __syncthreads();
+    uint32_t j0 = s0, j1 = level_offsets[l0 + 1];
+    for (uint32_t l = l0; l < l1; ++l) {
+        for (uint32_t k = j0 + t; k < j1; k += JOINT_THREADS) {
+            const uint32_t sl = (uint32_t)rec[k].w;
+            joint_solve_one<T>(lw, p, k - s0, make_int2((int)(sl & 0xFFFFu), (int)(sl >> 16)));
+        }
+        __syncthreads();
+        j0 = j1; if (l + 1 < l1) j1 = level_offsets[l + 2];
+    }
+    for (uint32_t k = t; k < nj; k += JOINT_THREADS) {   // write back what the solve writes (joint_solve_one's stores; a body without a SolverBody was never written)
+        const int4 r = rec[s0 + k];
+        const uint32_t j = (uint32_t)r.x, a = (uint32_t)r.w & 0xFFFFu, b = (uint32_t)r.w >> 16;
+        w.j_lag[j] = lw.j_lag[k]; w.j_rl0[j] = lw.j_rl0[k]; w.j_rl1[j] = lw.j_rl1[k];
+        if (!(lf[a] & AVN_SBF_NO_SOLVER_BODY)) { w.sb_dp[r.y] = lw.sb_dp[a]; w.sb_dq[r.y] = lw.sb_dq[a]; }
+        if (!(lf[b] & AVN_SBF_NO_SOLVER_BODY)) { w.sb_dp[r.z] = lw.sb_dp[b]; w.sb_dq[r.z] = lw.sb_dq[b]; }
+    }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_writeback_joint_forces(DW<T> w, StepParams<T> p) {
     uint32_t j = blockIdx.x * 256 + threadIdx.x;
@@ -378,6 +439,11 @@ template <class T> void launch_joint_schedule(const DW<T>& w, const StepParams<T
     if (op == 0) hipLaunchKernelGGL((k_joint_schedule<T, 0>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, rec);
     else hipLaunchKernelGGL((k_joint_schedule<T, 1>), dim3(n_components), dim3(JOINT_THREADS), 0, s, w, p, comp_level_begin, level_offsets, rec);
 }
+template <class T> void launch_joint_schedule_lds(const DW<T>& w, const StepParams<T>& p, uint32_t n_components, const uint32_t* comp_level_begin, const uint32_t* level_offsets, const int4* rec,
+                                                  const uint32_t* comp_bodies, uint32_t lds_bytes, hipStream_t s) {
+    if (!w.n_joints || !n_components) return;
+    hipLaunchKernelGGL((k_joint_schedule_lds<T>), dim3(n_components), dim3(JOINT_THREADS), lds_bytes, s, w, p, comp_level_begin, level_offsets, rec, comp_bodies);
+}
 template <class T> void launch_writeback_joint_forces(const DW<T>& w, const StepParams<T>& p, hipStream_t s) {
     if (w.n_joints) hipLaunchKernelGGL(k_writeback_joint_forces<T>, dim3((w.n_joints + 255) / 256), dim3(256), 0, s, w, p);
 }
@@ -385,6 +451,7 @@ template <class T> void launch_writeback_joint_forces(const DW<T>& w, const Step
 #define INST(T)                                                                                    \
     template void launch_prepare_joints<T>(const DW<T>&, hipStream_t);                    \
     template void launch_joint_schedule<T>(const DW<T>&, const StepParams<T>&, int, uint32_t, const uint32_t*, const uint32_t*, const int4*, hipStream_t); \
+    template void launch_joint_schedule_lds<T>(const DW<T>&, const StepParams<T>&, uint32_t, const uint32_t*, const uint32_t*, const int4*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_writeback_joint_forces<T>(const DW<T>&, const StepParams<T>&, hipStream_t);
 INST(float)
 INST(double)

@@ -158,12 +158,10 @@
             if ((st = upload_u32(s->d_comp_level_begin, s->comp_level_begin)) != AVN_OK) return st;
             if ((st = upload_u32(s->d_level_offsets, s->level_offsets)) != AVN_OK) return st;
             if ((st = upload_u32(s->d_order, s->order)) != AVN_OK) return st;
-            std::vector<uint32_t> rec(4 * s->order.size());
-            for (size_t k = 0; k < s->order.size(); ++k) {
-                const uint32_t j = s->order[k];
-                rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; rec[4 * k + 3] = 0u;
-            }
+            std::vector<uint32_t> rec;
+            fill_joint_recs(*s, rec, s == &sched_solve);
             if ((st = upload_u32(s->d_rec, rec)) != AVN_OK) return st;
+            if ((st = upload_u32(s->d_comp_bodies, s->comp_bodies)) != AVN_OK) return st;
             HIPCHK(hipStreamSynchronize(stream));   // (`rec` is a local: the copy must have left it)
         }
         HIPCHK(hipStreamSynchronize(stream));
@@ -186,16 +184,42 @@
     hipStream_t stream_side = nullptr;
     hipEvent_t ev_side_fork = nullptr, ev_side_done = nullptr;
     uint32_t side_bodies = 0, side_joints = 0;
+    // (joint, body1, body2, local slots) per schedule slot + the per-component body counts of the LDS walk.  `lds`: the XPBD solve (damping touches virtual DUMMY bodies: global walk)
+    bool joint_lds_enabled = !avn_env("AVN_NO_JOINT_LDS");
+    std::vector<uint32_t> jl_loc, jl_gen;
+    void fill_joint_recs(JointSchedule& sc, std::vector<uint32_t>& rec, bool lds) {
+        const size_t J = sc.order.size();
+        rec.assign(4 * J, 0u);
+        for (size_t k = 0; k < J; ++k) { const uint32_t j = sc.order[k]; rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; }
+        sc.comp_bodies.assign(sc.n_components, 0xFFFFFFFFu);
+        sc.lds_bytes = 0;
+        if (!lds || !joint_lds_enabled || !J) return;
+        const uint32_t N = dw.n_bodies;
+        if (jl_loc.size() < N) { jl_loc.resize(N); jl_gen.assign(N, 0u); }
+        if (jl_gen.size() < N) jl_gen.resize(N, 0u);
+        static uint32_t gen = 0;
+        constexpr size_t LDS_LIMIT = 64 * 1024;   // (the default dynamic-LDS ceiling of a launch)
+        for (uint32_t c = 0; c < sc.n_components; ++c) {
+            const uint32_t s0 = sc.level_offsets[sc.comp_level_begin[c]], s1 = sc.level_offsets[sc.comp_level_begin[c + 1]];
+            if (++gen == 0) { std::fill(jl_gen.begin(), jl_gen.end(), 0u); gen = 1; }
+            uint32_t nb = 0;
+            for (uint32_t k = s0; k < s1; ++k)
+                for (int side = 0; side < 2; ++side) { const uint32_t b = rec[4 * k + 1 + side]; if (b < N && jl_gen[b] != gen) { jl_gen[b] = gen; jl_loc[b] = nb++; } }
+            const size_t bytes = ((size_t)4 * nb + (size_t)15 * (s1 - s0)) * sizeof(V) + (size_t)4 * nb;
+            if (nb > 0xFFFFu || bytes > LDS_LIMIT || s1 - s0 < 2) continue;   // (a single joint gains nothing from staging)
+            for (uint32_t k = s0; k < s1; ++k) rec[4 * k + 3] = jl_loc[rec[4 * k + 1]] | (jl_loc[rec[4 * k + 2]] << 16);
+            sc.comp_bodies[c] = nb;
+            sc.lds_bytes = std::max(sc.lds_bytes, (uint32_t)bytes);
+        }
+    }
     avn_status upload_schedule(JointSchedule& sc) {
         avn_status st;
         if ((st = upload_u32(sc.d_comp_level_begin, sc.comp_level_begin)) != AVN_OK) return st;
         if ((st = upload_u32(sc.d_level_offsets, sc.level_offsets)) != AVN_OK) return st;
-        std::vector<uint32_t> rec(4 * sc.order.size());
-        for (size_t k = 0; k < sc.order.size(); ++k) {
-            const uint32_t j = sc.order[k];
-            rec[4 * k] = j; rec[4 * k + 1] = (uint32_t)h_j_body1[j]; rec[4 * k + 2] = (uint32_t)h_j_body2[j]; rec[4 * k + 3] = 0u;
-        }
+        std::vector<uint32_t> rec;
+        fill_joint_recs(sc, rec, &sc == &sched_solve_main || &sc == &sched_solve_side);
         if ((st = upload_u32(sc.d_rec, rec)) != AVN_OK) return st;
+        if ((st = upload_u32(sc.d_comp_bodies, sc.comp_bodies)) != AVN_OK) return st;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }

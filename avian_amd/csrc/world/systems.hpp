@@ -77,7 +77,8 @@
         if (!dw.n_joints) return;
         JointSchedule& sc = dw.body_group == 1u ? sched_solve_main : sched_solve;   // (island streams: the side islands' joints run in substep_side)
         if (!sc.n_components) return;
-        launch_joint_schedule<T>(dw, params, 0, (uint32_t)sc.n_components, sc.d_comp_level_begin.as<uint32_t>(), sc.d_level_offsets.as<uint32_t>(), sc.d_rec.as<int4>(), stream);
+        if (sc.lds_bytes) launch_joint_schedule_lds<T>(dw, params, (uint32_t)sc.n_components, sc.d_comp_level_begin.as<uint32_t>(), sc.d_level_offsets.as<uint32_t>(), sc.d_rec.as<int4>(), sc.d_comp_bodies.as<uint32_t>(), sc.lds_bytes, stream);
+        else launch_joint_schedule<T>(dw, params, 0, (uint32_t)sc.n_components, sc.d_comp_level_begin.as<uint32_t>(), sc.d_level_offsets.as<uint32_t>(), sc.d_rec.as<int4>(), stream);
         ++launches;
     }
     void xpbd_velocity_projection() { if (xpbd_body_passes_needed()) { launch_xpbd_velocity_projection<T>(dw, params, stream); ++launches; } }
@@ -129,8 +130,9 @@
         for (uint32_t it = 0; it < cfg.solver_iterations; ++it) {
             if (it == 0) { launch_xpbd_snapshot<T>(ds, stream_side); ++launches; }
             if (sched_solve_side.n_components) {
-                launch_joint_schedule<T>(ds, params, 0, (uint32_t)sched_solve_side.n_components, sched_solve_side.d_comp_level_begin.as<uint32_t>(),
-                                         sched_solve_side.d_level_offsets.as<uint32_t>(), sched_solve_side.d_rec.as<int4>(), stream_side);
+                JointSchedule& ss = sched_solve_side;
+                if (ss.lds_bytes) launch_joint_schedule_lds<T>(ds, params, (uint32_t)ss.n_components, ss.d_comp_level_begin.as<uint32_t>(), ss.d_level_offsets.as<uint32_t>(), ss.d_rec.as<int4>(), ss.d_comp_bodies.as<uint32_t>(), ss.lds_bytes, stream_side);
+                else launch_joint_schedule<T>(ds, params, 0, (uint32_t)ss.n_components, ss.d_comp_level_begin.as<uint32_t>(), ss.d_level_offsets.as<uint32_t>(), ss.d_rec.as<int4>(), stream_side);
                 ++launches;
             }
         }
