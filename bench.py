@@ -260,6 +260,17 @@ def main():
                 "avg_launch_us": prim["avg_launch_us"], "launches_per_pass": launches_per_pass,
                 "algorithmic_bytes_per_launch": int(algo_bytes_per_pass / launches_per_pass),
                 "measured": prim["measured"], "isolated": iso, "whole_step": whole_step}
+    #  `frac` above divides the PASS's bytes by the pass's launches -- one of which is a 2 500-manifold colour that runs in k_color_pass_oct, not in
+    # the dominant kernel.  The dominant kernel's OWN launches, so that its fraction can be reproduced from profiles/*kernel_stats_cfg2.csv (its average duration there):
+    big = [c for c in meta["color_counts"] if c >= 16384]   # the per-colour switch of world/contacts.hpp: lane form from ~16 k manifolds (hysteresis 12 288 / 20 480)
+    if big:
+        ppm = pts / max(meta["n_manifolds"], 1)
+        b_launch = (248 + 88 * ppm) * (sum(big) / len(big))
+        roofline["dominant_kernel_own_launches"] = {"launches_per_pass": len(big), "mean_manifolds_per_launch": round(sum(big) / len(big), 1), "algorithmic_bytes_per_launch": int(b_launch),
+                                                    "colour_sizes_of_the_pass": meta["color_counts"],
+                                                    "frac_at_the_isolated_launch_time": round(b_launch / (iso["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                                                    "note": "bytes of one lane-form launch (600 B x its manifolds at P = 4); divide by the kernel's average duration in the rocprofv3 stats of the same command "
+                                                            "(profiles/) for its own fraction; `frac_at_the_isolated_launch_time` uses this run's isolated pass time / all launches of the pass (an upper bound of the lane-form launch's time)"}
 
     # ---- declared extension: solver_iterations = 8 (BASELINE.json config 2 says "4 substeps x 8 XPBD iters"; the reference has no such knob --
     # SURVEY.md header note 2 -- so this is NOT the parity configuration and never `value`): 8 outer repeats of the biased solve, the relax pass
@@ -511,6 +522,12 @@ def main():
             cpu = multi if multi["value"] >= single["value"] else single    # the baseline is the CPU's best
             cpu = dict(cpu, single_thread={k: single[k] for k in ("value", "ms_per_step", "substep_loop_only_ms")},
                        multi_thread={k: multi[k] for k in ("value", "cores", "ms_per_step", "substep_loop_only_ms")})
+        # the like-for-like figure: the SUBSTEP LOOP of the restatement (no glam SIMD) against the device's substep loop on the same manifolds.  The whole-step
+        # rates are not divided: 97 % of the CPU step is the serial insertion sort / sweep / constraint generation outside the substeps, a quotient of them says nothing.
+        best_loop = min(x for x in (cpu.get("substep_loop_only_ms"), (cpu.get("single_thread") or {}).get("substep_loop_only_ms"), (cpu.get("multi_thread") or {}).get("substep_loop_only_ms")) if x)
+        # (`substep_loop_only_ms` is ONE substep -- avn_profile_system(SUBSTEP) -- of the step's `substeps`; the device figure is the whole loop of a step)
+        cpu["substep_loop_speedup"] = {"cpu_one_substep_ms": best_loop, "cpu_substep_loop_ms": round(best_loop * substeps, 2), "gpu_substep_loop_ms": round(tm.substeps_ms, 4),
+                                       "ratio": round(best_loop * substeps / tm.substeps_ms, 1) if tm.substeps_ms > 0 else None}
 
     # ---- N > 1: level-2 sharding leg -- ONE cfg2 island over all N GPUs (strong scaling), exchange issued by the library over RCCL ----------
     # Not part of `value`.  A watchdog guards the leg: should the exchange hang on some fabric, the JSON line is still printed (with
@@ -615,6 +632,9 @@ def main():
             # the same bodies in the device closed loop (real contacts: broad phase -> narrow phase -> bookkeeping -> solver), settled window; `value` above stays the
             # metric BASELINE.json defines (fixed manifold set), this is the number a user of the closed loop gets
             "value_closed_loop": (closed or {}).get("substeps_per_s"),
+            "value_frozen": round(total_substeps / elapsed, 3),
+            "value_of_record": "value_closed_loop (steps 100..119 of the device closed loop on the same 100 000 boxes: the rate a user of the drop-in gets); `value` is kept on BASELINE.json's "
+                               "fixed-manifold definition (SURVEY.md section 8d) because the driver's contract times exactly `steps` steps of that workload",
             "solver_iterations_8": iters8,
             "pcie_inclusive": pcie,
             "closed_loop": closed,
