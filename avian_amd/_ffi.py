@@ -222,6 +222,14 @@ class avn_despawn_list(C.Structure):
                 ("n_joints", C.c_uint32), ("joints", vp)]
 
 
+class avn_dshard_config(C.Structure):
+    _fields_ = [("struct_size", C.c_size_t), ("n_ranks", C.c_uint32), ("rank", C.c_uint32), ("body_owner", vp)]
+
+
+class avn_dshard_stats(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("n_ranks", "rank", "own_bodies", "own_manifolds", "global_manifolds", "exchanges")] + [("bytes_sent_per_step", C.c_uint64)]
+
+
 class avn_sleeping_stats(C.Structure):
     _fields_ = [("islands", avn_islands_stats)] + [(n, C.c_uint32) for n in ("n_awake_bodies", "last_islands_slept", "last_islands_woken", "last_manifolds_popped", "last_manifolds_pushed")] + [("last_host_ms", C.c_double)]
 
@@ -261,6 +269,7 @@ ABI_SYMBOLS = [
     "islands_collider_remove", "islands_body_remove", "islands_renumber_bodies", "islands_joint_remove", "islands_renumber_joints",
     "shard_create", "shard_destroy", "shard_last_error", "shard_phase2", "shard_new_local_pairs", "shard_active", "shard_phase3", "shard_removed_local", "shard_handles", "shard_stats_get",
     "islands_stats_get", "islands_state", "sleeping_enable", "sleeping_stats_get", "sleeping_state_get", "wake_bodies", "bounds_exchange", "despawn",
+    "dshard_enable", "dshard_bodies_pack", "dshard_bodies_unpack", "dshard_stats_get",
 ]
 
 
@@ -310,6 +319,11 @@ class Library:
         f("sleeping_state_get").argtypes = [vp, C.POINTER(avn_sleeping_out)]
         f("wake_bodies").argtypes = [vp, vp, C.c_size_t]
         f("despawn").argtypes = [vp, C.POINTER(avn_despawn_list)]
+        f("dshard_enable").argtypes = [vp, vp]
+        f("dshard_bodies_pack").argtypes = [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]
+        f("dshard_bodies_unpack").argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        f("dshard_stats_get").argtypes = [vp, C.POINTER(avn_dshard_stats)]
+        for n_ in ("dshard_enable", "dshard_bodies_pack", "dshard_bodies_unpack", "dshard_stats_get"): f(n_).restype = C.c_int
         f("bounds_exchange").argtypes = [vp, vp, C.c_uint32, C.POINTER(C.c_uint32), vp, C.c_uint32, C.POINTER(C.c_uint32)]
         f("comm_unique_id").argtypes = [vp]
         f("comm_init").argtypes = [vp, vp, C.c_int, C.c_int]
@@ -896,6 +910,35 @@ class World:
         self._check(self.lib.fn("despawn")(self.handle, C.byref(d)))
         self.n_bodies -= len(b)
         self.n_joints = getattr(self, "n_joints", 0) - len(j)
+
+    # -- the device closed loop sharded by islands (avn_dshard_*) -------------------------------------------------------------------------
+    def dshard_enable(self, n_ranks: int, rank: int, body_owner):
+        """``avn_dshard_enable``: this world simulates the bodies ``body_owner == rank`` and replicates everything else of the closed loop (None: off)."""
+        if body_owner is None:
+            self._check(self.lib.fn("dshard_enable")(self.handle, None)); return
+        o = np.ascontiguousarray(body_owner, np.int32)
+        assert len(o) == self.n_bodies
+        c = avn_dshard_config(C.sizeof(avn_dshard_config), int(n_ranks), int(rank), _ptr(o))
+        self._check(self.lib.fn("dshard_enable")(self.handle, C.byref(c)))
+        self._dshard = (int(n_ranks), int(rank), o.copy())
+
+    def dshard_bodies_pack(self) -> np.ndarray:
+        """this rank's bodies after the step as [n_own, 16] scalars (Position | inv mass, Rotation, LinearVelocity | gravity scale, AngularVelocity | damping)"""
+        n_ranks, rank, o = self._dshard
+        out = np.zeros((int((o == rank).sum()), 16), self.dtype)
+        nb = C.c_size_t()
+        self._check(self.lib.fn("dshard_bodies_pack")(self.handle, _ptr(out) if out.size else _ptr(np.zeros(1, self.dtype)), out.nbytes, C.byref(nb)))
+        assert nb.value == out.nbytes
+        return out
+
+    def dshard_bodies_unpack(self, from_rank: int, records: np.ndarray):
+        r = np.ascontiguousarray(records, self.dtype)
+        self._check(self.lib.fn("dshard_bodies_unpack")(self.handle, int(from_rank), _ptr(r) if r.size else None, r.nbytes))
+
+    def dshard_stats(self) -> "avn_dshard_stats":
+        st = avn_dshard_stats()
+        self._check(self.lib.fn("dshard_stats_get")(self.handle, C.byref(st)))
+        return st
 
     def bounds_exchange(self, max_ranks: int = 64):
         """``avn_bounds_exchange``: (bounds [n_ranks, 6], overlapping rank pairs [k, 2]) -- the library reduces this world's dynamic bounds on the

@@ -159,6 +159,10 @@ AVN_API avn_status avn_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) {
 AVN_API avn_status avn_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { GUARD(sleeping_state_get(o)); }
 AVN_API avn_status avn_wake_bodies(avn_world* w, const uint32_t* bodies, size_t n) { GUARD_MUT(wake_bodies(bodies, n)); }
 AVN_API avn_status avn_despawn(avn_world* w, const avn_despawn_list* d) { GUARD_MUT(despawn(d)); }
+AVN_API avn_status avn_dshard_enable(avn_world* w, const avn_dshard_config* c) { GUARD_MUT(dshard_enable(c)); }
+AVN_API avn_status avn_dshard_bodies_pack(avn_world* w, void* out, size_t cap, size_t* bytes) { GUARD(dshard_bodies_pack(out, cap, bytes)); }
+AVN_API avn_status avn_dshard_bodies_unpack(avn_world* w, uint32_t from_rank, const void* in, size_t bytes) { GUARD_MUT(dshard_bodies_unpack(from_rank, in, bytes)); }
+AVN_API avn_status avn_dshard_stats_get(avn_world* w, avn_dshard_stats* out) { GUARD(dshard_stats_get(out)); }
 AVN_API avn_status avn_comm_unique_id(uint8_t* out) {
     try { return avn::comm_unique_id(out, g_create_error); }
     catch (...) { g_create_error = "unexpected C++ exception"; return AVN_ERR_STATE; }

@@ -32,7 +32,11 @@ AVN_HD uint32_t meta_flags(uint32_t m) { return (m >> 16) & 0xFFu; }
 AVN_HD int meta_dominance(uint32_t m) { return (int)(int8_t)(m >> 24); }
 AVN_HD uint32_t meta_with_flags(uint32_t m, uint32_t flags) { return (m & ~(0xFFu << 16)) | ((flags & 0xFFu) << 16); }
 AVN_HD bool meta_active(uint32_t m) { return (meta_flags(m) & (AVN_BODY_SLEEPING | AVN_BODY_DISABLED)) == 0; }
-AVN_HD bool meta_has_solver_body(uint32_t m) { return meta_rb_type(m) != AVN_RB_STATIC && meta_active(m); }
+// internal body flag (bit 7 of the flags byte; the ABI's AVN_BODY_* use bits 0-3): the body is simulated by ANOTHER rank of a sharded closed loop (avn_dshard_enable).  Broad phase,
+// narrow phase and the ContactGraph / ConstraintGraph bookkeeping treat it like any body -- they are replicated on every rank --; it owns no SolverBody here, its components arrive
+// from its owner after every step.
+#define AVN_BODY_FOREIGN 0x80u
+AVN_HD bool meta_has_solver_body(uint32_t m) { return meta_rb_type(m) != AVN_RB_STATIC && meta_active(m) && !(meta_flags(m) & AVN_BODY_FOREIGN); }
 
 // SolverBodyFlags word kept per body: reference bits 0-7, plus
 #define AVN_SBF_NO_SOLVER_BODY 0x80000000u

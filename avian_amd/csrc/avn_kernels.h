@@ -184,7 +184,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 #define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,
-       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_N_SLEEP_OPS = 11 /* status changes of this step that name a Sleeping body (sleeping on) */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
+       PGC_N_PUSH = 7, PGC_N_POP = 8, PGC_REM_TOTAL = 9, PGC_ADD_DONE = 10 /* workgroups of k_pg_add_pairs that are done */, PGC_N_SLEEP_OPS = 11 /* status changes of this step that name a Sleeping body (sleeping on) */, PGC_LLEN = 228 /* [24] sharded closed loop: this rank's share of GraphColor::manifold_handles.len() */, PGC_SEQ = 12 /* [2] 64-bit count of pairs ever added: the edges' insertion stamps */,
        PGC_COLLECT = 14 /* k_pg_collect_edges: records written */, PGC_LEN = 32 /* [24] GraphColor::manifold_handles.len() */,
        PGC_BUCKET = 64 /* [26] ops per colour of this step -> offsets */, PGC_OFFSETS = 96 /* [25] colour offsets of the concatenated handles */,
        PGC_DBG = 130 /* [96] k_pg_replay diagnostics */, PGC_OVF_TILE = 256 /* [512] dynamic tile ids of the overflow passes of a step */, PGC_OVF_TILES = 512,
@@ -235,6 +235,12 @@ void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_ind
 template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_pair* pairs, uint32_t total, uint64_t* pair_set, uint32_t pair_set_cap, hipStream_t);
 // exclusive scan of PG::has (= op index per changed row) + the classification of the changed rows, one launch; ctr[PGC_N_OPS] <- changes.
 // PGC_BUCKET must be zero when it starts (k_pg_build_handles leaves it so).
+// Sharded device closed loop (avn_dshard_enable, k_graph.hip / k_transfer.hip): this rank's share of every colour list, order kept (ctr[PGC_LLEN + c] <- its length; error bit 16:
+// a manifold joins bodies of two ranks); FOREIGN flags from the owner array; the own bodies' components packed for / unpacked from the per-step all-gather
+void launch_pg_local_lists(const PG&, const uint4* ct_meta, const int32_t* owner, uint32_t rank, uint32_t* local_lists, hipStream_t);
+template <class T> void launch_dsh_set_foreign(const DW<T>&, const int32_t* owner, uint32_t rank, hipStream_t);
+template <class T> void launch_dsh_pack(const DW<T>&, const uint32_t* bodies, uint32_t n, void* out, hipStream_t);
+template <class T> void launch_dsh_unpack(const DW<T>&, const uint32_t* bodies, uint32_t n, const void* in, hipStream_t);
 void launch_pg_scan_classify(const PG&, uint32_t n_rows, uint32_t n_bodies, uint32_t* scan_state, hipStream_t, const uint32_t* bmeta_if_sleeping = nullptr);
 // split_island's neighbour lists as a CSR over bodies, from the rows (k_graph.hip, round 6): off[n_bodies + 2] (off[n_bodies + 1] = entries found), adj[n]
 struct IslAdj { uint32_t cap; uint32_t *e_key2, *e_other, *e_body, *k_a, *v_a, *k_b, *v_b; /* [cap] each */ };
@@ -256,7 +262,8 @@ void launch_pg_merge_free(const PG&, uint32_t head, uint32_t n_free, uint32_t n_
 // handles <- the colours' lists, concatenated.  sort_tab != NULL: colours 0..22 in KEY-BODY order instead of list order (the solver's second order, k_graph.hip;
 // sort_tab: [23][pg_sort_stride(n_bodies)] words, all PG_NONE on entry and on exit; sort_cnt: [23][stride / 2048] words of scratch; 3 launches instead of 1)
 uint32_t pg_sort_stride(uint32_t n_bodies);
-void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t);
+// (lens_at: PGC_LEN, or PGC_LLEN with PG::lists = the rank's local lists)
+void launch_pg_build_handles(const PG&, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t, uint32_t lens_at = PGC_LEN);
 template <class T> void launch_pg_rebuild_pair_set(const CT<T>&, const BP<T>&, uint32_t n_rows, hipStream_t);
 // overflow colour on the device: incidence CSR of the body-centric warm start + per-body ranks of the dataflow passes
 struct OverflowFlow { const uint32_t* rank; /* [2 n23] rank of the manifold among its body's overflow entries | PG_NONE */ uint32_t* ticket; /* [n_bodies] */ uint32_t* tiles; /* PGC_OVF_TILE words */ uint32_t* error; uint32_t poll_sleep = 8; /* x 64 clocks between polling rounds */ };

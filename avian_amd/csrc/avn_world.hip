@@ -431,6 +431,7 @@ template <class T> struct World : WorldBase {
 #include "world/islands.hpp"
 #include "world/sleeping.hpp"
 #include "world/despawn.hpp"
+#include "world/dshard.hpp"
 #include "world/timers.hpp"
 };
 

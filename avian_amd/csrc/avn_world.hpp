@@ -112,6 +112,10 @@ struct WorldBase {
     virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
     virtual avn_status wake_bodies(const uint32_t*, size_t) = 0;
     virtual avn_status despawn(const avn_despawn_list*) = 0;
+    virtual avn_status dshard_enable(const avn_dshard_config*) = 0;
+    virtual avn_status dshard_bodies_pack(void*, size_t, size_t*) = 0;
+    virtual avn_status dshard_bodies_unpack(uint32_t, const void*, size_t) = 0;
+    virtual avn_status dshard_stats_get(avn_dshard_stats*) = 0;
 };
 
 // RCCL transport of the level-2 halo exchange (avn_comm.cpp; librccl is opened on first use)

@@ -876,11 +876,11 @@ void launch_compact_u8(const uint8_t* src, uint8_t* dst, const uint32_t* new_ind
 // colour ever name the same key body (the colouring's invariant broken, e.g. by a body that changed its type under a live contact), the
 // loser of the compare-and-swap goes to the END of the colour's range (ctr[PGC_SORT_DUP + colour]): nothing is lost.
 __global__ __launch_bounds__(256) void k_pg_build_handles(PG pg, uint32_t* __restrict__ handles, uint32_t* __restrict__ color_offsets, uint32_t total,
-                                                          const uint4* __restrict__ ct_meta, uint32_t* __restrict__ tab, uint32_t tab_stride) {
+                                                          const uint4* __restrict__ ct_meta, uint32_t* __restrict__ tab, uint32_t tab_stride, uint32_t lens_at) {
     __shared__ uint32_t off[AVN_GRAPH_COLOR_COUNT + 1];
     if (threadIdx.x == 0) {
         uint32_t a = 0;
-        for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { off[c] = a; a += pg.ctr[PGC_LEN + c]; }
+        for (uint32_t c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { off[c] = a; a += pg.ctr[lens_at + c]; }
         off[AVN_GRAPH_COLOR_COUNT] = a;
     }
     __syncthreads();
@@ -946,9 +946,9 @@ __global__ __launch_bounds__(256) void k_pg_sort_emit(PG pg, uint32_t* __restric
     }
 }
 uint32_t pg_sort_stride(uint32_t n_bodies) { return ((n_bodies + PG_SORT_CHUNK - 1u) / PG_SORT_CHUNK) * PG_SORT_CHUNK; }
-void launch_pg_build_handles(const PG& pg, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t s) {
+void launch_pg_build_handles(const PG& pg, uint32_t* handles, uint32_t* color_offsets, uint32_t total, const uint4* ct_meta, uint32_t* sort_tab, uint32_t* sort_cnt, uint32_t n_bodies, hipStream_t s, uint32_t lens_at) {
     const uint32_t stride = pg_sort_stride(n_bodies), n_chunks = stride / PG_SORT_CHUNK;
-    hipLaunchKernelGGL(k_pg_build_handles, dim3((total + 255) / 256 + 1), dim3(256), 0, s, pg, handles, color_offsets, total, ct_meta, sort_tab, stride);
+    hipLaunchKernelGGL(k_pg_build_handles, dim3((total + 255) / 256 + 1), dim3(256), 0, s, pg, handles, color_offsets, total, ct_meta, sort_tab, stride, lens_at);
     if (!sort_tab || !n_chunks) return;
     hipLaunchKernelGGL(k_pg_sort_count, dim3(n_chunks, AVN_COLOR_OVERFLOW_INDEX), dim3(256), 0, s, pg, sort_tab, stride, n_chunks, sort_cnt);
     hipLaunchKernelGGL(k_pg_sort_emit, dim3(n_chunks, AVN_COLOR_OVERFLOW_INDEX), dim3(256), 0, s, pg, sort_tab, stride, n_chunks, sort_cnt, handles);
@@ -1012,6 +1012,48 @@ __global__ __launch_bounds__(256) void k_ovf_post(const uint32_t* __restrict__ k
 template <class T> void launch_ovf_csr(const DW<T>& w, uint32_t o0, uint32_t n23, const uint32_t* keys, const uint32_t* vals, uint32_t* inc_off, uint32_t* inc_ent, uint32_t* rank, hipStream_t s) {
     hipLaunchKernelGGL(k_ovf_offsets, dim3((w.n_bodies + 256) / 256), dim3(256), 0, s, keys, 2 * n23, w.n_bodies, inc_off);
     if (n23) hipLaunchKernelGGL(k_ovf_post, dim3((2 * n23 + 255) / 256), dim3(256), 0, s, keys, vals, 2 * n23, w.n_bodies, o0, inc_off, inc_ent, rank);
+}
+
+// ---- the sharded closed loop (avn_dshard_enable): this rank's share of the colour lists -----------------------------------------------------------------------
+// Every rank replays every rank's status changes on the SAME ContactGraph / ConstraintGraph (ids, colours and list positions are global facts: DESIGN.md section 6), so
+// PG::lists are the single world's lists on every rank.  The solver of a rank only takes the manifolds of the bodies it simulates: a stable compaction of every list by
+// "the manifold's non-static body is mine" -- a restriction keeps the relative order, which is all the overflow colour's serial solve needs.  One workgroup per colour,
+// 256 entries at a time.  A manifold between bodies of two ranks means the islands have met (the level-1 re-partition's business): error bit 16.
+__global__ __launch_bounds__(256) void k_pg_local_lists(PG pg, const uint4* __restrict__ ct_meta, const int32_t* __restrict__ owner, uint32_t rank, uint32_t* __restrict__ local) {
+    __shared__ uint32_t ws[4];
+    __shared__ uint32_t s_base;
+    const uint32_t c = blockIdx.x, t = threadIdx.x;
+    const uint32_t L = pg.ctr[PGC_LEN + c];
+    const uint32_t* __restrict__ list = pg.lists + (size_t)c * pg.list_stride;
+    uint32_t* __restrict__ out = local + (size_t)c * pg.list_stride;
+    if (t == 0) s_base = 0u;
+    __syncthreads();
+    for (uint32_t k0 = 0; k0 < L; k0 += 256u) {
+        const uint32_t k = k0 + t;
+        uint32_t cid = 0u, mine = 0u;
+        if (k < L) {
+            cid = list[k];
+            const int2 b = pg.bodies[cid];
+            const uint32_t fl = ct_meta[cid].z;
+            const int o1 = (fl & AVN_CP_STATIC1) ? -1 : owner[b.x], o2 = (fl & AVN_CP_STATIC2) ? -1 : owner[b.y];
+            if (o1 >= 0 && o2 >= 0 && o1 != o2) atomicOr(&pg.ctr[PGC_ERROR], 16u);
+            mine = ((o1 >= 0 ? o1 : o2) == (int)rank) ? 1u : 0u;
+        }
+        const unsigned long long bal = __ballot(mine);
+        const uint32_t lane = t & 63u, wv = t >> 6;
+        if (lane == 0) ws[wv] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_base;
+        for (uint32_t j = 0; j < wv; ++j) before += ws[j];
+        if (mine) out[before + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull))] = cid;
+        __syncthreads();
+        if (t == 0) s_base += (ws[0] + ws[1]) + (ws[2] + ws[3]);
+        __syncthreads();
+    }
+    if (t == 0) pg.ctr[PGC_LLEN + c] = s_base;
+}
+void launch_pg_local_lists(const PG& pg, const uint4* ct_meta, const int32_t* owner, uint32_t rank, uint32_t* local_lists, hipStream_t s) {
+    hipLaunchKernelGGL(k_pg_local_lists, dim3(AVN_GRAPH_COLOR_COUNT), dim3(256), 0, s, pg, ct_meta, owner, rank, local_lists);
 }
 
 // ---- the contact graph's adjacency for split_island (world/sleeping.hpp, round 6) -------------------------------------------------------

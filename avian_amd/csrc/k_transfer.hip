@@ -224,6 +224,40 @@ template void launch_halo_pack<double>(const DW<double>&, const int32_t*, uint32
 template void launch_halo_unpack<float>(const DW<float>&, const int32_t*, uint32_t, const Vec4<float>*, hipStream_t);
 template void launch_halo_unpack<double>(const DW<double>&, const int32_t*, uint32_t, const Vec4<double>*, hipStream_t);
 
+// ---- sharded closed loop (avn_dshard_enable): FOREIGN flags, and the bodies' components for the per-step all-gather --------------------------------------------------
+template <class T>
+__global__ __launch_bounds__(256) void k_dsh_set_foreign(DW<T> w, const int32_t* __restrict__ owner, uint32_t rank) {
+    const uint32_t b = blockIdx.x * 256 + threadIdx.x;
+    if (b >= w.n_bodies) return;
+    const uint32_t m = w.bmeta[b];
+    const bool foreign = owner && owner[b] >= 0 && owner[b] != (int)rank;
+    w.bmeta[b] = meta_with_flags(m, foreign ? (meta_flags(m) | AVN_BODY_FOREIGN) : (meta_flags(m) & ~(uint32_t)AVN_BODY_FOREIGN));
+}
+// Position / Rotation / LinearVelocity / AngularVelocity records of the listed bodies, four records per body (the w lanes are constants of the upload: identical on every rank)
+template <class T>
+__global__ __launch_bounds__(256) void k_dsh_pack(DW<T> w, const uint32_t* __restrict__ bodies, uint32_t n, Vec4<T>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bodies[i];
+    out[4 * (size_t)i] = w.pos[b]; out[4 * (size_t)i + 1] = w.rot[b]; out[4 * (size_t)i + 2] = w.lvel[b]; out[4 * (size_t)i + 3] = w.avel[b];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_dsh_unpack(DW<T> w, const uint32_t* __restrict__ bodies, uint32_t n, const Vec4<T>* __restrict__ in) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t b = bodies[i];
+    w.pos[b] = in[4 * (size_t)i]; w.rot[b] = in[4 * (size_t)i + 1]; w.lvel[b] = in[4 * (size_t)i + 2]; w.avel[b] = in[4 * (size_t)i + 3];
+}
+template <class T> void launch_dsh_set_foreign(const DW<T>& w, const int32_t* owner, uint32_t rank, hipStream_t s) {
+    if (w.n_bodies) hipLaunchKernelGGL(k_dsh_set_foreign<T>, dim3((w.n_bodies + 255) / 256), dim3(256), 0, s, w, owner, rank);
+}
+template <class T> void launch_dsh_pack(const DW<T>& w, const uint32_t* bodies, uint32_t n, void* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_dsh_pack<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, (Vec4<T>*)out);
+}
+template <class T> void launch_dsh_unpack(const DW<T>& w, const uint32_t* bodies, uint32_t n, const void* in, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_dsh_unpack<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, (const Vec4<T>*)in);
+}
+
 #define INST(T)                                                                                     \
     template void launch_pack_bodies<T>(const DW<T>&, const BodyStage<T>&, hipStream_t);            \
     template void launch_pack_manifolds<T>(const DW<T>&, const ManifoldStage<T>&, hipStream_t);     \
@@ -234,7 +268,10 @@ template void launch_halo_unpack<double>(const DW<double>&, const int32_t*, uint
     template void launch_unpack_impulses<T>(const DW<T>&, T*, T*, T*, hipStream_t);                 \
     template void launch_unpack_constraints<T>(const DW<T>&, const ConstraintsStage<T>&, hipStream_t); \
     template void launch_unpack_joints<T>(const DW<T>&, T*, T*, T*, T*, T*, T*, T*, hipStream_t);           \
-    template void launch_unpack_aabbs<T>(const BP<T>&, T*, T*, uint32_t*, hipStream_t);
+    template void launch_unpack_aabbs<T>(const BP<T>&, T*, T*, uint32_t*, hipStream_t);           \
+    template void launch_dsh_set_foreign<T>(const DW<T>&, const int32_t*, uint32_t, hipStream_t);  \
+    template void launch_dsh_pack<T>(const DW<T>&, const uint32_t*, uint32_t, void*, hipStream_t); \
+    template void launch_dsh_unpack<T>(const DW<T>&, const uint32_t*, uint32_t, const void*, hipStream_t);
 INST(float)
 INST(double)
 #undef INST

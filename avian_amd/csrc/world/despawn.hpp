@@ -22,6 +22,7 @@
         if (!d || (d->struct_size != sizeof(avn_despawn_list) && d->struct_size != AVN_DESPAWN_LIST_SIZE_R4) || (d->n_colliders && !d->collider_entities) || (d->n_bodies && !d->bodies)) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
         if (d->struct_size == sizeof(avn_despawn_list) && d->n_joints && !d->joints) { error = "despawn: bad argument"; return AVN_ERR_BAD_ARG; }
         if (!pipe_on || !pipe_dev) { error = "despawn: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
+        if (dsh_on) { error = "despawn: not inside a sharded closed loop (avn_dshard_enable(NULL), despawn on every rank, enable again)"; return AVN_ERR_STATE; }
         if (despawn_needs_bodies || despawn_needs_colliders) { error = "despawn: the previous avn_despawn is still waiting for avn_bodies_upload / avn_colliders_upload"; return AVN_ERR_STATE; }
         if (despawn_broken) { error = "despawn: an earlier avn_despawn failed half-way; restart the closed loop (avn_pipeline_enable(0), uploads, avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         pg_new_ids_count = 0; last_timers.pair_count = 0;   // (the last step's new-pair ids may name rows that leave now: avn_pipeline_new_pair_ids_get reports an empty list until the next step)

@@ -195,7 +195,8 @@
         if (word & 2u) error += " k_overflow_flow: a ticket wait of the overflow colour's solve timed out (the step's velocities are not the reference's);";
         if (word & 4u) error += " k_pack_contacts: avn_contacts_upload named a contact id whose row is not live (skipped);";
         if (word & 8u) error += " k_overflow_flow: a manifold's overflow rank and its constraint flags disagree about which body has a SolverBody;";
-        if (word & ~15u) error += " unknown bits in the error word;";
+        if (word & 16u) error += " sharded closed loop: a manifold joins bodies of two ranks -- their islands have met (avn_bounds_exchange / re-partition before stepping on);";
+        if (word & ~31u) error += " unknown bits in the error word;";
         error += " the error word has been cleared";
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_ERROR, 0, 4, stream));
         HIPCHK(hipMemsetAsync(pg.ctr + PGC_BUCKET, 0, 32 * 4, stream));   // (an aborted batch never reached k_pg_build_handles, which cleans these)
@@ -277,8 +278,10 @@
                 launches += 3;
             }
             HIPCHK(hipGetLastError());
+            if (dsh_on && (st = dsh_local_lists()) != AVN_OK) return st;   // sharded closed loop: this rank's share of every colour list (ctr[PGC_LLEN ..])
             uint32_t* h = (uint32_t*)pin_ctr.p + 64;
             HIPCHK(hipMemcpyAsync(h, pg.ctr, 64 * 4, hipMemcpyDeviceToHost, stream));   // the counters block up to the colours' lengths, in one copy
+            if (dsh_on) HIPCHK(hipMemcpyAsync(h + 64, pg.ctr + PGC_LLEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
             if (!ev_spin) HIPCHK(hipEventCreateWithFlags(&ev_spin, hipEventDisableTiming));
             HIPCHK(hipEventRecord(ev_spin, stream));   // (the host waits for THIS point, not for what it enqueues below)
             // Round 5: what follows the replay on the device -- handle lists, the body-sorted order, constraint generation: 90 us of a settled cfg2
@@ -296,7 +299,7 @@
                 if (e2 != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
                 const bool sorted_ub = handle_sort && M_ub >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M_ub;
                 if (sorted_ub && (st = pg_sort_ensure()) != AVN_OK) return st;
-                launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M_ub, ct.meta, sorted_ub ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
+                launch_pg_build_handles(dsh_on ? dsh_pg() : pg, b_handles.as<uint32_t>(), dw.color_offsets, M_ub, ct.meta, sorted_ub ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream, dsh_on ? (uint32_t)PGC_LLEN : (uint32_t)PGC_LEN);
                 launches += sorted_ub ? 3 : 1;
                 DW<T> dwp = dw; dwp.n_manifolds = M_ub;
                 RowsView<T> rv{b_handles.as<uint32_t>(), ct.meta, bp.col_info, ct.rows};
@@ -338,8 +341,11 @@
             pipe_stats.manifolds_pushed = h[PGC_N_PUSH]; pipe_stats.manifolds_popped = h[PGC_N_POP];
             uint32_t offs[AVN_GRAPH_COLOR_COUNT + 1];
             uint32_t M = 0;
-            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[PGC_LEN + c]; offs[c] = M; M += h[PGC_LEN + c]; }
+            // (sharded: the lists' lengths are the whole world's, the solver's offsets this rank's share)
+            dsh_global_manifolds = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) { pgm_len[c] = h[PGC_LEN + c]; dsh_global_manifolds += pgm_len[c]; const uint32_t len = dsh_on ? h[64 + c] : pgm_len[c]; offs[c] = M; M += len; }
             offs[AVN_GRAPH_COLOR_COUNT] = M;
+            dsh_own_manifolds = M;
             if ((st = ensure_manifold_capacity(M)) != AVN_OK) return st;
             if ((dw.n_manifolds == 0) != (M == 0)) graph_valid = false;   // (no captured kernel reads DW::n_manifolds; only "any manifolds at all" shapes the substep)
             dw.n_manifolds = M;
@@ -352,7 +358,7 @@
             if (!early) {
                 const bool sorted = handle_sort && M >= 4096u && (uint64_t)AVN_COLOR_OVERFLOW_INDEX * dw.n_bodies <= 32ull * M;
                 if (sorted && (st = pg_sort_ensure()) != AVN_OK) return st;
-                launch_pg_build_handles(pg, b_handles.as<uint32_t>(), dw.color_offsets, M, ct.meta, sorted ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream);
+                launch_pg_build_handles(dsh_on ? dsh_pg() : pg, b_handles.as<uint32_t>(), dw.color_offsets, M, ct.meta, sorted ? b_pg_sort_tab.as<uint32_t>() : nullptr, b_pg_sort_cnt.as<uint32_t>(), dw.n_bodies, stream, dsh_on ? (uint32_t)PGC_LLEN : (uint32_t)PGC_LEN);
                 launches += sorted ? 3 : 1;
                 HIPCHK(hipGetLastError());
             } else if (M > M_ub) { error = "device closed loop: more manifolds after an op batch than manifolds before + ops"; return AVN_ERR_STATE; }
@@ -536,6 +542,7 @@
             pipe_stats.last_host_ms += slp_ms;
         }
         if (slp_on && (st = sleeping_after_solver()) != AVN_OK) return st;   // split_island + the Sleeping set (synchronises: the host reads the timers)
+        if (dsh_on && (st = dsh_exchange_in_step()) != AVN_OK) return st;   // sharded closed loop with a communicator: the ranks' own bodies to everybody (one all-gather)
         HIPCHK(hipEventRecord(ev[4], stream));
         ev_valid = true;
         last_timers.kernel_launches = launches;

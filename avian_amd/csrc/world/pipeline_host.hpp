@@ -57,13 +57,15 @@
         if (!off || !ids || !n) return AVN_ERR_BAD_ARG;
         if (pipe_dev) {   // the lists live on the device: fetched on request (tests, inspection)
             HIPCHK(hipStreamSynchronize(stream));
-            std::memcpy(pipe_offsets, color_offsets, sizeof pipe_offsets);
-            pipe_handles.resize(dw.n_manifolds);
+            // (offsets from the lists' own lengths: in the sharded closed loop the solver's colour offsets are this rank's share, the lists are the whole world's)
+            pipe_offsets[0] = 0;
+            for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) pipe_offsets[c + 1] = pipe_offsets[c] + pgm_len[c];
+            pipe_handles.resize(pipe_offsets[AVN_GRAPH_COLOR_COUNT]);
             // GraphColor::manifold_handles, i.e. the bookkeeping's lists in the reference's order (PG::lists) -- not the solver's arrays, whose order
             // inside colours 0..22 is by key body since round 5 (b_handles; the overflow colour is in list order there too)
             for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
-                const uint32_t len = color_offsets[c + 1] - color_offsets[c];
-                if (len) HIPCHK(hipMemcpyAsync(pipe_handles.data() + color_offsets[c], pg.lists + (size_t)c * pg.list_stride, (size_t)len * 4, hipMemcpyDeviceToHost, stream));
+                const uint32_t len = pipe_offsets[c + 1] - pipe_offsets[c];
+                if (len) HIPCHK(hipMemcpyAsync(pipe_handles.data() + pipe_offsets[c], pg.lists + (size_t)c * pg.list_stride, (size_t)len * 4, hipMemcpyDeviceToHost, stream));
             }
             HIPCHK(hipStreamSynchronize(stream));
         }

@@ -182,6 +182,7 @@
         if (p->struct_size != sizeof(avn_sleep_params)) { error = "sleeping_enable: bad params"; return AVN_ERR_BAD_ARG; }
         if (!pipe_on || !pipe_dev) { error = "sleeping_enable: needs the device closed loop (avn_pipeline_enable(1))"; return AVN_ERR_STATE; }
         if (pgm_next_id) { error = "sleeping_enable: enable it before the first step of the closed loop"; return AVN_ERR_STATE; }
+        if (dsh_on) { error = "sleeping_enable: not combined with avn_dshard_enable"; return AVN_ERR_STATE; }
         const uint32_t n = dw.n_bodies;
         if (h_rb_type.size() != n) { error = "sleeping_enable: upload bodies first"; return AVN_ERR_STATE; }
         avn_status st;

@@ -768,6 +768,33 @@ def tensor_gather(dist, torch):
     return gather
 
 
+# ---- the DEVICE closed loop sharded by islands (avn_dshard_*, round 6): every world replicates the front of the step, simulates its own bodies, and the bodies' components
+#      go round once per step.  With avn_comm_init the library issues that all-gather itself inside avn_step; these two helpers are the host-mediated forms. ----
+def dshard_step_in_process(worlds):
+    """one step of every rank in ONE process (several worlds on one device, or on the CPU oracle): step, then every rank's bodies to every other world"""
+    for w in worlds:
+        w.step()
+    recs = [w.dshard_bodies_pack() for w in worlds]
+    for r, w in enumerate(worlds):
+        for q, rec in enumerate(recs):
+            if q != r:
+                w.dshard_bodies_unpack(q, rec)
+
+
+def dshard_step_distributed(world, gather):
+    """one step of this process's rank; `gather` = tensor_gather(dist, torch): one all-gather of the ranks' body records (rank order), split by the owner table"""
+    n_ranks, rank, owner = world._dshard
+    world.step()
+    mine = world.dshard_bodies_pack()
+    allrec = gather(mine.reshape(-1)).reshape(-1, 16)
+    at = 0
+    for q in range(n_ranks):
+        n = int((owner == q).sum())
+        if q != rank:
+            world.dshard_bodies_unpack(q, allrec[at:at + n])
+        at += n
+
+
 def step_in_process_native(loops: List["ShardedClosedLoopNative"]):
     """One step of every rank in ONE process: the gathers are concatenations in rank order."""
     p1 = [l.phase1() for l in loops]

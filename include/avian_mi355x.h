@@ -929,6 +929,41 @@ typedef struct avn_despawn_list {
 #define AVN_DESPAWN_LIST_SIZE_R4 (offsetof(avn_despawn_list, n_joints))
 AVN_API avn_status AVN_FN(despawn)(avn_world* w, const avn_despawn_list* d);
 
+/* ---- the DEVICE closed loop sharded by islands over several worlds / ranks (round 6) ------------------------------------------------------
+ * avn_shard_* above is the host model: replicated integer bookkeeping in host C++, each rank's physics through the host pipeline mode.  This is the same idea with
+ * the bookkeeping where avn_pipeline_enable(1) keeps it -- on the device -- and one exchange per step:
+ *   * every rank holds EVERY body and collider (global indices) and runs the whole front of the step on them: AABBs, sweep-and-prune, IdPool, narrow phase, the status
+ *     loop, greedy colouring, swap_remove replay.  These are pure functions of the bodies' components, which are equal on every rank, so pair sequences, ContactIds,
+ *     colours and list positions ARE the single world's on every rank without a word exchanged (the reference's IdPool hands out the lowest free id and
+ *     ConstraintGraph::pop_manifold moves the LAST handle of a list into the hole -- data_structures/id_pool.rs:31-40, constraint_graph.rs:245-296 -- so they cannot
+ *     be sharded without changing results);
+ *   * a body is SIMULATED by exactly one rank (`body_owner`): only there it owns a SolverBody, and that rank's solver takes its share of every GraphColor's
+ *     manifold_handles -- the global list restricted to the manifolds of its own bodies, relative order kept (what the overflow colour's serial solve needs);
+ *   * after the solver every rank's own bodies' Position / Rotation / LinearVelocity / AngularVelocity go to all the others: ONE all-gather per step, issued by the
+ *     library on the world's stream through ncclAllGather when avn_comm_init has run (inside avn_step), or moved by the host between steps with
+ *     avn_dshard_bodies_pack / _unpack (several worlds in one process, gloo).  The host still reads only the step's counters.
+ * Islands of different ranks must not touch: a manifold between bodies of two owners fails the step (AVN_ERR_STATE) -- avn_bounds_exchange sees it coming, the level-1
+ * re-partition handles it.  Not combined with avn_sleeping_enable, avn_despawn or the island blocks (the solver runs its colour launches); results are bit-identical
+ * to the single world (tests/test_gpu_dshard.py, tests/test_dshard_cpu.py). */
+typedef struct avn_dshard_config {
+    size_t struct_size;          /* sizeof(avn_dshard_config) */
+    uint32_t n_ranks, rank;
+    const int32_t* body_owner;   /* [n_bodies] the rank that simulates the body; -1 = nobody (static bodies: replicated) */
+} avn_dshard_config;
+/* after avn_pipeline_enable(1), before the first step (or between steps with an unchanged body count); cfg = NULL switches it off */
+AVN_API avn_status AVN_FN(dshard_enable)(avn_world* w, const avn_dshard_config* cfg);
+/* host-mediated exchange: this rank's bodies (ascending index) as 4 records of 4 scalars each -- (Position, inv mass) (Rotation) (LinearVelocity, gravity scale)
+ * (AngularVelocity, linear damping) -- in the world's scalar type; *bytes = n_own x 16 scalars.  unpack writes the records of rank `from_rank`'s bodies. */
+AVN_API avn_status AVN_FN(dshard_bodies_pack)(avn_world* w, void* out, size_t cap_bytes, size_t* bytes);
+AVN_API avn_status AVN_FN(dshard_bodies_unpack)(avn_world* w, uint32_t from_rank, const void* in, size_t bytes);
+typedef struct avn_dshard_stats {
+    uint32_t n_ranks, rank, own_bodies, own_manifolds;   /* this rank's share of the step just taken */
+    uint32_t global_manifolds;                          /* constraint handles of the replicated ConstraintGraph */
+    uint32_t exchanges;                                 /* all-gathers the library issued itself (avn_comm_init) since avn_dshard_enable */
+    uint64_t bytes_sent_per_step;                       /* own bodies x 16 scalars */
+} avn_dshard_stats;
+AVN_API avn_status AVN_FN(dshard_stats_get)(avn_world* w, avn_dshard_stats* out);
+
 /* ---- the closed loop sharded by ISLANDS: replicated integer bookkeeping (round 5; host C++, no device needed) ---------------------------------------------
  * Islands spread over ranks, results equal to the single world's bit for bit.  The reference's IdPool hands out the LOWEST free ContactId in the broad
  * phase's GLOBAL emission order (data_structures/id_pool.rs:31-40, collision/broad_phase.rs:387-388), NarrowPhase::update walks status changes in

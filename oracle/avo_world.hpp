@@ -315,6 +315,10 @@ struct WorldBase {
     virtual avn_status sleeping_state_get(const avn_sleeping_out*) = 0;
     virtual avn_status wake_bodies(const uint32_t*, size_t) = 0;
     virtual avn_status despawn(const avn_despawn_list*) = 0;
+    virtual avn_status dshard_enable(const avn_dshard_config*) = 0;
+    virtual avn_status dshard_bodies_pack(void*, size_t, size_t*) = 0;
+    virtual avn_status dshard_bodies_unpack(uint32_t, const void*, size_t) = 0;
+    virtual avn_status dshard_stats_get(avn_dshard_stats*) = 0;
 };
 
 struct ConstraintGraph;  // defined below (solver/constraint_graph.rs restatement)
@@ -386,6 +390,68 @@ template <class S> struct World : WorldBase {
     }
     avn_status pipeline_step();
     avn_status pipeline_refresh_handles();
+    // ---- the closed loop sharded by islands (header: avn_dshard_*): the whole front of the step on every body, a SolverBody only for the bodies this rank simulates,
+    //      the solver's handle list = the replicated colour lists restricted to those bodies' manifolds (order kept), the other ranks' bodies copied in after every step ----
+    bool dsh_on = false;
+    uint32_t dsh_ranks = 1, dsh_rank = 0, dsh_own_manifolds = 0, dsh_global_manifolds = 0;
+    std::vector<int32_t> dsh_owner;
+    bool dsh_foreign(size_t b) const { return dsh_on && b < dsh_owner.size() && dsh_owner[b] >= 0 && (uint32_t)dsh_owner[b] != dsh_rank; }
+    void dsh_refresh_solver_bodies() { for (size_t b = 0; b < bodies.size(); ++b) bodies[b].has_solver_body = bodies[b].rb_type != AVN_RB_STATIC && bodies[b].active() && !dsh_foreign(b); }
+    avn_status dshard_enable(const avn_dshard_config* c) override {
+        if (!c) { dsh_on = false; dsh_refresh_solver_bodies(); return AVN_OK; }
+        if (c->struct_size != sizeof(avn_dshard_config) || !c->n_ranks || c->rank >= c->n_ranks || !c->body_owner) { error = "dshard_enable: bad argument"; return AVN_ERR_BAD_ARG; }
+        if (!pipe) { error = "dshard_enable: needs the closed loop (avn_pipeline_enable)"; return AVN_ERR_STATE; }
+        if (slp) { error = "dshard_enable: not combined with avn_sleeping_enable (the island manager is per world)"; return AVN_ERR_STATE; }
+        for (size_t b = 0; b < bodies.size(); ++b) {
+            if (c->body_owner[b] >= (int32_t)c->n_ranks) { error = "dshard_enable: body_owner names a rank that does not exist"; return AVN_ERR_BAD_ARG; }
+            if (c->body_owner[b] < 0 && bodies[b].rb_type != AVN_RB_STATIC) { error = "dshard_enable: every non-static body needs an owner"; return AVN_ERR_BAD_ARG; }
+        }
+        dsh_owner.assign(c->body_owner, c->body_owner + bodies.size());
+        dsh_ranks = c->n_ranks; dsh_rank = c->rank; dsh_on = true;
+        dsh_refresh_solver_bodies();
+        return AVN_OK;
+    }
+    avn_status dshard_bodies_pack(void* out, size_t cap, size_t* bytes) override {
+        if (!dsh_on) { error = "dshard_bodies_pack: avn_dshard_enable first"; return AVN_ERR_STATE; }
+        size_t n = 0;
+        for (size_t b = 0; b < bodies.size(); ++b) n += dsh_owner[b] == (int32_t)dsh_rank;
+        if (bytes) *bytes = n * 16 * sizeof(S);
+        if (!out || cap < n * 16 * sizeof(S)) { error = "dshard_bodies_pack: the buffer is too small"; return AVN_ERR_BAD_ARG; }
+        S* o = (S*)out;
+        for (size_t b = 0; b < bodies.size(); ++b) {
+            if (dsh_owner[b] != (int32_t)dsh_rank) continue;
+            const Body<S>& B = bodies[b];
+            const S rec[16] = {B.position.x, B.position.y, B.position.z, B.inv_mass, B.rotation.x, B.rotation.y, B.rotation.z, B.rotation.w,
+                               B.linear_velocity.x, B.linear_velocity.y, B.linear_velocity.z, B.gravity_scale, B.angular_velocity.x, B.angular_velocity.y, B.angular_velocity.z, B.linear_damping};
+            std::memcpy(o, rec, sizeof rec); o += 16;
+        }
+        return AVN_OK;
+    }
+    avn_status dshard_bodies_unpack(uint32_t from, const void* in, size_t bytes) override {
+        if (!dsh_on) { error = "dshard_bodies_unpack: avn_dshard_enable first"; return AVN_ERR_STATE; }
+        if (from >= dsh_ranks || from == dsh_rank) { error = "dshard_bodies_unpack: another rank of the shard"; return AVN_ERR_BAD_ARG; }
+        size_t n = 0;
+        for (size_t b = 0; b < bodies.size(); ++b) n += dsh_owner[b] == (int32_t)from;
+        if (bytes != n * 16 * sizeof(S) || (n && !in)) { error = "dshard_bodies_unpack: the byte count is not that rank's bodies x 16 scalars"; return AVN_ERR_BAD_ARG; }
+        const S* r = (const S*)in;
+        for (size_t b = 0; b < bodies.size(); ++b) {
+            if (dsh_owner[b] != (int32_t)from) continue;
+            Body<S>& B = bodies[b];
+            B.position = {r[0], r[1], r[2]}; B.rotation = {r[4], r[5], r[6], r[7]}; B.linear_velocity = {r[8], r[9], r[10]}; B.angular_velocity = {r[12], r[13], r[14]};
+            r += 16;
+        }
+        return AVN_OK;
+    }
+    avn_status dshard_stats_get(avn_dshard_stats* o) override {
+        if (!o) return AVN_ERR_BAD_ARG;
+        std::memset(o, 0, sizeof *o);
+        if (!dsh_on) return AVN_OK;
+        uint32_t own = 0;
+        for (size_t b = 0; b < bodies.size(); ++b) own += dsh_owner[b] == (int32_t)dsh_rank;
+        o->n_ranks = dsh_ranks; o->rank = dsh_rank; o->own_bodies = own; o->own_manifolds = dsh_own_manifolds; o->global_manifolds = dsh_global_manifolds;
+        o->bytes_sent_per_step = (uint64_t)own * 16 * sizeof(S);
+        return AVN_OK;
+    }
     // ---- persistent islands + sleeping in the closed loop (header: avn_sleeping_enable; avo_islands.hpp) ----
     struct Sleeping {
         avn_sleep_params p;
@@ -472,7 +538,7 @@ template <class S> struct World : WorldBase {
             o.locked_axes = rd<uint8_t>(b->locked_axes, i, 0);
             o.dominance = rd<int8_t>(b->dominance, i, 0);
             o.body_flags = rd<uint8_t>(b->body_flags, i, 0);
-            o.has_solver_body = o.rb_type != AVN_RB_STATIC && o.active();
+            o.has_solver_body = o.rb_type != AVN_RB_STATIC && o.active() && !dsh_foreign(i);
             o.sb = SolverBody<S>();
             o.si = SolverBodyInertia<S>();
             o.vid = VelocityIntegrationData<S>();
@@ -2145,8 +2211,8 @@ struct PipelineState {
     std::unordered_map<uint32_t, uint32_t> node_of_collider;
     uint32_t node(uint32_t collider) { auto it = node_of_collider.find(collider); if (it != node_of_collider.end()) return it->second; const uint32_t n = (uint32_t)node_of_collider.size() + nodes_dropped; node_of_collider.emplace(collider, n); return n; }
     uint32_t nodes_dropped = 0;   // (node indices are never reused: a removed collider's node stays behind, empty)
-    std::vector<uint32_t> handles;
-    uint32_t offsets[AVN_GRAPH_COLOR_COUNT + 1] = {0};
+    std::vector<uint32_t> handles, report_handles;   // the solver's list | the ConstraintGraph's lists as avn_pipeline_handles_get reports them (equal unless the loop is sharded)
+    uint32_t offsets[AVN_GRAPH_COLOR_COUNT + 1] = {0}, report_offsets[AVN_GRAPH_COLOR_COUNT + 1] = {0};
     avn_pipeline_stats stats;
     bool handles_dirty = true;
     PipelineState() { std::memset(&stats, 0, sizeof stats); }
@@ -2178,21 +2244,31 @@ template <class S> avn_status World<S>::pipeline_handles_get(uint32_t* off, cons
     if (!off || !ids || !n) return AVN_ERR_BAD_ARG;
     static const uint32_t none = 0;
     if (!pipe) { std::memset(off, 0, sizeof(uint32_t) * (AVN_GRAPH_COLOR_COUNT + 1)); *ids = &none; *n = 0; return AVN_OK; }
-    std::memcpy(off, pipe->offsets, sizeof pipe->offsets);
-    *ids = pipe->handles.data(); *n = pipe->handles.size();
+    std::memcpy(off, pipe->report_offsets, sizeof pipe->report_offsets);
+    *ids = pipe->report_handles.data(); *n = pipe->report_handles.size();
     return AVN_OK;
 }
 // GraphColor::manifold_handles of all colours, concatenated colour-major -> the solver's handle list (when the lists changed)
 template <class S> avn_status World<S>::pipeline_refresh_handles() {
     PipelineState& P = *pipe;
     if (!P.handles_dirty) return AVN_OK;
-    size_t n = 0;
-    P.handles.clear();
+    size_t n = 0, g = 0;
+    P.handles.clear(); P.report_handles.clear();
     for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) {
-        P.offsets[c] = (uint32_t)n;
-        for (const auto& h : P.graph.colors[c].manifold_handles) { P.handles.push_back((uint32_t)(h.handle >> 8)); ++n; }
+        P.offsets[c] = (uint32_t)n; P.report_offsets[c] = (uint32_t)g;
+        for (const auto& h : P.graph.colors[c].manifold_handles) {
+            P.report_handles.push_back((uint32_t)(h.handle >> 8)); ++g;   // what avn_pipeline_handles_get reports: the ConstraintGraph's lists (the whole world's on every rank of a shard)
+            if (dsh_on) {   // the solver's share: the manifolds of the bodies this rank simulates, order kept
+                const bool f1 = dsh_foreign(h.body1), f2 = dsh_foreign(h.body2);
+                const bool d1 = bodies[h.body1].rb_type != AVN_RB_STATIC, d2 = bodies[h.body2].rb_type != AVN_RB_STATIC;
+                if (d1 && d2 && f1 != f2) { error = "sharded closed loop: a manifold joins bodies of two ranks -- their islands have met"; return AVN_ERR_STATE; }
+                if ((d1 && f1) || (d2 && f2)) continue;
+            }
+            P.handles.push_back((uint32_t)(h.handle >> 8)); ++n;
+        }
     }
-    P.offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n;
+    P.offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)n; P.report_offsets[AVN_GRAPH_COLOR_COUNT] = (uint32_t)g;
+    dsh_own_manifolds = (uint32_t)n; dsh_global_manifolds = (uint32_t)g;
     avn_status st = manifold_handles_upload(P.offsets, P.handles.data());
     if (st != AVN_OK) return st;
     P.handles_dirty = false;
@@ -2395,7 +2471,7 @@ template <class S> void World<S>::sleeping_apply(bool count) {
     for (uint32_t b : M.bodies_slept) { bodies[b].body_flags |= AVN_BODY_SLEEPING; bodies[b].has_solver_body = false; }
     for (uint32_t b : M.bodies_woken) {
         bodies[b].body_flags &= (uint8_t)~AVN_BODY_SLEEPING;
-        bodies[b].has_solver_body = bodies[b].rb_type != AVN_RB_STATIC && bodies[b].active();
+        bodies[b].has_solver_body = bodies[b].rb_type != AVN_RB_STATIC && bodies[b].active() && !dsh_foreign(b);
         slp->timer[b] = 0.0f;   // sleep_timer.0 = 0.0 (sleeping.rs:492)
     }
     if (count) { slp->last_popped = (uint32_t)M.popped.size(); slp->last_pushed = (uint32_t)M.pushed.size(); }

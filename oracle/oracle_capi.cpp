@@ -88,6 +88,10 @@ avn_status avo_sleeping_stats_get(avn_world* w, avn_sleeping_stats* o) { FWD(sle
 avn_status avo_sleeping_state_get(avn_world* w, const avn_sleeping_out* o) { FWD(sleeping_state_get(o)); }
 avn_status avo_wake_bodies(avn_world* w, const uint32_t* ids, size_t n) { FWD(wake_bodies(ids, n)); }
 avn_status avo_despawn(avn_world* w, const avn_despawn_list* d) { FWD(despawn(d)); }
+avn_status avo_dshard_enable(avn_world* w, const avn_dshard_config* c) { FWD(dshard_enable(c)); }
+avn_status avo_dshard_bodies_pack(avn_world* w, void* out, size_t cap, size_t* bytes) { FWD(dshard_bodies_pack(out, cap, bytes)); }
+avn_status avo_dshard_bodies_unpack(avn_world* w, uint32_t from, const void* in, size_t bytes) { FWD(dshard_bodies_unpack(from, in, bytes)); }
+avn_status avo_dshard_stats_get(avn_world* w, avn_dshard_stats* o) { FWD(dshard_stats_get(o)); }
 // Checker for avn_level2_plan_* (header).  Deliberately organised the other way round from the product's planner: per colour a
 // body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
 // body in ascending index, so they come out sorted without sorting.
