@@ -237,7 +237,7 @@ template <class T> void launch_pg_add_pairs(const PG&, const CT<T>&, const avn_p
 // PGC_BUCKET must be zero when it starts (k_pg_build_handles leaves it so).
 // Sharded device closed loop (avn_dshard_enable, k_graph.hip / k_transfer.hip): this rank's share of every colour list, order kept (ctr[PGC_LLEN + c] <- its length; error bit 16:
 // a manifold joins bodies of two ranks); FOREIGN flags from the owner array; the own bodies' components packed for / unpacked from the per-step all-gather
-void launch_pg_local_lists(const PG&, const uint4* ct_meta, const int32_t* owner, uint32_t rank, uint32_t* local_lists, hipStream_t);
+void launch_pg_local_lists(const PG&, const uint4* ct_meta, const int32_t* owner, uint32_t rank, uint32_t* local_lists, uint32_t* chunk_counts /* [24][n_chunks] */, uint32_t n_chunks /* of 2 048 entries: covers the longest list */, hipStream_t);
 template <class T> void launch_dsh_set_foreign(const DW<T>&, const int32_t* owner, uint32_t rank, hipStream_t);
 template <class T> void launch_dsh_pack(const DW<T>&, const uint32_t* bodies, uint32_t n, void* out, hipStream_t);
 template <class T> void launch_dsh_unpack(const DW<T>&, const uint32_t* bodies, uint32_t n, const void* in, hipStream_t);

@@ -10,7 +10,7 @@
     std::vector<uint32_t> dsh_list, dsh_off;        // bodies by owner (ascending inside a rank), dsh_off[r] .. dsh_off[r + 1]
     uint32_t dsh_max_own = 0;
     bool dsh_island_enabled_before = true;
-    DevBuf b_dsh_owner, b_dsh_list, b_dsh_send, b_dsh_recv, b_dsh_local;
+    DevBuf b_dsh_owner, b_dsh_list, b_dsh_send, b_dsh_recv, b_dsh_local, b_dsh_cnt;
     avn_status dsh_apply_flags() {   // FOREIGN flags on the device + the host's "has a SolverBody" mirror
         launch_dsh_set_foreign<T>(dw, dsh_on ? b_dsh_owner.as<int32_t>() : nullptr, dsh_rank, stream); ++launches;
         HIPCHK(hipGetLastError());
@@ -60,11 +60,17 @@
         return dsh_apply_flags();
     }
     // the local lists live next to PG::lists, same stride
-    avn_status dsh_local_lists() {
+    avn_status dsh_local_lists(uint32_t n_ops) {
         hipError_t err;
         if (b_dsh_local.ensure((size_t)AVN_GRAPH_COLOR_COUNT * pg.list_stride * 4, err)) graph_valid = false;
         if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-        launch_pg_local_lists(pg, ct.meta, b_dsh_owner.as<int32_t>(), dsh_rank, b_dsh_local.as<uint32_t>(), stream); ++launches;
+        // chunks of 2 048 entries: a list is at most its length before the batch + the batch's ops long (the exact lengths are read on the device)
+        uint32_t longest = 0;
+        for (int c = 0; c < AVN_GRAPH_COLOR_COUNT; ++c) longest = std::max(longest, pgm_len[c]);
+        const uint32_t n_chunks = std::max(1u, (longest + n_ops + 2047u) / 2048u);
+        b_dsh_cnt.ensure((size_t)AVN_GRAPH_COLOR_COUNT * n_chunks * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        launch_pg_local_lists(pg, ct.meta, b_dsh_owner.as<int32_t>(), dsh_rank, b_dsh_local.as<uint32_t>(), b_dsh_cnt.as<uint32_t>(), n_chunks, stream); launches += 2;
         HIPCHK(hipGetLastError());
         return AVN_OK;
     }

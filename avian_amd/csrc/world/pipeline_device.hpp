@@ -278,7 +278,7 @@
                 launches += 3;
             }
             HIPCHK(hipGetLastError());
-            if (dsh_on && (st = dsh_local_lists()) != AVN_OK) return st;   // sharded closed loop: this rank's share of every colour list (ctr[PGC_LLEN ..])
+            if (dsh_on && (st = dsh_local_lists(n_ops)) != AVN_OK) return st;   // sharded closed loop: this rank's share of every colour list (ctr[PGC_LLEN ..])
             uint32_t* h = (uint32_t*)pin_ctr.p + 64;
             HIPCHK(hipMemcpyAsync(h, pg.ctr, 64 * 4, hipMemcpyDeviceToHost, stream));   // the counters block up to the colours' lengths, in one copy
             if (dsh_on) HIPCHK(hipMemcpyAsync(h + 64, pg.ctr + PGC_LLEN, AVN_GRAPH_COLOR_COUNT * 4, hipMemcpyDeviceToHost, stream));
