@@ -259,7 +259,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -310,6 +310,8 @@ class Library:
         f("level2_plan_destroy").argtypes = [vp]
         f("level2_plan_destroy").restype = None
         f("level2_plan_rank").argtypes = [vp, C.c_uint32, C.POINTER(avn_level2_rank)]
+        f("level2_plan_rank_overflow").argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32))]
+        f("halo_overflow_levels_upload").argtypes = [vp, C.c_uint32, vp, C.c_size_t]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
         f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
@@ -405,14 +407,15 @@ class Library:
         return out[: n.value].astype(np.int64)
 
     def level2_plan(self, rb_type, center_x, body1, body2, color_offsets, n_ranks: int):
-        """``avn_level2_plan_*``: per rank a dict(bodies, manifolds, color_offsets, peers, send_offsets, send_bodies, recv_offsets, recv_bodies)."""
+        """``avn_level2_plan_*``: per rank a dict(bodies, manifolds, color_offsets, peers, send_offsets, send_bodies, recv_offsets, recv_bodies, n_overflow_levels,
+        overflow_level).  Exchange slots: 23 colours + n_overflow_levels (1 unless an overflow-colour manifold touches a shared body)."""
         rb = np.ascontiguousarray(rb_type, np.uint8); cx = np.ascontiguousarray(center_x, np.float64)
         b1 = np.ascontiguousarray(body1, np.int32); b2 = np.ascontiguousarray(body2, np.int32); co = np.ascontiguousarray(color_offsets, np.uint32)
         inp = avn_level2_in(len(rb), _ptr(rb), _ptr(cx), len(b1), _ptr(b1), _ptr(b2), _ptr(co), int(n_ranks))
         h = vp()
         st = self.fn("level2_plan_create")(C.byref(inp), C.byref(h))
         if st != 0:
-            raise AvnError(st, "level2_plan: refused (an overflow-colour manifold on a shared body, or bad indices)")
+            raise AvnError(st, "level2_plan: refused (bad indices)")
         try:
             out = []
             for r in range(n_ranks):
@@ -422,12 +425,18 @@ class Library:
                     raise AvnError(st, "level2_plan_rank")
                 arr = lambda p, n, t: np.ctypeslib.as_array(p, shape=(n,)).astype(t).copy() if n else np.zeros(0, t)
                 npeers = k.halo.n_peers
-                nl = 24 * npeers + 1 if npeers else 1
+                nlev = C.c_uint32(); lev_p = C.POINTER(C.c_uint32)()
+                st = self.fn("level2_plan_rank_overflow")(h, r, C.byref(nlev), C.byref(lev_p))
+                if st != 0:
+                    raise AvnError(st, "level2_plan_rank_overflow")
+                nl = (23 + nlev.value) * npeers + 1 if npeers else 1
+                n_ovf = int(k.color_offsets[24] - k.color_offsets[23])
                 so = arr(C.cast(k.halo.send_offsets, C.POINTER(C.c_uint32)), nl, np.uint32); ro = arr(C.cast(k.halo.recv_offsets, C.POINTER(C.c_uint32)), nl, np.uint32)
                 out.append(dict(bodies=arr(k.bodies, k.n_bodies, np.int64), manifolds=arr(k.manifolds, k.n_manifolds, np.int64), color_offsets=arr(k.color_offsets, 25, np.uint32),
                                 peers=arr(C.cast(k.halo.peer_rank, C.POINTER(C.c_int32)), npeers, np.int32), send_offsets=so,
                                 send_bodies=arr(C.cast(k.halo.send_bodies, C.POINTER(C.c_int32)), int(so[-1]), np.int32), recv_offsets=ro,
-                                recv_bodies=arr(C.cast(k.halo.recv_bodies, C.POINTER(C.c_int32)), int(ro[-1]), np.int32)))
+                                recv_bodies=arr(C.cast(k.halo.recv_bodies, C.POINTER(C.c_int32)), int(ro[-1]), np.int32),
+                                n_overflow_levels=int(nlev.value), overflow_level=arr(lev_p, n_ovf, np.uint32)))
             return out
         finally:
             self.fn("level2_plan_destroy")(h)
@@ -813,6 +822,11 @@ class World:
         self._check(self.lib.fn("synchronize")(self.handle))
 
     # -- level-2 sharding (one island over several worlds) -----------------------------------------------------------------
+    def halo_overflow_levels_upload(self, n_levels: int, level_of):
+        """``avn_halo_overflow_levels_upload``: call BEFORE halo_plan_upload when the planner cut the overflow colour into levels."""
+        lv = np.ascontiguousarray(level_of, np.uint32)
+        self._check(self.lib.fn("halo_overflow_levels_upload")(self.handle, int(n_levels), _ptr(lv), len(lv)))
+
     def halo_plan_upload(self, peers, send_offsets, send_bodies, recv_offsets, recv_bodies):
         peers = np.ascontiguousarray(peers, np.int32)
         so = np.ascontiguousarray(send_offsets, np.uint32); sb = np.ascontiguousarray(send_bodies, np.int32)

@@ -146,6 +146,7 @@ AVN_API avn_status avn_islands_partition(const avn_islands_in* in, int32_t* isla
 }
 
 AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD_MUT(halo_plan_upload(p)); }
+AVN_API avn_status avn_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { GUARD_MUT(halo_overflow_levels_upload(n_levels, level_of, count)); }
 AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD_MUT(run_color_pass(pass, color)); }
 AVN_API avn_status avn_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { GUARD(halo_pack(color, peer, out, count)); }
 AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD_MUT(halo_unpack(color, peer, in, count)); }

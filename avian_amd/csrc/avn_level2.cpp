@@ -15,7 +15,9 @@ struct avn_level2_plan {
         std::vector<uint32_t> manifolds, color_offsets;
         std::vector<int32_t> peers, send_bodies, recv_bodies;
         std::vector<uint32_t> send_offsets, recv_offsets;
+        std::vector<uint32_t> overflow_level;   // per local overflow manifold (local order): its level in the GLOBAL overflow list, 0-based
     };
+    uint32_t n_overflow_levels = 1;
     std::vector<Rank> ranks;
 };
 
@@ -59,33 +61,57 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
             for (uint32_t r = 0; r < R; ++r) k += held[r][b];
             shared[b] = k > 1;
         }
-        // sends[s][c][r] = global bodies rank s hands to rank r after colour c
-        std::vector<std::vector<std::map<uint32_t, std::vector<int32_t>>>> sends(R, std::vector<std::map<uint32_t, std::vector<int32_t>>>(C));
+        // Exchange SLOTS: slot c < 23 = colour c.  The overflow colour is solved serially in list order (solver/plugin.rs:461-467); only the relative order of manifolds
+        // that share a body matters, so it is cut into LEVELS over the GLOBAL list -- level(m) = 1 + the highest level of an earlier overflow manifold on one of m's
+        // non-static bodies; manifolds of one level share no body -- and slot 23 + l = level l: every world runs its own manifolds of the level, then the shared bodies they
+        // moved travel, exactly as after a colour.  (Round 5 refused an overflow manifold on a shared body.)  Without one, the overflow colour stays ONE slot (23).
+        const uint32_t o0 = in->color_offsets[AVN_COLOR_OVERFLOW_INDEX], o1 = in->color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
+        bool ovf_shared = false;
+        for (uint32_t m = o0; m < o1 && !ovf_shared; ++m) ovf_shared = shared[in->body1[m]] || shared[in->body2[m]];
+        std::vector<uint32_t> level(o1 - o0, 0u);
+        uint32_t n_levels = 1;
+        if (ovf_shared) {
+            std::vector<uint32_t> last(N, 0u);
+            n_levels = 0;
+            for (uint32_t m = o0; m < o1; ++m) {
+                const uint32_t a = (uint32_t)in->body1[m], b = (uint32_t)in->body2[m];
+                const uint32_t lv = 1u + std::max(is_static(a) ? 0u : last[a], is_static(b) ? 0u : last[b]);
+                if (!is_static(a)) last[a] = lv;
+                if (!is_static(b)) last[b] = lv;
+                level[m - o0] = lv - 1u;
+                n_levels = std::max(n_levels, lv);
+            }
+            n_levels = std::max(n_levels, 1u);
+        }
+        const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels;
+        auto slot_of = [&](uint32_t c, uint32_t m) { return c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX ? (uint32_t)AVN_COLOR_OVERFLOW_INDEX + level[m - o0] : c; };
+        // sends[s][slot][r] = global bodies rank s hands to rank r after the slot
+        std::vector<std::vector<std::map<uint32_t, std::vector<int32_t>>>> sends(R, std::vector<std::map<uint32_t, std::vector<int32_t>>>(S));
         for (uint32_t c = 0; c < C; ++c)
             for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m) {
-                const uint32_t s = (uint32_t)m_owner[m];
+                const uint32_t s = (uint32_t)m_owner[m], slot = slot_of(c, m);
                 const int32_t bb[2] = {in->body1[m], in->body2[m]};
                 for (int32_t b : bb) {
                     if (!shared[b]) continue;
-                    if (c == AVN_COLOR_OVERFLOW_INDEX) return AVN_ERR_BAD_ARG;   // solved serially across worlds: not supported
-                    for (uint32_t r = 0; r < R; ++r) if (r != s && held[r][b]) sends[s][c][r].push_back(b);
+                    for (uint32_t r = 0; r < R; ++r) if (r != s && held[r][b]) sends[s][slot][r].push_back(b);
                 }
             }
         avn_level2_plan* pl = new avn_level2_plan;
         pl->ranks.resize(R);
+        pl->n_overflow_levels = n_levels;
         for (uint32_t r = 0; r < R; ++r) {
             avn_level2_plan::Rank& k = pl->ranks[r];
             std::vector<int32_t> g2l(N, -1);
             for (uint32_t b = 0; b < N; ++b) if (held[r][b]) { g2l[b] = (int32_t)k.bodies.size(); k.bodies.push_back((int32_t)b); }
             std::vector<uint8_t> is_peer(R, 0);
-            for (uint32_t c = 0; c < C; ++c) {
+            for (uint32_t c = 0; c < S; ++c) {
                 for (auto& kv : sends[r][c]) is_peer[kv.first] = 1;
                 for (uint32_t s = 0; s < R; ++s) if (s != r && sends[s][c].count(r)) is_peer[s] = 1;
             }
             for (uint32_t p = 0; p < R; ++p) if (is_peer[p]) k.peers.push_back((int32_t)p);
             k.send_offsets.push_back(0); k.recv_offsets.push_back(0);
             if (!k.peers.empty())
-                for (uint32_t c = 0; c < C; ++c)
+                for (uint32_t c = 0; c < S; ++c)
                     for (int32_t p : k.peers) {
                         std::vector<int32_t> a, b;
                         auto it = sends[r][c].find((uint32_t)p); if (it != sends[r][c].end()) a = it->second;
@@ -97,7 +123,8 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
                     }
             k.color_offsets.assign(C + 1, 0);
             for (uint32_t c = 0; c < C; ++c) {
-                for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m) if ((uint32_t)m_owner[m] == r) k.manifolds.push_back(m);
+                for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m)
+                    if ((uint32_t)m_owner[m] == r) { k.manifolds.push_back(m); if (c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX) k.overflow_level.push_back(level[m - o0]); }
                 k.color_offsets[c + 1] = (uint32_t)k.manifolds.size();
             }
         }
@@ -195,6 +222,13 @@ AVN_API avn_status avn_level2_plan_rank(const avn_level2_plan* plan, uint32_t ra
     out->halo.n_peers = (uint32_t)k.peers.size(); out->halo.peer_rank = k.peers.data();
     out->halo.send_offsets = k.send_offsets.data(); out->halo.send_bodies = k.send_bodies.data();
     out->halo.recv_offsets = k.recv_offsets.data(); out->halo.recv_bodies = k.recv_bodies.data();
+    return AVN_OK;
+}
+
+AVN_API avn_status avn_level2_plan_rank_overflow(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_levels, const uint32_t** level_of_local_overflow_manifold) {
+    if (!plan || rank >= plan->ranks.size() || !n_levels || !level_of_local_overflow_manifold) return AVN_ERR_BAD_ARG;
+    *n_levels = plan->n_overflow_levels;
+    *level_of_local_overflow_manifold = plan->ranks[rank].overflow_level.data();
     return AVN_OK;
 }
 

@@ -7,8 +7,42 @@
     // (list k = colour * n_peers + peer), so a colour costs one pack launch, one grouped RCCL send/recv and one unpack launch.
     struct HaloPlan {
         std::vector<int32_t> peers, send, recv;
-        std::vector<uint32_t> send_off, recv_off;   // [24 * n_peers + 1]
+        std::vector<uint32_t> send_off, recv_off;   // [n_slots * n_peers + 1]
     } halo;
+    // exchange slots: colours 0..22, then the overflow colour -- ONE slot (the world's whole overflow colour), or one per level of the GLOBAL overflow list when a
+    // manifold of it touches a shared body (avn_halo_overflow_levels_upload; round 6).  l2_order = this world's overflow manifolds grouped by level, l2_off[l] the groups.
+    uint32_t l2_levels = 1;
+    std::vector<uint32_t> l2_level_of, l2_order, l2_off;
+    DevBuf b_l2_order;
+    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
+    avn_status halo_overflow_levels_upload(uint32_t n_levels, const uint32_t* level_of, size_t count) override {
+        if (count && !level_of) { error = "halo_overflow_levels_upload: null array"; return AVN_ERR_BAD_ARG; }
+        for (size_t i = 0; i < count; ++i) if (level_of[i] >= std::max(n_levels, 1u)) { error = "halo_overflow_levels_upload: level out of range"; return AVN_ERR_BAD_ARG; }
+        HIPCHK(hipStreamSynchronize(stream));
+        l2_levels = std::max(n_levels, 1u);
+        l2_level_of.assign(level_of, level_of + count);
+        halo = HaloPlan(); halo_on = false;   // (a plan uploaded before counted other slots)
+        drop_graph();
+        return AVN_OK;
+    }
+    // this world's overflow manifolds grouped by level (a counting sort: list order inside a level, though manifolds of a level share no body)
+    avn_status l2_build_levels() {
+        const uint32_t o0 = color_offsets[AVN_COLOR_OVERFLOW_INDEX], n23 = color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - o0;
+        if (l2_level_of.size() != n23) { error = "level-2: avn_halo_overflow_levels_upload named " + std::to_string(l2_level_of.size()) + " overflow manifolds, the world holds " + std::to_string(n23); return AVN_ERR_STATE; }
+        l2_off.assign(l2_levels + 1, 0u);
+        for (uint32_t l : l2_level_of) ++l2_off[l + 1];
+        for (uint32_t l = 0; l < l2_levels; ++l) l2_off[l + 1] += l2_off[l];
+        l2_order.resize(n23);
+        std::vector<uint32_t> cur(l2_off.begin(), l2_off.end() - 1);
+        for (uint32_t i = 0; i < n23; ++i) l2_order[cur[l2_level_of[i]]++] = o0 + i;
+        hipError_t err;
+        b_l2_order.ensure(std::max<size_t>(n23, 1) * 4, err);
+        if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        if (n23) HIPCHK(hipMemcpy(b_l2_order.p, l2_order.data(), (size_t)n23 * 4, hipMemcpyHostToDevice));
+        l2_built_for = dw.n_manifolds;
+        return AVN_OK;
+    }
+    uint32_t l2_built_for = 0xFFFFFFFFu;
     DevBuf b_halo_send, b_halo_recv, b_halo_out, b_halo_in;
     bool halo_on = false;
 #ifdef AVN_MEASURE   // measurement build only (make measure): the default library has no switch that changes results
@@ -20,7 +54,7 @@
     std::vector<CommXfer> xf_send, xf_recv;
     avn_status halo_plan_upload(const avn_halo_plan* p) override {
         if (!p) { error = "halo_plan_upload: null plan"; return AVN_ERR_BAD_ARG; }
-        const size_t n = (size_t)AVN_GRAPH_COLOR_COUNT * p->n_peers;
+        const size_t n = (size_t)halo_slots() * p->n_peers;
         if (p->n_peers && (!p->peer_rank || !p->send_offsets || !p->recv_offsets)) { error = "halo_plan_upload: null array"; return AVN_ERR_BAD_ARG; }
         HaloPlan h;
         if (p->n_peers) {
@@ -51,10 +85,22 @@
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
-    // one colour of one contact pass, in the single-world launch shape (overflow colour: the host schedule's launches)
+    // one colour of one contact pass, in the single-world launch shape (overflow colour: the host schedule's launches); slot >= 23 with levels: ONE level of the overflow colour
     avn_status color_pass_enqueue(int pass, uint32_t color) {
-        if (!dw.n_manifolds || !grid_blocks[color]) return AVN_OK;
         if (pipe_dev) { error = "level-2 colour passes need host-uploaded manifolds (not the device closed loop)"; return AVN_ERR_STATE; }
+        if (l2_levels > 1 && color >= (uint32_t)AVN_COLOR_OVERFLOW_INDEX) {
+            if (!dw.n_manifolds) return AVN_OK;
+            if (l2_built_for != dw.n_manifolds || l2_off.size() != l2_levels + 1) { avn_status sb = l2_build_levels(); if (sb != AVN_OK) return sb; }
+            const uint32_t l = color - (uint32_t)AVN_COLOR_OVERFLOW_INDEX;
+            if (l2_off[l + 1] == l2_off[l]) return AVN_OK;   // none of this world's manifolds in the level
+            uint32_t gb[AVN_GRAPH_COLOR_COUNT] = {0};
+            gb[AVN_COLOR_OVERFLOW_INDEX] = 1;
+            OverflowSchedule ovf{0, nullptr, nullptr, nullptr, b_l2_order.as<uint32_t>(), l2_off.data() + l, 1};   // one device-wide launch over the level's manifolds
+            launches += launch_contact_pass<T>(dw, params, pass, gb, use_handles ? nullptr : color_offsets, ovf, stream);
+            return AVN_OK;
+        }
+        if (color >= AVN_GRAPH_COLOR_COUNT) return AVN_OK;
+        if (!dw.n_manifolds || !grid_blocks[color]) return AVN_OK;
         uint32_t gb[AVN_GRAPH_COLOR_COUNT] = {0};
         gb[color] = grid_blocks[color];
         OverflowSchedule ovf{0, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
@@ -80,7 +126,7 @@
         }
     }
     avn_status run_color_pass(avn_system sys, uint32_t color) override {
-        if (color >= AVN_GRAPH_COLOR_COUNT) { error = "run_color_pass: colour out of range"; return AVN_ERR_BAD_ARG; }
+        if (color >= halo_slots()) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
         const int pass = color_pass_of(sys);
         if (pass < 0) { error = "run_color_pass: not a contact pass"; return AVN_ERR_BAD_ARG; }
         avn_status st = need_bodies();
@@ -93,7 +139,7 @@
         return AVN_OK;
     }
     avn_status halo_list(uint32_t color, uint32_t peer, const std::vector<uint32_t>& off, size_t* b0, size_t* b1) {
-        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size()) { error = "halo: colour or peer out of range"; return AVN_ERR_BAD_ARG; }
+        if (color >= halo_slots() || peer >= halo.peers.size()) { error = "halo: colour / slot or peer out of range"; return AVN_ERR_BAD_ARG; }
         const size_t k = (size_t)color * halo.peers.size() + peer;
         *b0 = off[k]; *b1 = off[k + 1];
         return AVN_OK;
@@ -182,8 +228,9 @@
     uint32_t halo_exchanges = 0;
     // one contact pass in level-2 form: colours in solve order (overflow first), exchange after each
     avn_status level2_pass(int pass) {
-        static const auto order = [] { std::array<uint32_t, AVN_GRAPH_COLOR_COUNT> o; o[0] = AVN_COLOR_OVERFLOW_INDEX; for (uint32_t c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) o[c + 1] = c; return o; }();
-        for (uint32_t c : order) {
+        // solve order: the overflow colour first (its levels in order), then colours 0..22
+        for (uint32_t k = 0; k < halo_slots(); ++k) {
+            const uint32_t c = k < l2_levels ? (uint32_t)AVN_COLOR_OVERFLOW_INDEX + k : k - l2_levels;
             avn_status st = color_pass_enqueue(pass, c);
             if (st == AVN_OK) st = halo_exchange(c);
             if (st != AVN_OK) return st;

@@ -401,10 +401,26 @@ class Level2Rank:
     manifolds: np.ndarray         # global manifold indices (colour-major order of the global set)
     color_offsets: np.ndarray     # [25] local colour offsets
     peers: np.ndarray             # ranks this world exchanges with
-    send_offsets: np.ndarray      # [24 * n_peers + 1]
+    send_offsets: np.ndarray      # [(23 + n_overflow_levels) * n_peers + 1]: exchange SLOT-major (slot c < 23 = colour c, slot 23 + l = overflow level l)
     send_bodies: np.ndarray       # LOCAL body indices
     recv_offsets: np.ndarray
     recv_bodies: np.ndarray
+    n_overflow_levels: int = 1    # > 1: the overflow colour is cut into levels of the GLOBAL list (an overflow manifold touches a shared body)
+    overflow_level: np.ndarray = None   # [this world's overflow manifolds, local order] level of each
+
+    @property
+    def n_slots(self) -> int:
+        return F.COLOR_OVERFLOW_INDEX + self.n_overflow_levels
+
+    def solve_order(self):
+        """Exchange slots in solve order: the overflow colour first (solver/plugin.rs:461-467), level by level, then colours 0..22."""
+        return [F.COLOR_OVERFLOW_INDEX + l for l in range(self.n_overflow_levels)] + list(range(F.COLOR_OVERFLOW_INDEX))
+
+    def upload(self, world):
+        """avn_halo_overflow_levels_upload (when levelled) + avn_halo_plan_upload."""
+        if self.n_overflow_levels > 1:
+            world.halo_overflow_levels_upload(self.n_overflow_levels, self.overflow_level)
+        world.halo_plan_upload(self.peers, self.send_offsets, self.send_bodies, self.recv_offsets, self.recv_bodies)
 
 
 def level2_plan_lib(lib: F.Library, position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray,
@@ -417,7 +433,8 @@ def level2_plan_lib(lib: F.Library, position: np.ndarray, rb_type: np.ndarray, b
     except F.AvnError as e:
         raise ValueError(str(e))
     for k in ranks:
-        out.append(Level2Rank(k["bodies"], k["manifolds"], k["color_offsets"], k["peers"], k["send_offsets"], k["send_bodies"], k["recv_offsets"], k["recv_bodies"]))
+        out.append(Level2Rank(k["bodies"], k["manifolds"], k["color_offsets"], k["peers"], k["send_offsets"], k["send_bodies"], k["recv_offsets"], k["recv_bodies"],
+                              k["n_overflow_levels"], k["overflow_level"]))
     return out
 
 
@@ -446,47 +463,64 @@ def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, bo
         held[r][b1[mine]] = True; held[r][b2[mine]] = True
     held = np.stack(held)                                 # [R, n]
     shared = moving & (held.sum(0) > 1)
-    # per colour: the rank that moves each shared body, and who needs it
-    sends = [[{} for _ in range(len(offs) - 1)] for _ in range(world_size)]   # sends[s][c][r] = [global body ...]
+    # Exchange slots: colours 0..22, then the overflow colour -- one slot, or (when one of its manifolds touches a shared body) one slot per LEVEL of the global
+    # list: the reference walks it serially (solver/plugin.rs:461-467) and only the relative order of manifolds sharing a body matters, so
+    # level(m) = the number of overflow manifolds in front of m on the deepest chain through its non-static bodies; manifolds of one level share no body.
+    n_col = len(offs) - 2
+    o0, o1 = int(offs[n_col]), int(offs[n_col + 1])
     touches = shared[b1] | shared[b2]                     # (only manifolds on a shared body take part in the exchange)
-    for c in range(len(offs) - 1):
+    level = np.zeros(o1 - o0, np.int64)
+    n_levels = 1
+    if touches[o0:o1].any():
+        depth = np.zeros(n, np.int64)
+        for m in range(o0, o1):
+            bb = [b for b in (int(b1[m]), int(b2[m])) if not static[b]]
+            d = max((int(depth[b]) for b in bb), default=0)
+            level[m - o0] = d
+            for b in bb:
+                depth[b] = d + 1
+            n_levels = max(n_levels, d + 1)
+    n_slots = n_col + n_levels
+    sends = [[{} for _ in range(n_slots)] for _ in range(world_size)]   # sends[s][slot][r] = [global body ...]
+    for c in range(n_col + 1):
         for m in (np.flatnonzero(touches[offs[c]:offs[c + 1]]) + offs[c]).tolist():
             s = int(m_owner[m])
+            slot = c if c < n_col else n_col + int(level[m - o0])
             for b in (int(b1[m]), int(b2[m])):
                 if not shared[b]:
                     continue
-                if c == len(offs) - 2:
-                    raise ValueError("level2_plan: an overflow-colour manifold touches a body shared between slabs (solved serially across worlds: not supported)")
                 for r in np.flatnonzero(held[:, b]):
                     if r != s:
-                        sends[s][c].setdefault(int(r), []).append(b)
+                        sends[s][slot].setdefault(int(r), []).append(b)
     out = []
     for r in range(world_size):
         bodies = np.flatnonzero(held[r])
         g2l = np.full(n, -1, np.int64); g2l[bodies] = np.arange(len(bodies))
-        peers = sorted({p for c in range(len(offs) - 1) for p in sends[r][c]} | {s for s in range(world_size) if s != r and any(r in sends[s][c] for c in range(len(offs) - 1))})
+        peers = sorted({p for c in range(n_slots) for p in sends[r][c]} | {s for s in range(world_size) if s != r and any(r in sends[s][c] for c in range(n_slots))})
         so, sb, ro, rb = [0], [], [0], []
-        for c in range(len(offs) - 1):
+        for c in range(n_slots):
             for p in peers:
                 lst = sorted(sends[r][c].get(p, [])); sb.extend(g2l[lst].tolist()); so.append(len(sb))
                 lst = sorted(sends[p][c].get(r, [])); rb.extend(g2l[lst].tolist()); ro.append(len(rb))
         mine = m_of[r]
         local_offs = np.concatenate([[0], np.cumsum(np.bincount(color_of[mine], minlength=len(offs) - 1))])
         out.append(Level2Rank(bodies, mine, local_offs.astype(np.uint32), np.asarray(peers, np.int32), np.asarray(so if peers else [0], np.uint32), np.asarray(sb, np.int32),
-                              np.asarray(ro if peers else [0], np.uint32), np.asarray(rb, np.int32)))
+                              np.asarray(ro if peers else [0], np.uint32), np.asarray(rb, np.int32), n_levels, level[mine[mine >= o0] - o0].astype(np.uint32)))
     return out
 
 
 def level2_local_manifolds(rank: Level2Rank, manifolds: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
     """The rank's rows of a global manifold dict (arrays whose first dimension is the manifold count), bodies re-indexed."""
     n = len(manifolds["body1"])
-    g2l = {int(g): i for i, g in enumerate(rank.bodies)}
+    bodies = np.asarray(rank.bodies, np.int64)
+    g2l = np.full(int(bodies.max()) + 1 if len(bodies) else 1, -1, np.int64); g2l[bodies] = np.arange(len(bodies))
     out = {}
     for k, v in manifolds.items():
         a = np.asarray(v) if v is not None else None
         out[k] = a[rank.manifolds] if a is not None and a.ndim >= 1 and len(a) == n else v
-    out["body1"] = np.asarray([g2l[int(b)] for b in out["body1"]], np.int32)
-    out["body2"] = np.asarray([g2l[int(b)] for b in out["body2"]], np.int32)
+    out["body1"] = g2l[np.asarray(out["body1"], np.int64)].astype(np.int32)
+    out["body2"] = g2l[np.asarray(out["body2"], np.int64)].astype(np.int32)
+    assert (out["body1"] >= 0).all() and (out["body2"] >= 0).all(), "a rank's manifold names a body the rank does not hold"
     return out
 
 
@@ -494,9 +528,9 @@ CONTACT_PASSES = ("WARM_START", "SOLVE_CONTACTS_BIAS", "SOLVE_CONTACTS_RELAX", "
 
 
 def level2_pass(world, rank: Level2Rank, system: str, exchange):
-    """One contact pass, colour by colour in solve order (overflow first), with the halo exchange after every colour.
-    exchange(color, {peer_index: records to send}) -> {peer_index: records received}."""
-    for c in [F.COLOR_OVERFLOW_INDEX] + list(range(F.COLOR_OVERFLOW_INDEX)):
+    """One contact pass, slot by slot in solve order (the overflow colour first -- level by level when the planner cut it --, then colours 0..22), with the halo
+    exchange after every slot.  exchange(slot, {peer_index: records to send}) -> {peer_index: records received}."""
+    for c in rank.solve_order():
         world.run_color_pass(system, c)
         if len(rank.peers) == 0:
             continue

@@ -725,6 +725,14 @@ def main():
                                                                steps=5, warmup=2, check_steps=2, bits=64)
                 except Exception as e:  # noqa: BLE001
                     level2["cfg5_500k_f64"] = {"status": "error: " + str(e)[:300]}
+                # round 6: the REAL cfg5 -- the closed loop's own manifolds 6 steps into the collapse (~ 1.7 * 10^5 of them in the overflow colour, on bodies shared
+                # between slabs): the overflow colour travels level by level (hundreds of exchange slots per pass: a latency chain, reported as measured)
+                if os.environ.get("AVN_BENCH_LEVEL2_CFG5_CLOSED_LOOP", "1") != "0":
+                    try:
+                        level2["cfg5_500k_f64_closed_loop_manifolds"] = level2_bench.run(lib, rank, world_size, local_rank, bcast, armax, dist.barrier, dims=(100, 50, 100), substeps=8,
+                                                                                         steps=3, warmup=1, check_steps=1, bits=64, closed_loop_steps=6)
+                    except Exception as e:  # noqa: BLE001
+                        level2["cfg5_500k_f64_closed_loop_manifolds"] = {"status": "error: " + str(e)[:300]}
         except Exception as e:  # noqa: BLE001 -- reported in the line, never fatal for the headline figure
             level2 = {"status": "error: " + str(e)[:300]}
         done.set()

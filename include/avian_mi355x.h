@@ -601,6 +601,13 @@ typedef struct avn_halo_plan {
     const int32_t* recv_bodies;
 } avn_halo_plan;
 AVN_API avn_status AVN_FN(halo_plan_upload)(avn_world* w, const avn_halo_plan* plan);
+/* Round 6: the overflow colour ACROSS worlds.  The reference solves it serially in list order (solver/plugin.rs:461-467); only the relative order of manifolds that share
+ * a body matters, so the planner cuts the GLOBAL list into levels (level(m) = 1 + the highest level of an earlier overflow manifold on one of m's non-static bodies) and
+ * every level becomes an exchange SLOT behind the colours: slot c < 23 = colour c, slot 23 + l = overflow level l.  avn_halo_overflow_levels_upload tells a world the
+ * number of levels and the level of each of ITS overflow manifolds (local order); call it BEFORE avn_halo_plan_upload, whose offset arrays then hold
+ * (23 + n_levels) * n_peers + 1 entries.  Never called (or n_levels <= 1): 24 slots, slot 23 = the world's whole overflow colour, as before.  In avn_run_color_pass /
+ * avn_halo_pack / avn_halo_unpack `color` is the slot. */
+AVN_API avn_status AVN_FN(halo_overflow_levels_upload)(avn_world* w, uint32_t n_levels, const uint32_t* level_of_local_overflow_manifold, size_t count);
 AVN_API avn_status AVN_FN(run_color_pass)(avn_world* w, avn_system pass, uint32_t color);
 AVN_API avn_status AVN_FN(halo_pack)(avn_world* w, uint32_t color, uint32_t peer, void* out /* [8 * count] scalars */, size_t* count);
 AVN_API avn_status AVN_FN(halo_unpack)(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count);
@@ -630,7 +637,9 @@ AVN_API avn_status AVN_FN(interval_orders_merge)(uint32_t n_lists, const uint32_
  * send / receive lists -- everything avn_halo_plan_upload and the per-rank uploads need, so that a host in any language shards without
  * re-implementing it.  Slabs are cut at the quantiles of the non-static bodies' x; a manifold belongs to the slab of its body1 (body2 when
  * body1 is static); a body is SHARED when more than one world holds it; lists are in ascending global body index (the same order on both
- * sides of every pair of ranks).  AVN_ERR_BAD_ARG when an overflow-colour manifold touches a shared body. */
+ * sides of every pair of ranks).  When an overflow-colour manifold touches a shared body the overflow colour is cut into levels (avn_halo_overflow_levels_upload) and
+ * halo.send_offsets / recv_offsets hold (23 + n_levels) * n_peers + 1 entries -- avn_level2_plan_rank_overflow returns n_levels (1: the plain 24 slots) and the levels of
+ * the rank's overflow manifolds.  Joints are not planned: a joint between bodies of two worlds is still the host's to refuse. */
 typedef struct avn_level2_in {
     uint32_t n_bodies;
     const uint8_t* rb_type;        /* [n_bodies] AVN_RB_* */
@@ -651,6 +660,7 @@ typedef struct avn_level2_plan avn_level2_plan;
 AVN_API avn_status AVN_FN(level2_plan_create)(const avn_level2_in* in, avn_level2_plan** out);
 AVN_API void AVN_FN(level2_plan_destroy)(avn_level2_plan* plan);
 AVN_API avn_status AVN_FN(level2_plan_rank)(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out);
+AVN_API avn_status AVN_FN(level2_plan_rank_overflow)(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_levels, const uint32_t** level_of_local_overflow_manifold /* [rank's overflow manifolds] */);
 #define AVN_COMM_ID_BYTES 128
 AVN_API avn_status AVN_FN(comm_unique_id)(uint8_t* out /* [AVN_COMM_ID_BYTES] */);
 AVN_API avn_status AVN_FN(comm_init)(avn_world* w, const uint8_t* unique_id, int n_ranks, int rank);

@@ -292,6 +292,7 @@ struct WorldBase {
     virtual avn_status sleep_get(const avn_sleep_out*) = 0;
     virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
+    virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
     virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
     virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
@@ -948,9 +949,14 @@ template <class S> struct World : WorldBase {
     // ... the constraints of one colour 0..22 touch disjoint bodies: par_for_each(&mut color.contact_constraints, 64, ..)
     // (plugin.rs:476,564,662)
     int only_color = -1;   // >= 0: the pass functions below visit this colour only (avn_run_color_pass, level-2 sharding)
+    int only_level = -1;   // with only_color == overflow and levels uploaded (avn_halo_overflow_levels_upload): this level of the overflow colour only, in list order
+    std::vector<uint32_t> l2_level_of;
+    uint32_t l2_levels = 1;
     template <class F> void for_each_constraint_in_solver_order(F f) {
-        if (only_color < 0 || only_color == AVN_COLOR_OVERFLOW_INDEX)
-            for (ContactConstraint<S>& k : color_constraints[AVN_COLOR_OVERFLOW_INDEX]) f(k);
+        if (only_color < 0 || only_color == AVN_COLOR_OVERFLOW_INDEX) {
+            std::vector<ContactConstraint<S>>& ov = color_constraints[AVN_COLOR_OVERFLOW_INDEX];
+            for (size_t i = 0; i < ov.size(); ++i) if (only_level < 0 || (i < l2_level_of.size() && (int)l2_level_of[i] == only_level)) f(ov[i]);
+        }
         for (int c = 0; c < AVN_COLOR_OVERFLOW_INDEX; ++c) {
             if (only_color >= 0 && only_color != c) continue;
             std::vector<ContactConstraint<S>>& v = color_constraints[c];
@@ -1988,9 +1994,18 @@ template <class S> struct World : WorldBase {
     }
     // ---- level-2 sharding (header: avn_halo_plan) ----
     struct Halo { std::vector<int32_t> peers; std::vector<uint32_t> send_off, recv_off; std::vector<int32_t> send, recv; } halo;
+    avn_status halo_overflow_levels_upload(uint32_t n_levels, const uint32_t* level_of, size_t count) override {
+        if (count && !level_of) { error = "halo_overflow_levels_upload: null array"; return AVN_ERR_BAD_ARG; }
+        for (size_t i = 0; i < count; ++i) if (level_of[i] >= std::max(n_levels, 1u)) { error = "halo_overflow_levels_upload: level out of range"; return AVN_ERR_BAD_ARG; }
+        l2_levels = std::max(n_levels, 1u);
+        l2_level_of.assign(level_of, level_of + count);
+        halo = Halo();
+        return AVN_OK;
+    }
+    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
     avn_status halo_plan_upload(const avn_halo_plan* p) override {
         if (!p) return AVN_ERR_BAD_ARG;
-        const size_t n = (size_t)AVN_GRAPH_COLOR_COUNT * p->n_peers;
+        const size_t n = (size_t)halo_slots() * p->n_peers;
         if (p->n_peers && (!p->peer_rank || !p->send_offsets || !p->recv_offsets)) { error = "halo_plan_upload: null array"; return AVN_ERR_BAD_ARG; }
         halo.peers.assign(p->peer_rank, p->peer_rank + p->n_peers);
         halo.send_off.assign(p->send_offsets, p->send_offsets + (p->n_peers ? n + 1 : 0)); halo.recv_off.assign(p->recv_offsets, p->recv_offsets + (p->n_peers ? n + 1 : 0));
@@ -2001,8 +2016,10 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status run_color_pass(avn_system pass, uint32_t color) override {
-        if (color >= AVN_GRAPH_COLOR_COUNT) { error = "run_color_pass: colour out of range"; return AVN_ERR_BAD_ARG; }
-        only_color = (int)color;
+        if (color >= halo_slots()) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
+        only_color = (int)std::min<uint32_t>(color, AVN_COLOR_OVERFLOW_INDEX);
+        only_level = (l2_levels > 1 && color >= (uint32_t)AVN_COLOR_OVERFLOW_INDEX) ? (int)(color - AVN_COLOR_OVERFLOW_INDEX) : -1;
+        if (only_level >= 0 && l2_level_of.size() != color_constraints[AVN_COLOR_OVERFLOW_INDEX].size()) { only_color = only_level = -1; error = "level-2: avn_halo_overflow_levels_upload does not name this world's overflow manifolds"; return AVN_ERR_STATE; }
         avn_status st = AVN_OK;
         switch (pass) {
             case AVN_SYS_WARM_START: warm_start(); break;
@@ -2011,11 +2028,11 @@ template <class S> struct World : WorldBase {
             case AVN_SYS_SOLVE_RESTITUTION: solve_restitution(); break;
             default: error = "run_color_pass: not a contact pass"; st = AVN_ERR_BAD_ARG;
         }
-        only_color = -1;
+        only_color = -1; only_level = -1;
         return st;
     }
     avn_status halo_pack(uint32_t color, uint32_t peer, void* out, size_t* count) override {
-        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size() || !count) return AVN_ERR_BAD_ARG;
+        if (color >= halo_slots() || peer >= halo.peers.size() || !count) return AVN_ERR_BAD_ARG;
         const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.send_off[k], b1 = halo.send_off[k + 1];
         *count = b1 - b0;
         S* o = (S*)out;
@@ -2028,7 +2045,7 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status halo_unpack(uint32_t color, uint32_t peer, const void* in, size_t count) override {
-        if (color >= AVN_GRAPH_COLOR_COUNT || peer >= halo.peers.size()) return AVN_ERR_BAD_ARG;
+        if (color >= halo_slots() || peer >= halo.peers.size()) return AVN_ERR_BAD_ARG;
         const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.recv_off[k], b1 = halo.recv_off[k + 1];
         if (count != b1 - b0 || (count && !in)) { error = "halo_unpack: count does not match the plan"; return AVN_ERR_BAD_ARG; }
         const S* r = (const S*)in;

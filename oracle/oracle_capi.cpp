@@ -96,8 +96,9 @@ avn_status avo_dshard_stats_get(avn_world* w, avn_dshard_stats* o) { FWD(dshard_
 // body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
 // body in ascending index, so they come out sorted without sorting.
 struct avn_level2_plan {
-    struct Rank { std::vector<int32_t> bodies, peers, send_bodies, recv_bodies; std::vector<uint32_t> manifolds, color_offsets, send_offsets, recv_offsets; };
+    struct Rank { std::vector<int32_t> bodies, peers, send_bodies, recv_bodies; std::vector<uint32_t> manifolds, color_offsets, send_offsets, recv_offsets, overflow_level; };
     std::vector<Rank> ranks;
+    uint32_t n_overflow_levels = 1;
 };
 avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) {
     if (!in || !out || in->n_ranks == 0 || !in->color_offsets || (in->n_bodies && (!in->rb_type || !in->center_x)) || (in->n_manifolds && (!in->body1 || !in->body2))) return AVN_ERR_BAD_ARG;
@@ -126,21 +127,38 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
     }
     for (uint32_t b : dyn) holders[b].insert((uint32_t)slab[b]);
     auto shared = [&](uint32_t b) { return in->rb_type[b] != AVN_RB_STATIC && holders[b].size() > 1; };
-    // mover[c][b] = the rank whose manifold of colour c touches shared body b (-1: none)
-    std::vector<std::vector<int32_t>> mover(C, std::vector<int32_t>(N, -1));
+    // Exchange slots: colours 0..22, then the LEVELS of the overflow colour when one of its manifolds touches a shared body (header: avn_level2_plan_rank_overflow).
+    // A manifold's level = how many overflow manifolds lie in front of it on the deepest chain through its bodies: per body the depth reached so far, walked in list order.
+    const uint32_t o0 = in->color_offsets[AVN_COLOR_OVERFLOW_INDEX], o1 = in->color_offsets[AVN_COLOR_OVERFLOW_INDEX + 1];
+    bool levelled = false;
+    for (uint32_t m = o0; m < o1; ++m) levelled = levelled || shared((uint32_t)in->body1[m]) || shared((uint32_t)in->body2[m]);
+    std::vector<uint32_t> lev(o1 - o0, 0u), depth(N, 0u);
+    uint32_t n_levels = 1;
+    if (levelled)
+        for (uint32_t m = o0; m < o1; ++m) {
+            uint32_t d = 0;
+            for (int32_t b : {in->body1[m], in->body2[m]}) if (in->rb_type[b] != AVN_RB_STATIC) d = std::max(d, depth[b]);
+            lev[m - o0] = d;
+            for (int32_t b : {in->body1[m], in->body2[m]}) if (in->rb_type[b] != AVN_RB_STATIC) depth[b] = d + 1;
+            n_levels = std::max(n_levels, d + 1);
+        }
+    const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels;
+    // mover[slot][b] = the rank whose manifold of that slot touches shared body b (-1: none)
+    std::vector<std::vector<int32_t>> mover(S, std::vector<int32_t>(N, -1));
     for (uint32_t c = 0; c < C; ++c)
         for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m)
             for (int32_t b : {in->body1[m], in->body2[m]})
-                if (shared((uint32_t)b)) { if (c == AVN_COLOR_OVERFLOW_INDEX) return AVN_ERR_BAD_ARG; mover[c][b] = owner_of[m]; }
+                if (shared((uint32_t)b)) mover[c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX ? c + lev[m - o0] : c][b] = owner_of[m];
     avn_level2_plan* pl = new avn_level2_plan;
     pl->ranks.resize(R);
+    pl->n_overflow_levels = n_levels;
     for (uint32_t r = 0; r < R; ++r) {
         auto& k = pl->ranks[r];
         std::vector<int32_t> local(N, -1);
         for (uint32_t b = 0; b < N; ++b)
             if (in->rb_type[b] == AVN_RB_STATIC || holders[b].count(r)) { local[b] = (int32_t)k.bodies.size(); k.bodies.push_back((int32_t)b); }
         std::set<int32_t> peers;
-        for (uint32_t c = 0; c < C; ++c)
+        for (uint32_t c = 0; c < S; ++c)
             for (uint32_t b : dyn) {
                 if (mover[c][b] < 0 || !holders[b].count(r)) continue;
                 if ((uint32_t)mover[c][b] == r) { for (uint32_t h : holders[b]) if (h != r) peers.insert((int32_t)h); }
@@ -149,7 +167,7 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
         k.peers.assign(peers.begin(), peers.end());
         k.send_offsets.push_back(0); k.recv_offsets.push_back(0);
         if (!k.peers.empty())
-            for (uint32_t c = 0; c < C; ++c)
+            for (uint32_t c = 0; c < S; ++c)
                 for (int32_t p : k.peers) {
                     for (uint32_t b : dyn) {
                         if (mover[c][b] == (int32_t)r && holders[b].count((uint32_t)p)) k.send_bodies.push_back(local[b]);
@@ -159,7 +177,8 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
                 }
         k.color_offsets.assign(C + 1, 0);
         for (uint32_t c = 0; c < C; ++c) {
-            for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m) if ((uint32_t)owner_of[m] == r) k.manifolds.push_back(m);
+            for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m)
+                if ((uint32_t)owner_of[m] == r) { k.manifolds.push_back(m); if (c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX) k.overflow_level.push_back(lev[m - o0]); }
             k.color_offsets[c + 1] = (uint32_t)k.manifolds.size();
         }
     }
@@ -167,6 +186,12 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
     return AVN_OK;
 }
 void avo_level2_plan_destroy(avn_level2_plan* plan) { delete plan; }
+avn_status avo_level2_plan_rank_overflow(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_levels, const uint32_t** level_of) {
+    if (!plan || rank >= plan->ranks.size() || !n_levels || !level_of) return AVN_ERR_BAD_ARG;
+    *n_levels = plan->n_overflow_levels; *level_of = plan->ranks[rank].overflow_level.data();
+    return AVN_OK;
+}
+avn_status avo_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { FWD(halo_overflow_levels_upload(n_levels, level_of, count)); }
 avn_status avo_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out) {
     if (!plan || !out || rank >= plan->ranks.size()) return AVN_ERR_BAD_ARG;
     const auto& k = plan->ranks[rank];

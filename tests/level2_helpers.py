@@ -19,6 +19,14 @@ def global_problem(lib, nx, ny, nz, seed=0, restitution=0.0):
     return sc, scenes.permute_manifolds(mf, perm), offs, restitution
 
 
+def overflow_from(offs, keep):
+    """The same colour-major manifold set with colours >= keep moved into the overflow colour (list order = their colour-major order): what a deep pile does to
+    the reference's 24-colour graph (constraint_graph.rs:163-196) -- and most of those manifolds then sit on bodies shared between slabs."""
+    o = np.asarray(offs).copy()
+    o[keep:24] = o[keep]
+    return o
+
+
 def make_single(lib, bits, sc, pm, offs, restitution, substeps):
     w = F.World(lib, F.default_config(bits, substeps=substeps))
     w.bodies_upload(**sc.body_kwargs())
@@ -33,7 +41,7 @@ def make_split(lib, bits, sc, pm, offs, restitution, substeps, world_size):
         w = F.World(lib, F.default_config(bits, substeps=substeps))
         w.bodies_upload(**{k: (np.asarray(v)[r.bodies] if v is not None else None) for k, v in sc.body_kwargs().items()})
         scenes.upload_manifolds(w, shard.level2_local_manifolds(r, pm), r.color_offsets, sc.friction, restitution)
-        w.halo_plan_upload(r.peers, r.send_offsets, r.send_bodies, r.recv_offsets, r.recv_bodies)
+        r.upload(w)
         worlds.append(w)
     return plan, worlds
 
@@ -48,7 +56,7 @@ def step_split_in_process(plan, worlds, substeps, restitution):
             w.run_system(system)
 
     def contact_pass(system):
-        for c in [F.COLOR_OVERFLOW_INDEX] + list(range(F.COLOR_OVERFLOW_INDEX)):
+        for c in plan[0].solve_order():
             for w in worlds:
                 w.run_color_pass(system, c)
             box = {}
@@ -87,3 +95,60 @@ def compare_with_single(single, plan, worlds):
         gi = w.impulses_download()
         for k in imp:
             assert np.array_equal(imp[k][pl.manifolds], gi[k]), f"impulses.{k} of a slab differ from the single world"
+
+
+def closed_loop_problem(lib, bits, dims, steps, substeps=4, friction=0.5):
+    """avian_amd.level2_bench.closed_loop_island (the bench's `--gpus N` leg uses the same set): the device closed loop's own manifolds of a collapsing box stack in
+    the host-uploaded form level 2 works on.  Returns (scene with the stepped body state, manifolds, offsets, warm-start impulses)."""
+    from avian_amd import level2_bench
+    return level2_bench.closed_loop_island(lib, F, scenes, bits, dims, steps, substeps=substeps, friction=friction)
+
+
+def save_problem(path, sc, mf, offs, warm):
+    np.savez(path, offs=offs, wn=warm[0], wt=warm[1], **{"b_" + k: v for k, v in sc.body_kwargs().items() if v is not None}, **{"m_" + k: v for k, v in mf.items()})
+
+
+def load_problem(path):
+    d = np.load(path)
+    body = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
+    mf = {k[2:]: d[k] for k in d.files if k.startswith("m_")}
+    return body, mf, d["offs"], (d["wn"], d["wt"])
+
+
+def make_world_from(lib, bits, body, mf, offs, warm, substeps, rank=None):
+    """A host-manifold world of a closed_loop_problem: the whole set, or one level-2 rank's share of it (plan uploaded)."""
+    w = F.World(lib, F.default_config(bits, substeps=substeps))
+    if rank is None:
+        w.bodies_upload(**body)
+        scenes.upload_manifolds(w, mf, offs, mf["friction"], mf["restitution"], warm[0], warm[1])
+        return w
+    w.bodies_upload(**{k: np.asarray(v)[rank.bodies] for k, v in body.items()})
+    lm = shard.level2_local_manifolds(rank, mf)
+    scenes.upload_manifolds(w, lm, rank.color_offsets, lm["friction"], lm["restitution"], warm[0][rank.manifolds], warm[1][rank.manifolds])
+    rank.upload(w)
+    return w
+
+
+def cfg5_shaped_case(lib_gen, libs_single, lib_split, world_sizes, steps=2, substeps=2, dims=(50, 20, 50), problem=None):
+    """VERDICT r5 item 3's case: >= 50 000 bodies in f64 with >= 10 000 overflow-colour manifolds (the closed loop's own colouring of a collapsing stack), over
+    2 / 4 slabs; every slab's bodies and impulses == the unsplit world's on each of `libs_single`, every step."""
+    sc, mf, offs, warm = problem if problem is not None else closed_loop_problem(lib_gen, 64, dims, 4, substeps=8)
+    body = {k: v for k, v in sc.body_kwargs().items() if v is not None}
+    assert sc.n > 50_000 and offs[24] - offs[23] >= 10_000
+    for R in world_sizes:
+        plan = shard.level2_plan_lib(lib_split, sc.position, sc.rb_type, mf["body1"], mf["body2"], offs, R)
+        L = plan[0].n_overflow_levels
+        n_p = [len(p.peers) for p in plan]
+        assert L > 1 and sum(int(p.send_offsets[-1] - p.send_offsets[23 * n]) for p, n in zip(plan, n_p) if n) > 1000, "the overflow levels must carry shared bodies"
+        singles = [make_world_from(l, 64, body, mf, offs, warm, substeps) for l in libs_single]
+        worlds = [make_world_from(lib_split, 64, body, mf, offs, warm, substeps, rank=r) for r in plan]
+        for _ in range(steps):
+            for s in singles:
+                s.run_system("SOLVER")
+            step_split_in_process(plan, worlds, substeps, False)
+            for s in singles:
+                compare_with_single(s, plan, worlds)
+        assert float(np.abs(singles[0].bodies_download()["linear_velocity"]).max()) > 0.05
+        for w in singles + worlds:
+            w.close()
+    return sc, mf, offs, warm

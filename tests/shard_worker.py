@@ -176,17 +176,19 @@ def run_slabs(lib, rank, world, steps, out_path, device=None):
         np.savez(out_path, **{f"pairs_s{s}": r for s, r in enumerate(per_step)})
 
 
-def run_level2(lib, rank, world, steps, out_path):
+def run_level2(lib, rank, world, steps, out_path, keep=None):
     """Level-2 sharding over real ranks: this rank builds ONLY its slab world, steps it with shard.level2_solver and moves the boundary
     records with point-to-point sends (gloo here; the library's own RCCL transport replaces this loop on a multi-GPU node)."""
-    from level2_helpers import global_problem
+    from level2_helpers import global_problem, overflow_from
     sc, pm, offs, _ = global_problem(lib, 8, 4, 5, seed=7)
+    if keep is not None:   # colours >= keep in the overflow colour: its levels travel between the ranks as extra exchange slots
+        offs = overflow_from(offs, keep)
     plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world)
     me = plan[rank]
     w = F.World(lib, F.default_config(32, substeps=3))
     w.bodies_upload(**{k: (np.asarray(v)[me.bodies] if v is not None else None) for k, v in sc.body_kwargs().items()})
     scenes.upload_manifolds(w, shard.level2_local_manifolds(me, pm), me.color_offsets, sc.friction, 0.3)
-    w.halo_plan_upload(me.peers, me.send_offsets, me.send_bodies, me.recv_offsets, me.recv_bodies)
+    me.upload(w)
 
     def exchange(color, out, need):
         n_p = len(me.peers)
@@ -206,14 +208,45 @@ def run_level2(lib, rank, world, steps, out_path):
     np.savez(out_path + f".rank{rank}.npz", bodies=me.bodies, manifolds=me.manifolds, **{"b_" + k: v for k, v in b.items()}, **{"i_" + k: v for k, v in imp.items()})
 
 
+def run_level2_problem(lib, rank, world, steps, out_path):
+    """Level 2 on a saved closed-loop manifold set (level2_helpers.save_problem): f64, overflow levels as exchange slots."""
+    from level2_helpers import load_problem, make_world_from
+    body, mf, offs, warm = load_problem(out_path + ".problem.npz")
+    plan = shard.level2_plan_lib(lib, body["position"], body["rb_type"], mf["body1"], mf["body2"], offs, world)
+    me = plan[rank]
+    w = make_world_from(lib, 64, body, mf, offs, warm, 2, rank=me)
+
+    def exchange(slot, out, need):
+        n_p = len(me.peers)
+        reqs, bufs = [], {}
+        for p in need:
+            cnt = int(me.recv_offsets[slot * n_p + p + 1] - me.recv_offsets[slot * n_p + p])
+            bufs[p] = torch.empty((cnt, 8), dtype=torch.float64)
+            reqs.append(dist.irecv(bufs[p], src=int(me.peers[p]), tag=slot))
+        for p, rec in out.items():
+            reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(rec, np.float64)), dst=int(me.peers[p]), tag=slot))
+        for r in reqs:
+            r.wait()
+        return {p: bufs[p].numpy() for p in need}
+    for _ in range(steps):
+        shard.level2_solver(w, me, 2, exchange, restitution=False)
+    b = w.bodies_download(); imp = w.impulses_download()
+    np.savez(out_path + f".rank{rank}.npz", bodies=me.bodies, manifolds=me.manifolds, n_levels=me.n_overflow_levels, **{"b_" + k: v for k, v in b.items()}, **{"i_" + k: v for k, v in imp.items()})
+
+
 def main():
     case, out_path, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     backend = os.environ.get("AVN_SHARD_BACKEND", "oracle")
     dist.init_process_group(backend="gloo" if backend == "oracle" else "nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
     lib = oracle_lib() if backend == "oracle" else hip_lib()
-    if case == "level2":
-        run_level2(lib, rank, world, steps, out_path)
+    if case == "level2_problem":
+        run_level2_problem(lib, rank, world, steps, out_path)
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+    if case in ("level2", "level2_overflow"):
+        run_level2(lib, rank, world, steps, out_path, keep=4 if case == "level2_overflow" else None)
         dist.barrier()
         dist.destroy_process_group()
         return

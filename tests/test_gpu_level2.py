@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from helpers import F, hip_lib, oracle_lib
-from level2_helpers import compare_with_single, global_problem, make_single, make_split, step_split_in_process
+from level2_helpers import compare_with_single, global_problem, make_single, make_split, overflow_from, step_split_in_process
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,6 +31,33 @@ def test_split_island_equals_single_world_on_hip(bits, world_size, restitution):
         step_split_in_process(plan, worlds, 3, restitution > 0)
         compare_with_single(single, plan, worlds)
         compare_with_single(ref, plan, worlds)
+
+
+@pytest.mark.parametrize("bits,world_size,keep,restitution", [(32, 2, 6, 0.0), (32, 3, 0, 0.3), (64, 2, 3, 0.3), (32, 4, 10, 0.0)])
+def test_overflow_colour_on_shared_bodies_on_hip(bits, world_size, keep, restitution):
+    """Round 6: overflow-colour manifolds on shared bodies -- the global list cut into levels, one exchange slot per level (avn_halo_overflow_levels_upload).
+    Split HIP worlds == the unsplit HIP world == the unsplit oracle, bit for bit."""
+    hip, orc = hip_lib(), oracle_lib()
+    sc, pm, offs, _ = global_problem(orc, 8, 4, 5, seed=bits + world_size + keep)
+    offs = overflow_from(offs, keep)
+    single = make_single(hip, bits, sc, pm, offs, restitution, 3)
+    ref = make_single(orc, bits, sc, pm, offs, restitution, 3)
+    plan, worlds = make_split(hip, bits, sc, pm, offs, restitution, 3, world_size)
+    assert plan[0].n_overflow_levels > 1
+    for step in range(3):
+        single.run_system("SOLVER")
+        ref.run_system("SOLVER")
+        step_split_in_process(plan, worlds, 3, restitution > 0)
+        compare_with_single(single, plan, worlds)
+        compare_with_single(ref, plan, worlds)
+
+
+def test_cfg5_shaped_closed_loop_manifolds_over_2_and_4_slabs_on_hip():
+    """The cfg5-shaped case (50 000 cuboids f64, the HIP closed loop's own manifolds with ~10^5 in the overflow colour): HIP slabs == the unsplit HIP world == the
+    unsplit oracle, every step, bodies and impulses."""
+    from level2_helpers import cfg5_shaped_case
+    hip, orc = hip_lib(), oracle_lib()
+    cfg5_shaped_case(hip, [hip, orc], hip, (2, 4))
 
 
 def test_overflow_colour_inside_a_slab_runs_in_order():
@@ -99,6 +126,42 @@ for bits in (32, 64):
     assert bounds.shape == (1, 6) and np.array_equal(bounds[0], np.concatenate([mn, mx])) and len(ov) == 0, (bounds, mn, mx)
     b0, ov0 = plain.bounds_exchange()     # no communicator: a world is its own only rank
     assert np.array_equal(b0[0], np.concatenate(plain.dynamic_bounds())) and len(ov0) == 0
+# round 6: the overflow colour cut into levels, every level an exchange slot -- colours >= 5 moved into the overflow colour, the levels of the global list as the
+# planner assigns them; the world is its own peer for every slot
+from level2_helpers import overflow_from
+for bits in (32, 64):
+    sc, pm, offs, _ = global_problem(orc, 6, 3, 4, seed=12)
+    offs = overflow_from(offs, 5)
+    o0, o1 = int(offs[23]), int(offs[24])
+    depth = np.zeros(sc.n, np.int64); level = np.zeros(o1 - o0, np.int64)
+    for m in range(o0, o1):
+        bb = [int(b) for b in (pm["body1"][m], pm["body2"][m]) if sc.rb_type[b] != F.RB_STATIC]
+        level[m - o0] = max(depth[b] for b in bb)
+        for b in bb:
+            depth[b] = level[m - o0] + 1
+    L = int(level.max()) + 1
+    assert L > 3
+    plain = make_single(hip, bits, sc, pm, offs, 0.3, 3)
+    looped = make_single(hip, bits, sc, pm, offs, 0.3, 3)
+    so = [0]; bodies = []
+    for slot in range(23 + L):
+        m = np.arange(offs[slot], offs[slot + 1]) if slot < 23 else o0 + np.flatnonzero(level == slot - 23)
+        b = np.unique(np.concatenate([pm["body1"][m], pm["body2"][m]])) if len(m) else np.zeros(0, np.int64)
+        b = b[sc.rb_type[b] == F.RB_DYNAMIC]
+        bodies.append(b); so.append(so[-1] + len(b))
+    bodies = np.concatenate(bodies).astype(np.int32)
+    looped.halo_overflow_levels_upload(L, level)
+    looped.halo_plan_upload([0], so, bodies, so, bodies)
+    looped.comm_init(hip.comm_unique_id(), 1, 0)
+    for _ in range(3):
+        plain.step(); looped.step()
+    looped.synchronize(); plain.synchronize()
+    a, b = plain.bodies_download(), looped.bodies_download()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), ("levels", bits, k)
+    ia, ib = plain.impulses_download(), looped.impulses_download()
+    for k in ia:
+        assert np.array_equal(ia[k], ib[k]), ("levels", bits, k)
 print("SELF_EXCHANGE_OK")
 """
 

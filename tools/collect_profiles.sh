@@ -19,6 +19,14 @@ cpf closed_loop_step110_timeline.txt closed_loop_step110_timeline.txt
 cpf closed_loop_switches_ab.txt closed_loop_switches_ab.txt
 cpf closed_loop_r4_vs_r5_same_box.txt closed_loop_r4_vs_r5_same_box.txt
 cpf sleeping_step230_timeline.txt sleeping_step230_timeline.txt
+cpf sleeping_cfg2_windows.txt sleeping_cfg2_windows.txt
+cpf sleeping_cfg2_host_phases.txt sleeping_cfg2_host_phases.txt
+cpf sleeping_cfg2_switches_ab.txt sleeping_cfg2_switches_ab.txt
+cpf sleeping_cfg2_steps110_111_timeline.txt sleeping_cfg2_steps110_111_timeline.txt
+cpf sleeping_many_pyramids_windows.txt sleeping_many_pyramids_windows.txt
+cpf cfg3_closed_loop_joint_lds_ab.txt cfg3_closed_loop_joint_lds_ab.txt
+cpf cfg5_closed_loop_windows.txt cfg5_closed_loop_windows.txt
+cpf dshard_cost_model.txt dshard_cost_model.txt
 cpf narrow_phase_cutoffs.txt narrow_phase_cutoffs.txt
 cpf pmc_narrow_phase.json pmc_narrow_phase.json
 cpf pmc_closed_loop_settled.json pmc_closed_loop_settled.json

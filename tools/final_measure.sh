@@ -63,6 +63,16 @@ if [ -f $R/avian_amd/csrc/ab/libavian_r4.so ]; then
     echo "== round 4 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r4.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
   done > $O/closed_loop_r4_vs_r5_same_box.txt 2>&1
 fi
+# round 6: avn_sleeping_enable at cfg2's scale -- window by window next to the sleeping-off run, the host phases of every step, each of the round's mechanisms switched off
+# alone on this box, a two-step kernel timeline (a split step and its neighbour); the bench's sleeping scene; cfg3 / cfg5 closed loops; the sharded device loop's cost model
+AVN_LIB_PATH=$M AVN_SLP_TRACE=1 timeout 200 python tools/time_sleeping_cfg2.py 140 > $O/sleeping_cfg2_windows.txt 2> $O/sleeping_cfg2_host_phases.txt
+for e in "" AVN_SLP_NO_FAST=1 AVN_SLP_HOST_SPLIT=1 AVN_SLP_SYNC_SPLIT=1; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e timeout 300 python tools/time_sleeping_cfg2.py 140 2>/dev/null | grep "sleeping=1 steps\|ratio"; done > $O/sleeping_cfg2_switches_ab.txt
+bash tools/sleeping_cfg2_timeline.sh 110 > /dev/null 2>&1; cp $R/gpurun_out/slp_timeline/timeline.txt $O/sleeping_cfg2_steps110_111_timeline.txt 2>/dev/null
+timeout 120 python tools/time_sleeping.py 9 > $O/sleeping_many_pyramids_windows.txt 2>&1
+bash tools/sleeping_timeline.sh 230 > /dev/null 2>&1; cp $R/gpurun_out/sleeping_timeline/timeline.txt $O/sleeping_step230_timeline.txt 2>/dev/null
+for e in 0 1; do AVN_LIB_PATH=$M $( [ $e = 1 ] && echo env AVN_NO_JOINT_LDS=1 ) timeout 200 python tools/time_cfg3.py 2>/dev/null | sed "s/^/joint_lds_off=$e /"; done > $O/cfg3_closed_loop_joint_lds_ab.txt
+timeout 300 python tools/time_cfg5.py 1 > $O/cfg5_closed_loop_windows.txt 2>/dev/null
+timeout 300 python tools/time_dshard.py 120 > $O/dshard_cost_model.txt 2>/dev/null
 timeout 300 python tools/pmc_closed_loop_tail.py $O/pmc_closed_loop_settled.json 120 20 > $O/pmc_closed_loop_settled.txt 2>&1
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
