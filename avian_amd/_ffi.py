@@ -254,12 +254,35 @@ class avn_level2_rank(C.Structure):
 PAIR_DTYPE = np.dtype([("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<i4"), ("body2", "<i4"),
                        ("flags", "<u4"), ("reserved", "<u4")])
 
+# ---- host shapes (include/avian_mi355x.h "host shapes"): the two AnyCollider callbacks -----------------------------------------------------
+SHAPE_CUBOID, SHAPE_BALL, SHAPE_HOST = 0, 1, 2
+HOST_SHAPE_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p)   # avn_host_aabb_fn == avn_host_manifolds_fn in shape
+
+
+class avn_host_shape_stats(C.Structure):
+    _fields_ = [("host_colliders", C.c_uint32), ("last_aabb_queries", C.c_uint32), ("last_manifold_queries", C.c_uint32), ("last_manifolds_with_points", C.c_uint32),
+                ("bytes_to_host", C.c_uint64), ("bytes_from_host", C.c_uint64), ("last_callback_ms", C.c_double)]
+
+
+def host_shape_dtypes(bits: int):
+    """numpy views of avn_host_aabb_query_fNN, avn_host_aabb_fNN, avn_host_manifold_query_fNN, avn_host_manifold_fNN."""
+    S = "<f4" if bits == 32 else "<f8"
+    aq = np.dtype([("collider", "<u4"), ("swept", "<u4"), ("start_position", S, 3), ("start_rotation", S, 4), ("end_position", S, 3), ("end_rotation", S, 4)])
+    ab = np.dtype([("min", S, 3), ("max", S, 3)])
+    mq = np.dtype([("contact_id", "<u4"), ("collider1", "<u4"), ("collider2", "<u4"), ("reserved", "<u4"), ("position1", S, 3), ("rotation1", S, 4), ("position2", S, 3),
+                   ("rotation2", S, 4), ("max_contact_distance", S)])
+    mm = np.dtype([("point_count", "<u4")] + ([("reserved", "<u4")] if bits == 64 else []) +
+                  [("normal", S, 3), ("anchor1", S, (MAX_QUERY_POINTS, 3)), ("penetration", S, MAX_QUERY_POINTS), ("feature_id1", "<u4", MAX_QUERY_POINTS), ("feature_id2", "<u4", MAX_QUERY_POINTS)])
+    assert (aq.itemsize, ab.itemsize, mq.itemsize, mm.itemsize) == ((64, 24, 76, 400) if bits == 32 else (120, 48, 136, 672))
+    return aq, ab, mq, mm
+
+
 # every symbol include/avian_mi355x.h declares (without prefix)
 ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -312,6 +335,8 @@ class Library:
         f("level2_plan_rank").argtypes = [vp, C.c_uint32, C.POINTER(avn_level2_rank)]
         f("level2_plan_rank_overflow").argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32))]
         f("halo_overflow_levels_upload").argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        f("host_shapes_set").argtypes = [vp, HOST_SHAPE_FN, HOST_SHAPE_FN, vp]
+        f("host_shape_stats_get").argtypes = [vp, C.POINTER(avn_host_shape_stats)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
         f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
@@ -822,6 +847,42 @@ class World:
         self._check(self.lib.fn("synchronize")(self.handle))
 
     # -- level-2 sharding (one island over several worlds) -----------------------------------------------------------------
+    # -- host shapes: AnyCollider::aabb_with_context / contact_manifolds_with_context as callbacks ------------------------------------------
+    def host_shapes_set(self, aabb_fn, manifolds_fn):
+        """``avn_host_shapes_set``.  aabb_fn(queries, out) and manifolds_fn(queries, out) get numpy structured arrays that VIEW the library's buffers
+        (host_shape_dtypes): read `queries`, fill `out` in place.  None, None unregisters."""
+        if aabb_fn is None:
+            self._hs_keep = None
+            self._check(self.lib.fn("host_shapes_set")(self.handle, None, None, None))
+            return
+        errors = self._hs_errors = []
+
+        def wrap(fn, qi, oi):
+            def cb(user, bits, n, q, o):
+                try:
+                    dt = host_shape_dtypes(int(bits))
+                    qa = np.frombuffer((C.c_char * (n * dt[qi].itemsize)).from_address(q), dtype=dt[qi])
+                    oa = np.frombuffer((C.c_char * (n * dt[oi].itemsize)).from_address(o), dtype=dt[oi])
+                    fn(qa, oa)
+                except BaseException as e:  # noqa: BLE001 -- an exception must not unwind through C; the caller re-raises it after the step
+                    errors.append(e)
+            return HOST_SHAPE_FN(cb)
+        a, m = wrap(aabb_fn, 0, 1), wrap(manifolds_fn, 2, 3)
+        self._hs_keep = (a, m)   # (ctypes callbacks must outlive the registration)
+        self._check(self.lib.fn("host_shapes_set")(self.handle, a, m, None))
+
+    def host_shape_errors(self):
+        """Exceptions raised inside the Python callbacks since the last call (a C caller cannot propagate them)."""
+        e = list(getattr(self, "_hs_errors", []))
+        if e:
+            self._hs_errors.clear()
+        return e
+
+    def host_shape_stats(self) -> avn_host_shape_stats:
+        st = avn_host_shape_stats()
+        self._check(self.lib.fn("host_shape_stats_get")(self.handle, C.byref(st)))
+        return st
+
     def halo_overflow_levels_upload(self, n_levels: int, level_of):
         """``avn_halo_overflow_levels_upload``: call BEFORE halo_plan_upload when the planner cut the overflow colour into levels."""
         lv = np.ascontiguousarray(level_of, np.uint32)

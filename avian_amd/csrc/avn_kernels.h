@@ -153,15 +153,22 @@ size_t np_survivor_list_slack();     // entries np_row / np_axis need beyond `ca
 size_t np_survivor_counter_bytes();  // size of np_ctr
 template <class T> void launch_init_contact_rows(const CT<T>&, const uint32_t* ids, const uint32_t* slot1, const uint32_t* slot2, const uint32_t* pair_flags, uint32_t n, hipStream_t);
 template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* ids, uint32_t n, hipStream_t);
+// host shapes (include/avian_mi355x.h): where the light kernel leaves the queries of pairs with an AVN_SHAPE_HOST collider; queries == nullptr: the world holds none
+// (the plain kernels run).  host_only: a retry after the list overflowed -- only those pairs are visited (they wrote nothing the first time), everything else is skipped
+struct NpHostList { void* queries = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t host_only = 0; };
+template <class T> void launch_narrow_phase_host(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool dense, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg,
+                                                 uint32_t* has, const void* queries /* sorted by contact id */, const void* manifolds, uint32_t n, hipStream_t);
+template <class T> void launch_host_aabb_queries(const DW<T>&, const BP<T>&, const StepParams<T>&, const uint32_t* slots, uint32_t n, void* out, hipStream_t);
+template <class T> void launch_host_aabb_apply(const BP<T>&, const StepParams<T>&, const uint32_t* slots, uint32_t n, const void* in, hipStream_t);
 // NarrowPhase::update_contacts over the active pairs; changes[0..*n_changes) in arbitrary order (the host sorts by id)
 template <class T> void launch_narrow_phase(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* active, uint32_t n_active,
-                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t);
+                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t, const NpHostList& hl = NpHostList());
 // dense form (device closed loop): every row id < n_rows with AVN_CP_ROW_USED is a pair; the row's status change goes to chg[id] / has[id]
 // (id order = the order NarrowPhase::update walks the status bits) and rows that must be removed are counted in *n_remove
 template <class T> void launch_narrow_phase_dense(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t n_rows, uint32_t* chg, uint32_t* has,
-                                                  uint32_t* n_remove, hipStream_t, bool reset_counter = true /* false: *n_remove is known to be zero (no memset launch) */);
+                                                  uint32_t* n_remove, hipStream_t, bool reset_counter = true /* false: *n_remove is known to be zero (no memset launch) */, const NpHostList& hl = NpHostList());
 template <class T> void launch_narrow_phase_rows(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t* list, uint32_t n_list, uint32_t range_base, uint32_t n_range,
-                                                 uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t);   // rows added this step (counter not reset)
+                                                 uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t, const NpHostList& hl = NpHostList());   // rows added this step (counter not reset)
 // manifold m of the solver-side arrays <- row handles[m] of the contact table (GraphColor::manifold_handles indirection)
 // store_contact_impulses' write into the ContactGraph (plugin.rs:744-749): table row <- DW::mp_w
 template <class T> void launch_scatter_impulses(const DW<T>&, const CT<T>&, const uint32_t* handles, hipStream_t);

@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepPara
     Vec4<T> he4 = bp.col_he[c];  // (half_extents.xyz, collision_margin)
     T spec = bp.col_spec[c];
     uint32_t shape = ci.z & 0xFFu, cflags = (ci.z >> 8) & 0xFFu;
+    if (shape == AVN_SHAPE_HOST) return;   // AnyCollider::aabb_with_context is the host's: k_host_aabb_queries / k_host_aabb_apply wrote this collider's box
     int body = (int)ci.y;
     V3<T> pos = xyz<T>(w.pos[body]);
     Q4<T> rot = quat<T>(w.rot[body]);
@@ -78,6 +79,63 @@ __global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepPara
     bp.aabb_min[c] = make4<T>(mn - gg, 0);
     bp.aabb_max[c] = make4<T>(mx + gg, 0);
 }
+
+// Host shapes (include/avian_mi355x.h "host shapes"): update_aabb for the colliders whose AnyCollider::aabb lives on the host.  k_host_aabb_queries writes what
+// aabb_with_context / swept_aabb_with_context are called with (backend.rs:556-620: the start pose and, with a positive speculative margin, the predicted end pose --
+// the same expressions as k_update_aabb); the host answers one box per collider; k_host_aabb_apply grows it by contact_tolerance + collision margin (backend.rs:560,618).
+template <class T> struct HostAabbQ { uint32_t collider, swept; T start_position[3], start_rotation[4], end_position[3], end_rotation[4]; };   // == avn_host_aabb_query_fNN
+template <class T> struct HostAabb { T min[3], max[3]; };                                                                                    // == avn_host_aabb_fNN
+static_assert(sizeof(HostAabbQ<float>) == sizeof(avn_host_aabb_query_f32) && sizeof(HostAabbQ<double>) == sizeof(avn_host_aabb_query_f64), "host aabb query layout");
+static_assert(sizeof(HostAabb<float>) == sizeof(avn_host_aabb_f32) && sizeof(HostAabb<double>) == sizeof(avn_host_aabb_f64), "host aabb layout");
+template <class T>
+__global__ __launch_bounds__(256) void k_host_aabb_queries(DW<T> w, BP<T> bp, StepParams<T> p, const uint32_t* __restrict__ slots, uint32_t n, HostAabbQ<T>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = slots[i];
+    const uint4 ci = bp.col_info[c];
+    const T spec = bp.col_spec[c];
+    const uint32_t cflags = (ci.z >> 8) & 0xFFu;
+    const int body = (int)ci.y;
+    const V3<T> pos = xyz<T>(w.pos[body]);
+    const Q4<T> rot = quat<T>(w.rot[body]);
+    const V3<T> lv = xyz<T>(w.lvel[body]), av = xyz<T>(w.avel[body]);
+    const T delta_secs = p.dt_adj;
+    const T speculative_margin = (cflags & AVN_COLLIDER_SWEPT_CCD) ? Limits<T>::max : (spec >= T(0) ? spec : p.default_speculative_margin);
+    HostAabbQ<T> q;
+    q.collider = ci.x;
+    q.swept = speculative_margin <= T(0) ? 0u : 1u;
+    Q4<T> end_rot = rot; V3<T> end_pos = pos;
+    if (q.swept) {
+        end_rot = fast_renormalize(qmul(from_scaled_axis(av * delta_secs), rot));
+        end_pos = pos + clamp_length_max(lv * delta_secs, smax(speculative_margin, p.contact_tolerance));
+    }
+    q.start_position[0] = pos.x; q.start_position[1] = pos.y; q.start_position[2] = pos.z;
+    q.start_rotation[0] = rot.x; q.start_rotation[1] = rot.y; q.start_rotation[2] = rot.z; q.start_rotation[3] = rot.w;
+    q.end_position[0] = end_pos.x; q.end_position[1] = end_pos.y; q.end_position[2] = end_pos.z;
+    q.end_rotation[0] = end_rot.x; q.end_rotation[1] = end_rot.y; q.end_rotation[2] = end_rot.z; q.end_rotation[3] = end_rot.w;
+    out[i] = q;
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_host_aabb_apply(BP<T> bp, StepParams<T> p, const uint32_t* __restrict__ slots, uint32_t n, const HostAabb<T>* __restrict__ in) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t c = slots[i];
+    const T g = p.contact_tolerance + bp.col_he[c].w;
+    const HostAabb<T> a = in[i];
+    const V3<T> gg{g, g, g};
+    bp.aabb_min[c] = make4<T>(V3<T>{a.min[0], a.min[1], a.min[2]} - gg, 0);
+    bp.aabb_max[c] = make4<T>(V3<T>{a.max[0], a.max[1], a.max[2]} + gg, 0);
+}
+template <class T> void launch_host_aabb_queries(const DW<T>& w, const BP<T>& bp, const StepParams<T>& p, const uint32_t* slots, uint32_t n, void* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_host_aabb_queries<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bp, p, slots, n, (HostAabbQ<T>*)out);
+}
+template <class T> void launch_host_aabb_apply(const BP<T>& bp, const StepParams<T>& p, const uint32_t* slots, uint32_t n, const void* in, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_host_aabb_apply<T>, dim3((n + 255) / 256), dim3(256), 0, s, bp, p, slots, n, (const HostAabb<T>*)in);
+}
+template void launch_host_aabb_queries<float>(const DW<float>&, const BP<float>&, const StepParams<float>&, const uint32_t*, uint32_t, void*, hipStream_t);
+template void launch_host_aabb_queries<double>(const DW<double>&, const BP<double>&, const StepParams<double>&, const uint32_t*, uint32_t, void*, hipStream_t);
+template void launch_host_aabb_apply<float>(const BP<float>&, const StepParams<float>&, const uint32_t*, uint32_t, const void*, hipStream_t);
+template void launch_host_aabb_apply<double>(const BP<double>&, const StepParams<double>&, const uint32_t*, uint32_t, const void*, hipStream_t);
 
 // Per-workgroup partial union of the AABBs of colliders on non-static bodies (multi-GPU proximity bound, header:
 // avn_dynamic_bounds).  partial[b] = (min.xyz, max.xyz) as T; the host reduces the few hundred partials.

@@ -113,10 +113,18 @@ template <class T> struct NpSinkOf<T, true> { typedef NpLdsSink<T> type; };
 // One pair.  HEAVY = false: the whole update unless the pair is a cuboid-cuboid one that survives the SAT -- then nothing is written,
 // *deferred = true and *axis holds the separating direction.  HEAVY = true: the deferred pair again, from the top (every input is re-read:
 // nothing was written), with the SAT replaced by *axis.
-template <class T, bool DENSE, bool HEAVY>
+// HS (host shapes, round 6: include/avian_mi355x.h "host shapes"): a pair with an AVN_SHAPE_HOST collider.  HEAVY = false: nothing is written, *deferred = true and
+// *hq holds the query contact_manifolds_with_context gets (system_param.rs:700-712); HEAVY = true: the pair again from the top with the manifold the host returned
+// (*hm) in the place of contact_query::contact_manifolds' -- margins, speculative filter, pruning, matching, status as for every other pair.
+template <class T> struct NpHostQ { uint32_t contact_id, collider1, collider2, reserved; T position1[3], rotation1[4], position2[3], rotation2[4], max_contact_distance; };   // == avn_host_manifold_query_fNN
+template <class T> struct NpHostM { uint32_t point_count; T normal[3]; T anchor1[3 * AVN_MAX_QUERY_POINTS]; T penetration[AVN_MAX_QUERY_POINTS]; uint32_t fid1[AVN_MAX_QUERY_POINTS], fid2[AVN_MAX_QUERY_POINTS]; };   // == avn_host_manifold_fNN
+static_assert(sizeof(NpHostQ<float>) == sizeof(avn_host_manifold_query_f32) && sizeof(NpHostQ<double>) == sizeof(avn_host_manifold_query_f64), "host query layout");
+static_assert(sizeof(NpHostM<float>) == sizeof(avn_host_manifold_f32) && sizeof(NpHostM<double>) == sizeof(avn_host_manifold_f64) && offsetof(NpHostM<double>, normal) == offsetof(avn_host_manifold_f64, normal), "host manifold layout");
+static_assert(AVN_MAX_QUERY_POINTS <= AVN_NP_MAX_RAW, "a host manifold fits the raw-point column");
+template <class T, bool DENSE, bool HEAVY, bool HS = false>
 __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t c,
                                avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                               uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col) {
+                               uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col, NpHostQ<T>* hq = nullptr, const NpHostM<T>* hm = nullptr) {
     uint4 meta = ct.meta[c];
     // (a free id; or a pair of ContactGraph::sleeping_pairs: update_contacts walks the ACTIVE pairs only, system_param.rs:437-475)
     if (DENSE && (!(meta.z & AVN_CP_ROW_USED) || (meta.z & AVN_CP_ROW_SLEEPING))) { chg[c] = 0u; has[c] = 0u; return; }
@@ -131,6 +139,9 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
     const Vec4<T> mn1 = bp.aabb_min[slot1], mx1 = bp.aabb_max[slot1], mn2 = bp.aabb_min[slot2], mx2 = bp.aabb_max[slot2];
     const bool overlap = mn1.x <= mx2.x && mx1.x >= mn2.x && mn1.y <= mx2.y && mx1.y >= mn2.y && mn1.z <= mx2.z && mx1.z >= mn2.z;
     const bool interacts = (ly1.x & ly2.y) != 0 && (ly2.x & ly1.y) != 0;
+    // (HS retry -- the query list overflowed and was grown: only the pairs that were handed to the host are visited again; they wrote nothing the first time)
+    const bool hs_retry = HS && !HEAVY && hq->reserved != 0u;
+    if (hs_retry && (((ci1.z & 0xFFu) != AVN_SHAPE_HOST && (ci2.z & 0xFFu) != AVN_SHAPE_HOST) || !overlap || !interacts)) return;
     if (!overlap || !interacts) {
         flags |= AVN_CP_DISJOINT_AABB;
         status = true;
@@ -174,6 +185,14 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         const V3<T> relative_linear_velocity = lin_vel2 - lin_vel1;
         const T effective_speculative_margin = delta_secs * length(relative_linear_velocity);
         const T max_contact_distance = smax(effective_speculative_margin, p.contact_tolerance) + collision_margin_sum;
+        if (HS && !HEAVY && ((ci1.z & 0xFFu) == AVN_SHAPE_HOST || (ci2.z & 0xFFu) == AVN_SHAPE_HOST)) {   // the manifold is the host's: hand the query over, write nothing
+            hq->contact_id = c; hq->collider1 = ci1.x; hq->collider2 = ci2.x; hq->reserved = 0u;
+            hq->position1[0] = x1.x; hq->position1[1] = x1.y; hq->position1[2] = x1.z; hq->rotation1[0] = q1.x; hq->rotation1[1] = q1.y; hq->rotation1[2] = q1.z; hq->rotation1[3] = q1.w;
+            hq->position2[0] = x2.x; hq->position2[1] = x2.y; hq->position2[2] = x2.z; hq->rotation2[0] = q2.x; hq->rotation2[1] = q2.y; hq->rotation2[2] = q2.z; hq->rotation2[3] = q2.w;
+            hq->max_contact_distance = max_contact_distance;
+            *deferred = true;
+            return;
+        }
         const bool was_touching = flags & AVN_CP_TOUCHING;
         // old_manifolds = contacts.manifolds.clone(): only what match_contacts reads (constant indices: registers)
         V3<T> old_a1[AVN_MAX_MANIFOLD_POINTS], old_a2[AVN_MAX_MANIFOLD_POINTS];
@@ -205,7 +224,14 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         Sink sink = Sink::make(lds_col);
         V3<T> normal = vzero<T>();
         bool defer = HEAVY;
-        const bool has_manifold = NP_DEBUG(p) == 1u ? false
+        bool has_manifold;
+        if (HS && HEAVY) {   // contact_manifolds_with_context answered by the host
+            const uint32_t n = hm->point_count < (uint32_t)AVN_MAX_QUERY_POINTS ? hm->point_count : (uint32_t)AVN_MAX_QUERY_POINTS;
+            normal = V3<T>{hm->normal[0], hm->normal[1], hm->normal[2]};
+            for (uint32_t k = 0; k < n; ++k) sink.put(V3<T>{hm->anchor1[3 * k], hm->anchor1[3 * k + 1], hm->anchor1[3 * k + 2]}, hm->penetration[k], hm->fid1[k], hm->fid2[k]);
+            has_manifold = n != 0u;
+        } else
+        has_manifold = NP_DEBUG(p) == 1u ? false
             : contact_manifolds_pair_sink<T, Sink, HEAVY ? 2 : 1>(ci1.z & 0xFFu, xyz<T>(he1), x1, q1, ci2.z & 0xFFu, xyz<T>(he2), x2, q2, max_contact_distance, sink, normal, &defer, axis);
         if (!HEAVY && defer) { if (NP_DEBUG(p) == 2u) defer = false; else { *deferred = true; return; } }
         if (!HEAVY && has_manifold) load_manifold_inputs();
@@ -358,14 +384,29 @@ __host__ __device__ __forceinline__ uint32_t np_list_segment(uint32_t n_pairs) {
     const uint32_t wgs = (n_pairs + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS;
     return NP_LIGHT_THREADS * ((wgs + NP_LISTS - 1) / NP_LISTS);
 }
-template <class T, bool DENSE>
+// HS: the world holds AVN_SHAPE_HOST colliders -- their pairs' queries are appended to hostq[0 .. *hostq_n) (arbitrary order: the host sorts by contact id)
+template <class T, bool DENSE, bool HS = false>
 __global__ __launch_bounds__(NP_LIGHT_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
                                                                    avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                                                                   uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base) {
+                                                                   uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base, NpHostQ<T>* __restrict__ hostq = nullptr,
+                                                                   uint32_t* __restrict__ hostq_n = nullptr, uint32_t hostq_cap = 0u, uint32_t host_only = 0u) {
     const uint32_t a = blockIdx.x * NP_LIGHT_THREADS + threadIdx.x;
     bool deferred = false;
     V3<T> axis = vzero<T>();
     uint32_t c = 0;
+    if (HS) {
+        NpHostQ<T> q;
+        q.contact_id = 0xFFFFFFFFu; q.reserved = host_only;
+        if (a < n_active) {
+            c = !DENSE ? active[a] : (active || n_list || range_base) ? (a < n_list ? active[a] : range_base + (a - n_list)) : a;
+            np_update_pair<T, DENSE, false, true>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, nullptr, &q, nullptr);
+        }
+        if (deferred && q.contact_id != 0xFFFFFFFFu) {   // a host pair (few of them: one atomic each); past the capacity only the count grows and the host retries larger
+            const uint32_t k = atomicAdd(hostq_n, 1u);
+            if (k < hostq_cap) hostq[k] = q;
+            deferred = false;
+        }
+    } else
     if (a < n_active) {
         // DENSE with a row list (the rows a step ADDED, narrow phase overlapped with the broad phase): ids list[0 .. n_list), then the
         // contiguous fresh ids range_base ..; DENSE without one: every row id; sparse: the active list
@@ -406,6 +447,17 @@ __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_heavy(DW<T> w, BP<T
     }
     __syncthreads();
     if (threadIdx.x == 0 && atomicAdd(ctr + 1, 1u) == (n + NP_THREADS - 1) / NP_THREADS - 1u) { atomicExch(ctr, 0u); atomicExch(ctr + 1, 0u); }
+}
+// the pairs the host answered: one lane each, its raw points in the lane's LDS column like a surviving cuboid pair's
+template <class T, bool DENSE>
+__global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_host(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes,
+                                                                  uint32_t* __restrict__ chg, uint32_t* __restrict__ has, const NpHostQ<T>* __restrict__ q, const NpHostM<T>* __restrict__ m, uint32_t n) {
+    __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];
+    const uint32_t i = blockIdx.x * NP_THREADS + threadIdx.x;
+    if (i >= n) return;
+    bool deferred = false;
+    V3<T> axis = vzero<T>();
+    np_update_pair<T, DENSE, true, true>(w, bp, ct, p, q[i].contact_id, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x, nullptr, m + i);
 }
 size_t np_survivor_list_slack() { return (size_t)NP_LISTS * NP_LIGHT_THREADS; }
 size_t np_survivor_counter_bytes() { return (size_t)NP_LISTS * NP_CTR_STRIDE * sizeof(uint32_t); }
@@ -534,29 +586,47 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
     if (n) hipLaunchKernelGGL(k_clear_contact_rows<T>, dim3((n + 255) / 256), dim3(256), 0, st, ct, ids, n);
 }
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
-                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t st) {
-    (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
+                                            avn_contact_change* changes, uint32_t* n_changes, hipStream_t st, const NpHostList& hl) {
+    if (!hl.host_only) (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
     if (!n_active) return;
+    if (hl.queries) hipLaunchKernelGGL((k_narrow_phase<T, false, true>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    else
     hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
+    if (hl.host_only) return;   // (a retry hands no cuboid pair over: nothing for the second kernel)
     launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
-                                                  uint32_t* n_remove, hipStream_t st, bool reset_counter) {
+                                                  uint32_t* n_remove, hipStream_t st, bool reset_counter, const NpHostList& hl) {
     if (reset_counter) (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
     if (!n_rows) return;
+    if (hl.queries) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    else
     hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
+    if (hl.host_only) return;
     launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st);
 }
 // the rows list[0 .. n_list) followed by range_base .. range_base + n_range: same per-row work and outputs as the dense form; the
 // removal counter is NOT reset (it continues the count of the launch over the older rows)
 template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* list, uint32_t n_list, uint32_t range_base,
-                                                 uint32_t n_range, uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t st) {
+                                                 uint32_t n_range, uint32_t* chg, uint32_t* has, uint32_t* n_remove, hipStream_t st, const NpHostList& hl) {
     const uint32_t n = n_list + n_range;
     if (!n) return;
     // (range_base = 0 with an empty list would read as the plain dense form: a world's first pairs take the dense launch instead)
+    if (hl.queries) {
+        if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+        else hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    } else
     if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u);
     else hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
+    if (hl.host_only) return;
     launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st);
+}
+// the pairs the host answered (queries sorted by contact id on the host, manifolds in the same order): dense = the closed loop's chg / has outputs, else the change list
+template <class T> void launch_narrow_phase_host(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, bool dense, avn_contact_change* changes, uint32_t* n_changes,
+                                                 uint32_t* chg, uint32_t* has, const void* queries, const void* manifolds, uint32_t n, hipStream_t st) {
+    if (!n) return;
+    if (dense) hipLaunchKernelGGL((k_narrow_phase_host<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_changes, chg, has, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n);
+    else hipLaunchKernelGGL((k_narrow_phase_host<T, false>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, nullptr, nullptr, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n);
 }
 template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_scatter_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, ct, handles);
@@ -573,9 +643,10 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     template void launch_pack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, uint32_t*, hipStream_t);                              \
     template void launch_init_contact_rows<T>(const CT<T>&, const uint32_t*, const uint32_t*, const uint32_t*, const uint32_t*, uint32_t, hipStream_t); \
     template void launch_clear_contact_rows<T>(const CT<T>&, const uint32_t*, uint32_t, hipStream_t);                                                \
-    template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t); \
-    template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, bool); \
-    template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t); \
+    template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t, const NpHostList&); \
+    template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, bool, const NpHostList&); \
+    template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, const NpHostList&); \
+    template void launch_narrow_phase_host<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool, avn_contact_change*, uint32_t*, uint32_t*, uint32_t*, const void*, const void*, uint32_t, hipStream_t); \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
     template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);
 INST(float)

@@ -7,6 +7,7 @@
     // (mode 1: the broad phase's counters only -- a frozen-manifold step prepares its constraints on the OTHER stream meanwhile; mode 2, the
     //  closed loop, where everything of the step is behind this kernel: the constraint count too)
     avn_status update_aabb(int step_counters = 0) {
+        if (hs_any()) { avn_status sh = hs_aabbs(bs); if (sh != AVN_OK) return sh; }   // AnyCollider::aabb_with_context of the host's shapes (world/host_shapes.hpp)
         const bool ran = launch_update_aabb<T>(dw, bp, params, bs, step_counters ? b_misc.as<uint32_t>() + (step_counters == 2 ? 32 : 33) : nullptr, step_counters == 2 ? 6u : step_counters ? 5u : 0u);
         bp_counters_clean = step_counters && ran;
         constraint_count_clean = step_counters == 2 && ran;

@@ -127,9 +127,15 @@
         h_changes.clear();
         if (!n_active) return AVN_OK;
         uint32_t* d_count = b_misc.as<uint32_t>() + 40;
-        launch_narrow_phase<T>(dw, bp, ct, params, b_active.as<uint32_t>(), n_active, b_changes.as<avn_contact_change>(), d_count, stream);
+        const NpHostList hl = hs_begin(stream);
+        launch_narrow_phase<T>(dw, bp, ct, params, b_active.as<uint32_t>(), n_active, b_changes.as<avn_contact_change>(), d_count, stream, hl);
         ++launches;
         HIPCHK(hipGetLastError());
+        if (hl.queries) {   // pairs with a host-shaped collider: contact_manifolds_with_context on the host, the rest of update_contacts here (world/host_shapes.hpp)
+            hs_launches.push_back(HsLaunch{0, n_active, 0, 0, 0, b_active.as<uint32_t>()});
+            avn_status sh = hs_manifolds(false, params, b_changes.as<avn_contact_change>(), d_count, nullptr, nullptr, stream);
+            if (sh != AVN_OK) return sh;
+        }
         // the count and the first CHANGES_PREFIX changes come back in one round trip (pinned memory, one synchronisation);
         // only a step with more changes than that pays a second copy
         const uint32_t prefix = std::min<uint32_t>(CHANGES_PREFIX, n_active);

@@ -402,12 +402,14 @@
         if (np_debug_step >= 0 && (uint32_t)np_debug_step != pipe_step_no) np_params.np_debug = 0u;
         ++pipe_step_no;
         const bool np_overlap = np_overlap_enabled && n_rows_old != 0 && bp.n_intervals != 0;
+        const NpHostList hs_hl = hs_begin(stream);   // (host shapes: the list of this step's pairs whose manifold the host computes -- empty world/host_shapes.hpp when there are none)
         if (np_overlap) {
             if (!ev_np_fork) { HIPCHK(hipEventCreateWithFlags(&ev_np_fork, hipEventDisableTiming | EV_FLAGS)); HIPCHK(hipEventCreateWithFlags(&ev_np_old, hipEventDisableTiming | EV_FLAGS)); }
             HIPCHK(hipEventRecord(ev_np_fork, stream));
             HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_fork, 0));
             // (issued BEFORE the broad phase's ~20 launches: the host needs ~150 us to enqueue those, and the narrow phase would start that late)
-            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false);
+            launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows_old, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false, hs_hl);
+            hs_launches.push_back(HsLaunch{1, n_rows_old, 0, 0, 0, nullptr});
             ++launches;
             HIPCHK(hipEventRecord(ev_np_old, stream));
             bs = stream_bp;
@@ -482,11 +484,13 @@
         const uint32_t n_rows = pgm_next_id;
         uint32_t n_ops = 0, n_rem = 0, n_sleep_ops = 0;
         if (n_rows) {
-            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false); ++launches; }
+            if (!np_overlap) { launch_narrow_phase_dense<T>(dw, bp, ct, np_params, n_rows, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, false, hs_hl); hs_launches.push_back(HsLaunch{1, n_rows, 0, 0, 0, nullptr}); ++launches; }
             else if (total) {   // the rows this step added: the lowest free ids first (k_pg_add_pairs), then the fresh ones
-                launch_narrow_phase_rows<T>(dw, bp, ct, np_params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream);
+                launch_narrow_phase_rows<T>(dw, bp, ct, np_params, pg.free_ids + head_old, used_ids, n_rows_old, total - used_ids, pg.chg, pg.has, pg.ctr + PGC_N_REM, stream, hs_hl);
+                hs_launches.push_back(HsLaunch{2, used_ids, n_rows_old, total - used_ids, 0, pg.free_ids + head_old});
                 ++launches;
             }
+            if (hs_hl.queries && (st = hs_manifolds(true, np_params, nullptr, pg.ctr + PGC_N_REM, pg.chg, pg.has, stream)) != AVN_OK) return fail(st);
             if ((st = pg_batch_begin()) != AVN_OK) return fail(st);
             launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream, slp_on ? dw.bmeta : nullptr);   // ops numbered in ascending ContactId AND classified
             ++launches;

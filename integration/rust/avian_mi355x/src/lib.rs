@@ -5,8 +5,8 @@
 //!     PhysicsPlugins::default()
 //!         .build()
 //!         .disable::<BroadPhasePlugin>()      // src/collision/broad_phase.rs:33-170
-//!         // NarrowPhasePlugin stays: with the default `Mi355xMode::Auto` the step runs closed-loop on the device whenever every collider is a
-//!         // Ball / Cuboid without hooks (Avian's narrow phase then walks an empty pair list) and falls back to Avian's own narrow phase
+//!         // NarrowPhasePlugin stays: with the default `Mi355xMode::Auto` the step runs closed-loop on the device whenever no collider carries
+//!         // hooks (Ball / Cuboid in kernels, other shapes through host_shapes.rs) (Avian's narrow phase then walks an empty pair list) and falls back to Avian's own narrow phase
 //!         // otherwise; disable it only with an explicit `Mi355xMode::ClosedLoop`
 //!         .disable::<IntegratorPlugin>()      // src/dynamics/integrator/mod.rs:45-88
 //!         .disable::<SolverPlugin>()          // src/dynamics/solver/plugin.rs:88-151
@@ -21,7 +21,8 @@
 //!
 //! Layers: [`world::Mi355xWorld`] is the safe owner of the `avn_world*`; [`staging::Staging`] turns ECS queries into the
 //! Structure-of-Arrays the C ABI borrows for the duration of a call; [`plugins`] holds the systems of the rigid-body path, [`joints`] the
-//! XpbdSolverPlugin replacement, [`closed_loop`] what the device closed loop owes the ECS (collision events, `CollidingEntities`, `Sleeping`).
+//! XpbdSolverPlugin replacement, [`closed_loop`] what the device closed loop owes the ECS (collision events, `CollidingEntities`, `Sleeping`),
+//! [`host_shapes`] the two `AnyCollider` methods of every collider that is not a Ball / Cuboid, called back by the library (`avn_host_shapes_set`).
 //!
 //! Every component the recipe above takes away from Avian has a system here:
 //!
@@ -35,6 +36,7 @@
 //! | (closed loop only) island sleeping | `Sleeping`, `SleepTimer`, wake on change | `closed_loop::gpu_closed_loop_sleeping`, `gpu_closed_loop_wake_on_changed` (the library's island manager decides: `avn_sleeping_enable`) |
 
 pub mod closed_loop;
+pub mod host_shapes;
 pub mod joints;
 pub mod plugins;
 pub mod staging;

@@ -23,8 +23,8 @@ use core::time::Duration;
 /// How much of the step stays on the device.
 #[derive(Clone, Copy, Default, PartialEq, Eq)]
 pub enum Mi355xMode {
-    /// The default: `ClosedLoop` whenever the scene allows it -- every collider a Ball or a Cuboid on a rigid body the staging knows, no
-    /// `ActiveCollisionHooks` -- and `HostNarrowPhase` otherwise, decided per step (`Mi355xSettings::effective_mode`).  The host-manifold
+    /// The default: `ClosedLoop` whenever the scene allows it -- every collider on a rigid body the staging knows (Ball / Cuboid in device kernels, every other
+    /// shape through the host-shape callbacks of host_shapes.rs), no `ActiveCollisionHooks` -- and `HostNarrowPhase` otherwise, decided per step (`Mi355xSettings::effective_mode`).  The host-manifold
     /// flow moves ~160 MB over PCIe per cfg2 step (5 ms) where the closed loop moves three counter blocks: it must not be what a user
     /// gets without asking.
     #[default]
@@ -32,7 +32,7 @@ pub enum Mi355xMode {
     /// Avian's own (parry) narrow phase keeps running on the host; its manifolds are uploaded every step (`avn_manifolds_upload`),
     /// the substep loop runs device-resident.  Works with every collider shape; pays the manifold upload over PCIe.
     HostNarrowPhase,
-    /// Ball / Cuboid colliders only: contact rows live in HBM, `NarrowPhase::update_contacts`, the status-change loop, the
+    /// Contact rows live in HBM (Ball / Cuboid manifolds from device kernels, other shapes' from `Collider::contact_manifolds` through the callback), `NarrowPhase::update_contacts`, the status-change loop, the
     /// `ConstraintGraph` and the `IdPool` run on the device (`avn_pipeline_enable(1)`); per step only new pairs and body state cross
     /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_pipeline_new_pair_ids_get` + `avn_contact_changes_get` by
     /// `closed_loop::gpu_closed_loop_events`; sleeping is the library's own island manager (`avn_sleeping_enable`), mirrored into `Sleeping` /
@@ -61,7 +61,7 @@ impl Mi355xSettings {
         if self.mode == Mi355xMode::HostNarrowPhase { return Mi355xMode::HostNarrowPhase; }
         if st.colliders_with_hooks != 0 || st.colliders_unsupported != 0 {
             if !self.warned_hooks && self.mode == Mi355xMode::ClosedLoop {
-                bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks, {} are not Ball / Cuboid colliders on a known body: running in HostNarrowPhase mode",
+                bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks, {} are not on a known rigid body: running in HostNarrowPhase mode",
                                  st.colliders_with_hooks, st.colliders_unsupported);
                 self.warned_hooks = true;
             }
@@ -82,6 +82,7 @@ impl Plugin for Mi355xPhysicsPlugin {
         };
         app.insert_resource(world).init_resource::<Mi355xStaging>().insert_resource(Mi355xSettings { mode: self.mode, warned_hooks: false });
         app.init_resource::<crate::joints::JointStaging>().init_resource::<crate::closed_loop::ContactMirror>().init_resource::<crate::closed_loop::ClosedLoopSleeping>();
+        app.init_resource::<crate::host_shapes::HostShapeTable>();   // colliders that are not Ball / Cuboid: answered through avn_host_shapes_set (registered in gpu_upload_bodies)
         app.init_resource::<SolverDiagnostics>().init_resource::<CollisionDiagnostics>();
 
         // the same sets as the plugins being replaced: src/collision/broad_phase.rs:51-74, src/dynamics/solver/plugin.rs:103-150,
@@ -147,7 +148,13 @@ fn gpu_upload_bodies(
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
     js: Res<crate::joints::JointStaging>,
     live_joints: Query<(), (Or<(With<FixedJoint>, With<RevoluteJoint>, With<SphericalJoint>, With<PrismaticJoint>, With<DistanceJoint>)>, Without<JointDisabled>)>,
+    mut host_shapes: ResMut<crate::host_shapes::HostShapeTable>, mut host_shapes_registered: Local<bool>,
 ) {
+    if !*host_shapes_registered {   // (the resource's address is stable from here on: Bevy boxes resources)
+        let raw = w.raw();
+        let s = host_shapes.register(raw); w.check(s);
+        *host_shapes_registered = true;
+    }
     let st = &mut st.0;
     // Despawns since the last step, in the order Bevy reports the removals (= the order Avian's own observers ran in).  The staging still holds
     // LAST frame's numbering here: body index = position in `body_entities` (sorted by Entity, so dropping entries is the stable compaction
@@ -164,7 +171,7 @@ fn gpu_upload_bodies(
         .map(|(i, _)| i as u32).collect();
     w.despawn(&gone_bodies, &gone_colliders, &gone_joints);
     st.fill_bodies(bodies.iter(), |e| increments.get(e).map_or((Vec3::ZERO, Vec3::ZERO), |v| (v.linear_increment(), v.angular_increment())));
-    st.fill_colliders(colliders.iter());
+    st.fill_colliders(colliders.iter(), &mut host_shapes);   // Ball / Cuboid: device shapes; everything else: AVN_SHAPE_HOST + its Collider into the table
     let (b, c) = (st.bodies_desc(), st.colliders_desc());
     let raw = w.raw();
     let s1 = unsafe { ffi::avn_bodies_upload(raw, &b) }; w.check(s1);

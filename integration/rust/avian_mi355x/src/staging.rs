@@ -95,12 +95,14 @@ impl Staging {
     }
 
     /// Colliders in the order `AabbIntervals` would hold them (existing ones keep their place, new ones are appended:
-    /// src/collision/broad_phase.rs:214-315).  Only Ball / Cuboid shapes sitting on their rigid-body entity are supported by the device
-    /// AABB update and narrow phase; anything else makes the plugin fall back to the stock broad phase for that collider's pairs.
+    /// src/collision/broad_phase.rs:214-315).  Ball / Cuboid shapes have device kernels; every other shape is uploaded as `AVN_SHAPE_HOST` and answered by the two
+    /// callbacks of host_shapes.rs (its `Collider` goes into `host_shapes`): it stays in the closed loop.  Only a collider that is not on a known rigid body is unsupported.
     pub fn fill_colliders<'a>(
         &mut self,
         colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
+        host_shapes: &mut crate::host_shapes::HostShapeTable,
     ) {
+        host_shapes.colliders.clear();
         macro_rules! clear { ($($f:ident),*) => { $( self.$f.clear(); )* } }
         clear!(collider_entities, collider_slot, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative);
         self.colliders_with_hooks = 0;
@@ -109,8 +111,9 @@ impl Staging {
             let shape = collider.shape_scaled();
             let (kind, he) = if let Some(b) = shape.as_ball() { (ffi::AVN_SHAPE_BALL, Vec3::new(b.radius, 0.0, 0.0)) }
                              else if let Some(c) = shape.as_cuboid() { (ffi::AVN_SHAPE_CUBOID, Vec3::new(c.half_extents.x, c.half_extents.y, c.half_extents.z)) }
-                             else { self.colliders_unsupported += 1; continue };
+                             else { (ffi::AVN_SHAPE_HOST, Vec3::ZERO) };   // capsule, cylinder, cone, convex hull, ...: aabb / contact_manifolds stay on the host
             let Some(&body) = self.body_index.get(&of.body) else { self.colliders_unsupported += 1; continue };
+            if kind == ffi::AVN_SHAPE_HOST { host_shapes.colliders.insert(e.index(), collider.clone()); }
             self.collider_slot.insert(e.index(), self.collider_entities.len());
             if hooks { self.colliders_with_hooks += 1; }
             self.collider_entities.push(e);

@@ -291,6 +291,8 @@ struct WorldBase {
     virtual avn_status sleep_update(const avn_sleep_params*, avn_sleep_stats*) = 0;
     virtual avn_status sleep_get(const avn_sleep_out*) = 0;
     virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
+    virtual avn_status host_shapes_set(avn_host_aabb_fn, avn_host_manifolds_fn, void*) = 0;
+    virtual avn_status host_shape_stats_get(avn_host_shape_stats*) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
     virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
@@ -1376,12 +1378,14 @@ template <class S> struct World : WorldBase {
         if (!c || (c->count && (!c->entity_index || !c->body || !c->shape || !c->half_extents))) { error = "colliders_upload: null array"; return AVN_ERR_BAD_ARG; }
         std::vector<Collider<S>> next(c->count);
         std::unordered_map<uint32_t, uint32_t> next_slot;
+        uint32_t n_host_here = 0;
         for (uint32_t i = 0; i < c->count; ++i) {
             Collider<S>& o = next[i];
             o.entity = c->entity_index[i];
             o.body = c->body[i];
             if (o.body < 0 || (size_t)o.body >= bodies.size()) { error = "colliders_upload: body index out of range"; return AVN_ERR_BAD_ARG; }
             o.shape = c->shape[i];
+            n_host_here += o.shape == AVN_SHAPE_HOST;
             o.half_extents = rd3(c->half_extents, i);
             o.memberships = rd<uint32_t>(c->memberships, i, 1u);
             o.filters = rd<uint32_t>(c->filters, i, 0xFFFFFFFFu);
@@ -1409,6 +1413,7 @@ template <class S> struct World : WorldBase {
         colliders.swap(next);
         collider_slot.swap(next_slot);
         intervals.swap(kept);
+        n_host_colliders = n_host_here;
         have_colliders = true;
         despawn_needs_colliders = false;
         if (slp)   // colliders spawned inside the loop join their body's RigidBodyColliders (upload order = Add order)
@@ -1689,7 +1694,11 @@ template <class S> struct World : WorldBase {
                 bool was_touching = r.flags & AVN_CP_TOUCHING;
                 CtRow old = r;  // old_manifolds = contacts.manifolds.clone()
                 QueryManifold<S> qm;
-                bool has = contact_manifolds_pair<S>(c1.shape, c1.half_extents, b1.position, b1.rotation, c2.shape, c2.half_extents, b2.position, b2.rotation, max_contact_distance, qm);
+                bool has;
+                if (c1.shape == AVN_SHAPE_HOST || c2.shape == AVN_SHAPE_HOST)   // AnyCollider::contact_manifolds_with_context on the host (system_param.rs:700-712; header: "host shapes")
+                    has = host_contact_manifold(id, c1, b1, c2, b2, max_contact_distance, qm);
+                else
+                has = contact_manifolds_pair<S>(c1.shape, c1.half_extents, b1.position, b1.rotation, c2.shape, c2.half_extents, b2.position, b2.rotation, max_contact_distance, qm);
                 // retain_mut over the (at most one) manifold
                 CtPoint kept[AVO_MAX_RAW_POINTS];
                 int nk = 0;
@@ -1754,14 +1763,61 @@ template <class S> struct World : WorldBase {
         {
             const size_t n = active_pairs.size(), chunk = std::max<size_t>(n / pool.threads, 1), chunks = n ? (n + chunk - 1) / chunk : 0;
             std::vector<std::vector<avn_contact_change>> per_chunk(pool.threads == 1 || n < 64 ? 1 : chunks);
-            if (per_chunk.size() == 1) { for (uint32_t id : active_pairs) update_pair(id, per_chunk[0]); }
-            else pool.par_for_each(n, 64, [&](size_t b0, size_t b1) { std::vector<avn_contact_change>& out = per_chunk[b0 / chunk]; for (size_t i = b0; i < b1; ++i) update_pair(active_pairs[i], out); });
+            // (pairs with a host-shaped collider call back into the host: on the calling thread, in ascending contact id, after the pool's share)
+            auto host_pair = [&](uint32_t id) {
+                if (n_host_colliders == 0) return false;
+                const CtRow& r = contact_rows[id];
+                auto i1 = collider_slot.find(r.collider1), i2 = collider_slot.find(r.collider2);
+                return i1 != collider_slot.end() && i2 != collider_slot.end() && (colliders[i1->second].shape == AVN_SHAPE_HOST || colliders[i2->second].shape == AVN_SHAPE_HOST);
+            };
+            if (per_chunk.size() == 1) { for (uint32_t id : active_pairs) if (!host_pair(id)) update_pair(id, per_chunk[0]); }
+            else pool.par_for_each(n, 64, [&](size_t b0, size_t b1) { std::vector<avn_contact_change>& out = per_chunk[b0 / chunk]; for (size_t i = b0; i < b1; ++i) if (!host_pair(active_pairs[i])) update_pair(active_pairs[i], out); });
+            if (n_host_colliders) {
+                std::vector<uint32_t> hp;
+                for (uint32_t id : active_pairs) if (host_pair(id)) hp.push_back(id);
+                std::sort(hp.begin(), hp.end());
+                hs_stats.last_manifold_queries = (uint32_t)hp.size(); hs_stats.last_manifolds_with_points = 0;
+                for (uint32_t id : hp) update_pair(id, per_chunk[0]);
+            }
             for (const std::vector<avn_contact_change>& v : per_chunk) contact_changes.insert(contact_changes.end(), v.begin(), v.end());
         }
         std::sort(contact_changes.begin(), contact_changes.end(), [](const avn_contact_change& a, const avn_contact_change& b) { return a.contact_id < b.contact_id; });
         // the status processing of system_param.rs:141-389 clears these once handled (host side); here they are per-step outputs
         for (const avn_contact_change& c : contact_changes)
             contact_rows[c.contact_id].flags &= ~(uint32_t)(AVN_CP_STARTED_TOUCHING | AVN_CP_STOPPED_TOUCHING | AVN_CP_STARTED_GENERATING_CONSTRAINTS);
+    }
+    // ---- host shapes (header: "host shapes"): the two AnyCollider methods through the callbacks, one query per call ----
+    avn_host_aabb_fn hs_aabb_fn = nullptr; avn_host_manifolds_fn hs_manifolds_fn = nullptr; void* hs_user = nullptr;
+    uint32_t n_host_colliders = 0;
+    avn_host_shape_stats hs_stats{};
+    template <class Q> struct HostAabbQ { uint32_t collider, swept; Q start_position[3], start_rotation[4], end_position[3], end_rotation[4]; };
+    template <class Q> struct HostAabb { Q min[3], max[3]; };
+    template <class Q> struct HostMQ { uint32_t contact_id, collider1, collider2, reserved; Q position1[3], rotation1[4], position2[3], rotation2[4], max_contact_distance; };
+    template <class Q> struct HostMM { uint32_t point_count; Q normal[3]; Q anchor1[3 * AVN_MAX_QUERY_POINTS]; Q penetration[AVN_MAX_QUERY_POINTS]; uint32_t fid1[AVN_MAX_QUERY_POINTS], fid2[AVN_MAX_QUERY_POINTS]; };
+    static_assert(sizeof(HostMM<float>) == sizeof(avn_host_manifold_f32) && sizeof(HostMM<double>) == sizeof(avn_host_manifold_f64), "host manifold layout");
+    static_assert(sizeof(HostMQ<float>) == sizeof(avn_host_manifold_query_f32) && sizeof(HostMQ<double>) == sizeof(avn_host_manifold_query_f64), "host query layout");
+    static_assert(sizeof(HostAabbQ<float>) == sizeof(avn_host_aabb_query_f32) && sizeof(HostAabbQ<double>) == sizeof(avn_host_aabb_query_f64), "host aabb query layout");
+    avn_status host_shapes_set(avn_host_aabb_fn a, avn_host_manifolds_fn m, void* user) override {
+        if ((a == nullptr) != (m == nullptr)) { error = "host_shapes_set: both callbacks or none"; return AVN_ERR_BAD_ARG; }
+        hs_aabb_fn = a; hs_manifolds_fn = m; hs_user = user;
+        return AVN_OK;
+    }
+    avn_status host_shape_stats_get(avn_host_shape_stats* o) override { if (!o) return AVN_ERR_BAD_ARG; hs_stats.host_colliders = n_host_colliders; *o = hs_stats; return AVN_OK; }
+    bool host_contact_manifold(uint32_t id, const Collider<S>& c1, const Body<S>& b1, const Collider<S>& c2, const Body<S>& b2, S max_contact_distance, QueryManifold<S>& qm) {
+        HostMQ<S> q{id, c1.entity, c2.entity, 0u, {b1.position.x, b1.position.y, b1.position.z}, {b1.rotation.x, b1.rotation.y, b1.rotation.z, b1.rotation.w},
+                    {b2.position.x, b2.position.y, b2.position.z}, {b2.rotation.x, b2.rotation.y, b2.rotation.z, b2.rotation.w}, max_contact_distance};
+        HostMM<S> m;
+        std::memset(&m, 0, sizeof m);
+        hs_manifolds_fn(hs_user, (uint32_t)(8 * sizeof(S)), 1u, &q, &m);
+        hs_stats.bytes_to_host += sizeof q; hs_stats.bytes_from_host += sizeof q + sizeof m;
+        qm.n = (int)std::min<uint32_t>(m.point_count, AVN_MAX_QUERY_POINTS);
+        qm.normal = {m.normal[0], m.normal[1], m.normal[2]};
+        for (int k = 0; k < qm.n; ++k) {
+            V3<S> anchor1{m.anchor1[3 * k], m.anchor1[3 * k + 1], m.anchor1[3 * k + 2]};
+            qm.pts[k] = {anchor1, anchor1 + (b1.position - b2.position), b1.position + anchor1, m.penetration[k], m.fid1[k], m.fid2[k]};   // contact_query.rs:243-248
+        }
+        hs_stats.last_manifolds_with_points += qm.n != 0;
+        return qm.n != 0;
     }
     // the manifolds prepare_contact_constraints reads through GraphColor::manifold_handles (plugin.rs:389-398)
     void gather_manifolds_from_handles() {
@@ -1825,11 +1881,27 @@ template <class S> struct World : WorldBase {
         S delta_secs = dt_adj;
         S default_speculative_margin = (S)cfg.length_unit * (cfg.default_speculative_margin >= (double)std::numeric_limits<S>::max() ? std::numeric_limits<S>::max() : (S)cfg.default_speculative_margin);
         S contact_tolerance = (S)cfg.length_unit * (S)cfg.contact_tolerance;
+        hs_stats.last_aabb_queries = 0;
         for (Collider<S>& c : colliders) {
             const Body<S>& b = bodies[c.body];
             S speculative_margin = (c.cflags & AVN_COLLIDER_SWEPT_CCD) ? std::numeric_limits<S>::max()
                                    : (c.speculative_margin >= S(0) ? c.speculative_margin : default_speculative_margin);
             S g = contact_tolerance + c.collision_margin;
+            if (c.shape == AVN_SHAPE_HOST) {   // aabb_with_context / swept_aabb_with_context on the host (backend.rs:556-620; header: "host shapes")
+                const bool swept = !(speculative_margin <= S(0));
+                Q4<S> end_rot = b.rotation; V3<S> end_pos = b.position;
+                if (swept) {
+                    end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), b.rotation));
+                    end_pos = b.position + clamp_length_max(b.linear_velocity * delta_secs, smax(speculative_margin, contact_tolerance));
+                }
+                HostAabbQ<S> q{c.entity, swept ? 1u : 0u, {b.position.x, b.position.y, b.position.z}, {b.rotation.x, b.rotation.y, b.rotation.z, b.rotation.w},
+                               {end_pos.x, end_pos.y, end_pos.z}, {end_rot.x, end_rot.y, end_rot.z, end_rot.w}};
+                HostAabb<S> a{};
+                hs_aabb_fn(hs_user, (uint32_t)(8 * sizeof(S)), 1u, &q, &a);
+                hs_stats.bytes_to_host += sizeof q; hs_stats.bytes_from_host += sizeof a; ++hs_stats.last_aabb_queries;
+                c.aabb = {V3<S>{a.min[0], a.min[1], a.min[2]} - V3<S>{g, g, g}, V3<S>{a.max[0], a.max[1], a.max[2]} + V3<S>{g, g, g}};
+                continue;
+            }
             if (speculative_margin <= S(0)) {
                 ColliderAabb<S> a = shape_aabb(c, b.position, b.rotation);
                 c.aabb = {a.min - V3<S>{g, g, g}, a.max + V3<S>{g, g, g}};
@@ -1959,7 +2031,7 @@ template <class S> struct World : WorldBase {
     }
     avn_status run_system(avn_system sys) override {
         switch (sys) {
-            case AVN_SYS_UPDATE_AABB: update_aabb(); break;
+            case AVN_SYS_UPDATE_AABB: if (n_host_colliders && !hs_aabb_fn) { error = "the world holds AVN_SHAPE_HOST colliders and no callbacks (avn_host_shapes_set)"; return AVN_ERR_STATE; } update_aabb(); break;
             case AVN_SYS_COLLECT_COLLISION_PAIRS: collect_collision_pairs(); break;
             case AVN_SYS_PREPARE_SOLVER_BODIES: prepare_solver_bodies(); break;
             case AVN_SYS_PREPARE_JOINTS: prepare_joints(); break;
@@ -1979,12 +2051,13 @@ template <class S> struct World : WorldBase {
             case AVN_SYS_STORE_CONTACT_IMPULSES: store_contact_impulses(); break;
             case AVN_SYS_SUBSTEP: substep(); break;
             case AVN_SYS_SOLVER: solver(); break;
-            case AVN_SYS_NARROW_PHASE: narrow_phase(); break;
+            case AVN_SYS_NARROW_PHASE: if (n_host_colliders && !hs_aabb_fn) { error = "the world holds AVN_SHAPE_HOST colliders and no callbacks (avn_host_shapes_set)"; return AVN_ERR_STATE; } narrow_phase(); break;
             default: error = "run_system: unknown system"; return AVN_ERR_BAD_ARG;
         }
         return AVN_OK;
     }
     avn_status step() override {
+        if (n_host_colliders && !hs_aabb_fn) { error = "the world holds AVN_SHAPE_HOST colliders and no callbacks (avn_host_shapes_set)"; return AVN_ERR_STATE; }
         if (pipe) return pipeline_step();
         diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
         if (have_colliders) timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });

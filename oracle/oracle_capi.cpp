@@ -191,6 +191,8 @@ avn_status avo_level2_plan_rank_overflow(const avn_level2_plan* plan, uint32_t r
     *n_levels = plan->n_overflow_levels; *level_of = plan->ranks[rank].overflow_level.data();
     return AVN_OK;
 }
+avn_status avo_host_shapes_set(avn_world* w, avn_host_aabb_fn a, avn_host_manifolds_fn m, void* user) { FWD(host_shapes_set(a, m, user)); }
+avn_status avo_host_shape_stats_get(avn_world* w, avn_host_shape_stats* o) { FWD(host_shape_stats_get(o)); }
 avn_status avo_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { FWD(halo_overflow_levels_upload(n_levels, level_of, count)); }
 avn_status avo_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out) {
     if (!plan || !out || rank >= plan->ranks.size()) return AVN_ERR_BAD_ARG;

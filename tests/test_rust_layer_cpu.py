@@ -83,3 +83,25 @@ def test_every_promised_system_exists_and_is_registered():
     for name, s in src.items():
         for mentioned in set(re.findall(r"`(?:\w+::)*(gpu_\w+)`", s)):
             assert re.search(rf"fn {mentioned}\(", everything), f"{name} mentions `{mentioned}`, which does not exist"
+
+
+def test_host_shape_trampolines_use_the_reference_names_and_the_header_records():
+    """host_shapes.rs answers avn_host_aabb_fn / avn_host_manifolds_fn with the reference's own SimpleCollider methods and ContactPoint fields: every one of them
+    must exist in /root/reference (when present here), the trampolines must be registered, and fill_colliders must route non-Ball / Cuboid shapes to the table."""
+    src = sources()
+    hs = src["host_shapes.rs"]
+    for used in ("avn_host_shapes_set", "avn_host_aabb_query_f32", "avn_host_aabb_f32", "avn_host_manifold_query_f32", "avn_host_manifold_f32", "AVN_MAX_QUERY_POINTS"):
+        assert f"ffi::{used}" in hs
+    assert "AVN_SHAPE_HOST" in src["staging.rs"] and "host_shapes.colliders.insert" in src["staging.rs"]
+    assert "host_shapes.register(raw)" in src["plugins.rs"] and "init_resource::<crate::host_shapes::HostShapeTable>" in src["plugins.rs"]
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        return
+    collider_mod = open(os.path.join(ref, "collision", "collider", "mod.rs")).read()
+    contact_types = open(os.path.join(ref, "collision", "contact_types", "mod.rs")).read()
+    for method in ("fn aabb(", "fn swept_aabb(", "fn contact_manifolds("):   # SimpleCollider (collider/mod.rs:263-320)
+        assert method in collider_mod and "." + method[3:] in hs, method
+    for field in ("anchor1", "penetration", "feature_id1", "feature_id2"):
+        assert re.search(rf"pub {field}:", contact_types) and f"p.{field}" in hs, field
+    assert re.search(r"pub normal: Vector", contact_types) and "m.normal" in hs and "m.points" in hs
+    assert re.search(r"pub min: Vector", collider_mod) and "aabb.min" in hs and "aabb.max" in hs
