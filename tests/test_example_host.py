@@ -28,3 +28,13 @@ def test_example_runs_the_closed_loop_on_the_device():
     build()
     r = subprocess.run([EXE, "12", "10", "12", "60"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "DEMO_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_host_shapes_example_capsules_from_a_compiled_host():
+    """examples/host_shapes_demo.cpp: capsules that exist only in the host's two callbacks next to a device box stack, in the library's closed loop."""
+    build()
+    exe = os.path.join(REPO, "examples", "host_shapes_demo")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "12", "10", "12", "400", "150"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "HOST_SHAPES_DEMO_OK" in r.stdout, r.stdout + r.stderr

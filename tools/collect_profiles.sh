@@ -27,6 +27,7 @@ cpf sleeping_many_pyramids_windows.txt sleeping_many_pyramids_windows.txt
 cpf cfg3_closed_loop_joint_lds_ab.txt cfg3_closed_loop_joint_lds_ab.txt
 cpf cfg5_closed_loop_windows.txt cfg5_closed_loop_windows.txt
 cpf dshard_cost_model.txt dshard_cost_model.txt
+cpf host_shapes_demo.txt host_shapes_demo.txt
 cpf narrow_phase_cutoffs.txt narrow_phase_cutoffs.txt
 cpf pmc_narrow_phase.json pmc_narrow_phase.json
 cpf pmc_closed_loop_settled.json pmc_closed_loop_settled.json

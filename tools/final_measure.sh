@@ -73,6 +73,8 @@ bash tools/sleeping_timeline.sh 230 > /dev/null 2>&1; cp $R/gpurun_out/sleeping_
 for e in 0 1; do AVN_LIB_PATH=$M $( [ $e = 1 ] && echo env AVN_NO_JOINT_LDS=1 ) timeout 200 python tools/time_cfg3.py 2>/dev/null | sed "s/^/joint_lds_off=$e /"; done > $O/cfg3_closed_loop_joint_lds_ab.txt
 timeout 300 python tools/time_cfg5.py 1 > $O/cfg5_closed_loop_windows.txt 2>/dev/null
 timeout 300 python tools/time_dshard.py 120 > $O/dshard_cost_model.txt 2>/dev/null
+# round 6: host shapes -- a compiled host whose capsules exist only in its two callbacks, next to cfg2's box stack in the closed loop: cost per step with 1 000 / 10 000 of them
+( cd $R/examples && make -s >/dev/null 2>&1; for c in 1000 10000; do timeout 120 ./host_shapes_demo 50 40 50 $c 140; done ) > $O/host_shapes_demo.txt 2>&1
 timeout 300 python tools/pmc_closed_loop_tail.py $O/pmc_closed_loop_settled.json 120 20 > $O/pmc_closed_loop_settled.txt 2>&1
 for s in many large; do prof scene_$s python $R/tools/profile_reference_scene.py $s; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*domain_stats.csv" -delete; find $O -name "*agent_info.csv" -delete
