@@ -108,6 +108,7 @@ class avn_joints_out(C.Structure):
 
 
 JOINT_FIXED, JOINT_REVOLUTE, JOINT_SPHERICAL, JOINT_PRISMATIC, JOINT_DISTANCE = 0, 1, 2, 3, 4
+JOINT_TYPE_COUNT = 5
 JOINT_HAS_LIMIT1, JOINT_HAS_LIMIT2 = 1, 2
 
 
@@ -242,6 +243,10 @@ class avn_sleep_out(C.Structure):
     _fields_ = [("sleep_timer", vp), ("island", vp), ("island_rests", vp), ("island_wakes", vp)]
 
 
+class avn_level2_joints(C.Structure):
+    _fields_ = [("n_joints", C.c_uint32), ("body1", C.POINTER(C.c_int32)), ("body2", C.POINTER(C.c_int32)), ("joint_type", C.POINTER(C.c_uint8)), ("damped", C.c_uint32)]
+
+
 class avn_halo_plan(C.Structure):
     _fields_ = [("n_peers", C.c_uint32), ("peer_rank", vp), ("send_offsets", vp), ("send_bodies", vp), ("recv_offsets", vp), ("recv_bodies", vp)]
 
@@ -282,7 +287,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -335,6 +340,9 @@ class Library:
         f("level2_plan_rank").argtypes = [vp, C.c_uint32, C.POINTER(avn_level2_rank)]
         f("level2_plan_rank_overflow").argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32))]
         f("halo_overflow_levels_upload").argtypes = [vp, C.c_uint32, vp, C.c_size_t]
+        f("halo_joint_slot_set").argtypes = [vp, C.c_uint32, C.c_uint32]
+        f("level2_plan_create_joints").argtypes = [C.POINTER(avn_level2_in), C.POINTER(avn_level2_joints), C.POINTER(vp)]
+        f("level2_plan_rank_joints").argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         f("host_shapes_set").argtypes = [vp, HOST_SHAPE_FN, HOST_SHAPE_FN, vp]
         f("host_shape_stats_get").argtypes = [vp, C.POINTER(avn_host_shape_stats)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
@@ -431,14 +439,19 @@ class Library:
             raise AvnError(st, "interval_orders_merge: bad arguments")
         return out[: n.value].astype(np.int64)
 
-    def level2_plan(self, rb_type, center_x, body1, body2, color_offsets, n_ranks: int):
+    def level2_plan(self, rb_type, center_x, body1, body2, color_offsets, n_ranks: int, joints=None):
         """``avn_level2_plan_*``: per rank a dict(bodies, manifolds, color_offsets, peers, send_offsets, send_bodies, recv_offsets, recv_bodies, n_overflow_levels,
         overflow_level).  Exchange slots: 23 colours + n_overflow_levels (1 unless an overflow-colour manifold touches a shared body)."""
         rb = np.ascontiguousarray(rb_type, np.uint8); cx = np.ascontiguousarray(center_x, np.float64)
         b1 = np.ascontiguousarray(body1, np.int32); b2 = np.ascontiguousarray(body2, np.int32); co = np.ascontiguousarray(color_offsets, np.uint32)
         inp = avn_level2_in(len(rb), _ptr(rb), _ptr(cx), len(b1), _ptr(b1), _ptr(b2), _ptr(co), int(n_ranks))
         h = vp()
-        st = self.fn("level2_plan_create")(C.byref(inp), C.byref(h))
+        if joints is not None:   # (joint body1, joint body2, joint_type, damped): avn_level2_plan_create_joints
+            jb1 = np.ascontiguousarray(joints[0], np.int32); jb2 = np.ascontiguousarray(joints[1], np.int32); jt = np.ascontiguousarray(joints[2], np.uint8)
+            jn = avn_level2_joints(len(jb1), C.cast(_ptr(jb1), C.POINTER(C.c_int32)), C.cast(_ptr(jb2), C.POINTER(C.c_int32)), C.cast(_ptr(jt), C.POINTER(C.c_uint8)), 1 if joints[3] else 0)
+            st = self.fn("level2_plan_create_joints")(C.byref(inp), C.byref(jn), C.byref(h))
+        else:
+            st = self.fn("level2_plan_create")(C.byref(inp), C.byref(h))
         if st != 0:
             raise AvnError(st, "level2_plan: refused (bad indices)")
         try:
@@ -454,14 +467,19 @@ class Library:
                 st = self.fn("level2_plan_rank_overflow")(h, r, C.byref(nlev), C.byref(lev_p))
                 if st != 0:
                     raise AvnError(st, "level2_plan_rank_overflow")
-                nl = (23 + nlev.value) * npeers + 1 if npeers else 1
+                nj = C.c_uint32(); jp = C.POINTER(C.c_uint32)(); jslot = C.c_uint32(); gj = C.c_uint32()
+                st = self.fn("level2_plan_rank_joints")(h, r, C.byref(nj), C.byref(jp), C.byref(jslot), C.byref(gj))
+                if st != 0:
+                    raise AvnError(st, "level2_plan_rank_joints")
+                nl = (23 + nlev.value + jslot.value) * npeers + 1 if npeers else 1
                 n_ovf = int(k.color_offsets[24] - k.color_offsets[23])
                 so = arr(C.cast(k.halo.send_offsets, C.POINTER(C.c_uint32)), nl, np.uint32); ro = arr(C.cast(k.halo.recv_offsets, C.POINTER(C.c_uint32)), nl, np.uint32)
                 out.append(dict(bodies=arr(k.bodies, k.n_bodies, np.int64), manifolds=arr(k.manifolds, k.n_manifolds, np.int64), color_offsets=arr(k.color_offsets, 25, np.uint32),
                                 peers=arr(C.cast(k.halo.peer_rank, C.POINTER(C.c_int32)), npeers, np.int32), send_offsets=so,
                                 send_bodies=arr(C.cast(k.halo.send_bodies, C.POINTER(C.c_int32)), int(so[-1]), np.int32), recv_offsets=ro,
                                 recv_bodies=arr(C.cast(k.halo.recv_bodies, C.POINTER(C.c_int32)), int(ro[-1]), np.int32),
-                                n_overflow_levels=int(nlev.value), overflow_level=arr(lev_p, n_ovf, np.uint32)))
+                                n_overflow_levels=int(nlev.value), overflow_level=arr(lev_p, n_ovf, np.uint32),
+                                joints=arr(jp, nj.value, np.int64) if joints is not None else None, joint_slot=bool(jslot.value), global_joints=bool(gj.value)))
             return out
         finally:
             self.fn("level2_plan_destroy")(h)
@@ -888,6 +906,11 @@ class World:
         lv = np.ascontiguousarray(level_of, np.uint32)
         self._check(self.lib.fn("halo_overflow_levels_upload")(self.handle, int(n_levels), _ptr(lv), len(lv)))
 
+    def halo_joint_slot_set(self, joint_slot: bool, global_joints: bool):
+        """``avn_halo_joint_slot_set``: call BEFORE halo_plan_upload (the joint slot is one more slot behind the colours and overflow levels, 16 scalars per body)."""
+        self._check(self.lib.fn("halo_joint_slot_set")(self.handle, 1 if joint_slot else 0, 1 if global_joints else 0))
+        self._halo_joint = bool(joint_slot)
+
     def halo_plan_upload(self, peers, send_offsets, send_bodies, recv_offsets, recv_bodies):
         peers = np.ascontiguousarray(peers, np.int32)
         so = np.ascontiguousarray(send_offsets, np.uint32); sb = np.ascontiguousarray(send_bodies, np.int32)
@@ -902,7 +925,8 @@ class World:
     def halo_pack(self, color: int, peer: int) -> np.ndarray:
         peers, so, _ = self._halo
         n = int(so[color * len(peers) + peer + 1] - so[color * len(peers) + peer])
-        out = np.zeros((n, 8), self.dtype)
+        joint = getattr(self, "_halo_joint", False) and len(peers) and color == (len(so) - 1) // len(peers) - 1   # the last slot of a plan with a joint slot
+        out = np.zeros((n, 16 if joint else 8), self.dtype)
         cnt = C.c_size_t()
         self._check(self.lib.fn("halo_pack")(self.handle, int(color), int(peer), _ptr(out), C.byref(cnt)))
         assert cnt.value == n

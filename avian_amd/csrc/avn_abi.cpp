@@ -149,6 +149,7 @@ AVN_API avn_status avn_host_shapes_set(avn_world* w, avn_host_aabb_fn aabb, avn_
 AVN_API avn_status avn_host_shape_stats_get(avn_world* w, avn_host_shape_stats* out) { GUARD(host_shape_stats_get(out)); }
 AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD_MUT(halo_plan_upload(p)); }
 AVN_API avn_status avn_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { GUARD_MUT(halo_overflow_levels_upload(n_levels, level_of, count)); }
+AVN_API avn_status avn_halo_joint_slot_set(avn_world* w, uint32_t joint_slot, uint32_t global_joints) { GUARD_MUT(halo_joint_slot_set(joint_slot, global_joints)); }
 AVN_API avn_status avn_run_color_pass(avn_world* w, avn_system pass, uint32_t color) { GUARD_MUT(run_color_pass(pass, color)); }
 AVN_API avn_status avn_halo_pack(avn_world* w, uint32_t color, uint32_t peer, void* out, size_t* count) { GUARD(halo_pack(color, peer, out, count)); }
 AVN_API avn_status avn_halo_unpack(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count) { GUARD_MUT(halo_unpack(color, peer, in, count)); }

@@ -316,6 +316,8 @@ void launch_sleep_reset(float* timer, const uint32_t* bodies, uint32_t n, uint32
 // level-2 sharding: (SolverBody linear | angular velocity records) of a list of bodies <-> a contiguous buffer of 2 records per body
 template <class T> void launch_halo_pack(const DW<T>&, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t);
 template <class T> void launch_halo_unpack(const DW<T>&, const int32_t* bodies, uint32_t n, const Vec4<T>* in, hipStream_t);
+template <class T> void launch_halo_pack_joint(const DW<T>&, const int32_t* bodies, uint32_t n, Vec4<T>* out /* 4 records per body */, hipStream_t);
+template <class T> void launch_halo_unpack_joint(const DW<T>&, const int32_t* bodies, uint32_t n, const Vec4<T>* in, hipStream_t);
 template <class T> struct ManifoldStage {
     const int32_t *body1, *body2;
     const T *normal, *friction, *restitution, *tangent_velocity, *anchor1, *anchor2, *penetration, *normal_speed, *warm_n, *warm_t;

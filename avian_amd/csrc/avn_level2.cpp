@@ -16,14 +16,15 @@ struct avn_level2_plan {
         std::vector<int32_t> peers, send_bodies, recv_bodies;
         std::vector<uint32_t> send_offsets, recv_offsets;
         std::vector<uint32_t> overflow_level;   // per local overflow manifold (local order): its level in the GLOBAL overflow list, 0-based
+        std::vector<uint32_t> joints;           // global joint indices owned (ascending)
     };
     uint32_t n_overflow_levels = 1;
+    bool joint_slot = false, global_joints = false;
     std::vector<Rank> ranks;
 };
 
-extern "C" {
-
-AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) {
+static avn_status plan_create(const avn_level2_in* in, const avn_level2_joints* jn, avn_level2_plan** out) {
+    if (jn && jn->n_joints && (!jn->body1 || !jn->body2 || !jn->joint_type)) return AVN_ERR_BAD_ARG;
     if (!in || !out || in->n_ranks == 0 || (in->n_bodies && (!in->rb_type || !in->center_x)) || (in->n_manifolds && (!in->body1 || !in->body2)) || !in->color_offsets)
         return AVN_ERR_BAD_ARG;
     *out = nullptr;
@@ -54,6 +55,30 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
         for (uint32_t r = 0; r < R; ++r)
             for (uint32_t b = 0; b < N; ++b) held[r][b] = is_static(b) || owner[b] == (int32_t)r;
         for (uint32_t m = 0; m < M; ++m) { held[m_owner[m]][in->body1[m]] = 1; held[m_owner[m]][in->body2[m]] = 1; }
+        // joints (header: avn_halo_joint_slot_set): components over non-static bodies and -- with JointDamping -- the per-type DUMMY pair (virtual nodes N + 2 t, + 1);
+        // owner of a component = the slab of its lowest non-static body; the owner holds every body of the component
+        const uint32_t J = jn ? jn->n_joints : 0u;
+        std::vector<uint8_t> jointed(N, 0);
+        std::vector<int32_t> body_comp_owner(N, -1), j_owner(J, 0);
+        if (J) {
+            std::vector<uint32_t> parent(N + 2u * AVN_JOINT_TYPE_COUNT);
+            for (uint32_t i = 0; i < parent.size(); ++i) parent[i] = i;
+            auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+            std::vector<int64_t> any_node(J, -1);
+            for (uint32_t j = 0; j < J; ++j) {
+                if (jn->body1[j] < 0 || jn->body2[j] < 0 || (uint32_t)jn->body1[j] >= N || (uint32_t)jn->body2[j] >= N || jn->joint_type[j] >= AVN_JOINT_TYPE_COUNT) return AVN_ERR_BAD_ARG;
+                const uint32_t a = (uint32_t)jn->body1[j], b = (uint32_t)jn->body2[j], t = jn->joint_type[j];
+                const int64_t na = is_static(a) ? (jn->damped ? (int64_t)(N + 2u * t) : -1) : (int64_t)a, nb = is_static(b) ? (jn->damped ? (int64_t)(N + 2u * t + 1u) : -1) : (int64_t)b;
+                if (na >= 0 && nb >= 0) { const uint32_t ra = find((uint32_t)na), rb = find((uint32_t)nb); if (ra != rb) parent[std::max(ra, rb)] = std::min(ra, rb); }
+                any_node[j] = std::max(na, nb);
+                if (!is_static(a)) jointed[a] = 1;
+                if (!is_static(b)) jointed[b] = 1;
+            }
+            std::vector<int32_t> comp_owner(parent.size(), -1);
+            for (uint32_t b = 0; b < N; ++b) if (jointed[b]) { const uint32_t r = find(b); if (comp_owner[r] < 0) comp_owner[r] = owner[b]; }   // ascending: the lowest body decides
+            for (uint32_t b = 0; b < N; ++b) if (jointed[b]) { body_comp_owner[b] = comp_owner[find(b)]; held[(uint32_t)body_comp_owner[b]][b] = 1; }
+            for (uint32_t j = 0; j < J; ++j) { const int32_t o = any_node[j] >= 0 ? comp_owner[find((uint32_t)any_node[j])] : -1; j_owner[j] = o < 0 ? 0 : o; }
+        }
         std::vector<uint8_t> shared(N, 0);
         for (uint32_t b = 0; b < N; ++b) {
             if (is_static(b)) continue;
@@ -83,7 +108,9 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
             }
             n_levels = std::max(n_levels, 1u);
         }
-        const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels;
+        bool joint_slot = false;
+        for (uint32_t b = 0; b < N && !joint_slot; ++b) joint_slot = jointed[b] && shared[b];
+        const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels + (joint_slot ? 1u : 0u);
         auto slot_of = [&](uint32_t c, uint32_t m) { return c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX ? (uint32_t)AVN_COLOR_OVERFLOW_INDEX + level[m - o0] : c; };
         // sends[s][slot][r] = global bodies rank s hands to rank r after the slot
         std::vector<std::vector<std::map<uint32_t, std::vector<int32_t>>>> sends(R, std::vector<std::map<uint32_t, std::vector<int32_t>>>(S));
@@ -96,9 +123,15 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
                     for (uint32_t r = 0; r < R; ++r) if (r != s && held[r][b]) sends[s][slot][r].push_back(b);
                 }
             }
+        if (joint_slot)   // the joint slot: a component's shared bodies, from its owner to the other holders (ascending body index)
+            for (uint32_t b = 0; b < N; ++b)
+                if (jointed[b] && shared[b])
+                    for (uint32_t r = 0; r < R; ++r) if ((int32_t)r != body_comp_owner[b] && held[r][b]) sends[(uint32_t)body_comp_owner[b]][S - 1][r].push_back((int32_t)b);
         avn_level2_plan* pl = new avn_level2_plan;
         pl->ranks.resize(R);
         pl->n_overflow_levels = n_levels;
+        pl->joint_slot = joint_slot; pl->global_joints = J != 0;
+        for (uint32_t j = 0; j < J; ++j) pl->ranks[(uint32_t)j_owner[j]].joints.push_back(j);
         for (uint32_t r = 0; r < R; ++r) {
             avn_level2_plan::Rank& k = pl->ranks[r];
             std::vector<int32_t> g2l(N, -1);
@@ -131,6 +164,20 @@ AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_pl
         *out = pl;
         return AVN_OK;
     } catch (const std::bad_alloc&) { return AVN_ERR_OOM; } catch (...) { return AVN_ERR_STATE; }
+}
+
+extern "C" {
+
+AVN_API avn_status avn_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) { return plan_create(in, nullptr, out); }
+AVN_API avn_status avn_level2_plan_create_joints(const avn_level2_in* in, const avn_level2_joints* joints, avn_level2_plan** out) {
+    if (!joints) return AVN_ERR_BAD_ARG;
+    return plan_create(in, joints, out);
+}
+AVN_API avn_status avn_level2_plan_rank_joints(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_joints, const uint32_t** joints, uint32_t* joint_slot, uint32_t* global_joints) {
+    if (!plan || rank >= plan->ranks.size() || !n_joints || !joints || !joint_slot || !global_joints) return AVN_ERR_BAD_ARG;
+    *n_joints = (uint32_t)plan->ranks[rank].joints.size(); *joints = plan->ranks[rank].joints.data();
+    *joint_slot = plan->joint_slot ? 1u : 0u; *global_joints = plan->global_joints ? 1u : 0u;
+    return AVN_OK;
 }
 
 AVN_API void avn_level2_plan_destroy(avn_level2_plan* plan) { delete plan; }

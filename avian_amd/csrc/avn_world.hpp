@@ -101,6 +101,7 @@ struct WorldBase {
     virtual avn_status host_shape_stats_get(avn_host_shape_stats*) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
+    virtual avn_status halo_joint_slot_set(uint32_t, uint32_t) = 0;
     virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
     virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;

@@ -213,6 +213,31 @@ __global__ __launch_bounds__(256) void k_halo_unpack(DW<T> w, const int32_t* __r
     const int32_t b = bodies[i];
     w.sb_lin[b] = in[2 * i]; w.sb_ang[b] = in[2 * i + 1];
 }
+// the joint slot's records (header: avn_halo_joint_slot_set): the whole SolverBody -- delta position / rotation and both velocities
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_pack_joint(DW<T> w, const int32_t* __restrict__ bodies, uint32_t n, Vec4<T>* __restrict__ out) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = bodies[i];
+    out[4 * i] = w.sb_dp[b]; out[4 * i + 1] = w.sb_dq[b]; out[4 * i + 2] = w.sb_lin[b]; out[4 * i + 3] = w.sb_ang[b];
+}
+template <class T>
+__global__ __launch_bounds__(256) void k_halo_unpack_joint(DW<T> w, const int32_t* __restrict__ bodies, uint32_t n, const Vec4<T>* __restrict__ in) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int32_t b = bodies[i];
+    w.sb_dp[b] = in[4 * i]; w.sb_dq[b] = in[4 * i + 1]; w.sb_lin[b] = in[4 * i + 2]; w.sb_ang[b] = in[4 * i + 3];
+}
+template <class T> void launch_halo_pack_joint(const DW<T>& w, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_halo_pack_joint<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, out);
+}
+template <class T> void launch_halo_unpack_joint(const DW<T>& w, const int32_t* bodies, uint32_t n, const Vec4<T>* in, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_halo_unpack_joint<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, in);
+}
+template void launch_halo_pack_joint<float>(const DW<float>&, const int32_t*, uint32_t, Vec4<float>*, hipStream_t);
+template void launch_halo_pack_joint<double>(const DW<double>&, const int32_t*, uint32_t, Vec4<double>*, hipStream_t);
+template void launch_halo_unpack_joint<float>(const DW<float>&, const int32_t*, uint32_t, const Vec4<float>*, hipStream_t);
+template void launch_halo_unpack_joint<double>(const DW<double>&, const int32_t*, uint32_t, const Vec4<double>*, hipStream_t);
 template <class T> void launch_halo_pack(const DW<T>& w, const int32_t* bodies, uint32_t n, Vec4<T>* out, hipStream_t s) {
     if (n) hipLaunchKernelGGL(k_halo_pack<T>, dim3((n + 255) / 256), dim3(256), 0, s, w, bodies, n, out);
 }

@@ -14,7 +14,18 @@
     uint32_t l2_levels = 1;
     std::vector<uint32_t> l2_level_of, l2_order, l2_off;
     DevBuf b_l2_order;
-    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
+    // round 6: the joint slot (header: avn_halo_joint_slot_set) -- behind the colours and levels; its records are the whole SolverBody (4 Vec4 per body instead of 2)
+    bool l2_joint_slot = false, l2_global_joints = false;
+    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels + (l2_joint_slot ? 1u : 0u); }
+    uint32_t joint_slot_index() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
+    bool is_joint_slot(uint32_t slot) const { return l2_joint_slot && slot == joint_slot_index(); }
+    avn_status halo_joint_slot_set(uint32_t joint_slot, uint32_t global_joints) override {
+        HIPCHK(hipStreamSynchronize(stream));
+        l2_joint_slot = joint_slot != 0; l2_global_joints = global_joints != 0;
+        halo = HaloPlan(); halo_on = false;   // (a plan uploaded before counted other slots)
+        drop_graph();
+        return AVN_OK;
+    }
     avn_status halo_overflow_levels_upload(uint32_t n_levels, const uint32_t* level_of, size_t count) override {
         if (count && !level_of) { error = "halo_overflow_levels_upload: null array"; return AVN_ERR_BAD_ARG; }
         for (size_t i = 0; i < count; ++i) if (level_of[i] >= std::max(n_levels, 1u)) { error = "halo_overflow_levels_upload: level out of range"; return AVN_ERR_BAD_ARG; }
@@ -78,8 +89,8 @@
         hipError_t err;
         b_halo_send.ensure(std::max<size_t>(halo.send.size(), 1) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         b_halo_recv.ensure(std::max<size_t>(halo.recv.size(), 1) * 4, err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-        b_halo_out.ensure(std::max<size_t>(halo.send.size(), 1) * 2 * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
-        b_halo_in.ensure(std::max<size_t>(halo.recv.size(), 1) * 2 * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_halo_out.ensure(std::max<size_t>(halo.send.size(), 1) * 4 * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_halo_in.ensure(std::max<size_t>(halo.recv.size(), 1) * 4 * sizeof(V), err);   // (record k of list entry i at 2 i: the joint slot, the LAST slot, spills into the doubled tail) if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
         if (!halo.send.empty()) HIPCHK(hipMemcpyAsync(b_halo_send.p, halo.send.data(), halo.send.size() * 4, hipMemcpyHostToDevice, stream));
         if (!halo.recv.empty()) HIPCHK(hipMemcpyAsync(b_halo_recv.p, halo.recv.data(), halo.recv.size() * 4, hipMemcpyHostToDevice, stream));
         HIPCHK(hipStreamSynchronize(stream));
@@ -88,6 +99,7 @@
     // one colour of one contact pass, in the single-world launch shape (overflow colour: the host schedule's launches); slot >= 23 with levels: ONE level of the overflow colour
     avn_status color_pass_enqueue(int pass, uint32_t color) {
         if (pipe_dev) { error = "level-2 colour passes need host-uploaded manifolds (not the device closed loop)"; return AVN_ERR_STATE; }
+        if (is_joint_slot(color)) return AVN_OK;   // (not a contact slot)
         if (l2_levels > 1 && color >= (uint32_t)AVN_COLOR_OVERFLOW_INDEX) {
             if (!dw.n_manifolds) return AVN_OK;
             if (l2_built_for != dw.n_manifolds || l2_off.size() != l2_levels + 1) { avn_status sb = l2_build_levels(); if (sb != AVN_OK) return sb; }
@@ -126,7 +138,7 @@
         }
     }
     avn_status run_color_pass(avn_system sys, uint32_t color) override {
-        if (color >= halo_slots()) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
+        if (color >= halo_slots() || is_joint_slot(color)) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
         const int pass = color_pass_of(sys);
         if (pass < 0) { error = "run_color_pass: not a contact pass"; return AVN_ERR_BAD_ARG; }
         avn_status st = need_bodies();
@@ -137,6 +149,12 @@
         HIPCHK(hipGetLastError());
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
+    }
+    // where list entry `a` of slot `slot` lives in b_halo_out / b_halo_in (in Vec4 records): 2 per body; the joint slot -- the last one -- 4 per body from its own start
+    size_t halo_rec(uint32_t slot, const std::vector<uint32_t>& off, size_t a) const {
+        if (!is_joint_slot(slot)) return 2 * a;
+        const size_t s0 = off[(size_t)slot * halo.peers.size()];
+        return 2 * s0 + 4 * (a - s0);
     }
     avn_status halo_list(uint32_t color, uint32_t peer, const std::vector<uint32_t>& off, size_t* b0, size_t* b1) {
         if (color >= halo_slots() || peer >= halo.peers.size()) { error = "halo: colour / slot or peer out of range"; return AVN_ERR_BAD_ARG; }
@@ -153,8 +171,12 @@
         if (b1 == b0) return AVN_OK;
         if (!out) { error = "halo_pack: null output"; return AVN_ERR_BAD_ARG; }
         if ((st = need_bodies()) != AVN_OK) return st;
-        launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + b0, (uint32_t)(b1 - b0), b_halo_out.as<V>() + 2 * b0, stream); ++launches;
-        HIPCHK(hipMemcpyAsync(out, b_halo_out.as<V>() + 2 * b0, (b1 - b0) * 2 * sizeof(V), hipMemcpyDeviceToHost, stream));
+        const size_t rv = is_joint_slot(color) ? 4 : 2;
+        V* rec = b_halo_out.as<V>() + halo_rec(color, halo.send_off, b0);
+        if (rv == 4) launch_halo_pack_joint<T>(dw, b_halo_send.as<int32_t>() + b0, (uint32_t)(b1 - b0), rec, stream);
+        else launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + b0, (uint32_t)(b1 - b0), rec, stream);
+        ++launches;
+        HIPCHK(hipMemcpyAsync(out, rec, (b1 - b0) * rv * sizeof(V), hipMemcpyDeviceToHost, stream));
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
@@ -165,8 +187,12 @@
         if (count != b1 - b0 || (count && !in)) { error = "halo_unpack: count does not match the plan"; return AVN_ERR_BAD_ARG; }
         if (!count) return AVN_OK;
         if ((st = need_bodies()) != AVN_OK) return st;
-        HIPCHK(hipMemcpyAsync(b_halo_in.as<V>() + 2 * b0, in, count * 2 * sizeof(V), hipMemcpyHostToDevice, stream));
-        launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + b0, (uint32_t)count, b_halo_in.as<V>() + 2 * b0, stream); ++launches;
+        const size_t rv = is_joint_slot(color) ? 4 : 2;
+        V* rec = b_halo_in.as<V>() + halo_rec(color, halo.recv_off, b0);
+        HIPCHK(hipMemcpyAsync(rec, in, count * rv * sizeof(V), hipMemcpyHostToDevice, stream));
+        if (rv == 4) launch_halo_unpack_joint<T>(dw, b_halo_recv.as<int32_t>() + b0, (uint32_t)count, rec, stream);
+        else launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + b0, (uint32_t)count, rec, stream);
+        ++launches;
         HIPCHK(hipStreamSynchronize(stream));
         return AVN_OK;
     }
@@ -212,24 +238,34 @@
         const size_t np = halo.peers.size(), k0 = (size_t)c * np;
         const size_t s0 = halo.send_off[k0], s1 = halo.send_off[k0 + np], r0 = halo.recv_off[k0], r1 = halo.recv_off[k0 + np];
         if (s1 == s0 && r1 == r0) return AVN_OK;
-        if (s1 > s0) { launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + s0, (uint32_t)(s1 - s0), b_halo_out.as<V>() + 2 * s0, stream); ++launches; }
+        const bool jt = is_joint_slot(c);
+        const size_t rv = jt ? 4 : 2;
+        if (s1 > s0) {
+            if (jt) launch_halo_pack_joint<T>(dw, b_halo_send.as<int32_t>() + s0, (uint32_t)(s1 - s0), b_halo_out.as<V>() + halo_rec(c, halo.send_off, s0), stream);
+            else launch_halo_pack<T>(dw, b_halo_send.as<int32_t>() + s0, (uint32_t)(s1 - s0), b_halo_out.as<V>() + 2 * s0, stream);
+            ++launches;
+        }
         xf_send.clear(); xf_recv.clear();
         for (size_t p = 0; p < np; ++p) {
             const size_t a = halo.send_off[k0 + p], b = halo.send_off[k0 + p + 1], ra = halo.recv_off[k0 + p], rb = halo.recv_off[k0 + p + 1];
-            if (b > a) xf_send.push_back(CommXfer{b_halo_out.as<V>() + 2 * a, (b - a) * 2 * sizeof(V), halo.peers[p]});
-            if (rb > ra) xf_recv.push_back(CommXfer{b_halo_in.as<V>() + 2 * ra, (rb - ra) * 2 * sizeof(V), halo.peers[p]});
+            if (b > a) xf_send.push_back(CommXfer{b_halo_out.as<V>() + halo_rec(c, halo.send_off, a), (b - a) * rv * sizeof(V), halo.peers[p]});
+            if (rb > ra) xf_recv.push_back(CommXfer{b_halo_in.as<V>() + halo_rec(c, halo.recv_off, ra), (rb - ra) * rv * sizeof(V), halo.peers[p]});
         }
         avn_status st = comm.exchange(xf_send.data(), xf_send.size(), xf_recv.data(), xf_recv.size(), stream, error);
         if (st != AVN_OK) return st;
         ++halo_exchanges;
-        if (r1 > r0) { launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + r0, (uint32_t)(r1 - r0), b_halo_in.as<V>() + 2 * r0, stream); ++launches; }
+        if (r1 > r0) {
+            if (jt) launch_halo_unpack_joint<T>(dw, b_halo_recv.as<int32_t>() + r0, (uint32_t)(r1 - r0), b_halo_in.as<V>() + halo_rec(c, halo.recv_off, r0), stream);
+            else launch_halo_unpack<T>(dw, b_halo_recv.as<int32_t>() + r0, (uint32_t)(r1 - r0), b_halo_in.as<V>() + 2 * r0, stream);
+            ++launches;
+        }
         return AVN_OK;
     }
     uint32_t halo_exchanges = 0;
     // one contact pass in level-2 form: colours in solve order (overflow first), exchange after each
     avn_status level2_pass(int pass) {
         // solve order: the overflow colour first (its levels in order), then colours 0..22
-        for (uint32_t k = 0; k < halo_slots(); ++k) {
+        for (uint32_t k = 0; k < (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; ++k) {   // (the contact slots; the joint slot, when there is one, follows the joint systems)
             const uint32_t c = k < l2_levels ? (uint32_t)AVN_COLOR_OVERFLOW_INDEX + k : k - l2_levels;
             avn_status st = color_pass_enqueue(pass, c);
             if (st == AVN_OK) st = halo_exchange(c);
@@ -249,6 +285,7 @@
             for (uint32_t it = 0; it < cfg.solver_iterations; ++it) xpbd_solve(it == 0);
             xpbd_velocity_projection();
             joint_damping();
+            if (l2_joint_slot && (st = halo_exchange(joint_slot_index())) != AVN_OK) return st;   // the joint components' shared bodies: owner -> the other holders
         }
         return AVN_OK;
     }

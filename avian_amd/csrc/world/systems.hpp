@@ -71,7 +71,7 @@
     //    a + (-a) = 0, so the two systems are exact no-ops (up to the sign of a zero) and are skipped;
     //  - f64 (scalar `DQuat`, left-to-right sums): y = ((-wy + xz) + yw) - zx leaves a rounding residual of order
     //    ulp(wy), so the reference really perturbs omega every substep — replicate, don't "fix" (found by the cfg5 test).
-    bool xpbd_body_passes_needed() const { return dw.n_joints != 0 || sizeof(T) == 8; }
+    bool xpbd_body_passes_needed() const { return dw.n_joints != 0 || sizeof(T) == 8 || l2_global_joints; }   // (level 2: the UNSPLIT world holds joints, so it runs both passes over all bodies)
     void xpbd_solve(bool snapshot) {
         if (snapshot && xpbd_body_passes_needed()) { launch_xpbd_snapshot<T>(dw, stream); ++launches; }
         if (!dw.n_joints) return;

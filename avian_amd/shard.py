@@ -407,9 +407,16 @@ class Level2Rank:
     recv_bodies: np.ndarray
     n_overflow_levels: int = 1    # > 1: the overflow colour is cut into levels of the GLOBAL list (an overflow manifold touches a shared body)
     overflow_level: np.ndarray = None   # [this world's overflow manifolds, local order] level of each
+    joints: np.ndarray = None     # global joint indices this world owns (ascending: the global solve order restricted); None: the plan was made without joints
+    joint_slot: bool = False      # one more exchange slot behind the colours and levels: the SolverBody records of shared bodies a joint component moved
+    global_joints: bool = False   # the unsplit world holds joints: every world runs the XPBD snapshot / velocity projection over its bodies as the unsplit one does
 
     @property
     def n_slots(self) -> int:
+        return F.COLOR_OVERFLOW_INDEX + self.n_overflow_levels + (1 if self.joint_slot else 0)
+
+    @property
+    def joint_slot_index(self) -> int:
         return F.COLOR_OVERFLOW_INDEX + self.n_overflow_levels
 
     def solve_order(self):
@@ -420,27 +427,34 @@ class Level2Rank:
         """avn_halo_overflow_levels_upload (when levelled) + avn_halo_plan_upload."""
         if self.n_overflow_levels > 1:
             world.halo_overflow_levels_upload(self.n_overflow_levels, self.overflow_level)
+        if self.global_joints:
+            world.halo_joint_slot_set(self.joint_slot, True)
         world.halo_plan_upload(self.peers, self.send_offsets, self.send_bodies, self.recv_offsets, self.recv_bodies)
 
 
 def level2_plan_lib(lib: F.Library, position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray,
-                    world_size: int) -> List[Level2Rank]:
+                    world_size: int, joints=None) -> List[Level2Rank]:
     """The plan from the library's own planner (avn_level2_plan_*: what a host in any language calls).  `level2_plan` below is the same
     rule in numpy, kept as its independent check (tests/test_level2_cpu.py)."""
     out = []
     try:
-        ranks = lib.level2_plan(rb_type, np.asarray(position, np.float64)[:, 0], body1, body2, color_offsets, world_size)
+        ranks = lib.level2_plan(rb_type, np.asarray(position, np.float64)[:, 0], body1, body2, color_offsets, world_size, joints=joints)
     except F.AvnError as e:
         raise ValueError(str(e))
     for k in ranks:
         out.append(Level2Rank(k["bodies"], k["manifolds"], k["color_offsets"], k["peers"], k["send_offsets"], k["send_bodies"], k["recv_offsets"], k["recv_bodies"],
-                              k["n_overflow_levels"], k["overflow_level"]))
+                              k["n_overflow_levels"], k["overflow_level"], k.get("joints"), bool(k.get("joint_slot", False)), bool(k.get("global_joints", False))))
     return out
 
 
 def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, body2: np.ndarray, color_offsets: np.ndarray, world_size: int,
-                has_solver_body: np.ndarray = None) -> List[Level2Rank]:
-    """body1 / body2: the GLOBAL colour-major manifold set; color_offsets: its [25] offsets (the reference's colouring of the whole island)."""
+                has_solver_body: np.ndarray = None, joints=None) -> List[Level2Rank]:
+    """body1 / body2: the GLOBAL colour-major manifold set; color_offsets: its [25] offsets (the reference's colouring of the whole island).
+    joints = (joint body1 [J], joint body2 [J], joint_type [J], damped: bool) or None.  The reference walks the joints of a type serially (xpbd/plugin.rs:145-189,
+    joint_damping solver/plugin.rs:756-830), so a joint COMPONENT -- joints linked through non-static bodies, and, with JointDamping, through the type's DUMMY pair
+    that stands in for bodies without a SolverBody (plugin.rs:766-767) -- is the unit of ownership: it belongs to the slab of its lowest non-static body, its owner
+    holds all its bodies, and after the joint systems of a substep the owner sends the SolverBody records (delta position / rotation, velocities) of the component's
+    SHARED bodies to their other holders: the joint slot, one exchange per substep."""
     position = np.asarray(position, np.float64); rb_type = np.asarray(rb_type)
     b1 = np.asarray(body1, np.int64); b2 = np.asarray(body2, np.int64)
     offs = np.asarray(color_offsets, np.int64)
@@ -461,6 +475,38 @@ def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, bo
         m_of.append(mine)
         held[r][static] = True; held[r][owner == r] = True
         held[r][b1[mine]] = True; held[r][b2[mine]] = True
+    j_owner = None
+    jointed = np.zeros(n, bool)
+    if joints is not None and len(joints[0]):
+        jb1, jb2, jt = np.asarray(joints[0], np.int64), np.asarray(joints[1], np.int64), np.asarray(joints[2], np.int64)
+        damped = bool(joints[3])
+        parent = np.arange(n + 2 * F.JOINT_TYPE_COUNT)
+
+        def find(x):
+            while parent[x] != x:
+                parent[x] = parent[parent[x]]
+                x = parent[x]
+            return x
+        node = np.full((len(jb1), 2), -1, np.int64)
+        for j in range(len(jb1)):
+            a, b, t = int(jb1[j]), int(jb2[j]), int(jt[j])
+            na = (n + 2 * t if damped else -1) if static[a] else a
+            nb = (n + 2 * t + 1 if damped else -1) if static[b] else b
+            node[j] = (na, nb)
+            if na >= 0 and nb >= 0:
+                ra, rb_ = find(na), find(nb)
+                if ra != rb_:
+                    parent[max(ra, rb_)] = min(ra, rb_)
+            for x in (a, b):
+                if not static[x]:
+                    jointed[x] = True
+        comp_owner = {}
+        for b in np.flatnonzero(jointed).tolist():     # ascending: the first body met is the component's lowest
+            comp_owner.setdefault(find(b), int(owner[b]))
+        j_owner = np.array([comp_owner.get(find(int(max(node[j]))), 0) if max(node[j]) >= 0 else 0 for j in range(len(jb1))], np.int64)
+        for b in np.flatnonzero(jointed).tolist():
+            held[comp_owner[find(b)]][b] = True
+        body_comp_owner = {b: comp_owner[find(b)] for b in np.flatnonzero(jointed).tolist()}
     held = np.stack(held)                                 # [R, n]
     shared = moving & (held.sum(0) > 1)
     # Exchange slots: colours 0..22, then the overflow colour -- one slot, or (when one of its manifolds touches a shared body) one slot per LEVEL of the global
@@ -480,8 +526,15 @@ def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, bo
             for b in bb:
                 depth[b] = d + 1
             n_levels = max(n_levels, d + 1)
-    n_slots = n_col + n_levels
+    joint_slot = bool(j_owner is not None and (shared & jointed).any())
+    n_slots = n_col + n_levels + (1 if joint_slot else 0)
     sends = [[{} for _ in range(n_slots)] for _ in range(world_size)]   # sends[s][slot][r] = [global body ...]
+    if joint_slot:
+        for b in np.flatnonzero(shared & jointed).tolist():
+            s = body_comp_owner[b]
+            for r in np.flatnonzero(held[:, b]):
+                if r != s:
+                    sends[s][n_slots - 1].setdefault(int(r), []).append(b)
     for c in range(n_col + 1):
         for m in (np.flatnonzero(touches[offs[c]:offs[c + 1]]) + offs[c]).tolist():
             s = int(m_owner[m])
@@ -505,7 +558,8 @@ def level2_plan(position: np.ndarray, rb_type: np.ndarray, body1: np.ndarray, bo
         mine = m_of[r]
         local_offs = np.concatenate([[0], np.cumsum(np.bincount(color_of[mine], minlength=len(offs) - 1))])
         out.append(Level2Rank(bodies, mine, local_offs.astype(np.uint32), np.asarray(peers, np.int32), np.asarray(so if peers else [0], np.uint32), np.asarray(sb, np.int32),
-                              np.asarray(ro if peers else [0], np.uint32), np.asarray(rb, np.int32), n_levels, level[mine[mine >= o0] - o0].astype(np.uint32)))
+                              np.asarray(ro if peers else [0], np.uint32), np.asarray(rb, np.int32), n_levels, level[mine[mine >= o0] - o0].astype(np.uint32),
+                              np.flatnonzero(j_owner == r) if j_owner is not None else (np.zeros(0, np.int64) if joints is not None else None), joint_slot, j_owner is not None))
     return out
 
 
@@ -525,6 +579,17 @@ def level2_local_manifolds(rank: Level2Rank, manifolds: Dict[str, np.ndarray]) -
 
 
 CONTACT_PASSES = ("WARM_START", "SOLVE_CONTACTS_BIAS", "SOLVE_CONTACTS_RELAX", "SOLVE_RESTITUTION")
+
+
+def level2_exchange_slot(world, rank: Level2Rank, c: int, exchange):
+    np_ = len(rank.peers)
+    if np_ == 0:
+        return
+    out = {p: world.halo_pack(c, p) for p in range(np_) if rank.send_offsets[c * np_ + p + 1] > rank.send_offsets[c * np_ + p]}
+    need = [p for p in range(np_) if rank.recv_offsets[c * np_ + p + 1] > rank.recv_offsets[c * np_ + p]]
+    got = exchange(c, out, need)
+    for p in need:
+        world.halo_unpack(c, p, got[p])
 
 
 def level2_pass(world, rank: Level2Rank, system: str, exchange):
@@ -562,6 +627,8 @@ def level2_solver(world, rank: Level2Rank, substeps: int, exchange, restitution:
             level2_pass(world, rank, "SOLVE_CONTACTS_RELAX", exchange)
         for s in ("XPBD_SOLVE", "XPBD_VELOCITY_PROJECTION", "JOINT_DAMPING"):
             world.run_system(s)
+        if rank.joint_slot:   # the joint components' shared bodies: SolverBody records from the component's owner to the other holders
+            level2_exchange_slot(world, rank, rank.joint_slot_index, exchange)
     world.run_system("CLEAR_VELOCITY_INCREMENTS")
     if restitution:
         level2_pass(world, rank, "SOLVE_RESTITUTION", exchange)

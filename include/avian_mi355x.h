@@ -671,6 +671,15 @@ AVN_API avn_status AVN_FN(halo_plan_upload)(avn_world* w, const avn_halo_plan* p
  * (23 + n_levels) * n_peers + 1 entries.  Never called (or n_levels <= 1): 24 slots, slot 23 = the world's whole overflow colour, as before.  In avn_run_color_pass /
  * avn_halo_pack / avn_halo_unpack `color` is the slot. */
 AVN_API avn_status AVN_FN(halo_overflow_levels_upload)(avn_world* w, uint32_t n_levels, const uint32_t* level_of_local_overflow_manifold, size_t count);
+/* Round 6: joints ACROSS worlds.  The reference walks the joints of a type serially (xpbd/plugin.rs:145-189; joint_damping, solver/plugin.rs:756-830), so the planner
+ * (avn_level2_plan_create_joints) makes a joint COMPONENT the unit of ownership -- joints linked through non-static bodies and, with JointDamping, through the type's
+ * DUMMY pair that stands in for bodies without a SolverBody (plugin.rs:766-767); owner = the slab of the component's lowest non-static body, which holds all its bodies --
+ * and adds ONE exchange slot behind the colours and overflow levels: after the joint systems of a substep (XPBD solve, velocity projection, joint damping) the owner
+ * sends the SolverBody records of the component's SHARED bodies to their other holders.  avn_halo_joint_slot_set(w, joint_slot, global_joints), BEFORE
+ * avn_halo_plan_upload: joint_slot != 0 -> the plan's offset arrays hold one more slot (index 23 + n_levels), whose records in avn_halo_pack / _unpack are 16 scalars per
+ * body (delta_position.xyz 0 | delta_rotation.xyzw | linear_velocity.xyz 0 | angular_velocity.xyz 0) instead of 8; global_joints != 0 -> the unsplit world holds joints,
+ * so this world runs the XPBD snapshot / velocity projection over its bodies even when it owns no joint (the unsplit world does: xpbd/plugin.rs:61-76,192-240). */
+AVN_API avn_status AVN_FN(halo_joint_slot_set)(avn_world* w, uint32_t joint_slot, uint32_t global_joints);
 AVN_API avn_status AVN_FN(run_color_pass)(avn_world* w, avn_system pass, uint32_t color);
 AVN_API avn_status AVN_FN(halo_pack)(avn_world* w, uint32_t color, uint32_t peer, void* out /* [8 * count] scalars */, size_t* count);
 AVN_API avn_status AVN_FN(halo_unpack)(avn_world* w, uint32_t color, uint32_t peer, const void* in, size_t count);
@@ -702,7 +711,7 @@ AVN_API avn_status AVN_FN(interval_orders_merge)(uint32_t n_lists, const uint32_
  * body1 is static); a body is SHARED when more than one world holds it; lists are in ascending global body index (the same order on both
  * sides of every pair of ranks).  When an overflow-colour manifold touches a shared body the overflow colour is cut into levels (avn_halo_overflow_levels_upload) and
  * halo.send_offsets / recv_offsets hold (23 + n_levels) * n_peers + 1 entries -- avn_level2_plan_rank_overflow returns n_levels (1: the plain 24 slots) and the levels of
- * the rank's overflow manifolds.  Joints are not planned: a joint between bodies of two worlds is still the host's to refuse. */
+ * the rank's overflow manifolds.  Joints: avn_level2_plan_create_joints (a joint component is owned by one world, its shared bodies travel in the joint slot). */
 typedef struct avn_level2_in {
     uint32_t n_bodies;
     const uint8_t* rb_type;        /* [n_bodies] AVN_RB_* */
@@ -723,6 +732,17 @@ typedef struct avn_level2_plan avn_level2_plan;
 AVN_API avn_status AVN_FN(level2_plan_create)(const avn_level2_in* in, avn_level2_plan** out);
 AVN_API void AVN_FN(level2_plan_destroy)(avn_level2_plan* plan);
 AVN_API avn_status AVN_FN(level2_plan_rank)(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out);
+/* the same plan for a world with joints (see avn_halo_joint_slot_set): joints of a rank = the global joint array restricted to the components it owns, in array order */
+typedef struct avn_level2_joints {
+    uint32_t n_joints;
+    const int32_t* body1;        /* [J] global body indices */
+    const int32_t* body2;        /* [J] */
+    const uint8_t* joint_type;   /* [J] AVN_JOINT_* */
+    uint32_t damped;             /* the joints carry JointDamping (avn_joints.damping_linear != NULL) */
+} avn_level2_joints;
+AVN_API avn_status AVN_FN(level2_plan_create_joints)(const avn_level2_in* in, const avn_level2_joints* joints, avn_level2_plan** out);
+AVN_API avn_status AVN_FN(level2_plan_rank_joints)(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_joints, const uint32_t** joints /* global joint indices, ascending */,
+                                                   uint32_t* joint_slot /* the halo arrays carry the joint slot */, uint32_t* global_joints);
 AVN_API avn_status AVN_FN(level2_plan_rank_overflow)(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_levels, const uint32_t** level_of_local_overflow_manifold /* [rank's overflow manifolds] */);
 #define AVN_COMM_ID_BYTES 128
 AVN_API avn_status AVN_FN(comm_unique_id)(uint8_t* out /* [AVN_COMM_ID_BYTES] */);

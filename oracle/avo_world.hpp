@@ -295,6 +295,7 @@ struct WorldBase {
     virtual avn_status host_shape_stats_get(avn_host_shape_stats*) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
+    virtual avn_status halo_joint_slot_set(uint32_t, uint32_t) = 0;
     virtual avn_status run_color_pass(avn_system, uint32_t) = 0;
     virtual avn_status halo_pack(uint32_t, uint32_t, void*, size_t*) = 0;
     virtual avn_status halo_unpack(uint32_t, uint32_t, const void*, size_t) = 0;
@@ -2075,7 +2076,15 @@ template <class S> struct World : WorldBase {
         halo = Halo();
         return AVN_OK;
     }
-    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
+    // the joint slot (header: avn_halo_joint_slot_set): behind the colours and levels, records = the whole SolverBody (16 scalars)
+    bool l2_joint_slot = false;
+    avn_status halo_joint_slot_set(uint32_t joint_slot, uint32_t /* global_joints: this restatement always runs the XPBD body passes */) override {
+        l2_joint_slot = joint_slot != 0;
+        halo = Halo();
+        return AVN_OK;
+    }
+    uint32_t halo_slots() const { return (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels + (l2_joint_slot ? 1u : 0u); }
+    bool is_joint_slot(uint32_t slot) const { return l2_joint_slot && slot == (uint32_t)AVN_COLOR_OVERFLOW_INDEX + l2_levels; }
     avn_status halo_plan_upload(const avn_halo_plan* p) override {
         if (!p) return AVN_ERR_BAD_ARG;
         const size_t n = (size_t)halo_slots() * p->n_peers;
@@ -2089,7 +2098,7 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status run_color_pass(avn_system pass, uint32_t color) override {
-        if (color >= halo_slots()) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
+        if (color >= halo_slots() || is_joint_slot(color)) { error = "run_color_pass: colour / slot out of range"; return AVN_ERR_BAD_ARG; }
         only_color = (int)std::min<uint32_t>(color, AVN_COLOR_OVERFLOW_INDEX);
         only_level = (l2_levels > 1 && color >= (uint32_t)AVN_COLOR_OVERFLOW_INDEX) ? (int)(color - AVN_COLOR_OVERFLOW_INDEX) : -1;
         if (only_level >= 0 && l2_level_of.size() != color_constraints[AVN_COLOR_OVERFLOW_INDEX].size()) { only_color = only_level = -1; error = "level-2: avn_halo_overflow_levels_upload does not name this world's overflow manifolds"; return AVN_ERR_STATE; }
@@ -2109,6 +2118,17 @@ template <class S> struct World : WorldBase {
         const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.send_off[k], b1 = halo.send_off[k + 1];
         *count = b1 - b0;
         S* o = (S*)out;
+        if (is_joint_slot(color)) {
+            for (size_t i = b0; i < b1 && o; ++i) {
+                const SolverBody<S>& sb = bodies[halo.send[i]].sb;
+                S* r = o + 16 * (i - b0);
+                r[0] = sb.delta_position.x; r[1] = sb.delta_position.y; r[2] = sb.delta_position.z; r[3] = S(0);
+                r[4] = sb.delta_rotation.x; r[5] = sb.delta_rotation.y; r[6] = sb.delta_rotation.z; r[7] = sb.delta_rotation.w;
+                r[8] = sb.linear_velocity.x; r[9] = sb.linear_velocity.y; r[10] = sb.linear_velocity.z; r[11] = S(0);
+                r[12] = sb.angular_velocity.x; r[13] = sb.angular_velocity.y; r[14] = sb.angular_velocity.z; r[15] = S(0);
+            }
+            return AVN_OK;
+        }
         for (size_t i = b0; i < b1 && o; ++i) {
             const SolverBody<S>& sb = bodies[halo.send[i]].sb;
             S* r = o + 8 * (i - b0);
@@ -2122,6 +2142,14 @@ template <class S> struct World : WorldBase {
         const size_t k = (size_t)color * halo.peers.size() + peer, b0 = halo.recv_off[k], b1 = halo.recv_off[k + 1];
         if (count != b1 - b0 || (count && !in)) { error = "halo_unpack: count does not match the plan"; return AVN_ERR_BAD_ARG; }
         const S* r = (const S*)in;
+        if (is_joint_slot(color)) {
+            for (size_t i = b0; i < b1; ++i, r += 16) {
+                SolverBody<S>& sb = bodies[halo.recv[i]].sb;
+                sb.delta_position = V3<S>{r[0], r[1], r[2]}; sb.delta_rotation = Q4<S>{r[4], r[5], r[6], r[7]};
+                sb.linear_velocity = V3<S>{r[8], r[9], r[10]}; sb.angular_velocity = V3<S>{r[12], r[13], r[14]};
+            }
+            return AVN_OK;
+        }
         for (size_t i = b0; i < b1; ++i, r += 8) {
             SolverBody<S>& sb = bodies[halo.recv[i]].sb;
             sb.linear_velocity = V3<S>{r[0], r[1], r[2]}; sb.angular_velocity = V3<S>{r[4], r[5], r[6]};

@@ -96,11 +96,16 @@ avn_status avo_dshard_stats_get(avn_world* w, avn_dshard_stats* o) { FWD(dshard_
 // body -> owner-of-its-manifold table (a non-static body is in at most one manifold per colour), then the send lists are read off BODY by
 // body in ascending index, so they come out sorted without sorting.
 struct avn_level2_plan {
-    struct Rank { std::vector<int32_t> bodies, peers, send_bodies, recv_bodies; std::vector<uint32_t> manifolds, color_offsets, send_offsets, recv_offsets, overflow_level; };
+    struct Rank { std::vector<int32_t> bodies, peers, send_bodies, recv_bodies; std::vector<uint32_t> manifolds, color_offsets, send_offsets, recv_offsets, overflow_level, joints; };
     std::vector<Rank> ranks;
     uint32_t n_overflow_levels = 1;
+    bool joint_slot = false, global_joints = false;
 };
-avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) {
+static avn_status level2_plan_create(const avn_level2_in* in, const avn_level2_joints* jn, avn_level2_plan** out);
+avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out) { return level2_plan_create(in, nullptr, out); }
+avn_status avo_level2_plan_create_joints(const avn_level2_in* in, const avn_level2_joints* jn, avn_level2_plan** out) { return jn ? level2_plan_create(in, jn, out) : AVN_ERR_BAD_ARG; }
+static avn_status level2_plan_create(const avn_level2_in* in, const avn_level2_joints* jn, avn_level2_plan** out) {
+    if (jn && jn->n_joints && (!jn->body1 || !jn->body2 || !jn->joint_type)) return AVN_ERR_BAD_ARG;
     if (!in || !out || in->n_ranks == 0 || !in->color_offsets || (in->n_bodies && (!in->rb_type || !in->center_x)) || (in->n_manifolds && (!in->body1 || !in->body2))) return AVN_ERR_BAD_ARG;
     *out = nullptr;
     const uint32_t N = in->n_bodies, M = in->n_manifolds, R = in->n_ranks, C = AVN_GRAPH_COLOR_COUNT;
@@ -126,6 +131,36 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
         holders[a].insert((uint32_t)owner_of[m]); holders[b].insert((uint32_t)owner_of[m]);
     }
     for (uint32_t b : dyn) holders[b].insert((uint32_t)slab[b]);
+    // joints (header: avn_halo_joint_slot_set): a flood over the joint graph -- nodes = non-static bodies + (with JointDamping) the two DUMMY stand-ins of every joint type --
+    // started from the bodies in ascending order, so a component's first body is its lowest and decides the owner; the owner holds every body of the component
+    const uint32_t J = jn ? jn->n_joints : 0u, NV = N + 2u * AVN_JOINT_TYPE_COUNT;
+    std::vector<int32_t> comp_owner_of_node(NV, -1), joint_owner(J, 0);
+    std::vector<uint8_t> jointed(N, 0);
+    if (J) {
+        std::vector<std::vector<uint32_t>> adj(NV);
+        std::vector<int64_t> a_node(J, -1);
+        for (uint32_t j = 0; j < J; ++j) {
+            const int32_t a = jn->body1[j], b = jn->body2[j];
+            if (a < 0 || b < 0 || (uint32_t)a >= N || (uint32_t)b >= N || jn->joint_type[j] >= AVN_JOINT_TYPE_COUNT) return AVN_ERR_BAD_ARG;
+            const bool sa = in->rb_type[a] == AVN_RB_STATIC, sb = in->rb_type[b] == AVN_RB_STATIC;
+            const int64_t na = sa ? (jn->damped ? (int64_t)N + 2 * jn->joint_type[j] : -1) : a, nb = sb ? (jn->damped ? (int64_t)N + 2 * jn->joint_type[j] + 1 : -1) : b;
+            if (na >= 0 && nb >= 0) { adj[(size_t)na].push_back((uint32_t)nb); adj[(size_t)nb].push_back((uint32_t)na); }
+            a_node[j] = na >= 0 ? na : nb;
+            if (!sa) jointed[a] = 1;
+            if (!sb) jointed[b] = 1;
+        }
+        for (uint32_t b0 : dyn) {
+            if (!jointed[b0] || comp_owner_of_node[b0] >= 0) continue;
+            std::vector<uint32_t> stack{b0};
+            comp_owner_of_node[b0] = slab[b0];
+            while (!stack.empty()) {
+                const uint32_t x = stack.back(); stack.pop_back();
+                for (uint32_t y : adj[x]) if (comp_owner_of_node[y] < 0) { comp_owner_of_node[y] = slab[b0]; stack.push_back(y); }
+            }
+        }
+        for (uint32_t b : dyn) if (jointed[b]) holders[b].insert((uint32_t)comp_owner_of_node[b]);
+        for (uint32_t j = 0; j < J; ++j) joint_owner[j] = a_node[j] >= 0 && comp_owner_of_node[(size_t)a_node[j]] >= 0 ? comp_owner_of_node[(size_t)a_node[j]] : 0;
+    }
     auto shared = [&](uint32_t b) { return in->rb_type[b] != AVN_RB_STATIC && holders[b].size() > 1; };
     // Exchange slots: colours 0..22, then the LEVELS of the overflow colour when one of its manifolds touches a shared body (header: avn_level2_plan_rank_overflow).
     // A manifold's level = how many overflow manifolds lie in front of it on the deepest chain through its bodies: per body the depth reached so far, walked in list order.
@@ -142,16 +177,21 @@ avn_status avo_level2_plan_create(const avn_level2_in* in, avn_level2_plan** out
             for (int32_t b : {in->body1[m], in->body2[m]}) if (in->rb_type[b] != AVN_RB_STATIC) depth[b] = d + 1;
             n_levels = std::max(n_levels, d + 1);
         }
-    const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels;
+    bool joint_slot = false;
+    for (uint32_t b : dyn) joint_slot = joint_slot || (jointed[b] && shared(b));
+    const uint32_t S = (uint32_t)AVN_COLOR_OVERFLOW_INDEX + n_levels + (joint_slot ? 1u : 0u);
     // mover[slot][b] = the rank whose manifold of that slot touches shared body b (-1: none)
     std::vector<std::vector<int32_t>> mover(S, std::vector<int32_t>(N, -1));
     for (uint32_t c = 0; c < C; ++c)
         for (uint32_t m = in->color_offsets[c]; m < in->color_offsets[c + 1]; ++m)
             for (int32_t b : {in->body1[m], in->body2[m]})
                 if (shared((uint32_t)b)) mover[c == (uint32_t)AVN_COLOR_OVERFLOW_INDEX ? c + lev[m - o0] : c][b] = owner_of[m];
+    if (joint_slot) for (uint32_t b : dyn) if (jointed[b] && shared(b)) mover[S - 1][b] = comp_owner_of_node[b];   // the joint slot: the component's owner moves its shared bodies
     avn_level2_plan* pl = new avn_level2_plan;
     pl->ranks.resize(R);
     pl->n_overflow_levels = n_levels;
+    pl->joint_slot = joint_slot; pl->global_joints = J != 0;
+    for (uint32_t j = 0; j < J; ++j) pl->ranks[(uint32_t)joint_owner[j]].joints.push_back(j);
     for (uint32_t r = 0; r < R; ++r) {
         auto& k = pl->ranks[r];
         std::vector<int32_t> local(N, -1);
@@ -193,6 +233,13 @@ avn_status avo_level2_plan_rank_overflow(const avn_level2_plan* plan, uint32_t r
 }
 avn_status avo_host_shapes_set(avn_world* w, avn_host_aabb_fn a, avn_host_manifolds_fn m, void* user) { FWD(host_shapes_set(a, m, user)); }
 avn_status avo_host_shape_stats_get(avn_world* w, avn_host_shape_stats* o) { FWD(host_shape_stats_get(o)); }
+avn_status avo_level2_plan_rank_joints(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_joints, const uint32_t** joints, uint32_t* joint_slot, uint32_t* global_joints) {
+    if (!plan || rank >= plan->ranks.size() || !n_joints || !joints || !joint_slot || !global_joints) return AVN_ERR_BAD_ARG;
+    *n_joints = (uint32_t)plan->ranks[rank].joints.size(); *joints = plan->ranks[rank].joints.data();
+    *joint_slot = plan->joint_slot; *global_joints = plan->global_joints;
+    return AVN_OK;
+}
+avn_status avo_halo_joint_slot_set(avn_world* w, uint32_t joint_slot, uint32_t global_joints) { FWD(halo_joint_slot_set(joint_slot, global_joints)); }
 avn_status avo_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { FWD(halo_overflow_levels_upload(n_levels, level_of, count)); }
 avn_status avo_level2_plan_rank(const avn_level2_plan* plan, uint32_t rank, avn_level2_rank* out) {
     if (!plan || !out || rank >= plan->ranks.size()) return AVN_ERR_BAD_ARG;

@@ -176,18 +176,24 @@ def run_slabs(lib, rank, world, steps, out_path, device=None):
         np.savez(out_path, **{f"pairs_s{s}": r for s, r in enumerate(per_step)})
 
 
-def run_level2(lib, rank, world, steps, out_path, keep=None):
+def run_level2(lib, rank, world, steps, out_path, keep=None, joints=False):
     """Level-2 sharding over real ranks: this rank builds ONLY its slab world, steps it with shard.level2_solver and moves the boundary
     records with point-to-point sends (gloo here; the library's own RCCL transport replaces this loop on a multi-GPU node)."""
     from level2_helpers import global_problem, overflow_from
     sc, pm, offs, _ = global_problem(lib, 8, 4, 5, seed=7)
     if keep is not None:   # colours >= keep in the overflow colour: its levels travel between the ranks as extra exchange slots
         offs = overflow_from(offs, keep)
-    plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world)
+    jkw = None
+    if joints:   # joints on bodies shared between the two ranks: the joint slot travels after every substep's joint systems
+        from level2_helpers import restrict_joints, stack_joints
+        jkw = stack_joints(sc, 8, 4, 5, seed=2, damped=True)
+    plan = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, world, joints=(jkw["body1"], jkw["body2"], jkw["joint_type"], True) if joints else None)
     me = plan[rank]
     w = F.World(lib, F.default_config(32, substeps=3))
     w.bodies_upload(**{k: (np.asarray(v)[me.bodies] if v is not None else None) for k, v in sc.body_kwargs().items()})
     scenes.upload_manifolds(w, shard.level2_local_manifolds(me, pm), me.color_offsets, sc.friction, 0.3)
+    if joints and len(me.joints):
+        w.joints_upload(**restrict_joints(jkw, me, me.joints))
     me.upload(w)
 
     def exchange(color, out, need):
@@ -195,7 +201,7 @@ def run_level2(lib, rank, world, steps, out_path, keep=None):
         reqs, bufs = [], {}
         for p in need:
             cnt = int(me.recv_offsets[color * n_p + p + 1] - me.recv_offsets[color * n_p + p])
-            bufs[p] = torch.empty((cnt, 8), dtype=torch.float32)
+            bufs[p] = torch.empty((cnt, 16 if me.joint_slot and color == me.joint_slot_index else 8), dtype=torch.float32)
             reqs.append(dist.irecv(bufs[p], src=int(me.peers[p]), tag=color))
         for p, rec in out.items():
             reqs.append(dist.isend(torch.from_numpy(np.ascontiguousarray(rec, np.float32)), dst=int(me.peers[p]), tag=color))
@@ -203,7 +209,7 @@ def run_level2(lib, rank, world, steps, out_path, keep=None):
             r.wait()
         return {p: bufs[p].numpy() for p in need}
     for _ in range(steps):
-        shard.level2_solver(w, me, 3, exchange, restitution=True)
+        shard.level2_solver(w, me, 3, exchange, restitution=True, has_joints=joints)
     b = w.bodies_download(); imp = w.impulses_download()
     np.savez(out_path + f".rank{rank}.npz", bodies=me.bodies, manifolds=me.manifolds, **{"b_" + k: v for k, v in b.items()}, **{"i_" + k: v for k, v in imp.items()})
 
@@ -245,8 +251,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
         return
-    if case in ("level2", "level2_overflow"):
-        run_level2(lib, rank, world, steps, out_path, keep=4 if case == "level2_overflow" else None)
+    if case in ("level2", "level2_overflow", "level2_joints"):
+        run_level2(lib, rank, world, steps, out_path, keep=4 if case == "level2_overflow" else None, joints=case == "level2_joints")
         dist.barrier()
         dist.destroy_process_group()
         return

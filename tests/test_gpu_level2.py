@@ -52,6 +52,27 @@ def test_overflow_colour_on_shared_bodies_on_hip(bits, world_size, keep, restitu
         compare_with_single(ref, plan, worlds)
 
 
+@pytest.mark.parametrize("bits,world_size,damped,keep", [(32, 2, True, None), (32, 3, False, None), (64, 2, True, 6), (32, 4, True, None)])
+def test_joints_on_shared_bodies_on_hip(bits, world_size, damped, keep):
+    """Round 6: joints whose bodies are shared between slabs (the joint slot, avn_halo_joint_slot_set).  Split HIP worlds == the unsplit HIP world == the unsplit
+    oracle: bodies, impulses and the joints' lagrange sums / forces."""
+    from level2_helpers import compare_joints_with_single, make_joint_worlds, stack_joints, step_split_with_joints
+    hip, orc = hip_lib(), oracle_lib()
+    sc, pm, offs, _ = global_problem(orc, 8, 4, 5, seed=bits + world_size)
+    if keep is not None:
+        offs = overflow_from(offs, keep)
+    jkw = stack_joints(sc, 8, 4, 5, seed=world_size, damped=damped)
+    single, plan, worlds = make_joint_worlds(hip, bits, sc, pm, offs, 0.0, 3, world_size, jkw)
+    ref = make_single(orc, bits, sc, pm, offs, 0.0, 3); ref.joints_upload(**jkw)
+    assert plan[0].joint_slot
+    for step in range(3):
+        single.run_system("SOLVER"); ref.run_system("SOLVER")
+        step_split_with_joints(plan, worlds, 3, False)
+        compare_with_single(single, plan, worlds); compare_with_single(ref, plan, worlds)
+        compare_joints_with_single(single, plan, worlds); compare_joints_with_single(ref, plan, worlds)
+    assert float(np.abs(single.joints_download()["total_lagrange"]).max()) > 1e-4
+
+
 def test_cfg5_shaped_closed_loop_manifolds_over_2_and_4_slabs_on_hip():
     """The cfg5-shaped case (50 000 cuboids f64, the HIP closed loop's own manifolds with ~10^5 in the overflow colour): HIP slabs == the unsplit HIP world == the
     unsplit oracle, every step, bodies and impulses."""
@@ -162,6 +183,35 @@ for bits in (32, 64):
     ia, ib = plain.impulses_download(), looped.impulses_download()
     for k in ia:
         assert np.array_equal(ia[k], ib[k]), ("levels", bits, k)
+# round 6: the joint slot through the library's own exchange -- a jointed stack whose every jointed body travels rank 0 -> rank 0 after the joint systems of every substep
+from level2_helpers import stack_joints
+for bits in (32, 64):
+    sc, pm, offs, _ = global_problem(orc, 6, 3, 4, seed=13)
+    jkw = stack_joints(sc, 6, 3, 4, seed=3, damped=True)
+    plain = make_single(hip, bits, sc, pm, offs, 0.0, 3); plain.joints_upload(**jkw)
+    looped = make_single(hip, bits, sc, pm, offs, 0.0, 3); looped.joints_upload(**jkw)
+    so = [0]; bodies = []
+    for c in range(24):
+        m = np.arange(offs[c], offs[c + 1])
+        b = np.unique(np.concatenate([pm["body1"][m], pm["body2"][m]])) if len(m) else np.zeros(0, np.int64)
+        b = b[sc.rb_type[b] == F.RB_DYNAMIC]
+        bodies.append(b); so.append(so[-1] + len(b))
+    jb = np.unique(np.concatenate([jkw["body1"], jkw["body2"]])); jb = jb[sc.rb_type[jb] == F.RB_DYNAMIC]
+    bodies.append(jb); so.append(so[-1] + len(jb))       # slot 24: the joint slot
+    bodies = np.concatenate(bodies).astype(np.int32)
+    looped.halo_joint_slot_set(True, True)
+    looped.halo_plan_upload([0], so, bodies, so, bodies)
+    looped.comm_init(hip.comm_unique_id(), 1, 0)
+    for _ in range(3):
+        plain.step(); looped.step()
+    looped.synchronize(); plain.synchronize()
+    a, b = plain.bodies_download(), looped.bodies_download()
+    for k in a:
+        assert np.array_equal(a[k], b[k]), ("joint slot", bits, k)
+    ja, jb_ = plain.joints_download(), looped.joints_download()
+    for k in ja:
+        assert np.array_equal(ja[k], jb_[k]), ("joint slot", bits, k)
+    assert float(np.abs(ja["total_lagrange"]).max()) > 1e-4
 print("SELF_EXCHANGE_OK")
 """
 

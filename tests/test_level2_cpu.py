@@ -150,7 +150,7 @@ def test_library_planner_equals_the_numpy_planner():
                         assert np.array_equal(np.asarray(getattr(a, f)).astype(np.int64), np.asarray(getattr(b, f)).astype(np.int64)), (keep, R, L.prefix, f)
 
 
-@pytest.mark.parametrize("case", ["level2", "level2_overflow"])
+@pytest.mark.parametrize("case", ["level2", "level2_overflow", "level2_joints"])
 def test_level2_over_gloo_world_size_2(tmp_path, case):
     """Two real processes (torch.distributed, gloo): each builds only its slab, steps it with shard.level2_solver and exchanges the boundary
     records point to point after every colour (level2_overflow: and after every LEVEL of the overflow colour, which then holds the manifolds of
@@ -162,7 +162,13 @@ def test_level2_over_gloo_world_size_2(tmp_path, case):
     sc, pm, offs, _ = global_problem(lib, 8, 4, 5, seed=7)
     if case == "level2_overflow":
         offs = overflow_from(offs, 4)
+    jkw = None
+    if case == "level2_joints":
+        from level2_helpers import stack_joints
+        jkw = stack_joints(sc, 8, 4, 5, seed=2, damped=True)
     single = make_single(lib, 32, sc, pm, offs, 0.3, 3)
+    if jkw is not None:
+        single.joints_upload(**jkw)
     for _ in range(3):
         single.run_system("SOLVER")
     ref, imp = single.bodies_download(), single.impulses_download()
@@ -175,3 +181,49 @@ def test_level2_over_gloo_world_size_2(tmp_path, case):
             assert np.array_equal(imp[k][d["manifolds"]], d["i_" + k]), f"rank {r}: impulses.{k}"
         seen[d["manifolds"]] = True
     assert seen.all()
+
+
+@pytest.mark.parametrize("bits,world_size,damped,keep", [(32, 2, True, None), (32, 3, False, None), (64, 2, True, 6), (32, 4, True, None)])
+def test_joints_on_shared_bodies_equal_the_single_world(bits, world_size, damped, keep):
+    """Round 6: joints whose bodies are shared between slabs.  A joint component belongs to one world (its owner holds all its bodies); after the joint systems of
+    every substep the owner's SolverBody records of the component's shared bodies travel to the other holders (the joint slot).  Chains across every cut, joints to the
+    static ground (with JointDamping: one serial chain through the DUMMY pair), three joint types; keep != None: together with overflow levels."""
+    from level2_helpers import compare_joints_with_single, make_joint_worlds, stack_joints, step_split_with_joints
+    lib = oracle_lib()
+    sc, pm, offs, _ = global_problem(lib, 8, 4, 5, seed=bits + world_size)
+    if keep is not None:
+        offs = overflow_from(offs, keep)
+    jkw = stack_joints(sc, 8, 4, 5, seed=world_size, damped=damped)
+    single, plan, worlds = make_joint_worlds(lib, bits, sc, pm, offs, 0.0, 3, world_size, jkw)
+    assert plan[0].joint_slot and plan[0].global_joints and sum(len(p.joints) for p in plan) == len(jkw["body1"])
+    n_p = [len(p.peers) for p in plan]
+    js = plan[0].joint_slot_index
+    assert sum(int(p.send_offsets[(js + 1) * n] - p.send_offsets[js * n]) for p, n in zip(plan, n_p) if n) > 0, "the joint slot must carry bodies"
+    for step in range(3):
+        single.run_system("SOLVER")
+        step_split_with_joints(plan, worlds, 3, False)
+        compare_with_single(single, plan, worlds)
+        compare_joints_with_single(single, plan, worlds)
+    assert float(np.abs(single.joints_download()["total_lagrange"]).max()) > 1e-4, "the joints must have worked"
+
+
+def test_joint_planners_agree():
+    from helpers import hip_lib
+    from level2_helpers import stack_joints
+    lib = oracle_lib()
+    sc, pm, offs, _ = global_problem(lib, 9, 3, 4)
+    for damped in (True, False):
+        jkw = stack_joints(sc, 9, 3, 4, seed=1, damped=damped)
+        jp = (jkw["body1"], jkw["body2"], jkw["joint_type"], damped)
+        for R in (2, 3, 4):
+            want = shard.level2_plan(sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, R, joints=jp)
+            for L in (hip_lib(), lib):
+                got = shard.level2_plan_lib(L, sc.position, sc.rb_type, pm["body1"], pm["body2"], offs, R, joints=jp)
+                for a, b in zip(got, want):
+                    for f in ("bodies", "manifolds", "color_offsets", "peers", "send_offsets", "send_bodies", "recv_offsets", "recv_bodies", "n_overflow_levels", "joints", "joint_slot", "global_joints"):
+                        assert np.array_equal(np.asarray(getattr(a, f)).astype(np.int64), np.asarray(getattr(b, f)).astype(np.int64)), (damped, R, L.prefix, f)
+            if damped:   # every damped joint with a static body of one type shares the DUMMY pair: one owner
+                for t in (F.JOINT_DISTANCE, F.JOINT_SPHERICAL):
+                    g = np.flatnonzero((jkw["joint_type"] == t) & ((jkw["body1"] == 0) | (jkw["body2"] == 0)))
+                    owners = {r for r, p in enumerate(want) for j in g if j in set(p.joints.tolist())}
+                    assert len(owners) == 1, (t, owners)
