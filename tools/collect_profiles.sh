@@ -18,6 +18,9 @@ cpf closed_loop_breakdown.txt closed_loop_breakdown.txt
 cpf closed_loop_step110_timeline.txt closed_loop_step110_timeline.txt
 cpf closed_loop_switches_ab.txt closed_loop_switches_ab.txt
 cpf closed_loop_r4_vs_r5_same_box.txt closed_loop_r4_vs_r5_same_box.txt
+cpf closed_loop_r5_vs_r6_same_box.txt closed_loop_r5_vs_r6_same_box.txt
+cpf sleeping_cfg2_r5_vs_r6_same_box.txt sleeping_cfg2_r5_vs_r6_same_box.txt
+cpf level2_cfg5_closed_loop_manifolds_world1.json level2_cfg5_closed_loop_manifolds_world1.json
 cpf sleeping_step230_timeline.txt sleeping_step230_timeline.txt
 cpf sleeping_cfg2_windows.txt sleeping_cfg2_windows.txt
 cpf sleeping_cfg2_host_phases.txt sleeping_cfg2_host_phases.txt

@@ -56,12 +56,14 @@ timeout 120 python tools/time_pcie.py 20 > $O/pcie_calls.json 2> $O/pcie.err
 # the closed loop: one steady step's kernel timeline, the narrow phase's cut-off timings, A/B of the round's switches on this box
 bash tools/step_timeline.sh 110 > /dev/null 2>&1; cp $R/gpurun_out/timeline/timeline.txt $O/closed_loop_step110_timeline.txt 2>/dev/null
 for e in "" AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_NO_EARLY_PREPARE=1 "AVN_NO_OCT=1 AVN_OVF_TICKETS=1 AVN_NO_HANDLE_SORT=1 AVN_NO_EARLY_PREPARE=1"; do echo "== ${e:-default}"; env AVN_LIB_PATH=$M $e python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py; done > $O/closed_loop_switches_ab.txt
-# this tree against round 4's library ON THIS BOX (boxes of the pool differ by 10-15 %): avian_amd/csrc/ab/libavian_r4.so is the round-4 tree built next to this one
-if [ -f $R/avian_amd/csrc/ab/libavian_r4.so ]; then
+# this tree against round 5's library ON THIS BOX (boxes of the pool differ by 10-15 %): avian_amd/csrc/ab/libavian_r5.so is the round-5 tree (git archive of the round-5 commit) built next to this one
+if [ -f $R/avian_amd/csrc/ab/libavian_r5.so ]; then
   for k in 1 2; do
-    echo "== round 5 (this tree), run $k"; python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
-    echo "== round 4 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r4.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
-  done > $O/closed_loop_r4_vs_r5_same_box.txt 2>&1
+    echo "== round 6 (this tree), run $k"; python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
+    echo "== round 5 library, run $k"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r5.so python tools/time_closed_loop.py 50 40 50 120 2>&1 | python tools/window_means.py
+  done > $O/closed_loop_r5_vs_r6_same_box.txt 2>&1
+  ( echo "== round 6 (this tree), avn_sleeping_enable at cfg2's scale"; timeout 200 python tools/time_sleeping_cfg2.py 60 2>/dev/null | grep "steps\|ratio"
+    echo "== round 5 library, same tool"; AVN_AB_OLDER_LIBRARY=1 AVN_LIB_PATH=$R/avian_amd/csrc/ab/libavian_r5.so timeout 300 python tools/time_sleeping_cfg2.py 60 2>&1 | grep "steps\|ratio\|rror" ) > $O/sleeping_cfg2_r5_vs_r6_same_box.txt 2>&1
 fi
 # round 6: avn_sleeping_enable at cfg2's scale -- window by window next to the sleeping-off run, the host phases of every step, each of the round's mechanisms switched off
 # alone on this box, a two-step kernel timeline (a split step and its neighbour); the bench's sleeping scene; cfg3 / cfg5 closed loops; the sharded device loop's cost model
@@ -84,4 +86,6 @@ timeout 400 python tools/time_configs.py $O/other_configs.json > $O/time_configs
 timeout 400 python tools/bench_reference_scenes.py 300 4 $O/reference_scenes.json > $O/reference_scenes.log 2>&1; tail -2 $O/reference_scenes.log
 AVN_BENCH_SINGLE_DEVICE=1 AVN_BENCH_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_single_device.json 2> $O/bench_n2.err; tail -c 300 $O/bench_n2_single_device.json; echo
 timeout 200 python tools/level2_multi_gpu.py --steps 10 2> $O/level2.err | grep '^{' > $O/level2_world1.json; tail -c 300 $O/level2_world1.json; echo
+# round 6: the level-2 leg on the closed loop's own manifolds (overflow colour included), one rank: a smoke of the leg bench.py --gpus N runs, and the unsplit step time of that set
+timeout 300 python tools/level2_multi_gpu.py --dims 100 50 100 --bits 64 --substeps 8 --steps 3 --warmup 1 --closed-loop-steps 6 2>> $O/level2.err | grep '^{' > $O/level2_cfg5_closed_loop_manifolds_world1.json
 ls -la $O

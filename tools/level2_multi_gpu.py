@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bits", type=int, default=32)
     ap.add_argument("--substeps", type=int, default=4)
+    ap.add_argument("--closed-loop-steps", type=int, default=0, help="> 0: the island's manifolds are the device closed loop's own after that many steps (overflow colour included)")
+    ap.add_argument("--check-steps", type=int, default=3)
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -43,7 +45,8 @@ def main():
         t = torch.tensor([x], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
-    res = level2_bench.run(lib, rank, world, local, bcast, armax, dist.barrier, dims=tuple(args.dims), steps=args.steps, warmup=args.warmup, bits=args.bits, substeps=args.substeps)
+    res = level2_bench.run(lib, rank, world, local, bcast, armax, dist.barrier, dims=tuple(args.dims), steps=args.steps, warmup=args.warmup, bits=args.bits, substeps=args.substeps,
+                           closed_loop_steps=args.closed_loop_steps, check_steps=args.check_steps)
     if rank == 0:
         print(json.dumps(res))
     dist.destroy_process_group()
