@@ -427,8 +427,8 @@ class Level2Rank:
         """avn_halo_overflow_levels_upload (when levelled) + avn_halo_plan_upload."""
         if self.n_overflow_levels > 1:
             world.halo_overflow_levels_upload(self.n_overflow_levels, self.overflow_level)
-        if self.global_joints:
-            world.halo_joint_slot_set(self.joint_slot, True)
+        if self.global_joints or getattr(world, "_halo_joint", False):   # (also back to "no joint slot" on a world that carried one)
+            world.halo_joint_slot_set(self.joint_slot, self.global_joints)
         world.halo_plan_upload(self.peers, self.send_offsets, self.send_bodies, self.recv_offsets, self.recv_bodies)
 
 
