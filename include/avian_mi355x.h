@@ -648,7 +648,8 @@ AVN_API avn_status AVN_FN(pipeline_new_pair_ids_get)(avn_world* w, const uint32_
  * global colour of each manifold) every world runs the colour launches of the single-world step on its subset, and after each colour the
  * world whose manifold moved a shared body hands that body's (linear, angular) velocity to the other holders: the single world's state is
  * restored before the next colour, so the split run is BIT-IDENTICAL to the unsplit one (a body is in at most one manifold per colour).
- * Not supported in this form: overflow-colour manifolds or joints on shared bodies (rejected by the planner, avian_amd/shard.py).
+ * Round 6: overflow-colour manifolds on shared bodies travel level by level (avn_halo_overflow_levels_upload) and joints on shared bodies as owned components with a
+ * joint slot (avn_halo_joint_slot_set): exchange SLOTS = 23 colours, then the overflow levels (or the one overflow colour), then -- when planned -- the joint slot.
  *
  *   avn_halo_plan_upload   per (colour, peer): local body indices to send and to receive, in the same order on both sides
  *   avn_run_color_pass     one colour of one contact pass (AVN_SYS_WARM_START / SOLVE_CONTACTS_BIAS / SOLVE_CONTACTS_RELAX / SOLVE_RESTITUTION)

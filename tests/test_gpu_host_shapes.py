@@ -121,3 +121,11 @@ def test_capsules_on_hip_equal_the_oracle_given_the_same_host_answers():
     assert not wh.host_shape_errors() and ch.queries == co.queries
     y = wh.bodies_download()["position"][1:, 1]
     assert (y > top + 0.25 - 0.03).all() and np.median(y) < top + 0.25 + 0.05
+
+
+def test_host_shapes_with_sleeping_and_a_despawn_on_hip():
+    """Host-flagged colliders next to avn_sleeping_enable and an avn_despawn of a host-shaped body: hosted HIP world == native HIP world every step (bodies, colour
+    lists, island ids, Sleeping flags, timers), and the hosted HIP world == the hosted oracle world at the end."""
+    from test_host_shapes_cpu import _combo
+    slept, hs = _combo(hip_lib(), oracle_lib())
+    assert hs.manifold_queries > 200 and slept > 0

@@ -81,3 +81,44 @@ def test_capsules_a_shape_the_library_has_no_kernel_for_come_to_rest_on_the_grou
     assert (y < top + 0.25 + 0.45).all(), "every capsule lies on the ground or leans on a neighbour"
     assert np.median(y) < top + 0.25 + 0.05
     assert float(np.abs(b["linear_velocity"][1:, 1]).max()) < 0.05, "at rest vertically (a lying capsule may still roll: there is no rolling friction)"
+
+
+def _combo(lib, query_lib, seed=11, steps=160):
+    """Host-flagged colliders with sleeping enabled and a despawn in the middle: hosted world == native world every step."""
+    bodies, colliders = dropped_boxes(seed=seed, n=30)
+    rng = np.random.default_rng(seed)
+    host = rng.random(len(colliders["shape"])) < 0.4
+    host[5] = True   # (the body despawned below carries a host shape)
+    native, hosted, hs = make_pair(lib, query_lib, 32, bodies, colliders, host)
+    for w in (native, hosted):
+        w.pipeline_enable(); w.sleeping_enable()
+    slept = 0
+    for step in range(steps):
+        if step == 60:   # despawn body 5 with its collider, re-upload what remains (INTEGRATION.md section 5)
+            keep = np.arange(len(bodies["inv_mass"])) != 5
+            for w, cols in ((native, colliders), (hosted, dict(colliders, shape=np.where(host, F.SHAPE_HOST, colliders["shape"]).astype(np.uint8)))):
+                st = w.bodies_download()
+                w.despawn(bodies=[5])
+                nb = {k: np.asarray(v)[keep] for k, v in bodies.items()}
+                nb.update({k: v[keep] for k, v in st.items()})
+                nc = {k: np.asarray(v)[keep] for k, v in cols.items()}
+                nc["body"] = np.arange(int(keep.sum()), dtype=np.int32)
+                w.bodies_upload(**nb); w.colliders_upload(**nc)
+        native.step(); hosted.step()
+        assert not hosted.host_shape_errors()
+        a, b = native.bodies_download(), hosted.bodies_download()
+        for k in a:
+            assert np.array_equal(a[k], b[k]), f"step {step}: bodies.{k}"
+        (oa, ha), (ob, hb) = native.pipeline_handles(), hosted.pipeline_handles()
+        assert np.array_equal(oa, ob) and np.array_equal(ha, hb), f"step {step}: colour lists"
+        sa, sb = native.sleeping_state(), hosted.sleeping_state()
+        for k in sa:
+            assert np.array_equal(sa[k], sb[k]), f"step {step}: sleeping state.{k}"
+        slept = max(slept, int(sa["sleeping"].sum()))
+    return slept, hs
+
+
+def test_host_shapes_with_sleeping_and_a_despawn():
+    lib = oracle_lib()
+    slept, hs = _combo(lib, lib)
+    assert hs.manifold_queries > 200 and slept > 0, "bodies must have fallen asleep with host shapes in the loop"
