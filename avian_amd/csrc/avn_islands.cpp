@@ -547,15 +547,25 @@ avn_status IslandManager::sleeping_systems(const float* sleep_timer, const uint8
     awake_.assign(islands_.size(), 0);
     candidate_timer_ = 0.0f;
     const uint32_t n = std::min<uint32_t>(n_bodies, (uint32_t)node_.size());
-    // update_sleeping_states, island side (sleeping.rs:224-239), in body order (the ABI's stand-in for the query's iteration order)
+    // update_sleeping_states, island side (sleeping.rs:224-239), in body order (the ABI's stand-in for the query's iteration order), and
+    // wake_islands_with_sleeping_disabled (:164-182) in the SAME pass (round 6: at 10^5 bodies two passes over the arrays were a fifth of the Sleeping set's host time):
+    // the second system only sets awake flags, which the first never reads, so fusing the loops changes no result; the candidate still goes to the FIRST body with the
+    // largest timer (strict >, ascending body index)
+    const uint8_t* node = node_.data(); const uint32_t* isl_of = isl_of_.data(); uint8_t* awake = awake_.data();
+    uint32_t n_flag_awake = 0;
     for (uint32_t b = 0; b < n; ++b) {
-        if (!node_[b] || !(flags[b] & 1u)) continue;
-        const uint32_t isl = isl_of_[b];
-        if (sleep_timer[b] < time_to_sleep) awake_[isl] = 1;
-        else if (islands_[isl].removed > 0 && sleep_timer[b] > candidate_timer_) { candidate_ = isl; candidate_timer_ = sleep_timer[b]; }
+        const uint32_t f = flags[b];
+        n_flag_awake += (f >> 2) & 1u;
+        if (!node[b] || !(f & 3u)) continue;
+        const uint32_t isl = isl_of[b];
+        if (f & 2u) awake[isl] = 1;
+        if (!(f & 1u)) continue;
+        const float t = sleep_timer[b];
+        if (t < time_to_sleep) awake[isl] = 1;
+        else if (t > candidate_timer_ && islands_[isl].removed > 0) { candidate_ = isl; candidate_timer_ = t; }
     }
-    // wake_islands_with_sleeping_disabled, :164-182
-    for (uint32_t b = 0; b < n; ++b) if (node_[b] && (flags[b] & 2u)) awake_[isl_of_[b]] = 1;
+    for (uint32_t b = n; b < n_bodies; ++b) n_flag_awake += (flags[b] >> 2) & 1u;
+    last_flag_awake_ = n_flag_awake;
     // sleep_islands, :243-280, in slab key order
     std::vector<uint32_t> to_sleep, to_wake;
     for (uint32_t k = 0; k < islands_.size(); ++k) {

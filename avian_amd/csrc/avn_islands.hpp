@@ -75,6 +75,7 @@ public:
     avn_status flush_wake();
     avn_status split_candidate_now();
     avn_status sleeping_systems(const float* sleep_timer, const uint8_t* flags, uint32_t n_bodies, float time_to_sleep);
+    uint32_t last_flag_awake() const { return last_flag_awake_; }   // bodies whose flags carried bit 2 (owned a SolverBody) in the last sleeping_systems: counted in its one pass
     avn_status wake_body(uint32_t body);
     avn_status sleep_body(uint32_t body);
     // despawn (avn_despawn / avn_islands_collider_remove ...): see the header
@@ -123,6 +124,7 @@ private:
     struct EdgeLists { std::vector<uint32_t> out, in; };   // insertion order; the reference iterates newest first
 
     std::vector<uint8_t> node_, asleep_;
+    uint32_t last_flag_awake_ = 0;
     std::vector<uint32_t> isl_of_;
     std::vector<std::vector<uint32_t>> colliders_of_;
     // colliders by Entity::index(): a dense table for the indices an ECS hands out (small integers), a map behind it for anything above

@@ -319,10 +319,8 @@
         HIPCHK(hipStreamSynchronize(stream));
         double m2 = slp_now();
         t0 = std::chrono::steady_clock::now();
-        uint32_t awake = 0;
-        for (uint32_t b = 0; b < n; ++b) awake += (h_flags[b] >> 2) & 1u;
-        slp_n_awake = awake;
         if ((st = isl.sleeping_systems(h_timer, h_flags, n, slp_time_to_sleep)) != AVN_OK) return slp_fail(st);
+        slp_n_awake = isl.last_flag_awake();   // (counted inside the manager's one pass over the flags)
         slp_last_slept = isl.last_slept(); slp_last_woken = isl.last_woken();
         host_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         double m3 = slp_now();
