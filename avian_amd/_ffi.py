@@ -269,6 +269,25 @@ class avn_host_shape_stats(C.Structure):
                 ("bytes_to_host", C.c_uint64), ("bytes_from_host", C.c_uint64), ("last_callback_ms", C.c_double)]
 
 
+# ---- collision hooks (include/avian_mi355x.h "collision hooks"): CollisionHooks::filter_pairs / modify_contacts as callbacks -----------------
+HOOK_FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)                 # avn_filter_pairs_fn
+HOOK_MODIFY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)                 # avn_modify_contacts_fn
+HOOK_PAIR_DTYPE = np.dtype([("index", "<u4"), ("collider1", "<u4"), ("collider2", "<u4")])          # avn_hook_pair
+
+
+class avn_collision_hook_stats(C.Structure):
+    _fields_ = [("last_filter_queries", C.c_uint32), ("last_filter_rejected", C.c_uint32), ("last_modify_queries", C.c_uint32), ("last_modify_rejected", C.c_uint32),
+                ("bytes_to_host", C.c_uint64), ("bytes_from_host", C.c_uint64), ("last_callback_ms", C.c_double)]
+
+
+def hook_contact_dtype(bits: int):
+    """numpy view of avn_hook_contact_fNN."""
+    S = "<f4" if bits == 32 else "<f8"
+    return np.dtype([("contact_id", "<u4"), ("collider1", "<u4"), ("collider2", "<u4"), ("body1", "<u4"), ("body2", "<u4"), ("flags", "<u4"), ("touching", "<u4"),
+                     ("manifold_count", "<u4"), ("point_count", "<u4"), ("reserved", "<u4"), ("normal", S, 3), ("friction", S), ("restitution", S), ("tangent_velocity", S, 3),
+                     ("anchor1", S, (4, 3)), ("anchor2", S, (4, 3)), ("penetration", S, 4), ("normal_speed", S, 4), ("feature_id1", "<u4", 4), ("feature_id2", "<u4", 4)])
+
+
 def host_shape_dtypes(bits: int):
     """numpy views of avn_host_aabb_query_fNN, avn_host_aabb_fNN, avn_host_manifold_query_fNN, avn_host_manifold_fNN."""
     S = "<f4" if bits == 32 else "<f8"
@@ -287,7 +306,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "collision_hooks_set", "collision_hook_stats_get", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -345,6 +364,8 @@ class Library:
         f("level2_plan_rank_joints").argtypes = [vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.POINTER(C.c_uint32)), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
         f("host_shapes_set").argtypes = [vp, HOST_SHAPE_FN, HOST_SHAPE_FN, vp]
         f("host_shape_stats_get").argtypes = [vp, C.POINTER(avn_host_shape_stats)]
+        f("collision_hooks_set").argtypes = [vp, HOOK_FILTER_FN, HOOK_MODIFY_FN, vp]
+        f("collision_hook_stats_get").argtypes = [vp, C.POINTER(avn_collision_hook_stats)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
         f("sleep_get").argtypes = [vp, C.POINTER(avn_sleep_out)]
@@ -888,6 +909,35 @@ class World:
         a, m = wrap(aabb_fn, 0, 1), wrap(manifolds_fn, 2, 3)
         self._hs_keep = (a, m)   # (ctypes callbacks must outlive the registration)
         self._check(self.lib.fn("host_shapes_set")(self.handle, a, m, None))
+
+    # -- collision hooks: CollisionHooks::filter_pairs / modify_contacts as callbacks -----------------------------------------------------
+    def collision_hooks_set(self, filter_fn=None, modify_fn=None):
+        """``avn_collision_hooks_set``.  filter_fn(pairs, should_collide): `pairs` a HOOK_PAIR_DTYPE array (emission order), `should_collide` a uint8 array preset to 1,
+        written in place.  modify_fn(contacts): a hook_contact_dtype array (ascending contact id) modified in place (touching = the hook's return value).  Both arrays
+        VIEW the library's buffers.  None = the trait's default for that hook; None, None unregisters."""
+        errors = self._hs_errors = getattr(self, "_hs_errors", [])
+
+        def cb_filter(user, n, q, o):
+            try:
+                filter_fn(np.frombuffer((C.c_char * (n * HOOK_PAIR_DTYPE.itemsize)).from_address(q), dtype=HOOK_PAIR_DTYPE), np.frombuffer((C.c_char * n).from_address(o), dtype=np.uint8))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+
+        def cb_modify(user, bits, n, r):
+            try:
+                dt = hook_contact_dtype(int(bits))
+                modify_fn(np.frombuffer((C.c_char * (n * dt.itemsize)).from_address(r), dtype=dt))
+            except BaseException as e:  # noqa: BLE001
+                errors.append(e)
+        f = HOOK_FILTER_FN(cb_filter) if filter_fn is not None else HOOK_FILTER_FN()
+        m = HOOK_MODIFY_FN(cb_modify) if modify_fn is not None else HOOK_MODIFY_FN()
+        self._hk_keep = (f, m)
+        self._check(self.lib.fn("collision_hooks_set")(self.handle, f, m, None))
+
+    def collision_hook_stats(self) -> avn_collision_hook_stats:
+        st = avn_collision_hook_stats()
+        self._check(self.lib.fn("collision_hook_stats_get")(self.handle, C.byref(st)))
+        return st
 
     def host_shape_errors(self):
         """Exceptions raised inside the Python callbacks since the last call (a C caller cannot propagate them)."""

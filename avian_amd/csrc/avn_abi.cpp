@@ -147,6 +147,8 @@ AVN_API avn_status avn_islands_partition(const avn_islands_in* in, int32_t* isla
 
 AVN_API avn_status avn_host_shapes_set(avn_world* w, avn_host_aabb_fn aabb, avn_host_manifolds_fn manifolds, void* user) { GUARD_MUT(host_shapes_set(aabb, manifolds, user)); }
 AVN_API avn_status avn_host_shape_stats_get(avn_world* w, avn_host_shape_stats* out) { GUARD(host_shape_stats_get(out)); }
+AVN_API avn_status avn_collision_hooks_set(avn_world* w, avn_filter_pairs_fn filter, avn_modify_contacts_fn modify, void* user) { GUARD_MUT(collision_hooks_set(filter, modify, user)); }
+AVN_API avn_status avn_collision_hook_stats_get(avn_world* w, avn_collision_hook_stats* out) { GUARD(collision_hook_stats_get(out)); }
 AVN_API avn_status avn_halo_plan_upload(avn_world* w, const avn_halo_plan* p) { GUARD_MUT(halo_plan_upload(p)); }
 AVN_API avn_status avn_halo_overflow_levels_upload(avn_world* w, uint32_t n_levels, const uint32_t* level_of, size_t count) { GUARD_MUT(halo_overflow_levels_upload(n_levels, level_of, count)); }
 AVN_API avn_status avn_halo_joint_slot_set(avn_world* w, uint32_t joint_slot, uint32_t global_joints) { GUARD_MUT(halo_joint_slot_set(joint_slot, global_joints)); }

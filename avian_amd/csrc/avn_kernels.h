@@ -155,9 +155,17 @@ template <class T> void launch_init_contact_rows(const CT<T>&, const uint32_t* i
 template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* ids, uint32_t n, hipStream_t);
 // host shapes (include/avian_mi355x.h): where the light kernel leaves the queries of pairs with an AVN_SHAPE_HOST collider; queries == nullptr: the world holds none
 // (the plain kernels run).  host_only: a retry after the list overflowed -- only those pairs are visited (they wrote nothing the first time), everything else is skipped
-struct NpHostList { void* queries = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t host_only = 0; };
+// collision hooks (include/avian_mi355x.h): CollisionHooks::modify_contacts for the pairs flagged AVN_CP_MODIFY_CONTACTS that have a manifold.  Three passes over such a pair:
+// phase 1 (inside the step's ordinary launches): the pair stops at the hook point, writes NOTHING but AVN_CP_ROW_HOOK_PENDING and is counted; phase 2 (the same launches
+// again, visiting only pending rows): the ContactPair as the hook sees it goes to records[0 .. *count) (the host sized the list from phase 1's count); phase 3
+// (launch_narrow_phase_hooked): the pair again from the top with the record the hook returned in the place of its manifold -- match_contacts, status change, row.
+// count == nullptr: no modify hook is registered (the plain kernels run unless the world holds host shapes).
+struct NpHookList { void* records = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t phase = 0; };
+struct NpHostList { void* queries = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t host_only = 0; NpHookList hook; bool any() const { return queries != nullptr || hook.count != nullptr; } };
+template <class T> void launch_narrow_phase_hooked(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool dense, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg,
+                                                   uint32_t* has, const void* records /* sorted by contact id, as the hook left them */, uint32_t n, hipStream_t);
 template <class T> void launch_narrow_phase_host(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool dense, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg,
-                                                 uint32_t* has, const void* queries /* sorted by contact id */, const void* manifolds, uint32_t n, hipStream_t);
+                                                 uint32_t* has, const void* queries /* sorted by contact id */, const void* manifolds, uint32_t n, hipStream_t, const NpHookList& hook = NpHookList());
 template <class T> void launch_host_aabb_queries(const DW<T>&, const BP<T>&, const StepParams<T>&, const uint32_t* slots, uint32_t n, void* out, hipStream_t);
 template <class T> void launch_host_aabb_apply(const BP<T>&, const StepParams<T>&, const uint32_t* slots, uint32_t n, const void* in, hipStream_t);
 // NarrowPhase::update_contacts over the active pairs; changes[0..*n_changes) in arbitrary order (the host sorts by id)
@@ -181,6 +189,9 @@ template <class T> void launch_unpack_contacts(const CT<T>&, const uint32_t* ids
 template <class T> void launch_remap_row_slots(const CT<T>&, const uint32_t* map, uint32_t n_old, uint32_t apply, uint32_t* n_orphans, hipStream_t);   // collider slots of live rows after a re-upload
 template <class T> void launch_pack_contacts(const CT<T>&, const uint32_t* ids, uint32_t n, const ContactsStage<T>&, uint32_t* error, hipStream_t);   // stage -> rows (ids without a live row: skipped, *error |= 4)
 void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_t n, hipStream_t);
+// CollisionHooks::filter_pairs in the device closed loop (k_graph.hip): the emitted pairs that ask for the filter; the emission list without the rejected ones
+void launch_hook_filter_collect(const avn_pair* pairs, uint32_t total, avn_hook_pair* out /* [total] */, uint32_t* count, hipStream_t);
+void launch_hook_filter_compact(const avn_pair* in, avn_pair* out, uint32_t total, const uint32_t* rejected /* ascending emission indices */, uint32_t n_rejected, hipStream_t);
 
 // ---- k_graph.hip: the closed loop's integer bookkeeping ON THE DEVICE -------------------------------------------------------
 // ContactGraph edge list + IdPool (data_structures/id_pool.rs:31-40), the status-change loop of NarrowPhase::update
@@ -188,6 +199,7 @@ void launch_hs_remove(uint64_t* tab, uint32_t cap, const uint64_t* keys, uint32_
 // that a step of the closed loop moves only a few counters over the bus.
 #define PG_NONE 0xFFFFFFFFu
 #define AVN_CP_ROW_USED 0x40000000u   // internal row flag (never reported through the ABI): the ContactId is live
+#define AVN_CP_ROW_HOOK_PENDING 0x10000000u   // internal row flag, alive only inside one narrow phase: the pair waits for CollisionHooks::modify_contacts (k_narrow.hip)
 #define AVN_CP_ROW_SLEEPING 0x20000000u   // internal row flag: ContactEdgeFlags::SLEEPING -- the pair is in ContactGraph::sleeping_pairs, the narrow phase does not update it
 // counters block (uint32 words of PG::ctr)
 enum { PGC_FREE_HEAD = 0, PGC_N_FREE = 1, PGC_NEXT_ID = 2, PGC_N_OPS = 3, PGC_N_REM = 4, PGC_ERROR = 5, PGC_TILE = 6 /* dynamic tile ids of k_pg_color */,

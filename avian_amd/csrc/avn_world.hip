@@ -423,6 +423,7 @@ template <class T> struct World : WorldBase {
 #include "world/joints.hpp"
 #include "world/broad_phase_data.hpp"
 #include "world/host_shapes.hpp"
+#include "world/hooks.hpp"
 #include "world/contacts.hpp"
 #include "world/pipeline_host.hpp"
 #include "world/pipeline_device.hpp"

@@ -99,6 +99,8 @@ struct WorldBase {
     virtual avn_status pipeline_new_pair_ids_get(const uint32_t**, size_t*) = 0;
     virtual avn_status host_shapes_set(avn_host_aabb_fn, avn_host_manifolds_fn, void*) = 0;
     virtual avn_status host_shape_stats_get(avn_host_shape_stats*) = 0;
+    virtual avn_status collision_hooks_set(avn_filter_pairs_fn, avn_modify_contacts_fn, void*) = 0;
+    virtual avn_status collision_hook_stats_get(avn_collision_hook_stats*) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
     virtual avn_status halo_joint_slot_set(uint32_t, uint32_t) = 0;

@@ -114,6 +114,32 @@ template <class T> void launch_pg_add_pairs(const PG& pg, const CT<T>& ct, const
     hipLaunchKernelGGL(k_pg_add_pairs<T>, dim3((total + 255) / 256), dim3(256), 0, s, pg, ct, pairs, total, pair_set, pair_set_cap - 1u);
 }
 
+// ---- collision hooks: CollisionHooks::filter_pairs (broad_phase.rs:431-439; include/avian_mi355x.h "collision hooks") ----------------------
+// The emitted pairs one of whose colliders asks for the filter, with their place in the emission order (arbitrary list order: the host sorts by it) ...
+__global__ __launch_bounds__(256) void k_hook_filter_collect(const avn_pair* __restrict__ pairs, uint32_t total, avn_hook_pair* __restrict__ out, uint32_t* __restrict__ count) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const avn_pair pr = pairs[i];
+    if (!(pr.flags & AVN_PAIR_NEEDS_CUSTOM_FILTER)) return;
+    const uint32_t k = atomicAdd(count, 1u);   // (k < total: the list is sized for every pair)
+    out[k] = avn_hook_pair{i, pr.collider1, pr.collider2};
+}
+// ... and the emission list without the pairs the hook rejected (rej: ascending emission indices), order kept
+__global__ __launch_bounds__(256) void k_hook_filter_compact(const avn_pair* __restrict__ in, avn_pair* __restrict__ out, uint32_t total, const uint32_t* __restrict__ rej, uint32_t n_rej) {
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    uint32_t lo = 0, hi = n_rej;   // rejected indices below i
+    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (rej[mid] < i) lo = mid + 1; else hi = mid; }
+    if (lo < n_rej && rej[lo] == i) return;
+    out[i - lo] = in[i];
+}
+void launch_hook_filter_collect(const avn_pair* pairs, uint32_t total, avn_hook_pair* out, uint32_t* count, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(k_hook_filter_collect, dim3((total + 255) / 256), dim3(256), 0, s, pairs, total, out, count);
+}
+void launch_hook_filter_compact(const avn_pair* in, avn_pair* out, uint32_t total, const uint32_t* rej, uint32_t n_rej, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(k_hook_filter_compact, dim3((total + 255) / 256), dim3(256), 0, s, in, out, total, rej, n_rej);
+}
+
 // ---- the status-change loop, decision part (system_param.rs:155-373) ------------------------------------------------------------
 // one changed row -> op k (k = the number of changed rows with a lower ContactId: the reference's processing order)
 __device__ __forceinline__ void pg_classify_row(const PG& pg, uint32_t c, uint32_t k, uint32_t n_bodies, uint32_t* hist, const uint32_t* __restrict__ bmeta) {

@@ -121,11 +121,24 @@ template <class T> struct NpHostM { uint32_t point_count; T normal[3]; T anchor1
 static_assert(sizeof(NpHostQ<float>) == sizeof(avn_host_manifold_query_f32) && sizeof(NpHostQ<double>) == sizeof(avn_host_manifold_query_f64), "host query layout");
 static_assert(sizeof(NpHostM<float>) == sizeof(avn_host_manifold_f32) && sizeof(NpHostM<double>) == sizeof(avn_host_manifold_f64) && offsetof(NpHostM<double>, normal) == offsetof(avn_host_manifold_f64, normal), "host manifold layout");
 static_assert(AVN_MAX_QUERY_POINTS <= AVN_NP_MAX_RAW, "a host manifold fits the raw-point column");
+// collision hooks (include/avian_mi355x.h "collision hooks", NpHookList in avn_kernels.h): the ContactPair as CollisionHooks::modify_contacts sees / leaves it
+template <class T> struct NpHookC { uint32_t contact_id, collider1, collider2, body1, body2, flags, touching, manifold_count, point_count, reserved;
+                                    T normal[3], friction, restitution, tangent_velocity[3], anchor1[12], anchor2[12], penetration[4], normal_speed[4]; uint32_t fid1[4], fid2[4]; };   // == avn_hook_contact_fNN
+static_assert(sizeof(NpHookC<float>) == sizeof(avn_hook_contact_f32) && sizeof(NpHookC<double>) == sizeof(avn_hook_contact_f64) && offsetof(NpHookC<double>, normal) == offsetof(avn_hook_contact_f64, normal) &&
+              offsetof(NpHookC<float>, fid1) == offsetof(avn_hook_contact_f32, feature_id1), "hook record layout");
+template <class T> struct NpHookCtx { NpHookC<T>* rec; uint32_t* count; uint32_t cap, phase; const NpHookC<T>* in; };   // in != nullptr: phase 3, this pair's record
+template <class T> __host__ __device__ __forceinline__ NpHookCtx<T> np_hook_ctx(const NpHookList& l) { return NpHookCtx<T>{(NpHookC<T>*)l.records, l.count, l.cap, l.phase, nullptr}; }
 template <class T, bool DENSE, bool HEAVY, bool HS = false>
 __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t c,
                                avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
-                               uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col, NpHostQ<T>* hq = nullptr, const NpHostM<T>* hm = nullptr) {
+                               uint32_t* __restrict__ has, bool* deferred, V3<T>* axis, T* lds_col, NpHostQ<T>* hq = nullptr, const NpHostM<T>* hm = nullptr,
+                               const NpHookCtx<T>* hk = nullptr) {
     uint4 meta = ct.meta[c];
+    // (collision hooks: phase 2 visits only the rows phase 1 left pending; the bit itself is not a flag of the pair)
+    const bool hk_on = HS && hk != nullptr && hk->count != nullptr;
+    const bool hooked = HS && HEAVY && hk != nullptr && hk->in != nullptr;   // phase 3: the hook's answer is this pair's manifold
+    if (hk_on && hk->phase == 2u && !(meta.z & AVN_CP_ROW_HOOK_PENDING)) return;
+    if (HS) meta.z &= ~(uint32_t)AVN_CP_ROW_HOOK_PENDING;
     // (a free id; or a pair of ContactGraph::sleeping_pairs: update_contacts walks the ACTIVE pairs only, system_param.rs:437-475)
     if (DENSE && (!(meta.z & AVN_CP_ROW_USED) || (meta.z & AVN_CP_ROW_SLEEPING))) { chg[c] = 0u; has[c] = 0u; return; }
     const uint32_t slot1 = meta.x, slot2 = meta.y;
@@ -186,6 +199,7 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         const T effective_speculative_margin = delta_secs * length(relative_linear_velocity);
         const T max_contact_distance = smax(effective_speculative_margin, p.contact_tolerance) + collision_margin_sum;
         if (HS && !HEAVY && ((ci1.z & 0xFFu) == AVN_SHAPE_HOST || (ci2.z & 0xFFu) == AVN_SHAPE_HOST)) {   // the manifold is the host's: hand the query over, write nothing
+            if (hk_on && hk->phase == 2u) return;   // (its record is collected by k_narrow_phase_host's second pass)
             hq->contact_id = c; hq->collider1 = ci1.x; hq->collider2 = ci2.x; hq->reserved = 0u;
             hq->position1[0] = x1.x; hq->position1[1] = x1.y; hq->position1[2] = x1.z; hq->rotation1[0] = q1.x; hq->rotation1[1] = q1.y; hq->rotation1[2] = q1.z; hq->rotation1[3] = q1.w;
             hq->position2[0] = x2.x; hq->position2[1] = x2.y; hq->position2[2] = x2.z; hq->rotation2[0] = q2.x; hq->rotation2[1] = q2.y; hq->rotation2[2] = q2.z; hq->rotation2[3] = q2.w;
@@ -225,7 +239,8 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         V3<T> normal = vzero<T>();
         bool defer = HEAVY;
         bool has_manifold;
-        if (HS && HEAVY) {   // contact_manifolds_with_context answered by the host
+        if (hooked) has_manifold = false;   // (nothing to compute: the pair's points are in the record)
+        else if (HS && HEAVY && hm) {   // contact_manifolds_with_context answered by the host
             const uint32_t n = hm->point_count < (uint32_t)AVN_MAX_QUERY_POINTS ? hm->point_count : (uint32_t)AVN_MAX_QUERY_POINTS;
             normal = V3<T>{hm->normal[0], hm->normal[1], hm->normal[2]};
             for (uint32_t k = 0; k < n; ++k) sink.put(V3<T>{hm->anchor1[3 * k], hm->anchor1[3 * k + 1], hm->anchor1[3 * k + 2]}, hm->penetration[k], hm->fid1[k], hm->fid2[k]);
@@ -309,16 +324,56 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
             if (T(o0 + o1 + o2 + o3) + T(point_count) == T(123456.75)) chg[c] = 7u;
             return;
         }
-        const bool touching = n_manifolds != 0;
+        bool touching = n_manifolds != 0;
+        V3<T> tangent_velocity = vzero<T>();   // system_param.rs:722-729; only a hook changes it
+        // CollisionHooks::modify_contacts (system_param.rs:770-778): `touching && flags.contains(MODIFY_CONTACTS)`
+        if (hk_on && !hooked && touching && (flags & AVN_CP_MODIFY_CONTACTS)) {
+            if (hk->phase != 2u) {   // phase 1: counted and left pending; the row is otherwise untouched
+                atomicAdd(hk->count, 1u);
+                ct.meta[c].z = meta.z | AVN_CP_ROW_HOOK_PENDING;
+                return;
+            }
+            const uint32_t slot = atomicAdd(hk->count, 1u);
+            if (slot < hk->cap) {
+                NpHookC<T>& r = hk->rec[slot];
+                r.contact_id = c; r.collider1 = ci1.x; r.collider2 = ci2.x; r.body1 = ci1.y; r.body2 = ci2.y; r.flags = flags & 0xFFFFu;
+                r.touching = 1u; r.manifold_count = 1u; r.point_count = point_count; r.reserved = 0u;
+                r.normal[0] = normal.x; r.normal[1] = normal.y; r.normal[2] = normal.z; r.friction = friction; r.restitution = restitution;
+                r.tangent_velocity[0] = T(0); r.tangent_velocity[1] = T(0); r.tangent_velocity[2] = T(0);
+                for (uint32_t k = 0; k < (uint32_t)AVN_MAX_MANIFOLD_POINTS; ++k) {
+                    NpPt<T> pt;
+                    pt.anchor1 = vzero<T>(); pt.anchor2 = vzero<T>(); pt.penetration = T(0); pt.normal_speed = T(0); pt.fid1 = 0u; pt.fid2 = 0u;
+                    if (k < point_count) build(k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3)), pt);
+                    r.anchor1[3 * k] = pt.anchor1.x; r.anchor1[3 * k + 1] = pt.anchor1.y; r.anchor1[3 * k + 2] = pt.anchor1.z;
+                    r.anchor2[3 * k] = pt.anchor2.x; r.anchor2[3 * k + 1] = pt.anchor2.y; r.anchor2[3 * k + 2] = pt.anchor2.z;
+                    r.penetration[k] = pt.penetration; r.normal_speed[k] = pt.normal_speed; r.fid1[k] = pt.fid1; r.fid2[k] = pt.fid2;
+                }
+            }
+            return;
+        }
+        if (hooked) {   // the pair as the hook left it; !touching: manifolds.clear()
+            const NpHookC<T>& r = *hk->in;
+            touching = r.touching != 0u;
+            n_manifolds = touching && r.manifold_count ? 1u : 0u;
+            point_count = n_manifolds ? (r.point_count < (uint32_t)AVN_MAX_MANIFOLD_POINTS ? r.point_count : (uint32_t)AVN_MAX_MANIFOLD_POINTS) : 0u;
+            normal = V3<T>{r.normal[0], r.normal[1], r.normal[2]}; friction = r.friction; restitution = r.restitution;
+            tangent_velocity = V3<T>{r.tangent_velocity[0], r.tangent_velocity[1], r.tangent_velocity[2]};
+        }
         flags = touching ? (flags | AVN_CP_TOUCHING) : (flags & ~(uint32_t)AVN_CP_TOUCHING);
-        if (touching) {
+        if (touching && (!hooked || n_manifolds)) {
             if (!HEAVY) load_old_points();
             const T thr = T(0.1) * p.length_unit;
             const T thr2 = thr * thr;
             ct.n(c) = make4<T>(normal, friction);
-            ct.tv(c) = make4<T>(T(0), T(0), T(0), restitution);
+            ct.tv(c) = make4<T>(tangent_velocity, restitution);
             for (uint32_t k = 0; k < point_count; ++k) {
                 NpPt<T> pt;
+                if (hooked) {
+                    const NpHookC<T>& r = *hk->in;
+                    pt.anchor1 = V3<T>{r.anchor1[3 * k], r.anchor1[3 * k + 1], r.anchor1[3 * k + 2]}; pt.anchor2 = V3<T>{r.anchor2[3 * k], r.anchor2[3 * k + 1], r.anchor2[3 * k + 2]};
+                    pt.penetration = r.penetration[k]; pt.normal_speed = r.normal_speed[k]; pt.fid1 = r.fid1[k]; pt.fid2 = r.fid2[k];
+                    pt.warm_n = T(0); pt.warm_tx = T(0); pt.warm_ty = T(0);
+                } else
                 build(k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3)), pt);
                 if (p.match_contacts && old_n) {  // ContactManifold::match_contacts
                     bool matched = false;
@@ -389,7 +444,7 @@ template <class T, bool DENSE, bool HS = false>
 __global__ __launch_bounds__(NP_LIGHT_THREADS) void k_narrow_phase(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, const uint32_t* __restrict__ active, uint32_t n_active,
                                                                    avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg,
                                                                    uint32_t* __restrict__ has, uint32_t n_list, uint32_t range_base, NpHostQ<T>* __restrict__ hostq = nullptr,
-                                                                   uint32_t* __restrict__ hostq_n = nullptr, uint32_t hostq_cap = 0u, uint32_t host_only = 0u) {
+                                                                   uint32_t* __restrict__ hostq_n = nullptr, uint32_t hostq_cap = 0u, uint32_t host_only = 0u, NpHookCtx<T> hk = NpHookCtx<T>()) {
     const uint32_t a = blockIdx.x * NP_LIGHT_THREADS + threadIdx.x;
     bool deferred = false;
     V3<T> axis = vzero<T>();
@@ -399,9 +454,9 @@ __global__ __launch_bounds__(NP_LIGHT_THREADS) void k_narrow_phase(DW<T> w, BP<T
         q.contact_id = 0xFFFFFFFFu; q.reserved = host_only;
         if (a < n_active) {
             c = !DENSE ? active[a] : (active || n_list || range_base) ? (a < n_list ? active[a] : range_base + (a - n_list)) : a;
-            np_update_pair<T, DENSE, false, true>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, nullptr, &q, nullptr);
+            np_update_pair<T, DENSE, false, true>(w, bp, ct, p, c, changes, n_changes, chg, has, &deferred, &axis, nullptr, &q, nullptr, &hk);
         }
-        if (deferred && q.contact_id != 0xFFFFFFFFu) {   // a host pair (few of them: one atomic each); past the capacity only the count grows and the host retries larger
+        if (deferred && q.contact_id != 0xFFFFFFFFu && hostq_n) {   // a host pair (few of them: one atomic each); past the capacity only the count grows and the host retries larger
             const uint32_t k = atomicAdd(hostq_n, 1u);
             if (k < hostq_cap) hostq[k] = q;
             deferred = false;
@@ -430,9 +485,10 @@ __global__ __launch_bounds__(NP_LIGHT_THREADS) void k_narrow_phase(DW<T> w, BP<T
 // workgroup (chunk, list) = (blockIdx / NP_LISTS, blockIdx mod NP_LISTS): the populated chunks come first in the grid.  The last workgroup of
 // a list to finish clears the list's counters for the next launch (every workgroup that takes part has read the count before it reports);
 // the workgroups beyond a list's end leave without touching anything.
-template <class T, bool DENSE>
+template <class T, bool DENSE, bool HS = false>
 __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_heavy(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, avn_contact_change* __restrict__ changes,
-                                                                   uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg, uint32_t* __restrict__ has, uint32_t n_pairs) {
+                                                                   uint32_t* __restrict__ n_changes, uint32_t* __restrict__ chg, uint32_t* __restrict__ has, uint32_t n_pairs,
+                                                                   NpHookCtx<T> hk = NpHookCtx<T>()) {
     __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];   // f32: 24 KB, f64: 48 KB
     const uint32_t list = blockIdx.x % NP_LISTS, chunk = blockIdx.x / NP_LISTS;
     uint32_t* ctr = ct.np_ctr + list * NP_CTR_STRIDE;
@@ -443,6 +499,8 @@ __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_heavy(DW<T> w, BP<T
         const size_t k = (size_t)list * np_list_segment(n_pairs) + i;
         V3<T> axis{ct.np_axis[3 * k], ct.np_axis[3 * k + 1], ct.np_axis[3 * k + 2]};
         bool deferred = false;
+        if (HS) np_update_pair<T, DENSE, true, true>(w, bp, ct, p, ct.np_row[k], changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x, nullptr, nullptr, &hk);
+        else
         np_update_pair<T, DENSE, true>(w, bp, ct, p, ct.np_row[k], changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x);
     }
     __syncthreads();
@@ -451,21 +509,36 @@ __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_heavy(DW<T> w, BP<T
 // the pairs the host answered: one lane each, its raw points in the lane's LDS column like a surviving cuboid pair's
 template <class T, bool DENSE>
 __global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_host(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes,
-                                                                  uint32_t* __restrict__ chg, uint32_t* __restrict__ has, const NpHostQ<T>* __restrict__ q, const NpHostM<T>* __restrict__ m, uint32_t n) {
+                                                                  uint32_t* __restrict__ chg, uint32_t* __restrict__ has, const NpHostQ<T>* __restrict__ q, const NpHostM<T>* __restrict__ m, uint32_t n,
+                                                                  NpHookCtx<T> hk) {
     __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];
     const uint32_t i = blockIdx.x * NP_THREADS + threadIdx.x;
     if (i >= n) return;
     bool deferred = false;
     V3<T> axis = vzero<T>();
-    np_update_pair<T, DENSE, true, true>(w, bp, ct, p, q[i].contact_id, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x, nullptr, m + i);
+    np_update_pair<T, DENSE, true, true>(w, bp, ct, p, q[i].contact_id, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x, nullptr, m + i, &hk);
+}
+// collision hooks, phase 3: the pairs CollisionHooks::modify_contacts answered, one lane each -- the remainder of update_contacts from the returned record
+template <class T, bool DENSE>
+__global__ __launch_bounds__(NP_THREADS) void k_narrow_phase_hooked(DW<T> w, BP<T> bp, CT<T> ct, StepParams<T> p, avn_contact_change* __restrict__ changes, uint32_t* __restrict__ n_changes,
+                                                                    uint32_t* __restrict__ chg, uint32_t* __restrict__ has, const NpHookC<T>* __restrict__ rec, uint32_t n) {
+    __shared__ T s_pts[NP_POINT_WORDS * AVN_NP_MAX_RAW * NP_THREADS];
+    const uint32_t i = blockIdx.x * NP_THREADS + threadIdx.x;
+    if (i >= n) return;
+    bool deferred = false;
+    V3<T> axis = vzero<T>();
+    const NpHookCtx<T> hk{nullptr, nullptr, 0u, 3u, rec + i};
+    np_update_pair<T, DENSE, true, true>(w, bp, ct, p, rec[i].contact_id, changes, n_changes, chg, has, &deferred, &axis, s_pts + threadIdx.x, nullptr, nullptr, &hk);
 }
 size_t np_survivor_list_slack() { return (size_t)NP_LISTS * NP_LIGHT_THREADS; }
 size_t np_survivor_counter_bytes() { return (size_t)NP_LISTS * NP_CTR_STRIDE * sizeof(uint32_t); }
 template <class T, bool DENSE>
 static void launch_np_heavy(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg, uint32_t* has,
-                            uint32_t n_pairs, hipStream_t st) {
+                            uint32_t n_pairs, hipStream_t st, const NpHookList& hook = NpHookList()) {
     const uint32_t chunks = np_list_segment(n_pairs) / NP_THREADS;
-    hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs);
+    if (hook.count) hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE, true>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs, np_hook_ctx<T>(hook));
+    else
+    hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs, NpHookCtx<T>());
 }
 
 template <class T>
@@ -503,7 +576,7 @@ __global__ __launch_bounds__(256) void k_unpack_contacts(CT<T> ct, const uint32_
     uint4 meta = ct.meta[c];
     if (!(meta.z & AVN_CP_ROW_USED)) meta = make_uint4(0u, 0u, 0u, 0u);   // a free id: reads back as an empty pair (flags 0, no points), never as stale data
     const uint32_t np = (meta.w & 0xFFu) ? ((meta.w >> 8) & 0xFFu) : 0u;
-    if (o.flags) o.flags[i] = meta.z & ~(uint32_t)(AVN_CP_ROW_USED | AVN_CP_ROW_SLEEPING);
+    if (o.flags) o.flags[i] = meta.z & ~(uint32_t)(AVN_CP_ROW_USED | AVN_CP_ROW_SLEEPING | AVN_CP_ROW_HOOK_PENDING);
     if (o.point_count) o.point_count[i] = (uint8_t)np;
     Vec4<T> n4 = np ? ct.n(c) : make4<T>(0, 0, 0, 0), tv = np ? ct.tv(c) : make4<T>(0, 0, 0, 0);
     st3(o.normal, i, xyz<T>(n4));
@@ -587,23 +660,23 @@ template <class T> void launch_clear_contact_rows(const CT<T>& ct, const uint32_
 }
 template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, const uint32_t* active, uint32_t n_active,
                                             avn_contact_change* changes, uint32_t* n_changes, hipStream_t st, const NpHostList& hl) {
-    if (!hl.host_only) (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
+    if (!hl.host_only && hl.hook.phase != 2u) (void)hipMemsetAsync(n_changes, 0, sizeof(uint32_t), st);
     if (!n_active) return;
-    if (hl.queries) hipLaunchKernelGGL((k_narrow_phase<T, false, true>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    if (hl.any()) hipLaunchKernelGGL((k_narrow_phase<T, false, true>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only, np_hook_ctx<T>(hl.hook));
     else
     hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
     if (hl.host_only) return;   // (a retry hands no cuboid pair over: nothing for the second kernel)
-    launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st);
+    launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st, hl.hook);
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t st, bool reset_counter, const NpHostList& hl) {
     if (reset_counter) (void)hipMemsetAsync(n_remove, 0, sizeof(uint32_t), st);
     if (!n_rows) return;
-    if (hl.queries) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    if (hl.any()) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only, np_hook_ctx<T>(hl.hook));
     else
     hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
     if (hl.host_only) return;
-    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st, hl.hook);
 }
 // the rows list[0 .. n_list) followed by range_base .. range_base + n_range: same per-row work and outputs as the dense form; the
 // removal counter is NOT reset (it continues the count of the launch over the older rows)
@@ -612,21 +685,27 @@ template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp
     const uint32_t n = n_list + n_range;
     if (!n) return;
     // (range_base = 0 with an empty list would read as the plain dense form: a world's first pairs take the dense launch instead)
-    if (hl.queries) {
-        if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
-        else hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only);
+    if (hl.any()) {
+        if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only, np_hook_ctx<T>(hl.hook));
+        else hipLaunchKernelGGL((k_narrow_phase<T, true, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base, (NpHostQ<T>*)hl.queries, hl.count, hl.cap, hl.host_only, np_hook_ctx<T>(hl.hook));
     } else
     if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u);
     else hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
     if (hl.host_only) return;
-    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st, hl.hook);
 }
 // the pairs the host answered (queries sorted by contact id on the host, manifolds in the same order): dense = the closed loop's chg / has outputs, else the change list
 template <class T> void launch_narrow_phase_host(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, bool dense, avn_contact_change* changes, uint32_t* n_changes,
-                                                 uint32_t* chg, uint32_t* has, const void* queries, const void* manifolds, uint32_t n, hipStream_t st) {
+                                                 uint32_t* chg, uint32_t* has, const void* queries, const void* manifolds, uint32_t n, hipStream_t st, const NpHookList& hook) {
     if (!n) return;
-    if (dense) hipLaunchKernelGGL((k_narrow_phase_host<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_changes, chg, has, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n);
-    else hipLaunchKernelGGL((k_narrow_phase_host<T, false>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, nullptr, nullptr, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n);
+    if (dense) hipLaunchKernelGGL((k_narrow_phase_host<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_changes, chg, has, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n, np_hook_ctx<T>(hook));
+    else hipLaunchKernelGGL((k_narrow_phase_host<T, false>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, nullptr, nullptr, (const NpHostQ<T>*)queries, (const NpHostM<T>*)manifolds, n, np_hook_ctx<T>(hook));
+}
+template <class T> void launch_narrow_phase_hooked(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, bool dense, avn_contact_change* changes, uint32_t* n_changes,
+                                                   uint32_t* chg, uint32_t* has, const void* records, uint32_t n, hipStream_t st) {
+    if (!n) return;
+    if (dense) hipLaunchKernelGGL((k_narrow_phase_hooked<T, true>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, nullptr, n_changes, chg, has, (const NpHookC<T>*)records, n);
+    else hipLaunchKernelGGL((k_narrow_phase_hooked<T, false>), dim3((n + NP_THREADS - 1) / NP_THREADS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, nullptr, nullptr, (const NpHookC<T>*)records, n);
 }
 template <class T> void launch_scatter_impulses(const DW<T>& w, const CT<T>& ct, const uint32_t* handles, hipStream_t st) {
     if (w.n_manifolds) hipLaunchKernelGGL(k_scatter_impulses<T>, dim3((w.n_manifolds + 255) / 256), dim3(256), 0, st, w, ct, handles);
@@ -646,7 +725,8 @@ template <class T> void launch_pack_contacts(const CT<T>& ct, const uint32_t* id
     template void launch_narrow_phase<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, avn_contact_change*, uint32_t*, hipStream_t, const NpHostList&); \
     template void launch_narrow_phase_dense<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, bool, const NpHostList&); \
     template void launch_narrow_phase_rows<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, const uint32_t*, uint32_t, uint32_t, uint32_t, uint32_t*, uint32_t*, uint32_t*, hipStream_t, const NpHostList&); \
-    template void launch_narrow_phase_host<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool, avn_contact_change*, uint32_t*, uint32_t*, uint32_t*, const void*, const void*, uint32_t, hipStream_t); \
+    template void launch_narrow_phase_host<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool, avn_contact_change*, uint32_t*, uint32_t*, uint32_t*, const void*, const void*, uint32_t, hipStream_t, const NpHookList&); \
+    template void launch_narrow_phase_hooked<T>(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool, avn_contact_change*, uint32_t*, uint32_t*, uint32_t*, const void*, uint32_t, hipStream_t); \
     template void launch_scatter_impulses<T>(const DW<T>&, const CT<T>&, const uint32_t*, hipStream_t);                                               \
     template void launch_unpack_contacts<T>(const CT<T>&, const uint32_t*, uint32_t, const ContactsStage<T>&, hipStream_t);
 INST(float)

@@ -92,6 +92,8 @@
             HIPCHK(hipMemcpyAsync(h_pairs.data(), b_pairs.p, (size_t)total * sizeof(avn_pair), hipMemcpyDeviceToHost, bs));
             // add_edge_and_key_with (reference contact_graph.rs:521-566): the new keys join the pair set
             HIPCHK(hipStreamSynchronize(bs));
+            hk_filter_host(h_pairs);   // CollisionHooks::filter_pairs, when a callback is registered (world/hooks.hpp): rejected pairs never enter the pair set
+            total = (uint32_t)h_pairs.size();
             std::vector<uint64_t> nk(total);
             for (uint32_t i = 0; i < total; ++i) { uint32_t a = h_pairs[i].collider1, b = h_pairs[i].collider2; nk[i] = a < b ? ((uint64_t)a << 32) | b : ((uint64_t)b << 32) | a; }
             if (contact_keys_live) h_live_keys.insert(nk.begin(), nk.end());

@@ -131,9 +131,13 @@
         launch_narrow_phase<T>(dw, bp, ct, params, b_active.as<uint32_t>(), n_active, b_changes.as<avn_contact_change>(), d_count, stream, hl);
         ++launches;
         HIPCHK(hipGetLastError());
+        if (hl.any()) hs_launches.push_back(HsLaunch{0, n_active, 0, 0, 0, b_active.as<uint32_t>()});
         if (hl.queries) {   // pairs with a host-shaped collider: contact_manifolds_with_context on the host, the rest of update_contacts here (world/host_shapes.hpp)
-            hs_launches.push_back(HsLaunch{0, n_active, 0, 0, 0, b_active.as<uint32_t>()});
             avn_status sh = hs_manifolds(false, params, b_changes.as<avn_contact_change>(), d_count, nullptr, nullptr, stream);
+            if (sh != AVN_OK) return sh;
+        }
+        if (hl.hook.count) {   // pairs waiting for CollisionHooks::modify_contacts (world/hooks.hpp)
+            avn_status sh = hk_modify(false, params, b_changes.as<avn_contact_change>(), d_count, nullptr, nullptr, stream);
             if (sh != AVN_OK) return sh;
         }
         // the count and the first CHANGES_PREFIX changes come back in one round trip (pinned memory, one synchronisation);

@@ -79,10 +79,12 @@
     // before the step's first narrow-phase launch: the list is empty
     NpHostList hs_begin(hipStream_t s) {
         hs_launches.clear();
-        if (!hs_any()) return NpHostList();
-        (void)hipMemsetAsync(b_hs_cnt.p, 0, 4, s);
-        return hs_list();
+        NpHostList l;
+        if (hs_any()) { (void)hipMemsetAsync(b_hs_cnt.p, 0, 4, s); l = hs_list(); }
+        if (hk_begin(l, s) != AVN_OK) l.hook = NpHookList();   // (collision hooks, world/hooks.hpp: phase 1 rides the same launches)
+        return l;
     }
+    NpHookList hk_phase1() const { NpHookList h; if (hk_modify_active() && b_hk_cnt.p) { h.count = b_hk_cnt.as<uint32_t>(); h.phase = 1; } return h; }
     NpHostList hs_list(uint32_t host_only = 0) const {
         NpHostList l;
         if (!hs_any()) return l;
@@ -105,13 +107,7 @@
         if (n > hs_mq_cap) {   // more pairs than the list held: grow, then only those pairs again (they wrote nothing; the list is refilled from its start)
             if ((st = hs_reserve_queries(n + n / 2)) != AVN_OK) return st;
             HIPCHK(hipMemsetAsync(b_hs_cnt.p, 0, 4, s));
-            const NpHostList l = hs_list(1);
-            for (const HsLaunch& k : hs_launches) {
-                if (k.form == 0) launch_narrow_phase<T>(dw, bp, ct, np, k.list, k.a, changes, n_changes, s, l);
-                else if (k.form == 1) launch_narrow_phase_dense<T>(dw, bp, ct, np, k.a, chg, has, n_changes, s, false, l);
-                else launch_narrow_phase_rows<T>(dw, bp, ct, np, k.list, k.a, k.b, k.c, chg, has, n_changes, s, l);
-                ++launches;
-            }
+            hs_rerun(hs_list(1), dense, np, changes, n_changes, chg, has, s);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_cnt, b_hs_cnt.p, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -142,7 +138,7 @@
         }
         HIPCHK(hipMemcpyAsync(b_hs_mq.p, hq, (size_t)n * HS_MQ, hipMemcpyHostToDevice, s));
         HIPCHK(hipMemcpyAsync(b_hs_mm.p, hm, (size_t)n * HS_MM, hipMemcpyHostToDevice, s));
-        launch_narrow_phase_host<T>(dw, bp, ct, np, dense, changes, n_changes, chg, has, b_hs_mq.p, b_hs_mm.p, n, s); ++launches;
+        launch_narrow_phase_host<T>(dw, bp, ct, np, dense, changes, n_changes, chg, has, b_hs_mq.p, b_hs_mm.p, n, s, hk_phase1()); ++launches;
         HIPCHK(hipGetLastError());
         hs_stats.bytes_to_host += (uint64_t)n * HS_MQ; hs_stats.bytes_from_host += (uint64_t)n * (HS_MQ + HS_MM);
         return AVN_OK;

@@ -447,6 +447,9 @@
                 if (err != hipSuccess) { error = "pair buffer allocation failed"; return fail(AVN_ERR_OOM); }
                 launch_sweep<T>(bp, collect_n, true, sweep_scratch, b_counts.as<uint32_t>(), b_offsets.as<uint32_t>(), b_pairs.as<avn_pair>(), bs);
                 launches += 2;
+                if ((st = hk_filter_device(total, bs)) != AVN_OK) return fail(st);   // CollisionHooks::filter_pairs: the pairs the hook rejects never get an id (world/hooks.hpp)
+            }
+            if (total) {
                 const uint32_t fresh = total > pgm_n_free ? total - pgm_n_free : 0u;
                 if ((st = ensure_contact_rows(pgm_next_id + fresh)) != AVN_OK) return fail(st);   // (growing synchronises the world's stream first: the launch over the old rows is done)
                 if (np_overlap) HIPCHK(hipStreamWaitEvent(stream_bp, ev_np_old, 0));               // nothing below may touch a row while that launch runs
@@ -491,6 +494,7 @@
                 ++launches;
             }
             if (hs_hl.queries && (st = hs_manifolds(true, np_params, nullptr, pg.ctr + PGC_N_REM, pg.chg, pg.has, stream)) != AVN_OK) return fail(st);
+            if (hs_hl.hook.count && (st = hk_modify(true, np_params, nullptr, pg.ctr + PGC_N_REM, pg.chg, pg.has, stream)) != AVN_OK) return fail(st);   // CollisionHooks::modify_contacts
             if ((st = pg_batch_begin()) != AVN_OK) return fail(st);
             launch_pg_scan_classify(pg, n_rows, dw.n_bodies, b_pg_sums.as<uint32_t>(), stream, slp_on ? dw.bmeta : nullptr);   // ops numbered in ascending ContactId AND classified
             ++launches;

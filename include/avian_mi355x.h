@@ -379,14 +379,63 @@ AVN_API avn_status AVN_FN(host_shapes_set)(avn_world* w, avn_host_aabb_fn aabb, 
 typedef struct avn_host_shape_stats { uint32_t host_colliders, last_aabb_queries, last_manifold_queries, last_manifolds_with_points; uint64_t bytes_to_host, bytes_from_host; double last_callback_ms; } avn_host_shape_stats;
 AVN_API avn_status AVN_FN(host_shape_stats_get)(avn_world* w, avn_host_shape_stats* out);
 
+/* ---- collision hooks (round 6): CollisionHooks::filter_pairs / modify_contacts as callbacks ---------------------------------------------
+ *      The reference's two user hooks (collision/hooks.rs:137-231) run only for colliders that carry ActiveCollisionHooks
+ *      (AVN_COLLIDER_FILTER_PAIRS / AVN_COLLIDER_MODIFY_CONTACTS in avn_colliders::collider_flags).  Until round 6 a world with such a collider had to leave the
+ *      closed loop (HostNarrowPhase mode: every manifold re-sent every step).  With the callbacks registered it stays; per step the bus carries 12 B per
+ *      pair the filter is asked about and 232 / 392 B (f32 / f64) each way per TOUCHING pair whose contacts a hook may modify -- nothing for the rest of the world.
+ *        filter_pairs     broad_phase.rs:431-439: asked for every NEW candidate pair (AABBs intersect, layers interact, not yet in the ContactGraph, no
+ *                         joint disables it) one of whose colliders has FILTER_PAIRS, in the sweep's emission order, before the pair gets its ContactId.  A
+ *                         rejected pair does not enter the graph, so it is asked about again every step while the AABBs overlap -- as in the reference.
+ *                         should_collide[] is preset to 1.
+ *        modify_contacts  narrow_phase/system_param.rs:770-778: called for every pair flagged MODIFY_CONTACTS (either collider had the flag when the pair was
+ *                         created) that has a manifold after the speculative filter and prune_points, BEFORE match_contacts and the status change:
+ *                         the record holds the ContactPair as the hook sees it (one manifold: convex pairs) and is modified IN PLACE;
+ *                         touching = the hook's return value (0: manifolds.clear(), the pair stops / does not start touching).  Everything after the hook --
+ *                         match_contacts against the previous step's points (warm-start impulses never leave HBM), manifold_count_change, the status
+ *                         change -- runs on the device from the returned record.  The callback gets its records in ascending contact_id.
+ *      NULL for either hook = the trait's default (true / unmodified).  The callbacks run on the thread that calls avn_step / avn_run_system, between two
+ *      stream synchronisations.  Works in the device closed loop, in the host-bookkeeping loop and in AVN_SYS_BROAD_PHASE / AVN_SYS_NARROW_PHASE
+ *      (with a filter registered, avn_pairs_get returns the pairs that passed; AVN_PAIR_NEEDS_CUSTOM_FILTER stays set on them as information). */
+typedef struct avn_hook_pair { uint32_t index /* place in the step's emission order */, collider1, collider2 /* Entity::index() */; } avn_hook_pair;
+typedef struct avn_hook_contact_f32 {
+    uint32_t contact_id, collider1, collider2; /* Entity::index() */
+    uint32_t body1, body2;      /* body-table indices (ContactPair::body1 / body2) */
+    uint32_t flags;             /* AVN_CP_* as update_contacts has set them when the hook runs: STATIC1/2, GENERATE_CONSTRAINTS current, TOUCHING still the previous step's */
+    uint32_t touching;          /* in: 1.  out: the hook's return value */
+    uint32_t manifold_count;    /* in: 1.  out: 0 if the hook emptied ContactPair::manifolds, else 1 */
+    uint32_t point_count;       /* in: 1..4.  out: 0..4 (points [0, point_count) are kept, in this order) */
+    uint32_t reserved;
+    float normal[3];            /* ContactManifold::normal */
+    float friction, restitution;
+    float tangent_velocity[3];  /* in: 0 (system_param.rs:722-729) */
+    float anchor1[12], anchor2[12];   /* [3 * 4] relative to the bodies' centres of mass, world orientation */
+    float penetration[4], normal_speed[4];
+    uint32_t feature_id1[4], feature_id2[4];
+} avn_hook_contact_f32;
+typedef struct avn_hook_contact_f64 {
+    uint32_t contact_id, collider1, collider2, body1, body2, flags, touching, manifold_count, point_count, reserved;
+    double normal[3];
+    double friction, restitution;
+    double tangent_velocity[3];
+    double anchor1[12], anchor2[12];
+    double penetration[4], normal_speed[4];
+    uint32_t feature_id1[4], feature_id2[4];
+} avn_hook_contact_f64;
+typedef void (*avn_filter_pairs_fn)(void* user, uint32_t n, const avn_hook_pair* pairs /* emission order */, uint8_t* should_collide /* [n], preset to 1 */);
+typedef void (*avn_modify_contacts_fn)(void* user, uint32_t scalar_bits, uint32_t n, void* contacts /* avn_hook_contact_fNN[n], ascending contact_id, in place */);
+AVN_API avn_status AVN_FN(collision_hooks_set)(avn_world* w, avn_filter_pairs_fn filter, avn_modify_contacts_fn modify, void* user);
+typedef struct avn_collision_hook_stats { uint32_t last_filter_queries, last_filter_rejected, last_modify_queries, last_modify_rejected; uint64_t bytes_to_host, bytes_from_host; double last_callback_ms; } avn_collision_hook_stats;
+AVN_API avn_status AVN_FN(collision_hook_stats_get)(avn_world* w, avn_collision_hook_stats* out);
+
 /* ---- narrow phase, part 2: the ContactGraph side kept on device ----------------------------
  *      NarrowPhase::update_contacts (collision/narrow_phase/system_param.rs:437-830) runs as AVN_SYS_NARROW_PHASE over a
  *      device-resident table of contact pairs indexed by the reference's ContactId (contact_graph.rs, id_pool.rs); the
  *      manifolds it produces stay in HBM and feed prepare_contact_constraints through a colour-major list of handles
  *      (= GraphColor::manifold_handles, constraint_graph.rs:66-80), so that per step only STATUS CHANGES cross the bus.
  *      The host keeps what the reference keeps in host structures: ContactId allocation, the ConstraintGraph, events.
- *      Convex pairs only (Ball / Cuboid): one manifold per pair, manifold index 0.  CollisionHooks::modify_contacts is not
- *      called (the library cannot call back): pairs flagged AVN_PAIR_MODIFY_CONTACTS are processed unmodified. */
+ *      Convex pairs only (Ball / Cuboid): one manifold per pair, manifold index 0.  CollisionHooks::modify_contacts is called through
+ *      avn_collision_hooks_set's callback when one is registered; without one, pairs flagged AVN_PAIR_MODIFY_CONTACTS are processed unmodified. */
 /* ContactPairFlags (contact_types/mod.rs) as stored per table row; bits 8.. are this step's status outputs */
 enum { AVN_CP_TOUCHING = 1, AVN_CP_GENERATE_CONSTRAINTS = 2, AVN_CP_STATIC1 = 4, AVN_CP_STATIC2 = 8, AVN_CP_MODIFY_CONTACTS = 16,
        AVN_CP_CONTACT_EVENTS = 32,

@@ -293,6 +293,8 @@ struct WorldBase {
     virtual avn_status sleep_reset(const uint32_t*, size_t) = 0;
     virtual avn_status host_shapes_set(avn_host_aabb_fn, avn_host_manifolds_fn, void*) = 0;
     virtual avn_status host_shape_stats_get(avn_host_shape_stats*) = 0;
+    virtual avn_status collision_hooks_set(avn_filter_pairs_fn, avn_modify_contacts_fn, void*) = 0;
+    virtual avn_status collision_hook_stats_get(avn_collision_hook_stats*) = 0;
     virtual avn_status halo_plan_upload(const avn_halo_plan*) = 0;
     virtual avn_status halo_overflow_levels_upload(uint32_t, const uint32_t*, size_t) = 0;
     virtual avn_status halo_joint_slot_set(uint32_t, uint32_t) = 0;
@@ -367,6 +369,7 @@ template <class S> struct World : WorldBase {
         int32_t manifold_count_change = 0;
         uint32_t n_manifolds = 0;                // 0 | 1
         V3<S> normal{0, 0, 0};
+        V3<S> tangent_velocity{0, 0, 0};         // ContactManifold::tangent_velocity: zero unless CollisionHooks::modify_contacts set it
         S friction = 0, restitution = 0;
         int point_count = 0;
         CtPoint pts[AVN_MAX_MANIFOLD_POINTS];
@@ -1730,8 +1733,11 @@ template <class S> struct World : WorldBase {
                         r.point_count = nk;
                     }
                     r.n_manifolds = 1;
+                    r.tangent_velocity = vzero<S>();   // system_param.rs:722-729
                 }
                 bool touching = r.n_manifolds != 0;
+                // CollisionHooks::modify_contacts (system_param.rs:770-778; header: "collision hooks")
+                if (touching && (r.flags & AVN_CP_MODIFY_CONTACTS) && hk_modify_fn) touching = hook_modify_contacts(id, r, c1, c2);
                 r.flags = touching ? (r.flags | AVN_CP_TOUCHING) : (r.flags & ~(uint32_t)AVN_CP_TOUCHING);
                 if (r.n_manifolds <= 4 && cfg.match_contacts && touching && old.n_manifolds) {
                     // ContactManifold::match_contacts (contact_types/mod.rs:425-475)
@@ -1766,6 +1772,7 @@ template <class S> struct World : WorldBase {
             std::vector<std::vector<avn_contact_change>> per_chunk(pool.threads == 1 || n < 64 ? 1 : chunks);
             // (pairs with a host-shaped collider call back into the host: on the calling thread, in ascending contact id, after the pool's share)
             auto host_pair = [&](uint32_t id) {
+                if (hk_modify_fn && (contact_rows[id].flags & AVN_CP_MODIFY_CONTACTS)) return true;   // (a pair whose hook may call back: with the host pairs, on this thread)
                 if (n_host_colliders == 0) return false;
                 const CtRow& r = contact_rows[id];
                 auto i1 = collider_slot.find(r.collider1), i2 = collider_slot.find(r.collider2);
@@ -1773,7 +1780,8 @@ template <class S> struct World : WorldBase {
             };
             if (per_chunk.size() == 1) { for (uint32_t id : active_pairs) if (!host_pair(id)) update_pair(id, per_chunk[0]); }
             else pool.par_for_each(n, 64, [&](size_t b0, size_t b1) { std::vector<avn_contact_change>& out = per_chunk[b0 / chunk]; for (size_t i = b0; i < b1; ++i) if (!host_pair(active_pairs[i])) update_pair(active_pairs[i], out); });
-            if (n_host_colliders) {
+            hk_stats.last_modify_queries = hk_stats.last_modify_rejected = 0;
+            if (n_host_colliders || hk_modify_fn) {
                 std::vector<uint32_t> hp;
                 for (uint32_t id : active_pairs) if (host_pair(id)) hp.push_back(id);
                 std::sort(hp.begin(), hp.end());
@@ -1786,6 +1794,47 @@ template <class S> struct World : WorldBase {
         // the status processing of system_param.rs:141-389 clears these once handled (host side); here they are per-step outputs
         for (const avn_contact_change& c : contact_changes)
             contact_rows[c.contact_id].flags &= ~(uint32_t)(AVN_CP_STARTED_TOUCHING | AVN_CP_STOPPED_TOUCHING | AVN_CP_STARTED_GENERATING_CONSTRAINTS);
+    }
+    // ---- collision hooks (header: "collision hooks"): CollisionHooks::filter_pairs / modify_contacts through the callbacks, one record per call ----
+    avn_filter_pairs_fn hk_filter_fn = nullptr; avn_modify_contacts_fn hk_modify_fn = nullptr; void* hk_user = nullptr;
+    avn_collision_hook_stats hk_stats{};
+    template <class Q> struct HookC { uint32_t contact_id, collider1, collider2, body1, body2, flags, touching, manifold_count, point_count, reserved;
+                                      Q normal[3], friction, restitution, tangent_velocity[3], anchor1[12], anchor2[12], penetration[4], normal_speed[4]; uint32_t fid1[4], fid2[4]; };
+    static_assert(sizeof(HookC<float>) == sizeof(avn_hook_contact_f32) && sizeof(HookC<double>) == sizeof(avn_hook_contact_f64), "hook record layout");
+    avn_status collision_hooks_set(avn_filter_pairs_fn f, avn_modify_contacts_fn m, void* user) override { hk_filter_fn = f; hk_modify_fn = m; hk_user = user; return AVN_OK; }
+    avn_status collision_hook_stats_get(avn_collision_hook_stats* o) override { if (!o) return AVN_ERR_BAD_ARG; *o = hk_stats; return AVN_OK; }
+    // the pair as the hook sees it -> the callback -> the pair as the hook left it; returns the hook's `touching`
+    bool hook_modify_contacts(uint32_t id, CtRow& r, const Collider<S>& c1, const Collider<S>& c2) {
+        HookC<S> h;
+        std::memset(&h, 0, sizeof h);
+        h.contact_id = id; h.collider1 = c1.entity; h.collider2 = c2.entity; h.body1 = (uint32_t)c1.body; h.body2 = (uint32_t)c2.body;
+        h.flags = r.flags & 0xFFFFu; h.touching = 1u; h.manifold_count = 1u; h.point_count = (uint32_t)r.point_count;
+        h.normal[0] = r.normal.x; h.normal[1] = r.normal.y; h.normal[2] = r.normal.z; h.friction = r.friction; h.restitution = r.restitution;
+        for (int k = 0; k < r.point_count; ++k) {
+            const CtPoint& pt = r.pts[k];
+            h.anchor1[3 * k] = pt.anchor1.x; h.anchor1[3 * k + 1] = pt.anchor1.y; h.anchor1[3 * k + 2] = pt.anchor1.z;
+            h.anchor2[3 * k] = pt.anchor2.x; h.anchor2[3 * k + 1] = pt.anchor2.y; h.anchor2[3 * k + 2] = pt.anchor2.z;
+            h.penetration[k] = pt.penetration; h.normal_speed[k] = pt.normal_speed; h.fid1[k] = pt.feature_id1; h.fid2[k] = pt.feature_id2;
+        }
+        hk_modify_fn(hk_user, (uint32_t)(8 * sizeof(S)), 1u, &h);
+        ++hk_stats.last_modify_queries; hk_stats.bytes_to_host += sizeof h; hk_stats.bytes_from_host += sizeof h;
+        const bool touching = h.touching != 0u;
+        hk_stats.last_modify_rejected += !touching;
+        r.n_manifolds = touching && h.manifold_count ? 1u : 0u;   // !touching: manifolds.clear()
+        r.point_count = r.n_manifolds ? (int)std::min<uint32_t>(h.point_count, AVN_MAX_MANIFOLD_POINTS) : 0;
+        if (r.n_manifolds) {
+            r.normal = {h.normal[0], h.normal[1], h.normal[2]}; r.friction = h.friction; r.restitution = h.restitution;
+            r.tangent_velocity = {h.tangent_velocity[0], h.tangent_velocity[1], h.tangent_velocity[2]};
+            for (int k = 0; k < r.point_count; ++k) {
+                CtPoint pt;
+                pt.anchor1 = {h.anchor1[3 * k], h.anchor1[3 * k + 1], h.anchor1[3 * k + 2]}; pt.anchor2 = {h.anchor2[3 * k], h.anchor2[3 * k + 1], h.anchor2[3 * k + 2]};
+                pt.penetration = h.penetration[k]; pt.normal_speed = h.normal_speed[k];
+                pt.warm_start_normal_impulse = 0; pt.normal_impulse = 0; pt.warm_start_tangent_impulse = {0, 0};   // (ContactPoint::new's zeros: the record does not carry impulses)
+                pt.feature_id1 = h.fid1[k]; pt.feature_id2 = h.fid2[k];
+                r.pts[k] = pt;
+            }
+        }
+        return touching;
     }
     // ---- host shapes (header: "host shapes"): the two AnyCollider methods through the callbacks, one query per call ----
     avn_host_aabb_fn hs_aabb_fn = nullptr; avn_host_manifolds_fn hs_manifolds_fn = nullptr; void* hs_user = nullptr;
@@ -1830,7 +1879,7 @@ template <class S> struct World : WorldBase {
             ContactManifold<S>& m = manifolds[i];
             m.body1 = colliders[collider_slot.at(r.collider1)].body;
             m.body2 = colliders[collider_slot.at(r.collider2)].body;
-            m.normal = r.normal; m.tangent_velocity = vzero<S>();
+            m.normal = r.normal; m.tangent_velocity = r.tangent_velocity;
             m.friction = r.friction; m.restitution = r.restitution;
             m.point_count = (uint8_t)(r.n_manifolds ? r.point_count : 0);
             m.flags = (r.flags & AVN_CP_GENERATE_CONSTRAINTS) ? AVN_MANIFOLD_GENERATES_CONSTRAINTS : 0;
@@ -1958,6 +2007,7 @@ template <class S> struct World : WorldBase {
                 });
         }
         pairs.clear();
+        hk_stats.last_filter_queries = hk_stats.last_filter_rejected = 0;
         for (size_t i = 0; i < intervals.size(); ++i) {
             const Collider<S>& c1 = colliders[intervals[i].collider];
             uint8_t flags1 = intervals[i].flags;
@@ -1973,6 +2023,13 @@ template <class S> struct World : WorldBase {
                 if (pair_set.count(key)) continue;
                 if (collision_disabled_bodies.count(pair_key((uint32_t)c1.body, (uint32_t)c2.body))) continue;
                 uint8_t u = flags1 | flags2;
+                if ((u & AVN_AABB_CUSTOM_FILTER) && hk_filter_fn) {   // CollisionHooks::filter_pairs, broad_phase.rs:431-439 (header: "collision hooks")
+                    const avn_hook_pair q{(uint32_t)pairs.size() + hk_stats.last_filter_rejected, c1.entity, c2.entity};
+                    uint8_t should_collide = 1;
+                    hk_filter_fn(hk_user, 1u, &q, &should_collide);
+                    ++hk_stats.last_filter_queries; hk_stats.bytes_to_host += sizeof q; hk_stats.bytes_from_host += 1;
+                    if (!should_collide) { ++hk_stats.last_filter_rejected; continue; }
+                }
                 avn_pair p;
                 p.collider1 = c1.entity; p.collider2 = c2.entity; p.body1 = c1.body; p.body2 = c2.body;
                 p.flags = 0; p.reserved = 0;
