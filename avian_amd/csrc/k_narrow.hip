@@ -333,6 +333,8 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
                 ct.meta[c].z = meta.z | AVN_CP_ROW_HOOK_PENDING;
                 return;
             }
+            // (the bit goes here: a row whose id was recycled this step is in the range of the launch over the old rows AND in the list of the new ones)
+            ct.meta[c].z = meta.z;
             const uint32_t slot = atomicAdd(hk->count, 1u);
             if (slot < hk->cap) {
                 NpHookC<T>& r = hk->rec[slot];

@@ -17,7 +17,7 @@
         }
         HIPCHK(hipStreamSynchronize(stream));
         if (C) HIPCHK(hipMemcpy(ct.col_mat, mats.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
-        if (use_handles) any_restitution = materials_restitution;
+        if (use_handles) any_restitution = materials_restitution || hk_restitution;
         return AVN_OK;
     }
     avn_status ensure_contact_rows(uint32_t rows) {
@@ -240,7 +240,7 @@
         if (M) HIPCHK(hipMemcpy(b_handles.p, ids, (size_t)M * 4, hipMemcpyHostToDevice));
         if (!use_handles) graph_valid = false;
         use_handles = true;
-        any_restitution = materials_restitution;
+        any_restitution = materials_restitution || hk_restitution;
         incidence_dirty = true;
         return AVN_OK;
     }

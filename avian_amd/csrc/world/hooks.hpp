@@ -6,6 +6,7 @@
     avn_filter_pairs_fn hk_filter_fn = nullptr;
     avn_modify_contacts_fn hk_modify_fn = nullptr;
     void* hk_user = nullptr;
+    bool hk_restitution = false;   // a hook has left a restitution != 0 in a record: the restitution pass runs from then on whatever the materials say (sticky)
     bool hk_any_filter = false, hk_any_modify = false;   // a collider has carried the flag since the world was created (rows keep MODIFY_CONTACTS from their creation: sticky)
     DevBuf b_hk_cnt, b_hk_rec, b_hk_fq, b_hk_rej, b_pairs_alt;
     Pinned pin_hk;
@@ -162,7 +163,10 @@
             const uint32_t* r = (const uint32_t*)(rec + (size_t)i * HK_REC);   // (contact_id, collider1, collider2, body1, body2, flags, touching, manifold_count, point_count)
             if (r[8] > (uint32_t)AVN_MAX_MANIFOLD_POINTS) { error = "collision hooks: modify_contacts left more than 4 points in a manifold"; return AVN_ERR_BAD_ARG; }
             hk_stats.last_modify_rejected += r[6] == 0u;
+            const T* rs = (const T*)(rec + (size_t)i * HK_REC + 10 * sizeof(uint32_t));   // (normal[3], friction, restitution, ...)
+            if (r[6] && !(rs[4] == T(0))) hk_restitution = true;
         }
+        if (hk_restitution) any_restitution = true;
         HIPCHK(hipMemcpyAsync(b_hk_rec.p, rec, (size_t)n * HK_REC, hipMemcpyHostToDevice, s));
         launch_narrow_phase_hooked<T>(dw, bp, ct, np, dense, changes, n_changes, chg, has, b_hk_rec.p, n, s); ++launches;
         HIPCHK(hipGetLastError());

@@ -108,7 +108,7 @@
         dw.n_manifolds = 0;
         set_color_offsets(zero);
         HIPCHK(hipMemcpy(dw.color_offsets, zero, sizeof zero, hipMemcpyHostToDevice));
-        use_handles = true; any_restitution = materials_restitution;
+        use_handles = true; any_restitution = materials_restitution || hk_restitution;
         incidence_dirty = true; graph_valid = false;
         if (pin_ctr.ensure(4096) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
         return AVN_OK;

@@ -5,14 +5,14 @@
 //!     PhysicsPlugins::default()
 //!         .build()
 //!         .disable::<BroadPhasePlugin>()      // src/collision/broad_phase.rs:33-170
-//!         // NarrowPhasePlugin stays: with the default `Mi355xMode::Auto` the step runs closed-loop on the device whenever no collider carries
-//!         // hooks (Ball / Cuboid in kernels, other shapes through host_shapes.rs) (Avian's narrow phase then walks an empty pair list) and falls back to Avian's own narrow phase
-//!         // otherwise; disable it only with an explicit `Mi355xMode::ClosedLoop`
+//!         // NarrowPhasePlugin stays: with the default `Mi355xMode::Auto` the step runs closed-loop on the device (Ball / Cuboid in kernels, other shapes through
+//!         // host_shapes.rs, `CollisionHooks` through hooks.rs; Avian's narrow phase then walks an empty pair list) and falls back to Avian's own narrow phase only
+//!         // for colliders that sit on no known rigid body; disable it only with an explicit `Mi355xMode::ClosedLoop`
 //!         .disable::<IntegratorPlugin>()      // src/dynamics/integrator/mod.rs:45-88
 //!         .disable::<SolverPlugin>()          // src/dynamics/solver/plugin.rs:88-151
 //!         .disable::<XpbdSolverPlugin>()      // src/dynamics/solver/xpbd/plugin.rs:21-110: joints.rs uploads all five joint types with JointDamping /
 //!                                             // JointCollisionDisabled and writes JointForces back
-//!         .add(Mi355xPhysicsPlugin::default()),
+//!         .add(Mi355xPhysicsPlugin::<()>::default()),   // or ::<MyHooks>: the same `CollisionHooks` parameter as `PhysicsPlugins::with_collision_hooks::<MyHooks>()`
 //! );
 //! ```
 //! `SolverSchedulePlugin` stays enabled: it owns the ordering of `SolverSystems` and the substep runner
@@ -22,7 +22,8 @@
 //! Layers: [`world::Mi355xWorld`] is the safe owner of the `avn_world*`; [`staging::Staging`] turns ECS queries into the
 //! Structure-of-Arrays the C ABI borrows for the duration of a call; [`plugins`] holds the systems of the rigid-body path, [`joints`] the
 //! XpbdSolverPlugin replacement, [`closed_loop`] what the device closed loop owes the ECS (collision events, `CollidingEntities`, `Sleeping`),
-//! [`host_shapes`] the two `AnyCollider` methods of every collider that is not a Ball / Cuboid, called back by the library (`avn_host_shapes_set`).
+//! [`host_shapes`] the two `AnyCollider` methods of every collider that is not a Ball / Cuboid, called back by the library (`avn_host_shapes_set`),
+//! [`hooks`] the application's `CollisionHooks` (`filter_pairs`, `modify_contacts`), called back for the pairs of `ActiveCollisionHooks` colliders (`avn_collision_hooks_set`).
 //!
 //! Every component the recipe above takes away from Avian has a system here:
 //!
@@ -36,6 +37,7 @@
 //! | (closed loop only) island sleeping | `Sleeping`, `SleepTimer`, wake on change | `closed_loop::gpu_closed_loop_sleeping`, `gpu_closed_loop_wake_on_changed` (the library's island manager decides: `avn_sleeping_enable`) |
 
 pub mod closed_loop;
+pub mod hooks;
 pub mod host_shapes;
 pub mod joints;
 pub mod plugins;

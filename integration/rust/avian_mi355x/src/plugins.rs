@@ -17,6 +17,7 @@ use avian3d::{
     prelude::*,
 };
 use avian_mi355x_sys as ffi;
+use bevy::ecs::system::{StaticSystemParam, SystemParamItem};
 use bevy::prelude::*;
 use core::time::Duration;
 
@@ -24,7 +25,7 @@ use core::time::Duration;
 #[derive(Clone, Copy, Default, PartialEq, Eq)]
 pub enum Mi355xMode {
     /// The default: `ClosedLoop` whenever the scene allows it -- every collider on a rigid body the staging knows (Ball / Cuboid in device kernels, every other
-    /// shape through the host-shape callbacks of host_shapes.rs), no `ActiveCollisionHooks` -- and `HostNarrowPhase` otherwise, decided per step (`Mi355xSettings::effective_mode`).  The host-manifold
+    /// shape through the host-shape callbacks of host_shapes.rs; `ActiveCollisionHooks` colliders through the hook callbacks of hooks.rs) -- and `HostNarrowPhase` otherwise, decided per step (`Mi355xSettings::effective_mode`).  The host-manifold
     /// flow moves ~160 MB over PCIe per cfg2 step (5 ms) where the closed loop moves three counter blocks: it must not be what a user
     /// gets without asking.
     #[default]
@@ -37,16 +38,20 @@ pub enum Mi355xMode {
     /// the bus.  Collision events / `CollidingEntities` are rebuilt from `avn_pipeline_new_pair_ids_get` + `avn_contact_changes_get` by
     /// `closed_loop::gpu_closed_loop_events`; sleeping is the library's own island manager (`avn_sleeping_enable`), mirrored into `Sleeping` /
     /// `SleepTimer` by `closed_loop::gpu_closed_loop_sleeping`.
-    /// `CollisionHooks` (src/collision/hooks.rs:147-186) cannot run on the device: while any uploaded collider carries
-    /// `ActiveCollisionHooks` the plugin runs the step in `HostNarrowPhase` mode instead (`effective_mode`), where Avian's own narrow phase
-    /// calls `filter_pairs` / `modify_contacts` as always.
+    /// `CollisionHooks` (src/collision/hooks.rs:147-186) are called back from inside `avn_step` (hooks.rs, `avn_collision_hooks_set`): `filter_pairs` before a
+    /// candidate pair gets its `ContactId`, `modify_contacts` between `prune_points` and `match_contacts` -- only the pairs of `ActiveCollisionHooks` colliders
+    /// cross the bus (until round 6 one such collider sent the whole world to `HostNarrowPhase` mode).
     ClosedLoop,
 }
 
-#[derive(Default)]
-pub struct Mi355xPhysicsPlugin {
+/// `H`: the application's `CollisionHooks` system parameter, exactly as for `PhysicsPlugins::with_collision_hooks::<H>()` (`()` = no hooks).
+pub struct Mi355xPhysicsPlugin<H: CollisionHooks + 'static = ()> {
     pub mode: Mi355xMode,
     pub device: i32,
+    _hooks: core::marker::PhantomData<H>,
+}
+impl<H: CollisionHooks + 'static> Default for Mi355xPhysicsPlugin<H> {
+    fn default() -> Self { Self { mode: Mi355xMode::default(), device: 0, _hooks: core::marker::PhantomData } }
 }
 
 #[derive(Resource, Default)]
@@ -54,15 +59,14 @@ pub struct Mi355xStaging(pub Staging);
 #[derive(Resource)]
 struct Mi355xSettings { mode: Mi355xMode, warned_hooks: bool }
 impl Mi355xSettings {
-    /// ClosedLoop only while no collider needs a host hook (hooks.rs:162-186: MODIFY_CONTACTS pairs must pass through `modify_contacts`,
-    /// FILTER_PAIRS pairs through `filter_pairs`); the switch is per step -- leaving / entering the device loop is avn_pipeline_enable(0 / 1),
+    /// ClosedLoop unless a collider sits on something the staging does not know as a rigid body (colliders with `ActiveCollisionHooks` stay: their pairs go through
+    /// `filter_pairs` / `modify_contacts` by callback, hooks.rs); the switch is per step -- leaving / entering the device loop is avn_pipeline_enable(0 / 1),
     /// which drops / rebuilds the device contact rows (one step without warm starting, like any ContactGraph rebuild).
     fn effective_mode(&mut self, st: &Staging) -> Mi355xMode {
         if self.mode == Mi355xMode::HostNarrowPhase { return Mi355xMode::HostNarrowPhase; }
-        if st.colliders_with_hooks != 0 || st.colliders_unsupported != 0 {
+        if st.colliders_unsupported != 0 {
             if !self.warned_hooks && self.mode == Mi355xMode::ClosedLoop {
-                bevy::log::warn!("avian_mi355x: {} collider(s) carry ActiveCollisionHooks, {} are not on a known rigid body: running in HostNarrowPhase mode",
-                                 st.colliders_with_hooks, st.colliders_unsupported);
+                bevy::log::warn!("avian_mi355x: {} collider(s) are not on a known rigid body: running in HostNarrowPhase mode", st.colliders_unsupported);
                 self.warned_hooks = true;
             }
             return Mi355xMode::HostNarrowPhase;
@@ -71,7 +75,10 @@ impl Mi355xSettings {
     }
 }
 
-impl Plugin for Mi355xPhysicsPlugin {
+impl<H: CollisionHooks + 'static> Plugin for Mi355xPhysicsPlugin<H>
+where
+    for<'w, 's> SystemParamItem<'w, 's, H>: CollisionHooks,
+{
     fn build(&self, app: &mut App) {
         let mut config = default_config();
         config.device = self.device;
@@ -94,7 +101,7 @@ impl Plugin for Mi355xPhysicsPlugin {
                 // XpbdSolverPlugin's PrepareJoints: the step's joint set of all five types, with JointDamping and JointCollisionDisabled
                 crate::joints::gpu_upload_joints.in_set(SolverSystems::PrepareJoints),
                 gpu_upload_constraints.in_set(SolverSystems::PrepareContactConstraints),   // (HostNarrowPhase steps only: checked inside)
-                gpu_solver.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER)
+                gpu_solver::<H>.in_set(SolverSystems::Substep),   // prepare + ALL substeps + restitution, device resident (AVN_SYS_SOLVER); in the closed loop the user's CollisionHooks are called back from inside it
                 gpu_download.in_set(SolverSystems::StoreContactImpulses),
                 crate::joints::gpu_download_joints.in_set(SolverSystems::Writeback),   // writeback_joint_forces::<T> of all five types (xpbd/plugin.rs:242-260)
                 // closed loop only (each returns at once otherwise): the status loop's events, then the library's sleeping verdict into the ECS
@@ -144,7 +151,7 @@ fn sync_config(
 fn gpu_upload_bodies(
     mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
     increments: Query<&VelocityIntegrationData>,
-    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
+    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>)>,
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
     js: Res<crate::joints::JointStaging>,
     live_joints: Query<(), (Or<(With<FixedJoint>, With<RevoluteJoint>, With<SphericalJoint>, With<PrismaticJoint>, With<DistanceJoint>)>, Without<JointDisabled>)>,
@@ -222,10 +229,23 @@ fn gpu_upload_constraints(mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStagi
 /// SolverSystems::PrepareSolverBodies .. Restitution in one call.  `SolverSchedulePlugin`'s own runner (src/dynamics/solver/schedule.rs:194-213)
 /// still loops over the (now nearly empty) `SubstepSchedule`; user systems added there see host `SolverBody` state only if the application
 /// opts into per-substep round trips (caveat).
-fn gpu_solver(mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>) {
+fn gpu_solver<H: CollisionHooks + 'static>(
+    mut w: ResMut<Mi355xWorld>, st: Res<Mi355xStaging>, mut settings: ResMut<Mi355xSettings>, hooks: StaticSystemParam<H>, mut commands: Commands,
+) where
+    for<'w, 's> SystemParamItem<'w, 's, H>: CollisionHooks,
+{
     match settings.effective_mode(&st.0) {
-        Mi355xMode::HostNarrowPhase => w.run_system(ffi::AVN_SYS_SOLVER),
-        Mi355xMode::ClosedLoop | Mi355xMode::Auto => w.step(),   // (effective_mode never returns Auto) avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
+        Mi355xMode::HostNarrowPhase => w.run_system(ffi::AVN_SYS_SOLVER),   // (Avian's own broad / narrow phase called the hooks)
+        Mi355xMode::ClosedLoop | Mi355xMode::Auto => {   // (effective_mode never returns Auto) avn_pipeline_enable(1) was called when the mode was selected: the whole PhysicsSchedule pass of the path
+            if st.0.colliders_with_hooks == 0 { w.step(); return; }
+            // CollisionHooks::filter_pairs / modify_contacts are called back from inside avn_step for the pairs of ActiveCollisionHooks colliders (hooks.rs)
+            let raw = w.raw();
+            let hooks = hooks.into_inner();
+            let mut ctx = crate::hooks::HookContext::<H> { hooks: &hooks, commands: &mut commands, staging: &st.0 };
+            let s = ctx.register(raw); w.check(s);
+            w.step();
+            let s = crate::hooks::HookContext::<H>::unregister(raw); w.check(s);
+        }
     }
 }
 

@@ -99,7 +99,7 @@ impl Staging {
     /// callbacks of host_shapes.rs (its `Collider` goes into `host_shapes`): it stays in the closed loop.  Only a collider that is not on a known rigid body is unsupported.
     pub fn fill_colliders<'a>(
         &mut self,
-        colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Has<ActiveCollisionHooks>)>,
+        colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&'a ActiveCollisionHooks>)>,
         host_shapes: &mut crate::host_shapes::HostShapeTable,
     ) {
         host_shapes.colliders.clear();
@@ -115,12 +115,15 @@ impl Staging {
             let Some(&body) = self.body_index.get(&of.body) else { self.colliders_unsupported += 1; continue };
             if kind == ffi::AVN_SHAPE_HOST { host_shapes.colliders.insert(e.index(), collider.clone()); }
             self.collider_slot.insert(e.index(), self.collider_entities.len());
-            if hooks { self.colliders_with_hooks += 1; }
+            // ActiveCollisionHooks (src/collision/hooks.rs:213-231): which of the two hooks this collider asks for (broad_phase.rs:266-273)
+            let filter = hooks.is_some_and(|h| h.contains(ActiveCollisionHooks::FILTER_PAIRS));
+            let modify = hooks.is_some_and(|h| h.contains(ActiveCollisionHooks::MODIFY_CONTACTS));
+            if filter || modify { self.colliders_with_hooks += 1; }
             self.collider_entities.push(e);
             self.c_entity_index.push(e.index()); self.c_body.push(body); self.c_shape.push(kind as u8); push3(&mut self.c_half_extents, he);
             self.c_memberships.push(layers.memberships.0); self.c_filters.push(layers.filters.0);
             self.c_flags.push((if sensor { ffi::AVN_COLLIDER_SENSOR } else { 0 } | if events { ffi::AVN_COLLIDER_EVENTS } else { 0 }
-                               | if hooks { ffi::AVN_COLLIDER_FILTER_PAIRS | ffi::AVN_COLLIDER_MODIFY_CONTACTS } else { 0 }) as u8);
+                               | if filter { ffi::AVN_COLLIDER_FILTER_PAIRS } else { 0 } | if modify { ffi::AVN_COLLIDER_MODIFY_CONTACTS } else { 0 }) as u8);
             self.c_margin.push(margin.map_or(0.0, |m| m.0)); self.c_speculative.push(spec.map_or(-1.0, |s| s.0));   // < 0: absent (NarrowPhaseConfig default applies)
         }
     }

@@ -70,7 +70,7 @@ def test_every_promised_system_exists_and_is_registered():
     assert {"gpu_upload_joints", "gpu_download_joints", "gpu_closed_loop_events", "gpu_closed_loop_sleeping", "gpu_solver", "gpu_broad_phase"} <= promised
     build = src["plugins.rs"][src["plugins.rs"].index("fn build"):src["plugins.rs"].index("fn sync_config")]
     for system in promised:
-        assert re.search(rf"fn {system}\(", everything), f"lib.rs promises `{system}`: no such function in the crate"
+        assert re.search(rf"fn {system}(<[^(]*>)?\(", everything), f"lib.rs promises `{system}`: no such function in the crate"
         assert system in build, f"`{system}` exists but Mi355xPhysicsPlugin::build never adds it to the schedule"
     # the recipe disables XpbdSolverPlugin: all five joint types, their damping, their collision switch and their forces must be staged
     joints = src["joints.rs"]
@@ -82,7 +82,7 @@ def test_every_promised_system_exists_and_is_registered():
     # nothing in the crate may name a function that does not exist (round 4: plugins.rs promised a gpu_closed_loop_events that was never written)
     for name, s in src.items():
         for mentioned in set(re.findall(r"`(?:\w+::)*(gpu_\w+)`", s)):
-            assert re.search(rf"fn {mentioned}\(", everything), f"{name} mentions `{mentioned}`, which does not exist"
+            assert re.search(rf"fn {mentioned}(<[^(]*>)?\(", everything), f"{name} mentions `{mentioned}`, which does not exist"
 
 
 def test_host_shape_trampolines_use_the_reference_names_and_the_header_records():
@@ -105,3 +105,40 @@ def test_host_shape_trampolines_use_the_reference_names_and_the_header_records()
         assert re.search(rf"pub {field}:", contact_types) and f"p.{field}" in hs, field
     assert re.search(r"pub normal: Vector", contact_types) and "m.normal" in hs and "m.points" in hs
     assert re.search(r"pub min: Vector", collider_mod) and "aabb.min" in hs and "aabb.max" in hs
+
+
+def test_hook_trampolines_use_the_reference_names_and_the_header_records():
+    """hooks.rs answers avn_filter_pairs_fn / avn_modify_contacts_fn with the application's CollisionHooks: the trait methods, the ContactPair / ContactManifold /
+    ContactPoint fields it reads and writes and the ActiveCollisionHooks bits the staging tests must exist in /root/reference (when present here); the context must be
+    registered around avn_step by the (generic) solver system; a collider with hooks must no longer push the plugin out of the closed loop."""
+    src = sources()
+    hk = src["hooks.rs"]
+    for used in ("avn_collision_hooks_set", "avn_hook_pair", "avn_hook_contact_f32", "AVN_MAX_MANIFOLD_POINTS", "AVN_CP_TOUCHING", "AVN_CP_GENERATE_CONSTRAINTS"):
+        assert f"ffi::{used}" in hk
+    plugins = src["plugins.rs"]
+    assert "gpu_solver::<H>" in plugins and "HookContext::<H>" in plugins and "ctx.register(raw)" in plugins and "unregister(raw)" in plugins
+    assert "StaticSystemParam<H>" in plugins and "SystemParamItem<'w, 's, H>: CollisionHooks" in plugins
+    mode = plugins[plugins.index("fn effective_mode"):plugins.index("impl<H: CollisionHooks + 'static> Plugin")]
+    assert "colliders_with_hooks" not in mode, "hooks no longer decide the mode: they are called back inside the closed loop"
+    assert "ActiveCollisionHooks::FILTER_PAIRS" in src["staging.rs"] and "ActiveCollisionHooks::MODIFY_CONTACTS" in src["staging.rs"]
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        return
+    hooks_rs = open(os.path.join(ref, "collision", "hooks.rs")).read()
+    contact_types = open(os.path.join(ref, "collision", "contact_types", "mod.rs")).read()
+    broad = open(os.path.join(ref, "collision", "broad_phase.rs")).read()
+    assert "fn filter_pairs(&self, collider1: Entity, collider2: Entity, commands: &mut Commands) -> bool" in hooks_rs and ".filter_pairs(c1, c2, ctx.commands)" in hk
+    assert "fn modify_contacts(&self, contacts: &mut ContactPair, commands: &mut Commands) -> bool" in hooks_rs and ".modify_contacts(&mut pair, ctx.commands)" in hk
+    assert "const FILTER_PAIRS" in hooks_rs and "const MODIFY_CONTACTS" in hooks_rs
+    assert "for<'w, 's> SystemParamItem<'w, 's, H>: CollisionHooks" in broad   # (the bound the reference's own generic systems carry)
+    assert "pub fn new(collider1: Entity, collider2: Entity, contact_id: ContactId) -> Self" in contact_types and "ContactPair::new(" in hk
+    assert "pub fn new(anchor1: Vector, anchor2: Vector, world_point: Vector, penetration: Scalar) -> Self" in contact_types and "ContactPoint::new(" in hk
+    assert "pub fn new(points: impl IntoIterator<Item = ContactPoint>, normal: Vector) -> Self" in contact_types and "ContactManifold::new(" in hk
+    for field in ("body1", "body2", "manifolds", "flags"):
+        assert re.search(rf"pub {field}:", contact_types) and f"pair.{field}" in hk, field
+    for field in ("friction", "restitution", "tangent_velocity", "normal", "points"):
+        assert re.search(rf"pub {field}:", contact_types) and (f"manifold.{field}" in hk or f"m.{field}" in hk), field
+    for field in ("anchor1", "anchor2", "penetration", "normal_speed", "feature_id1", "feature_id2"):
+        assert re.search(rf"pub {field}:", contact_types) and f"p.{field}" in hk, field
+    for flag in ("TOUCHING", "GENERATE_CONSTRAINTS", "STATIC1", "STATIC2", "MODIFY_CONTACTS"):
+        assert f"const {flag} =" in contact_types and f"ContactPairFlags::{flag}" in hk, flag
