@@ -104,29 +104,37 @@
         uint32_t n = *h_cnt;
         hs_stats.last_manifold_queries = n; hs_stats.last_manifolds_with_points = 0;
         if (!n) return AVN_OK;
+        uint32_t listed = n;   // entries in the device list (a retry may hold a pair twice, below)
         if (n > hs_mq_cap) {   // more pairs than the list held: grow, then only those pairs again (they wrote nothing; the list is refilled from its start)
-            if ((st = hs_reserve_queries(n + n / 2)) != AVN_OK) return st;
+            // A row whose id was recycled in this step is in the range of the launch over the OLD rows (it was a free id when that launch ran) and in the list of the
+            // NEW ones: the retry's relaunch of both meets it twice.  The list is sized for that (every pair twice at worst) and the duplicates leave below.
+            if ((st = hs_reserve_queries(2 * n + 16)) != AVN_OK) return st;
             HIPCHK(hipMemsetAsync(b_hs_cnt.p, 0, 4, s));
             hs_rerun(hs_list(1), dense, np, changes, n_changes, chg, has, s);
             HIPCHK(hipGetLastError());
             HIPCHK(hipMemcpyAsync(h_cnt, b_hs_cnt.p, 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (*h_cnt != n) { error = "host shapes: the retry found " + std::to_string(*h_cnt) + " pairs, the first pass " + std::to_string(n); return AVN_ERR_STATE; }
+            listed = *h_cnt;
+            if (listed < n || listed > hs_mq_cap) { error = "host shapes: the retry found " + std::to_string(listed) + " pairs, the first pass " + std::to_string(n); return AVN_ERR_STATE; }
         }
-        if (pin_hs.cap < (size_t)n * (HS_MQ + HS_MM) + 64) {
-            if (pin_hs.ensure((size_t)hs_mq_cap * (HS_MQ + HS_MM) + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
+        if (pin_hs.cap < (size_t)listed * (HS_MQ + HS_MM) + 64) {
+            if (pin_hs.ensure((size_t)std::max(hs_mq_cap, listed) * (HS_MQ + HS_MM) + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
         }
-        char* hq = (char*)pin_hs.p + 64; char* hm = hq + (size_t)n * HS_MQ;
-        HIPCHK(hipMemcpyAsync(hq, b_hs_mq.p, (size_t)n * HS_MQ, hipMemcpyDeviceToHost, s));
+        char* hq = (char*)pin_hs.p + 64;
+        HIPCHK(hipMemcpyAsync(hq, b_hs_mq.p, (size_t)listed * HS_MQ, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        {   // ascending contact id: the order update_contacts would meet them in, and a deterministic callback
-            std::vector<uint32_t> idx(n);
-            for (uint32_t i = 0; i < n; ++i) idx[i] = i;
-            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return *(const uint32_t*)(hq + (size_t)a * HS_MQ) < *(const uint32_t*)(hq + (size_t)b * HS_MQ); });
+        {   // ascending contact id: the order update_contacts would meet them in, and a deterministic callback; a pair listed twice keeps one entry
+            std::vector<uint32_t> idx(listed);
+            for (uint32_t i = 0; i < listed; ++i) idx[i] = i;
+            auto cid = [&](uint32_t i) { return *(const uint32_t*)(hq + (size_t)i * HS_MQ); };
+            std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cid(a) < cid(b); });
+            idx.erase(std::unique(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return cid(a) == cid(b); }), idx.end());
+            if (idx.size() != n) { error = "host shapes: the retry found " + std::to_string(idx.size()) + " distinct pairs, the first pass " + std::to_string(n); return AVN_ERR_STATE; }
             std::vector<char> tmp((size_t)n * HS_MQ);
             for (uint32_t i = 0; i < n; ++i) std::memcpy(tmp.data() + (size_t)i * HS_MQ, hq + (size_t)idx[i] * HS_MQ, HS_MQ);
             std::memcpy(hq, tmp.data(), tmp.size());
         }
+        char* hm = hq + (size_t)n * HS_MQ;
         std::memset(hm, 0, (size_t)n * HS_MM);
         const auto t0 = std::chrono::steady_clock::now();
         hs_manifolds_fn(hs_user, (uint32_t)(8 * sizeof(T)), n, hq, hm);

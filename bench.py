@@ -358,9 +358,17 @@ def main():
             keep.clear()
         except NameError:
             pass
-        def closed_windows(sleeping):
+        def closed_windows(sleeping, hooked=0.0):
             wc = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
-            wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**sc.collider_kwargs())
+            ck = sc.collider_kwargs()
+            if hooked:   # a fraction of the boxes carries ActiveCollisionHooks (both bits); the callbacks are vectorised numpy: the leg prices the round trips, not Python loops
+                fl = np.zeros(sc.n, np.uint8)
+                fl[1:][np.random.default_rng(0).random(sc.n - 1) < hooked] = F.COLLIDER_FILTER_PAIRS | F.COLLIDER_MODIFY_CONTACTS
+                ck["collider_flags"] = fl
+                def _modify(recs):
+                    recs["friction"] *= recs["friction"].dtype.type(0.9)
+                wc.collision_hooks_set(lambda pairs, keep: None, _modify)
+            wc.bodies_upload(**sc.body_kwargs()); wc.colliders_upload(**ck)
             wc.existing_pairs_upload(np.zeros(0, np.uint64))
             wc.collider_materials_upload(friction=sc.friction, restitution=sc.restitution)
             wc.pipeline_enable()    # ContactGraph / IdPool / ConstraintGraph bookkeeping on the device (k_graph.hip)
@@ -398,6 +406,11 @@ def main():
                 wc.step()
             steady = window(20)      # steps 100..119: the pile has stopped compacting (2-3e4 status changes per step, a few hundred overflow manifolds)
             ps = wc.pipeline_stats()
+            if hooked:
+                hk = wc.collision_hook_stats()
+                steady["hooks"] = {"hooked_colliders": int((ck["collider_flags"] != 0).sum()), "filter_queries_last_step": int(hk.last_filter_queries), "modify_records_last_step": int(hk.last_modify_queries),
+                                   "bytes_each_way_last_step": int(hk.last_modify_queries) * F.hook_contact_dtype(32).itemsize + int(hk.last_filter_queries) * F.HOOK_PAIR_DTYPE.itemsize,
+                                   "callback_ms_last_step": round(hk.last_callback_ms, 3), "python_errors": len(wc.host_shape_errors())}
             wc.close()
             return transient, settled, steady, ps
         transient, settled, steady, ps = closed_windows(False)
@@ -418,6 +431,16 @@ def main():
                                                   "change names a Sleeping body; split_island's walk reads a device-built CSR and, for an island that is still one piece, runs on a worker thread"}
         except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the line down
             closed["sleeping_enabled"] = {"status": "error: " + str(e)[:300]}
+        # the same windows with 1 % of the boxes carrying ActiveCollisionHooks (round 6): filter_pairs / modify_contacts called back from inside avn_step,
+        # only the hooked pairs on the bus -- the scene that used to force the PCIe-inclusive HostNarrowPhase mode below
+        try:
+            t3, s3, st3, _ = closed_windows(False, hooked=0.01)
+            closed["collision_hooks_1pct"] = {"steady_steps_100_119": st3, "steps_24_43": s3, "transient_steps_4_23": t3,
+                                              "settled_ratio_to_unhooked": round(st3["ms_per_step"] / steady["ms_per_step"], 3),
+                                              "note": "avn_collision_hooks_set: 1 % of the boxes flagged FILTER_PAIRS | MODIFY_CONTACTS; the filter accepts everything, modify_contacts scales the friction "
+                                                      "(vectorised numpy callbacks through ctypes); two extra round trips per step (the pending count, the records)"}
+        except Exception as e:  # noqa: BLE001
+            closed["collision_hooks_1pct"] = {"status": "error: " + str(e)[:300]}
         # measured HBM-side traffic of the settled closed-loop step next to the algorithmic bytes: two rocprofv3 --pmc passes of
         # tools/time_closed_loop.py (FETCH_SIZE, WRITE_SIZE separately, kernel-trace only), per-kernel means over the last 10 of 120 steps
         if not args.no_traffic:

@@ -38,3 +38,14 @@ def test_host_shapes_example_capsules_from_a_compiled_host():
     assert os.path.exists(exe)
     r = subprocess.run([exe, "12", "10", "12", "400", "150"], capture_output=True, text=True, timeout=180)
     assert r.returncode == 0 and "HOST_SHAPES_DEMO_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_collision_hooks_example_a_belt_and_ghosts_from_a_compiled_host():
+    """examples/collision_hooks_demo.cpp: CollisionHooks::filter_pairs / modify_contacts as the callbacks of a compiled host (a conveyor belt through tangent_velocity,
+    boxes that pass through each other through the pair filter) next to an unhooked pile, in the library's closed loop."""
+    build()
+    exe = os.path.join(REPO, "examples", "collision_hooks_demo")
+    assert os.path.exists(exe)
+    r = subprocess.run([exe, "12", "10", "12", "8", "16", "150"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "HOOKS_DEMO_OK" in r.stdout, r.stdout + r.stderr
