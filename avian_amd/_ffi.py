@@ -269,6 +269,10 @@ class avn_host_shape_stats(C.Structure):
                 ("bytes_to_host", C.c_uint64), ("bytes_from_host", C.c_uint64), ("last_callback_ms", C.c_double)]
 
 
+class avn_collider_transforms(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("is_child", C.c_void_p), ("translation", C.c_void_p), ("rotation", C.c_void_p)]
+
+
 # ---- collision hooks (include/avian_mi355x.h "collision hooks"): CollisionHooks::filter_pairs / modify_contacts as callbacks -----------------
 HOOK_FILTER_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p)                 # avn_filter_pairs_fn
 HOOK_MODIFY_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p)                 # avn_modify_contacts_fn
@@ -306,7 +310,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "collision_hooks_set", "collision_hook_stats_get", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "collision_hooks_set", "collision_hook_stats_get", "collider_transforms_upload", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -365,6 +369,7 @@ class Library:
         f("host_shapes_set").argtypes = [vp, HOST_SHAPE_FN, HOST_SHAPE_FN, vp]
         f("host_shape_stats_get").argtypes = [vp, C.POINTER(avn_host_shape_stats)]
         f("collision_hooks_set").argtypes = [vp, HOOK_FILTER_FN, HOOK_MODIFY_FN, vp]
+        f("collider_transforms_upload").argtypes = [vp, C.POINTER(avn_collider_transforms)]
         f("collision_hook_stats_get").argtypes = [vp, C.POINTER(avn_collision_hook_stats)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
@@ -735,6 +740,17 @@ class World:
     def existing_pairs_upload(self, keys):
         keys = np.ascontiguousarray(keys, dtype=np.uint64)
         self._check(self.lib.fn("existing_pairs_upload")(self.handle, _ptr(keys), keys.size))
+
+    def collider_transforms_upload(self, is_child=None, translation=None, rotation=None):
+        """``avn_collider_transforms_upload``: ColliderTransform of the colliders that are CHILD entities of their rigid body (after every colliders_upload).
+        No arguments: no collider is a child."""
+        if is_child is None:
+            self._check(self.lib.fn("collider_transforms_upload")(self.handle, None))
+            return
+        c = self.n_colliders
+        keep = [self._i(is_child, np.uint8), self._s(translation, (c, 3)), self._s(rotation, (c, 4))]
+        s = avn_collider_transforms(c, *[_ptr(a) for a in keep])
+        self._check(self.lib.fn("collider_transforms_upload")(self.handle, C.byref(s)))
 
     def pairs_get(self) -> np.ndarray:
         p, n = vp(), C.c_size_t()

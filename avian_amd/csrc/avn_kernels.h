@@ -29,7 +29,21 @@ template <class T> struct BP {
     uint32_t disabled_cap;
     Vec4<T>* s_bb;         // per group of 8 consecutive sorted records: (min of min.y, max of max.y, min of min.z, max of max.z) -- the sweep's batch cull
     Vec4<T>* s_bb2;        // the same bounds per 64 consecutive sorted records (second level of the cull)
+    // child colliders (avn_collider_transforms_upload): ColliderTransform per collider slot; nullptr = every collider sits on its body's entity
+    Vec4<T>* col_lpos;     // (translation.xyz, 1 = child | 0)
+    Vec4<T>* col_lrot;     // rotation xyzw
 };
+// update_child_collider_position (collision/collider/collider_transform/plugin.rs:62-91): a collider's Position / Rotation from its body's
+template <class T> __device__ __forceinline__ void collider_pose(const BP<T>& bp, uint32_t slot, V3<T> body_pos, Q4<T> body_rot, V3<T>& pos, Q4<T>& rot, bool* child = nullptr) {
+    pos = body_pos; rot = body_rot;
+    if (child) *child = false;
+    if (!bp.col_lpos) return;
+    const Vec4<T> lp = bp.col_lpos[slot];
+    if (lp.w == T(0)) return;
+    pos = body_pos + qrot(body_rot, xyz<T>(lp));
+    rot = qnormalize(qmul(body_rot, quat<T>(bp.col_lrot[slot])));
+    if (child) *child = true;
+}
 #define AVN_IV_DROPPED 0x80000000u
 #define AVN_IV_LONG 0x40000000u   // > SW_CAP sweep candidates: swept by k_sweep_long in chunks
 
@@ -161,7 +175,9 @@ template <class T> void launch_clear_contact_rows(const CT<T>&, const uint32_t* 
 // (launch_narrow_phase_hooked): the pair again from the top with the record the hook returned in the place of its manifold -- match_contacts, status change, row.
 // count == nullptr: no modify hook is registered (the plain kernels run unless the world holds host shapes).
 struct NpHookList { void* records = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t phase = 0; };
-struct NpHostList { void* queries = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t host_only = 0; NpHookList hook; bool any() const { return queries != nullptr || hook.count != nullptr; } };
+// locals: the world holds child colliders (BP::col_lpos): their poses are computed by the HS instantiations only
+struct NpHostList { void* queries = nullptr; uint32_t* count = nullptr; uint32_t cap = 0; uint32_t host_only = 0; NpHookList hook; bool locals = false;
+                    bool any() const { return queries != nullptr || hook.count != nullptr || locals; } };
 template <class T> void launch_narrow_phase_hooked(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool dense, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg,
                                                    uint32_t* has, const void* records /* sorted by contact id, as the hook left them */, uint32_t n, hipStream_t);
 template <class T> void launch_narrow_phase_host(const DW<T>&, const BP<T>&, const CT<T>&, const StepParams<T>&, bool dense, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg,

@@ -192,6 +192,9 @@ template <class T> AVN_HD V3<T> qrot(Q4<T> q, V3<T> v) {
 }
 AVN_HD float qlength_squared(Q4<float> q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
 AVN_HD double qlength_squared(Q4<double> q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+// glam Quat::normalize = Vec4::normalize: SSE2 (f32) divides by the length, the scalar path (f64) multiplies by its reciprocal
+AVN_HD Q4<float> qnormalize(Q4<float> q) { const float l = sqrt_t(qlength_squared(q)); return Q4<float>{q.x / l, q.y / l, q.z / l, q.w / l}; }
+AVN_HD Q4<double> qnormalize(Q4<double> q) { const double r = 1.0 / sqrt_t(qlength_squared(q)); return Q4<double>{q.x * r, q.y * r, q.z * r, q.w * r}; }
 // reference physics_transform/transform.rs:811-817
 template <class T> AVN_HD Q4<T> fast_renormalize(Q4<T> q) {
     T k = T(0.5) * (T(3) - qlength_squared(q));

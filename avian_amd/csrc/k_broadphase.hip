@@ -59,6 +59,12 @@ __global__ __launch_bounds__(256) void k_update_aabb(DW<T> w, BP<T> bp, StepPara
     V3<T> pos = xyz<T>(w.pos[body]);
     Q4<T> rot = quat<T>(w.rot[body]);
     V3<T> lv = xyz<T>(w.lvel[body]), av = xyz<T>(w.avel[body]);
+    if (bp.col_lpos) {   // a child collider: its own pose, and the body's velocity at its offset from the centre of mass (backend.rs:569-586)
+        const V3<T> bpos = pos; const Q4<T> brot = rot;
+        bool child;
+        collider_pose<T>(bp, c, bpos, brot, pos, rot, &child);
+        if (child) { const V3<T> offset = (pos - bpos) - qrot(brot, xyz<T>(w.com[body])); lv = lv + cross(av, offset); }
+    }
     T delta_secs = p.dt_adj;
     T speculative_margin = (cflags & AVN_COLLIDER_SWEPT_CCD) ? Limits<T>::max : (spec >= T(0) ? spec : p.default_speculative_margin);
     T g = p.contact_tolerance + he4.w;
@@ -96,9 +102,16 @@ __global__ __launch_bounds__(256) void k_host_aabb_queries(DW<T> w, BP<T> bp, St
     const T spec = bp.col_spec[c];
     const uint32_t cflags = (ci.z >> 8) & 0xFFu;
     const int body = (int)ci.y;
-    const V3<T> pos = xyz<T>(w.pos[body]);
-    const Q4<T> rot = quat<T>(w.rot[body]);
-    const V3<T> lv = xyz<T>(w.lvel[body]), av = xyz<T>(w.avel[body]);
+    V3<T> pos = xyz<T>(w.pos[body]);
+    Q4<T> rot = quat<T>(w.rot[body]);
+    V3<T> lv = xyz<T>(w.lvel[body]);
+    const V3<T> av = xyz<T>(w.avel[body]);
+    if (bp.col_lpos) {   // a child collider (as in k_update_aabb)
+        const V3<T> bpos = pos; const Q4<T> brot = rot;
+        bool child;
+        collider_pose<T>(bp, c, bpos, brot, pos, rot, &child);
+        if (child) { const V3<T> offset = (pos - bpos) - qrot(brot, xyz<T>(w.com[body])); lv = lv + cross(av, offset); }
+    }
     const T delta_secs = p.dt_adj;
     const T speculative_margin = (cflags & AVN_COLLIDER_SWEPT_CCD) ? Limits<T>::max : (spec >= T(0) ? spec : p.default_speculative_margin);
     HostAabbQ<T> q;

@@ -164,16 +164,19 @@ __device__ void np_update_pair(const DW<T>& w, const BP<T>& bp, const CT<T>& ct,
         const bool have1 = !(meta_flags(bm1) & AVN_BODY_DISABLED), have2 = !(meta_flags(bm2) & AVN_BODY_DISABLED);
         const Vec4<T> pos1 = w.pos[body1], pos2 = w.pos[body2], rot1 = w.rot[body1], rot2 = w.rot[body2];
         const bool is_static1 = have1 && meta_rb_type(bm1) == AVN_RB_STATIC, is_static2 = have2 && meta_rb_type(bm2) == AVN_RB_STATIC;
-        const V3<T> x1 = xyz<T>(pos1), x2 = xyz<T>(pos2);
-        const Q4<T> q1 = quat<T>(rot1), q2 = quat<T>(rot2);
-        // the collider sits on the body entity: collider.position - body.position
-        const V3<T> collider_offset1 = have1 ? x1 - x1 : vzero<T>(), collider_offset2 = have2 ? x2 - x2 : vzero<T>();
+        const V3<T> bx1 = xyz<T>(pos1), bx2 = xyz<T>(pos2);   // the BODIES' poses ...
+        const Q4<T> bq1 = quat<T>(rot1), bq2 = quat<T>(rot2);
+        V3<T> x1 = bx1, x2 = bx2;                              // ... and the COLLIDERS': the same unless the collider is a child entity (HS instantiations, BP::col_lpos)
+        Q4<T> q1 = bq1, q2 = bq2;
+        if (HS && bp.col_lpos) { collider_pose<T>(bp, slot1, bx1, bq1, x1, q1); collider_pose<T>(bp, slot2, bx2, bq2, x2, q2); }
+        // collider.position - body.position (zero for a collider on the body's entity)
+        const V3<T> collider_offset1 = have1 ? x1 - bx1 : vzero<T>(), collider_offset2 = have2 ? x2 - bx2 : vzero<T>();
         // what only a pair WITH a manifold needs (centres of mass, angular velocities, materials): the heavy kernel loads it up front, the light
         // one -- whose cuboid pairs end apart or deferred -- only for a ball pair that touches (6 of its ~26 scattered 16-byte gathers per pair)
         V3<T> world_com1 = vzero<T>(), world_com2 = vzero<T>(), ang_vel1 = vzero<T>(), ang_vel2 = vzero<T>();
         T friction = T(0), restitution = T(0);
         auto load_manifold_inputs = [&]() {
-            world_com1 = have1 ? qrot(q1, xyz<T>(w.com[body1])) : vzero<T>(); world_com2 = have2 ? qrot(q2, xyz<T>(w.com[body2])) : vzero<T>();
+            world_com1 = have1 ? qrot(bq1, xyz<T>(w.com[body1])) : vzero<T>(); world_com2 = have2 ? qrot(bq2, xyz<T>(w.com[body2])) : vzero<T>();
             ang_vel1 = have1 ? xyz<T>(w.avel[body1]) : vzero<T>(); ang_vel2 = have2 ? xyz<T>(w.avel[body2]) : vzero<T>();
             const Vec4<T> m1 = ct.col_mat[slot1], m2 = ct.col_mat[slot2];
             const uint32_t r1 = scalar_to_bits(m1.z), r2 = scalar_to_bits(m2.z);
@@ -536,9 +539,9 @@ size_t np_survivor_list_slack() { return (size_t)NP_LISTS * NP_LIGHT_THREADS; }
 size_t np_survivor_counter_bytes() { return (size_t)NP_LISTS * NP_CTR_STRIDE * sizeof(uint32_t); }
 template <class T, bool DENSE>
 static void launch_np_heavy(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, avn_contact_change* changes, uint32_t* n_changes, uint32_t* chg, uint32_t* has,
-                            uint32_t n_pairs, hipStream_t st, const NpHookList& hook = NpHookList()) {
+                            uint32_t n_pairs, hipStream_t st, const NpHookList& hook = NpHookList(), bool hs = false) {
     const uint32_t chunks = np_list_segment(n_pairs) / NP_THREADS;
-    if (hook.count) hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE, true>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs, np_hook_ctx<T>(hook));
+    if (hook.count || hs) hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE, true>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs, np_hook_ctx<T>(hook));
     else
     hipLaunchKernelGGL((k_narrow_phase_heavy<T, DENSE>), dim3(chunks * NP_LISTS), dim3(NP_THREADS), 0, st, w, bp, ct, p, changes, n_changes, chg, has, n_pairs, NpHookCtx<T>());
 }
@@ -668,7 +671,7 @@ template <class T> void launch_narrow_phase(const DW<T>& w, const BP<T>& bp, con
     else
     hipLaunchKernelGGL((k_narrow_phase<T, false>), dim3((n_active + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, active, n_active, changes, n_changes, nullptr, nullptr, 0u, 0u);
     if (hl.host_only) return;   // (a retry hands no cuboid pair over: nothing for the second kernel)
-    launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st, hl.hook);
+    launch_np_heavy<T, false>(w, bp, ct, p, changes, n_changes, nullptr, nullptr, n_active, st, hl.hook, hl.any());
 }
 template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, uint32_t n_rows, uint32_t* chg, uint32_t* has,
                                                   uint32_t* n_remove, hipStream_t st, bool reset_counter, const NpHostList& hl) {
@@ -678,7 +681,7 @@ template <class T> void launch_narrow_phase_dense(const DW<T>& w, const BP<T>& b
     else
     hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_rows + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_rows, nullptr, n_remove, chg, has, 0u, 0u);
     if (hl.host_only) return;
-    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st, hl.hook);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n_rows, st, hl.hook, hl.any());
 }
 // the rows list[0 .. n_list) followed by range_base .. range_base + n_range: same per-row work and outputs as the dense form; the
 // removal counter is NOT reset (it continues the count of the launch over the older rows)
@@ -694,7 +697,7 @@ template <class T> void launch_narrow_phase_rows(const DW<T>& w, const BP<T>& bp
     if (!n_list && !range_base) hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n_range + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, nullptr, n_range, nullptr, n_remove, chg, has, 0u, 0u);
     else hipLaunchKernelGGL((k_narrow_phase<T, true>), dim3((n + NP_LIGHT_THREADS - 1) / NP_LIGHT_THREADS), dim3(NP_LIGHT_THREADS), 0, st, w, bp, ct, p, list, n, nullptr, n_remove, chg, has, n_list, range_base);
     if (hl.host_only) return;
-    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st, hl.hook);
+    launch_np_heavy<T, true>(w, bp, ct, p, nullptr, n_remove, chg, has, n, st, hl.hook, hl.any());
 }
 // the pairs the host answered (queries sorted by contact id on the host, manifolds in the same order): dense = the closed loop's chg / has outputs, else the change list
 template <class T> void launch_narrow_phase_host(const DW<T>& w, const BP<T>& bp, const CT<T>& ct, const StepParams<T>& p, bool dense, avn_contact_change* changes, uint32_t* n_changes,

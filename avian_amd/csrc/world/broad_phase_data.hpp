@@ -195,6 +195,7 @@
         despawn_needs_colliders = false;
         { avn_status sh = hs_on_colliders_upload(c); if (sh != AVN_OK) return sh; }
         { avn_status sh = hk_on_colliders_upload(c); if (sh != AVN_OK) return sh; }
+        bp.col_lpos = nullptr; bp.col_lrot = nullptr; tf_any = false;   // (every collider sits on its body again until avn_collider_transforms_upload says otherwise)
         if (slp_on) {   // colliders spawned inside the loop join the island manager's RigidBodyColliders lists (upload order = Add order)
             for (uint32_t i = 0; i < C; ++i) {
                 if (isl.has_collider(c->entity_index[i])) continue;

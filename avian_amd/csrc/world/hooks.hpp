@@ -137,7 +137,7 @@
         if (pin_hk.ensure((size_t)n * HK_REC + 64) != hipSuccess) { error = "hipHostMalloc failed"; return AVN_ERR_OOM; }
         HIPCHK(hipMemsetAsync(d_cnt, 0, 4, s));
         NpHostList l;
-        l.hook.records = b_hk_rec.p; l.hook.count = d_cnt; l.hook.cap = hk_rec_cap; l.hook.phase = 2;
+        l.hook.records = b_hk_rec.p; l.hook.count = d_cnt; l.hook.cap = hk_rec_cap; l.hook.phase = 2; l.locals = tf_any;
         hs_rerun(l, dense, np, changes, n_changes, chg, has, s);
         if (hs_any() && hs_stats.last_manifold_queries)   // (pending pairs with a host-shaped collider: their manifolds are still in the answer list)
             { launch_narrow_phase_host<T>(dw, bp, ct, np, dense, changes, n_changes, chg, has, b_hs_mq.p, b_hs_mm.p, hs_stats.last_manifold_queries, s, l.hook); ++launches; }
@@ -171,5 +171,34 @@
         launch_narrow_phase_hooked<T>(dw, bp, ct, np, dense, changes, n_changes, chg, has, b_hk_rec.p, n, s); ++launches;
         HIPCHK(hipGetLastError());
         hk_stats.bytes_to_host += (uint64_t)n * HK_REC; hk_stats.bytes_from_host += (uint64_t)n * HK_REC;
+        return AVN_OK;
+    }
+
+    // ---- child colliders (include/avian_mi355x.h "child colliders"): ColliderTransform per collider slot; the kernels compute the child's pose from its body's ----
+    DevBuf b_col_lpos, b_col_lrot;
+    bool tf_any = false;
+    avn_status collider_transforms_upload(const avn_collider_transforms* t) override {
+        HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipStreamSynchronize(stream_bp));
+        if (!t || !t->count) { bp.col_lpos = nullptr; bp.col_lrot = nullptr; tf_any = false; return AVN_OK; }
+        if (t->count != bp.n_colliders) { error = "collider_transforms_upload: count differs from the last colliders_upload"; return AVN_ERR_BAD_ARG; }
+        if (!t->is_child || !t->translation || !t->rotation) { error = "collider_transforms_upload: null array"; return AVN_ERR_BAD_ARG; }
+        const uint32_t C = t->count;
+        std::vector<V> lp(C), lr(C);
+        bool any = false;
+        const T* tr = (const T*)t->translation; const T* ro = (const T*)t->rotation;
+        for (uint32_t i = 0; i < C; ++i) {
+            const bool child = t->is_child[i] != 0;
+            any |= child;
+            lp[i] = make4<T>(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2], child ? T(1) : T(0));
+            lr[i] = make4<T>(ro[4 * i], ro[4 * i + 1], ro[4 * i + 2], ro[4 * i + 3]);
+        }
+        tf_any = any;
+        if (!any) { bp.col_lpos = nullptr; bp.col_lrot = nullptr; return AVN_OK; }
+        hipError_t err;
+        b_col_lpos.ensure((size_t)C * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        b_col_lrot.ensure((size_t)C * sizeof(V), err); if (err != hipSuccess) { error = "hipMalloc failed"; return AVN_ERR_OOM; }
+        HIPCHK(hipMemcpy(b_col_lpos.p, lp.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b_col_lrot.p, lr.data(), (size_t)C * sizeof(V), hipMemcpyHostToDevice));
+        bp.col_lpos = b_col_lpos.as<V>(); bp.col_lrot = b_col_lrot.as<V>();
         return AVN_OK;
     }

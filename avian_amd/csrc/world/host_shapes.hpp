@@ -82,13 +82,14 @@
         NpHostList l;
         if (hs_any()) { (void)hipMemsetAsync(b_hs_cnt.p, 0, 4, s); l = hs_list(); }
         if (hk_begin(l, s) != AVN_OK) l.hook = NpHookList();   // (collision hooks, world/hooks.hpp: phase 1 rides the same launches)
+        l.locals = tf_any;                                      // (child colliders: the HS instantiations compute their poses)
         return l;
     }
     NpHookList hk_phase1() const { NpHookList h; if (hk_modify_active() && b_hk_cnt.p) { h.count = b_hk_cnt.as<uint32_t>(); h.phase = 1; } return h; }
     NpHostList hs_list(uint32_t host_only = 0) const {
         NpHostList l;
         if (!hs_any()) return l;
-        l.queries = b_hs_mq.p; l.count = b_hs_cnt.as<uint32_t>(); l.cap = hs_mq_cap; l.host_only = host_only;
+        l.queries = b_hs_mq.p; l.count = b_hs_cnt.as<uint32_t>(); l.cap = hs_mq_cap; l.host_only = host_only; l.locals = tf_any;
         return l;
     }
     // after the step's light + heavy launches (all on `s`): the pairs with a host collider have left their queries; ask the host, then run update_contacts' remainder

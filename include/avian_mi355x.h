@@ -262,8 +262,8 @@ typedef struct avn_joints {
     const uint8_t* collision_disabled; /* [J] NULL = 0 */
 } avn_joints;
 
-/* ---- colliders for the broad phase (a24-a27).  A collider sits on its rigid body entity
- *      (no child-collider offset in this round). --------------------------------------------- */
+/* ---- colliders for the broad phase (a24-a27).  A collider sits on its rigid body entity unless
+ *      avn_collider_transforms_upload (below) says it is a child of it. ------------------------ */
 typedef struct avn_colliders {
     uint32_t count;                 /* C */
     const uint32_t* entity_index;   /* [C] Entity::index() used for PairKey; must be unique */
@@ -276,6 +276,25 @@ typedef struct avn_colliders {
     const void* collision_margin;   /* [C] NULL = 0 */
     const void* speculative_margin; /* [C] NULL or <0 = use config default */
 } avn_colliders;
+
+/* ---- child colliders (round 6): colliders on CHILD entities of their rigid body (compound bodies) -------------------------------------
+ *      Avian keeps a ColliderTransform per collider (collision/collider/collider_transform/mod.rs:20-27: translation, rotation, scale relative to the
+ *      rigid body) and, first thing in every step, update_child_collider_position (collider_transform/plugin.rs:62-91) sets the child's
+ *          Position = rb_pos + rb_rot * translation,   Rotation = (rb_rot * rotation).normalize().
+ *      The device computes exactly that wherever a collider's pose is read -- update_aabb (collider/backend.rs:498-624: for a child the swept box uses the
+ *      body's velocity AT THE COLLIDER'S OFFSET from the centre of mass, :569-586), update_contacts (narrow_phase/system_param.rs:540-575: the manifold is
+ *      computed at the colliders' poses, anchors are shifted by collider_offset = collider.position - body.position), the host-shape queries -- so a
+ *      compound body needs no per-step upload: one entry per collider, after every avn_colliders_upload (which puts all colliders back on their bodies).
+ *      `scale` is the host's: half_extents / radius are uploaded scaled (Collider::shape_scaled), `translation` is ColliderTransform::translation as
+ *      propagate_collider_transforms leaves it (already multiplied by the parents' scale).  Mass properties of the compound (ComputedMass,
+ *      ComputedAngularInertia, ComputedCenterOfMass) are the host's as for any body. */
+typedef struct avn_collider_transforms {
+    uint32_t count;               /* C of the last avn_colliders_upload */
+    const uint8_t* is_child;      /* [C] 1: the collider is a child entity of its body (ColliderTransform applies); 0: it sits on the body's entity */
+    const void* translation;      /* [3C] ColliderTransform::translation */
+    const void* rotation;         /* [4C] ColliderTransform::rotation (xyzw) */
+} avn_collider_transforms;
+AVN_API avn_status AVN_FN(collider_transforms_upload)(avn_world* w, const avn_collider_transforms* t);   /* NULL or count 0: no collider is a child */
 
 typedef struct avn_pair {
     uint32_t collider1; /* Entity::index() of the collider earlier in sorted order (broad_phase.rs:443) */

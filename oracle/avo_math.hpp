@@ -208,6 +208,9 @@ template <class S> inline V3<S> qrot(Q4<S> q, V3<S> v) {
 // glam Quat::length_squared: SSE2 dot4 = (x2+z2)+(y2+w2) for f32, scalar for f64
 inline float qlength_squared(Q4<float> q) { return (q.x * q.x + q.z * q.z) + (q.y * q.y + q.w * q.w); }
 inline double qlength_squared(Q4<double> q) { return q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w; }
+// glam Quat::normalize = Vec4::normalize: SSE2 (f32) divides by the length, the scalar path (f64) multiplies by its reciprocal
+inline Q4<float> qnormalize(Q4<float> q) { const float l = std::sqrt(qlength_squared(q)); return {q.x / l, q.y / l, q.z / l, q.w / l}; }
+inline Q4<double> qnormalize(Q4<double> q) { const double r = 1.0 / std::sqrt(qlength_squared(q)); return {q.x * r, q.y * r, q.z * r, q.w * r}; }
 // physics_transform/transform.rs:811-817 Rotation::fast_renormalize
 template <class S> inline Q4<S> fast_renormalize(Q4<S> q) {
     S l2 = qlength_squared(q);

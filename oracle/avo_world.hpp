@@ -255,6 +255,10 @@ template <class S> struct Collider {
     uint32_t memberships, filters;
     S collision_margin, speculative_margin;  // speculative < 0 = absent
     ColliderAabb<S> aabb;
+    // a collider on a CHILD entity of its rigid body (avn_collider_transforms_upload): ColliderTransform::translation / rotation, scale applied by the host
+    bool child = false;
+    V3<S> local_translation{0, 0, 0};
+    Q4<S> local_rotation{0, 0, 0, 1};
 };
 struct AabbInterval {  // broad_phase.rs:177-185 (aabb/layers looked up through the collider slot)
     uint32_t collider;  // slot in `colliders`
@@ -280,6 +284,7 @@ struct WorldBase {
     virtual avn_status joints_upload(const avn_joints*) = 0;
     virtual avn_status joints_download(const avn_joints_out*) = 0;
     virtual avn_status colliders_upload(const avn_colliders*) = 0;
+    virtual avn_status collider_transforms_upload(const avn_collider_transforms*) = 0;
     virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;
     virtual avn_status pairs_get(const avn_pair**, size_t*) = 0;
     virtual avn_status aabbs_download(void*, void*, uint32_t*, size_t*) = 0;
@@ -1378,6 +1383,27 @@ template <class S> struct World : WorldBase {
     // =============================================================================================
     //                                      BROAD PHASE
     // =============================================================================================
+    // child colliders (header: "child colliders"): ColliderTransform of the colliders that are not on their body's entity; a colliders_upload puts every collider back on its body
+    avn_status collider_transforms_upload(const avn_collider_transforms* t) override {
+        if (!t || !t->count) { for (Collider<S>& c : colliders) c.child = false; return AVN_OK; }
+        if (t->count != colliders.size()) { error = "collider_transforms_upload: count differs from the last colliders_upload"; return AVN_ERR_BAD_ARG; }
+        if (!t->is_child || !t->translation || !t->rotation) { error = "collider_transforms_upload: null array"; return AVN_ERR_BAD_ARG; }
+        for (uint32_t i = 0; i < t->count; ++i) {
+            Collider<S>& c = colliders[i];
+            c.child = t->is_child[i] != 0;
+            c.local_translation = rd3(t->translation, i);
+            const S* r = (const S*)t->rotation + 4 * (size_t)i;
+            c.local_rotation = {r[0], r[1], r[2], r[3]};
+        }
+        return AVN_OK;
+    }
+    // update_child_collider_position (collision/collider/collider_transform/plugin.rs:62-91): Position / Rotation of a collider; its body's for a collider on the body's entity
+    static void collider_pose(const Collider<S>& c, const Body<S>& b, V3<S>& pos, Q4<S>& rot) {
+        pos = b.position; rot = b.rotation;
+        if (!c.child) return;
+        pos = b.position + qrot(b.rotation, c.local_translation);
+        rot = qnormalize(qmul(b.rotation, c.local_rotation));
+    }
     avn_status colliders_upload(const avn_colliders* c) override {
         if (!c || (c->count && (!c->entity_index || !c->body || !c->shape || !c->half_extents))) { error = "colliders_upload: null array"; return AVN_ERR_BAD_ARG; }
         std::vector<Collider<S>> next(c->count);
@@ -1675,7 +1701,9 @@ template <class S> struct World : WorldBase {
                 const bool have1 = !(b1.body_flags & AVN_BODY_DISABLED), have2 = !(b2.body_flags & AVN_BODY_DISABLED);  // Without<RigidBodyDisabled>
                 // the collider sits on the body entity: collider.position = body.position
                 bool is_static1 = have1 && b1.rb_type == AVN_RB_STATIC, is_static2 = have2 && b2.rb_type == AVN_RB_STATIC;
-                V3<S> collider_offset1 = have1 ? b1.position - b1.position : vzero<S>(), collider_offset2 = have2 ? b2.position - b2.position : vzero<S>();
+                V3<S> cpos1, cpos2; Q4<S> crot1, crot2;   // the colliders' own Position / Rotation (a child collider: update_child_collider_position)
+                collider_pose(c1, b1, cpos1, crot1); collider_pose(c2, b2, cpos2, crot2);
+                V3<S> collider_offset1 = have1 ? cpos1 - b1.position : vzero<S>(), collider_offset2 = have2 ? cpos2 - b2.position : vzero<S>();
                 V3<S> world_com1 = have1 ? qrot(b1.rotation, b1.center_of_mass) : vzero<S>(), world_com2 = have2 ? qrot(b2.rotation, b2.center_of_mass) : vzero<S>();
                 V3<S> lin_vel1 = have1 ? b1.linear_velocity : vzero<S>(), lin_vel2 = have2 ? b2.linear_velocity : vzero<S>();
                 V3<S> ang_vel1 = have1 ? b1.angular_velocity : vzero<S>(), ang_vel2 = have2 ? b2.angular_velocity : vzero<S>();
@@ -1700,9 +1728,9 @@ template <class S> struct World : WorldBase {
                 QueryManifold<S> qm;
                 bool has;
                 if (c1.shape == AVN_SHAPE_HOST || c2.shape == AVN_SHAPE_HOST)   // AnyCollider::contact_manifolds_with_context on the host (system_param.rs:700-712; header: "host shapes")
-                    has = host_contact_manifold(id, c1, b1, c2, b2, max_contact_distance, qm);
+                    has = host_contact_manifold(id, c1, cpos1, crot1, c2, cpos2, crot2, max_contact_distance, qm);
                 else
-                has = contact_manifolds_pair<S>(c1.shape, c1.half_extents, b1.position, b1.rotation, c2.shape, c2.half_extents, b2.position, b2.rotation, max_contact_distance, qm);
+                has = contact_manifolds_pair<S>(c1.shape, c1.half_extents, cpos1, crot1, c2.shape, c2.half_extents, cpos2, crot2, max_contact_distance, qm);
                 // retain_mut over the (at most one) manifold
                 CtPoint kept[AVO_MAX_RAW_POINTS];
                 int nk = 0;
@@ -1853,9 +1881,8 @@ template <class S> struct World : WorldBase {
         return AVN_OK;
     }
     avn_status host_shape_stats_get(avn_host_shape_stats* o) override { if (!o) return AVN_ERR_BAD_ARG; hs_stats.host_colliders = n_host_colliders; *o = hs_stats; return AVN_OK; }
-    bool host_contact_manifold(uint32_t id, const Collider<S>& c1, const Body<S>& b1, const Collider<S>& c2, const Body<S>& b2, S max_contact_distance, QueryManifold<S>& qm) {
-        HostMQ<S> q{id, c1.entity, c2.entity, 0u, {b1.position.x, b1.position.y, b1.position.z}, {b1.rotation.x, b1.rotation.y, b1.rotation.z, b1.rotation.w},
-                    {b2.position.x, b2.position.y, b2.position.z}, {b2.rotation.x, b2.rotation.y, b2.rotation.z, b2.rotation.w}, max_contact_distance};
+    bool host_contact_manifold(uint32_t id, const Collider<S>& c1, V3<S> p1, Q4<S> r1, const Collider<S>& c2, V3<S> p2, Q4<S> r2, S max_contact_distance, QueryManifold<S>& qm) {
+        HostMQ<S> q{id, c1.entity, c2.entity, 0u, {p1.x, p1.y, p1.z}, {r1.x, r1.y, r1.z, r1.w}, {p2.x, p2.y, p2.z}, {r2.x, r2.y, r2.z, r2.w}, max_contact_distance};
         HostMM<S> m;
         std::memset(&m, 0, sizeof m);
         hs_manifolds_fn(hs_user, (uint32_t)(8 * sizeof(S)), 1u, &q, &m);
@@ -1864,7 +1891,7 @@ template <class S> struct World : WorldBase {
         qm.normal = {m.normal[0], m.normal[1], m.normal[2]};
         for (int k = 0; k < qm.n; ++k) {
             V3<S> anchor1{m.anchor1[3 * k], m.anchor1[3 * k + 1], m.anchor1[3 * k + 2]};
-            qm.pts[k] = {anchor1, anchor1 + (b1.position - b2.position), b1.position + anchor1, m.penetration[k], m.fid1[k], m.fid2[k]};   // contact_query.rs:243-248
+            qm.pts[k] = {anchor1, anchor1 + (p1 - p2), p1 + anchor1, m.penetration[k], m.fid1[k], m.fid2[k]};   // contact_query.rs:243-248
         }
         hs_stats.last_manifolds_with_points += qm.n != 0;
         return qm.n != 0;
@@ -1937,14 +1964,19 @@ template <class S> struct World : WorldBase {
             S speculative_margin = (c.cflags & AVN_COLLIDER_SWEPT_CCD) ? std::numeric_limits<S>::max()
                                    : (c.speculative_margin >= S(0) ? c.speculative_margin : default_speculative_margin);
             S g = contact_tolerance + c.collision_margin;
+            // the collider's own Position / Rotation; a child collider of a rotating body orbits it: the velocity at its offset from the centre of mass (backend.rs:569-586)
+            V3<S> cpos; Q4<S> crot;
+            collider_pose(c, b, cpos, crot);
+            V3<S> lin_vel = b.linear_velocity;
+            if (c.child) { const V3<S> offset = (cpos - b.position) - qrot(b.rotation, b.center_of_mass); lin_vel = b.linear_velocity + cross(b.angular_velocity, offset); }
             if (c.shape == AVN_SHAPE_HOST) {   // aabb_with_context / swept_aabb_with_context on the host (backend.rs:556-620; header: "host shapes")
                 const bool swept = !(speculative_margin <= S(0));
-                Q4<S> end_rot = b.rotation; V3<S> end_pos = b.position;
+                Q4<S> end_rot = crot; V3<S> end_pos = cpos;
                 if (swept) {
-                    end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), b.rotation));
-                    end_pos = b.position + clamp_length_max(b.linear_velocity * delta_secs, smax(speculative_margin, contact_tolerance));
+                    end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), crot));
+                    end_pos = cpos + clamp_length_max(lin_vel * delta_secs, smax(speculative_margin, contact_tolerance));
                 }
-                HostAabbQ<S> q{c.entity, swept ? 1u : 0u, {b.position.x, b.position.y, b.position.z}, {b.rotation.x, b.rotation.y, b.rotation.z, b.rotation.w},
+                HostAabbQ<S> q{c.entity, swept ? 1u : 0u, {cpos.x, cpos.y, cpos.z}, {crot.x, crot.y, crot.z, crot.w},
                                {end_pos.x, end_pos.y, end_pos.z}, {end_rot.x, end_rot.y, end_rot.z, end_rot.w}};
                 HostAabb<S> a{};
                 hs_aabb_fn(hs_user, (uint32_t)(8 * sizeof(S)), 1u, &q, &a);
@@ -1953,13 +1985,13 @@ template <class S> struct World : WorldBase {
                 continue;
             }
             if (speculative_margin <= S(0)) {
-                ColliderAabb<S> a = shape_aabb(c, b.position, b.rotation);
+                ColliderAabb<S> a = shape_aabb(c, cpos, crot);
                 c.aabb = {a.min - V3<S>{g, g, g}, a.max + V3<S>{g, g, g}};
                 continue;
             }
-            Q4<S> end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), b.rotation));
-            V3<S> end_pos = b.position + clamp_length_max(b.linear_velocity * delta_secs, smax(speculative_margin, contact_tolerance));
-            ColliderAabb<S> a0 = shape_aabb(c, b.position, b.rotation);
+            Q4<S> end_rot = fast_renormalize(qmul(from_scaled_axis(b.angular_velocity * delta_secs), crot));
+            V3<S> end_pos = cpos + clamp_length_max(lin_vel * delta_secs, smax(speculative_margin, contact_tolerance));
+            ColliderAabb<S> a0 = shape_aabb(c, cpos, crot);
             ColliderAabb<S> a1 = shape_aabb(c, end_pos, end_rot);
             ColliderAabb<S> m{vmin(a0.min, a1.min), vmax(a0.max, a1.max)};
             c.aabb = {m.min - V3<S>{g, g, g}, m.max + V3<S>{g, g, g}};
