@@ -151,7 +151,7 @@ fn sync_config(
 fn gpu_upload_bodies(
     mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
     increments: Query<&VelocityIntegrationData>,
-    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>)>,
+    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>, Option<&ColliderTransform>)>,
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
     js: Res<crate::joints::JointStaging>,
     live_joints: Query<(), (Or<(With<FixedJoint>, With<RevoluteJoint>, With<SphericalJoint>, With<PrismaticJoint>, With<DistanceJoint>)>, Without<JointDisabled>)>,
@@ -183,6 +183,8 @@ fn gpu_upload_bodies(
     let raw = w.raw();
     let s1 = unsafe { ffi::avn_bodies_upload(raw, &b) }; w.check(s1);
     let s2 = unsafe { ffi::avn_colliders_upload(raw, &c) }; w.check(s2);
+    // compound bodies: the ColliderTransform of the colliders that are child entities (the device computes their Position / Rotation from the bodies': update_child_collider_position)
+    if st.c_is_child.iter().any(|&c| c != 0) { let t = st.collider_transforms_desc(); let s3 = unsafe { ffi::avn_collider_transforms_upload(raw, &t) }; w.check(s3); }
 }
 
 /// BroadPhasePlugin replacement (src/collision/broad_phase.rs:347-474): device AABB update + sweep-and-prune; the new pairs come back in

@@ -29,6 +29,9 @@ pub struct Staging {
     pub colliders_unsupported: usize,
     pub c_entity_index: Vec<u32>, pub c_body: Vec<i32>, pub c_shape: Vec<u8>, pub c_half_extents: Vec<f32>,
     pub c_memberships: Vec<u32>, pub c_filters: Vec<u32>, pub c_flags: Vec<u8>, pub c_margin: Vec<f32>, pub c_speculative: Vec<f32>,
+    /// child colliders (a collider entity that is not its rigid body's entity): `ColliderTransform::translation` / `rotation`; the device computes the child's
+    /// Position / Rotation from its body's every step, as `update_child_collider_position` does (src/collision/collider/collider_transform/plugin.rs:62-91)
+    pub c_is_child: Vec<u8>, pub c_local_translation: Vec<f32>, pub c_local_rotation: Vec<f32>,
     // avn_manifolds (colour-major: the order of GraphColor::manifold_handles, src/dynamics/solver/constraint_graph.rs:66-80)
     pub m_offsets: [u32; ffi::AVN_GRAPH_COLOR_COUNT as usize + 1],
     pub m_handles: Vec<(ContactId, usize)>,
@@ -99,15 +102,15 @@ impl Staging {
     /// callbacks of host_shapes.rs (its `Collider` goes into `host_shapes`): it stays in the closed loop.  Only a collider that is not on a known rigid body is unsupported.
     pub fn fill_colliders<'a>(
         &mut self,
-        colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&'a ActiveCollisionHooks>)>,
+        colliders: impl Iterator<Item = (Entity, &'a Collider, &'a ColliderOf, &'a CollisionLayers, Option<&'a CollisionMargin>, Option<&'a SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&'a ActiveCollisionHooks>, Option<&'a ColliderTransform>)>,
         host_shapes: &mut crate::host_shapes::HostShapeTable,
     ) {
         host_shapes.colliders.clear();
         macro_rules! clear { ($($f:ident),*) => { $( self.$f.clear(); )* } }
-        clear!(collider_entities, collider_slot, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative);
+        clear!(collider_entities, collider_slot, c_entity_index, c_body, c_shape, c_half_extents, c_memberships, c_filters, c_flags, c_margin, c_speculative, c_is_child, c_local_translation, c_local_rotation);
         self.colliders_with_hooks = 0;
         self.colliders_unsupported = 0;
-        for (e, collider, of, layers, margin, spec, sensor, events, hooks) in colliders {
+        for (e, collider, of, layers, margin, spec, sensor, events, hooks, transform) in colliders {
             let shape = collider.shape_scaled();
             let (kind, he) = if let Some(b) = shape.as_ball() { (ffi::AVN_SHAPE_BALL, Vec3::new(b.radius, 0.0, 0.0)) }
                              else if let Some(c) = shape.as_cuboid() { (ffi::AVN_SHAPE_CUBOID, Vec3::new(c.half_extents.x, c.half_extents.y, c.half_extents.z)) }
@@ -125,6 +128,20 @@ impl Staging {
             self.c_flags.push((if sensor { ffi::AVN_COLLIDER_SENSOR } else { 0 } | if events { ffi::AVN_COLLIDER_EVENTS } else { 0 }
                                | if filter { ffi::AVN_COLLIDER_FILTER_PAIRS } else { 0 } | if modify { ffi::AVN_COLLIDER_MODIFY_CONTACTS } else { 0 }) as u8);
             self.c_margin.push(margin.map_or(0.0, |m| m.0)); self.c_speculative.push(spec.map_or(-1.0, |s| s.0));   // < 0: absent (NarrowPhaseConfig default applies)
+            // a child collider: ColliderOf names another entity than its own (update_child_collider_position's query is `Without<RigidBody>`); the shape above is
+            // already scaled (`shape_scaled`), the translation carries the parents' scale (propagate_collider_transforms)
+            let child = of.body != e;
+            let t = transform.copied().unwrap_or_default();
+            self.c_is_child.push(child as u8);
+            push3(&mut self.c_local_translation, t.translation);
+            self.c_local_rotation.extend_from_slice(&t.rotation.0.to_array());
+        }
+    }
+
+    /// `avn_collider_transforms_upload`, after every `avn_colliders_upload` (which puts all colliders back on their bodies).
+    pub fn collider_transforms_desc(&self) -> ffi::avn_collider_transforms {
+        ffi::avn_collider_transforms {
+            count: self.collider_entities.len() as u32, is_child: self.c_is_child.as_ptr(), translation: p(&self.c_local_translation), rotation: p(&self.c_local_rotation),
         }
     }
 

@@ -25,7 +25,7 @@ def test_compound_bodies_equal_the_oracle(bits, seed, n, steps):
         dev.step(); ref.step()
         assert_same_compound_step(dev, ref, step)
         most = max(most, dev.pipeline_stats().manifolds)
-    assert most > n, "the compounds must have landed on each other and on the slab"
+    assert most > 20, "compounds must have landed on the slab and on each other"
 
 
 def test_no_speculative_margin_and_the_host_bookkeeping_mode():
