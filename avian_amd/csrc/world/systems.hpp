@@ -190,15 +190,35 @@
             ovf_epoch_after_substeps = ovf_epoch;
             return sl;
         }
+        // Round 6: the device closed loop launches its FIRST substep directly and replays the graph for the others.  A graph's first kernel starts ~43 us after
+        // hipGraphLaunch returns (measured, above / profiles/r06_closed_loop_step110_timeline.txt) with the device idle behind the step's front; a direct launch
+        // starts within a few microseconds, and the graph's start-up then hides under the ~190 us the first substep runs.  Same kernels, same order: bit-identical.
+        const bool split = graph_split_enabled && pipe_dev && !groups_active && cfg.substeps >= 2;
+        uint32_t epoch_after_first = 0;
+        if (split) {
+            if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
+            ovf_epoch = 0;
+            substep();
+            epoch_after_first = ovf_epoch;
+            ht("first substep launched directly");
+        }
+        if (graph_valid && (graph_is_split != split || (split && graph_first_epoch != epoch_after_first))) graph_valid = false;
         if (!graph_valid) {
             if (avn_env("AVN_DBG_CAPTURE")) std::fprintf(stderr, "[avn] substep graph re-captured (M %u, overflow grid %u)\n", dw.n_manifolds, ovf_grid_blocks);
             drop_graph();
             uint32_t before = launches;
             HIPCHK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+            avn_status sl = AVN_OK;
+            if (split) {   // substeps 1 .. S-1, continuing the first one's epochs
+                ovf_epoch = epoch_after_first; substep_index = 1;
+                for (uint32_t s = 1; s < cfg.substeps; ++s) substep();
+            } else {
             // the overflow passes' tickets and tile counters restart with every step (a kernel node, replayed first)
             if (flow) { launch_overflow_reset(b_ovf_ticket.as<uint32_t>(), dw.n_bodies + 1, pg.ctr + PGC_OVF_TILE, PGC_OVF_TILES, stream); ++launches; }
             ovf_epoch = 0;
-            const avn_status sl = substep_loop();   // (the side islands' stream joins the capture through the fork event and leaves it at the join)
+            sl = substep_loop();   // (the side islands' stream joins the capture through the fork event and leaves it at the join)
+            }
+            graph_is_split = split; graph_first_epoch = epoch_after_first;
             dw.body_group = 0u;
             ovf_epoch_after_substeps = ovf_epoch;
             // whatever went wrong inside the capture, the stream must leave capture mode and the partial graph must not survive
@@ -226,6 +246,9 @@
         return AVN_OK;
     }
     uint32_t graph_launches = 0;
+    bool graph_is_split = false;          // the captured graph holds substeps 1 .. S-1 (the first one is launched directly)
+    uint32_t graph_first_epoch = 0;       // ... and continues the overflow epochs from here
+    bool graph_split_enabled = !avn_env("AVN_NO_GRAPH_SPLIT");   // (A/B in `make measure` builds)
     bool bodies_prepared_early = false;    // prepare_solver_bodies + pre_process_velocity_increments of this step are already on the stream
     bool constraints_prepared_early = false;   // k_prepare_contact_constraints of this step is already on the stream (pg_apply_ops)
     bool slot_clear_pending = false;       // DW::inc_slot is being set to EMPTY on stream_bp (ev_slot_clear): build_incidence_slots skips its own memset
