@@ -2487,6 +2487,11 @@ template <class S> avn_status World<S>::pipeline_step() {
     diag.broad_phase_ms = 0; diag.narrow_phase_ms = 0;
     timed(diag.broad_phase_ms, [&] { update_aabb(); collect_collision_pairs(); });
     auto np_t0 = std::chrono::steady_clock::now();
+    // AVO_PIPE_TIMING=1 (debug aid): where a closed-loop step of this restatement spends its wall clock
+    static const bool pipe_timing_on = std::getenv("AVO_PIPE_TIMING") != nullptr;
+    double tm_phase[5] = {0, 0, 0, 0, 0};
+    auto tm_last = np_t0;
+    auto tm_mark = [&](int k) { auto now = std::chrono::steady_clock::now(); tm_phase[k] += std::chrono::duration<double, std::milli>(now - tm_last).count(); tm_last = now; };
     new_pair_ids.clear();
     if (!pairs.empty()) {
         std::vector<uint32_t> ids, c1, c2, fl;
@@ -2505,9 +2510,11 @@ template <class S> avn_status World<S>::pipeline_step() {
         P.stats.pairs_added += ids.size();
         if (slp) for (size_t i = 0; i < ids.size(); ++i) { st = slp->isl.pair_add(ids[i], c1[i], c2[i]); if (st != AVN_OK) { error = slp->isl.error; return st; } }
     }
+    tm_mark(0);
     avn_status st = active_pairs_set(P.active.data(), P.active.size());
     if (st != AVN_OK) return st;
     narrow_phase();
+    tm_mark(1);
     auto push = [&](uint32_t cid, uint32_t flags) {
         PipelineState::Pair& p = P.pairs[cid];
         P.graph.push_manifold(((uint64_t)cid << 8) | p.n_handles, (uint32_t)p.b1, (uint32_t)p.b2, flags & AVN_CP_STATIC1, flags & AVN_CP_STATIC2);
@@ -2567,8 +2574,10 @@ template <class S> avn_status World<S>::pipeline_step() {
         slp->isl.flush_wake();
         sleeping_apply(false);
     }
+    tm_mark(2);
     st = pipeline_refresh_handles();
     if (st != AVN_OK) return st;
+    tm_mark(3);
     P.stats.last_overflow_manifolds = P.offsets[AVN_COLOR_OVERFLOW_INDEX + 1] - P.offsets[AVN_COLOR_OVERFLOW_INDEX];
     diag.narrow_phase_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - np_t0).count();
     if (pipe_stats_on) {
@@ -2617,7 +2626,10 @@ template <class S> avn_status World<S>::pipeline_step() {
         std::fprintf(stderr, "[avo pipe] changes %zu push %u pop %u (overflow pops %u, max/colour %u, tail-window pops %u) op depth %u | manifolds %zu overflow %u levels %u | new pairs %zu removed %zu\n",
                      contact_changes.size(), n_push, n_pop, pops_c[AVN_COLOR_OVERFLOW_INDEX], max_pops, win_pops, max_depth, P.handles.size(), P.stats.last_overflow_manifolds, levels, pairs.size(), removed.size());
     }
+    tm_last = std::chrono::steady_clock::now();
     solver();
+    tm_mark(4);
+    if (pipe_timing_on) std::fprintf(stderr, "[avo timing] broad phase %.0f | pair add %.0f | narrow phase %.0f | status loop + removals %.0f | handle lists %.0f | solver %.0f ms\n", diag.broad_phase_ms, tm_phase[0], tm_phase[1], tm_phase[2], tm_phase[3], tm_phase[4]);
     diag.contact_count = (uint32_t)P.active.size();
     if (slp) { sleeping_systems(); return pipeline_refresh_handles(); }   // (SleepIslands / WakeIslands changed the colour lists: what avn_pipeline_handles_get shows is the state after the step)
     return AVN_OK;

@@ -15,7 +15,7 @@ if REPO not in sys.path:
 from avian_amd import _ffi as F  # noqa: E402
 
 ORACLE_DIR = os.path.join(REPO, "oracle")
-ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+ORACLE_SO = os.environ.get("AVO_LIB_PATH") or os.path.join(ORACLE_DIR, "liboracle.so")   # (AVO_LIB_PATH: a sanitizer build of the checker, tools/sanitize_cpu.sh)
 _oracle = None
 
 
