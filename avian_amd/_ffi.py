@@ -310,7 +310,7 @@ ABI_SYMBOLS = [
     "world_create", "world_destroy", "last_error", "config_set", "bodies_upload", "bodies_download",
     "solver_bodies_download", "manifolds_upload", "impulses_download", "constraints_download",
     "distance_joints_upload", "joints_download", "colliders_upload", "existing_pairs_upload", "pairs_get",
-    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "collision_hooks_set", "collision_hook_stats_get", "collider_transforms_upload", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
+    "aabbs_download", "run_system", "step", "synchronize", "timers_get", "diagnostics_get", "halo_plan_upload", "run_color_pass", "halo_pack", "halo_unpack", "comm_unique_id", "comm_init", "islands_get", "sleep_update", "sleep_get", "sleep_reset", "level2_plan_create", "level2_plan_destroy", "level2_plan_rank", "level2_plan_rank_overflow", "halo_overflow_levels_upload", "host_shapes_set", "host_shape_stats_get", "collision_hooks_set", "collision_hook_stats_get", "collider_transforms_upload", "local_accelerations_upload", "halo_joint_slot_set", "level2_plan_create_joints", "level2_plan_rank_joints", "slab_select", "interval_orders_merge", "profile_system", "pair_key", "constraint_graph_create",
     "constraint_graph_destroy", "constraint_graph_push", "constraint_graph_pop", "constraint_graph_lists",
     "islands_partition", "dynamic_bounds", "constraint_graph_push_batch", "joints_upload", "contact_manifolds",
     "collider_materials_upload", "contact_pairs_add", "contact_pairs_remove", "active_pairs_set", "contact_changes_get", "manifold_handles_upload",
@@ -370,6 +370,7 @@ class Library:
         f("host_shape_stats_get").argtypes = [vp, C.POINTER(avn_host_shape_stats)]
         f("collision_hooks_set").argtypes = [vp, HOOK_FILTER_FN, HOOK_MODIFY_FN, vp]
         f("collider_transforms_upload").argtypes = [vp, C.POINTER(avn_collider_transforms)]
+        f("local_accelerations_upload").argtypes = [vp, C.c_uint32, vp, vp]
         f("collision_hook_stats_get").argtypes = [vp, C.POINTER(avn_collision_hook_stats)]
         f("islands_get").argtypes = [vp, vp, C.POINTER(C.c_uint32)]
         f("sleep_update").argtypes = [vp, C.POINTER(avn_sleep_params), C.POINTER(avn_sleep_stats)]
@@ -751,6 +752,16 @@ class World:
         keep = [self._i(is_child, np.uint8), self._s(translation, (c, 3)), self._s(rotation, (c, 4))]
         s = avn_collider_transforms(c, *[_ptr(a) for a in keep])
         self._check(self.lib.fn("collider_transforms_upload")(self.handle, C.byref(s)))
+
+    def local_accelerations_upload(self, linear=None, angular=None):
+        """``avn_local_accelerations_upload``: AccumulatedLocalAcceleration per body (what ConstantLocalForce & co. and ``Forces::apply_local_*`` accumulated),
+        applied by every substep in front of integrate_velocities.  No arguments: no body has one."""
+        if linear is None and angular is None:
+            self._check(self.lib.fn("local_accelerations_upload")(self.handle, 0, None, None))
+            return
+        n = len(linear) if linear is not None else len(angular)
+        keep = [None if linear is None else self._s(linear, (n, 3)), None if angular is None else self._s(angular, (n, 3))]
+        self._check(self.lib.fn("local_accelerations_upload")(self.handle, n, _ptr(keep[0]), _ptr(keep[1])))
 
     def pairs_get(self) -> np.ndarray:
         p, n = vp(), C.c_size_t()

@@ -62,6 +62,7 @@ AVN_API avn_status avn_joints_upload(avn_world* w, const avn_joints* j) { GUARD_
 AVN_API avn_status avn_joints_download(avn_world* w, const avn_joints_out* o) { GUARD(joints_download(o)); }
 AVN_API avn_status avn_colliders_upload(avn_world* w, const avn_colliders* c) { GUARD_MUT(colliders_upload(c)); }
 AVN_API avn_status avn_collider_transforms_upload(avn_world* w, const avn_collider_transforms* t) { GUARD_MUT(collider_transforms_upload(t)); }
+AVN_API avn_status avn_local_accelerations_upload(avn_world* w, uint32_t count, const void* linear, const void* angular) { GUARD_MUT(local_accelerations_upload(count, linear, angular)); }
 AVN_API avn_status avn_existing_pairs_upload(avn_world* w, const uint64_t* k, size_t n) { GUARD_MUT(existing_pairs_upload(k, n)); }
 AVN_API avn_status avn_pairs_get(avn_world* w, const avn_pair** o, size_t* n) { GUARD(pairs_get(o, n)); }
 AVN_API avn_status avn_aabbs_download(avn_world* w, void* mn, void* mx, uint32_t* e, size_t* n) { GUARD(aabbs_download(mn, mx, e, n)); }

@@ -25,6 +25,20 @@ template <class T>
 __device__ __forceinline__ bool integrate_velocities_one(const DW<T>& w, const StepParams<T>& p, uint32_t i, uint32_t sbf, V3<T>& v, V3<T>& om, const Vec4<T>* dq) {
     uint32_t meta = w.bmeta[i];
     bool touched = false;
+    // apply_local_acceleration (forces/plugin.rs:207-241; in IntegrationSystems::Velocity IN FRONT of integrate_velocities, :34-38): every body with a
+    // SolverBody and no CustomVelocityIntegration, kinematic ones included; LockedAxes::apply_to_vec (the translation locks, locked_axes.rs:230-243)
+    // masks BOTH world-space vectors, as written there.  A per-body system: running it here is the reference's order for this body.
+    if (w.lacc_l && !(meta_flags(meta) & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) {
+        Q4<T> rotation = qmul(quat<T>(*dq), quat<T>(w.rot[i]));
+        V3<T> wl = qrot(rotation, xyz<T>(w.lacc_l[i])), wa = qrot(rotation, xyz<T>(w.lacc_a[i]));
+        uint32_t locked = meta_locked(meta);
+        if (locked & 0x20u) { wl.x = T(0); wa.x = T(0); }
+        if (locked & 0x10u) { wl.y = T(0); wa.y = T(0); }
+        if (locked & 0x08u) { wl.z = T(0); wa.z = T(0); }
+        v = v + wl * p.h_f64cast;
+        om = om + wa * p.h_f64cast;
+        touched = true;
+    }
     if (!(meta_flags(meta) & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION) && !(sbf & AVN_SB_KINEMATIC)) {
         Vec4<T> il = w.vid_l[i], ia = w.vid_a[i];
         v = v * il.w;

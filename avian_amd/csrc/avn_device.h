@@ -92,6 +92,9 @@ template <class T> struct DW {
     V* iloc_b;     // (m12, m22, max_linear_speed, max_angular_speed)
     V* acc_l;      // (accumulated linear acceleration.xyz, 0)
     V* acc_a;      // (accumulated angular acceleration.xyz, 0)
+    // AccumulatedLocalAcceleration (forces/mod.rs:661-673; avn_local_accelerations_upload): nullptr = no body has one
+    const V* lacc_l;   // (local linear acceleration.xyz, 0)
+    const V* lacc_a;   // (local angular acceleration.xyz, 0)
     uint32_t* bmeta;
     // ---- solver bodies (SolverBody / SolverBodyInertia / VelocityIntegrationData) ----
     Pair2<V> sb_lin;   // (linear_velocity.xyz, 0)      \ one 2-record slot per body

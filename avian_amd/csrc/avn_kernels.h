@@ -368,6 +368,7 @@ template <class T> struct ColliderStage {
 template <class T> void launch_pack_colliders(const BP<T>&, const ColliderStage<T>&, hipStream_t);
 // unpack: device records -> planar staging arrays laid out like the *_out structs (nullptr = skip)
 template <class T> void launch_unpack_bodies(const DW<T>&, T* position, T* rotation, T* linear_velocity, T* angular_velocity, hipStream_t);
+template <class T> void launch_pack_local_accelerations(Vec4<T>* lin, Vec4<T>* ang, const T* s_lin, const T* s_ang, uint32_t n, hipStream_t);
 template <class T> struct SolverBodiesStage {
     T *linear_velocity, *angular_velocity, *delta_position, *delta_rotation, *inv_mass, *inv_inertia_world, *linear_increment, *angular_increment,
         *linear_damping_rhs, *angular_damping_rhs;

@@ -139,6 +139,7 @@ template <class T> struct World : WorldBase {
     uint32_t cap_bodies = 0, cap_manifolds = 0, cap_joints = 0, cap_colliders = 0;
     // body buffers (Vec4 each)
     DevBuf b_pos, b_rot, b_lvel, b_avel, b_com, b_iloc_a, b_iloc_b, b_acc_l, b_acc_a, b_bmeta;
+    DevBuf b_lacc_l, b_lacc_a;   // AccumulatedLocalAcceleration (avn_local_accelerations_upload); dw.lacc_l == nullptr while no body has one
     DevBuf b_sb_vel, b_sb_delta, b_si, b_vid_l, b_vid_a, b_pre_dp, b_pre_dq, b_sb_flags;
     DevBuf b_m_bodies, b_m_n, b_m_tv, b_m_meta, b_mp_a1, b_mp_a2, b_mp_w, b_c_h1, b_c_pa, b_c_pb, b_c_pc, b_c_pd, b_c_reldom, b_misc;
     DevBuf b_j_bodies, b_j_a1, b_j_a2, b_j_par, b_j_b1, b_j_b2, b_j_ax, b_j_l2, b_j_r1, b_j_r2, b_j_cd, b_j_lag, b_j_s0, b_j_s1, b_j_s2, b_j_s3, b_j_rl0, b_j_rl1, b_j_force,

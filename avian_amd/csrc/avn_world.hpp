@@ -75,6 +75,7 @@ struct WorldBase {
     virtual avn_status joints_download(const avn_joints_out*) = 0;
     virtual avn_status colliders_upload(const avn_colliders*) = 0;
     virtual avn_status collider_transforms_upload(const avn_collider_transforms*) = 0;
+    virtual avn_status local_accelerations_upload(uint32_t count, const void* linear, const void* angular) = 0;
     virtual avn_status existing_pairs_upload(const uint64_t*, size_t) = 0;
     virtual avn_status pairs_get(const avn_pair**, size_t*) = 0;
     virtual avn_status aabbs_download(void*, void*, uint32_t*, size_t*) = 0;

@@ -41,6 +41,15 @@ __global__ __launch_bounds__(256) void k_pack_bodies(DW<T> w, BodyStage<T> s) {
     w.sb_flags[i] = meta_has_solver_body(meta) ? 0u : AVN_SBF_NO_SOLVER_BODY;
 }
 
+// avn_local_accelerations_upload: AccumulatedLocalAcceleration::{linear, angular} per body (either array may be absent = zero)
+template <class T>
+__global__ __launch_bounds__(256) void k_pack_local_accelerations(Vec4<T>* lin, Vec4<T>* ang, const T* s_lin, const T* s_ang, uint32_t n) {
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    lin[i] = make4<T>(ld3(s_lin, i), 0);
+    ang[i] = make4<T>(ld3(s_ang, i), 0);
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void k_pack_manifolds(DW<T> w, ManifoldStage<T> s) {
     uint32_t m = blockIdx.x * 256 + threadIdx.x;
@@ -188,6 +197,7 @@ template <class T> void launch_pack_bodies(const DW<T>& w, const BodyStage<T>& s
 template <class T> void launch_pack_manifolds(const DW<T>& w, const ManifoldStage<T>& s, hipStream_t st) { if (w.n_manifolds) hipLaunchKernelGGL(k_pack_manifolds<T>, g256(w.n_manifolds), dim3(256), 0, st, w, s); }
 template <class T> void launch_pack_joints(const DW<T>& w, const JointStage<T>& s, hipStream_t st) { if (w.n_joints) hipLaunchKernelGGL(k_pack_joints<T>, g256(w.n_joints), dim3(256), 0, st, w, s); }
 template <class T> void launch_pack_colliders(const BP<T>& bp, const ColliderStage<T>& s, hipStream_t st) { if (bp.n_colliders) hipLaunchKernelGGL(k_pack_colliders<T>, g256(bp.n_colliders), dim3(256), 0, st, bp, s); }
+template <class T> void launch_pack_local_accelerations(Vec4<T>* lin, Vec4<T>* ang, const T* s_lin, const T* s_ang, uint32_t n, hipStream_t st) { if (n) hipLaunchKernelGGL(k_pack_local_accelerations<T>, g256(n), dim3(256), 0, st, lin, ang, s_lin, s_ang, n); }
 template <class T> void launch_unpack_bodies(const DW<T>& w, T* p, T* r, T* l, T* a, hipStream_t st) { if (w.n_bodies) hipLaunchKernelGGL(k_unpack_bodies<T>, g256(w.n_bodies), dim3(256), 0, st, w, p, r, l, a); }
 template <class T> void launch_unpack_solver_bodies(const DW<T>& w, const SolverBodiesStage<T>& o, hipStream_t st) { if (w.n_bodies) hipLaunchKernelGGL(k_unpack_solver_bodies<T>, g256(w.n_bodies), dim3(256), 0, st, w, o); }
 template <class T> void launch_unpack_impulses(const DW<T>& w, T* a, T* b, T* c, hipStream_t st) { if (w.n_manifolds) hipLaunchKernelGGL(k_unpack_impulses<T>, g256(w.n_manifolds), dim3(256), 0, st, w, a, b, c); }
@@ -289,6 +299,7 @@ template <class T> void launch_dsh_unpack(const DW<T>& w, const uint32_t* bodies
     template void launch_pack_joints<T>(const DW<T>&, const JointStage<T>&, hipStream_t);           \
     template void launch_pack_colliders<T>(const BP<T>&, const ColliderStage<T>&, hipStream_t);     \
     template void launch_unpack_bodies<T>(const DW<T>&, T*, T*, T*, T*, hipStream_t);               \
+    template void launch_pack_local_accelerations<T>(Vec4<T>*, Vec4<T>*, const T*, const T*, uint32_t, hipStream_t); \
     template void launch_unpack_solver_bodies<T>(const DW<T>&, const SolverBodiesStage<T>&, hipStream_t); \
     template void launch_unpack_impulses<T>(const DW<T>&, T*, T*, T*, hipStream_t);                 \
     template void launch_unpack_constraints<T>(const DW<T>&, const ConstraintsStage<T>&, hipStream_t); \

@@ -32,6 +32,7 @@
             cap_bodies = (uint32_t)c;
             if (pipe_dev) { avn_status sg = pg_bcol_grow(); if (sg != AVN_OK) return sg; }   // bodies spawned inside the closed loop: their colour masks start empty
         }
+        if (dw.n_bodies != n && dw.lacc_l) { dw.lacc_l = dw.lacc_a = nullptr; graph_valid = false; }   // (header: an upload with another body count drops the local accelerations)
         if (moved || dw.n_bodies != n) graph_valid = false;
         if (have_bodies && n < dw.n_bodies && !after_despawn) {
             // fewer bodies than before: everything that may still index a body >= n is dropped (the host re-uploads it; nothing
@@ -104,6 +105,30 @@
         incidence_dirty = true;
         have_bodies = true;
         despawn_needs_bodies = false;
+        HIPCHK(hipStreamSynchronize(stream));  // host arrays are only borrowed for the call
+        return AVN_OK;
+    }
+    // AccumulatedLocalAcceleration (forces/mod.rs:661-673), consumed by apply_local_acceleration in front of integrate_velocities in every substep
+    // (forces/plugin.rs:207-241): avn_body_ops.h integrate_velocities_one
+    avn_status local_accelerations_upload(uint32_t count, const void* linear, const void* angular) override {
+        if (count == 0 || (!linear && !angular)) {
+            if (dw.lacc_l) { dw.lacc_l = dw.lacc_a = nullptr; graph_valid = false; }
+            return AVN_OK;
+        }
+        if (!have_bodies || count != dw.n_bodies) { error = "local_accelerations_upload: count differs from the last bodies_upload"; return AVN_ERR_BAD_ARG; }
+        if (despawn_needs_bodies) { error = "local_accelerations_upload: avn_despawn removed bodies: upload the remaining bodies (avn_bodies_upload) first"; return AVN_ERR_STATE; }
+        slp_world_asleep = slp_world_idle = false;
+        bool moved = false;
+        Vec4<T>*dl = nullptr, *da = nullptr;
+        HIPCHK(hipStreamSynchronize(stream));
+        GROW(b_lacc_l, (size_t)cap_bodies, dl); GROW(b_lacc_a, (size_t)cap_bodies, da);
+        avn_status st = stage_reserve(al(sizeof(T) * 3 * (size_t)count) * 2 + 1024);
+        if (st != AVN_OK) return st;
+        const T *sl = nullptr, *sa = nullptr;
+        if ((st = stage_in<T>(linear, 3 * (size_t)count, &sl)) != AVN_OK || (st = stage_in<T>(angular, 3 * (size_t)count, &sa)) != AVN_OK) return st;
+        launch_pack_local_accelerations<T>(dl, da, sl, sa, count, stream);
+        HIPCHK(hipGetLastError());
+        if (dw.lacc_l != dl || dw.lacc_a != da) { dw.lacc_l = dl; dw.lacc_a = da; graph_valid = false; }
         HIPCHK(hipStreamSynchronize(stream));  // host arrays are only borrowed for the call
         return AVN_OK;
     }

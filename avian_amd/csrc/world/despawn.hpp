@@ -245,6 +245,7 @@
                 if ((st = build_hash_set(b_disabled_set, bp.disabled_set, bp.disabled_cap, disabled.data(), (uint32_t)disabled.size())) != AVN_OK) return st;
             }
             for (uint32_t s_ = 0; s_ < h_col_body.size(); ++s_) h_col_body[s_] = (h_col_body[s_] >= 0 && !gone_body[(uint32_t)h_col_body[s_]]) ? (int32_t)new_index[(uint32_t)h_col_body[s_]] : -1;
+            dw.lacc_l = dw.lacc_a = nullptr;   // (header: a despawn of bodies drops the local accelerations; the host uploads them again for what remains)
             joint_schedule_dirty = true; groups_dirty = true; incidence_dirty = true; graph_valid = false;
             isl_labels_step_valid = false; island_backoff = 0;
             despawn_needs_bodies = true; despawn_expected_bodies = n_new;

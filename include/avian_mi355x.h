@@ -610,6 +610,21 @@ AVN_API avn_status AVN_FN(bodies_upload)(avn_world* w, const avn_bodies* b);
 /* replaces the writes of writeback_solver_bodies */
 AVN_API avn_status AVN_FN(bodies_download)(avn_world* w, const avn_bodies_out* out);
 AVN_API avn_status AVN_FN(solver_bodies_download)(avn_world* w, const avn_solver_bodies_out* out);
+/* AccumulatedLocalAcceleration (dynamics/rigid_body/forces/mod.rs:661-673: what ConstantLocalForce / ConstantLocalTorque /
+ * ConstantLocalLinearAcceleration / ConstantLocalAngularAcceleration and Forces::apply_local_* accumulate before the step,
+ * forces/plugin.rs:145-203), consumed by apply_local_acceleration -- a SubstepSchedule system in front of integrate_velocities
+ * (forces/plugin.rs:34-38,62-65,207-241).  Replaces that system: in EVERY substep, for every body that has a SolverBody and no
+ * CustomVelocityIntegration (kinematic bodies included: the reference's query has no body-type filter),
+ *     rotation = SolverBody::delta_rotation * Rotation;  v += locked(rotation * linear) * h;  omega += locked(rotation * angular) * h
+ * with h = Time<Substeps>::delta_secs_f64() as Scalar and `locked` = LockedAxes::apply_to_vec for BOTH vectors (the TRANSLATION locks
+ * also mask the angular acceleration: forces/plugin.rs:227-230 with rigid_body/locked_axes.rs:230-243 -- restated as written).
+ *   linear, angular: [3n] scalars of the world's type, n = the number of bodies of the last avn_bodies_upload; either may be NULL = zero.
+ *   count 0 (or both NULL): no body has a local acceleration -- the system costs nothing (every RigidBody carries the component in the
+ *   reference, all zero by default: adding rotation * 0 changes at most the sign of a zero velocity component).
+ * The values stay in effect until the next call, an avn_bodies_upload with another body count, or avn_despawn (all three drop them).  The
+ * reference clears the component after every step (clear_accumulated_local_acceleration, forces/plugin.rs:68-71,243-251) and accumulates it
+ * again before the next: a host mirrors that by uploading what it accumulated before each step (count 0 once nothing is left). */
+AVN_API avn_status AVN_FN(local_accelerations_upload)(avn_world* w, uint32_t count, const void* linear, const void* angular);
 
 /* replaces the ContactGraph/ConstraintGraph reads of prepare_contact_constraints */
 AVN_API avn_status AVN_FN(manifolds_upload)(avn_world* w, const avn_manifolds* m);

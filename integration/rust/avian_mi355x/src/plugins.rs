@@ -6,6 +6,7 @@ use avian3d::{
     collision::{broad_phase::BroadPhaseSystems, narrow_phase::NarrowPhaseConfig},
     dynamics::{
         integrator::IntegrationSystems,
+        rigid_body::forces::AccumulatedLocalAcceleration,
         solver::{
             constraint_graph::ConstraintGraph,
             schedule::{SolverSystems, SubstepCount},
@@ -150,7 +151,7 @@ fn sync_config(
 /// (src/collision/collider/backend.rs:498-624) read.
 fn gpu_upload_bodies(
     mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
-    increments: Query<&VelocityIntegrationData>,
+    increments: Query<&VelocityIntegrationData>, local_accelerations: Query<&AccumulatedLocalAcceleration>,
     colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>, Option<&ColliderTransform>)>,
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
     js: Res<crate::joints::JointStaging>,
@@ -183,6 +184,12 @@ fn gpu_upload_bodies(
     let raw = w.raw();
     let s1 = unsafe { ffi::avn_bodies_upload(raw, &b) }; w.check(s1);
     let s2 = unsafe { ffi::avn_colliders_upload(raw, &c) }; w.check(s2);
+    // apply_local_acceleration (ForceSystems::ApplyLocalAcceleration, a SubstepSchedule system in front of integrate_velocities): the device runs it inside
+    // integrate_velocities from what ForcePlugin accumulated for this step; bodies_upload keeps the previous values only for an unchanged body count
+    st.fill_local_accelerations(|e| local_accelerations.get(e).ok().map(|a| (a.linear, a.angular)));
+    let s4 = if st.local_accel_any { unsafe { ffi::avn_local_accelerations_upload(raw, st.body_entities.len() as u32, st.local_accel_linear.as_ptr().cast(), st.local_accel_angular.as_ptr().cast()) } }
+             else { unsafe { ffi::avn_local_accelerations_upload(raw, 0, core::ptr::null(), core::ptr::null()) } };
+    w.check(s4);
     // compound bodies: the ColliderTransform of the colliders that are child entities (the device computes their Position / Rotation from the bodies': update_child_collider_position)
     if st.c_is_child.iter().any(|&c| c != 0) { let t = st.collider_transforms_desc(); let s3 = unsafe { ffi::avn_collider_transforms_upload(raw, &t) }; w.check(s3); }
 }

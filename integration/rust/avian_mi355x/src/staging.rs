@@ -18,6 +18,9 @@ pub struct Staging {
     pub linear_damping: Vec<f32>, pub angular_damping: Vec<f32>, pub gravity_scale: Vec<f32>,
     pub accel_linear: Vec<f32>, pub accel_angular: Vec<f32>, pub max_linear_speed: Vec<f32>, pub max_angular_speed: Vec<f32>,
     pub rb_type: Vec<u8>, pub locked_axes: Vec<u8>, pub dominance: Vec<i8>, pub body_flags: Vec<u8>,
+    /// `AccumulatedLocalAcceleration` per body (src/dynamics/rigid_body/forces/mod.rs:661-673), for `avn_local_accelerations_upload`; `local_accel_any`:
+    /// some body's is non-zero this step (all zero = the call is made with count 0 and the substep system costs nothing)
+    pub local_accel_linear: Vec<f32>, pub local_accel_angular: Vec<f32>, pub local_accel_any: bool,
     // avn_colliders
     pub collider_entities: Vec<Entity>,
     /// `Entity::index()` of a collider -> its slot of the last upload (what a device pair's collider index resolves through)
@@ -82,6 +85,18 @@ impl Staging {
             self.locked_axes.push(locked.map_or(0, |l| l.to_bits()));
             self.dominance.push(dom.map_or(0, |d| d.0));
             self.body_flags.push((if sleeping { ffi::AVN_BODY_SLEEPING } else { 0 } | if disabled { ffi::AVN_BODY_DISABLED } else { 0 }) as u8);
+        }
+    }
+
+    /// What `apply_local_acceleration` reads (src/dynamics/rigid_body/forces/plugin.rs:207-241), in the body order of the last `fill_bodies`:
+    /// ForcePlugin's own systems have accumulated ConstantLocalForce & co. and `Forces::apply_local_*` into the component before the step (:145-203) and
+    /// clear it after (:243-251) -- both stay Avian's; only the substep system that consumes it runs on the device.
+    pub fn fill_local_accelerations(&mut self, get: impl Fn(Entity) -> Option<(Vec3, Vec3)>) {
+        self.local_accel_linear.clear(); self.local_accel_angular.clear(); self.local_accel_any = false;
+        for &e in &self.body_entities {
+            let (l, a) = get(e).unwrap_or((Vec3::ZERO, Vec3::ZERO));
+            self.local_accel_any |= l != Vec3::ZERO || a != Vec3::ZERO;
+            push3(&mut self.local_accel_linear, l); push3(&mut self.local_accel_angular, a);
         }
     }
 

@@ -277,6 +277,7 @@ struct WorldBase {
     virtual avn_status bodies_upload(const avn_bodies*) = 0;
     virtual avn_status bodies_download(const avn_bodies_out*) = 0;
     virtual avn_status solver_bodies_download(const avn_solver_bodies_out*) = 0;
+    virtual avn_status local_accelerations_upload(uint32_t, const void*, const void*) = 0;
     virtual avn_status manifolds_upload(const avn_manifolds*) = 0;
     virtual avn_status impulses_download(const avn_impulses_out*) = 0;
     virtual avn_status constraints_download(const avn_constraints_out*) = 0;
@@ -527,6 +528,7 @@ template <class S> struct World : WorldBase {
         size_t n = b->count;
         if (despawn_needs_bodies && n != bodies.size()) { error = "bodies_upload: after avn_despawn exactly the remaining bodies must be uploaded"; return AVN_ERR_STATE; }
         despawn_needs_bodies = false;
+        if (n != bodies.size()) { local_acc_linear.clear(); local_acc_angular.clear(); }   // (header: dropped by an upload with another body count)
         bodies.resize(n);
         accel_linear.resize(n);
         accel_angular.resize(n);
@@ -569,6 +571,15 @@ template <class S> struct World : WorldBase {
                 if (!slp->disabled.empty() && slp->disabled.size() < n) slp->disabled.resize(n, 0);
             }
         }
+        return AVN_OK;
+    }
+    // AccumulatedLocalAcceleration per body (forces/mod.rs:661-673); empty = no body has one (header: avn_local_accelerations_upload)
+    std::vector<V3<S>> local_acc_linear, local_acc_angular;
+    avn_status local_accelerations_upload(uint32_t count, const void* linear, const void* angular) override {
+        if (count == 0 || (!linear && !angular)) { local_acc_linear.clear(); local_acc_angular.clear(); return AVN_OK; }
+        if (count != bodies.size()) { error = "local_accelerations_upload: count differs from the last bodies_upload"; return AVN_ERR_BAD_ARG; }
+        local_acc_linear.resize(count); local_acc_angular.resize(count);
+        for (size_t i = 0; i < count; ++i) { local_acc_linear[i] = rd3(linear, i); local_acc_angular[i] = rd3(angular, i); }
         return AVN_OK;
     }
     avn_status bodies_download(const avn_bodies_out* o) override {
@@ -824,6 +835,20 @@ template <class S> struct World : WorldBase {
     // integrator/mod.rs:343-391, then clamp_velocities :467-500
     void integrate_velocities() {
         S delta_secs = h_f64cast;
+        // apply_local_acceleration, forces/plugin.rs:207-241 (ForceSystems::ApplyLocalAcceleration: in IntegrationSystems::Velocity, before integrate_velocities,
+        // :34-38): every (SolverBody, AccumulatedLocalAcceleration, Rotation) Without<CustomVelocityIntegration> -- kinematic bodies too; apply_to_vec (the
+        // TRANSLATION locks, locked_axes.rs:230-243) masks both vectors, as written there
+        if (!local_acc_linear.empty())
+            par_bodies([&](size_t i, Body<S>& b) {
+                if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) return;
+                const Q4<S> rotation = qmul(b.sb.delta_rotation, b.rotation);
+                const uint32_t locked = b.sb.flags & 0x3Fu;
+                auto apply_to_vec = [&](V3<S> v) { if (locked & 0x20u) v.x = S(0); if (locked & 0x10u) v.y = S(0); if (locked & 0x08u) v.z = S(0); return v; };
+                const V3<S> world_linear_acceleration = apply_to_vec(qrot(rotation, local_acc_linear[i]));
+                const V3<S> world_angular_acceleration = apply_to_vec(qrot(rotation, local_acc_angular[i]));
+                b.sb.linear_velocity = b.sb.linear_velocity + world_linear_acceleration * delta_secs;
+                b.sb.angular_velocity = b.sb.angular_velocity + world_angular_acceleration * delta_secs;
+            });
         par_bodies([&](size_t, Body<S>& b) {
             if (!b.has_solver_body || (b.body_flags & AVN_BODY_CUSTOM_VELOCITY_INTEGRATION)) return;
             if (b.sb.is_kinematic()) return;
@@ -2847,6 +2872,7 @@ template <class S> avn_status World<S>::despawn(const avn_despawn_list* d) {
         nb.reserve(n_new); al.reserve(n_new); aa.reserve(n_new);
         for (size_t b = 0; b < n_old; ++b) if (!gone_body[b]) { nb.push_back(bodies[b]); al.push_back(accel_linear[b]); aa.push_back(accel_angular[b]); }
         bodies.swap(nb); accel_linear.swap(al); accel_angular.swap(aa);
+        if (d->n_bodies) { local_acc_linear.clear(); local_acc_angular.clear(); }   // (header: a despawn of bodies drops the local accelerations: the host uploads them again for what remains)
     }
     // colliders: the despawned ones leave; the others keep their relative slot order, intervals are retained in place (broad_phase.rs:230-279)
     {

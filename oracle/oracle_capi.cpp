@@ -234,6 +234,7 @@ avn_status avo_level2_plan_rank_overflow(const avn_level2_plan* plan, uint32_t r
 avn_status avo_host_shapes_set(avn_world* w, avn_host_aabb_fn a, avn_host_manifolds_fn m, void* user) { FWD(host_shapes_set(a, m, user)); }
 avn_status avo_host_shape_stats_get(avn_world* w, avn_host_shape_stats* o) { FWD(host_shape_stats_get(o)); }
 avn_status avo_collider_transforms_upload(avn_world* w, const avn_collider_transforms* t) { FWD(collider_transforms_upload(t)); }
+avn_status avo_local_accelerations_upload(avn_world* w, uint32_t count, const void* linear, const void* angular) { FWD(local_accelerations_upload(count, linear, angular)); }
 avn_status avo_collision_hooks_set(avn_world* w, avn_filter_pairs_fn f, avn_modify_contacts_fn m, void* user) { FWD(collision_hooks_set(f, m, user)); }
 avn_status avo_collision_hook_stats_get(avn_world* w, avn_collision_hook_stats* o) { FWD(collision_hook_stats_get(o)); }
 avn_status avo_level2_plan_rank_joints(const avn_level2_plan* plan, uint32_t rank, uint32_t* n_joints, const uint32_t** joints, uint32_t* joint_slot, uint32_t* global_joints) {

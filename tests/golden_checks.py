@@ -31,6 +31,10 @@ def run_kat(lib, case, bits=32, **cfgkw):
               accel_linear=arr("accel_linear", [0, 0, 0]), accel_angular=arr("accel_angular", [0, 0, 0]))
     imp = arr("impulse_linear", [0, 0, 0])   # Forces::apply_linear_impulse in FixedUpdate: LinearVelocity += J / m BEFORE every physics step
     impa = arr("impulse_angular", [0, 0, 0])  # apply_angular_impulse: AngularVelocity += I_world^-1 J (isotropic inertia in these tests: I^-1 = inv_inertia_local[0])
+    # Forces::apply_local_force / _torque / _linear_acceleration / _angular_acceleration accumulate into AccumulatedLocalAcceleration in the body's LOCAL frame
+    # (forces/query_data.rs:344-349,374-379,526-530,554-558); apply_local_acceleration turns it into the world every substep (forces/plugin.rs:207-241)
+    lacc_l, lacc_a = arr("local_accel_linear", [0, 0, 0]), arr("local_accel_angular", [0, 0, 0])
+    local = np.any(lacc_l) or np.any(lacc_a)
     kick = np.any(imp) or np.any(impa)
     reupload = kick or np.any(kw["accel_linear"]) or np.any(kw["accel_angular"])
     for s in range(case["steps"]):
@@ -44,6 +48,8 @@ def run_kat(lib, case, bits=32, **cfgkw):
             kw["angular_velocity"] = np.asarray(kw["angular_velocity"], np.float64) + impa * kw["inv_inertia_local"][:, :1]
         if s == 0 or reupload:
             w.bodies_upload(**kw)
+        if local:   # (cleared after every step and accumulated again before the next: clear_accumulated_local_acceleration, forces/plugin.rs:243-251)
+            w.local_accelerations_upload(lacc_l, lacc_a)
         w.step()
     w.synchronize()
     out = w.bodies_download()
