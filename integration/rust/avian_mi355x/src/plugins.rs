@@ -152,7 +152,8 @@ fn sync_config(
 fn gpu_upload_bodies(
     mut w: ResMut<Mi355xWorld>, mut st: ResMut<Mi355xStaging>, bodies: Query<crate::staging::BodyItem<'static>>,
     increments: Query<&VelocityIntegrationData>, local_accelerations: Query<&AccumulatedLocalAcceleration>,
-    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>, Option<&ColliderTransform>)>,
+    colliders: Query<(Entity, &Collider, &ColliderOf, &CollisionLayers, Option<&CollisionMargin>, Option<&SpeculativeMargin>, Has<Sensor>, Has<CollisionEventsEnabled>, Option<&ActiveCollisionHooks>, Option<&ColliderTransform>), Without<ColliderDisabled>>,   // (the filter of the reference's intervals and narrow phase: src/collision/broad_phase.rs:84,225,297, narrow_phase/system_param.rs:70)
+    newly_disabled_colliders: Query<Entity, Added<ColliderDisabled>>,   // leave like despawned ones (remove_collider_on::<Add, (Disabled, ColliderDisabled)>, narrow_phase/mod.rs:153); they come back as new colliders when the component is removed (broad_phase.rs:117-130)
     mut removed_bodies: RemovedComponents<RigidBody>, mut removed_colliders: RemovedComponents<ColliderMarker>,
     js: Res<crate::joints::JointStaging>,
     live_joints: Query<(), (Or<(With<FixedJoint>, With<RevoluteJoint>, With<SphericalJoint>, With<PrismaticJoint>, With<DistanceJoint>)>, Without<JointDisabled>)>,
@@ -170,7 +171,7 @@ fn gpu_upload_bodies(
     // ConstraintGraph / islands without restarting the loop (round 4; it used to be avn_pipeline_enable(0 / 1): a step without warm starting).
     let gone_bodies: Vec<u32> = removed_bodies.read().filter_map(|e| st.body_index.get(&e).map(|&i| i as u32)).collect();
     let gone_of_bodies: std::collections::HashSet<u32> = gone_bodies.iter().copied().collect();
-    let gone_colliders: Vec<u32> = removed_colliders.read()
+    let gone_colliders: Vec<u32> = removed_colliders.read().chain(newly_disabled_colliders.iter())
         .filter(|e| st.collider_slot.get(&e.index()).is_some_and(|&s| !gone_of_bodies.contains(&(st.c_body[s] as u32))))   // (a body's own colliders leave with it)
         .map(|e| e.index()).collect();
     // joints of the last upload that are gone: their entity lost its joint component (or gained JointDisabled), or one of their bodies was despawned
