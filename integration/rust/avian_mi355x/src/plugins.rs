@@ -67,7 +67,7 @@ impl Mi355xSettings {
         if self.mode == Mi355xMode::HostNarrowPhase { return Mi355xMode::HostNarrowPhase; }
         if st.colliders_unsupported != 0 {
             if !self.warned_hooks && self.mode == Mi355xMode::ClosedLoop {
-                bevy::log::warn!("avian_mi355x: {} collider(s) are not on a known rigid body: running in HostNarrowPhase mode", st.colliders_unsupported);
+                bevy::log::warn!("avian_mi355x: {} collider(s) are not on a known rigid body or have a composite shape (trimesh, heightfield, compound: several manifolds per pair): running in HostNarrowPhase mode", st.colliders_unsupported);
                 self.warned_hooks = true;
             }
             return Mi355xMode::HostNarrowPhase;

@@ -27,7 +27,7 @@ pub struct Staging {
     pub collider_slot: bevy::platform::collections::HashMap<u32, usize>,
     /// colliders of the last upload that carry `ActiveCollisionHooks` (filter_pairs / modify_contacts need the host narrow phase)
     pub colliders_with_hooks: usize,
-    /// colliders the device narrow phase cannot take (neither Ball nor Cuboid, or not on a body the staging knows): with any of them the
+    /// colliders the closed loop cannot take (not on a body the staging knows, or a COMPOSITE shape -- several manifolds per pair): with any of them the
     /// step must keep Avian's own narrow phase (`Mi355xSettings::effective_mode`)
     pub colliders_unsupported: usize,
     pub c_entity_index: Vec<u32>, pub c_body: Vec<i32>, pub c_shape: Vec<u8>, pub c_half_extents: Vec<f32>,
@@ -131,6 +131,11 @@ impl Staging {
                              else if let Some(c) = shape.as_cuboid() { (ffi::AVN_SHAPE_CUBOID, Vec3::new(c.half_extents.x, c.half_extents.y, c.half_extents.z)) }
                              else { (ffi::AVN_SHAPE_HOST, Vec3::ZERO) };   // capsule, cylinder, cone, convex hull, ...: aabb / contact_manifolds stay on the host
             let Some(&body) = self.body_index.get(&of.body) else { self.colliders_unsupported += 1; continue };
+            // A composite shape (TriMesh, HeightField, Compound, Polyline, Voxels) answers contact_manifolds with SEVERAL manifolds per pair, each pushed into a colour of
+            // its own (src/dynamics/solver/constraint_graph.rs:162-236); the device's contact rows hold one manifold per pair (include/avian_mi355x.h, host shapes: "convex
+            // shapes"), so such a world keeps Avian's narrow phase and ContactGraph (HostNarrowPhase mode: every manifold of every pair is uploaded) instead of silently
+            // solving manifolds[0] only.
+            if kind == ffi::AVN_SHAPE_HOST && shape.as_composite_shape().is_some() { self.colliders_unsupported += 1; }
             if kind == ffi::AVN_SHAPE_HOST { host_shapes.colliders.insert(e.index(), collider.clone()); }
             self.collider_slot.insert(e.index(), self.collider_entities.len());
             // ActiveCollisionHooks (src/collision/hooks.rs:213-231): which of the two hooks this collider asks for (broad_phase.rs:266-273)
