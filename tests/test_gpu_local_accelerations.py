@@ -120,3 +120,27 @@ def test_kinematic_custom_and_errors_on_the_device():
         color_and_upload(w, oracle_lib(), wd2); w.step()
         outs.append(w.bodies_download())
     for k in outs[0]: assert_same(outs[0][k], outs[1][k], k)
+
+
+def test_despawn_drops_the_values_and_the_host_uploads_them_for_what_remains():
+    """avn_despawn renumbers the bodies: the library drops the local accelerations (header) and the host brings them back for the compacted set."""
+    from test_gpu_despawn import despawn_both, make_pair as make_loop_pair
+    bodies, colliders = dropped_boxes(seed=43, n=48)
+    n = len(bodies["inv_mass"])
+    lin, ang = random_local_accelerations(11, n, fraction=0.5)
+    wo, wh = make_loop_pair(bodies, colliders)
+    for w in (wo, wh): w.local_accelerations_upload(lin, ang)
+    for s in range(20):
+        wo.step(); wh.step()
+    gone = [5, 17, 18, 30]
+    keep = np.ones(n, bool); keep[gone] = False
+    despawn_both((wo, wh), bodies, colliders, gone)
+    for s in range(3):   # nothing uploaded yet: the remaining bodies coast without their thrusters, on both sides alike
+        wo.step(); wh.step()
+        bo, bh = wo.bodies_download(), wh.bodies_download()
+        for k in bo: assert_same(bo[k], bh[k], f"after despawn, step {s}: bodies.{k}")
+    for w in (wo, wh): w.local_accelerations_upload(lin[keep], ang[keep])
+    for s in range(15):
+        wo.step(); wh.step()
+        bo, bh = wo.bodies_download(), wh.bodies_download()
+        for k in bo: assert_same(bo[k], bh[k], f"values back, step {s}: bodies.{k}")

@@ -87,3 +87,43 @@ def test_values_stay_until_replaced_and_are_dropped_by_another_body_count():
     w.step(); w1.step()
     a, b = w.bodies_download(), w1.bodies_download()
     for k in a: assert_same(a[k], b[k], k)
+
+
+def test_despawn_drops_the_values():
+    """After avn_despawn of bodies the oracle holds no local acceleration until the host uploads them for the remaining bodies (header)."""
+    from pipeline_scenes import dropped_boxes
+    from test_despawn_cpu import subset
+    bodies, colliders = dropped_boxes(seed=43, n=24)
+    n = len(bodies["inv_mass"])
+    lin, ang = random_local_accelerations(11, n, fraction=0.8)
+
+    def world(b, c):
+        w = F.World(oracle_lib(), F.default_config(32, substeps=4))
+        w.bodies_upload(**b); w.colliders_upload(**c)
+        w.existing_pairs_upload(np.zeros(0, np.uint64)); w.collider_materials_upload(friction=0.5)
+        w.pipeline_enable()
+        return w
+    w = world(bodies, colliders)
+    w.local_accelerations_upload(lin, ang)
+    for _ in range(5): w.step()
+    state = w.bodies_download()
+    gone = [n - 1]   # (the last body: the remaining indices keep their numbers)
+    mask = np.ones(n, bool); mask[gone] = False
+    cmask = mask[np.asarray(colliders["body"])]
+    w.despawn(bodies=gone, collider_entities=())
+    nb = subset(bodies, mask)
+    for k in ("position", "rotation", "linear_velocity", "angular_velocity"): nb[k] = state[k][mask].astype(np.float64)
+    nc = {k: (np.asarray(v)[cmask] if isinstance(v, np.ndarray) and len(v) == len(cmask) else v) for k, v in colliders.items()}
+    w.bodies_upload(**nb); w.colliders_upload(**nc); w.collider_materials_upload(friction=0.5)
+    before = w.bodies_download()
+    w.step()
+    after = w.bodies_download()
+    # a body in free flight (far above the pile) with a thruster but no upload after the despawn: only gravity acts on it
+    dv = after["linear_velocity"] - before["linear_velocity"]
+    free = np.argmax(before["position"][:, 1])
+    assert np.any(lin[mask][free] != 0), "pick a seed whose topmost body has a thruster"
+    assert abs(dv[free][0]) < 1e-6 and abs(dv[free][2]) < 1e-6 and abs(dv[free][1] + 9.81 / 60.0) < 1e-4
+    with pytest.raises(Exception):
+        w.local_accelerations_upload(lin, ang)   # the old count is refused
+    w.local_accelerations_upload(lin[mask], ang[mask])
+    w.step()
