@@ -502,6 +502,55 @@ def main():
         except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the line down
             closed["sleeping"] = {"status": "error: " + str(e)[:300]}
 
+    # ---- the PCIe-inclusive step on the manifolds a closed loop really holds ("measure it on the closed loop's own step-110 manifolds"): the frozen
+    # benchmark set above carries 678 k manifolds (strip contacts between diagonal neighbours included); the same 100 000 boxes hold ~204 k once settled.  HostNarrowPhase
+    # mode as a host would run it: bodies + every manifold WITH its warm-start impulses up, step, bodies + impulses down, page-locked staging buffers.
+    if pcie is not None and closed is not None and rank == 0 and world_size == 1:
+        try:
+            from avian_amd import level2_bench, scenes
+            nx_c, ny_c, nz_c, _ = SCENES[args.scene]
+            sc2, mf2, offs2, warm2 = level2_bench.closed_loop_island(lib, F, scenes, 32, (nx_c, ny_c, nz_c), 110, substeps=substeps, device=local_rank)
+            w2 = F.World(lib, F.default_config(32, substeps=substeps, device=local_rank))
+            keep2 = []
+
+            def pin2(a, dtype=None):
+                a = np.ascontiguousarray(a)
+                if dtype is not None and a.dtype.kind == "f":
+                    a = a.astype(dtype)
+                t = torch.from_numpy(a).pin_memory(); keep2.append(t)
+                return t.numpy()
+            it2 = {"body1": np.int32, "body2": np.int32, "point_count": np.uint8, "rb_type": np.uint8, "locked_axes": np.uint8, "body_flags": np.uint8, "dominance": np.int8}
+            bk2 = {k: (pin2(np.asarray(v).astype(it2[k]) if k in it2 else v, w2.dtype) if v is not None else None) for k, v in sc2.body_kwargs().items()}
+            fr2, re2 = pin2(mf2.pop("friction"), w2.dtype), pin2(mf2.pop("restitution"), w2.dtype)
+            mfp2 = {k: pin2(np.asarray(v).astype(it2[k]) if k in it2 else v, w2.dtype) for k, v in mf2.items()}
+            wn2, wt2 = pin2(warm2[0], w2.dtype), pin2(warm2[1], w2.dtype)
+            n_b2, n_m2 = sc2.n, len(mfp2["body1"])
+            bout2 = {k: pin2(np.zeros(sh, w2.dtype)) for k, sh in (("position", (n_b2, 3)), ("rotation", (n_b2, 4)), ("linear_velocity", (n_b2, 3)), ("angular_velocity", (n_b2, 3)))}
+            iout2 = {k: pin2(np.zeros(sh, w2.dtype)) for k, sh in (("warm_start_normal_impulse", (n_m2, 4)), ("warm_start_tangent_impulse", (n_m2, 4, 2)), ("normal_impulse", (n_m2, 4)))}
+
+            def pcie_step2():
+                w2.bodies_upload(**bk2)
+                scenes.upload_manifolds(w2, mfp2, offs2, fr2, re2, wn2, wt2)
+                w2.step()
+                w2.bodies_download(out=bout2); w2.impulses_download(out=iout2)
+                w2.synchronize()
+            for _ in range(3):
+                pcie_step2()
+            per2 = []
+            for _ in range(20):
+                c0 = time.perf_counter(); pcie_step2(); per2.append((time.perf_counter() - c0) * 1e3)
+            up2 = sum(int(v.nbytes) for v in bk2.values() if v is not None) + sum(int(v.nbytes) for v in mfp2.values()) + fr2.nbytes + re2.nbytes + wn2.nbytes + wt2.nbytes
+            down2 = sum(int(v.nbytes) for v in bout2.values()) + sum(int(v.nbytes) for v in iout2.values())
+            pcie["closed_loop_manifolds"] = {
+                "ms_per_step": round(float(np.median(per2)), 3), "mean_ms_per_step": round(float(np.mean(per2)), 3), "max_ms_per_step": round(float(np.max(per2)), 3), "steps": 20,
+                "statistic": "median over the steps", "manifolds": int(n_m2), "overflow_manifolds": int(offs2[24] - offs2[23]), "host_bytes_up_per_step": int(up2), "host_bytes_down_per_step": int(down2),
+                "note": "the same flow on the manifold set the device closed loop holds after 110 steps of this scene (its own narrow phase and ConstraintGraph), warm-start impulses uploaded "
+                        "with the manifolds as a host ContactGraph would: what HostNarrowPhase mode costs on a settled pile of this size; the set is re-sent unchanged every step "
+                        "(the flow's cost does not depend on whether it changed)"}
+            w2.close(); keep2.clear()
+        except Exception as e:  # noqa: BLE001 -- a secondary leg must not take the line down
+            pcie["closed_loop_manifolds"] = {"status": "error: " + str(e)[:300]}
+
     # ---- CPU baseline: the oracle on the same inputs, rank 0 at N=1 only, bounded sample -------------------------
     cpu = None
     if rank == 0 and world_size == 1 and not args.no_cpu_baseline:

@@ -14,10 +14,19 @@ from bench import setup_world
 
 def main():
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+    cl_steps = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # > 0: the manifold set of the device closed loop after that many steps (with its warm-start impulses) instead of the frozen synthetic one
     lib = avian_amd.load_library()
-    sc = scenes.box_stack(50, 40, 50)
-    w = F.World(lib, F.default_config(32, substeps=4))
-    meta = setup_world(w, lib, sc)
+    warm = (None, None)
+    if cl_steps:
+        from avian_amd import level2_bench
+        sc, mf, offs, warm = level2_bench.closed_loop_island(lib, F, scenes, 32, (50, 40, 50), cl_steps)
+        w = F.World(lib, F.default_config(32, substeps=4))
+        fr_a, re_a = mf.pop("friction"), mf.pop("restitution")
+        meta = {"manifolds": mf, "offsets": offs, "n_manifolds": len(mf["body1"])}
+    else:
+        sc = scenes.box_stack(50, 40, 50)
+        w = F.World(lib, F.default_config(32, substeps=4))
+        meta = setup_world(w, lib, sc)
     keep = []
     ints = {"body1": np.int32, "body2": np.int32, "point_count": np.uint8, "manifold_flags": np.uint8, "rb_type": np.uint8}
     def pinned(k, a):
@@ -28,7 +37,8 @@ def main():
         t = torch.from_numpy(a).pin_memory(); keep.append(t); return t.numpy()
     bk = {k: pinned(k, v) for k, v in sc.body_kwargs().items()}
     mfp = {k: pinned(k, v) for k, v in meta["manifolds"].items()}
-    fr = pinned("f", np.full(meta["n_manifolds"], sc.friction, np.float32)); re_ = pinned("f", np.full(meta["n_manifolds"], sc.restitution, np.float32))
+    fr = pinned("f", fr_a if cl_steps else np.full(meta["n_manifolds"], sc.friction, np.float32)); re_ = pinned("f", re_a if cl_steps else np.full(meta["n_manifolds"], sc.restitution, np.float32))
+    wn, wt = (pinned("f", warm[0]), pinned("f", warm[1])) if cl_steps else (None, None)
     bout = {k: pinned("f", np.zeros(sh, np.float32)) for k, sh in (("position", (sc.n, 3)), ("rotation", (sc.n, 4)), ("linear_velocity", (sc.n, 3)), ("angular_velocity", (sc.n, 3)))}
     M = meta["n_manifolds"]
     iout = {k: pinned("f", np.zeros(sh, np.float32)) for k, sh in (("warm_start_normal_impulse", (M, 4)), ("warm_start_tangent_impulse", (M, 4, 2)), ("normal_impulse", (M, 4)))}
@@ -39,7 +49,7 @@ def main():
         if it == 1:
             acc.clear()
         timed("bodies_upload", lambda: w.bodies_upload(**bk))
-        timed("manifolds_upload", lambda: scenes.upload_manifolds(w, mfp, meta["offsets"], fr, re_))
+        timed("manifolds_upload", lambda: scenes.upload_manifolds(w, mfp, meta["offsets"], fr, re_, wn, wt))
         timed("step+sync", lambda: (w.step(), w.synchronize()))
         timed("bodies_download", lambda: w.bodies_download(out=bout))
         timed("impulses_download", lambda: w.impulses_download(out=iout))
