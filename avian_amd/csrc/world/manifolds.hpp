@@ -127,16 +127,23 @@
                 k2[m - o0] = h_body_has_sb[h_m_body2[m]] ? h_m_body2[m] : -1;
             }
             uint32_t before = sched_overflow.n_components;
+            const bool levels_before = sched_overflow.gorder.size() > overflow_level_threshold;   // (the form contact_pass picks: one device-wide launch per LEVEL, sizes captured)
+            const std::vector<uint32_t> glevels_before = levels_before ? sched_overflow.glevel_offsets : std::vector<uint32_t>();
             sched_overflow.build(ms, k1, k2, N, ms.size() > overflow_level_threshold);
-            void* p0 = sched_overflow.d_order.p; void* p1 = sched_overflow.d_level_offsets.p; void* p2 = sched_overflow.d_comp_level_begin.p;
+            void* p0 = sched_overflow.d_order.p; void* p1 = sched_overflow.d_level_offsets.p; void* p2 = sched_overflow.d_comp_level_begin.p; void* p3 = sched_overflow.d_gorder.p;
             avn_status st;
             if ((st = upload_u32(sched_overflow.d_comp_level_begin, sched_overflow.comp_level_begin)) != AVN_OK) return st;
             if ((st = upload_u32(sched_overflow.d_level_offsets, sched_overflow.level_offsets)) != AVN_OK) return st;
             if ((st = upload_u32(sched_overflow.d_order, sched_overflow.order)) != AVN_OK) return st;
             if ((st = upload_u32(sched_overflow.d_gorder, sched_overflow.gorder)) != AVN_OK) return st;
             HIPCHK(hipStreamSynchronize(stream));
-            if (o1 > o0) graph_valid = false;  // level sizes are captured launch parameters
-            if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p) graph_valid = false;
+            // What the substep graph captured of the overflow colour: per-component form (k_overflow_pass) -- the grid (n_components) and the three pointers, checked
+            // below; the arrays are read at replay.  Per-level form -- every level's (first, count) as launch parameters: re-capture when they differ.  (Until round 6
+            // ANY non-empty overflow colour invalidated the graph with every upload: a host that re-sends a settled pile's manifolds every step -- HostNarrowPhase mode --
+            // paid a capture + instantiate per step for a schedule that had not changed.)
+            const bool levels_now = sched_overflow.gorder.size() > overflow_level_threshold;
+            if (levels_now != levels_before || (levels_now && glevels_before != sched_overflow.glevel_offsets)) graph_valid = false;
+            if (before != sched_overflow.n_components || p0 != sched_overflow.d_order.p || p1 != sched_overflow.d_level_offsets.p || p2 != sched_overflow.d_comp_level_begin.p || p3 != sched_overflow.d_gorder.p) graph_valid = false;
         }
         islands_dirty = true;   // rebuilt by solver_front AFTER the prepare kernels are enqueued (host work overlaps them)
         incidence_dirty = false;

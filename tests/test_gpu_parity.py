@@ -296,3 +296,37 @@ def test_bad_arguments_are_reported_not_crashed():
     bad = F.default_config(32); bad.scalar_bits = 16
     with pytest.raises(F.AvnError):
         F.World(hip_lib(), bad)
+
+
+@pytest.mark.parametrize("threshold", [None, "16"])
+def test_reuploading_manifolds_every_step_keeps_the_substep_graph_honest(threshold, monkeypatch):
+    """HostNarrowPhase mode: the host re-sends the manifold set before every step.  The substep graph survives an upload whose overflow colour keeps its captured launch
+    parameters (round 6) and must be re-captured when they change: the same set twice, then hub manifolds leaving / returning (other level sizes, other component
+    counts), in the per-component form and -- measure build, AVN_OVERFLOW_LEVEL_THRESHOLD -- in the per-level form whose level sizes are launch parameters."""
+    from helpers import hip_measure_lib
+    lib = hip_lib()
+    if threshold is not None:
+        monkeypatch.setenv("AVN_OVERFLOW_LEVEL_THRESHOLD", threshold)
+        lib = hip_measure_lib()
+    wd = random_world(seed=31, n_bodies=260, n_manifolds=500, hub_degree=70, with_odd_features=False)
+    m_all = len(wd["manifolds"]["body1"])
+    wo = F.World(oracle_lib(), F.default_config(32, substeps=3, use_graph=1))
+    wh = F.World(lib, F.default_config(32, substeps=3, use_graph=1))
+    rng = np.random.default_rng(2)
+    keep_sets = [np.arange(m_all)] * 3                                                         # the same set three times: the graph is replayed
+    keep_sets += [np.sort(rng.choice(m_all, m_all - 25, replace=False)) for _ in range(3)]     # manifolds leave (the hub's among them): other levels
+    keep_sets += [np.arange(m_all)] * 2 + [np.arange(m_all - 70)] + [np.arange(m_all)]         # back; the hub's 70 manifolds gone altogether (no overflow colour); back
+    for s, keep in enumerate(keep_sets):
+        sub = dict(wd)
+        sub["manifolds"] = {k: np.asarray(v)[keep] for k, v in wd["manifolds"].items()}
+        for k in ("friction", "restitution", "warm_n", "warm_t"): sub[k] = wd[k][keep]
+        for w in (wo, wh):
+            if s == 0: color_and_upload(w, oracle_lib(), sub)
+            else:
+                from avian_amd import scenes
+                offsets, perm = scenes.color_manifolds(oracle_lib(), sub["manifolds"], np.asarray(wd["bodies"]["rb_type"]))
+                pm = scenes.permute_manifolds(sub["manifolds"], perm)
+                scenes.upload_manifolds(w, pm, offsets, sub["friction"][perm], sub["restitution"][perm], warm_n=sub["warm_n"][perm], warm_t=sub["warm_t"][perm])
+            w.step()
+        wh.synchronize()
+        compare_all(wo, wh, f"upload {s}")
