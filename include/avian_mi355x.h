@@ -623,7 +623,9 @@ AVN_API avn_status AVN_FN(solver_bodies_download)(avn_world* w, const avn_solver
  *   reference, all zero by default: adding rotation * 0 changes at most the sign of a zero velocity component).
  * The values stay in effect until the next call, an avn_bodies_upload with another body count, or avn_despawn (all three drop them).  The
  * reference clears the component after every step (clear_accumulated_local_acceleration, forces/plugin.rs:68-71,243-251) and accumulates it
- * again before the next: a host mirrors that by uploading what it accumulated before each step (count 0 once nothing is left). */
+ * again before the next: a host mirrors that by uploading what it accumulated before each step (count 0 once nothing is left).
+ * Sleeping: a sleeping body has no SolverBody and is skipped, as in the reference; Forces::apply_local_* WAKE the body they push (try_wake_up,
+ * forces/query_data.rs:344-349) -- with avn_sleeping_enable that is the host's avn_wake_bodies call, like every other host-side change of a sleeping body. */
 AVN_API avn_status AVN_FN(local_accelerations_upload)(avn_world* w, uint32_t count, const void* linear, const void* angular);
 
 /* replaces the ContactGraph/ConstraintGraph reads of prepare_contact_constraints */
