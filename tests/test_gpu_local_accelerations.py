@@ -144,3 +144,14 @@ def test_despawn_drops_the_values_and_the_host_uploads_them_for_what_remains():
         wo.step(); wh.step()
         bo, bh = wo.bodies_download(), wh.bodies_download()
         for k in bo: assert_same(bo[k], bh[k], f"values back, step {s}: bodies.{k}")
+
+
+@pytest.mark.parametrize("bits,world_size", [(32, 2), (64, 3)])
+def test_level2_slabs_carry_local_accelerations_on_hip(bits, world_size):
+    from test_local_accelerations_cpu import _split_with_thrusters
+    _split_with_thrusters(hip_lib(), oracle_lib(), bits, world_size)
+
+
+def test_device_sharded_closed_loop_carries_local_accelerations_on_hip():
+    from test_local_accelerations_cpu import _dshard_with_thrusters
+    _dshard_with_thrusters(hip_lib(), 32, 50)

@@ -127,3 +127,52 @@ def test_despawn_drops_the_values():
         w.local_accelerations_upload(lin, ang)   # the old count is refused
     w.local_accelerations_upload(lin[mask], ang[mask])
     w.step()
+
+
+def _split_with_thrusters(lib, ref_lib, bits, world_size):
+    """One island over `world_size` slab worlds (level 2): every slab uploads the local accelerations of ITS bodies (shared bodies on both sides, like every other body
+    component) and must stay bit-identical to the unsplit world."""
+    from level2_helpers import compare_with_single, global_problem, make_single, make_split, step_split_in_process
+    sc, pm, offs, _ = global_problem(oracle_lib(), 8, 4, 5, seed=3 + world_size)
+    lin, ang = random_local_accelerations(17, sc.n, fraction=0.6)
+    single = make_single(lib, bits, sc, pm, offs, 0.0, 3)
+    ref = make_single(ref_lib, bits, sc, pm, offs, 0.0, 3)
+    plan, worlds = make_split(lib, bits, sc, pm, offs, 0.0, 3, world_size)
+    single.local_accelerations_upload(lin, ang); ref.local_accelerations_upload(lin, ang)
+    for pl, w in zip(plan, worlds):
+        w.local_accelerations_upload(lin[pl.bodies], ang[pl.bodies])
+    assert sum(len(p.send_bodies) for p in plan) > 0
+    for _ in range(3):
+        single.run_system("SOLVER"); ref.run_system("SOLVER")
+        step_split_in_process(plan, worlds, 3, False)
+        compare_with_single(single, plan, worlds)
+        compare_with_single(ref, plan, worlds)
+
+
+@pytest.mark.parametrize("bits,world_size", [(32, 2), (64, 3)])
+def test_level2_slabs_carry_local_accelerations(bits, world_size):
+    _split_with_thrusters(oracle_lib(), oracle_lib(), bits, world_size)
+
+
+def _dshard_with_thrusters(lib, bits, steps):
+    """The DEVICE closed loop sharded by islands: every rank holds every body (and every body's local acceleration), simulates its own; against the single world every step."""
+    import dshard_helpers as D
+    from avian_amd import shard
+    from test_dshard_cpu import owner_by_pile
+    from test_sharded_closed_loop_cpu import piles
+    bodies, colliders = piles(2, 24)
+    owner = owner_by_pile(bodies, 2, 24)
+    lin, ang = random_local_accelerations(23, len(bodies["inv_mass"]), fraction=0.5)
+    lin *= 0.5; ang *= 0.5
+    ref, ranks = D.make_worlds(lib, bits, bodies, colliders, owner, 2)
+    for w in [ref] + ranks: w.local_accelerations_upload(lin, ang)
+    for s in range(steps):
+        ref.step()
+        shard.dshard_step_in_process(ranks)
+        D.compare(s, ref, ranks, owner)
+    return ref
+
+
+def test_device_sharded_closed_loop_carries_local_accelerations():
+    ref = _dshard_with_thrusters(oracle_lib(), 32, 50)
+    assert ref.pipeline_stats().manifolds_pushed > 0
