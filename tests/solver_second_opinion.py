@@ -485,3 +485,16 @@ def unprepared(A):
     on the components' Default: zero vectors, the identity rotation difference."""
     z = (A.zero,) * 3
     return dict(world_r1=z, world_r2=z, center_difference=z, total_lagrange=z, total_rotation_lagrange=z, rotation_difference=(A.zero, A.zero, A.zero, A.one))
+
+
+# ---- apply_local_acceleration (dynamics/rigid_body/forces/plugin.rs:207-241), written from its text --------------------------------------------------------
+def apply_local_acceleration(A, lin_vel, ang_vel, delta_rotation, rotation, local_linear, local_angular, locked_bits, delta_secs):
+    """let rotation = solver_body.delta_rotation * *rotation;  world = locked_axes.apply_to_vec(rotation * local)  for BOTH vectors (apply_to_vec = the translation
+    locks: bits 0b100_000 x, 0b010_000 y, 0b001_000 z, locked_axes.rs:230-243);  velocity += world * delta_secs."""
+    rot = A.qmul(delta_rotation, rotation)
+
+    def apply_to_vec(v):
+        return (A.zero if locked_bits & 0b100_000 else v[0], A.zero if locked_bits & 0b010_000 else v[1], A.zero if locked_bits & 0b001_000 else v[2])
+    wl = apply_to_vec(A.qrot(rot, local_linear))
+    wa = apply_to_vec(A.qrot(rot, local_angular))
+    return A.add(lin_vel, A.scale(wl, delta_secs)), A.add(ang_vel, A.scale(wa, delta_secs))

@@ -236,3 +236,46 @@ def test_fixed_joints_against_the_restatement(bits):
         assert turned > 40
     finally:
         lib.dll.avo_use_libm_trig(0)
+
+
+@pytest.mark.parametrize("bits", [32, 64])
+def test_apply_local_acceleration_against_the_restatement(bits):
+    """apply_local_acceleration (forces/plugin.rs:207-241) in the oracle against the third restatement: the SolverBody state in front of INTEGRATE_VELOCITIES
+    goes to the restatement (delta_rotation as the oracle's integrate_positions left it -- the trigonometry is not what is compared here), and the velocities after the
+    system must be what it makes of them, bit for bit.  The bodies have nothing else that integrate_velocities would add (no gravity, no damping, isotropic inertia:
+    v * 1 + 0), kinematic bodies and locked axes included."""
+    A = S.Arith(bits)
+    rng = np.random.default_rng(7 + bits)
+    n = 48
+    rot = rng.normal(size=(n, 4)); rot /= np.linalg.norm(rot, axis=1, keepdims=True)
+    rb = np.zeros(n, np.uint8); rb[:6] = F.RB_KINEMATIC
+    iso = rng.uniform(0.5, 4.0, n)
+    inv_i = np.zeros((n, 6)); inv_i[:, 0] = inv_i[:, 3] = inv_i[:, 5] = iso
+    locked = np.where(rng.random(n) < 0.4, rng.integers(0, 64, n), 0).astype(np.uint8)
+    bodies = dict(position=rng.uniform(-5, 5, (n, 3)), rotation=rot, linear_velocity=rng.normal(size=(n, 3)), angular_velocity=rng.normal(scale=2.0, size=(n, 3)),
+                  inv_mass=rng.uniform(0.3, 2.0, n), inv_inertia_local=inv_i, rb_type=rb, locked_axes=locked)
+    lin = np.where(rng.random((n, 1)) < 0.8, rng.normal(scale=5.0, size=(n, 3)), 0.0)
+    ang = np.where(rng.random((n, 1)) < 0.8, rng.normal(scale=3.0, size=(n, 3)), 0.0)
+    cfg = F.default_config(bits, substeps=3, gravity=(0.0, 0.0, 0.0))
+    w = F.World(oracle_lib(), cfg)
+    w.bodies_upload(**bodies)
+    w.local_accelerations_upload(lin, ang)
+    ts = S.time_scalars(A, int(cfg.dt_ns), 3)
+    T = A.T
+    rot_t = np.asarray(bodies["rotation"], T)   # the Rotation component as the world holds it
+    lin_t, ang_t = np.asarray(lin, T), np.asarray(ang, T)
+    w.run_system("PREPARE_SOLVER_BODIES"); w.run_system("PRE_PROCESS_VELOCITY_INCREMENTS")
+    moved = 0
+    for sub in range(3):
+        before = w.solver_bodies_download()
+        w.run_system("INTEGRATE_VELOCITIES")
+        after = w.solver_bodies_download()
+        exp_l, exp_a = np.array(before["linear_velocity"]), np.array(before["angular_velocity"])
+        for i in range(n):
+            l, a = S.apply_local_acceleration(A, A.v(before["linear_velocity"][i]), A.v(before["angular_velocity"][i]), tuple(T(x) for x in before["delta_rotation"][i]),
+                                              tuple(rot_t[i]), A.v(lin_t[i]), A.v(ang_t[i]), int(locked[i]), ts["h"])
+            exp_l[i], exp_a[i] = l, a
+        same(after["linear_velocity"], exp_l, f"substep {sub}: linear_velocity"); same(after["angular_velocity"], exp_a, f"substep {sub}: angular_velocity")
+        moved += int((np.asarray(after["linear_velocity"]) != np.asarray(before["linear_velocity"])).any(axis=1).sum())
+        w.run_system("INTEGRATE_POSITIONS")
+    assert moved > n and not np.array_equal(after["delta_rotation"], np.tile([0, 0, 0, 1], (n, 1))), "the later substeps must see a turned body"
